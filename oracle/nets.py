@@ -1,0 +1,373 @@
+"""Generator / discriminator of the reference, restated as torch-CPU fp32 functions.
+
+Test infrastructure only (see oracle/__init__.py).  PARITY UNPINNED.
+
+Parameters live in flat dicts keyed by the reference's Chainer ``namedparams``
+paths (what its .npz snapshots contain), e.g. ``mapping/l/0/c/W``,
+``gen/blocks/3/c0/c/W``, ``blocks/5/c_sc/c/W``.  All tensors are NCHW float32,
+weights OIHW, exactly as in the reference (net.py, common/networks/component/*).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+SQRT2 = float(np.sqrt(2))
+
+
+def lrelu(x):
+    """chainer F.leaky_relu default slope 0.2."""
+    return F.leaky_relu(x, 0.2)
+
+
+def inv_c(fan_in, gain=SQRT2):
+    """pggan.py:15-18,41-44: gain * sqrt(1 / fan_in) (the *input* is scaled by it)."""
+    return float(gain * np.sqrt(1.0 / fan_in))
+
+
+def eq_conv(x, p, name, pad, gain=SQRT2):
+    """pggan.py:13-24 (EqualizedConv2d.forward): c(inv_c * x), cross-correlation."""
+    W = p[name + "/c/W"]
+    b = p.get(name + "/c/b")
+    return F.conv2d(inv_c(W.shape[1] * W.shape[2] ** 2, gain) * x, W, b, padding=pad)
+
+
+def eq_linear(x, p, name, gain=SQRT2):
+    """pggan.py:39-50 (EqualizedLinear.forward); L.Linear flattens trailing dims."""
+    W = p[name + "/c/W"]
+    b = p.get(name + "/c/b")
+    return F.linear(inv_c(W.shape[1], gain) * x.reshape(x.shape[0], -1), W, b)
+
+
+def pixel_norm(x, eps=1e-8):
+    """pggan.py:7-10 (feature_vector_normalization)."""
+    alpha = 1.0 / torch.sqrt(torch.mean(x * x, dim=1, keepdim=True) + eps)
+    return alpha * x
+
+
+def adain(x, scale, shift, eps=1e-5):
+    """normalization/adain.py:10-77: per-(b,c) instance norm (biased var,
+    (var+eps)^-1/2) followed by x_hat * scale + shift."""
+    B, C = x.shape[:2]
+    flat = x.reshape(B * C, -1)
+    mean = flat.mean(dim=1, keepdim=True)
+    var = ((flat - mean) ** 2).mean(dim=1, keepdim=True)
+    xhat = ((flat - mean) * (var + eps) ** -0.5).reshape(x.shape)
+    return xhat * scale.reshape(B, C, 1, 1) + shift.reshape(B, C, 1, 1)
+
+
+def up2(x):
+    """rescale.py:4-5 (unpooling_2d k=2,s=2): nearest replicate."""
+    return x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+
+
+def down2(x):
+    """rescale.py:12-13 (average_pooling_2d 2x2)."""
+    return F.avg_pool2d(x, 2, 2)
+
+
+def l2_normalize(x, eps=1e-5):
+    """chainer F.normalize(axis=1): x / (||x||_2 + eps)."""
+    return x / (torch.sqrt((x * x).sum(dim=1, keepdim=True)) + eps)
+
+
+def split_stage(stage, max_stage=17):
+    stage = min(stage, max_stage - 1e-8)
+    fl = math.floor(stage)
+    return fl, stage - fl
+
+
+# ---------------------------------------------------------------- parameter construction
+
+def _normal(gen, *shape):
+    return torch.randn(*shape, generator=gen, dtype=torch.float32)
+
+
+def init_stylegan(ch=256, seed=0, initial_depth=1.0, rgbd=True):
+    """Random-init parameters with the reference's initialisers (net.py:22-216):
+    W ~ N(0,1), biases 0, style-scale bias 1, const input 1, noise scale 0,
+    depth row of every `outs` conv W=0, b=log(e^initial_depth - 1)."""
+    g = torch.Generator().manual_seed(seed)
+    p = {}
+    for i in range(0, 16, 2):
+        p[f"mapping/l/{i}/c/W"] = _normal(g, ch, ch)
+        p[f"mapping/l/{i}/c/b"] = torch.zeros(ch)
+    chans = [(ch, ch), (ch, ch), (ch, ch), (ch, ch), (ch // 2, ch), (ch // 4, ch // 2)]  # (out, in)
+    out_ch = 4 if rgbd else 3
+    for i, (co, ci) in enumerate(chans):
+        pre = f"gen/blocks/{i}"
+        if i == 0:
+            p[pre + "/W"] = torch.ones(ci, 4, 4)
+        p[pre + "/b0/b"] = torch.zeros(co)
+        p[pre + "/b1/b"] = torch.zeros(co)
+        p[pre + "/n0/b/W"] = torch.zeros(co)
+        p[pre + "/n1/b/W"] = torch.zeros(co)
+        for s in ("s0", "s1"):
+            p[f"{pre}/{s}/s/c/W"] = _normal(g, co, ch)
+            p[f"{pre}/{s}/s/c/b"] = torch.ones(co)
+            p[f"{pre}/{s}/b/c/W"] = _normal(g, co, ch)
+            p[f"{pre}/{s}/b/c/b"] = torch.zeros(co)
+        p[pre + "/c0/c/W"] = _normal(g, co, ci, 3, 3)
+        p[pre + "/c1/c/W"] = _normal(g, co, co, 3, 3)
+    for i, (co, _) in enumerate(chans):
+        W = _normal(g, out_ch, co, 1, 1)
+        b = torch.zeros(out_ch)
+        if rgbd:
+            W[-1] = 0
+            b[-1] = math.log(math.e ** initial_depth - 1)
+        p[f"gen/outs/{i}/c/W"] = W
+        p[f"gen/outs/{i}/c/b"] = b
+    if rgbd:
+        p["gen/l1/c/W"] = _normal(g, ch, ch + 9)
+        p["gen/l1/c/b"] = torch.zeros(ch)
+        p["gen/l2/c/W"] = _normal(g, ch, ch)
+        p["gen/l2/c/b"] = torch.zeros(ch)
+    return p
+
+
+def init_dcgan(in_ch=256, ch=512, seed=0, initial_depth=1.0, rgbd=True):
+    """net.py:651-695 (DCGANGenerator.__init__)."""
+    g = torch.Generator().manual_seed(seed)
+    p = {}
+    p["linear/c/W"] = _normal(g, ch * 16, in_ch + (9 if rgbd else 0))
+    p["linear/c/b"] = torch.zeros(ch * 16)
+    chans = [(ch, ch), (ch, ch), (ch, ch), (ch // 2, ch), (ch // 4, ch // 2)]
+    out_ch = 4 if rgbd else 3
+    for i, (co, ci) in enumerate(chans):
+        pre = f"blocks/{i}"
+        p[pre + "/b0/b"] = torch.zeros(co)
+        p[pre + "/b1/b"] = torch.zeros(co)
+        p[pre + "/n0/b/W"] = torch.zeros(co)
+        p[pre + "/n1/b/W"] = torch.zeros(co)
+        p[pre + "/c0/c/W"] = _normal(g, co, ci, 3, 3)
+        p[pre + "/c1/c/W"] = _normal(g, co, co, 3, 3)
+        W = _normal(g, out_ch, co, 1, 1)
+        b = torch.zeros(out_ch)
+        if rgbd:
+            W[-1] = 0
+            b[-1] = math.log(math.e ** initial_depth - 1)
+        p[f"outs/{i}/c/W"] = W
+        p[f"outs/{i}/c/b"] = b
+    return p
+
+
+def init_discriminator(ch=256, seed=1, out_dim=1, res=True):
+    """net.py:429-455 (Discriminator.__init__, sn=False)."""
+    g = torch.Generator().manual_seed(seed)
+    p = {}
+    p["blocks/0/c0/c/W"] = _normal(g, ch, ch, 3, 3)
+    p["blocks/0/c0/c/b"] = torch.zeros(ch)
+    p["blocks/0/c1/c/W"] = _normal(g, ch, ch, 4, 4)
+    p["blocks/0/c1/c/b"] = torch.zeros(ch)
+    p["blocks/0/l2/c/W"] = _normal(g, out_dim, ch)
+    p["blocks/0/l2/c/b"] = torch.zeros(out_dim)
+    chans = [None, (ch, ch), (ch, ch), (ch, ch), (ch // 2, ch), (ch // 4, ch // 2)]  # (in, out)
+    for i in range(1, 6):
+        ci, co = chans[i]
+        names = ("c0", "c1", "c_sc") if res else ("c0", "c1")
+        for nm in names:
+            cin = co if nm == "c1" else ci
+            p[f"blocks/{i}/{nm}/c/W"] = _normal(g, co, cin, 3, 3)
+            p[f"blocks/{i}/{nm}/c/b"] = torch.zeros(co)
+    ins = [ch, ch, ch, ch, ch // 2, ch // 4]
+    for i, co in enumerate(ins):
+        p[f"ins/{i}/c/W"] = _normal(g, co, 3, 1, 1)
+        p[f"ins/{i}/c/b"] = torch.zeros(co)
+    return p
+
+
+def make_hidden(n, ch, rng=np.random):
+    """net.py:333-343 (StyleGANGenerator.make_hidden): z ~ N(0,1) (n,2ch,1,1),
+    divided by sqrt(sum_c z^2 / ch + 1e-8) -- the divisor uses ch, not 2ch."""
+    z = rng.normal(size=(n, ch * 2, 1, 1)).astype("f")
+    z /= np.sqrt(np.sum(z * z, axis=1, keepdims=True) / ch + 1e-8)
+    return z
+
+
+def make_hidden_dcgan(n, in_ch, rng=np.random):
+    """net.py:697-707."""
+    z = rng.normal(size=(n, in_ch)).astype("f")
+    z /= np.sqrt(np.sum(z * z, axis=1, keepdims=True) / in_ch + 1e-8)
+    return z
+
+
+# ---------------------------------------------------------------- StyleGAN generator
+
+def mapping(p, z):
+    """net.py:58-62 (MappingNetwork.forward): pixel-norm then 8x (linear, lrelu)."""
+    h = pixel_norm(z)
+    for i in range(0, 16, 2):
+        h = lrelu(eq_linear(h, p, f"mapping/l/{i}"))
+    return h
+
+
+def style_block(p, name, w, h):
+    """net.py:90-102 (StyleBlock): AdaIN(h, s(w), b(w)), both linears gain 1."""
+    return adain(h, eq_linear(w, p, name + "/s", gain=1.0), eq_linear(w, p, name + "/b", gain=1.0))
+
+
+def synthesis_block(p, i, w, x):
+    """net.py:130-161 (SynthesisBlock.forward) with add_noise=False, enable_blur=False."""
+    pre = f"gen/blocks/{i}"
+    if i == 0:
+        W = p[pre + "/W"]
+        h = W.unsqueeze(0).expand(w.shape[0], *W.shape)
+    else:
+        h = eq_conv(up2(x), p, pre + "/c0", 1)
+    h = lrelu(h + p[pre + "/b0/b"].reshape(1, -1, 1, 1))
+    h = style_block(p, pre + "/s0", w, h)
+    h = eq_conv(h, p, pre + "/c1", 1)
+    h = lrelu(h + p[pre + "/b1/b"].reshape(1, -1, 1, 1))
+    h = style_block(p, pre + "/s1", w, h)
+    return h
+
+
+def rotate_w(p, w, theta9):
+    """net.py:220-224."""
+    h = torch.cat([w, theta9 * 16], dim=1)
+    h = lrelu(eq_linear(h, p, "gen/l1"))
+    return lrelu(eq_linear(h, p, "gen/l2"))
+
+
+def depth_head(h):
+    """net.py:294-299: depth = 1 / (softplus(h[:, -1:]) + 1e-4), RGB untouched."""
+    return torch.cat([h[:, :3], 1.0 / (F.softplus(h[:, -1:]) + 1e-4)], dim=1)
+
+
+def style_generator(p, w, w2, stage, theta9, rgbd=True, return_feature=False):
+    """net.py:232-311 (StyleGenerator.forward), train mode."""
+    st, alpha = split_stage(stage)
+    feat = None
+    h = None
+
+    def run_block(i, w_cur, h):
+        if rgbd and i < 2:
+            return synthesis_block(p, i, rotate_w(p, w_cur, theta9), h)
+        return synthesis_block(p, i, w_cur, h)
+
+    if st % 2 == 0:
+        k = (st - 2) // 2
+        for i in range(0, k + 2):
+            if i == 3:
+                w = w2
+            h = run_block(i, w, h)
+            if i == 3:
+                feat = h
+        h = eq_conv(h, p, f"gen/outs/{k + 1}", 0, gain=1.0)
+    else:
+        k = (st - 1) // 2
+        for i in range(0, k + 1):
+            if i == 3:
+                w = w2
+            h = run_block(i, w, h)
+            if i == 3:
+                feat = h
+        h0 = up2(eq_conv(h, p, f"gen/outs/{k}", 0, gain=1.0))
+        # net.py:290 -- the faded-in block gets the un-rotated w (whatever `w` is now)
+        h1 = eq_conv(synthesis_block(p, k + 1, w, h), p, f"gen/outs/{k + 1}", 0, gain=1.0)
+        h = (1.0 - alpha) * h0 + alpha * h1
+    if rgbd:
+        h = depth_head(h)
+    return (h, feat) if return_feature else h
+
+
+def stylegan_generator(p, z, stage, theta9, rgbd=True, return_feature=False):
+    """net.py:345-354 (StyleGANGenerator.forward): z (B,2ch,1,1) split in two latents."""
+    z = torch.as_tensor(z)
+    theta9 = torch.as_tensor(theta9)
+    half = z.shape[1] // 2
+    w = mapping(p, z[:, :half])
+    w2 = mapping(p, z[:, half:])
+    return style_generator(p, w, w2, stage, theta9, rgbd, return_feature)
+
+
+# ---------------------------------------------------------------- DCGAN (PGGAN) generator
+
+def dcgan_block(p, i, x):
+    """net.py:621-648 (DCGANBlock.forward), add_noise=False."""
+    pre = f"blocks/{i}"
+    h = eq_conv(up2(x), p, pre + "/c0", 1)
+    h = l2_normalize(lrelu(h + p[pre + "/b0/b"].reshape(1, -1, 1, 1)))
+    h = eq_conv(h, p, pre + "/c1", 1)
+    h = l2_normalize(lrelu(h + p[pre + "/b1/b"].reshape(1, -1, 1, 1)))
+    return h
+
+
+def dcgan_generator(p, z, stage, theta9, rgbd=True):
+    """net.py:709-773 (DCGANGenerator.forward), train mode."""
+    z = torch.as_tensor(z)
+    theta9 = torch.as_tensor(theta9)
+    st, alpha = split_stage(stage)
+    h = torch.cat([z, theta9 * 10], dim=1) if rgbd else z
+    ch = p["blocks/0/c0/c/W"].shape[1]
+    h = eq_linear(h, p, "linear").reshape(z.shape[0], ch, 4, 4)
+    if st % 2 == 0:
+        k = (st - 2) // 2
+        for i in range(0, k + 1):
+            h = dcgan_block(p, i, h)
+        h = eq_conv(h, p, f"outs/{k}", 0, gain=1.0)
+    else:
+        k = (st - 1) // 2
+        for i in range(0, k):
+            h = dcgan_block(p, i, h)
+        h0 = up2(eq_conv(h, p, f"outs/{k - 1}", 0, gain=1.0))
+        h1 = eq_conv(dcgan_block(p, k, h), p, f"outs/{k}", 0, gain=1.0)
+        h = (1.0 - alpha) * h0 + alpha * h1
+    return depth_head(h) if rgbd else h
+
+
+# ---------------------------------------------------------------- discriminator
+
+def dis_block(p, i, x, res=True):
+    """net.py:408-426 (DiscriminatorBlock.forward) / :372-377 (base block i == 0)."""
+    pre = f"blocks/{i}"
+    if i == 0:
+        h = lrelu(eq_conv(x, p, pre + "/c0", 1))
+        h = lrelu(eq_conv(h, p, pre + "/c1", 0))
+        return eq_linear(h, p, pre + "/l2", gain=1.0)
+    h = lrelu(eq_conv(x, p, pre + "/c0", 1))
+    h = eq_conv(h, p, pre + "/c1", 1)
+    if res:
+        h = h + eq_conv(x, p, pre + "/c_sc", 1)
+    return down2(lrelu(h))
+
+
+def discriminator(p, x, stage, return_hidden=False, res=True):
+    """net.py:469-504 (Discriminator.forward)."""
+    st, alpha = split_stage(stage)
+    feat = None
+    if st % 2 == 0:
+        k = (st - 2) // 2
+        h = lrelu(eq_conv(x, p, f"ins/{k + 1}", 0))
+        for i in reversed(range(0, k + 2)):
+            if i == 3:
+                feat = h
+            h = dis_block(p, i, h, res)
+    else:
+        k = (st - 1) // 2
+        h0 = lrelu(eq_conv(down2(x), p, f"ins/{k}", 0))
+        h1 = dis_block(p, k + 1, lrelu(eq_conv(x, p, f"ins/{k + 1}", 0)), res)
+        h = (1.0 - alpha) * h0 + alpha * h1
+        for i in reversed(range(0, k + 1)):
+            if i == 3:
+                feat = h
+            h = dis_block(p, i, h, res)
+    return (h, feat) if return_hidden else h
+
+
+def downsize_real(x, stage, max_stage=17):
+    """common/utils/pggan.py:6-50."""
+    size = x.shape[2]
+    st, alpha = split_stage(stage, max_stage)
+    if st % 2 == 0:
+        k = (st - 2) // 2
+        target = 4 * 2 ** (k + 1)
+        scale = size // target
+        return F.avg_pool2d(x, scale, scale) if scale > 1 else x
+    k = (st - 1) // 2
+    lo, hi = 4 * 2 ** k, 4 * 2 ** (k + 1)
+    s_lo, s_hi = size // lo, size // hi
+    r_lo = up2(F.avg_pool2d(x, s_lo, s_lo)) if s_lo > 1 else x
+    r_hi = F.avg_pool2d(x, s_hi, s_hi) if s_hi > 1 else x
+    return (1 - alpha) * r_lo + alpha * r_hi
