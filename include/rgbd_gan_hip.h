@@ -1,0 +1,131 @@
+/*
+ * rgbd_gan_hip.h -- C ABI of librgbdgan_hip.so (MI355X / gfx950 kernels for the RGBD-GAN hot path).
+ *
+ * The reference (nogu-atsu/RGBD-GAN) has no FFI layer: every FLOP of its training step runs inside
+ * Chainer F.* / L.* calls (cuDNN / cuBLAS / CuPy).  Each entry point below replaces one group of
+ * those call sites; the reference file:line is given per function.  The Python host in
+ * rgbd_gan_amd/ binds these with ctypes (rgbd_gan_amd/_lib.py); INTEGRATION.md shows the stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers owned by the caller unless a
+ *     parameter is documented as host; nothing is allocated or freed inside
+ *   - `stream` is a hipStream_t passed as void*; every launch goes to that stream, no call syncs
+ *   - return value: 0 on success, negative on error (-1 bad argument, -2 HIP launch error);
+ *     rgbd_last_error() returns a thread-local description
+ *   - activations inside the conv stack are NHWC bf16; images at the API edge are NCHW fp32
+ *     (the reference's layout); master weights are OIHW fp32 (the reference's layout)
+ *   - thread-safe per stream; no global state
+ */
+#ifndef RGBD_GAN_HIP_H
+#define RGBD_GAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RGBD_ABI_VERSION 1
+
+int rgbd_abi_version(void);
+const char* rgbd_last_error(void);
+
+/* ------------------------------------------------------------------ 3D-consistency (warp) loss
+ * Replaces common/loss_functions.py:63-146 (LossFuncRotate.__call__), :171-182 (warp / inv_warp)
+ * and :185-228 (bilinear) -- about 100 CuPy kernels per call in the reference.
+ *
+ * img, img_rot : (b, 4, S, S) fp32 NCHW, channel 3 = depth.
+ * coef         : (b, 24) fp32 = A(9, row-major) c(3) A'(9) c'(3) computed on the HOST in NumPy exactly as
+ *                loss_functions.py:174,181 associate them (zp' = A (z p) - c ; zp'_rot = A' (z_rot p) + c').
+ * flags        : bit0 occlusion_aware, bit1 use max_depth, bit2 use min_depth.
+ * partials     : workspace, >= 4 * ceil(b*S*S/256) floats.
+ * loss         : 1 float.
+ * dbg_*        : optional (NULL to skip). dbg_zp (2,b,S*S,3) fp32; dbg_warped (2,b*S*S,4) fp32 (before the
+ *                occlusion mask, like the reference's debug=True return); dbg_idx (2,b*S*S,4) int32 =
+ *                masked u0, v0, v1 and the out-of-frame mask.  Index 0 = img->img_rot direction.
+ * Index math is evaluated unfused (no FMA contraction) left to right so the integer outputs are
+ * bit-exact against oracle/warp_loss.py:forward_np.
+ */
+#define RGBD_WARP_OCCLUSION 1
+#define RGBD_WARP_MAX_DEPTH 2
+#define RGBD_WARP_MIN_DEPTH 4
+int rgbd_warp_loss_fwd(const float* img, const float* img_rot, const float* coef, int b, int S,
+                       int flags, float lambda_geometric, float max_depth, float min_depth,
+                       float* partials, float* loss,
+                       float* dbg_zp, float* dbg_warped, int32_t* dbg_idx, void* stream);
+
+/* Backward of the above.  grad_loss: 1 float on the device (d objective / d loss).
+ * grad_img, grad_img_rot: (b,4,S,S) fp32, overwritten (zeroed inside, then accumulated with atomics). */
+int rgbd_warp_loss_bwd(const float* img, const float* img_rot, const float* coef, int b, int S,
+                       int flags, float lambda_geometric, float max_depth, float min_depth,
+                       const float* grad_loss, float* grad_img, float* grad_img_rot, void* stream);
+
+/* ------------------------------------------------------------------ equalized-LR convolution engine
+ * Replaces pggan.py:13-24 (EqualizedConv2d -> L.Convolution2D = cuDNN fprop/dgrad/wgrad) for the
+ * 3x3 convolutions of net.py:124-125 (SynthesisBlock), :363,389-392 (Discriminator blocks), :615-616 (DCGAN).
+ *
+ * rgbd_pack_weights: master W (Cout,Cin,KH,KW) fp32 -> bf16 images with inv_c folded in:
+ *   w_fprop [KH*KW][Cout][Cin]            (K-contiguous rows for the forward implicit GEMM)
+ *   w_dgrad [KH*KW][Cin][Cout], taps flipped (so dgrad is the same kernel run on dY)
+ * Either output may be NULL.
+ */
+int rgbd_pack_weights(const float* w, int cout, int cin, int kh, int kw, float scale,
+                      void* w_fprop, void* w_dgrad, void* stream);
+
+/* Implicit-GEMM forward convolution on MFMA (bf16 in, fp32 accumulate), stride 1.
+ *   x   : (B, Hin, Win, Cin) bf16 NHWC.  If `upsample` != 0 the convolution runs on the nearest-2x
+ *         upsampled image (rescale.py:4-5 fused into the gather), so Hout = 2*Hin + 2*pad - KH + 1.
+ *   wp  : packed weights [KH*KW][Cout][Cin] bf16 (rgbd_pack_weights).
+ *   bias: (Cout) fp32 or NULL.  lrelu_channels: output channels [0, lrelu_channels) get leaky-ReLU(slope)
+ *         after the bias (0 = none).  residual: (B,Hout,Wout,Cout) bf16 added after the activation, or NULL.
+ *   y   : (B, Hout, Wout, Cout) bf16 NHWC.
+ * Requires Cin % 64 == 0 and Cout % 64 == 0.  dgrad = this function on dY with w_dgrad, pad' = KH-1-pad.
+ */
+int rgbd_conv2d_fprop_bf16(const void* x, const void* wp, const float* bias, const void* residual, void* y,
+                           int B, int Hin, int Win, int Cin, int Cout, int KH, int KW, int pad,
+                           int upsample, int lrelu_channels, float slope, void* stream);
+
+/* Weight gradient: dwp[tap][co][ci] += sum_{b,h,w} dy[b,h,w,co] * x[b,h+kh-pad,w+kw-pad,ci]  (fp32, atomics).
+ *   x  : (B,H,W,Cin) bf16, dy : (B,H,W,Cout) bf16 (same H,W: stride 1, pad = (K-1)/2), K in {1,3}.
+ *   dwp: [K*K][Cout][Cin] fp32, must be zeroed by the caller (or hold a value to accumulate into).
+ * Requires Cin % 64 == 0, Cout % 64 == 0, H and W powers of two >= 4.
+ */
+int rgbd_conv2d_wgrad_bf16(const void* x, const void* dy, float* dwp,
+                           int B, int H, int W, int Cin, int Cout, int K, void* stream);
+
+/* dwp [K*K][Cout][Cin] fp32 -> dw (Cout,Cin,K,K) fp32, dw = scale * dwp (+ dw if accumulate). */
+int rgbd_unpack_wgrad(const float* dwp, float* dw, int cout, int cin, int kh, int kw, float scale,
+                      int accumulate, void* stream);
+
+/* ------------------------------------------------------------------ AdaIN (instance norm + style affine)
+ * Replaces normalization/adain.py:54-73 (reshape + F.batch_normalization + broadcast mul/add) and its backward.
+ *   x (B,HW,C) bf16 NHWC; scale, shift (B,C) fp32; eps 1e-5; biased variance.
+ *   sums: workspace (B,C,2) fp32, zeroed inside.  mean, rstd: (B,C) fp32 outputs (saved for backward).
+ */
+int rgbd_adain_fwd(const void* x, const float* scale, const float* shift, void* y,
+                   float* sums, float* mean, float* rstd, int B, int HW, int C, float eps, void* stream);
+/* dy (B,HW,C) bf16 -> dx bf16, dscale/dshift (B,C) fp32 (overwritten).  sums: workspace (B,C,2) fp32. */
+int rgbd_adain_bwd(const void* x, const void* dy, const float* scale, const float* mean, const float* rstd,
+                   void* dx, float* dscale, float* dshift, float* sums, int B, int HW, int C, void* stream);
+
+/* ------------------------------------------------------------------ optimizer
+ * Replaces chainer.optimizers.Adam + GradientClipping(5) (train_rgbd.py:151-161), one launch group per
+ * optimizer instead of one elementwise kernel per parameter tensor.
+ *   p, g, m, v : flat fp32 buffers of n elements (all parameters of one optimizer, contiguous).
+ *   grad_scale : multiplied into g first (1/world_size after an all-reduce(sum)).
+ *   Global L2 norm of grad_scale*g is computed on the device; rate = min(1, clip/norm).
+ *   Segments (HOST arrays, nseg entries): seg_begin[i] .. seg_begin[i+1] (seg_begin has nseg+1 entries)
+ *   use step size alpha_t[i] = alpha_i * sqrt(1-beta2^t) / (1-beta1^t), computed by the caller.
+ *   m += (1-b1)(g-m); v += (1-b2)(g*g-v); p -= alpha_t * m / (sqrt(v) + eps)   (eps outside the correction)
+ *   workspace: >= 1024 + 8 floats.  norm_out: optional device float receiving the pre-clip norm.
+ */
+int rgbd_adam_clip_multi(float* p, float* g, float* m, float* v, int64_t n,
+                         int nseg, const int64_t* seg_begin, const float* seg_alpha_t,
+                         float beta1, float beta2, float eps, float clip, float grad_scale,
+                         float* workspace, float* norm_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

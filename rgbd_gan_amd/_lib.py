@@ -1,0 +1,60 @@
+"""ctypes binding of librgbdgan_hip.so -- the only door between the Python host and the HIP kernels.
+
+The product path has no fallback: if the shared library is missing or an entry point fails, an exception
+is raised (RuntimeError carrying rgbd_last_error()).
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librgbdgan_hip.so")
+ABI_VERSION = 1
+
+_P = c_void_p
+
+# name -> argtypes, exactly the prototypes of include/rgbd_gan_hip.h
+PROTOTYPES = {
+    "rgbd_abi_version": ([], c_int),
+    "rgbd_last_error": ([], c_char_p),
+    "rgbd_warp_loss_fwd": ([_P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P], c_int),
+    "rgbd_warp_loss_bwd": ([_P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P], c_int),
+    "rgbd_pack_weights": ([_P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P], c_int),
+    "rgbd_conv2d_fprop_bf16": ([_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                c_int, c_int, c_float, _P], c_int),
+    "rgbd_conv2d_wgrad_bf16": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P], c_int),
+    "rgbd_unpack_wgrad": ([_P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P], c_int),
+    "rgbd_adain_fwd": ([_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P], c_int),
+    "rgbd_adain_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P], c_int),
+    "rgbd_adam_clip_multi": ([_P, _P, _P, _P, c_int64, c_int, POINTER(c_int64), POINTER(c_float), c_float, c_float,
+                              c_float, c_float, c_float, _P, _P, _P], c_int),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library once; raise (never fall back) when it is absent or has the wrong ABI."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -m rgbd_gan_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU or PyTorch fallback for the hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (argtypes, restype) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = restype
+    got = lib.rgbd_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"librgbdgan_hip.so ABI {got} != expected {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().rgbd_last_error()
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,360 @@
+// Implicit-GEMM convolution engine for gfx950 (bf16 MFMA, fp32 accumulate), NHWC activations.
+//
+// fprop / dgrad : D[co][pixel] = sum_{tap,ci} Wp[tap][co][ci] * X[pixel + tap][ci]
+//   A operand = packed weights (K-contiguous rows), B operand = gathered pixels (channels contiguous in
+//   NHWC), so both MFMA operands are plain 16-byte LDS reads and the accumulator holds 4 consecutive output
+//   channels per lane (8-byte NHWC stores).  The im2col matrix is never materialised: each K step gathers one
+//   filter tap x 64 input channels for 128 output pixels straight from the activation tensor; nearest-2x
+//   upsampling (rescale.py:4-5) is folded into that gather's address arithmetic.
+//   Roofline: MFMA (bf16 dense ~2.5 PFLOP/s) for Cin,Cout >= 128; the 64-channel 128x128 layers sit at
+//   ~290-380 FLOP/B, i.e. at the HBM/MFMA ridge, so they are HBM-bound unless epilogues stay fused.
+//
+// wgrad : dW[tap][co][ci] = sum_pixel dY[pixel][co] * X[pixel + tap][ci]
+//   The reduction index is the pixel, which is the *strided* index of both NHWC operands.  gfx950's
+//   ds_read_b64_tr_b16 transposes while reading LDS, so both operands are staged pixel-major exactly as they
+//   sit in HBM and read K(pixel)-contiguous for v_mfma_f32_32x32x16_bf16.  One workgroup keeps all 9 taps of
+//   a 64x64 (co,ci) tile in registers (144 accumulator VGPRs per lane), stages an 8x16-pixel patch of dY and the
+//   10x18 halo patch of X once, and sweeps its share of patches; partial sums leave through fp32 atomics shaped
+//   as two 128-byte row segments per wave instruction (MI355X_MICROARCH.md, "Global float atomics").
+#include "common.h"
+
+namespace {
+
+struct ConvArgs {
+    const unsigned short* x;
+    const unsigned short* wp;
+    const float* bias;
+    const unsigned short* resid;
+    unsigned short* y;
+    int B, Hin, Win, Cin, Cout, KH, KW, pad, ups, Hout, Wout, lrelu_ch;
+    float slope;
+    long M;
+};
+
+__device__ __forceinline__ u32x4 ldg16(const unsigned short* p) { return *reinterpret_cast<const u32x4*>(p); }
+
+template <int BN>
+__global__ __launch_bounds__(256) void conv_fprop_kernel(ConvArgs a) {
+    constexpr int BM = 128;                  // output pixels per workgroup
+    constexpr int P_BYTES = BM * 128;        // 128 rows x 64 bf16
+    constexpr int W_BYTES = BN * 128;
+    constexpr int STAGE = P_BYTES + W_BYTES;
+    constexpr int WAVES_CO = BN / 64;        // 64 output channels per wave along N
+    constexpr int WAVES_PX = 4 / WAVES_CO;
+    constexpr int PX_PER_WAVE = BM / WAVES_PX;
+    constexpr int TPX = PX_PER_WAVE / 16;
+    constexpr int WROWS = BN / 32;           // weight rows staged per thread
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int n_tiles = a.Cout / BN;
+    const int nt = blockIdx.x % n_tiles;
+    const long mt = blockIdx.x / n_tiles;
+    const long m0 = mt * BM;
+    const int n0 = nt * BN;
+    const int wave_co = (wid / WAVES_PX) * 64;
+    const int wave_px = (wid % WAVES_PX) * PX_PER_WAVE;
+
+    // ---- gather bookkeeping: this thread stages rows prow, prow+32, .. at 16-byte chunk `chunk`
+    const int chunk = tid & 7;
+    const int prow = tid >> 3;
+    const int swz = (chunk ^ (prow & 7)) << 4;   // row & 7 == prow & 7 for every row this thread touches
+    const int HWo = a.Hout * a.Wout;
+    const int Hup = a.ups ? 2 * a.Hin : a.Hin;
+    const int Wup = a.ups ? 2 * a.Win : a.Win;
+    int pb[4], ph[4], pw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long m = m0 + prow + 32 * i;
+        if (m < a.M) {
+            const int b = (int)(m / HWo);
+            const int r = (int)(m - (long)b * HWo);
+            const int ho = r / a.Wout;
+            pb[i] = b; ph[i] = ho; pw[i] = r - ho * a.Wout;
+        } else {
+            pb[i] = 0; ph[i] = -0x40000000; pw[i] = 0;
+        }
+    }
+    const int nkc = a.Cin >> 6;
+    const int nk = a.KH * a.KW * nkc;
+
+    u32x4 regP[4], regW[WROWS];
+    auto load_tiles = [&](int kt) {
+        const int tap = kt / nkc;
+        const int c0 = (kt - tap * nkc) << 6;
+        const int kh = tap / a.KW;
+        const int dh = kh - a.pad, dw = (tap - kh * a.KW) - a.pad;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int hi = ph[i] + dh, wi = pw[i] + dw;
+            const bool ok = (unsigned)hi < (unsigned)Hup && (unsigned)wi < (unsigned)Wup;
+            const int hs = a.ups ? (hi >> 1) : hi, ws = a.ups ? (wi >> 1) : wi;
+            const long off = (((long)pb[i] * a.Hin + hs) * a.Win + ws) * a.Cin + c0 + chunk * 8;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (ok) v = ldg16(a.x + off);
+            regP[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < WROWS; ++i) {
+            const long off = ((long)tap * a.Cout + n0 + prow + 32 * i) * a.Cin + c0 + chunk * 8;
+            regW[i] = ldg16(a.wp + off);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        unsigned char* base = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<u32x4*>(base + (prow + 32 * i) * 128 + swz) = regP[i];
+#pragma unroll
+        for (int i = 0; i < WROWS; ++i)
+            *reinterpret_cast<u32x4*>(base + P_BYTES + (prow + 32 * i) * 128 + swz) = regW[i];
+    };
+
+    f32x4 acc[4][TPX];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TPX; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int r16 = lane & 15, q = lane >> 4;
+    auto compute = [&](int buf) {
+        const unsigned char* pbase = smem + buf * STAGE;
+        const unsigned char* wbase = pbase + P_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int off = ((4 * s + q) ^ (r16 & 7)) << 4;
+            bf16x8 af[4], bfr[TPX];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                af[t] = *reinterpret_cast<const bf16x8*>(wbase + (wave_co + t * 16 + r16) * 128 + off);
+#pragma unroll
+            for (int t = 0; t < TPX; ++t)
+                bfr[t] = *reinterpret_cast<const bf16x8*>(pbase + (wave_px + t * 16 + r16) * 128 + off);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < TPX; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tiles(kt + 1);
+        compute(cur);
+        if (kt + 1 < nk) store_tiles(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias -> leaky ReLU (first lrelu_ch channels) -> residual -> bf16 NHWC
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int co = n0 + wave_co + i * 16 + 4 * q;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(a.bias + co);
+            bv[0] = t[0]; bv[1] = t[1]; bv[2] = t[2]; bv[3] = t[3];
+        }
+        const bool act = co < a.lrelu_ch;   // lrelu_ch is a multiple of 4 by construction (channel groups of 64)
+#pragma unroll
+        for (int j = 0; j < TPX; ++j) {
+            const long m = m0 + wave_px + j * 16 + r16;
+            if (m < a.M) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = acc[i][j][r] + bv[r];
+                    if (act) t = t > 0.f ? t : t * a.slope;
+                    v[r] = t;
+                }
+                const long o = m * a.Cout + co;
+                if (a.resid) {
+                    const u32x2 rr = *reinterpret_cast<const u32x2*>(a.resid + o);
+                    v[0] += bf16_lo(rr[0]); v[1] += bf16_hi(rr[0]);
+                    v[2] += bf16_lo(rr[1]); v[3] += bf16_hi(rr[1]);
+                }
+                u32x2 out = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                *reinterpret_cast<u32x2*>(a.y + o) = out;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ wgrad
+struct WgradArgs {
+    const unsigned short* x;
+    const unsigned short* dy;
+    float* dwp;
+    int B, H, W, Cin, Cout;
+    int PH, PW, lgPW;      // patch of output pixels (powers of two)
+    int npx, npy;          // patches per image along x / y
+    int total_patches, patches_per_wg;
+};
+
+__device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (s16x4 __attribute__((address_space(3)))*)(const_cast<unsigned char*>(p)));
+}
+
+template <int NT>  // filter taps: 9 (3x3, pad 1) or 1 (1x1)
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
+    constexpr int HALO = NT == 9 ? 1 : 0;
+    constexpr int KW = NT == 9 ? 3 : 1;
+    constexpr int MAX_X_ROWS = (8 + 2 * HALO) * (16 + 2 * HALO);
+    __shared__ __attribute__((aligned(16))) unsigned char xs[MAX_X_ROWS * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char ys[128 * 128];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int ci0 = blockIdx.y * 64, co0 = blockIdx.z * 64;
+    const int wc = wid >> 1, wi = wid & 1;             // wave -> (co half, ci half) of the 64x64 tile
+    const int HPW = a.PW + 2 * HALO, HPH = a.PH + 2 * HALO;
+    const int npix = a.PH * a.PW;
+    const int xrows = HPH * HPW;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // transposed-read lane roles (cdna_hip_programming.md T10): within each 16-lane group, lane 4q+p supplies
+    // the address of block row q (a pixel), columns 4p..4p+3 (channels); it receives column (lane & 15).
+    const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+    const int m_base = 16 * (g & 1), k_base = 8 * (g >> 1);
+    const int a_col_bytes = (wc * 32 + m_base + 4 * pp) * 2;
+    const int b_col_bytes = (wi * 32 + m_base + 4 * pp) * 2;
+
+    const int p_begin = blockIdx.x * a.patches_per_wg;
+    const int p_end = min(a.total_patches, p_begin + a.patches_per_wg);
+    for (int patch = p_begin; patch < p_end; ++patch) {
+        const int per_img = a.npx * a.npy;
+        const int b = patch / per_img;
+        const int rem = patch - b * per_img;
+        const int pyi = rem / a.npx;
+        const int y0 = pyi * a.PH, x0 = (rem - pyi * a.npx) * a.PW;
+        // ---- stage X halo patch (zero outside the image) and dY patch, pixel-major, 64 channels = 128 B per row;
+        //      bit 6 of the in-row byte offset is XORed with bit 1 of the row so 4 consecutive rows x 64 B cover
+        //      all 64 banks once for ds_read_b64_tr_b16.
+        for (int pc = tid; pc < xrows * 8; pc += 256) {
+            const int row = pc >> 3, chunk = pc & 7;
+            const int hy = row / HPW, hx = row - hy * HPW;
+            const int yy = y0 + hy - HALO, xx = x0 + hx - HALO;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W)
+                v = ldg16(a.x + (((long)b * a.H + yy) * a.W + xx) * a.Cin + ci0 + chunk * 8);
+            *reinterpret_cast<u32x4*>(xs + row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4)) = v;
+        }
+        for (int pc = tid; pc < npix * 8; pc += 256) {
+            const int row = pc >> 3, chunk = pc & 7;
+            const int py = row >> a.lgPW, px = row & (a.PW - 1);
+            const u32x4 v = ldg16(a.dy + (((long)b * a.H + y0 + py) * a.W + x0 + px) * a.Cout + co0 + chunk * 8);
+            *reinterpret_cast<u32x4*>(ys + row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4)) = v;
+        }
+        __syncthreads();
+        for (int ks = 0; ks < npix; ks += 16) {
+            const int pix0 = ks + k_base + qq, pix1 = pix0 + 4;
+            const s16x4 a0 = lds_tr16(ys + pix0 * 128 + (a_col_bytes ^ (((pix0 >> 1) & 1) << 6)));
+            const s16x4 a1 = lds_tr16(ys + pix1 * 128 + (a_col_bytes ^ (((pix1 >> 1) & 1) << 6)));
+            const bf16x8 af = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+            const int h0 = (pix0 >> a.lgPW) * HPW + (pix0 & (a.PW - 1));   // halo row of tap (0,0)
+            const int h1 = (pix1 >> a.lgPW) * HPW + (pix1 & (a.PW - 1));
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int toff = (t / KW) * HPW + (t % KW);
+                const int r0 = h0 + toff, r1 = h1 + toff;
+                const s16x4 b0 = lds_tr16(xs + r0 * 128 + (b_col_bytes ^ (((r0 >> 1) & 1) << 6)));
+                const s16x4 b1 = lds_tr16(xs + r1 * 128 + (b_col_bytes ^ (((r1 >> 1) & 1) << 6)));
+                const bf16x8 bfr = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- reduce across workgroups: D[row = co][col = ci]; one register = two 128-byte row segments per wave
+    const int col = lane & 31, rhalf = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * rhalf;
+            float* dst = a.dwp + ((long)t * a.Cout + co0 + wc * 32 + row) * a.Cin + ci0 + wi * 32 + col;
+            atomicAdd(dst, acc[t][r]);
+        }
+    }
+}
+
+int ilog2(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+}  // namespace
+
+extern "C" int rgbd_conv2d_fprop_bf16(const void* x, const void* wp, const float* bias, const void* residual,
+                                      void* y, int B, int Hin, int Win, int Cin, int Cout, int KH, int KW, int pad,
+                                      int upsample, int lrelu_channels, float slope, void* stream) {
+    RGBD_REQUIRE(x && wp && y, "rgbd_conv2d_fprop_bf16: null pointer");
+    RGBD_REQUIRE(B > 0 && Hin > 0 && Win > 0 && KH > 0 && KW > 0 && pad >= 0, "rgbd_conv2d_fprop_bf16: bad shape");
+    RGBD_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0,
+                 "rgbd_conv2d_fprop_bf16: Cin and Cout must be multiples of 64 (Cin=%d Cout=%d)", Cin, Cout);
+    RGBD_REQUIRE(lrelu_channels % 4 == 0 && lrelu_channels >= 0 && lrelu_channels <= Cout,
+                 "rgbd_conv2d_fprop_bf16: lrelu_channels must be a multiple of 4 in [0, Cout]");
+    ConvArgs a;
+    a.x = (const unsigned short*)x; a.wp = (const unsigned short*)wp; a.bias = bias;
+    a.resid = (const unsigned short*)residual; a.y = (unsigned short*)y;
+    a.B = B; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.pad = pad;
+    a.ups = upsample ? 1 : 0;
+    const int Hup = upsample ? 2 * Hin : Hin, Wup = upsample ? 2 * Win : Win;
+    a.Hout = Hup + 2 * pad - KH + 1;
+    a.Wout = Wup + 2 * pad - KW + 1;
+    RGBD_REQUIRE(a.Hout > 0 && a.Wout > 0, "rgbd_conv2d_fprop_bf16: empty output");
+    a.lrelu_ch = lrelu_channels; a.slope = slope;
+    a.M = (long)B * a.Hout * a.Wout;
+    const long mtiles = (a.M + 127) / 128;
+    hipStream_t st = (hipStream_t)stream;
+    if (Cout % 128 == 0) {
+        const long grid = mtiles * (Cout / 128);
+        RGBD_REQUIRE(grid < 0x7fffffffL, "rgbd_conv2d_fprop_bf16: grid too large");
+        conv_fprop_kernel<128><<<(unsigned)grid, 256, 0, st>>>(a);
+    } else {
+        const long grid = mtiles * (Cout / 64);
+        RGBD_REQUIRE(grid < 0x7fffffffL, "rgbd_conv2d_fprop_bf16: grid too large");
+        conv_fprop_kernel<64><<<(unsigned)grid, 256, 0, st>>>(a);
+    }
+    RGBD_CHECK_LAUNCH("conv_fprop_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_conv2d_wgrad_bf16(const void* x, const void* dy, float* dwp, int B, int H, int W, int Cin,
+                                      int Cout, int K, void* stream) {
+    RGBD_REQUIRE(x && dy && dwp, "rgbd_conv2d_wgrad_bf16: null pointer");
+    RGBD_REQUIRE(K == 1 || K == 3, "rgbd_conv2d_wgrad_bf16: K must be 1 or 3 (K=%d)", K);
+    RGBD_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0,
+                 "rgbd_conv2d_wgrad_bf16: Cin and Cout must be multiples of 64 (Cin=%d Cout=%d)", Cin, Cout);
+    RGBD_REQUIRE(B > 0 && H >= 4 && W >= 4 && (H & (H - 1)) == 0 && (W & (W - 1)) == 0,
+                 "rgbd_conv2d_wgrad_bf16: H and W must be powers of two >= 4 (H=%d W=%d)", H, W);
+    WgradArgs a;
+    a.x = (const unsigned short*)x; a.dy = (const unsigned short*)dy; a.dwp = dwp;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.PW = W < 16 ? W : 16;
+    a.PH = H < 8 ? H : 8;
+    a.lgPW = ilog2(a.PW);
+    a.npx = W / a.PW; a.npy = H / a.PH;
+    a.total_patches = B * a.npx * a.npy;
+    const int tiles = (Cin / 64) * (Cout / 64);
+    int nsplit = 1024 / tiles;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > a.total_patches) nsplit = a.total_patches;
+    a.patches_per_wg = (a.total_patches + nsplit - 1) / nsplit;
+    nsplit = (a.total_patches + a.patches_per_wg - 1) / a.patches_per_wg;
+    dim3 grid(nsplit, Cin / 64, Cout / 64);
+    hipStream_t st = (hipStream_t)stream;
+    if (K == 3) conv_wgrad_kernel<9><<<grid, 256, 0, st>>>(a);
+    else        conv_wgrad_kernel<1><<<grid, 256, 0, st>>>(a);
+    RGBD_CHECK_LAUNCH("conv_wgrad_kernel");
+    return 0;
+}

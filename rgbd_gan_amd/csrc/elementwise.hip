@@ -1,0 +1,335 @@
+// HBM-bound helper kernels: weight packing, AdaIN, clipped Adam.  All vectorised 16 B per lane where the
+// layout allows; bounded by the ~6.3 TB/s achievable HBM rate (MI355X_MICROARCH.md), not by MFMA.
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void rgbd_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* rgbd_last_error(void) { return g_err; }
+extern "C" int rgbd_abi_version(void) { return RGBD_ABI_VERSION; }
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ weights
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, int cout, int cin, int kh,
+                                                           int kw, float scale, unsigned short* __restrict__ wf,
+                                                           unsigned short* __restrict__ wd) {
+    const long total = (long)cout * cin * kh * kw;
+    const int taps = kh * kw;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        // e indexes the packed forward image [tap][co][ci] so stores are coalesced
+        const int ci = (int)(e % cin);
+        const long r = e / cin;
+        const int co = (int)(r % cout);
+        const int tap = (int)(r / cout);
+        const float v = w[((long)co * cin + ci) * taps + tap] * scale;
+        const unsigned short h = f32_to_bf16_bits(v);
+        if (wf) wf[e] = h;
+        if (wd) wd[((long)(taps - 1 - tap) * cin + ci) * cout + co] = h;
+    }
+}
+
+__global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __restrict__ dw,
+                                                           int cout, int cin, int taps, float scale, int accumulate) {
+    const long total = (long)cout * cin * taps;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int tap = (int)(e % taps);
+        const long r = e / taps;
+        const int ci = (int)(r % cin);
+        const int co = (int)(r / cin);
+        const float v = dwp[((long)tap * cout + co) * cin + ci] * scale;
+        dw[e] = accumulate ? dw[e] + v : v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ AdaIN
+// x is (B, HW, C) bf16.  A block owns one batch item, one 64-channel group and a strip of pixels:
+// thread t handles the 8-channel chunk (t & 7) of pixels (t >> 3), (t >> 3) + 32, ...
+constexpr int ADAIN_STRIP = 1024;
+
+template <bool WITH_DY>
+__global__ __launch_bounds__(256) void adain_reduce_kernel(const unsigned short* __restrict__ x,
+                                                           const unsigned short* __restrict__ dy,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, float* __restrict__ sums,
+                                                           int HW, int C) {
+    const int b = blockIdx.z, cg = blockIdx.y, strip = blockIdx.x;
+    const int chunk = threadIdx.x & 7, lane_p = threadIdx.x >> 3;
+    const int c0 = cg * 64 + chunk * 8;
+    const int p_begin = strip * ADAIN_STRIP;
+    const int p_end = min(HW, p_begin + ADAIN_STRIP);
+    float s0[8], s1[8], mu[8], rs[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        s0[k] = 0.f; s1[k] = 0.f;
+        if (WITH_DY) { mu[k] = mean[(long)b * C + c0 + k]; rs[k] = rstd[(long)b * C + c0 + k]; }
+    }
+    for (int p = p_begin + lane_p; p < p_end; p += 32) {
+        const long off = ((long)b * HW + p) * C + c0;
+        const u32x4 xv = *reinterpret_cast<const u32x4*>(x + off);
+        u32x4 gv;
+        if (WITH_DY) gv = *reinterpret_cast<const u32x4*>(dy + off);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xl = bf16_lo(xv[k]), xh = bf16_hi(xv[k]);
+            if (WITH_DY) {
+                const float gl = bf16_lo(gv[k]), gh = bf16_hi(gv[k]);
+                s0[2 * k] += gl; s0[2 * k + 1] += gh;
+                s1[2 * k] += gl * ((xl - mu[2 * k]) * rs[2 * k]);
+                s1[2 * k + 1] += gh * ((xh - mu[2 * k + 1]) * rs[2 * k + 1]);
+            } else {
+                s0[2 * k] += xl; s0[2 * k + 1] += xh;
+                s1[2 * k] += xl * xl; s1[2 * k + 1] += xh * xh;
+            }
+        }
+    }
+    __shared__ float red[2][32][65];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        red[0][lane_p][chunk * 8 + k] = s0[k];
+        red[1][lane_p][chunk * 8 + k] = s1[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6, c = threadIdx.x & 63;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) acc += red[which][r][c];
+        atomicAdd(sums + ((long)b * C + cg * 64 + c) * 2 + which, acc);
+    }
+}
+
+__global__ __launch_bounds__(256) void adain_finalize_kernel(const float* __restrict__ sums, float* __restrict__ mean,
+                                                             float* __restrict__ rstd, int n, float inv_hw,
+                                                             float eps) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float m = sums[2 * i] * inv_hw;
+    float var = sums[2 * i + 1] * inv_hw - m * m;
+    var = fmaxf(var, 0.f);
+    mean[i] = m;
+    rstd[i] = rsqrtf(var + eps);
+}
+
+// y = (x - mean) * rstd * scale + shift
+__global__ __launch_bounds__(256) void adain_apply_kernel(const unsigned short* __restrict__ x,
+                                                          const float* __restrict__ scale,
+                                                          const float* __restrict__ shift,
+                                                          const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd,
+                                                          unsigned short* __restrict__ y, long nvec, int HW, int C) {
+    const int cvec = C >> 3;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nvec; e += (long)gridDim.x * 256) {
+        const int cv = (int)(e % cvec);
+        const long pix = e / cvec;
+        const int b = (int)(pix / HW);
+        const long sidx = (long)b * C + cv * 8;
+        const u32x4 xv = *reinterpret_cast<const u32x4*>(x + e * 8);
+        u32x4 out;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float a0 = rstd[sidx + 2 * k] * scale[sidx + 2 * k];
+            const float a1 = rstd[sidx + 2 * k + 1] * scale[sidx + 2 * k + 1];
+            const float r0 = (bf16_lo(xv[k]) - mean[sidx + 2 * k]) * a0 + shift[sidx + 2 * k];
+            const float r1 = (bf16_hi(xv[k]) - mean[sidx + 2 * k + 1]) * a1 + shift[sidx + 2 * k + 1];
+            out[k] = pack_bf16x2(r0, r1);
+        }
+        *reinterpret_cast<u32x4*>(y + e * 8) = out;
+    }
+}
+
+// dx = rstd * scale * (dy - sum(dy)/HW - xhat * sum(dy*xhat)/HW);  sums = (sum dy, sum dy*xhat) per (b,c)
+__global__ __launch_bounds__(256) void adain_bwd_apply_kernel(const unsigned short* __restrict__ x,
+                                                              const unsigned short* __restrict__ dy,
+                                                              const float* __restrict__ scale,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd,
+                                                              const float* __restrict__ sums,
+                                                              unsigned short* __restrict__ dx, long nvec, int HW,
+                                                              int C, float inv_hw) {
+    const int cvec = C >> 3;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nvec; e += (long)gridDim.x * 256) {
+        const int cv = (int)(e % cvec);
+        const long pix = e / cvec;
+        const int b = (int)(pix / HW);
+        const long sidx = (long)b * C + cv * 8;
+        const u32x4 xv = *reinterpret_cast<const u32x4*>(x + e * 8);
+        const u32x4 gv = *reinterpret_cast<const u32x4*>(dy + e * 8);
+        u32x4 out;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float r[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const long s = sidx + 2 * k + h;
+                const float xh = ((h ? bf16_hi(xv[k]) : bf16_lo(xv[k])) - mean[s]) * rstd[s];
+                const float g = h ? bf16_hi(gv[k]) : bf16_lo(gv[k]);
+                r[h] = rstd[s] * scale[s] * (g - sums[2 * s] * inv_hw - xh * sums[2 * s + 1] * inv_hw);
+            }
+            out[k] = pack_bf16x2(r[0], r[1]);
+        }
+        *reinterpret_cast<u32x4*>(dx + e * 8) = out;
+    }
+}
+
+__global__ __launch_bounds__(256) void split_sums_kernel(const float* __restrict__ sums, float* __restrict__ dscale,
+                                                         float* __restrict__ dshift, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    dshift[i] = sums[2 * i];
+    dscale[i] = sums[2 * i + 1];
+}
+
+// ------------------------------------------------------------------------------------------------ Adam
+constexpr int NORM_BLOCKS = 1024;
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float gscale,
+                                                    float* __restrict__ partial) {
+    float acc = 0.f;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const float v = g[e] * gscale;
+        acc += v * v;
+    }
+    acc = wave_sum(acc);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ws[NORM_BLOCKS] = norm, ws[NORM_BLOCKS + 1] = rate
+__global__ __launch_bounds__(256) void norm_final_kernel(float* __restrict__ ws, int nblocks, float clip,
+                                                         float* __restrict__ norm_out) {
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < nblocks; k += 256) acc += (double)ws[k];
+    __shared__ double red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float norm = (float)sqrt(red[0]);
+        const float rate = clip / norm;   // chainer GradientClipping: scale only when rate < 1
+        ws[NORM_BLOCKS] = norm;
+        ws[NORM_BLOCKS + 1] = rate < 1.f ? rate : 1.f;
+        if (norm_out) norm_out[0] = norm;
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long begin,
+                                                   long end, float alpha_t, float beta1, float beta2, float eps,
+                                                   float gscale, const float* __restrict__ ws) {
+    const float rate = ws[NORM_BLOCKS + 1] * gscale;
+    for (long e = begin + (long)blockIdx.x * 256 + threadIdx.x; e < end; e += (long)gridDim.x * 256) {
+        const float grad = g[e] * rate;
+        float mm = m[e], vv = v[e];
+        mm += (1.f - beta1) * (grad - mm);
+        vv += (1.f - beta2) * (grad * grad - vv);
+        m[e] = mm;
+        v[e] = vv;
+        p[e] -= alpha_t * mm / (sqrtf(vv) + eps);
+    }
+}
+
+}  // namespace
+
+extern "C" int rgbd_pack_weights(const float* w, int cout, int cin, int kh, int kw, float scale, void* w_fprop,
+                                 void* w_dgrad, void* stream) {
+    RGBD_REQUIRE(w && (w_fprop || w_dgrad), "rgbd_pack_weights: null pointer");
+    RGBD_REQUIRE(cout > 0 && cin > 0 && kh > 0 && kw > 0, "rgbd_pack_weights: bad shape");
+    const long total = (long)cout * cin * kh * kw;
+    const int blocks = (int)min((long)2048, (total + 255) / 256);
+    pack_weights_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(w, cout, cin, kh, kw, scale,
+                                                                 (unsigned short*)w_fprop, (unsigned short*)w_dgrad);
+    RGBD_CHECK_LAUNCH("pack_weights_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_unpack_wgrad(const float* dwp, float* dw, int cout, int cin, int kh, int kw, float scale,
+                                 int accumulate, void* stream) {
+    RGBD_REQUIRE(dwp && dw, "rgbd_unpack_wgrad: null pointer");
+    const long total = (long)cout * cin * kh * kw;
+    const int blocks = (int)min((long)2048, (total + 255) / 256);
+    unpack_wgrad_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(dwp, dw, cout, cin, kh * kw, scale, accumulate);
+    RGBD_CHECK_LAUNCH("unpack_wgrad_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_adain_fwd(const void* x, const float* scale, const float* shift, void* y, float* sums,
+                              float* mean, float* rstd, int B, int HW, int C, float eps, void* stream) {
+    RGBD_REQUIRE(x && scale && shift && y && sums && mean && rstd, "rgbd_adain_fwd: null pointer");
+    RGBD_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 64 == 0, "rgbd_adain_fwd: C must be a multiple of 64 (C=%d)", C);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(sums, 0, (size_t)B * C * 2 * sizeof(float), st) != hipSuccess) {
+        rgbd_set_error("rgbd_adain_fwd: memset failed");
+        return -2;
+    }
+    dim3 grid(ceil_div(HW, ADAIN_STRIP), C / 64, B);
+    adain_reduce_kernel<false><<<grid, 256, 0, st>>>((const unsigned short*)x, nullptr, nullptr, nullptr, sums, HW, C);
+    RGBD_CHECK_LAUNCH("adain_reduce_kernel");
+    adain_finalize_kernel<<<ceil_div((long)B * C, 256), 256, 0, st>>>(sums, mean, rstd, B * C, 1.f / (float)HW, eps);
+    RGBD_CHECK_LAUNCH("adain_finalize_kernel");
+    const long nvec = (long)B * HW * C / 8;
+    const int blocks = (int)min((long)4096, (nvec + 255) / 256);
+    adain_apply_kernel<<<blocks, 256, 0, st>>>((const unsigned short*)x, scale, shift, mean, rstd,
+                                               (unsigned short*)y, nvec, HW, C);
+    RGBD_CHECK_LAUNCH("adain_apply_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_adain_bwd(const void* x, const void* dy, const float* scale, const float* mean,
+                              const float* rstd, void* dx, float* dscale, float* dshift, float* sums, int B,
+                              int HW, int C, void* stream) {
+    RGBD_REQUIRE(x && dy && scale && mean && rstd && dx && dscale && dshift && sums, "rgbd_adain_bwd: null pointer");
+    RGBD_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 64 == 0, "rgbd_adain_bwd: C must be a multiple of 64 (C=%d)", C);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(sums, 0, (size_t)B * C * 2 * sizeof(float), st) != hipSuccess) {
+        rgbd_set_error("rgbd_adain_bwd: memset failed");
+        return -2;
+    }
+    dim3 grid(ceil_div(HW, ADAIN_STRIP), C / 64, B);
+    adain_reduce_kernel<true><<<grid, 256, 0, st>>>((const unsigned short*)x, (const unsigned short*)dy, mean, rstd,
+                                                    sums, HW, C);
+    RGBD_CHECK_LAUNCH("adain_reduce_kernel<dy>");
+    const long nvec = (long)B * HW * C / 8;
+    const int blocks = (int)min((long)4096, (nvec + 255) / 256);
+    adain_bwd_apply_kernel<<<blocks, 256, 0, st>>>((const unsigned short*)x, (const unsigned short*)dy, scale, mean,
+                                                   rstd, sums, (unsigned short*)dx, nvec, HW, C, 1.f / (float)HW);
+    RGBD_CHECK_LAUNCH("adain_bwd_apply_kernel");
+    split_sums_kernel<<<ceil_div((long)B * C, 256), 256, 0, st>>>(sums, dscale, dshift, B * C);
+    RGBD_CHECK_LAUNCH("split_sums_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_adam_clip_multi(float* p, float* g, float* m, float* v, int64_t n, int nseg,
+                                    const int64_t* seg_begin, const float* seg_alpha_t, float beta1, float beta2,
+                                    float eps, float clip, float grad_scale, float* workspace, float* norm_out,
+                                    void* stream) {
+    RGBD_REQUIRE(p && g && m && v && workspace && seg_begin && seg_alpha_t, "rgbd_adam_clip_multi: null pointer");
+    RGBD_REQUIRE(n > 0 && nseg > 0, "rgbd_adam_clip_multi: empty");
+    RGBD_REQUIRE(seg_begin[0] == 0 && seg_begin[nseg] == n, "rgbd_adam_clip_multi: segments must cover [0,n)");
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = (int)min((long)NORM_BLOCKS, (long)((n + 255) / 256));
+    sumsq_kernel<<<nb, 256, 0, st>>>(g, n, grad_scale, workspace);
+    RGBD_CHECK_LAUNCH("sumsq_kernel");
+    norm_final_kernel<<<1, 256, 0, st>>>(workspace, nb, clip, norm_out);
+    RGBD_CHECK_LAUNCH("norm_final_kernel");
+    for (int s = 0; s < nseg; ++s) {
+        const long b = seg_begin[s], e = seg_begin[s + 1];
+        RGBD_REQUIRE(e >= b, "rgbd_adam_clip_multi: segments must be ascending");
+        if (e == b) continue;
+        const int blocks = (int)min((long)2048, (e - b + 255) / 256);
+        adam_kernel<<<blocks, 256, 0, st>>>(p, g, m, v, b, e, seg_alpha_t[s], beta1, beta2, eps, grad_scale, workspace);
+        RGBD_CHECK_LAUNCH("adam_kernel");
+    }
+    return 0;
+}

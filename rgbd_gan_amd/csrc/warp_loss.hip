@@ -1,0 +1,275 @@
+// Fused 3D-consistency loss: depth warp + bilinear sampling + out-of-frame / occlusion masks + L1 terms.
+//
+// Replaces common/loss_functions.py:63-146,171-228 of the reference (about 100 small CuPy kernels and
+// 8 scatter-adds per call) with one forward and one backward kernel.  HBM-bound and tiny (about 1.5 MB per
+// view pair), so the goal is launch count and exact index math, not MFMA.
+//
+// THIS FILE IS COMPILED WITH -ffp-contract=off: the projection and interpolation arithmetic must be
+// evaluated unfused, left to right, to be bit-exact against oracle/warp_loss.py:forward_np
+// ("Bit-exactness definition").
+#include "common.h"
+
+namespace {
+
+struct PixelWarp {
+    float zp0, zp1, zp2;      // projected z * (x, y, 1)
+    float den, u, v;          // u = row coordinate, v = column coordinate (reference swaps x/y)
+    float u0f, u1f, v0f, v1f;
+    float w1, w2, w3, w4;     // masked interpolation weights
+    int u0m, v0m, v1m;        // masked taps (u1m == u0m: loss_functions.py:219)
+    bool mask;
+};
+
+// coef: A(9) c(3); sign = -1 for warp (zp = A(z p) - c), +1 for inv_warp (zp = A'(z p) + c').
+__device__ __forceinline__ PixelWarp project_pixel(const float* __restrict__ cf, float sign, float z,
+                                                   int i, int j, int S) {
+    PixelWarp w;
+    const float p0 = (float)j, p1 = (float)i;
+    const float a0 = z * p0, a1 = z * p1, a2 = z * 1.0f;
+    float s0 = (cf[0] * a0 + cf[1] * a1) + cf[2] * a2;
+    float s1 = (cf[3] * a0 + cf[4] * a1) + cf[5] * a2;
+    float s2 = (cf[6] * a0 + cf[7] * a1) + cf[8] * a2;
+    if (sign < 0.f) { s0 = s0 - cf[9]; s1 = s1 - cf[10]; s2 = s2 - cf[11]; }
+    else            { s0 = s0 + cf[9]; s1 = s1 + cf[10]; s2 = s2 + cf[11]; }
+    w.zp0 = s0; w.zp1 = s1; w.zp2 = s2;
+    w.den = fminf(fmaxf(s2, 1e-4f), 10000.f);
+    const float x = s0 / w.den;
+    const float y = s1 / w.den;
+    w.u = y; w.v = x;
+    const int u0 = (int)w.u;   // truncation toward zero (saturating for out-of-range; such pixels are masked)
+    const int v0 = (int)w.v;
+    const int u1 = (int)((unsigned)u0 + 1u);
+    const int v1 = (int)((unsigned)v0 + 1u);
+    w.u0f = (float)u0; w.u1f = (float)u1; w.v0f = (float)v0; w.v1f = (float)v1;
+    w.w1 = (w.u1f - w.u) * (w.v1f - w.v);
+    w.w2 = (w.u - w.u0f) * (w.v1f - w.v);
+    w.w3 = (w.u1f - w.u) * (w.v - w.v0f);
+    w.w4 = (w.u - w.u0f) * (w.v - w.v0f);
+    const float lim = (float)(S - 1);
+    w.mask = (w.u >= 0.f) && (w.u < lim) && (w.v >= 0.f) && (w.v < lim) && (s2 > 1e-4f);
+    const float mf = w.mask ? 1.f : 0.f;
+    w.u0m = w.mask ? u0 : 0;
+    w.v0m = w.mask ? v0 : 0;
+    w.v1m = w.mask ? v1 : 0;
+    w.w1 *= mf; w.w2 *= mf; w.w3 *= mf; w.w4 *= mf;
+    return w;
+}
+
+// grid: (ceil(b*hw/256), 2). blockIdx.y = direction (0: sample img_rot at warp(img); 1: the inverse).
+__global__ __launch_bounds__(256) void warp_loss_fwd_kernel(
+    const float* __restrict__ img, const float* __restrict__ img_rot, const float* __restrict__ coef,
+    int b, int S, int flags, float max_depth, float min_depth,
+    float* __restrict__ partials, float* __restrict__ dbg_zp, float* __restrict__ dbg_warped,
+    int32_t* __restrict__ dbg_idx) {
+    const int dir = blockIdx.y;
+    const int hw = S * S;
+    const long n = (long)blockIdx.x * 256 + threadIdx.x;
+    const long N = (long)b * hw;
+    const float* own = dir == 0 ? img : img_rot;   // image whose depth is projected / whose RGB is the target
+    const float* src = dir == 0 ? img_rot : img;   // image that is sampled
+    float l_rgb = 0.f, l_d = 0.f;
+    if (n < N) {
+        const int bi = (int)(n / hw);
+        const int pix = (int)(n - (long)bi * hw);
+        const int i = pix / S, j = pix - i * S;
+        const float* cf = coef + bi * 24 + dir * 12;
+        const float* ob = own + (long)bi * 4 * hw;
+        const float* sb = src + (long)bi * 4 * hw;
+        const float z = ob[3 * hw + pix];
+        const PixelWarp w = project_pixel(cf, dir == 0 ? -1.f : 1.f, z, i, j, S);
+        const int o00 = w.u0m * S + w.v0m;
+        const int o01 = w.u0m * S + w.v1m;
+        float warped[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float a = sb[c * hw + o00];
+            const float d = sb[c * hw + o01];
+            // taps in the reference's order: (u0,v0), (u1,v0), (u0,v1), (u1,v1) with u1 == u0
+            warped[c] = ((w.w1 * a + w.w2 * a) + w.w3 * d) + w.w4 * d;
+        }
+        const float mf = w.mask ? 1.f : 0.f;
+        float target[4];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) target[c] = ob[c * hw + pix] * mf;
+        target[3] = w.zp2 * mf;
+        bool vis = true;
+        if (flags & RGBD_WARP_OCCLUSION) vis = vis && (warped[3] > w.zp2);
+        if (flags & RGBD_WARP_MAX_DEPTH) vis = vis && (z < max_depth);
+        if (flags & RGBD_WARP_MIN_DEPTH) vis = vis && (z > min_depth);
+        const float vf = vis ? 1.f : 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) l_rgb += fabsf(warped[c] * vf - target[c] * vf);
+        l_d = fabsf(warped[3] * vf - target[3] * vf);
+        if (dbg_zp) {
+            float* o = dbg_zp + ((long)dir * N + n) * 3;
+            o[0] = w.zp0; o[1] = w.zp1; o[2] = w.zp2;
+        }
+        if (dbg_warped) {
+            float* o = dbg_warped + ((long)dir * N + n) * 4;
+            o[0] = warped[0]; o[1] = warped[1]; o[2] = warped[2]; o[3] = warped[3];
+        }
+        if (dbg_idx) {
+            int32_t* o = dbg_idx + ((long)dir * N + n) * 4;
+            o[0] = w.u0m; o[1] = w.v0m; o[2] = w.v1m; o[3] = w.mask ? 1 : 0;
+        }
+    }
+    // deterministic block reduction
+    __shared__ float red[2][4];
+    l_rgb = wave_sum(l_rgb);
+    l_d = wave_sum(l_d);
+    const int wid = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wid] = l_rgb; red[1][wid] = l_d; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float* o = partials + ((long)blockIdx.x * 2 + dir) * 2;
+        o[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        o[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
+// one block: loss = mae_rgb(fwd) + mae_rgb(inv) + lambda * (mae_d(fwd) + mae_d(inv))
+__global__ __launch_bounds__(256) void warp_loss_final_kernel(const float* __restrict__ partials, int nblocks,
+                                                             float inv_n, float lambda_geo,
+                                                             float* __restrict__ loss) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};  // rgb0, d0, rgb1, d1
+    for (int k = threadIdx.x; k < nblocks; k += 256) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] += partials[(long)k * 4 + q];
+    }
+    __shared__ float red[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = wave_sum(acc[q]);
+    const int wid = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[q][wid] = acc[q];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] = (red[q][0] + red[q][1]) + (red[q][2] + red[q][3]);
+        const float rgb = t[0] * (inv_n / 3.f) + t[2] * (inv_n / 3.f);
+        const float dep = t[1] * inv_n * lambda_geo + t[3] * inv_n * lambda_geo;
+        loss[0] = rgb + dep;
+    }
+}
+
+__global__ __launch_bounds__(256) void warp_loss_bwd_kernel(
+    const float* __restrict__ img, const float* __restrict__ img_rot, const float* __restrict__ coef,
+    int b, int S, int flags, float lambda_geo, float max_depth, float min_depth,
+    const float* __restrict__ grad_loss, float* __restrict__ gimg, float* __restrict__ gimg_rot) {
+    const int dir = blockIdx.y;
+    const int hw = S * S;
+    const long n = (long)blockIdx.x * 256 + threadIdx.x;
+    const long N = (long)b * hw;
+    if (n >= N) return;
+    const float* own = dir == 0 ? img : img_rot;
+    const float* src = dir == 0 ? img_rot : img;
+    float* gown = dir == 0 ? gimg : gimg_rot;
+    float* gsrc = dir == 0 ? gimg_rot : gimg;
+    const int bi = (int)(n / hw);
+    const int pix = (int)(n - (long)bi * hw);
+    const int i = pix / S, j = pix - i * S;
+    const float* cf = coef + bi * 24 + dir * 12;
+    const float* ob = own + (long)bi * 4 * hw;
+    const float* sb = src + (long)bi * 4 * hw;
+    float* gob = gown + (long)bi * 4 * hw;
+    float* gsb = gsrc + (long)bi * 4 * hw;
+    const float z = ob[3 * hw + pix];
+    const PixelWarp w = project_pixel(cf, dir == 0 ? -1.f : 1.f, z, i, j, S);
+    if (!w.mask) return;  // masked pixels have zero weights, zero targets and constant taps: no gradient
+    const int o00 = w.u0m * S + w.v0m;
+    const int o01 = w.u0m * S + w.v1m;
+    float a[4], d[4], warped[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        a[c] = sb[c * hw + o00];
+        d[c] = sb[c * hw + o01];
+        warped[c] = ((w.w1 * a[c] + w.w2 * a[c]) + w.w3 * d[c]) + w.w4 * d[c];
+    }
+    bool vis = true;
+    if (flags & RGBD_WARP_OCCLUSION) vis = vis && (warped[3] > w.zp2);
+    if (flags & RGBD_WARP_MAX_DEPTH) vis = vis && (z < max_depth);
+    if (flags & RGBD_WARP_MIN_DEPTH) vis = vis && (z > min_depth);
+    if (!vis) return;
+    const float go = grad_loss[0];
+    const float inv_n = 1.f / (float)N;
+    const float k_rgb = go * inv_n / 3.f;
+    const float k_d = go * inv_n * lambda_geo;
+    float g[4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float diff = warped[c] - ob[c * hw + pix];
+        g[c] = diff > 0.f ? k_rgb : (diff < 0.f ? -k_rgb : 0.f);
+    }
+    {
+        const float diff = warped[3] - w.zp2;
+        g[3] = diff > 0.f ? k_d : (diff < 0.f ? -k_d : 0.f);
+    }
+    // (1) gathered values -> scatter-add into the sampled image (two distinct taps; rows u0 and "u1" coincide)
+    const float wl = w.w1 + w.w2, wr = w.w3 + w.w4;
+    float gw_a = 0.f, gw_d = 0.f;  // sum_c g[c] * tap value
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        atomicAdd(gsb + c * hw + o00, g[c] * wl);
+        atomicAdd(gsb + c * hw + o01, g[c] * wr);
+        gw_a += g[c] * a[c];
+        gw_d += g[c] * d[c];
+    }
+    // (2) targets: own RGB and projected depth
+#pragma unroll
+    for (int c = 0; c < 3; ++c) atomicAdd(gob + c * hw + pix, -g[c]);
+    float gzp2 = -g[3];
+    // (3) interpolation weights -> (u, v) -> zp -> own depth.  dL/dw1 = dL/dw2 = gw_a, dL/dw3 = dL/dw4 = gw_d.
+    const float du1 = w.u1f - w.u, du0 = w.u - w.u0f, dv1 = w.v1f - w.v, dv0 = w.v - w.v0f;
+    const float gu = (gw_a * (-dv1) + gw_a * dv1) + (gw_d * (-dv0) + gw_d * dv0);   // cancels exactly
+    const float gv = (gw_a * (-du1) + gw_a * (-du0)) + (gw_d * du1 + gw_d * du0);
+    const float gzp1 = gu / w.den;
+    const float gzp0 = gv / w.den;
+    const float gden = -(gu * w.u + gv * w.v) / w.den;
+    if (w.zp2 >= 1e-4f && w.zp2 <= 10000.f) gzp2 += gden;
+    const float p0 = (float)j, p1 = (float)i;
+    const float gz = gzp0 * (cf[0] * p0 + cf[1] * p1 + cf[2]) + gzp1 * (cf[3] * p0 + cf[4] * p1 + cf[5]) +
+                     gzp2 * (cf[6] * p0 + cf[7] * p1 + cf[8]);
+    atomicAdd(gob + 3 * hw + pix, gz);
+}
+
+}  // namespace
+
+extern "C" int rgbd_warp_loss_fwd(const float* img, const float* img_rot, const float* coef, int b, int S,
+                                  int flags, float lambda_geometric, float max_depth, float min_depth,
+                                  float* partials, float* loss, float* dbg_zp, float* dbg_warped,
+                                  int32_t* dbg_idx, void* stream) {
+    RGBD_REQUIRE(img && img_rot && coef && partials && loss, "rgbd_warp_loss_fwd: null pointer");
+    RGBD_REQUIRE(b > 0 && S >= 2, "rgbd_warp_loss_fwd: bad shape b=%d S=%d", b, S);
+    const long N = (long)b * S * S;
+    const int nblocks = ceil_div(N, 256);
+    hipStream_t st = (hipStream_t)stream;
+    warp_loss_fwd_kernel<<<dim3(nblocks, 2), 256, 0, st>>>(img, img_rot, coef, b, S, flags, max_depth, min_depth,
+                                                           partials, dbg_zp, dbg_warped, dbg_idx);
+    RGBD_CHECK_LAUNCH("warp_loss_fwd_kernel");
+    warp_loss_final_kernel<<<1, 256, 0, st>>>(partials, nblocks, 1.f / (float)N, lambda_geometric, loss);
+    RGBD_CHECK_LAUNCH("warp_loss_final_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_warp_loss_bwd(const float* img, const float* img_rot, const float* coef, int b, int S,
+                                  int flags, float lambda_geometric, float max_depth, float min_depth,
+                                  const float* grad_loss, float* grad_img, float* grad_img_rot, void* stream) {
+    RGBD_REQUIRE(img && img_rot && coef && grad_loss && grad_img && grad_img_rot,
+                 "rgbd_warp_loss_bwd: null pointer");
+    RGBD_REQUIRE(b > 0 && S >= 2, "rgbd_warp_loss_bwd: bad shape b=%d S=%d", b, S);
+    const long N = (long)b * S * S;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(grad_img, 0, N * 4 * sizeof(float), st) != hipSuccess ||
+        hipMemsetAsync(grad_img_rot, 0, N * 4 * sizeof(float), st) != hipSuccess) {
+        rgbd_set_error("rgbd_warp_loss_bwd: memset failed");
+        return -2;
+    }
+    warp_loss_bwd_kernel<<<dim3(ceil_div(N, 256), 2), 256, 0, st>>>(img, img_rot, coef, b, S, flags,
+                                                                    lambda_geometric, max_depth, min_depth,
+                                                                    grad_loss, grad_img, grad_img_rot);
+    RGBD_CHECK_LAUNCH("warp_loss_bwd_kernel");
+    return 0;
+}

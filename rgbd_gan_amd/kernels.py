@@ -1,0 +1,155 @@
+"""Thin, typed wrappers: torch device tensors in, C-ABI calls out.  No arithmetic happens here."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _chk(t, dtype, name):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a GPU tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: expected a contiguous tensor")
+
+
+# ------------------------------------------------------------------ warp loss
+def warp_loss_fwd(img, img_rot, coef, flags, lambda_geometric, max_depth=0.0, min_depth=0.0, debug=False):
+    """img, img_rot (b,4,S,S) fp32; coef (b,24) fp32 -> loss (1,) [+ debug tensors]."""
+    for t, n in ((img, "img"), (img_rot, "img_rot"), (coef, "coef")):
+        _chk(t, F32, n)
+    b, C, S, _ = img.shape
+    if C != 4 or img_rot.shape != img.shape or coef.shape != (b, 24):
+        raise RuntimeError(f"warp_loss_fwd: bad shapes {tuple(img.shape)} {tuple(img_rot.shape)} {tuple(coef.shape)}")
+    N = b * S * S
+    partials = torch.empty(4 * ((N + 255) // 256), dtype=F32, device=img.device)
+    loss = torch.empty(1, dtype=F32, device=img.device)
+    zp = warped = idx = None
+    if debug:
+        zp = torch.empty(2, b, S * S, 3, dtype=F32, device=img.device)
+        warped = torch.empty(2, N, 4, dtype=F32, device=img.device)
+        idx = torch.empty(2, N, 4, dtype=torch.int32, device=img.device)
+    rc = _lib.load().rgbd_warp_loss_fwd(_ptr(img), _ptr(img_rot), _ptr(coef), b, S, int(flags),
+                                        float(lambda_geometric), float(max_depth), float(min_depth),
+                                        _ptr(partials), _ptr(loss), _ptr(zp), _ptr(warped), _ptr(idx), _stream())
+    _lib.check(rc, "rgbd_warp_loss_fwd")
+    return (loss, zp, warped, idx) if debug else loss
+
+
+def warp_loss_bwd(img, img_rot, coef, flags, lambda_geometric, max_depth, min_depth, grad_loss):
+    _chk(grad_loss, F32, "grad_loss")
+    b, _, S, _ = img.shape
+    gimg = torch.empty_like(img)
+    gimg_rot = torch.empty_like(img_rot)
+    rc = _lib.load().rgbd_warp_loss_bwd(_ptr(img), _ptr(img_rot), _ptr(coef), b, S, int(flags),
+                                        float(lambda_geometric), float(max_depth), float(min_depth),
+                                        _ptr(grad_loss), _ptr(gimg), _ptr(gimg_rot), _stream())
+    _lib.check(rc, "rgbd_warp_loss_bwd")
+    return gimg, gimg_rot
+
+
+# ------------------------------------------------------------------ conv engine
+def pack_weights(w, scale, want_fprop=True, want_dgrad=True):
+    """w (Cout,Cin,KH,KW) fp32 -> (w_fprop [T][Cout][Cin], w_dgrad [T][Cin][Cout]) bf16 with `scale` folded in."""
+    _chk(w, F32, "w")
+    co, ci, kh, kw = w.shape
+    wf = torch.empty(kh * kw, co, ci, dtype=BF16, device=w.device) if want_fprop else None
+    wd = torch.empty(kh * kw, ci, co, dtype=BF16, device=w.device) if want_dgrad else None
+    rc = _lib.load().rgbd_pack_weights(_ptr(w), co, ci, kh, kw, float(scale), _ptr(wf), _ptr(wd), _stream())
+    _lib.check(rc, "rgbd_pack_weights")
+    return wf, wd
+
+
+def conv2d_fprop(x, wp, KH, KW, pad, bias=None, residual=None, upsample=False, lrelu_channels=0, slope=0.2):
+    """x (B,H,W,Cin) bf16, wp [KH*KW][Cout][Cin] bf16 -> y (B,Hout,Wout,Cout) bf16."""
+    _chk(x, BF16, "x"); _chk(wp, BF16, "wp"); _chk(bias, F32, "bias"); _chk(residual, BF16, "residual")
+    B, H, W, Cin = x.shape
+    T, Cout, Cin2 = wp.shape
+    if T != KH * KW or Cin2 != Cin:
+        raise RuntimeError(f"conv2d_fprop: weights {tuple(wp.shape)} do not match x {tuple(x.shape)} K={KH}x{KW}")
+    Hup, Wup = (2 * H, 2 * W) if upsample else (H, W)
+    Hout, Wout = Hup + 2 * pad - KH + 1, Wup + 2 * pad - KW + 1
+    y = torch.empty(B, Hout, Wout, Cout, dtype=BF16, device=x.device)
+    if residual is not None and residual.shape != y.shape:
+        raise RuntimeError("conv2d_fprop: residual shape mismatch")
+    rc = _lib.load().rgbd_conv2d_fprop_bf16(_ptr(x), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(y), B, H, W, Cin,
+                                            Cout, KH, KW, pad, int(bool(upsample)), int(lrelu_channels),
+                                            float(slope), _stream())
+    _lib.check(rc, "rgbd_conv2d_fprop_bf16")
+    return y
+
+
+def conv2d_wgrad(x, dy, K, scale, out=None, accumulate=False):
+    """x (B,H,W,Cin) bf16, dy (B,H,W,Cout) bf16 -> dW (Cout,Cin,K,K) fp32 = scale * sum dy (x) x."""
+    _chk(x, BF16, "x"); _chk(dy, BF16, "dy")
+    B, H, W, Cin = x.shape
+    Cout = dy.shape[3]
+    if dy.shape[:3] != x.shape[:3]:
+        raise RuntimeError(f"conv2d_wgrad: spatial mismatch {tuple(x.shape)} vs {tuple(dy.shape)}")
+    dwp = torch.zeros(K * K, Cout, Cin, dtype=F32, device=x.device)
+    lib = _lib.load()
+    rc = lib.rgbd_conv2d_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(dwp), B, H, W, Cin, Cout, K, _stream())
+    _lib.check(rc, "rgbd_conv2d_wgrad_bf16")
+    if out is None:
+        out = torch.empty(Cout, Cin, K, K, dtype=F32, device=x.device)
+        accumulate = False
+    rc = lib.rgbd_unpack_wgrad(_ptr(dwp), _ptr(out), Cout, Cin, K, K, float(scale), int(bool(accumulate)), _stream())
+    _lib.check(rc, "rgbd_unpack_wgrad")
+    return out
+
+
+# ------------------------------------------------------------------ AdaIN
+def adain_fwd(x, scale, shift, eps=1e-5):
+    """x (B,H,W,C) bf16; scale, shift (B,C) fp32 -> y, mean, rstd."""
+    _chk(x, BF16, "x"); _chk(scale, F32, "scale"); _chk(shift, F32, "shift")
+    B, H, W, C = x.shape
+    y = torch.empty_like(x)
+    sums = torch.empty(B, C, 2, dtype=F32, device=x.device)
+    mean = torch.empty(B, C, dtype=F32, device=x.device)
+    rstd = torch.empty(B, C, dtype=F32, device=x.device)
+    rc = _lib.load().rgbd_adain_fwd(_ptr(x), _ptr(scale), _ptr(shift), _ptr(y), _ptr(sums), _ptr(mean), _ptr(rstd),
+                                    B, H * W, C, float(eps), _stream())
+    _lib.check(rc, "rgbd_adain_fwd")
+    return y, mean, rstd
+
+
+def adain_bwd(x, dy, scale, mean, rstd):
+    _chk(x, BF16, "x"); _chk(dy, BF16, "dy"); _chk(scale, F32, "scale")
+    B, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    dscale = torch.empty(B, C, dtype=F32, device=x.device)
+    dshift = torch.empty(B, C, dtype=F32, device=x.device)
+    sums = torch.empty(B, C, 2, dtype=F32, device=x.device)
+    rc = _lib.load().rgbd_adain_bwd(_ptr(x), _ptr(dy), _ptr(scale), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dscale),
+                                    _ptr(dshift), _ptr(sums), B, H * W, C, _stream())
+    _lib.check(rc, "rgbd_adain_bwd")
+    return dx, dscale, dshift
+
+
+# ------------------------------------------------------------------ optimizer
+def adam_clip_multi(p, g, m, v, seg_begin, seg_alpha_t, beta1, beta2, eps, clip, grad_scale, workspace, norm_out=None):
+    for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v"), (workspace, "workspace")):
+        _chk(t, F32, n)
+    n = p.numel()
+    nseg = len(seg_alpha_t)
+    sb = (ctypes.c_int64 * (nseg + 1))(*[int(s) for s in seg_begin])
+    sa = (ctypes.c_float * nseg)(*[float(a) for a in seg_alpha_t])
+    rc = _lib.load().rgbd_adam_clip_multi(_ptr(p), _ptr(g), _ptr(m), _ptr(v), n, nseg, sb, sa, float(beta1),
+                                          float(beta2), float(eps), float(clip), float(grad_scale), _ptr(workspace),
+                                          _ptr(norm_out), _stream())
+    _lib.check(rc, "rgbd_adam_clip_multi")

@@ -1,0 +1,221 @@
+"""Parity of every HIP kernel (called through the C ABI) against the CPU oracle.  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import camera, nets, step, warp_loss
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+# ------------------------------------------------------------------------------------------------ warp loss
+def _warp_case(b, S, seed, pose_scale=0.3):
+    rng = np.random.RandomState(seed)
+    img = rng.uniform(-1, 1, (b, 4, S, S)).astype("float32")
+    img_rot = rng.uniform(-1, 1, (b, 4, S, S)).astype("float32")
+    img[:, 3] = rng.uniform(0.7, 1.3, (b, S, S))
+    img_rot[:, 3] = rng.uniform(0.7, 1.3, (b, S, S))
+    th = rng.uniform(-pose_scale, pose_scale, (2 * b, 6)).astype("float32")
+    th[:, 2] = 0
+    th[:, 3:] *= 0.1
+    cams = camera.camera_matrices(th)
+    return img, img_rot, cams[:b], cams[b:]
+
+
+def _coef(cam, cam_rot, S):
+    K, inv_K, _ = warp_loss.intrinsics(S)
+    R, t = warp_loss.relative_pose(cam, cam_rot)
+    A, c, A2, c2 = warp_loss.warp_coefficients(K, inv_K, R, t)
+    b = len(cam)
+    return np.concatenate([A.reshape(b, 9), c, A2.reshape(b, 9), c2], axis=1).astype("float32")
+
+
+@pytest.mark.parametrize("b,S,occ", [(3, 16, False), (3, 16, True), (2, 32, True), (16, 128, True)])
+def test_warp_loss_forward_bit_exact_indices(b, S, occ):
+    from rgbd_gan_amd import kernels
+    img, img_rot, cam, cam_rot = _warp_case(b, S, seed=10 + S)
+    ref = warp_loss.forward_np(img, cam, img_rot, cam_rot, occlusion_aware=occ, lambda_geometric=2.0)
+    coef = torch.from_numpy(_coef(cam, cam_rot, S)).to(dev())
+    loss, zp, warped, idx = kernels.warp_loss_fwd(torch.from_numpy(img).to(dev()), torch.from_numpy(img_rot).to(dev()),
+                                                  coef, 1 if occ else 0, 2.0, debug=True)
+    idx = idx.cpu().numpy()
+    zp = zp.cpu().numpy()
+    warped = warped.cpu().numpy()
+    # integer outputs: exact
+    np.testing.assert_array_equal(idx[0, :, 0], ref["u0"])
+    np.testing.assert_array_equal(idx[0, :, 1], ref["v0"])
+    np.testing.assert_array_equal(idx[0, :, 2], ref["v1"])
+    np.testing.assert_array_equal(idx[0, :, 3].astype(bool), ref["mask"])
+    np.testing.assert_array_equal(idx[1, :, 0], ref["u0_rot"])
+    np.testing.assert_array_equal(idx[1, :, 1], ref["v0_rot"])
+    np.testing.assert_array_equal(idx[1, :, 3].astype(bool), ref["mask_rot"])
+    # fp32 intermediates: bit-exact (same unfused evaluation order)
+    np.testing.assert_array_equal(zp[0].view(np.uint32), ref["zp"].view(np.uint32))
+    np.testing.assert_array_equal(zp[1].view(np.uint32), ref["zp_rot"].view(np.uint32))
+    np.testing.assert_array_equal(warped[0].view(np.uint32), ref["warped"].view(np.uint32))
+    np.testing.assert_array_equal(warped[1].view(np.uint32), ref["warped_rot"].view(np.uint32))
+    assert ref["mask"].any() and not ref["mask"].all()
+    # north_star tolerance: warp-consistency loss within 1e-4 of the reference math
+    assert abs(float(loss.item()) - ref["loss"]) < 1e-4 * max(1.0, abs(ref["loss"]))
+
+
+@pytest.mark.parametrize("b,S,occ", [(3, 16, False), (2, 32, True)])
+def test_warp_loss_backward_matches_autograd(b, S, occ):
+    from rgbd_gan_amd import kernels
+    img, img_rot, cam, cam_rot = _warp_case(b, S, seed=20 + S)
+    ti = torch.from_numpy(img).requires_grad_(True)
+    tr = torch.from_numpy(img_rot).requires_grad_(True)
+    loss, _ = warp_loss.loss_torch(ti, cam, tr, cam_rot, occlusion_aware=occ, lambda_geometric=3.0)
+    (loss * 1.7).backward()
+    coef = torch.from_numpy(_coef(cam, cam_rot, S)).to(dev())
+    go = torch.tensor([1.7], dtype=torch.float32, device=dev())
+    gi, gr = kernels.warp_loss_bwd(torch.from_numpy(img).to(dev()), torch.from_numpy(img_rot).to(dev()), coef,
+                                   1 if occ else 0, 3.0, 0.0, 0.0, go)
+    scale = float(ti.grad.abs().max())
+    # tolerance: fp32 with atomics (order-dependent last bits); gradients are O(1/(b*S*S))
+    torch.testing.assert_close(gi.cpu(), ti.grad, atol=2e-5 * scale, rtol=1e-4)
+    torch.testing.assert_close(gr.cpu(), tr.grad, atol=2e-5 * scale, rtol=1e-4)
+
+
+def test_warp_loss_zero_for_identical_views_full_size():
+    from rgbd_gan_amd import kernels
+    S, b = 128, 16
+    rng = np.random.RandomState(0)
+    img = rng.uniform(-1, 1, (b, 4, S, S)).astype("float32")
+    img[:, 3] = 1.0
+    cam = camera.camera_matrices(np.zeros((b, 6), "float32"))
+    coef = torch.from_numpy(_coef(cam, cam, S)).to(dev())
+    t = torch.from_numpy(img).to(dev())
+    loss = kernels.warp_loss_fwd(t, t.clone(), coef, 0, 3.0)
+    assert float(loss.item()) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ conv engine
+CONV_CASES = [
+    # B, H, W, Cin, Cout, K, pad, ups, bias, lrelu_ch, resid
+    (3, 4, 4, 64, 64, 3, 1, False, False, 0, False),      # M = 48 < one tile
+    (2, 8, 8, 64, 128, 3, 1, False, True, 128, False),
+    (2, 8, 8, 128, 64, 3, 1, True, True, 64, False),      # fused nearest-2x upsample -> 16x16
+    (2, 16, 16, 64, 256, 3, 1, False, True, 128, False),  # c0 || c_sc style: lrelu on the first half only
+    (2, 16, 16, 128, 128, 3, 1, False, True, 0, True),    # residual add
+    (1, 32, 32, 64, 64, 1, 0, False, True, 64, False),    # 1x1
+    (4, 1, 1, 256, 256, 4, 3, False, False, 0, False),    # "full" conv: dgrad of the 4x4 valid conv
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fprop_matches_oracle(case):
+    from rgbd_gan_amd import kernels
+    B, H, W, Cin, Cout, K, pad, ups, use_bias, lrelu_ch, use_res = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = bf16_round(torch.randn(B, Cin, H, W, generator=g))
+    w = torch.randn(Cout, Cin, K, K, generator=g)
+    scale = float(np.sqrt(2.0 / (Cin * K * K)))
+    bias = torch.randn(Cout, generator=g) if use_bias else None
+    wq = bf16_round(w * scale)
+    xin = nets.up2(x) if ups else x
+    ref = F.conv2d(xin, wq, bias, padding=pad)
+    if lrelu_ch:
+        ref = torch.cat([F.leaky_relu(ref[:, :lrelu_ch], 0.2), ref[:, lrelu_ch:]], 1)
+    res = None
+    if use_res:
+        res = bf16_round(torch.randn(ref.shape, generator=g))
+        ref = ref + res
+    wf, _ = kernels.pack_weights(w.to(dev()), scale, True, False)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev()).to(torch.bfloat16)
+    rd = res.permute(0, 2, 3, 1).contiguous().to(dev()).to(torch.bfloat16) if use_res else None
+    y = kernels.conv2d_fprop(xd, wf, K, K, pad, bias=bias.to(dev()) if use_bias else None, residual=rd,
+                             upsample=ups, lrelu_channels=lrelu_ch)
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    # tolerance: output is rounded to bf16 (2^-9 relative) on top of fp32 accumulation-order noise
+    torch.testing.assert_close(got, ref, atol=2e-2, rtol=1e-2)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,K,pad", [(2, 8, 8, 64, 128, 3, 1), (2, 16, 16, 128, 64, 3, 1),
+                                                    (3, 4, 4, 64, 64, 1, 0)])
+def test_conv_dgrad_matches_autograd(B, H, W, Cin, Cout, K, pad):
+    from rgbd_gan_amd import kernels
+    g = torch.Generator().manual_seed(7)
+    scale = float(np.sqrt(2.0 / (Cin * K * K)))
+    w = torch.randn(Cout, Cin, K, K, generator=g)
+    wq = bf16_round(w * scale)
+    x = torch.randn(B, Cin, H, W, generator=g, requires_grad=True)
+    dy = bf16_round(torch.randn(B, Cout, H, W, generator=g))
+    F.conv2d(x, wq, None, padding=pad).backward(dy)
+    _, wd = kernels.pack_weights(w.to(dev()), scale, False, True)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(dev()).to(torch.bfloat16)
+    dx = kernels.conv2d_fprop(dyd, wd, K, K, K - 1 - pad)
+    torch.testing.assert_close(dx.float().cpu().permute(0, 3, 1, 2), x.grad, atol=2e-2, rtol=1e-2)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,K", [(2, 4, 4, 64, 64, 3), (3, 8, 8, 64, 128, 3), (2, 16, 16, 128, 64, 3),
+                                               (2, 32, 32, 64, 64, 3), (1, 64, 64, 64, 64, 3), (2, 16, 16, 64, 64, 1)])
+def test_conv_wgrad_matches_autograd(B, H, W, Cin, Cout, K):
+    from rgbd_gan_amd import kernels
+    g = torch.Generator().manual_seed(11)
+    x = bf16_round(torch.randn(B, Cin, H, W, generator=g))
+    dy = bf16_round(torch.randn(B, Cout, H, W, generator=g))
+    w = torch.zeros(Cout, Cin, K, K, requires_grad=True)
+    F.conv2d(x, w, None, padding=(K - 1) // 2).backward(dy)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev()).to(torch.bfloat16)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(dev()).to(torch.bfloat16)
+    dw = kernels.conv2d_wgrad(xd, dyd, K, 0.5)
+    ref = w.grad * 0.5
+    tol = 1e-3 * float(ref.abs().max())   # fp32 accumulate of exact bf16 products; only summation order differs
+    torch.testing.assert_close(dw.cpu(), ref, atol=tol, rtol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ AdaIN
+@pytest.mark.parametrize("B,H,C", [(2, 4, 64), (3, 16, 128), (2, 64, 64)])
+def test_adain_forward_backward(B, H, C):
+    from rgbd_gan_amd import kernels
+    g = torch.Generator().manual_seed(3)
+    x = bf16_round(torch.randn(B, C, H, H, generator=g) * 1.5 + 0.3).requires_grad_(True)
+    s = (torch.randn(B, C, generator=g) + 1).requires_grad_(True)
+    t = torch.randn(B, C, generator=g).requires_grad_(True)
+    dy = bf16_round(torch.randn(B, C, H, H, generator=g))
+    y = nets.adain(x, s, t)
+    y.backward(dy)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(dev()).to(torch.bfloat16)
+    yd, mean, rstd = kernels.adain_fwd(xd, s.detach().to(dev()), t.detach().to(dev()))
+    torch.testing.assert_close(yd.float().cpu().permute(0, 3, 1, 2), y.detach(), atol=3e-2, rtol=1e-2)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(dev()).to(torch.bfloat16)
+    dx, ds, dt = kernels.adain_bwd(xd, dyd, s.detach().to(dev()), mean, rstd)
+    torch.testing.assert_close(dx.float().cpu().permute(0, 3, 1, 2), x.grad, atol=3e-2, rtol=2e-2)
+    torch.testing.assert_close(ds.cpu(), s.grad, atol=1e-3 * H * H, rtol=1e-3)
+    torch.testing.assert_close(dt.cpu(), t.grad, atol=1e-3 * H * H, rtol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------ Adam + clip
+@pytest.mark.parametrize("gnorm_scale", [0.01, 30.0])
+def test_adam_clip_matches_chainer_restatement(gnorm_scale):
+    from rgbd_gan_amd import kernels
+    g = torch.Generator().manual_seed(5)
+    n1, n2 = 1000, 333
+    p = torch.randn(n1 + n2, generator=g)
+    params = {"a": p[:n1].clone().requires_grad_(True), "b": p[n1:].clone().requires_grad_(True)}
+    opt = step.ChainerAdam(params, alpha=1e-3, beta1=0.0, beta2=0.999, alpha_override={"b": 1e-5})
+    pd = p.clone().to(dev())
+    md, vd = torch.zeros_like(pd), torch.zeros_like(pd)
+    ws = torch.empty(1024 + 8, device=dev())
+    norm = torch.empty(1, device=dev())
+    for t in range(1, 4):
+        grads = torch.randn(n1 + n2, generator=g) * gnorm_scale
+        params["a"].grad = grads[:n1].clone()
+        params["b"].grad = grads[n1:].clone()
+        ref_norm = opt.update()
+        fix2 = 1.0 - 0.999 ** t
+        kernels.adam_clip_multi(pd, (grads * 2.0).to(dev()), md, vd, [0, n1, n1 + n2],
+                                [1e-3 * np.sqrt(fix2), 1e-5 * np.sqrt(fix2)], 0.0, 0.999, 1e-8, 5.0, 0.5, ws, norm)
+        assert abs(float(norm.item()) - ref_norm) < 1e-4 * ref_norm
+        ref = torch.cat([params["a"].detach(), params["b"].detach()])
+        torch.testing.assert_close(pd.cpu(), ref, atol=1e-6, rtol=1e-5)
