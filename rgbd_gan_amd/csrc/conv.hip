@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(ConvArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue: bias -> leaky ReLU (first lrelu_ch channels) -> residual -> bf16 NHWC
+    // ---- epilogue: bias -> residual -> leaky ReLU (first lrelu_ch channels) -> bf16 NHWC
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int co = n0 + wave_co + i * 16 + 4 * q;
@@ -165,16 +165,16 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(ConvArgs a) {
             if (m < a.M) {
                 float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float t = acc[i][j][r] + bv[r];
-                    if (act) t = t > 0.f ? t : t * a.slope;
-                    v[r] = t;
-                }
+                for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[r];
                 const long o = m * a.Cout + co;
                 if (a.resid) {
                     const u32x2 rr = *reinterpret_cast<const u32x2*>(a.resid + o);
                     v[0] += bf16_lo(rr[0]); v[1] += bf16_hi(rr[0]);
                     v[2] += bf16_lo(rr[1]); v[3] += bf16_hi(rr[1]);
+                }
+                if (act) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : v[r] * a.slope;
                 }
                 u32x2 out = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
                 *reinterpret_cast<u32x2*>(a.y + o) = out;

@@ -1,0 +1,421 @@
+"""Generator / discriminator with the reference's public surface (net.py of nogu-atsu/RGBD-GAN), built on
+the HIP conv engine.
+
+Drop-in surface kept:
+    StyleGANGenerator(ch, enable_blur, rgbd, rotate_conv_input, use_encoder, use_occupancy_net, initial_depth)
+        .mapping, .gen, .make_hidden(n), __call__(z, stage, theta=None, return_feature=False)    net.py:314-354
+    DCGANGenerator(in_ch, ch, ...)   same call                                                    net.py:651-773
+    Discriminator(ch, out_dim, enable_blur, sn, res)  __call__(x, stage, return_hidden=False), .sn  net.py:429-504
+Inputs / outputs at this surface are NCHW fp32 device tensors like the reference's arrays; inside, activations
+are NHWC bf16 and every 3x3 convolution runs in rgbd_gan_amd/csrc/conv.hip.  Parameters carry the reference's
+Chainer names (``namedparams``) so its snapshots load unchanged.
+
+Not supported (unreachable with the shipped configs, asserted): enable_blur, sn, use_encoder (bigan),
+use_occupancy_net, rotate_conv_input.
+"""
+import contextlib
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import functional as Fn
+from .params import ParamStore, depth_row_init
+
+SQRT2 = float(np.sqrt(2))
+BF16 = torch.bfloat16
+
+
+def _inv_c(fan_in, gain=SQRT2):
+    return float(gain * np.sqrt(1.0 / fan_in))
+
+
+def _split_stage(stage, max_stage):
+    stage = min(stage, max_stage - 1e-8)
+    fl = math.floor(stage)
+    return fl, stage - fl
+
+
+def _as_device_tensor(a, device, dtype=torch.float32):
+    if torch.is_tensor(a):
+        return a.to(device=device, dtype=dtype)
+    return torch.as_tensor(np.asarray(a), dtype=dtype).to(device)
+
+
+class _Link:
+    """Minimal stand-in for chainer.Link: named parameters over one or more ParamStores."""
+
+    stores = ()
+
+    def namedparams(self):
+        for prefix, store in self.stores:
+            for name in store.names:
+                yield "/" + prefix + name, store.params[name]
+
+    def params(self):
+        for _, p in self.namedparams():
+            yield p
+
+    def cleargrads(self):
+        for _, store in self.stores:
+            store.zero_grad()
+
+    def state_dict(self):
+        out = {}
+        for prefix, store in self.stores:
+            for k, v in store.state_dict().items():
+                out[prefix + k] = v
+        return out
+
+    def load_state_dict(self, arrays, strict=True):
+        for prefix, store in self.stores:
+            sub = {k[len(prefix):]: v for k, v in arrays.items() if k.startswith(prefix)}
+            store.load(sub, strict=strict)
+
+    def to_gpu(self, device=None):
+        return self
+
+    @contextlib.contextmanager
+    def frozen(self):
+        """Run a forward whose backward must not produce weight gradients (D inside the generator step)."""
+        ps = list(self.params())
+        for p in ps:
+            p.requires_grad_(False)
+        try:
+            yield self
+        finally:
+            for p in ps:
+                p.requires_grad_(True)
+
+
+# ---------------------------------------------------------------------------------------------- StyleGAN
+class MappingNetwork(_Link):
+    """net.py:22-62: pixel-norm then 8 x (equalized linear, leaky ReLU).  Tiny GEMMs (M=B, N=K=ch): fp32 library
+    matmul; launch-latency bound, not a roofline kernel."""
+
+    def __init__(self, ch, device, seed=0):
+        self.ch = ch
+        specs = []
+        for i in range(0, 16, 2):
+            specs += [(f"l/{i}/c/W", (ch, ch), "normal"), (f"l/{i}/c/b", (ch,), "zeros")]
+        self.store = ParamStore(specs, device, seed)
+        self.stores = (("", self.store),)
+        self.inv_c = _inv_c(ch)
+
+    def __call__(self, z):
+        h = z.reshape(z.shape[0], -1)
+        h = h * torch.rsqrt(torch.mean(h * h, dim=1, keepdim=True) + 1e-8)
+        p = self.store.params
+        for i in range(0, 16, 2):
+            h = Fn.lrelu(F.linear(h * self.inv_c, p[f"l/{i}/c/W"], p[f"l/{i}/c/b"]))
+        return h
+
+    forward = __call__
+
+
+class StyleGenerator(_Link):
+    """net.py:164-311.  Channel plan at ch: blocks (ch,ch,ch,ch,ch/2,ch/4) at 4..128 px."""
+
+    def __init__(self, ch, device, rgbd=True, initial_depth=1.0, seed=1):
+        self.ch, self.rgbd, self.max_stage = ch, rgbd, 17
+        self.chans = [(ch, ch), (ch, ch), (ch, ch), (ch, ch), (ch // 2, ch), (ch // 4, ch // 2)]  # (out, in)
+        out_ch = 4 if rgbd else 3
+        w_init, b_init = depth_row_init(initial_depth, out_ch, rgbd)
+        specs = []
+        for i, (co, ci) in enumerate(self.chans):
+            pre = f"blocks/{i}"
+            if i == 0:
+                specs.append((pre + "/W", (ci, 4, 4), "ones"))
+            specs += [(pre + "/b0/b", (co,), "zeros"), (pre + "/b1/b", (co,), "zeros"),
+                      (pre + "/n0/b/W", (co,), "zeros"), (pre + "/n1/b/W", (co,), "zeros")]
+            for s in ("s0", "s1"):
+                specs += [(f"{pre}/{s}/s/c/W", (co, ch), "normal"), (f"{pre}/{s}/s/c/b", (co,), "ones"),
+                          (f"{pre}/{s}/b/c/W", (co, ch), "normal"), (f"{pre}/{s}/b/c/b", (co,), "zeros")]
+            specs += [(pre + "/c0/c/W", (co, ci, 3, 3), "normal"), (pre + "/c1/c/W", (co, co, 3, 3), "normal")]
+        for i, (co, _) in enumerate(self.chans):
+            specs += [(f"outs/{i}/c/W", (out_ch, co, 1, 1), w_init), (f"outs/{i}/c/b", (out_ch,), b_init)]
+        if rgbd:
+            specs += [("l1/c/W", (ch, ch + 9), "normal"), ("l1/c/b", (ch,), "zeros"),
+                      ("l2/c/W", (ch, ch), "normal"), ("l2/c/b", (ch,), "zeros")]
+        self.store = ParamStore(specs, device, seed)
+        self.stores = (("", self.store),)
+        p = self.store.params
+        self.c0 = [None] + [Fn.ConvLayer(p[f"blocks/{i}/c0/c/W"], _inv_c(self.chans[i][1] * 9), 1)
+                            for i in range(1, 6)]
+        self.c1 = [Fn.ConvLayer(p[f"blocks/{i}/c1/c/W"], _inv_c(self.chans[i][0] * 9), 1) for i in range(6)]
+
+    # -- pieces
+    def _style(self, name, w, h):
+        """net.py:90-102 (StyleBlock): AdaIN(h, s(w), b(w)); both linears gain 1."""
+        p = self.store.params
+        c = _inv_c(self.ch, 1.0)
+        scale = F.linear(w * c, p[name + "/s/c/W"], p[name + "/s/c/b"])
+        shift = F.linear(w * c, p[name + "/b/c/W"], p[name + "/b/c/b"])
+        return Fn.adain(h, scale, shift)
+
+    def _block(self, i, w, x):
+        """net.py:130-161 (SynthesisBlock.forward), add_noise False (forced at net.py:243)."""
+        p = self.store.params
+        pre = f"blocks/{i}"
+        if i == 0:
+            const = p[pre + "/W"].permute(1, 2, 0).unsqueeze(0)                  # (1,4,4,ch)
+            h = Fn.lrelu(const + p[pre + "/b0/b"]).to(BF16).expand(w.shape[0], 4, 4, self.chans[0][1])
+            h = h.contiguous()
+        else:
+            h = Fn.conv_bias_lrelu(x, self.c0[i], p[pre + "/b0/b"], upsample=True)
+        h = self._style(pre + "/s0", w, h)
+        h = Fn.conv_bias_lrelu(h, self.c1[i], p[pre + "/b1/b"])
+        h = self._style(pre + "/s1", w, h)
+        return h
+
+    def rotate_w(self, w, theta):
+        """net.py:220-224."""
+        p = self.store.params
+        h = torch.cat([w, theta * 16], dim=1)
+        h = Fn.lrelu(F.linear(h * _inv_c(self.ch + 9), p["l1/c/W"], p["l1/c/b"]))
+        return Fn.lrelu(F.linear(h * _inv_c(self.ch), p["l2/c/W"], p["l2/c/b"]))
+
+    def _to_rgbd(self, i, h):
+        """outs[i]: 1x1 conv (gain 1) from NHWC bf16 to NCHW fp32; fp32 accumulate (bandwidth-bound, Cout=4)."""
+        p = self.store.params
+        W = p[f"outs/{i}/c/W"]
+        y = F.linear(h.float() * _inv_c(W.shape[1], 1.0), W.reshape(W.shape[0], W.shape[1]), p[f"outs/{i}/c/b"])
+        return y.permute(0, 3, 1, 2)
+
+    def __call__(self, w, w2, stage, theta=None, add_noise=True, return_feature=False):
+        st, alpha = _split_stage(stage, self.max_stage)
+        if self.rgbd and theta is None:
+            raise AssertionError("theta is None")
+        feat = None
+        h = None
+
+        def run(i, w_cur, h):
+            return self._block(i, self.rotate_w(w_cur, theta) if (self.rgbd and i < 2) else w_cur, h)
+
+        if st % 2 == 0:
+            k = (st - 2) // 2
+            for i in range(0, k + 2):
+                if i == 3:
+                    w = w2
+                h = run(i, w, h)
+                if return_feature and i == 3:
+                    feat = h
+            out = self._to_rgbd(k + 1, h)
+        else:
+            k = (st - 1) // 2
+            for i in range(0, k + 1):
+                if i == 3:
+                    w = w2
+                h = run(i, w, h)
+                if return_feature and i == 3:
+                    feat = h
+            lo = self._to_rgbd(k, h)
+            lo = lo.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+            hi = self._to_rgbd(k + 1, self._block(k + 1, w, h))      # net.py:290: un-rotated w
+            out = (1.0 - alpha) * lo + alpha * hi
+        if self.rgbd:
+            depth = 1.0 / (F.softplus(out[:, 3:]) + 1e-4)            # net.py:296
+            out = torch.cat([out[:, :3], depth], dim=1)
+        out = out.contiguous()
+        if return_feature:
+            return out, (feat.permute(0, 3, 1, 2).float() if feat is not None else None)
+        return out
+
+    forward = __call__
+
+
+class StyleGANGenerator(_Link):
+    def __init__(self, ch, enable_blur=False, rgbd=False, rotate_conv_input=False, use_encoder=False,
+                 use_occupancy_net=False, initial_depth=None, device="cuda:0", seed=0):
+        assert not enable_blur, "enable_blur is not supported (False in every shipped config)"
+        assert not rotate_conv_input and not use_encoder and not use_occupancy_net, "unsupported generator option"
+        assert ch % 256 == 0, "the MFMA conv engine needs ch/4 to be a multiple of 64"
+        self.ch = ch
+        self.device = torch.device(device)
+        self.mapping = MappingNetwork(ch, device, seed)
+        self.gen = StyleGenerator(ch, device, rgbd, 1.0 if initial_depth is None else initial_depth, seed + 1)
+        self.stores = (("mapping/", self.mapping.store), ("gen/", self.gen.store))
+        self.train = True
+
+    def make_hidden(self, batch_size):
+        """net.py:333-343; drawn on the device (the reference draws with cupy when on GPU)."""
+        z = torch.randn(batch_size, self.ch * 2, 1, 1, device=self.device)
+        return z / torch.sqrt(torch.sum(z * z, dim=1, keepdim=True) / self.ch + 1e-8)
+
+    def __call__(self, z, stage, theta=None, return_feature=False):
+        z = _as_device_tensor(z, self.device).reshape(-1, 2 * self.ch)
+        theta = _as_device_tensor(theta, self.device) if theta is not None else None
+        w = self.mapping(z[:, :self.ch])
+        w2 = self.mapping(z[:, self.ch:])
+        out = self.gen(w, w2=w2, stage=stage, theta=theta, return_feature=return_feature)
+        if not self.train and not return_feature and out.shape[2] < 64:     # net.py:305-309 (eval-mode upsample)
+            scale = 64 // out.shape[2]
+            out = out.repeat_interleave(scale, dim=2).repeat_interleave(scale, dim=3)
+        return out
+
+    forward = __call__
+
+
+# ---------------------------------------------------------------------------------------------- DCGAN (PGGAN)
+class DCGANGenerator(_Link):
+    """net.py:603-773."""
+
+    def __init__(self, in_ch=128, ch=512, enable_blur=False, rgbd=False, use_encoder=False, use_occupancy_net=False,
+                 initial_depth=None, device="cuda:0", seed=0):
+        assert not enable_blur and not use_encoder and not use_occupancy_net, "unsupported generator option"
+        assert ch % 256 == 0
+        self.in_ch, self.ch, self.rgbd, self.max_stage = in_ch, ch, rgbd, 17
+        self.device = torch.device(device)
+        self.chans = [(ch, ch), (ch, ch), (ch, ch), (ch // 2, ch), (ch // 4, ch // 2)]
+        out_ch = 4 if rgbd else 3
+        w_init, b_init = depth_row_init(1.0 if initial_depth is None else initial_depth, out_ch, rgbd)
+        specs = [("linear/c/W", (ch * 16, in_ch + (9 if rgbd else 0)), "normal"), ("linear/c/b", (ch * 16,), "zeros")]
+        for i, (co, ci) in enumerate(self.chans):
+            pre = f"blocks/{i}"
+            specs += [(pre + "/b0/b", (co,), "zeros"), (pre + "/b1/b", (co,), "zeros"),
+                      (pre + "/n0/b/W", (co,), "zeros"), (pre + "/n1/b/W", (co,), "zeros"),
+                      (pre + "/c0/c/W", (co, ci, 3, 3), "normal"), (pre + "/c1/c/W", (co, co, 3, 3), "normal")]
+        for i, (co, _) in enumerate(self.chans):
+            specs += [(f"outs/{i}/c/W", (out_ch, co, 1, 1), w_init), (f"outs/{i}/c/b", (out_ch,), b_init)]
+        self.store = ParamStore(specs, device, seed)
+        self.stores = (("", self.store),)
+        p = self.store.params
+        self.c0 = [Fn.ConvLayer(p[f"blocks/{i}/c0/c/W"], _inv_c(self.chans[i][1] * 9), 1) for i in range(5)]
+        self.c1 = [Fn.ConvLayer(p[f"blocks/{i}/c1/c/W"], _inv_c(self.chans[i][0] * 9), 1) for i in range(5)]
+        self.train = True
+
+    def make_hidden(self, batch_size):
+        z = torch.randn(batch_size, self.in_ch, device=self.device)
+        return z / torch.sqrt(torch.sum(z * z, dim=1, keepdim=True) / self.in_ch + 1e-8)
+
+    @staticmethod
+    def _normalize(h):
+        """chainer F.normalize over channels: x / (||x||_2 + 1e-5); fp32 norm."""
+        f = h.float()
+        return (f / (torch.sqrt((f * f).sum(dim=3, keepdim=True)) + 1e-5)).to(BF16)
+
+    def _block(self, i, x):
+        p = self.store.params
+        pre = f"blocks/{i}"
+        h = self._normalize(Fn.conv_bias_lrelu(x, self.c0[i], p[pre + "/b0/b"], upsample=True))
+        return self._normalize(Fn.conv_bias_lrelu(h, self.c1[i], p[pre + "/b1/b"]))
+
+    def _to_rgbd(self, i, h):
+        p = self.store.params
+        W = p[f"outs/{i}/c/W"]
+        y = F.linear(h.float() * _inv_c(W.shape[1], 1.0), W.reshape(W.shape[0], W.shape[1]), p[f"outs/{i}/c/b"])
+        return y.permute(0, 3, 1, 2)
+
+    def __call__(self, z, stage, theta=None, style_mixing_rate=None, add_noise=True, return_feature=False):
+        z = _as_device_tensor(z, self.device).reshape(-1, self.in_ch)
+        st, alpha = _split_stage(stage, self.max_stage)
+        if self.rgbd:
+            if theta is None:
+                raise AssertionError("theta is None")
+            h = torch.cat([z, _as_device_tensor(theta, self.device) * 10], dim=1)
+        else:
+            h = z
+        p = self.store.params
+        h = F.linear(h * _inv_c(h.shape[1]), p["linear/c/W"], p["linear/c/b"])
+        h = h.reshape(z.shape[0], self.ch, 4, 4).permute(0, 2, 3, 1).contiguous().to(BF16)
+        if st % 2 == 0:
+            k = (st - 2) // 2
+            for i in range(0, k + 1):
+                h = self._block(i, h)
+            out = self._to_rgbd(k, h)
+        else:
+            k = (st - 1) // 2
+            for i in range(0, k):
+                h = self._block(i, h)
+            lo = self._to_rgbd(k - 1, h).repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+            hi = self._to_rgbd(k, self._block(k, h))
+            out = (1.0 - alpha) * lo + alpha * hi
+        if self.rgbd:
+            out = torch.cat([out[:, :3], 1.0 / (F.softplus(out[:, 3:]) + 1e-4)], dim=1)
+        return out.contiguous()
+
+    forward = __call__
+
+
+# ---------------------------------------------------------------------------------------------- discriminator
+class Discriminator(_Link):
+    """net.py:429-504 with res blocks (net.py:380-426) and the 4x4 base block (net.py:357-377)."""
+
+    def __init__(self, ch=512, out_dim=1, enable_blur=False, sn=False, res=False, device="cuda:0", seed=100):
+        assert not enable_blur, "enable_blur is not supported"
+        assert not sn, "spectral normalisation is not supported (sn: False in every shipped config)"
+        assert ch % 256 == 0
+        self.ch, self.sn, self.res, self.max_stage = ch, sn, res, 17
+        self.device = torch.device(device)
+        self.chans = [None, (ch, ch), (ch, ch), (ch, ch), (ch // 2, ch), (ch // 4, ch // 2)]  # (in, out)
+        self.in_chans = [ch, ch, ch, ch, ch // 2, ch // 4]
+        specs = [("blocks/0/c0/c/W", (ch, ch, 3, 3), "normal"), ("blocks/0/c0/c/b", (ch,), "zeros"),
+                 ("blocks/0/c1/c/W", (ch, ch, 4, 4), "normal"), ("blocks/0/c1/c/b", (ch,), "zeros"),
+                 ("blocks/0/l2/c/W", (out_dim, ch), "normal"), ("blocks/0/l2/c/b", (out_dim,), "zeros")]
+        for i in range(1, 6):
+            ci, co = self.chans[i]
+            for nm in (("c0", "c1", "c_sc") if res else ("c0", "c1")):
+                cin = co if nm == "c1" else ci
+                specs += [(f"blocks/{i}/{nm}/c/W", (co, cin, 3, 3), "normal"), (f"blocks/{i}/{nm}/c/b", (co,), "zeros")]
+        for i, co in enumerate(self.in_chans):
+            specs += [(f"ins/{i}/c/W", (co, 3, 1, 1), "normal"), (f"ins/{i}/c/b", (co,), "zeros")]
+        self.store = ParamStore(specs, device, seed)
+        self.stores = (("", self.store),)
+        p = self.store.params
+        self.conv = {}
+        self.conv["blocks/0/c0"] = Fn.ConvLayer(p["blocks/0/c0/c/W"], _inv_c(ch * 9), 1)
+        for i in range(1, 6):
+            ci, co = self.chans[i]
+            for nm in (("c0", "c1", "c_sc") if res else ("c0", "c1")):
+                cin = co if nm == "c1" else ci
+                self.conv[f"blocks/{i}/{nm}"] = Fn.ConvLayer(p[f"blocks/{i}/{nm}/c/W"], _inv_c(cin * 9), 1)
+
+    def _from_rgb(self, i, x):
+        """ins[i]: 1x1 conv 3 -> C on the NCHW fp32 image, + bias, leaky ReLU, to NHWC bf16 (bandwidth-bound)."""
+        p = self.store.params
+        W = p[f"ins/{i}/c/W"]
+        h = F.linear(x.permute(0, 2, 3, 1) * _inv_c(3), W.reshape(W.shape[0], 3), p[f"ins/{i}/c/b"])
+        return Fn.lrelu(h).to(BF16)
+
+    def _block(self, i, x):
+        p = self.store.params
+        pre = f"blocks/{i}"
+        if i == 0:
+            h = Fn.lrelu(Fn.conv(x, self.conv[pre + "/c0"]) + p[pre + "/c0/c/b"].to(BF16))
+            W = p[pre + "/c1/c/W"]                                     # 4x4 valid conv == linear over (h,w,c)
+            Wm = W.permute(0, 2, 3, 1).reshape(W.shape[0], -1)
+            h = F.linear(h.float().reshape(h.shape[0], -1) * _inv_c(W.shape[1] * 16), Wm, p[pre + "/c1/c/b"])
+            h = Fn.lrelu(h)
+            return F.linear(h * _inv_c(self.ch, 1.0), p[pre + "/l2/c/W"], p[pre + "/l2/c/b"])
+        h = Fn.lrelu(Fn.conv(x, self.conv[pre + "/c0"]) + p[pre + "/c0/c/b"].to(BF16))
+        h = Fn.conv(h, self.conv[pre + "/c1"]) + p[pre + "/c1/c/b"].to(BF16)
+        if self.res:
+            h = h + (Fn.conv(x, self.conv[pre + "/c_sc"]) + p[pre + "/c_sc/c/b"].to(BF16))
+        return Fn.avg_pool2_nhwc(Fn.lrelu(h))
+
+    def __call__(self, x, stage, return_hidden=False):
+        x = _as_device_tensor(x, self.device)
+        st, alpha = _split_stage(stage, self.max_stage)
+        feat = None
+        if st % 2 == 0:
+            k = (st - 2) // 2
+            h = self._from_rgb(k + 1, x)
+            for i in reversed(range(0, k + 2)):
+                if i == 3:
+                    feat = h
+                h = self._block(i, h)
+        else:
+            k = (st - 1) // 2
+            h0 = self._from_rgb(k, F.avg_pool2d(x, 2, 2))
+            h1 = self._block(k + 1, self._from_rgb(k + 1, x))
+            h = ((1.0 - alpha) * h0.float() + alpha * h1.float()).to(BF16)
+            for i in reversed(range(0, k + 1)):
+                if i == 3:
+                    feat = h
+                h = self._block(i, h)
+        if return_hidden:
+            return h, (feat.permute(0, 3, 1, 2).float() if feat is not None else None)
+        return h
+
+    forward = __call__

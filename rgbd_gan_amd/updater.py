@@ -1,0 +1,266 @@
+"""The training step: RGBDUpdater with the reference's constructor and properties (updater.py:214-448).
+
+    RGBDUpdater(models=[gen, dis(, smoothed)], config=..., optimizer={'map','gen','dis'}, iterator=...,
+                lambda_gp=..., smoothing=..., total_gpu=..., prior=...)
+    .stage  .iteration  .update()  .update_core()  .observation
+
+One update_core() = one generator step + one discriminator step:
+    G: x_fake = G(z, stage, theta9); adversarial loss through D (weights frozen: no D weight gradients are computed,
+       the reference computes and discards them); 3D-consistency loss between the two views of each latent
+       (HIP warp-loss kernel); depth hinge; backward; Adam(map), Adam(gen).
+    D: D(x_fake.detach()), D(x_real); softplus losses; R1 penalty on reals by double backward through the HIP
+       conv engine; backward; Adam(dis).
+Data-parallel: each optimizer's flat gradient buffer is all-reduced once (RCCL); the map/gen all-reduce is launched
+right after the G backward and overlaps the D step's forward/backward (which only reads x_fake's values).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import functional as Fn
+from .common.loss_functions import LossFuncRotate, loss_func_dcgan_dis, loss_func_dcgan_gen, loss_l2
+
+
+def update_camera_matrices(mat, axis1, axis2, theta):
+    """updater.py:26-42: left-multiply every 4x4 by a rotation of `theta` in the (axis1, axis2) plane."""
+    rot = np.zeros_like(mat)
+    idx = np.arange(4)
+    rot[:, idx, idx] = 1
+    c, s = np.cos(theta), np.sin(theta)
+    rot[:, axis1, axis1] = c
+    rot[:, axis1, axis2] = -s
+    rot[:, axis2, axis1] = s
+    rot[:, axis2, axis2] = c
+    return np.matmul(rot, mat)
+
+
+def get_camera_matries(thetas, order=(0, 1, 2)):
+    """updater.py:45-60 (name kept, typo included): (n,6) [x,y,z rotation, x,y,z translation] -> (n,4,4) float32."""
+    mat = np.zeros((len(thetas), 4, 4), dtype="float32")
+    idx = np.arange(4)
+    mat[:, idx, idx] = [1, 1, -1, 1]
+    mat[:, 2, 3] = 1
+    for i in order:
+        mat = update_camera_matrices(mat, (i + 1) % 3, (i + 2) % 3, thetas[:, i])
+    mat[:, :3, 3] = mat[:, :3, 3] + thetas[:, 3:]
+    return mat
+
+
+class CameraParamPrior:
+    """train_rgbd.py:192-217."""
+
+    def __init__(self, config):
+        self.rotation_range = np.array([config.x_rotate, config.y_rotate, config.z_rotate])
+        self.camera_param_range = np.array([config.x_rotate, config.y_rotate, config.z_rotate,
+                                            config.x_translate, config.y_translate, config.z_translate])
+        self.uniform = config.uniform_distribution
+
+    def sample(self, batch_size):
+        half = batch_size // 2
+        thetas = np.random.uniform(-1, 1, size=(half, 6))
+        eps = np.random.uniform(0, 0.5, size=(half, 6))
+        sign = np.random.choice(2, size=(half, 3)) * 2 - 1
+        limit = np.clip(1 / (self.rotation_range + 1e-8), 0, 1)       # limit the angle difference
+        if self.uniform:
+            eps[:, :3] = eps[:, :3] * sign * limit
+        else:
+            wraps = self.rotation_range == 3.1415
+            eps[:, :3] = eps[:, :3] * (sign * wraps + np.abs(sign) * (self.rotation_range != 3.1415)) * limit
+        thetas2 = -eps * np.sign(thetas) + thetas
+        if self.uniform:
+            thetas2 = thetas2 * (-1 <= thetas2) * (thetas2 <= 1) + (-2 - thetas2) * (thetas2 < -1) + \
+                      (2 - thetas2) * (thetas2 > 1)
+        thetas = np.concatenate([thetas, thetas2], axis=0) * self.camera_param_range[None]
+        return thetas.astype("float32")
+
+
+def downsize_real(x_real, stage, max_stage=17):
+    """common/utils/pggan.py:6-50 on a device tensor (NCHW fp32)."""
+    import math
+    size = x_real.shape[2]
+    assert x_real.shape[2] == x_real.shape[3]
+    stage = min(stage, max_stage - 1e-8)
+    alpha = stage - math.floor(stage)
+    stage = math.floor(stage)
+    if stage % 2 == 0:
+        k = (stage - 2) // 2
+        image_size = 4 * (2 ** (k + 1))
+        assert image_size <= size
+        scale = size // image_size
+        return F.avg_pool2d(x_real, scale, scale) if scale > 1 else x_real
+    k = (stage - 1) // 2
+    lo, hi = 4 * (2 ** k), 4 * (2 ** (k + 1))
+    assert hi <= size
+    s_lo, s_hi = size // lo, size // hi
+    r_lo, r_hi = x_real, x_real
+    if s_lo > 1:
+        r_lo = F.avg_pool2d(x_real, s_lo, s_lo).repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+    if s_hi > 1:
+        r_hi = F.avg_pool2d(x_real, s_hi, s_hi)
+    return (1 - alpha) * r_lo + alpha * r_hi
+
+
+class RGBDUpdater:
+    def __init__(self, models, config, **kwargs):
+        if len(models) == 2:
+            models = list(models) + [None]
+        if config.bigan:
+            raise AssertionError("bigan is not supported")
+        self.gen, self.dis, self.smoothed_gen = models
+        self.config = config
+        self.smoothing = kwargs.pop("smoothing")
+        self.lambda_gp = kwargs.pop("lambda_gp")
+        self.total_gpu = kwargs.pop("total_gpu")
+        self.prior = kwargs.pop("prior")
+        self._optimizers = kwargs.pop("optimizer")
+        self._iterators = {"main": kwargs.pop("iterator")}
+        lambda_geometric = config.lambda_geometric if config.lambda_geometric else 3
+        self.loss_func_rotate = LossFuncRotate(torch, lambda_geometric=lambda_geometric)
+        self.stage_interval = list(map(int, str(config.stage_interval).split(",")))
+        self.camera_param_range = np.array([config.x_rotate, config.y_rotate, config.z_rotate,
+                                            config.x_translate, config.y_translate, config.z_translate])
+        self.iteration = 0
+        self.observation = {}
+        # the reference asserts not-NaN (a host sync) three times per step (updater.py:336,360,439); here the losses
+        # stay on the device and are checked every `nan_check_interval` iterations (1 = the reference's behaviour)
+        self.nan_check_interval = int(kwargs.pop("nan_check_interval", 100))
+        self.fixed_stage = kwargs.pop("fixed_stage", None)   # bench / tests: pin the stage
+        self.device = self.gen.device
+
+    # ---- chainer StandardUpdater surface
+    def get_optimizer(self, name):
+        return self._optimizers[name]
+
+    def get_iterator(self, name):
+        return self._iterators[name]
+
+    @property
+    def stage(self):
+        return self.get_stage()
+
+    def get_stage(self):
+        """updater.py:252-256."""
+        if self.fixed_stage is not None:
+            return self.fixed_stage
+        for i, interval in enumerate(self.stage_interval):
+            if self.iteration + 1 <= interval:
+                prev = self.stage_interval[i - 1]
+                return i - 1 + (self.iteration - prev) / (interval - prev)
+        return self.config.max_stage - 1e-8
+
+    def get_x_real_data(self, batch, batch_size):
+        """updater.py:259-268; device tensors pass straight through (no host round trip)."""
+        if torch.is_tensor(batch):
+            return batch.to(self.device, torch.float32)
+        rows = []
+        for i in range(batch_size):
+            inst = batch[i]
+            if isinstance(inst, tuple):
+                inst = inst[0]
+            rows.append(np.asarray(inst).astype("f"))
+        return torch.from_numpy(np.stack(rows)).to(self.device)
+
+    def get_z_fake_data(self, batch_size):
+        return self.gen.make_hidden(batch_size)
+
+    def update(self):
+        self.update_core()
+        self.iteration += 1
+
+    def _check_finite(self):
+        for key in ("gen/loss_adv", "gen/loss_rotate", "dis/loss_adv"):
+            v = self.observation.get(key)
+            if v is not None and not bool(torch.isfinite(v)):
+                raise AssertionError(f"{key} is not finite at iteration {self.iteration}")
+
+    # ---- the step
+    def update_core(self, batch=None, z_fake_data=None, thetas=None):
+        """Optional arguments let tests and the benchmark inject fixed inputs; by default they are drawn exactly as
+        the reference draws them (iterator, make_hidden, prior.sample)."""
+        cfg = self.config
+        use_rotate = self.iteration > cfg.start_rotation
+        stylegan = cfg.generator_architecture == "stylegan"
+        opt_g_m = self.get_optimizer("map") if stylegan else None
+        opt_g_g = self.get_optimizer("gen")
+        opt_d = self.get_optimizer("dis")
+        self.gen.cleargrads()
+        self.dis.cleargrads()
+        obs = self.observation
+
+        stage = self.stage
+        if batch is None:
+            batch = self.get_iterator("main").next()
+        batch_size = len(batch)
+        x_real_data = self.get_x_real_data(batch, batch_size)
+        if z_fake_data is None:
+            z_half = self.get_z_fake_data(batch_size // 2)
+            z_fake_data = torch.cat([z_half, z_half], dim=0)               # same latent for both views
+        if thetas is None:
+            thetas = self.prior.sample(batch_size)
+        thetas = np.asarray(thetas, dtype="float32")
+        random_camera_matrices = get_camera_matries(thetas)                 # host, (B,4,4) fp32
+        theta9 = np.concatenate([np.cos(thetas[:, :3]), np.sin(thetas[:, :3]), thetas[:, 3:]], axis=1)
+        theta9 = torch.from_numpy(theta9.astype("float32")).to(self.device)
+
+        with torch.no_grad():
+            x_real = downsize_real(x_real_data, stage).contiguous()
+        image_size = x_real.shape[2]
+        half = batch_size // 2
+
+        # ------------------------------------------------------------ generator step
+        x_fake = self.gen(z_fake_data, stage, theta9)
+        with self.dis.frozen():
+            y_fake, _ = self.dis(x_fake[:, :3], stage=stage, return_hidden=True)
+        loss_gen = loss_func_dcgan_gen(y_fake)
+        obs["gen/loss_adv"] = loss_gen.detach()
+        if use_rotate:
+            loss_rotate, _ = self.loss_func_rotate(x_fake[:half], random_camera_matrices[:half],
+                                                   x_fake[half:], random_camera_matrices[half:],
+                                                   self.iteration >= cfg.start_occlusion_aware)
+            if cfg.rotate_feature:
+                raise AssertionError("rotate_feature is not supported")
+            if cfg.lambda_depth > 0:
+                loss_rotate = loss_rotate + torch.mean(F.relu(cfg.depth_min - x_fake[:, -1]) ** 2) * cfg.lambda_depth
+            obs["gen/loss_rotate"] = loss_rotate.detach()
+            lambda_rotate = cfg.lambda_rotate if cfg.lambda_rotate else 2
+            lambda_rotate = lambda_rotate if image_size <= 128 else lambda_rotate * 2
+            loss_gen = loss_gen + loss_rotate * lambda_rotate
+            if cfg.use_occupancy_net_loss:
+                raise AssertionError("occupancy-net loss is not supported")
+        if cfg.optical_flow:
+            raise AssertionError("optical flow loss is not supported")
+        loss_gen.backward()
+        if opt_g_m is not None:
+            opt_g_m.start_allreduce()
+        opt_g_g.start_allreduce()
+        x_fake_data = x_fake.detach()
+        del loss_gen, x_fake, y_fake
+
+        # ------------------------------------------------------------ discriminator step (overlaps the all-reduce)
+        self.dis.cleargrads()
+        y_fake = self.dis(x_fake_data[:, :3].contiguous(), stage=stage)
+        x_real_v = x_real.detach().requires_grad_(True)
+        y_real = self.dis(x_real_v, stage=stage)
+        loss_dis = loss_func_dcgan_dis(y_fake, y_real)
+        if not self.dis.sn and self.lambda_gp > 0:
+            with Fn.input_grads_only():
+                grad_x, = torch.autograd.grad([y_real.sum()], [x_real_v], create_graph=True)
+            grad_l2 = torch.sqrt(torch.sum(grad_x ** 2, dim=(1, 2, 3)))
+            loss_gp = self.lambda_gp * loss_l2(grad_l2, 0.0)
+            obs["dis/loss_gp"] = loss_gp.detach()
+            loss_dis = loss_dis + loss_gp
+        obs["dis/loss_adv"] = loss_dis.detach()
+        loss_dis.backward()
+        opt_d.start_allreduce()
+
+        # ------------------------------------------------------------ parameter updates
+        if opt_g_m is not None:
+            opt_g_m.update()
+        opt_g_g.update()
+        if self.smoothed_gen is not None:
+            raise AssertionError("keep_smoothed_gen is not supported yet")
+        opt_d.update()
+
+        obs["stage"], obs["batch_size"], obs["image_size"] = stage, batch_size, image_size
+        if self.nan_check_interval > 0 and (self.iteration + 1) % self.nan_check_interval == 0:
+            self._check_finite()

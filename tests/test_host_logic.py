@@ -1,0 +1,87 @@
+"""CPU tests of the host side of the product (no kernels run): schedule, cameras, prior, config, parameter store."""
+import numpy as np
+import torch
+
+from oracle import camera as ocam
+from rgbd_gan_amd import updater as up
+from rgbd_gan_amd.optimizer import FlatAdam
+from rgbd_gan_amd.params import ParamStore
+from rgbd_gan_amd.utils.yaml_utils import Config
+
+
+def _cfg(**kw):
+    base = dict(x_rotate=0.3054, y_rotate=1.0472, z_rotate=0, x_translate=0, y_translate=0, z_translate=0,
+                stage_interval="0,0,0,0,0,0,0,100000, 150000, 160000, 180000, 300000", max_stage=11)
+    base.update(kw)
+    return Config(base)
+
+
+def test_config_missing_keys_read_none():
+    c = _cfg()
+    assert c.rgb is None and c.lambda_rotate is None and c.uniform_distribution is None
+    c.gpu = 3
+    assert c.gpu == 3 and c["gpu"] == 3
+
+
+def test_camera_matrices_match_oracle_bitwise():
+    rng = np.random.RandomState(0)
+    th = rng.uniform(-1, 1, (7, 6)).astype("float32")
+    np.testing.assert_array_equal(up.get_camera_matries(th), ocam.camera_matrices(th))
+
+
+def test_prior_matches_oracle_and_uniform_branch():
+    for uniform, yrot in ((None, 1.0472), (None, 3.1415), (True, 3.1415)):
+        cfg = _cfg(y_rotate=yrot, uniform_distribution=uniform)
+        np.random.seed(4)
+        a = up.CameraParamPrior(cfg).sample(10)
+        np.random.seed(4)
+        b = ocam.PosePrior(cfg.x_rotate, cfg.y_rotate, cfg.z_rotate, uniform=bool(uniform)).sample(10)
+        np.testing.assert_array_equal(a, b)
+        if uniform:   # only the uniform branch reflects the second view back into the range
+            assert np.abs(a[:, 1]).max() <= yrot + 1e-6
+
+
+def test_stage_schedule_matches_oracle():
+    class U(up.RGBDUpdater):
+        def __init__(self, cfg):
+            self.config = cfg
+            self.stage_interval = list(map(int, cfg.stage_interval.split(",")))
+            self.fixed_stage = None
+            self.iteration = 0
+    u = U(_cfg())
+    for it in (0, 1, 49999, 50000, 99999, 100000, 155000, 170000, 180000, 299999, 300000, 10 ** 6):
+        u.iteration = it
+        assert u.stage == ocam.stage_of(it, u.stage_interval, 11)
+
+
+def test_downsize_real_matches_oracle():
+    from oracle import nets
+    x = torch.randn(2, 3, 128, 128)
+    for st in (6.0, 7.3, 8.0, 9.5, 10.0, 10.99999999):
+        torch.testing.assert_close(up.downsize_real(x, st), nets.downsize_real(x, st))
+
+
+def test_param_store_grad_views_accumulate_in_place():
+    store = ParamStore([("a/W", (3, 5), "normal"), ("a/b", (5,), "zeros"), ("c", (2, 2, 3), "ones")], "cpu", seed=1)
+    assert store.numel % 4 == 0
+    loss = (store["a/W"] ** 2).sum() + (store["c"] * 3).sum() + store["a/b"].sum()
+    loss.backward()
+    off = store.offsets["c"]
+    assert torch.equal(store.grad[off:off + 12], torch.full((12,), 3.0))
+    assert store["c"].grad.data_ptr() == store.grad.data_ptr() + 4 * off
+    store.zero_grad()
+    assert float(store.grad.abs().sum()) == 0.0 and float(store["a/W"].grad.abs().sum()) == 0.0
+    sd = store.state_dict()
+    sd["a/b"] = np.arange(5, dtype="float32")
+    store.load(sd)
+    assert float(store.flat[store.offsets["a/b"] + 4]) == 4.0
+
+
+def test_adam_segments_follow_alpha_overrides():
+    store = ParamStore([("l0/W", (8,), "normal"), ("l1/c/W", (8,), "normal"), ("l1/c/b", (4,), "zeros"),
+                        ("l2/W", (8,), "normal")], "cpu")
+    opt = FlatAdam(store, alpha=1e-3)
+    opt.set_alpha("l1/c/W", 1e-5)
+    opt.set_alpha("l1/c/b", 1e-5)
+    begins, alphas = opt._segments()
+    assert begins == [0, 8, 20, 28] and alphas == [1e-3, 1e-5, 1e-3]

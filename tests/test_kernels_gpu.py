@@ -106,7 +106,7 @@ CONV_CASES = [
     (2, 8, 8, 64, 128, 3, 1, False, True, 128, False),
     (2, 8, 8, 128, 64, 3, 1, True, True, 64, False),      # fused nearest-2x upsample -> 16x16
     (2, 16, 16, 64, 256, 3, 1, False, True, 128, False),  # c0 || c_sc style: lrelu on the first half only
-    (2, 16, 16, 128, 128, 3, 1, False, True, 0, True),    # residual add
+    (2, 16, 16, 128, 128, 3, 1, False, True, 128, True),  # residual add, then lrelu
     (1, 32, 32, 64, 64, 1, 0, False, True, 64, False),    # 1x1
     (4, 1, 1, 256, 256, 4, 3, False, False, 0, False),    # "full" conv: dgrad of the 4x4 valid conv
 ]
@@ -124,12 +124,12 @@ def test_conv_fprop_matches_oracle(case):
     wq = bf16_round(w * scale)
     xin = nets.up2(x) if ups else x
     ref = F.conv2d(xin, wq, bias, padding=pad)
-    if lrelu_ch:
-        ref = torch.cat([F.leaky_relu(ref[:, :lrelu_ch], 0.2), ref[:, lrelu_ch:]], 1)
     res = None
     if use_res:
         res = bf16_round(torch.randn(ref.shape, generator=g))
         ref = ref + res
+    if lrelu_ch:
+        ref = torch.cat([F.leaky_relu(ref[:, :lrelu_ch], 0.2), ref[:, lrelu_ch:]], 1)
     wf, _ = kernels.pack_weights(w.to(dev()), scale, True, False)
     xd = x.permute(0, 2, 3, 1).contiguous().to(dev()).to(torch.bfloat16)
     rd = res.permute(0, 2, 3, 1).contiguous().to(dev()).to(torch.bfloat16) if use_res else None

@@ -1,0 +1,172 @@
+"""Model- and step-level parity of the HIP engine against the fp32 CPU oracle (same weights, same inputs).
+
+Tolerances: the engine stores activations and conv operands in bf16 (8 mantissa bits) and accumulates in fp32, the
+oracle is fp32 throughout; through ~12 conv layers a relative L2 error of ~1 % is the expected noise floor, so
+tensors are compared by relative L2 error and gradients additionally by cosine similarity.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import camera, nets, step
+
+pytestmark = pytest.mark.gpu
+
+CH = 256
+
+
+def rel_err(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def cosine(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+def _models(seed=0):
+    from rgbd_gan_amd.net import Discriminator, StyleGANGenerator
+    gp = nets.init_stylegan(CH, seed=seed)
+    dp = nets.init_discriminator(CH, seed=seed + 1)
+    gen = StyleGANGenerator(CH, rgbd=True)
+    dis = Discriminator(CH, res=True)
+    gen.load_state_dict(gp)
+    dis.load_state_dict(dp)
+    return gp, dp, gen, dis
+
+
+def _inputs(B, seed=1):
+    rng = np.random.RandomState(seed)
+    zh = nets.make_hidden(B // 2, CH, rng)
+    z = np.concatenate([zh, zh])
+    np.random.seed(seed + 1)
+    thetas = camera.PosePrior(0.3054, 1.0472, 0).sample(B)
+    x_real = (rng.randint(0, 256, (B, 3, 128, 128)).astype("float32") / 127.5 - 1)
+    return z, thetas, x_real
+
+
+@pytest.mark.parametrize("stage", [10.0, 9.5, 6.0])
+def test_generator_forward_matches_oracle(stage):
+    gp, _, gen, _ = _models()
+    z, thetas, _ = _inputs(4)
+    t9 = camera.theta9(thetas)
+    with torch.no_grad():
+        ref = nets.stylegan_generator(gp, z, stage, t9)
+        got = gen(z, stage, t9).cpu()
+    assert got.shape == ref.shape
+    assert rel_err(got[:, :3], ref[:, :3]) < 4e-2
+    # depth head starts as a constant (W=0): must match tightly
+    torch.testing.assert_close(got[:, 3], ref[:, 3], atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("stage", [10.0, 9.5, 6.0])
+def test_discriminator_forward_and_input_grad_match_oracle(stage):
+    _, dp, _, dis = _models()
+    size = {10.0: 128, 9.5: 128, 6.0: 32}[stage]
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(2, 3, size, size, generator=g) * 2 - 1
+    xr = x.clone().requires_grad_(True)
+    yr = nets.discriminator(dp, xr, stage)
+    yr.sum().backward()
+    xd = x.cuda().requires_grad_(True)
+    yd = dis(xd, stage)
+    yd.sum().backward()
+    scale = float(yr.abs().max())
+    assert float((yd.detach().cpu() - yr.detach()).abs().max()) < 4e-2 * max(scale, 1.0)
+    assert rel_err(xd.grad.cpu(), xr.grad) < 5e-2
+    assert cosine(xd.grad.cpu(), xr.grad) > 0.998
+
+
+def test_r1_double_backward_matches_oracle():
+    _, dp, _, dis = _models()
+    dpl = {k: v.clone().requires_grad_(True) for k, v in dp.items()}
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 3, 128, 128, generator=g) * 2 - 1
+    xr = x.clone().requires_grad_(True)
+    gp_ref = step.r1_penalty(nets.discriminator(dpl, xr, 10.0), xr, 1.0)
+    gp_ref.backward()
+
+    from rgbd_gan_amd import functional as Fn
+    from rgbd_gan_amd.common.loss_functions import loss_l2
+    dis.cleargrads()
+    xd = x.cuda().requires_grad_(True)
+    yd = dis(xd, 10.0)
+    with Fn.input_grads_only():
+        gx, = torch.autograd.grad([yd.sum()], [xd], create_graph=True)
+    gp = loss_l2(torch.sqrt(torch.sum(gx ** 2, dim=(1, 2, 3))), 0.0)
+    gp.backward()
+    assert abs(float(gp) - float(gp_ref)) < 5e-2 * abs(float(gp_ref))
+    checked = 0
+    for name in ("blocks/5/c0/c/W", "blocks/5/c1/c/W", "blocks/5/c_sc/c/W", "blocks/4/c1/c/W", "blocks/2/c0/c/W",
+                 "blocks/0/c0/c/W", "blocks/0/c1/c/W", "ins/5/c/W"):
+        a, b = dis.store[name].grad.cpu(), dpl[name].grad
+        assert cosine(a, b) > 0.99, name
+        assert abs(float(a.norm() / b.norm()) - 1.0) < 5e-2, name
+        checked += 1
+    assert checked == 8
+
+
+CFG = dict(lambda_gp=1.0, lambda_depth=10, depth_min=1.0, lambda_geometric=None, lambda_rotate=None,
+           start_rotation=2000, start_occlusion_aware=2000)
+
+
+def test_full_training_step_matches_oracle():
+    """One update_core (G step + D step + R1 + 3D loss + clipped Adam) at stage 10, B=4, on identical inputs."""
+    from rgbd_gan_amd.optimizer import FlatAdam
+    from rgbd_gan_amd.updater import CameraParamPrior, RGBDUpdater
+    from rgbd_gan_amd.utils.yaml_utils import Config
+    gp, dp, gen, dis = _models(seed=2)
+    z, thetas, x_real = _inputs(4, seed=7)
+    # make the depth channel non-trivial so the warp loss sees geometry
+    for i in range(6):
+        gp[f"gen/outs/{i}/c/W"][-1] = torch.randn(gp[f"gen/outs/{i}/c/W"][-1].shape) * 0.3
+    gen.load_state_dict(gp)
+    iteration = 200000
+
+    # ---- oracle
+    gpl = {k: v.clone().requires_grad_(True) for k, v in gp.items()}
+    dpl = {k: v.clone().requires_grad_(True) for k, v in dp.items()}
+    omap = {k: v for k, v in gpl.items() if k.startswith("mapping/")}
+    ogen = {k: v for k, v in gpl.items() if k.startswith("gen/")}
+    low = {k: 1e-5 for k in ("gen/l1/c/W", "gen/l1/c/b", "gen/l2/c/W", "gen/l2/c/b")}
+    oopt = {"map": step.ChainerAdam(omap, 1e-5), "gen": step.ChainerAdam(ogen, 1e-3, alpha_override=low),
+            "dis": step.ChainerAdam(dpl, 3e-3)}
+    ref = step.rgbd_step(gpl, dpl, oopt, x_real, z, thetas, 10.0, CFG, iteration)
+
+    # ---- engine
+    cfg = Config(dict(generator_architecture="stylegan", stage_interval="0,0,0,0,0,0,0,100000,150000,160000,180000,300000",
+                      max_stage=11, start_rotation=2000, start_occlusion_aware=2000, lambda_depth=10, depth_min=1.0,
+                      x_rotate=0.3054, y_rotate=1.0472, z_rotate=0, x_translate=0, y_translate=0, z_translate=0,
+                      bigan=False))
+    opt = {"map": FlatAdam(gen.mapping.store, 1e-5), "gen": FlatAdam(gen.gen.store, 1e-3),
+           "dis": FlatAdam(dis.store, 3e-3)}
+    for n in ("l1/c/W", "l1/c/b", "l2/c/W", "l2/c/b"):
+        opt["gen"].set_alpha(n, 1e-5)
+    upd = RGBDUpdater(models=[gen, dis], config=cfg, optimizer=opt, iterator=None, lambda_gp=1.0, smoothing=0.999,
+                      total_gpu=1, prior=CameraParamPrior(cfg), fixed_stage=10.0)
+    upd.iteration = iteration
+    upd.update_core(batch=torch.from_numpy(x_real), z_fake_data=torch.from_numpy(z), thetas=thetas)
+    obs = {k: float(v) for k, v in upd.observation.items()}
+
+    for key in ("gen/loss_adv", "gen/loss_rotate", "dis/loss_gp", "dis/loss_adv"):
+        assert abs(obs[key] - ref[key]) < 5e-2 * max(1.0, abs(ref[key])), (key, obs[key], ref[key])
+    # gradients that drove the update (still in the flat buffers)
+    for store, prefix, names in ((gen.gen.store, "gen/", ["blocks/5/c1/c/W", "blocks/5/c0/c/W", "blocks/3/c1/c/W",
+                                                          "blocks/1/s0/s/c/W", "outs/5/c/W", "l2/c/W"]),
+                                 (gen.mapping.store, "mapping/", ["l/14/c/W", "l/0/c/W"]),
+                                 (dis.store, "", ["blocks/5/c0/c/W", "blocks/4/c_sc/c/W", "blocks/1/c1/c/W",
+                                                  "blocks/0/c1/c/W", "ins/5/c/W"])):
+        src = gpl if prefix else dpl
+        for n in names:
+            a, b = store[n].grad.cpu(), src[prefix + n].grad
+            assert cosine(a, b) > 0.97, (prefix + n, cosine(a, b))
+    # pre-clip gradient norms seen by the optimizers
+    for k, o in (("norm_map", opt["map"]), ("norm_gen", opt["gen"]), ("norm_dis", opt["dis"])):
+        assert abs(float(o.grad_norm) - ref[k]) < 8e-2 * ref[k], (k, float(o.grad_norm), ref[k])
+    # Adam moved every live weight by about alpha (beta1 = 0, t = 1): |dp| = alpha * |g| / (|g| + eps')
+    w_new = dis.store["blocks/5/c1/c/W"].detach().cpu()
+    w_ref = dpl["blocks/5/c1/c/W"].detach()
+    assert float((w_new - dp["blocks/5/c1/c/W"]).abs().max()) <= 3e-3 * 1.001
+    agree = float(((w_new - dp["blocks/5/c1/c/W"]).sign() == (w_ref - dp["blocks/5/c1/c/W"]).sign()).float().mean())
+    assert agree > 0.9
