@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""Throughput of the RGBD-GAN training step (G + D + 3D-consistency loss) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--config configs/stylegan_shapenet_car.yml]
+
+A "step" is one RGBDUpdater.update_core(): generator step (forward, D forward with frozen weights, warp loss,
+backward, clipped Adam on mapping + synthesis) and discriminator step (fake + real forward, R1 double backward,
+backward, clipped Adam), on synthetic data already resident in HBM.  One process per GPU; for N > 1 launch with
+torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE from the environment), gradients all-reduced over RCCL.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# algorithmic conv+linear FLOPs per generated image of one step at stage 10, ch=256:
+# 3 F_G + 11 F_D with F_G = 10.45, F_D = 24.11 GFLOP
+STEP_GFLOP_PER_IMAGE = 296.6
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's batchsize, 32)")
+    ap.add_argument("--config", default=os.path.join(ROOT, "configs", "stylegan_shapenet_car.yml"))
+    ap.add_argument("--iteration", type=int, default=200000, help="steady state: stage 10, rotation + occlusion on")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(batch=4):
+    """The CPU restatement of the same step (oracle/step.py; Chainer is unavailable), timed on the host cores on a
+    bounded sample: one update_core at 128x128, ch=256, `batch` images."""
+    import numpy as np
+    import torch
+    from oracle import camera, nets, step
+    torch.set_num_threads(os.cpu_count() or 1)
+    ch = 256
+    gp = {k: v.requires_grad_(True) for k, v in nets.init_stylegan(ch, seed=0).items()}
+    dp = {k: v.requires_grad_(True) for k, v in nets.init_discriminator(ch, seed=1).items()}
+    omap = {k: v for k, v in gp.items() if k.startswith("mapping/")}
+    ogen = {k: v for k, v in gp.items() if k.startswith("gen/")}
+    opt = {"map": step.ChainerAdam(omap, 1e-5), "gen": step.ChainerAdam(ogen, 1e-3), "dis": step.ChainerAdam(dp, 3e-3)}
+    rng = np.random.RandomState(0)
+    zh = nets.make_hidden(batch // 2, ch, rng)
+    z = np.concatenate([zh, zh])
+    np.random.seed(2)
+    thetas = camera.PosePrior(0.3054, 3.1415, 0).sample(batch)
+    x_real = rng.randint(0, 256, (batch, 3, 128, 128)).astype("float32") / 127.5 - 1
+    cfg = dict(lambda_gp=1.0, lambda_depth=10, depth_min=0.6, lambda_geometric=2, lambda_rotate=None,
+               start_rotation=2000, start_occlusion_aware=2000)
+    t0 = time.time()
+    step.rgbd_step(gp, dp, opt, x_real, z, thetas, 10.0, cfg, 200000)
+    dt = time.time() - t0
+    return {"value": batch / dt, "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 update_core, batch {batch}, 128x128, ch=256, fp32 torch-CPU restatement of the reference "
+                      f"path (Chainer unavailable), {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    from rgbd_gan_amd import kernels
+    from rgbd_gan_amd.dist import Communicator
+    from rgbd_gan_amd.training import DeviceImageIterator, build_training
+    from rgbd_gan_amd.utils import yaml_utils
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    comm = Communicator()
+    local = comm.intra_rank if comm.size > 1 else 0
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    config = yaml_utils.load(args.config)
+    B = args.batch or config.batchsize
+    np.random.seed(2 + comm.rank)
+    torch.manual_seed(comm.rank)
+    images = np.random.RandomState(comm.rank).randint(0, 256, (256, 3, 128, 128)).astype("uint8")
+    it = DeviceImageIterator(images, B, device, seed=comm.rank)
+    gen, dis, opt, upd = build_training(config, device, comm if comm.size > 1 else None, iterator=it,
+                                        nan_check_interval=0)
+    upd.iteration = args.iteration
+
+    def sync():
+        torch.cuda.synchronize()
+        comm.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        upd.update()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        upd.update()
+    sync()
+    elapsed = comm.max_over_ranks(time.perf_counter() - t0)
+    upd._check_finite()
+
+    ms = elapsed / args.steps * 1e3
+    value = B * comm.size * args.steps / elapsed
+    line = {
+        "metric": "img/s (G+D+3D-loss step) at 128x128", "value": round(value, 2), "unit": "img/s",
+        "n_gpus": comm.size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"{os.path.basename(args.config)} stage {upd.stage:.2f} (128x128), RGBDUpdater.update_core, "
+                               f"StyleGAN ch={config.ch}, rotation+occlusion loss on, R1 on",
+                   "per_gpu_batch": B, "global_batch": B * comm.size, "parallelism": f"dp{comm.size}"},
+        "step_tflops_algorithmic": round(value * STEP_GFLOP_PER_IMAGE / 1e3, 2),
+        "mfma_roofline_frac_whole_step": round(value * STEP_GFLOP_PER_IMAGE / 1e3 / (MFMA_BF16_PEAK_TFLOPS * comm.size), 4),
+    }
+
+    if comm.rank == 0 and not args.no_roofline:
+        # per-launch HIP-event timing of the conv kernels over extra (untimed) steps, on the launch stream
+        with kernels.launch_profile() as prof:
+            for _ in range(2):
+                upd.update()
+        summ = prof.summary()
+        table = {k: {"launches": n, "ms": round(t * 1e3, 3), "tflops": round(f / t / 1e12, 1),
+                     "avg_us": round(t / n * 1e6, 1), "gbps": round(b / t / 1e9, 1)} for k, (n, t, f, b) in summ.items()}
+        dom = max(summ, key=lambda k: summ[k][1])
+        n, t, f, b = summ[dom]
+        line["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(f / t / 1e12, 2),
+                            "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(f / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                            "traffic": None, "launches": n, "avg_launch_us": round(t / n * 1e6, 2),
+                            "flops_per_launch_avg": f / n}
+        line["kernels"] = table
+    elif comm.size > 1 and not args.no_roofline:
+        for _ in range(2):                      # keep ranks in lock-step with rank 0's extra steps
+            upd.update()
+    if comm.rank == 0 and comm.size == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline()
+    if comm.rank == 0:
+        print(json.dumps(line), flush=True)
+    comm.barrier()
+    comm.close()
+
+
+if __name__ == "__main__":
+    main()

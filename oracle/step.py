@@ -100,7 +100,7 @@ def rgbd_step(gen_params, dis_params, opt, x_real_full, z, thetas, stage, cfg, i
     y_fake = nets.discriminator(dis_params, x_fake[:, :3], stage)
     loss_adv_g = loss_gen_adv(y_fake)
     loss_gen = loss_adv_g
-    out = {"gen/loss_adv": float(loss_adv_g)}
+    out = {"gen/loss_adv": float(loss_adv_g.detach())}
     if use_rotate:
         lam_geo = cfg.get("lambda_geometric") or 3
         loss_rot, _ = warp_loss.loss_torch(x_fake[:B // 2], cams[:B // 2], x_fake[B // 2:], cams[B // 2:],
@@ -108,12 +108,12 @@ def rgbd_step(gen_params, dis_params, opt, x_real_full, z, thetas, stage, cfg, i
                                            lambda_geometric=lam_geo)
         if cfg["lambda_depth"] > 0:
             loss_rot = loss_rot + depth_hinge(x_fake, cfg["depth_min"], cfg["lambda_depth"])
-        out["gen/loss_rotate"] = float(loss_rot)
+        out["gen/loss_rotate"] = float(loss_rot.detach())
         lam_rot = cfg.get("lambda_rotate") or 2
         lam_rot = lam_rot if image_size <= 128 else lam_rot * 2
         loss_gen = loss_gen + loss_rot * lam_rot
     loss_gen.backward()
-    out["loss_gen_total"] = float(loss_gen)
+    out["loss_gen_total"] = float(loss_gen.detach())
     if "map" in opt:
         out["norm_map"] = opt["map"].update()
     out["norm_gen"] = opt["gen"].update()
@@ -124,12 +124,12 @@ def rgbd_step(gen_params, dis_params, opt, x_real_full, z, thetas, stage, cfg, i
     x_real = x_real.clone().requires_grad_(True)
     y_real = nets.discriminator(dis_params, x_real, stage)
     loss_dis = loss_dis_adv(y_fake, y_real)
-    out["dis/loss_adv_only"] = float(loss_dis)
+    out["dis/loss_adv_only"] = float(loss_dis.detach())
     if cfg["lambda_gp"] > 0:
         loss_gp = r1_penalty(y_real, x_real, cfg["lambda_gp"])
-        out["dis/loss_gp"] = float(loss_gp)
+        out["dis/loss_gp"] = float(loss_gp.detach())
         loss_dis = loss_dis + loss_gp
-    out["dis/loss_adv"] = float(loss_dis)
+    out["dis/loss_adv"] = float(loss_dis.detach())
     loss_dis.backward()
     out["norm_dis"] = opt["dis"].update()
     out["x_fake"] = x_fake.detach()

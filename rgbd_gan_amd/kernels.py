@@ -8,6 +8,44 @@ from . import _lib
 BF16 = torch.bfloat16
 F32 = torch.float32
 
+# ---- optional per-launch timing (bench.py's roofline leg): HIP events on the launch stream around each kernel
+_PROFILE = None
+
+
+class launch_profile:
+    """with kernels.launch_profile() as prof: ...  -> prof.summary() = {kernel: (launches, seconds, flops, bytes)}.
+    Events are recorded on torch's current stream, which is the stream every kernel here is launched on."""
+
+    def __enter__(self):
+        global _PROFILE
+        self.records = []
+        _PROFILE = self.records
+        return self
+
+    def __exit__(self, *exc):
+        global _PROFILE
+        _PROFILE = None
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, flops, nbytes, e0, e1 in self.records:
+            n, t, f, b = out.get(name, (0, 0.0, 0.0, 0.0))
+            out[name] = (n + 1, t + e0.elapsed_time(e1) * 1e-3, f + flops, b + nbytes)
+        return out
+
+
+def _timed(name, flops, nbytes, fn):
+    if _PROFILE is None:
+        return fn()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = fn()
+    e1.record()
+    _PROFILE.append((name, flops, nbytes, e0, e1))
+    return rc
+
 
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -87,9 +125,13 @@ def conv2d_fprop(x, wp, KH, KW, pad, bias=None, residual=None, upsample=False, l
     y = torch.empty(B, Hout, Wout, Cout, dtype=BF16, device=x.device)
     if residual is not None and residual.shape != y.shape:
         raise RuntimeError("conv2d_fprop: residual shape mismatch")
-    rc = _lib.load().rgbd_conv2d_fprop_bf16(_ptr(x), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(y), B, H, W, Cin,
-                                            Cout, KH, KW, pad, int(bool(upsample)), int(lrelu_channels),
-                                            float(slope), _stream())
+    lib = _lib.load()
+    flops = 2.0 * B * Hout * Wout * Cout * Cin * KH * KW
+    nbytes = 2.0 * (x.numel() + y.numel() + wp.numel() + (residual.numel() if residual is not None else 0))
+    rc = _timed(f"conv_fprop_kernel<{128 if Cout % 128 == 0 else 64}>", flops, nbytes,
+                lambda: lib.rgbd_conv2d_fprop_bf16(_ptr(x), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(y), B, H, W,
+                                                   Cin, Cout, KH, KW, pad, int(bool(upsample)), int(lrelu_channels),
+                                                   float(slope), _stream()))
     _lib.check(rc, "rgbd_conv2d_fprop_bf16")
     return y
 
@@ -103,7 +145,10 @@ def conv2d_wgrad(x, dy, K, scale, out=None, accumulate=False):
         raise RuntimeError(f"conv2d_wgrad: spatial mismatch {tuple(x.shape)} vs {tuple(dy.shape)}")
     dwp = torch.zeros(K * K, Cout, Cin, dtype=F32, device=x.device)
     lib = _lib.load()
-    rc = lib.rgbd_conv2d_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(dwp), B, H, W, Cin, Cout, K, _stream())
+    flops = 2.0 * B * H * W * Cout * Cin * K * K
+    nbytes = 2.0 * (x.numel() + dy.numel()) + 4.0 * dwp.numel()
+    rc = _timed(f"conv_wgrad_kernel<{K * K}>", flops, nbytes,
+                lambda: lib.rgbd_conv2d_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(dwp), B, H, W, Cin, Cout, K, _stream()))
     _lib.check(rc, "rgbd_conv2d_wgrad_bf16")
     if out is None:
         out = torch.empty(Cout, Cin, K, K, dtype=F32, device=x.device)

@@ -1,0 +1,107 @@
+"""Model / optimizer / data set-up shared by train_rgbd.py and bench.py (train_rgbd.py:172-258,306-361 of the reference)."""
+import glob
+import os
+
+import numpy as np
+import torch
+
+from .net import DCGANGenerator, Discriminator, StyleGANGenerator
+from .optimizer import FlatAdam
+from .updater import CameraParamPrior, RGBDUpdater
+
+
+def setup_generator(config, device):
+    """train_rgbd.py:220-246."""
+    rgbd = False if config.rgb else True
+    arch = config.generator_architecture
+    if arch == "stylegan":
+        return StyleGANGenerator(config.ch, enable_blur=config.enable_blur, rgbd=rgbd,
+                                 rotate_conv_input=config.rotate_conv_input, use_encoder=config.bigan,
+                                 use_occupancy_net=config.use_occupancy_net_loss, initial_depth=config.initial_depth,
+                                 device=device)
+    if arch == "dcgan":
+        # NB the reference passes config.ch as in_ch and leaves ch at its default 512 (train_rgbd.py:230)
+        return DCGANGenerator(config.ch, enable_blur=config.enable_blur, rgbd=rgbd, use_encoder=config.bigan,
+                              use_occupancy_net=config.use_occupancy_net_loss, initial_depth=config.initial_depth,
+                              device=device)
+    raise AssertionError(f"{arch} is not supported by the MI355X engine yet")
+
+
+def setup_discriminator(config, device):
+    """train_rgbd.py:249-258."""
+    if config.bigan:
+        raise AssertionError("bigan is not supported")
+    return Discriminator(ch=config.ch, enable_blur=config.enable_blur, sn=config.sn, res=config.res_dis, device=device)
+
+
+def make_optimizers(config, generator, discriminator, comm=None):
+    """train_rgbd.py:314-343: Adam(beta1, beta2) + GradientClipping(5); map runs at alpha_g/100, and so do gen.l1/l2."""
+    b1, b2 = config.adam_beta1, config.adam_beta2
+    if config.generator_architecture == "stylegan":
+        opt = {"map": FlatAdam(generator.mapping.store, config.adam_alpha_g / 100, b1, b2, comm=comm),
+               "gen": FlatAdam(generator.gen.store, config.adam_alpha_g, b1, b2, comm=comm),
+               "dis": FlatAdam(discriminator.store, config.adam_alpha_d, b1, b2, comm=comm)}
+        if not config.rgb:
+            for n in ("l1/c/W", "l2/c/W", "l1/c/b", "l2/c/b"):
+                opt["gen"].set_alpha(n, config.adam_alpha_g / 100)
+        return opt
+    return {"gen": FlatAdam(generator.store, config.adam_alpha_g, b1, b2, comm=comm),
+            "dis": FlatAdam(discriminator.store, config.adam_alpha_d, b1, b2, comm=comm)}
+
+
+def make_dataset(dataset_path, image_path):
+    """train_rgbd.py:172-184: `images.npy` cache (uint8, N x 3 x H x W), built from the glob on first use."""
+    cache = f"{dataset_path}/images.npy"
+    if os.path.exists(cache):
+        return np.load(cache)
+    from PIL import Image
+    imgs = [np.array(Image.open(p)).transpose(2, 0, 1) for p in sorted(glob.glob(image_path))]
+    imgs = np.array(imgs, dtype="uint8")
+    np.save(cache, imgs)
+    return imgs
+
+
+class DeviceImageIterator:
+    """SerialIterator + TransformDataset(x / 127.5 - 1) of train_rgbd.py:308-310 with the uint8 data set resident
+    in HBM (an FFHQ-sized 70k x 3 x 128 x 128 set is 3.4 GB of the 288 GB): a batch is one gather + one normalise on
+    the device instead of a Python list and a host-to-device copy per step (updater.py:259-268)."""
+
+    def __init__(self, images_u8, batch_size, device, shuffle=True, seed=None):
+        self.data = torch.as_tensor(images_u8).to(device)
+        self.batch_size, self.shuffle = batch_size, shuffle
+        self.gen = torch.Generator(device="cpu")
+        if seed is not None:
+            self.gen.manual_seed(seed)
+        self.epoch, self._pos = 0, 0
+        self._order = self._new_order()
+
+    def _new_order(self):
+        n = self.data.shape[0]
+        return torch.randperm(n, generator=self.gen) if self.shuffle else torch.arange(n)
+
+    def next(self):
+        n = self.data.shape[0]
+        idx = self._order[self._pos:self._pos + self.batch_size]
+        self._pos += self.batch_size
+        if self._pos >= n:                                    # wrap like chainer's SerialIterator(repeat=True)
+            self.epoch += 1
+            rest = self._pos - n
+            self._order = self._new_order()
+            if rest > 0:
+                idx = torch.cat([idx, self._order[:rest]])
+            self._pos = rest
+        batch = self.data[idx.to(self.data.device)]
+        return batch.to(torch.float32) / 127.5 - 1
+
+    __next__ = next
+
+
+def build_training(config, device, comm=None, iterator=None, **updater_kwargs):
+    generator = setup_generator(config, device)
+    discriminator = setup_discriminator(config, device)
+    optimizer = make_optimizers(config, generator, discriminator, comm)
+    updater = RGBDUpdater(models=[generator, discriminator], config=config, optimizer=optimizer, iterator=iterator,
+                          lambda_gp=config.lambda_gp, smoothing=config.smoothing,
+                          total_gpu=comm.size if comm is not None else 1, prior=CameraParamPrior(config),
+                          **updater_kwargs)
+    return generator, discriminator, optimizer, updater
