@@ -38,13 +38,16 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(batch=4):
+def cpu_baseline(batch=2, threads=None):
     """The CPU restatement of the same step (oracle/step.py; Chainer is unavailable), timed on the host cores on a
     bounded sample: one update_core at 128x128, ch=256, `batch` images."""
     import numpy as np
     import torch
     from oracle import camera, nets, step
-    torch.set_num_threads(os.cpu_count() or 1)
+    # a bounded sample on a bounded thread count: torch-CPU convolutions at this batch size stop scaling (and
+    # collapse with hundreds of threads), so use at most 16 host cores and say so in `cores`
+    threads = threads or min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(threads)
     ch = 256
     gp = {k: v.requires_grad_(True) for k, v in nets.init_stylegan(ch, seed=0).items()}
     dp = {k: v.requires_grad_(True) for k, v in nets.init_discriminator(ch, seed=1).items()}
