@@ -87,17 +87,15 @@ int rgbd_conv2d_fprop_bf16(const void* x, const void* wp, const float* bias, con
                            int B, int Hin, int Win, int Cin, int Cout, int KH, int KW, int pad,
                            int upsample, int lrelu_channels, float slope, void* stream);
 
-/* Weight gradient: dwp[tap][co][ci] += sum_{b,h,w} dy[b,h,w,co] * x[b,h+kh-pad,w+kw-pad,ci]  (fp32, atomics).
+/* Weight gradient: dw[co][ci][kh][kw] (+)= scale * sum_{b,h,w} dy[b,h,w,co] * x[b,h+kh-pad,w+kw-pad,ci]  (fp32).
  *   x  : (B,H,W,Cin) bf16, dy : (B,H,W,Cout) bf16 (same H,W: stride 1, pad = (K-1)/2), K in {1,3}.
- *   dwp: [K*K][Cout][Cin] fp32, must be zeroed by the caller (or hold a value to accumulate into).
+ *   dw : (Cout,Cin,K,K) fp32 = the master-weight gradient (scale = inv_c of the equalized-LR conv).
+ *   workspace: rgbd_conv2d_wgrad_workspace(...) bytes; holds one partial (K*K,Cout,Cin) slab per workgroup.
  * Requires Cin % 64 == 0, Cout % 64 == 0, H and W powers of two >= 4.
  */
-int rgbd_conv2d_wgrad_bf16(const void* x, const void* dy, float* dwp,
-                           int B, int H, int W, int Cin, int Cout, int K, void* stream);
-
-/* dwp [K*K][Cout][Cin] fp32 -> dw (Cout,Cin,K,K) fp32, dw = scale * dwp (+ dw if accumulate). */
-int rgbd_unpack_wgrad(const float* dwp, float* dw, int cout, int cin, int kh, int kw, float scale,
-                      int accumulate, void* stream);
+int64_t rgbd_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int K);
+int rgbd_conv2d_wgrad_bf16(const void* x, const void* dy, void* workspace, float* dw,
+                           int B, int H, int W, int Cin, int Cout, int K, float scale, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------ AdaIN (instance norm + style affine)
  * Replaces normalization/adain.py:54-73 (reshape + F.batch_normalization + broadcast mul/add) and its backward.

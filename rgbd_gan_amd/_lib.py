@@ -22,8 +22,8 @@ PROTOTYPES = {
     "rgbd_pack_weights": ([_P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P], c_int),
     "rgbd_conv2d_fprop_bf16": ([_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                 c_int, c_int, c_float, _P], c_int),
-    "rgbd_conv2d_wgrad_bf16": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P], c_int),
-    "rgbd_unpack_wgrad": ([_P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P], c_int),
+    "rgbd_conv2d_wgrad_workspace": ([c_int, c_int, c_int, c_int, c_int, c_int], c_int64),
+    "rgbd_conv2d_wgrad_bf16": ([_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P], c_int),
     "rgbd_adain_fwd": ([_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P], c_int),
     "rgbd_adain_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P], c_int),
     "rgbd_adam_clip_multi": ([_P, _P, _P, _P, c_int64, c_int, POINTER(c_int64), POINTER(c_float), c_float, c_float,

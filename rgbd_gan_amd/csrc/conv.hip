@@ -14,8 +14,8 @@
 //   ds_read_b64_tr_b16 transposes while reading LDS, so both operands are staged pixel-major exactly as they
 //   sit in HBM and read K(pixel)-contiguous for v_mfma_f32_32x32x16_bf16.  One workgroup keeps all 9 taps of
 //   a 64x64 (co,ci) tile in registers (144 accumulator VGPRs per lane), stages an 8x16-pixel patch of dY and the
-//   10x18 halo patch of X once, and sweeps its share of patches; partial sums leave through fp32 atomics shaped
-//   as two 128-byte row segments per wave instruction (MI355X_MICROARCH.md, "Global float atomics").
+//   10x18 halo patch of X once, and sweeps its share of patches; partial sums leave as plain fp32 stores into
+//   one slab per workgroup (two 128-byte row segments per wave instruction) and a second kernel sums the slabs.
 #include "common.h"
 
 namespace {
@@ -29,12 +29,13 @@ struct ConvArgs {
     int B, Hin, Win, Cin, Cout, KH, KW, pad, ups, Hout, Wout, lrelu_ch;
     float slope;
     long M;
+    int x_bytes, w_bytes;
 };
 
 __device__ __forceinline__ u32x4 ldg16(const unsigned short* p) { return *reinterpret_cast<const u32x4*>(p); }
 
 template <int BN>
-__global__ __launch_bounds__(256) void conv_fprop_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_fprop_kernel(ConvArgs a) {
     constexpr int BM = 128;                  // output pixels per workgroup
     constexpr int P_BYTES = BM * 128;        // 128 rows x 64 bf16
     constexpr int W_BYTES = BN * 128;
@@ -48,8 +49,15 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int n_tiles = a.Cout / BN;
-    const int nt = blockIdx.x % n_tiles;
-    const long mt = blockIdx.x / n_tiles;
+    // XCD-aware tile order (cdna_hip_programming.md T1, bijective form): blocks are dealt round-robin over the 8
+    // XCDs, so give each XCD a contiguous run of tiles -- neighbours share pixel halos and weight panels in its L2.
+    unsigned bid = blockIdx.x;
+    {
+        const unsigned nwg = gridDim.x, xcd = bid & 7u, q8 = nwg >> 3, r8 = nwg & 7u;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    }
+    const int nt = bid % n_tiles;
+    const long mt = bid / n_tiles;
     const long m0 = mt * BM;
     const int n0 = nt * BN;
     const int wave_co = (wid / WAVES_PX) * 64;
@@ -78,8 +86,13 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(ConvArgs a) {
     const int nkc = a.Cin >> 6;
     const int nk = a.KH * a.KW * nkc;
 
-    u32x4 regP[4], regW[WROWS];
-    auto load_tiles = [&](int kt) {
+    // Register prefetch: the gathered pixel tile of step k+2 is in flight from HBM while the tile of step k+1
+    // waits in registers and step k is multiplied out of LDS; the weight tile (L2-resident, shared by every
+    // workgroup) is fetched one step ahead.  One barrier per K step.  Offsets are 32-bit (host checks sizes).
+    u32x4 regPa[4], regPb[4], regW[WROWS];
+    const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.x), 0, a.x_bytes, 0x00020000);
+    const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.wp), 0, a.w_bytes, 0x00020000);
+    auto load_pixels = [&](int kt, u32x4 (&regP)[4]) {
         const int tap = kt / nkc;
         const int c0 = (kt - tap * nkc) << 6;
         const int kh = tap / a.KW;
@@ -89,18 +102,24 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(ConvArgs a) {
             const int hi = ph[i] + dh, wi = pw[i] + dw;
             const bool ok = (unsigned)hi < (unsigned)Hup && (unsigned)wi < (unsigned)Wup;
             const int hs = a.ups ? (hi >> 1) : hi, ws = a.ups ? (wi >> 1) : wi;
-            const long off = (((long)pb[i] * a.Hin + hs) * a.Win + ws) * a.Cin + c0 + chunk * 8;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (ok) v = ldg16(a.x + off);
-            regP[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < WROWS; ++i) {
-            const long off = ((long)tap * a.Cout + n0 + prow + 32 * i) * a.Cin + c0 + chunk * 8;
-            regW[i] = ldg16(a.wp + off);
+            // Buffer load with hardware range checking: out-of-frame lanes get an offset past num_records and
+            // the load returns zeros -- no branch (which would make hipcc drain vmcnt(0) and serialise the
+            // prefetch) and no select after the load (which would force an early wait on it).
+            const unsigned off = ok ? (unsigned)(((pb[i] * a.Hin + hs) * a.Win + ws) * a.Cin + c0 + chunk * 8) * 2u
+                                    : 0x80000000u;
+            regP[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0);
         }
     };
-    auto store_tiles = [&](int buf) {
+    auto load_weights = [&](int kt) {
+        const int tap = kt / nkc;
+        const int c0 = (kt - tap * nkc) << 6;
+#pragma unroll
+        for (int i = 0; i < WROWS; ++i) {
+            const unsigned off = (unsigned)((tap * a.Cout + n0 + prow + 32 * i) * a.Cin + c0 + chunk * 8) * 2u;
+            regW[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, 0);
+        }
+    };
+    auto store_tiles = [&](int buf, const u32x4 (&regP)[4]) {
         unsigned char* base = smem + buf * STAGE;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -138,14 +157,29 @@ __global__ __launch_bounds__(256) void conv_fprop_kernel(ConvArgs a) {
         }
     };
 
-    load_tiles(0);
-    store_tiles(0);
+    load_pixels(0, regPa);
+    load_weights(0);
+    store_tiles(0, regPa);
+    const int last = nk - 1;
+    load_pixels(min(1, last), regPa);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_tiles(kt + 1);
-        compute(cur);
-        if (kt + 1 < nk) store_tiles(cur ^ 1);
+    // Steps past the end re-load the last tile (clamped index) instead of branching, so the loop body has no
+    // conditional memory operations and hipcc keeps counted vmcnt waits (loads stay in flight across barriers).
+    for (int kt = 0; kt < nk; kt += 2) {
+        // even step: LDS buffer 0 holds tile kt, set A holds the pixels of tile kt+1
+        load_weights(min(kt + 1, last));
+        asm volatile("" ::: "memory");   // keep issue order weights -> pixels: vmcnt retires in order
+        load_pixels(min(kt + 2, last), regPb);
+        compute(0);
+        store_tiles(1, regPa);
+        __syncthreads();
+        if (kt + 1 >= nk) break;
+        // odd step: LDS buffer 1 holds tile kt+1, set B holds the pixels of tile kt+2
+        load_weights(min(kt + 2, last));
+        asm volatile("" ::: "memory");
+        load_pixels(min(kt + 3, last), regPa);
+        compute(1);
+        store_tiles(0, regPb);
         __syncthreads();
     }
 
@@ -273,16 +307,36 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
         }
         __syncthreads();
     }
-    // ---- reduce across workgroups: D[row = co][col = ci]; one register = two 128-byte row segments per wave
+    // ---- each workgroup stores its partial (tap, co, ci) tile into its own slab with plain stores (fp32 atomics
+    //      run at ~1.3 TB/s chip-wide, plain stores at ~6 TB/s: MI355X_MICROARCH.md "Global float atomics");
+    //      wgrad_reduce_kernel sums the slabs.  D[row = co][col = ci]: one register = two 128-byte row segments.
     const int col = lane & 31, rhalf = lane >> 5;
+    float* slab = a.dwp + (long)blockIdx.x * NT * a.Cout * a.Cin;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * rhalf;
-            float* dst = a.dwp + ((long)t * a.Cout + co0 + wc * 32 + row) * a.Cin + ci0 + wi * 32 + col;
-            atomicAdd(dst, acc[t][r]);
+            slab[((long)t * a.Cout + co0 + wc * 32 + row) * a.Cin + ci0 + wi * 32 + col] = acc[t][r];
         }
+    }
+}
+
+// dw[co][ci][tap] = scale * sum_s slab[s][tap][co][ci]  (+ dw when accumulating).  Reads are coalesced along ci.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
+                                                           int nslab, int taps, int cout, int cin, float scale,
+                                                           int accumulate) {
+    const long total = (long)taps * cout * cin;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        float acc = 0.f;
+        for (int s = 0; s < nslab; ++s) acc += slabs[(long)s * total + e];
+        const int ci = (int)(e % cin);
+        const long r = e / cin;
+        const int co = (int)(r % cout);
+        const int tap = (int)(r / cout);
+        const long o = ((long)co * cin + ci) * taps + tap;
+        const float v = acc * scale;
+        dw[o] = accumulate ? dw[o] + v : v;
     }
 }
 
@@ -312,6 +366,10 @@ extern "C" int rgbd_conv2d_fprop_bf16(const void* x, const void* wp, const float
     a.Hout = Hup + 2 * pad - KH + 1;
     a.Wout = Wup + 2 * pad - KW + 1;
     RGBD_REQUIRE(a.Hout > 0 && a.Wout > 0, "rgbd_conv2d_fprop_bf16: empty output");
+    RGBD_REQUIRE((long)B * Hin * Win * Cin < 0x3fffffffL && (long)KH * KW * Cout * Cin < 0x3fffffffL,
+                 "rgbd_conv2d_fprop_bf16: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
+    a.x_bytes = (int)((long)B * Hin * Win * Cin * 2);
+    a.w_bytes = (int)((long)KH * KW * Cout * Cin * 2);
     a.lrelu_ch = lrelu_channels; a.slope = slope;
     a.M = (long)B * a.Hout * a.Wout;
     const long mtiles = (a.M + 127) / 128;
@@ -329,32 +387,59 @@ extern "C" int rgbd_conv2d_fprop_bf16(const void* x, const void* wp, const float
     return 0;
 }
 
-extern "C" int rgbd_conv2d_wgrad_bf16(const void* x, const void* dy, float* dwp, int B, int H, int W, int Cin,
-                                      int Cout, int K, void* stream) {
-    RGBD_REQUIRE(x && dy && dwp, "rgbd_conv2d_wgrad_bf16: null pointer");
+namespace {
+struct WgradPlan {
+    int PH, PW, lgPW, npx, npy, total_patches, patches_per_wg, nsplit;
+};
+WgradPlan plan_wgrad(int B, int H, int W, int Cin, int Cout) {
+    WgradPlan p;
+    p.PW = W < 16 ? W : 16;
+    p.PH = H < 8 ? H : 8;
+    p.lgPW = ilog2(p.PW);
+    p.npx = W / p.PW;
+    p.npy = H / p.PH;
+    p.total_patches = B * p.npx * p.npy;
+    const int tiles = (Cin / 64) * (Cout / 64);
+    // two workgroups per CU (the loop is single-buffered: the second workgroup hides the first one's loads);
+    // every workgroup costs one (taps x 64 x 64) fp32 slab of reduction traffic, so do not over-split
+    int nsplit = 512 / tiles;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > p.total_patches) nsplit = p.total_patches;
+    p.patches_per_wg = (p.total_patches + nsplit - 1) / nsplit;
+    p.nsplit = (p.total_patches + p.patches_per_wg - 1) / p.patches_per_wg;
+    return p;
+}
+}  // namespace
+
+extern "C" int64_t rgbd_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int K) {
+    if (B <= 0 || H < 4 || W < 4 || Cin % 64 || Cout % 64 || (K != 1 && K != 3)) return -1;
+    const WgradPlan p = plan_wgrad(B, H, W, Cin, Cout);
+    return (int64_t)p.nsplit * K * K * Cout * Cin * (int64_t)sizeof(float);
+}
+
+extern "C" int rgbd_conv2d_wgrad_bf16(const void* x, const void* dy, void* workspace, float* dw, int B, int H, int W,
+                                      int Cin, int Cout, int K, float scale, int accumulate, void* stream) {
+    RGBD_REQUIRE(x && dy && workspace && dw, "rgbd_conv2d_wgrad_bf16: null pointer");
     RGBD_REQUIRE(K == 1 || K == 3, "rgbd_conv2d_wgrad_bf16: K must be 1 or 3 (K=%d)", K);
     RGBD_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0,
                  "rgbd_conv2d_wgrad_bf16: Cin and Cout must be multiples of 64 (Cin=%d Cout=%d)", Cin, Cout);
     RGBD_REQUIRE(B > 0 && H >= 4 && W >= 4 && (H & (H - 1)) == 0 && (W & (W - 1)) == 0,
                  "rgbd_conv2d_wgrad_bf16: H and W must be powers of two >= 4 (H=%d W=%d)", H, W);
+    const WgradPlan p = plan_wgrad(B, H, W, Cin, Cout);
     WgradArgs a;
-    a.x = (const unsigned short*)x; a.dy = (const unsigned short*)dy; a.dwp = dwp;
+    a.x = (const unsigned short*)x; a.dy = (const unsigned short*)dy; a.dwp = (float*)workspace;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
-    a.PW = W < 16 ? W : 16;
-    a.PH = H < 8 ? H : 8;
-    a.lgPW = ilog2(a.PW);
-    a.npx = W / a.PW; a.npy = H / a.PH;
-    a.total_patches = B * a.npx * a.npy;
-    const int tiles = (Cin / 64) * (Cout / 64);
-    int nsplit = 1024 / tiles;
-    if (nsplit < 1) nsplit = 1;
-    if (nsplit > a.total_patches) nsplit = a.total_patches;
-    a.patches_per_wg = (a.total_patches + nsplit - 1) / nsplit;
-    nsplit = (a.total_patches + a.patches_per_wg - 1) / a.patches_per_wg;
-    dim3 grid(nsplit, Cin / 64, Cout / 64);
+    a.PW = p.PW; a.PH = p.PH; a.lgPW = p.lgPW; a.npx = p.npx; a.npy = p.npy;
+    a.total_patches = p.total_patches; a.patches_per_wg = p.patches_per_wg;
+    dim3 grid(p.nsplit, Cin / 64, Cout / 64);
     hipStream_t st = (hipStream_t)stream;
     if (K == 3) conv_wgrad_kernel<9><<<grid, 256, 0, st>>>(a);
     else        conv_wgrad_kernel<1><<<grid, 256, 0, st>>>(a);
     RGBD_CHECK_LAUNCH("conv_wgrad_kernel");
+    const long total = (long)K * K * Cout * Cin;
+    const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+    wgrad_reduce_kernel<<<blocks, 256, 0, st>>>((const float*)workspace, dw, p.nsplit, K * K, Cout, Cin, scale,
+                                                accumulate);
+    RGBD_CHECK_LAUNCH("wgrad_reduce_kernel");
     return 0;
 }

@@ -35,19 +35,6 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     }
 }
 
-__global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __restrict__ dw,
-                                                           int cout, int cin, int taps, float scale, int accumulate) {
-    const long total = (long)cout * cin * taps;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        const int tap = (int)(e % taps);
-        const long r = e / taps;
-        const int ci = (int)(r % cin);
-        const int co = (int)(r / cin);
-        const float v = dwp[((long)tap * cout + co) * cin + ci] * scale;
-        dw[e] = accumulate ? dw[e] + v : v;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ AdaIN
 // x is (B, HW, C) bf16.  A block owns one batch item, one 64-channel group and a strip of pixels:
 // thread t handles the 8-channel chunk (t & 7) of pixels (t >> 3), (t >> 3) + 32, ...
@@ -251,16 +238,6 @@ extern "C" int rgbd_pack_weights(const float* w, int cout, int cin, int kh, int 
     pack_weights_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(w, cout, cin, kh, kw, scale,
                                                                  (unsigned short*)w_fprop, (unsigned short*)w_dgrad);
     RGBD_CHECK_LAUNCH("pack_weights_kernel");
-    return 0;
-}
-
-extern "C" int rgbd_unpack_wgrad(const float* dwp, float* dw, int cout, int cin, int kh, int kw, float scale,
-                                 int accumulate, void* stream) {
-    RGBD_REQUIRE(dwp && dw, "rgbd_unpack_wgrad: null pointer");
-    const long total = (long)cout * cin * kh * kw;
-    const int blocks = (int)min((long)2048, (total + 255) / 256);
-    unpack_wgrad_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(dwp, dw, cout, cin, kh * kw, scale, accumulate);
-    RGBD_CHECK_LAUNCH("unpack_wgrad_kernel");
     return 0;
 }
 

@@ -143,18 +143,20 @@ def conv2d_wgrad(x, dy, K, scale, out=None, accumulate=False):
     Cout = dy.shape[3]
     if dy.shape[:3] != x.shape[:3]:
         raise RuntimeError(f"conv2d_wgrad: spatial mismatch {tuple(x.shape)} vs {tuple(dy.shape)}")
-    dwp = torch.zeros(K * K, Cout, Cin, dtype=F32, device=x.device)
     lib = _lib.load()
-    flops = 2.0 * B * H * W * Cout * Cin * K * K
-    nbytes = 2.0 * (x.numel() + dy.numel()) + 4.0 * dwp.numel()
-    rc = _timed(f"conv_wgrad_kernel<{K * K}>", flops, nbytes,
-                lambda: lib.rgbd_conv2d_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(dwp), B, H, W, Cin, Cout, K, _stream()))
-    _lib.check(rc, "rgbd_conv2d_wgrad_bf16")
+    ws_bytes = lib.rgbd_conv2d_wgrad_workspace(B, H, W, Cin, Cout, K)
+    if ws_bytes < 0:
+        raise RuntimeError(f"conv2d_wgrad: unsupported shape x={tuple(x.shape)} dy={tuple(dy.shape)} K={K}")
+    ws = torch.empty(ws_bytes // 4, dtype=F32, device=x.device)
     if out is None:
         out = torch.empty(Cout, Cin, K, K, dtype=F32, device=x.device)
         accumulate = False
-    rc = lib.rgbd_unpack_wgrad(_ptr(dwp), _ptr(out), Cout, Cin, K, K, float(scale), int(bool(accumulate)), _stream())
-    _lib.check(rc, "rgbd_unpack_wgrad")
+    flops = 2.0 * B * H * W * Cout * Cin * K * K
+    nbytes = 2.0 * (x.numel() + dy.numel()) + 2.0 * ws_bytes
+    rc = _timed(f"conv_wgrad_kernel<{K * K}>+reduce", flops, nbytes,
+                lambda: lib.rgbd_conv2d_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(ws), _ptr(out), B, H, W, Cin, Cout, K,
+                                                   float(scale), int(bool(accumulate)), _stream()))
+    _lib.check(rc, "rgbd_conv2d_wgrad_bf16")
     return out
 
 
