@@ -108,6 +108,29 @@ int rgbd_adain_fwd(const void* x, const float* scale, const float* shift, void* 
 int rgbd_adain_bwd(const void* x, const void* dy, const float* scale, const float* mean, const float* rstd,
                    void* dx, float* dscale, float* dshift, float* sums, int B, int HW, int C, void* stream);
 
+/* ------------------------------------------------------------------ small fused elementwise / 1x1 kernels (HBM-bound)
+ * rgbd_lrelu_bwd: dz = dy * (y > 0 ? 1 : slope) on channels [0, act_channels) of (M,C) bf16 tensors, pass-through on
+ *   the rest (backward of F.leaky_relu, net.py:152,159,410,416, evaluated from the activation's OUTPUT).
+ * rgbd_colsum_bf16: out[c] = sum_m x[m][c] (fp32): bias gradients of the convs.
+ */
+int rgbd_lrelu_bwd(const void* dy, const void* y, void* dz, int64_t M, int C, int act_channels, float slope,
+                   void* stream);
+int rgbd_colsum_bf16(const void* x, float* out, int64_t M, int C, void* stream);
+
+/* 1x1 convolutions between NCHW fp32 image planes (KP = 3 or 4 channels) and NHWC bf16 features (C channels):
+ *   rgbd_from_planes: y[b,p,co] = act(wscale * sum_k w[co][k] x[b,k,p] + bias[co])   -- Discriminator.ins, net.py:449-455
+ *   rgbd_to_planes  : out[b,k,p] = wscale * sum_c w[k][c] h[b,p,c] + bias[k]           -- StyleGenerator.outs, net.py:186-191
+ *                     (also the input gradient of from_planes with w transposed)
+ *   rgbd_planes_outer: o[k][c] = sum_{b,p} planes[b,k,p] * t[b,p,c]; tsum[c] = sum t   -- their weight / bias gradients
+ * w is fp32, row-major as written; bias / tsum may be NULL.
+ */
+int rgbd_from_planes(const float* x, const float* w, const float* bias, void* y, int B, int HW, int KP, int C,
+                     float wscale, int act, float slope, void* stream);
+int rgbd_to_planes(const void* h, const float* w, const float* bias, float* out, int B, int HW, int KP, int C,
+                   float wscale, void* stream);
+int rgbd_planes_outer(const void* t, const float* planes, float* o, float* tsum, int B, int HW, int KP, int C,
+                      void* stream);
+
 /* ------------------------------------------------------------------ optimizer
  * Replaces chainer.optimizers.Adam + GradientClipping(5) (train_rgbd.py:151-161), one launch group per
  * optimizer instead of one elementwise kernel per parameter tensor.

@@ -173,6 +173,177 @@ __global__ __launch_bounds__(256) void split_sums_kernel(const float* __restrict
     dscale[i] = sums[2 * i + 1];
 }
 
+// ------------------------------------------------------------------------------------------------ leaky ReLU grad
+// dz = dy * (y > 0 ? 1 : slope) on the first act_channels channels of an NHWC bf16 tensor (rest pass through).
+// y is the *output* of the activation (sign-preserving), so no pre-activation tensor is kept.
+__global__ __launch_bounds__(256) void lrelu_bwd_kernel(const unsigned short* __restrict__ dy,
+                                                        const unsigned short* __restrict__ y,
+                                                        unsigned short* __restrict__ dz, long nvec, int C,
+                                                        int act_channels, float slope) {
+    const int cvec = C >> 3;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nvec; e += (long)gridDim.x * 256) {
+        const int c0 = (int)(e % cvec) * 8;
+        const u32x4 g = *reinterpret_cast<const u32x4*>(dy + e * 8);
+        u32x4 out = g;
+        if (c0 < act_channels) {
+            const u32x4 yy = *reinterpret_cast<const u32x4*>(y + e * 8);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float g0 = bf16_lo(g[k]), g1 = bf16_hi(g[k]);
+                const float r0 = bf16_lo(yy[k]) > 0.f ? g0 : g0 * slope;
+                const float r1 = bf16_hi(yy[k]) > 0.f ? g1 : g1 * slope;
+                out[k] = pack_bf16x2(r0, r1);
+            }
+        }
+        *reinterpret_cast<u32x4*>(dz + e * 8) = out;
+    }
+}
+
+// column sums of an (M, C) bf16 matrix -> out[C] fp32 (atomics; out zeroed by the caller): bias gradients.
+__global__ __launch_bounds__(256) void colsum_kernel(const unsigned short* __restrict__ x, float* __restrict__ out,
+                                                     long M, int C, int rows_per_block) {
+    const int cg = blockIdx.y;
+    const int chunk = threadIdx.x & 7, lane_p = threadIdx.x >> 3;
+    const int c0 = cg * 64 + chunk * 8;
+    const long r_begin = (long)blockIdx.x * rows_per_block;
+    const long r_end = min(M, r_begin + rows_per_block);
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long r = r_begin + lane_p; r < r_end; r += 32) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(x + r * C + c0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s[2 * k] += bf16_lo(v[k]); s[2 * k + 1] += bf16_hi(v[k]); }
+    }
+    __shared__ float red[32][65];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[lane_p][chunk * 8 + k] = s[k];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float acc = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) acc += red[r][threadIdx.x];
+        atomicAdd(out + cg * 64 + threadIdx.x, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ RGB <-> features
+// from_rgb: y[b,h,w,co] = act( sum_c w[co][c] * x[b,c,h,w] + bias[co] ), x NCHW fp32 (KP planes), y NHWC bf16.
+// One thread = one pixel x 8 output channels (16-byte store).  HBM-bound: 4*KP B in, 2*C B out per pixel.
+template <int KP>
+__global__ __launch_bounds__(256) void from_planes_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias,
+                                                          unsigned short* __restrict__ y, int B, int HW, int C,
+                                                          float wscale, int act, float slope) {
+    const int cvec = C >> 3;
+    const long nvec = (long)B * HW * cvec;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nvec; e += (long)gridDim.x * 256) {
+        const int cv = (int)(e % cvec);
+        const long pix = e / cvec;
+        const int b = (int)(pix / HW);
+        const int p = (int)(pix - (long)b * HW);
+        float xin[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) xin[k] = x[((long)b * KP + k) * HW + p] * wscale;
+        float r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int co = cv * 8 + j;
+            float acc = bias ? bias[co] : 0.f;
+#pragma unroll
+            for (int k = 0; k < KP; ++k) acc += w[co * KP + k] * xin[k];
+            if (act) acc = acc > 0.f ? acc : acc * slope;
+            r[j] = acc;
+        }
+        u32x4 out = {pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3]), pack_bf16x2(r[4], r[5]), pack_bf16x2(r[6], r[7])};
+        *reinterpret_cast<u32x4*>(y + e * 8) = out;
+    }
+}
+
+// to_planes: out[b,k,h,w] = sum_c w[k][c] * h[b,h,w,c] * wscale + bias[k]; h NHWC bf16, out NCHW fp32 (KP planes).
+// 8 lanes cooperate on one pixel (16 B of channels each, shuffle reduce); used for the generator's `outs` 1x1
+// conv (KP = 4) and for the input gradient of from_rgb (KP = 3, weights transposed by the caller).
+template <int KP>
+__global__ __launch_bounds__(256) void to_planes_kernel(const unsigned short* __restrict__ h,
+                                                        const float* __restrict__ w, const float* __restrict__ bias,
+                                                        float* __restrict__ out, int B, int HW, int C, float wscale) {
+    const int sub = threadIdx.x & 7;
+    const long npix = (long)B * HW;
+    for (long pix = (long)blockIdx.x * 32 + (threadIdx.x >> 3); pix < npix; pix += (long)gridDim.x * 32) {
+        float acc[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) acc[k] = 0.f;
+        for (int c0 = sub * 8; c0 < C; c0 += 64) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(h + pix * C + c0);
+            float f[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { f[2 * q] = bf16_lo(v[q]); f[2 * q + 1] = bf16_hi(v[q]); }
+#pragma unroll
+            for (int k = 0; k < KP; ++k)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[k] += w[k * C + c0 + j] * f[j];
+        }
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            acc[k] += __shfl_xor(acc[k], 1, 64);
+            acc[k] += __shfl_xor(acc[k], 2, 64);
+            acc[k] += __shfl_xor(acc[k], 4, 64);
+        }
+        if (sub == 0) {
+            const int b = (int)(pix / HW);
+            const int p = (int)(pix - (long)b * HW);
+#pragma unroll
+            for (int k = 0; k < KP; ++k) out[((long)b * KP + k) * HW + p] = acc[k] * wscale + (bias ? bias[k] : 0.f);
+        }
+    }
+}
+
+// planes_outer: o[k][c] += sum_pix p[b,k,pix] * t[b,pix,c] (fp32 atomics; o zeroed by the caller), plus
+// tsum[c] += sum_pix t[b,pix,c] when tsum != NULL.  Weight (and bias) gradients of from_rgb / to_rgb.
+template <int KP>
+__global__ __launch_bounds__(256) void planes_outer_kernel(const unsigned short* __restrict__ t,
+                                                           const float* __restrict__ p, float* __restrict__ o,
+                                                           float* __restrict__ tsum, int B, int HW, int C,
+                                                           int rows_per_block) {
+    const int cg = blockIdx.y, b = blockIdx.z;
+    const int chunk = threadIdx.x & 7, lane_p = threadIdx.x >> 3;
+    const int c0 = cg * 64 + chunk * 8;
+    const int r_begin = blockIdx.x * rows_per_block;
+    const int r_end = min(HW, r_begin + rows_per_block);
+    float acc[KP + 1][8];
+#pragma unroll
+    for (int k = 0; k <= KP; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
+    for (int r = r_begin + lane_p; r < r_end; r += 32) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(t + ((long)b * HW + r) * C + c0);
+        float f[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { f[2 * q] = bf16_lo(v[q]); f[2 * q + 1] = bf16_hi(v[q]); }
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const float pv = p[((long)b * KP + k) * HW + r];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[k][j] += pv * f[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[KP][j] += f[j];
+    }
+    __shared__ float red[32][65];
+    for (int k = 0; k <= KP; ++k) {
+        if (k == KP && !tsum) break;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[lane_p][chunk * 8 + j] = acc[k][j];
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            float a2 = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) a2 += red[r][threadIdx.x];
+            if (k < KP) atomicAdd(o + (long)k * C + cg * 64 + threadIdx.x, a2);
+            else atomicAdd(tsum + cg * 64 + threadIdx.x, a2);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ Adam
 constexpr int NORM_BLOCKS = 1024;
 
@@ -284,6 +455,77 @@ extern "C" int rgbd_adain_bwd(const void* x, const void* dy, const float* scale,
     RGBD_CHECK_LAUNCH("adain_bwd_apply_kernel");
     split_sums_kernel<<<ceil_div((long)B * C, 256), 256, 0, st>>>(sums, dscale, dshift, B * C);
     RGBD_CHECK_LAUNCH("split_sums_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_lrelu_bwd(const void* dy, const void* y, void* dz, int64_t M, int C, int act_channels,
+                              float slope, void* stream) {
+    RGBD_REQUIRE(dy && y && dz, "rgbd_lrelu_bwd: null pointer");
+    RGBD_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && act_channels % 8 == 0, "rgbd_lrelu_bwd: C must be a multiple of 8");
+    const long nvec = M * C / 8;
+    const int blocks = (int)min((long)4096, (nvec + 255) / 256);
+    lrelu_bwd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((const unsigned short*)dy, (const unsigned short*)y,
+                                                             (unsigned short*)dz, nvec, C, act_channels, slope);
+    RGBD_CHECK_LAUNCH("lrelu_bwd_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_colsum_bf16(const void* x, float* out, int64_t M, int C, void* stream) {
+    RGBD_REQUIRE(x && out, "rgbd_colsum_bf16: null pointer");
+    RGBD_REQUIRE(M > 0 && C > 0 && C % 64 == 0, "rgbd_colsum_bf16: C must be a multiple of 64 (C=%d)", C);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(out, 0, (size_t)C * sizeof(float), st) != hipSuccess) {
+        rgbd_set_error("rgbd_colsum_bf16: memset failed");
+        return -2;
+    }
+    const int rows = 2048;
+    dim3 grid(ceil_div(M, rows), C / 64);
+    colsum_kernel<<<grid, 256, 0, st>>>((const unsigned short*)x, out, M, C, rows);
+    RGBD_CHECK_LAUNCH("colsum_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_from_planes(const float* x, const float* w, const float* bias, void* y, int B, int HW, int KP,
+                                int C, float wscale, int act, float slope, void* stream) {
+    RGBD_REQUIRE(x && w && y, "rgbd_from_planes: null pointer");
+    RGBD_REQUIRE((KP == 3 || KP == 4) && C % 8 == 0 && B > 0 && HW > 0, "rgbd_from_planes: bad shape KP=%d C=%d", KP, C);
+    const long nvec = (long)B * HW * C / 8;
+    const int blocks = (int)min((long)8192, (nvec + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    if (KP == 3) from_planes_kernel<3><<<blocks, 256, 0, st>>>(x, w, bias, (unsigned short*)y, B, HW, C, wscale, act, slope);
+    else         from_planes_kernel<4><<<blocks, 256, 0, st>>>(x, w, bias, (unsigned short*)y, B, HW, C, wscale, act, slope);
+    RGBD_CHECK_LAUNCH("from_planes_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_to_planes(const void* h, const float* w, const float* bias, float* out, int B, int HW, int KP,
+                              int C, float wscale, void* stream) {
+    RGBD_REQUIRE(h && w && out, "rgbd_to_planes: null pointer");
+    RGBD_REQUIRE((KP == 3 || KP == 4) && C % 64 == 0 && B > 0 && HW > 0, "rgbd_to_planes: bad shape KP=%d C=%d", KP, C);
+    const long npix = (long)B * HW;
+    const int blocks = (int)min((long)8192, (npix + 31) / 32);
+    hipStream_t st = (hipStream_t)stream;
+    if (KP == 3) to_planes_kernel<3><<<blocks, 256, 0, st>>>((const unsigned short*)h, w, bias, out, B, HW, C, wscale);
+    else         to_planes_kernel<4><<<blocks, 256, 0, st>>>((const unsigned short*)h, w, bias, out, B, HW, C, wscale);
+    RGBD_CHECK_LAUNCH("to_planes_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_planes_outer(const void* t, const float* p, float* o, float* tsum, int B, int HW, int KP, int C,
+                                 void* stream) {
+    RGBD_REQUIRE(t && p && o, "rgbd_planes_outer: null pointer");
+    RGBD_REQUIRE((KP == 3 || KP == 4) && C % 64 == 0 && B > 0 && HW > 0, "rgbd_planes_outer: bad shape KP=%d C=%d", KP, C);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(o, 0, (size_t)KP * C * sizeof(float), st) != hipSuccess ||
+        (tsum && hipMemsetAsync(tsum, 0, (size_t)C * sizeof(float), st) != hipSuccess)) {
+        rgbd_set_error("rgbd_planes_outer: memset failed");
+        return -2;
+    }
+    const int rows = 1024;
+    dim3 grid(ceil_div(HW, rows), C / 64, B);
+    if (KP == 3) planes_outer_kernel<3><<<grid, 256, 0, st>>>((const unsigned short*)t, p, o, tsum, B, HW, C, rows);
+    else         planes_outer_kernel<4><<<grid, 256, 0, st>>>((const unsigned short*)t, p, o, tsum, B, HW, C, rows);
+    RGBD_CHECK_LAUNCH("planes_outer_kernel");
     return 0;
 }
 

@@ -181,39 +181,141 @@ def lrelu(x):
     return F.leaky_relu(x, 0.2)
 
 
-class _ConvBiasLrelu(torch.autograd.Function):
-    """y = lrelu(conv(x, W) + b) with bias and activation fused into the MFMA kernel's epilogue
-    (net.py:144-152,155-159: c0/c1 -> L.Bias -> F.leaky_relu).  First-order only (generator path)."""
+class _LreluGrad(torch.autograd.Function):
+    """dz = dy * lrelu'(.) evaluated from the activation OUTPUT y; linear in dy, so its own backward is itself."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, layer, ups):
+    def forward(ctx, dy, y, act_channels):
+        ctx.act_channels = act_channels
+        ctx.save_for_backward(y)
+        return kernels.lrelu_bwd(dy.contiguous(), y, act_channels)
+
+    @staticmethod
+    def backward(ctx, ddz):
+        y, = ctx.saved_tensors
+        return _LreluGrad.apply(ddz.contiguous(), y, ctx.act_channels), None, None
+
+
+class _ColSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = x.shape
+        return kernels.colsum(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).expand(ctx.shape)
+
+
+class _ConvBiasAct(torch.autograd.Function):
+    """y = act(conv(x, W) + b + residual) with everything after the MFMA accumulation fused into the kernel's
+    epilogue (net.py:144-159 c -> L.Bias -> leaky_relu; net.py:410-416 c1(h) + shortcut -> leaky_relu).
+    The backward is assembled from differentiable pieces (lrelu-grad, dgrad, wgrad, column sum), so the R1 double
+    backward goes through it."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, residual, layer, ups, act):
         wf, _ = layer.packed()
         x = x.contiguous()
-        y = kernels.conv2d_fprop(x, wf, layer.K, layer.K, layer.pad, bias=bias.contiguous(), upsample=ups,
-                                 lrelu_channels=w.shape[0])
-        ctx.layer, ctx.ups = layer, ups
-        ctx.save_for_backward(x, y)
+        y = kernels.conv2d_fprop(x, wf, layer.K, layer.K, layer.pad, bias=bias.contiguous(),
+                                 residual=residual.contiguous() if residual is not None else None, upsample=ups,
+                                 lrelu_channels=w.shape[0] if act else 0)
+        ctx.layer, ctx.ups, ctx.act = layer, ups, act
+        ctx.save_for_backward(x, w, y)
         return y
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
-        x, y = ctx.saved_tensors
+        x, w, y = ctx.saved_tensors
         layer, ups = ctx.layer, ctx.ups
-        dz = torch.where(y > 0, dy, dy * 0.2).contiguous()
+        dz = _LreluGrad.apply(dy.contiguous(), y, w.shape[0]) if ctx.act else dy.contiguous()
+        dx = dw = db = dres = None
+        if ctx.needs_input_grad[0]:
+            dx = _ConvDgrad.apply(dz, w, layer, ups)
+        if ctx.needs_input_grad[1] and not _SKIP_WGRAD:
+            dw = _ConvWgrad.apply(x, dz, layer, ups)
+        if ctx.needs_input_grad[2] and not _SKIP_WGRAD:
+            db = _ColSum.apply(dz)
+        if ctx.needs_input_grad[3]:
+            dres = dz
+        return dx, dw, db, dres, None, None, None
+
+
+def conv_bias_lrelu(x, layer, bias, upsample=False, residual=None):
+    return _ConvBiasAct.apply(x, layer.weight, bias, residual, layer, bool(upsample), True)
+
+
+def conv_bias(x, layer, bias, upsample=False, residual=None):
+    return _ConvBiasAct.apply(x, layer.weight, bias, residual, layer, bool(upsample), False)
+
+
+# ---- 1x1 convolutions between NCHW fp32 image planes and NHWC bf16 features (fromRGB / toRGB)
+class _FromPlanes(torch.autograd.Function):
+    """y[b,p,c] = act(s * sum_k w[c][k] x[b,k,p] + bias[c])   (Discriminator.ins, net.py:449-455, 485,493-494)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, scale, act):
+        x = x.contiguous()
+        y = kernels.from_planes(x, w.contiguous(), bias.contiguous() if bias is not None else None, scale, act)
+        ctx.scale, ctx.act, ctx.has_bias = scale, act, bias is not None
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dz = _LreluGrad.apply(dy.contiguous(), y, y.shape[-1]) if ctx.act else dy.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            _, wd = layer.packed()
-            dx = kernels.conv2d_fprop(dz, wd, layer.K, layer.K, layer.K - 1 - layer.pad)
-            if ups:
-                dx = _sum_pool2(dx)
-        if ctx.needs_input_grad[1]:
-            xe = upsample2(x).contiguous() if ups else x
-            dw = kernels.conv2d_wgrad(xe, dz, layer.K, layer.inv_c)
-        if ctx.needs_input_grad[2]:
-            db = dz.float().sum(dim=(0, 1, 2))
+            dx = _ToPlanes.apply(dz, w.t(), None, ctx.scale)
+        if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and not _SKIP_WGRAD:
+            o, ts = _PlanesOuter.apply(dz, x, ctx.has_bias)
+            dw = o.t() * ctx.scale
+            db = ts if ctx.has_bias else None
         return dx, dw, db, None, None
 
 
-def conv_bias_lrelu(x, layer, bias, upsample=False):
-    return _ConvBiasLrelu.apply(x, layer.weight, bias, layer, bool(upsample))
+class _ToPlanes(torch.autograd.Function):
+    """out[b,k,p] = s * sum_c w[k][c] h[b,p,c] + bias[k]   (StyleGenerator.outs, net.py:186-191,270,289-290)."""
+
+    @staticmethod
+    def forward(ctx, h, w, bias, scale):
+        h = h.contiguous()
+        ctx.scale, ctx.has_bias = scale, bias is not None
+        ctx.save_for_backward(h, w)
+        return kernels.to_planes(h, w.contiguous(), bias.contiguous() if bias is not None else None, scale)
+
+    @staticmethod
+    def backward(ctx, dout):
+        h, w = ctx.saved_tensors
+        dout = dout.contiguous()
+        dh = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dh = _FromPlanes.apply(dout, w.t(), None, ctx.scale, False)
+        if ctx.needs_input_grad[1] and not _SKIP_WGRAD:
+            o, _ = _PlanesOuter.apply(h, dout, False)
+            dw = o * ctx.scale
+        if ctx.has_bias and ctx.needs_input_grad[2] and not _SKIP_WGRAD:
+            db = dout.sum(dim=(0, 2, 3))
+        return dh, dw, db, None
+
+
+class _PlanesOuter(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, planes, want_tsum):
+        o, ts = kernels.planes_outer(t.contiguous(), planes.contiguous(), want_tsum)
+        if ts is None:
+            ts = o.new_zeros(())
+        return o, ts
+
+    @staticmethod
+    def backward(ctx, go, gts):
+        raise NotImplementedError("third-order derivatives through the 1x1 plane kernels are not supported")
+
+
+def from_planes(x, w, bias, scale, act=True):
+    return _FromPlanes.apply(x, w, bias, float(scale), bool(act))
+
+
+def to_planes(h, w, bias, scale):
+    return _ToPlanes.apply(h, w, bias, float(scale))

@@ -160,6 +160,63 @@ def conv2d_wgrad(x, dy, K, scale, out=None, accumulate=False):
     return out
 
 
+# ------------------------------------------------------------------ fused elementwise / 1x1
+def lrelu_bwd(dy, y, act_channels, slope=0.2):
+    """dz = dy * (y > 0 ? 1 : slope) on channels [0, act_channels) of NHWC bf16 tensors."""
+    _chk(dy, BF16, "dy"); _chk(y, BF16, "y")
+    C = y.shape[-1]
+    dz = torch.empty_like(y)
+    rc = _lib.load().rgbd_lrelu_bwd(_ptr(dy), _ptr(y), _ptr(dz), y.numel() // C, C, int(act_channels), float(slope),
+                                    _stream())
+    _lib.check(rc, "rgbd_lrelu_bwd")
+    return dz
+
+
+def colsum(x):
+    """(.., C) bf16 -> (C,) fp32 column sums."""
+    _chk(x, BF16, "x")
+    C = x.shape[-1]
+    out = torch.empty(C, dtype=F32, device=x.device)
+    rc = _lib.load().rgbd_colsum_bf16(_ptr(x), _ptr(out), x.numel() // C, C, _stream())
+    _lib.check(rc, "rgbd_colsum_bf16")
+    return out
+
+
+def from_planes(x, w, bias, wscale, act, slope=0.2):
+    """x (B,KP,H,W) fp32, w (C,KP) fp32 -> (B,H,W,C) bf16 = act(wscale * w x + bias)."""
+    _chk(x, F32, "x"); _chk(w, F32, "w"); _chk(bias, F32, "bias")
+    B, KP, H, W = x.shape
+    C = w.shape[0]
+    y = torch.empty(B, H, W, C, dtype=BF16, device=x.device)
+    rc = _lib.load().rgbd_from_planes(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, H * W, KP, C, float(wscale),
+                                      int(bool(act)), float(slope), _stream())
+    _lib.check(rc, "rgbd_from_planes")
+    return y
+
+
+def to_planes(h, w, bias, wscale):
+    """h (B,H,W,C) bf16, w (KP,C) fp32 -> (B,KP,H,W) fp32 = wscale * w h + bias."""
+    _chk(h, BF16, "h"); _chk(w, F32, "w"); _chk(bias, F32, "bias")
+    B, H, W, C = h.shape
+    KP = w.shape[0]
+    out = torch.empty(B, KP, H, W, dtype=F32, device=h.device)
+    rc = _lib.load().rgbd_to_planes(_ptr(h), _ptr(w), _ptr(bias), _ptr(out), B, H * W, KP, C, float(wscale), _stream())
+    _lib.check(rc, "rgbd_to_planes")
+    return out
+
+
+def planes_outer(t, planes, want_tsum=False):
+    """t (B,H,W,C) bf16, planes (B,KP,H,W) fp32 -> o (KP,C) fp32 [, tsum (C,) fp32]."""
+    _chk(t, BF16, "t"); _chk(planes, F32, "planes")
+    B, H, W, C = t.shape
+    KP = planes.shape[1]
+    o = torch.empty(KP, C, dtype=F32, device=t.device)
+    ts = torch.empty(C, dtype=F32, device=t.device) if want_tsum else None
+    rc = _lib.load().rgbd_planes_outer(_ptr(t), _ptr(planes), _ptr(o), _ptr(ts), B, H * W, KP, C, _stream())
+    _lib.check(rc, "rgbd_planes_outer")
+    return o, ts
+
+
 # ------------------------------------------------------------------ AdaIN
 def adain_fwd(x, scale, shift, eps=1e-5):
     """x (B,H,W,C) bf16; scale, shift (B,C) fp32 -> y, mean, rstd."""

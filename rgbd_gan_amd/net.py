@@ -177,11 +177,10 @@ class StyleGenerator(_Link):
         return Fn.lrelu(F.linear(h * _inv_c(self.ch), p["l2/c/W"], p["l2/c/b"]))
 
     def _to_rgbd(self, i, h):
-        """outs[i]: 1x1 conv (gain 1) from NHWC bf16 to NCHW fp32; fp32 accumulate (bandwidth-bound, Cout=4)."""
+        """outs[i]: 1x1 conv (gain 1) from NHWC bf16 to NCHW fp32, fp32 accumulate (bandwidth-bound, Cout = 4)."""
         p = self.store.params
         W = p[f"outs/{i}/c/W"]
-        y = F.linear(h.float() * _inv_c(W.shape[1], 1.0), W.reshape(W.shape[0], W.shape[1]), p[f"outs/{i}/c/b"])
-        return y.permute(0, 3, 1, 2)
+        return Fn.to_planes(h, W.reshape(W.shape[0], W.shape[1]), p[f"outs/{i}/c/b"], _inv_c(W.shape[1], 1.0))
 
     def __call__(self, w, w2, stage, theta=None, add_noise=True, return_feature=False):
         st, alpha = _split_stage(stage, self.max_stage)
@@ -304,8 +303,7 @@ class DCGANGenerator(_Link):
     def _to_rgbd(self, i, h):
         p = self.store.params
         W = p[f"outs/{i}/c/W"]
-        y = F.linear(h.float() * _inv_c(W.shape[1], 1.0), W.reshape(W.shape[0], W.shape[1]), p[f"outs/{i}/c/b"])
-        return y.permute(0, 3, 1, 2)
+        return Fn.to_planes(h, W.reshape(W.shape[0], W.shape[1]), p[f"outs/{i}/c/b"], _inv_c(W.shape[1], 1.0))
 
     def __call__(self, z, stage, theta=None, style_mixing_rate=None, add_noise=True, return_feature=False):
         z = _as_device_tensor(z, self.device).reshape(-1, self.in_ch)
@@ -372,27 +370,27 @@ class Discriminator(_Link):
                 self.conv[f"blocks/{i}/{nm}"] = Fn.ConvLayer(p[f"blocks/{i}/{nm}/c/W"], _inv_c(cin * 9), 1)
 
     def _from_rgb(self, i, x):
-        """ins[i]: 1x1 conv 3 -> C on the NCHW fp32 image, + bias, leaky ReLU, to NHWC bf16 (bandwidth-bound)."""
+        """ins[i]: 1x1 conv 3 -> C on the NCHW fp32 image, + bias, leaky ReLU, to NHWC bf16 (one HBM-bound kernel)."""
         p = self.store.params
         W = p[f"ins/{i}/c/W"]
-        h = F.linear(x.permute(0, 2, 3, 1) * _inv_c(3), W.reshape(W.shape[0], 3), p[f"ins/{i}/c/b"])
-        return Fn.lrelu(h).to(BF16)
+        return Fn.from_planes(x, W.reshape(W.shape[0], 3), p[f"ins/{i}/c/b"], _inv_c(3), act=True)
 
     def _block(self, i, x):
         p = self.store.params
         pre = f"blocks/{i}"
         if i == 0:
-            h = Fn.lrelu(Fn.conv(x, self.conv[pre + "/c0"]) + p[pre + "/c0/c/b"].to(BF16))
+            h = Fn.conv_bias_lrelu(x, self.conv[pre + "/c0"], p[pre + "/c0/c/b"])
             W = p[pre + "/c1/c/W"]                                     # 4x4 valid conv == linear over (h,w,c)
             Wm = W.permute(0, 2, 3, 1).reshape(W.shape[0], -1)
             h = F.linear(h.float().reshape(h.shape[0], -1) * _inv_c(W.shape[1] * 16), Wm, p[pre + "/c1/c/b"])
             h = Fn.lrelu(h)
             return F.linear(h * _inv_c(self.ch, 1.0), p[pre + "/l2/c/W"], p[pre + "/l2/c/b"])
-        h = Fn.lrelu(Fn.conv(x, self.conv[pre + "/c0"]) + p[pre + "/c0/c/b"].to(BF16))
-        h = Fn.conv(h, self.conv[pre + "/c1"]) + p[pre + "/c1/c/b"].to(BF16)
-        if self.res:
-            h = h + (Fn.conv(x, self.conv[pre + "/c_sc"]) + p[pre + "/c_sc/c/b"].to(BF16))
-        return Fn.avg_pool2_nhwc(Fn.lrelu(h))
+        # net.py:408-426: h = lrelu(c0 x); h = lrelu(c1 h + c_sc x); avg-pool.  Bias, shortcut add and activation
+        # all ride in the conv epilogues.
+        h = Fn.conv_bias_lrelu(x, self.conv[pre + "/c0"], p[pre + "/c0/c/b"])
+        sc = Fn.conv_bias(x, self.conv[pre + "/c_sc"], p[pre + "/c_sc/c/b"]) if self.res else None
+        h = Fn.conv_bias_lrelu(h, self.conv[pre + "/c1"], p[pre + "/c1/c/b"], residual=sc)
+        return Fn.avg_pool2_nhwc(h)
 
     def __call__(self, x, stage, return_hidden=False):
         x = _as_device_tensor(x, self.device)

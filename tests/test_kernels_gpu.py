@@ -219,3 +219,44 @@ def test_adam_clip_matches_chainer_restatement(gnorm_scale):
         assert abs(float(norm.item()) - ref_norm) < 1e-4 * ref_norm
         ref = torch.cat([params["a"].detach(), params["b"].detach()])
         torch.testing.assert_close(pd.cpu(), ref, atol=1e-6, rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ fused elementwise / 1x1
+def test_lrelu_bwd_and_colsum():
+    from rgbd_gan_amd import kernels
+    g = torch.Generator().manual_seed(2)
+    y = bf16_round(torch.randn(3, 8, 8, 128, generator=g))
+    dy = bf16_round(torch.randn(3, 8, 8, 128, generator=g))
+    dz = kernels.lrelu_bwd(dy.to(dev()).to(torch.bfloat16), y.to(dev()).to(torch.bfloat16), 64)
+    ref = dy.clone()
+    ref[..., :64] = torch.where(y[..., :64] > 0, dy[..., :64], dy[..., :64] * 0.2)
+    torch.testing.assert_close(dz.float().cpu(), bf16_round(ref), atol=1e-6, rtol=1e-6)
+    cs = kernels.colsum(dy.to(dev()).to(torch.bfloat16))
+    torch.testing.assert_close(cs.cpu(), dy.reshape(-1, 128).sum(0), atol=1e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,H,C,KP", [(2, 16, 64, 3), (3, 8, 256, 3), (2, 32, 128, 4)])
+def test_plane_kernels_match_oracle(B, H, C, KP):
+    from rgbd_gan_amd import kernels
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, KP, H, H, generator=g)
+    w = torch.randn(C, KP, generator=g)
+    b = torch.randn(C, generator=g)
+    s = 0.7
+    ref = F.leaky_relu(F.conv2d(x * s, w.reshape(C, KP, 1, 1), b), 0.2)
+    y = kernels.from_planes(x.to(dev()), w.to(dev()), b.to(dev()), s, True)
+    torch.testing.assert_close(y.float().cpu().permute(0, 3, 1, 2), ref, atol=2e-2, rtol=1e-2)
+    # to_planes: h NHWC bf16 -> planes
+    h = bf16_round(torch.randn(B, C, H, H, generator=g))
+    w2 = torch.randn(KP, C, generator=g)
+    b2 = torch.randn(KP, generator=g)
+    ref2 = F.conv2d(h * s, w2.reshape(KP, C, 1, 1), b2)
+    hd = h.permute(0, 2, 3, 1).contiguous().to(dev()).to(torch.bfloat16)
+    out = kernels.to_planes(hd, w2.to(dev()), b2.to(dev()), s)
+    torch.testing.assert_close(out.cpu(), ref2, atol=1e-3 * C ** 0.5, rtol=1e-4)
+    # planes_outer: o[k][c] = sum planes[b,k,p] * t[b,p,c]
+    o, ts = kernels.planes_outer(hd, x.to(dev()), True)
+    ref_o = torch.einsum("bkhw,bchw->kc", x, h)
+    torch.testing.assert_close(o.cpu(), ref_o, atol=1e-3 * float(ref_o.abs().max()), rtol=1e-4)
+    torch.testing.assert_close(ts.cpu(), h.sum(dim=(0, 2, 3)), atol=1e-3 * float(h.sum(dim=(0, 2, 3)).abs().max()) + 1e-3,
+                               rtol=1e-4)
