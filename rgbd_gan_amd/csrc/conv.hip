@@ -217,6 +217,197 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(ConvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ 3x3 patch kernel
+// The hot fprop/dgrad kernel for 3x3 pad-1 convolutions on images of 16x16 and larger.
+//
+// One 512-thread workgroup (8 waves, one per CU) owns a 16x16 patch of output pixels x BN output channels.
+// Per 64-channel slice of the input it stages the 18x18 halo patch ONCE (10x10 when the nearest-2x upsample
+// is folded in) and runs all nine filter taps out of LDS: the im2col expansion (9x re-read of every input
+// pixel) happens in LDS addressing, not in L2/HBM traffic.  Per K step (one tap x 64 channels) only the BN x 64
+// weight tile is fetched (L2-resident, three LDS buffers, register prefetch two steps ahead).  Global->LDS
+// traffic per K step drops from 32 KB per 128 pixels (gather kernel above) to ~20 KB per 256 pixels.
+//   MFMA operands: A = weight rows (K contiguous), B = halo-patch pixel rows.  A lane's LDS address is
+//   (per-lane term depending only on the horizontal tap) + (compile-time row offset), so the unrolled tap loop
+//   needs six address VGPRs; the 16-byte chunk index is XORed with (halo column & 7), which keeps ds_read_b128
+//   conflict-free for every tap shift (the halo width is even, so row parity == column parity).
+template <int BN, bool UPS>
+__global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(ConvArgs a) {
+    constexpr int HPW = UPS ? 10 : 18;            // halo patch width (and height)
+    constexpr int NROWS = HPW * HPW;
+    constexpr int P_BYTES = 18 * 18 * 128;
+    constexpr int W_BYTES = BN * 128;
+    constexpr int WAVES_CO = BN / 64;
+    constexpr int WAVES_PX = 8 / WAVES_CO;
+    constexpr int PX_PER_WAVE = 256 / WAVES_PX;   // 64 or 32 pixels = 4 or 2 patch rows
+    constexpr int TPX = PX_PER_WAVE / 16;
+    constexpr int WP = BN / 64;                   // weight pieces (16 B) staged per thread per K step
+    constexpr int PP = (NROWS * 8 + 511) / 512;   // halo pieces per thread per channel slice (6 or 2)
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    unsigned char* const patch_lds = dsm;                       // [2][P_BYTES]
+    unsigned char* const w_lds = dsm + 2 * P_BYTES;             // [3][W_BYTES]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int n_tiles = a.Cout / BN;
+    unsigned bid = blockIdx.x;
+    {
+        const unsigned nwg = gridDim.x, xcd = bid & 7u, q8 = nwg >> 3, r8 = nwg & 7u;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    }
+    const int nt = bid % n_tiles;
+    const int pt = bid / n_tiles;
+    const int tiles_x = a.Wout >> 4, tiles_y = a.Hout >> 4;
+    const int b = pt / (tiles_x * tiles_y);
+    const int rem = pt - b * tiles_x * tiles_y;
+    const int ty = rem / tiles_x;
+    const int y0 = ty << 4, x0 = (rem - ty * tiles_x) << 4;
+    const int n0 = nt * BN;
+    const int wave_co = (wid / WAVES_PX) * 64;
+    const int wave_py = (wid % WAVES_PX) * TPX;                  // first patch row of this wave
+
+    const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.x), 0, a.x_bytes, 0x00020000);
+    const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.wp), 0, a.w_bytes, 0x00020000);
+
+    // ---- halo staging plan (fixed per thread).  Channel slice / tap offsets are wave-uniform and go into the
+    //      scalar offset operand of the buffer loads, so these stay the only address VGPRs.
+    const int hy0 = UPS ? (y0 >> 1) - 1 : y0 - 1, hx0 = UPS ? (x0 >> 1) - 1 : x0 - 1;
+    unsigned psrc[PP];
+    int pdst[PP];
+#pragma unroll
+    for (int i = 0; i < PP; ++i) {
+        const int p = tid + 512 * i;
+        const int row = p >> 3, ch8 = p & 7;
+        const int hy = row / HPW, hx = row - hy * HPW;
+        const int yy = hy0 + hy, xx = hx0 + hx;
+        const bool ok = row < NROWS && (unsigned)yy < (unsigned)a.Hin && (unsigned)xx < (unsigned)a.Win;
+        psrc[i] = ok ? (unsigned)((((b * a.Hin + yy) * a.Win + xx) * a.Cin + ch8 * 8) * 2) : 0x80000000u;
+        pdst[i] = row < NROWS ? row * 128 + ((ch8 ^ (hx & 7)) << 4) : -1;
+    }
+    const int wrow = tid >> 3, wch8 = tid & 7;
+    const int wdst = wrow * 128 + ((wch8 ^ (wrow & 7)) << 4);
+    const unsigned wsrc0 = (unsigned)(((n0 + wrow) * a.Cin + wch8 * 8) * 2);
+    const int tap_stride = a.Cout * a.Cin * 2;
+    const int row64_stride = 64 * a.Cin * 2;
+
+    const int nc = a.Cin >> 6;
+    u32x4 Pr[PP], Wr[3][WP];
+    auto load_patch = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < PP; ++i) Pr[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, psrc[i], c * 128, 0);
+    };
+    auto store_patch = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PP; ++i)
+            if (pdst[i] >= 0) *reinterpret_cast<u32x4*>(patch_lds + buf * P_BYTES + pdst[i]) = Pr[i];
+    };
+    auto load_w = [&](int c, int t, u32x4 (&R)[WP]) {
+#pragma unroll
+        for (int i = 0; i < WP; ++i)
+            R[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wsrc0, t * tap_stride + i * row64_stride + c * 128, 0);
+    };
+    auto store_w = [&](int buf, const u32x4 (&R)[WP]) {
+#pragma unroll
+        for (int i = 0; i < WP; ++i) *reinterpret_cast<u32x4*>(w_lds + buf * W_BYTES + wdst + i * 64 * 128) = R[i];
+    };
+
+    f32x4 acc[4][TPX];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TPX; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int r16 = lane & 15, q = lane >> 4;
+    int aoff[2], boff[3][2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        aoff[s2] = (wave_co + r16) * 128 + (((4 * s2 + q) ^ (r16 & 7)) << 4);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int colx = UPS ? ((r16 + kw - 1) >> 1) + 1 : r16 + kw;
+            const int row0 = UPS ? (wave_py >> 1) : wave_py;
+            boff[kw][s2] = (row0 * HPW + colx) * 128 + (((4 * s2 + q) ^ (colx & 7)) << 4);
+        }
+    }
+
+    auto compute = [&](const unsigned char* pbuf, const unsigned char* wbuf, int kh, int kw) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 af[4], bfr[TPX];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                af[i] = *reinterpret_cast<const bf16x8*>(wbuf + aoff[s2] + i * 16 * 128);
+#pragma unroll
+            for (int j = 0; j < TPX; ++j) {
+                const int rj = UPS ? ((j + kh - 1) >> 1) + 1 : j + kh;   // compile-time after unrolling
+                bfr[j] = *reinterpret_cast<const bf16x8*>(pbuf + boff[kw][s2] + rj * HPW * 128);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < TPX; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // ---- prologue
+    load_patch(0);
+    load_w(0, 0, Wr[0]);
+    load_w(0, 1, Wr[1]);
+    store_patch(0);
+    store_w(0, Wr[0]);
+    load_patch(min(1, nc - 1));
+    __syncthreads();
+    // ---- main loop: nine statically unrolled tap steps per 64-channel slice; every memory operation is
+    //      unconditional (indices clamp at the tail) so hipcc keeps counted vmcnt waits across the barriers
+    for (int c = 0; c < nc; ++c) {
+        const unsigned char* pbuf = patch_lds + (c & 1) * P_BYTES;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int t2 = (t + 2) % 9;
+            const int c2 = min(c + (t + 2) / 9, nc - 1);
+            load_w(c2, t2, Wr[(t + 2) % 3]);
+            compute(pbuf, w_lds + (t % 3) * W_BYTES, t / 3, t % 3);
+            store_w((t + 1) % 3, Wr[(t + 1) % 3]);
+            if (t == 6) store_patch((c + 1) & 1);
+            if (t == 7) {
+                asm volatile("" ::: "memory");
+                load_patch(min(c + 2, nc - 1));
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: bias -> residual -> leaky ReLU -> bf16 NHWC
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int co = n0 + wave_co + i * 16 + 4 * q;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(a.bias + co);
+            bv[0] = t[0]; bv[1] = t[1]; bv[2] = t[2]; bv[3] = t[3];
+        }
+        const bool act = co < a.lrelu_ch;
+#pragma unroll
+        for (int j = 0; j < TPX; ++j) {
+            const int yy = y0 + wave_py + j, xx = x0 + r16;
+            const long o = (((long)b * a.Hout + yy) * a.Wout + xx) * a.Cout + co;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[r];
+            if (a.resid) {
+                const u32x2 rr = *reinterpret_cast<const u32x2*>(a.resid + o);
+                v[0] += bf16_lo(rr[0]); v[1] += bf16_hi(rr[0]);
+                v[2] += bf16_lo(rr[1]); v[3] += bf16_hi(rr[1]);
+            }
+            if (act) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : v[r] * a.slope;
+            }
+            u32x2 out = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            *reinterpret_cast<u32x2*>(a.y + o) = out;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ wgrad
 struct WgradArgs {
     const unsigned short* x;
@@ -340,6 +531,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+bool g_force_gather = false;   // test hook: route every shape through the generic gather kernel
+
 int ilog2(int v) {
     int l = 0;
     while ((1 << l) < v) ++l;
@@ -347,6 +540,11 @@ int ilog2(int v) {
 }
 
 }  // namespace
+
+extern "C" int rgbd_debug_force_gather_kernel(int on) {
+    g_force_gather = on != 0;
+    return 0;
+}
 
 extern "C" int rgbd_conv2d_fprop_bf16(const void* x, const void* wp, const float* bias, const void* residual,
                                       void* y, int B, int Hin, int Win, int Cin, int Cout, int KH, int KW, int pad,
@@ -374,6 +572,27 @@ extern "C" int rgbd_conv2d_fprop_bf16(const void* x, const void* wp, const float
     a.M = (long)B * a.Hout * a.Wout;
     const long mtiles = (a.M + 127) / 128;
     hipStream_t st = (hipStream_t)stream;
+    if (KH == 3 && KW == 3 && pad == 1 && a.Hout % 16 == 0 && a.Wout % 16 == 0 && !g_force_gather) {
+        const bool wide = Cout % 128 == 0;
+        const long grid = (long)B * (a.Hout / 16) * (a.Wout / 16) * (wide ? Cout / 128 : Cout / 64);
+        RGBD_REQUIRE(grid < 0x7fffffffL, "rgbd_conv2d_fprop_bf16: grid too large");
+        const int lds = 2 * 324 * 128 + 3 * (wide ? 128 : 64) * 128;
+        const void* fn = wide ? (a.ups ? (const void*)&conv3x3_patch_kernel<128, true>
+                                       : (const void*)&conv3x3_patch_kernel<128, false>)
+                              : (a.ups ? (const void*)&conv3x3_patch_kernel<64, true>
+                                       : (const void*)&conv3x3_patch_kernel<64, false>);
+        RGBD_REQUIRE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess,
+                     "rgbd_conv2d_fprop_bf16: cannot reserve %d B of LDS", lds);
+        if (wide) {
+            if (a.ups) conv3x3_patch_kernel<128, true><<<(unsigned)grid, 512, lds, st>>>(a);
+            else       conv3x3_patch_kernel<128, false><<<(unsigned)grid, 512, lds, st>>>(a);
+        } else {
+            if (a.ups) conv3x3_patch_kernel<64, true><<<(unsigned)grid, 512, lds, st>>>(a);
+            else       conv3x3_patch_kernel<64, false><<<(unsigned)grid, 512, lds, st>>>(a);
+        }
+        RGBD_CHECK_LAUNCH("conv3x3_patch_kernel");
+        return 0;
+    }
     if (Cout % 128 == 0) {
         const long grid = mtiles * (Cout / 128);
         RGBD_REQUIRE(grid < 0x7fffffffL, "rgbd_conv2d_fprop_bf16: grid too large");

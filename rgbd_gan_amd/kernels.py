@@ -128,7 +128,9 @@ def conv2d_fprop(x, wp, KH, KW, pad, bias=None, residual=None, upsample=False, l
     lib = _lib.load()
     flops = 2.0 * B * Hout * Wout * Cout * Cin * KH * KW
     nbytes = 2.0 * (x.numel() + y.numel() + wp.numel() + (residual.numel() if residual is not None else 0))
-    rc = _timed(f"conv_fprop_kernel<{128 if Cout % 128 == 0 else 64}>", flops, nbytes,
+    patch = KH == 3 and KW == 3 and pad == 1 and Hout % 16 == 0 and Wout % 16 == 0
+    kname = ("conv3x3_patch_kernel" if patch else "conv_fprop_kernel") + f"<{128 if Cout % 128 == 0 else 64}>"
+    rc = _timed(kname, flops, nbytes,
                 lambda: lib.rgbd_conv2d_fprop_bf16(_ptr(x), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(y), B, H, W,
                                                    Cin, Cout, KH, KW, pad, int(bool(upsample)), int(lrelu_channels),
                                                    float(slope), _stream()))

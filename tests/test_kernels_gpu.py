@@ -109,6 +109,13 @@ CONV_CASES = [
     (2, 16, 16, 128, 128, 3, 1, False, True, 128, True),  # residual add, then lrelu
     (1, 32, 32, 64, 64, 1, 0, False, True, 64, False),    # 1x1
     (4, 1, 1, 256, 256, 4, 3, False, False, 0, False),    # "full" conv: dgrad of the 4x4 valid conv
+    # halo-patch kernel (3x3 pad 1, >= 16x16): several patches per image, several channel slices, both widths
+    (3, 32, 32, 256, 128, 3, 1, False, True, 128, False),
+    (2, 64, 64, 64, 64, 3, 1, False, True, 64, True),
+    (1, 128, 128, 64, 128, 3, 1, False, False, 0, False),
+    (2, 16, 16, 256, 128, 3, 1, True, True, 128, False),   # upsample 16 -> 32, Cin 256
+    (3, 32, 32, 128, 64, 3, 1, True, True, 64, False),     # upsample 32 -> 64, narrow output
+    (2, 8, 8, 64, 256, 3, 1, True, False, 0, False),       # upsample 8 -> 16 (single patch)
 ]
 
 
@@ -260,3 +267,23 @@ def test_plane_kernels_match_oracle(B, H, C, KP):
     torch.testing.assert_close(o.cpu(), ref_o, atol=1e-3 * float(ref_o.abs().max()), rtol=1e-4)
     torch.testing.assert_close(ts.cpu(), h.sum(dim=(0, 2, 3)), atol=1e-3 * float(h.sum(dim=(0, 2, 3)).abs().max()) + 1e-3,
                                rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,ups", [(2, 128, 64, 128, False), (2, 64, 128, 64, True), (4, 32, 256, 256, False)])
+def test_patch_kernel_agrees_with_gather_kernel(B, H, Cin, Cout, ups):
+    """Two independent implementations of the same convolution (halo-patch vs generic gather) at layer sizes."""
+    from rgbd_gan_amd import _lib, kernels
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, H, H, Cin, generator=g).to(dev()).to(torch.bfloat16)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g).to(dev())
+    bias = torch.randn(Cout, generator=g).to(dev())
+    wf, _ = kernels.pack_weights(w, float(np.sqrt(2.0 / (Cin * 9))), True, False)
+    y_patch = kernels.conv2d_fprop(x, wf, 3, 3, 1, bias=bias, upsample=ups, lrelu_channels=Cout)
+    lib = _lib.load()
+    lib.rgbd_debug_force_gather_kernel(1)
+    try:
+        y_gather = kernels.conv2d_fprop(x, wf, 3, 3, 1, bias=bias, upsample=ups, lrelu_channels=Cout)
+    finally:
+        lib.rgbd_debug_force_gather_kernel(0)
+    # same bf16 inputs, fp32 accumulation in a different order, one bf16 rounding at the end
+    torch.testing.assert_close(y_patch.float(), y_gather.float(), atol=2e-2, rtol=8e-3)
