@@ -108,6 +108,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         upd.update()
+    t_enqueue = time.perf_counter() - t0          # host time to enqueue the steps (GPU still running)
     sync()
     elapsed = comm.max_over_ranks(time.perf_counter() - t0)
     upd._check_finite()
@@ -121,16 +122,20 @@ def main():
         "config": {"workload": f"{os.path.basename(args.config)} stage {upd.stage:.2f} (128x128), RGBDUpdater.update_core, "
                                f"StyleGAN ch={config.ch}, rotation+occlusion loss on, R1 on",
                    "per_gpu_batch": B, "global_batch": B * comm.size, "parallelism": f"dp{comm.size}"},
+        "host_enqueue_ms_per_step": round(t_enqueue / args.steps * 1e3, 3),
         "step_tflops_algorithmic": round(value * STEP_GFLOP_PER_IMAGE / 1e3, 2),
         "mfma_roofline_frac_whole_step": round(value * STEP_GFLOP_PER_IMAGE / 1e3 / (MFMA_BF16_PEAK_TFLOPS * comm.size), 4),
     }
 
     if comm.rank == 0 and not args.no_roofline:
         # per-launch HIP-event timing of the conv kernels over extra (untimed) steps, on the launch stream
+        # (eager launches: graph replays bypass the Python wrappers that record the events)
+        upd.use_graphs = False
         with kernels.launch_profile() as prof:
             for _ in range(2):
                 upd.update()
         summ = prof.summary()
+        upd.use_graphs = True
         table = {k: {"launches": n, "ms": round(t * 1e3, 3), "tflops": round(f / t / 1e12, 1),
                      "avg_us": round(t / n * 1e6, 1), "gbps": round(b / t / 1e9, 1)} for k, (n, t, f, b) in summ.items()}
         dom = max(summ, key=lambda k: summ[k][1])

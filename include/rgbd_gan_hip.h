@@ -118,8 +118,8 @@ int rgbd_adain_bwd(const void* x, const void* dy, const float* scale, const floa
  * rgbd_colsum_bf16: out[c] = sum_m x[m][c] (fp32): bias gradients of the convs.
  */
 int rgbd_lrelu_bwd(const void* dy, const void* y, void* dz, int64_t M, int C, int act_channels, float slope,
-                   void* stream);
-int rgbd_colsum_bf16(const void* x, float* out, int64_t M, int C, void* stream);
+                   float* bias_grad /* NULL, or (C) fp32: += column sums of dz in the same pass */, void* stream);
+int rgbd_colsum_bf16(const void* x, float* out, int64_t M, int C, int accumulate, void* stream);
 
 /* 1x1 convolutions between NCHW fp32 image planes (KP = 3 or 4 channels) and NHWC bf16 features (C channels):
  *   rgbd_from_planes: y[b,p,co] = act(wscale * sum_k w[co][k] x[b,k,p] + bias[co])   -- Discriminator.ins, net.py:449-455
@@ -141,15 +141,17 @@ int rgbd_planes_outer(const void* t, const float* planes, float* o, float* tsum,
  *   p, g, m, v : flat fp32 buffers of n elements (all parameters of one optimizer, contiguous).
  *   grad_scale : multiplied into g first (1/world_size after an all-reduce(sum)).
  *   Global L2 norm of grad_scale*g is computed on the device; rate = min(1, clip/norm).
- *   Segments (HOST arrays, nseg entries): seg_begin[i] .. seg_begin[i+1] (seg_begin has nseg+1 entries)
- *   use step size alpha_t[i] = alpha_i * sqrt(1-beta2^t) / (1-beta1^t), computed by the caller.
+ *   Segments (HOST arrays): seg_begin[i] .. seg_begin[i+1] (nseg+1 entries) use base step size seg_alpha[i].
+ *   step: device int32 holding chainer's update counter t; the call increments it and applies the bias correction
+ *         alpha_t = alpha * sqrt(1-beta2^t) / (1-beta1^t) on the device, so the launch sequence and its arguments are
+ *         identical every iteration (the whole training step can be captured in a HIP graph).
  *   m += (1-b1)(g-m); v += (1-b2)(g*g-v); p -= alpha_t * m / (sqrt(v) + eps)   (eps outside the correction)
  *   workspace: >= 1024 + 8 floats.  norm_out: optional device float receiving the pre-clip norm.
  */
 int rgbd_adam_clip_multi(float* p, float* g, float* m, float* v, int64_t n,
-                         int nseg, const int64_t* seg_begin, const float* seg_alpha_t,
+                         int nseg, const int64_t* seg_begin, const float* seg_alpha,
                          float beta1, float beta2, float eps, float clip, float grad_scale,
-                         float* workspace, float* norm_out, void* stream);
+                         int32_t* step, float* workspace, float* norm_out, void* stream);
 
 #ifdef __cplusplus
 }

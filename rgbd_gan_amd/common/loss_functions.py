@@ -88,6 +88,21 @@ class LossFuncRotate:
         return np.concatenate([A.reshape(b, 9), c.reshape(b, 3), A2.reshape(b, 9), c2.reshape(b, 3)],
                               axis=1).astype("float32")
 
+    def coefficients_for_size(self, size, theta, theta_rot):
+        """Host half of __call__: (re)build the intrinsics for `size` like the reference does on a size change,
+        then return the (b,24) warp constants.  Lets a caller upload them itself (HIP-graph replays)."""
+        if self.size != size:
+            self.init_params(self.xp, size=size)
+        return self.coefficients(theta, theta_rot)
+
+    def loss_from_coefficients(self, img, img_rot, coef, occlusion_aware=False, max_depth=None, min_depth=None):
+        """Device half of __call__: the fused warp-loss kernels on constants already resident on the device."""
+        flags = (WARP_OCCLUSION if occlusion_aware else 0) | (WARP_MAX_DEPTH if max_depth is not None else 0) | \
+                (WARP_MIN_DEPTH if min_depth is not None else 0)
+        return Fn.warp_loss(img, img_rot, coef, flags, self.lambda_geometric,
+                            0.0 if max_depth is None else float(max_depth),
+                            0.0 if min_depth is None else float(min_depth))
+
     def __call__(self, img, theta, img_rot, theta_rot, occlusion_aware=False, debug=False, max_depth=None,
                  min_depth=None):
         if self.norm != "l1":

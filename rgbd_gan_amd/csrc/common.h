@@ -18,6 +18,11 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 void rgbd_set_error(const char* fmt, ...);
 
+// Zero `bytes` (multiple of 4) with a kernel launch instead of hipMemsetAsync: identical in eager mode, and inside
+// a captured HIP graph it is an ordinary kernel node in the dependency chain (memset nodes proved unreliable on
+// replay with ROCm 7.2).  Returns hipSuccess or the launch error.
+hipError_t rgbd_zero_async(void* ptr, size_t bytes, hipStream_t stream);
+
 #define RGBD_REQUIRE(cond, ...)            \
     do {                                   \
         if (!(cond)) {                     \

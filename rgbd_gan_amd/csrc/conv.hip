@@ -417,6 +417,7 @@ struct WgradArgs {
     int PH, PW, lgPW;      // patch of output pixels (powers of two)
     int npx, npy;          // patches per image along x / y
     int total_patches, patches_per_wg;
+    int x_bytes, y_bytes;
 };
 
 __device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p) {
@@ -429,6 +430,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
     constexpr int HALO = NT == 9 ? 1 : 0;
     constexpr int KW = NT == 9 ? 3 : 1;
     constexpr int MAX_X_ROWS = (8 + 2 * HALO) * (16 + 2 * HALO);
+    constexpr int XP = (MAX_X_ROWS * 8 + 255) / 256;   // 16-byte pieces of the X halo patch per thread (6 / 4)
+    constexpr int YP = 4;                              // pieces of the dY patch per thread (128 rows)
     __shared__ __attribute__((aligned(16))) unsigned char xs[MAX_X_ROWS * 128];
     __shared__ __attribute__((aligned(16))) unsigned char ys[128 * 128];
 
@@ -438,6 +441,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
     const int HPW = a.PW + 2 * HALO, HPH = a.PH + 2 * HALO;
     const int npix = a.PH * a.PW;
     const int xrows = HPH * HPW;
+    const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.x), 0, a.x_bytes, 0x00020000);
+    const auto yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.dy), 0, a.y_bytes, 0x00020000);
 
     f32x16 acc[NT];
 #pragma unroll
@@ -452,33 +457,68 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
     const int a_col_bytes = (wc * 32 + m_base + 4 * pp) * 2;
     const int b_col_bytes = (wi * 32 + m_base + 4 * pp) * 2;
 
-    const int p_begin = blockIdx.x * a.patches_per_wg;
-    const int p_end = min(a.total_patches, p_begin + a.patches_per_wg);
-    for (int patch = p_begin; patch < p_end; ++patch) {
-        const int per_img = a.npx * a.npy;
+    // ---- staging plan: patch-independent parts of the source offsets / LDS destinations of this thread's pieces.
+    //      Pieces outside the halo patch or outside the image load through an out-of-range buffer offset (zeros).
+    int xrel[XP], xdst[XP], yrel[YP], ydst[YP];
+    short xhy[XP], xhx[XP];
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+        const int pc = tid + 256 * i;
+        const int row = pc >> 3, chunk = pc & 7;
+        const int hy = row / HPW, hx = row - hy * HPW;
+        const bool in = row < xrows;
+        xhy[i] = in ? (short)(hy - HALO) : (short)-30000;
+        xhx[i] = (short)(hx - HALO);
+        xrel[i] = (((hy - HALO) * a.W + (hx - HALO)) * a.Cin + ci0 + chunk * 8) * 2;
+        xdst[i] = in ? row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4) : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < YP; ++i) {
+        const int pc = tid + 256 * i;
+        const int row = pc >> 3, chunk = pc & 7;
+        const int py = row >> a.lgPW, px = row & (a.PW - 1);
+        const bool in = row < npix;
+        yrel[i] = in ? ((py * a.W + px) * a.Cout + co0 + chunk * 8) * 2 : (int)0x80000000;
+        ydst[i] = in ? row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4) : -1;
+    }
+    u32x4 Xr[XP], Yr[YP];
+    const int per_img = a.npx * a.npy;
+    auto load_patch = [&](int patch) {
         const int b = patch / per_img;
         const int rem = patch - b * per_img;
         const int pyi = rem / a.npx;
         const int y0 = pyi * a.PH, x0 = (rem - pyi * a.npx) * a.PW;
-        // ---- stage X halo patch (zero outside the image) and dY patch, pixel-major, 64 channels = 128 B per row;
-        //      bit 6 of the in-row byte offset is XORed with bit 1 of the row so 4 consecutive rows x 64 B cover
-        //      all 64 banks once for ds_read_b64_tr_b16.
-        for (int pc = tid; pc < xrows * 8; pc += 256) {
-            const int row = pc >> 3, chunk = pc & 7;
-            const int hy = row / HPW, hx = row - hy * HPW;
-            const int yy = y0 + hy - HALO, xx = x0 + hx - HALO;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W)
-                v = ldg16(a.x + (((long)b * a.H + yy) * a.W + xx) * a.Cin + ci0 + chunk * 8);
-            *reinterpret_cast<u32x4*>(xs + row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4)) = v;
+        const int xbase = ((b * a.H + y0) * a.W + x0) * a.Cin * 2;
+        const int ybase = ((b * a.H + y0) * a.W + x0) * a.Cout * 2;
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            const bool ok = (unsigned)(y0 + xhy[i]) < (unsigned)a.H && (unsigned)(x0 + xhx[i]) < (unsigned)a.W;
+            Xr[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (unsigned)(xbase + xrel[i]) : 0x80000000u, 0, 0);
         }
-        for (int pc = tid; pc < npix * 8; pc += 256) {
-            const int row = pc >> 3, chunk = pc & 7;
-            const int py = row >> a.lgPW, px = row & (a.PW - 1);
-            const u32x4 v = ldg16(a.dy + (((long)b * a.H + y0 + py) * a.W + x0 + px) * a.Cout + co0 + chunk * 8);
-            *reinterpret_cast<u32x4*>(ys + row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4)) = v;
-        }
-        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < YP; ++i)
+            Yr[i] = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, (unsigned)yrel[i] + (unsigned)ybase, 0, 0);
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int i = 0; i < XP; ++i)
+            if (xdst[i] >= 0) *reinterpret_cast<u32x4*>(xs + xdst[i]) = Xr[i];
+#pragma unroll
+        for (int i = 0; i < YP; ++i)
+            if (ydst[i] >= 0) *reinterpret_cast<u32x4*>(ys + ydst[i]) = Yr[i];
+    };
+
+    const int p_begin = blockIdx.x * a.patches_per_wg;
+    const int p_end = min(a.total_patches, p_begin + a.patches_per_wg);
+    if (p_begin < p_end) {
+        load_patch(p_begin);
+        store_patch();
+    }
+    __syncthreads();
+    for (int patch = p_begin; patch < p_end; ++patch) {
+        // the next patch travels HBM -> registers while this one is multiplied out of LDS (clamped at the end so
+        // the loop body has no conditional memory operations)
+        load_patch(min(patch + 1, p_end - 1));
         for (int ks = 0; ks < npix; ks += 16) {
             const int pix0 = ks + k_base + qq, pix1 = pix0 + 4;
             const s16x4 a0 = lds_tr16(ys + pix0 * 128 + (a_col_bytes ^ (((pix0 >> 1) & 1) << 6)));
@@ -497,6 +537,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
             }
         }
         __syncthreads();
+        store_patch();
+        __syncthreads();
     }
     // ---- each workgroup stores its partial (tap, co, ci) tile into its own slab with plain stores (fp32 atomics
     //      run at ~1.3 TB/s chip-wide, plain stores at ~6 TB/s: MI355X_MICROARCH.md "Global float atomics");
@@ -513,20 +555,43 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
     }
 }
 
-// dw[co][ci][tap] = scale * sum_s slab[s][tap][co][ci]  (+ dw when accumulating).  Reads are coalesced along ci.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
-                                                           int nslab, int taps, int cout, int cin, float scale,
-                                                           int accumulate) {
+// Stage 1 of the slab reduction: grid (element chunks, slab groups); every thread owns one float4 of the packed
+// (tap, co, ci) tile, sums its group's slabs with independent loads in flight and adds the partial into `accum`
+// (zeroed by the host wrapper) with fp32 atomics -- 16 groups x 147 KB of atomics, negligible.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ accum,
+                                                           int nslab, long total) {
+    const long e4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e4 >= total) return;
+    const int per_group = (nslab + gridDim.y - 1) / gridDim.y;
+    const int s_begin = blockIdx.y * per_group;
+    const int s_end = min(nslab, s_begin + per_group);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int s2 = s_begin;
+    for (; s2 + 4 <= s_end; s2 += 4) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(slabs + (long)(s2 + 0) * total + e4);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(slabs + (long)(s2 + 1) * total + e4);
+        const f32x4 v2 = *reinterpret_cast<const f32x4*>(slabs + (long)(s2 + 2) * total + e4);
+        const f32x4 v3 = *reinterpret_cast<const f32x4*>(slabs + (long)(s2 + 3) * total + e4);
+        acc += (v0 + v1) + (v2 + v3);
+    }
+    for (; s2 < s_end; ++s2) acc += *reinterpret_cast<const f32x4*>(slabs + (long)s2 * total + e4);
+    if (s_begin < s_end) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicAdd(accum + e4 + k, acc[k]);
+    }
+}
+
+// Stage 2: packed (tap, co, ci) -> master layout (co, ci, tap) with the equalized-LR scale.
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ accum, float* __restrict__ dw,
+                                                           int taps, int cout, int cin, float scale, int accumulate) {
     const long total = (long)taps * cout * cin;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        float acc = 0.f;
-        for (int s = 0; s < nslab; ++s) acc += slabs[(long)s * total + e];
         const int ci = (int)(e % cin);
         const long r = e / cin;
         const int co = (int)(r % cout);
         const int tap = (int)(r / cout);
         const long o = ((long)co * cin + ci) * taps + tap;
-        const float v = acc * scale;
+        const float v = accum[e] * scale;
         dw[o] = accumulate ? dw[o] + v : v;
     }
 }
@@ -581,8 +646,13 @@ extern "C" int rgbd_conv2d_fprop_bf16(const void* x, const void* wp, const float
                                        : (const void*)&conv3x3_patch_kernel<128, false>)
                               : (a.ups ? (const void*)&conv3x3_patch_kernel<64, true>
                                        : (const void*)&conv3x3_patch_kernel<64, false>);
-        RGBD_REQUIRE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess,
-                     "rgbd_conv2d_fprop_bf16: cannot reserve %d B of LDS", lds);
+        static bool attr_done[4] = {false, false, false, false};   // once per variant (not a stream operation)
+        const int variant = (wide ? 2 : 0) + (a.ups ? 1 : 0);
+        if (!attr_done[variant]) {
+            RGBD_REQUIRE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess,
+                         "rgbd_conv2d_fprop_bf16: cannot reserve %d B of LDS", lds);
+            attr_done[variant] = true;
+        }
         if (wide) {
             if (a.ups) conv3x3_patch_kernel<128, true><<<(unsigned)grid, 512, lds, st>>>(a);
             else       conv3x3_patch_kernel<128, false><<<(unsigned)grid, 512, lds, st>>>(a);
@@ -633,7 +703,8 @@ WgradPlan plan_wgrad(int B, int H, int W, int Cin, int Cout) {
 extern "C" int64_t rgbd_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int K) {
     if (B <= 0 || H < 4 || W < 4 || Cin % 64 || Cout % 64 || (K != 1 && K != 3)) return -1;
     const WgradPlan p = plan_wgrad(B, H, W, Cin, Cout);
-    return (int64_t)p.nsplit * K * K * Cout * Cin * (int64_t)sizeof(float);
+    // nsplit slabs + one accumulation tile
+    return ((int64_t)p.nsplit + 1) * K * K * Cout * Cin * (int64_t)sizeof(float);
 }
 
 extern "C" int rgbd_conv2d_wgrad_bf16(const void* x, const void* dy, void* workspace, float* dw, int B, int H, int W,
@@ -650,15 +721,27 @@ extern "C" int rgbd_conv2d_wgrad_bf16(const void* x, const void* dy, void* works
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.PW = p.PW; a.PH = p.PH; a.lgPW = p.lgPW; a.npx = p.npx; a.npy = p.npy;
     a.total_patches = p.total_patches; a.patches_per_wg = p.patches_per_wg;
+    RGBD_REQUIRE((long)B * H * W * Cin < 0x3fffffffL && (long)B * H * W * Cout < 0x3fffffffL,
+                 "rgbd_conv2d_wgrad_bf16: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
+    a.x_bytes = (int)((long)B * H * W * Cin * 2);
+    a.y_bytes = (int)((long)B * H * W * Cout * 2);
     dim3 grid(p.nsplit, Cin / 64, Cout / 64);
     hipStream_t st = (hipStream_t)stream;
+    const long total = (long)K * K * Cout * Cin;
+    float* accum = (float*)workspace + (long)p.nsplit * total;
+    if (rgbd_zero_async(accum, total * sizeof(float), st) != hipSuccess) {
+        rgbd_set_error("rgbd_conv2d_wgrad_bf16: memset failed");
+        return -2;
+    }
     if (K == 3) conv_wgrad_kernel<9><<<grid, 256, 0, st>>>(a);
     else        conv_wgrad_kernel<1><<<grid, 256, 0, st>>>(a);
     RGBD_CHECK_LAUNCH("conv_wgrad_kernel");
-    const long total = (long)K * K * Cout * Cin;
-    const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
-    wgrad_reduce_kernel<<<blocks, 256, 0, st>>>((const float*)workspace, dw, p.nsplit, K * K, Cout, Cin, scale,
-                                                accumulate);
+    const int groups = p.nsplit >= 64 ? 16 : (p.nsplit >= 8 ? 4 : 1);
+    wgrad_reduce_kernel<<<dim3((unsigned)((total / 4 + 255) / 256), groups), 256, 0, st>>>((const float*)workspace, accum,
+                                                                                          p.nsplit, total);
     RGBD_CHECK_LAUNCH("wgrad_reduce_kernel");
+    const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+    wgrad_finish_kernel<<<blocks, 256, 0, st>>>(accum, dw, K * K, Cout, Cin, scale, accumulate);
+    RGBD_CHECK_LAUNCH("wgrad_finish_kernel");
     return 0;
 }

@@ -11,6 +11,18 @@ void rgbd_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+__global__ __launch_bounds__(256) void zero_kernel(unsigned int* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+
+hipError_t rgbd_zero_async(void* ptr, size_t bytes, hipStream_t stream) {
+    const size_t n = bytes / 4;
+    if (n == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    zero_kernel<<<blocks, 256, 0, stream>>>((unsigned int*)ptr, n);
+    return hipGetLastError();
+}
+
 extern "C" const char* rgbd_last_error(void) { return g_err; }
 extern "C" int rgbd_abi_version(void) { return RGBD_ABI_VERSION; }
 
@@ -199,6 +211,50 @@ __global__ __launch_bounds__(256) void lrelu_bwd_kernel(const unsigned short* __
     }
 }
 
+// Same, fused with the bias gradient: bias_grad[c] += sum_m dz[m][c] (fp32 atomics into the caller's buffer).
+// A block owns a strip of rows and one 64-channel group so the column sums reduce on chip; one pass over HBM.
+__global__ __launch_bounds__(256) void lrelu_bwd_colsum_kernel(const unsigned short* __restrict__ dy,
+                                                               const unsigned short* __restrict__ y,
+                                                               unsigned short* __restrict__ dz, long M, int C,
+                                                               int act_channels, float slope, int rows_per_block,
+                                                               float* __restrict__ bias_grad) {
+    const int cg = blockIdx.y;
+    const int chunk = threadIdx.x & 7, lane_p = threadIdx.x >> 3;
+    const int c0 = cg * 64 + chunk * 8;
+    const bool act = c0 < act_channels;
+    const long r_begin = (long)blockIdx.x * rows_per_block;
+    const long r_end = min(M, r_begin + rows_per_block);
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long r = r_begin + lane_p; r < r_end; r += 32) {
+        const long off = r * C + c0;
+        const u32x4 g = *reinterpret_cast<const u32x4*>(dy + off);
+        u32x4 out = g;
+        if (act) {
+            const u32x4 yy = *reinterpret_cast<const u32x4*>(y + off);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float g0 = bf16_lo(g[k]), g1 = bf16_hi(g[k]);
+                const float r0 = bf16_lo(yy[k]) > 0.f ? g0 : g0 * slope;
+                const float r1 = bf16_hi(yy[k]) > 0.f ? g1 : g1 * slope;
+                out[k] = pack_bf16x2(r0, r1);
+            }
+        }
+        *reinterpret_cast<u32x4*>(dz + off) = out;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s[2 * k] += bf16_lo(out[k]); s[2 * k + 1] += bf16_hi(out[k]); }
+    }
+    __shared__ float red[32][65];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[lane_p][chunk * 8 + k] = s[k];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float acc = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) acc += red[r][threadIdx.x];
+        atomicAdd(bias_grad + cg * 64 + threadIdx.x, acc);
+    }
+}
+
 // column sums of an (M, C) bf16 matrix -> out[C] fp32 (atomics; out zeroed by the caller): bias gradients.
 __global__ __launch_bounds__(256) void colsum_kernel(const unsigned short* __restrict__ x, float* __restrict__ out,
                                                      long M, int C, int rows_per_block) {
@@ -361,8 +417,9 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// ws[NORM_BLOCKS] = norm, ws[NORM_BLOCKS + 1] = rate
+// ws[NORM_BLOCKS] = norm, ws[NORM_BLOCKS + 1] = rate, ws[NORM_BLOCKS + 2] = sqrt(1-b2^t)/(1-b1^t); *step += 1
 __global__ __launch_bounds__(256) void norm_final_kernel(float* __restrict__ ws, int nblocks, float clip,
+                                                         float beta1, float beta2, int* __restrict__ step,
                                                          float* __restrict__ norm_out) {
     double acc = 0.0;
     for (int k = threadIdx.x; k < nblocks; k += 256) acc += (double)ws[k];
@@ -378,15 +435,21 @@ __global__ __launch_bounds__(256) void norm_final_kernel(float* __restrict__ ws,
         const float rate = clip / norm;   // chainer GradientClipping: scale only when rate < 1
         ws[NORM_BLOCKS] = norm;
         ws[NORM_BLOCKS + 1] = rate < 1.f ? rate : 1.f;
+        const int t = step[0] + 1;        // chainer Adam: t counts updates, incremented before use
+        step[0] = t;
+        const double fix1 = 1.0 - pow((double)beta1, (double)t);
+        const double fix2 = 1.0 - pow((double)beta2, (double)t);
+        ws[NORM_BLOCKS + 2] = (float)(sqrt(fix2) / fix1);
         if (norm_out) norm_out[0] = norm;
     }
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long begin,
-                                                   long end, float alpha_t, float beta1, float beta2, float eps,
+                                                   long end, float alpha, float beta1, float beta2, float eps,
                                                    float gscale, const float* __restrict__ ws) {
     const float rate = ws[NORM_BLOCKS + 1] * gscale;
+    const float alpha_t = alpha * ws[NORM_BLOCKS + 2];
     for (long e = begin + (long)blockIdx.x * 256 + threadIdx.x; e < end; e += (long)gridDim.x * 256) {
         const float grad = g[e] * rate;
         float mm = m[e], vv = v[e];
@@ -417,7 +480,7 @@ extern "C" int rgbd_adain_fwd(const void* x, const float* scale, const float* sh
     RGBD_REQUIRE(x && scale && shift && y && sums && mean && rstd, "rgbd_adain_fwd: null pointer");
     RGBD_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 64 == 0, "rgbd_adain_fwd: C must be a multiple of 64 (C=%d)", C);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(sums, 0, (size_t)B * C * 2 * sizeof(float), st) != hipSuccess) {
+    if (rgbd_zero_async(sums, (size_t)B * C * 2 * sizeof(float), st) != hipSuccess) {
         rgbd_set_error("rgbd_adain_fwd: memset failed");
         return -2;
     }
@@ -440,7 +503,7 @@ extern "C" int rgbd_adain_bwd(const void* x, const void* dy, const float* scale,
     RGBD_REQUIRE(x && dy && scale && mean && rstd && dx && dscale && dshift && sums, "rgbd_adain_bwd: null pointer");
     RGBD_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 64 == 0, "rgbd_adain_bwd: C must be a multiple of 64 (C=%d)", C);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(sums, 0, (size_t)B * C * 2 * sizeof(float), st) != hipSuccess) {
+    if (rgbd_zero_async(sums, (size_t)B * C * 2 * sizeof(float), st) != hipSuccess) {
         rgbd_set_error("rgbd_adain_bwd: memset failed");
         return -2;
     }
@@ -459,22 +522,32 @@ extern "C" int rgbd_adain_bwd(const void* x, const void* dy, const float* scale,
 }
 
 extern "C" int rgbd_lrelu_bwd(const void* dy, const void* y, void* dz, int64_t M, int C, int act_channels,
-                              float slope, void* stream) {
+                              float slope, float* bias_grad, void* stream) {
     RGBD_REQUIRE(dy && y && dz, "rgbd_lrelu_bwd: null pointer");
     RGBD_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && act_channels % 8 == 0, "rgbd_lrelu_bwd: C must be a multiple of 8");
+    hipStream_t st = (hipStream_t)stream;
+    if (bias_grad) {
+        RGBD_REQUIRE(C % 64 == 0, "rgbd_lrelu_bwd: the fused bias gradient needs C %% 64 == 0 (C=%d)", C);
+        const int rows = 2048;
+        dim3 grid(ceil_div(M, rows), C / 64);
+        lrelu_bwd_colsum_kernel<<<grid, 256, 0, st>>>((const unsigned short*)dy, (const unsigned short*)y,
+                                                      (unsigned short*)dz, M, C, act_channels, slope, rows, bias_grad);
+        RGBD_CHECK_LAUNCH("lrelu_bwd_colsum_kernel");
+        return 0;
+    }
     const long nvec = M * C / 8;
     const int blocks = (int)min((long)4096, (nvec + 255) / 256);
-    lrelu_bwd_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((const unsigned short*)dy, (const unsigned short*)y,
-                                                             (unsigned short*)dz, nvec, C, act_channels, slope);
+    lrelu_bwd_kernel<<<blocks, 256, 0, st>>>((const unsigned short*)dy, (const unsigned short*)y,
+                                             (unsigned short*)dz, nvec, C, act_channels, slope);
     RGBD_CHECK_LAUNCH("lrelu_bwd_kernel");
     return 0;
 }
 
-extern "C" int rgbd_colsum_bf16(const void* x, float* out, int64_t M, int C, void* stream) {
+extern "C" int rgbd_colsum_bf16(const void* x, float* out, int64_t M, int C, int accumulate, void* stream) {
     RGBD_REQUIRE(x && out, "rgbd_colsum_bf16: null pointer");
     RGBD_REQUIRE(M > 0 && C > 0 && C % 64 == 0, "rgbd_colsum_bf16: C must be a multiple of 64 (C=%d)", C);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(out, 0, (size_t)C * sizeof(float), st) != hipSuccess) {
+    if (!accumulate && rgbd_zero_async(out, (size_t)C * sizeof(float), st) != hipSuccess) {
         rgbd_set_error("rgbd_colsum_bf16: memset failed");
         return -2;
     }
@@ -516,8 +589,8 @@ extern "C" int rgbd_planes_outer(const void* t, const float* p, float* o, float*
     RGBD_REQUIRE(t && p && o, "rgbd_planes_outer: null pointer");
     RGBD_REQUIRE((KP == 3 || KP == 4) && C % 64 == 0 && B > 0 && HW > 0, "rgbd_planes_outer: bad shape KP=%d C=%d", KP, C);
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(o, 0, (size_t)KP * C * sizeof(float), st) != hipSuccess ||
-        (tsum && hipMemsetAsync(tsum, 0, (size_t)C * sizeof(float), st) != hipSuccess)) {
+    if (rgbd_zero_async(o, (size_t)KP * C * sizeof(float), st) != hipSuccess ||
+        (tsum && rgbd_zero_async(tsum, (size_t)C * sizeof(float), st) != hipSuccess)) {
         rgbd_set_error("rgbd_planes_outer: memset failed");
         return -2;
     }
@@ -530,24 +603,24 @@ extern "C" int rgbd_planes_outer(const void* t, const float* p, float* o, float*
 }
 
 extern "C" int rgbd_adam_clip_multi(float* p, float* g, float* m, float* v, int64_t n, int nseg,
-                                    const int64_t* seg_begin, const float* seg_alpha_t, float beta1, float beta2,
-                                    float eps, float clip, float grad_scale, float* workspace, float* norm_out,
-                                    void* stream) {
-    RGBD_REQUIRE(p && g && m && v && workspace && seg_begin && seg_alpha_t, "rgbd_adam_clip_multi: null pointer");
+                                    const int64_t* seg_begin, const float* seg_alpha, float beta1, float beta2,
+                                    float eps, float clip, float grad_scale, int32_t* step, float* workspace,
+                                    float* norm_out, void* stream) {
+    RGBD_REQUIRE(p && g && m && v && workspace && seg_begin && seg_alpha && step, "rgbd_adam_clip_multi: null pointer");
     RGBD_REQUIRE(n > 0 && nseg > 0, "rgbd_adam_clip_multi: empty");
     RGBD_REQUIRE(seg_begin[0] == 0 && seg_begin[nseg] == n, "rgbd_adam_clip_multi: segments must cover [0,n)");
     hipStream_t st = (hipStream_t)stream;
     const int nb = (int)min((long)NORM_BLOCKS, (long)((n + 255) / 256));
     sumsq_kernel<<<nb, 256, 0, st>>>(g, n, grad_scale, workspace);
     RGBD_CHECK_LAUNCH("sumsq_kernel");
-    norm_final_kernel<<<1, 256, 0, st>>>(workspace, nb, clip, norm_out);
+    norm_final_kernel<<<1, 256, 0, st>>>(workspace, nb, clip, beta1, beta2, step, norm_out);
     RGBD_CHECK_LAUNCH("norm_final_kernel");
     for (int s = 0; s < nseg; ++s) {
         const long b = seg_begin[s], e = seg_begin[s + 1];
         RGBD_REQUIRE(e >= b, "rgbd_adam_clip_multi: segments must be ascending");
         if (e == b) continue;
         const int blocks = (int)min((long)2048, (e - b + 255) / 256);
-        adam_kernel<<<blocks, 256, 0, st>>>(p, g, m, v, b, e, seg_alpha_t[s], beta1, beta2, eps, grad_scale, workspace);
+        adam_kernel<<<blocks, 256, 0, st>>>(p, g, m, v, b, e, seg_alpha[s], beta1, beta2, eps, grad_scale, workspace);
         RGBD_CHECK_LAUNCH("adam_kernel");
     }
     return 0;

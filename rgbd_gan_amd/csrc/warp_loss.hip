@@ -262,8 +262,8 @@ extern "C" int rgbd_warp_loss_bwd(const float* img, const float* img_rot, const 
     RGBD_REQUIRE(b > 0 && S >= 2, "rgbd_warp_loss_bwd: bad shape b=%d S=%d", b, S);
     const long N = (long)b * S * S;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(grad_img, 0, N * 4 * sizeof(float), st) != hipSuccess ||
-        hipMemsetAsync(grad_img_rot, 0, N * 4 * sizeof(float), st) != hipSuccess) {
+    if (rgbd_zero_async(grad_img, N * 4 * sizeof(float), st) != hipSuccess ||
+        rgbd_zero_async(grad_img_rot, N * 4 * sizeof(float), st) != hipSuccess) {
         rgbd_set_error("rgbd_warp_loss_bwd: memset failed");
         return -2;
     }

@@ -62,6 +62,18 @@ class ConvLayer:
         return self._wf, self._wd
 
 
+def _direct_grad(p):
+    """During a plain backward (no graph being built) weight / bias gradients are accumulated straight into the
+    flat gradient buffer by the kernels (wgrad's accumulate mode, the fused bias-gradient atomics) instead of
+    materialising a tensor for autograd's AccumulateGrad to add -- one tiny kernel per parameter saved."""
+    return (not torch.is_grad_enabled()) and p.grad is not None and p.grad.is_contiguous()
+
+
+def _wgrad_into(x, dy, w, layer, ups):
+    xe = upsample2(x).contiguous() if ups else x.contiguous()
+    kernels.conv2d_wgrad(xe, dy.contiguous(), layer.K, layer.inv_c, out=w.grad, accumulate=True)
+
+
 def _sum_pool2(x):
     """(B,2H,2W,C) -> (B,H,W,C): adjoint of nearest-2x upsampling."""
     B, H, W, C = x.shape
@@ -89,7 +101,10 @@ class _ConvFprop(torch.autograd.Function):
         dx = _ConvDgrad.apply(dy, w, ctx.layer, ctx.ups) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1] and not _SKIP_WGRAD:
-            dw = _ConvWgrad.apply(x, dy, ctx.layer, ctx.ups)
+            if _direct_grad(w):
+                _wgrad_into(x, dy, w, ctx.layer, ctx.ups)
+            else:
+                dw = _ConvWgrad.apply(x, dy, ctx.layer, ctx.ups)
         return dx, dw, None, None
 
 
@@ -109,7 +124,10 @@ class _ConvDgrad(torch.autograd.Function):
         g_dy = _ConvFprop.apply(ddx, w, ctx.layer, ctx.ups) if ctx.needs_input_grad[0] else None
         g_w = None
         if ctx.needs_input_grad[1] and not _SKIP_WGRAD:
-            g_w = _ConvWgrad.apply(ddx, dy, ctx.layer, ctx.ups)
+            if _direct_grad(w):
+                _wgrad_into(ddx, dy, w, ctx.layer, ctx.ups)
+            else:
+                g_w = _ConvWgrad.apply(ddx, dy, ctx.layer, ctx.ups)
         return g_dy, g_w, None, None
 
 
@@ -221,21 +239,33 @@ class _ConvBiasAct(torch.autograd.Function):
                                  residual=residual.contiguous() if residual is not None else None, upsample=ups,
                                  lrelu_channels=w.shape[0] if act else 0)
         ctx.layer, ctx.ups, ctx.act = layer, ups, act
-        ctx.save_for_backward(x, w, y)
+        ctx.save_for_backward(x, w, y, bias)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, y = ctx.saved_tensors
+        x, w, y, bias = ctx.saved_tensors
         layer, ups = ctx.layer, ctx.ups
-        dz = _LreluGrad.apply(dy.contiguous(), y, w.shape[0]) if ctx.act else dy.contiguous()
+        want_b = ctx.needs_input_grad[2] and not _SKIP_WGRAD
         dx = dw = db = dres = None
+        if want_b and _direct_grad(bias):
+            # bias gradient rides along: fused into the lrelu-grad pass, or one accumulating column-sum pass
+            if ctx.act:
+                dz = kernels.lrelu_bwd(dy.contiguous(), y, w.shape[0], bias_grad=bias.grad)
+            else:
+                dz = dy.contiguous()
+                kernels.colsum(dz, out=bias.grad)
+        else:
+            dz = _LreluGrad.apply(dy.contiguous(), y, w.shape[0]) if ctx.act else dy.contiguous()
+            if want_b:
+                db = _ColSum.apply(dz)
         if ctx.needs_input_grad[0]:
             dx = _ConvDgrad.apply(dz, w, layer, ups)
         if ctx.needs_input_grad[1] and not _SKIP_WGRAD:
-            dw = _ConvWgrad.apply(x, dz, layer, ups)
-        if ctx.needs_input_grad[2] and not _SKIP_WGRAD:
-            db = _ColSum.apply(dz)
+            if _direct_grad(w):
+                _wgrad_into(x, dz, w, layer, ups)
+            else:
+                dw = _ConvWgrad.apply(x, dz, layer, ups)
         if ctx.needs_input_grad[3]:
             dres = dz
         return dx, dw, db, dres, None, None, None

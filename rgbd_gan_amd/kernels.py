@@ -163,23 +163,26 @@ def conv2d_wgrad(x, dy, K, scale, out=None, accumulate=False):
 
 
 # ------------------------------------------------------------------ fused elementwise / 1x1
-def lrelu_bwd(dy, y, act_channels, slope=0.2):
-    """dz = dy * (y > 0 ? 1 : slope) on channels [0, act_channels) of NHWC bf16 tensors."""
-    _chk(dy, BF16, "dy"); _chk(y, BF16, "y")
+def lrelu_bwd(dy, y, act_channels, slope=0.2, bias_grad=None):
+    """dz = dy * (y > 0 ? 1 : slope) on channels [0, act_channels) of NHWC bf16 tensors.
+    bias_grad (C,) fp32: if given, the column sums of dz are ADDED to it in the same pass."""
+    _chk(dy, BF16, "dy"); _chk(y, BF16, "y"); _chk(bias_grad, F32, "bias_grad")
     C = y.shape[-1]
     dz = torch.empty_like(y)
     rc = _lib.load().rgbd_lrelu_bwd(_ptr(dy), _ptr(y), _ptr(dz), y.numel() // C, C, int(act_channels), float(slope),
-                                    _stream())
+                                    _ptr(bias_grad), _stream())
     _lib.check(rc, "rgbd_lrelu_bwd")
     return dz
 
 
-def colsum(x):
-    """(.., C) bf16 -> (C,) fp32 column sums."""
-    _chk(x, BF16, "x")
+def colsum(x, out=None):
+    """(.., C) bf16 -> (C,) fp32 column sums (added to `out` when given)."""
+    _chk(x, BF16, "x"); _chk(out, F32, "out")
     C = x.shape[-1]
-    out = torch.empty(C, dtype=F32, device=x.device)
-    rc = _lib.load().rgbd_colsum_bf16(_ptr(x), _ptr(out), x.numel() // C, C, _stream())
+    acc = out is not None
+    if out is None:
+        out = torch.empty(C, dtype=F32, device=x.device)
+    rc = _lib.load().rgbd_colsum_bf16(_ptr(x), _ptr(out), x.numel() // C, C, int(acc), _stream())
     _lib.check(rc, "rgbd_colsum_bf16")
     return out
 
@@ -248,14 +251,17 @@ def adain_bwd(x, dy, scale, mean, rstd):
 
 
 # ------------------------------------------------------------------ optimizer
-def adam_clip_multi(p, g, m, v, seg_begin, seg_alpha_t, beta1, beta2, eps, clip, grad_scale, workspace, norm_out=None):
+def adam_clip_multi(p, g, m, v, seg_begin, seg_alpha, beta1, beta2, eps, clip, grad_scale, step, workspace,
+                    norm_out=None):
+    """step: int32 device tensor (1,) = chainer's update counter t, incremented on the device by this call."""
     for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v"), (workspace, "workspace")):
         _chk(t, F32, n)
+    _chk(step, torch.int32, "step")
     n = p.numel()
-    nseg = len(seg_alpha_t)
+    nseg = len(seg_alpha)
     sb = (ctypes.c_int64 * (nseg + 1))(*[int(s) for s in seg_begin])
-    sa = (ctypes.c_float * nseg)(*[float(a) for a in seg_alpha_t])
+    sa = (ctypes.c_float * nseg)(*[float(a) for a in seg_alpha])
     rc = _lib.load().rgbd_adam_clip_multi(_ptr(p), _ptr(g), _ptr(m), _ptr(v), n, nseg, sb, sa, float(beta1),
-                                          float(beta2), float(eps), float(clip), float(grad_scale), _ptr(workspace),
-                                          _ptr(norm_out), _stream())
+                                          float(beta2), float(eps), float(clip), float(grad_scale), _ptr(step),
+                                          _ptr(workspace), _ptr(norm_out), _stream())
     _lib.check(rc, "rgbd_adam_clip_multi")

@@ -19,7 +19,7 @@ class FlatAdam:
         self.store = store
         self.alpha, self.beta1, self.beta2, self.eps, self.clip = alpha, beta1, beta2, eps, clip
         self.comm = comm                      # rgbd_gan_amd.dist.Communicator or None
-        self.t = 0
+        self.step = torch.zeros(1, dtype=torch.int32, device=store.flat.device)   # chainer's t, kept on the device
         self.m = torch.zeros_like(store.flat)
         self.v = torch.zeros_like(store.flat)
         self.workspace = torch.empty(1024 + 8, dtype=torch.float32, device=store.flat.device)
@@ -68,19 +68,19 @@ class FlatAdam:
             self.comm.wait(self._pending)
             self._pending = None
             grad_scale = 1.0 / self.comm.size
-        self.t += 1
-        fix1 = 1.0 - self.beta1 ** self.t
-        fix2 = 1.0 - self.beta2 ** self.t
         begins, alphas = self._segments()
-        alpha_t = [a * np.sqrt(fix2) / fix1 for a in alphas]
-        kernels.adam_clip_multi(self.store.flat, self.store.grad, self.m, self.v, begins, alpha_t, self.beta1,
-                                self.beta2, self.eps, self.clip, grad_scale, self.workspace, self.grad_norm)
+        kernels.adam_clip_multi(self.store.flat, self.store.grad, self.m, self.v, begins, alphas, self.beta1,
+                                self.beta2, self.eps, self.clip, grad_scale, self.step, self.workspace, self.grad_norm)
         functional.bump_weight_epoch()
+
+    @property
+    def t(self):
+        return int(self.step.item())
 
     def state_dict(self):
         return {"t": self.t, "m": self.m.cpu().numpy(), "v": self.v.cpu().numpy()}
 
     def load_state_dict(self, sd):
-        self.t = int(sd["t"])
+        self.step.fill_(int(sd["t"]))
         self.m.copy_(torch.as_tensor(sd["m"]))
         self.v.copy_(torch.as_tensor(sd["v"]))

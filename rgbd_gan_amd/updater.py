@@ -13,6 +13,8 @@ One update_core() = one generator step + one discriminator step:
 Data-parallel: each optimizer's flat gradient buffer is all-reduced once (RCCL); the map/gen all-reduce is launched
 right after the G backward and overlaps the D step's forward/backward (which only reads x_fake's values).
 """
+import math
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -100,6 +102,29 @@ def downsize_real(x_real, stage, max_stage=17):
     return (1 - alpha) * r_lo + alpha * r_hi
 
 
+class _HostStager:
+    """Small host -> device uploads without blocking the host on the stream: a ring of pinned staging buffers,
+    each guarded by an event (the reference does a blocking cupy.asarray per step, updater.py:267,315-318)."""
+
+    def __init__(self, shape, dtype, device, depth=4):
+        self.dev = torch.empty(shape, dtype=dtype, device=device)
+        self.pinned = [torch.empty(shape, dtype=dtype).pin_memory() for _ in range(depth)]
+        self.events = [None] * depth
+        self.i = 0
+
+    def upload(self, array):
+        k = self.i
+        self.i = (self.i + 1) % len(self.pinned)
+        if self.events[k] is not None:
+            self.events[k].synchronize()
+        self.pinned[k].copy_(torch.as_tensor(array).reshape(self.dev.shape))
+        self.dev.copy_(self.pinned[k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[k] = ev
+        return self.dev
+
+
 class RGBDUpdater:
     def __init__(self, models, config, **kwargs):
         if len(models) == 2:
@@ -107,6 +132,8 @@ class RGBDUpdater:
         if config.bigan:
             raise AssertionError("bigan is not supported")
         self.gen, self.dis, self.smoothed_gen = models
+        if self.smoothed_gen is not None:
+            raise AssertionError("keep_smoothed_gen is not supported yet")
         self.config = config
         self.smoothing = kwargs.pop("smoothing")
         self.lambda_gp = kwargs.pop("lambda_gp")
@@ -125,6 +152,13 @@ class RGBDUpdater:
         # stay on the device and are checked every `nan_check_interval` iterations (1 = the reference's behaviour)
         self.nan_check_interval = int(kwargs.pop("nan_check_interval", 100))
         self.fixed_stage = kwargs.pop("fixed_stage", None)   # bench / tests: pin the stage
+        # HIP graphs: the G phase, the D phase and the optimizer phase of a step are captured once per
+        # (batch, stage, loss flags) and replayed; collectives stay outside the graphs.  Fade-in (odd) stages change
+        # a blend factor every iteration and run eagerly.
+        self.use_graphs = bool(kwargs.pop("use_graphs", True))
+        self.graph_warmup = int(kwargs.pop("graph_warmup", 2))
+        self.graph_phases = tuple(kwargs.pop("graph_phases", ("gen", "dis", "opt")))
+        self._graphs, self._eager_calls, self._stagers = {}, {}, {}
         self.device = self.gen.device
 
     # ---- chainer StandardUpdater surface
@@ -173,73 +207,55 @@ class RGBDUpdater:
             if v is not None and not bool(torch.isfinite(v)):
                 raise AssertionError(f"{key} is not finite at iteration {self.iteration}")
 
-    # ---- the step
-    def update_core(self, batch=None, z_fake_data=None, thetas=None):
-        """Optional arguments let tests and the benchmark inject fixed inputs; by default they are drawn exactly as
-        the reference draws them (iterator, make_hidden, prior.sample)."""
+    def _stager(self, name, shape, dtype=torch.float32):
+        key = (name, tuple(shape))
+        if key not in self._stagers:
+            self._stagers[key] = _HostStager(shape, dtype, self.device)
+        return self._stagers[key]
+
+    # ---- the three phases of a step (each one is capturable: device work only, fixed launch sequence)
+    def _gen_phase(self, st):
         cfg = self.config
-        use_rotate = self.iteration > cfg.start_rotation
-        stylegan = cfg.generator_architecture == "stylegan"
-        opt_g_m = self.get_optimizer("map") if stylegan else None
-        opt_g_g = self.get_optimizer("gen")
-        opt_d = self.get_optimizer("dis")
+        stage, B, half = st["stage"], st["B"], st["B"] // 2
         self.gen.cleargrads()
         self.dis.cleargrads()
         obs = self.observation
-
-        stage = self.stage
-        if batch is None:
-            batch = self.get_iterator("main").next()
-        batch_size = len(batch)
-        x_real_data = self.get_x_real_data(batch, batch_size)
-        if z_fake_data is None:
-            z_half = self.get_z_fake_data(batch_size // 2)
-            z_fake_data = torch.cat([z_half, z_half], dim=0)               # same latent for both views
-        if thetas is None:
-            thetas = self.prior.sample(batch_size)
-        thetas = np.asarray(thetas, dtype="float32")
-        random_camera_matrices = get_camera_matries(thetas)                 # host, (B,4,4) fp32
-        theta9 = np.concatenate([np.cos(thetas[:, :3]), np.sin(thetas[:, :3]), thetas[:, 3:]], axis=1)
-        theta9 = torch.from_numpy(theta9.astype("float32")).to(self.device)
-
+        if st["z"] is not None:
+            z = st["z"]
+        else:
+            z_half = self.get_z_fake_data(half)
+            z = torch.cat([z_half, z_half], dim=0)                          # same latent for both views
         with torch.no_grad():
-            x_real = downsize_real(x_real_data, stage).contiguous()
-        image_size = x_real.shape[2]
-        half = batch_size // 2
-
-        # ------------------------------------------------------------ generator step
-        x_fake = self.gen(z_fake_data, stage, theta9)
+            st["x_real"] = downsize_real(st["x_real_full"], stage).contiguous()
+        x_fake = self.gen(z, stage, st["theta9"])
         with self.dis.frozen():
             y_fake, _ = self.dis(x_fake[:, :3], stage=stage, return_hidden=True)
         loss_gen = loss_func_dcgan_gen(y_fake)
         obs["gen/loss_adv"] = loss_gen.detach()
-        if use_rotate:
-            loss_rotate, _ = self.loss_func_rotate(x_fake[:half], random_camera_matrices[:half],
-                                                   x_fake[half:], random_camera_matrices[half:],
-                                                   self.iteration >= cfg.start_occlusion_aware)
+        if st["use_rotate"]:
+            loss_rotate = self.loss_func_rotate.loss_from_coefficients(x_fake[:half], x_fake[half:], st["coef"],
+                                                                       st["occlusion"])
             if cfg.rotate_feature:
                 raise AssertionError("rotate_feature is not supported")
             if cfg.lambda_depth > 0:
                 loss_rotate = loss_rotate + torch.mean(F.relu(cfg.depth_min - x_fake[:, -1]) ** 2) * cfg.lambda_depth
             obs["gen/loss_rotate"] = loss_rotate.detach()
             lambda_rotate = cfg.lambda_rotate if cfg.lambda_rotate else 2
-            lambda_rotate = lambda_rotate if image_size <= 128 else lambda_rotate * 2
+            lambda_rotate = lambda_rotate if st["x_real"].shape[2] <= 128 else lambda_rotate * 2
             loss_gen = loss_gen + loss_rotate * lambda_rotate
             if cfg.use_occupancy_net_loss:
                 raise AssertionError("occupancy-net loss is not supported")
         if cfg.optical_flow:
             raise AssertionError("optical flow loss is not supported")
         loss_gen.backward()
-        if opt_g_m is not None:
-            opt_g_m.start_allreduce()
-        opt_g_g.start_allreduce()
-        x_fake_data = x_fake.detach()
-        del loss_gen, x_fake, y_fake
+        st["x_fake_data"] = x_fake.detach()
 
-        # ------------------------------------------------------------ discriminator step (overlaps the all-reduce)
+    def _dis_phase(self, st):
+        stage = st["stage"]
+        obs = self.observation
         self.dis.cleargrads()
-        y_fake = self.dis(x_fake_data[:, :3].contiguous(), stage=stage)
-        x_real_v = x_real.detach().requires_grad_(True)
+        y_fake = self.dis(st["x_fake_data"][:, :3].contiguous(), stage=stage)
+        x_real_v = st["x_real"].detach().requires_grad_(True)
         y_real = self.dis(x_real_v, stage=stage)
         loss_dis = loss_func_dcgan_dis(y_fake, y_real)
         if not self.dis.sn and self.lambda_gp > 0:
@@ -251,16 +267,108 @@ class RGBDUpdater:
             loss_dis = loss_dis + loss_gp
         obs["dis/loss_adv"] = loss_dis.detach()
         loss_dis.backward()
-        opt_d.start_allreduce()
 
-        # ------------------------------------------------------------ parameter updates
+    def _opt_phase(self, st):
+        for name in ("map", "gen", "dis"):
+            if name in self._optimizers:
+                self._optimizers[name].update()
+
+    def _distributed(self):
+        opt = self._optimizers["gen"]
+        return opt.comm is not None and opt.comm.size > 1
+
+    def _run_phase(self, name, fn, st, key):
+        """Eager for the first calls of a configuration, then capture once and replay."""
+        if key is None or name not in self.graph_phases:
+            fn(st)
+            return
+        gkey = key + (name,)
+        entry = self._graphs.get(gkey)
+        if entry is None:
+            n = self._eager_calls.get(gkey, 0)
+            if n < self.graph_warmup:
+                self._eager_calls[gkey] = n + 1
+                fn(st)
+                return
+            graph = torch.cuda.CUDAGraph()
+            saved = dict(self.observation)
+            with torch.cuda.graph(graph):
+                fn(st)
+            # keep every tensor the phase handed over alive: it lives in the graph's private pool
+            entry = {"graph": graph, "st": dict(st), "obs": {k: v for k, v in self.observation.items()
+                                                             if saved.get(k) is not v}}
+            self._graphs[gkey] = entry
+        else:
+            st.update({k: v for k, v in entry["st"].items() if k in ("x_real", "x_fake_data")})
+            self.observation.update(entry["obs"])
+        entry["graph"].replay()
+
+    # ---- the step
+    def update_core(self, batch=None, z_fake_data=None, thetas=None):
+        """Optional arguments let tests and the benchmark inject fixed inputs; by default they are drawn exactly as
+        the reference draws them (iterator, make_hidden, prior.sample)."""
+        cfg = self.config
+        stylegan = cfg.generator_architecture == "stylegan"
+        opt_g_m = self.get_optimizer("map") if stylegan else None
+        opt_g_g = self.get_optimizer("gen")
+        opt_d = self.get_optimizer("dis")
+        stage = self.stage
+        if batch is None:
+            batch = self.get_iterator("main").next()
+        batch_size = len(batch)
+        half = batch_size // 2
+        x_real_data = self.get_x_real_data(batch, batch_size)
+
+        # ---- host side, NumPy, exactly as the reference: pose prior, camera matrices, pose code, warp constants
+        if thetas is None:
+            thetas = self.prior.sample(batch_size)
+        thetas = np.asarray(thetas, dtype="float32")
+        random_camera_matrices = get_camera_matries(thetas)                 # (B,4,4) fp32
+        theta9 = np.concatenate([np.cos(thetas[:, :3]), np.sin(thetas[:, :3]), thetas[:, 3:]], axis=1).astype("float32")
+        use_rotate = self.iteration > cfg.start_rotation
+        occlusion = self.iteration >= cfg.start_occlusion_aware
+        st = {"stage": stage, "B": batch_size, "use_rotate": use_rotate, "occlusion": occlusion,
+              "x_real_full": x_real_data, "z": None}
+        st["theta9"] = self._stager("theta9", (batch_size, 9)).upload(theta9)
+        if use_rotate:
+            image_size = int(downsize_real(torch.empty(1, 1, x_real_data.shape[2], x_real_data.shape[3]), stage).shape[2])
+            coef = self.loss_func_rotate.coefficients_for_size(image_size, random_camera_matrices[:half],
+                                                               random_camera_matrices[half:])
+            st["coef"] = self._stager("coef", (half, 24)).upload(coef)
+        if z_fake_data is not None:
+            z_in = torch.as_tensor(z_fake_data).to(self.device, torch.float32)
+            zkey = ("z",) + tuple(z_in.shape)
+            if zkey not in self._stagers:
+                self._stagers[zkey] = torch.empty_like(z_in)
+            self._stagers[zkey].copy_(z_in)
+            st["z"] = self._stagers[zkey]
+
+        fl = math.floor(min(stage, 17 - 1e-8))
+        graphable = self.use_graphs and fl % 2 == 0
+        key = None
+        if graphable:
+            # graphs read their inputs from fixed addresses: park the batch in a persistent buffer
+            skey = ("x_real_full",) + tuple(x_real_data.shape)
+            if skey not in self._stagers:
+                self._stagers[skey] = torch.empty_like(x_real_data)
+            self._stagers[skey].copy_(x_real_data)
+            st["x_real_full"] = self._stagers[skey]
+            key = (batch_size, fl, use_rotate, occlusion, tuple(x_real_data.shape), z_fake_data is not None)
+
+        self._run_phase("gen", self._gen_phase, st, key)
         if opt_g_m is not None:
-            opt_g_m.update()
-        opt_g_g.update()
-        if self.smoothed_gen is not None:
-            raise AssertionError("keep_smoothed_gen is not supported yet")
-        opt_d.update()
+            opt_g_m.start_allreduce()
+        opt_g_g.start_allreduce()
+        self._run_phase("dis", self._dis_phase, st, key)                   # overlaps the map/gen all-reduce
+        opt_d.start_allreduce()
+        if self._distributed():
+            self._opt_phase(st)                                             # waits on the collectives: stays eager
+        else:
+            self._run_phase("opt", self._opt_phase, st, key)
+        if key is not None:
+            Fn.bump_weight_epoch()      # replays change the weights behind Python's back: invalidate packed caches
 
-        obs["stage"], obs["batch_size"], obs["image_size"] = stage, batch_size, image_size
+        obs = self.observation
+        obs["stage"], obs["batch_size"], obs["image_size"] = stage, batch_size, int(st["x_real"].shape[2])
         if self.nan_check_interval > 0 and (self.iteration + 1) % self.nan_check_interval == 0:
             self._check_finite()

@@ -215,14 +215,15 @@ def test_adam_clip_matches_chainer_restatement(gnorm_scale):
     md, vd = torch.zeros_like(pd), torch.zeros_like(pd)
     ws = torch.empty(1024 + 8, device=dev())
     norm = torch.empty(1, device=dev())
+    step_dev = torch.zeros(1, dtype=torch.int32, device=dev())
     for t in range(1, 4):
         grads = torch.randn(n1 + n2, generator=g) * gnorm_scale
         params["a"].grad = grads[:n1].clone()
         params["b"].grad = grads[n1:].clone()
         ref_norm = opt.update()
-        fix2 = 1.0 - 0.999 ** t
-        kernels.adam_clip_multi(pd, (grads * 2.0).to(dev()), md, vd, [0, n1, n1 + n2],
-                                [1e-3 * np.sqrt(fix2), 1e-5 * np.sqrt(fix2)], 0.0, 0.999, 1e-8, 5.0, 0.5, ws, norm)
+        kernels.adam_clip_multi(pd, (grads * 2.0).to(dev()), md, vd, [0, n1, n1 + n2], [1e-3, 1e-5], 0.0, 0.999,
+                                1e-8, 5.0, 0.5, step_dev, ws, norm)
+        assert int(step_dev.item()) == t
         assert abs(float(norm.item()) - ref_norm) < 1e-4 * ref_norm
         ref = torch.cat([params["a"].detach(), params["b"].detach()])
         torch.testing.assert_close(pd.cpu(), ref, atol=1e-6, rtol=1e-5)
@@ -240,6 +241,11 @@ def test_lrelu_bwd_and_colsum():
     torch.testing.assert_close(dz.float().cpu(), bf16_round(ref), atol=1e-6, rtol=1e-6)
     cs = kernels.colsum(dy.to(dev()).to(torch.bfloat16))
     torch.testing.assert_close(cs.cpu(), dy.reshape(-1, 128).sum(0), atol=1e-3, rtol=1e-4)
+    # fused variant: same dz, column sums of dz ADDED to the given buffer
+    bg = torch.full((128,), 2.0, device=dev())
+    dz2 = kernels.lrelu_bwd(dy.to(dev()).to(torch.bfloat16), y.to(dev()).to(torch.bfloat16), 64, bias_grad=bg)
+    assert torch.equal(dz2, dz)
+    torch.testing.assert_close(bg.cpu(), dz.float().cpu().reshape(-1, 128).sum(0) + 2.0, atol=1e-3, rtol=1e-4)
 
 
 @pytest.mark.parametrize("B,H,C,KP", [(2, 16, 64, 3), (3, 8, 256, 3), (2, 32, 128, 4)])
