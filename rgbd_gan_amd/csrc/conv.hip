@@ -352,22 +352,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(ConvArgs a) {
     load_patch(0);
     load_w(0, 0, Wr[0]);
     load_w(0, 1, Wr[1]);
+    load_w(0, 2, Wr[2]);
     store_patch(0);
     store_w(0, Wr[0]);
     load_patch(min(1, nc - 1));
     __syncthreads();
     // ---- main loop: nine statically unrolled tap steps per 64-channel slice; every memory operation is
-    //      unconditional (indices clamp at the tail) so hipcc keeps counted vmcnt waits across the barriers
+    //      unconditional (indices clamp at the tail) so hipcc keeps counted vmcnt waits across the barriers.
+    //      Weight tile k+3 is requested while tile k is multiplied: two full K steps of latency cover.
     for (int c = 0; c < nc; ++c) {
         const unsigned char* pbuf = patch_lds + (c & 1) * P_BYTES;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const int t2 = (t + 2) % 9;
-            const int c2 = min(c + (t + 2) / 9, nc - 1);
-            load_w(c2, t2, Wr[(t + 2) % 3]);
             compute(pbuf, w_lds + (t % 3) * W_BYTES, t / 3, t % 3);
             store_w((t + 1) % 3, Wr[(t + 1) % 3]);
             if (t == 6) store_patch((c + 1) & 1);
+            const int t3 = (t + 3) % 9;
+            const int c3 = min(c + (t + 3) / 9, nc - 1);
+            load_w(c3, t3, Wr[t % 3]);                 // Wr[t % 3] (tile k) went to LDS one step ago
             if (t == 7) {
                 asm volatile("" ::: "memory");
                 load_patch(min(c + 2, nc - 1));
