@@ -1,0 +1,58 @@
+"""Generate the golden vectors in this directory FROM THE ORACLE (the reference has no fixtures and cannot run here:
+parity with Chainer is unpinned; these pin the oracle and the HIP kernels to each other across revisions).
+
+    python tests/golden/make_fixtures.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import camera, warp_loss  # noqa: E402
+
+
+def warp_case(seed, b, S, occ, lam):
+    rng = np.random.RandomState(seed)
+    img = rng.uniform(-1, 1, (b, 4, S, S)).astype("float32")
+    img_rot = rng.uniform(-1, 1, (b, 4, S, S)).astype("float32")
+    img[:, 3] = rng.uniform(0.7, 1.3, (b, S, S))
+    img_rot[:, 3] = rng.uniform(0.7, 1.3, (b, S, S))
+    th = rng.uniform(-0.3, 0.3, (2 * b, 6)).astype("float32")
+    th[:, 2] = 0
+    th[:, 3:] *= 0.1
+    cams = camera.camera_matrices(th)
+    ref = warp_loss.forward_np(img, cams[:b], img_rot, cams[b:], occlusion_aware=occ, lambda_geometric=lam)
+    ti = torch.from_numpy(img).requires_grad_(True)
+    tr = torch.from_numpy(img_rot).requires_grad_(True)
+    loss, _ = warp_loss.loss_torch(ti, cams[:b], tr, cams[b:], occlusion_aware=occ, lambda_geometric=lam)
+    loss.backward()
+    coef = np.concatenate([ref["A"].reshape(b, 9), ref["c"], ref["A2"].reshape(b, 9), ref["c2"]], 1).astype("float32")
+    return dict(img=img, img_rot=img_rot, thetas=th, cam=cams[:b], cam_rot=cams[b:], coef=coef,
+                occlusion=np.array(occ), lambda_geometric=np.array(lam, "float32"),
+                loss=np.array(ref["loss"]), zp=ref["zp"], zp_rot=ref["zp_rot"], warped=ref["warped"],
+                warped_rot=ref["warped_rot"], mask=ref["mask"], mask_rot=ref["mask_rot"], u0=ref["u0"], v0=ref["v0"],
+                v1=ref["v1"], u0_rot=ref["u0_rot"], v0_rot=ref["v0_rot"], v1_rot=ref["v1_rot"],
+                grad_img=ti.grad.numpy(), grad_img_rot=tr.grad.numpy())
+
+
+def main():
+    np.savez_compressed(os.path.join(HERE, "warp_loss_b2_s16_occ.npz"), **warp_case(101, 2, 16, True, 3.0))
+    np.savez_compressed(os.path.join(HERE, "warp_loss_b3_s8.npz"), **warp_case(102, 3, 8, False, 2.0))
+    np.random.seed(7)
+    prior = camera.PosePrior(0.3054, 1.0472, 0)
+    th = prior.sample(8)
+    np.random.seed(7)
+    th_u = camera.PosePrior(0.3054, 3.1415, 0, uniform=True).sample(8)
+    si = camera.parse_stage_interval("0,0,0,0,0,0,0,100000, 150000, 160000, 180000, 300000")
+    its = np.array([0, 1, 49999, 50000, 100000, 125000, 150000, 155000, 160000, 170000, 180000, 240000, 300000, 999999])
+    np.savez_compressed(os.path.join(HERE, "host_math.npz"), thetas=th, thetas_uniform=th_u,
+                        cams=camera.camera_matrices(th), theta9=camera.theta9(th), iterations=its,
+                        stages=np.array([camera.stage_of(int(i), si, 11) for i in its]))
+    print("wrote", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))
+
+
+if __name__ == "__main__":
+    main()

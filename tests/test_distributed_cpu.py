@@ -1,0 +1,87 @@
+"""World-size-2 (gloo, CPU) test of the data-parallel optimizer logic: ChainerMN semantics restated in
+rgbd_gan_amd/optimizer.py -- first update() only broadcasts rank 0's parameters, later updates all-reduce the flat
+gradient buffer and every rank applies the same clipped Adam step on the MEAN gradient.
+
+The HIP Adam kernel cannot run on CPU, so this test swaps the kernel wrapper for a torch restatement (a test double
+of the C ABI call, same arguments); everything above it (flat buffers, segments, collectives, ordering) is the
+product code."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+
+def _cpu_adam(p, g, m, v, seg_begin, seg_alpha, beta1, beta2, eps, clip, grad_scale, step, workspace, norm_out=None):
+    gs = g * grad_scale
+    norm = float(torch.sqrt((gs.double() ** 2).sum()))
+    rate = min(1.0, clip / norm) if norm > 0 else 1.0
+    step += 1
+    t = int(step.item())
+    corr = np.sqrt(1 - beta2 ** t) / (1 - beta1 ** t)
+    for i, a in enumerate(seg_alpha):
+        sl = slice(int(seg_begin[i]), int(seg_begin[i + 1]))
+        gr = gs[sl] * rate
+        m[sl] += (1 - beta1) * (gr - m[sl])
+        v[sl] += (1 - beta2) * (gr * gr - v[sl])
+        p[sl] -= a * corr * m[sl] / (torch.sqrt(v[sl]) + eps)
+    if norm_out is not None:
+        norm_out.fill_(norm)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from rgbd_gan_amd import kernels
+    from rgbd_gan_amd.dist import Communicator
+    from rgbd_gan_amd.optimizer import FlatAdam
+    from rgbd_gan_amd.params import ParamStore
+    kernels.adam_clip_multi = _cpu_adam
+    comm = Communicator(backend="gloo")
+    store = ParamStore([("a/W", (5, 3), "normal"), ("a/b", (3,), "zeros")], "cpu", seed=100 + rank)  # ranks differ
+    opt = FlatAdam(store, alpha=1e-2, comm=comm)
+    opt.set_alpha("a/b", 1e-4)
+    start = store.flat.clone()
+    # 1st update: broadcast only
+    store.grad.fill_(1.0)
+    opt.update()
+    after_bcast = store.flat.clone()
+    # 2nd update: rank-dependent gradients -> mean
+    g = torch.arange(store.numel, dtype=torch.float32) * (rank + 1)
+    store.grad.copy_(g)
+    opt.start_allreduce()
+    opt.update()
+    q.put((rank, start.numpy(), after_bcast.numpy(), store.flat.clone().numpy(), int(opt.step.item()),
+           float(opt.grad_norm)))
+    comm.close()
+
+
+def test_two_rank_allreduce_and_first_update_broadcast():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, start0, b0, end0, t0, n0), (r1, start1, b1, end1, t1, n1) = res
+    assert not np.allclose(start0, start1)                  # different initial weights
+    np.testing.assert_array_equal(b0, start0)               # first update(): broadcast of rank 0, no step ...
+    np.testing.assert_array_equal(b1, start0)
+    assert t0 == t1 == 1                                    # ... and Adam's t counted only the real step
+    np.testing.assert_array_equal(end0, end1)               # identical step on every rank
+    # reference: single process on the mean gradient
+    n = len(start0)
+    gmean = torch.arange(n, dtype=torch.float32) * 1.5
+    p = torch.from_numpy(start0.copy())
+    m, v, stp = torch.zeros(n), torch.zeros(n), torch.zeros(1, dtype=torch.int32)
+    _cpu_adam(p, gmean, m, v, [0, 16, n], [1e-2, 1e-4], 0.0, 0.999, 1e-8, 5.0, 1.0, stp, None)
+    np.testing.assert_allclose(end0, p.numpy(), rtol=1e-6, atol=1e-7)
+    assert abs(n0 - float(torch.sqrt((gmean.double() ** 2).sum()))) < 1e-3

@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Training entry point with the reference's command line (train_rgbd.py:261-470 of nogu-atsu/RGBD-GAN):
+
+    python train_rgbd.py [-g GPU] --config_path configs/ffhq_stylegan_occlusion.yml
+    python -m torch.distributed.run --nproc-per-node 8 train_rgbd.py --config_path ...   (config: use_mpi: True)
+
+`--config` is accepted as an alias (the reference's README spells it that way).  One process per GPU; under
+torch.distributed the gradients of each optimizer are averaged with one RCCL all-reduce per step.
+Outputs: {out}/Generator_{iter}.npz, Discriminator_{iter}.npz, snapshot_iter_{iter}.npz, *_latest.npz, {out}/log.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from rgbd_gan_amd.dist import Communicator
+from rgbd_gan_amd.training import DeviceImageIterator, build_training, make_dataset
+from rgbd_gan_amd.utils import yaml_utils
+
+
+def save_npz(path, link):
+    np.savez(path, **link.state_dict())
+
+
+def main():
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--gpu", "-g", type=int, default=0)
+    parser.add_argument("--config_path", "--config", type=str, default="configs/ffhq_stylegan_occlusion.yml")
+    args = parser.parse_args()
+    config = yaml_utils.load(args.config_path)
+    config.gpu = args.gpu
+    print(config.stage_interval)
+
+    comm = Communicator() if (config.use_mpi or int(os.environ.get("WORLD_SIZE", "1")) > 1) else None
+    device_index = comm.intra_rank if comm is not None and comm.size > 1 else config.gpu
+    torch.cuda.set_device(device_index)
+    device = torch.device("cuda", device_index)
+    is_master = comm is None or comm.rank == 0
+
+    images = make_dataset(config.dataset_path, config.image_path)       # uint8 (N,3,128,128), images.npy cache
+    iterator = DeviceImageIterator(images, config.batchsize, device)
+    if config.nvprof or config.enable_cuda_profiling:
+        config.iteration = 10
+    generator, discriminator, optimizer, updater = build_training(
+        config, device, comm if comm is not None and comm.size > 1 else None, iterator=iterator,
+        nan_check_interval=config.display_interval or 100)
+    models = [("Generator", generator), ("Discriminator", discriminator)]
+
+    out = config.out
+    if is_master:
+        os.makedirs(out, exist_ok=True)
+    # resume (train_rgbd.py:405-459): explicit iteration or the newest complete set in auto_resume_dir
+    resume = config.get_model_from_interation or ""
+    if not resume and config.auto_resume:
+        d = config.auto_resume_dir or out
+        cands = []
+        for f in os.listdir(d) if os.path.isdir(d) else []:
+            if f.startswith("Generator_") and f.endswith(".npz") and f[10:-4].isdigit():
+                it = f[10:-4]
+                if all(os.path.exists(f"{d}/{n}_{it}.npz") for n, _ in models) and \
+                        os.path.exists(f"{d}/snapshot_iter_{it}.npz"):
+                    cands.append(int(it))
+        resume = str(max(cands)) if cands else ""
+    if resume:
+        d = (config.auto_resume_dir or out) if config.auto_resume else out
+        print(f"Resume from {resume}")
+        for name, m in models:
+            m.load_state_dict(dict(np.load(f"{d}/{name}_{resume}.npz")), strict=False)
+        snap = np.load(f"{d}/snapshot_iter_{resume}.npz", allow_pickle=True)
+        updater.iteration = int(snap["iteration"])
+        for k, o in optimizer.items():
+            o.load_state_dict({"t": snap[f"{k}/t"], "m": snap[f"{k}/m"], "v": snap[f"{k}/v"]})
+
+    log, t0 = [], time.time()
+    while updater.iteration < config.iteration:
+        updater.update()
+        it = updater.iteration
+        if is_master and it % (config.display_interval or 100) == 0:
+            obs = {k: (float(v) if torch.is_tensor(v) else v) for k, v in updater.observation.items()}
+            entry = {"iteration": it, "elapsed_time": time.time() - t0, **obs}
+            log.append(entry)
+            print(json.dumps(entry))
+            with open(f"{out}/log", "w") as f:
+                json.dump(log, f, indent=1)
+        if is_master and it % (config.snapshot_interval or 10000) == 0:
+            for name, m in models:
+                save_npz(f"{out}/{name}_{it}.npz", m)
+            snap = {"iteration": it}
+            for k, o in optimizer.items():
+                sd = o.state_dict()
+                snap.update({f"{k}/t": sd["t"], f"{k}/m": sd["m"], f"{k}/v": sd["v"]})
+            np.savez(f"{out}/snapshot_iter_{it}.npz", **snap)
+    if is_master:
+        for name, m in models:
+            save_npz(f"{out}/{name}_latest.npz", m)
+    if comm is not None:
+        comm.close()
+
+
+if __name__ == "__main__":
+    main()
