@@ -18,6 +18,8 @@
 //   one slab per workgroup (two 128-byte row segments per wave instruction) and a second kernel sums the slabs.
 #include "common.h"
 
+#include <type_traits>
+
 namespace {
 
 struct ConvArgs {
@@ -427,28 +429,34 @@ __device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p) {
         (s16x4 __attribute__((address_space(3)))*)(const_cast<unsigned char*>(p)));
 }
 
-template <int NT>  // filter taps: 9 (3x3, pad 1) or 1 (1x1)
-__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
+template <int NT, bool FAST>  // filter taps: 9 (3x3, pad 1) or 1 (1x1); FAST: 8x16 patches (images >= 16x16)
+__global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradArgs a) {
+    // 8 waves, one workgroup per CU.  Wave w owns the 32x32 sub-tile (w>>1 & 1, w & 1) of the 64x64 (co, ci) tile for
+    // one half of the filter taps (waves 0-3: taps 0..4, waves 4-7: taps 5..8; waves w and w+4 share a SIMD, so every
+    // SIMD carries all nine taps).  LDS is double buffered: patch p+1 is written while patch p is multiplied, patch
+    // p+2 is in flight in registers; one barrier per 8x16-pixel patch.
     constexpr int HALO = NT == 9 ? 1 : 0;
     constexpr int KW = NT == 9 ? 3 : 1;
+    constexpr int TG0 = NT == 9 ? 5 : 1;               // taps of wave group 0
     constexpr int MAX_X_ROWS = (8 + 2 * HALO) * (16 + 2 * HALO);
-    constexpr int XP = (MAX_X_ROWS * 8 + 255) / 256;   // 16-byte pieces of the X halo patch per thread (6 / 4)
-    constexpr int YP = 4;                              // pieces of the dY patch per thread (128 rows)
-    __shared__ __attribute__((aligned(16))) unsigned char xs[MAX_X_ROWS * 128];
-    __shared__ __attribute__((aligned(16))) unsigned char ys[128 * 128];
+    constexpr int X_BYTES = MAX_X_ROWS * 128, Y_BYTES = 128 * 128;
+    constexpr int XP = (MAX_X_ROWS * 8 + 511) / 512;   // 16-byte pieces of the X halo patch per thread (3 / 2)
+    constexpr int YP = 2;                              // pieces of the dY patch per thread (128 rows)
+    extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];   // [2][X_BYTES + Y_BYTES]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int ci0 = blockIdx.y * 64, co0 = blockIdx.z * 64;
-    const int wc = wid >> 1, wi = wid & 1;             // wave -> (co half, ci half) of the 64x64 tile
+    const int wc = (wid >> 1) & 1, wi = wid & 1;       // wave -> (co half, ci half) of the 64x64 tile
+    const int tg = __builtin_amdgcn_readfirstlane(wid) >> 2;   // tap group (wave-uniform by construction)
     const int HPW = a.PW + 2 * HALO, HPH = a.PH + 2 * HALO;
     const int npix = a.PH * a.PW;
     const int xrows = HPH * HPW;
     const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.x), 0, a.x_bytes, 0x00020000);
     const auto yrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.dy), 0, a.y_bytes, 0x00020000);
 
-    f32x16 acc[NT];
+    f32x16 acc[TG0];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < TG0; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -465,23 +473,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
     short xhy[XP], xhx[XP];
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
-        const int pc = tid + 256 * i;
+        const int pc = tid + 512 * i;
         const int row = pc >> 3, chunk = pc & 7;
         const int hy = row / HPW, hx = row - hy * HPW;
         const bool in = row < xrows;
         xhy[i] = in ? (short)(hy - HALO) : (short)-30000;
         xhx[i] = (short)(hx - HALO);
         xrel[i] = (((hy - HALO) * a.W + (hx - HALO)) * a.Cin + ci0 + chunk * 8) * 2;
-        xdst[i] = in ? row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4) : -1;
+        // the 64-byte half of a row is swapped by bit 1 of the halo COLUMN (halo width is even, so row parity ==
+        // column parity): four consecutive pixels x 64 B then cover all 64 banks once for ds_read_b64_tr_b16, and
+        // the swizzle of a tap-shifted read depends only on the lane and the horizontal tap
+        xdst[i] = in ? row * 128 + ((chunk ^ (((hx >> 1) & 1) << 2)) << 4) : -1;
     }
 #pragma unroll
     for (int i = 0; i < YP; ++i) {
-        const int pc = tid + 256 * i;
+        const int pc = tid + 512 * i;
         const int row = pc >> 3, chunk = pc & 7;
         const int py = row >> a.lgPW, px = row & (a.PW - 1);
         const bool in = row < npix;
         yrel[i] = in ? ((py * a.W + px) * a.Cout + co0 + chunk * 8) * 2 : (int)0x80000000;
-        ydst[i] = in ? row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4) : -1;
+        ydst[i] = in ? X_BYTES + row * 128 + ((chunk ^ (((px >> 1) & 1) << 2)) << 4) : -1;
     }
     u32x4 Xr[XP], Yr[YP];
     const int per_img = a.npx * a.npy;
@@ -501,45 +512,97 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
         for (int i = 0; i < YP; ++i)
             Yr[i] = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, (unsigned)yrel[i] + (unsigned)ybase, 0, 0);
     };
-    auto store_patch = [&]() {
+    auto store_patch = [&](int buf) {
+        unsigned char* base = wsm + buf * (X_BYTES + Y_BYTES);
 #pragma unroll
         for (int i = 0; i < XP; ++i)
-            if (xdst[i] >= 0) *reinterpret_cast<u32x4*>(xs + xdst[i]) = Xr[i];
+            if (xdst[i] >= 0) *reinterpret_cast<u32x4*>(base + xdst[i]) = Xr[i];
 #pragma unroll
         for (int i = 0; i < YP; ++i)
-            if (ydst[i] >= 0) *reinterpret_cast<u32x4*>(ys + ydst[i]) = Yr[i];
+            if (ydst[i] >= 0) *reinterpret_cast<u32x4*>(base + ydst[i]) = Yr[i];
     };
+
+    // fast-path lane constants: pixel column of this lane's two transposed reads and their swizzled byte offsets
+    int fa[2], fb[3][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int px = k_base + qq + 4 * h;                                   // 0..15 within the patch row
+        fa[h] = px * 128 + (a_col_bytes ^ (((px >> 1) & 1) << 6));
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int hx = px + kw;                                           // halo column of tap kw
+            fb[kw][h] = hx * 128 + (b_col_bytes ^ (((hx >> 1) & 1) << 6));
+        }
+    }
 
     const int p_begin = blockIdx.x * a.patches_per_wg;
     const int p_end = min(a.total_patches, p_begin + a.patches_per_wg);
     if (p_begin < p_end) {
         load_patch(p_begin);
-        store_patch();
+        store_patch(0);
+        load_patch(min(p_begin + 1, p_end - 1));
     }
     __syncthreads();
     for (int patch = p_begin; patch < p_end; ++patch) {
-        // the next patch travels HBM -> registers while this one is multiplied out of LDS (clamped at the end so
-        // the loop body has no conditional memory operations)
-        load_patch(min(patch + 1, p_end - 1));
+        const int cur = (patch - p_begin) & 1;
+        const unsigned char* xs = wsm + cur * (X_BYTES + Y_BYTES);
+        const unsigned char* ys = xs + X_BYTES;
+        if (FAST) {
+            // PW == 16: the 16 pixels of a K step are one patch row, so every LDS address is
+            // (per-lane constant of the horizontal tap) + (compile-time row offset): no address VALU in the loop.
+            // The tap group is wave-uniform; each group gets its own fully unrolled body (compile-time taps).
+            auto body = [&](auto tgc) {
+                constexpr int TG = decltype(tgc)::value;
+#pragma unroll
+                for (int kr = 0; kr < 8; ++kr) {                       // patch row = K step
+                    const s16x4 a0 = lds_tr16(ys + fa[0] + kr * 16 * 128);
+                    const s16x4 a1 = lds_tr16(ys + fa[1] + kr * 16 * 128);
+                    const bf16x8 af = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                    for (int tt = 0; tt < TG0; ++tt) {
+                        constexpr int dummy = 0;
+                        (void)dummy;
+                        const int t = TG * TG0 + tt;
+                        if (t < NT) {
+                            const int kh = t / KW, kw = t - kh * KW;
+                            const int ro = (kr + kh) * (16 + 2 * HALO) * 128;
+                            const s16x4 b0 = lds_tr16(xs + fb[kw][0] + ro);
+                            const s16x4 b1 = lds_tr16(xs + fb[kw][1] + ro);
+                            const bf16x8 bfr = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+                            acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[tt], 0, 0, 0);
+                        }
+                    }
+                }
+            };
+            if (tg == 0) body(std::integral_constant<int, 0>{});
+            else         body(std::integral_constant<int, 1>{});
+        } else {
         for (int ks = 0; ks < npix; ks += 16) {
             const int pix0 = ks + k_base + qq, pix1 = pix0 + 4;
-            const s16x4 a0 = lds_tr16(ys + pix0 * 128 + (a_col_bytes ^ (((pix0 >> 1) & 1) << 6)));
-            const s16x4 a1 = lds_tr16(ys + pix1 * 128 + (a_col_bytes ^ (((pix1 >> 1) & 1) << 6)));
+            const int px0 = pix0 & (a.PW - 1), px1 = pix1 & (a.PW - 1);
+            const s16x4 a0 = lds_tr16(ys + pix0 * 128 + (a_col_bytes ^ (((px0 >> 1) & 1) << 6)));
+            const s16x4 a1 = lds_tr16(ys + pix1 * 128 + (a_col_bytes ^ (((px1 >> 1) & 1) << 6)));
             const bf16x8 af = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
-            const int h0 = (pix0 >> a.lgPW) * HPW + (pix0 & (a.PW - 1));   // halo row of tap (0,0)
-            const int h1 = (pix1 >> a.lgPW) * HPW + (pix1 & (a.PW - 1));
+            const int h0 = (pix0 >> a.lgPW) * HPW + px0;   // halo row of tap (0,0)
+            const int h1 = (pix1 >> a.lgPW) * HPW + px1;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int toff = (t / KW) * HPW + (t % KW);
-                const int r0 = h0 + toff, r1 = h1 + toff;
-                const s16x4 b0 = lds_tr16(xs + r0 * 128 + (b_col_bytes ^ (((r0 >> 1) & 1) << 6)));
-                const s16x4 b1 = lds_tr16(xs + r1 * 128 + (b_col_bytes ^ (((r1 >> 1) & 1) << 6)));
-                const bf16x8 bfr = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[t], 0, 0, 0);
+            for (int tt = 0; tt < TG0; ++tt) {
+                const int t = tg * TG0 + tt;              // wave-uniform tap index
+                if (t < NT) {
+                    const int kw = t % KW;
+                    const int toff = (t / KW) * HPW + kw;
+                    const int r0 = h0 + toff, r1 = h1 + toff;
+                    const s16x4 b0 = lds_tr16(xs + r0 * 128 + (b_col_bytes ^ ((((px0 + kw) >> 1) & 1) << 6)));
+                    const s16x4 b1 = lds_tr16(xs + r1 * 128 + (b_col_bytes ^ ((((px1 + kw) >> 1) & 1) << 6)));
+                    const bf16x8 bfr = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[tt], 0, 0, 0);
+                }
             }
         }
-        __syncthreads();
-        store_patch();
+        }
+        // patch+1 (registers) -> the other LDS buffer (last read one barrier ago), patch+2 -> registers
+        store_patch(cur ^ 1);
+        load_patch(min(patch + 2, p_end - 1));
         __syncthreads();
     }
     // ---- each workgroup stores its partial (tap, co, ci) tile into its own slab with plain stores (fp32 atomics
@@ -548,11 +611,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
     const int col = lane & 31, rhalf = lane >> 5;
     float* slab = a.dwp + (long)blockIdx.x * NT * a.Cout * a.Cin;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
+    for (int tt = 0; tt < TG0; ++tt) {
+        const int t = tg * TG0 + tt;
+        if (t < NT) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * rhalf;
-            slab[((long)t * a.Cout + co0 + wc * 32 + row) * a.Cin + ci0 + wi * 32 + col] = acc[t][r];
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * rhalf;
+                slab[((long)t * a.Cout + co0 + wc * 32 + row) * a.Cin + ci0 + wi * 32 + col] = acc[tt][r];
+            }
         }
     }
 }
@@ -691,9 +757,9 @@ WgradPlan plan_wgrad(int B, int H, int W, int Cin, int Cout) {
     p.npy = H / p.PH;
     p.total_patches = B * p.npx * p.npy;
     const int tiles = (Cin / 64) * (Cout / 64);
-    // two workgroups per CU (the loop is single-buffered: the second workgroup hides the first one's loads);
-    // every workgroup costs one (taps x 64 x 64) fp32 slab of reduction traffic, so do not over-split
-    int nsplit = 512 / tiles;
+    // one 8-wave workgroup per CU (LDS double-buffered inside the kernel); every workgroup costs one
+    // (taps x 64 x 64) fp32 slab of reduction traffic, so do not over-split
+    int nsplit = 256 / tiles;
     if (nsplit < 1) nsplit = 1;
     if (nsplit > p.total_patches) nsplit = p.total_patches;
     p.patches_per_wg = (p.total_patches + nsplit - 1) / nsplit;
@@ -735,8 +801,26 @@ extern "C" int rgbd_conv2d_wgrad_bf16(const void* x, const void* dy, void* works
         rgbd_set_error("rgbd_conv2d_wgrad_bf16: memset failed");
         return -2;
     }
-    if (K == 3) conv_wgrad_kernel<9><<<grid, 256, 0, st>>>(a);
-    else        conv_wgrad_kernel<1><<<grid, 256, 0, st>>>(a);
+    {
+        static bool attr_done[4] = {false, false, false, false};
+        const bool fast = p.PW == 16 && p.PH == 8;
+        const int v = (K == 3 ? 0 : 2) + (fast ? 1 : 0);
+        const int lds = K == 3 ? 2 * (180 * 128 + 128 * 128) : 2 * (128 * 128 + 128 * 128);
+        const void* fn = K == 3 ? (fast ? (const void*)&conv_wgrad_kernel<9, true> : (const void*)&conv_wgrad_kernel<9, false>)
+                                : (fast ? (const void*)&conv_wgrad_kernel<1, true> : (const void*)&conv_wgrad_kernel<1, false>);
+        if (!attr_done[v]) {
+            RGBD_REQUIRE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess,
+                         "rgbd_conv2d_wgrad_bf16: cannot reserve %d B of LDS", lds);
+            attr_done[v] = true;
+        }
+        if (K == 3) {
+            if (fast) conv_wgrad_kernel<9, true><<<grid, 512, lds, st>>>(a);
+            else      conv_wgrad_kernel<9, false><<<grid, 512, lds, st>>>(a);
+        } else {
+            if (fast) conv_wgrad_kernel<1, true><<<grid, 512, lds, st>>>(a);
+            else      conv_wgrad_kernel<1, false><<<grid, 512, lds, st>>>(a);
+        }
+    }
     RGBD_CHECK_LAUNCH("conv_wgrad_kernel");
     const int groups = p.nsplit >= 64 ? 16 : (p.nsplit >= 8 ? 4 : 1);
     wgrad_reduce_kernel<<<dim3((unsigned)((total / 4 + 255) / 256), groups), 256, 0, st>>>((const float*)workspace, accum,

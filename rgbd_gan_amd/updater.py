@@ -344,7 +344,8 @@ class RGBDUpdater:
             st["z"] = self._stagers[zkey]
 
         fl = math.floor(min(stage, 17 - 1e-8))
-        graphable = self.use_graphs and fl % 2 == 0
+        # graphs are single-GPU only this round: capture next to a live RCCL communicator is untested on this pool
+        graphable = self.use_graphs and fl % 2 == 0 and not self._distributed()
         key = None
         if graphable:
             # graphs read their inputs from fixed addresses: park the batch in a persistent buffer
