@@ -78,7 +78,7 @@ int rgbd_pack_weights(const float* w, int cout, int cin, int kh, int kw, float s
  *         upsampled image (rescale.py:4-5 fused into the gather), so Hout = 2*Hin + 2*pad - KH + 1.
  *   wp  : packed weights [KH*KW][Cout][Cin] bf16 (rgbd_pack_weights).
  *   bias: (Cout) fp32 or NULL.  residual: (B,Hout,Wout,Cout) bf16 added after the bias, or NULL.
- *         lrelu_channels: output channels [0, lrelu_channels) then get leaky-ReLU(slope) (0 = none), i.e.
+ *         lrelu_channels (multiple of 16): output channels [0, lrelu_channels) then get leaky-ReLU(slope) (0 = none), i.e.
  *         y = lrelu(conv + bias + residual) as in net.py:413-416.
  *   y   : (B, Hout, Wout, Cout) bf16 NHWC.
  * Requires Cin % 64 == 0 and Cout % 64 == 0.  dgrad = this function on dY with w_dgrad, pad' = KH-1-pad.

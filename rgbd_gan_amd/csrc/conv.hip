@@ -32,6 +32,7 @@ struct ConvArgs {
     float slope;
     long M;
     int x_bytes, w_bytes;
+    int ptiles, wgs_per_ntile;      // patch kernel: pixel tiles per output-channel tile, persistent workgroups per N tile
 };
 
 __device__ __forceinline__ u32x4 ldg16(const unsigned short* p) { return *reinterpret_cast<const u32x4*>(p); }
@@ -249,19 +250,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(ConvArgs a) {
     unsigned char* const w_lds = dsm + 2 * P_BYTES;             // [3][W_BYTES]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int n_tiles = a.Cout / BN;
+    // ---- persistent tile loop: this workgroup owns output-channel tile `nt` and the pixel tiles [pt_begin, pt_end).
+    //      Consecutive logical workgroups get consecutive tile ranges and, through the XCD remap, share an L2
+    //      (neighbouring patches share halos; all of them share the weight tiles).
     unsigned bid = blockIdx.x;
     {
         const unsigned nwg = gridDim.x, xcd = bid & 7u, q8 = nwg >> 3, r8 = nwg & 7u;
         bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     }
-    const int nt = bid % n_tiles;
-    const int pt = bid / n_tiles;
-    const int tiles_x = a.Wout >> 4, tiles_y = a.Hout >> 4;
-    const int b = pt / (tiles_x * tiles_y);
-    const int rem = pt - b * tiles_x * tiles_y;
-    const int ty = rem / tiles_x;
-    const int y0 = ty << 4, x0 = (rem - ty * tiles_x) << 4;
+    const int nt = bid / a.wgs_per_ntile;
+    const int slot = bid - nt * a.wgs_per_ntile;
+    const int pt_begin = (int)((long)slot * a.ptiles / a.wgs_per_ntile);
+    const int pt_end = (int)((long)(slot + 1) * a.ptiles / a.wgs_per_ntile);
+    const int tiles_x = a.Wout >> 4, tiles_per_img = tiles_x * (a.Hout >> 4);
     const int n0 = nt * BN;
     const int wave_co = (wid / WAVES_PX) * 64;
     const int wave_py = (wid % WAVES_PX) * TPX;                  // first patch row of this wave
@@ -269,32 +270,54 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(ConvArgs a) {
     const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.x), 0, a.x_bytes, 0x00020000);
     const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.wp), 0, a.w_bytes, 0x00020000);
 
-    // ---- halo staging plan (fixed per thread).  Channel slice / tap offsets are wave-uniform and go into the
-    //      scalar offset operand of the buffer loads, so these stay the only address VGPRs.
-    const int hy0 = UPS ? (y0 >> 1) - 1 : y0 - 1, hx0 = UPS ? (x0 >> 1) - 1 : x0 - 1;
-    unsigned psrc[PP];
-    int pdst[PP];
+    const int nc = a.Cin >> 6;
+    const int g_total = (pt_end - pt_begin) * nc;               // (tile, channel slice) pairs of this workgroup
+    if (g_total <= 0) return;
+
+    // ---- halo staging: LDS destinations are fixed per thread; sources depend on the tile and are recomputed per
+    //      slice (once per nine K steps).  Channel-slice / tap offsets are wave-uniform scalars.
+    int pdst[PP], prow_hy[PP], prow_hx[PP];
 #pragma unroll
     for (int i = 0; i < PP; ++i) {
         const int p = tid + 512 * i;
         const int row = p >> 3, ch8 = p & 7;
         const int hy = row / HPW, hx = row - hy * HPW;
-        const int yy = hy0 + hy, xx = hx0 + hx;
-        const bool ok = row < NROWS && (unsigned)yy < (unsigned)a.Hin && (unsigned)xx < (unsigned)a.Win;
-        psrc[i] = ok ? (unsigned)((((b * a.Hin + yy) * a.Win + xx) * a.Cin + ch8 * 8) * 2) : 0x80000000u;
+        prow_hy[i] = row < NROWS ? hy : -100000;
+        prow_hx[i] = hx;
         pdst[i] = row < NROWS ? row * 128 + ((ch8 ^ (hx & 7)) << 4) : -1;
     }
+    const int pch8 = (tid & 7) * 8;
     const int wrow = tid >> 3, wch8 = tid & 7;
     const int wdst = wrow * 128 + ((wch8 ^ (wrow & 7)) << 4);
-    const unsigned wsrc0 = (unsigned)(((n0 + wrow) * a.Cin + wch8 * 8) * 2);
+    // LDS row (64*w + 16*t + m) of the weight tile holds output channel 64*w + 16*(m>>2) + 4*t + (m&3): with the
+    // 16x16 MFMA accumulator layout (lane q = lane>>4 holds rows 4q..4q+3 of each 16-row tile t) every lane then
+    // owns 16 CONSECUTIVE output channels of its pixel -> 16-byte NHWC stores, four lanes cover a 128-byte line
+    const int wm = wrow & 15, wt = (wrow >> 4) & 3;
+    const int wperm = (wrow & ~63) + 16 * (wm >> 2) + 4 * wt + (wm & 3);
+    const unsigned wsrc0 = (unsigned)(((n0 + wperm) * a.Cin + wch8 * 8) * 2);
     const int tap_stride = a.Cout * a.Cin * 2;
     const int row64_stride = 64 * a.Cin * 2;
 
-    const int nc = a.Cin >> 6;
     u32x4 Pr[PP], Wr[3][WP];
-    auto load_patch = [&](int c) {
+    auto tile_origin = [&](int pt, int& b, int& y0, int& x0) {
+        b = pt / tiles_per_img;
+        const int rem = pt - b * tiles_per_img;
+        const int ty = rem / tiles_x;
+        y0 = ty << 4;
+        x0 = (rem - ty * tiles_x) << 4;
+    };
+    auto load_patch = [&](int g) {                              // g: global (tile, slice) index, clamped by caller
+        const int ti = g / nc, c = g - ti * nc;
+        int b, y0, x0;
+        tile_origin(pt_begin + ti, b, y0, x0);
+        const int hy0 = UPS ? (y0 >> 1) - 1 : y0 - 1, hx0 = UPS ? (x0 >> 1) - 1 : x0 - 1;
 #pragma unroll
-        for (int i = 0; i < PP; ++i) Pr[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, psrc[i], c * 128, 0);
+        for (int i = 0; i < PP; ++i) {
+            const int yy = hy0 + prow_hy[i], xx = hx0 + prow_hx[i];
+            const bool ok = (unsigned)yy < (unsigned)a.Hin && (unsigned)xx < (unsigned)a.Win;
+            const unsigned off = ok ? (unsigned)((((b * a.Hin + yy) * a.Win + xx) * a.Cin + pch8) * 2) : 0x80000000u;
+            Pr[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, c * 128, 0);
+        }
     };
     auto store_patch = [&](int buf) {
 #pragma unroll
@@ -350,65 +373,85 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(ConvArgs a) {
         }
     };
 
-    // ---- prologue
+    // bias of this lane's 16 output channels: loaded once (the output-channel tile is fixed for the whole persistent
+    // loop) -- a load inside the per-tile epilogue would wait behind, and so drain, the prefetched next tile
+    float bv[16];
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) bv[k2] = a.bias ? a.bias[n0 + wave_co + 16 * q + k2] : 0.f;
+
+    auto epilogue = [&](int pt) {       // bias -> residual -> leaky ReLU -> bf16 NHWC, then clear the accumulators
+        int b, y0, x0;
+        tile_origin(pt, b, y0, x0);
+        const int co = n0 + wave_co + 16 * q;            // this lane's 16 consecutive output channels
+        const bool act = co < a.lrelu_ch;
+#pragma unroll
+        for (int j = 0; j < TPX; ++j) {
+            const int yy = y0 + wave_py + j, xx = x0 + r16;
+            const long o = (((long)b * a.Hout + yy) * a.Wout + xx) * a.Cout + co;
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[4 * i + r] = acc[i][j][r] + bv[4 * i + r];
+            if (a.resid) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const u32x4 rr = *reinterpret_cast<const u32x4*>(a.resid + o + 8 * h);
+#pragma unroll
+                    for (int w2 = 0; w2 < 4; ++w2) {
+                        v[8 * h + 2 * w2] += bf16_lo(rr[w2]);
+                        v[8 * h + 2 * w2 + 1] += bf16_hi(rr[w2]);
+                    }
+                }
+            }
+            if (act) {
+#pragma unroll
+                for (int k2 = 0; k2 < 16; ++k2) v[k2] = v[k2] > 0.f ? v[k2] : v[k2] * a.slope;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                u32x4 out = {pack_bf16x2(v[8 * h + 0], v[8 * h + 1]), pack_bf16x2(v[8 * h + 2], v[8 * h + 3]),
+                             pack_bf16x2(v[8 * h + 4], v[8 * h + 5]), pack_bf16x2(v[8 * h + 6], v[8 * h + 7])};
+                *reinterpret_cast<u32x4*>(a.y + o + 8 * h) = out;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+
+    // ---- prologue (once per workgroup; later tiles are prefetched under the previous tile's K steps)
     load_patch(0);
     load_w(0, 0, Wr[0]);
     load_w(0, 1, Wr[1]);
     load_w(0, 2, Wr[2]);
     store_patch(0);
     store_w(0, Wr[0]);
-    load_patch(min(1, nc - 1));
+    load_patch(min(1, g_total - 1));
     __syncthreads();
-    // ---- main loop: nine statically unrolled tap steps per 64-channel slice; every memory operation is
-    //      unconditional (indices clamp at the tail) so hipcc keeps counted vmcnt waits across the barriers.
-    //      Weight tile k+3 is requested while tile k is multiplied: two full K steps of latency cover.
-    for (int c = 0; c < nc; ++c) {
-        const unsigned char* pbuf = patch_lds + (c & 1) * P_BYTES;
+    // ---- main loop over (tile, channel slice) pairs; nine statically unrolled tap steps each.  Every memory
+    //      operation in the tap loop is unconditional (indices clamp / wrap) so hipcc keeps counted vmcnt waits
+    //      across the barriers.  Weight tile k+3 is requested while tile k is multiplied.
+    int c = 0, pt = pt_begin;
+    for (int g = 0; g < g_total; ++g) {
+        const unsigned char* pbuf = patch_lds + (g & 1) * P_BYTES;
+        const int c_next = c + 1 == nc ? 0 : c + 1;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             compute(pbuf, w_lds + (t % 3) * W_BYTES, t / 3, t % 3);
             store_w((t + 1) % 3, Wr[(t + 1) % 3]);
-            if (t == 6) store_patch((c + 1) & 1);
-            const int t3 = (t + 3) % 9;
-            const int c3 = min(c + (t + 3) / 9, nc - 1);
-            load_w(c3, t3, Wr[t % 3]);                 // Wr[t % 3] (tile k) went to LDS one step ago
+            if (t == 6) store_patch((g + 1) & 1);
+            load_w(t + 3 >= 9 ? c_next : c, (t + 3) % 9, Wr[t % 3]);   // Wr[t % 3] (tile k) went to LDS one step ago
             if (t == 7) {
                 asm volatile("" ::: "memory");
-                load_patch(min(c + 2, nc - 1));
+                load_patch(min(g + 2, g_total - 1));
             }
             __syncthreads();
         }
-    }
-
-    // ---- epilogue: bias -> residual -> leaky ReLU -> bf16 NHWC
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int co = n0 + wave_co + i * 16 + 4 * q;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (a.bias) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(a.bias + co);
-            bv[0] = t[0]; bv[1] = t[1]; bv[2] = t[2]; bv[3] = t[3];
+        if (c_next == 0) {             // last slice of this pixel tile: write it out while the next tile streams in
+            epilogue(pt);
+            ++pt;
         }
-        const bool act = co < a.lrelu_ch;
-#pragma unroll
-        for (int j = 0; j < TPX; ++j) {
-            const int yy = y0 + wave_py + j, xx = x0 + r16;
-            const long o = (((long)b * a.Hout + yy) * a.Wout + xx) * a.Cout + co;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[r];
-            if (a.resid) {
-                const u32x2 rr = *reinterpret_cast<const u32x2*>(a.resid + o);
-                v[0] += bf16_lo(rr[0]); v[1] += bf16_hi(rr[0]);
-                v[2] += bf16_lo(rr[1]); v[3] += bf16_hi(rr[1]);
-            }
-            if (act) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : v[r] * a.slope;
-            }
-            u32x2 out = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-            *reinterpret_cast<u32x2*>(a.y + o) = out;
-        }
+        c = c_next;
     }
 }
 
@@ -686,8 +729,8 @@ extern "C" int rgbd_conv2d_fprop_bf16(const void* x, const void* wp, const float
     RGBD_REQUIRE(B > 0 && Hin > 0 && Win > 0 && KH > 0 && KW > 0 && pad >= 0, "rgbd_conv2d_fprop_bf16: bad shape");
     RGBD_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0,
                  "rgbd_conv2d_fprop_bf16: Cin and Cout must be multiples of 64 (Cin=%d Cout=%d)", Cin, Cout);
-    RGBD_REQUIRE(lrelu_channels % 4 == 0 && lrelu_channels >= 0 && lrelu_channels <= Cout,
-                 "rgbd_conv2d_fprop_bf16: lrelu_channels must be a multiple of 4 in [0, Cout]");
+    RGBD_REQUIRE(lrelu_channels % 16 == 0 && lrelu_channels >= 0 && lrelu_channels <= Cout,
+                 "rgbd_conv2d_fprop_bf16: lrelu_channels must be a multiple of 16 in [0, Cout]");
     ConvArgs a;
     a.x = (const unsigned short*)x; a.wp = (const unsigned short*)wp; a.bias = bias;
     a.resid = (const unsigned short*)residual; a.y = (unsigned short*)y;
@@ -707,8 +750,25 @@ extern "C" int rgbd_conv2d_fprop_bf16(const void* x, const void* wp, const float
     hipStream_t st = (hipStream_t)stream;
     if (KH == 3 && KW == 3 && pad == 1 && a.Hout % 16 == 0 && a.Wout % 16 == 0 && !g_force_gather) {
         const bool wide = Cout % 128 == 0;
-        const long grid = (long)B * (a.Hout / 16) * (a.Wout / 16) * (wide ? Cout / 128 : Cout / 64);
-        RGBD_REQUIRE(grid < 0x7fffffffL, "rgbd_conv2d_fprop_bf16: grid too large");
+        const int n_tiles = wide ? Cout / 128 : Cout / 64;
+        const long ptiles = (long)B * (a.Hout / 16) * (a.Wout / 16);
+        RGBD_REQUIRE(ptiles < 0x7fffffffL, "rgbd_conv2d_fprop_bf16: too many tiles");
+        // persistent workgroups: one per CU (the kernel's LDS footprint allows exactly one), split evenly over the
+        // output-channel tiles; each walks a contiguous range of pixel tiles
+        static int num_cus = 0;
+        if (num_cus == 0) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                num_cus = prop.multiProcessorCount;
+            if (num_cus <= 0) num_cus = 256;
+        }
+        int per_nt = num_cus / n_tiles;
+        if (per_nt < 1) per_nt = 1;
+        if (per_nt > ptiles) per_nt = (int)ptiles;
+        a.ptiles = (int)ptiles;
+        a.wgs_per_ntile = per_nt;
+        const long grid = (long)per_nt * n_tiles;
         const int lds = 2 * 324 * 128 + 3 * (wide ? 128 : 64) * 128;
         const void* fn = wide ? (a.ups ? (const void*)&conv3x3_patch_kernel<128, true>
                                        : (const void*)&conv3x3_patch_kernel<128, false>)
@@ -761,7 +821,10 @@ WgradPlan plan_wgrad(int B, int H, int W, int Cin, int Cout) {
     // (taps x 64 x 64) fp32 slab of reduction traffic, so do not over-split
     int nsplit = 256 / tiles;
     if (nsplit < 1) nsplit = 1;
-    if (nsplit > p.total_patches) nsplit = p.total_patches;
+    // small layers: a slab costs 147 KB of traffic (written, then read by the reduction) -- as much as ~18 patches of
+    // operands -- so give every workgroup at least 8 patches even if that leaves CUs idle
+    if (nsplit > p.total_patches / 8) nsplit = p.total_patches / 8;
+    if (nsplit < 1) nsplit = 1;
     p.patches_per_wg = (p.total_patches + nsplit - 1) / nsplit;
     p.nsplit = (p.total_patches + p.patches_per_wg - 1) / p.patches_per_wg;
     return p;
