@@ -1,0 +1,90 @@
+"""The shipped configs drive the engine unmodified (keys identical to the reference's YAML files): DCGAN generator
+parity, a DCGAN training step, and train_rgbd.py end to end on a synthetic images.npy."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import camera, nets
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def rel_err(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("stage", [8.0, 9.5])
+def test_dcgan_generator_matches_oracle(stage):
+    from rgbd_gan_amd.net import DCGANGenerator
+    p = nets.init_dcgan(in_ch=256, ch=512, seed=3)
+    gen = DCGANGenerator(256, rgbd=True)                 # reference: DCGANGenerator(config.ch) -> in_ch=256, ch=512
+    gen.load_state_dict(p)
+    z = nets.make_hidden_dcgan(2, 256, np.random.RandomState(1))
+    np.random.seed(4)
+    t9 = camera.theta9(camera.PosePrior(0.3054, 3.1415, 0).sample(2))
+    with torch.no_grad():
+        ref = nets.dcgan_generator(p, z, stage, t9)
+        got = gen(z, stage, t9).cpu()
+    assert got.shape == ref.shape
+    assert rel_err(got[:, :3], ref[:, :3]) < 5e-2
+    torch.testing.assert_close(got[:, 3], ref[:, 3], atol=1e-5, rtol=1e-5)
+
+
+def test_dcgan_config_training_steps_run():
+    from rgbd_gan_amd.training import DeviceImageIterator, build_training
+    from rgbd_gan_amd.utils import yaml_utils
+    cfg = yaml_utils.load(os.path.join(ROOT, "configs", "dcgan_shapenet_car.yml"))
+    images = np.random.RandomState(0).randint(0, 256, (16, 3, 128, 128)).astype("uint8")
+    np.random.seed(0)
+    torch.manual_seed(0)
+    it = DeviceImageIterator(images, 8, "cuda:0", seed=0)             # BASELINE C1: 64x64 (stage 8), batch 8
+    gen, dis, opt, upd = build_training(cfg, "cuda:0", iterator=it, fixed_stage=8.0, nan_check_interval=1)
+    assert "map" not in opt
+    upd.iteration = 3000
+    w0 = gen.store["blocks/3/c1/c/W"].detach().clone()
+    for _ in range(4):
+        upd.update()
+    obs = {k: float(v) for k, v in upd.observation.items()}
+    assert obs["image_size"] == 64 and obs["batch_size"] == 8
+    assert all(np.isfinite(v) for v in obs.values())
+    assert float((gen.store["blocks/3/c1/c/W"] - w0).abs().max()) > 0
+    assert int(opt["gen"].t) == 4 and int(opt["dis"].t) == 4
+
+
+def test_train_rgbd_cli_end_to_end(tmp_path):
+    """python train_rgbd.py --config_path <ffhq config with paths / iteration count patched> on a synthetic images.npy:
+    progressive stage 6 (32x32) from iteration 0, snapshots + log written, then resume."""
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "ffhq_stylegan_occlusion.yml")))
+    data = tmp_path / "data"
+    out = tmp_path / "out"
+    data.mkdir()
+    np.save(data / "images.npy", np.random.RandomState(0).randint(0, 256, (24, 3, 128, 128)).astype("uint8"))
+    cfg.update(dataset_path=str(data), out=str(out), iteration=6, batchsize=4, snapshot_interval=3, display_interval=2)
+    path = tmp_path / "cfg.yml"
+    yaml.safe_dump(cfg, open(path, "w"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train_rgbd.py"), "-g", "0", "--config_path", str(path)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    files = set(os.listdir(out))
+    assert {"Generator_3.npz", "Discriminator_3.npz", "snapshot_iter_3.npz", "Generator_6.npz", "Generator_latest.npz",
+            "Discriminator_latest.npz", "log"} <= files
+    log = json.load(open(out / "log"))
+    assert log[-1]["iteration"] == 6 and log[-1]["image_size"] == 32 and abs(log[-1]["stage"] - 6.0) < 1e-3
+    g = np.load(out / "Generator_latest.npz")
+    assert "mapping/l/0/c/W" in g.files and "gen/blocks/5/c1/c/W" in g.files and g["gen/outs/5/c/W"].shape == (4, 64, 1, 1)
+    # resume from iteration 6 up to 8
+    cfg.update(iteration=8, get_model_from_interation="6")
+    yaml.safe_dump(cfg, open(path, "w"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train_rgbd.py"), "--config", str(path)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Resume from 6" in r.stdout
+    assert json.load(open(out / "log"))[-1]["iteration"] == 8
