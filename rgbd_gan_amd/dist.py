@@ -15,12 +15,16 @@ class Communicator:
         self.size = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.intra_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if os.environ.get("RGBD_SHARE_DEVICE"):          # every rank on cuda:0 (single-GPU test boxes)
+            self.intra_rank = 0
         self.owns_group = False
         if self.size > 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             if backend is None:
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+                # RGBD_DIST_BACKEND=gloo lets several ranks share one GPU (tests of the multi-process path on a
+                # single-GPU box; RCCL refuses duplicate devices)
+                backend = os.environ.get("RGBD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             if backend == "nccl":
                 torch.cuda.set_device(self.intra_rank)
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.size)

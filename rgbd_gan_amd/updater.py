@@ -292,8 +292,18 @@ class RGBDUpdater:
                 return
             graph = torch.cuda.CUDAGraph()
             saved = dict(self.observation)
-            with torch.cuda.graph(graph):
+            try:
+                with torch.cuda.graph(graph):
+                    fn(st)
+            except Exception as exc:      # capture refused (driver / collective library state): stay correct, go eager
+                import sys
+                print(f"[rgbd_gan_amd] HIP graph capture of phase '{name}' failed ({type(exc).__name__}: {exc}); "
+                      "continuing without graphs", file=sys.stderr, flush=True)
+                self.use_graphs = False
+                self._graphs.clear()
+                torch.cuda.synchronize()
                 fn(st)
+                return
             # keep every tensor the phase handed over alive: it lives in the graph's private pool
             entry = {"graph": graph, "st": dict(st), "obs": {k: v for k, v in self.observation.items()
                                                              if saved.get(k) is not v}}
@@ -344,8 +354,9 @@ class RGBDUpdater:
             st["z"] = self._stagers[zkey]
 
         fl = math.floor(min(stage, 17 - 1e-8))
-        # graphs are single-GPU only this round: capture next to a live RCCL communicator is untested on this pool
-        graphable = self.use_graphs and fl % 2 == 0 and not self._distributed()
+        # under data parallelism the G and D phases are still replayed as graphs; the collectives and the optimizer
+        # phase (which waits on them) stay eager
+        graphable = self.use_graphs and fl % 2 == 0
         key = None
         if graphable:
             # graphs read their inputs from fixed addresses: park the batch in a persistent buffer
