@@ -135,6 +135,33 @@ int rgbd_to_planes(const void* h, const float* w, const float* bias, float* out,
 int rgbd_planes_outer(const void* t, const float* planes, float* o, float* tsum, int B, int HW, int KP, int C,
                       void* stream);
 
+/* ------------------------------------------------------------------ DeepVoxels frustum path (config 4)
+ * rgbd_proj_idcs: deepvoxel/projection.py:48-105 (compute_proj_idcs) for a whole batch of cameras at once.
+ *   cam2world (B,16) fp32 row-major 4x4.  Frustum of W x H x D elements, grid of G^3 voxels.
+ *   Out: idx (B,N) int32 and coords (B,3,N) fp32, N = W*H*D, compacted IN ORDER (first counts[b] entries valid),
+ *   counts (B) int32.  workspace: B * ceil(N/256) int32.  Index math unfused fp32, bit-exact vs oracle/deepvoxels.py.
+ * rgbd_trilinear_{fwd,bwd}: deepvoxel.py:388-428 (interpolate_trilinear); grid (B,F,G,G,G) fp32 indexed [x][y][z]
+ *   with x = coords[2], y = coords[1], z = coords[0]; out (B,F,N) (zero-filled inside; reshape to (B,F,D,H,W)).
+ * rgbd_occlusion_accum_{fwd,bwd}: deepvoxel.py:574-587 (AccumulativeOcclusionNet, occnet_nf = 4) + the compositing of
+ *   DeepVoxels.forward :886-889 + depth rescale :903-904.  vol (B,F,D,HW) fp32; W1 (4,F+1) [column 0 = depth
+ *   coordinate], b1 (4), W2 (4), b2 (1) fp32 master weights (equalized-LR scales applied inside).
+ *   fwd out: s, w (B,D,HW) (saved for bwd), feat (B,F,HW), depth (B,HW).
+ *   bwd out: dvol (B,F,D,HW); dparams = [dW1 | db1 | dW2 | db2] (zeroed inside); dw_ws, ds_ws: (B,D,HW) workspaces.
+ */
+int rgbd_proj_idcs(const float* cam2world, int B, int W, int H, int D, int G, float voxel_size, float near_plane,
+                   float fx, float fy, float cx, float cy, int32_t* idx, float* coords, int32_t* counts,
+                   int32_t* workspace, void* stream);
+int rgbd_trilinear_fwd(const float* grid, const int32_t* idx, const float* coords, const int32_t* counts, float* out,
+                       int B, int F, int G, int N, void* stream);
+int rgbd_trilinear_bwd(const float* dout, const int32_t* idx, const float* coords, const int32_t* counts, float* dgrid,
+                       int B, int F, int G, int N, void* stream);
+int rgbd_occlusion_accum_fwd(const float* vol, const float* W1, const float* b1, const float* W2, const float* b2,
+                             float threshold, float voxel_size, float near_plane, float* s, float* w, float* feat,
+                             float* depth, int B, int F, int D, int HW, void* stream);
+int rgbd_occlusion_accum_bwd(const float* vol, const float* W1, const float* b1, const float* W2, const float* s,
+                             const float* w, const float* dfeat, const float* ddepth, float voxel_size, float* dw_ws,
+                             float* ds_ws, float* dvol, float* dparams, int B, int F, int D, int HW, void* stream);
+
 /* ------------------------------------------------------------------ optimizer
  * Replaces chainer.optimizers.Adam + GradientClipping(5) (train_rgbd.py:151-161), one launch group per
  * optimizer instead of one elementwise kernel per parameter tensor.

@@ -17,6 +17,7 @@ SOURCES = [
     ("elementwise.hip", []),
     ("warp_loss.hip", ["-ffp-contract=off"]),
     ("conv.hip", []),
+    ("deepvoxels.hip", ["-ffp-contract=off"]),
 ]
 COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 

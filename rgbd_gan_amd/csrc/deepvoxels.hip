@@ -1,0 +1,441 @@
+// DeepVoxels frustum path (config 4 of the reference): projection index math, trilinear resampling of the voxel grid
+// into the camera frustum, accumulative occlusion compositing.  All HBM-bound (4.2 MB grid -> 29.4 MB frustum volume
+// per sample); fp32 like the reference.
+//
+// Replaces deepvoxel/projection.py:48-105 (compute_proj_idcs, a Python loop over the batch with boolean
+// compaction), deepvoxel/deepvoxel.py:388-428 (interpolate_trilinear: 8 advanced-index gathers + scatter_add) and
+// deepvoxel/deepvoxel.py:574-587,886-889,903-904 (AccumulativeOcclusionNet + compositing + depth rescale).
+//
+// COMPILED WITH -ffp-contract=off: the index math is specified unfused, left to right, in float32
+// (oracle/deepvoxels.py), and must be bit-exact against it.
+#include "common.h"
+
+namespace {
+
+struct FrustumArgs {
+    int W, H, D, G;          // image width/height, frustum depth, grid side
+    float voxel, near_plane, fx, fy, cx, cy;
+};
+
+// voxel coordinates of frustum element n for camera matrix C (row-major 4x4); returns the in-grid mask
+__device__ __forceinline__ bool frustum_point(const FrustumArgs& f, const float* __restrict__ C, int n, float v[3]) {
+    const int wh = f.W * f.H;
+    const int zi = n / wh;
+    float zc = (float)zi;
+    const int tmp = n - (int)((zc * (float)f.W) * (float)f.H);
+    float yc = (float)tmp / (float)f.W;                 // true division: fractional row coordinate (projection.py:69)
+    float xc = (float)(tmp % f.W);
+    zc = zc * f.voxel;
+    zc = zc + f.near_plane;
+    xc = (xc - f.cx) / f.fx;
+    yc = (yc - f.cy) / f.fy;
+    xc = xc * zc;
+    yc = yc * zc;
+    bool in = true;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float g = ((C[4 * k + 0] * xc + C[4 * k + 1] * yc) + C[4 * k + 2] * zc) + C[4 * k + 3];
+        v[k] = g / f.voxel + (float)(f.G / 2);
+        in = in && (v[k] >= 0.f) && (v[k] < (float)f.G);
+    }
+    return in;
+}
+
+// pass 1: number of in-grid elements per 256-element block (order-preserving compaction needs a scan)
+__global__ __launch_bounds__(256) void proj_count_kernel(FrustumArgs f, const float* __restrict__ cams, int N,
+                                                         int* __restrict__ block_counts) {
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    float v[3];
+    const bool in = n < N && frustum_point(f, cams + b * 16, n, v);
+    const unsigned long long m = __ballot(in);
+    __shared__ int wc[4];
+    if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[b * gridDim.x + blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+}
+
+// pass 2: exclusive scan of the block counts of one sample (one block per sample), total -> counts[b]
+__global__ __launch_bounds__(1024) void proj_scan_kernel(int* __restrict__ block_counts, int nblocks,
+                                                         int* __restrict__ counts) {
+    const int b = blockIdx.x;
+    int* bc = block_counts + b * nblocks;
+    __shared__ int part[1024];
+    const int per = (nblocks + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = min(nblocks, lo + per);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += bc[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {          // Hillis-Steele inclusive scan
+        const int t = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - s;
+    for (int i = lo; i < hi; ++i) { const int c = bc[i]; bc[i] = run; run += c; }
+    if (threadIdx.x == 1023) counts[b] = part[1023];
+}
+
+// pass 3: recompute and write (n, v) at block offset + rank inside the block
+__global__ __launch_bounds__(256) void proj_write_kernel(FrustumArgs f, const float* __restrict__ cams, int N,
+                                                         const int* __restrict__ block_offsets,
+                                                         int* __restrict__ idx, float* __restrict__ coords) {
+    const int b = blockIdx.y;
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    float v[3];
+    const bool in = n < N && frustum_point(f, cams + b * 16, n, v);
+    const unsigned long long m = __ballot(in);
+    __shared__ int wc[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) wc[wid] = __popcll(m);
+    __syncthreads();
+    int base = block_offsets[b * gridDim.x + blockIdx.x];
+    for (int w2 = 0; w2 < wid; ++w2) base += wc[w2];
+    if (in) {
+        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        idx[(long)b * N + pos] = n;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) coords[((long)b * 3 + k) * N + pos] = v[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ trilinear
+struct Corners {
+    int o[8];
+    float w[8];
+};
+
+__device__ __forceinline__ Corners trilinear_corners(const float* __restrict__ coords, long base, int N, int pos,
+                                                     int G) {
+    // deepvoxel.py:394-410: x = v[2], y = v[1], z = v[0]; grid indexed [x][y][z]
+    const float xi = coords[base + 2l * N + pos], yi = coords[base + 1l * N + pos], zi = coords[base + pos];
+    const int x0 = (int)xi, y0 = (int)yi, z0 = (int)zi;
+    const int x1 = min(max(x0 + 1, 0), G - 1), y1 = min(max(y0 + 1, 0), G - 1), z1 = min(max(z0 + 1, 0), G - 1);
+    const float x = xi - (float)x0, y = yi - (float)y0, z = zi - (float)z0;
+    Corners c;
+    // same order as the reference's eight terms; each weight is a left-to-right product
+    c.o[0] = (x0 * G + y0) * G + z0; c.w[0] = ((1.f - x) * (1.f - y)) * (1.f - z);
+    c.o[1] = (x1 * G + y0) * G + z0; c.w[1] = (x * (1.f - y)) * (1.f - z);
+    c.o[2] = (x0 * G + y1) * G + z0; c.w[2] = ((1.f - x) * y) * (1.f - z);
+    c.o[3] = (x0 * G + y0) * G + z1; c.w[3] = ((1.f - x) * (1.f - y)) * z;
+    c.o[4] = (x1 * G + y0) * G + z1; c.w[4] = (x * (1.f - y)) * z;
+    c.o[5] = (x0 * G + y1) * G + z1; c.w[5] = ((1.f - x) * y) * z;
+    c.o[6] = (x1 * G + y1) * G + z0; c.w[6] = (x * y) * (1.f - z);
+    c.o[7] = (x1 * G + y1) * G + z1; c.w[7] = (x * y) * z;
+    return c;
+}
+
+// out (B,F,N) must be zero-filled; thread = one compacted frustum element, loop over features
+__global__ __launch_bounds__(256) void trilinear_fwd_kernel(const float* __restrict__ grid, const int* __restrict__ idx,
+                                                            const float* __restrict__ coords,
+                                                            const int* __restrict__ counts, float* __restrict__ out,
+                                                            int F, int G, int N) {
+    const int b = blockIdx.y;
+    const int pos = blockIdx.x * 256 + threadIdx.x;
+    if (pos >= counts[b]) return;
+    const Corners c = trilinear_corners(coords, (long)b * 3 * N, N, pos, G);
+    const int n = idx[(long)b * N + pos];
+    const long g3 = (long)G * G * G;
+    for (int f = 0; f < F; ++f) {
+        const float* g = grid + ((long)b * F + f) * g3;
+        float acc = g[c.o[0]] * c.w[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) acc = acc + g[c.o[k]] * c.w[k];
+        out[((long)b * F + f) * N + n] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void trilinear_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ idx,
+                                                            const float* __restrict__ coords,
+                                                            const int* __restrict__ counts, float* __restrict__ dgrid,
+                                                            int F, int G, int N) {
+    const int b = blockIdx.y;
+    const int pos = blockIdx.x * 256 + threadIdx.x;
+    if (pos >= counts[b]) return;
+    const Corners c = trilinear_corners(coords, (long)b * 3 * N, N, pos, G);
+    const int n = idx[(long)b * N + pos];
+    const long g3 = (long)G * G * G;
+    for (int f = 0; f < F; ++f) {
+        const float go = dout[((long)b * F + f) * N + n];
+        float* g = dgrid + ((long)b * F + f) * g3;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) atomicAdd(g + c.o[k], go * c.w[k]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ occlusion
+constexpr int OCC_NF = 4;       // occnet_nf (deepvoxel.py:835)
+constexpr int OCC_MAXF = 32;    // grid features
+
+struct OccArgs {
+    int B, F, D, HW;            // vol is (B, F, D, HW)
+    float c1, c2, threshold;    // equalized-LR scales sqrt(2/(F+1)), sqrt(2/nf)
+};
+
+__device__ __forceinline__ float depth_coord(int d, int D) { return (float)(d - D / 2) / (float)D; }
+
+// s[b,d,p] = sigmoid( W2 . lrelu(W1 . c1*[coord, vol] + b1) * c2 + b2 - threshold )
+__global__ __launch_bounds__(256) void occ_score_kernel(OccArgs a, const float* __restrict__ vol,
+                                                        const float* __restrict__ W1, const float* __restrict__ b1,
+                                                        const float* __restrict__ W2, const float* __restrict__ b2,
+                                                        float* __restrict__ s) {
+    const long vox = (long)a.D * a.HW;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)a.B * vox) return;
+    const int b = (int)(i / vox);
+    const long r = i - (long)b * vox;
+    const int d = (int)(r / a.HW);
+    float h[OCC_NF];
+    const float xc = depth_coord(d, a.D) * a.c1;
+#pragma unroll
+    for (int j = 0; j < OCC_NF; ++j) h[j] = b1[j] + W1[j * (a.F + 1)] * xc;
+    for (int f = 0; f < a.F; ++f) {
+        const float x = vol[((long)b * a.F + f) * vox + r] * a.c1;
+#pragma unroll
+        for (int j = 0; j < OCC_NF; ++j) h[j] += W1[j * (a.F + 1) + 1 + f] * x;
+    }
+    float pre = b2[0];
+#pragma unroll
+    for (int j = 0; j < OCC_NF; ++j) {
+        const float hj = h[j] > 0.f ? h[j] : 0.2f * h[j];
+        pre += W2[j] * (hj * a.c2);
+    }
+    s[i] = 1.f / (1.f + __expf(-(pre - a.threshold)));
+}
+
+// per ray: w[d] = clip(cumsum s, 0, 1)[d] - clip(...)[d-1]; depth = sum w * coord (rescaled)
+__global__ __launch_bounds__(256) void occ_scan_kernel(OccArgs a, const float* __restrict__ s, float* __restrict__ w,
+                                                       float* __restrict__ depth, float depth_scale, float near_plane) {
+    const long ray = (long)blockIdx.x * 256 + threadIdx.x;
+    if (ray >= (long)a.B * a.HW) return;
+    const int b = (int)(ray / a.HW);
+    const int p = (int)(ray - (long)b * a.HW);
+    const long base = (long)b * a.D * a.HW + p;
+    float run = 0.f, prev = 0.f, dacc = 0.f;
+    for (int d = 0; d < a.D; ++d) {
+        run += s[base + (long)d * a.HW];
+        const float c = fminf(fmaxf(run, 0.f), 1.f);
+        const float wd = c - prev;
+        prev = c;
+        w[base + (long)d * a.HW] = wd;
+        dacc += depth_coord(d, a.D) * wd;
+    }
+    depth[ray] = ((dacc + 0.5f) * depth_scale) + near_plane;
+}
+
+// feat[b,f,p] = sum_d w[b,d,p] * vol[b,f,d,p]
+__global__ __launch_bounds__(256) void occ_compose_kernel(OccArgs a, const float* __restrict__ vol,
+                                                          const float* __restrict__ w, float* __restrict__ feat) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)a.B * a.F * a.HW) return;
+    const int p = (int)(i % a.HW);
+    const long bf = i / a.HW;
+    const int b = (int)(bf / a.F);
+    float acc = 0.f;
+    for (int d = 0; d < a.D; ++d)
+        acc += w[((long)b * a.D + d) * a.HW + p] * vol[(bf * a.D + d) * a.HW + p];
+    feat[i] = acc;
+}
+
+// backward 1: dw[b,d,p] = sum_f dfeat[b,f,p] * vol[b,f,d,p] + ddepth'[b,p] * coord(d)
+__global__ __launch_bounds__(256) void occ_bwd_dw_kernel(OccArgs a, const float* __restrict__ vol,
+                                                         const float* __restrict__ dfeat,
+                                                         const float* __restrict__ ddepth, float depth_scale,
+                                                         float* __restrict__ dw) {
+    const long vox = (long)a.D * a.HW;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)a.B * vox) return;
+    const int b = (int)(i / vox);
+    const long r = i - (long)b * vox;
+    const int d = (int)(r / a.HW);
+    const int p = (int)(r - (long)d * a.HW);
+    float acc = ddepth[(long)b * a.HW + p] * depth_scale * depth_coord(d, a.D);
+    for (int f = 0; f < a.F; ++f) acc += dfeat[((long)b * a.F + f) * a.HW + p] * vol[((long)b * a.F + f) * vox + r];
+    dw[i] = acc;
+}
+
+// backward 2 (per ray): dw -> ds through diff, clip (closed interval passes) and cumsum
+__global__ __launch_bounds__(256) void occ_bwd_scan_kernel(OccArgs a, const float* __restrict__ s,
+                                                           const float* __restrict__ dw, float* __restrict__ ds) {
+    const long ray = (long)blockIdx.x * 256 + threadIdx.x;
+    if (ray >= (long)a.B * a.HW) return;
+    const int b = (int)(ray / a.HW);
+    const int p = (int)(ray - (long)b * a.HW);
+    const long base = (long)b * a.D * a.HW + p;
+    // forward running sums are needed for the clip mask: recompute them into ds first
+    float run = 0.f;
+    for (int d = 0; d < a.D; ++d) {
+        run += s[base + (long)d * a.HW];
+        ds[base + (long)d * a.HW] = run;
+    }
+    float next_dw = 0.f, acc = 0.f;
+    for (int d = a.D - 1; d >= 0; --d) {
+        const float cur = dw[base + (long)d * a.HW];
+        const float dc = cur - next_dw;                 // c[d] enters w[d] (+) and w[d+1] (-)
+        next_dw = cur;
+        const float cs = ds[base + (long)d * a.HW];
+        if (cs >= 0.f && cs <= 1.f) acc += dc;          // clip gradient
+        ds[base + (long)d * a.HW] = acc;                // reverse cumulative sum
+    }
+}
+
+// backward 3: through the per-voxel MLP; dvol = w * dfeat (compositing) + MLP path; weight gradients via block
+// reduction + atomics (dW1 nf x (F+1), db1 nf, dW2 nf, db2 1 -> packed in dparams)
+__global__ __launch_bounds__(256) void occ_bwd_mlp_kernel(OccArgs a, const float* __restrict__ vol,
+                                                          const float* __restrict__ W1, const float* __restrict__ b1,
+                                                          const float* __restrict__ W2, const float* __restrict__ s,
+                                                          const float* __restrict__ ds, const float* __restrict__ w,
+                                                          const float* __restrict__ dfeat, float* __restrict__ dvol,
+                                                          float* __restrict__ dparams) {
+    const long vox = (long)a.D * a.HW;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < (long)a.B * vox;
+    const int nW1 = OCC_NF * (a.F + 1);
+    float dpre1[OCC_NF] = {0.f, 0.f, 0.f, 0.f}, h_act[OCC_NF] = {0.f, 0.f, 0.f, 0.f};
+    float dpre2 = 0.f, xc = 0.f;
+    int b = 0, p = 0;
+    long r = 0;
+    if (live) {
+        b = (int)(i / vox);
+        r = i - (long)b * vox;
+        const int d = (int)(r / a.HW);
+        p = (int)(r - (long)d * a.HW);
+        float h[OCC_NF];
+        xc = depth_coord(d, a.D) * a.c1;
+#pragma unroll
+        for (int j = 0; j < OCC_NF; ++j) h[j] = b1[j] + W1[j * (a.F + 1)] * xc;
+        for (int f = 0; f < a.F; ++f) {
+            const float x = vol[((long)b * a.F + f) * vox + r] * a.c1;
+#pragma unroll
+            for (int j = 0; j < OCC_NF; ++j) h[j] += W1[j * (a.F + 1) + 1 + f] * x;
+        }
+        const float sv = s[i];
+        dpre2 = ds[i] * sv * (1.f - sv);
+#pragma unroll
+        for (int j = 0; j < OCC_NF; ++j) {
+            h_act[j] = h[j] > 0.f ? h[j] : 0.2f * h[j];
+            dpre1[j] = W2[j] * a.c2 * dpre2 * (h[j] > 0.f ? 1.f : 0.2f);
+        }
+        const float wd = w[i];
+        for (int f = 0; f < a.F; ++f) {
+            float dx = 0.f;
+#pragma unroll
+            for (int j = 0; j < OCC_NF; ++j) dx += W1[j * (a.F + 1) + 1 + f] * dpre1[j];
+            dvol[((long)b * a.F + f) * vox + r] = wd * dfeat[((long)b * a.F + f) * a.HW + p] + dx * a.c1;
+        }
+    }
+    // ---- weight gradients: wave reduce, then one atomic per wave per parameter
+    const int lane = threadIdx.x & 63;
+    for (int j = 0; j < OCC_NF; ++j) {
+        float v0 = wave_sum(dpre1[j] * xc);                              // dW1[j][0] (depth-coordinate channel)
+        if (lane == 0) atomicAdd(dparams + j * (a.F + 1), v0);
+        float v1 = wave_sum(dpre1[j]);                                    // db1[j]
+        if (lane == 0) atomicAdd(dparams + nW1 + j, v1);
+        float v2 = wave_sum(dpre2 * a.c2 * h_act[j]);                     // dW2[j]
+        if (lane == 0) atomicAdd(dparams + nW1 + OCC_NF + j, v2);
+    }
+    {
+        float v3 = wave_sum(dpre2);                                       // db2
+        if (lane == 0) atomicAdd(dparams + nW1 + 2 * OCC_NF, v3);
+    }
+    for (int f = 0; f < a.F; ++f) {
+        const float x = live ? vol[((long)b * a.F + f) * vox + r] * a.c1 : 0.f;
+#pragma unroll
+        for (int j = 0; j < OCC_NF; ++j) {
+            const float v = wave_sum(dpre1[j] * x);
+            if (lane == 0) atomicAdd(dparams + j * (a.F + 1) + 1 + f, v);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int rgbd_proj_idcs(const float* cam2world, int B, int W, int H, int D, int G, float voxel_size,
+                              float near_plane, float fx, float fy, float cx, float cy, int32_t* idx, float* coords,
+                              int32_t* counts, int32_t* workspace, void* stream) {
+    RGBD_REQUIRE(cam2world && idx && coords && counts && workspace, "rgbd_proj_idcs: null pointer");
+    RGBD_REQUIRE(B > 0 && W > 0 && H > 0 && D > 0 && G > 0, "rgbd_proj_idcs: bad shape");
+    const long N = (long)W * H * D;
+    RGBD_REQUIRE(N < (1l << 24), "rgbd_proj_idcs: frustum must have fewer than 2^24 elements (float-exact indices)");
+    FrustumArgs f{W, H, D, G, voxel_size, near_plane, fx, fy, cx, cy};
+    const int nblocks = (int)((N + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    proj_count_kernel<<<dim3(nblocks, B), 256, 0, st>>>(f, cam2world, (int)N, workspace);
+    RGBD_CHECK_LAUNCH("proj_count_kernel");
+    proj_scan_kernel<<<B, 1024, 0, st>>>(workspace, nblocks, counts);
+    RGBD_CHECK_LAUNCH("proj_scan_kernel");
+    proj_write_kernel<<<dim3(nblocks, B), 256, 0, st>>>(f, cam2world, (int)N, workspace, idx, coords);
+    RGBD_CHECK_LAUNCH("proj_write_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_trilinear_fwd(const float* grid, const int32_t* idx, const float* coords, const int32_t* counts,
+                                  float* out, int B, int F, int G, int N, void* stream) {
+    RGBD_REQUIRE(grid && idx && coords && counts && out, "rgbd_trilinear_fwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (rgbd_zero_async(out, (size_t)B * F * N * sizeof(float), st) != hipSuccess) {
+        rgbd_set_error("rgbd_trilinear_fwd: zero fill failed");
+        return -2;
+    }
+    trilinear_fwd_kernel<<<dim3((N + 255) / 256, B), 256, 0, st>>>(grid, idx, coords, counts, out, F, G, N);
+    RGBD_CHECK_LAUNCH("trilinear_fwd_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_trilinear_bwd(const float* dout, const int32_t* idx, const float* coords, const int32_t* counts,
+                                  float* dgrid, int B, int F, int G, int N, void* stream) {
+    RGBD_REQUIRE(dout && idx && coords && counts && dgrid, "rgbd_trilinear_bwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (rgbd_zero_async(dgrid, (size_t)B * F * G * G * G * sizeof(float), st) != hipSuccess) {
+        rgbd_set_error("rgbd_trilinear_bwd: zero fill failed");
+        return -2;
+    }
+    trilinear_bwd_kernel<<<dim3((N + 255) / 256, B), 256, 0, st>>>(dout, idx, coords, counts, dgrid, F, G, N);
+    RGBD_CHECK_LAUNCH("trilinear_bwd_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_occlusion_accum_fwd(const float* vol, const float* W1, const float* b1, const float* W2,
+                                        const float* b2, float threshold, float voxel_size, float near_plane,
+                                        float* s, float* w, float* feat, float* depth, int B, int F, int D, int HW,
+                                        void* stream) {
+    RGBD_REQUIRE(vol && W1 && b1 && W2 && b2 && s && w && feat && depth, "rgbd_occlusion_accum_fwd: null pointer");
+    RGBD_REQUIRE(F > 0 && F <= OCC_MAXF && B > 0 && D > 0 && HW > 0, "rgbd_occlusion_accum_fwd: bad shape");
+    OccArgs a{B, F, D, HW, sqrtf(2.f / (float)(F + 1)), sqrtf(2.f / (float)OCC_NF), threshold};
+    hipStream_t st = (hipStream_t)stream;
+    const long nv = (long)B * D * HW;
+    occ_score_kernel<<<(unsigned)((nv + 255) / 256), 256, 0, st>>>(a, vol, W1, b1, W2, b2, s);
+    RGBD_CHECK_LAUNCH("occ_score_kernel");
+    occ_scan_kernel<<<(unsigned)(((long)B * HW + 255) / 256), 256, 0, st>>>(a, s, w, depth, (float)D * voxel_size,
+                                                                           near_plane);
+    RGBD_CHECK_LAUNCH("occ_scan_kernel");
+    occ_compose_kernel<<<(unsigned)(((long)B * F * HW + 255) / 256), 256, 0, st>>>(a, vol, w, feat);
+    RGBD_CHECK_LAUNCH("occ_compose_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_occlusion_accum_bwd(const float* vol, const float* W1, const float* b1, const float* W2,
+                                        const float* s, const float* w, const float* dfeat, const float* ddepth,
+                                        float voxel_size, float* dw_ws, float* ds_ws, float* dvol, float* dparams,
+                                        int B, int F, int D, int HW, void* stream) {
+    RGBD_REQUIRE(vol && W1 && b1 && W2 && s && w && dfeat && ddepth && dw_ws && ds_ws && dvol && dparams,
+                 "rgbd_occlusion_accum_bwd: null pointer");
+    RGBD_REQUIRE(F > 0 && F <= OCC_MAXF && B > 0 && D > 0 && HW > 0, "rgbd_occlusion_accum_bwd: bad shape");
+    OccArgs a{B, F, D, HW, sqrtf(2.f / (float)(F + 1)), sqrtf(2.f / (float)OCC_NF), 0.f};
+    hipStream_t st = (hipStream_t)stream;
+    const int nparams = OCC_NF * (F + 1) + OCC_NF + OCC_NF + 1;
+    if (rgbd_zero_async(dparams, (size_t)((nparams + 3) / 4 * 4) * sizeof(float), st) != hipSuccess) {
+        rgbd_set_error("rgbd_occlusion_accum_bwd: zero fill failed");
+        return -2;
+    }
+    const long nv = (long)B * D * HW;
+    occ_bwd_dw_kernel<<<(unsigned)((nv + 255) / 256), 256, 0, st>>>(a, vol, dfeat, ddepth, (float)D * voxel_size, dw_ws);
+    RGBD_CHECK_LAUNCH("occ_bwd_dw_kernel");
+    occ_bwd_scan_kernel<<<(unsigned)(((long)B * HW + 255) / 256), 256, 0, st>>>(a, s, dw_ws, ds_ws);
+    RGBD_CHECK_LAUNCH("occ_bwd_scan_kernel");
+    occ_bwd_mlp_kernel<<<(unsigned)((nv + 255) / 256), 256, 0, st>>>(a, vol, W1, b1, W2, s, ds_ws, w, dfeat, dvol, dparams);
+    RGBD_CHECK_LAUNCH("occ_bwd_mlp_kernel");
+    return 0;
+}

@@ -1,0 +1,101 @@
+"""interpolate_trilinear and the accumulative occlusion compositing (reference deepvoxel/deepvoxel.py:388-428,
+544-587, 886-889, 903-904) as differentiable ops on the HIP kernels.  fp32, NCDHW like the reference."""
+import numpy as np
+import torch
+
+from .. import _lib
+from ..kernels import _ptr, _stream
+
+OCC_NF = 4
+
+
+class _Trilinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, grid, idx, coords, counts, N):
+        grid = grid.contiguous()
+        B, F, G = grid.shape[0], grid.shape[1], grid.shape[2]
+        out = torch.empty(B, F, N, dtype=torch.float32, device=grid.device)
+        rc = _lib.load().rgbd_trilinear_fwd(_ptr(grid), _ptr(idx), _ptr(coords), _ptr(counts), _ptr(out), B, F, G, N,
+                                            _stream())
+        _lib.check(rc, "rgbd_trilinear_fwd")
+        ctx.save_for_backward(idx, coords, counts)
+        ctx.dims = (B, F, G, N)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout):
+        idx, coords, counts = ctx.saved_tensors
+        B, F, G, N = ctx.dims
+        dgrid = torch.empty(B, F, G, G, G, dtype=torch.float32, device=dout.device)
+        rc = _lib.load().rgbd_trilinear_bwd(_ptr(dout.contiguous()), _ptr(idx), _ptr(coords), _ptr(counts), _ptr(dgrid),
+                                            B, F, G, N, _stream())
+        _lib.check(rc, "rgbd_trilinear_bwd")
+        return dgrid, None, None, None, None
+
+
+def interpolate_trilinear_batch(grid, idx, coords, counts, img_shape, frustrum_depth):
+    """grid (B,F,G,G,G); idx/coords/counts from ProjectionHelper.compute_proj_idcs_batch -> (B,F,depth,H,W)."""
+    N = img_shape[0] * img_shape[1] * frustrum_depth
+    out = _Trilinear.apply(grid, idx, coords, counts, N)
+    return out.reshape(grid.shape[0], grid.shape[1], frustrum_depth, img_shape[0], img_shape[1])
+
+
+def interpolate_trilinear(grid, lin_ind_frustrum, voxel_coords, img_shape, frustrum_depth):
+    """Reference signature (deepvoxel.py:388): grid (1,F,G,G,G), one sample's compacted indices / coordinates."""
+    N = img_shape[0] * img_shape[1] * frustrum_depth
+    m = lin_ind_frustrum.shape[0]
+    idx = torch.zeros(1, N, dtype=torch.int32, device=grid.device)
+    coords = torch.zeros(1, 3, N, dtype=torch.float32, device=grid.device)
+    idx[0, :m] = lin_ind_frustrum.to(torch.int32)
+    coords[0, :, :m] = voxel_coords
+    counts = torch.tensor([m], dtype=torch.int32, device=grid.device)
+    return interpolate_trilinear_batch(grid, idx, coords, counts, img_shape, frustrum_depth)
+
+
+class _OcclusionAccum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vol, W1, b1, W2, b2, threshold, voxel_size, near_plane):
+        vol = vol.contiguous()
+        B, F, D, H, W = vol.shape
+        dev = vol.device
+        s = torch.empty(B, D, H * W, dtype=torch.float32, device=dev)
+        w = torch.empty_like(s)
+        feat = torch.empty(B, F, H, W, dtype=torch.float32, device=dev)
+        depth = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev)
+        W1c, b1c, W2c, b2c = (t.contiguous() for t in (W1, b1, W2, b2))
+        rc = _lib.load().rgbd_occlusion_accum_fwd(_ptr(vol), _ptr(W1c), _ptr(b1c), _ptr(W2c), _ptr(b2c), float(threshold),
+                                                  float(voxel_size), float(near_plane), _ptr(s), _ptr(w), _ptr(feat),
+                                                  _ptr(depth), B, F, D, H * W, _stream())
+        _lib.check(rc, "rgbd_occlusion_accum_fwd")
+        ctx.save_for_backward(vol, W1c, b1c, W2c, s, w)
+        ctx.voxel_size = float(voxel_size)
+        return feat, depth, w.reshape(B, 1, D, H, W)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dfeat, ddepth, dw_unused):
+        vol, W1, b1, W2, s, w = ctx.saved_tensors
+        B, F, D, H, W = vol.shape
+        dev = vol.device
+        dw_ws = torch.empty(B, D, H * W, dtype=torch.float32, device=dev)
+        ds_ws = torch.empty_like(dw_ws)
+        dvol = torch.empty_like(vol)
+        nparams = OCC_NF * (F + 1) + 2 * OCC_NF + 1
+        dparams = torch.empty((nparams + 3) // 4 * 4, dtype=torch.float32, device=dev)
+        rc = _lib.load().rgbd_occlusion_accum_bwd(_ptr(vol), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(s), _ptr(w),
+                                                  _ptr(dfeat.contiguous()), _ptr(ddepth.contiguous()), ctx.voxel_size,
+                                                  _ptr(dw_ws), _ptr(ds_ws), _ptr(dvol), _ptr(dparams), B, F, D, H * W,
+                                                  _stream())
+        _lib.check(rc, "rgbd_occlusion_accum_bwd")
+        n1 = OCC_NF * (F + 1)
+        return (dvol, dparams[:n1].reshape(OCC_NF, F + 1), dparams[n1:n1 + OCC_NF],
+                dparams[n1 + OCC_NF:n1 + 2 * OCC_NF], dparams[n1 + 2 * OCC_NF:n1 + 2 * OCC_NF + 1],
+                None, None, None)
+
+
+def accumulative_occlusion(vol, W1, b1, W2, b2, threshold=4.0, voxel_size=0.0171875, near_plane=float(np.sqrt(3) / 4)):
+    """vol (B,F,D,H,W) -> (features (B,F,H,W), depth (B,1,H,W) in camera units, weights (B,1,D,H,W)).
+    W1 (4,F+1), b1 (4,), W2 (1,4), b2 (1,): the two 1x1x1 equalized convs of AccumulativeOcclusionNet (the depth
+    coordinate is input channel 0)."""
+    return _OcclusionAccum.apply(vol, W1, b1, W2.reshape(-1), b2, threshold, voxel_size, near_plane)

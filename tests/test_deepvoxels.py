@@ -1,0 +1,123 @@
+"""DeepVoxels frustum path: oracle known answers on CPU, HIP parity on GPU."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import camera, deepvoxels as odv
+
+
+def _cams(n, seed=0):
+    rng = np.random.RandomState(seed)
+    th = rng.uniform(-1, 1, (n, 6)).astype("float32") * np.array([0.3054, 3.1415, 0, 0, 0, 0], "float32")
+    return camera.camera_matrices(th)
+
+
+def test_frustum_constants_and_fractional_row():
+    fr = odv.Frustum()
+    assert fr.depth == 56 and fr.n == 229376
+    assert abs(fr.voxel_size - 0.0171875) < 1e-12 and abs(fr.near_plane - 0.4330127) < 1e-7
+    # n = 65: tmp = 65, yc0 = 65 / 64 = 1.015625 (TRUE division: fractional), xc0 = 1
+    n = np.array([65], "int32")
+    tmp = n - ((n // 4096).astype("float32") * 64 * 64).astype("int32")
+    assert float(tmp / 64) == 1.015625 and int(tmp % 64) == 1
+    np.testing.assert_allclose(odv.depth_coords(fr)[[0, 28, 55]], [-0.5, 0.0, 27 / 56], atol=1e-7)
+
+
+def test_proj_idcs_oracle_properties():
+    fr = odv.Frustum()
+    lin, v = odv.proj_idcs_np(_cams(1)[0], fr)
+    assert lin.dtype == np.int32 and v.dtype == np.float32 and v.shape == (3, len(lin))
+    assert (np.diff(lin) > 0).all()                          # ordered compaction
+    assert (v >= 0).all() and (v < 32).all()
+    assert 0.2 * fr.n < len(lin) < 0.9 * fr.n
+    far = np.eye(4, dtype="float32")
+    far[2, 3] = 100.0
+    assert odv.proj_idcs_np(far, fr) is None                 # nothing inside -> None, as the reference
+
+
+@pytest.mark.gpu
+def test_hip_proj_idcs_bit_exact():
+    from rgbd_gan_amd.deepvoxel.projection import ProjectionHelper
+    fr = odv.Frustum()
+    K = np.array([[128., 0, 32., 0], [0, 128., 32., 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    ph = ProjectionHelper(K, K, [64, 64], [64, 64], 0.0, 32 * fr.voxel_size + fr.near_plane, [32, 32, 32],
+                          fr.voxel_size, fr.near_plane, fr.depth)
+    cams = _cams(5, seed=3)
+    idx, coords, counts = ph.compute_proj_idcs_batch(cams)
+    for b in range(5):
+        lin, v = odv.proj_idcs_np(cams[b], fr)
+        m = int(counts[b])
+        assert m == len(lin)
+        np.testing.assert_array_equal(idx[b, :m].cpu().numpy(), lin)
+        np.testing.assert_array_equal(coords[b, :, :m].cpu().numpy().view(np.uint32), v.view(np.uint32))
+    one = ph.compute_proj_idcs(cams[2])
+    np.testing.assert_array_equal(one[0].cpu().numpy(), odv.proj_idcs_np(cams[2], fr)[0])
+    far = np.eye(4, dtype="float32")
+    far[2, 3] = 100.0
+    assert ph.compute_proj_idcs(far) is None
+
+
+@pytest.mark.gpu
+def test_hip_trilinear_forward_backward():
+    from rgbd_gan_amd.deepvoxel import deepvoxel as dv
+    fr = odv.Frustum()
+    cams = _cams(2, seed=5)
+    g = torch.Generator().manual_seed(0)
+    grid = torch.randn(2, 8, 32, 32, 32, generator=g)
+    outs, grads = [], []
+    dout = torch.randn(2, 8, fr.depth, 64, 64, generator=g)
+    for b in range(2):
+        lin, v = odv.proj_idcs_np(cams[b], fr)
+        gb = grid[b:b + 1].clone().requires_grad_(True)
+        o = odv.trilinear_torch(gb, lin, v, fr)
+        o.backward(dout[b:b + 1])
+        outs.append(o.detach())
+        grads.append(gb.grad)
+    from rgbd_gan_amd.deepvoxel.projection import ProjectionHelper
+    K = np.array([[128., 0, 32., 0], [0, 128., 32., 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    ph = ProjectionHelper(K, K, [64, 64], [64, 64], 0.0, 1.0, [32, 32, 32], fr.voxel_size, fr.near_plane, fr.depth)
+    idx, coords, counts = ph.compute_proj_idcs_batch(cams)
+    gd = grid.cuda().requires_grad_(True)
+    od = dv.interpolate_trilinear_batch(gd, idx, coords, counts, [64, 64], fr.depth)
+    od.backward(dout.cuda())
+    torch.testing.assert_close(od.detach().cpu(), torch.cat(outs), atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(gd.grad.cpu(), torch.cat(grads), atol=1e-3, rtol=1e-4)
+    # reference signature, one sample
+    lin, v = odv.proj_idcs_np(cams[0], fr)
+    o1 = dv.interpolate_trilinear(grid[:1].cuda(), torch.from_numpy(lin).cuda(), torch.from_numpy(v).cuda(), [64, 64], fr.depth)
+    torch.testing.assert_close(o1.cpu(), outs[0], atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_hip_accumulative_occlusion_forward_backward():
+    from rgbd_gan_amd.deepvoxel import deepvoxel as dv
+    fr = odv.Frustum()
+    g = torch.Generator().manual_seed(1)
+    B, F = 2, 32
+    vol = (torch.randn(B, F, fr.depth, 64, 64, generator=g) * 0.5)
+    W1 = torch.randn(4, F + 1, generator=g)
+    b1 = torch.randn(4, generator=g) * 0.1
+    W2 = torch.randn(1, 4, generator=g) * 2
+    b2 = torch.full((1,), 3.0)                              # around the threshold so the cumulative sum saturates mid-ray
+    dfeat = torch.randn(B, F, 64, 64, generator=g)
+    ddepth = torch.randn(B, 1, 64, 64, generator=g)
+    ref_f, ref_d, ref_g = [], [], []
+    params = [t.clone().requires_grad_(True) for t in (W1, b1, W2, b2)]
+    for b in range(B):
+        vb = vol[b:b + 1].clone().requires_grad_(True)
+        f, d, w = odv.occlusion_torch(vb, *params, fr=fr)
+        (f * dfeat[b:b + 1]).sum().backward(retain_graph=True)
+        (d * ddepth[b:b + 1]).sum().backward()
+        ref_f.append(f.detach()); ref_d.append(d.detach()); ref_g.append(vb.grad)
+    vd = vol.cuda().requires_grad_(True)
+    pd = [t.clone().cuda().requires_grad_(True) for t in (W1, b1, W2, b2)]
+    f, d, w = dv.accumulative_occlusion(vd, *pd, threshold=4.0, voxel_size=fr.voxel_size, near_plane=fr.near_plane)
+    ((f * dfeat.cuda()).sum() + (d * ddepth.cuda()).sum()).backward()
+    torch.testing.assert_close(f.detach().cpu(), torch.cat(ref_f), atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(d.detach().cpu(), torch.cat(ref_d), atol=1e-5, rtol=1e-5)
+    wsum = w.sum(dim=2)
+    assert float(wsum.max()) <= 1.0 + 1e-5 and float(wsum.min()) >= 0.0
+    torch.testing.assert_close(vd.grad.cpu(), torch.cat(ref_g), atol=2e-4, rtol=1e-3)
+    for got, ref in zip(pd, params):
+        scale = float(ref.grad.abs().max())
+        torch.testing.assert_close(got.grad.cpu(), ref.grad, atol=2e-3 * scale, rtol=2e-3)
