@@ -38,6 +38,25 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes of this same command
+    (profiles/r01/bench_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, corrected as
+    MI355X_MICROARCH.md prescribes: 2 * FETCH_SIZE + WRITE_SIZE, KB).  None when the file or the kernel is absent."""
+    path = os.path.join(ROOT, "profiles", "r01", "bench_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as fjson:
+        ks = json.load(fjson)["kernels"]
+    base = kernel.split("<")[0]
+    width = kernel.split("<")[1].rstrip(">") if "<" in kernel else ""
+    tot = cnt = 0
+    for name, v in ks.items():
+        if name.startswith(base + "<" + width) or name == kernel:
+            tot += v["hbm_bytes_per_launch"] * v["launches"]
+            cnt += v["launches"]
+    return round(tot / cnt) if cnt else None
+
+
 def cpu_baseline(batch=2, threads=None):
     """The CPU restatement of the same step (oracle/step.py; Chainer is unavailable), timed on the host cores on a
     bounded sample: one update_core at 128x128, ch=256, `batch` images."""
@@ -140,9 +159,10 @@ def main():
                      "avg_us": round(t / n * 1e6, 1), "gbps": round(b / t / 1e9, 1)} for k, (n, t, f, b) in summ.items()}
         dom = max(summ, key=lambda k: summ[k][1])
         n, t, f, b = summ[dom]
+        traffic = pmc_traffic(dom)
         line["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(f / t / 1e12, 2),
                             "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(f / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-                            "traffic": None, "launches": n, "avg_launch_us": round(t / n * 1e6, 2),
+                            "traffic": traffic, "launches": n, "avg_launch_us": round(t / n * 1e6, 2),
                             "flops_per_launch_avg": f / n}
         line["kernels"] = table
     elif comm.size > 1 and not args.no_roofline:

@@ -121,6 +121,15 @@ int rgbd_lrelu_bwd(const void* dy, const void* y, void* dz, int64_t M, int C, in
                    float* bias_grad /* NULL, or (C) fp32: += column sums of dz in the same pass */, void* stream);
 int rgbd_colsum_bf16(const void* x, float* out, int64_t M, int C, int accumulate, void* stream);
 
+/* 2x2 average pooling of the discriminator blocks (rescale.py:12-13) fused with the leaky-ReLU that precedes it:
+ *   rgbd_unpool2_lrelu_bwd: dz[b,h,w,c] = 0.25 * dp[b,h/2,w/2,c] * lrelu'(y[b,h,w,c])   (y NULL: no mask); bias_grad as above
+ *   rgbd_pool2_masked     : out[b,hp,wp,c] = 0.25 * sum_{2x2} x * lrelu'(y)              (y NULL: plain average pool)
+ * The two are adjoint (same mask), which closes the pair under differentiation (R1 double backward).
+ */
+int rgbd_unpool2_lrelu_bwd(const void* dp, const void* y, void* dz, int B, int H, int W, int C, float slope,
+                           float* bias_grad, void* stream);
+int rgbd_pool2_masked(const void* x, const void* y, void* out, int B, int H, int W, int C, float slope, void* stream);
+
 /* 1x1 convolutions between NCHW fp32 image planes (KP = 3 or 4 channels) and NHWC bf16 features (C channels):
  *   rgbd_from_planes: y[b,p,co] = act(wscale * sum_k w[co][k] x[b,k,p] + bias[co])   -- Discriminator.ins, net.py:449-455
  *   rgbd_to_planes  : out[b,k,p] = wscale * sum_c w[k][c] h[b,p,c] + bias[k]           -- StyleGenerator.outs, net.py:186-191

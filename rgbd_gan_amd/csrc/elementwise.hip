@@ -255,6 +255,99 @@ __global__ __launch_bounds__(256) void lrelu_bwd_colsum_kernel(const unsigned sh
     }
 }
 
+// ---- 2x2 average pooling fused with the leaky-ReLU gradient (discriminator blocks: net.py:416,425 lrelu -> downscale2x)
+// unpool: dz[b,h,w,c] = 0.25 * dp[b,h/2,w/2,c] * (y ? (y[b,h,w,c] > 0 ? 1 : slope) : 1)  (+ column sums -> bias_grad)
+// The expanded gradient of the pooling (the reference materialises it) is never written.
+__global__ __launch_bounds__(256) void unpool_lrelu_bwd_kernel(const unsigned short* __restrict__ dp,
+                                                               const unsigned short* __restrict__ y,
+                                                               unsigned short* __restrict__ dz, long M, int H, int W,
+                                                               int C, float slope, int rows_per_block,
+                                                               float* __restrict__ bias_grad) {
+    const int cg = blockIdx.y;
+    const int chunk = threadIdx.x & 7, lane_p = threadIdx.x >> 3;
+    const int c0 = cg * 64 + chunk * 8;
+    const long r_begin = (long)blockIdx.x * rows_per_block;
+    const long r_end = min(M, r_begin + rows_per_block);
+    const int Wp = W >> 1, Hp = H >> 1;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long r = r_begin + lane_p; r < r_end; r += 32) {
+        const int w = (int)(r % W);
+        const long t = r / W;
+        const int h = (int)(t % H);
+        const long b = t / H;
+        const long rp = (b * Hp + (h >> 1)) * Wp + (w >> 1);
+        const u32x4 g = *reinterpret_cast<const u32x4*>(dp + rp * C + c0);
+        u32x4 yy = {0u, 0u, 0u, 0u};
+        if (y) yy = *reinterpret_cast<const u32x4*>(y + r * C + c0);
+        u32x4 out;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float g0 = bf16_lo(g[k]) * 0.25f, g1 = bf16_hi(g[k]) * 0.25f;
+            if (y) {
+                g0 = bf16_lo(yy[k]) > 0.f ? g0 : g0 * slope;
+                g1 = bf16_hi(yy[k]) > 0.f ? g1 : g1 * slope;
+            }
+            out[k] = pack_bf16x2(g0, g1);
+            s[2 * k] += bf16_lo(out[k]);
+            s[2 * k + 1] += bf16_hi(out[k]);
+        }
+        *reinterpret_cast<u32x4*>(dz + r * C + c0) = out;
+    }
+    if (bias_grad) {
+        __shared__ float red[32][65];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[lane_p][chunk * 8 + k] = s[k];
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            float acc = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) acc += red[r][threadIdx.x];
+            atomicAdd(bias_grad + cg * 64 + threadIdx.x, acc);
+        }
+    }
+}
+
+// pool: out[b,hp,wp,c] = 0.25 * sum_{2x2} x[b,h,w,c] * (y ? lrelu'(y[b,h,w,c]) : 1)
+__global__ __launch_bounds__(256) void pool2_masked_kernel(const unsigned short* __restrict__ x,
+                                                           const unsigned short* __restrict__ y,
+                                                           unsigned short* __restrict__ out, long nvec_out, int H, int W,
+                                                           int C, float slope) {
+    const int cvec = C >> 3;
+    const int Wp = W >> 1, Hp = H >> 1;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nvec_out; e += (long)gridDim.x * 256) {
+        const int cv = (int)(e % cvec);
+        const long rp = e / cvec;
+        const int wp = (int)(rp % Wp);
+        const long t = rp / Wp;
+        const int hp = (int)(t % Hp);
+        const long b = t / Hp;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const long r = (b * H + 2 * hp + dy) * W + 2 * wp + dx;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(x + r * C + cv * 8);
+                u32x4 yy = {0u, 0u, 0u, 0u};
+                if (y) yy = *reinterpret_cast<const u32x4*>(y + r * C + cv * 8);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float v0 = bf16_lo(v[k]), v1 = bf16_hi(v[k]);
+                    if (y) {
+                        v0 = bf16_lo(yy[k]) > 0.f ? v0 : v0 * slope;
+                        v1 = bf16_hi(yy[k]) > 0.f ? v1 : v1 * slope;
+                    }
+                    acc[2 * k] += v0;
+                    acc[2 * k + 1] += v1;
+                }
+            }
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = pack_bf16x2(acc[2 * k] * 0.25f, acc[2 * k + 1] * 0.25f);
+        *reinterpret_cast<u32x4*>(out + e * 8) = o;
+    }
+}
+
 // column sums of an (M, C) bf16 matrix -> out[C] fp32 (atomics; out zeroed by the caller): bias gradients.
 __global__ __launch_bounds__(256) void colsum_kernel(const unsigned short* __restrict__ x, float* __restrict__ out,
                                                      long M, int C, int rows_per_block) {
@@ -555,6 +648,33 @@ extern "C" int rgbd_colsum_bf16(const void* x, float* out, int64_t M, int C, int
     dim3 grid(ceil_div(M, rows), C / 64);
     colsum_kernel<<<grid, 256, 0, st>>>((const unsigned short*)x, out, M, C, rows);
     RGBD_CHECK_LAUNCH("colsum_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_unpool2_lrelu_bwd(const void* dp, const void* y, void* dz, int B, int H, int W, int C, float slope,
+                                      float* bias_grad, void* stream) {
+    RGBD_REQUIRE(dp && dz, "rgbd_unpool2_lrelu_bwd: null pointer");
+    RGBD_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C % 64 == 0,
+                 "rgbd_unpool2_lrelu_bwd: H, W must be even and C a multiple of 64 (H=%d W=%d C=%d)", H, W, C);
+    const long M = (long)B * H * W;
+    const int rows = 2048;
+    dim3 grid(ceil_div(M, rows), C / 64);
+    unpool_lrelu_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const unsigned short*)dp, (const unsigned short*)y,
+                                                                  (unsigned short*)dz, M, H, W, C, slope, rows, bias_grad);
+    RGBD_CHECK_LAUNCH("unpool_lrelu_bwd_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_pool2_masked(const void* x, const void* y, void* out, int B, int H, int W, int C, float slope,
+                                 void* stream) {
+    RGBD_REQUIRE(x && out, "rgbd_pool2_masked: null pointer");
+    RGBD_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C % 8 == 0,
+                 "rgbd_pool2_masked: H, W must be even and C a multiple of 8 (H=%d W=%d C=%d)", H, W, C);
+    const long nvec = (long)B * (H / 2) * (W / 2) * C / 8;
+    const int blocks = (int)min((long)4096, (nvec + 255) / 256);
+    pool2_masked_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((const unsigned short*)x, (const unsigned short*)y,
+                                                                 (unsigned short*)out, nvec, H, W, C, slope);
+    RGBD_CHECK_LAUNCH("pool2_masked_kernel");
     return 0;
 }
 

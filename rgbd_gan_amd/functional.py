@@ -190,9 +190,8 @@ def warp_loss(img, img_rot, coef, flags, lambda_geometric, max_depth=0.0, min_de
 
 
 def avg_pool2_nhwc(x):
-    """rescale.py:12-13 on NHWC (differentiable, twice)."""
-    B, H, W, C = x.shape
-    return x.view(B, H // 2, 2, W // 2, 2, C).mean(dim=(2, 4))
+    """rescale.py:12-13 on NHWC bf16 (differentiable, twice)."""
+    return _PoolMasked.apply(x, x, False)
 
 
 def lrelu(x):
@@ -225,22 +224,53 @@ class _ColSum(torch.autograd.Function):
         return g.to(torch.bfloat16).expand(ctx.shape)
 
 
-class _ConvBiasAct(torch.autograd.Function):
-    """y = act(conv(x, W) + b + residual) with everything after the MFMA accumulation fused into the kernel's
-    epilogue (net.py:144-159 c -> L.Bias -> leaky_relu; net.py:410-416 c1(h) + shortcut -> leaky_relu).
-    The backward is assembled from differentiable pieces (lrelu-grad, dgrad, wgrad, column sum), so the R1 double
-    backward goes through it."""
+class _UnpoolLreluGrad(torch.autograd.Function):
+    """dz = 0.25 * upsample2(dp) * lrelu'(y): backward of (leaky ReLU -> 2x2 average pool) in one pass.  Linear in dp;
+    its adjoint is _PoolMasked with the same mask."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, residual, layer, ups, act):
+    def forward(ctx, dp, y, shape, use_mask):
+        ctx.use_mask = use_mask
+        ctx.save_for_backward(y)
+        return kernels.unpool2_lrelu_bwd(dp.contiguous(), y if use_mask else None, shape)
+
+    @staticmethod
+    def backward(ctx, ddz):
+        y, = ctx.saved_tensors
+        return _PoolMasked.apply(ddz.contiguous(), y, ctx.use_mask), None, None, None
+
+
+class _PoolMasked(torch.autograd.Function):
+    """out = 0.25 * sum_{2x2} x * lrelu'(y)  (use_mask False: plain 2x2 average pooling, rescale.py:12-13)."""
+
+    @staticmethod
+    def forward(ctx, x, y, use_mask):
+        ctx.use_mask, ctx.shape = use_mask, tuple(x.shape)
+        ctx.save_for_backward(y)
+        return kernels.pool2_masked(x.contiguous(), y if use_mask else None)
+
+    @staticmethod
+    def backward(ctx, g):
+        y, = ctx.saved_tensors
+        return _UnpoolLreluGrad.apply(g.contiguous(), y, ctx.shape, ctx.use_mask), None, None
+
+
+class _ConvBiasAct(torch.autograd.Function):
+    """y = act(conv(x, W) + b + residual) [-> 2x2 average pool] with everything after the MFMA accumulation fused
+    into the kernel's epilogue (net.py:144-159 c -> L.Bias -> leaky_relu; net.py:410-426 c1(h) + shortcut ->
+    leaky_relu -> downscale2x).  The backward is assembled from differentiable pieces (lrelu-grad / unpool-lrelu-grad,
+    dgrad, wgrad, column sum), so the R1 double backward goes through it."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, residual, layer, ups, act, pool):
         wf, _ = layer.packed()
         x = x.contiguous()
         y = kernels.conv2d_fprop(x, wf, layer.K, layer.K, layer.pad, bias=bias.contiguous(),
                                  residual=residual.contiguous() if residual is not None else None, upsample=ups,
                                  lrelu_channels=w.shape[0] if act else 0)
-        ctx.layer, ctx.ups, ctx.act = layer, ups, act
+        ctx.layer, ctx.ups, ctx.act, ctx.pool = layer, ups, act, pool
         ctx.save_for_backward(x, w, y, bias)
-        return y
+        return kernels.pool2_masked(y) if pool else y
 
     @staticmethod
     def backward(ctx, dy):
@@ -248,17 +278,22 @@ class _ConvBiasAct(torch.autograd.Function):
         layer, ups = ctx.layer, ctx.ups
         want_b = ctx.needs_input_grad[2] and not _SKIP_WGRAD
         dx = dw = db = dres = None
-        if want_b and _direct_grad(bias):
-            # bias gradient rides along: fused into the lrelu-grad pass, or one accumulating column-sum pass
-            if ctx.act:
-                dz = kernels.lrelu_bwd(dy.contiguous(), y, w.shape[0], bias_grad=bias.grad)
+        dy = dy.contiguous()
+        fast_b = want_b and _direct_grad(bias)          # bias gradient rides along in the same pass
+        if ctx.pool:
+            if fast_b:
+                dz = kernels.unpool2_lrelu_bwd(dy, y if ctx.act else None, tuple(y.shape), bias_grad=bias.grad)
             else:
-                dz = dy.contiguous()
-                kernels.colsum(dz, out=bias.grad)
+                dz = _UnpoolLreluGrad.apply(dy, y, tuple(y.shape), ctx.act)
+        elif ctx.act:
+            dz = kernels.lrelu_bwd(dy, y, w.shape[0], bias_grad=bias.grad) if fast_b else \
+                _LreluGrad.apply(dy, y, w.shape[0])
         else:
-            dz = _LreluGrad.apply(dy.contiguous(), y, w.shape[0]) if ctx.act else dy.contiguous()
-            if want_b:
-                db = _ColSum.apply(dz)
+            dz = dy
+            if fast_b:
+                kernels.colsum(dz, out=bias.grad)
+        if want_b and not fast_b:
+            db = _ColSum.apply(dz)
         if ctx.needs_input_grad[0]:
             dx = _ConvDgrad.apply(dz, w, layer, ups)
         if ctx.needs_input_grad[1] and not _SKIP_WGRAD:
@@ -268,15 +303,15 @@ class _ConvBiasAct(torch.autograd.Function):
                 dw = _ConvWgrad.apply(x, dz, layer, ups)
         if ctx.needs_input_grad[3]:
             dres = dz
-        return dx, dw, db, dres, None, None, None
+        return dx, dw, db, dres, None, None, None, None
 
 
-def conv_bias_lrelu(x, layer, bias, upsample=False, residual=None):
-    return _ConvBiasAct.apply(x, layer.weight, bias, residual, layer, bool(upsample), True)
+def conv_bias_lrelu(x, layer, bias, upsample=False, residual=None, pool=False):
+    return _ConvBiasAct.apply(x, layer.weight, bias, residual, layer, bool(upsample), True, bool(pool))
 
 
 def conv_bias(x, layer, bias, upsample=False, residual=None):
-    return _ConvBiasAct.apply(x, layer.weight, bias, residual, layer, bool(upsample), False)
+    return _ConvBiasAct.apply(x, layer.weight, bias, residual, layer, bool(upsample), False, False)
 
 
 # ---- 1x1 convolutions between NCHW fp32 image planes and NHWC bf16 features (fromRGB / toRGB)

@@ -187,6 +187,27 @@ def colsum(x, out=None):
     return out
 
 
+def unpool2_lrelu_bwd(dp, y, shape, slope=0.2, bias_grad=None):
+    """dz (B,H,W,C) = 0.25 * upsample2(dp) * lrelu'(y); y may be None (plain average-pool backward)."""
+    _chk(dp, BF16, "dp"); _chk(y, BF16, "y"); _chk(bias_grad, F32, "bias_grad")
+    B, H, W, C = shape
+    dz = torch.empty(B, H, W, C, dtype=BF16, device=dp.device)
+    rc = _lib.load().rgbd_unpool2_lrelu_bwd(_ptr(dp), _ptr(y), _ptr(dz), B, H, W, C, float(slope), _ptr(bias_grad),
+                                            _stream())
+    _lib.check(rc, "rgbd_unpool2_lrelu_bwd")
+    return dz
+
+
+def pool2_masked(x, y=None, slope=0.2):
+    """out (B,H/2,W/2,C) = 0.25 * sum_{2x2} x * lrelu'(y); y None: plain 2x2 average pooling."""
+    _chk(x, BF16, "x"); _chk(y, BF16, "y")
+    B, H, W, C = x.shape
+    out = torch.empty(B, H // 2, W // 2, C, dtype=BF16, device=x.device)
+    rc = _lib.load().rgbd_pool2_masked(_ptr(x), _ptr(y), _ptr(out), B, H, W, C, float(slope), _stream())
+    _lib.check(rc, "rgbd_pool2_masked")
+    return out
+
+
 def from_planes(x, w, bias, wscale, act, slope=0.2):
     """x (B,KP,H,W) fp32, w (C,KP) fp32 -> (B,H,W,C) bf16 = act(wscale * w x + bias)."""
     _chk(x, F32, "x"); _chk(w, F32, "w"); _chk(bias, F32, "bias")

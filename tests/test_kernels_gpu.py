@@ -293,3 +293,32 @@ def test_patch_kernel_agrees_with_gather_kernel(B, H, Cin, Cout, ups):
         lib.rgbd_debug_force_gather_kernel(0)
     # same bf16 inputs, fp32 accumulation in a different order, one bf16 rounding at the end
     torch.testing.assert_close(y_patch.float(), y_gather.float(), atol=2e-2, rtol=8e-3)
+
+
+def test_pool_and_unpool_lrelu_kernels():
+    from rgbd_gan_amd import kernels
+    g = torch.Generator().manual_seed(4)
+    B, H, C = 2, 16, 128
+    y = bf16_round(torch.randn(B, H, H, C, generator=g))
+    x = bf16_round(torch.randn(B, H, H, C, generator=g))
+    dp = bf16_round(torch.randn(B, H // 2, H // 2, C, generator=g))
+    mask = torch.where(y > 0, torch.ones_like(y), torch.full_like(y, 0.2))
+    up = dp.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+    yd, xd, dpd = (t.to(dev()).to(torch.bfloat16) for t in (y, x, dp))
+    # unpool (+ fused bias gradient)
+    bg = torch.zeros(C, device=dev())
+    dz = kernels.unpool2_lrelu_bwd(dpd, yd, (B, H, H, C), bias_grad=bg)
+    torch.testing.assert_close(dz.float().cpu(), bf16_round(0.25 * up * mask), atol=1e-6, rtol=1e-6)
+    torch.testing.assert_close(bg.cpu(), dz.float().cpu().reshape(-1, C).sum(0), atol=1e-3, rtol=1e-4)
+    dz0 = kernels.unpool2_lrelu_bwd(dpd, None, (B, H, H, C))
+    torch.testing.assert_close(dz0.float().cpu(), bf16_round(0.25 * up), atol=1e-6, rtol=1e-6)
+    # pool, masked and plain; adjointness <pool(x), dp> == <x, unpool(dp)>
+    pm = kernels.pool2_masked(xd, yd)
+    ref = (x * mask).reshape(B, H // 2, 2, H // 2, 2, C).sum(dim=(2, 4)) * 0.25
+    torch.testing.assert_close(pm.float().cpu(), bf16_round(ref), atol=1e-2, rtol=1e-2)
+    pp = kernels.pool2_masked(xd)
+    ref0 = x.reshape(B, H // 2, 2, H // 2, 2, C).mean(dim=(2, 4))
+    torch.testing.assert_close(pp.float().cpu(), bf16_round(ref0), atol=1e-2, rtol=1e-2)
+    lhs = float((ref.double() * dp.double()).sum())
+    rhs = float((x.double() * (0.25 * up * mask).double()).sum())
+    assert abs(lhs - rhs) < 1e-6 * max(1.0, abs(lhs))
