@@ -144,6 +144,18 @@ int rgbd_to_planes(const void* h, const float* w, const float* bias, float* out,
 int rgbd_planes_outer(const void* t, const float* planes, float* o, float* tsum, int B, int HW, int KP, int C,
                       void* stream);
 
+/* ------------------------------------------------------------------ small equalized-LR linear layers (M <= 64 rows, fp32)
+ * Replace pggan.py:39-50 (EqualizedLinear = scale + L.Linear) + F.leaky_relu for the mapping MLP (net.py:58-62), the
+ * pose-conditioned style (net.py:220-224) and the StyleBlock affines (net.py:96-101): launch-latency bound.
+ *   fwd: y (M,N) = act(c * x (M,K) W(N,K)^T + bias);  act = leaky ReLU(slope) or identity.
+ *   bwd: dz = dy * lrelu'(y) (when act);  dx (M,K) (+)= c * dz W;  dw (N,K) += c * dz^T x;  db (N) += sum_m dz.
+ *        dx / dw / db may be NULL to skip; dw and db ACCUMULATE (they are the optimizer's flat gradient views).
+ */
+int rgbd_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, float c, int act,
+                    float slope, void* stream);
+int rgbd_linear_bwd(const float* dy, const float* y, const float* x, const float* w, float* dx, float* dw, float* db,
+                    int M, int K, int N, float c, int act, float slope, int accumulate_dx, void* stream);
+
 /* ------------------------------------------------------------------ DeepVoxels frustum path (config 4)
  * rgbd_proj_idcs: deepvoxel/projection.py:48-105 (compute_proj_idcs) for a whole batch of cameras at once.
  *   cam2world (B,16) fp32 row-major 4x4.  Frustum of W x H x D elements, grid of G^3 voxels.

@@ -34,6 +34,8 @@ PROTOTYPES = {
     "rgbd_from_planes": ([_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, c_float, _P], c_int),
     "rgbd_to_planes": ([_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P], c_int),
     "rgbd_planes_outer": ([_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P], c_int),
+    "rgbd_linear_fwd": ([_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_float, _P], c_int),
+    "rgbd_linear_bwd": ([_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_float, c_int, _P], c_int),
     "rgbd_proj_idcs": ([_P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_float,
                         _P, _P, _P, _P, _P], c_int),
     "rgbd_trilinear_fwd": ([_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P], c_int),

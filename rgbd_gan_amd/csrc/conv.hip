@@ -89,47 +89,45 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(ConvArgs a) {
     const int nkc = a.Cin >> 6;
     const int nk = a.KH * a.KW * nkc;
 
-    // Register prefetch: the gathered pixel tile of step k+2 is in flight from HBM while the tile of step k+1
-    // waits in registers and step k is multiplied out of LDS; the weight tile (L2-resident, shared by every
-    // workgroup) is fetched one step ahead.  One barrier per K step.  Offsets are 32-bit (host checks sizes).
-    u32x4 regPa[4], regPb[4], regW[WROWS];
+    // Register prefetch, three rotating sets: tiles k+1, k+2, k+3 are in registers / in flight while tile k is
+    // multiplied out of LDS (two LDS buffers, one barrier per K step).  The layers that use this kernel are the tiny
+    // 4x4 / 8x8 ones, where a handful of workgroups walk a long K loop alone on their CU: latency, not bandwidth.
+    // Offsets are 32-bit (host checks sizes).
+    u32x4 regP[3][4], regW[3][WROWS];
     const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.x), 0, a.x_bytes, 0x00020000);
     const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.wp), 0, a.w_bytes, 0x00020000);
-    auto load_pixels = [&](int kt, u32x4 (&regP)[4]) {
+    auto load_tile = [&](int kt, u32x4 (&rP)[4], u32x4 (&rW)[WROWS]) {
+        // K steps past the end load zeros (out-of-range offsets): the loop below then needs no early exit, every
+        // step is unconditional and hipcc keeps counted vmcnt waits around the whole unrolled body
+        const unsigned dead = kt >= nk ? 0x80000000u : 0u;
         const int tap = kt / nkc;
         const int c0 = (kt - tap * nkc) << 6;
         const int kh = tap / a.KW;
         const int dh = kh - a.pad, dw = (tap - kh * a.KW) - a.pad;
 #pragma unroll
+        for (int i = 0; i < WROWS; ++i) {
+            const unsigned off = (unsigned)((tap * a.Cout + n0 + prow + 32 * i) * a.Cin + c0 + chunk * 8) * 2u;
+            rW[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off | dead, 0, 0);
+        }
+#pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int hi = ph[i] + dh, wi = pw[i] + dw;
             const bool ok = (unsigned)hi < (unsigned)Hup && (unsigned)wi < (unsigned)Wup;
             const int hs = a.ups ? (hi >> 1) : hi, ws = a.ups ? (wi >> 1) : wi;
-            // Buffer load with hardware range checking: out-of-frame lanes get an offset past num_records and
-            // the load returns zeros -- no branch (which would make hipcc drain vmcnt(0) and serialise the
-            // prefetch) and no select after the load (which would force an early wait on it).
+            // range-checked buffer load: out-of-frame lanes read zeros, no branch and no select after the load
             const unsigned off = ok ? (unsigned)(((pb[i] * a.Hin + hs) * a.Win + ws) * a.Cin + c0 + chunk * 8) * 2u
                                     : 0x80000000u;
-            regP[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off, 0, 0);
+            rP[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, off | dead, 0, 0);
         }
     };
-    auto load_weights = [&](int kt) {
-        const int tap = kt / nkc;
-        const int c0 = (kt - tap * nkc) << 6;
-#pragma unroll
-        for (int i = 0; i < WROWS; ++i) {
-            const unsigned off = (unsigned)((tap * a.Cout + n0 + prow + 32 * i) * a.Cin + c0 + chunk * 8) * 2u;
-            regW[i] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, off, 0, 0);
-        }
-    };
-    auto store_tiles = [&](int buf, const u32x4 (&regP)[4]) {
+    auto store_tile = [&](int buf, const u32x4 (&rP)[4], const u32x4 (&rW)[WROWS]) {
         unsigned char* base = smem + buf * STAGE;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<u32x4*>(base + (prow + 32 * i) * 128 + swz) = regP[i];
+            *reinterpret_cast<u32x4*>(base + (prow + 32 * i) * 128 + swz) = rP[i];
 #pragma unroll
         for (int i = 0; i < WROWS; ++i)
-            *reinterpret_cast<u32x4*>(base + P_BYTES + (prow + 32 * i) * 128 + swz) = regW[i];
+            *reinterpret_cast<u32x4*>(base + P_BYTES + (prow + 32 * i) * 128 + swz) = rW[i];
     };
 
     f32x4 acc[4][TPX];
@@ -160,30 +158,20 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(ConvArgs a) {
         }
     };
 
-    load_pixels(0, regPa);
-    load_weights(0);
-    store_tiles(0, regPa);
-    const int last = nk - 1;
-    load_pixels(min(1, last), regPa);
+    load_tile(0, regP[0], regW[0]);
+    load_tile(1, regP[1], regW[1]);
+    load_tile(2, regP[2], regW[2]);
+    store_tile(0, regP[0], regW[0]);
     __syncthreads();
-    // Steps past the end re-load the last tile (clamped index) instead of branching, so the loop body has no
-    // conditional memory operations and hipcc keeps counted vmcnt waits (loads stay in flight across barriers).
-    for (int kt = 0; kt < nk; kt += 2) {
-        // even step: LDS buffer 0 holds tile kt, set A holds the pixels of tile kt+1
-        load_weights(min(kt + 1, last));
-        asm volatile("" ::: "memory");   // keep issue order weights -> pixels: vmcnt retires in order
-        load_pixels(min(kt + 2, last), regPb);
-        compute(0);
-        store_tiles(1, regPa);
-        __syncthreads();
-        if (kt + 1 >= nk) break;
-        // odd step: LDS buffer 1 holds tile kt+1, set B holds the pixels of tile kt+2
-        load_weights(min(kt + 2, last));
-        asm volatile("" ::: "memory");
-        load_pixels(min(kt + 3, last), regPa);
-        compute(1);
-        store_tiles(0, regPb);
-        __syncthreads();
+    for (int kt = 0; kt < nk; kt += 3) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int k = kt + r;                                                // k >= nk: multiplies zero tiles
+            compute(k & 1);
+            store_tile((k + 1) & 1, regP[(r + 1) % 3], regW[(r + 1) % 3]);     // tile k+1, requested two steps ago
+            load_tile(k + 3, regP[r], regW[r]);                                  // set r (tile k) is in LDS already
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: bias -> residual -> leaky ReLU (first lrelu_ch channels) -> bf16 NHWC

@@ -493,6 +493,142 @@ __global__ __launch_bounds__(256) void planes_outer_kernel(const unsigned short*
     }
 }
 
+// ------------------------------------------------------------------------------------------------ small linears
+// Equalized-LR linear layers with a small batch (M <= 64 rows): mapping MLP (net.py:58-62), pose-conditioned style
+// (net.py:220-224), StyleBlock affines (net.py:96-101).  y = act(c * x W^T + b), fp32 like the reference.  These are
+// launch-latency bound (2 MFLOP each): one launch per layer forward, two backward, instead of ~10 library / elementwise
+// launches.  x (M,K), W (N,K), y (M,N) row-major.
+constexpr int LIN_MAXM = 64;
+
+// block = 256 threads -> 8 output columns for all rows: thread = (row m = tid & 63, column pair tid >> 6).
+// Few, long phases (K in chunks of 128): the kernel's time is load latency, so it uses N/8 blocks instead of N/32.
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y, int M,
+                                                         int K, int N, float c, int act, float slope) {
+    __shared__ float xs[LIN_MAXM][129];
+    __shared__ float ws[8][129];
+    const int n0 = blockIdx.x * 8;
+    const int m = threadIdx.x & 63, nq = threadIdx.x >> 6;
+    float acc0 = 0.f, acc1 = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 128) {
+        for (int e = threadIdx.x; e < M * 128; e += 256) {
+            const int mm = e >> 7, kk = e & 127;
+            xs[mm][kk] = (k0 + kk < K) ? x[(long)mm * K + k0 + kk] : 0.f;
+        }
+        for (int e = threadIdx.x; e < 8 * 128; e += 256) {
+            const int n = e >> 7, kk = e & 127;
+            ws[n][kk] = (n0 + n < N && k0 + kk < K) ? w[(long)(n0 + n) * K + k0 + kk] : 0.f;
+        }
+        __syncthreads();
+        if (m < M) {
+#pragma unroll 16
+            for (int kk = 0; kk < 128; ++kk) {
+                const float xv = xs[m][kk];
+                acc0 += xv * ws[2 * nq][kk];
+                acc1 += xv * ws[2 * nq + 1][kk];
+            }
+        }
+        __syncthreads();
+    }
+    if (m < M) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + 2 * nq + j;
+            if (n < N) {
+                float v = (j ? acc1 : acc0) * c + (bias ? bias[n] : 0.f);
+                if (act) v = v > 0.f ? v : v * slope;
+                y[(long)m * N + n] = v;
+            }
+        }
+    }
+}
+
+// dx[m][k] (+)= c * sum_n dz[m][n] W[n][k], dz = dy * lrelu'(y) when act.  block -> 8 k-columns for all rows.
+__global__ __launch_bounds__(256) void linear_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                           const float* __restrict__ w, float* __restrict__ dx, int M,
+                                                           int K, int N, float c, int act, float slope, int accumulate) {
+    __shared__ float zs[LIN_MAXM][129];
+    __shared__ float ws[128][9];
+    const int k0 = blockIdx.x * 8;
+    const int m = threadIdx.x & 63, kq = threadIdx.x >> 6;
+    float acc0 = 0.f, acc1 = 0.f;
+    for (int n0 = 0; n0 < N; n0 += 128) {
+        for (int e = threadIdx.x; e < M * 128; e += 256) {
+            const int mm = e >> 7, nn = e & 127;
+            float g = 0.f;
+            if (n0 + nn < N) {
+                g = dy[(long)mm * N + n0 + nn];
+                if (act && !(y[(long)mm * N + n0 + nn] > 0.f)) g *= slope;
+            }
+            zs[mm][nn] = g;
+        }
+        for (int e = threadIdx.x; e < 128 * 8; e += 256) {
+            const int nn = e >> 3, kk = e & 7;
+            ws[nn][kk] = (n0 + nn < N && k0 + kk < K) ? w[(long)(n0 + nn) * K + k0 + kk] : 0.f;
+        }
+        __syncthreads();
+        if (m < M) {
+#pragma unroll 16
+            for (int nn = 0; nn < 128; ++nn) {
+                const float g = zs[m][nn];
+                acc0 += g * ws[nn][2 * kq];
+                acc1 += g * ws[nn][2 * kq + 1];
+            }
+        }
+        __syncthreads();
+    }
+    if (m < M) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = k0 + 2 * kq + j;
+            if (k < K) {
+                const long o = (long)m * K + k;
+                const float v = (j ? acc1 : acc0) * c;
+                dx[o] = accumulate ? dx[o] + v : v;
+            }
+        }
+    }
+}
+
+// dW[n][k] += c * sum_m dz[m][n] x[m][k];  db[n] += sum_m dz[m][n].  block -> 16 n-rows x 64 k-columns (4 per thread).
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                           const float* __restrict__ x, float* __restrict__ dw,
+                                                           float* __restrict__ db, int M, int K, int N, float c, int act,
+                                                           float slope) {
+    __shared__ float zs[LIN_MAXM][17];
+    __shared__ float xs[LIN_MAXM][65];
+    const int n0 = blockIdx.y * 16, k0 = blockIdx.x * 64;
+    for (int e = threadIdx.x; e < M * 16; e += 256) {
+        const int m = e >> 4, nn = e & 15;
+        float g = 0.f;
+        if (n0 + nn < N) {
+            g = dy[(long)m * N + n0 + nn];
+            if (act && !(y[(long)m * N + n0 + nn] > 0.f)) g *= slope;
+        }
+        zs[m][nn] = g;
+    }
+    for (int e = threadIdx.x; e < M * 64; e += 256) {
+        const int m = e >> 6, kk = e & 63;
+        xs[m][kk] = (k0 + kk < K) ? x[(long)m * K + k0 + kk] : 0.f;
+    }
+    __syncthreads();
+    const int nl = threadIdx.x >> 4, kq = (threadIdx.x & 15) * 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    for (int m = 0; m < M; ++m) {
+        const float g = zs[m][nl];
+        bsum += g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += g * xs[m][kq + j];
+    }
+    if (n0 + nl < N) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k0 + kq + j < K) dw[(long)(n0 + nl) * K + k0 + kq + j] += acc[j] * c;
+        if (db && blockIdx.x == 0 && kq == 0) db[n0 + nl] += bsum;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ Adam
 constexpr int NORM_BLOCKS = 1024;
 
@@ -719,6 +855,33 @@ extern "C" int rgbd_planes_outer(const void* t, const float* p, float* o, float*
     if (KP == 3) planes_outer_kernel<3><<<grid, 256, 0, st>>>((const unsigned short*)t, p, o, tsum, B, HW, C, rows);
     else         planes_outer_kernel<4><<<grid, 256, 0, st>>>((const unsigned short*)t, p, o, tsum, B, HW, C, rows);
     RGBD_CHECK_LAUNCH("planes_outer_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int K, int N,
+                               float c, int act, float slope, void* stream) {
+    RGBD_REQUIRE(x && w && y, "rgbd_linear_fwd: null pointer");
+    RGBD_REQUIRE(M > 0 && M <= LIN_MAXM && K > 0 && N > 0, "rgbd_linear_fwd: needs 0 < M <= %d (M=%d)", LIN_MAXM, M);
+    linear_fwd_kernel<<<(N + 7) / 8, 256, 0, (hipStream_t)stream>>>(x, w, bias, y, M, K, N, c, act, slope);
+    RGBD_CHECK_LAUNCH("linear_fwd_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_linear_bwd(const float* dy, const float* y, const float* x, const float* w, float* dx, float* dw,
+                               float* db, int M, int K, int N, float c, int act, float slope, int accumulate_dx,
+                               void* stream) {
+    RGBD_REQUIRE(dy && x && w, "rgbd_linear_bwd: null pointer");
+    RGBD_REQUIRE(!act || y, "rgbd_linear_bwd: the activation output y is needed for its gradient");
+    RGBD_REQUIRE(M > 0 && M <= LIN_MAXM && K > 0 && N > 0, "rgbd_linear_bwd: needs 0 < M <= %d (M=%d)", LIN_MAXM, M);
+    hipStream_t st = (hipStream_t)stream;
+    if (dx) {
+        linear_dgrad_kernel<<<(K + 7) / 8, 256, 0, st>>>(dy, y, w, dx, M, K, N, c, act, slope, accumulate_dx);
+        RGBD_CHECK_LAUNCH("linear_dgrad_kernel");
+    }
+    if (dw) {
+        linear_wgrad_kernel<<<dim3((K + 63) / 64, (N + 15) / 16), 256, 0, st>>>(dy, y, x, dw, db, M, K, N, c, act, slope);
+        RGBD_CHECK_LAUNCH("linear_wgrad_kernel");
+    }
     return 0;
 }
 

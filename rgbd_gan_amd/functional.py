@@ -384,3 +384,41 @@ def from_planes(x, w, bias, scale, act=True):
 
 def to_planes(h, w, bias, scale):
     return _ToPlanes.apply(h, w, bias, float(scale))
+
+
+class _LinearAct(torch.autograd.Function):
+    """y = act(c * x W^T + b) for a handful of rows (first-order only: generator side).  Weight and bias gradients are
+    accumulated straight into the flat gradient buffer when one is bound.  Rows are processed in groups of 64."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, c, act):
+        x = x.contiguous()
+        w = w.contiguous()
+        b = bias.contiguous() if bias is not None else None
+        y = torch.cat([kernels.linear_fwd(x[i:i + 64], w, b, c, act) for i in range(0, x.shape[0], 64)]) \
+            if x.shape[0] > 64 else kernels.linear_fwd(x, w, b, c, act)
+        ctx.c, ctx.act = c, act
+        ctx.save_for_backward(x, w, bias, y)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, w, bias, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_b = bias is not None and ctx.needs_input_grad[2]
+        direct = need_w and _direct_grad(w) and (not need_b or _direct_grad(bias))
+        dw = w.grad if direct else (torch.zeros_like(w) if need_w else None)
+        db = (bias.grad if direct else torch.zeros_like(bias)) if need_b else None
+        dxs = [kernels.linear_bwd(dy[i:i + 64], y[i:i + 64], x[i:i + 64], w, ctx.c, ctx.act, want_dx=need_x, dw=dw, db=db)
+               for i in range(0, x.shape[0], 64)]
+        dx = (dxs[0] if len(dxs) == 1 else torch.cat(dxs)) if need_x else None
+        if direct:
+            return dx, None, None, None, None
+        return dx, dw, db, None, None
+
+
+def linear_act(x, w, bias, c, act=True):
+    """Equalized-LR linear (pggan.py:39-50) + optional leaky ReLU on a small batch of rows, one HIP launch."""
+    return _LinearAct.apply(x, w, bias, float(c), bool(act))

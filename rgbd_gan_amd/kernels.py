@@ -243,6 +243,32 @@ def planes_outer(t, planes, want_tsum=False):
     return o, ts
 
 
+# ------------------------------------------------------------------ small linears
+def linear_fwd(x, w, bias, c, act, slope=0.2):
+    """x (M,K), w (N,K) fp32 -> y (M,N) = act(c * x w^T + bias), M <= 64."""
+    _chk(x, F32, "x"); _chk(w, F32, "w"); _chk(bias, F32, "bias")
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty(M, N, dtype=F32, device=x.device)
+    rc = _lib.load().rgbd_linear_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), M, K, N, float(c), int(bool(act)),
+                                     float(slope), _stream())
+    _lib.check(rc, "rgbd_linear_fwd")
+    return y
+
+
+def linear_bwd(dy, y, x, w, c, act, want_dx=True, dw=None, db=None, slope=0.2):
+    """Returns dx (or None); accumulates into dw / db when given."""
+    for t, n in ((dy, "dy"), (y, "y"), (x, "x"), (w, "w"), (dw, "dw"), (db, "db")):
+        _chk(t, F32, n)
+    M, K = x.shape
+    N = w.shape[0]
+    dx = torch.empty(M, K, dtype=F32, device=x.device) if want_dx else None
+    rc = _lib.load().rgbd_linear_bwd(_ptr(dy), _ptr(y), _ptr(x), _ptr(w), _ptr(dx), _ptr(dw), _ptr(db), M, K, N,
+                                     float(c), int(bool(act)), float(slope), 0, _stream())
+    _lib.check(rc, "rgbd_linear_bwd")
+    return dx
+
+
 # ------------------------------------------------------------------ AdaIN
 def adain_fwd(x, scale, shift, eps=1e-5):
     """x (B,H,W,C) bf16; scale, shift (B,C) fp32 -> y, mean, rstd."""

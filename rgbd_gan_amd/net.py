@@ -92,7 +92,7 @@ class _Link:
 # ---------------------------------------------------------------------------------------------- StyleGAN
 class MappingNetwork(_Link):
     """net.py:22-62: pixel-norm then 8 x (equalized linear, leaky ReLU).  Tiny GEMMs (M=B, N=K=ch): fp32 library
-    matmul; launch-latency bound, not a roofline kernel."""
+    kernel per layer (rgbd_linear_fwd); launch-latency bound, not a roofline kernel."""
 
     def __init__(self, ch, device, seed=0):
         self.ch = ch
@@ -108,7 +108,7 @@ class MappingNetwork(_Link):
         h = h * torch.rsqrt(torch.mean(h * h, dim=1, keepdim=True) + 1e-8)
         p = self.store.params
         for i in range(0, 16, 2):
-            h = Fn.lrelu(F.linear(h * self.inv_c, p[f"l/{i}/c/W"], p[f"l/{i}/c/b"]))
+            h = Fn.linear_act(h, p[f"l/{i}/c/W"], p[f"l/{i}/c/b"], self.inv_c, act=True)
         return h
 
     forward = __call__
@@ -150,8 +150,8 @@ class StyleGenerator(_Link):
         """net.py:90-102 (StyleBlock): AdaIN(h, s(w), b(w)); both linears gain 1."""
         p = self.store.params
         c = _inv_c(self.ch, 1.0)
-        scale = F.linear(w * c, p[name + "/s/c/W"], p[name + "/s/c/b"])
-        shift = F.linear(w * c, p[name + "/b/c/W"], p[name + "/b/c/b"])
+        scale = Fn.linear_act(w, p[name + "/s/c/W"], p[name + "/s/c/b"], c, act=False)
+        shift = Fn.linear_act(w, p[name + "/b/c/W"], p[name + "/b/c/b"], c, act=False)
         return Fn.adain(h, scale, shift)
 
     def _block(self, i, w, x):
@@ -173,8 +173,8 @@ class StyleGenerator(_Link):
         """net.py:220-224."""
         p = self.store.params
         h = torch.cat([w, theta * 16], dim=1)
-        h = Fn.lrelu(F.linear(h * _inv_c(self.ch + 9), p["l1/c/W"], p["l1/c/b"]))
-        return Fn.lrelu(F.linear(h * _inv_c(self.ch), p["l2/c/W"], p["l2/c/b"]))
+        h = Fn.linear_act(h, p["l1/c/W"], p["l1/c/b"], _inv_c(self.ch + 9), act=True)
+        return Fn.linear_act(h, p["l2/c/W"], p["l2/c/b"], _inv_c(self.ch), act=True)
 
     def _to_rgbd(self, i, h):
         """outs[i]: 1x1 conv (gain 1) from NHWC bf16 to NCHW fp32, fp32 accumulate (bandwidth-bound, Cout = 4)."""

@@ -322,3 +322,26 @@ def test_pool_and_unpool_lrelu_kernels():
     lhs = float((ref.double() * dp.double()).sum())
     rhs = float((x.double() * (0.25 * up * mask).double()).sum())
     assert abs(lhs - rhs) < 1e-6 * max(1.0, abs(lhs))
+
+
+@pytest.mark.parametrize("M,K,N,act", [(32, 256, 256, True), (4, 265, 256, True), (64, 256, 128, False), (7, 256, 64, False),
+                                       (100, 256, 256, True)])
+def test_small_linear_forward_backward(M, K, N, act):
+    from rgbd_gan_amd import functional as Fn
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(M, K, generator=g, requires_grad=True)
+    w = torch.randn(N, K, generator=g, requires_grad=True)
+    b = torch.randn(N, generator=g, requires_grad=True)
+    dy = torch.randn(M, N, generator=g)
+    c = float(np.sqrt(2.0 / K))
+    ref = F.linear(x * c, w, b)
+    if act:
+        ref = F.leaky_relu(ref, 0.2)
+    ref.backward(dy)
+    xd, wd, bd = (t.detach().to(dev()).requires_grad_(True) for t in (x, w, b))
+    y = Fn.linear_act(xd, wd, bd, c, act)
+    y.backward(dy.to(dev()))
+    torch.testing.assert_close(y.detach().cpu(), ref.detach(), atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(xd.grad.cpu(), x.grad, atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(wd.grad.cpu(), w.grad, atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(bd.grad.cpu(), b.grad, atol=1e-4, rtol=1e-4)
