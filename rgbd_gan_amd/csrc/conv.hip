@@ -655,9 +655,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradArgs a) {
 }
 
 // Stage 1 of the slab reduction: grid (element chunks, slab groups); every thread owns one float4 of the packed
-// (tap, co, ci) tile, sums its group's slabs with independent loads in flight and adds the partial into `accum`
-// (zeroed by the host wrapper) with fp32 atomics -- 16 groups x 147 KB of atomics, negligible.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ accum,
+// (tap, co, ci) tile, sums its group's slabs with independent loads in flight and stores the group partial
+// (plain stores: no zero fill, no atomics).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ partial,
                                                            int nslab, long total) {
     const long e4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (e4 >= total) return;
@@ -674,15 +674,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         acc += (v0 + v1) + (v2 + v3);
     }
     for (; s2 < s_end; ++s2) acc += *reinterpret_cast<const f32x4*>(slabs + (long)s2 * total + e4);
-    if (s_begin < s_end) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) atomicAdd(accum + e4 + k, acc[k]);
-    }
+    *reinterpret_cast<f32x4*>(partial + (long)blockIdx.y * total + e4) = acc;
 }
 
-// Stage 2: packed (tap, co, ci) -> master layout (co, ci, tap) with the equalized-LR scale.
-__global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ accum, float* __restrict__ dw,
-                                                           int taps, int cout, int cin, float scale, int accumulate) {
+// Stage 2: sum the group partials; packed (tap, co, ci) -> master layout (co, ci, tap) with the equalized-LR scale.
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ partial, int groups,
+                                                           float* __restrict__ dw, int taps, int cout, int cin,
+                                                           float scale, int accumulate) {
     const long total = (long)taps * cout * cin;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         const int ci = (int)(e % cin);
@@ -690,7 +688,9 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restri
         const int co = (int)(r % cout);
         const int tap = (int)(r / cout);
         const long o = ((long)co * cin + ci) * taps + tap;
-        const float v = accum[e] * scale;
+        float v = partial[e];
+        for (int g = 1; g < groups; ++g) v += partial[(long)g * total + e];
+        v *= scale;
         dw[o] = accumulate ? dw[o] + v : v;
     }
 }
@@ -822,8 +822,8 @@ WgradPlan plan_wgrad(int B, int H, int W, int Cin, int Cout) {
 extern "C" int64_t rgbd_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int K) {
     if (B <= 0 || H < 4 || W < 4 || Cin % 64 || Cout % 64 || (K != 1 && K != 3)) return -1;
     const WgradPlan p = plan_wgrad(B, H, W, Cin, Cout);
-    // nsplit slabs + one accumulation tile
-    return ((int64_t)p.nsplit + 1) * K * K * Cout * Cin * (int64_t)sizeof(float);
+    // nsplit slabs + up to 16 group partials of the two-stage reduction
+    return ((int64_t)p.nsplit + 16) * K * K * Cout * Cin * (int64_t)sizeof(float);
 }
 
 extern "C" int rgbd_conv2d_wgrad_bf16(const void* x, const void* dy, void* workspace, float* dw, int B, int H, int W,
@@ -847,11 +847,7 @@ extern "C" int rgbd_conv2d_wgrad_bf16(const void* x, const void* dy, void* works
     dim3 grid(p.nsplit, Cin / 64, Cout / 64);
     hipStream_t st = (hipStream_t)stream;
     const long total = (long)K * K * Cout * Cin;
-    float* accum = (float*)workspace + (long)p.nsplit * total;
-    if (rgbd_zero_async(accum, total * sizeof(float), st) != hipSuccess) {
-        rgbd_set_error("rgbd_conv2d_wgrad_bf16: memset failed");
-        return -2;
-    }
+    float* partial = (float*)workspace + (long)p.nsplit * total;
     {
         static bool attr_done[4] = {false, false, false, false};
         const bool fast = p.PW == 16 && p.PH == 8;
@@ -874,11 +870,11 @@ extern "C" int rgbd_conv2d_wgrad_bf16(const void* x, const void* dy, void* works
     }
     RGBD_CHECK_LAUNCH("conv_wgrad_kernel");
     const int groups = p.nsplit >= 64 ? 16 : (p.nsplit >= 8 ? 4 : 1);
-    wgrad_reduce_kernel<<<dim3((unsigned)((total / 4 + 255) / 256), groups), 256, 0, st>>>((const float*)workspace, accum,
+    wgrad_reduce_kernel<<<dim3((unsigned)((total / 4 + 255) / 256), groups), 256, 0, st>>>((const float*)workspace, partial,
                                                                                           p.nsplit, total);
     RGBD_CHECK_LAUNCH("wgrad_reduce_kernel");
     const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
-    wgrad_finish_kernel<<<blocks, 256, 0, st>>>(accum, dw, K * K, Cout, Cin, scale, accumulate);
+    wgrad_finish_kernel<<<blocks, 256, 0, st>>>(partial, groups, dw, K * K, Cout, Cin, scale, accumulate);
     RGBD_CHECK_LAUNCH("wgrad_finish_kernel");
     return 0;
 }
