@@ -135,3 +135,61 @@ def rgbd_step(gen_params, dis_params, opt, x_real_full, z, thetas, stage, cfg, i
     out["x_fake"] = x_fake.detach()
     out["stage"], out["batch_size"], out["image_size"] = stage, B, image_size
     return out
+
+
+def loss_gen_adv_focal(y_fake, gamma):
+    """loss_functions.py:7-14: softplus(-y) * sigmoid(-y)^gamma, mean."""
+    return (F.softplus(-y_fake) * torch.sigmoid(-y_fake) ** gamma).sum() / y_fake.numel()
+
+
+def deepvoxels_step(gen_params, map_params, dis_params, opt, x_real_full, z_fake, thetas, cfg, iteration):
+    """updater_deepvoxels.py:123-252 on explicit inputs.
+
+    z_fake = (z, z2, z_dis, z2_dis): the tiled latents of the generator step and the fresh ones of the discriminator
+    step, each (B,ch).  opt: {'map','gen','dis'} ChainerAdam.  cfg: lambda_gp, lambda_depth, depth_min,
+    focal_loss_gamma, start_rotation, lambda_geometric (or None)."""
+    from . import deepvoxels_nets as dvn
+    B = x_real_full.shape[0]
+    stage = 8.5
+    use_rotate = iteration > cfg["start_rotation"]
+    cams = camera.camera_matrices(thetas)
+    for o in opt.values():
+        o.zero_grad()
+    x_real = torch.as_tensor(x_real_full)
+    scale = x_real.shape[-1] // 64
+    if scale > 1:
+        x_real = F.avg_pool2d(x_real, scale, scale)
+    z, z2, zd, zd2 = (torch.as_tensor(t) for t in z_fake)
+    x_fake = dvn.deepvoxels_generator(gen_params, map_params, z, z2, cams)
+    y_fake = nets.discriminator(dis_params, x_fake[:, :3], stage)
+    loss_adv_g = loss_gen_adv_focal(y_fake, cfg["focal_loss_gamma"])
+    loss_gen = loss_adv_g
+    out = {"gen/loss_adv": float(loss_adv_g.detach())}
+    if use_rotate:
+        loss_rot, _ = warp_loss.loss_torch(x_fake[:B // 2], cams[:B // 2], x_fake[B // 2:], cams[B // 2:],
+                                           occlusion_aware=False, lambda_geometric=cfg.get("lambda_geometric") or 3)
+        loss_rot = loss_rot + depth_hinge(x_fake, cfg["depth_min"], cfg["lambda_depth"])
+        out["gen/loss_rotate"] = float(loss_rot.detach())
+        loss_gen = loss_gen + loss_rot * 0.3                                  # updater_deepvoxels.py:202 (see a27)
+    loss_gen.backward()
+    out["norm_map"] = opt["map"].update()
+    out["norm_gen"] = opt["gen"].update()
+    out["x_fake"] = x_fake.detach()
+    opt["dis"].zero_grad()
+
+    with torch.no_grad():
+        x_fake_d = dvn.deepvoxels_generator(gen_params, map_params, zd, zd2, cams)
+    y_fake = nets.discriminator(dis_params, x_fake_d[:, :3], stage)
+    x_real = x_real.clone().requires_grad_(True)
+    y_real = nets.discriminator(dis_params, x_real, stage)
+    loss_adv = loss_dis_adv(y_fake, y_real)
+    loss_dis = loss_adv
+    if cfg["lambda_gp"] > 0:
+        loss_gp = r1_penalty(y_real, x_real, cfg["lambda_gp"])
+        out["dis/loss_gp"] = float(loss_gp.detach())
+        loss_dis = loss_adv + loss_gp
+    out["dis/loss_adv"] = float(loss_adv.detach())
+    loss_dis.backward()
+    out["norm_dis"] = opt["dis"].update()
+    out["x_fake_dis"] = x_fake_d
+    return out

@@ -819,11 +819,13 @@ WgradPlan plan_wgrad(int B, int H, int W, int Cin, int Cout) {
 }
 }  // namespace
 
+static int wgrad_groups(int nsplit) { return nsplit >= 64 ? 16 : (nsplit >= 8 ? 4 : 1); }
+
 extern "C" int64_t rgbd_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int K) {
     if (B <= 0 || H < 4 || W < 4 || Cin % 64 || Cout % 64 || (K != 1 && K != 3)) return -1;
     const WgradPlan p = plan_wgrad(B, H, W, Cin, Cout);
-    // nsplit slabs + up to 16 group partials of the two-stage reduction
-    return ((int64_t)p.nsplit + 16) * K * K * Cout * Cin * (int64_t)sizeof(float);
+    // nsplit slabs + the group partials of the two-stage reduction
+    return ((int64_t)p.nsplit + wgrad_groups(p.nsplit)) * K * K * Cout * Cin * (int64_t)sizeof(float);
 }
 
 extern "C" int rgbd_conv2d_wgrad_bf16(const void* x, const void* dy, void* workspace, float* dw, int B, int H, int W,
@@ -869,7 +871,7 @@ extern "C" int rgbd_conv2d_wgrad_bf16(const void* x, const void* dy, void* works
         }
     }
     RGBD_CHECK_LAUNCH("conv_wgrad_kernel");
-    const int groups = p.nsplit >= 64 ? 16 : (p.nsplit >= 8 ? 4 : 1);
+    const int groups = wgrad_groups(p.nsplit);
     wgrad_reduce_kernel<<<dim3((unsigned)((total / 4 + 255) / 256), groups), 256, 0, st>>>((const float*)workspace, partial,
                                                                                           p.nsplit, total);
     RGBD_CHECK_LAUNCH("wgrad_reduce_kernel");

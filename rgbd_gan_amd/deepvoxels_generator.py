@@ -1,0 +1,343 @@
+"""DeepVoxels generator with the reference's surface (deepvoxels_generator.py of nogu-atsu/RGBD-GAN) on the HIP
+kernels: config 4 (configs/deepvoxels_shapenet_car.yml, occlusion_type "accumulative").
+
+    MappingNetwork3D(ch)        .make_hidden(n), __call__(z)                          deepvoxels_generator.py:28-68
+    VoxelGenerator(ch, ch_out)  __call__(w) -> (B,32,32,32,32)                         :112-188
+    StyleGenerator(w_ch, in_ch, hidden_ch)   __call__(h, w, stage) -> (B,3,64,64)      :191-222   (the 2-D renderer)
+    Generator(ch, occlusion_type, background_generator, config)                        :225-323
+        .mapping, .projection, .make_hidden(n), __call__(z, stage, camera_matrices, z2=None, z3=None, z4=None, theta=None)
+
+How the layers map onto the conv engine (rgbd_gan_amd/csrc/conv.hip, NHWC bf16, channels in multiples of 64):
+  * 3x3x3 convolution: the three depth taps are folded into input channels -- the input volume (B,D,H,W,C) is
+    concatenated with its two depth-shifted copies to (B*D,H,W,3C) and ONE 3x3 implicit-GEMM conv with the weight
+    rearranged to (Cout, 3C, 3, 3) produces all 27 taps with a single fp32 accumulation.  Nearest 2x upsampling is
+    a depth repeat plus the conv kernel's own fused H/W upsample.
+  * 4x4 stride-2 convolution: the 16 taps are folded into input channels (B,H/2,W/2,16C) and run as a 1x1 conv (a
+    plain GEMM, M = B*H*W/4, K = 16C).
+  * channel counts that are not multiples of 64 (32-channel voxel blocks, the 288 -> 3 output conv) are zero padded;
+    padded activations are exactly zero everywhere (zero weights, biases and style shifts), so results are unchanged.
+The master parameters keep the reference's shapes and Chainer names; the rearranged weights are differentiable
+views of them (functional.DerivedConvLayer).  Frustum resampling and the accumulative occlusion compositing are the
+fp32 kernels of csrc/deepvoxels.hip (deepvoxel/projection.py, deepvoxel/deepvoxel.py).
+
+Not supported (unreachable with the shipped config, asserted): occlusion types "deepvoxels" / "rendernet",
+background_generator, enable_blur.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import functional as Fn
+from .deepvoxel.deepvoxel import accumulative_occlusion, interpolate_trilinear_batch
+from .deepvoxel.projection import ProjectionHelper
+from .net import BF16, SQRT2, _Link, _as_device_tensor, _inv_c
+from .params import ParamStore
+
+GRID_FEATS = 32
+OCC_NF = 4
+
+
+def _pad_to(t, n, dim=-1):
+    """Zero-pad dimension `dim` of t up to n entries (differentiable)."""
+    extra = n - t.shape[dim]
+    if extra == 0:
+        return t
+    dim = dim % t.dim()
+    pads = [0, 0] * (t.dim() - 1 - dim) + [0, extra]
+    return F.pad(t, pads)
+
+
+def _ceil64(n):
+    return (n + 63) // 64 * 64
+
+
+class MappingNetwork3D(_Link):
+    """deepvoxels_generator.py:28-68.  Owned by Generator but NOT one of its registered children (:271), so it has
+    its own optimizer ('map', train_rgbd.py:337) and its own snapshot file."""
+
+    def __init__(self, ch=512, device="cuda:0", seed=0):
+        self.ch = ch
+        self.device = torch.device(device)
+        specs = []
+        for i in range(0, 16, 2):
+            specs += [(f"l/{i}/c/W", (ch, ch), "normal"), (f"l/{i}/c/b", (ch,), "zeros")]
+        self.store = ParamStore(specs, device, seed)
+        self.stores = (("", self.store),)
+        self.inv_c = _inv_c(ch)
+
+    def make_hidden(self, batch_size):
+        """:53-62: plain N(0,1), shape (B,ch,1,1,1) (the normalisation happens in forward)."""
+        return torch.randn(batch_size, self.ch, 1, 1, 1, device=self.device)
+
+    def __call__(self, x):
+        h = _as_device_tensor(x, self.device).reshape(x.shape[0], -1)
+        h = h * torch.rsqrt(torch.mean(h * h, dim=1, keepdim=True) + 1e-8)
+        p = self.store.params
+        for i in range(0, 16, 2):
+            h = Fn.linear_act(h, p[f"l/{i}/c/W"], p[f"l/{i}/c/b"], self.inv_c, act=True)
+        return h
+
+    forward = __call__
+
+
+class _StyleMixin:
+    def _style(self, name, w, h):
+        """StyleBlock (:96-109): AdaIN(h, s(w), b(w)) over all spatial axes; h is (B, ..., Cpad) bf16."""
+        p = self.p
+        c = _inv_c(self.w_ch, 1.0)
+        C = h.shape[-1]
+        scale = _pad_to(Fn.linear_act(w, p[name + "/s/c/W"], p[name + "/s/c/b"], c, act=False), C)
+        shift = _pad_to(Fn.linear_act(w, p[name + "/b/c/W"], p[name + "/b/c/b"], c, act=False), C)
+        shp = h.shape
+        out = Fn.adain(h.reshape(shp[0], -1, 1, C), scale, shift)
+        return out.reshape(shp)
+
+
+def voxel_channels(ch):
+    return [(ch // 4, ch // 4), (ch // 4, ch // 4), (ch // 8, ch // 4), (ch // 8, ch // 8)]      # (out, in)
+
+
+def voxel_specs(prefix, ch, ch_out):
+    specs = []
+    for i, (co, ci) in enumerate(voxel_channels(ch)):
+        pre = f"{prefix}net/{i}"
+        if i == 0:
+            specs.append((pre + "/W", (ci, 4, 4, 4), "ones"))
+        specs += [(pre + "/b0/b", (co,), "zeros"), (pre + "/b1/b", (co,), "zeros"),
+                  (pre + "/n0/b/W", (co,), "zeros"), (pre + "/n1/b/W", (co,), "zeros")]
+        for s in ("s0", "s1"):
+            specs += [(f"{pre}/{s}/s/c/W", (co, ch), "normal"), (f"{pre}/{s}/s/c/b", (co,), "ones"),
+                      (f"{pre}/{s}/b/c/W", (co, ch), "normal"), (f"{pre}/{s}/b/c/b", (co,), "zeros")]
+        specs += [(pre + "/c0/c/W", (co, ci, 3, 3, 3), "normal"), (pre + "/c1/c/W", (co, co, 3, 3, 3), "normal")]
+    specs += [(prefix + "out/c/W", (ch_out, ch // 8, 1, 1, 1), "normal"), (prefix + "out/c/b", (ch_out,), "zeros")]
+    return specs
+
+
+class VoxelGenerator(_Link, _StyleMixin):
+    """:171-188 with SynthesisBlock3D :112-168 (add_noise False, enable_blur False)."""
+
+    def __init__(self, ch, ch_out, device="cuda:0", seed=1, store=None, prefix=""):
+        self.ch = self.w_ch = ch
+        self.ch_out = ch_out
+        self.prefix = prefix
+        if store is None:
+            store = ParamStore(voxel_specs(prefix, ch, ch_out), device, seed)
+            self.stores = (("", store),)
+        self.store = store
+        self.p = _Prefixed(store.params, prefix)
+        self.chans = voxel_channels(ch)
+        self.c0, self.c1 = [None], []
+        for i, (co, ci) in enumerate(self.chans):
+            if i > 0:
+                self.c0.append(self._conv3d_layer(f"net/{i}/c0/c/W", ci))
+            self.c1.append(self._conv3d_layer(f"net/{i}/c1/c/W", co))
+        W = self.p["out/c/W"]
+        self.out = Fn.DerivedConvLayer(
+            lambda: _pad_to(_pad_to(W.reshape(W.shape[0], W.shape[1], 1, 1), _ceil64(W.shape[1]), 1), _ceil64(W.shape[0]), 0),
+            _inv_c(W.shape[1]), 1, 0)
+
+    def _conv3d_layer(self, name, cin):
+        """(Cout,Cin,3,3,3) -> (Cout64, 3*Cin64, 3, 3) with input channel index kd*Cin64 + ci.
+        pggan.py:31: inv_c = sqrt(2) * sqrt(1 / (in_ch * ksize**2)) -- ksize squared, also in 3-D."""
+        W = self.p[name]
+
+        def derive():
+            w = _pad_to(_pad_to(W, _ceil64(W.shape[1]), 1), _ceil64(W.shape[0]), 0)       # (Co,Ci,kd,kh,kw)
+            return w.permute(0, 2, 1, 3, 4).reshape(w.shape[0], 3 * w.shape[1], 3, 3)
+        return Fn.DerivedConvLayer(derive, _inv_c(cin * 9), 3, 1)
+
+    @staticmethod
+    def _conv3d(x, layer, bias, upsample):
+        """x (B,D,H,W,C) -> lrelu(conv3d(up(x)) + bias) as one 2-D conv over (B*D) depth slices."""
+        if upsample:
+            x = x.repeat_interleave(2, dim=1)
+        B, D, H, W, C = x.shape
+        xp = F.pad(x, (0, 0, 0, 0, 0, 0, 1, 1))
+        x3 = torch.cat([xp[:, 0:D], xp[:, 1:D + 1], xp[:, 2:D + 2]], dim=-1).reshape(B * D, H, W, 3 * C)
+        y = Fn.conv_bias_lrelu(x3, layer, bias, upsample=upsample)
+        return y.reshape(B, D, y.shape[1], y.shape[2], y.shape[3])
+
+    def _block(self, i, w, x):
+        p = self.p
+        pre = f"net/{i}"
+        co, ci = self.chans[i]
+        C = _ceil64(co)
+        if i == 0:
+            const = p[pre + "/W"].permute(1, 2, 3, 0).unsqueeze(0)                       # (1,4,4,4,ci)
+            h = _pad_to(Fn.lrelu(const + p[pre + "/b0/b"]), C).to(BF16)
+            h = h.expand(w.shape[0], 4, 4, 4, C).contiguous()
+        else:
+            h = self._conv3d(x, self.c0[i], _pad_to(p[pre + "/b0/b"], C), True)
+        h = self._style(pre + "/s0", w, h)
+        h = self._conv3d(h, self.c1[i], _pad_to(p[pre + "/b1/b"], C), False)
+        return self._style(pre + "/s1", w, h)
+
+    def __call__(self, w):
+        h = None
+        for i in range(4):
+            h = self._block(i, w, h)
+        B, D, H, W, C = h.shape
+        y = Fn.conv_bias(h.reshape(B * D, H, W, C), self.out, _pad_to(self.p["out/c/b"], _ceil64(self.ch_out)))
+        y = y.reshape(B, D, H, W, -1)[..., :self.ch_out]
+        return y.permute(0, 4, 1, 2, 3).float().contiguous()                            # b x ch_out x 32 x 32 x 32
+
+    forward = __call__
+
+
+class _Prefixed:
+    """View of a parameter dict under a name prefix."""
+
+    def __init__(self, params, prefix):
+        self.params, self.prefix = params, prefix
+
+    def __getitem__(self, name):
+        return self.params[self.prefix + name]
+
+
+def renderer_specs(prefix, w_ch, in_ch, hidden):
+    h = hidden
+    specs = []
+    convs = {"c0": (2 * h, in_ch, 4), "c1": (4 * h, 2 * h, 4), "c4": (4 * h, 4 * h, 3), "c5": (2 * h, 4 * h, 3),
+             "c6": (h, 4 * h, 3), "c7": (3, h + in_ch, 3)}
+    for name, (co, ci, k) in convs.items():
+        specs += [(f"{prefix}{name}/c/W", (co, ci, k, k), "normal"), (f"{prefix}{name}/c/b", (co,), "zeros")]
+    for name, co in {"s0": 2 * h, "s1": 4 * h, "s4": 4 * h, "s5": 2 * h, "s6": h}.items():
+        pre = f"{prefix}{name}"
+        specs += [(pre + "/s/c/W", (co, w_ch), "normal"), (pre + "/s/c/b", (co,), "ones"),
+                  (pre + "/b/c/W", (co, w_ch), "normal"), (pre + "/b/c/b", (co,), "zeros")]
+    return specs
+
+
+class StyleGenerator(_Link, _StyleMixin):
+    """The 2-D rendering network (:191-222): 64x64x32 features -> 64x64 RGB, U-shaped with two skip concatenations."""
+
+    def __init__(self, w_ch, in_ch, hidden_ch=256, device="cuda:0", seed=2, store=None, prefix=""):
+        self.w_ch, self.in_ch, self.hidden = w_ch, in_ch, hidden_ch
+        if store is None:
+            store = ParamStore(renderer_specs(prefix, w_ch, in_ch, hidden_ch), device, seed)
+            self.stores = (("", store),)
+        self.store = store
+        self.p = p = _Prefixed(store.params, prefix)
+        self.layers = {}
+        for name in ("c0", "c1"):                       # 4x4 stride 2 pad 1 -> 1x1 over 16 folded taps
+            W = p[name + "/c/W"]
+            self.layers[name] = Fn.DerivedConvLayer(
+                lambda W=W: W.permute(0, 2, 3, 1).reshape(W.shape[0], 16 * W.shape[1], 1, 1), _inv_c(W.shape[1] * 16), 1, 0)
+        for name in ("c4", "c5", "c6"):
+            W = p[name + "/c/W"]
+            self.layers[name] = Fn.ConvLayer(W, _inv_c(W.shape[1] * 9), 1)
+        W7 = p["c7/c/W"]
+        self.layers["c7"] = Fn.DerivedConvLayer(
+            lambda: _pad_to(_pad_to(W7, _ceil64(W7.shape[1]), 1), 64, 0), _inv_c(W7.shape[1] * 9, 0.5), 3, 1)
+
+    @staticmethod
+    def _fold4x4s2(x):
+        """(B,H,W,C) -> (B,H/2,W/2,16C): channel index (ky*4 + kx)*C + c holds x_pad[2i+ky, 2j+kx, c]."""
+        B, H, W, C = x.shape
+        xp = F.pad(x, (0, 0, 1, 1, 1, 1))
+        cols = [xp[:, ky:ky + H:2, kx:kx + W:2] for ky in range(4) for kx in range(4)]
+        return torch.cat(cols, dim=-1)
+
+    def __call__(self, h, w, stage=None):
+        p = self.p
+        L = self.layers
+        x = h.permute(0, 2, 3, 1).to(BF16).contiguous()                                     # (B,64,64,32)
+        h1 = self._style("s0", w, Fn.conv_bias_lrelu(self._fold4x4s2(x), L["c0"], p["c0/c/b"]))
+        h2 = self._style("s1", w, Fn.conv_bias_lrelu(self._fold4x4s2(h1), L["c1"], p["c1/c/b"]))
+        h3 = self._style("s4", w, Fn.conv_bias_lrelu(h2, L["c4"], p["c4/c/b"]))
+        h3 = Fn.conv_bias_lrelu(h3, L["c5"], p["c5/c/b"], upsample=True)
+        h3 = torch.cat([self._style("s5", w, h3), h1], dim=-1)
+        h3 = Fn.conv_bias_lrelu(h3, L["c6"], p["c6/c/b"], upsample=True)
+        h3 = torch.cat([self._style("s6", w, h3), x], dim=-1)
+        h3 = _pad_to(h3, _ceil64(h3.shape[-1]))
+        out = Fn.conv_bias(h3, L["c7"], _pad_to(p["c7/c/b"], 64))
+        return out[..., :3].permute(0, 3, 1, 2).float().contiguous()
+
+    forward = __call__
+
+
+class DeepVoxels:
+    """deepvoxel/deepvoxel.py:797-909 restricted to occlusion_type == "accumulative": frustum resampling of the feature
+    grid for every camera, visibility weights from the two 1x1x1 convs, compositing along each ray, depth rescale."""
+
+    def __init__(self, params, prefix, frustrum_img_dims, grid_dims, voxel_size, near_plane, threshold=None):
+        self.p = _Prefixed(params, prefix + "occlusion_net/occlusion/")
+        self.frustrum_img_dims = frustrum_img_dims
+        self.frustrum_depth = int(np.ceil(np.sqrt(3) * grid_dims[-1]))
+        self.voxel_size, self.near_plane = voxel_size, near_plane
+        self.threshold = threshold if threshold else 4           # deepvoxel.py:555
+
+    def __call__(self, idx, coords, counts, deepvoxels):
+        vol = interpolate_trilinear_batch(deepvoxels, idx, coords, counts, self.frustrum_img_dims, self.frustrum_depth)
+        p = self.p
+        W1, W2 = p["0/net/1/c/W"], p["2/net/1/c/W"]
+        feats, depth, _ = accumulative_occlusion(vol, W1.reshape(W1.shape[0], W1.shape[1]), p["0/net/1/c/b"],
+                                                 W2.reshape(1, -1), p["2/net/1/c/b"], float(self.threshold),
+                                                 float(self.voxel_size), float(self.near_plane))
+        return feats, depth
+
+
+class Generator(_Link):
+    """deepvoxels_generator.py:225-323."""
+
+    def __init__(self, ch, occlusion_type="deepvoxels", background_generator=False, config=None, device="cuda:0",
+                 seed=0):
+        assert occlusion_type == "accumulative", \
+            "only occlusion_type 'accumulative' (configs/deepvoxels_shapenet_car.yml) is built on the HIP kernels"
+        assert not background_generator, "background_generator is not supported"
+        assert ch % 256 == 0
+        self.ch = ch
+        self.device = torch.device(device)
+        self.use_background_generator = False
+        scale = 0.5
+        grid_dim = 32
+        near_plane = np.sqrt(3) / 4
+        lift_intrinsic = np.array([[64 * 2., 0.0, 32., 0.0], [0.0, 64 * 2., 32., 0.0], [0.0, 0.0, 1.0, 0.0],
+                                   [0.0, 0.0, 0.0, 1.0]])
+        voxel_size = (1. / grid_dim) * 1.1 * scale
+        depth_max = grid_dim * voxel_size + near_plane
+        grid_dims = 3 * [grid_dim]
+        proj_image_dims = [64, 64]
+        frustrum_depth = int(np.ceil(np.sqrt(3) * grid_dims[-1]))
+        self.projection = ProjectionHelper(projection_intrinsic=lift_intrinsic, lifting_intrinsic=lift_intrinsic,
+                                           depth_min=0., depth_max=depth_max, projection_image_dims=proj_image_dims,
+                                           lifting_image_dims=proj_image_dims, grid_dims=grid_dims,
+                                           voxel_size=voxel_size, device=device, frustrum_depth=frustrum_depth,
+                                           near_plane=near_plane)
+        occ = "deepvoxel/occlusion_net/occlusion"
+        specs = voxel_specs("voxel_gen/", ch, GRID_FEATS)
+        specs += [(occ + "/0/net/1/c/W", (OCC_NF, GRID_FEATS + 1, 1, 1, 1), "normal"),
+                  (occ + "/0/net/1/c/b", (OCC_NF,), "zeros"),
+                  (occ + "/2/net/1/c/W", (1, OCC_NF, 1, 1, 1), "normal"), (occ + "/2/net/1/c/b", (1,), "zeros")]
+        specs += renderer_specs("style_generator/", ch, GRID_FEATS, 256)
+        for i, (co, ci) in zip((0, 2, 4), ((64, 8), (64, 64), (9, 64))):     # CameraParamGenerator (net.py:795-804): unused
+            specs += [(f"camera_param_generator/net/{i}/c/W", (co, ci), "normal"),
+                      (f"camera_param_generator/net/{i}/c/b", (co,), "zeros")]
+        self.store = ParamStore(specs, device, seed + 1)
+        self.stores = (("", self.store),)
+        self.voxel_gen = VoxelGenerator(ch, GRID_FEATS, device, store=self.store, prefix="voxel_gen/")
+        threshold = getattr(config, "accumulative_threshold", None) if config is not None else None
+        self.deepvoxel = DeepVoxels(self.store.params, "deepvoxel/", proj_image_dims, grid_dims, voxel_size, near_plane,
+                                    threshold)
+        self.style_generator = StyleGenerator(ch, GRID_FEATS, 256, device, store=self.store, prefix="style_generator/")
+        self.mapping = MappingNetwork3D(ch, device, seed)        # not a registered child in the reference (:271)
+        self.train = True
+
+    def make_hidden(self, batch_size):
+        """:273-283."""
+        z = torch.randn(batch_size, self.ch, 1, 1, device=self.device)
+        return z / torch.sqrt(torch.sum(z * z, dim=1, keepdim=True) / self.ch + 1e-8)
+
+    def __call__(self, z, stage, camera_matrices, z2=None, z3=None, z4=None, theta=None):
+        idx, coords, counts = self.projection.compute_proj_idcs_batch(camera_matrices)
+        z = _as_device_tensor(z, self.device)
+        w = self.mapping(z)
+        voxel = self.voxel_gen(w)
+        novel_feats, depth = self.deepvoxel(idx, coords, counts, voxel)
+        if z2 is None:
+            z2 = self.make_hidden(z.shape[0])
+        w2 = self.mapping(_as_device_tensor(z2, self.device))
+        novel_img = self.style_generator(novel_feats, w2, stage)
+        return torch.cat([novel_img, depth], dim=1)
+
+    forward = __call__

@@ -62,11 +62,30 @@ class ConvLayer:
         return self._wf, self._wd
 
 
+class DerivedConvLayer(ConvLayer):
+    """A convolution whose kernel-side weight is a differentiable rearrangement of a reference-shaped master
+    parameter: zero padding of channels up to the 64-channel granularity of the MFMA kernels, the depth taps of a
+    3x3x3 kernel folded into input channels, the 4x4 stride-2 taps folded into input channels (deepvoxels path).
+    `derive()` returns the (Cout',Cin',K,K) fp32 tensor attached to the master, so weight gradients flow back through
+    ordinary autograd instead of the direct flat-buffer accumulation."""
+
+    def __init__(self, derive, inv_c, K, pad):
+        self.derive = derive
+        self.inv_c = float(inv_c)
+        self.K, self.pad = K, pad
+        self._epoch = -1
+        self._wf = self._wd = None
+
+    @property
+    def weight(self):
+        return self.derive()
+
+
 def _direct_grad(p):
     """During a plain backward (no graph being built) weight / bias gradients are accumulated straight into the
     flat gradient buffer by the kernels (wgrad's accumulate mode, the fused bias-gradient atomics) instead of
     materialising a tensor for autograd's AccumulateGrad to add -- one tiny kernel per parameter saved."""
-    return (not torch.is_grad_enabled()) and p.grad is not None and p.grad.is_contiguous()
+    return (not torch.is_grad_enabled()) and p.is_leaf and p.grad is not None and p.grad.is_contiguous()
 
 
 def _wgrad_into(x, dy, w, layer, ups):

@@ -24,7 +24,17 @@ def setup_generator(config, device):
         return DCGANGenerator(config.ch, enable_blur=config.enable_blur, rgbd=rgbd, use_encoder=config.bigan,
                               use_occupancy_net=config.use_occupancy_net_loss, initial_depth=config.initial_depth,
                               device=device)
-    raise AssertionError(f"{arch} is not supported by the MI355X engine yet")
+    if arch == "deepvoxels":
+        from .deepvoxels_generator import Generator
+        if config.rendernet_projection:
+            occlusion_type = "rendernet"
+        elif config.occlusion_type:
+            occlusion_type = config.occlusion_type
+        else:
+            occlusion_type = "deepvoxels"
+        return Generator(config.ch, occlusion_type=occlusion_type, background_generator=config.background_generator,
+                         config=config, device=device)
+    raise AssertionError(f"{arch} is not supported")
 
 
 def setup_discriminator(config, device):
@@ -45,6 +55,10 @@ def make_optimizers(config, generator, discriminator, comm=None):
             for n in ("l1/c/W", "l2/c/W", "l1/c/b", "l2/c/b"):
                 opt["gen"].set_alpha(n, config.adam_alpha_g / 100)
         return opt
+    if config.generator_architecture == "deepvoxels":
+        return {"map": FlatAdam(generator.mapping.store, config.adam_alpha_g / 100, b1, b2, comm=comm),
+                "gen": FlatAdam(generator.store, config.adam_alpha_g, b1, b2, comm=comm),
+                "dis": FlatAdam(discriminator.store, config.adam_alpha_d, b1, b2, comm=comm)}
     return {"gen": FlatAdam(generator.store, config.adam_alpha_g, b1, b2, comm=comm),
             "dis": FlatAdam(discriminator.store, config.adam_alpha_d, b1, b2, comm=comm)}
 
@@ -100,8 +114,14 @@ def build_training(config, device, comm=None, iterator=None, **updater_kwargs):
     generator = setup_generator(config, device)
     discriminator = setup_discriminator(config, device)
     optimizer = make_optimizers(config, generator, discriminator, comm)
-    updater = RGBDUpdater(models=[generator, discriminator], config=config, optimizer=optimizer, iterator=iterator,
-                          lambda_gp=config.lambda_gp, smoothing=config.smoothing,
-                          total_gpu=comm.size if comm is not None else 1, prior=CameraParamPrior(config),
-                          **updater_kwargs)
+    if config.generator_architecture == "deepvoxels":             # train_rgbd.py:355-356
+        from .updater_deepvoxels import DeepVoxelsUpdater as Updater
+        for k in ("use_graphs", "graph_warmup", "graph_phases", "fixed_stage"):
+            updater_kwargs.pop(k, None)
+    else:
+        Updater = RGBDUpdater
+    updater = Updater(models=[generator, discriminator], config=config, optimizer=optimizer, iterator=iterator,
+                      lambda_gp=config.lambda_gp, smoothing=config.smoothing,
+                      total_gpu=comm.size if comm is not None else 1, prior=CameraParamPrior(config),
+                      **updater_kwargs)
     return generator, discriminator, optimizer, updater

@@ -1,0 +1,167 @@
+"""DeepVoxels generator / updater on the HIP kernels against the fp32 CPU oracle
+(oracle/deepvoxels_nets.py, oracle/step.py:deepvoxels_step): same weights, same latents, same cameras.
+
+Tolerances as in test_model_gpu.py: bf16 activations / conv operands with fp32 accumulation against an fp32 oracle;
+tensors by relative L2 error, gradients by cosine similarity.  The frustum resampling and compositing stay fp32.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import camera, deepvoxels_nets as dvn, nets, step
+
+pytestmark = pytest.mark.gpu
+
+CH = 256
+
+
+def rel_err(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def cosine(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+def _generator(seed=0):
+    from rgbd_gan_amd.deepvoxels_generator import Generator
+    from rgbd_gan_amd.utils.yaml_utils import Config
+    gp = dvn.init_deepvoxels_generator(CH, seed=seed + 1)
+    mp = dvn.init_mapping3d(CH, seed=seed)
+    gen = Generator(CH, occlusion_type="accumulative", config=Config({}))
+    gen.load_state_dict(gp)
+    gen.mapping.load_state_dict(mp)
+    return gp, mp, gen
+
+
+def _inputs(B, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    zh, zh2 = torch.randn(B // 2, CH, generator=g), torch.randn(B // 2, CH, generator=g)
+    z, z2 = torch.cat([zh, zh]), torch.cat([zh2, zh2])
+    np.random.seed(seed + 1)
+    thetas = camera.PosePrior(0.3054, 3.1415, 0, uniform=True).sample(B)
+    return z, z2, thetas
+
+
+def test_parameter_names_and_shapes_match_oracle():
+    gp, mp, gen = _generator()
+    assert set(gen.state_dict().keys()) == set(gp.keys())
+    assert set(gen.mapping.state_dict().keys()) == set(mp.keys())
+    for k, v in gen.state_dict().items():
+        assert tuple(v.shape) == tuple(gp[k].shape), k
+
+
+def test_voxel_generator_matches_oracle():
+    gp, mp, gen = _generator()
+    z, _, _ = _inputs(2)
+    with torch.no_grad():
+        w_ref = dvn.mapping3d(mp, z)
+        ref = dvn.voxel_generator(gp, w_ref)
+        w = gen.mapping(z.cuda())
+        got = gen.voxel_gen(w).cpu()
+    assert rel_err(w.cpu(), w_ref) < 1e-4
+    assert got.shape == ref.shape == (2, 32, 32, 32, 32)
+    assert rel_err(got, ref) < 4e-2, rel_err(got, ref)
+
+
+def test_renderer_matches_oracle():
+    gp, mp, gen = _generator()
+    g = torch.Generator().manual_seed(4)
+    feats = torch.randn(2, 32, 64, 64, generator=g)
+    w = torch.randn(2, CH, generator=g)
+    with torch.no_grad():
+        ref = dvn.renderer(gp, feats, w)
+        got = gen.style_generator(feats.cuda(), w.cuda(), 8.5).cpu()
+    assert got.shape == ref.shape == (2, 3, 64, 64)
+    assert rel_err(got, ref) < 4e-2, rel_err(got, ref)
+
+
+def test_generator_forward_and_gradients_match_oracle():
+    gp, mp, gen = _generator()
+    z, z2, thetas = _inputs(2)
+    cams = camera.camera_matrices(thetas)
+    gpl = {k: v.clone().requires_grad_(True) for k, v in gp.items()}
+    mpl = {k: v.clone().requires_grad_(True) for k, v in mp.items()}
+    ref = dvn.deepvoxels_generator(gpl, mpl, z, z2, cams)
+    g = torch.Generator().manual_seed(9)
+    probe = torch.randn(ref.shape, generator=g)
+    (ref * probe).sum().backward()
+
+    gen.cleargrads()
+    gen.mapping.cleargrads()
+    got = gen(z, 8.5, cams, z2=z2)
+    (got * probe.cuda()).sum().backward()
+    assert got.shape == ref.shape == (2, 4, 64, 64)
+    assert rel_err(got[:, :3].detach().cpu(), ref[:, :3].detach()) < 5e-2
+    assert rel_err(got[:, 3].detach().cpu(), ref[:, 3].detach()) < 2e-2
+    for name in ("style_generator/c7/c/W", "style_generator/c6/c/W", "style_generator/c4/c/W", "style_generator/c1/c/W",
+                 "style_generator/c0/c/W", "style_generator/s5/s/c/W", "style_generator/c0/c/b",
+                 "deepvoxel/occlusion_net/occlusion/0/net/1/c/W", "voxel_gen/out/c/W", "voxel_gen/net/3/c1/c/W",
+                 "voxel_gen/net/2/c0/c/W", "voxel_gen/net/1/c0/c/W", "voxel_gen/net/0/c1/c/W", "voxel_gen/net/0/W",
+                 "voxel_gen/net/2/s0/b/c/W"):
+        a, b = gen.store[name].grad.cpu(), gpl[name].grad
+        assert cosine(a, b) > 0.9, (name, cosine(a, b))
+        assert 0.8 < float(a.norm() / b.norm()) < 1.25, (name, float(a.norm() / b.norm()))
+    # a bias in front of (leaky ReLU ->) AdaIN is nearly cancelled by the mean subtraction: its gradient is a small
+    # difference of large sums and correspondingly noisy in bf16
+    a, b = gen.store["voxel_gen/net/3/b1/b"].grad.cpu(), gpl["voxel_gen/net/3/b1/b"].grad
+    assert cosine(a, b) > 0.6, cosine(a, b)
+    for name in ("l/14/c/W", "l/0/c/W"):
+        a, b = gen.mapping.store[name].grad.cpu(), mpl[name].grad
+        assert cosine(a, b) > 0.9, (name, cosine(a, b))
+    # parameters the forward never touches keep a zero gradient (noise scales, the unused first-block conv, the
+    # camera-parameter MLP): chainer zero-fills them before the update
+    for name in ("voxel_gen/net/1/n0/b/W", "voxel_gen/net/0/c0/c/W", "camera_param_generator/net/0/c/W"):
+        assert float(gen.store[name].grad.abs().max()) == 0.0
+
+
+CFG = dict(lambda_gp=1.0, lambda_depth=10, depth_min=0.6, focal_loss_gamma=2.0, start_rotation=0, lambda_geometric=None)
+
+
+def test_deepvoxels_training_step_matches_oracle():
+    from rgbd_gan_amd.net import Discriminator
+    from rgbd_gan_amd.optimizer import FlatAdam
+    from rgbd_gan_amd.updater import CameraParamPrior
+    from rgbd_gan_amd.updater_deepvoxels import DeepVoxelsUpdater
+    from rgbd_gan_amd.utils.yaml_utils import Config
+    gp, mp, gen = _generator(seed=3)
+    dp = nets.init_discriminator(CH, seed=8)
+    dis = Discriminator(CH, res=True)
+    dis.load_state_dict(dp)
+    B = 4
+    z, z2, thetas = _inputs(B, seed=5)
+    g = torch.Generator().manual_seed(6)
+    zd, zd2 = torch.randn(B, CH, generator=g), torch.randn(B, CH, generator=g)
+    x_real = (np.random.RandomState(7).randint(0, 256, (B, 3, 128, 128)).astype("float32") / 127.5 - 1)
+    iteration = 10
+
+    gpl = {k: v.clone().requires_grad_(True) for k, v in gp.items()}
+    mpl = {k: v.clone().requires_grad_(True) for k, v in mp.items()}
+    dpl = {k: v.clone().requires_grad_(True) for k, v in dp.items()}
+    oopt = {"map": step.ChainerAdam(mpl, 1e-5), "gen": step.ChainerAdam(gpl, 1e-3), "dis": step.ChainerAdam(dpl, 3e-3)}
+    ref = step.deepvoxels_step(gpl, mpl, dpl, oopt, x_real, (z, z2, zd, zd2), thetas, CFG, iteration)
+
+    cfg = Config(dict(generator_architecture="deepvoxels", stage_interval="0,0,0,0,0,0,0,0", max_stage=11,
+                      start_rotation=0, start_occlusion_aware=0, lambda_depth=10, depth_min=0.6, focal_loss_gamma=2.0,
+                      x_rotate=0.3054, y_rotate=3.1415, z_rotate=0, x_translate=0, y_translate=0, z_translate=0,
+                      uniform_distribution=True, bigan=False))
+    opt = {"map": FlatAdam(gen.mapping.store, 1e-5), "gen": FlatAdam(gen.store, 1e-3), "dis": FlatAdam(dis.store, 3e-3)}
+    upd = DeepVoxelsUpdater(models=[gen, dis], config=cfg, optimizer=opt, iterator=None, lambda_gp=1.0, smoothing=0.999,
+                            total_gpu=1, prior=CameraParamPrior(cfg))
+    upd.iteration = iteration
+    upd.update_core(batch=torch.from_numpy(x_real), z_fake=(z, z2, zd, zd2), thetas=thetas)
+    obs = {k: float(v) for k, v in upd.observation.items()}
+    assert obs["stage"] == 8.5 and obs["image_size"] == 64
+    for key in ("gen/loss_adv", "gen/loss_rotate", "dis/loss_gp", "dis/loss_adv"):
+        assert abs(obs[key] - ref[key]) < 6e-2 * max(1.0, abs(ref[key])), (key, obs[key], ref[key])
+    for k, o in (("norm_map", opt["map"]), ("norm_gen", opt["gen"]), ("norm_dis", opt["dis"])):
+        assert abs(float(o.grad_norm) - ref[k]) < 0.1 * ref[k], (k, float(o.grad_norm), ref[k])
+    # the generator moved: every live weight by about alpha (beta1 = 0, first update)
+    w0, w1 = gp["style_generator/c6/c/W"], gen.store["style_generator/c6/c/W"].detach().cpu()
+    wr = gpl["style_generator/c6/c/W"].detach()
+    assert 0 < float((w1 - w0).abs().max()) <= 1e-3 * 1.001
+    agree = float(((w1 - w0).sign() == (wr - w0).sign()).float().mean())
+    assert agree > 0.85, agree
+    assert opt["map"].t == opt["gen"].t == opt["dis"].t == 1
