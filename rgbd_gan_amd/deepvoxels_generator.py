@@ -51,6 +51,31 @@ def _ceil64(n):
     return (n + 63) // 64 * 64
 
 
+def fold_conv3d_weight(W):
+    """(Cout,Cin,3,3,3) -> (Cout64, 3*Cin64, 3, 3): input channel kd*Cin64 + ci carries depth tap kd."""
+    w = _pad_to(_pad_to(W, _ceil64(W.shape[1]), 1), _ceil64(W.shape[0]), 0)
+    return w.permute(0, 2, 1, 3, 4).reshape(w.shape[0], 3 * w.shape[1], 3, 3)
+
+
+def fold_depth_taps(x):
+    """(B,D,H,W,C) -> (B*D,H,W,3C): every depth slice next to its two zero-padded neighbours."""
+    B, D, H, W, C = x.shape
+    xp = F.pad(x, (0, 0, 0, 0, 0, 0, 1, 1))
+    return torch.cat([xp[:, 0:D], xp[:, 1:D + 1], xp[:, 2:D + 2]], dim=-1).reshape(B * D, H, W, 3 * C)
+
+
+def fold_4x4s2_weight(W):
+    """(Cout,Cin,4,4) -> (Cout,16*Cin,1,1): input channel (ky*4 + kx)*Cin + ci."""
+    return W.permute(0, 2, 3, 1).reshape(W.shape[0], 16 * W.shape[1], 1, 1)
+
+
+def fold_4x4s2(x):
+    """(B,H,W,C) -> (B,H/2,W/2,16C): channel (ky*4 + kx)*C + c holds x_pad[2i+ky, 2j+kx, c] (pad 1)."""
+    B, H, W, C = x.shape
+    xp = F.pad(x, (0, 0, 1, 1, 1, 1))
+    return torch.cat([xp[:, ky:ky + H:2, kx:kx + W:2] for ky in range(4) for kx in range(4)], dim=-1)
+
+
 class MappingNetwork3D(_Link):
     """deepvoxels_generator.py:28-68.  Owned by Generator but NOT one of its registered children (:271), so it has
     its own optimizer ('map', train_rgbd.py:337) and its own snapshot file."""
@@ -140,21 +165,15 @@ class VoxelGenerator(_Link, _StyleMixin):
         """(Cout,Cin,3,3,3) -> (Cout64, 3*Cin64, 3, 3) with input channel index kd*Cin64 + ci.
         pggan.py:31: inv_c = sqrt(2) * sqrt(1 / (in_ch * ksize**2)) -- ksize squared, also in 3-D."""
         W = self.p[name]
-
-        def derive():
-            w = _pad_to(_pad_to(W, _ceil64(W.shape[1]), 1), _ceil64(W.shape[0]), 0)       # (Co,Ci,kd,kh,kw)
-            return w.permute(0, 2, 1, 3, 4).reshape(w.shape[0], 3 * w.shape[1], 3, 3)
-        return Fn.DerivedConvLayer(derive, _inv_c(cin * 9), 3, 1)
+        return Fn.DerivedConvLayer(lambda: fold_conv3d_weight(W), _inv_c(cin * 9), 3, 1)
 
     @staticmethod
     def _conv3d(x, layer, bias, upsample):
         """x (B,D,H,W,C) -> lrelu(conv3d(up(x)) + bias) as one 2-D conv over (B*D) depth slices."""
         if upsample:
             x = x.repeat_interleave(2, dim=1)
-        B, D, H, W, C = x.shape
-        xp = F.pad(x, (0, 0, 0, 0, 0, 0, 1, 1))
-        x3 = torch.cat([xp[:, 0:D], xp[:, 1:D + 1], xp[:, 2:D + 2]], dim=-1).reshape(B * D, H, W, 3 * C)
-        y = Fn.conv_bias_lrelu(x3, layer, bias, upsample=upsample)
+        B, D = x.shape[:2]
+        y = Fn.conv_bias_lrelu(fold_depth_taps(x), layer, bias, upsample=upsample)
         return y.reshape(B, D, y.shape[1], y.shape[2], y.shape[3])
 
     def _block(self, i, w, x):
@@ -221,8 +240,7 @@ class StyleGenerator(_Link, _StyleMixin):
         self.layers = {}
         for name in ("c0", "c1"):                       # 4x4 stride 2 pad 1 -> 1x1 over 16 folded taps
             W = p[name + "/c/W"]
-            self.layers[name] = Fn.DerivedConvLayer(
-                lambda W=W: W.permute(0, 2, 3, 1).reshape(W.shape[0], 16 * W.shape[1], 1, 1), _inv_c(W.shape[1] * 16), 1, 0)
+            self.layers[name] = Fn.DerivedConvLayer(lambda W=W: fold_4x4s2_weight(W), _inv_c(W.shape[1] * 16), 1, 0)
         for name in ("c4", "c5", "c6"):
             W = p[name + "/c/W"]
             self.layers[name] = Fn.ConvLayer(W, _inv_c(W.shape[1] * 9), 1)
@@ -230,20 +248,12 @@ class StyleGenerator(_Link, _StyleMixin):
         self.layers["c7"] = Fn.DerivedConvLayer(
             lambda: _pad_to(_pad_to(W7, _ceil64(W7.shape[1]), 1), 64, 0), _inv_c(W7.shape[1] * 9, 0.5), 3, 1)
 
-    @staticmethod
-    def _fold4x4s2(x):
-        """(B,H,W,C) -> (B,H/2,W/2,16C): channel index (ky*4 + kx)*C + c holds x_pad[2i+ky, 2j+kx, c]."""
-        B, H, W, C = x.shape
-        xp = F.pad(x, (0, 0, 1, 1, 1, 1))
-        cols = [xp[:, ky:ky + H:2, kx:kx + W:2] for ky in range(4) for kx in range(4)]
-        return torch.cat(cols, dim=-1)
-
     def __call__(self, h, w, stage=None):
         p = self.p
         L = self.layers
         x = h.permute(0, 2, 3, 1).to(BF16).contiguous()                                     # (B,64,64,32)
-        h1 = self._style("s0", w, Fn.conv_bias_lrelu(self._fold4x4s2(x), L["c0"], p["c0/c/b"]))
-        h2 = self._style("s1", w, Fn.conv_bias_lrelu(self._fold4x4s2(h1), L["c1"], p["c1/c/b"]))
+        h1 = self._style("s0", w, Fn.conv_bias_lrelu(fold_4x4s2(x), L["c0"], p["c0/c/b"]))
+        h2 = self._style("s1", w, Fn.conv_bias_lrelu(fold_4x4s2(h1), L["c1"], p["c1/c/b"]))
         h3 = self._style("s4", w, Fn.conv_bias_lrelu(h2, L["c4"], p["c4/c/b"]))
         h3 = Fn.conv_bias_lrelu(h3, L["c5"], p["c5/c/b"], upsample=True)
         h3 = torch.cat([self._style("s5", w, h3), h1], dim=-1)

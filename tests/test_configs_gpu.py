@@ -88,3 +88,35 @@ def test_train_rgbd_cli_end_to_end(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     assert "Resume from 6" in r.stdout
     assert json.load(open(out / "log"))[-1]["iteration"] == 8
+
+
+def test_train_rgbd_cli_deepvoxels_config(tmp_path):
+    """configs/deepvoxels_shapenet_car.yml (BASELINE config 4) through train_rgbd.py: DeepVoxelsUpdater at the fixed
+    stage 8.5 (64x64), batch 10, generator / discriminator / mapping snapshots, resume."""
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "deepvoxels_shapenet_car.yml")))
+    data = tmp_path / "data"
+    out = tmp_path / "out"
+    data.mkdir()
+    np.save(data / "images.npy", np.random.RandomState(0).randint(0, 256, (30, 3, 128, 128)).astype("uint8"))
+    cfg.update(dataset_path=str(data), out=str(out), iteration=4, snapshot_interval=2, display_interval=2)
+    path = tmp_path / "cfg.yml"
+    yaml.safe_dump(cfg, open(path, "w"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train_rgbd.py"), "--config_path", str(path)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    files = set(os.listdir(out))
+    assert {"Generator_2.npz", "Discriminator_2.npz", "Map_2.npz", "snapshot_iter_4.npz", "Map_latest.npz", "log"} <= files
+    log = json.load(open(out / "log"))
+    assert log[-1]["iteration"] == 4 and log[-1]["image_size"] == 64 and log[-1]["stage"] == 8.5
+    assert log[-1]["batch_size"] == 10
+    assert all(np.isfinite(log[-1][k]) for k in ("gen/loss_adv", "gen/loss_rotate", "dis/loss_adv", "dis/loss_gp"))
+    g = np.load(out / "Generator_latest.npz")
+    assert g["voxel_gen/net/2/c0/c/W"].shape == (32, 64, 3, 3, 3) and g["style_generator/c1/c/W"].shape == (1024, 512, 4, 4)
+    assert np.load(out / "Map_latest.npz")["l/14/c/W"].shape == (256, 256)
+    cfg.update(iteration=5, get_model_from_interation="4")
+    yaml.safe_dump(cfg, open(path, "w"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train_rgbd.py"), "--config", str(path)],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Resume from 4" in r.stdout
