@@ -183,6 +183,24 @@ int rgbd_occlusion_accum_bwd(const float* vol, const float* W1, const float* b1,
                              const float* w, const float* dfeat, const float* ddepth, float voxel_size, float* dw_ws,
                              float* ds_ws, float* dvol, float* dparams, int B, int F, int D, int HW, void* stream);
 
+/* ------------------------------------------------------------------ small fused pointwise ops
+ * rgbd_conv2d_dgrad_bf16: input gradient of a stride-1 convolution, dx (B,H+2*(K-1-pad)-K+1,...,Cin) from
+ *   dy (B,H,W,Cout) and the dgrad image of rgbd_pack_weights ([K*K][Cin][Cout], taps flipped): the same
+ *   implicit-GEMM kernels as fprop (chainer's Convolution2DFunction backward, pggan.py:13-24).
+ * rgbd_pixelnorm_{fwd,bwd}: pggan.py:7-10 (feature_vector_normalization) on (M,C) fp32 rows:
+ *   y = x * rsqrt(mean_c x^2 + eps);  dx = r * (dy - y * mean_c(dy * y)).
+ * rgbd_depth_head_{fwd,bwd}: net.py:296 on (B,4,HW) fp32 planes: channels 0-2 pass through,
+ *   y3 = 1 / (softplus(x3) + 1e-4);  dx3 = -dy3 * y3^2 * sigmoid(x3).
+ * rgbd_ema_update: copy_param.py:17-40 (soft_copy_param) over a flat parameter buffer: dst = (1-tau) dst + tau src.
+ */
+int rgbd_conv2d_dgrad_bf16(const void* dy, const void* wp_dgrad, void* dx, int B, int H, int W, int Cin, int Cout, int K,
+                           int pad, void* stream);
+int rgbd_pixelnorm_fwd(const float* x, float* y, int M, int C, float eps, void* stream);
+int rgbd_pixelnorm_bwd(const float* x, const float* dy, float* dx, int M, int C, float eps, void* stream);
+int rgbd_depth_head_fwd(const float* x, float* y, int B, int HW, void* stream);
+int rgbd_depth_head_bwd(const float* x, const float* y, const float* dy, float* dx, int B, int HW, void* stream);
+int rgbd_ema_update(float* dst, const float* src, int64_t n, float tau, void* stream);
+
 /* ------------------------------------------------------------------ optimizer
  * Replaces chainer.optimizers.Adam + GradientClipping(5) (train_rgbd.py:151-161), one launch group per
  * optimizer instead of one elementwise kernel per parameter tensor.

@@ -819,6 +819,14 @@ WgradPlan plan_wgrad(int B, int H, int W, int Cin, int Cout) {
 }
 }  // namespace
 
+extern "C" int rgbd_conv2d_dgrad_bf16(const void* dy, const void* wp_dgrad, void* dx, int B, int H, int W, int Cin,
+                                      int Cout, int K, int pad, void* stream) {
+    RGBD_REQUIRE(K >= 1 && pad >= 0 && pad <= K - 1, "rgbd_conv2d_dgrad_bf16: need 0 <= pad <= K-1 (K=%d pad=%d)", K, pad);
+    // dx = correlation of dy with the flipped, transposed kernel at padding K-1-pad
+    return rgbd_conv2d_fprop_bf16(dy, wp_dgrad, nullptr, nullptr, dx, B, H, W, Cout, Cin, K, K, K - 1 - pad, 0, 0, 0.2f,
+                                  stream);
+}
+
 static int wgrad_groups(int nsplit) { return nsplit >= 64 ? 16 : (nsplit >= 8 ? 4 : 1); }
 
 extern "C" int64_t rgbd_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int K) {

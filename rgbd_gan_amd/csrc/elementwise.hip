@@ -885,6 +885,103 @@ extern "C" int rgbd_linear_bwd(const float* dy, const float* y, const float* x, 
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------- small pointwise ops
+namespace {
+__global__ __launch_bounds__(256) void pixelnorm_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        float* __restrict__ out, int C, float eps) {
+    // one block per row; dy == nullptr: forward
+    __shared__ float red[2][4];
+    const float* xr = x + (long)blockIdx.x * C;
+    float sq = 0.f, dot = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float v = xr[c];
+        sq += v * v;
+        if (dy) dot += v * dy[(long)blockIdx.x * C + c];
+    }
+    sq = wave_sum(sq);
+    dot = wave_sum(dot);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sq; red[1][threadIdx.x >> 6] = dot; }
+    __syncthreads();
+    sq = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    dot = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const float r = 1.0f / sqrtf(sq / (float)C + eps);
+    const float k = dy ? r * dot / (float)C : 0.f;           // mean(dy * y)
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const long i = (long)blockIdx.x * C + c;
+        out[i] = dy ? r * (dy[i] - xr[c] * r * k) : xr[c] * r;
+    }
+}
+
+__global__ __launch_bounds__(256) void depth_head_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                         const float* __restrict__ dy, float* __restrict__ out,
+                                                         long HW, long total) {
+    // total = B*4*HW; dy == nullptr: forward
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ch = (int)((i / HW) & 3);
+        if (ch != 3) {
+            out[i] = dy ? dy[i] : x[i];
+        } else if (!dy) {
+            const float v = x[i];
+            const float sp = fmaxf(v, 0.f) + log1pf(expf(-fabsf(v)));
+            out[i] = 1.0f / (sp + 1e-4f);
+        } else {
+            const float v = x[i], yy = y[i];
+            const float sg = 1.0f / (1.0f + expf(-v));
+            out[i] = -dy[i] * yy * yy * sg;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ dst, const float* __restrict__ src, long n,
+                                                  float tau) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float d = dst[i];
+        d *= (1.0f - tau);                 // copy_param.py:30-31: two statements, two roundings
+        d += tau * src[i];
+        dst[i] = d;
+    }
+}
+}  // namespace
+
+extern "C" int rgbd_pixelnorm_fwd(const float* x, float* y, int M, int C, float eps, void* stream) {
+    RGBD_REQUIRE(x && y && M > 0 && C > 0, "rgbd_pixelnorm_fwd: bad arguments");
+    pixelnorm_kernel<<<M, 256, 0, (hipStream_t)stream>>>(x, nullptr, y, C, eps);
+    RGBD_CHECK_LAUNCH("pixelnorm_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_pixelnorm_bwd(const float* x, const float* dy, float* dx, int M, int C, float eps, void* stream) {
+    RGBD_REQUIRE(x && dy && dx && M > 0 && C > 0, "rgbd_pixelnorm_bwd: bad arguments");
+    pixelnorm_kernel<<<M, 256, 0, (hipStream_t)stream>>>(x, dy, dx, C, eps);
+    RGBD_CHECK_LAUNCH("pixelnorm_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_depth_head_fwd(const float* x, float* y, int B, int HW, void* stream) {
+    RGBD_REQUIRE(x && y && B > 0 && HW > 0, "rgbd_depth_head_fwd: bad arguments");
+    const long total = (long)B * 4 * HW;
+    depth_head_kernel<<<(int)min((long)2048, (total + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, nullptr, nullptr, y,
+                                                                                                 HW, total);
+    RGBD_CHECK_LAUNCH("depth_head_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_depth_head_bwd(const float* x, const float* y, const float* dy, float* dx, int B, int HW,
+                                   void* stream) {
+    RGBD_REQUIRE(x && y && dy && dx && B > 0 && HW > 0, "rgbd_depth_head_bwd: bad arguments");
+    const long total = (long)B * 4 * HW;
+    depth_head_kernel<<<(int)min((long)2048, (total + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, y, dy, dx, HW, total);
+    RGBD_CHECK_LAUNCH("depth_head_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_ema_update(float* dst, const float* src, int64_t n, float tau, void* stream) {
+    RGBD_REQUIRE(dst && src && n > 0, "rgbd_ema_update: bad arguments");
+    ema_kernel<<<(int)min((long)2048, (long)((n + 255) / 256)), 256, 0, (hipStream_t)stream>>>(dst, src, n, tau);
+    RGBD_CHECK_LAUNCH("ema_kernel");
+    return 0;
+}
+
 extern "C" int rgbd_adam_clip_multi(float* p, float* g, float* m, float* v, int64_t n, int nseg,
                                     const int64_t* seg_begin, const float* seg_alpha, float beta1, float beta2,
                                     float eps, float clip, float grad_scale, int32_t* step, float* workspace,

@@ -95,8 +95,7 @@ class MappingNetwork3D(_Link):
         return torch.randn(batch_size, self.ch, 1, 1, 1, device=self.device)
 
     def __call__(self, x):
-        h = _as_device_tensor(x, self.device).reshape(x.shape[0], -1)
-        h = h * torch.rsqrt(torch.mean(h * h, dim=1, keepdim=True) + 1e-8)
+        h = Fn.pixel_norm(_as_device_tensor(x, self.device).reshape(x.shape[0], -1))
         p = self.store.params
         for i in range(0, 16, 2):
             h = Fn.linear_act(h, p[f"l/{i}/c/W"], p[f"l/{i}/c/b"], self.inv_c, act=True)

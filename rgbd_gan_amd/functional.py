@@ -133,7 +133,7 @@ class _ConvDgrad(torch.autograd.Function):
         ctx.layer, ctx.ups = layer, ups
         ctx.save_for_backward(dy, w)
         _, wd = layer.packed()
-        dx = kernels.conv2d_fprop(dy.contiguous(), wd, layer.K, layer.K, layer.K - 1 - layer.pad)
+        dx = kernels.conv2d_dgrad(dy.contiguous(), wd, layer.K, layer.pad)
         return _sum_pool2(dx) if ups else dx
 
     @staticmethod
@@ -441,3 +441,42 @@ class _LinearAct(torch.autograd.Function):
 def linear_act(x, w, bias, c, act=True):
     """Equalized-LR linear (pggan.py:39-50) + optional leaky ReLU on a small batch of rows, one HIP launch."""
     return _LinearAct.apply(x, w, bias, float(c), bool(act))
+
+
+class _PixelNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return kernels.pixelnorm(x)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        return kernels.pixelnorm(x, dy.contiguous())
+
+
+def pixel_norm(x):
+    """pggan.py:7-10 (feature_vector_normalization) on (M,C) fp32 rows."""
+    return _PixelNorm.apply(x)
+
+
+class _DepthHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        y = kernels.depth_head_fwd(x)
+        ctx.save_for_backward(x, y)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        return kernels.depth_head_bwd(x, y, dy.contiguous())
+
+
+def depth_head(x):
+    """net.py:296: (B,4,H,W) fp32 planes -> RGB unchanged, depth = 1 / (softplus(x3) + 1e-4)."""
+    return _DepthHead.apply(x)

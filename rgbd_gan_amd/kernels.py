@@ -138,6 +138,27 @@ def conv2d_fprop(x, wp, KH, KW, pad, bias=None, residual=None, upsample=False, l
     return y
 
 
+def conv2d_dgrad(dy, wd, K, pad):
+    """dy (B,H,W,Cout) bf16, wd [K*K][Cin][Cout] bf16 (dgrad image of pack_weights) -> dx (B,H',W',Cin) bf16."""
+    _chk(dy, BF16, "dy"); _chk(wd, BF16, "wd")
+    B, H, W, Cout = dy.shape
+    T, Cin, Cout2 = wd.shape
+    if T != K * K or Cout2 != Cout:
+        raise RuntimeError(f"conv2d_dgrad: weights {tuple(wd.shape)} do not match dy {tuple(dy.shape)} K={K}")
+    pd = K - 1 - pad
+    Ho, Wo = H + 2 * pd - K + 1, W + 2 * pd - K + 1
+    dx = torch.empty(B, Ho, Wo, Cin, dtype=BF16, device=dy.device)
+    lib = _lib.load()
+    flops = 2.0 * B * Ho * Wo * Cout * Cin * K * K
+    nbytes = 2.0 * (dy.numel() + dx.numel() + wd.numel())
+    patch = K == 3 and pd == 1 and Ho % 16 == 0 and Wo % 16 == 0
+    kname = ("conv3x3_patch_kernel" if patch else "conv_fprop_kernel") + f"<{128 if Cin % 128 == 0 else 64}>"
+    rc = _timed(kname, flops, nbytes,
+                lambda: lib.rgbd_conv2d_dgrad_bf16(_ptr(dy), _ptr(wd), _ptr(dx), B, H, W, Cin, Cout, K, pad, _stream()))
+    _lib.check(rc, "rgbd_conv2d_dgrad_bf16")
+    return dx
+
+
 def conv2d_wgrad(x, dy, K, scale, out=None, accumulate=False):
     """x (B,H,W,Cin) bf16, dy (B,H,W,Cout) bf16 -> dW (Cout,Cin,K,K) fp32 = scale * sum dy (x) x."""
     _chk(x, BF16, "x"); _chk(dy, BF16, "dy")
@@ -295,6 +316,49 @@ def adain_bwd(x, dy, scale, mean, rstd):
                                     _ptr(dshift), _ptr(sums), B, H * W, C, _stream())
     _lib.check(rc, "rgbd_adain_bwd")
     return dx, dscale, dshift
+
+
+# ------------------------------------------------------------------ small pointwise ops
+def pixelnorm(x, dy=None, eps=1e-8):
+    """x (M,C) fp32 -> x * rsqrt(mean_c x^2 + eps); with dy: the input gradient instead."""
+    _chk(x, F32, "x"); _chk(dy, F32, "dy")
+    M, C = x.shape
+    out = torch.empty_like(x)
+    lib = _lib.load()
+    if dy is None:
+        rc = lib.rgbd_pixelnorm_fwd(_ptr(x), _ptr(out), M, C, float(eps), _stream())
+    else:
+        rc = lib.rgbd_pixelnorm_bwd(_ptr(x), _ptr(dy), _ptr(out), M, C, float(eps), _stream())
+    _lib.check(rc, "rgbd_pixelnorm")
+    return out
+
+
+def depth_head_fwd(x):
+    """x (B,4,H,W) fp32 -> [x0, x1, x2, 1 / (softplus(x3) + 1e-4)]."""
+    _chk(x, F32, "x")
+    B, C, H, W = x.shape
+    if C != 4:
+        raise RuntimeError(f"depth_head_fwd: expected 4 planes, got {C}")
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().rgbd_depth_head_fwd(_ptr(x), _ptr(y), B, H * W, _stream()), "rgbd_depth_head_fwd")
+    return y
+
+
+def depth_head_bwd(x, y, dy):
+    _chk(x, F32, "x"); _chk(y, F32, "y"); _chk(dy, F32, "dy")
+    B, _, H, W = x.shape
+    dx = torch.empty_like(x)
+    _lib.check(_lib.load().rgbd_depth_head_bwd(_ptr(x), _ptr(y), _ptr(dy), _ptr(dx), B, H * W, _stream()),
+               "rgbd_depth_head_bwd")
+    return dx
+
+
+def ema_update(dst, src, tau):
+    """dst = (1 - tau) * dst + tau * src over flat fp32 buffers (soft_copy_param)."""
+    _chk(dst, F32, "dst"); _chk(src, F32, "src")
+    if dst.numel() != src.numel():
+        raise RuntimeError("ema_update: size mismatch")
+    _lib.check(_lib.load().rgbd_ema_update(_ptr(dst), _ptr(src), dst.numel(), float(tau), _stream()), "rgbd_ema_update")
 
 
 # ------------------------------------------------------------------ optimizer

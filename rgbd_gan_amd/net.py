@@ -104,8 +104,7 @@ class MappingNetwork(_Link):
         self.inv_c = _inv_c(ch)
 
     def __call__(self, z):
-        h = z.reshape(z.shape[0], -1)
-        h = h * torch.rsqrt(torch.mean(h * h, dim=1, keepdim=True) + 1e-8)
+        h = Fn.pixel_norm(z.reshape(z.shape[0], -1))
         p = self.store.params
         for i in range(0, 16, 2):
             h = Fn.linear_act(h, p[f"l/{i}/c/W"], p[f"l/{i}/c/b"], self.inv_c, act=True)
@@ -214,8 +213,7 @@ class StyleGenerator(_Link):
             hi = self._to_rgbd(k + 1, self._block(k + 1, w, h))      # net.py:290: un-rotated w
             out = (1.0 - alpha) * lo + alpha * hi
         if self.rgbd:
-            depth = 1.0 / (F.softplus(out[:, 3:]) + 1e-4)            # net.py:296
-            out = torch.cat([out[:, :3], depth], dim=1)
+            out = Fn.depth_head(out)                                  # net.py:296
         out = out.contiguous()
         if return_feature:
             return out, (feat.permute(0, 3, 1, 2).float() if feat is not None else None)
@@ -330,7 +328,7 @@ class DCGANGenerator(_Link):
             hi = self._to_rgbd(k, self._block(k, h))
             out = (1.0 - alpha) * lo + alpha * hi
         if self.rgbd:
-            out = torch.cat([out[:, :3], 1.0 / (F.softplus(out[:, 3:]) + 1e-4)], dim=1)
+            out = Fn.depth_head(out)
         return out.contiguous()
 
     forward = __call__

@@ -10,7 +10,7 @@ from .optimizer import FlatAdam
 from .updater import CameraParamPrior, RGBDUpdater
 
 
-def setup_generator(config, device):
+def setup_generator(config, device, seed=0):
     """train_rgbd.py:220-246."""
     rgbd = False if config.rgb else True
     arch = config.generator_architecture
@@ -18,12 +18,12 @@ def setup_generator(config, device):
         return StyleGANGenerator(config.ch, enable_blur=config.enable_blur, rgbd=rgbd,
                                  rotate_conv_input=config.rotate_conv_input, use_encoder=config.bigan,
                                  use_occupancy_net=config.use_occupancy_net_loss, initial_depth=config.initial_depth,
-                                 device=device)
+                                 device=device, seed=seed)
     if arch == "dcgan":
         # NB the reference passes config.ch as in_ch and leaves ch at its default 512 (train_rgbd.py:230)
         return DCGANGenerator(config.ch, enable_blur=config.enable_blur, rgbd=rgbd, use_encoder=config.bigan,
                               use_occupancy_net=config.use_occupancy_net_loss, initial_depth=config.initial_depth,
-                              device=device)
+                              device=device, seed=seed)
     if arch == "deepvoxels":
         from .deepvoxels_generator import Generator
         if config.rendernet_projection:
@@ -33,7 +33,7 @@ def setup_generator(config, device):
         else:
             occlusion_type = "deepvoxels"
         return Generator(config.ch, occlusion_type=occlusion_type, background_generator=config.background_generator,
-                         config=config, device=device)
+                         config=config, device=device, seed=seed)
     raise AssertionError(f"{arch} is not supported")
 
 
@@ -114,13 +114,16 @@ def build_training(config, device, comm=None, iterator=None, **updater_kwargs):
     generator = setup_generator(config, device)
     discriminator = setup_discriminator(config, device)
     optimizer = make_optimizers(config, generator, discriminator, comm)
+    models = [generator, discriminator]
+    if config.keep_smoothed_gen and (comm is None or comm.rank == 0):       # train_rgbd.py:124-125,288-295
+        models.append(setup_generator(config, device, seed=1000))    # its own random init, like the reference
     if config.generator_architecture == "deepvoxels":             # train_rgbd.py:355-356
         from .updater_deepvoxels import DeepVoxelsUpdater as Updater
         for k in ("use_graphs", "graph_warmup", "graph_phases", "fixed_stage"):
             updater_kwargs.pop(k, None)
     else:
         Updater = RGBDUpdater
-    updater = Updater(models=[generator, discriminator], config=config, optimizer=optimizer, iterator=iterator,
+    updater = Updater(models=models, config=config, optimizer=optimizer, iterator=iterator,
                       lambda_gp=config.lambda_gp, smoothing=config.smoothing,
                       total_gpu=comm.size if comm is not None else 1, prior=CameraParamPrior(config),
                       **updater_kwargs)

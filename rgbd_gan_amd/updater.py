@@ -20,6 +20,7 @@ import torch
 import torch.nn.functional as F
 
 from . import functional as Fn
+from .common.utils.copy_param import soft_copy_param
 from .common.loss_functions import LossFuncRotate, loss_func_dcgan_dis, loss_func_dcgan_gen, loss_l2
 
 
@@ -132,8 +133,6 @@ class RGBDUpdater:
         if config.bigan:
             raise AssertionError("bigan is not supported")
         self.gen, self.dis, self.smoothed_gen = models
-        if self.smoothed_gen is not None:
-            raise AssertionError("keep_smoothed_gen is not supported yet")
         self.config = config
         self.smoothing = kwargs.pop("smoothing")
         self.lambda_gp = kwargs.pop("lambda_gp")
@@ -272,6 +271,8 @@ class RGBDUpdater:
         for name in ("map", "gen", "dis"):
             if name in self._optimizers:
                 self._optimizers[name].update()
+        if self.smoothed_gen is not None:          # updater.py:397-400 (after the generator update; D never touches G)
+            soft_copy_param(self.smoothed_gen, self.gen, 1.0 - self.smoothing)
 
     def _distributed(self):
         opt = self._optimizers["gen"]

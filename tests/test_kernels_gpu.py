@@ -345,3 +345,74 @@ def test_small_linear_forward_backward(M, K, N, act):
     torch.testing.assert_close(xd.grad.cpu(), x.grad, atol=1e-4, rtol=1e-4)
     torch.testing.assert_close(wd.grad.cpu(), w.grad, atol=1e-4, rtol=1e-4)
     torch.testing.assert_close(bd.grad.cpu(), b.grad, atol=1e-4, rtol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ small pointwise ops
+@pytest.mark.parametrize("M,C", [(32, 256), (5, 512), (1, 265)])
+def test_pixelnorm_forward_backward(M, C):
+    from rgbd_gan_amd import functional as Fn
+    g = torch.Generator().manual_seed(M + C)
+    x = torch.randn(M, C, generator=g)
+    dy = torch.randn(M, C, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ref = nets.pixel_norm(xr)
+    ref.backward(dy)
+    xd = x.to(dev()).requires_grad_(True)
+    got = Fn.pixel_norm(xd)
+    got.backward(dy.to(dev()))
+    torch.testing.assert_close(got.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-5)
+
+
+def test_depth_head_forward_backward():
+    from rgbd_gan_amd import functional as Fn
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 4, 16, 16, generator=g) * 4
+    x[0, 3, 0, :4] = torch.tensor([-30.0, 30.0, 0.0, -90.0])            # softplus tails
+    dy = torch.randn(3, 4, 16, 16, generator=g)
+    xr = x.clone().requires_grad_(True)
+    ref = nets.depth_head(xr)
+    ref.backward(dy)
+    xd = x.to(dev()).requires_grad_(True)
+    got = Fn.depth_head(xd)
+    got.backward(dy.to(dev()))
+    torch.testing.assert_close(got.detach().cpu(), ref.detach(), rtol=2e-6, atol=1e-6)
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-4)
+    assert torch.equal(got[:, :3].detach().cpu(), x[:, :3])
+
+
+def test_ema_update_matches_two_statement_form():
+    from rgbd_gan_amd import kernels
+    g = torch.Generator().manual_seed(1)
+    dst, src = torch.randn(100003, generator=g), torch.randn(100003, generator=g)
+    tau = 1.0 - 0.999
+    ref = dst.clone()
+    ref *= (1 - tau)                      # copy_param.py:30-31
+    ref += tau * src
+    d = dst.to(dev())
+    kernels.ema_update(d, src.to(dev()), tau)
+    torch.testing.assert_close(d.cpu(), ref, rtol=1e-6, atol=1e-7)
+
+
+def test_smoothed_generator_tracks_updates():
+    """keep_smoothed_gen (updater.py:397-400): after each step smoothed = 0.999 smoothed + 0.001 gen."""
+    from rgbd_gan_amd.training import DeviceImageIterator, build_training
+    from rgbd_gan_amd.utils.yaml_utils import Config
+    cfg = dict(generator_architecture="stylegan", ch=256, stage_interval="0,0,0,0,0,0,0,100000,150000,160000,180000,300000",
+               max_stage=11, start_rotation=2000, start_occlusion_aware=2000, lambda_depth=10, depth_min=1.0,
+               x_rotate=0.3054, y_rotate=1.0472, z_rotate=0, x_translate=0, y_translate=0, z_translate=0, bigan=False,
+               adam_alpha_g=0.001, adam_alpha_d=0.003, adam_beta1=0.0, adam_beta2=0.999, lambda_gp=1.0, smoothing=0.999,
+               res_dis=True, sn=False, enable_blur=False, keep_smoothed_gen=True)
+    images = np.random.RandomState(0).randint(0, 256, (8, 3, 128, 128)).astype("uint8")
+    it = DeviceImageIterator(images, 4, "cuda:0", seed=3)
+    gen, dis, opt, upd = build_training(Config(cfg), "cuda:0", iterator=it, fixed_stage=6.0, use_graphs=False,
+                                        nan_check_interval=0)
+    sm = upd.smoothed_gen
+    assert sm is not None and not torch.equal(sm.gen.store.flat, gen.gen.store.flat)
+    s0 = sm.gen.store.flat.clone()
+    upd.update()
+    expect = s0 * (1 - 0.001) + 0.001 * gen.gen.store.flat
+    torch.testing.assert_close(sm.gen.store.flat, expect, rtol=1e-5, atol=1e-6)
+    m0 = sm.mapping.store.flat.clone()
+    upd.update()
+    torch.testing.assert_close(sm.mapping.store.flat, m0 * (1 - 0.001) + 0.001 * gen.mapping.store.flat, rtol=1e-5, atol=1e-6)

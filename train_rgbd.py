@@ -53,6 +53,8 @@ def main():
         config, device, comm if comm is not None and comm.size > 1 else None, iterator=iterator,
         nan_check_interval=config.display_interval or 100)
     models = [("Generator", generator), ("Discriminator", discriminator)]
+    if updater.smoothed_gen is not None:                               # train_rgbd.py:293-295
+        models.append(("SmoothedGenerator", updater.smoothed_gen))
     if config.generator_architecture == "deepvoxels":                  # train_rgbd.py:374-377,456-459
         models.append(("Map", generator.mapping))
 
