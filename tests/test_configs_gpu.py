@@ -67,7 +67,8 @@ def test_train_rgbd_cli_end_to_end(tmp_path):
     out = tmp_path / "out"
     data.mkdir()
     np.save(data / "images.npy", np.random.RandomState(0).randint(0, 256, (24, 3, 128, 128)).astype("uint8"))
-    cfg.update(dataset_path=str(data), out=str(out), iteration=6, batchsize=4, snapshot_interval=3, display_interval=2)
+    cfg.update(dataset_path=str(data), out=str(out), iteration=6, batchsize=4, snapshot_interval=3, display_interval=2,
+               evaluation_sample_interval=3)
     path = tmp_path / "cfg.yml"
     yaml.safe_dump(cfg, open(path, "w"))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "train_rgbd.py"), "-g", "0", "--config_path", str(path)],
@@ -78,6 +79,10 @@ def test_train_rgbd_cli_end_to_end(tmp_path):
             "Discriminator_latest.npz", "log"} <= files
     log = json.load(open(out / "log"))
     assert log[-1]["iteration"] == 6 and log[-1]["image_size"] == 32 and abs(log[-1]["stage"] - 6.0) < 1e-3
+    # preview tiles (train_rgbd.py:83-90): 8 x 8 samples, RGB rows interleaved with depth rows, eval-mode upsample to 64
+    from PIL import Image
+    assert {"image_latest.png", "image00000000.png"} <= set(os.listdir(out / "preview"))
+    assert Image.open(out / "preview" / "image_latest.png").size == (8 * 64, 16 * 64)
     g = np.load(out / "Generator_latest.npz")
     assert "mapping/l/0/c/W" in g.files and "gen/blocks/5/c1/c/W" in g.files and g["gen/outs/5/c/W"].shape == (4, 64, 1, 1)
     # resume from iteration 6 up to 8
@@ -99,7 +104,8 @@ def test_train_rgbd_cli_deepvoxels_config(tmp_path):
     out = tmp_path / "out"
     data.mkdir()
     np.save(data / "images.npy", np.random.RandomState(0).randint(0, 256, (30, 3, 128, 128)).astype("uint8"))
-    cfg.update(dataset_path=str(data), out=str(out), iteration=4, snapshot_interval=2, display_interval=2)
+    cfg.update(dataset_path=str(data), out=str(out), iteration=4, snapshot_interval=2, display_interval=2,
+               evaluation_sample_interval=4)
     path = tmp_path / "cfg.yml"
     yaml.safe_dump(cfg, open(path, "w"))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "train_rgbd.py"), "--config_path", str(path)],
@@ -114,6 +120,8 @@ def test_train_rgbd_cli_deepvoxels_config(tmp_path):
     g = np.load(out / "Generator_latest.npz")
     assert g["voxel_gen/net/2/c0/c/W"].shape == (32, 64, 3, 3, 3) and g["style_generator/c1/c/W"].shape == (1024, 512, 4, 4)
     assert np.load(out / "Map_latest.npz")["l/14/c/W"].shape == (256, 256)
+    from PIL import Image
+    assert Image.open(out / "preview" / "image_latest.png").size == (8 * 64, 16 * 64)
     cfg.update(iteration=5, get_model_from_interation="4")
     yaml.safe_dump(cfg, open(path, "w"))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "train_rgbd.py"), "--config", str(path)],

@@ -85,3 +85,24 @@ def test_adam_segments_follow_alpha_overrides():
     opt.set_alpha("l1/c/b", 1e-5)
     begins, alphas = opt._segments()
     assert begins == [0, 8, 20, 28] and alphas == [1e-3, 1e-5, 1e-3]
+
+
+def test_convert_batch_images_layout():
+    """save_images.py:9-24: sample (r, c) at row-block 2r (RGB) and 2r+1 (depth as clip(128/d)), column-block c."""
+    from rgbd_gan_amd.common.utils.save_images import convert_batch_images
+    rows, cols, H = 2, 3, 4
+    x = np.zeros((rows * cols, 4, H, H), dtype="float32")
+    for i in range(rows * cols):
+        x[i, :3] = i / 10.0 - 0.2
+        x[i, 3] = 1.0 + i
+    img = convert_batch_images(x, rows, cols)
+    assert img.shape == (2 * rows * H, cols * H, 3) and img.dtype == np.uint8
+    for r in range(rows):
+        for c in range(cols):
+            i = r * cols + c
+            rgb = img[(2 * r) * H:(2 * r + 1) * H, c * H:(c + 1) * H]
+            dep = img[(2 * r + 1) * H:(2 * r + 2) * H, c * H:(c + 1) * H]
+            assert (rgb == np.uint8(np.clip((i / 10.0 - 0.2) * 127.5 + 127.5, 0, 255))).all()
+            assert (dep == np.uint8(np.clip(128.0 / (1.0 + i), 0, 255))).all()
+    rgb_only = convert_batch_images(x[:, :3], rows, cols)
+    assert rgb_only.shape == (rows * H, cols * H, 3)

@@ -83,6 +83,13 @@ def main():
         for k, o in optimizer.items():
             o.load_state_dict({"t": snap[f"{k}/t"], "m": snap[f"{k}/m"], "v": snap[f"{k}/v"]})
 
+    previews = []
+    if is_master and config.evaluation_sample_interval:                # train_rgbd.py:386-396
+        from rgbd_gan_amd.common.utils.save_images import PreviewSampler
+        previews.append(PreviewSampler(generator, out, config, rows=8, cols=8))
+        if updater.smoothed_gen is not None:
+            previews.append(PreviewSampler(updater.smoothed_gen, out, config, rows=8, cols=8, subdir="preview_smoothed"))
+
     log, t0 = [], time.time()
     while updater.iteration < config.iteration:
         updater.update()
@@ -94,6 +101,9 @@ def main():
             print(json.dumps(entry))
             with open(f"{out}/log", "w") as f:
                 json.dump(log, f, indent=1)
+        if previews and it % config.evaluation_sample_interval == 0:
+            for pv in previews:
+                pv(updater.stage, it)
         if is_master and it % (config.snapshot_interval or 10000) == 0:
             for name, m in models:
                 save_npz(f"{out}/{name}_{it}.npz", m)
