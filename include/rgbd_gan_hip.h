@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RGBD_ABI_VERSION 1
+#define RGBD_ABI_VERSION 2
 
 int rgbd_abi_version(void);
 const char* rgbd_last_error(void);
@@ -81,11 +81,15 @@ int rgbd_pack_weights(const float* w, int cout, int cin, int kh, int kw, float s
  *         lrelu_channels (multiple of 16): output channels [0, lrelu_channels) then get leaky-ReLU(slope) (0 = none), i.e.
  *         y = lrelu(conv + bias + residual) as in net.py:413-416.
  *   y   : (B, Hout, Wout, Cout) bf16 NHWC.
+ *   workspace: rgbd_conv2d_fprop_workspace(...) bytes of device scratch, or NULL.  Layers with few output tiles and
+ *         a long reduction (the 4x4 .. 16x16 images) are split along K over several workgroups per tile; the fp32
+ *         partial sums go through this scratch and a second kernel applies the epilogue.  NULL = never split.
  * Requires Cin % 64 == 0 and Cout % 64 == 0.  dgrad = this function on dY with w_dgrad, pad' = KH-1-pad.
  */
+int64_t rgbd_conv2d_fprop_workspace(int B, int Hin, int Win, int Cin, int Cout, int KH, int KW, int pad, int upsample);
 int rgbd_conv2d_fprop_bf16(const void* x, const void* wp, const float* bias, const void* residual, void* y,
                            int B, int Hin, int Win, int Cin, int Cout, int KH, int KW, int pad,
-                           int upsample, int lrelu_channels, float slope, void* stream);
+                           int upsample, int lrelu_channels, float slope, void* workspace, void* stream);
 
 /* Test hook: when on != 0, rgbd_conv2d_fprop_bf16 uses the generic gather kernel for every shape (by default 3x3
  * pad-1 convolutions on images of 16x16 and larger run the halo-patch kernel). */
@@ -186,7 +190,8 @@ int rgbd_occlusion_accum_bwd(const float* vol, const float* W1, const float* b1,
 /* ------------------------------------------------------------------ small fused pointwise ops
  * rgbd_conv2d_dgrad_bf16: input gradient of a stride-1 convolution, dx (B,H+2*(K-1-pad)-K+1,...,Cin) from
  *   dy (B,H,W,Cout) and the dgrad image of rgbd_pack_weights ([K*K][Cin][Cout], taps flipped): the same
- *   implicit-GEMM kernels as fprop (chainer's Convolution2DFunction backward, pggan.py:13-24).
+ *   implicit-GEMM kernels as fprop (chainer's Convolution2DFunction backward, pggan.py:13-24); workspace =
+ *   rgbd_conv2d_fprop_workspace(B, H, W, Cout, Cin, K, K, K-1-pad, 0) bytes or NULL.
  * rgbd_pixelnorm_{fwd,bwd}: pggan.py:7-10 (feature_vector_normalization) on (M,C) fp32 rows:
  *   y = x * rsqrt(mean_c x^2 + eps);  dx = r * (dy - y * mean_c(dy * y)).
  * rgbd_depth_head_{fwd,bwd}: net.py:296 on (B,4,HW) fp32 planes: channels 0-2 pass through,
@@ -194,7 +199,7 @@ int rgbd_occlusion_accum_bwd(const float* vol, const float* W1, const float* b1,
  * rgbd_ema_update: copy_param.py:17-40 (soft_copy_param) over a flat parameter buffer: dst = (1-tau) dst + tau src.
  */
 int rgbd_conv2d_dgrad_bf16(const void* dy, const void* wp_dgrad, void* dx, int B, int H, int W, int Cin, int Cout, int K,
-                           int pad, void* stream);
+                           int pad, void* workspace, void* stream);
 int rgbd_pixelnorm_fwd(const float* x, float* y, int M, int C, float eps, void* stream);
 int rgbd_pixelnorm_bwd(const float* x, const float* dy, float* dx, int M, int C, float eps, void* stream);
 int rgbd_depth_head_fwd(const float* x, float* y, int B, int HW, void* stream);

@@ -9,7 +9,7 @@ from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librgbdgan_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _P = c_void_p
 
@@ -20,8 +20,9 @@ PROTOTYPES = {
     "rgbd_warp_loss_fwd": ([_P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P], c_int),
     "rgbd_warp_loss_bwd": ([_P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P], c_int),
     "rgbd_pack_weights": ([_P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P], c_int),
+    "rgbd_conv2d_fprop_workspace": ([c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int], c_int64),
     "rgbd_conv2d_fprop_bf16": ([_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                c_int, c_int, c_float, _P], c_int),
+                                c_int, c_int, c_float, _P, _P], c_int),
     "rgbd_debug_force_gather_kernel": ([c_int], c_int),
     "rgbd_conv2d_wgrad_workspace": ([c_int, c_int, c_int, c_int, c_int, c_int], c_int64),
     "rgbd_conv2d_wgrad_bf16": ([_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P], c_int),
@@ -44,7 +45,7 @@ PROTOTYPES = {
                                   c_int, _P], c_int),
     "rgbd_occlusion_accum_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, c_int, c_int, c_int, c_int,
                                   _P], c_int),
-    "rgbd_conv2d_dgrad_bf16": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P], c_int),
+    "rgbd_conv2d_dgrad_bf16": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P], c_int),
     "rgbd_pixelnorm_fwd": ([_P, _P, c_int, c_int, c_float, _P], c_int),
     "rgbd_pixelnorm_bwd": ([_P, _P, _P, c_int, c_int, c_float, _P], c_int),
     "rgbd_depth_head_fwd": ([_P, _P, c_int, c_int, _P], c_int),

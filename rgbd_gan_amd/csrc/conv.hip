@@ -18,6 +18,7 @@
 //   one slab per workgroup (two 128-byte row segments per wave instruction) and a second kernel sums the slabs.
 #include "common.h"
 
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -33,6 +34,8 @@ struct ConvArgs {
     long M;
     int x_bytes, w_bytes;
     int ptiles, wgs_per_ntile;      // patch kernel: pixel tiles per output-channel tile, persistent workgroups per N tile
+    int ksplit;                     // gather kernel: workgroups per output tile along K (1 = no split)
+    float* partial;                 // gather kernel, ksplit > 1: [ksplit][M][Cout] fp32 partial sums
 };
 
 __device__ __forceinline__ u32x4 ldg16(const unsigned short* p) { return *reinterpret_cast<const u32x4*>(p); }
@@ -59,6 +62,11 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(ConvArgs a) {
         const unsigned nwg = gridDim.x, xcd = bid & 7u, q8 = nwg >> 3, r8 = nwg & 7u;
         bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     }
+    // split-K: the tiny layers (4x4 .. 16x16 images) have a handful of output tiles and a long K loop; one
+    // workgroup would pull its whole ~1 MB operand panel through a single CU's L1.  ksplit workgroups share a tile,
+    // each walks a slice of the K steps and leaves fp32 partial sums for conv_splitk_finish_kernel.
+    const int sidx = (int)(bid % (unsigned)a.ksplit);
+    bid /= (unsigned)a.ksplit;
     const int nt = bid % n_tiles;
     const long mt = bid / n_tiles;
     const long m0 = mt * BM;
@@ -87,7 +95,9 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(ConvArgs a) {
         }
     }
     const int nkc = a.Cin >> 6;
-    const int nk = a.KH * a.KW * nkc;
+    const int nk_all = a.KH * a.KW * nkc;
+    const int kbeg = (int)((long)sidx * nk_all / a.ksplit);
+    const int nk = (int)((long)(sidx + 1) * nk_all / a.ksplit);     // this workgroup's K steps: [kbeg, nk)
 
     // Register prefetch, three rotating sets: tiles k+1, k+2, k+3 are in registers / in flight while tile k is
     // multiplied out of LDS (two LDS buffers, one barrier per K step).  The layers that use this kernel are the tiny
@@ -158,20 +168,34 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(ConvArgs a) {
         }
     };
 
-    load_tile(0, regP[0], regW[0]);
-    load_tile(1, regP[1], regW[1]);
-    load_tile(2, regP[2], regW[2]);
+    load_tile(kbeg + 0, regP[0], regW[0]);
+    load_tile(kbeg + 1, regP[1], regW[1]);
+    load_tile(kbeg + 2, regP[2], regW[2]);
     store_tile(0, regP[0], regW[0]);
     __syncthreads();
-    for (int kt = 0; kt < nk; kt += 3) {
+    for (int kt = 0; kt < nk - kbeg; kt += 3) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            const int k = kt + r;                                                // k >= nk: multiplies zero tiles
+            const int k = kt + r;                                                // kbeg + k >= nk: multiplies zero tiles
             compute(k & 1);
             store_tile((k + 1) & 1, regP[(r + 1) % 3], regW[(r + 1) % 3]);     // tile k+1, requested two steps ago
-            load_tile(k + 3, regP[r], regW[r]);                                  // set r (tile k) is in LDS already
+            load_tile(kbeg + k + 3, regP[r], regW[r]);                           // set r (tile k) is in LDS already
             __syncthreads();
         }
+    }
+
+    if (a.partial) {     // split-K: raw fp32 partial sums, epilogue in conv_splitk_finish_kernel
+        float* pp = a.partial + (long)sidx * a.M * a.Cout;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = n0 + wave_co + i * 16 + 4 * q;
+#pragma unroll
+            for (int j = 0; j < TPX; ++j) {
+                const long m = m0 + wave_px + j * 16 + r16;
+                if (m < a.M) *reinterpret_cast<f32x4*>(pp + m * a.Cout + co) = acc[i][j];
+            }
+        }
+        return;
     }
 
     // ---- epilogue: bias -> residual -> leaky ReLU (first lrelu_ch channels) -> bf16 NHWC
@@ -205,6 +229,31 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(ConvArgs a) {
                 *reinterpret_cast<u32x2*>(a.y + o) = out;
             }
         }
+    }
+}
+
+// Epilogue of the split-K path: sum the K-slice partials, then bias -> residual -> leaky ReLU -> bf16 NHWC.
+__global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const float* __restrict__ partial, int S, long M,
+                                                                 int Cout, const float* __restrict__ bias,
+                                                                 const unsigned short* __restrict__ resid, int lrelu_ch,
+                                                                 float slope, unsigned short* __restrict__ y) {
+    const long total = M * Cout;
+    for (long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4; e < total; e += (long)gridDim.x * 1024) {
+        const int co = (int)(e % Cout);
+        f32x4 v = *reinterpret_cast<const f32x4*>(partial + e);
+        for (int s2 = 1; s2 < S; ++s2) v += *reinterpret_cast<const f32x4*>(partial + (long)s2 * total + e);
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + co);
+        if (resid) {
+            const u32x2 rr = *reinterpret_cast<const u32x2*>(resid + e);
+            v[0] += bf16_lo(rr[0]); v[1] += bf16_hi(rr[0]);
+            v[2] += bf16_lo(rr[1]); v[3] += bf16_hi(rr[1]);
+        }
+        if (co < lrelu_ch) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : v[r] * slope;
+        }
+        u32x2 out = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        *reinterpret_cast<u32x2*>(y + e) = out;
     }
 }
 
@@ -710,9 +759,52 @@ extern "C" int rgbd_debug_force_gather_kernel(int on) {
     return 0;
 }
 
+namespace {
+// Split-K plan of the gather kernel: 1 (no split) when the unsplit launch already fills the chip.
+struct FpropPlan {
+    bool patch;      // 3x3 pad-1 halo-patch kernel
+    int ksplit;
+};
+FpropPlan plan_fprop(int B, int Hout, int Wout, int Cin, int Cout, int KH, int KW, int pad) {
+    FpropPlan p;
+    const long M = (long)B * Hout * Wout;
+    const int bn = Cout % 128 == 0 ? 128 : 64;
+    const long tiles = ((M + 127) / 128) * (Cout / bn);
+    const int nk = KH * KW * (Cin / 64);
+    const bool eligible = KH == 3 && KW == 3 && pad == 1 && Hout % 16 == 0 && Wout % 16 == 0 && !g_force_gather;
+    const long patch_wgs = (long)B * (Hout / 16) * (Wout / 16) * (Cout / bn);
+    // measured (scripts/time_small_conv.py, B=32, 256 channels): a workgroup's K loop is issue/latency bound at
+    // ~0.9 us per step whatever the tile count, so split until ~128 workgroups exist, at most 6 ways (beyond that
+    // the fp32 partial traffic costs more than the shorter loops save); 16x16 images stay on the halo-patch kernel
+    p.patch = eligible && patch_wgs >= 64;
+    p.ksplit = 1;
+    if (!p.patch && tiles < 128) {
+        long s = (128 + tiles - 1) / tiles;
+        if (s > 6) s = 6;
+        if (s > nk / 2) s = nk / 2;
+        if (s > 1) p.ksplit = (int)s;
+    }
+    if (const char* e = getenv("RGBD_DEBUG_KSPLIT")) {          // tuning aid: 0 = patch kernel where eligible, n = force n
+        const int v = atoi(e);
+        if (v == 0) { p.patch = eligible; p.ksplit = 1; }
+        else if (v > 0) { p.patch = false; p.ksplit = v > nk / 2 ? (nk / 2 > 0 ? nk / 2 : 1) : v; }
+    }
+    return p;
+}
+}  // namespace
+
+extern "C" int64_t rgbd_conv2d_fprop_workspace(int B, int Hin, int Win, int Cin, int Cout, int KH, int KW, int pad,
+                                               int upsample) {
+    if (B <= 0 || Hin <= 0 || Win <= 0 || Cin % 64 || Cout % 64 || KH <= 0 || KW <= 0 || pad < 0) return -1;
+    const int Hout = (upsample ? 2 * Hin : Hin) + 2 * pad - KH + 1, Wout = (upsample ? 2 * Win : Win) + 2 * pad - KW + 1;
+    if (Hout <= 0 || Wout <= 0) return -1;
+    const FpropPlan p = plan_fprop(B, Hout, Wout, Cin, Cout, KH, KW, pad);
+    return p.ksplit > 1 ? (int64_t)p.ksplit * B * Hout * Wout * Cout * (int64_t)sizeof(float) : 0;
+}
+
 extern "C" int rgbd_conv2d_fprop_bf16(const void* x, const void* wp, const float* bias, const void* residual,
                                       void* y, int B, int Hin, int Win, int Cin, int Cout, int KH, int KW, int pad,
-                                      int upsample, int lrelu_channels, float slope, void* stream) {
+                                      int upsample, int lrelu_channels, float slope, void* workspace, void* stream) {
     RGBD_REQUIRE(x && wp && y, "rgbd_conv2d_fprop_bf16: null pointer");
     RGBD_REQUIRE(B > 0 && Hin > 0 && Win > 0 && KH > 0 && KW > 0 && pad >= 0, "rgbd_conv2d_fprop_bf16: bad shape");
     RGBD_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0,
@@ -736,7 +828,14 @@ extern "C" int rgbd_conv2d_fprop_bf16(const void* x, const void* wp, const float
     a.M = (long)B * a.Hout * a.Wout;
     const long mtiles = (a.M + 127) / 128;
     hipStream_t st = (hipStream_t)stream;
-    if (KH == 3 && KW == 3 && pad == 1 && a.Hout % 16 == 0 && a.Wout % 16 == 0 && !g_force_gather) {
+    FpropPlan plan = plan_fprop(B, a.Hout, a.Wout, Cin, Cout, KH, KW, pad);
+    if (!workspace && plan.ksplit > 1) {       // no scratch from the caller: unsplit (the halo-patch kernel if it applies)
+        plan.ksplit = 1;
+        plan.patch = KH == 3 && KW == 3 && pad == 1 && a.Hout % 16 == 0 && a.Wout % 16 == 0 && !g_force_gather;
+    }
+    a.ksplit = plan.ksplit;
+    a.partial = plan.ksplit > 1 ? (float*)workspace : nullptr;
+    if (plan.patch) {
         const bool wide = Cout % 128 == 0;
         const int n_tiles = wide ? Cout / 128 : Cout / 64;
         const long ptiles = (long)B * (a.Hout / 16) * (a.Wout / 16);
@@ -780,15 +879,22 @@ extern "C" int rgbd_conv2d_fprop_bf16(const void* x, const void* wp, const float
         return 0;
     }
     if (Cout % 128 == 0) {
-        const long grid = mtiles * (Cout / 128);
+        const long grid = mtiles * (Cout / 128) * a.ksplit;
         RGBD_REQUIRE(grid < 0x7fffffffL, "rgbd_conv2d_fprop_bf16: grid too large");
         conv_fprop_kernel<128><<<(unsigned)grid, 256, 0, st>>>(a);
     } else {
-        const long grid = mtiles * (Cout / 64);
+        const long grid = mtiles * (Cout / 64) * a.ksplit;
         RGBD_REQUIRE(grid < 0x7fffffffL, "rgbd_conv2d_fprop_bf16: grid too large");
         conv_fprop_kernel<64><<<(unsigned)grid, 256, 0, st>>>(a);
     }
     RGBD_CHECK_LAUNCH("conv_fprop_kernel");
+    if (a.ksplit > 1) {
+        const long quads = a.M * Cout / 4;
+        conv_splitk_finish_kernel<<<(unsigned)((quads + 255) / 256 < 2048 ? (quads + 255) / 256 : 2048), 256, 0, st>>>(
+            a.partial, a.ksplit, a.M, Cout, bias, (const unsigned short*)residual, lrelu_channels, slope,
+            (unsigned short*)y);
+        RGBD_CHECK_LAUNCH("conv_splitk_finish_kernel");
+    }
     return 0;
 }
 
@@ -820,11 +926,11 @@ WgradPlan plan_wgrad(int B, int H, int W, int Cin, int Cout) {
 }  // namespace
 
 extern "C" int rgbd_conv2d_dgrad_bf16(const void* dy, const void* wp_dgrad, void* dx, int B, int H, int W, int Cin,
-                                      int Cout, int K, int pad, void* stream) {
+                                      int Cout, int K, int pad, void* workspace, void* stream) {
     RGBD_REQUIRE(K >= 1 && pad >= 0 && pad <= K - 1, "rgbd_conv2d_dgrad_bf16: need 0 <= pad <= K-1 (K=%d pad=%d)", K, pad);
     // dx = correlation of dy with the flipped, transposed kernel at padding K-1-pad
     return rgbd_conv2d_fprop_bf16(dy, wp_dgrad, nullptr, nullptr, dx, B, H, W, Cout, Cin, K, K, K - 1 - pad, 0, 0, 0.2f,
-                                  stream);
+                                  workspace, stream);
 }
 
 static int wgrad_groups(int nsplit) { return nsplit >= 64 ? 16 : (nsplit >= 8 ? 4 : 1); }

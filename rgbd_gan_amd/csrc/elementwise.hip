@@ -218,6 +218,8 @@ __global__ __launch_bounds__(256) void lrelu_bwd_colsum_kernel(const unsigned sh
                                                                unsigned short* __restrict__ dz, long M, int C,
                                                                int act_channels, float slope, int rows_per_block,
                                                                float* __restrict__ bias_grad) {
+    // 8 lanes cover one row's 64-channel group (128 B), 32 rows per pass, FOUR passes' loads issued before any is
+    // used: 8 independent 16-byte loads in flight per lane keep HBM busy with a handful of waves per CU.
     const int cg = blockIdx.y;
     const int chunk = threadIdx.x & 7, lane_p = threadIdx.x >> 3;
     const int c0 = cg * 64 + chunk * 8;
@@ -225,23 +227,34 @@ __global__ __launch_bounds__(256) void lrelu_bwd_colsum_kernel(const unsigned sh
     const long r_begin = (long)blockIdx.x * rows_per_block;
     const long r_end = min(M, r_begin + rows_per_block);
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (long r = r_begin + lane_p; r < r_end; r += 32) {
-        const long off = r * C + c0;
-        const u32x4 g = *reinterpret_cast<const u32x4*>(dy + off);
-        u32x4 out = g;
-        if (act) {
-            const u32x4 yy = *reinterpret_cast<const u32x4*>(y + off);
+    for (long r0 = r_begin + lane_p; r0 < r_end; r0 += 128) {
+        u32x4 g[4], yy[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float g0 = bf16_lo(g[k]), g1 = bf16_hi(g[k]);
-                const float r0 = bf16_lo(yy[k]) > 0.f ? g0 : g0 * slope;
-                const float r1 = bf16_hi(yy[k]) > 0.f ? g1 : g1 * slope;
-                out[k] = pack_bf16x2(r0, r1);
+        for (int u = 0; u < 4; ++u) {
+            const long r = r0 + 32 * u;
+            const long off = (r < r_end ? r : r0) * C + c0;
+            g[u] = *reinterpret_cast<const u32x4*>(dy + off);
+            yy[u] = act ? *reinterpret_cast<const u32x4*>(y + off) : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long r = r0 + 32 * u;
+            if (r < r_end) {
+                u32x4 out = g[u];
+                if (act) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float g0 = bf16_lo(g[u][k]), g1 = bf16_hi(g[u][k]);
+                        const float v0 = bf16_lo(yy[u][k]) > 0.f ? g0 : g0 * slope;
+                        const float v1 = bf16_hi(yy[u][k]) > 0.f ? g1 : g1 * slope;
+                        out[k] = pack_bf16x2(v0, v1);
+                    }
+                }
+                *reinterpret_cast<u32x4*>(dz + r * C + c0) = out;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { s[2 * k] += bf16_lo(out[k]); s[2 * k + 1] += bf16_hi(out[k]); }
             }
         }
-        *reinterpret_cast<u32x4*>(dz + off) = out;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { s[2 * k] += bf16_lo(out[k]); s[2 * k + 1] += bf16_hi(out[k]); }
     }
     __shared__ float red[32][65];
 #pragma unroll
@@ -255,14 +268,12 @@ __global__ __launch_bounds__(256) void lrelu_bwd_colsum_kernel(const unsigned sh
     }
 }
 
-// ---- 2x2 average pooling fused with the leaky-ReLU gradient (discriminator blocks: net.py:416,425 lrelu -> downscale2x)
-// unpool: dz[b,h,w,c] = 0.25 * dp[b,h/2,w/2,c] * (y ? (y[b,h,w,c] > 0 ? 1 : slope) : 1)  (+ column sums -> bias_grad)
-// The expanded gradient of the pooling (the reference materialises it) is never written.
 __global__ __launch_bounds__(256) void unpool_lrelu_bwd_kernel(const unsigned short* __restrict__ dp,
                                                                const unsigned short* __restrict__ y,
                                                                unsigned short* __restrict__ dz, long M, int H, int W,
                                                                int C, float slope, int rows_per_block,
                                                                float* __restrict__ bias_grad) {
+    // same lane layout and 4-pass load batching as lrelu_bwd_colsum_kernel; dp is read at the pooled position
     const int cg = blockIdx.y;
     const int chunk = threadIdx.x & 7, lane_p = threadIdx.x >> 3;
     const int c0 = cg * 64 + chunk * 8;
@@ -270,28 +281,38 @@ __global__ __launch_bounds__(256) void unpool_lrelu_bwd_kernel(const unsigned sh
     const long r_end = min(M, r_begin + rows_per_block);
     const int Wp = W >> 1, Hp = H >> 1;
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (long r = r_begin + lane_p; r < r_end; r += 32) {
-        const int w = (int)(r % W);
-        const long t = r / W;
-        const int h = (int)(t % H);
-        const long b = t / H;
-        const long rp = (b * Hp + (h >> 1)) * Wp + (w >> 1);
-        const u32x4 g = *reinterpret_cast<const u32x4*>(dp + rp * C + c0);
-        u32x4 yy = {0u, 0u, 0u, 0u};
-        if (y) yy = *reinterpret_cast<const u32x4*>(y + r * C + c0);
-        u32x4 out;
+    for (long r0 = r_begin + lane_p; r0 < r_end; r0 += 128) {
+        u32x4 g[4], yy[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float g0 = bf16_lo(g[k]) * 0.25f, g1 = bf16_hi(g[k]) * 0.25f;
-            if (y) {
-                g0 = bf16_lo(yy[k]) > 0.f ? g0 : g0 * slope;
-                g1 = bf16_hi(yy[k]) > 0.f ? g1 : g1 * slope;
-            }
-            out[k] = pack_bf16x2(g0, g1);
-            s[2 * k] += bf16_lo(out[k]);
-            s[2 * k + 1] += bf16_hi(out[k]);
+        for (int u = 0; u < 4; ++u) {
+            const long r = (r0 + 32 * u) < r_end ? (r0 + 32 * u) : r0;
+            const int w = (int)(r % W);
+            const long t = r / W;
+            const int h = (int)(t % H);
+            const long b = t / H;
+            const long rp = (b * Hp + (h >> 1)) * Wp + (w >> 1);
+            g[u] = *reinterpret_cast<const u32x4*>(dp + rp * C + c0);
+            yy[u] = y ? *reinterpret_cast<const u32x4*>(y + r * C + c0) : u32x4{0u, 0u, 0u, 0u};
         }
-        *reinterpret_cast<u32x4*>(dz + r * C + c0) = out;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long r = r0 + 32 * u;
+            if (r < r_end) {
+                u32x4 out;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float g0 = bf16_lo(g[u][k]) * 0.25f, g1 = bf16_hi(g[u][k]) * 0.25f;
+                    if (y) {
+                        g0 = bf16_lo(yy[u][k]) > 0.f ? g0 : g0 * slope;
+                        g1 = bf16_hi(yy[u][k]) > 0.f ? g1 : g1 * slope;
+                    }
+                    out[k] = pack_bf16x2(g0, g1);
+                    s[2 * k] += bf16_lo(out[k]);
+                    s[2 * k + 1] += bf16_hi(out[k]);
+                }
+                *reinterpret_cast<u32x4*>(dz + r * C + c0) = out;
+            }
+        }
     }
     if (bias_grad) {
         __shared__ float red[32][65];
@@ -757,7 +778,7 @@ extern "C" int rgbd_lrelu_bwd(const void* dy, const void* y, void* dz, int64_t M
     hipStream_t st = (hipStream_t)stream;
     if (bias_grad) {
         RGBD_REQUIRE(C % 64 == 0, "rgbd_lrelu_bwd: the fused bias gradient needs C %% 64 == 0 (C=%d)", C);
-        const int rows = 2048;
+        const int rows = 512;
         dim3 grid(ceil_div(M, rows), C / 64);
         lrelu_bwd_colsum_kernel<<<grid, 256, 0, st>>>((const unsigned short*)dy, (const unsigned short*)y,
                                                       (unsigned short*)dz, M, C, act_channels, slope, rows, bias_grad);
@@ -793,7 +814,7 @@ extern "C" int rgbd_unpool2_lrelu_bwd(const void* dp, const void* y, void* dz, i
     RGBD_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C % 64 == 0,
                  "rgbd_unpool2_lrelu_bwd: H, W must be even and C a multiple of 64 (H=%d W=%d C=%d)", H, W, C);
     const long M = (long)B * H * W;
-    const int rows = 2048;
+    const int rows = 512;
     dim3 grid(ceil_div(M, rows), C / 64);
     unpool_lrelu_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const unsigned short*)dp, (const unsigned short*)y,
                                                                   (unsigned short*)dz, M, H, W, C, slope, rows, bias_grad);

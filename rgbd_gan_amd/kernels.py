@@ -113,6 +113,14 @@ def pack_weights(w, scale, want_fprop=True, want_dgrad=True):
     return wf, wd
 
 
+def _fprop_workspace(lib, B, H, W, Cin, Cout, KH, KW, pad, ups, device):
+    """Scratch for the split-K path of the small layers (None when the shape is not split)."""
+    nbytes = lib.rgbd_conv2d_fprop_workspace(B, H, W, Cin, Cout, KH, KW, pad, ups)
+    if nbytes < 0:
+        raise RuntimeError(f"conv2d: unsupported shape B={B} H={H} W={W} Cin={Cin} Cout={Cout} K={KH}x{KW} pad={pad}")
+    return torch.empty(nbytes // 4, dtype=F32, device=device) if nbytes > 0 else None
+
+
 def conv2d_fprop(x, wp, KH, KW, pad, bias=None, residual=None, upsample=False, lrelu_channels=0, slope=0.2):
     """x (B,H,W,Cin) bf16, wp [KH*KW][Cout][Cin] bf16 -> y (B,Hout,Wout,Cout) bf16."""
     _chk(x, BF16, "x"); _chk(wp, BF16, "wp"); _chk(bias, F32, "bias"); _chk(residual, BF16, "residual")
@@ -128,12 +136,14 @@ def conv2d_fprop(x, wp, KH, KW, pad, bias=None, residual=None, upsample=False, l
     lib = _lib.load()
     flops = 2.0 * B * Hout * Wout * Cout * Cin * KH * KW
     nbytes = 2.0 * (x.numel() + y.numel() + wp.numel() + (residual.numel() if residual is not None else 0))
-    patch = KH == 3 and KW == 3 and pad == 1 and Hout % 16 == 0 and Wout % 16 == 0
+    ws = _fprop_workspace(lib, B, H, W, Cin, Cout, KH, KW, pad, int(bool(upsample)), x.device)
+    patch = KH == 3 and KW == 3 and pad == 1 and Hout % 16 == 0 and Wout % 16 == 0 and ws is None \
+        and B * (Hout // 16) * (Wout // 16) * (Cout // (128 if Cout % 128 == 0 else 64)) >= 64
     kname = ("conv3x3_patch_kernel" if patch else "conv_fprop_kernel") + f"<{128 if Cout % 128 == 0 else 64}>"
     rc = _timed(kname, flops, nbytes,
                 lambda: lib.rgbd_conv2d_fprop_bf16(_ptr(x), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(y), B, H, W,
                                                    Cin, Cout, KH, KW, pad, int(bool(upsample)), int(lrelu_channels),
-                                                   float(slope), _stream()))
+                                                   float(slope), _ptr(ws), _stream()))
     _lib.check(rc, "rgbd_conv2d_fprop_bf16")
     return y
 
@@ -151,10 +161,13 @@ def conv2d_dgrad(dy, wd, K, pad):
     lib = _lib.load()
     flops = 2.0 * B * Ho * Wo * Cout * Cin * K * K
     nbytes = 2.0 * (dy.numel() + dx.numel() + wd.numel())
-    patch = K == 3 and pd == 1 and Ho % 16 == 0 and Wo % 16 == 0
+    ws = _fprop_workspace(lib, B, H, W, Cout, Cin, K, K, pd, 0, dy.device)
+    patch = K == 3 and pd == 1 and Ho % 16 == 0 and Wo % 16 == 0 and ws is None \
+        and B * (Ho // 16) * (Wo // 16) * (Cin // (128 if Cin % 128 == 0 else 64)) >= 64
     kname = ("conv3x3_patch_kernel" if patch else "conv_fprop_kernel") + f"<{128 if Cin % 128 == 0 else 64}>"
     rc = _timed(kname, flops, nbytes,
-                lambda: lib.rgbd_conv2d_dgrad_bf16(_ptr(dy), _ptr(wd), _ptr(dx), B, H, W, Cin, Cout, K, pad, _stream()))
+                lambda: lib.rgbd_conv2d_dgrad_bf16(_ptr(dy), _ptr(wd), _ptr(dx), B, H, W, Cin, Cout, K, pad, _ptr(ws),
+                                                   _stream()))
     _lib.check(rc, "rgbd_conv2d_dgrad_bf16")
     return dx
 

@@ -416,3 +416,32 @@ def test_smoothed_generator_tracks_updates():
     m0 = sm.mapping.store.flat.clone()
     upd.update()
     torch.testing.assert_close(sm.mapping.store.flat, m0 * (1 - 0.001) + 0.001 * gen.mapping.store.flat, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,K,pad,ups", [(32, 8, 256, 256, 3, 1, False), (32, 4, 256, 256, 3, 1, False),
+                                                     (2, 16, 256, 256, 3, 1, False), (4, 4, 256, 256, 3, 1, True),
+                                                     (2, 8, 256, 128, 1, 0, False), (3, 5, 64, 128, 3, 1, False)])
+def test_split_k_path_matches_unsplit(B, H, Cin, Cout, K, pad, ups):
+    """Small layers are split along K over several workgroups (fp32 partials + finishing kernel): same result as the
+    single-pass kernel up to the fp32 summation order, including bias / residual / leaky ReLU / ragged M."""
+    from rgbd_gan_amd import _lib, kernels
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B * 100 + H)
+    x = torch.randn(B, H, H, Cin, generator=g).to(torch.bfloat16).to(dev())
+    w = torch.randn(Cout, Cin, K, K, generator=g).to(dev())
+    bias = torch.randn(Cout, generator=g).to(dev())
+    Ho = (2 * H if ups else H) + 2 * pad - K + 1
+    res = torch.randn(B, Ho, Ho, Cout, generator=g).to(torch.bfloat16).to(dev())
+    wf, _ = kernels.pack_weights(w, float(np.sqrt(2.0 / (Cin * K * K))))
+    assert lib.rgbd_conv2d_fprop_workspace(B, H, H, Cin, Cout, K, K, pad, int(ups)) > 0      # these shapes are split
+    y_split = kernels.conv2d_fprop(x, wf, K, K, pad, bias=bias, residual=res, upsample=ups, lrelu_channels=Cout)
+    # unsplit: call the C ABI without scratch
+    y_ref = torch.empty_like(y_split)
+    rc = lib.rgbd_conv2d_fprop_bf16(kernels._ptr(x), kernels._ptr(wf), kernels._ptr(bias), kernels._ptr(res),
+                                    kernels._ptr(y_ref), B, H, H, Cin, Cout, K, K, pad, int(ups), Cout, 0.2, None,
+                                    kernels._stream())
+    assert rc == 0
+    d = (y_split.float() - y_ref.float()).abs().max().item()
+    scale = y_ref.float().abs().max().item()
+    assert d <= 2 ** -7 * scale, (d, scale)            # one bf16 ulp of the largest output
+    assert (y_split.float() - y_ref.float()).abs().mean().item() < 1e-3 * scale
