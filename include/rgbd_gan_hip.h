@@ -107,14 +107,16 @@ int rgbd_conv2d_wgrad_bf16(const void* x, const void* dy, void* workspace, float
 
 /* ------------------------------------------------------------------ AdaIN (instance norm + style affine)
  * Replaces normalization/adain.py:54-73 (reshape + F.batch_normalization + broadcast mul/add) and its backward.
- *   x (B,HW,C) bf16 NHWC; scale, shift (B,C) fp32; eps 1e-5; biased variance.
+ *   x (B,HW,C) bf16 NHWC; scale, shift: B rows of C fp32 values, rows `ld` floats apart (ld = C for plain (B,C)
+ *   arrays; ld = 2C with shift = scale + C when one fused linear produced [scale | shift], net.py:96-101);
+ *   eps 1e-5; biased variance.
  *   sums: workspace (B,C,2) fp32, zeroed inside.  mean, rstd: (B,C) fp32 outputs (saved for backward).
  */
 int rgbd_adain_fwd(const void* x, const float* scale, const float* shift, void* y,
-                   float* sums, float* mean, float* rstd, int B, int HW, int C, float eps, void* stream);
-/* dy (B,HW,C) bf16 -> dx bf16, dscale/dshift (B,C) fp32 (overwritten).  sums: workspace (B,C,2) fp32. */
+                   float* sums, float* mean, float* rstd, int B, int HW, int C, int ld, float eps, void* stream);
+/* dy (B,HW,C) bf16 -> dx bf16, dscale/dshift fp32 rows `ld` apart like scale (overwritten).  sums: workspace (B,C,2). */
 int rgbd_adain_bwd(const void* x, const void* dy, const float* scale, const float* mean, const float* rstd,
-                   void* dx, float* dscale, float* dshift, float* sums, int B, int HW, int C, void* stream);
+                   void* dx, float* dscale, float* dshift, float* sums, int B, int HW, int C, int ld, void* stream);
 
 /* ------------------------------------------------------------------ small fused elementwise / 1x1 kernels (HBM-bound)
  * rgbd_lrelu_bwd: dz = dy * (y > 0 ? 1 : slope) on channels [0, act_channels) of (M,C) bf16 tensors, pass-through on

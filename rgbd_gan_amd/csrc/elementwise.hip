@@ -122,21 +122,23 @@ __global__ __launch_bounds__(256) void adain_apply_kernel(const unsigned short* 
                                                           const float* __restrict__ shift,
                                                           const float* __restrict__ mean,
                                                           const float* __restrict__ rstd,
-                                                          unsigned short* __restrict__ y, long nvec, int HW, int C) {
+                                                          unsigned short* __restrict__ y, long nvec, int HW, int C,
+                                                          int ld) {
     const int cvec = C >> 3;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nvec; e += (long)gridDim.x * 256) {
         const int cv = (int)(e % cvec);
         const long pix = e / cvec;
         const int b = (int)(pix / HW);
         const long sidx = (long)b * C + cv * 8;
+        const long aidx = (long)b * ld + cv * 8;        // scale / shift rows are ld floats apart
         const u32x4 xv = *reinterpret_cast<const u32x4*>(x + e * 8);
         u32x4 out;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float a0 = rstd[sidx + 2 * k] * scale[sidx + 2 * k];
-            const float a1 = rstd[sidx + 2 * k + 1] * scale[sidx + 2 * k + 1];
-            const float r0 = (bf16_lo(xv[k]) - mean[sidx + 2 * k]) * a0 + shift[sidx + 2 * k];
-            const float r1 = (bf16_hi(xv[k]) - mean[sidx + 2 * k + 1]) * a1 + shift[sidx + 2 * k + 1];
+            const float a0 = rstd[sidx + 2 * k] * scale[aidx + 2 * k];
+            const float a1 = rstd[sidx + 2 * k + 1] * scale[aidx + 2 * k + 1];
+            const float r0 = (bf16_lo(xv[k]) - mean[sidx + 2 * k]) * a0 + shift[aidx + 2 * k];
+            const float r1 = (bf16_hi(xv[k]) - mean[sidx + 2 * k + 1]) * a1 + shift[aidx + 2 * k + 1];
             out[k] = pack_bf16x2(r0, r1);
         }
         *reinterpret_cast<u32x4*>(y + e * 8) = out;
@@ -151,13 +153,14 @@ __global__ __launch_bounds__(256) void adain_bwd_apply_kernel(const unsigned sho
                                                               const float* __restrict__ rstd,
                                                               const float* __restrict__ sums,
                                                               unsigned short* __restrict__ dx, long nvec, int HW,
-                                                              int C, float inv_hw) {
+                                                              int C, float inv_hw, int ld) {
     const int cvec = C >> 3;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nvec; e += (long)gridDim.x * 256) {
         const int cv = (int)(e % cvec);
         const long pix = e / cvec;
         const int b = (int)(pix / HW);
         const long sidx = (long)b * C + cv * 8;
+        const long aidx = (long)b * ld + cv * 8;
         const u32x4 xv = *reinterpret_cast<const u32x4*>(x + e * 8);
         const u32x4 gv = *reinterpret_cast<const u32x4*>(dy + e * 8);
         u32x4 out;
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(256) void adain_bwd_apply_kernel(const unsigned sho
                 const long s = sidx + 2 * k + h;
                 const float xh = ((h ? bf16_hi(xv[k]) : bf16_lo(xv[k])) - mean[s]) * rstd[s];
                 const float g = h ? bf16_hi(gv[k]) : bf16_lo(gv[k]);
-                r[h] = rstd[s] * scale[s] * (g - sums[2 * s] * inv_hw - xh * sums[2 * s + 1] * inv_hw);
+                r[h] = rstd[s] * scale[aidx + 2 * k + h] * (g - sums[2 * s] * inv_hw - xh * sums[2 * s + 1] * inv_hw);
             }
             out[k] = pack_bf16x2(r[0], r[1]);
         }
@@ -178,11 +181,12 @@ __global__ __launch_bounds__(256) void adain_bwd_apply_kernel(const unsigned sho
 }
 
 __global__ __launch_bounds__(256) void split_sums_kernel(const float* __restrict__ sums, float* __restrict__ dscale,
-                                                         float* __restrict__ dshift, int n) {
+                                                         float* __restrict__ dshift, int n, int C, int ld) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    dshift[i] = sums[2 * i];
-    dscale[i] = sums[2 * i + 1];
+    const long o = (long)(i / C) * ld + (i % C);
+    dshift[o] = sums[2 * i];
+    dscale[o] = sums[2 * i + 1];
 }
 
 // ------------------------------------------------------------------------------------------------ leaky ReLU grad
@@ -726,8 +730,9 @@ extern "C" int rgbd_pack_weights(const float* w, int cout, int cin, int kh, int 
 }
 
 extern "C" int rgbd_adain_fwd(const void* x, const float* scale, const float* shift, void* y, float* sums,
-                              float* mean, float* rstd, int B, int HW, int C, float eps, void* stream) {
+                              float* mean, float* rstd, int B, int HW, int C, int ld, float eps, void* stream) {
     RGBD_REQUIRE(x && scale && shift && y && sums && mean && rstd, "rgbd_adain_fwd: null pointer");
+    RGBD_REQUIRE(ld >= C, "rgbd_adain_fwd: ld must be >= C");
     RGBD_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 64 == 0, "rgbd_adain_fwd: C must be a multiple of 64 (C=%d)", C);
     hipStream_t st = (hipStream_t)stream;
     if (rgbd_zero_async(sums, (size_t)B * C * 2 * sizeof(float), st) != hipSuccess) {
@@ -742,15 +747,16 @@ extern "C" int rgbd_adain_fwd(const void* x, const float* scale, const float* sh
     const long nvec = (long)B * HW * C / 8;
     const int blocks = (int)min((long)4096, (nvec + 255) / 256);
     adain_apply_kernel<<<blocks, 256, 0, st>>>((const unsigned short*)x, scale, shift, mean, rstd,
-                                               (unsigned short*)y, nvec, HW, C);
+                                               (unsigned short*)y, nvec, HW, C, ld);
     RGBD_CHECK_LAUNCH("adain_apply_kernel");
     return 0;
 }
 
 extern "C" int rgbd_adain_bwd(const void* x, const void* dy, const float* scale, const float* mean,
                               const float* rstd, void* dx, float* dscale, float* dshift, float* sums, int B,
-                              int HW, int C, void* stream) {
+                              int HW, int C, int ld, void* stream) {
     RGBD_REQUIRE(x && dy && scale && mean && rstd && dx && dscale && dshift && sums, "rgbd_adain_bwd: null pointer");
+    RGBD_REQUIRE(ld >= C, "rgbd_adain_bwd: ld must be >= C");
     RGBD_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 64 == 0, "rgbd_adain_bwd: C must be a multiple of 64 (C=%d)", C);
     hipStream_t st = (hipStream_t)stream;
     if (rgbd_zero_async(sums, (size_t)B * C * 2 * sizeof(float), st) != hipSuccess) {
@@ -764,9 +770,9 @@ extern "C" int rgbd_adain_bwd(const void* x, const void* dy, const float* scale,
     const long nvec = (long)B * HW * C / 8;
     const int blocks = (int)min((long)4096, (nvec + 255) / 256);
     adain_bwd_apply_kernel<<<blocks, 256, 0, st>>>((const unsigned short*)x, (const unsigned short*)dy, scale, mean,
-                                                   rstd, sums, (unsigned short*)dx, nvec, HW, C, 1.f / (float)HW);
+                                                   rstd, sums, (unsigned short*)dx, nvec, HW, C, 1.f / (float)HW, ld);
     RGBD_CHECK_LAUNCH("adain_bwd_apply_kernel");
-    split_sums_kernel<<<ceil_div((long)B * C, 256), 256, 0, st>>>(sums, dscale, dshift, B * C);
+    split_sums_kernel<<<ceil_div((long)B * C, 256), 256, 0, st>>>(sums, dscale, dshift, B * C, C, ld);
     RGBD_CHECK_LAUNCH("split_sums_kernel");
     return 0;
 }

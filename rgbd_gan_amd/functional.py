@@ -186,6 +186,29 @@ def adain(x, scale, shift):
     return _AdaIN.apply(x, scale.float(), shift.float())
 
 
+class _AdaINFused(torch.autograd.Function):
+    """AdaIN whose scale and shift arrive as the two halves of one (B,2C) tensor (the output of the fused style
+    affine): no slicing copies forward, one gradient tensor backward."""
+
+    @staticmethod
+    def forward(ctx, x, ss):
+        ss = ss.contiguous()
+        y, mean, rstd = kernels.adain_fwd(x.contiguous(), ss)
+        ctx.save_for_backward(x, ss, mean, rstd)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, ss, mean, rstd = ctx.saved_tensors
+        dx, dss, _ = kernels.adain_bwd(x.contiguous(), dy.contiguous(), ss, mean, rstd, fused=True)
+        return dx, dss
+
+
+def adain_fused(x, scale_shift):
+    return _AdaINFused.apply(x, scale_shift)
+
+
 class _WarpLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, img_rot, coef, flags, lam, max_depth, min_depth):

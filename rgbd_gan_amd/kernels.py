@@ -304,31 +304,45 @@ def linear_bwd(dy, y, x, w, c, act, want_dx=True, dw=None, db=None, slope=0.2):
 
 
 # ------------------------------------------------------------------ AdaIN
-def adain_fwd(x, scale, shift, eps=1e-5):
-    """x (B,H,W,C) bf16; scale, shift (B,C) fp32 -> y, mean, rstd."""
+def _off(t, nfloats):
+    return ctypes.c_void_p(t.data_ptr() + 4 * nfloats)
+
+
+def adain_fwd(x, scale, shift=None, eps=1e-5):
+    """x (B,H,W,C) bf16; scale, shift (B,C) fp32 -- or scale = (B,2C) fused [scale | shift] with shift None
+    -> y, mean, rstd."""
     _chk(x, BF16, "x"); _chk(scale, F32, "scale"); _chk(shift, F32, "shift")
     B, H, W, C = x.shape
+    fused = shift is None
+    if scale.shape != (B, 2 * C if fused else C):
+        raise RuntimeError(f"adain_fwd: scale {tuple(scale.shape)} does not match x {tuple(x.shape)}")
     y = torch.empty_like(x)
     sums = torch.empty(B, C, 2, dtype=F32, device=x.device)
     mean = torch.empty(B, C, dtype=F32, device=x.device)
     rstd = torch.empty(B, C, dtype=F32, device=x.device)
-    rc = _lib.load().rgbd_adain_fwd(_ptr(x), _ptr(scale), _ptr(shift), _ptr(y), _ptr(sums), _ptr(mean), _ptr(rstd),
-                                    B, H * W, C, float(eps), _stream())
+    rc = _lib.load().rgbd_adain_fwd(_ptr(x), _ptr(scale), _off(scale, C) if fused else _ptr(shift), _ptr(y), _ptr(sums),
+                                    _ptr(mean), _ptr(rstd), B, H * W, C, 2 * C if fused else C, float(eps), _stream())
     _lib.check(rc, "rgbd_adain_fwd")
     return y, mean, rstd
 
 
-def adain_bwd(x, dy, scale, mean, rstd):
+def adain_bwd(x, dy, scale, mean, rstd, fused=False):
+    """-> dx, dscale, dshift; with fused (scale = (B,2C) [scale | shift]): dx, d[scale | shift] (B,2C), None."""
     _chk(x, BF16, "x"); _chk(dy, BF16, "dy"); _chk(scale, F32, "scale")
     B, H, W, C = x.shape
     dx = torch.empty_like(x)
-    dscale = torch.empty(B, C, dtype=F32, device=x.device)
-    dshift = torch.empty(B, C, dtype=F32, device=x.device)
     sums = torch.empty(B, C, 2, dtype=F32, device=x.device)
-    rc = _lib.load().rgbd_adain_bwd(_ptr(x), _ptr(dy), _ptr(scale), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dscale),
-                                    _ptr(dshift), _ptr(sums), B, H * W, C, _stream())
+    if fused:
+        dss = torch.empty(B, 2 * C, dtype=F32, device=x.device)
+        dscale, dshift, ld = _ptr(dss), _off(dss, C), 2 * C
+    else:
+        ds = torch.empty(B, C, dtype=F32, device=x.device)
+        dsh = torch.empty(B, C, dtype=F32, device=x.device)
+        dscale, dshift, ld = _ptr(ds), _ptr(dsh), C
+    rc = _lib.load().rgbd_adain_bwd(_ptr(x), _ptr(dy), _ptr(scale), _ptr(mean), _ptr(rstd), _ptr(dx), dscale,
+                                    dshift, _ptr(sums), B, H * W, C, ld, _stream())
     _lib.check(rc, "rgbd_adain_bwd")
-    return dx, dscale, dshift
+    return (dx, dss, None) if fused else (dx, ds, dsh)
 
 
 # ------------------------------------------------------------------ small pointwise ops

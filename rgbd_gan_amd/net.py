@@ -128,9 +128,9 @@ class StyleGenerator(_Link):
                 specs.append((pre + "/W", (ci, 4, 4), "ones"))
             specs += [(pre + "/b0/b", (co,), "zeros"), (pre + "/b1/b", (co,), "zeros"),
                       (pre + "/n0/b/W", (co,), "zeros"), (pre + "/n1/b/W", (co,), "zeros")]
-            for s in ("s0", "s1"):
-                specs += [(f"{pre}/{s}/s/c/W", (co, ch), "normal"), (f"{pre}/{s}/s/c/b", (co,), "ones"),
-                          (f"{pre}/{s}/b/c/W", (co, ch), "normal"), (f"{pre}/{s}/b/c/b", (co,), "zeros")]
+            for s in ("s0", "s1"):        # scale / shift affines back to back: one fused launch (ParamStore.fused)
+                specs += [(f"{pre}/{s}/s/c/W", (co, ch), "normal"), (f"{pre}/{s}/b/c/W", (co, ch), "normal"),
+                          (f"{pre}/{s}/s/c/b", (co,), "ones"), (f"{pre}/{s}/b/c/b", (co,), "zeros")]
             specs += [(pre + "/c0/c/W", (co, ci, 3, 3), "normal"), (pre + "/c1/c/W", (co, co, 3, 3), "normal")]
         for i, (co, _) in enumerate(self.chans):
             specs += [(f"outs/{i}/c/W", (out_ch, co, 1, 1), w_init), (f"outs/{i}/c/b", (out_ch,), b_init)]
@@ -147,11 +147,11 @@ class StyleGenerator(_Link):
     # -- pieces
     def _style(self, name, w, h):
         """net.py:90-102 (StyleBlock): AdaIN(h, s(w), b(w)); both linears gain 1."""
-        p = self.store.params
-        c = _inv_c(self.ch, 1.0)
-        scale = Fn.linear_act(w, p[name + "/s/c/W"], p[name + "/s/c/b"], c, act=False)
-        shift = Fn.linear_act(w, p[name + "/b/c/W"], p[name + "/b/c/b"], c, act=False)
-        return Fn.adain(h, scale, shift)
+        co = self.store.shapes[name + "/s/c/W"][0]
+        W = self.store.fused((name + "/s/c/W", name + "/b/c/W"), (2 * co, self.ch))
+        b = self.store.fused((name + "/s/c/b", name + "/b/c/b"), (2 * co,))
+        ss = Fn.linear_act(w, W, b, _inv_c(self.ch, 1.0), act=False)           # [scale | shift] in one launch
+        return Fn.adain_fused(h, ss)
 
     def _block(self, i, w, x):
         """net.py:130-161 (SynthesisBlock.forward), add_noise False (forced at net.py:243)."""
@@ -188,8 +188,14 @@ class StyleGenerator(_Link):
         feat = None
         h = None
 
+        rotated = {}
+
         def run(i, w_cur, h):
-            return self._block(i, self.rotate_w(w_cur, theta) if (self.rgbd and i < 2) else w_cur, h)
+            if self.rgbd and i < 2:                 # blocks 0 and 1 see the same pose-conditioned style: compute once
+                if id(w_cur) not in rotated:
+                    rotated[id(w_cur)] = self.rotate_w(w_cur, theta)
+                return self._block(i, rotated[id(w_cur)], h)
+            return self._block(i, w_cur, h)
 
         if st % 2 == 0:
             k = (st - 2) // 2
@@ -243,8 +249,10 @@ class StyleGANGenerator(_Link):
     def __call__(self, z, stage, theta=None, return_feature=False):
         z = _as_device_tensor(z, self.device).reshape(-1, 2 * self.ch)
         theta = _as_device_tensor(theta, self.device) if theta is not None else None
-        w = self.mapping(z[:, :self.ch])
-        w2 = self.mapping(z[:, self.ch:])
+        # net.py:348-350 maps the two latent halves separately with the same network: one batch of 2B rows here
+        n = z.shape[0]
+        ww = self.mapping(torch.cat([z[:, :self.ch], z[:, self.ch:]], dim=0))
+        w, w2 = ww[:n], ww[n:]
         out = self.gen(w, w2=w2, stage=stage, theta=theta, return_feature=return_feature)
         if not self.train and not return_feature and out.shape[2] < 64:     # net.py:305-309 (eval-mode upsample)
             scale = 64 // out.shape[2]

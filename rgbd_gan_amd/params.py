@@ -52,6 +52,7 @@ class ParamStore:
             p = self.flat[off:off + n].view(self.shapes[name])
             p.requires_grad_(True)
             self.params[name] = p
+        self._fused = {}
         self.bind_grads()
 
     def bind_grads(self):
@@ -60,12 +61,41 @@ class ParamStore:
             n = p.numel()
             off = self.offsets[name]
             p.grad = self.grad[off:off + n].view(self.shapes[name])
+        for (names, _), (p, off) in self._fused.items():
+            p.grad = self.grad[off:off + p.numel()].view(p.shape)
+
+    def fused(self, names, shape):
+        """One leaf tensor over several parameters that sit back to back in the flat buffer (e.g. the scale and shift
+        affines of a style block, stacked along the output dimension), with its gradient bound to the same span of the
+        flat gradient buffer: a single kernel launch then serves all of them."""
+        key = (tuple(names), tuple(shape))
+        if key not in self._fused:
+            off = self.offsets[names[0]]
+            pos = off
+            for nm in names:
+                if self.offsets[nm] != pos:
+                    raise ValueError(f"fused{tuple(names)}: parameters are not adjacent in the flat buffer")
+                pos += int(np.prod(self.shapes[nm]))
+                if int(np.prod(self.shapes[nm])) % 4:
+                    raise ValueError(f"fused: {nm} is padded")
+            n = pos - off
+            if n != int(np.prod(shape)):
+                raise ValueError("fused: shape does not cover the parameters")
+            p = self.flat[off:off + n].view(shape)
+            p.requires_grad_(True)
+            p.grad = self.grad[off:off + n].view(shape)
+            self._fused[key] = (p, off)
+        return self._fused[key][0]
 
     def zero_grad(self):
         self.grad.zero_()
         for name, p in self.params.items():
             g = p.grad
             if g is None or g.data_ptr() != self.grad.data_ptr() + 4 * self.offsets[name]:
+                self.bind_grads()
+                break
+        for p, off in self._fused.values():
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
                 self.bind_grads()
                 break
 
