@@ -527,40 +527,58 @@ constexpr int LIN_MAXM = 64;
 
 // block = 256 threads -> 8 output columns for all rows: thread = (row m = tid & 63, column pair tid >> 6).
 // Few, long phases (K in chunks of 128): the kernel's time is load latency, so it uses N/8 blocks instead of N/32.
+// Forward / input-gradient of the small linears on the fp32 matrix cores (v_mfma_f32_16x16x4_f32): a wave owns a
+// 16 x 16 output tile, its lane (r = lane & 15, q = lane >> 4) streams four consecutive K values of row r of each
+// operand per step straight from global memory (no LDS, no barriers; the operands are L2-resident and the whole
+// problem is a few MFLOP, so the kernels are one dependent-load latency long).  The four waves of a block take the
+// four 16-row slices of the <= 64 rows and share the other operand's tile through L1.
+template <bool VEC>
 __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ y, int M,
                                                          int K, int N, float c, int act, float slope) {
-    __shared__ float xs[LIN_MAXM][129];
-    __shared__ float ws[8][129];
-    const int n0 = blockIdx.x * 8;
-    const int m = threadIdx.x & 63, nq = threadIdx.x >> 6;
-    float acc0 = 0.f, acc1 = 0.f;
-    for (int k0 = 0; k0 < K; k0 += 128) {
-        for (int e = threadIdx.x; e < M * 128; e += 256) {
-            const int mm = e >> 7, kk = e & 127;
-            xs[mm][kk] = (k0 + kk < K) ? x[(long)mm * K + k0 + kk] : 0.f;
-        }
-        for (int e = threadIdx.x; e < 8 * 128; e += 256) {
-            const int n = e >> 7, kk = e & 127;
-            ws[n][kk] = (n0 + n < N && k0 + kk < K) ? w[(long)(n0 + n) * K + k0 + kk] : 0.f;
-        }
-        __syncthreads();
-        if (m < M) {
-#pragma unroll 16
-            for (int kk = 0; kk < 128; ++kk) {
-                const float xv = xs[m][kk];
-                acc0 += xv * ws[2 * nq][kk];
-                acc1 += xv * ws[2 * nq + 1][kk];
+    const int lane = threadIdx.x & 63, m0 = (threadIdx.x >> 6) * 16;
+    if (m0 >= M) return;
+    const int r = lane & 15, q = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const bool mok = m0 + r < M, nok = n0 + r < N;
+    const float* xr = x + (long)(mok ? m0 + r : 0) * K;
+    const float* wr = w + (long)(nok ? n0 + r : 0) * K;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc = zero;
+    for (int k0 = 0; k0 < K; k0 += 128) {          // 8 K-steps of 16 per chunk: 16 independent loads in flight
+        f32x4 a[8], b[8];
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) {
+            const int kb = k0 + 16 * s2 + 4 * q;
+            if (VEC) {
+                const int kc = kb < K ? kb : 0;
+                a[s2] = *reinterpret_cast<const f32x4*>(xr + kc);
+                b[s2] = *reinterpret_cast<const f32x4*>(wr + kc);
+                if (kb >= K || !mok) a[s2] = zero;
+                if (kb >= K || !nok) b[s2] = zero;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = kb + j < K;
+                    const float av = xr[ok ? kb + j : 0], bv = wr[ok ? kb + j : 0];
+                    a[s2][j] = ok && mok ? av : 0.f;
+                    b[s2][j] = ok && nok ? bv : 0.f;
+                }
             }
         }
-        __syncthreads();
-    }
-    if (m < M) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + 2 * nq + j;
-            if (n < N) {
-                float v = (j ? acc1 : acc0) * c + (bias ? bias[n] : 0.f);
+        for (int s2 = 0; s2 < 8; ++s2)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s2][j], b[s2][j], acc, 0, 0, 0);
+    }
+    const int n = n0 + r;
+    if (n < N) {
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int m = m0 + 4 * q + t;
+            if (m < M) {
+                float v = acc[t] * c + bv;
                 if (act) v = v > 0.f ? v : v * slope;
                 y[(long)m * N + n] = v;
             }
@@ -568,54 +586,67 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
     }
 }
 
-// dx[m][k] (+)= c * sum_n dz[m][n] W[n][k], dz = dy * lrelu'(y) when act.  block -> 8 k-columns for all rows.
+template <bool VEC>
 __global__ __launch_bounds__(256) void linear_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                            const float* __restrict__ w, float* __restrict__ dx, int M,
                                                            int K, int N, float c, int act, float slope, int accumulate) {
-    __shared__ float zs[LIN_MAXM][129];
-    __shared__ float ws[128][9];
-    const int k0 = blockIdx.x * 8;
-    const int m = threadIdx.x & 63, kq = threadIdx.x >> 6;
-    float acc0 = 0.f, acc1 = 0.f;
-    for (int n0 = 0; n0 < N; n0 += 128) {
-        for (int e = threadIdx.x; e < M * 128; e += 256) {
-            const int mm = e >> 7, nn = e & 127;
-            float g = 0.f;
-            if (n0 + nn < N) {
-                g = dy[(long)mm * N + n0 + nn];
-                if (act && !(y[(long)mm * N + n0 + nn] > 0.f)) g *= slope;
-            }
-            zs[mm][nn] = g;
-        }
-        for (int e = threadIdx.x; e < 128 * 8; e += 256) {
-            const int nn = e >> 3, kk = e & 7;
-            ws[nn][kk] = (n0 + nn < N && k0 + kk < K) ? w[(long)(n0 + nn) * K + k0 + kk] : 0.f;
-        }
-        __syncthreads();
-        if (m < M) {
-#pragma unroll 16
-            for (int nn = 0; nn < 128; ++nn) {
-                const float g = zs[m][nn];
-                acc0 += g * ws[nn][2 * kq];
-                acc1 += g * ws[nn][2 * kq + 1];
-            }
-        }
-        __syncthreads();
-    }
-    if (m < M) {
+    const int lane = threadIdx.x & 63, m0 = (threadIdx.x >> 6) * 16;
+    if (m0 >= M) return;
+    const int r = lane & 15, q = lane >> 4;
+    const int k0 = blockIdx.x * 16;
+    const bool mok = m0 + r < M, kok = k0 + r < K;
+    const long zrow = (long)(mok ? m0 + r : 0) * N;
+    const float* wc = w + (kok ? k0 + r : 0);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc = zero;
+    for (int n0 = 0; n0 < N; n0 += 64) {           // 4 N-steps of 16 per chunk
+        f32x4 a[4], yy[4], b[4];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int k = k0 + 2 * kq + j;
-            if (k < K) {
+        for (int s2 = 0; s2 < 4; ++s2) {
+            const int nb = n0 + 16 * s2 + 4 * q;
+            if (VEC) {
+                const int nc = nb < N ? nb : 0;
+                a[s2] = *reinterpret_cast<const f32x4*>(dy + zrow + nc);
+                yy[s2] = act ? *reinterpret_cast<const f32x4*>(y + zrow + nc) : f32x4{1.f, 1.f, 1.f, 1.f};
+                if (nb >= N || !mok) a[s2] = zero;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool ok = nb + j < N;
+                    const float av = dy[zrow + (ok ? nb + j : 0)];
+                    yy[s2][j] = act ? y[zrow + (ok ? nb + j : 0)] : 1.f;
+                    a[s2][j] = ok && mok ? av : 0.f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = nb + j < N;
+                const float bv = wc[(long)(ok ? nb + j : 0) * K];
+                b[s2][j] = ok && kok ? bv : 0.f;
+            }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float g = yy[s2][j] > 0.f ? a[s2][j] : a[s2][j] * slope;
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(g, b[s2][j], acc, 0, 0, 0);
+            }
+    }
+    const int k = k0 + r;
+    if (k < K) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int m = m0 + 4 * q + t;
+            if (m < M) {
                 const long o = (long)m * K + k;
-                const float v = (j ? acc1 : acc0) * c;
+                const float v = acc[t] * c;
                 dx[o] = accumulate ? dx[o] + v : v;
             }
         }
     }
 }
 
-// dW[n][k] += c * sum_m dz[m][n] x[m][k];  db[n] += sum_m dz[m][n].  block -> 16 n-rows x 64 k-columns (4 per thread).
 __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                            const float* __restrict__ x, float* __restrict__ dw,
                                                            float* __restrict__ db, int M, int K, int N, float c, int act,
@@ -889,7 +920,8 @@ extern "C" int rgbd_linear_fwd(const float* x, const float* w, const float* bias
                                float c, int act, float slope, void* stream) {
     RGBD_REQUIRE(x && w && y, "rgbd_linear_fwd: null pointer");
     RGBD_REQUIRE(M > 0 && M <= LIN_MAXM && K > 0 && N > 0, "rgbd_linear_fwd: needs 0 < M <= %d (M=%d)", LIN_MAXM, M);
-    linear_fwd_kernel<<<(N + 7) / 8, 256, 0, (hipStream_t)stream>>>(x, w, bias, y, M, K, N, c, act, slope);
+    if ((K & 3) == 0) linear_fwd_kernel<true><<<(N + 15) / 16, 256, 0, (hipStream_t)stream>>>(x, w, bias, y, M, K, N, c, act, slope);
+    else              linear_fwd_kernel<false><<<(N + 15) / 16, 256, 0, (hipStream_t)stream>>>(x, w, bias, y, M, K, N, c, act, slope);
     RGBD_CHECK_LAUNCH("linear_fwd_kernel");
     return 0;
 }
@@ -902,7 +934,8 @@ extern "C" int rgbd_linear_bwd(const float* dy, const float* y, const float* x, 
     RGBD_REQUIRE(M > 0 && M <= LIN_MAXM && K > 0 && N > 0, "rgbd_linear_bwd: needs 0 < M <= %d (M=%d)", LIN_MAXM, M);
     hipStream_t st = (hipStream_t)stream;
     if (dx) {
-        linear_dgrad_kernel<<<(K + 7) / 8, 256, 0, st>>>(dy, y, w, dx, M, K, N, c, act, slope, accumulate_dx);
+        if ((N & 3) == 0) linear_dgrad_kernel<true><<<(K + 15) / 16, 256, 0, st>>>(dy, y, w, dx, M, K, N, c, act, slope, accumulate_dx);
+        else              linear_dgrad_kernel<false><<<(K + 15) / 16, 256, 0, st>>>(dy, y, w, dx, M, K, N, c, act, slope, accumulate_dx);
         RGBD_CHECK_LAUNCH("linear_dgrad_kernel");
     }
     if (dw) {
