@@ -73,6 +73,21 @@ int rgbd_warp_loss_bwd(const float* img, const float* img_rot, const float* coef
 int rgbd_pack_weights(const float* w, int cout, int cin, int kh, int kw, float scale,
                       void* w_fprop, void* w_dgrad, void* stream);
 
+/* The same for every convolution of a network in ONE launch (after an optimizer update all layers need new bf16
+ * images).  descs_device: n descriptors in DEVICE memory (they never change: master weights and packed images have
+ * fixed addresses); descriptor i owns blocks [block_begin[i], block_begin[i+1]) of the total_blocks-block grid.
+ */
+typedef struct rgbd_pack_desc {
+    const float* w;       /* (cout,cin,kh,kw) fp32 master */
+    void* w_fprop;        /* [taps][cout][cin] bf16 or NULL */
+    void* w_dgrad;        /* [taps][cin][cout] bf16, taps flipped, or NULL */
+    int cout, cin, taps;
+    float scale;
+    int block_begin;
+    int reserved;
+} rgbd_pack_desc;
+int rgbd_pack_weights_multi(const rgbd_pack_desc* descs_device, int n, int total_blocks, void* stream);
+
 /* Implicit-GEMM forward convolution on MFMA (bf16 in, fp32 accumulate), stride 1.
  *   x   : (B, Hin, Win, Cin) bf16 NHWC.  If `upsample` != 0 the convolution runs on the nearest-2x
  *         upsampled image (rescale.py:4-5 fused into the gather), so Hout = 2*Hin + 2*pad - KH + 1.
@@ -110,11 +125,14 @@ int rgbd_conv2d_wgrad_bf16(const void* x, const void* dy, void* workspace, float
  *   x (B,HW,C) bf16 NHWC; scale, shift: B rows of C fp32 values, rows `ld` floats apart (ld = C for plain (B,C)
  *   arrays; ld = 2C with shift = scale + C when one fused linear produced [scale | shift], net.py:96-101);
  *   eps 1e-5; biased variance.
- *   sums: workspace (B,C,2) fp32, zeroed inside.  mean, rstd: (B,C) fp32 outputs (saved for backward).
+ *   sums: workspace (B,C,2) fp32 that the CALLER has zeroed (per-strip partial sums are added into it; callers carve
+ *   it out of one arena cleared once per step instead of paying a clear per call).  mean, rstd: (B,C) fp32 outputs
+ *   (saved for backward).  Two launches: strip reduction, normalise + affine.
  */
 int rgbd_adain_fwd(const void* x, const float* scale, const float* shift, void* y,
                    float* sums, float* mean, float* rstd, int B, int HW, int C, int ld, float eps, void* stream);
-/* dy (B,HW,C) bf16 -> dx bf16, dscale/dshift fp32 rows `ld` apart like scale (overwritten).  sums: workspace (B,C,2). */
+/* dy (B,HW,C) bf16 -> dx bf16, dscale/dshift fp32 rows `ld` apart like scale (overwritten).
+ * sums: workspace (B,C,2) fp32, zeroed by the caller. */
 int rgbd_adain_bwd(const void* x, const void* dy, const float* scale, const float* mean, const float* rstd,
                    void* dx, float* dscale, float* dshift, float* sums, int B, int HW, int C, int ld, void* stream);
 
@@ -207,6 +225,8 @@ int rgbd_pixelnorm_bwd(const float* x, const float* dy, float* dx, int M, int C,
 int rgbd_depth_head_fwd(const float* x, float* y, int B, int HW, void* stream);
 int rgbd_depth_head_bwd(const float* x, const float* y, const float* dy, float* dx, int B, int HW, void* stream);
 int rgbd_ema_update(float* dst, const float* src, int64_t n, float tau, void* stream);
+/* Clear n floats with a kernel launch (a plain kernel node inside captured HIP graphs, unlike hipMemsetAsync). */
+int rgbd_zero_f32(float* p, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------ optimizer
  * Replaces chainer.optimizers.Adam + GradientClipping(5) (train_rgbd.py:151-161), one launch group per

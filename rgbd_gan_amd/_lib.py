@@ -20,6 +20,7 @@ PROTOTYPES = {
     "rgbd_warp_loss_fwd": ([_P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P], c_int),
     "rgbd_warp_loss_bwd": ([_P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P], c_int),
     "rgbd_pack_weights": ([_P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P], c_int),
+    "rgbd_pack_weights_multi": ([_P, c_int, c_int, _P], c_int),
     "rgbd_conv2d_fprop_workspace": ([c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int], c_int64),
     "rgbd_conv2d_fprop_bf16": ([_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                 c_int, c_int, c_float, _P, _P], c_int),
@@ -51,6 +52,7 @@ PROTOTYPES = {
     "rgbd_depth_head_fwd": ([_P, _P, c_int, c_int, _P], c_int),
     "rgbd_depth_head_bwd": ([_P, _P, _P, _P, c_int, c_int, _P], c_int),
     "rgbd_ema_update": ([_P, _P, c_int64, c_float, _P], c_int),
+    "rgbd_zero_f32": ([_P, c_int64, _P], c_int),
     "rgbd_adam_clip_multi": ([_P, _P, _P, _P, c_int64, c_int, POINTER(c_int64), POINTER(c_float), c_float, c_float,
                               c_float, c_float, c_float, _P, _P, _P, _P], c_int),
 }

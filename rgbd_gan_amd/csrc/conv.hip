@@ -703,44 +703,48 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradArgs a) {
     }
 }
 
-// Stage 1 of the slab reduction: grid (element chunks, slab groups); every thread owns one float4 of the packed
-// (tap, co, ci) tile, sums its group's slabs with independent loads in flight and stores the group partial
-// (plain stores: no zero fill, no atomics).
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ partial,
-                                                           int nslab, long total) {
-    const long e4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (e4 >= total) return;
-    const int per_group = (nslab + gridDim.y - 1) / gridDim.y;
-    const int s_begin = blockIdx.y * per_group;
-    const int s_end = min(nslab, s_begin + per_group);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    int s2 = s_begin;
-    for (; s2 + 4 <= s_end; s2 += 4) {
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(slabs + (long)(s2 + 0) * total + e4);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(slabs + (long)(s2 + 1) * total + e4);
-        const f32x4 v2 = *reinterpret_cast<const f32x4*>(slabs + (long)(s2 + 2) * total + e4);
-        const f32x4 v3 = *reinterpret_cast<const f32x4*>(slabs + (long)(s2 + 3) * total + e4);
-        acc += (v0 + v1) + (v2 + v3);
-    }
-    for (; s2 < s_end; ++s2) acc += *reinterpret_cast<const f32x4*>(slabs + (long)s2 * total + e4);
-    *reinterpret_cast<f32x4*>(partial + (long)blockIdx.y * total + e4) = acc;
-}
-
-// Stage 2: sum the group partials; packed (tap, co, ci) -> master layout (co, ci, tap) with the equalized-LR scale.
-__global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ partial, int groups,
-                                                           float* __restrict__ dw, int taps, int cout, int cin,
-                                                           float scale, int accumulate) {
+// Slab reduction + layout change in one launch.  A block owns 32 float4 of the packed (tap, co, ci) tile; its 256
+// threads are 32 quads x 8 slab groups: every thread sums its group's slabs with four independent loads in flight,
+// the eight partials meet in LDS, and the quad's owner writes scale * sum to the master layout dw[co][ci][tap]
+// (plain stores or read-add-write: dw is the optimizer's accumulating gradient buffer).
+__global__ __launch_bounds__(256) void wgrad_reduce_finish_kernel(const float* __restrict__ slabs, int nslab,
+                                                                  float* __restrict__ dw, int taps, int cout, int cin,
+                                                                  float scale, int accumulate) {
+    __shared__ f32x4 part[8][32];
     const long total = (long)taps * cout * cin;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        const int ci = (int)(e % cin);
-        const long r = e / cin;
+    const int quad = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const long e4 = ((long)blockIdx.x * 32 + quad) * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (e4 < total) {
+        const int per_group = (nslab + 7) >> 3;
+        const int s_begin = grp * per_group;
+        const int s_end = min(nslab, s_begin + per_group);
+        int s2 = s_begin;
+        for (; s2 + 4 <= s_end; s2 += 4) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(slabs + (long)(s2 + 0) * total + e4);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(slabs + (long)(s2 + 1) * total + e4);
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(slabs + (long)(s2 + 2) * total + e4);
+            const f32x4 v3 = *reinterpret_cast<const f32x4*>(slabs + (long)(s2 + 3) * total + e4);
+            acc += (v0 + v1) + (v2 + v3);
+        }
+        for (; s2 < s_end; ++s2) acc += *reinterpret_cast<const f32x4*>(slabs + (long)s2 * total + e4);
+    }
+    part[grp][quad] = acc;
+    __syncthreads();
+    if (grp == 0 && e4 < total) {
+#pragma unroll
+        for (int g = 1; g < 8; ++g) acc += part[g][quad];
+        // packed (tap, co, ci) -> master (co, ci, tap); cin is a multiple of 64, so the four elements share (tap, co)
+        const int ci = (int)(e4 % cin);
+        const long r = e4 / cin;
         const int co = (int)(r % cout);
         const int tap = (int)(r / cout);
-        const long o = ((long)co * cin + ci) * taps + tap;
-        float v = partial[e];
-        for (int g = 1; g < groups; ++g) v += partial[(long)g * total + e];
-        v *= scale;
-        dw[o] = accumulate ? dw[o] + v : v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long o = ((long)co * cin + ci + k) * taps + tap;
+            const float v = acc[k] * scale;
+            dw[o] = accumulate ? dw[o] + v : v;
+        }
     }
 }
 
@@ -933,13 +937,10 @@ extern "C" int rgbd_conv2d_dgrad_bf16(const void* dy, const void* wp_dgrad, void
                                   workspace, stream);
 }
 
-static int wgrad_groups(int nsplit) { return nsplit >= 64 ? 16 : (nsplit >= 8 ? 4 : 1); }
-
 extern "C" int64_t rgbd_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int K) {
     if (B <= 0 || H < 4 || W < 4 || Cin % 64 || Cout % 64 || (K != 1 && K != 3)) return -1;
     const WgradPlan p = plan_wgrad(B, H, W, Cin, Cout);
-    // nsplit slabs + the group partials of the two-stage reduction
-    return ((int64_t)p.nsplit + wgrad_groups(p.nsplit)) * K * K * Cout * Cin * (int64_t)sizeof(float);
+    return (int64_t)p.nsplit * K * K * Cout * Cin * (int64_t)sizeof(float);
 }
 
 extern "C" int rgbd_conv2d_wgrad_bf16(const void* x, const void* dy, void* workspace, float* dw, int B, int H, int W,
@@ -963,7 +964,6 @@ extern "C" int rgbd_conv2d_wgrad_bf16(const void* x, const void* dy, void* works
     dim3 grid(p.nsplit, Cin / 64, Cout / 64);
     hipStream_t st = (hipStream_t)stream;
     const long total = (long)K * K * Cout * Cin;
-    float* partial = (float*)workspace + (long)p.nsplit * total;
     {
         static bool attr_done[4] = {false, false, false, false};
         const bool fast = p.PW == 16 && p.PH == 8;
@@ -985,12 +985,8 @@ extern "C" int rgbd_conv2d_wgrad_bf16(const void* x, const void* dy, void* works
         }
     }
     RGBD_CHECK_LAUNCH("conv_wgrad_kernel");
-    const int groups = wgrad_groups(p.nsplit);
-    wgrad_reduce_kernel<<<dim3((unsigned)((total / 4 + 255) / 256), groups), 256, 0, st>>>((const float*)workspace, partial,
-                                                                                          p.nsplit, total);
-    RGBD_CHECK_LAUNCH("wgrad_reduce_kernel");
-    const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
-    wgrad_finish_kernel<<<blocks, 256, 0, st>>>(partial, groups, dw, K * K, Cout, Cin, scale, accumulate);
-    RGBD_CHECK_LAUNCH("wgrad_finish_kernel");
+    wgrad_reduce_finish_kernel<<<(unsigned)((total / 4 + 31) / 32), 256, 0, st>>>((const float*)workspace, p.nsplit, dw,
+                                                                                 K * K, Cout, Cin, scale, accumulate);
+    RGBD_CHECK_LAUNCH("wgrad_reduce_finish_kernel");
     return 0;
 }

@@ -26,6 +26,15 @@ hipError_t rgbd_zero_async(void* ptr, size_t bytes, hipStream_t stream) {
 extern "C" const char* rgbd_last_error(void) { return g_err; }
 extern "C" int rgbd_abi_version(void) { return RGBD_ABI_VERSION; }
 
+extern "C" int rgbd_zero_f32(float* p, int64_t n, void* stream) {
+    RGBD_REQUIRE(p && n > 0, "rgbd_zero_f32: bad arguments");
+    if (rgbd_zero_async(p, (size_t)n * sizeof(float), (hipStream_t)stream) != hipSuccess) {
+        rgbd_set_error("rgbd_zero_f32: launch failed");
+        return -2;
+    }
+    return 0;
+}
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------ weights
@@ -104,26 +113,15 @@ __global__ __launch_bounds__(256) void adain_reduce_kernel(const unsigned short*
     }
 }
 
-__global__ __launch_bounds__(256) void adain_finalize_kernel(const float* __restrict__ sums, float* __restrict__ mean,
-                                                             float* __restrict__ rstd, int n, float inv_hw,
-                                                             float eps) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float m = sums[2 * i] * inv_hw;
-    float var = sums[2 * i + 1] * inv_hw - m * m;
-    var = fmaxf(var, 0.f);
-    mean[i] = m;
-    rstd[i] = rsqrtf(var + eps);
-}
-
-// y = (x - mean) * rstd * scale + shift
+// y = (x - mean) * rstd * scale + shift, mean / rstd derived in place from the (sum x, sum x^2) pairs (adain.py:62-63:
+// biased variance, (var + eps)^-1/2); the thread that handles an image's first pixel also stores them for backward.
 __global__ __launch_bounds__(256) void adain_apply_kernel(const unsigned short* __restrict__ x,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift,
-                                                          const float* __restrict__ mean,
-                                                          const float* __restrict__ rstd,
+                                                          const float* __restrict__ sums,
+                                                          float* __restrict__ mean, float* __restrict__ rstd,
                                                           unsigned short* __restrict__ y, long nvec, int HW, int C,
-                                                          int ld) {
+                                                          int ld, float inv_hw, float eps) {
     const int cvec = C >> 3;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nvec; e += (long)gridDim.x * 256) {
         const int cv = (int)(e % cvec);
@@ -132,13 +130,32 @@ __global__ __launch_bounds__(256) void adain_apply_kernel(const unsigned short* 
         const long sidx = (long)b * C + cv * 8;
         const long aidx = (long)b * ld + cv * 8;        // scale / shift rows are ld floats apart
         const u32x4 xv = *reinterpret_cast<const u32x4*>(x + e * 8);
+        // 8 channels: (sum, sum of squares) pairs, scale, shift as 16-byte loads
+        const f32x4 sa = *reinterpret_cast<const f32x4*>(sums + 2 * sidx), sb = *reinterpret_cast<const f32x4*>(sums + 2 * sidx + 4);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(sums + 2 * sidx + 8), sd = *reinterpret_cast<const f32x4*>(sums + 2 * sidx + 12);
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(scale + aidx), g1 = *reinterpret_cast<const f32x4*>(scale + aidx + 4);
+        const f32x4 h0 = *reinterpret_cast<const f32x4*>(shift + aidx), h1 = *reinterpret_cast<const f32x4*>(shift + aidx + 4);
+        const float s1[8] = {sa[0], sa[2], sb[0], sb[2], sc[0], sc[2], sd[0], sd[2]};
+        const float s2[8] = {sa[1], sa[3], sb[1], sb[3], sc[1], sc[3], sd[1], sd[3]};
+        const float gg[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+        const float hh[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+        float m[8], rs[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            m[k] = s1[k] * inv_hw;
+            rs[k] = rsqrtf(fmaxf(s2[k] * inv_hw - m[k] * m[k], 0.f) + eps);
+        }
+        if (pix == (long)b * HW) {          // one thread per (image, 8-channel group) keeps the statistics for backward
+            *reinterpret_cast<f32x4*>(mean + sidx) = f32x4{m[0], m[1], m[2], m[3]};
+            *reinterpret_cast<f32x4*>(mean + sidx + 4) = f32x4{m[4], m[5], m[6], m[7]};
+            *reinterpret_cast<f32x4*>(rstd + sidx) = f32x4{rs[0], rs[1], rs[2], rs[3]};
+            *reinterpret_cast<f32x4*>(rstd + sidx + 4) = f32x4{rs[4], rs[5], rs[6], rs[7]};
+        }
         u32x4 out;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float a0 = rstd[sidx + 2 * k] * scale[aidx + 2 * k];
-            const float a1 = rstd[sidx + 2 * k + 1] * scale[aidx + 2 * k + 1];
-            const float r0 = (bf16_lo(xv[k]) - mean[sidx + 2 * k]) * a0 + shift[aidx + 2 * k];
-            const float r1 = (bf16_hi(xv[k]) - mean[sidx + 2 * k + 1]) * a1 + shift[aidx + 2 * k + 1];
+            const float r0 = (bf16_lo(xv[k]) - m[2 * k]) * (rs[2 * k] * gg[2 * k]) + hh[2 * k];
+            const float r1 = (bf16_hi(xv[k]) - m[2 * k + 1]) * (rs[2 * k + 1] * gg[2 * k + 1]) + hh[2 * k + 1];
             out[k] = pack_bf16x2(r0, r1);
         }
         *reinterpret_cast<u32x4*>(y + e * 8) = out;
@@ -152,8 +169,9 @@ __global__ __launch_bounds__(256) void adain_bwd_apply_kernel(const unsigned sho
                                                               const float* __restrict__ mean,
                                                               const float* __restrict__ rstd,
                                                               const float* __restrict__ sums,
-                                                              unsigned short* __restrict__ dx, long nvec, int HW,
-                                                              int C, float inv_hw, int ld) {
+                                                              unsigned short* __restrict__ dx,
+                                                              float* __restrict__ dscale, float* __restrict__ dshift,
+                                                              long nvec, int HW, int C, float inv_hw, int ld) {
     const int cvec = C >> 3;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nvec; e += (long)gridDim.x * 256) {
         const int cv = (int)(e % cvec);
@@ -163,30 +181,37 @@ __global__ __launch_bounds__(256) void adain_bwd_apply_kernel(const unsigned sho
         const long aidx = (long)b * ld + cv * 8;
         const u32x4 xv = *reinterpret_cast<const u32x4*>(x + e * 8);
         const u32x4 gv = *reinterpret_cast<const u32x4*>(dy + e * 8);
+        const f32x4 sa = *reinterpret_cast<const f32x4*>(sums + 2 * sidx), sb = *reinterpret_cast<const f32x4*>(sums + 2 * sidx + 4);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(sums + 2 * sidx + 8), sd = *reinterpret_cast<const f32x4*>(sums + 2 * sidx + 12);
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(scale + aidx), g1 = *reinterpret_cast<const f32x4*>(scale + aidx + 4);
+        const f32x4 m0 = *reinterpret_cast<const f32x4*>(mean + sidx), m1 = *reinterpret_cast<const f32x4*>(mean + sidx + 4);
+        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rstd + sidx), r1 = *reinterpret_cast<const f32x4*>(rstd + sidx + 4);
+        const float s1[8] = {sa[0], sa[2], sb[0], sb[2], sc[0], sc[2], sd[0], sd[2]};          // sum dy
+        const float s2[8] = {sa[1], sa[3], sb[1], sb[3], sc[1], sc[3], sd[1], sd[3]};          // sum dy * xhat
+        const float gg[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+        const float mm[8] = {m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2], m1[3]};
+        const float rr[8] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+        if (pix == (long)b * HW) {      // d shift = sum dy, d scale = sum dy * xhat (adain.py:76-77)
+            *reinterpret_cast<f32x4*>(dshift + aidx) = f32x4{s1[0], s1[1], s1[2], s1[3]};
+            *reinterpret_cast<f32x4*>(dshift + aidx + 4) = f32x4{s1[4], s1[5], s1[6], s1[7]};
+            *reinterpret_cast<f32x4*>(dscale + aidx) = f32x4{s2[0], s2[1], s2[2], s2[3]};
+            *reinterpret_cast<f32x4*>(dscale + aidx + 4) = f32x4{s2[4], s2[5], s2[6], s2[7]};
+        }
         u32x4 out;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float r[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const long s = sidx + 2 * k + h;
-                const float xh = ((h ? bf16_hi(xv[k]) : bf16_lo(xv[k])) - mean[s]) * rstd[s];
+                const int c = 2 * k + h;
+                const float xh = ((h ? bf16_hi(xv[k]) : bf16_lo(xv[k])) - mm[c]) * rr[c];
                 const float g = h ? bf16_hi(gv[k]) : bf16_lo(gv[k]);
-                r[h] = rstd[s] * scale[aidx + 2 * k + h] * (g - sums[2 * s] * inv_hw - xh * sums[2 * s + 1] * inv_hw);
+                r[h] = rr[c] * gg[c] * (g - s1[c] * inv_hw - xh * s2[c] * inv_hw);
             }
             out[k] = pack_bf16x2(r[0], r[1]);
         }
         *reinterpret_cast<u32x4*>(dx + e * 8) = out;
     }
-}
-
-__global__ __launch_bounds__(256) void split_sums_kernel(const float* __restrict__ sums, float* __restrict__ dscale,
-                                                         float* __restrict__ dshift, int n, int C, int ld) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const long o = (long)(i / C) * ld + (i % C);
-    dshift[o] = sums[2 * i];
-    dscale[o] = sums[2 * i + 1];
 }
 
 // ------------------------------------------------------------------------------------------------ leaky ReLU grad
@@ -760,25 +785,48 @@ extern "C" int rgbd_pack_weights(const float* w, int cout, int cin, int kh, int 
     return 0;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const rgbd_pack_desc* __restrict__ descs, int n) {
+    int d = 0;
+    for (int i = 1; i < n; ++i)
+        if (descs[i].block_begin <= (int)blockIdx.x) d = i;
+    const rgbd_pack_desc D = descs[d];
+    const int nblk = (d + 1 < n ? descs[d + 1].block_begin : (int)gridDim.x) - D.block_begin;
+    const long total = (long)D.cout * D.cin * D.taps;
+    unsigned short* wf = (unsigned short*)D.w_fprop;
+    unsigned short* wd = (unsigned short*)D.w_dgrad;
+    for (long e = (long)((int)blockIdx.x - D.block_begin) * 256 + threadIdx.x; e < total; e += (long)nblk * 256) {
+        const int ci = (int)(e % D.cin);
+        const long r = e / D.cin;
+        const int co = (int)(r % D.cout);
+        const int tap = (int)(r / D.cout);
+        const unsigned short h = f32_to_bf16_bits(D.w[((long)co * D.cin + ci) * D.taps + tap] * D.scale);
+        if (wf) wf[e] = h;
+        if (wd) wd[((long)(D.taps - 1 - tap) * D.cin + ci) * D.cout + co] = h;
+    }
+}
+}  // namespace
+
+extern "C" int rgbd_pack_weights_multi(const rgbd_pack_desc* descs_device, int n, int total_blocks, void* stream) {
+    RGBD_REQUIRE(descs_device && n > 0 && total_blocks > 0, "rgbd_pack_weights_multi: bad arguments");
+    pack_weights_multi_kernel<<<total_blocks, 256, 0, (hipStream_t)stream>>>(descs_device, n);
+    RGBD_CHECK_LAUNCH("pack_weights_multi_kernel");
+    return 0;
+}
+
 extern "C" int rgbd_adain_fwd(const void* x, const float* scale, const float* shift, void* y, float* sums,
                               float* mean, float* rstd, int B, int HW, int C, int ld, float eps, void* stream) {
     RGBD_REQUIRE(x && scale && shift && y && sums && mean && rstd, "rgbd_adain_fwd: null pointer");
     RGBD_REQUIRE(ld >= C, "rgbd_adain_fwd: ld must be >= C");
     RGBD_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 64 == 0, "rgbd_adain_fwd: C must be a multiple of 64 (C=%d)", C);
     hipStream_t st = (hipStream_t)stream;
-    if (rgbd_zero_async(sums, (size_t)B * C * 2 * sizeof(float), st) != hipSuccess) {
-        rgbd_set_error("rgbd_adain_fwd: memset failed");
-        return -2;
-    }
     dim3 grid(ceil_div(HW, ADAIN_STRIP), C / 64, B);
     adain_reduce_kernel<false><<<grid, 256, 0, st>>>((const unsigned short*)x, nullptr, nullptr, nullptr, sums, HW, C);
     RGBD_CHECK_LAUNCH("adain_reduce_kernel");
-    adain_finalize_kernel<<<ceil_div((long)B * C, 256), 256, 0, st>>>(sums, mean, rstd, B * C, 1.f / (float)HW, eps);
-    RGBD_CHECK_LAUNCH("adain_finalize_kernel");
     const long nvec = (long)B * HW * C / 8;
     const int blocks = (int)min((long)4096, (nvec + 255) / 256);
-    adain_apply_kernel<<<blocks, 256, 0, st>>>((const unsigned short*)x, scale, shift, mean, rstd,
-                                               (unsigned short*)y, nvec, HW, C, ld);
+    adain_apply_kernel<<<blocks, 256, 0, st>>>((const unsigned short*)x, scale, shift, sums, mean, rstd,
+                                               (unsigned short*)y, nvec, HW, C, ld, 1.f / (float)HW, eps);
     RGBD_CHECK_LAUNCH("adain_apply_kernel");
     return 0;
 }
@@ -790,10 +838,6 @@ extern "C" int rgbd_adain_bwd(const void* x, const void* dy, const float* scale,
     RGBD_REQUIRE(ld >= C, "rgbd_adain_bwd: ld must be >= C");
     RGBD_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 64 == 0, "rgbd_adain_bwd: C must be a multiple of 64 (C=%d)", C);
     hipStream_t st = (hipStream_t)stream;
-    if (rgbd_zero_async(sums, (size_t)B * C * 2 * sizeof(float), st) != hipSuccess) {
-        rgbd_set_error("rgbd_adain_bwd: memset failed");
-        return -2;
-    }
     dim3 grid(ceil_div(HW, ADAIN_STRIP), C / 64, B);
     adain_reduce_kernel<true><<<grid, 256, 0, st>>>((const unsigned short*)x, (const unsigned short*)dy, mean, rstd,
                                                     sums, HW, C);
@@ -801,10 +845,9 @@ extern "C" int rgbd_adain_bwd(const void* x, const void* dy, const float* scale,
     const long nvec = (long)B * HW * C / 8;
     const int blocks = (int)min((long)4096, (nvec + 255) / 256);
     adain_bwd_apply_kernel<<<blocks, 256, 0, st>>>((const unsigned short*)x, (const unsigned short*)dy, scale, mean,
-                                                   rstd, sums, (unsigned short*)dx, nvec, HW, C, 1.f / (float)HW, ld);
+                                                   rstd, sums, (unsigned short*)dx, dscale, dshift, nvec, HW, C,
+                                                   1.f / (float)HW, ld);
     RGBD_CHECK_LAUNCH("adain_bwd_apply_kernel");
-    split_sums_kernel<<<ceil_div((long)B * C, 256), 256, 0, st>>>(sums, dscale, dshift, B * C, C, ld);
-    RGBD_CHECK_LAUNCH("split_sums_kernel");
     return 0;
 }
 

@@ -54,12 +54,41 @@ class ConvLayer:
         self._epoch = -1
         self._wf = self._wd = None
 
+    group = None              # PackGroup: all convolutions of a network repacked by one launch
+
     def packed(self):
         if self._epoch != _WEIGHT_EPOCH:
-            with torch.no_grad():
-                self._wf, self._wd = kernels.pack_weights(self.weight.detach(), self.inv_c)
-            self._epoch = _WEIGHT_EPOCH
+            if self.group is not None:
+                self.group.repack()
+            else:
+                with torch.no_grad():
+                    self._wf, self._wd = kernels.pack_weights(self.weight.detach(), self.inv_c)
+                self._epoch = _WEIGHT_EPOCH
         return self._wf, self._wd
+
+
+class PackGroup:
+    """The convolutions of one network share persistent bf16 weight images and a device-resident descriptor table:
+    after an optimizer update the first layer that needs its image refreshes ALL of them with a single launch
+    (rgbd_pack_weights_multi) instead of one launch per layer."""
+
+    def __init__(self, layers):
+        self.layers = [l for l in layers if l is not None]
+        entries = []
+        for l in self.layers:
+            w = l.weight.detach()
+            co, ci, kh, kw = w.shape
+            l._wf = torch.empty(kh * kw, co, ci, dtype=torch.bfloat16, device=w.device)
+            l._wd = torch.empty(kh * kw, ci, co, dtype=torch.bfloat16, device=w.device)
+            l.group = self
+            entries.append((w, l.inv_c, l._wf, l._wd))
+        self.table = kernels.build_pack_table(entries)
+
+    def repack(self):
+        with torch.no_grad():
+            kernels.pack_weights_multi(self.table)
+        for l in self.layers:
+            l._epoch = _WEIGHT_EPOCH
 
 
 class DerivedConvLayer(ConvLayer):

@@ -113,6 +113,30 @@ def pack_weights(w, scale, want_fprop=True, want_dgrad=True):
     return wf, wd
 
 
+PACK_DESC = [("w", "<u8"), ("wf", "<u8"), ("wd", "<u8"), ("cout", "<i4"), ("cin", "<i4"), ("taps", "<i4"),
+             ("scale", "<f4"), ("block_begin", "<i4"), ("reserved", "<i4")]          # struct rgbd_pack_desc, 48 bytes
+
+
+def build_pack_table(entries):
+    """entries: list of (w fp32 (co,ci,k,k), scale, wf, wd) -> (device descriptor table, n, total_blocks)."""
+    import numpy as np
+    tab = np.zeros(len(entries), dtype=PACK_DESC)
+    assert tab.dtype.itemsize == 48
+    blocks = 0
+    for i, (w, scale, wf, wd) in enumerate(entries):
+        _chk(w, F32, "w"); _chk(wf, BF16, "wf"); _chk(wd, BF16, "wd")
+        co, ci, kh, kw = w.shape
+        tab[i] = (w.data_ptr(), wf.data_ptr(), wd.data_ptr(), co, ci, kh * kw, scale, blocks, 0)
+        blocks += min(256, (w.numel() + 255) // 256)
+    dev = torch.from_numpy(tab.view(np.uint8).copy()).to(entries[0][0].device)
+    return dev, len(entries), blocks
+
+
+def pack_weights_multi(table):
+    dev, n, blocks = table
+    _lib.check(_lib.load().rgbd_pack_weights_multi(_ptr(dev), n, blocks, _stream()), "rgbd_pack_weights_multi")
+
+
 def _fprop_workspace(lib, B, H, W, Cin, Cout, KH, KW, pad, ups, device):
     """Scratch for the split-K path of the small layers (None when the shape is not split)."""
     nbytes = lib.rgbd_conv2d_fprop_workspace(B, H, W, Cin, Cout, KH, KW, pad, ups)
@@ -304,6 +328,54 @@ def linear_bwd(dy, y, x, w, c, act, want_dx=True, dw=None, db=None, slope=0.2):
 
 
 # ------------------------------------------------------------------ AdaIN
+class _ZeroArena:
+    """Zero-initialised fp32 scratch handed out in slices while a training phase is active.
+
+    Kernels that accumulate with atomics (the AdaIN strip sums) need cleared memory; inside `with zero_arena.phase(dev)`
+    ONE clear of the arena's used prefix replaces one clear per call.  The clear covers the high-water mark of all
+    earlier phases, which has converged by the time a phase is captured into a HIP graph (two eager runs come first),
+    so every captured phase clears at least what it uses.  Outside a phase `take` returns fresh zeros."""
+
+    def __init__(self, nfloats=1 << 21):
+        self.nfloats = nfloats
+        self.buf, self.high, self.pos, self.active = {}, {}, {}, {}
+
+    def _key(self, device):
+        device = torch.device(device)
+        key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+        if key not in self.buf:
+            self.buf[key] = torch.zeros(self.nfloats, dtype=F32, device=device)
+            self.high[key], self.pos[key], self.active[key] = 0, 0, False
+        return key
+
+    def phase(self, device):
+        arena, key = self, self._key(device)
+
+        class _Phase:
+            def __enter__(self_):
+                if arena.high[key] > 0:
+                    rc = _lib.load().rgbd_zero_f32(_ptr(arena.buf[key]), arena.high[key], _stream())
+                    _lib.check(rc, "rgbd_zero_f32")
+                arena.pos[key], arena.active[key] = 0, True
+
+            def __exit__(self_, *exc):
+                arena.active[key] = False
+        return _Phase()
+
+    def take(self, n, device):
+        key = self._key(device)
+        n4 = (n + 3) // 4 * 4
+        if not self.active[key] or self.pos[key] + n4 > self.nfloats:
+            return torch.zeros(n, dtype=F32, device=device)
+        out = self.buf[key][self.pos[key]:self.pos[key] + n]
+        self.pos[key] += n4
+        self.high[key] = max(self.high[key], self.pos[key])
+        return out
+
+
+zero_arena = _ZeroArena()
+
+
 def _off(t, nfloats):
     return ctypes.c_void_p(t.data_ptr() + 4 * nfloats)
 
@@ -317,7 +389,7 @@ def adain_fwd(x, scale, shift=None, eps=1e-5):
     if scale.shape != (B, 2 * C if fused else C):
         raise RuntimeError(f"adain_fwd: scale {tuple(scale.shape)} does not match x {tuple(x.shape)}")
     y = torch.empty_like(x)
-    sums = torch.empty(B, C, 2, dtype=F32, device=x.device)
+    sums = zero_arena.take(B * C * 2, x.device)
     mean = torch.empty(B, C, dtype=F32, device=x.device)
     rstd = torch.empty(B, C, dtype=F32, device=x.device)
     rc = _lib.load().rgbd_adain_fwd(_ptr(x), _ptr(scale), _off(scale, C) if fused else _ptr(shift), _ptr(y), _ptr(sums),
@@ -331,7 +403,7 @@ def adain_bwd(x, dy, scale, mean, rstd, fused=False):
     _chk(x, BF16, "x"); _chk(dy, BF16, "dy"); _chk(scale, F32, "scale")
     B, H, W, C = x.shape
     dx = torch.empty_like(x)
-    sums = torch.empty(B, C, 2, dtype=F32, device=x.device)
+    sums = zero_arena.take(B * C * 2, x.device)
     if fused:
         dss = torch.empty(B, 2 * C, dtype=F32, device=x.device)
         dscale, dshift, ld = _ptr(dss), _off(dss, C), 2 * C

@@ -143,6 +143,7 @@ class StyleGenerator(_Link):
         self.c0 = [None] + [Fn.ConvLayer(p[f"blocks/{i}/c0/c/W"], _inv_c(self.chans[i][1] * 9), 1)
                             for i in range(1, 6)]
         self.c1 = [Fn.ConvLayer(p[f"blocks/{i}/c1/c/W"], _inv_c(self.chans[i][0] * 9), 1) for i in range(6)]
+        self.pack_group = Fn.PackGroup(self.c0 + self.c1)
 
     # -- pieces
     def _style(self, name, w, h):
@@ -288,6 +289,7 @@ class DCGANGenerator(_Link):
         p = self.store.params
         self.c0 = [Fn.ConvLayer(p[f"blocks/{i}/c0/c/W"], _inv_c(self.chans[i][1] * 9), 1) for i in range(5)]
         self.c1 = [Fn.ConvLayer(p[f"blocks/{i}/c1/c/W"], _inv_c(self.chans[i][0] * 9), 1) for i in range(5)]
+        self.pack_group = Fn.PackGroup(self.c0 + self.c1)
         self.train = True
 
     def make_hidden(self, batch_size):
@@ -374,6 +376,7 @@ class Discriminator(_Link):
             for nm in (("c0", "c1", "c_sc") if res else ("c0", "c1")):
                 cin = co if nm == "c1" else ci
                 self.conv[f"blocks/{i}/{nm}"] = Fn.ConvLayer(p[f"blocks/{i}/{nm}/c/W"], _inv_c(cin * 9), 1)
+        self.pack_group = Fn.PackGroup(list(self.conv.values()))
 
     def _from_rgb(self, i, x):
         """ins[i]: 1x1 conv 3 -> C on the NCHW fp32 image, + bias, leaky ReLU, to NHWC bf16 (one HBM-bound kernel)."""

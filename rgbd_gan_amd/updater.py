@@ -20,6 +20,7 @@ import torch
 import torch.nn.functional as F
 
 from . import functional as Fn
+from . import kernels
 from .common.utils.copy_param import soft_copy_param
 from .common.loss_functions import LossFuncRotate, loss_func_dcgan_dis, loss_func_dcgan_gen, loss_l2
 
@@ -214,6 +215,10 @@ class RGBDUpdater:
 
     # ---- the three phases of a step (each one is capturable: device work only, fixed launch sequence)
     def _gen_phase(self, st):
+        with kernels.zero_arena.phase(self.device):
+            self._gen_phase_body(st)
+
+    def _gen_phase_body(self, st):
         cfg = self.config
         stage, B, half = st["stage"], st["B"], st["B"] // 2
         self.gen.cleargrads()
