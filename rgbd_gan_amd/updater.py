@@ -298,8 +298,13 @@ class RGBDUpdater:
                 return
             graph = torch.cuda.CUDAGraph()
             saved = dict(self.observation)
+            # data parallel: let the collectives that overlap this phase finish first, and keep the capture local to
+            # this thread so the communicator's watchdog thread (event queries) cannot invalidate it
+            for opt in self._optimizers.values():
+                if getattr(opt, "_pending", None) is not None:
+                    opt.comm.wait(opt._pending)
             try:
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     fn(st)
             except Exception as exc:      # capture refused (driver / collective library state): stay correct, go eager
                 import sys
