@@ -3,8 +3,10 @@
 This package restates, in NumPy and torch-CPU fp32, the arithmetic that the
 reference (nogu-atsu/RGBD-GAN, Chainer/CuPy) performs on the path
 ``RGBDUpdater.update_core`` (updater.py:274-448) -> generator / discriminator
-(net.py) -> ``LossFuncRotate`` (common/loss_functions.py:31-228).  Each function
-cites the reference file:line it follows.
+(net.py) -> ``LossFuncRotate`` (common/loss_functions.py:31-228), and on the
+DeepVoxels variant ``DeepVoxelsUpdater.update_core`` (updater_deepvoxels.py:123-252)
+-> ``deepvoxels_generator.Generator`` -> deepvoxel/projection.py, deepvoxel/deepvoxel.py.
+Each function cites the reference file:line it follows.
 
 * It is the checker, never the product: only ``tests/``,
   ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may

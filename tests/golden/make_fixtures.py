@@ -11,7 +11,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
-from oracle import camera, warp_loss  # noqa: E402
+from oracle import camera, deepvoxels, warp_loss  # noqa: E402
 
 
 def warp_case(seed, b, S, occ, lam):
@@ -38,7 +38,38 @@ def warp_case(seed, b, S, occ, lam):
                 grad_img=ti.grad.numpy(), grad_img_rot=tr.grad.numpy())
 
 
+def deepvoxels_case(seed):
+    """A small frustum (16x16 image, 8^3 grid, 14 depth samples): projection indices / coordinates, resampled
+    volume, compositing outputs and first-order gradients."""
+    fr = deepvoxels.Frustum(grid_dim=8, img=16)
+    rng = np.random.RandomState(seed)
+    th = np.zeros((2, 6), "float32")
+    th[:, 0] = rng.uniform(-0.3, 0.3, 2)
+    th[:, 1] = rng.uniform(-2.0, 2.0, 2)
+    cams = camera.camera_matrices(th)
+    g = torch.Generator().manual_seed(seed)
+    F = 4
+    grid = torch.randn(2, F, 8, 8, 8, generator=g)
+    W1 = torch.randn(4, F + 1, generator=g)
+    b1 = torch.randn(4, generator=g) * 0.1
+    W2 = torch.randn(1, 4, generator=g) * 2
+    b2 = torch.full((1,), 3.0)
+    out = dict(thetas=th, cams=cams, grid=grid.numpy(), W1=W1.numpy(), b1=b1.numpy(), W2=W2.numpy(), b2=b2.numpy(),
+               grid_dim=np.array(8), img=np.array(16), depth=np.array(fr.depth), voxel_size=np.array(fr.voxel_size),
+               near_plane=np.array(fr.near_plane))
+    for i in range(2):
+        lin, v = deepvoxels.proj_idcs_np(cams[i], fr)
+        gi = grid[i:i + 1].clone().requires_grad_(True)
+        vol = deepvoxels.trilinear_torch(gi, lin, v, fr)
+        feat, depth, w = deepvoxels.occlusion_torch(vol, W1, b1, W2, b2, fr)
+        (feat.sum() + 2.0 * depth.sum()).backward()
+        out.update({f"lin{i}": lin, f"coords{i}": v, f"vol{i}": vol.detach().numpy(), f"feat{i}": feat.detach().numpy(),
+                    f"depth{i}": depth.detach().numpy(), f"weights{i}": w.detach().numpy(), f"dgrid{i}": gi.grad.numpy()})
+    return out
+
+
 def main():
+    np.savez_compressed(os.path.join(HERE, "deepvoxels_small.npz"), **deepvoxels_case(103))
     np.savez_compressed(os.path.join(HERE, "warp_loss_b2_s16_occ.npz"), **warp_case(101, 2, 16, True, 3.0))
     np.savez_compressed(os.path.join(HERE, "warp_loss_b3_s8.npz"), **warp_case(102, 3, 8, False, 2.0))
     np.random.seed(7)
