@@ -20,6 +20,7 @@ from . import kernels
 
 _WEIGHT_EPOCH = 0          # bumped whenever master weights change (optimizer step, checkpoint load)
 _SKIP_WGRAD = False        # set while only input gradients are wanted (R1's inner grad)
+_FROZEN_PTRS = frozenset()  # parameters (by storage address) whose gradients the current backward must not produce
 
 
 def bump_weight_epoch():
@@ -37,6 +38,24 @@ def input_grads_only():
         yield
     finally:
         _SKIP_WGRAD = old
+
+
+@contextlib.contextmanager
+def weight_grads_frozen(link):
+    """Inside, backward passes skip the weight / bias gradients of `link`'s parameters although the forward recorded
+    them as differentiable: the generator step differentiates D(x_fake) w.r.t. its input only, and the SAME recorded
+    forward is differentiated w.r.t. the discriminator's weights later, in the discriminator step."""
+    global _FROZEN_PTRS
+    old = _FROZEN_PTRS
+    _FROZEN_PTRS = old | frozenset(p.data_ptr() for p in link.params())
+    try:
+        yield
+    finally:
+        _FROZEN_PTRS = old
+
+
+def _skip_grad_of(p):
+    return _SKIP_WGRAD or (p is not None and p.data_ptr() in _FROZEN_PTRS)
 
 
 class ConvLayer:
@@ -148,7 +167,7 @@ class _ConvFprop(torch.autograd.Function):
         dy = dy.contiguous()
         dx = _ConvDgrad.apply(dy, w, ctx.layer, ctx.ups) if ctx.needs_input_grad[0] else None
         dw = None
-        if ctx.needs_input_grad[1] and not _SKIP_WGRAD:
+        if ctx.needs_input_grad[1] and not _skip_grad_of(w):
             if _direct_grad(w):
                 _wgrad_into(x, dy, w, ctx.layer, ctx.ups)
             else:
@@ -171,7 +190,7 @@ class _ConvDgrad(torch.autograd.Function):
         ddx = ddx.contiguous()
         g_dy = _ConvFprop.apply(ddx, w, ctx.layer, ctx.ups) if ctx.needs_input_grad[0] else None
         g_w = None
-        if ctx.needs_input_grad[1] and not _SKIP_WGRAD:
+        if ctx.needs_input_grad[1] and not _skip_grad_of(w):
             if _direct_grad(w):
                 _wgrad_into(ddx, dy, w, ctx.layer, ctx.ups)
             else:
@@ -347,7 +366,7 @@ class _ConvBiasAct(torch.autograd.Function):
     def backward(ctx, dy):
         x, w, y, bias = ctx.saved_tensors
         layer, ups = ctx.layer, ctx.ups
-        want_b = ctx.needs_input_grad[2] and not _SKIP_WGRAD
+        want_b = ctx.needs_input_grad[2] and not _skip_grad_of(bias)
         dx = dw = db = dres = None
         dy = dy.contiguous()
         fast_b = want_b and _direct_grad(bias)          # bias gradient rides along in the same pass
@@ -367,7 +386,7 @@ class _ConvBiasAct(torch.autograd.Function):
             db = _ColSum.apply(dz)
         if ctx.needs_input_grad[0]:
             dx = _ConvDgrad.apply(dz, w, layer, ups)
-        if ctx.needs_input_grad[1] and not _SKIP_WGRAD:
+        if ctx.needs_input_grad[1] and not _skip_grad_of(w):
             if _direct_grad(w):
                 _wgrad_into(x, dz, w, layer, ups)
             else:
@@ -404,7 +423,7 @@ class _FromPlanes(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = _ToPlanes.apply(dz, w.t(), None, ctx.scale)
-        if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and not _SKIP_WGRAD:
+        if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and not _skip_grad_of(w):
             o, ts = _PlanesOuter.apply(dz, x, ctx.has_bias)
             dw = o.t() * ctx.scale
             db = ts if ctx.has_bias else None
@@ -428,10 +447,10 @@ class _ToPlanes(torch.autograd.Function):
         dh = dw = db = None
         if ctx.needs_input_grad[0]:
             dh = _FromPlanes.apply(dout, w.t(), None, ctx.scale, False)
-        if ctx.needs_input_grad[1] and not _SKIP_WGRAD:
+        if ctx.needs_input_grad[1] and not _skip_grad_of(w):
             o, _ = _PlanesOuter.apply(h, dout, False)
             dw = o * ctx.scale
-        if ctx.has_bias and ctx.needs_input_grad[2] and not _SKIP_WGRAD:
+        if ctx.has_bias and ctx.needs_input_grad[2] and not _skip_grad_of(w):
             db = dout.sum(dim=(0, 2, 3))
         return dh, dw, db, None
 

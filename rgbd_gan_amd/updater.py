@@ -232,10 +232,16 @@ class RGBDUpdater:
         with torch.no_grad():
             st["x_real"] = downsize_real(st["x_real_full"], stage).contiguous()
         x_fake = self.gen(z, stage, st["theta9"])
-        with self.dis.frozen():
-            y_fake, _ = self.dis(x_fake[:, :3], stage=stage, return_hidden=True)
-        loss_gen = loss_func_dcgan_gen(y_fake)
-        obs["gen/loss_adv"] = loss_gen.detach()
+        # D(x_fake) is recorded ONCE per step: here it is differentiated w.r.t. its input (generator loss), in the
+        # discriminator phase the same recorded forward is differentiated w.r.t. D's weights.  The reference runs the
+        # discriminator on the same fakes twice (updater.py:331,404-405) with identical weights and identical values.
+        x_d = x_fake[:, :3].detach().contiguous().requires_grad_(True)
+        y_fake, _ = self.dis(x_d, stage=stage, return_hidden=True)
+        loss_adv = loss_func_dcgan_gen(y_fake)
+        obs["gen/loss_adv"] = loss_adv.detach()
+        with Fn.weight_grads_frozen(self.dis):
+            gx, = torch.autograd.grad(loss_adv, x_d, retain_graph=True)
+        heads, seeds = [x_fake[:, :3]], [gx]
         if st["use_rotate"]:
             loss_rotate = self.loss_func_rotate.loss_from_coefficients(x_fake[:half], x_fake[half:], st["coef"],
                                                                        st["occlusion"])
@@ -246,19 +252,23 @@ class RGBDUpdater:
             obs["gen/loss_rotate"] = loss_rotate.detach()
             lambda_rotate = cfg.lambda_rotate if cfg.lambda_rotate else 2
             lambda_rotate = lambda_rotate if st["x_real"].shape[2] <= 128 else lambda_rotate * 2
-            loss_gen = loss_gen + loss_rotate * lambda_rotate
+            heads.append(loss_rotate * lambda_rotate)
+            seeds.append(None)
             if cfg.use_occupancy_net_loss:
                 raise AssertionError("occupancy-net loss is not supported")
         if cfg.optical_flow:
             raise AssertionError("optical flow loss is not supported")
-        loss_gen.backward()
+        torch.autograd.backward(heads, seeds)
+        st["y_fake"] = y_fake if st.get("share_dfake", True) else None
         st["x_fake_data"] = x_fake.detach()
 
     def _dis_phase(self, st):
         stage = st["stage"]
         obs = self.observation
         self.dis.cleargrads()
-        y_fake = self.dis(st["x_fake_data"][:, :3].contiguous(), stage=stage)
+        y_fake = st.get("y_fake")
+        if y_fake is None:               # phase called on its own: record the forward here
+            y_fake = self.dis(st["x_fake_data"][:, :3].contiguous(), stage=stage)
         x_real_v = st["x_real"].detach().requires_grad_(True)
         y_real = self.dis(x_real_v, stage=stage)
         loss_dis = loss_func_dcgan_dis(y_fake, y_real)
@@ -378,6 +388,9 @@ class RGBDUpdater:
             st["x_real_full"] = self._stagers[skey]
             key = (batch_size, fl, use_rotate, occlusion, tuple(x_real_data.shape), z_fake_data is not None)
 
+        # the recorded D(x_fake) forward may only be shared when both phases run the same way (both replayed from
+        # graphs captured in the same iteration, or both eager)
+        st["share_dfake"] = key is None or (("gen" in self.graph_phases) == ("dis" in self.graph_phases))
         self._run_phase("gen", self._gen_phase, st, key)
         if opt_g_m is not None:
             opt_g_m.start_allreduce()
