@@ -232,15 +232,29 @@ class RGBDUpdater:
         with torch.no_grad():
             st["x_real"] = downsize_real(st["x_real_full"], stage).contiguous()
         x_fake = self.gen(z, stage, st["theta9"])
-        # D(x_fake) is recorded ONCE per step: here it is differentiated w.r.t. its input (generator loss), in the
-        # discriminator phase the same recorded forward is differentiated w.r.t. D's weights.  The reference runs the
-        # discriminator on the same fakes twice (updater.py:331,404-405) with identical weights and identical values.
+        # D(x_fake) is evaluated and differentiated ONCE per step.  The reference runs the discriminator on the same
+        # fakes twice with identical weights (updater.py:331,404-405) and back-propagates twice: once from the
+        # generator's loss (to the image) and once from the discriminator's loss (to D's weights).  D treats samples
+        # independently (no batch statistics), so both backward passes are the same linear map applied to per-sample
+        # seeds dL/dy_b; one pass seeded with the discriminator's dL_D/dy_b yields D's weight gradients AND, rescaled
+        # per sample by (dL_G/dy_b) / (dL_D/dy_b), the generator's image gradient.
         x_d = x_fake[:, :3].detach().contiguous().requires_grad_(True)
         y_fake, _ = self.dis(x_d, stage=stage, return_hidden=True)
-        loss_adv = loss_func_dcgan_gen(y_fake)
-        obs["gen/loss_adv"] = loss_adv.detach()
-        with Fn.weight_grads_frozen(self.dis):
-            gx, = torch.autograd.grad(loss_adv, x_d, retain_graph=True)
+        obs["gen/loss_adv"] = loss_func_dcgan_gen(y_fake.detach())
+        # seeds from logits clamped at -60: below that the generator's seed -sigmoid(-y)/B equals -1/B to fp32
+        # precision and the discriminator's sigmoid(y)/B is < 1e-26/B either way, but their ratio stays finite
+        # (an unclamped logit of -90 would give 0 * inf)
+        y_leaf = y_fake.detach().clamp(min=-60.0).requires_grad_(True)
+        seed_g, = torch.autograd.grad(loss_func_dcgan_gen(y_leaf), y_leaf)
+        if st.get("share_dfake", True):
+            seed_d, = torch.autograd.grad(torch.sum(F.softplus(y_leaf)) / y_leaf.numel(), y_leaf)
+            torch.autograd.backward([y_fake], [seed_d], inputs=[x_d] + list(self.dis.params()))
+            gx = x_d.grad * (seed_g / seed_d).reshape(-1, 1, 1, 1)
+            st["loss_dfake"] = torch.sum(F.softplus(y_fake.detach())) / y_fake.numel()   # fake term of loss_func_dcgan_dis
+        else:
+            with Fn.weight_grads_frozen(self.dis):
+                gx, = torch.autograd.grad([y_fake], [x_d], [seed_g])
+            st["loss_dfake"] = None
         heads, seeds = [x_fake[:, :3]], [gx]
         if st["use_rotate"]:
             loss_rotate = self.loss_func_rotate.loss_from_coefficients(x_fake[:half], x_fake[half:], st["coef"],
@@ -259,19 +273,23 @@ class RGBDUpdater:
         if cfg.optical_flow:
             raise AssertionError("optical flow loss is not supported")
         torch.autograd.backward(heads, seeds)
-        st["y_fake"] = y_fake if st.get("share_dfake", True) else None
         st["x_fake_data"] = x_fake.detach()
 
     def _dis_phase(self, st):
         stage = st["stage"]
         obs = self.observation
-        self.dis.cleargrads()
-        y_fake = st.get("y_fake")
-        if y_fake is None:               # phase called on its own: record the forward here
-            y_fake = self.dis(st["x_fake_data"][:, :3].contiguous(), stage=stage)
         x_real_v = st["x_real"].detach().requires_grad_(True)
         y_real = self.dis(x_real_v, stage=stage)
-        loss_dis = loss_func_dcgan_dis(y_fake, y_real)
+        if st.get("loss_dfake") is not None:
+            # the fake half of loss_func_dcgan_dis was differentiated in the generator phase (its weight gradients
+            # are already in D's gradient buffer, which is cleared at the start of the step)
+            loss_dis = torch.sum(F.softplus(-y_real)) / y_real.numel()
+            reported = loss_dis.detach() + st["loss_dfake"]
+        else:
+            self.dis.cleargrads()
+            y_fake = self.dis(st["x_fake_data"][:, :3].contiguous(), stage=stage)
+            loss_dis = loss_func_dcgan_dis(y_fake, y_real)
+            reported = loss_dis.detach()
         if not self.dis.sn and self.lambda_gp > 0:
             with Fn.input_grads_only():
                 grad_x, = torch.autograd.grad([y_real.sum()], [x_real_v], create_graph=True)
@@ -279,7 +297,8 @@ class RGBDUpdater:
             loss_gp = self.lambda_gp * loss_l2(grad_l2, 0.0)
             obs["dis/loss_gp"] = loss_gp.detach()
             loss_dis = loss_dis + loss_gp
-        obs["dis/loss_adv"] = loss_dis.detach()
+            reported = reported + loss_gp.detach()
+        obs["dis/loss_adv"] = reported
         loss_dis.backward()
 
     def _opt_phase(self, st):
