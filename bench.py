@@ -23,8 +23,9 @@ if ROOT not in sys.path:
 # 3 F_G + 11 F_D with F_G = 10.45, F_D = 24.11 GFLOP is the step as the reference executes it minus D's weight
 # gradients in the generator step.  This engine evaluates and back-propagates D(x_fake) once instead of twice (the
 # reference's second forward recomputes identical values, and its two input-gradient passes differ by a per-sample
-# scalar), so it EXECUTES 3 F_G + 9 F_D; the whole-step roofline fraction is reported on executed work.
-STEP_GFLOP_PER_IMAGE = 296.6 - 2 * 24.11
+# scalar), and folds the adversarial backward on the reals into the R1 double backward (again a per-sample scalar),
+# so it EXECUTES 3 F_G + 7 F_D; the whole-step roofline fraction is reported on executed work.
+STEP_GFLOP_PER_IMAGE = 296.6 - 4 * 24.11
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 

@@ -139,11 +139,17 @@ int rgbd_adain_bwd(const void* x, const void* dy, const float* scale, const floa
 /* ------------------------------------------------------------------ small fused elementwise / 1x1 kernels (HBM-bound)
  * rgbd_lrelu_bwd: dz = dy * (y > 0 ? 1 : slope) on channels [0, act_channels) of (M,C) bf16 tensors, pass-through on
  *   the rest (backward of F.leaky_relu, net.py:152,159,410,416, evaluated from the activation's OUTPUT).
- * rgbd_colsum_bf16: out[c] = sum_m x[m][c] (fp32): bias gradients of the convs.
+ * rgbd_colsum_bf16: out[c] = sum_m w(m) x[m][c] (fp32): bias gradients of the convs; w(m) = row_scale[m / rows_per_sample]
+ *   (per-sample weights) or 1 when row_scale is NULL.
  */
 int rgbd_lrelu_bwd(const void* dy, const void* y, void* dz, int64_t M, int C, int act_channels, float slope,
                    float* bias_grad /* NULL, or (C) fp32: += column sums of dz in the same pass */, void* stream);
-int rgbd_colsum_bf16(const void* x, float* out, int64_t M, int C, int accumulate, void* stream);
+int rgbd_colsum_bf16(const void* x, float* out, int64_t M, int C, int accumulate, const float* row_scale,
+                     int64_t rows_per_sample, void* stream);
+/* out = a + s[sample] * x on (B, elems_per_sample) bf16 tensors: folds the adversarial term of the discriminator loss
+ * into the operand of the R1 double-backward weight gradients (see rgbd_gan_amd/functional.py:adversarial_injection). */
+int rgbd_axpy_rows_bf16(const void* a, const void* x, const float* s, void* out, int64_t B, int64_t elems_per_sample,
+                        void* stream);
 
 /* 2x2 average pooling of the discriminator blocks (rescale.py:12-13) fused with the leaky-ReLU that precedes it:
  *   rgbd_unpool2_lrelu_bwd: dz[b,h,w,c] = 0.25 * dp[b,h/2,w/2,c] * lrelu'(y[b,h,w,c])   (y NULL: no mask); bias_grad as above

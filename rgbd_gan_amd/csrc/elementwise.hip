@@ -400,17 +400,32 @@ __global__ __launch_bounds__(256) void pool2_masked_kernel(const unsigned short*
 
 // column sums of an (M, C) bf16 matrix -> out[C] fp32 (atomics; out zeroed by the caller): bias gradients.
 __global__ __launch_bounds__(256) void colsum_kernel(const unsigned short* __restrict__ x, float* __restrict__ out,
-                                                     long M, int C, int rows_per_block) {
+                                                     long M, int C, int rows_per_block,
+                                                     const float* __restrict__ row_scale, long rows_per_sample) {
+    // out[c] += sum_r w(r) * x[r][c], w(r) = row_scale[r / rows_per_sample] (1 when row_scale is null)
     const int cg = blockIdx.y;
     const int chunk = threadIdx.x & 7, lane_p = threadIdx.x >> 3;
     const int c0 = cg * 64 + chunk * 8;
     const long r_begin = (long)blockIdx.x * rows_per_block;
     const long r_end = min(M, r_begin + rows_per_block);
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (long r = r_begin + lane_p; r < r_end; r += 32) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(x + r * C + c0);
+    for (long r0 = r_begin + lane_p; r0 < r_end; r0 += 128) {
+        u32x4 v[4];
+        float wgt[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { s[2 * k] += bf16_lo(v[k]); s[2 * k + 1] += bf16_hi(v[k]); }
+        for (int u = 0; u < 4; ++u) {
+            const long r = r0 + 32 * u;
+            const long rc = r < r_end ? r : r0;
+            v[u] = *reinterpret_cast<const u32x4*>(x + rc * C + c0);
+            wgt[u] = r < r_end ? (row_scale ? row_scale[rc / rows_per_sample] : 1.f) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s[2 * k] += wgt[u] * bf16_lo(v[u][k]);
+                s[2 * k + 1] += wgt[u] * bf16_hi(v[u][k]);
+            }
     }
     __shared__ float red[32][65];
 #pragma unroll
@@ -421,6 +436,23 @@ __global__ __launch_bounds__(256) void colsum_kernel(const unsigned short* __res
 #pragma unroll 8
         for (int r = 0; r < 32; ++r) acc += red[r][threadIdx.x];
         atomicAdd(out + cg * 64 + threadIdx.x, acc);
+    }
+}
+
+// out[r][c] = a[r][c] + s[r / rows_per_sample] * x[r][c]   (bf16 in / out, fp32 arithmetic)
+__global__ __launch_bounds__(256) void axpy_rows_kernel(const unsigned short* __restrict__ a,
+                                                        const unsigned short* __restrict__ x,
+                                                        const float* __restrict__ s, unsigned short* __restrict__ out,
+                                                        long nvec, long vec_per_sample) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nvec; e += (long)gridDim.x * 256) {
+        const float sc = s[e / vec_per_sample];
+        const u32x4 av = *reinterpret_cast<const u32x4*>(a + e * 8);
+        const u32x4 xv = *reinterpret_cast<const u32x4*>(x + e * 8);
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            o[k] = pack_bf16x2(bf16_lo(av[k]) + sc * bf16_lo(xv[k]), bf16_hi(av[k]) + sc * bf16_hi(xv[k]));
+        *reinterpret_cast<u32x4*>(out + e * 8) = o;
     }
 }
 
@@ -873,18 +905,33 @@ extern "C" int rgbd_lrelu_bwd(const void* dy, const void* y, void* dz, int64_t M
     return 0;
 }
 
-extern "C" int rgbd_colsum_bf16(const void* x, float* out, int64_t M, int C, int accumulate, void* stream) {
+extern "C" int rgbd_colsum_bf16(const void* x, float* out, int64_t M, int C, int accumulate, const float* row_scale,
+                                int64_t rows_per_sample, void* stream) {
     RGBD_REQUIRE(x && out, "rgbd_colsum_bf16: null pointer");
     RGBD_REQUIRE(M > 0 && C > 0 && C % 64 == 0, "rgbd_colsum_bf16: C must be a multiple of 64 (C=%d)", C);
+    RGBD_REQUIRE(!row_scale || rows_per_sample > 0, "rgbd_colsum_bf16: rows_per_sample must be positive with row_scale");
     hipStream_t st = (hipStream_t)stream;
     if (!accumulate && rgbd_zero_async(out, (size_t)C * sizeof(float), st) != hipSuccess) {
         rgbd_set_error("rgbd_colsum_bf16: memset failed");
         return -2;
     }
-    const int rows = 2048;
+    const int rows = 512;
     dim3 grid(ceil_div(M, rows), C / 64);
-    colsum_kernel<<<grid, 256, 0, st>>>((const unsigned short*)x, out, M, C, rows);
+    colsum_kernel<<<grid, 256, 0, st>>>((const unsigned short*)x, out, M, C, rows, row_scale,
+                                        row_scale ? rows_per_sample : 1);
     RGBD_CHECK_LAUNCH("colsum_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_axpy_rows_bf16(const void* a, const void* x, const float* s, void* out, int64_t B,
+                                   int64_t elems_per_sample, void* stream) {
+    RGBD_REQUIRE(a && x && s && out, "rgbd_axpy_rows_bf16: null pointer");
+    RGBD_REQUIRE(B > 0 && elems_per_sample > 0 && elems_per_sample % 8 == 0,
+                 "rgbd_axpy_rows_bf16: elements per sample must be a multiple of 8");
+    const long nvec = B * elems_per_sample / 8;
+    axpy_rows_kernel<<<(int)min((long)4096, (nvec + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        (const unsigned short*)a, (const unsigned short*)x, s, (unsigned short*)out, nvec, elems_per_sample / 8);
+    RGBD_CHECK_LAUNCH("axpy_rows_kernel");
     return 0;
 }
 

@@ -21,6 +21,7 @@ from . import kernels
 _WEIGHT_EPOCH = 0          # bumped whenever master weights change (optimizer step, checkpoint load)
 _SKIP_WGRAD = False        # set while only input gradients are wanted (R1's inner grad)
 _FROZEN_PTRS = frozenset()  # parameters (by storage address) whose gradients the current backward must not produce
+_INJECT = None             # per-sample seeds (B,) fp32 of the adversarial loss while the R1 double backward runs
 
 
 def bump_weight_epoch():
@@ -52,6 +53,26 @@ def weight_grads_frozen(link):
         yield
     finally:
         _FROZEN_PTRS = old
+
+
+@contextlib.contextmanager
+def adversarial_injection(seeds):
+    """Fold the adversarial term of the discriminator loss into the R1 double backward (updater.py:405-422).
+
+    With s_b = dL_adv/dy_b and dz1 the gradients of the R1 first-order pass (seed 1 per sample), the adversarial
+    backward through D(x_real) is s_b * dz1 sample by sample (D has no batch coupling), so for every convolution
+        dW = wgrad(ddx, dz1)  [R1 double backward]  +  wgrad(x, s_b * dz1)  [adversarial]  =  wgrad(ddx + s_b * x, dz1)
+        db = sum_b s_b * colsum_b(dz1)
+    i.e. the second input-gradient chain and the second weight-gradient pass of the reference's loss_dis.backward()
+    are replaced by one elementwise operand update per layer.  Inside this context the double-backward nodes that
+    know their forward input apply exactly that."""
+    global _INJECT
+    old = _INJECT
+    _INJECT = seeds.reshape(-1).float().contiguous()
+    try:
+        yield
+    finally:
+        _INJECT = old
 
 
 def _skip_grad_of(p):
@@ -176,9 +197,13 @@ class _ConvFprop(torch.autograd.Function):
 
 
 class _ConvDgrad(torch.autograd.Function):
+    """dx = dgrad(dy, W).  `x_fwd` / `bias` (optional, not differentiated here) are the forward input and the bias of
+    the convolution this node is the input gradient of: the adversarial injection needs them."""
+
     @staticmethod
-    def forward(ctx, dy, w, layer, ups):
+    def forward(ctx, dy, w, layer, ups, x_fwd=None, bias=None):
         ctx.layer, ctx.ups = layer, ups
+        ctx.x_fwd, ctx.bias = x_fwd, bias
         ctx.save_for_backward(dy, w)
         _, wd = layer.packed()
         dx = kernels.conv2d_dgrad(dy.contiguous(), wd, layer.K, layer.pad)
@@ -191,11 +216,21 @@ class _ConvDgrad(torch.autograd.Function):
         g_dy = _ConvFprop.apply(ddx, w, ctx.layer, ctx.ups) if ctx.needs_input_grad[0] else None
         g_w = None
         if ctx.needs_input_grad[1] and not _skip_grad_of(w):
+            operand = ddx
+            if _INJECT is not None and ctx.x_fwd is not None:
+                if ctx.ups or not _direct_grad(w):
+                    raise RuntimeError("adversarial injection needs plain (non-upsampling) convs with bound gradients")
+                operand = kernels.axpy_rows(ddx, ctx.x_fwd.detach().contiguous(), _INJECT)
+                b = ctx.bias
+                if b is not None and not _skip_grad_of(b):
+                    if not _direct_grad(b):
+                        raise RuntimeError("adversarial injection needs bias gradients bound to the flat buffer")
+                    kernels.colsum(dy, out=b.grad, row_scale=_INJECT, rows_per_sample=dy.shape[1] * dy.shape[2])
             if _direct_grad(w):
-                _wgrad_into(ddx, dy, w, ctx.layer, ctx.ups)
+                _wgrad_into(operand, dy, w, ctx.layer, ctx.ups)
             else:
-                g_w = _ConvWgrad.apply(ddx, dy, ctx.layer, ctx.ups)
-        return g_dy, g_w, None, None
+                g_w = _ConvWgrad.apply(operand, dy, ctx.layer, ctx.ups)
+        return g_dy, g_w, None, None, None, None
 
 
 class _ConvWgrad(torch.autograd.Function):
@@ -281,15 +316,48 @@ def warp_loss(img, img_rot, coef, flags, lambda_geometric, max_depth=0.0, min_de
 
 def avg_pool2_nhwc(x):
     """rescale.py:12-13 on NHWC bf16 (differentiable, twice)."""
-    return _PoolMasked.apply(x, x, False)
+    return _PoolMasked.apply(x, x.detach(), False)
+
+
+class _MaskMul(torch.autograd.Function):
+    """dy * mask with a constant mask: linear in dy, its own adjoint."""
+
+    @staticmethod
+    def forward(ctx, dy, mask):
+        ctx.save_for_backward(mask)
+        return dy * mask
+
+    @staticmethod
+    def backward(ctx, g):
+        mask, = ctx.saved_tensors
+        return _MaskMul.apply(g, mask), None
+
+
+class _Lrelu(torch.autograd.Function):
+    """Leaky ReLU (slope 0.2) on small fp32 tensors whose backward keeps no autograd edge to the input: the slope mask
+    is a constant of the backward graph (torch's own double backward hands an all-zero gradient to the input, which
+    makes a later backward walk the whole network behind it)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y = F.leaky_relu(x, 0.2)
+        ctx.save_for_backward(torch.where(x > 0, 1.0, 0.2).to(x.dtype))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        mask, = ctx.saved_tensors
+        return _MaskMul.apply(dy, mask)
 
 
 def lrelu(x):
-    return F.leaky_relu(x, 0.2)
+    return _Lrelu.apply(x)
 
 
 class _LreluGrad(torch.autograd.Function):
-    """dz = dy * lrelu'(.) evaluated from the activation OUTPUT y; linear in dy, so its own backward is itself."""
+    """dz = dy * lrelu'(.) evaluated from the activation OUTPUT y; linear in dy, so its own backward is itself.
+    Callers pass y DETACHED: the mask is piecewise constant in y (zero derivative almost everywhere), and an autograd
+    edge to y would make a later backward walk the whole recorded forward with all-zero gradients."""
 
     @staticmethod
     def forward(ctx, dy, y, act_channels):
@@ -300,7 +368,7 @@ class _LreluGrad(torch.autograd.Function):
     @staticmethod
     def backward(ctx, ddz):
         y, = ctx.saved_tensors
-        return _LreluGrad.apply(ddz.contiguous(), y, ctx.act_channels), None, None
+        return _LreluGrad.apply(ddz.contiguous(), y.detach(), ctx.act_channels), None, None
 
 
 class _ColSum(torch.autograd.Function):
@@ -327,7 +395,7 @@ class _UnpoolLreluGrad(torch.autograd.Function):
     @staticmethod
     def backward(ctx, ddz):
         y, = ctx.saved_tensors
-        return _PoolMasked.apply(ddz.contiguous(), y, ctx.use_mask), None, None, None
+        return _PoolMasked.apply(ddz.contiguous(), y.detach(), ctx.use_mask), None, None, None
 
 
 class _PoolMasked(torch.autograd.Function):
@@ -342,7 +410,7 @@ class _PoolMasked(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         y, = ctx.saved_tensors
-        return _UnpoolLreluGrad.apply(g.contiguous(), y, ctx.shape, ctx.use_mask), None, None
+        return _UnpoolLreluGrad.apply(g.contiguous(), y.detach(), ctx.shape, ctx.use_mask), None, None
 
 
 class _ConvBiasAct(torch.autograd.Function):
@@ -374,10 +442,10 @@ class _ConvBiasAct(torch.autograd.Function):
             if fast_b:
                 dz = kernels.unpool2_lrelu_bwd(dy, y if ctx.act else None, tuple(y.shape), bias_grad=bias.grad)
             else:
-                dz = _UnpoolLreluGrad.apply(dy, y, tuple(y.shape), ctx.act)
+                dz = _UnpoolLreluGrad.apply(dy, y.detach(), tuple(y.shape), ctx.act)
         elif ctx.act:
             dz = kernels.lrelu_bwd(dy, y, w.shape[0], bias_grad=bias.grad) if fast_b else \
-                _LreluGrad.apply(dy, y, w.shape[0])
+                _LreluGrad.apply(dy, y.detach(), w.shape[0])
         else:
             dz = dy
             if fast_b:
@@ -385,7 +453,7 @@ class _ConvBiasAct(torch.autograd.Function):
         if want_b and not fast_b:
             db = _ColSum.apply(dz)
         if ctx.needs_input_grad[0]:
-            dx = _ConvDgrad.apply(dz, w, layer, ups)
+            dx = _ConvDgrad.apply(dz, w, layer, ups, x.detach(), bias)
         if ctx.needs_input_grad[1] and not _skip_grad_of(w):
             if _direct_grad(w):
                 _wgrad_into(x, dz, w, layer, ups)
@@ -413,16 +481,17 @@ class _FromPlanes(torch.autograd.Function):
         x = x.contiguous()
         y = kernels.from_planes(x, w.contiguous(), bias.contiguous() if bias is not None else None, scale, act)
         ctx.scale, ctx.act, ctx.has_bias = scale, act, bias is not None
+        ctx.bias_ref = bias
         ctx.save_for_backward(x, w, y)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
-        dz = _LreluGrad.apply(dy.contiguous(), y, y.shape[-1]) if ctx.act else dy.contiguous()
+        dz = _LreluGrad.apply(dy.contiguous(), y.detach(), y.shape[-1]) if ctx.act else dy.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = _ToPlanes.apply(dz, w.t(), None, ctx.scale)
+            dx = _ToPlanes.apply(dz, w.t(), None, ctx.scale, x.detach(), ctx.bias_ref)
         if (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and not _skip_grad_of(w):
             o, ts = _PlanesOuter.apply(dz, x, ctx.has_bias)
             dw = o.t() * ctx.scale
@@ -431,12 +500,15 @@ class _FromPlanes(torch.autograd.Function):
 
 
 class _ToPlanes(torch.autograd.Function):
-    """out[b,k,p] = s * sum_c w[k][c] h[b,p,c] + bias[k]   (StyleGenerator.outs, net.py:186-191,270,289-290)."""
+    """out[b,k,p] = s * sum_c w[k][c] h[b,p,c] + bias[k]   (StyleGenerator.outs, net.py:186-191,270,289-290).
+    `inj_x` / `inj_bias`: when this node is the input gradient of a fromRGB layer, its forward image and bias (for the
+    adversarial injection, see adversarial_injection)."""
 
     @staticmethod
-    def forward(ctx, h, w, bias, scale):
+    def forward(ctx, h, w, bias, scale, inj_x=None, inj_bias=None):
         h = h.contiguous()
         ctx.scale, ctx.has_bias = scale, bias is not None
+        ctx.inj_x, ctx.inj_bias = inj_x, inj_bias
         ctx.save_for_backward(h, w)
         return kernels.to_planes(h, w.contiguous(), bias.contiguous() if bias is not None else None, scale)
 
@@ -448,11 +520,19 @@ class _ToPlanes(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dh = _FromPlanes.apply(dout, w.t(), None, ctx.scale, False)
         if ctx.needs_input_grad[1] and not _skip_grad_of(w):
-            o, _ = _PlanesOuter.apply(h, dout, False)
+            operand = dout
+            if _INJECT is not None and ctx.inj_x is not None:
+                operand = dout + _INJECT.reshape(-1, 1, 1, 1) * ctx.inj_x.detach()
+                b = ctx.inj_bias
+                if b is not None and not _skip_grad_of(b):
+                    if not _direct_grad(b):
+                        raise RuntimeError("adversarial injection needs bias gradients bound to the flat buffer")
+                    kernels.colsum(h, out=b.grad, row_scale=_INJECT, rows_per_sample=h.shape[1] * h.shape[2])
+            o, _ = _PlanesOuter.apply(h, operand.contiguous(), False)
             dw = o * ctx.scale
         if ctx.has_bias and ctx.needs_input_grad[2] and not _skip_grad_of(w):
             db = dout.sum(dim=(0, 2, 3))
-        return dh, dw, db, None
+        return dh, dw, db, None, None, None
 
 
 class _PlanesOuter(torch.autograd.Function):

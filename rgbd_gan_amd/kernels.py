@@ -233,15 +233,29 @@ def lrelu_bwd(dy, y, act_channels, slope=0.2, bias_grad=None):
     return dz
 
 
-def colsum(x, out=None):
-    """(.., C) bf16 -> (C,) fp32 column sums (added to `out` when given)."""
-    _chk(x, BF16, "x"); _chk(out, F32, "out")
+def colsum(x, out=None, row_scale=None, rows_per_sample=0):
+    """(.., C) bf16 -> (C,) fp32 column sums (added to `out` when given); with row_scale (B,) fp32 every row is weighted
+    by the entry of its sample (rows_per_sample consecutive rows per sample)."""
+    _chk(x, BF16, "x"); _chk(out, F32, "out"); _chk(row_scale, F32, "row_scale")
     C = x.shape[-1]
     acc = out is not None
     if out is None:
         out = torch.empty(C, dtype=F32, device=x.device)
-    rc = _lib.load().rgbd_colsum_bf16(_ptr(x), _ptr(out), x.numel() // C, C, int(acc), _stream())
+    rc = _lib.load().rgbd_colsum_bf16(_ptr(x), _ptr(out), x.numel() // C, C, int(acc), _ptr(row_scale),
+                                      int(rows_per_sample), _stream())
     _lib.check(rc, "rgbd_colsum_bf16")
+    return out
+
+
+def axpy_rows(a, x, s):
+    """a + s[b] * x for (B, ...) bf16 tensors, s (B,) fp32."""
+    _chk(a, BF16, "a"); _chk(x, BF16, "x"); _chk(s, F32, "s")
+    if a.shape != x.shape or s.numel() != a.shape[0]:
+        raise RuntimeError(f"axpy_rows: shapes {tuple(a.shape)} {tuple(x.shape)} {tuple(s.shape)}")
+    out = torch.empty_like(a)
+    rc = _lib.load().rgbd_axpy_rows_bf16(_ptr(a), _ptr(x), _ptr(s), _ptr(out), a.shape[0], a.numel() // a.shape[0],
+                                         _stream())
+    _lib.check(rc, "rgbd_axpy_rows_bf16")
     return out
 
 

@@ -378,6 +378,12 @@ class Discriminator(_Link):
                 self.conv[f"blocks/{i}/{nm}"] = Fn.ConvLayer(p[f"blocks/{i}/{nm}/c/W"], _inv_c(cin * 9), 1)
         self.pack_group = Fn.PackGroup(list(self.conv.values()))
 
+    def tail_params(self):
+        """Parameters of the dense tail after the conv stack (4x4 valid conv as a linear + the output linear), the part
+        of the discriminator that runs through torch ops."""
+        p = self.store.params
+        return [p["blocks/0/c1/c/W"], p["blocks/0/c1/c/b"], p["blocks/0/l2/c/W"], p["blocks/0/l2/c/b"]]
+
     def _from_rgb(self, i, x):
         """ins[i]: 1x1 conv 3 -> C on the NCHW fp32 image, + bias, leaky ReLU, to NHWC bf16 (one HBM-bound kernel)."""
         p = self.store.params

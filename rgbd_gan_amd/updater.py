@@ -14,6 +14,7 @@ Data-parallel: each optimizer's flat gradient buffer is all-reduced once (RCCL);
 right after the G backward and overlaps the D step's forward/backward (which only reads x_fake's values).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -280,25 +281,41 @@ class RGBDUpdater:
         obs = self.observation
         x_real_v = st["x_real"].detach().requires_grad_(True)
         y_real = self.dis(x_real_v, stage=stage)
-        if st.get("loss_dfake") is not None:
+        fake_done = st.get("loss_dfake") is not None
+        if fake_done:
             # the fake half of loss_func_dcgan_dis was differentiated in the generator phase (its weight gradients
             # are already in D's gradient buffer, which is cleared at the start of the step)
-            loss_dis = torch.sum(F.softplus(-y_real)) / y_real.numel()
-            reported = loss_dis.detach() + st["loss_dfake"]
+            y_fake = None
+            reported = torch.sum(F.softplus(-y_real.detach())) / y_real.numel() + st["loss_dfake"]
         else:
             self.dis.cleargrads()
             y_fake = self.dis(st["x_fake_data"][:, :3].contiguous(), stage=stage)
-            loss_dis = loss_func_dcgan_dis(y_fake, y_real)
-            reported = loss_dis.detach()
-        if not self.dis.sn and self.lambda_gp > 0:
+            reported = loss_func_dcgan_dis(y_fake.detach(), y_real.detach())
+        r1 = not self.dis.sn and self.lambda_gp > 0
+        if r1:
             with Fn.input_grads_only():
                 grad_x, = torch.autograd.grad([y_real.sum()], [x_real_v], create_graph=True)
             grad_l2 = torch.sqrt(torch.sum(grad_x ** 2, dim=(1, 2, 3)))
             loss_gp = self.lambda_gp * loss_l2(grad_l2, 0.0)
             obs["dis/loss_gp"] = loss_gp.detach()
-            loss_dis = loss_dis + loss_gp
             reported = reported + loss_gp.detach()
         obs["dis/loss_adv"] = reported
+        if r1 and fake_done and not os.environ.get("RGBD_NO_INJECT"):
+            # loss_dis = softplus(-y_real).mean() + loss_gp.  The adversarial term on the reals is not back-propagated
+            # through the recorded forward: its per-sample seeds are folded into the R1 double backward
+            # (functional.adversarial_injection); only the dense tail after the conv stack (torch ops) takes them
+            # the ordinary way.
+            y_leaf = y_real.detach().requires_grad_(True)
+            seed, = torch.autograd.grad(torch.sum(F.softplus(-y_leaf)) / y_leaf.numel(), y_leaf)
+            torch.autograd.backward([y_real], [seed], inputs=self.dis.tail_params(), retain_graph=True)
+            with Fn.adversarial_injection(seed):
+                loss_gp.backward()
+            return
+        loss_dis = torch.sum(F.softplus(-y_real)) / y_real.numel()
+        if y_fake is not None:
+            loss_dis = loss_dis + torch.sum(F.softplus(y_fake)) / y_fake.numel()
+        if r1:
+            loss_dis = loss_dis + loss_gp
         loss_dis.backward()
 
     def _opt_phase(self, st):
