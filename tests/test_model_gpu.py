@@ -112,8 +112,12 @@ CFG = dict(lambda_gp=1.0, lambda_depth=10, depth_min=1.0, lambda_geometric=None,
            start_rotation=2000, start_occlusion_aware=2000)
 
 
-def test_full_training_step_matches_oracle():
-    """One update_core (G step + D step + R1 + 3D loss + clipped Adam) at stage 10, B=4, on identical inputs."""
+@pytest.mark.parametrize("stage", [10.0, 9.5])
+def test_full_training_step_matches_oracle(stage):
+    """One update_core (G step + D step + R1 + 3D loss + clipped Adam) at stage 10 (and in the 64 -> 128 fade-in),
+    B=4, on identical inputs.  The oracle restates the reference step literally (D on the fakes twice, three separate
+    backward passes); the engine's single-pass dataflow must give the same losses, gradients
+    and update."""
     from rgbd_gan_amd.optimizer import FlatAdam
     from rgbd_gan_amd.updater import CameraParamPrior, RGBDUpdater
     from rgbd_gan_amd.utils.yaml_utils import Config
@@ -133,7 +137,7 @@ def test_full_training_step_matches_oracle():
     low = {k: 1e-5 for k in ("gen/l1/c/W", "gen/l1/c/b", "gen/l2/c/W", "gen/l2/c/b")}
     oopt = {"map": step.ChainerAdam(omap, 1e-5), "gen": step.ChainerAdam(ogen, 1e-3, alpha_override=low),
             "dis": step.ChainerAdam(dpl, 3e-3)}
-    ref = step.rgbd_step(gpl, dpl, oopt, x_real, z, thetas, 10.0, CFG, iteration)
+    ref = step.rgbd_step(gpl, dpl, oopt, x_real, z, thetas, stage, CFG, iteration)
 
     # ---- engine
     cfg = Config(dict(generator_architecture="stylegan", stage_interval="0,0,0,0,0,0,0,100000,150000,160000,180000,300000",
@@ -145,7 +149,7 @@ def test_full_training_step_matches_oracle():
     for n in ("l1/c/W", "l1/c/b", "l2/c/W", "l2/c/b"):
         opt["gen"].set_alpha(n, 1e-5)
     upd = RGBDUpdater(models=[gen, dis], config=cfg, optimizer=opt, iterator=None, lambda_gp=1.0, smoothing=0.999,
-                      total_gpu=1, prior=CameraParamPrior(cfg), fixed_stage=10.0)
+                      total_gpu=1, prior=CameraParamPrior(cfg), fixed_stage=stage)
     upd.iteration = iteration
     upd.update_core(batch=torch.from_numpy(x_real), z_fake_data=torch.from_numpy(z), thetas=thetas)
     obs = {k: float(v) for k, v in upd.observation.items()}
