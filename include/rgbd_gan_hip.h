@@ -143,7 +143,7 @@ int rgbd_adain_bwd(const void* x, const void* dy, const float* scale, const floa
  *   (per-sample weights) or 1 when row_scale is NULL.
  */
 int rgbd_lrelu_bwd(const void* dy, const void* y, void* dz, int64_t M, int C, int act_channels, float slope,
-                   float* bias_grad /* NULL, or (C) fp32: += column sums of dz in the same pass */, void* stream);
+                   float* bias_grad, const float* row_scale, int64_t rows_per_sample, void* stream);
 int rgbd_colsum_bf16(const void* x, float* out, int64_t M, int C, int accumulate, const float* row_scale,
                      int64_t rows_per_sample, void* stream);
 /* out = a + s[sample] * x on (B, elems_per_sample) bf16 tensors: folds the adversarial term of the discriminator loss
@@ -157,7 +157,7 @@ int rgbd_axpy_rows_bf16(const void* a, const void* x, const float* s, void* out,
  * The two are adjoint (same mask), which closes the pair under differentiation (R1 double backward).
  */
 int rgbd_unpool2_lrelu_bwd(const void* dp, const void* y, void* dz, int B, int H, int W, int C, float slope,
-                           float* bias_grad, void* stream);
+                           float* bias_grad, const float* row_scale, void* stream);
 int rgbd_pool2_masked(const void* x, const void* y, void* out, int B, int H, int W, int C, float slope, void* stream);
 
 /* 1x1 convolutions between NCHW fp32 image planes (KP = 3 or 4 channels) and NHWC bf16 features (C channels):

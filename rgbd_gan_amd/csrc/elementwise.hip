@@ -246,7 +246,10 @@ __global__ __launch_bounds__(256) void lrelu_bwd_colsum_kernel(const unsigned sh
                                                                const unsigned short* __restrict__ y,
                                                                unsigned short* __restrict__ dz, long M, int C,
                                                                int act_channels, float slope, int rows_per_block,
-                                                               float* __restrict__ bias_grad) {
+                                                               float* __restrict__ bias_grad,
+                                                               const float* __restrict__ row_scale,
+                                                               long rows_per_sample) {
+    // bias_grad[c] += sum_r w(r) dz[r][c], w(r) = row_scale[r / rows_per_sample] (1 when row_scale is null).
     // 8 lanes cover one row's 64-channel group (128 B), 32 rows per pass, FOUR passes' loads issued before any is
     // used: 8 independent 16-byte loads in flight per lane keep HBM busy with a handful of waves per CU.
     const int cg = blockIdx.y;
@@ -280,8 +283,9 @@ __global__ __launch_bounds__(256) void lrelu_bwd_colsum_kernel(const unsigned sh
                     }
                 }
                 *reinterpret_cast<u32x4*>(dz + r * C + c0) = out;
+                const float wr = row_scale ? row_scale[r / rows_per_sample] : 1.f;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { s[2 * k] += bf16_lo(out[k]); s[2 * k + 1] += bf16_hi(out[k]); }
+                for (int k = 0; k < 4; ++k) { s[2 * k] += wr * bf16_lo(out[k]); s[2 * k + 1] += wr * bf16_hi(out[k]); }
             }
         }
     }
@@ -301,7 +305,8 @@ __global__ __launch_bounds__(256) void unpool_lrelu_bwd_kernel(const unsigned sh
                                                                const unsigned short* __restrict__ y,
                                                                unsigned short* __restrict__ dz, long M, int H, int W,
                                                                int C, float slope, int rows_per_block,
-                                                               float* __restrict__ bias_grad) {
+                                                               float* __restrict__ bias_grad,
+                                                               const float* __restrict__ row_scale) {
     // same lane layout and 4-pass load batching as lrelu_bwd_colsum_kernel; dp is read at the pooled position
     const int cg = blockIdx.y;
     const int chunk = threadIdx.x & 7, lane_p = threadIdx.x >> 3;
@@ -328,6 +333,7 @@ __global__ __launch_bounds__(256) void unpool_lrelu_bwd_kernel(const unsigned sh
             const long r = r0 + 32 * u;
             if (r < r_end) {
                 u32x4 out;
+                const float wr = row_scale ? row_scale[r / ((long)H * W)] : 1.f;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     float g0 = bf16_lo(g[u][k]) * 0.25f, g1 = bf16_hi(g[u][k]) * 0.25f;
@@ -336,8 +342,8 @@ __global__ __launch_bounds__(256) void unpool_lrelu_bwd_kernel(const unsigned sh
                         g1 = bf16_hi(yy[u][k]) > 0.f ? g1 : g1 * slope;
                     }
                     out[k] = pack_bf16x2(g0, g1);
-                    s[2 * k] += bf16_lo(out[k]);
-                    s[2 * k + 1] += bf16_hi(out[k]);
+                    s[2 * k] += wr * bf16_lo(out[k]);
+                    s[2 * k + 1] += wr * bf16_hi(out[k]);
                 }
                 *reinterpret_cast<u32x4*>(dz + r * C + c0) = out;
             }
@@ -884,16 +890,19 @@ extern "C" int rgbd_adain_bwd(const void* x, const void* dy, const float* scale,
 }
 
 extern "C" int rgbd_lrelu_bwd(const void* dy, const void* y, void* dz, int64_t M, int C, int act_channels,
-                              float slope, float* bias_grad, void* stream) {
+                              float slope, float* bias_grad, const float* row_scale, int64_t rows_per_sample,
+                              void* stream) {
     RGBD_REQUIRE(dy && y && dz, "rgbd_lrelu_bwd: null pointer");
     RGBD_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && act_channels % 8 == 0, "rgbd_lrelu_bwd: C must be a multiple of 8");
     hipStream_t st = (hipStream_t)stream;
     if (bias_grad) {
         RGBD_REQUIRE(C % 64 == 0, "rgbd_lrelu_bwd: the fused bias gradient needs C %% 64 == 0 (C=%d)", C);
+        RGBD_REQUIRE(!row_scale || rows_per_sample > 0, "rgbd_lrelu_bwd: rows_per_sample must be positive with row_scale");
         const int rows = 512;
         dim3 grid(ceil_div(M, rows), C / 64);
         lrelu_bwd_colsum_kernel<<<grid, 256, 0, st>>>((const unsigned short*)dy, (const unsigned short*)y,
-                                                      (unsigned short*)dz, M, C, act_channels, slope, rows, bias_grad);
+                                                      (unsigned short*)dz, M, C, act_channels, slope, rows, bias_grad,
+                                                      row_scale, row_scale ? rows_per_sample : 1);
         RGBD_CHECK_LAUNCH("lrelu_bwd_colsum_kernel");
         return 0;
     }
@@ -936,7 +945,7 @@ extern "C" int rgbd_axpy_rows_bf16(const void* a, const void* x, const float* s,
 }
 
 extern "C" int rgbd_unpool2_lrelu_bwd(const void* dp, const void* y, void* dz, int B, int H, int W, int C, float slope,
-                                      float* bias_grad, void* stream) {
+                                      float* bias_grad, const float* row_scale, void* stream) {
     RGBD_REQUIRE(dp && dz, "rgbd_unpool2_lrelu_bwd: null pointer");
     RGBD_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C % 64 == 0,
                  "rgbd_unpool2_lrelu_bwd: H, W must be even and C a multiple of 64 (H=%d W=%d C=%d)", H, W, C);
@@ -944,7 +953,8 @@ extern "C" int rgbd_unpool2_lrelu_bwd(const void* dp, const void* y, void* dz, i
     const int rows = 512;
     dim3 grid(ceil_div(M, rows), C / 64);
     unpool_lrelu_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const unsigned short*)dp, (const unsigned short*)y,
-                                                                  (unsigned short*)dz, M, H, W, C, slope, rows, bias_grad);
+                                                                  (unsigned short*)dz, M, H, W, C, slope, rows, bias_grad,
+                                                                  row_scale);
     RGBD_CHECK_LAUNCH("unpool_lrelu_bwd_kernel");
     return 0;
 }

@@ -360,15 +360,17 @@ class _LreluGrad(torch.autograd.Function):
     edge to y would make a later backward walk the whole recorded forward with all-zero gradients."""
 
     @staticmethod
-    def forward(ctx, dy, y, act_channels):
+    def forward(ctx, dy, y, act_channels, inject_bias=None):
         ctx.act_channels = act_channels
         ctx.save_for_backward(y)
+        if inject_bias is not None:       # adversarial injection: d bias += sum_b s_b colsum_b(dz) in the same pass
+            return kernels.lrelu_bwd(dy.contiguous(), y, act_channels, bias_grad=inject_bias.grad, row_scale=_INJECT)
         return kernels.lrelu_bwd(dy.contiguous(), y, act_channels)
 
     @staticmethod
     def backward(ctx, ddz):
         y, = ctx.saved_tensors
-        return _LreluGrad.apply(ddz.contiguous(), y.detach(), ctx.act_channels), None, None
+        return _LreluGrad.apply(ddz.contiguous(), y.detach(), ctx.act_channels), None, None, None
 
 
 class _ColSum(torch.autograd.Function):
@@ -387,15 +389,18 @@ class _UnpoolLreluGrad(torch.autograd.Function):
     its adjoint is _PoolMasked with the same mask."""
 
     @staticmethod
-    def forward(ctx, dp, y, shape, use_mask):
+    def forward(ctx, dp, y, shape, use_mask, inject_bias=None):
         ctx.use_mask = use_mask
         ctx.save_for_backward(y)
+        if inject_bias is not None:
+            return kernels.unpool2_lrelu_bwd(dp.contiguous(), y if use_mask else None, shape,
+                                             bias_grad=inject_bias.grad, row_scale=_INJECT)
         return kernels.unpool2_lrelu_bwd(dp.contiguous(), y if use_mask else None, shape)
 
     @staticmethod
     def backward(ctx, ddz):
         y, = ctx.saved_tensors
-        return _PoolMasked.apply(ddz.contiguous(), y.detach(), ctx.use_mask), None, None, None
+        return _PoolMasked.apply(ddz.contiguous(), y.detach(), ctx.use_mask), None, None, None, None
 
 
 class _PoolMasked(torch.autograd.Function):
@@ -438,22 +443,29 @@ class _ConvBiasAct(torch.autograd.Function):
         dx = dw = db = dres = None
         dy = dy.contiguous()
         fast_b = want_b and _direct_grad(bias)          # bias gradient rides along in the same pass
+        # R1 first-order pass with the adversarial seeds known (adversarial_injection): the weighted bias sums are
+        # taken here, fused with the activation gradient, instead of in a pass of their own during the double backward
+        inj_b = bias if (_INJECT is not None and torch.is_grad_enabled() and ctx.needs_input_grad[2] and bias.is_leaf
+                         and bias.grad is not None and bias.data_ptr() not in _FROZEN_PTRS) else None
         if ctx.pool:
             if fast_b:
                 dz = kernels.unpool2_lrelu_bwd(dy, y if ctx.act else None, tuple(y.shape), bias_grad=bias.grad)
             else:
-                dz = _UnpoolLreluGrad.apply(dy, y.detach(), tuple(y.shape), ctx.act)
+                dz = _UnpoolLreluGrad.apply(dy, y.detach(), tuple(y.shape), ctx.act, inj_b)
         elif ctx.act:
             dz = kernels.lrelu_bwd(dy, y, w.shape[0], bias_grad=bias.grad) if fast_b else \
-                _LreluGrad.apply(dy, y.detach(), w.shape[0])
+                _LreluGrad.apply(dy, y.detach(), w.shape[0], inj_b)
         else:
             dz = dy
             if fast_b:
                 kernels.colsum(dz, out=bias.grad)
+            elif inj_b is not None:
+                kernels.colsum(dz.detach(), out=bias.grad, row_scale=_INJECT, rows_per_sample=dz.shape[1] * dz.shape[2])
         if want_b and not fast_b:
             db = _ColSum.apply(dz)
         if ctx.needs_input_grad[0]:
-            dx = _ConvDgrad.apply(dz, w, layer, ups, x.detach(), bias)
+            # bias=None when its injected gradient has been taken above
+            dx = _ConvDgrad.apply(dz, w, layer, ups, x.detach(), None if inj_b is not None else bias)
         if ctx.needs_input_grad[1] and not _skip_grad_of(w):
             if _direct_grad(w):
                 _wgrad_into(x, dz, w, layer, ups)

@@ -221,14 +221,16 @@ def conv2d_wgrad(x, dy, K, scale, out=None, accumulate=False):
 
 
 # ------------------------------------------------------------------ fused elementwise / 1x1
-def lrelu_bwd(dy, y, act_channels, slope=0.2, bias_grad=None):
+def lrelu_bwd(dy, y, act_channels, slope=0.2, bias_grad=None, row_scale=None):
     """dz = dy * (y > 0 ? 1 : slope) on channels [0, act_channels) of NHWC bf16 tensors.
-    bias_grad (C,) fp32: if given, the column sums of dz are ADDED to it in the same pass."""
-    _chk(dy, BF16, "dy"); _chk(y, BF16, "y"); _chk(bias_grad, F32, "bias_grad")
+    bias_grad (C,) fp32: if given, the column sums of dz are ADDED to it in the same pass, every row weighted by
+    row_scale[sample] (B,) fp32 when that is given."""
+    _chk(dy, BF16, "dy"); _chk(y, BF16, "y"); _chk(bias_grad, F32, "bias_grad"); _chk(row_scale, F32, "row_scale")
     C = y.shape[-1]
     dz = torch.empty_like(y)
+    rps = y.numel() // C // y.shape[0] if row_scale is not None else 0
     rc = _lib.load().rgbd_lrelu_bwd(_ptr(dy), _ptr(y), _ptr(dz), y.numel() // C, C, int(act_channels), float(slope),
-                                    _ptr(bias_grad), _stream())
+                                    _ptr(bias_grad), _ptr(row_scale), rps, _stream())
     _lib.check(rc, "rgbd_lrelu_bwd")
     return dz
 
@@ -259,13 +261,14 @@ def axpy_rows(a, x, s):
     return out
 
 
-def unpool2_lrelu_bwd(dp, y, shape, slope=0.2, bias_grad=None):
-    """dz (B,H,W,C) = 0.25 * upsample2(dp) * lrelu'(y); y may be None (plain average-pool backward)."""
-    _chk(dp, BF16, "dp"); _chk(y, BF16, "y"); _chk(bias_grad, F32, "bias_grad")
+def unpool2_lrelu_bwd(dp, y, shape, slope=0.2, bias_grad=None, row_scale=None):
+    """dz (B,H,W,C) = 0.25 * upsample2(dp) * lrelu'(y); y may be None (plain average-pool backward).  bias_grad /
+    row_scale as in lrelu_bwd."""
+    _chk(dp, BF16, "dp"); _chk(y, BF16, "y"); _chk(bias_grad, F32, "bias_grad"); _chk(row_scale, F32, "row_scale")
     B, H, W, C = shape
     dz = torch.empty(B, H, W, C, dtype=BF16, device=dp.device)
     rc = _lib.load().rgbd_unpool2_lrelu_bwd(_ptr(dp), _ptr(y), _ptr(dz), B, H, W, C, float(slope), _ptr(bias_grad),
-                                            _stream())
+                                            _ptr(row_scale), _stream())
     _lib.check(rc, "rgbd_unpool2_lrelu_bwd")
     return dz
 

@@ -13,6 +13,7 @@ One update_core() = one generator step + one discriminator step:
 Data-parallel: each optimizer's flat gradient buffer is all-reduced once (RCCL); the map/gen all-reduce is launched
 right after the G backward and overlaps the D step's forward/backward (which only reads x_fake's values).
 """
+import contextlib
 import math
 import os
 
@@ -292,21 +293,24 @@ class RGBDUpdater:
             y_fake = self.dis(st["x_fake_data"][:, :3].contiguous(), stage=stage)
             reported = loss_func_dcgan_dis(y_fake.detach(), y_real.detach())
         r1 = not self.dis.sn and self.lambda_gp > 0
+        inject = r1 and fake_done and not os.environ.get("RGBD_NO_INJECT")
+        seed = None
+        if inject:
+            # loss_dis = softplus(-y_real).mean() + loss_gp.  The adversarial term on the reals is not back-propagated
+            # through the recorded forward: its per-sample seeds are folded into the R1 passes
+            # (functional.adversarial_injection); only the dense tail after the conv stack (torch ops) takes them
+            # the ordinary way.
+            y_leaf = y_real.detach().requires_grad_(True)
+            seed, = torch.autograd.grad(torch.sum(F.softplus(-y_leaf)) / y_leaf.numel(), y_leaf)
         if r1:
-            with Fn.input_grads_only():
+            with Fn.input_grads_only(), (Fn.adversarial_injection(seed) if inject else contextlib.nullcontext()):
                 grad_x, = torch.autograd.grad([y_real.sum()], [x_real_v], create_graph=True)
             grad_l2 = torch.sqrt(torch.sum(grad_x ** 2, dim=(1, 2, 3)))
             loss_gp = self.lambda_gp * loss_l2(grad_l2, 0.0)
             obs["dis/loss_gp"] = loss_gp.detach()
             reported = reported + loss_gp.detach()
         obs["dis/loss_adv"] = reported
-        if r1 and fake_done and not os.environ.get("RGBD_NO_INJECT"):
-            # loss_dis = softplus(-y_real).mean() + loss_gp.  The adversarial term on the reals is not back-propagated
-            # through the recorded forward: its per-sample seeds are folded into the R1 double backward
-            # (functional.adversarial_injection); only the dense tail after the conv stack (torch ops) takes them
-            # the ordinary way.
-            y_leaf = y_real.detach().requires_grad_(True)
-            seed, = torch.autograd.grad(torch.sum(F.softplus(-y_leaf)) / y_leaf.numel(), y_leaf)
+        if inject:
             torch.autograd.backward([y_real], [seed], inputs=self.dis.tail_params(), retain_graph=True)
             with Fn.adversarial_injection(seed):
                 loss_gp.backward()
@@ -426,7 +430,8 @@ class RGBDUpdater:
 
         # the recorded D(x_fake) forward may only be shared when both phases run the same way (both replayed from
         # graphs captured in the same iteration, or both eager)
-        st["share_dfake"] = key is None or (("gen" in self.graph_phases) == ("dis" in self.graph_phases))
+        st["share_dfake"] = (key is None or (("gen" in self.graph_phases) == ("dis" in self.graph_phases))) \
+            and not os.environ.get("RGBD_NO_SHARE")
         self._run_phase("gen", self._gen_phase, st, key)
         if opt_g_m is not None:
             opt_g_m.start_allreduce()

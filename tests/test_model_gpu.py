@@ -4,6 +4,8 @@ Tolerances: the engine stores activations and conv operands in bf16 (8 mantissa 
 oracle is fp32 throughout; through ~12 conv layers a relative L2 error of ~1 % is the expected noise floor, so
 tensors are compared by relative L2 error and gradients additionally by cosine similarity.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -123,9 +125,12 @@ def test_full_training_step_matches_oracle(stage):
     from rgbd_gan_amd.utils.yaml_utils import Config
     gp, dp, gen, dis = _models(seed=2)
     z, thetas, x_real = _inputs(4, seed=7)
-    # make the depth channel non-trivial so the warp loss sees geometry
+    # make the depth channel non-trivial so the warp loss sees geometry.  Seeded and moderate: with large depth-head
+    # weights 1 / (softplus(x) + 1e-4) reaches 1e4 on some pixels, its derivative 1e8, and the generator gradient is
+    # then decided by a handful of pixels whose sign flips with bf16 rounding (cosine vs fp32 anywhere in [-0.1, 1])
+    torch.manual_seed(int(os.environ.get("RGBD_TEST_SEED", "0")))
     for i in range(6):
-        gp[f"gen/outs/{i}/c/W"][-1] = torch.randn(gp[f"gen/outs/{i}/c/W"][-1].shape) * 0.3
+        gp[f"gen/outs/{i}/c/W"][-1] = torch.randn(gp[f"gen/outs/{i}/c/W"][-1].shape) * 0.1
     gen.load_state_dict(gp)
     iteration = 200000
 
