@@ -54,6 +54,16 @@ class FlatAdam:
         if self.comm is not None and self.comm.size > 1 and not self._needs_broadcast:
             self._pending = self.comm.allreduce_async(self.store.grad)
 
+    def finish_allreduce(self):
+        """Make the current stream wait for this optimizer's gradient all-reduce (launching it now if nobody has).
+        Called eagerly before the optimizer phase, so that phase holds no collective and can be replayed as a graph."""
+        if self.comm is not None and self.comm.size > 1 and not self._needs_broadcast:
+            if self._pending is None:
+                self.start_allreduce()
+            self.comm.wait(self._pending)
+            self._pending = None
+            self._reduced = True
+
     @torch.no_grad()
     def update(self):
         if self._needs_broadcast:                      # ChainerMN: first update() = broadcast, no step
@@ -63,10 +73,9 @@ class FlatAdam:
             return
         grad_scale = 1.0
         if self.comm is not None and self.comm.size > 1:
-            if self._pending is None:
-                self.start_allreduce()
-            self.comm.wait(self._pending)
-            self._pending = None
+            if not getattr(self, "_reduced", False):
+                self.finish_allreduce()
+            self._reduced = False
             grad_scale = 1.0 / self.comm.size
         begins, alphas = self._segments()
         kernels.adam_clip_multi(self.store.flat, self.store.grad, self.m, self.v, begins, alphas, self.beta1,

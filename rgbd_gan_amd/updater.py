@@ -438,10 +438,12 @@ class RGBDUpdater:
         opt_g_g.start_allreduce()
         self._run_phase("dis", self._dis_phase, st, key)                   # overlaps the map/gen all-reduce
         opt_d.start_allreduce()
-        if self._distributed():
-            self._opt_phase(st)                                             # waits on the collectives: stays eager
-        else:
-            self._run_phase("opt", self._opt_phase, st, key)
+        # the collectives are waited for here, eagerly; the optimizer phase itself (clip + Adam + EMA) holds none and is
+        # replayed as a graph also under data parallelism
+        for opt in (opt_g_m, opt_g_g, opt_d):
+            if opt is not None:
+                opt.finish_allreduce()
+        self._run_phase("opt", self._opt_phase, st, key)
         if key is not None:
             Fn.bump_weight_epoch()      # replays change the weights behind Python's back: invalidate packed caches
 
