@@ -170,7 +170,8 @@ class VoxelGenerator(_Link, _StyleMixin):
     def _conv3d(x, layer, bias, upsample):
         """x (B,D,H,W,C) -> lrelu(conv3d(up(x)) + bias) as one 2-D conv over (B*D) depth slices."""
         if upsample:
-            x = x.repeat_interleave(2, dim=1)
+            B0, D0 = x.shape[:2]
+            x = x.unsqueeze(2).expand(B0, D0, 2, *x.shape[2:]).reshape(B0, 2 * D0, *x.shape[2:])
         B, D = x.shape[:2]
         y = Fn.conv_bias_lrelu(fold_depth_taps(x), layer, bias, upsample=upsample)
         return y.reshape(B, D, y.shape[1], y.shape[2], y.shape[3])

@@ -31,10 +31,35 @@ def _inv_c(fan_in, gain=SQRT2):
     return float(gain * np.sqrt(1.0 / fan_in))
 
 
+_ALPHA_OVERRIDE = None      # 0-dim device tensor holding the fade-in blend factor, or None
+
+
+@contextlib.contextmanager
+def alpha_override(alpha):
+    """Inside, the fade-in blend factor of the progressive stages (net.py:283-290,490-497 of the reference) is read
+    from this device scalar instead of being computed from the Python float `stage`: the launch sequence of a fade-in
+    step then depends only on floor(stage), so it can be captured once and replayed while alpha moves every
+    iteration."""
+    global _ALPHA_OVERRIDE
+    old = _ALPHA_OVERRIDE
+    _ALPHA_OVERRIDE = alpha
+    try:
+        yield
+    finally:
+        _ALPHA_OVERRIDE = old
+
+
 def _split_stage(stage, max_stage):
     stage = min(stage, max_stage - 1e-8)
     fl = math.floor(stage)
-    return fl, stage - fl
+    return fl, (stage - fl if _ALPHA_OVERRIDE is None else _ALPHA_OVERRIDE)
+
+
+def upsample_planes(x, scale=2):
+    """Nearest-neighbour upsampling of NCHW planes (F.unpooling_2d(k, k) of rescale.py:4-5) as an expand + reshape:
+    one copy kernel, no index tensors (repeat_interleave builds its index on the host, which stalls graph replays)."""
+    B, C, H, W = x.shape
+    return x.reshape(B, C, H, 1, W, 1).expand(B, C, H, scale, W, scale).reshape(B, C, H * scale, W * scale)
 
 
 def _as_device_tensor(a, device, dtype=torch.float32):
@@ -216,7 +241,7 @@ class StyleGenerator(_Link):
                 if return_feature and i == 3:
                     feat = h
             lo = self._to_rgbd(k, h)
-            lo = lo.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+            lo = upsample_planes(lo)
             hi = self._to_rgbd(k + 1, self._block(k + 1, w, h))      # net.py:290: un-rotated w
             out = (1.0 - alpha) * lo + alpha * hi
         if self.rgbd:
@@ -257,7 +282,7 @@ class StyleGANGenerator(_Link):
         out = self.gen(w, w2=w2, stage=stage, theta=theta, return_feature=return_feature)
         if not self.train and not return_feature and out.shape[2] < 64:     # net.py:305-309 (eval-mode upsample)
             scale = 64 // out.shape[2]
-            out = out.repeat_interleave(scale, dim=2).repeat_interleave(scale, dim=3)
+            out = upsample_planes(out, scale)
         return out
 
     forward = __call__
@@ -334,7 +359,7 @@ class DCGANGenerator(_Link):
             k = (st - 1) // 2
             for i in range(0, k):
                 h = self._block(i, h)
-            lo = self._to_rgbd(k - 1, h).repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+            lo = upsample_planes(self._to_rgbd(k - 1, h))
             hi = self._to_rgbd(k, self._block(k, h))
             out = (1.0 - alpha) * lo + alpha * hi
         if self.rgbd:

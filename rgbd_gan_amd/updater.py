@@ -80,14 +80,21 @@ class CameraParamPrior:
         return thetas.astype("float32")
 
 
+def downsized_size(stage, max_stage=17):
+    """Side length of downsize_real's output (pure arithmetic: running the pooling on a CPU dummy every step wakes the
+    host's intra-op thread pool and stalled the launch thread for tens of milliseconds in the fade-in stages)."""
+    fl = math.floor(min(stage, max_stage - 1e-8))
+    k = (fl - 2) // 2 if fl % 2 == 0 else (fl - 1) // 2
+    return 4 * (2 ** (k + 1))
+
+
 def downsize_real(x_real, stage, max_stage=17):
     """common/utils/pggan.py:6-50 on a device tensor (NCHW fp32)."""
     import math
     size = x_real.shape[2]
     assert x_real.shape[2] == x_real.shape[3]
-    stage = min(stage, max_stage - 1e-8)
-    alpha = stage - math.floor(stage)
-    stage = math.floor(stage)
+    from . import net
+    stage, alpha = net._split_stage(stage, max_stage)       # alpha: float, or the device scalar of net.alpha_override
     if stage % 2 == 0:
         k = (stage - 2) // 2
         image_size = 4 * (2 ** (k + 1))
@@ -100,10 +107,15 @@ def downsize_real(x_real, stage, max_stage=17):
     s_lo, s_hi = size // lo, size // hi
     r_lo, r_hi = x_real, x_real
     if s_lo > 1:
-        r_lo = F.avg_pool2d(x_real, s_lo, s_lo).repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+        r_lo = net.upsample_planes(F.avg_pool2d(x_real, s_lo, s_lo))
     if s_hi > 1:
         r_hi = F.avg_pool2d(x_real, s_hi, s_hi)
     return (1 - alpha) * r_lo + alpha * r_hi
+
+
+def _alpha_ctx(st):
+    from . import net
+    return net.alpha_override(st["alpha"]) if st.get("alpha") is not None else contextlib.nullcontext()
 
 
 class _HostStager:
@@ -217,7 +229,7 @@ class RGBDUpdater:
 
     # ---- the three phases of a step (each one is capturable: device work only, fixed launch sequence)
     def _gen_phase(self, st):
-        with kernels.zero_arena.phase(self.device):
+        with kernels.zero_arena.phase(self.device), _alpha_ctx(st):
             self._gen_phase_body(st)
 
     def _gen_phase_body(self, st):
@@ -278,6 +290,10 @@ class RGBDUpdater:
         st["x_fake_data"] = x_fake.detach()
 
     def _dis_phase(self, st):
+        with _alpha_ctx(st):
+            self._dis_phase_body(st)
+
+    def _dis_phase_body(self, st):
         stage = st["stage"]
         obs = self.observation
         x_real_v = st["x_real"].detach().requires_grad_(True)
@@ -402,7 +418,7 @@ class RGBDUpdater:
               "x_real_full": x_real_data, "z": None}
         st["theta9"] = self._stager("theta9", (batch_size, 9)).upload(theta9)
         if use_rotate:
-            image_size = int(downsize_real(torch.empty(1, 1, x_real_data.shape[2], x_real_data.shape[3]), stage).shape[2])
+            image_size = downsized_size(stage)
             coef = self.loss_func_rotate.coefficients_for_size(image_size, random_camera_matrices[:half],
                                                                random_camera_matrices[half:])
             st["coef"] = self._stager("coef", (half, 24)).upload(coef)
@@ -415,11 +431,15 @@ class RGBDUpdater:
             st["z"] = self._stagers[zkey]
 
         fl = math.floor(min(stage, 17 - 1e-8))
-        # under data parallelism the G and D phases are still replayed as graphs; the collectives and the optimizer
-        # phase (which waits on them) stay eager
-        graphable = self.use_graphs and fl % 2 == 0
+        graphable = self.use_graphs
         key = None
+        st["alpha"] = None
         if graphable:
+            if fl % 2 == 1:
+                # fade-in stage: the blend factor changes every iteration, so it lives in a device scalar that the
+                # captured phases read (net.alpha_override); the launch sequence depends on floor(stage) only
+                alpha = float(min(stage, 17 - 1e-8) - fl)
+                st["alpha"] = self._stager("alpha", (1,)).upload(np.array([alpha], dtype="float32"))[0]
             # graphs read their inputs from fixed addresses: park the batch in a persistent buffer
             skey = ("x_real_full",) + tuple(x_real_data.shape)
             if skey not in self._stagers:

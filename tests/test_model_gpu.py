@@ -184,11 +184,14 @@ def test_full_training_step_matches_oracle(stage):
     assert agree > 0.9
 
 
-def test_graph_replay_matches_eager_steps():
+@pytest.mark.parametrize("schedule", ["even stage", "fade-in"])
+def test_graph_replay_matches_eager_steps(schedule):
     """The captured-and-replayed step (HIP graphs: G phase, D phase, optimizer phase) is the same computation as the
     eager step.  GAN steps are chaotic (two EAGER runs from identical seeds already differ by ~10 % in the adversarial
     losses after 4 steps, through fp32 atomic ordering + bf16 rounding), so the comparison is per-step and loose;
-    what it catches is a graph that reads stale or clobbered buffers (NaN / inf / frozen values)."""
+    what it catches is a graph that reads stale or clobbered buffers (NaN / inf / frozen values).  "fade-in": the
+    real schedule inside the 64 -> 128 transition, where the blend factor moves every iteration and the replayed
+    phases read it from a device scalar."""
     from rgbd_gan_amd.training import DeviceImageIterator, build_training
     from rgbd_gan_amd.utils.yaml_utils import Config
     cfg = dict(generator_architecture="stylegan", ch=256, stage_interval="0,0,0,0,0,0,0,100000,150000,160000,180000,300000",
@@ -202,9 +205,10 @@ def test_graph_replay_matches_eager_steps():
         np.random.seed(11)
         torch.manual_seed(11)
         it = DeviceImageIterator(images, 4, "cuda:0", seed=3)
-        gen, dis, opt, upd = build_training(Config(cfg), "cuda:0", iterator=it, fixed_stage=8.0, use_graphs=use_graphs,
-                                            graph_warmup=2, nan_check_interval=0)
-        upd.iteration = 200000
+        gen, dis, opt, upd = build_training(Config(cfg), "cuda:0", iterator=it,
+                                            fixed_stage=8.0 if schedule == "even stage" else None,
+                                            use_graphs=use_graphs, graph_warmup=2, nan_check_interval=0)
+        upd.iteration = 200000 if schedule == "even stage" else 169998         # stage 9.4999 .. 9.5001: alpha ~ 0.5
         zgen = torch.Generator().manual_seed(5)
         rows = []
         for _ in range(5):
