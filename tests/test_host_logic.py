@@ -1,5 +1,6 @@
 """CPU tests of the host side of the product (no kernels run): schedule, cameras, prior, config, parameter store."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import camera as ocam
@@ -106,3 +107,53 @@ def test_convert_batch_images_layout():
             assert (dep == np.uint8(np.clip(128.0 / (1.0 + i), 0, 255))).all()
     rgb_only = convert_batch_images(x[:, :3], rows, cols)
     assert rgb_only.shape == (rows * H, cols * H, 3)
+
+
+def test_downsized_size_matches_downsize_real():
+    """updater.downsized_size is the arithmetic twin of downsize_real's output size (common/utils/pggan.py:6-50)."""
+    import torch
+    from rgbd_gan_amd.updater import downsize_real, downsized_size
+    for st in (2.0, 3.25, 4.0, 5.5, 6.0, 6.999, 7.0, 8.0, 9.5, 10.0, 10.9999, 16.5):
+        if downsized_size(st) <= 128:
+            assert downsized_size(st) == downsize_real(torch.zeros(1, 1, 128, 128), st).shape[2], st
+
+
+def test_upsample_planes_is_nearest_replication():
+    import torch
+    from rgbd_gan_amd.net import upsample_planes
+    x = torch.arange(2 * 3 * 4 * 5, dtype=torch.float32).reshape(2, 3, 4, 5)
+    ref = x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+    assert torch.equal(upsample_planes(x), ref)
+    assert torch.equal(upsample_planes(x, 4), x.repeat_interleave(4, dim=2).repeat_interleave(4, dim=3))
+
+
+def test_alpha_override_replaces_the_blend_factor_only():
+    import torch
+    from rgbd_gan_amd import net
+    assert net._split_stage(9.25, 17) == (9, 0.25)
+    a = torch.tensor(0.75)
+    with net.alpha_override(a):
+        fl, alpha = net._split_stage(9.25, 17)
+        assert fl == 9 and alpha is a
+        with net.alpha_override(None):
+            assert net._split_stage(9.25, 17)[1] == 0.25
+    assert net._split_stage(16.9999999999, 17)[0] == 16
+
+
+def test_param_store_fused_views_share_storage_and_gradient():
+    """ParamStore.fused: back-to-back parameters as one leaf (the style scale / shift affines served by one launch)."""
+    import torch
+    from rgbd_gan_amd.params import ParamStore
+    specs = [("a/W", (4, 8), "normal"), ("b/W", (4, 8), "normal"), ("a/b", (4,), "ones"), ("b/b", (4,), "zeros"),
+             ("c/W", (3, 5), "normal")]
+    st = ParamStore(specs, "cpu", seed=0)
+    W = st.fused(("a/W", "b/W"), (8, 8))
+    b = st.fused(("a/b", "b/b"), (8,))
+    assert torch.equal(W[:4], st["a/W"]) and torch.equal(W[4:], st["b/W"])
+    assert torch.equal(b, torch.cat([st["a/b"], st["b/b"]]))
+    (W.sum() * 2 + (b * torch.arange(8.0)).sum()).backward()
+    assert torch.equal(st["a/W"].grad, torch.full((4, 8), 2.0)) and torch.equal(st["b/b"].grad, torch.arange(4.0, 8.0))
+    st.zero_grad()
+    assert float(W.grad.abs().sum()) == 0.0 and W.grad.data_ptr() == st["a/W"].grad.data_ptr()
+    with pytest.raises(ValueError):
+        st.fused(("a/W", "c/W"), (4 * 8 + 15,))                # not adjacent
