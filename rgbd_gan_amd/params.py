@@ -7,6 +7,7 @@ pure_nccl communicator does (train_rgbd.py:154-156) -- sized for xGMI (2.1 / 26.
 
 Names are the reference's Chainer ``namedparams`` paths so its .npz snapshots load directly.
 """
+import contextlib
 import math
 
 import numpy as np
@@ -53,16 +54,36 @@ class ParamStore:
             p.requires_grad_(True)
             self.params[name] = p
         self._fused = {}
+        self.grad_alt = None          # second gradient buffer (alt_grads), allocated on first use
         self.bind_grads()
 
-    def bind_grads(self):
+    def bind_grads(self, buf=None):
         """Point every .grad at its slice of the flat gradient buffer so autograd accumulates in place."""
+        buf = self.grad if buf is None else buf
+        self._bound = buf
         for name, p in self.params.items():
             n = p.numel()
             off = self.offsets[name]
-            p.grad = self.grad[off:off + n].view(self.shapes[name])
+            p.grad = buf[off:off + n].view(self.shapes[name])
         for (names, _), (p, off) in self._fused.items():
-            p.grad = self.grad[off:off + p.numel()].view(p.shape)
+            p.grad = buf[off:off + p.numel()].view(p.shape)
+
+    @contextlib.contextmanager
+    def alt_grads(self):
+        """Inside, gradients accumulate into a SECOND flat buffer: two passes that run concurrently on different
+        streams (D on the fakes inside the generator phase, D on the reals in the discriminator phase) must not
+        read-modify-write the same gradient memory.  merge_alt() adds it back."""
+        if self.grad_alt is None:
+            self.grad_alt = torch.zeros_like(self.flat)
+        self.bind_grads(self.grad_alt)
+        try:
+            yield
+        finally:
+            self.bind_grads()
+
+    def merge_alt(self):
+        if self.grad_alt is not None:
+            self.grad.add_(self.grad_alt)
 
     def fused(self, names, shape):
         """One leaf tensor over several parameters that sit back to back in the flat buffer (e.g. the scale and shift
@@ -89,6 +110,8 @@ class ParamStore:
 
     def zero_grad(self):
         self.grad.zero_()
+        if self.grad_alt is not None:
+            self.grad_alt.zero_()
         for name, p in self.params.items():
             g = p.grad
             if g is None or g.data_ptr() != self.grad.data_ptr() + 4 * self.offsets[name]:

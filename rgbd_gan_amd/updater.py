@@ -171,7 +171,15 @@ class RGBDUpdater:
         # a blend factor every iteration and run eagerly.
         self.use_graphs = bool(kwargs.pop("use_graphs", True))
         self.graph_warmup = int(kwargs.pop("graph_warmup", 2))
-        self.graph_phases = tuple(kwargs.pop("graph_phases", ("gen", "dis", "opt")))
+        self.graph_phases = tuple(kwargs.pop("graph_phases", ("prep", "gen", "dis", "join", "opt")))
+        # the generator phase and the discriminator-on-reals phase are independent until the optimizer phase; on two
+        # streams the launch-latency bubbles of one fill with the other's kernels
+        # (not when several ranks share one GPU -- the single-GPU test arrangement of the multi-rank path: two
+        # processes x (two compute streams + the communicator's streams) oversubscribe the hardware queues and
+        # the collectives then take seconds)
+        self.concurrent_phases = bool(kwargs.pop("concurrent_phases", not os.environ.get("RGBD_SEQUENTIAL_PHASES")
+                                                 and not os.environ.get("RGBD_SHARE_DEVICE")))
+        self._side_stream = None
         self._graphs, self._eager_calls, self._stagers = {}, {}, {}
         self.device = self.gen.device
 
@@ -232,19 +240,27 @@ class RGBDUpdater:
         with kernels.zero_arena.phase(self.device), _alpha_ctx(st):
             self._gen_phase_body(st)
 
+    def _prep_phase(self, st):
+        """Everything both concurrent phases depend on: cleared gradient buffers, the down-sized real batch, and the
+        bf16 weight images of both networks (repacked here so neither phase does it behind the other's back)."""
+        self.gen.cleargrads()
+        self.dis.cleargrads()
+        with torch.no_grad():
+            st["x_real"] = downsize_real(st["x_real_full"], st["stage"]).contiguous()
+        for link in (getattr(self.gen, "gen", self.gen), self.dis):
+            group = getattr(link, "pack_group", None)
+            if group is not None:
+                group.layers[0].packed()
+
     def _gen_phase_body(self, st):
         cfg = self.config
         stage, B, half = st["stage"], st["B"], st["B"] // 2
-        self.gen.cleargrads()
-        self.dis.cleargrads()
         obs = self.observation
         if st["z"] is not None:
             z = st["z"]
         else:
             z_half = self.get_z_fake_data(half)
             z = torch.cat([z_half, z_half], dim=0)                          # same latent for both views
-        with torch.no_grad():
-            st["x_real"] = downsize_real(st["x_real_full"], stage).contiguous()
         x_fake = self.gen(z, stage, st["theta9"])
         # D(x_fake) is evaluated and differentiated ONCE per step.  The reference runs the discriminator on the same
         # fakes twice with identical weights (updater.py:331,404-405) and back-propagates twice: once from the
@@ -262,7 +278,11 @@ class RGBDUpdater:
         seed_g, = torch.autograd.grad(loss_func_dcgan_gen(y_leaf), y_leaf)
         if st.get("share_dfake", True):
             seed_d, = torch.autograd.grad(torch.sum(F.softplus(y_leaf)) / y_leaf.numel(), y_leaf)
-            torch.autograd.backward([y_fake], [seed_d], inputs=[x_d] + list(self.dis.params()))
+            with contextlib.ExitStack() as stack:
+                if st.get("concurrent"):          # D's real-batch gradients are being written on the other stream
+                    for _, store in self.dis.stores:
+                        stack.enter_context(store.alt_grads())
+                torch.autograd.backward([y_fake], [seed_d], inputs=[x_d] + list(self.dis.params()))
             gx = x_d.grad * (seed_g / seed_d).reshape(-1, 1, 1, 1)
             st["loss_dfake"] = torch.sum(F.softplus(y_fake.detach())) / y_fake.numel()   # fake term of loss_func_dcgan_dis
         else:
@@ -298,12 +318,13 @@ class RGBDUpdater:
         obs = self.observation
         x_real_v = st["x_real"].detach().requires_grad_(True)
         y_real = self.dis(x_real_v, stage=stage)
-        fake_done = st.get("loss_dfake") is not None
+        fake_done = bool(st.get("share_dfake", True))
         if fake_done:
-            # the fake half of loss_func_dcgan_dis was differentiated in the generator phase (its weight gradients
-            # are already in D's gradient buffer, which is cleared at the start of the step)
+            # the fake half of loss_func_dcgan_dis is differentiated in the generator phase (its weight gradients go
+            # to D's gradient buffers, which are cleared at the start of the step); its value is added to the report in
+            # the optimizer phase, after the two phases have joined
             y_fake = None
-            reported = torch.sum(F.softplus(-y_real.detach())) / y_real.numel() + st["loss_dfake"]
+            reported = torch.sum(F.softplus(-y_real.detach())) / y_real.numel()
         else:
             self.dis.cleargrads()
             y_fake = self.dis(st["x_fake_data"][:, :3].contiguous(), stage=stage)
@@ -325,7 +346,7 @@ class RGBDUpdater:
             loss_gp = self.lambda_gp * loss_l2(grad_l2, 0.0)
             obs["dis/loss_gp"] = loss_gp.detach()
             reported = reported + loss_gp.detach()
-        obs["dis/loss_adv"] = reported
+        st["dis_reported"] = reported
         if inject:
             torch.autograd.backward([y_real], [seed], inputs=self.dis.tail_params(), retain_graph=True)
             with Fn.adversarial_injection(seed):
@@ -337,6 +358,15 @@ class RGBDUpdater:
         if r1:
             loss_dis = loss_dis + loss_gp
         loss_dis.backward()
+
+    def _join_phase(self, st):
+        """After both phases: D's gradients from the fakes (generator phase, second buffer) join those from the reals,
+        and the reported discriminator loss gets its fake half."""
+        if st.get("concurrent"):
+            for _, store in self.dis.stores:
+                store.merge_alt()
+        lf = st.get("loss_dfake")
+        self.observation["dis/loss_adv"] = st["dis_reported"] + lf if lf is not None else st["dis_reported"]
 
     def _opt_phase(self, st):
         for name in ("map", "gen", "dis"):
@@ -452,11 +482,30 @@ class RGBDUpdater:
         # graphs captured in the same iteration, or both eager)
         st["share_dfake"] = (key is None or (("gen" in self.graph_phases) == ("dis" in self.graph_phases))) \
             and not os.environ.get("RGBD_NO_SHARE")
-        self._run_phase("gen", self._gen_phase, st, key)
-        if opt_g_m is not None:
-            opt_g_m.start_allreduce()
-        opt_g_g.start_allreduce()
-        self._run_phase("dis", self._dis_phase, st, key)                   # overlaps the map/gen all-reduce
+        st["concurrent"] = bool(self.concurrent_phases and st["share_dfake"])
+        self._run_phase("prep", self._prep_phase, st, key)
+        if st["concurrent"]:
+            main = torch.cuda.current_stream()
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=self.device)
+            side = self._side_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._run_phase("dis", self._dis_phase, st, key)           # D on the reals: side stream
+            self._run_phase("gen", self._gen_phase, st, key)               # G + D on the fakes: main stream
+            main.wait_stream(side)
+            # data parallel: the gradient all-reduces start only after the join, so the communicator never competes
+            # with two compute streams (map + gen 29 MB and dis 34 MB then go out back to back on an idle GPU)
+            if opt_g_m is not None:
+                opt_g_m.start_allreduce()
+            opt_g_g.start_allreduce()
+        else:
+            self._run_phase("gen", self._gen_phase, st, key)
+            if opt_g_m is not None:
+                opt_g_m.start_allreduce()
+            opt_g_g.start_allreduce()
+            self._run_phase("dis", self._dis_phase, st, key)               # overlaps the map/gen all-reduce
+        self._run_phase("join", self._join_phase, st, key)
         opt_d.start_allreduce()
         # the collectives are waited for here, eagerly; the optimizer phase itself (clip + Adam + EMA) holds none and is
         # replayed as a graph also under data parallelism
