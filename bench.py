@@ -119,7 +119,7 @@ def main():
     torch.manual_seed(comm.rank)
     images = np.random.RandomState(comm.rank).randint(0, 256, (256, 3, 128, 128)).astype("uint8")
     it = DeviceImageIterator(images, B, device, seed=comm.rank)
-    gen, dis, opt, upd = build_training(config, device, comm if comm.size > 1 else None, iterator=it,
+    gen, dis, opt, upd = build_training(config, device, comm if comm.active else None, iterator=it,
                                         nan_check_interval=0)
     upd.iteration = args.iteration
 

@@ -18,7 +18,11 @@ class Communicator:
         if os.environ.get("RGBD_SHARE_DEVICE"):          # every rank on cuda:0 (single-GPU test boxes)
             self.intra_rank = 0
         self.owns_group = False
-        if self.size > 1 and not dist.is_initialized():
+        # RGBD_DEBUG_FORCE_COLLECTIVES=1: run the broadcast / all-reduce calls even with a single rank (a one-rank RCCL
+        # group), so the data-parallel code path -- collectives next to graph replays and the two compute streams --
+        # can be exercised on a one-GPU box
+        self.force = bool(os.environ.get("RGBD_DEBUG_FORCE_COLLECTIVES"))
+        if (self.size > 1 or self.force) and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             if backend is None:
@@ -39,6 +43,11 @@ class Communicator:
 
     def broadcast(self, flat, src=0):
         dist.broadcast(flat, src=src)
+
+    @property
+    def active(self):
+        """True when collectives have to run (several ranks, or forced for testing)."""
+        return self.size > 1 or self.force
 
     def barrier(self):
         if self.size > 1:

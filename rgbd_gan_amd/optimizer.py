@@ -25,7 +25,7 @@ class FlatAdam:
         self.workspace = torch.empty(1024 + 8, dtype=torch.float32, device=store.flat.device)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=store.flat.device)
         self._alpha_of = {}
-        self._needs_broadcast = comm is not None and comm.size > 1
+        self._needs_broadcast = comm is not None and comm.active
         self._pending = None
 
     # chainer: param.update_rule.hyperparam.alpha = x
@@ -51,13 +51,13 @@ class FlatAdam:
 
     def start_allreduce(self):
         """Launch the gradient all-reduce (sum) asynchronously; update() waits for it."""
-        if self.comm is not None and self.comm.size > 1 and not self._needs_broadcast:
+        if self.comm is not None and self.comm.active and not self._needs_broadcast:
             self._pending = self.comm.allreduce_async(self.store.grad)
 
     def finish_allreduce(self):
         """Make the current stream wait for this optimizer's gradient all-reduce (launching it now if nobody has).
         Called eagerly before the optimizer phase, so that phase holds no collective and can be replayed as a graph."""
-        if self.comm is not None and self.comm.size > 1 and not self._needs_broadcast:
+        if self.comm is not None and self.comm.active and not self._needs_broadcast:
             if self._pending is None:
                 self.start_allreduce()
             self.comm.wait(self._pending)
@@ -72,7 +72,7 @@ class FlatAdam:
             functional.bump_weight_epoch()
             return
         grad_scale = 1.0
-        if self.comm is not None and self.comm.size > 1:
+        if self.comm is not None and self.comm.active:
             if not getattr(self, "_reduced", False):
                 self.finish_allreduce()
             self._reduced = False

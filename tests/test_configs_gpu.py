@@ -128,3 +128,17 @@ def test_train_rgbd_cli_deepvoxels_config(tmp_path):
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "Resume from 4" in r.stdout
+
+
+def test_data_parallel_path_on_a_one_rank_rccl_group():
+    """The data-parallel code path against real RCCL on this one GPU: a single-rank `nccl` process group with the
+    collectives forced on (RGBD_DEBUG_FORCE_COLLECTIVES): first update = broadcast only, then one all-reduce per
+    optimizer per step next to the replayed graphs and the two compute streams."""
+    env = dict(os.environ, RGBD_DEBUG_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0",
+               WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "4", "--batch", "8",
+                        "--no-cpu-baseline", "--no-roofline"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "graph capture" not in r.stderr, r.stderr[-2000:]          # no fallback to eager
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and np.isfinite(line["ms_per_step"])
