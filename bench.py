@@ -98,6 +98,11 @@ def cpu_baseline(batch=8, threads=None, budget_s=12.0, max_steps=12):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line (the JSON): everything else that writes to file descriptor 1 -- RCCL prints its
+    # version banner there when a process group is created -- is sent to stderr
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import numpy as np
     import torch
     from rgbd_gan_amd import kernels
@@ -178,7 +183,7 @@ def main():
     if comm.rank == 0 and comm.size == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline()
     if comm.rank == 0:
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=json_out, flush=True)
     comm.barrier()
     comm.close()
 

@@ -140,5 +140,7 @@ def test_data_parallel_path_on_a_one_rank_rccl_group():
                         "--no-cpu-baseline", "--no-roofline"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "graph capture" not in r.stderr, r.stderr[-2000:]          # no fallback to eager
-    line = json.loads(r.stdout.strip().splitlines()[-1])
+    rows = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]      # RCCL may print its banner to stdout
+    assert len(rows) == 1, r.stdout[-2000:]
+    line = json.loads(rows[0])
     assert line["n_gpus"] == 1 and line["value"] > 0 and np.isfinite(line["ms_per_step"])
