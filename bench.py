@@ -160,13 +160,14 @@ def main():
 
     if comm.rank == 0 and not args.no_roofline:
         # per-launch HIP-event timing of the conv kernels over extra (untimed) steps, on the launch stream
-        # (eager launches: graph replays bypass the Python wrappers that record the events)
-        upd.use_graphs = False
+        # (eager launches: graph replays bypass the Python wrappers that record the events; one stream: with the
+        # two-stream phase overlap an event pair would also time the other stream's kernels sharing the CUs)
+        upd.use_graphs, was_concurrent, upd.concurrent_phases = False, upd.concurrent_phases, False
         with kernels.launch_profile() as prof:
             for _ in range(2):
                 upd.update()
         summ = prof.summary()
-        upd.use_graphs = True
+        upd.use_graphs, upd.concurrent_phases = True, was_concurrent
         table = {k: {"launches": n, "ms": round(t * 1e3, 3), "tflops": round(f / t / 1e12, 1),
                      "avg_us": round(t / n * 1e6, 1), "gbps": round(b / t / 1e9, 1)} for k, (n, t, f, b) in summ.items()}
         dom = max(summ, key=lambda k: summ[k][1])
