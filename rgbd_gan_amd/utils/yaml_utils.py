@@ -1,30 +1,29 @@
-"""Config wrapper with the reference's contract (utils/yaml_utils.py:7-22): attribute access returns None for
-missing keys -- many behaviours of the training loop are selected by ABSENT keys (config.rgb, config.lambda_rotate,
-config.uniform_distribution, ...)."""
+"""Configuration object with the reference's contract (utils/yaml_utils.py:7-22): a YAML mapping whose keys read as
+attributes, and a MISSING key reads as None -- many behaviours of the training loop are selected by absent keys
+(config.rgb, config.lambda_rotate, config.uniform_distribution, config.keep_smoothed_gen, ...)."""
 import yaml
 
 
-class Config(object):
-    def __init__(self, config_dict):
-        object.__setattr__(self, "config", dict(config_dict))
+class Config(dict):
+    """dict with attribute access; `cfg.some_key` is `cfg.get("some_key")`, so unknown keys are None, not errors."""
 
     def __getattr__(self, key):
-        cfg = object.__getattribute__(self, "config")
-        return cfg[key] if key in cfg else None
+        if key.startswith("__"):           # keep copy / pickle protocol probes honest
+            raise AttributeError(key)
+        return self.get(key)
 
     def __setattr__(self, key, value):
-        if key == "config":
-            object.__setattr__(self, key, value)
-        else:
-            self.config[key] = value
+        self[key] = value
 
-    def __getitem__(self, key):
-        return self.config[key]
+    @property
+    def config(self):                      # the reference exposes the underlying mapping under this name
+        return self
 
     def __repr__(self):
-        return yaml.dump(self.config, default_flow_style=False)
+        return yaml.dump(dict(self), default_flow_style=False)
 
 
 def load(path):
-    with open(path) as f:
-        return Config(yaml.safe_load(f))
+    """Read a YAML file into a Config."""
+    with open(path) as stream:
+        return Config(yaml.safe_load(stream) or {})
