@@ -445,3 +445,50 @@ def test_split_k_path_matches_unsplit(B, H, Cin, Cout, K, pad, ups):
     scale = y_ref.float().abs().max().item()
     assert d <= 2 ** -7 * scale, (d, scale)            # one bf16 ulp of the largest output
     assert (y_split.float() - y_ref.float()).abs().mean().item() < 1e-3 * scale
+
+
+@pytest.mark.parametrize("max_depth,min_depth,occ", [(1.0, None, False), (None, 0.95, True), (1.2, 0.8, True)])
+def test_warp_loss_depth_range_masks(max_depth, min_depth, occ):
+    """max_depth / min_depth of LossFuncRotate.__call__ (loss_functions.py:104-118, the background-generator branch of
+    the deepvoxels updater): masks on the SOURCE depth, forward value and both gradients."""
+    from rgbd_gan_amd.common.loss_functions import LossFuncRotate
+    b, S = 2, 32
+    img, img_rot, cam, cam_rot = _warp_case(b, S, seed=77)
+    ref = warp_loss.forward_np(img, cam, img_rot, cam_rot, occlusion_aware=occ, lambda_geometric=3.0,
+                               max_depth=max_depth, min_depth=min_depth)
+    ti = torch.from_numpy(img).requires_grad_(True)
+    tr = torch.from_numpy(img_rot).requires_grad_(True)
+    lt, _ = warp_loss.loss_torch(ti, cam, tr, cam_rot, occlusion_aware=occ, lambda_geometric=3.0, max_depth=max_depth,
+                                 min_depth=min_depth)
+    lt.backward()
+    di = torch.from_numpy(img).to(dev()).requires_grad_(True)
+    dr = torch.from_numpy(img_rot).to(dev()).requires_grad_(True)
+    fn = LossFuncRotate(torch, lambda_geometric=3)
+    loss, _ = fn(di, cam, dr, cam_rot, occlusion_aware=occ, max_depth=max_depth, min_depth=min_depth)
+    loss.backward()
+    assert abs(float(loss.detach()) - ref["loss"]) < 1e-4 * max(1.0, abs(ref["loss"]))
+    assert abs(float(lt.detach()) - ref["loss"]) < 1e-5 * max(1.0, abs(ref["loss"]))
+    scale = float(ti.grad.abs().max())
+    torch.testing.assert_close(di.grad.cpu(), ti.grad, atol=2e-5 * scale, rtol=1e-4)
+    torch.testing.assert_close(dr.grad.cpu(), tr.grad, atol=2e-5 * scale, rtol=1e-4)
+    # the masks do remove pixels in this case (otherwise the test would not see the flags)
+    base = warp_loss.forward_np(img, cam, img_rot, cam_rot, occlusion_aware=occ, lambda_geometric=3.0)["loss"]
+    assert abs(base - ref["loss"]) > 1e-3
+
+
+def test_loss_func_rotate_debug_tuple():
+    """debug=True returns (warped, mask, zp, warped_rot, mask_rot, zp_rot) like loss_functions.py:100-102."""
+    from rgbd_gan_amd.common.loss_functions import LossFuncRotate
+    b, S = 2, 16
+    img, img_rot, cam, cam_rot = _warp_case(b, S, seed=5)
+    ref = warp_loss.forward_np(img, cam, img_rot, cam_rot, occlusion_aware=False, lambda_geometric=3.0)
+    out = LossFuncRotate(torch)(torch.from_numpy(img).to(dev()), cam, torch.from_numpy(img_rot).to(dev()), cam_rot,
+                                debug=True)
+    assert len(out) == 6
+    warped, mask, zp, warped_rot, mask_rot, zp_rot = (t.cpu().numpy() for t in out)
+    np.testing.assert_array_equal(warped.view(np.uint32), ref["warped"].view(np.uint32))
+    np.testing.assert_array_equal(mask, ref["mask"])
+    np.testing.assert_array_equal(zp.view(np.uint32), ref["zp"].view(np.uint32))
+    np.testing.assert_array_equal(warped_rot.view(np.uint32), ref["warped_rot"].view(np.uint32))
+    np.testing.assert_array_equal(mask_rot, ref["mask_rot"])
+    np.testing.assert_array_equal(zp_rot.view(np.uint32), ref["zp_rot"].view(np.uint32))
