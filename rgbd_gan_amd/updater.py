@@ -4,14 +4,17 @@
                 lambda_gp=..., smoothing=..., total_gpu=..., prior=...)
     .stage  .iteration  .update()  .update_core()  .observation
 
-One update_core() = one generator step + one discriminator step:
-    G: x_fake = G(z, stage, theta9); adversarial loss through D (weights frozen: no D weight gradients are computed,
-       the reference computes and discards them); 3D-consistency loss between the two views of each latent
-       (HIP warp-loss kernel); depth hinge; backward; Adam(map), Adam(gen).
-    D: D(x_fake.detach()), D(x_real); softplus losses; R1 penalty on reals by double backward through the HIP
-       conv engine; backward; Adam(dis).
-Data-parallel: each optimizer's flat gradient buffer is all-reduced once (RCCL); the map/gen all-reduce is launched
-right after the G backward and overlaps the D step's forward/backward (which only reads x_fake's values).
+One update_core() computes what the reference's generator step + discriminator step compute (same losses, same
+gradients, same Adam updates), arranged for the GPU:
+    prep : clear gradient buffers, down-size the reals, repack the bf16 weight images
+    gen  : x_fake = G(z, stage, theta9); ONE forward and ONE backward through D(x_fake) -- seeded with the
+           discriminator loss it gives D's weight gradients for the fakes, rescaled per sample it gives the
+           generator's adversarial image gradient; 3D-consistency loss (HIP warp-loss kernel) + depth hinge; G backward
+    dis  : D(x_real), R1 first-order pass, double backward with the adversarial seeds on the reals folded in
+           (runs on a second stream, concurrently with gen)
+    join : merge D's two gradient buffers;  opt : clip + Adam for map / gen / dis (+ EMA generator)
+Each phase is captured once per configuration as a HIP graph and replayed.
+Data-parallel: each optimizer's flat gradient buffer is all-reduced once (RCCL) between join and opt.
 """
 import contextlib
 import math
@@ -235,7 +238,8 @@ class RGBDUpdater:
             self._stagers[key] = _HostStager(shape, dtype, self.device)
         return self._stagers[key]
 
-    # ---- the three phases of a step (each one is capturable: device work only, fixed launch sequence)
+    # ---- the phases of a step: prep, gen || dis, join, opt (each one is capturable: device work only, fixed launch
+    #      sequence)
     def _gen_phase(self, st):
         with kernels.zero_arena.phase(self.device), _alpha_ctx(st):
             self._gen_phase_body(st)
@@ -374,10 +378,6 @@ class RGBDUpdater:
                 self._optimizers[name].update()
         if self.smoothed_gen is not None:          # updater.py:397-400 (after the generator update; D never touches G)
             soft_copy_param(self.smoothed_gen, self.gen, 1.0 - self.smoothing)
-
-    def _distributed(self):
-        opt = self._optimizers["gen"]
-        return opt.comm is not None and opt.comm.size > 1
 
     def _run_phase(self, name, fn, st, key):
         """Eager for the first calls of a configuration, then capture once and replay."""
