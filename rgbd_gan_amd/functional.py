@@ -157,8 +157,34 @@ def _direct_grad(p):
     return (not torch.is_grad_enabled()) and p.is_leaf and p.grad is not None and p.grad.is_contiguous()
 
 
+_DEFERRED = None           # list collecting weight-gradient launches instead of issuing them (deferred_wgrads)
+
+
+@contextlib.contextmanager
+def deferred_wgrads(items):
+    """Inside, the direct weight-gradient launches of a backward pass are not issued but appended to `items`
+    (operands, bound gradient view, kernel parameters).  A weight gradient is a leaf of the backward dependency graph,
+    so the caller can run the collected launches later, elsewhere (run_deferred_wgrads): the step moves D's
+    weight gradients for the fakes off the generator phase's critical chain onto the stream that has gone idle."""
+    global _DEFERRED
+    old = _DEFERRED
+    _DEFERRED = items
+    try:
+        yield items
+    finally:
+        _DEFERRED = old
+
+
+def run_deferred_wgrads(items):
+    for xe, dy, target, K, inv_c in items:
+        kernels.conv2d_wgrad(xe, dy, K, inv_c, out=target, accumulate=True)
+
+
 def _wgrad_into(x, dy, w, layer, ups):
     xe = upsample2(x).contiguous() if ups else x.contiguous()
+    if _DEFERRED is not None:
+        _DEFERRED.append((xe, dy.contiguous(), w.grad, layer.K, layer.inv_c))
+        return
     kernels.conv2d_wgrad(xe, dy.contiguous(), layer.K, layer.inv_c, out=w.grad, accumulate=True)
 
 

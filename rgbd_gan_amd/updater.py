@@ -9,7 +9,9 @@ gradients, same Adam updates), arranged for the GPU:
     prep : clear gradient buffers, down-size the reals, repack the bf16 weight images
     gen  : x_fake = G(z, stage, theta9); ONE forward and ONE backward through D(x_fake) -- seeded with the
            discriminator loss it gives D's weight gradients for the fakes, rescaled per sample it gives the
-           generator's adversarial image gradient; 3D-consistency loss (HIP warp-loss kernel) + depth hinge; G backward
+           generator's adversarial image gradient (gen_a); 3D-consistency loss (HIP warp-loss kernel) + depth hinge;
+           G backward (gen_b)
+    dfw  : D's weight gradients for the fakes, collected during gen_a, issued on the second stream behind dis
     dis  : D(x_real), R1 first-order pass, double backward with the adversarial seeds on the reals folded in
            (runs on a second stream, concurrently with gen)
     join : merge D's two gradient buffers;  opt : clip + Adam for map / gen / dis (+ EMA generator)
@@ -174,7 +176,7 @@ class RGBDUpdater:
         # a blend factor every iteration and run eagerly.
         self.use_graphs = bool(kwargs.pop("use_graphs", True))
         self.graph_warmup = int(kwargs.pop("graph_warmup", 2))
-        self.graph_phases = tuple(kwargs.pop("graph_phases", ("prep", "gen", "dis", "join", "opt")))
+        self.graph_phases = tuple(kwargs.pop("graph_phases", ("prep", "gen", "gen_a", "gen_b", "dfw", "dis", "join", "opt")))
         # the generator phase and the discriminator-on-reals phase are independent until the optimizer phase; on two
         # streams the launch-latency bubbles of one fill with the other's kernels
         # (not when several ranks share one GPU -- the single-GPU test arrangement of the multi-rank path: two
@@ -183,6 +185,9 @@ class RGBDUpdater:
         self.concurrent_phases = bool(kwargs.pop("concurrent_phases", not os.environ.get("RGBD_SEQUENTIAL_PHASES")
                                                  and not os.environ.get("RGBD_SHARE_DEVICE")))
         self._side_stream = None
+        # in that arrangement D's weight gradients for the fakes (leaves of the backward graph) are moved from the
+        # longer generator chain to the tail of the side stream
+        self.defer_dfake_wgrads = bool(kwargs.pop("defer_dfake_wgrads", not os.environ.get("RGBD_NO_DEFER")))
         self._graphs, self._eager_calls, self._stagers = {}, {}, {}
         self.device = self.gen.device
 
@@ -241,8 +246,25 @@ class RGBDUpdater:
     # ---- the phases of a step: prep, gen || dis, join, opt (each one is capturable: device work only, fixed launch
     #      sequence)
     def _gen_phase(self, st):
+        """G forward, the one pass through D(x_fake), G backward -- as one phase (sequential arrangement)."""
         with kernels.zero_arena.phase(self.device), _alpha_ctx(st):
             self._gen_phase_body(st)
+            self._gen_phase_tail(st)
+
+    def _gen_a_phase(self, st):
+        """First part of the generator phase in the two-stream arrangement: up to the image gradient gx.  D's weight
+        gradients for the fakes are only COLLECTED here (st['dfw']): they run on the other stream (_dfw_phase) once the
+        discriminator phase there has finished, instead of lengthening this stream's dependent chain."""
+        st["dfw"] = []
+        with kernels.zero_arena.phase(self.device), _alpha_ctx(st), Fn.deferred_wgrads(st["dfw"]):
+            self._gen_phase_body(st)
+
+    def _gen_b_phase(self, st):
+        with kernels.zero_arena.phase(self.device), _alpha_ctx(st):
+            self._gen_phase_tail(st)
+
+    def _dfw_phase(self, st):
+        Fn.run_deferred_wgrads(st["dfw"])
 
     def _prep_phase(self, st):
         """Everything both concurrent phases depend on: cleared gradient buffers, the down-sized real batch, and the
@@ -293,6 +315,12 @@ class RGBDUpdater:
             with Fn.weight_grads_frozen(self.dis):
                 gx, = torch.autograd.grad([y_fake], [x_d], [seed_g])
             st["loss_dfake"] = None
+        st["gx"], st["x_fake"] = gx, x_fake
+
+    def _gen_phase_tail(self, st):
+        """3-D consistency loss, depth hinge and the generator's backward from (gx, those losses)."""
+        cfg, obs = self.config, self.observation
+        x_fake, gx, half = st["x_fake"], st["gx"], st["B"] // 2
         heads, seeds = [x_fake[:, :3]], [gx]
         if st["use_rotate"]:
             loss_rotate = self.loss_func_rotate.loss_from_coefficients(x_fake[:half], x_fake[half:], st["coef"],
@@ -312,6 +340,7 @@ class RGBDUpdater:
             raise AssertionError("optical flow loss is not supported")
         torch.autograd.backward(heads, seeds)
         st["x_fake_data"] = x_fake.detach()
+        st["x_fake"] = st["gx"] = None                 # drop the autograd graph
 
     def _dis_phase(self, st):
         with _alpha_ctx(st):
@@ -492,7 +521,14 @@ class RGBDUpdater:
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 self._run_phase("dis", self._dis_phase, st, key)           # D on the reals: side stream
-            self._run_phase("gen", self._gen_phase, st, key)               # G + D on the fakes: main stream
+            if self.defer_dfake_wgrads:
+                self._run_phase("gen_a", self._gen_a_phase, st, key)       # G fwd, D(x_fake) fwd + input-gradient chain
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self._run_phase("dfw", self._dfw_phase, st, key)       # D's fake-batch weight gradients, after "dis"
+                self._run_phase("gen_b", self._gen_b_phase, st, key)       # 3-D loss + G backward
+            else:
+                self._run_phase("gen", self._gen_phase, st, key)           # G + D on the fakes: main stream
             main.wait_stream(side)
             # data parallel: the gradient all-reduces start only after the join, so the communicator never competes
             # with two compute streams (map + gen 29 MB and dis 34 MB then go out back to back on an idle GPU)
