@@ -318,6 +318,43 @@ def adain_fused(x, scale_shift):
     return _AdaINFused.apply(x, scale_shift)
 
 
+class StyleGroup:
+    """[scale | shift] rows of several consecutive style blocks, produced by ONE linear from their common latent:
+    `ss` (B, Wtot) with style block j in columns [offsets[j], offsets[j] + 2 C_j).  The AdaIN backward of every block
+    writes its window of one shared gradient buffer; the block that ran FIRST in the forward (its backward runs last:
+    every later block depends on its output) hands that buffer to autograd as the gradient of `ss`."""
+
+    def __init__(self, ss, offsets):
+        self.ss, self.offsets, self.dss = ss, offsets, None
+
+
+class _AdaINWindow(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ss, group, j):
+        y, mean, rstd = kernels.adain_fwd(x.contiguous(), ss, col_off=group.offsets[j])
+        ctx.group, ctx.j = group, j
+        ctx.save_for_backward(x, ss, mean, rstd)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, ss, mean, rstd = ctx.saved_tensors
+        g = ctx.group
+        if g.dss is None:
+            g.dss = torch.empty_like(ss)
+        dx, _, _ = kernels.adain_bwd(x.contiguous(), dy.contiguous(), ss, mean, rstd, fused=True,
+                                     col_off=g.offsets[ctx.j], out=g.dss)
+        if ctx.j == 0:
+            dss, g.dss = g.dss, None
+            return dx, dss, None, None
+        return dx, None, None, None
+
+
+def adain_window(x, group, j):
+    return _AdaINWindow.apply(x, group.ss, group, j)
+
+
 class _WarpLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, img_rot, coef, flags, lam, max_depth, min_depth):

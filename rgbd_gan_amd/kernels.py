@@ -397,38 +397,48 @@ def _off(t, nfloats):
     return ctypes.c_void_p(t.data_ptr() + 4 * nfloats)
 
 
-def adain_fwd(x, scale, shift=None, eps=1e-5):
-    """x (B,H,W,C) bf16; scale, shift (B,C) fp32 -- or scale = (B,2C) fused [scale | shift] with shift None
+def adain_fwd(x, scale, shift=None, eps=1e-5, col_off=0):
+    """x (B,H,W,C) bf16; scale, shift (B,C) fp32 -- or shift None and scale = (B,Wtot) fp32 whose columns
+    [col_off, col_off + 2C) hold [scale | shift] (the fused style-affine output, possibly of several style blocks)
     -> y, mean, rstd."""
     _chk(x, BF16, "x"); _chk(scale, F32, "scale"); _chk(shift, F32, "shift")
     B, H, W, C = x.shape
     fused = shift is None
-    if scale.shape != (B, 2 * C if fused else C):
+    if fused:
+        if scale.dim() != 2 or scale.shape[0] != B or col_off % 4 or col_off + 2 * C > scale.shape[1]:
+            raise RuntimeError(f"adain_fwd: window [{col_off},{col_off + 2 * C}) outside {tuple(scale.shape)}")
+        ld = scale.shape[1]
+    elif scale.shape != (B, C):
         raise RuntimeError(f"adain_fwd: scale {tuple(scale.shape)} does not match x {tuple(x.shape)}")
     y = torch.empty_like(x)
     sums = zero_arena.take(B * C * 2, x.device)
     mean = torch.empty(B, C, dtype=F32, device=x.device)
     rstd = torch.empty(B, C, dtype=F32, device=x.device)
-    rc = _lib.load().rgbd_adain_fwd(_ptr(x), _ptr(scale), _off(scale, C) if fused else _ptr(shift), _ptr(y), _ptr(sums),
-                                    _ptr(mean), _ptr(rstd), B, H * W, C, 2 * C if fused else C, float(eps), _stream())
+    rc = _lib.load().rgbd_adain_fwd(_ptr(x), _off(scale, col_off) if fused else _ptr(scale),
+                                    _off(scale, col_off + C) if fused else _ptr(shift), _ptr(y), _ptr(sums),
+                                    _ptr(mean), _ptr(rstd), B, H * W, C, ld if fused else C, float(eps), _stream())
     _lib.check(rc, "rgbd_adain_fwd")
     return y, mean, rstd
 
 
-def adain_bwd(x, dy, scale, mean, rstd, fused=False):
-    """-> dx, dscale, dshift; with fused (scale = (B,2C) [scale | shift]): dx, d[scale | shift] (B,2C), None."""
-    _chk(x, BF16, "x"); _chk(dy, BF16, "dy"); _chk(scale, F32, "scale")
+def adain_bwd(x, dy, scale, mean, rstd, fused=False, col_off=0, out=None):
+    """-> dx, dscale, dshift; with fused (scale = (B,Wtot), window [col_off, col_off + 2C) = [scale | shift]):
+    dx, d[scale | shift] written into the same window of `out` (B,Wtot) (allocated when None), None."""
+    _chk(x, BF16, "x"); _chk(dy, BF16, "dy"); _chk(scale, F32, "scale"); _chk(out, F32, "out")
     B, H, W, C = x.shape
     dx = torch.empty_like(x)
     sums = zero_arena.take(B * C * 2, x.device)
     if fused:
-        dss = torch.empty(B, 2 * C, dtype=F32, device=x.device)
-        dscale, dshift, ld = _ptr(dss), _off(dss, C), 2 * C
+        ld = scale.shape[1]
+        dss = out if out is not None else torch.empty(B, ld, dtype=F32, device=x.device)
+        if dss.shape != scale.shape:
+            raise RuntimeError("adain_bwd: gradient buffer shape mismatch")
+        sc, dscale, dshift = _off(scale, col_off), _off(dss, col_off), _off(dss, col_off + C)
     else:
         ds = torch.empty(B, C, dtype=F32, device=x.device)
         dsh = torch.empty(B, C, dtype=F32, device=x.device)
-        dscale, dshift, ld = _ptr(ds), _ptr(dsh), C
-    rc = _lib.load().rgbd_adain_bwd(_ptr(x), _ptr(dy), _ptr(scale), _ptr(mean), _ptr(rstd), _ptr(dx), dscale,
+        sc, dscale, dshift, ld = _ptr(scale), _ptr(ds), _ptr(dsh), C
+    rc = _lib.load().rgbd_adain_bwd(_ptr(x), _ptr(dy), sc, _ptr(mean), _ptr(rstd), _ptr(dx), dscale,
                                     dshift, _ptr(sums), B, H * W, C, ld, _stream())
     _lib.check(rc, "rgbd_adain_bwd")
     return (dx, dss, None) if fused else (dx, ds, dsh)

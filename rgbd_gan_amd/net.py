@@ -147,15 +147,21 @@ class StyleGenerator(_Link):
         out_ch = 4 if rgbd else 3
         w_init, b_init = depth_row_init(initial_depth, out_ch, rgbd)
         specs = []
+        # all style affines first, [scale | shift] rows of block 0 s0, block 0 s1, block 1 s0, ... back to back (and
+        # their biases likewise): the affines of any run of consecutive blocks are then ONE matrix (ParamStore.fused)
+        # and one launch (_style_group)
+        for i, (co, ci) in enumerate(self.chans):
+            for s in ("s0", "s1"):
+                specs += [(f"blocks/{i}/{s}/s/c/W", (co, ch), "normal"), (f"blocks/{i}/{s}/b/c/W", (co, ch), "normal")]
+        for i, (co, ci) in enumerate(self.chans):
+            for s in ("s0", "s1"):
+                specs += [(f"blocks/{i}/{s}/s/c/b", (co,), "ones"), (f"blocks/{i}/{s}/b/c/b", (co,), "zeros")]
         for i, (co, ci) in enumerate(self.chans):
             pre = f"blocks/{i}"
             if i == 0:
                 specs.append((pre + "/W", (ci, 4, 4), "ones"))
             specs += [(pre + "/b0/b", (co,), "zeros"), (pre + "/b1/b", (co,), "zeros"),
                       (pre + "/n0/b/W", (co,), "zeros"), (pre + "/n1/b/W", (co,), "zeros")]
-            for s in ("s0", "s1"):        # scale / shift affines back to back: one fused launch (ParamStore.fused)
-                specs += [(f"{pre}/{s}/s/c/W", (co, ch), "normal"), (f"{pre}/{s}/b/c/W", (co, ch), "normal"),
-                          (f"{pre}/{s}/s/c/b", (co,), "ones"), (f"{pre}/{s}/b/c/b", (co,), "zeros")]
             specs += [(pre + "/c0/c/W", (co, ci, 3, 3), "normal"), (pre + "/c1/c/W", (co, co, 3, 3), "normal")]
         for i, (co, _) in enumerate(self.chans):
             specs += [(f"outs/{i}/c/W", (out_ch, co, 1, 1), w_init), (f"outs/{i}/c/b", (out_ch,), b_init)]
@@ -179,19 +185,41 @@ class StyleGenerator(_Link):
         ss = Fn.linear_act(w, W, b, _inv_c(self.ch, 1.0), act=False)           # [scale | shift] in one launch
         return Fn.adain_fused(h, ss)
 
-    def _block(self, i, w, x):
-        """net.py:130-161 (SynthesisBlock.forward), add_noise False (forced at net.py:243)."""
+    def _style_group(self, w, i0, i1):
+        """StyleBlock affines (net.py:96-101) of blocks [i0, i1), all fed by the latent `w`, as one linear."""
+        names_w, names_b, offsets, tot = [], [], {}, 0
+        for i in range(i0, i1):
+            co = self.chans[i][0]
+            for s in ("s0", "s1"):
+                names_w += [f"blocks/{i}/{s}/s/c/W", f"blocks/{i}/{s}/b/c/W"]
+                names_b += [f"blocks/{i}/{s}/s/c/b", f"blocks/{i}/{s}/b/c/b"]
+                offsets[(i, s)] = tot
+                tot += 2 * co
+        W = self.store.fused(tuple(names_w), (tot, self.ch))
+        b = self.store.fused(tuple(names_b), (tot,))
+        ss = Fn.linear_act(w, W, b, _inv_c(self.ch, 1.0), act=False)
+        keys = list(offsets)
+        group = Fn.StyleGroup(ss, [offsets[k] for k in keys])
+        return {k: (group, j) for j, k in enumerate(keys)}
+
+    def _block(self, i, w, x, styles=None):
+        """net.py:130-161 (SynthesisBlock.forward), add_noise False (forced at net.py:243).  `styles`: the windows of
+        a _style_group covering this block (else its two affines are computed here from `w`)."""
         p = self.store.params
         pre = f"blocks/{i}"
+        if styles is not None:
+            style = lambda name, w_, h_: Fn.adain_window(h_, *styles[(i, name[-2:])])
+        else:
+            style = self._style
         if i == 0:
             const = p[pre + "/W"].permute(1, 2, 0).unsqueeze(0)                  # (1,4,4,ch)
             h = Fn.lrelu(const + p[pre + "/b0/b"]).to(BF16).expand(w.shape[0], 4, 4, self.chans[0][1])
             h = h.contiguous()
         else:
             h = Fn.conv_bias_lrelu(x, self.c0[i], p[pre + "/b0/b"], upsample=True)
-        h = self._style(pre + "/s0", w, h)
+        h = style(pre + "/s0", w, h)
         h = Fn.conv_bias_lrelu(h, self.c1[i], p[pre + "/b1/b"])
-        h = self._style(pre + "/s1", w, h)
+        h = style(pre + "/s1", w, h)
         return h
 
     def rotate_w(self, w, theta):
@@ -214,14 +242,17 @@ class StyleGenerator(_Link):
         feat = None
         h = None
 
-        rotated = {}
+        # blocks 0-1 take the pose-conditioned latent, block 2 `w`, blocks 3.. `w2` (net.py:258-263): the style
+        # affines of each run are computed by one linear when its first block comes up
+        groups = {}
 
         def run(i, w_cur, h):
-            if self.rgbd and i < 2:                 # blocks 0 and 1 see the same pose-conditioned style: compute once
-                if id(w_cur) not in rotated:
-                    rotated[id(w_cur)] = self.rotate_w(w_cur, theta)
-                return self._block(i, rotated[id(w_cur)], h)
-            return self._block(i, w_cur, h)
+            n_main = (st - 2) // 2 + 2 if st % 2 == 0 else (st - 1) // 2 + 1      # blocks of the main path
+            seg = (0, min(2, n_main)) if i < 2 else ((2, 3) if i == 2 else (3, n_main))
+            if seg not in groups:
+                src = self.rotate_w(w_cur, theta) if (self.rgbd and i < 2) else w_cur
+                groups[seg] = self._style_group(src, *seg)
+            return self._block(i, w_cur, h, styles=groups[seg])
 
         if st % 2 == 0:
             k = (st - 2) // 2
