@@ -205,7 +205,8 @@ int rgbd_proj_idcs(const float* cam2world, int B, int W, int H, int D, int G, fl
 int rgbd_trilinear_fwd(const float* grid, const int32_t* idx, const float* coords, const int32_t* counts, float* out,
                        int B, int F, int G, int N, void* stream);
 int rgbd_trilinear_bwd(const float* dout, const int32_t* idx, const float* coords, const int32_t* counts, float* dgrid,
-                       int B, int F, int G, int N, void* stream);
+                       float* workspace /* B*G^3*F floats: feature-major scatter target */, int B, int F, int G, int N,
+                       void* stream);
 int rgbd_occlusion_accum_fwd(const float* vol, const float* W1, const float* b1, const float* W2, const float* b2,
                              float threshold, float voxel_size, float near_plane, float* s, float* w, float* feat,
                              float* depth, int B, int F, int D, int HW, void* stream);

@@ -42,7 +42,7 @@ PROTOTYPES = {
     "rgbd_proj_idcs": ([_P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_float,
                         _P, _P, _P, _P, _P], c_int),
     "rgbd_trilinear_fwd": ([_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P], c_int),
-    "rgbd_trilinear_bwd": ([_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P], c_int),
+    "rgbd_trilinear_bwd": ([_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P], c_int),
     "rgbd_occlusion_accum_fwd": ([_P, _P, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P, _P, c_int, c_int, c_int,
                                   c_int, _P], c_int),
     "rgbd_occlusion_accum_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, c_int, c_int, c_int, c_int,

@@ -28,8 +28,9 @@ class _Trilinear(torch.autograd.Function):
         idx, coords, counts = ctx.saved_tensors
         B, F, G, N = ctx.dims
         dgrid = torch.empty(B, F, G, G, G, dtype=torch.float32, device=dout.device)
+        ws = torch.empty(B * G * G * G * F, dtype=torch.float32, device=dout.device)
         rc = _lib.load().rgbd_trilinear_bwd(_ptr(dout.contiguous()), _ptr(idx), _ptr(coords), _ptr(counts), _ptr(dgrid),
-                                            B, F, G, N, _stream())
+                                            _ptr(ws), B, F, G, N, _stream())
         _lib.check(rc, "rgbd_trilinear_bwd")
         return dgrid, None, None, None, None
 

@@ -9,8 +9,10 @@ Differences from RGBDUpdater that the reference has and this keeps (SURVEY.md se
   * the 3-D loss uses the projection intrinsics as K (:92-93), no occlusion flag (:193-196), weight 0.3 (the config
     lookup at :202 tests a misspelt key, so the YAML value can never be used), focal gamma from the YAML (:170).
 
-The class reuses RGBDUpdater's plumbing (optimizer / iterator accessors, batch conversion, finite checks) and
-replaces the step.
+The class reuses RGBDUpdater's plumbing (optimizer / iterator accessors, batch conversion, finite checks, pinned
+upload rings, HIP-graph capture / replay of device-only phases) and replaces the step: two phases, the generator step
+and the discriminator step, each captured once per configuration.  Everything data dependent in them (the number of
+frustum samples inside the grid) stays on the device.
 """
 import numpy as np
 import torch
@@ -55,6 +57,11 @@ class DeepVoxelsUpdater(RGBDUpdater):
         self.iteration, self.observation = 0, {}
         self.fixed_stage = None
         self.device = self.gen.device
+        comm = getattr(self._optimizers["gen"], "comm", None)
+        self.use_graphs = bool(kwargs.pop("use_graphs", True)) and not (comm is not None and comm.active)
+        self.graph_warmup = int(kwargs.pop("graph_warmup", 2))
+        self.graph_phases = ("dv_gen", "dv_dis")
+        self._graphs, self._eager_calls, self._stagers = {}, {}, {}
 
     def get_stage(self):
         return FIXED_STAGE
@@ -62,19 +69,28 @@ class DeepVoxelsUpdater(RGBDUpdater):
     def get_z_fake_data(self, batch_size):
         return self.gen.mapping.make_hidden(batch_size)
 
-    # ---- the two halves of a step
-    def _generator_step(self, latents, cams, theta9, half):
+    # ---- the two halves of a step (device work only: capturable)
+    def _dv_gen_phase(self, st):
         cfg, obs = self.config, self.observation
-        z, z2 = latents
-        x_fake = self.gen(z, FIXED_STAGE, cams, z2=z2, theta=theta9)
-        with self.dis.frozen():                                  # no D weight gradients in the generator step
+        half = st["B"] // 2
+        for link in (self.gen, self.gen.mapping, self.dis):
+            link.cleargrads()
+        if st["z"] is not None:
+            z, z2 = st["z"][0], st["z"][1]
+        else:                                                      # one latent per view PAIR (:146-148)
+            z = self.get_z_fake_data(half).repeat(2, 1, 1, 1, 1)
+            z2 = self.get_z_fake_data(half).repeat(2, 1, 1, 1, 1)
+        with torch.no_grad():
+            st["x_real"] = downsize_real(st["x_real_full"], IMG_SIZE).contiguous()
+        x_fake = self.gen(z, FIXED_STAGE, st["cams"], z2=z2, theta=st["theta9"])
+        with self.dis.frozen():                                    # no D weight gradients in the generator step
             y_fake = self.dis(x_fake[:, :3].contiguous(), stage=FIXED_STAGE)
         loss = loss_func_dcgan_gen(y_fake, cfg.focal_loss_gamma)
         obs["gen/loss_adv"] = loss.detach()
-        if self.iteration > cfg.start_rotation:
+        if st["use_rotate"]:
             if cfg.background_generator:
                 raise AssertionError("background_generator is not supported")
-            rot, _ = self.loss_func_rotate(x_fake[:half], cams[:half], x_fake[half:], cams[half:])
+            rot = self.loss_func_rotate.loss_from_coefficients(x_fake[:half], x_fake[half:], st["coef"], False)
             rot = rot + cfg.lambda_depth * torch.mean(F.relu(cfg.depth_min - x_fake[:, -1]) ** 2)
             obs["gen/loss_rotate"] = rot.detach()
             weight = cfg.lambda_loss_rotate if cfg.lambda_loss_rotatec else 0.3          # sic (:202)
@@ -83,14 +99,17 @@ class DeepVoxelsUpdater(RGBDUpdater):
         for name in ("map", "gen"):
             self.get_optimizer(name).update()
 
-    def _discriminator_step(self, latents, cams, theta9, x_real):
-        obs = self.observation
+    def _dv_dis_phase(self, st):
+        obs, B = self.observation, st["B"]
         self.dis.cleargrads()
-        z, z2 = latents
-        with torch.no_grad():                                    # fresh fakes from the UPDATED generator (:221-228)
-            x_fake = self.gen(z, FIXED_STAGE, cams, z2=z2, theta=theta9)
+        if st["z"] is not None:
+            z, z2 = st["z"][2], st["z"][3]
+        else:
+            z, z2 = self.get_z_fake_data(B), self.get_z_fake_data(B)
+        with torch.no_grad():                                      # fresh fakes from the UPDATED generator (:221-228)
+            x_fake = self.gen(z, FIXED_STAGE, st["cams"], z2=z2, theta=st["theta9"])
         y_fake = self.dis(x_fake[:, :3].contiguous(), stage=FIXED_STAGE)
-        x_real = x_real.detach().requires_grad_(True)
+        x_real = st["x_real"].detach().requires_grad_(True)
         y_real = self.dis(x_real, stage=FIXED_STAGE)
         adv = loss_func_dcgan_dis(y_fake, y_real)
         obs["dis/loss_adv"] = adv.detach()
@@ -106,30 +125,47 @@ class DeepVoxelsUpdater(RGBDUpdater):
 
     def update_core(self, batch=None, z_fake=None, thetas=None):
         """z_fake: optional (z, z2, z_dis, z2_dis) injected by tests; otherwise drawn as the reference draws them."""
-        for link in (self.gen, self.gen.mapping, self.dis):
-            link.cleargrads()
         if batch is None:
             batch = self.get_iterator("main").next()
         B = len(batch)
         half = B // 2
         x_real_full = self.get_x_real_data(batch, B)
-        if z_fake is None:
-            pair = lambda: self.get_z_fake_data(half).repeat(2, 1, 1, 1, 1)          # one latent per view PAIR
-            g_lat, d_lat = (pair(), pair()), None
-        else:
-            dev = [torch.as_tensor(z).to(self.device, torch.float32) for z in z_fake]
-            g_lat, d_lat = (dev[0], dev[1]), (dev[2], dev[3])
+        # host side, NumPy, as the reference: pose prior, camera matrices, pose code, warp constants
         thetas = np.asarray(self.prior.sample(B) if thetas is None else thetas, dtype="float32")
-        cams, theta9 = get_camera_matries(thetas), pose_code(thetas)
-        with torch.no_grad():
-            x_real = downsize_real(x_real_full, IMG_SIZE).contiguous()
+        cams = get_camera_matries(thetas)
+        use_rotate = self.iteration > self.config.start_rotation
+        st = {"B": B, "use_rotate": use_rotate, "z": None}
+        st["cams"] = self._stager("cams", (B, 4, 4)).upload(cams)
+        st["theta9"] = self._stager("theta9", (B, 9)).upload(pose_code(thetas))
+        if use_rotate:
+            coef = self.loss_func_rotate.coefficients_for_size(IMG_SIZE, cams[:half], cams[half:])
+            st["coef"] = self._stager("coef", (half, 24)).upload(coef)
+        if z_fake is not None:
+            zs = []
+            for i, z in enumerate(z_fake):
+                z = torch.as_tensor(z).to(self.device, torch.float32)
+                zkey = ("z", i) + tuple(z.shape)
+                if zkey not in self._stagers:
+                    self._stagers[zkey] = torch.empty_like(z)
+                self._stagers[zkey].copy_(z)
+                zs.append(self._stagers[zkey])
+            st["z"] = zs
+        key = None
+        if self.use_graphs:
+            skey = ("x_real_full",) + tuple(x_real_full.shape)
+            if skey not in self._stagers:
+                self._stagers[skey] = torch.empty_like(x_real_full)
+            self._stagers[skey].copy_(x_real_full)
+            x_real_full = self._stagers[skey]
+            key = (B, use_rotate, tuple(x_real_full.shape), z_fake is not None)
+        st["x_real_full"] = x_real_full
 
-        self._generator_step(g_lat, cams, theta9, half)
-        if d_lat is None:
-            d_lat = (self.get_z_fake_data(B), self.get_z_fake_data(B))
-        self._discriminator_step(d_lat, cams, theta9, x_real)
+        self._run_phase("dv_gen", self._dv_gen_phase, st, key)
+        self._run_phase("dv_dis", self._dv_dis_phase, st, key)
+        if key is not None:
+            Fn.bump_weight_epoch()      # replays change the weights behind Python's back: invalidate packed caches
 
         obs = self.observation
-        obs["stage"], obs["batch_size"], obs["image_size"] = FIXED_STAGE, B, int(x_real.shape[2])
+        obs["stage"], obs["batch_size"], obs["image_size"] = FIXED_STAGE, B, IMG_SIZE
         if self.nan_check_interval > 0 and (self.iteration + 1) % self.nan_check_interval == 0:
             self._check_finite()
