@@ -470,28 +470,48 @@ __global__ __launch_bounds__(256) void from_planes_kernel(const float* __restric
                                                           const float* __restrict__ bias,
                                                           unsigned short* __restrict__ y, int B, int HW, int C,
                                                           float wscale, int act, float slope) {
+    // A thread keeps ONE octet of output channels for its whole walk (the grid stride is a multiple of C/8), so its
+    // 8 x KP weights and 8 biases sit in registers; four pixels' plane values are requested before any is used.
     const int cvec = C >> 3;
     const long nvec = (long)B * HW * cvec;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nvec; e += (long)gridDim.x * 256) {
-        const int cv = (int)(e % cvec);
-        const long pix = e / cvec;
-        const int b = (int)(pix / HW);
-        const int p = (int)(pix - (long)b * HW);
-        float xin[KP];
+    const long e0 = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    const int cv = (int)(e0 % cvec);
+    float wr[8][KP], br[8];
 #pragma unroll
-        for (int k = 0; k < KP; ++k) xin[k] = x[((long)b * KP + k) * HW + p] * wscale;
-        float r[8];
+    for (int j = 0; j < 8; ++j) {
+        br[j] = bias ? bias[cv * 8 + j] : 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int co = cv * 8 + j;
-            float acc = bias ? bias[co] : 0.f;
+        for (int k = 0; k < KP; ++k) wr[j][k] = w[(cv * 8 + j) * KP + k] * wscale;
+    }
+    for (long e = e0; e < nvec; e += 4 * stride) {
+        float xin[4][KP];
 #pragma unroll
-            for (int k = 0; k < KP; ++k) acc += w[co * KP + k] * xin[k];
-            if (act) acc = acc > 0.f ? acc : acc * slope;
-            r[j] = acc;
+        for (int u = 0; u < 4; ++u) {
+            const long eu = e + u * stride;
+            const long pix = (eu < nvec ? eu : e) / cvec;
+            const int b = (int)(pix / HW);
+            const int p = (int)(pix - (long)b * HW);
+#pragma unroll
+            for (int k = 0; k < KP; ++k) xin[u][k] = x[((long)b * KP + k) * HW + p];
         }
-        u32x4 out = {pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3]), pack_bf16x2(r[4], r[5]), pack_bf16x2(r[6], r[7])};
-        *reinterpret_cast<u32x4*>(y + e * 8) = out;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long eu = e + u * stride;
+            if (eu < nvec) {
+                float r[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float acc = br[j];
+#pragma unroll
+                    for (int k = 0; k < KP; ++k) acc += wr[j][k] * xin[u][k];
+                    r[j] = act ? (acc > 0.f ? acc : acc * slope) : acc;
+                }
+                u32x4 out = {pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3]), pack_bf16x2(r[4], r[5]),
+                             pack_bf16x2(r[6], r[7])};
+                *reinterpret_cast<u32x4*>(y + eu * 8) = out;
+            }
+        }
     }
 }
 
@@ -550,19 +570,29 @@ __global__ __launch_bounds__(256) void planes_outer_kernel(const unsigned short*
     for (int k = 0; k <= KP; ++k)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
-    for (int r = r_begin + lane_p; r < r_end; r += 32) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(t + ((long)b * HW + r) * C + c0);
-        float f[8];
+    for (int r0 = r_begin + lane_p; r0 < r_end; r0 += 128) {            // four rows' loads in flight per lane
+        u32x4 v[4];
+        float pv[4][KP];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { f[2 * q] = bf16_lo(v[q]); f[2 * q + 1] = bf16_hi(v[q]); }
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + 32 * u < r_end ? r0 + 32 * u : r0;
+            v[u] = *reinterpret_cast<const u32x4*>(t + ((long)b * HW + r) * C + c0);
 #pragma unroll
-        for (int k = 0; k < KP; ++k) {
-            const float pv = p[((long)b * KP + k) * HW + r];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[k][j] += pv * f[j];
+            for (int k = 0; k < KP; ++k) pv[u][k] = r0 + 32 * u < r_end ? p[((long)b * KP + k) * HW + r] : 0.f;
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[KP][j] += f[j];
+        for (int u = 0; u < 4; ++u) {
+            if (r0 + 32 * u >= r_end) break;
+            float f[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { f[2 * q] = bf16_lo(v[u][q]); f[2 * q + 1] = bf16_hi(v[u][q]); }
+#pragma unroll
+            for (int k = 0; k < KP; ++k)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[k][j] += pv[u][k] * f[j];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[KP][j] += f[j];
+        }
     }
     __shared__ float red[32][65];
     for (int k = 0; k <= KP; ++k) {
@@ -1008,7 +1038,7 @@ extern "C" int rgbd_planes_outer(const void* t, const float* p, float* o, float*
         rgbd_set_error("rgbd_planes_outer: memset failed");
         return -2;
     }
-    const int rows = 1024;
+    const int rows = 512;
     dim3 grid(ceil_div(HW, rows), C / 64, B);
     if (KP == 3) planes_outer_kernel<3><<<grid, 256, 0, st>>>((const unsigned short*)t, p, o, tsum, B, HW, C, rows);
     else         planes_outer_kernel<4><<<grid, 256, 0, st>>>((const unsigned short*)t, p, o, tsum, B, HW, C, rows);
