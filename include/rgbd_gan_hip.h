@@ -152,12 +152,14 @@ int rgbd_axpy_rows_bf16(const void* a, const void* x, const float* s, void* out,
                         void* stream);
 
 /* 2x2 average pooling of the discriminator blocks (rescale.py:12-13) fused with the leaky-ReLU that precedes it:
- *   rgbd_unpool2_lrelu_bwd: dz[b,h,w,c] = 0.25 * dp[b,h/2,w/2,c] * lrelu'(y[b,h,w,c])   (y NULL: no mask); bias_grad as above
+ *   rgbd_unpool2_lrelu_bwd: dz[b,h,w,c] = 0.25 * dp[b,h/2,w/2,c] * lrelu'(y[b,h,w,c])   (y NULL: no mask); bias_grad as above;
+ *                           bias_grad2 (or NULL) receives the same column sums: in a residual block (net.py:413-416) the
+ *                           shortcut conv's bias has the gradient of the main conv's bias, dz being the gradient of both
  *   rgbd_pool2_masked     : out[b,hp,wp,c] = 0.25 * sum_{2x2} x * lrelu'(y)              (y NULL: plain average pool)
  * The two are adjoint (same mask), which closes the pair under differentiation (R1 double backward).
  */
 int rgbd_unpool2_lrelu_bwd(const void* dp, const void* y, void* dz, int B, int H, int W, int C, float slope,
-                           float* bias_grad, const float* row_scale, void* stream);
+                           float* bias_grad, float* bias_grad2, const float* row_scale, void* stream);
 int rgbd_pool2_masked(const void* x, const void* y, void* out, int B, int H, int W, int C, float slope, void* stream);
 
 /* 1x1 convolutions between NCHW fp32 image planes (KP = 3 or 4 channels) and NHWC bf16 features (C channels):

@@ -306,6 +306,7 @@ __global__ __launch_bounds__(256) void unpool_lrelu_bwd_kernel(const unsigned sh
                                                                unsigned short* __restrict__ dz, long M, int H, int W,
                                                                int C, float slope, int rows_per_block,
                                                                float* __restrict__ bias_grad,
+                                                               float* __restrict__ bias_grad2,
                                                                const float* __restrict__ row_scale) {
     // same lane layout and 4-pass load batching as lrelu_bwd_colsum_kernel; dp is read at the pooled position
     const int cg = blockIdx.y;
@@ -359,6 +360,7 @@ __global__ __launch_bounds__(256) void unpool_lrelu_bwd_kernel(const unsigned sh
 #pragma unroll 8
             for (int r = 0; r < 32; ++r) acc += red[r][threadIdx.x];
             atomicAdd(bias_grad + cg * 64 + threadIdx.x, acc);
+            if (bias_grad2) atomicAdd(bias_grad2 + cg * 64 + threadIdx.x, acc);
         }
     }
 }
@@ -975,7 +977,7 @@ extern "C" int rgbd_axpy_rows_bf16(const void* a, const void* x, const float* s,
 }
 
 extern "C" int rgbd_unpool2_lrelu_bwd(const void* dp, const void* y, void* dz, int B, int H, int W, int C, float slope,
-                                      float* bias_grad, const float* row_scale, void* stream) {
+                                      float* bias_grad, float* bias_grad2, const float* row_scale, void* stream) {
     RGBD_REQUIRE(dp && dz, "rgbd_unpool2_lrelu_bwd: null pointer");
     RGBD_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C % 64 == 0,
                  "rgbd_unpool2_lrelu_bwd: H, W must be even and C a multiple of 64 (H=%d W=%d C=%d)", H, W, C);
@@ -984,7 +986,7 @@ extern "C" int rgbd_unpool2_lrelu_bwd(const void* dp, const void* y, void* dz, i
     dim3 grid(ceil_div(M, rows), C / 64);
     unpool_lrelu_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const unsigned short*)dp, (const unsigned short*)y,
                                                                   (unsigned short*)dz, M, H, W, C, slope, rows, bias_grad,
-                                                                  row_scale);
+                                                                  bias_grad ? bias_grad2 : nullptr, row_scale);
     RGBD_CHECK_LAUNCH("unpool_lrelu_bwd_kernel");
     return 0;
 }

@@ -452,18 +452,19 @@ class _UnpoolLreluGrad(torch.autograd.Function):
     its adjoint is _PoolMasked with the same mask."""
 
     @staticmethod
-    def forward(ctx, dp, y, shape, use_mask, inject_bias=None):
+    def forward(ctx, dp, y, shape, use_mask, inject_bias=None, inject_bias2=None):
         ctx.use_mask = use_mask
         ctx.save_for_backward(y)
         if inject_bias is not None:
             return kernels.unpool2_lrelu_bwd(dp.contiguous(), y if use_mask else None, shape,
-                                             bias_grad=inject_bias.grad, row_scale=_INJECT)
+                                             bias_grad=inject_bias.grad, row_scale=_INJECT,
+                                             bias_grad2=inject_bias2.grad if inject_bias2 is not None else None)
         return kernels.unpool2_lrelu_bwd(dp.contiguous(), y if use_mask else None, shape)
 
     @staticmethod
     def backward(ctx, ddz):
         y, = ctx.saved_tensors
-        return _PoolMasked.apply(ddz.contiguous(), y.detach(), ctx.use_mask), None, None, None, None
+        return _PoolMasked.apply(ddz.contiguous(), y.detach(), ctx.use_mask), None, None, None, None, None
 
 
 class _PoolMasked(torch.autograd.Function):
@@ -488,13 +489,14 @@ class _ConvBiasAct(torch.autograd.Function):
     dgrad, wgrad, column sum), so the R1 double backward goes through it."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, residual, layer, ups, act, pool):
+    def forward(ctx, x, w, bias, residual, layer, ups, act, pool, tie=None, tie_owner=False):
         wf, _ = layer.packed()
         x = x.contiguous()
         y = kernels.conv2d_fprop(x, wf, layer.K, layer.K, layer.pad, bias=bias.contiguous(),
                                  residual=residual.contiguous() if residual is not None else None, upsample=ups,
                                  lrelu_channels=w.shape[0] if act else 0)
         ctx.layer, ctx.ups, ctx.act, ctx.pool = layer, ups, act, pool
+        ctx.tie, ctx.tie_owner = tie, tie_owner
         ctx.save_for_backward(x, w, y, bias)
         return kernels.pool2_masked(y) if pool else y
 
@@ -510,11 +512,28 @@ class _ConvBiasAct(torch.autograd.Function):
         # taken here, fused with the activation gradient, instead of in a pass of their own during the double backward
         inj_b = bias if (_INJECT is not None and torch.is_grad_enabled() and ctx.needs_input_grad[2] and bias.is_leaf
                          and bias.grad is not None and bias.data_ptr() not in _FROZEN_PTRS) else None
+        tie, tied_inject = ctx.tie, False
+        if tie is not None and ctx.tie_owner:
+            # shortcut conv of a residual block: the main conv's activation-gradient pass (which ran just before, dz
+            # being the gradient of both pre-activations) has already added the column sums to this bias
+            if tie.done:
+                tie.done = False
+                tied_inject = inj_b is not None
+                want_b, fast_b, inj_b = False, False, None
         if ctx.pool:
+            tb = None
+            if tie is not None and not ctx.tie_owner and (fast_b or inj_b is not None) and tie.usable(not fast_b):
+                tb = tie.bias
             if fast_b:
-                dz = kernels.unpool2_lrelu_bwd(dy, y if ctx.act else None, tuple(y.shape), bias_grad=bias.grad)
+                dz = kernels.unpool2_lrelu_bwd(dy, y if ctx.act else None, tuple(y.shape), bias_grad=bias.grad,
+                                               bias_grad2=tb.grad if tb is not None else None)
+                if tb is not None:
+                    tie.done = True
             else:
-                dz = _UnpoolLreluGrad.apply(dy, y.detach(), tuple(y.shape), ctx.act, inj_b)
+                dz = _UnpoolLreluGrad.apply(dy, y.detach(), tuple(y.shape), ctx.act, inj_b,
+                                            tb if inj_b is not None else None)
+                if tb is not None and inj_b is not None:
+                    tie.done = True
         elif ctx.act:
             dz = kernels.lrelu_bwd(dy, y, w.shape[0], bias_grad=bias.grad) if fast_b else \
                 _LreluGrad.apply(dy, y.detach(), w.shape[0], inj_b)
@@ -528,7 +547,7 @@ class _ConvBiasAct(torch.autograd.Function):
             db = _ColSum.apply(dz)
         if ctx.needs_input_grad[0]:
             # bias=None when its injected gradient has been taken above
-            dx = _ConvDgrad.apply(dz, w, layer, ups, x.detach(), None if inj_b is not None else bias)
+            dx = _ConvDgrad.apply(dz, w, layer, ups, x.detach(), None if (inj_b is not None or tied_inject) else bias)
         if ctx.needs_input_grad[1] and not _skip_grad_of(w):
             if _direct_grad(w):
                 _wgrad_into(x, dz, w, layer, ups)
@@ -536,15 +555,32 @@ class _ConvBiasAct(torch.autograd.Function):
                 dw = _ConvWgrad.apply(x, dz, layer, ups)
         if ctx.needs_input_grad[3]:
             dres = dz
-        return dx, dw, db, dres, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None
 
 
-def conv_bias_lrelu(x, layer, bias, upsample=False, residual=None, pool=False):
-    return _ConvBiasAct.apply(x, layer.weight, bias, residual, layer, bool(upsample), True, bool(pool))
+class BiasTie:
+    """Links the bias of a residual block's shortcut conv to the activation-gradient pass of the block's main conv
+    (net.py:413-416: h = lrelu(c1(h) + c_sc(x))): the gradient w.r.t. the sum is the gradient of BOTH biases, so the
+    fused pass adds its column sums to both gradient buffers and the shortcut conv skips a reduction of its own."""
+
+    def __init__(self, bias):
+        self.bias, self.done = bias, False
+
+    def usable(self, inject):
+        """Mirrors the conditions under which _ConvBiasAct.backward takes its own bias sums in the fused pass."""
+        b = self.bias
+        if inject:
+            return b.requires_grad and b.is_leaf and b.grad is not None and b.data_ptr() not in _FROZEN_PTRS
+        return b.requires_grad and _direct_grad(b) and not _skip_grad_of(b)
 
 
-def conv_bias(x, layer, bias, upsample=False, residual=None):
-    return _ConvBiasAct.apply(x, layer.weight, bias, residual, layer, bool(upsample), False, False)
+def conv_bias_lrelu(x, layer, bias, upsample=False, residual=None, pool=False, residual_tie=None):
+    return _ConvBiasAct.apply(x, layer.weight, bias, residual, layer, bool(upsample), True, bool(pool), residual_tie,
+                              False)
+
+
+def conv_bias(x, layer, bias, upsample=False, residual=None, tie=None):
+    return _ConvBiasAct.apply(x, layer.weight, bias, residual, layer, bool(upsample), False, False, tie, True)
 
 
 # ---- 1x1 convolutions between NCHW fp32 image planes and NHWC bf16 features (fromRGB / toRGB)

@@ -271,14 +271,15 @@ def axpy_rows(a, x, s):
     return out
 
 
-def unpool2_lrelu_bwd(dp, y, shape, slope=0.2, bias_grad=None, row_scale=None):
+def unpool2_lrelu_bwd(dp, y, shape, slope=0.2, bias_grad=None, row_scale=None, bias_grad2=None):
     """dz (B,H,W,C) = 0.25 * upsample2(dp) * lrelu'(y); y may be None (plain average-pool backward).  bias_grad /
-    row_scale as in lrelu_bwd."""
+    row_scale as in lrelu_bwd; bias_grad2 receives the same sums as bias_grad (shortcut bias of a residual block)."""
     _chk(dp, BF16, "dp"); _chk(y, BF16, "y"); _chk(bias_grad, F32, "bias_grad"); _chk(row_scale, F32, "row_scale")
+    _chk(bias_grad2, F32, "bias_grad2")
     B, H, W, C = shape
     dz = torch.empty(B, H, W, C, dtype=BF16, device=dp.device)
     rc = _lib.load().rgbd_unpool2_lrelu_bwd(_ptr(dp), _ptr(y), _ptr(dz), B, H, W, C, float(slope), _ptr(bias_grad),
-                                            _ptr(row_scale), _stream())
+                                            _ptr(bias_grad2), _ptr(row_scale), _stream())
     _lib.check(rc, "rgbd_unpool2_lrelu_bwd")
     return dz
 

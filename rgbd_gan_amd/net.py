@@ -459,8 +459,10 @@ class Discriminator(_Link):
         # net.py:408-426: h = lrelu(c0 x); h = lrelu(c1 h + c_sc x); avg-pool.  Bias, shortcut add and activation
         # all ride in the conv epilogues; the 2x2 average pool and its backward are fused with the activation gradient.
         h = Fn.conv_bias_lrelu(x, self.conv[pre + "/c0"], p[pre + "/c0/c/b"])
-        sc = Fn.conv_bias(x, self.conv[pre + "/c_sc"], p[pre + "/c_sc/c/b"]) if self.res else None
-        return Fn.conv_bias_lrelu(h, self.conv[pre + "/c1"], p[pre + "/c1/c/b"], residual=sc, pool=True)
+        tie = Fn.BiasTie(p[pre + "/c_sc/c/b"]) if self.res else None
+        sc = Fn.conv_bias(x, self.conv[pre + "/c_sc"], p[pre + "/c_sc/c/b"], tie=tie) if self.res else None
+        return Fn.conv_bias_lrelu(h, self.conv[pre + "/c1"], p[pre + "/c1/c/b"], residual=sc, pool=True,
+                                  residual_tie=tie)
 
     def __call__(self, x, stage, return_hidden=False):
         x = _as_device_tensor(x, self.device)

@@ -307,9 +307,11 @@ def test_pool_and_unpool_lrelu_kernels():
     yd, xd, dpd = (t.to(dev()).to(torch.bfloat16) for t in (y, x, dp))
     # unpool (+ fused bias gradient)
     bg = torch.zeros(C, device=dev())
-    dz = kernels.unpool2_lrelu_bwd(dpd, yd, (B, H, H, C), bias_grad=bg)
+    bg2 = torch.ones(C, device=dev())                   # the shortcut bias of a residual block gets the same sums
+    dz = kernels.unpool2_lrelu_bwd(dpd, yd, (B, H, H, C), bias_grad=bg, bias_grad2=bg2)
     torch.testing.assert_close(dz.float().cpu(), bf16_round(0.25 * up * mask), atol=1e-6, rtol=1e-6)
     torch.testing.assert_close(bg.cpu(), dz.float().cpu().reshape(-1, C).sum(0), atol=1e-3, rtol=1e-4)
+    assert torch.equal(bg2.cpu() - 1.0, (bg.cpu() + 1.0) - 1.0)
     dz0 = kernels.unpool2_lrelu_bwd(dpd, None, (B, H, H, C))
     torch.testing.assert_close(dz0.float().cpu(), bf16_round(0.25 * up), atol=1e-6, rtol=1e-6)
     # pool, masked and plain; adjointness <pool(x), dp> == <x, unpool(dp)>
