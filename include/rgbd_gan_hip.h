@@ -132,9 +132,13 @@ int rgbd_conv2d_wgrad_bf16(const void* x, const void* dy, void* workspace, float
 int rgbd_adain_fwd(const void* x, const float* scale, const float* shift, void* y,
                    float* sums, float* mean, float* rstd, int B, int HW, int C, int ld, float eps, void* stream);
 /* dy (B,HW,C) bf16 -> dx bf16, dscale/dshift fp32 rows `ld` apart like scale (overwritten).
- * sums: workspace (B,C,2) fp32, zeroed by the caller. */
+ * sums: workspace (B,C,2) fp32, zeroed by the caller.
+ * lrelu_slope > 0: x is the output of the leaky ReLU feeding this AdaIN (net.py:150-153: conv -> bias -> lrelu -> style)
+ *   and dx additionally carries that activation's gradient, dx *= (x > 0 ? 1 : lrelu_slope); bias_grad (C) fp32 or NULL
+ *   then accumulates sum_{b,p} dx (the gradient of the L.Bias in front of the activation). */
 int rgbd_adain_bwd(const void* x, const void* dy, const float* scale, const float* mean, const float* rstd,
-                   void* dx, float* dscale, float* dshift, float* sums, int B, int HW, int C, int ld, void* stream);
+                   void* dx, float* dscale, float* dshift, float* sums, int B, int HW, int C, int ld,
+                   float lrelu_slope, float* bias_grad, void* stream);
 
 /* ------------------------------------------------------------------ small fused elementwise / 1x1 kernels (HBM-bound)
  * rgbd_lrelu_bwd: dz = dy * (y > 0 ? 1 : slope) on channels [0, act_channels) of (M,C) bf16 tensors, pass-through on

@@ -163,6 +163,14 @@ __global__ __launch_bounds__(256) void adain_apply_kernel(const unsigned short* 
 }
 
 // dx = rstd * scale * (dy - sum(dy)/HW - xhat * sum(dy*xhat)/HW);  sums = (sum dy, sum dy*xhat) per (b,c)
+// A block owns a strip of rows of ONE sample and one 64-channel group: the per-(b,c) constants (mean, rstd, scale, the
+// two sums) are read once per thread, and 8 independent 16-byte loads per lane are in flight (lane layout and 4-pass
+// batching of lrelu_bwd_colsum_kernel below).
+// MASK: x is the OUTPUT of the leaky ReLU that feeds this AdaIN (net.py:150-153,157-160: conv -> bias -> lrelu -> style),
+// so the activation gradient is applied in the same pass, dz = dx * (x > 0 ? 1 : slope), and the bias gradient
+// bias_grad[c] += sum dz rides along: one pass over HBM instead of the AdaIN backward plus a separate
+// activation-gradient pass.
+template <bool MASK>
 __global__ __launch_bounds__(256) void adain_bwd_apply_kernel(const unsigned short* __restrict__ x,
                                                               const unsigned short* __restrict__ dy,
                                                               const float* __restrict__ scale,
@@ -171,46 +179,80 @@ __global__ __launch_bounds__(256) void adain_bwd_apply_kernel(const unsigned sho
                                                               const float* __restrict__ sums,
                                                               unsigned short* __restrict__ dx,
                                                               float* __restrict__ dscale, float* __restrict__ dshift,
-                                                              long nvec, int HW, int C, float inv_hw, int ld) {
-    const int cvec = C >> 3;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nvec; e += (long)gridDim.x * 256) {
-        const int cv = (int)(e % cvec);
-        const long pix = e / cvec;
-        const int b = (int)(pix / HW);
-        const long sidx = (long)b * C + cv * 8;
-        const long aidx = (long)b * ld + cv * 8;
-        const u32x4 xv = *reinterpret_cast<const u32x4*>(x + e * 8);
-        const u32x4 gv = *reinterpret_cast<const u32x4*>(dy + e * 8);
-        const f32x4 sa = *reinterpret_cast<const f32x4*>(sums + 2 * sidx), sb = *reinterpret_cast<const f32x4*>(sums + 2 * sidx + 4);
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(sums + 2 * sidx + 8), sd = *reinterpret_cast<const f32x4*>(sums + 2 * sidx + 12);
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(scale + aidx), g1 = *reinterpret_cast<const f32x4*>(scale + aidx + 4);
-        const f32x4 m0 = *reinterpret_cast<const f32x4*>(mean + sidx), m1 = *reinterpret_cast<const f32x4*>(mean + sidx + 4);
-        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rstd + sidx), r1 = *reinterpret_cast<const f32x4*>(rstd + sidx + 4);
-        const float s1[8] = {sa[0], sa[2], sb[0], sb[2], sc[0], sc[2], sd[0], sd[2]};          // sum dy
-        const float s2[8] = {sa[1], sa[3], sb[1], sb[3], sc[1], sc[3], sd[1], sd[3]};          // sum dy * xhat
-        const float gg[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-        const float mm[8] = {m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2], m1[3]};
-        const float rr[8] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
-        if (pix == (long)b * HW) {      // d shift = sum dy, d scale = sum dy * xhat (adain.py:76-77)
-            *reinterpret_cast<f32x4*>(dshift + aidx) = f32x4{s1[0], s1[1], s1[2], s1[3]};
-            *reinterpret_cast<f32x4*>(dshift + aidx + 4) = f32x4{s1[4], s1[5], s1[6], s1[7]};
-            *reinterpret_cast<f32x4*>(dscale + aidx) = f32x4{s2[0], s2[1], s2[2], s2[3]};
-            *reinterpret_cast<f32x4*>(dscale + aidx + 4) = f32x4{s2[4], s2[5], s2[6], s2[7]};
+                                                              int HW, int C, float inv_hw, int ld, int rows_per_block,
+                                                              float slope, float* __restrict__ bias_grad) {
+    const int cg = blockIdx.y, b = blockIdx.z;
+    const int chunk = threadIdx.x & 7, lane_p = threadIdx.x >> 3;
+    const int c0 = cg * 64 + chunk * 8;
+    const long sidx = (long)b * C + c0;
+    const long aidx = (long)b * ld + c0;
+    const f32x4 sa = *reinterpret_cast<const f32x4*>(sums + 2 * sidx), sb = *reinterpret_cast<const f32x4*>(sums + 2 * sidx + 4);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(sums + 2 * sidx + 8), sd = *reinterpret_cast<const f32x4*>(sums + 2 * sidx + 12);
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(scale + aidx), g1 = *reinterpret_cast<const f32x4*>(scale + aidx + 4);
+    const f32x4 m0 = *reinterpret_cast<const f32x4*>(mean + sidx), m1 = *reinterpret_cast<const f32x4*>(mean + sidx + 4);
+    const f32x4 r0v = *reinterpret_cast<const f32x4*>(rstd + sidx), r1v = *reinterpret_cast<const f32x4*>(rstd + sidx + 4);
+    const float s1[8] = {sa[0], sa[2], sb[0], sb[2], sc[0], sc[2], sd[0], sd[2]};          // sum dy
+    const float s2[8] = {sa[1], sa[3], sb[1], sb[3], sc[1], sc[3], sd[1], sd[3]};          // sum dy * xhat
+    const float gg[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+    const float mm[8] = {m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2], m1[3]};
+    const float rr[8] = {r0v[0], r0v[1], r0v[2], r0v[3], r1v[0], r1v[1], r1v[2], r1v[3]};
+    if (blockIdx.x == 0 && lane_p == 0) {      // d shift = sum dy, d scale = sum dy * xhat (adain.py:76-77)
+        *reinterpret_cast<f32x4*>(dshift + aidx) = f32x4{s1[0], s1[1], s1[2], s1[3]};
+        *reinterpret_cast<f32x4*>(dshift + aidx + 4) = f32x4{s1[4], s1[5], s1[6], s1[7]};
+        *reinterpret_cast<f32x4*>(dscale + aidx) = f32x4{s2[0], s2[1], s2[2], s2[3]};
+        *reinterpret_cast<f32x4*>(dscale + aidx + 4) = f32x4{s2[4], s2[5], s2[6], s2[7]};
+    }
+    const int r_begin = blockIdx.x * rows_per_block;
+    const int r_end = min(HW, r_begin + rows_per_block);
+    const long base = (long)b * HW;
+    float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int r0 = r_begin + lane_p; r0 < r_end; r0 += 128) {
+        u32x4 xv[4], gv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = (r0 + 32 * u) < r_end ? (r0 + 32 * u) : r0;
+            const long off = (base + r) * C + c0;
+            xv[u] = *reinterpret_cast<const u32x4*>(x + off);
+            gv[u] = *reinterpret_cast<const u32x4*>(dy + off);
         }
-        u32x4 out;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float r[2];
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + 32 * u;
+            if (r < r_end) {
+                u32x4 out;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int c = 2 * k + h;
-                const float xh = ((h ? bf16_hi(xv[k]) : bf16_lo(xv[k])) - mm[c]) * rr[c];
-                const float g = h ? bf16_hi(gv[k]) : bf16_lo(gv[k]);
-                r[h] = rr[c] * gg[c] * (g - s1[c] * inv_hw - xh * s2[c] * inv_hw);
+                for (int k = 0; k < 4; ++k) {
+                    float v[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int c = 2 * k + h;
+                        const float xr = h ? bf16_hi(xv[u][k]) : bf16_lo(xv[u][k]);
+                        const float xh = (xr - mm[c]) * rr[c];
+                        const float g = h ? bf16_hi(gv[u][k]) : bf16_lo(gv[u][k]);
+                        v[h] = rr[c] * gg[c] * (g - s1[c] * inv_hw - xh * s2[c] * inv_hw);
+                        if (MASK) v[h] = xr > 0.f ? v[h] : v[h] * slope;
+                    }
+                    out[k] = pack_bf16x2(v[0], v[1]);
+                    if (MASK) {
+                        bs[2 * k] += bf16_lo(out[k]);
+                        bs[2 * k + 1] += bf16_hi(out[k]);
+                    }
+                }
+                *reinterpret_cast<u32x4*>(dx + (base + r) * C + c0) = out;
             }
-            out[k] = pack_bf16x2(r[0], r[1]);
         }
-        *reinterpret_cast<u32x4*>(dx + e * 8) = out;
+    }
+    if (MASK && bias_grad) {
+        __shared__ float red[32][65];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[lane_p][chunk * 8 + k] = bs[k];
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            float acc = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) acc += red[r][threadIdx.x];
+            atomicAdd(bias_grad + cg * 64 + threadIdx.x, acc);
+        }
     }
 }
 
@@ -903,20 +945,26 @@ extern "C" int rgbd_adain_fwd(const void* x, const float* scale, const float* sh
 
 extern "C" int rgbd_adain_bwd(const void* x, const void* dy, const float* scale, const float* mean,
                               const float* rstd, void* dx, float* dscale, float* dshift, float* sums, int B,
-                              int HW, int C, int ld, void* stream) {
+                              int HW, int C, int ld, float lrelu_slope, float* bias_grad, void* stream) {
     RGBD_REQUIRE(x && dy && scale && mean && rstd && dx && dscale && dshift && sums, "rgbd_adain_bwd: null pointer");
     RGBD_REQUIRE(ld >= C, "rgbd_adain_bwd: ld must be >= C");
     RGBD_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 64 == 0, "rgbd_adain_bwd: C must be a multiple of 64 (C=%d)", C);
+    RGBD_REQUIRE(!bias_grad || lrelu_slope > 0.f, "rgbd_adain_bwd: bias_grad comes with the activation gradient (lrelu_slope > 0)");
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(ceil_div(HW, ADAIN_STRIP), C / 64, B);
     adain_reduce_kernel<true><<<grid, 256, 0, st>>>((const unsigned short*)x, (const unsigned short*)dy, mean, rstd,
                                                     sums, HW, C);
     RGBD_CHECK_LAUNCH("adain_reduce_kernel<dy>");
-    const long nvec = (long)B * HW * C / 8;
-    const int blocks = (int)min((long)4096, (nvec + 255) / 256);
-    adain_bwd_apply_kernel<<<blocks, 256, 0, st>>>((const unsigned short*)x, (const unsigned short*)dy, scale, mean,
-                                                   rstd, sums, (unsigned short*)dx, dscale, dshift, nvec, HW, C,
-                                                   1.f / (float)HW, ld);
+    const int rows = HW <= 4096 ? 256 : 512;
+    dim3 agrid(ceil_div(HW, rows), C / 64, B);
+    if (lrelu_slope > 0.f)
+        adain_bwd_apply_kernel<true><<<agrid, 256, 0, st>>>((const unsigned short*)x, (const unsigned short*)dy, scale,
+                                                            mean, rstd, sums, (unsigned short*)dx, dscale, dshift, HW, C,
+                                                            1.f / (float)HW, ld, rows, lrelu_slope, bias_grad);
+    else
+        adain_bwd_apply_kernel<false><<<agrid, 256, 0, st>>>((const unsigned short*)x, (const unsigned short*)dy, scale,
+                                                             mean, rstd, sums, (unsigned short*)dx, dscale, dshift, HW,
+                                                             C, 1.f / (float)HW, ld, rows, 0.f, nullptr);
     RGBD_CHECK_LAUNCH("adain_bwd_apply_kernel");
     return 0;
 }

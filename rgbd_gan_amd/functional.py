@@ -355,6 +355,57 @@ def adain_window(x, group, j):
     return _AdaINWindow.apply(x, group.ss, group, j)
 
 
+class _ConvLreluAdaIN(torch.autograd.Function):
+    """style(lrelu(conv(x, W) + b)) of a synthesis block (net.py:150-153 / 157-160) as one autograd node: bias and
+    activation ride in the conv epilogue, and in the backward the AdaIN input gradient, the activation gradient and
+    the bias gradient are ONE pass (rgbd_adain_bwd with lrelu_slope) -- the activation output is the AdaIN input, so
+    the slope mask costs no extra read.  First order only (the generator is never differentiated twice)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, ss, layer, ups, group, j):
+        wf, _ = layer.packed()
+        x = x.contiguous()
+        y = kernels.conv2d_fprop(x, wf, layer.K, layer.K, layer.pad, bias=bias.contiguous(), upsample=ups,
+                                 lrelu_channels=w.shape[0])
+        out, mean, rstd = kernels.adain_fwd(y, ss, col_off=group.offsets[j])
+        ctx.layer, ctx.ups, ctx.group, ctx.j = layer, ups, group, j
+        ctx.save_for_backward(x, w, y, bias, ss, mean, rstd)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout):
+        x, w, y, bias, ss, mean, rstd = ctx.saved_tensors
+        layer, ups, g = ctx.layer, ctx.ups, ctx.group
+        if g.dss is None:
+            g.dss = torch.empty_like(ss)
+        want_b = ctx.needs_input_grad[2] and not _skip_grad_of(bias)
+        fast_b = want_b and _direct_grad(bias)
+        dz, _, _ = kernels.adain_bwd(y, dout.contiguous(), ss, mean, rstd, fused=True, col_off=g.offsets[ctx.j],
+                                     out=g.dss, lrelu_slope=0.2, bias_grad=bias.grad if fast_b else None)
+        dx = dw = db = dss = None
+        if want_b and not fast_b:
+            db = kernels.colsum(dz)
+        if ctx.needs_input_grad[0]:
+            _, wd = layer.packed()
+            dx = kernels.conv2d_dgrad(dz, wd, layer.K, layer.pad)
+            if ups:
+                dx = _sum_pool2(dx)
+        if ctx.needs_input_grad[1] and not _skip_grad_of(w):
+            if _direct_grad(w):
+                _wgrad_into(x, dz, w, layer, ups)
+            else:
+                xe = upsample2(x).contiguous() if ups else x
+                dw = kernels.conv2d_wgrad(xe, dz, layer.K, layer.inv_c)
+        if ctx.j == 0:
+            dss, g.dss = g.dss, None
+        return dx, dw, db, dss, None, None, None, None
+
+
+def conv_bias_lrelu_adain(x, layer, bias, group, j, upsample=False):
+    return _ConvLreluAdaIN.apply(x, layer.weight, bias, group.ss, layer, bool(upsample), group, j)
+
+
 class _WarpLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, img_rot, coef, flags, lam, max_depth, min_depth):

@@ -432,10 +432,13 @@ def adain_fwd(x, scale, shift=None, eps=1e-5, col_off=0):
     return y, mean, rstd
 
 
-def adain_bwd(x, dy, scale, mean, rstd, fused=False, col_off=0, out=None):
+def adain_bwd(x, dy, scale, mean, rstd, fused=False, col_off=0, out=None, lrelu_slope=0.0, bias_grad=None):
     """-> dx, dscale, dshift; with fused (scale = (B,Wtot), window [col_off, col_off + 2C) = [scale | shift]):
-    dx, d[scale | shift] written into the same window of `out` (B,Wtot) (allocated when None), None."""
+    dx, d[scale | shift] written into the same window of `out` (B,Wtot) (allocated when None), None.
+    lrelu_slope > 0: x is a leaky-ReLU output and dx also carries that activation's gradient; bias_grad (C) fp32 then
+    accumulates the column sums of dx."""
     _chk(x, BF16, "x"); _chk(dy, BF16, "dy"); _chk(scale, F32, "scale"); _chk(out, F32, "out")
+    _chk(bias_grad, F32, "bias_grad")
     B, H, W, C = x.shape
     dx = torch.empty_like(x)
     sums = zero_arena.take(B * C * 2, x.device)
@@ -450,7 +453,8 @@ def adain_bwd(x, dy, scale, mean, rstd, fused=False, col_off=0, out=None):
         dsh = torch.empty(B, C, dtype=F32, device=x.device)
         sc, dscale, dshift, ld = _ptr(scale), _ptr(ds), _ptr(dsh), C
     rc = _lib.load().rgbd_adain_bwd(_ptr(x), _ptr(dy), sc, _ptr(mean), _ptr(rstd), _ptr(dx), dscale,
-                                    dshift, _ptr(sums), B, H * W, C, ld, _stream())
+                                    dshift, _ptr(sums), B, H * W, C, ld, float(lrelu_slope), _ptr(bias_grad),
+                                    _stream())
     _lib.check(rc, "rgbd_adain_bwd")
     return (dx, dss, None) if fused else (dx, ds, dsh)
 

@@ -215,12 +215,16 @@ class StyleGenerator(_Link):
             const = p[pre + "/W"].permute(1, 2, 0).unsqueeze(0)                  # (1,4,4,ch)
             h = Fn.lrelu(const + p[pre + "/b0/b"]).to(BF16).expand(w.shape[0], 4, 4, self.chans[0][1])
             h = h.contiguous()
+        elif styles is not None:      # conv -> bias -> lrelu -> style as one node (fused backward)
+            h = Fn.conv_bias_lrelu_adain(x, self.c0[i], p[pre + "/b0/b"], *styles[(i, "s0")], upsample=True)
         else:
             h = Fn.conv_bias_lrelu(x, self.c0[i], p[pre + "/b0/b"], upsample=True)
-        h = style(pre + "/s0", w, h)
+        if i == 0 or styles is None:
+            h = style(pre + "/s0", w, h)
+        if styles is not None:
+            return Fn.conv_bias_lrelu_adain(h, self.c1[i], p[pre + "/b1/b"], *styles[(i, "s1")])
         h = Fn.conv_bias_lrelu(h, self.c1[i], p[pre + "/b1/b"])
-        h = style(pre + "/s1", w, h)
-        return h
+        return style(pre + "/s1", w, h)
 
     def rotate_w(self, w, theta):
         """net.py:220-224."""

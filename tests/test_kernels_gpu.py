@@ -202,6 +202,34 @@ def test_adain_forward_backward(B, H, C):
     torch.testing.assert_close(dt.cpu(), t.grad, atol=1e-3 * H * H, rtol=1e-3)
 
 
+@pytest.mark.parametrize("B,H,C", [(2, 8, 64), (3, 32, 128), (2, 16, 256)])
+def test_adain_backward_with_fused_activation_gradient(B, H, C):
+    """conv -> bias -> lrelu -> AdaIN (net.py:150-153): the AdaIN input IS the activation output, so rgbd_adain_bwd can
+    apply the slope mask and take the bias sums in the same pass.  Oracle: autograd through lrelu + oracle AdaIN."""
+    from rgbd_gan_amd import kernels
+    g = torch.Generator().manual_seed(13)
+    z = (torch.randn(B, C, H, H, generator=g) * 1.5).requires_grad_(True)       # pre-activation
+    s = (torch.randn(B, C, generator=g) + 1)
+    t = torch.randn(B, C, generator=g)
+    dy = bf16_round(torch.randn(B, C, H, H, generator=g))
+    a = bf16_round(nets.lrelu(z).detach())                                       # what the conv epilogue stores
+    a_leaf = a.clone().requires_grad_(True)
+    nets.adain(a_leaf, s, t).backward(dy)
+    dz_ref = a_leaf.grad * torch.where(a > 0, 1.0, 0.2)
+    ad = a.permute(0, 2, 3, 1).contiguous().to(dev()).to(torch.bfloat16)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(dev()).to(torch.bfloat16)
+    _, mean, rstd = kernels.adain_fwd(ad, s.to(dev()), t.to(dev()))
+    bg = torch.full((C,), 2.0, device=dev())
+    dz, ds, dt = kernels.adain_bwd(ad, dyd, s.to(dev()), mean, rstd, lrelu_slope=0.2, bias_grad=bg)
+    torch.testing.assert_close(dz.float().cpu().permute(0, 3, 1, 2), dz_ref, atol=3e-2, rtol=2e-2)
+    torch.testing.assert_close(bg.cpu() - 2.0, dz.float().cpu().reshape(-1, C).sum(0), atol=2e-3 * H, rtol=1e-3)
+    # the unfused pair of passes gives the same tensors up to the extra bf16 rounding between them
+    dx, ds2, dt2 = kernels.adain_bwd(ad, dyd, s.to(dev()), mean, rstd)
+    dz2 = kernels.lrelu_bwd(dx, ad, C)
+    torch.testing.assert_close(dz.float(), dz2.float(), atol=2e-2, rtol=2e-2)
+    assert torch.equal(ds, ds2) and torch.equal(dt, dt2)
+
+
 # ------------------------------------------------------------------------------------------------ Adam + clip
 @pytest.mark.parametrize("gnorm_scale", [0.01, 30.0])
 def test_adam_clip_matches_chainer_restatement(gnorm_scale):
