@@ -114,11 +114,15 @@ int rgbd_debug_force_gather_kernel(int on);
  *   x  : (B,H,W,Cin) bf16, dy : (B,H,W,Cout) bf16 (same H,W: stride 1, pad = (K-1)/2), K in {1,3}.
  *   dw : (Cout,Cin,K,K) fp32 = the master-weight gradient (scale = inv_c of the equalized-LR conv).
  *   workspace: rgbd_conv2d_wgrad_workspace(...) bytes; holds one partial (K*K,Cout,Cin) slab per workgroup.
+ *   upsample != 0: x is (B,H/2,W/2,Cin) and stands for its nearest-neighbour 2x upsampling (rescale.py:4-5, the
+ *   generator's  c0(upscale2x(h))  at net.py:148-150) -- the halo gather reads source pixel (y/2, x/2), so the
+ *   4x larger operand is never materialised.
  * Requires Cin % 64 == 0, Cout % 64 == 0, H and W powers of two >= 4.
  */
 int64_t rgbd_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int K);
 int rgbd_conv2d_wgrad_bf16(const void* x, const void* dy, void* workspace, float* dw,
-                           int B, int H, int W, int Cin, int Cout, int K, float scale, int accumulate, void* stream);
+                           int B, int H, int W, int Cin, int Cout, int K, float scale, int accumulate, int upsample,
+                           void* stream);
 
 /* ------------------------------------------------------------------ AdaIN (instance norm + style affine)
  * Replaces normalization/adain.py:54-73 (reshape + F.batch_normalization + broadcast mul/add) and its backward.

@@ -26,7 +26,7 @@ PROTOTYPES = {
                                 c_int, c_int, c_float, _P, _P], c_int),
     "rgbd_debug_force_gather_kernel": ([c_int], c_int),
     "rgbd_conv2d_wgrad_workspace": ([c_int, c_int, c_int, c_int, c_int, c_int], c_int64),
-    "rgbd_conv2d_wgrad_bf16": ([_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P], c_int),
+    "rgbd_conv2d_wgrad_bf16": ([_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P], c_int),
     "rgbd_adain_fwd": ([_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P], c_int),
     "rgbd_adain_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P], c_int),
     "rgbd_lrelu_bwd": ([_P, _P, _P, c_int64, c_int, c_int, c_float, _P, _P, c_int64, _P], c_int),

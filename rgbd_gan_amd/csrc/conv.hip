@@ -502,6 +502,7 @@ struct WgradArgs {
     int npx, npy;          // patches per image along x / y
     int total_patches, patches_per_wg;
     int x_bytes, y_bytes;
+    int ups;               // x is (B,H/2,W/2,Cin) and is read through the nearest-2x upsampling (rescale.py:4-5)
 };
 
 __device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p) {
@@ -549,7 +550,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradArgs a) {
 
     // ---- staging plan: patch-independent parts of the source offsets / LDS destinations of this thread's pieces.
     //      Pieces outside the halo patch or outside the image load through an out-of-range buffer offset (zeros).
-    int xrel[XP], xdst[XP], yrel[YP], ydst[YP];
+    int xrel[XP], xdst[XP], yrel[YP], ydst[YP], xch[XP];
     short xhy[XP], xhx[XP];
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
@@ -560,6 +561,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradArgs a) {
         xhy[i] = in ? (short)(hy - HALO) : (short)-30000;
         xhx[i] = (short)(hx - HALO);
         xrel[i] = (((hy - HALO) * a.W + (hx - HALO)) * a.Cin + ci0 + chunk * 8) * 2;
+        xch[i] = (ci0 + chunk * 8) * 2;
         // the 64-byte half of a row is swapped by bit 1 of the halo COLUMN (halo width is even, so row parity ==
         // column parity): four consecutive pixels x 64 B then cover all 64 banks once for ds_read_b64_tr_b16, and
         // the swizzle of a tap-shifted read depends only on the lane and the horizontal tap
@@ -585,8 +587,14 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradArgs a) {
         const int ybase = ((b * a.H + y0) * a.W + x0) * a.Cout * 2;
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
-            const bool ok = (unsigned)(y0 + xhy[i]) < (unsigned)a.H && (unsigned)(x0 + xhx[i]) < (unsigned)a.W;
-            Xr[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (unsigned)(xbase + xrel[i]) : 0x80000000u, 0, 0);
+            const int yy = y0 + xhy[i], xx = x0 + xhx[i];
+            const bool ok = (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+            // upsampled operand: the halo is cut out of the VIRTUAL (H,W) image, pixel (yy,xx) of which is source pixel
+            // (yy/2, xx/2) -- the 4x larger tensor never exists (the address select is wave-uniform, the load is not
+            // conditional)
+            const int src = a.ups ? (((b * (a.H >> 1) + (yy >> 1)) * (a.W >> 1) + (xx >> 1)) * a.Cin) * 2 + xch[i]
+                                  : xbase + xrel[i];
+            Xr[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? (unsigned)src : 0x80000000u, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < YP; ++i)
@@ -944,7 +952,7 @@ extern "C" int64_t rgbd_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int
 }
 
 extern "C" int rgbd_conv2d_wgrad_bf16(const void* x, const void* dy, void* workspace, float* dw, int B, int H, int W,
-                                      int Cin, int Cout, int K, float scale, int accumulate, void* stream) {
+                                      int Cin, int Cout, int K, float scale, int accumulate, int upsample, void* stream) {
     RGBD_REQUIRE(x && dy && workspace && dw, "rgbd_conv2d_wgrad_bf16: null pointer");
     RGBD_REQUIRE(K == 1 || K == 3, "rgbd_conv2d_wgrad_bf16: K must be 1 or 3 (K=%d)", K);
     RGBD_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0,
@@ -959,8 +967,9 @@ extern "C" int rgbd_conv2d_wgrad_bf16(const void* x, const void* dy, void* works
     a.total_patches = p.total_patches; a.patches_per_wg = p.patches_per_wg;
     RGBD_REQUIRE((long)B * H * W * Cin < 0x3fffffffL && (long)B * H * W * Cout < 0x3fffffffL,
                  "rgbd_conv2d_wgrad_bf16: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
-    a.x_bytes = (int)((long)B * H * W * Cin * 2);
+    a.x_bytes = (int)((long)B * H * W * Cin * 2 / (upsample ? 4 : 1));
     a.y_bytes = (int)((long)B * H * W * Cout * 2);
+    a.ups = upsample ? 1 : 0;
     dim3 grid(p.nsplit, Cin / 64, Cout / 64);
     hipStream_t st = (hipStream_t)stream;
     const long total = (long)K * K * Cout * Cin;

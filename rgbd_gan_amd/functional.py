@@ -176,16 +176,16 @@ def deferred_wgrads(items):
 
 
 def run_deferred_wgrads(items):
-    for xe, dy, target, K, inv_c in items:
-        kernels.conv2d_wgrad(xe, dy, K, inv_c, out=target, accumulate=True)
+    for x, dy, target, K, inv_c, ups in items:
+        kernels.conv2d_wgrad(x, dy, K, inv_c, out=target, accumulate=True, upsample=ups)
 
 
 def _wgrad_into(x, dy, w, layer, ups):
-    xe = upsample2(x).contiguous() if ups else x.contiguous()
     if _DEFERRED is not None:
-        _DEFERRED.append((xe, dy.contiguous(), w.grad, layer.K, layer.inv_c))
+        _DEFERRED.append((x.contiguous(), dy.contiguous(), w.grad, layer.K, layer.inv_c, bool(ups)))
         return
-    kernels.conv2d_wgrad(xe, dy.contiguous(), layer.K, layer.inv_c, out=w.grad, accumulate=True)
+    kernels.conv2d_wgrad(x.contiguous(), dy.contiguous(), layer.K, layer.inv_c, out=w.grad, accumulate=True,
+                         upsample=bool(ups))
 
 
 def _sum_pool2(x):
@@ -262,8 +262,7 @@ class _ConvDgrad(torch.autograd.Function):
 class _ConvWgrad(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, dy, layer, ups):
-        xe = upsample2(x).contiguous() if ups else x.contiguous()
-        return kernels.conv2d_wgrad(xe, dy.contiguous(), layer.K, layer.inv_c)
+        return kernels.conv2d_wgrad(x.contiguous(), dy.contiguous(), layer.K, layer.inv_c, upsample=bool(ups))
 
     @staticmethod
     def backward(ctx, ddw):
@@ -395,8 +394,7 @@ class _ConvLreluAdaIN(torch.autograd.Function):
             if _direct_grad(w):
                 _wgrad_into(x, dz, w, layer, ups)
             else:
-                xe = upsample2(x).contiguous() if ups else x
-                dw = kernels.conv2d_wgrad(xe, dz, layer.K, layer.inv_c)
+                dw = kernels.conv2d_wgrad(x, dz, layer.K, layer.inv_c, upsample=ups)
         if ctx.j == 0:
             dss, g.dss = g.dss, None
         return dx, dw, db, dss, None, None, None, None

@@ -206,13 +206,16 @@ def conv2d_dgrad(dy, wd, K, pad):
     return dx
 
 
-def conv2d_wgrad(x, dy, K, scale, out=None, accumulate=False):
-    """x (B,H,W,Cin) bf16, dy (B,H,W,Cout) bf16 -> dW (Cout,Cin,K,K) fp32 = scale * sum dy (x) x."""
+def conv2d_wgrad(x, dy, K, scale, out=None, accumulate=False, upsample=False):
+    """x (B,H,W,Cin) bf16, dy (B,H,W,Cout) bf16 -> dW (Cout,Cin,K,K) fp32 = scale * sum dy (x) x.
+    upsample: x is (B,H/2,W/2,Cin) and stands for its nearest-2x upsampling (read through the index map, not copied)."""
     _chk(x, BF16, "x"); _chk(dy, BF16, "dy")
     B, H, W, Cin = x.shape
+    if upsample:
+        H, W = 2 * H, 2 * W
     Cout = dy.shape[3]
-    if dy.shape[:3] != x.shape[:3]:
-        raise RuntimeError(f"conv2d_wgrad: spatial mismatch {tuple(x.shape)} vs {tuple(dy.shape)}")
+    if tuple(dy.shape[:3]) != (B, H, W):
+        raise RuntimeError(f"conv2d_wgrad: spatial mismatch {tuple(x.shape)} vs {tuple(dy.shape)} (upsample={upsample})")
     lib = _lib.load()
     ws_bytes = lib.rgbd_conv2d_wgrad_workspace(B, H, W, Cin, Cout, K)
     if ws_bytes < 0:
@@ -225,7 +228,8 @@ def conv2d_wgrad(x, dy, K, scale, out=None, accumulate=False):
     nbytes = 2.0 * (x.numel() + dy.numel()) + 2.0 * ws_bytes
     rc = _timed(f"conv_wgrad_kernel<{K * K}>+reduce", flops, nbytes,
                 lambda: lib.rgbd_conv2d_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(ws), _ptr(out), B, H, W, Cin, Cout, K,
-                                                   float(scale), int(bool(accumulate)), _stream()))
+                                                   float(scale), int(bool(accumulate)), int(bool(upsample)),
+                                                   _stream()))
     _lib.check(rc, "rgbd_conv2d_wgrad_bf16")
     return out
 

@@ -181,6 +181,27 @@ def test_conv_wgrad_matches_autograd(B, H, W, Cin, Cout, K):
     torch.testing.assert_close(dw.cpu(), ref, atol=tol, rtol=1e-4)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 4, 4, 64, 64), (3, 8, 8, 128, 64), (2, 32, 32, 64, 128), (1, 64, 64, 64, 64)])
+def test_conv_wgrad_through_the_upsampling(B, H, W, Cin, Cout):
+    """c0(upscale2x(h)) of a synthesis block (net.py:148-150, rescale.py:4-5): the weight gradient reads the
+    half-resolution operand through the index map.  Oracle: autograd through F.interpolate(nearest) + conv2d."""
+    from rgbd_gan_amd import kernels
+    g = torch.Generator().manual_seed(12)
+    x = bf16_round(torch.randn(B, Cin, H // 2, W // 2, generator=g))
+    dy = bf16_round(torch.randn(B, Cout, H, W, generator=g))
+    w = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
+    F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, None, padding=1).backward(dy)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev()).to(torch.bfloat16)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(dev()).to(torch.bfloat16)
+    dw = kernels.conv2d_wgrad(xd, dyd, 3, 0.25, upsample=True)
+    ref = w.grad * 0.25
+    tol = 1e-3 * float(ref.abs().max())
+    torch.testing.assert_close(dw.cpu(), ref, atol=tol, rtol=1e-4)
+    # identical (same summation order) to the gradient on the materialised upsampled operand
+    xe = xd.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2).contiguous()
+    assert torch.equal(dw, kernels.conv2d_wgrad(xe, dyd, 3, 0.25))
+
+
 # ------------------------------------------------------------------------------------------------ AdaIN
 @pytest.mark.parametrize("B,H,C", [(2, 4, 64), (3, 16, 128), (2, 64, 64)])
 def test_adain_forward_backward(B, H, C):
