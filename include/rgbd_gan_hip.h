@@ -229,6 +229,9 @@ int rgbd_occlusion_accum_bwd(const float* vol, const float* W1, const float* b1,
  *   dy (B,H,W,Cout) and the dgrad image of rgbd_pack_weights ([K*K][Cin][Cout], taps flipped): the same
  *   implicit-GEMM kernels as fprop (chainer's Convolution2DFunction backward, pggan.py:13-24); workspace =
  *   rgbd_conv2d_fprop_workspace(B, H, W, Cout, Cin, K, K, K-1-pad, 0) bytes or NULL.
+ *   sum_pool2 != 0: dx is (B,H/2,W/2,Cin), the 2x2 sums of the input gradient -- the adjoint of the nearest-2x
+ *   upsampling in front of the generator's c0 (net.py:148-150, rescale.py:4-5) taken in the conv epilogue; needs
+ *   K = 3, pad = 1 and H, W multiples of 16.
  * rgbd_pixelnorm_{fwd,bwd}: pggan.py:7-10 (feature_vector_normalization) on (M,C) fp32 rows:
  *   y = x * rsqrt(mean_c x^2 + eps);  dx = r * (dy - y * mean_c(dy * y)).
  * rgbd_depth_head_{fwd,bwd}: net.py:296 on (B,4,HW) fp32 planes: channels 0-2 pass through,
@@ -236,7 +239,7 @@ int rgbd_occlusion_accum_bwd(const float* vol, const float* W1, const float* b1,
  * rgbd_ema_update: copy_param.py:17-40 (soft_copy_param) over a flat parameter buffer: dst = (1-tau) dst + tau src.
  */
 int rgbd_conv2d_dgrad_bf16(const void* dy, const void* wp_dgrad, void* dx, int B, int H, int W, int Cin, int Cout, int K,
-                           int pad, void* workspace, void* stream);
+                           int pad, int sum_pool2, void* workspace, void* stream);
 int rgbd_pixelnorm_fwd(const float* x, float* y, int M, int C, float eps, void* stream);
 int rgbd_pixelnorm_bwd(const float* x, const float* dy, float* dx, int M, int C, float eps, void* stream);
 int rgbd_depth_head_fwd(const float* x, float* y, int B, int HW, void* stream);

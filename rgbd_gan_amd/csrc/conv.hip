@@ -34,6 +34,7 @@ struct ConvArgs {
     long M;
     int x_bytes, w_bytes;
     int ptiles, wgs_per_ntile;      // patch kernel: pixel tiles per output-channel tile, persistent workgroups per N tile
+    int pool_sum;                   // patch kernel: write 2x2 SUMS of the result, y is (B,Hout/2,Wout/2,Cout)
     int ksplit;                     // gather kernel: workgroups per output tile along K (1 = no split)
     float* partial;                 // gather kernel, ksplit > 1: [ksplit][M][Cout] fp32 partial sums
 };
@@ -421,6 +422,40 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(ConvArgs a) {
         tile_origin(pt, b, y0, x0);
         const int co = n0 + wave_co + 16 * q;            // this lane's 16 consecutive output channels
         const bool act = co < a.lrelu_ch;
+        if (a.pool_sum) {
+            // adjoint of the nearest-2x upsample in front of a generator conv (rescale.py:4-5): the input gradient
+            // leaves as 2x2 sums at half resolution.  Rows pair up inside the lane (wave_py is even), columns between
+            // lanes r16 and r16^1 (one DPP quad permute per value); even lanes store.
+            const int Hp = a.Hout >> 1, Wp = a.Wout >> 1;
+#pragma unroll
+            for (int j = 0; j < TPX; j += 2) {
+                float v[16];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float t = acc[i][j][r] + acc[i][j + 1][r];
+                        const int o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, false);
+                        v[4 * i + r] = t + __builtin_bit_cast(float, o);
+                    }
+                if ((r16 & 1) == 0) {
+                    const int yy = (y0 + wave_py + j) >> 1, xx = (x0 + r16) >> 1;
+                    const long o = (((long)b * Hp + yy) * Wp + xx) * a.Cout + co;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        u32x4 out = {pack_bf16x2(v[8 * h + 0], v[8 * h + 1]), pack_bf16x2(v[8 * h + 2], v[8 * h + 3]),
+                                     pack_bf16x2(v[8 * h + 4], v[8 * h + 5]), pack_bf16x2(v[8 * h + 6], v[8 * h + 7])};
+                        *reinterpret_cast<u32x4*>(a.y + o + 8 * h) = out;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    acc[i][j + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < TPX; ++j) {
             const int yy = y0 + wave_py + j, xx = x0 + r16;
@@ -814,9 +849,9 @@ extern "C" int64_t rgbd_conv2d_fprop_workspace(int B, int Hin, int Win, int Cin,
     return p.ksplit > 1 ? (int64_t)p.ksplit * B * Hout * Wout * Cout * (int64_t)sizeof(float) : 0;
 }
 
-extern "C" int rgbd_conv2d_fprop_bf16(const void* x, const void* wp, const float* bias, const void* residual,
-                                      void* y, int B, int Hin, int Win, int Cin, int Cout, int KH, int KW, int pad,
-                                      int upsample, int lrelu_channels, float slope, void* workspace, void* stream) {
+static int conv_fprop_impl(const void* x, const void* wp, const float* bias, const void* residual,
+                           void* y, int B, int Hin, int Win, int Cin, int Cout, int KH, int KW, int pad,
+                           int upsample, int lrelu_channels, float slope, void* workspace, void* stream, int pool_sum) {
     RGBD_REQUIRE(x && wp && y, "rgbd_conv2d_fprop_bf16: null pointer");
     RGBD_REQUIRE(B > 0 && Hin > 0 && Win > 0 && KH > 0 && KW > 0 && pad >= 0, "rgbd_conv2d_fprop_bf16: bad shape");
     RGBD_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0,
@@ -844,6 +879,14 @@ extern "C" int rgbd_conv2d_fprop_bf16(const void* x, const void* wp, const float
     if (!workspace && plan.ksplit > 1) {       // no scratch from the caller: unsplit (the halo-patch kernel if it applies)
         plan.ksplit = 1;
         plan.patch = KH == 3 && KW == 3 && pad == 1 && a.Hout % 16 == 0 && a.Wout % 16 == 0 && !g_force_gather;
+    }
+    a.pool_sum = pool_sum ? 1 : 0;
+    if (pool_sum) {
+        RGBD_REQUIRE(KH == 3 && KW == 3 && pad == 1 && a.Hout % 16 == 0 && a.Wout % 16 == 0 && !bias && !residual &&
+                     lrelu_channels == 0 && !g_force_gather,
+                     "rgbd_conv2d_dgrad_bf16: sum_pool2 needs a 3x3 pad-1 conv on images that are multiples of 16x16");
+        plan.patch = true;
+        plan.ksplit = 1;
     }
     a.ksplit = plan.ksplit;
     a.partial = plan.ksplit > 1 ? (float*)workspace : nullptr;
@@ -910,6 +953,13 @@ extern "C" int rgbd_conv2d_fprop_bf16(const void* x, const void* wp, const float
     return 0;
 }
 
+extern "C" int rgbd_conv2d_fprop_bf16(const void* x, const void* wp, const float* bias, const void* residual,
+                                      void* y, int B, int Hin, int Win, int Cin, int Cout, int KH, int KW, int pad,
+                                      int upsample, int lrelu_channels, float slope, void* workspace, void* stream) {
+    return conv_fprop_impl(x, wp, bias, residual, y, B, Hin, Win, Cin, Cout, KH, KW, pad, upsample, lrelu_channels, slope,
+                           workspace, stream, 0);
+}
+
 namespace {
 struct WgradPlan {
     int PH, PW, lgPW, npx, npy, total_patches, patches_per_wg, nsplit;
@@ -938,11 +988,11 @@ WgradPlan plan_wgrad(int B, int H, int W, int Cin, int Cout) {
 }  // namespace
 
 extern "C" int rgbd_conv2d_dgrad_bf16(const void* dy, const void* wp_dgrad, void* dx, int B, int H, int W, int Cin,
-                                      int Cout, int K, int pad, void* workspace, void* stream) {
+                                      int Cout, int K, int pad, int sum_pool2, void* workspace, void* stream) {
     RGBD_REQUIRE(K >= 1 && pad >= 0 && pad <= K - 1, "rgbd_conv2d_dgrad_bf16: need 0 <= pad <= K-1 (K=%d pad=%d)", K, pad);
     // dx = correlation of dy with the flipped, transposed kernel at padding K-1-pad
-    return rgbd_conv2d_fprop_bf16(dy, wp_dgrad, nullptr, nullptr, dx, B, H, W, Cout, Cin, K, K, K - 1 - pad, 0, 0, 0.2f,
-                                  workspace, stream);
+    return conv_fprop_impl(dy, wp_dgrad, nullptr, nullptr, dx, B, H, W, Cout, Cin, K, K, K - 1 - pad, 0, 0, 0.2f,
+                           workspace, stream, sum_pool2);
 }
 
 extern "C" int64_t rgbd_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int K) {

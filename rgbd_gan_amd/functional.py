@@ -232,8 +232,7 @@ class _ConvDgrad(torch.autograd.Function):
         ctx.x_fwd, ctx.bias = x_fwd, bias
         ctx.save_for_backward(dy, w)
         _, wd = layer.packed()
-        dx = kernels.conv2d_dgrad(dy.contiguous(), wd, layer.K, layer.pad)
-        return _sum_pool2(dx) if ups else dx
+        return kernels.conv2d_dgrad(dy.contiguous(), wd, layer.K, layer.pad, sum_pool2=ups)
 
     @staticmethod
     def backward(ctx, ddx):
@@ -387,9 +386,7 @@ class _ConvLreluAdaIN(torch.autograd.Function):
             db = kernels.colsum(dz)
         if ctx.needs_input_grad[0]:
             _, wd = layer.packed()
-            dx = kernels.conv2d_dgrad(dz, wd, layer.K, layer.pad)
-            if ups:
-                dx = _sum_pool2(dx)
+            dx = kernels.conv2d_dgrad(dz, wd, layer.K, layer.pad, sum_pool2=ups)
         if ctx.needs_input_grad[1] and not _skip_grad_of(w):
             if _direct_grad(w):
                 _wgrad_into(x, dz, w, layer, ups)

@@ -164,6 +164,29 @@ def test_conv_dgrad_matches_autograd(B, H, W, Cin, Cout, K, pad):
     torch.testing.assert_close(dx.float().cpu().permute(0, 3, 1, 2), x.grad, atol=2e-2, rtol=1e-2)
 
 
+@pytest.mark.parametrize("B,H,Cin,Cout", [(2, 16, 128, 64), (3, 32, 64, 128), (2, 64, 128, 128), (2, 8, 64, 64)])
+def test_conv_dgrad_through_the_upsampling(B, H, Cin, Cout):
+    """Input gradient of c0(upscale2x(h)) (net.py:148-150): the 2x2 sums are taken in the epilogue of the halo-patch
+    kernel (8x8: second pass).  Oracle: autograd through F.interpolate(nearest) + conv2d."""
+    from rgbd_gan_amd import kernels
+    g = torch.Generator().manual_seed(17)
+    scale = float(np.sqrt(2.0 / (Cin * 9)))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g)
+    wq = bf16_round(w * scale)
+    x = torch.randn(B, Cin, H // 2, H // 2, generator=g, requires_grad=True)
+    dy = bf16_round(torch.randn(B, Cout, H, H, generator=g))
+    F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), wq, None, padding=1).backward(dy)
+    _, wd = kernels.pack_weights(w.to(dev()), scale, False, True)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(dev()).to(torch.bfloat16)
+    dx = kernels.conv2d_dgrad(dyd, wd, 3, 1, sum_pool2=True)
+    assert tuple(dx.shape) == (B, H // 2, H // 2, Cin)
+    torch.testing.assert_close(dx.float().cpu().permute(0, 3, 1, 2), x.grad, atol=4e-2, rtol=1e-2)
+    # against the two-pass form: only the bf16 rounding of the full-resolution intermediate differs
+    full = kernels.conv2d_dgrad(dyd, wd, 3, 1).float()
+    two_pass = full.view(B, H // 2, 2, H // 2, 2, Cin).sum(dim=(2, 4))
+    torch.testing.assert_close(dx.float(), two_pass, atol=4e-2, rtol=2e-2)
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,K", [(2, 4, 4, 64, 64, 3), (3, 8, 8, 64, 128, 3), (2, 16, 16, 128, 64, 3),
                                                (2, 32, 32, 64, 64, 3), (1, 64, 64, 64, 64, 3), (2, 16, 16, 64, 64, 1)])
 def test_conv_wgrad_matches_autograd(B, H, W, Cin, Cout, K):
