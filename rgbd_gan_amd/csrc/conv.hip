@@ -391,23 +391,34 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(ConvArgs a) {
         }
     }
 
+    // Pixel operands live in registers across the three VERTICAL taps of a filter column: output row j at vertical tap
+    // kh reads halo row j + kh, so the wave's TPX rows need only TPX + 2 distinct halo rows per filter column (fewer
+    // behind the folded upsample) -- read once when the column starts (kh == 0), reused by kh = 1, 2.  The tap loop
+    // therefore runs column-major (t = 3 kw + kh).  LDS reads per channel slice: 72 (weights) + 6 NR (pixels) instead
+    // of 72 + 18 TPX.
+    constexpr int NR = UPS ? TPX / 2 + 2 : TPX + 2;
+    bf16x8 brow[NR][2];
     auto compute = [&](const unsigned char* pbuf, const unsigned char* wbuf, int kh, int kw) {
+        if (kh == 0) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int r = 0; r < NR; ++r)
+                    brow[r][s2] = *reinterpret_cast<const bf16x8*>(pbuf + boff[kw][s2] + r * HPW * 128);
+        }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            bf16x8 af[4], bfr[TPX];
+            bf16x8 af[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 af[i] = *reinterpret_cast<const bf16x8*>(wbuf + aoff[s2] + i * 16 * 128);
 #pragma unroll
-            for (int j = 0; j < TPX; ++j) {
-                const int rj = UPS ? ((j + kh - 1) >> 1) + 1 : j + kh;   // compile-time after unrolling
-                bfr[j] = *reinterpret_cast<const bf16x8*>(pbuf + boff[kw][s2] + rj * HPW * 128);
-            }
-#pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < TPX; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TPX; ++j) {
+                    const int rj = UPS ? ((j + kh - 1) >> 1) + 1 : j + kh;   // compile-time after unrolling
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], brow[rj][s2], acc[i][j], 0, 0, 0);
+                }
         }
     };
 
@@ -493,9 +504,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(ConvArgs a) {
 
     // ---- prologue (once per workgroup; later tiles are prefetched under the previous tile's K steps)
     load_patch(0);
-    load_w(0, 0, Wr[0]);
-    load_w(0, 1, Wr[1]);
-    load_w(0, 2, Wr[2]);
+    load_w(0, 0, Wr[0]);          // step t multiplies filter tap (kh, kw) = (t % 3, t / 3): weight image 3 (t % 3) + t / 3
+    load_w(0, 3, Wr[1]);
+    load_w(0, 6, Wr[2]);
     store_patch(0);
     store_w(0, Wr[0]);
     load_patch(min(1, g_total - 1));
@@ -509,10 +520,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(ConvArgs a) {
         const int c_next = c + 1 == nc ? 0 : c + 1;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            compute(pbuf, w_lds + (t % 3) * W_BYTES, t / 3, t % 3);
+            compute(pbuf, w_lds + (t % 3) * W_BYTES, t % 3, t / 3);
             store_w((t + 1) % 3, Wr[(t + 1) % 3]);
             if (t == 6) store_patch((g + 1) & 1);
-            load_w(t + 3 >= 9 ? c_next : c, (t + 3) % 9, Wr[t % 3]);   // Wr[t % 3] (tile k) went to LDS one step ago
+            load_w(t + 3 >= 9 ? c_next : c, 3 * (((t + 3) % 9) % 3) + ((t + 3) % 9) / 3, Wr[t % 3]);   // Wr[t % 3] went to LDS one step ago
             if (t == 7) {
                 asm volatile("" ::: "memory");
                 load_patch(min(g + 2, g_total - 1));
