@@ -96,6 +96,9 @@ int rgbd_pack_weights_multi(const rgbd_pack_desc* descs_device, int n, int total
  *         lrelu_channels (multiple of 16): output channels [0, lrelu_channels) then get leaky-ReLU(slope) (0 = none), i.e.
  *         y = lrelu(conv + bias + residual) as in net.py:413-416.
  *   y   : (B, Hout, Wout, Cout) bf16 NHWC.
+ *   y_pooled: NULL, or (B, Hout/2, Wout/2, Cout) bf16 that receives the 2x2 average of y (of the bf16 values stored to
+ *         y) from the same epilogue -- the residual block's  downscale2x(leaky_relu(c1(h) + c_sc(x)))  (net.py:413-418,
+ *         rescale.py:12-13) without re-reading y; needs KH = KW = 3, pad = 1, Hout and Wout multiples of 16.
  *   workspace: rgbd_conv2d_fprop_workspace(...) bytes of device scratch, or NULL.  Layers with few output tiles and
  *         a long reduction (the 4x4 .. 16x16 images) are split along K over several workgroups per tile; the fp32
  *         partial sums go through this scratch and a second kernel applies the epilogue.  NULL = never split.
@@ -103,7 +106,7 @@ int rgbd_pack_weights_multi(const rgbd_pack_desc* descs_device, int n, int total
  */
 int64_t rgbd_conv2d_fprop_workspace(int B, int Hin, int Win, int Cin, int Cout, int KH, int KW, int pad, int upsample);
 int rgbd_conv2d_fprop_bf16(const void* x, const void* wp, const float* bias, const void* residual, void* y,
-                           int B, int Hin, int Win, int Cin, int Cout, int KH, int KW, int pad,
+                           void* y_pooled, int B, int Hin, int Win, int Cin, int Cout, int KH, int KW, int pad,
                            int upsample, int lrelu_channels, float slope, void* workspace, void* stream);
 
 /* Test hook: when on != 0, rgbd_conv2d_fprop_bf16 uses the generic gather kernel for every shape (by default 3x3

@@ -35,6 +35,7 @@ struct ConvArgs {
     int x_bytes, w_bytes;
     int ptiles, wgs_per_ntile;      // patch kernel: pixel tiles per output-channel tile, persistent workgroups per N tile
     int pool_sum;                   // patch kernel: write 2x2 SUMS of the result, y is (B,Hout/2,Wout/2,Cout)
+    unsigned short* ypool;          // patch kernel: also write the 2x2 AVERAGE of y to (B,Hout/2,Wout/2,Cout) (or null)
     int ksplit;                     // gather kernel: workgroups per output tile along K (1 = no split)
     float* partial;                 // gather kernel, ksplit > 1: [ksplit][M][Cout] fp32 partial sums
 };
@@ -467,6 +468,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(ConvArgs a) {
             }
             return;
         }
+        float ps[16];                   // ypool: running 2x2 sums of the bf16-rounded outputs of a row pair
 #pragma unroll
         for (int j = 0; j < TPX; ++j) {
             const int yy = y0 + wave_py + j, xx = x0 + r16;
@@ -496,6 +498,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(ConvArgs a) {
                 u32x4 out = {pack_bf16x2(v[8 * h + 0], v[8 * h + 1]), pack_bf16x2(v[8 * h + 2], v[8 * h + 3]),
                              pack_bf16x2(v[8 * h + 4], v[8 * h + 5]), pack_bf16x2(v[8 * h + 6], v[8 * h + 7])};
                 *reinterpret_cast<u32x4*>(a.y + o + 8 * h) = out;
+                if (a.ypool) {          // the block's downscale2x (rescale.py:12-13) of what was just stored
+#pragma unroll
+                    for (int w2 = 0; w2 < 4; ++w2) {
+                        const float lo = bf16_lo(out[w2]), hi = bf16_hi(out[w2]);
+                        ps[8 * h + 2 * w2] = (j & 1) ? ps[8 * h + 2 * w2] + lo : lo;
+                        ps[8 * h + 2 * w2 + 1] = (j & 1) ? ps[8 * h + 2 * w2 + 1] + hi : hi;
+                    }
+                }
+            }
+            if (a.ypool && (j & 1)) {
+#pragma unroll
+                for (int k2 = 0; k2 < 16; ++k2) {
+                    const int o2 = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ps[k2]), 0xB1, 0xF, 0xF, false);
+                    ps[k2] = 0.25f * (ps[k2] + __builtin_bit_cast(float, o2));
+                }
+                if ((r16 & 1) == 0) {
+                    const long op = (((long)b * (a.Hout >> 1) + (yy >> 1)) * (a.Wout >> 1) + (xx >> 1)) * a.Cout + co;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        u32x4 out = {pack_bf16x2(ps[8 * h + 0], ps[8 * h + 1]), pack_bf16x2(ps[8 * h + 2], ps[8 * h + 3]),
+                                     pack_bf16x2(ps[8 * h + 4], ps[8 * h + 5]), pack_bf16x2(ps[8 * h + 6], ps[8 * h + 7])};
+                        *reinterpret_cast<u32x4*>(a.ypool + op + 8 * h) = out;
+                    }
+                }
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -862,7 +888,8 @@ extern "C" int64_t rgbd_conv2d_fprop_workspace(int B, int Hin, int Win, int Cin,
 
 static int conv_fprop_impl(const void* x, const void* wp, const float* bias, const void* residual,
                            void* y, int B, int Hin, int Win, int Cin, int Cout, int KH, int KW, int pad,
-                           int upsample, int lrelu_channels, float slope, void* workspace, void* stream, int pool_sum) {
+                           int upsample, int lrelu_channels, float slope, void* workspace, void* stream, int pool_sum,
+                           void* y_pooled = nullptr) {
     RGBD_REQUIRE(x && wp && y, "rgbd_conv2d_fprop_bf16: null pointer");
     RGBD_REQUIRE(B > 0 && Hin > 0 && Win > 0 && KH > 0 && KW > 0 && pad >= 0, "rgbd_conv2d_fprop_bf16: bad shape");
     RGBD_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0,
@@ -892,6 +919,13 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
         plan.patch = KH == 3 && KW == 3 && pad == 1 && a.Hout % 16 == 0 && a.Wout % 16 == 0 && !g_force_gather;
     }
     a.pool_sum = pool_sum ? 1 : 0;
+    a.ypool = (unsigned short*)y_pooled;
+    if (y_pooled) {
+        RGBD_REQUIRE(KH == 3 && KW == 3 && pad == 1 && a.Hout % 16 == 0 && a.Wout % 16 == 0 && !pool_sum && !g_force_gather,
+                     "rgbd_conv2d_fprop_bf16: y_pooled needs a 3x3 pad-1 conv on images that are multiples of 16x16");
+        plan.patch = true;
+        plan.ksplit = 1;
+    }
     if (pool_sum) {
         RGBD_REQUIRE(KH == 3 && KW == 3 && pad == 1 && a.Hout % 16 == 0 && a.Wout % 16 == 0 && !bias && !residual &&
                      lrelu_channels == 0 && !g_force_gather,
@@ -965,10 +999,11 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
 }
 
 extern "C" int rgbd_conv2d_fprop_bf16(const void* x, const void* wp, const float* bias, const void* residual,
-                                      void* y, int B, int Hin, int Win, int Cin, int Cout, int KH, int KW, int pad,
-                                      int upsample, int lrelu_channels, float slope, void* workspace, void* stream) {
+                                      void* y, void* y_pooled, int B, int Hin, int Win, int Cin, int Cout, int KH, int KW,
+                                      int pad, int upsample, int lrelu_channels, float slope, void* workspace,
+                                      void* stream) {
     return conv_fprop_impl(x, wp, bias, residual, y, B, Hin, Win, Cin, Cout, KH, KW, pad, upsample, lrelu_channels, slope,
-                           workspace, stream, 0);
+                           workspace, stream, 0, y_pooled);
 }
 
 namespace {

@@ -540,11 +540,13 @@ class _ConvBiasAct(torch.autograd.Function):
         x = x.contiguous()
         y = kernels.conv2d_fprop(x, wf, layer.K, layer.K, layer.pad, bias=bias.contiguous(),
                                  residual=residual.contiguous() if residual is not None else None, upsample=ups,
-                                 lrelu_channels=w.shape[0] if act else 0)
+                                 lrelu_channels=w.shape[0] if act else 0, avg_pool2=pool)
+        if pool:
+            y, pooled = y
         ctx.layer, ctx.ups, ctx.act, ctx.pool = layer, ups, act, pool
         ctx.tie, ctx.tie_owner = tie, tie_owner
         ctx.save_for_backward(x, w, y, bias)
-        return kernels.pool2_masked(y) if pool else y
+        return pooled if pool else y
 
     @staticmethod
     def backward(ctx, dy):

@@ -155,8 +155,11 @@ def _fprop_workspace(lib, B, H, W, Cin, Cout, KH, KW, pad, ups, device):
     return torch.empty(nbytes // 4, dtype=F32, device=device) if nbytes > 0 else None
 
 
-def conv2d_fprop(x, wp, KH, KW, pad, bias=None, residual=None, upsample=False, lrelu_channels=0, slope=0.2):
-    """x (B,H,W,Cin) bf16, wp [KH*KW][Cout][Cin] bf16 -> y (B,Hout,Wout,Cout) bf16."""
+def conv2d_fprop(x, wp, KH, KW, pad, bias=None, residual=None, upsample=False, lrelu_channels=0, slope=0.2,
+                 avg_pool2=False):
+    """x (B,H,W,Cin) bf16, wp [KH*KW][Cout][Cin] bf16 -> y (B,Hout,Wout,Cout) bf16.
+    avg_pool2: -> (y, 2x2 average of y at half resolution); the average comes out of the conv epilogue for 3x3 convs on
+    images that are multiples of 16x16, out of a second pass (rgbd_pool2_masked) otherwise."""
     _chk(x, BF16, "x"); _chk(wp, BF16, "wp"); _chk(bias, F32, "bias"); _chk(residual, BF16, "residual")
     B, H, W, Cin = x.shape
     T, Cout, Cin2 = wp.shape
@@ -170,15 +173,19 @@ def conv2d_fprop(x, wp, KH, KW, pad, bias=None, residual=None, upsample=False, l
     lib = _lib.load()
     flops = 2.0 * B * Hout * Wout * Cout * Cin * KH * KW
     nbytes = 2.0 * (x.numel() + y.numel() + wp.numel() + (residual.numel() if residual is not None else 0))
-    ws = _fprop_workspace(lib, B, H, W, Cin, Cout, KH, KW, pad, int(bool(upsample)), x.device)
-    patch = KH == 3 and KW == 3 and pad == 1 and Hout % 16 == 0 and Wout % 16 == 0 and ws is None \
-        and B * (Hout // 16) * (Wout // 16) * (Cout // (128 if Cout % 128 == 0 else 64)) >= 64
+    fuse_pool = bool(avg_pool2) and KH == 3 and KW == 3 and pad == 1 and Hout % 16 == 0 and Wout % 16 == 0
+    yp = torch.empty(B, Hout // 2, Wout // 2, Cout, dtype=BF16, device=x.device) if fuse_pool else None
+    ws = None if fuse_pool else _fprop_workspace(lib, B, H, W, Cin, Cout, KH, KW, pad, int(bool(upsample)), x.device)
+    patch = fuse_pool or (KH == 3 and KW == 3 and pad == 1 and Hout % 16 == 0 and Wout % 16 == 0 and ws is None
+                          and B * (Hout // 16) * (Wout // 16) * (Cout // (128 if Cout % 128 == 0 else 64)) >= 64)
     kname = ("conv3x3_patch_kernel" if patch else "conv_fprop_kernel") + f"<{128 if Cout % 128 == 0 else 64}>"
     rc = _timed(kname, flops, nbytes,
-                lambda: lib.rgbd_conv2d_fprop_bf16(_ptr(x), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(y), B, H, W,
-                                                   Cin, Cout, KH, KW, pad, int(bool(upsample)), int(lrelu_channels),
+                lambda: lib.rgbd_conv2d_fprop_bf16(_ptr(x), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(y), _ptr(yp), B, H,
+                                                   W, Cin, Cout, KH, KW, pad, int(bool(upsample)), int(lrelu_channels),
                                                    float(slope), _ptr(ws), _stream()))
     _lib.check(rc, "rgbd_conv2d_fprop_bf16")
+    if avg_pool2:
+        return y, (yp if fuse_pool else pool2_masked(y))
     return y
 
 

@@ -164,6 +164,25 @@ def test_conv_dgrad_matches_autograd(B, H, W, Cin, Cout, K, pad):
     torch.testing.assert_close(dx.float().cpu().permute(0, 3, 1, 2), x.grad, atol=2e-2, rtol=1e-2)
 
 
+@pytest.mark.parametrize("B,H,Cin,Cout", [(2, 16, 64, 128), (3, 32, 128, 64), (2, 8, 64, 64)])
+def test_conv_with_pooled_second_output(B, H, Cin, Cout):
+    """downscale2x(leaky_relu(c1(h) + c_sc(x))) (net.py:413-418): the pooled tensor out of the conv epilogue equals the
+    separate pooling pass over the stored activations, and the activations are unchanged."""
+    from rgbd_gan_amd import kernels
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(B, H, H, Cin, generator=g).to(dev()).to(torch.bfloat16)
+    res = torch.randn(B, H, H, Cout, generator=g).to(dev()).to(torch.bfloat16)
+    bias = torch.randn(Cout, generator=g).to(dev())
+    wf, _ = kernels.pack_weights(torch.randn(Cout, Cin, 3, 3, generator=g).to(dev()), float(np.sqrt(2.0 / (Cin * 9))))
+    y_ref = kernels.conv2d_fprop(x, wf, 3, 3, 1, bias=bias, residual=res, lrelu_channels=Cout)
+    y, yp = kernels.conv2d_fprop(x, wf, 3, 3, 1, bias=bias, residual=res, lrelu_channels=Cout, avg_pool2=True)
+    # small images: y_ref comes from the split-K gather kernel (other summation order), so one bf16 ulp apart at most
+    torch.testing.assert_close(y.float(), y_ref.float(), atol=2 ** -7 * float(y_ref.float().abs().max()), rtol=0)
+    pooled = y.float().view(B, H // 2, 2, H // 2, 2, Cout).mean(dim=(2, 4))
+    torch.testing.assert_close(yp.float(), pooled.to(torch.bfloat16).float(), atol=1e-2, rtol=1e-2)
+    torch.testing.assert_close(yp.float(), kernels.pool2_masked(y).float(), atol=1e-2, rtol=1e-2)
+
+
 @pytest.mark.parametrize("B,H,Cin,Cout", [(2, 16, 128, 64), (3, 32, 64, 128), (2, 64, 128, 128), (2, 8, 64, 64)])
 def test_conv_dgrad_through_the_upsampling(B, H, Cin, Cout):
     """Input gradient of c0(upscale2x(h)) (net.py:148-150): the 2x2 sums are taken in the epilogue of the halo-patch
@@ -512,7 +531,7 @@ def test_split_k_path_matches_unsplit(B, H, Cin, Cout, K, pad, ups):
     # unsplit: call the C ABI without scratch
     y_ref = torch.empty_like(y_split)
     rc = lib.rgbd_conv2d_fprop_bf16(kernels._ptr(x), kernels._ptr(wf), kernels._ptr(bias), kernels._ptr(res),
-                                    kernels._ptr(y_ref), B, H, H, Cin, Cout, K, K, pad, int(ups), Cout, 0.2, None,
+                                    kernels._ptr(y_ref), None, B, H, H, Cin, Cout, K, K, pad, int(ups), Cout, 0.2, None,
                                     kernels._stream())
     assert rc == 0
     d = (y_split.float() - y_ref.float()).abs().max().item()
