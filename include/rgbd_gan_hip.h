@@ -232,6 +232,8 @@ int rgbd_occlusion_accum_bwd(const float* vol, const float* W1, const float* b1,
  *   dy (B,H,W,Cout) and the dgrad image of rgbd_pack_weights ([K*K][Cin][Cout], taps flipped): the same
  *   implicit-GEMM kernels as fprop (chainer's Convolution2DFunction backward, pggan.py:13-24); workspace =
  *   rgbd_conv2d_fprop_workspace(B, H, W, Cout, Cin, K, K, K-1-pad, 0) bytes or NULL.
+ *   residual: NULL or a tensor of dx's shape added in the epilogue -- the input gradient of a residual block's entry,
+ *   dgrad_c0(dz0) + dgrad_c_sc(dz1) (net.py:408-416: both convs read the block input), without an add pass.
  *   sum_pool2 != 0: dx is (B,H/2,W/2,Cin), the 2x2 sums of the input gradient -- the adjoint of the nearest-2x
  *   upsampling in front of the generator's c0 (net.py:148-150, rescale.py:4-5) taken in the conv epilogue; needs
  *   K = 3, pad = 1 and H, W multiples of 16.
@@ -241,8 +243,8 @@ int rgbd_occlusion_accum_bwd(const float* vol, const float* W1, const float* b1,
  *   y3 = 1 / (softplus(x3) + 1e-4);  dx3 = -dy3 * y3^2 * sigmoid(x3).
  * rgbd_ema_update: copy_param.py:17-40 (soft_copy_param) over a flat parameter buffer: dst = (1-tau) dst + tau src.
  */
-int rgbd_conv2d_dgrad_bf16(const void* dy, const void* wp_dgrad, void* dx, int B, int H, int W, int Cin, int Cout, int K,
-                           int pad, int sum_pool2, void* workspace, void* stream);
+int rgbd_conv2d_dgrad_bf16(const void* dy, const void* wp_dgrad, const void* residual, void* dx, int B, int H, int W,
+                           int Cin, int Cout, int K, int pad, int sum_pool2, void* workspace, void* stream);
 int rgbd_pixelnorm_fwd(const float* x, float* y, int M, int C, float eps, void* stream);
 int rgbd_pixelnorm_bwd(const float* x, const float* dy, float* dx, int M, int C, float eps, void* stream);
 int rgbd_depth_head_fwd(const float* x, float* y, int B, int HW, void* stream);

@@ -47,7 +47,7 @@ PROTOTYPES = {
                                   c_int, _P], c_int),
     "rgbd_occlusion_accum_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, c_int, c_int, c_int, c_int,
                                   _P], c_int),
-    "rgbd_conv2d_dgrad_bf16": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P], c_int),
+    "rgbd_conv2d_dgrad_bf16": ([_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P], c_int),
     "rgbd_pixelnorm_fwd": ([_P, _P, c_int, c_int, c_float, _P], c_int),
     "rgbd_pixelnorm_bwd": ([_P, _P, _P, c_int, c_int, c_float, _P], c_int),
     "rgbd_depth_head_fwd": ([_P, _P, c_int, c_int, _P], c_int),

@@ -1033,11 +1033,13 @@ WgradPlan plan_wgrad(int B, int H, int W, int Cin, int Cout) {
 }
 }  // namespace
 
-extern "C" int rgbd_conv2d_dgrad_bf16(const void* dy, const void* wp_dgrad, void* dx, int B, int H, int W, int Cin,
-                                      int Cout, int K, int pad, int sum_pool2, void* workspace, void* stream) {
+extern "C" int rgbd_conv2d_dgrad_bf16(const void* dy, const void* wp_dgrad, const void* residual, void* dx, int B, int H,
+                                      int W, int Cin, int Cout, int K, int pad, int sum_pool2, void* workspace,
+                                      void* stream) {
     RGBD_REQUIRE(K >= 1 && pad >= 0 && pad <= K - 1, "rgbd_conv2d_dgrad_bf16: need 0 <= pad <= K-1 (K=%d pad=%d)", K, pad);
+    RGBD_REQUIRE(!(residual && sum_pool2), "rgbd_conv2d_dgrad_bf16: residual and sum_pool2 are exclusive");
     // dx = correlation of dy with the flipped, transposed kernel at padding K-1-pad
-    return conv_fprop_impl(dy, wp_dgrad, nullptr, nullptr, dx, B, H, W, Cout, Cin, K, K, K - 1 - pad, 0, 0, 0.2f,
+    return conv_fprop_impl(dy, wp_dgrad, nullptr, residual, dx, B, H, W, Cout, Cin, K, K, K - 1 - pad, 0, 0, 0.2f,
                            workspace, stream, sum_pool2);
 }
 

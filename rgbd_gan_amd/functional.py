@@ -202,11 +202,12 @@ def upsample2(x):
 
 class _ConvFprop(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, layer, ups):
+    def forward(ctx, x, w, layer, ups, residual=None):
         ctx.layer, ctx.ups = layer, ups
         ctx.save_for_backward(x, w)
         wf, _ = layer.packed()
-        return kernels.conv2d_fprop(x.contiguous(), wf, layer.K, layer.K, layer.pad, upsample=ups)
+        return kernels.conv2d_fprop(x.contiguous(), wf, layer.K, layer.K, layer.pad, upsample=ups,
+                                    residual=residual.contiguous() if residual is not None else None)
 
     @staticmethod
     def backward(ctx, dy):
@@ -219,33 +220,55 @@ class _ConvFprop(torch.autograd.Function):
                 _wgrad_into(x, dy, w, ctx.layer, ctx.ups)
             else:
                 dw = _ConvWgrad.apply(x, dy, ctx.layer, ctx.ups)
-        return dx, dw, None, None
+        return dx, dw, None, None, (dy if ctx.needs_input_grad[4:5] == (True,) else None)
 
 
 class _ConvDgrad(torch.autograd.Function):
-    """dx = dgrad(dy, W).  `x_fwd` / `bias` (optional, not differentiated here) are the forward input and the bias of
-    the convolution this node is the input gradient of: the adversarial injection needs them."""
+    """dx = dgrad(dy, W) (+ resid).  `x_fwd` / `bias` (optional, not differentiated here) are the forward input and the
+    bias of the convolution this node is the input gradient of: the adversarial injection needs them.  `tie` / `role`:
+    the node belongs to a residual block (ResidualTie) as the input gradient of its shortcut conv (ROLE_SHORTCUT), main
+    conv (ROLE_MAIN) or entry conv (ROLE_ENTRY); see ResidualTie for what the three share."""
 
     @staticmethod
-    def forward(ctx, dy, w, layer, ups, x_fwd=None, bias=None):
+    def forward(ctx, dy, w, layer, ups, x_fwd=None, bias=None, tie=None, role=0, resid=None):
         ctx.layer, ctx.ups = layer, ups
         ctx.x_fwd, ctx.bias = x_fwd, bias
+        ctx.tie, ctx.role = tie, role
         ctx.save_for_backward(dy, w)
         _, wd = layer.packed()
-        return kernels.conv2d_dgrad(dy.contiguous(), wd, layer.K, layer.pad, sum_pool2=ups)
+        return kernels.conv2d_dgrad(dy.contiguous(), wd, layer.K, layer.pad, sum_pool2=ups,
+                                    residual=resid.contiguous() if resid is not None else None)
 
     @staticmethod
     def backward(ctx, ddx):
         dy, w = ctx.saved_tensors
         ddx = ddx.contiguous()
-        g_dy = _ConvFprop.apply(ddx, w, ctx.layer, ctx.ups) if ctx.needs_input_grad[0] else None
+        tie, role = ctx.tie, ctx.role
+        g_dy = None
+        if ctx.needs_input_grad[0]:
+            if tie is not None and role == ROLE_MAIN:
+                # d/d dz1 has two terms, c1(dd h0) here and c_sc(dd x) from the shortcut's node: one launch, the
+                # shortcut's term riding in the epilogue, when that node ran first
+                g_dy = _ConvFprop.apply(ddx, w, ctx.layer, ctx.ups, tie.take("g_sc", "main_seen"))
+            else:
+                g_dy = _ConvFprop.apply(ddx, w, ctx.layer, ctx.ups)
+                if tie is not None and role == ROLE_SHORTCUT and tie.give("g_sc", "main_seen", g_dy):
+                    g_dy = None
         g_w = None
         if ctx.needs_input_grad[1] and not _skip_grad_of(w):
             operand = ddx
             if _INJECT is not None and ctx.x_fwd is not None:
                 if ctx.ups or not _direct_grad(w):
                     raise RuntimeError("adversarial injection needs plain (non-upsampling) convs with bound gradients")
-                operand = kernels.axpy_rows(ddx, ctx.x_fwd.detach().contiguous(), _INJECT)
+                x_fwd = ctx.x_fwd.detach().contiguous()
+                key = (ddx.data_ptr(), x_fwd.data_ptr())
+                if tie is not None and role in (ROLE_SHORTCUT, ROLE_ENTRY) and tie.operand is not None \
+                        and tie.operand[0] == key:
+                    operand, tie.operand = tie.operand[1], None      # the block's other entry conv already formed it
+                else:
+                    operand = kernels.axpy_rows(ddx, x_fwd, _INJECT)
+                    if tie is not None and role in (ROLE_SHORTCUT, ROLE_ENTRY):
+                        tie.operand = (key, operand)
                 b = ctx.bias
                 if b is not None and not _skip_grad_of(b):
                     if not _direct_grad(b):
@@ -255,7 +278,7 @@ class _ConvDgrad(torch.autograd.Function):
                 _wgrad_into(operand, dy, w, ctx.layer, ctx.ups)
             else:
                 g_w = _ConvWgrad.apply(operand, dy, ctx.layer, ctx.ups)
-        return g_dy, g_w, None, None, None, None
+        return g_dy, g_w, None, None, None, None, None, None, (ddx if ctx.needs_input_grad[8:9] == (True,) else None)
 
 
 class _ConvWgrad(torch.autograd.Function):
@@ -535,7 +558,7 @@ class _ConvBiasAct(torch.autograd.Function):
     dgrad, wgrad, column sum), so the R1 double backward goes through it."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, residual, layer, ups, act, pool, tie=None, tie_owner=False):
+    def forward(ctx, x, w, bias, residual, layer, ups, act, pool, tie=None, role=0):
         wf, _ = layer.packed()
         x = x.contiguous()
         y = kernels.conv2d_fprop(x, wf, layer.K, layer.K, layer.pad, bias=bias.contiguous(),
@@ -544,7 +567,7 @@ class _ConvBiasAct(torch.autograd.Function):
         if pool:
             y, pooled = y
         ctx.layer, ctx.ups, ctx.act, ctx.pool = layer, ups, act, pool
-        ctx.tie, ctx.tie_owner = tie, tie_owner
+        ctx.tie, ctx.role = tie, role
         ctx.save_for_backward(x, w, y, bias)
         return pooled if pool else y
 
@@ -560,8 +583,8 @@ class _ConvBiasAct(torch.autograd.Function):
         # taken here, fused with the activation gradient, instead of in a pass of their own during the double backward
         inj_b = bias if (_INJECT is not None and torch.is_grad_enabled() and ctx.needs_input_grad[2] and bias.is_leaf
                          and bias.grad is not None and bias.data_ptr() not in _FROZEN_PTRS) else None
-        tie, tied_inject = ctx.tie, False
-        if tie is not None and ctx.tie_owner:
+        tie, tied_inject, role = ctx.tie, False, ctx.role
+        if tie is not None and role == ROLE_SHORTCUT:
             # shortcut conv of a residual block: the main conv's activation-gradient pass (which ran just before, dz
             # being the gradient of both pre-activations) has already added the column sums to this bias
             if tie.done:
@@ -570,7 +593,7 @@ class _ConvBiasAct(torch.autograd.Function):
                 want_b, fast_b, inj_b = False, False, None
         if ctx.pool:
             tb = None
-            if tie is not None and not ctx.tie_owner and (fast_b or inj_b is not None) and tie.usable(not fast_b):
+            if tie is not None and role == ROLE_MAIN and (fast_b or inj_b is not None) and tie.usable(not fast_b):
                 tb = tie.bias
             if fast_b:
                 dz = kernels.unpool2_lrelu_bwd(dy, y if ctx.act else None, tuple(y.shape), bias_grad=bias.grad,
@@ -595,7 +618,15 @@ class _ConvBiasAct(torch.autograd.Function):
             db = _ColSum.apply(dz)
         if ctx.needs_input_grad[0]:
             # bias=None when its injected gradient has been taken above
-            dx = _ConvDgrad.apply(dz, w, layer, ups, x.detach(), None if (inj_b is not None or tied_inject) else bias)
+            inj_bias = None if (inj_b is not None or tied_inject) else bias
+            if tie is not None and role == ROLE_ENTRY:
+                # block input gradient = dgrad_c0(dz0) + dgrad_c_sc(dz1): the shortcut's term (its node ran first) is
+                # added in this conv's epilogue instead of by the autograd engine
+                dx = _ConvDgrad.apply(dz, w, layer, ups, x.detach(), inj_bias, tie, role, tie.take("dx_sc", "entry_seen"))
+            else:
+                dx = _ConvDgrad.apply(dz, w, layer, ups, x.detach(), inj_bias, tie, role)
+                if tie is not None and role == ROLE_SHORTCUT and tie.give("dx_sc", "entry_seen", dx):
+                    dx = None
         if ctx.needs_input_grad[1] and not _skip_grad_of(w):
             if _direct_grad(w):
                 _wgrad_into(x, dz, w, layer, ups)
@@ -606,13 +637,27 @@ class _ConvBiasAct(torch.autograd.Function):
         return dx, dw, db, dres, None, None, None, None, None, None
 
 
-class BiasTie:
-    """Links the bias of a residual block's shortcut conv to the activation-gradient pass of the block's main conv
-    (net.py:413-416: h = lrelu(c1(h) + c_sc(x))): the gradient w.r.t. the sum is the gradient of BOTH biases, so the
-    fused pass adds its column sums to both gradient buffers and the shortcut conv skips a reduction of its own."""
+ROLE_SHORTCUT, ROLE_MAIN, ROLE_ENTRY = 1, 2, 3
+
+
+class ResidualTie:
+    """What the three convs of a residual block (net.py:408-416: h = lrelu(c0 x); y = lrelu(c1 h + c_sc x)) share in the
+    backward passes, so that sums the autograd engine would form with add kernels ride in conv epilogues instead:
+
+    * bias: the gradient w.r.t. the sum c1 h + c_sc x is the gradient of BOTH biases, so the main conv's fused
+      activation-gradient pass adds its column sums to both buffers and the shortcut conv skips its own reduction;
+    * dx_sc: the block input gradient dgrad_c0(dz0) + dgrad_c_sc(dz1) -- the shortcut's node (created later in the
+      forward, so run earlier by the engine) parks its term here and the entry conv adds it as an epilogue residual;
+    * g_sc: in the R1 double backward d/d dz1 = c1(dd h0) + c_sc(dd x), same arrangement one order up;
+    * operand: the injection operand dd x + s_b x is the same tensor for c0 and c_sc, formed once.
+
+    Every hand-over has a fallback: if the consumer ran first it flags that, and the producer then returns its term to
+    autograd the ordinary way (the engine adds)."""
 
     def __init__(self, bias):
         self.bias, self.done = bias, False
+        self.dx_sc = self.g_sc = self.operand = None
+        self.entry_seen = self.main_seen = False
 
     def usable(self, inject):
         """Mirrors the conditions under which _ConvBiasAct.backward takes its own bias sums in the fused pass."""
@@ -621,14 +666,36 @@ class BiasTie:
             return b.requires_grad and b.is_leaf and b.grad is not None and b.data_ptr() not in _FROZEN_PTRS
         return b.requires_grad and _direct_grad(b) and not _skip_grad_of(b)
 
+    def give(self, slot, seen_flag, value):
+        """Producer side: park `value` for the consumer (True), unless the consumer already ran (False)."""
+        if getattr(self, seen_flag):
+            setattr(self, seen_flag, False)
+            return False
+        setattr(self, slot, value)
+        return True
 
-def conv_bias_lrelu(x, layer, bias, upsample=False, residual=None, pool=False, residual_tie=None):
-    return _ConvBiasAct.apply(x, layer.weight, bias, residual, layer, bool(upsample), True, bool(pool), residual_tie,
-                              False)
+    def take(self, slot, seen_flag):
+        """Consumer side: the parked value, or None (and remember that the consumer has run)."""
+        value = getattr(self, slot)
+        setattr(self, slot, None)
+        if value is None:
+            setattr(self, seen_flag, True)
+        return value
+
+
+BiasTie = ResidualTie
+
+
+def conv_bias_lrelu(x, layer, bias, upsample=False, residual=None, pool=False, residual_tie=None, entry_tie=None):
+    """residual_tie: this is the main conv (c1) of a residual block; entry_tie: its entry conv (c0)."""
+    tie, role = (residual_tie, ROLE_MAIN) if residual_tie is not None else (entry_tie, ROLE_ENTRY if entry_tie else 0)
+    return _ConvBiasAct.apply(x, layer.weight, bias, residual, layer, bool(upsample), True, bool(pool), tie, role)
 
 
 def conv_bias(x, layer, bias, upsample=False, residual=None, tie=None):
-    return _ConvBiasAct.apply(x, layer.weight, bias, residual, layer, bool(upsample), False, False, tie, True)
+    """tie: this is the shortcut conv (c_sc) of a residual block."""
+    return _ConvBiasAct.apply(x, layer.weight, bias, residual, layer, bool(upsample), False, False, tie,
+                              ROLE_SHORTCUT if tie is not None else 0)
 
 
 # ---- 1x1 convolutions between NCHW fp32 image planes and NHWC bf16 features (fromRGB / toRGB)

@@ -189,28 +189,31 @@ def conv2d_fprop(x, wp, KH, KW, pad, bias=None, residual=None, upsample=False, l
     return y
 
 
-def conv2d_dgrad(dy, wd, K, pad, sum_pool2=False):
+def conv2d_dgrad(dy, wd, K, pad, sum_pool2=False, residual=None):
     """dy (B,H,W,Cout) bf16, wd [K*K][Cin][Cout] bf16 (dgrad image of pack_weights) -> dx (B,H',W',Cin) bf16.
     sum_pool2: return the 2x2 sums of dx at half resolution (adjoint of a nearest-2x upsample in front of the conv);
     taken in the conv epilogue for 3x3 convs on images that are multiples of 16x16, in a second pass otherwise."""
-    _chk(dy, BF16, "dy"); _chk(wd, BF16, "wd")
+    _chk(dy, BF16, "dy"); _chk(wd, BF16, "wd"); _chk(residual, BF16, "residual")
     B, H, W, Cout = dy.shape
     T, Cin, Cout2 = wd.shape
     if T != K * K or Cout2 != Cout:
         raise RuntimeError(f"conv2d_dgrad: weights {tuple(wd.shape)} do not match dy {tuple(dy.shape)} K={K}")
+    if residual is not None and (sum_pool2 or tuple(residual.shape) != (B, H + K - 1 - 2 * pad, W + K - 1 - 2 * pad, Cin)):
+        raise RuntimeError("conv2d_dgrad: residual must have the shape of dx (and excludes sum_pool2)")
     pd = K - 1 - pad
     Ho, Wo = H + 2 * pd - K + 1, W + 2 * pd - K + 1
     fuse = bool(sum_pool2) and K == 3 and pd == 1 and Ho % 16 == 0 and Wo % 16 == 0
     dx = torch.empty((B, Ho // 2, Wo // 2, Cin) if fuse else (B, Ho, Wo, Cin), dtype=BF16, device=dy.device)
     lib = _lib.load()
     flops = 2.0 * B * Ho * Wo * Cout * Cin * K * K
-    nbytes = 2.0 * (dy.numel() + dx.numel() + wd.numel())
+    nbytes = 2.0 * (dy.numel() + dx.numel() + wd.numel() + (residual.numel() if residual is not None else 0))
     ws = None if fuse else _fprop_workspace(lib, B, H, W, Cout, Cin, K, K, pd, 0, dy.device)
     patch = fuse or (K == 3 and pd == 1 and Ho % 16 == 0 and Wo % 16 == 0 and ws is None
                      and B * (Ho // 16) * (Wo // 16) * (Cin // (128 if Cin % 128 == 0 else 64)) >= 64)
     kname = ("conv3x3_patch_kernel" if patch else "conv_fprop_kernel") + f"<{128 if Cin % 128 == 0 else 64}>"
     rc = _timed(kname, flops, nbytes,
-                lambda: lib.rgbd_conv2d_dgrad_bf16(_ptr(dy), _ptr(wd), _ptr(dx), B, H, W, Cin, Cout, K, pad, int(fuse),
+                lambda: lib.rgbd_conv2d_dgrad_bf16(_ptr(dy), _ptr(wd), _ptr(residual), _ptr(dx), B, H, W, Cin, Cout, K, pad,
+                                                   int(fuse),
                                                    _ptr(ws), _stream()))
     _lib.check(rc, "rgbd_conv2d_dgrad_bf16")
     if sum_pool2 and not fuse:

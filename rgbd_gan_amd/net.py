@@ -462,8 +462,8 @@ class Discriminator(_Link):
             return F.linear(h * _inv_c(self.ch, 1.0), p[pre + "/l2/c/W"], p[pre + "/l2/c/b"])
         # net.py:408-426: h = lrelu(c0 x); h = lrelu(c1 h + c_sc x); avg-pool.  Bias, shortcut add and activation
         # all ride in the conv epilogues; the 2x2 average pool and its backward are fused with the activation gradient.
-        h = Fn.conv_bias_lrelu(x, self.conv[pre + "/c0"], p[pre + "/c0/c/b"])
-        tie = Fn.BiasTie(p[pre + "/c_sc/c/b"]) if self.res else None
+        tie = Fn.ResidualTie(p[pre + "/c_sc/c/b"]) if self.res else None
+        h = Fn.conv_bias_lrelu(x, self.conv[pre + "/c0"], p[pre + "/c0/c/b"], entry_tie=tie)
         sc = Fn.conv_bias(x, self.conv[pre + "/c_sc"], p[pre + "/c_sc/c/b"], tie=tie) if self.res else None
         return Fn.conv_bias_lrelu(h, self.conv[pre + "/c1"], p[pre + "/c1/c/b"], residual=sc, pool=True,
                                   residual_tie=tie)
