@@ -423,11 +423,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(ConvArgs a) {
         }
     };
 
-    // bias of this lane's 16 output channels: loaded once (the output-channel tile is fixed for the whole persistent
-    // loop) -- a load inside the per-tile epilogue would wait behind, and so drain, the prefetched next tile
-    float bv[16];
-#pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) bv[k2] = a.bias ? a.bias[n0 + wave_co + 16 * q + k2] : 0.f;
+    // bias of the tile's output channels: parked in LDS once (the output-channel tile is fixed for the whole persistent
+    // loop) -- a global load inside the per-tile epilogue would wait behind, and so drain, the prefetched next tile, and
+    // 16 registers per lane held across the MFMA loop would push the kernel past 224 VGPRs (see the launch bounds)
+    float* const bias_lds = reinterpret_cast<float*>(dsm + 2 * P_BYTES + 3 * W_BYTES);   // [BN], visible after the prologue barrier
+    if (tid < BN) bias_lds[tid] = a.bias ? a.bias[n0 + tid] : 0.f;
 
     auto epilogue = [&](int pt) {       // bias -> residual -> leaky ReLU -> bf16 NHWC, then clear the accumulators
         int b, y0, x0;
@@ -475,9 +475,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(ConvArgs a) {
             const long o = (((long)b * a.Hout + yy) * a.Wout + xx) * a.Cout + co;
             float v[16];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_lds + wave_co + 16 * q + 4 * i);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[4 * i + r] = acc[i][j][r] + bv[4 * i + r];
+                for (int r = 0; r < 4; ++r) v[4 * i + r] = acc[i][j][r] + bq[r];
+            }
             if (a.resid) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -956,7 +958,7 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
         a.ptiles = (int)ptiles;
         a.wgs_per_ntile = per_nt;
         const long grid = (long)per_nt * n_tiles;
-        const int lds = 2 * 324 * 128 + 3 * (wide ? 128 : 64) * 128;
+        const int lds = 2 * 324 * 128 + 3 * (wide ? 128 : 64) * 128 + (wide ? 128 : 64) * 4;
         const void* fn = wide ? (a.ups ? (const void*)&conv3x3_patch_kernel<128, true>
                                        : (const void*)&conv3x3_patch_kernel<128, false>)
                               : (a.ups ? (const void*)&conv3x3_patch_kernel<64, true>
