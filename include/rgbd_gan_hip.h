@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RGBD_ABI_VERSION 2
+#define RGBD_ABI_VERSION 3
 
 int rgbd_abi_version(void);
 const char* rgbd_last_error(void);
@@ -126,6 +126,22 @@ int64_t rgbd_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int 
 int rgbd_conv2d_wgrad_bf16(const void* x, const void* dy, void* workspace, float* dw,
                            int B, int H, int W, int Cin, int Cout, int K, float scale, int accumulate, int upsample,
                            void* stream);
+/* The two halves of rgbd_conv2d_wgrad_bf16 for callers that collect the weight gradients of a whole backward pass
+ * (Chainer runs them inside Convolution2DFunction.backward, pggan.py:13-24; order among them is free):
+ *   rgbd_conv2d_wgrad_partial_bf16: the MFMA kernel only -- per-workgroup partial slabs into `workspace`
+ *     (rgbd_conv2d_wgrad_workspace bytes = nsplit slabs of K*K*Cout*Cin floats);
+ *   rgbd_wgrad_reduce_multi: slab sums + layout change + scale (+ accumulate) for n such workspaces in one launch per
+ *     32 descriptors.  `descs` is HOST memory (copied into the kernel arguments). */
+typedef struct rgbd_wgrad_reduce_desc {
+    const float* workspace;   /* nsplit slabs of [taps][cout][cin] floats */
+    float* dw;                /* (cout, cin, K, K) master-weight gradient */
+    int32_t nsplit, taps, cout, cin;
+    float scale;
+    int32_t accumulate;
+} rgbd_wgrad_reduce_desc;
+int rgbd_conv2d_wgrad_partial_bf16(const void* x, const void* dy, void* workspace, int B, int H, int W, int Cin, int Cout,
+                                   int K, int upsample, void* stream);
+int rgbd_wgrad_reduce_multi(const rgbd_wgrad_reduce_desc* descs, int n, void* stream);
 
 /* ------------------------------------------------------------------ AdaIN (instance norm + style affine)
  * Replaces normalization/adain.py:54-73 (reshape + F.batch_normalization + broadcast mul/add) and its backward.

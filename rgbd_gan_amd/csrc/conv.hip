@@ -789,13 +789,12 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradArgs a) {
 // threads are 32 quads x 8 slab groups: every thread sums its group's slabs with four independent loads in flight,
 // the eight partials meet in LDS, and the quad's owner writes scale * sum to the master layout dw[co][ci][tap]
 // (plain stores or read-add-write: dw is the optimizer's accumulating gradient buffer).
-__global__ __launch_bounds__(256) void wgrad_reduce_finish_kernel(const float* __restrict__ slabs, int nslab,
-                                                                  float* __restrict__ dw, int taps, int cout, int cin,
-                                                                  float scale, int accumulate) {
+__device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ slabs, int nslab, float* __restrict__ dw,
+                                                   int taps, int cout, int cin, float scale, int accumulate, long block) {
     __shared__ f32x4 part[8][32];
     const long total = (long)taps * cout * cin;
     const int quad = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const long e4 = ((long)blockIdx.x * 32 + quad) * 4;
+    const long e4 = (block * 32 + quad) * 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (e4 < total) {
         const int per_group = (nslab + 7) >> 3;
@@ -828,6 +827,29 @@ __global__ __launch_bounds__(256) void wgrad_reduce_finish_kernel(const float* _
             dw[o] = accumulate ? dw[o] + v : v;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_finish_kernel(const float* __restrict__ slabs, int nslab,
+                                                                  float* __restrict__ dw, int taps, int cout, int cin,
+                                                                  float scale, int accumulate) {
+    wgrad_reduce_block(slabs, nslab, dw, taps, cout, cin, scale, accumulate, blockIdx.x);
+}
+
+// The same reduction for up to WGRAD_MULTI_MAX weight gradients in ONE launch (descriptors by value in the kernel
+// arguments): a backward pass whose weight gradients were deferred (functional.deferred_wgrads) pays one reduction launch
+// instead of one per layer.
+constexpr int WGRAD_MULTI_MAX = 32;
+struct WgradMultiArgs {
+    rgbd_wgrad_reduce_desc d[WGRAD_MULTI_MAX];
+    int block_begin[WGRAD_MULTI_MAX + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(WgradMultiArgs m) {
+    int i = 0;
+    while (i + 1 < m.n && (int)blockIdx.x >= m.block_begin[i + 1]) ++i;     // block-uniform scan, <= 32 entries
+    const rgbd_wgrad_reduce_desc& d = m.d[i];
+    wgrad_reduce_block(d.workspace, d.nsplit, d.dw, d.taps, d.cout, d.cin, d.scale, d.accumulate,
+                       (long)blockIdx.x - m.block_begin[i]);
 }
 
 bool g_force_gather = false;   // test hook: route every shape through the generic gather kernel
@@ -1051,9 +1073,9 @@ extern "C" int64_t rgbd_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int
     return (int64_t)p.nsplit * K * K * Cout * Cin * (int64_t)sizeof(float);
 }
 
-extern "C" int rgbd_conv2d_wgrad_bf16(const void* x, const void* dy, void* workspace, float* dw, int B, int H, int W,
-                                      int Cin, int Cout, int K, float scale, int accumulate, int upsample, void* stream) {
-    RGBD_REQUIRE(x && dy && workspace && dw, "rgbd_conv2d_wgrad_bf16: null pointer");
+static int wgrad_partial_impl(const void* x, const void* dy, void* workspace, int B, int H, int W, int Cin, int Cout, int K,
+                              int upsample, void* stream, int* nsplit_out) {
+    RGBD_REQUIRE(x && dy && workspace, "rgbd_conv2d_wgrad_bf16: null pointer");
     RGBD_REQUIRE(K == 1 || K == 3, "rgbd_conv2d_wgrad_bf16: K must be 1 or 3 (K=%d)", K);
     RGBD_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0,
                  "rgbd_conv2d_wgrad_bf16: Cin and Cout must be multiples of 64 (Cin=%d Cout=%d)", Cin, Cout);
@@ -1072,7 +1094,6 @@ extern "C" int rgbd_conv2d_wgrad_bf16(const void* x, const void* dy, void* works
     a.ups = upsample ? 1 : 0;
     dim3 grid(p.nsplit, Cin / 64, Cout / 64);
     hipStream_t st = (hipStream_t)stream;
-    const long total = (long)K * K * Cout * Cin;
     {
         static bool attr_done[4] = {false, false, false, false};
         const bool fast = p.PW == 16 && p.PH == 8;
@@ -1094,8 +1115,47 @@ extern "C" int rgbd_conv2d_wgrad_bf16(const void* x, const void* dy, void* works
         }
     }
     RGBD_CHECK_LAUNCH("conv_wgrad_kernel");
-    wgrad_reduce_finish_kernel<<<(unsigned)((total / 4 + 31) / 32), 256, 0, st>>>((const float*)workspace, p.nsplit, dw,
-                                                                                 K * K, Cout, Cin, scale, accumulate);
+    *nsplit_out = p.nsplit;
+    return 0;
+}
+
+extern "C" int rgbd_conv2d_wgrad_bf16(const void* x, const void* dy, void* workspace, float* dw, int B, int H, int W,
+                                      int Cin, int Cout, int K, float scale, int accumulate, int upsample, void* stream) {
+    RGBD_REQUIRE(dw, "rgbd_conv2d_wgrad_bf16: null pointer");
+    int nsplit = 0;
+    const int rc = wgrad_partial_impl(x, dy, workspace, B, H, W, Cin, Cout, K, upsample, stream, &nsplit);
+    if (rc != 0) return rc;
+    const long total = (long)K * K * Cout * Cin;
+    wgrad_reduce_finish_kernel<<<(unsigned)((total / 4 + 31) / 32), 256, 0, (hipStream_t)stream>>>(
+        (const float*)workspace, nsplit, dw, K * K, Cout, Cin, scale, accumulate);
     RGBD_CHECK_LAUNCH("wgrad_reduce_finish_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_conv2d_wgrad_partial_bf16(const void* x, const void* dy, void* workspace, int B, int H, int W,
+                                              int Cin, int Cout, int K, int upsample, void* stream) {
+    int nsplit = 0;
+    return wgrad_partial_impl(x, dy, workspace, B, H, W, Cin, Cout, K, upsample, stream, &nsplit);
+}
+
+extern "C" int rgbd_wgrad_reduce_multi(const rgbd_wgrad_reduce_desc* descs, int n, void* stream) {
+    RGBD_REQUIRE(descs && n > 0, "rgbd_wgrad_reduce_multi: no descriptors");
+    for (int base = 0; base < n; base += WGRAD_MULTI_MAX) {
+        WgradMultiArgs m;
+        m.n = n - base < WGRAD_MULTI_MAX ? n - base : WGRAD_MULTI_MAX;
+        long blocks = 0;
+        for (int i = 0; i < m.n; ++i) {
+            const rgbd_wgrad_reduce_desc& d = descs[base + i];
+            RGBD_REQUIRE(d.workspace && d.dw && d.nsplit > 0 && (d.taps == 1 || d.taps == 9) && d.cout > 0 && d.cin > 0 &&
+                         d.cin % 64 == 0 && d.cout % 64 == 0, "rgbd_wgrad_reduce_multi: bad descriptor %d", base + i);
+            m.d[i] = d;
+            m.block_begin[i] = (int)blocks;
+            blocks += ((long)d.taps * d.cout * d.cin / 4 + 31) / 32;
+        }
+        RGBD_REQUIRE(blocks < 0x7fffffffL, "rgbd_wgrad_reduce_multi: grid too large");
+        m.block_begin[m.n] = (int)blocks;
+        wgrad_reduce_multi_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(m);
+        RGBD_CHECK_LAUNCH("wgrad_reduce_multi_kernel");
+    }
     return 0;
 }

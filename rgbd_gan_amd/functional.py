@@ -176,8 +176,7 @@ def deferred_wgrads(items):
 
 
 def run_deferred_wgrads(items):
-    for x, dy, target, K, inv_c, ups in items:
-        kernels.conv2d_wgrad(x, dy, K, inv_c, out=target, accumulate=True, upsample=ups)
+    kernels.conv2d_wgrad_batch(items)
 
 
 def _wgrad_into(x, dy, w, layer, ups):

@@ -278,6 +278,45 @@ def colsum(x, out=None, row_scale=None, rows_per_sample=0):
     return out
 
 
+WGRAD_REDUCE_DESC = [("workspace", "<u8"), ("dw", "<u8"), ("nsplit", "<i4"), ("taps", "<i4"), ("cout", "<i4"),
+                     ("cin", "<i4"), ("scale", "<f4"), ("accumulate", "<i4")]      # struct rgbd_wgrad_reduce_desc, 40 bytes
+
+
+def conv2d_wgrad_batch(items):
+    """Weight gradients of several convs, `items` = [(x, dy, target dW fp32, K, scale, upsample)], accumulated into their
+    targets: one MFMA launch each (per-workgroup partial slabs) and ONE slab-reduction launch per 32 of them."""
+    import numpy as np
+    if not items:
+        return
+    lib = _lib.load()
+    tab = np.zeros(len(items), dtype=WGRAD_REDUCE_DESC)
+    assert tab.dtype.itemsize == 40
+    keep = []
+    for i, (x, dy, target, K, scale, ups) in enumerate(items):
+        _chk(x, BF16, "x"); _chk(dy, BF16, "dy"); _chk(target, F32, "target")
+        B, H, W, Cin = x.shape
+        if ups:
+            H, W = 2 * H, 2 * W
+        Cout = dy.shape[3]
+        if tuple(dy.shape[:3]) != (B, H, W) or tuple(target.shape) != (Cout, Cin, K, K):
+            raise RuntimeError(f"conv2d_wgrad_batch: shape mismatch x={tuple(x.shape)} dy={tuple(dy.shape)} "
+                               f"dW={tuple(target.shape)} upsample={ups}")
+        ws_bytes = lib.rgbd_conv2d_wgrad_workspace(B, H, W, Cin, Cout, K)
+        if ws_bytes < 0:
+            raise RuntimeError(f"conv2d_wgrad_batch: unsupported shape x={tuple(x.shape)} dy={tuple(dy.shape)} K={K}")
+        ws = torch.empty(ws_bytes // 4, dtype=F32, device=x.device)
+        keep.append(ws)
+        flops = 2.0 * B * H * W * Cout * Cin * K * K
+        nbytes = 2.0 * (x.numel() + dy.numel()) + 2.0 * ws_bytes
+        rc = _timed(f"conv_wgrad_kernel<{K * K}>+reduce", flops, nbytes,
+                    lambda: lib.rgbd_conv2d_wgrad_partial_bf16(_ptr(x), _ptr(dy), _ptr(ws), B, H, W, Cin, Cout, K,
+                                                               int(bool(ups)), _stream()))
+        _lib.check(rc, "rgbd_conv2d_wgrad_partial_bf16")
+        tab[i] = (ws.data_ptr(), target.data_ptr(), ws_bytes // (4 * K * K * Cout * Cin), K * K, Cout, Cin, float(scale), 1)
+    rc = lib.rgbd_wgrad_reduce_multi(tab.ctypes.data, len(items), _stream())
+    _lib.check(rc, "rgbd_wgrad_reduce_multi")
+
+
 def axpy_rows(a, x, s):
     """a + s[b] * x for (B, ...) bf16 tensors, s (B,) fp32."""
     _chk(a, BF16, "a"); _chk(x, BF16, "x"); _chk(s, F32, "s")

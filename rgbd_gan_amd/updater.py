@@ -338,7 +338,15 @@ class RGBDUpdater:
                 raise AssertionError("occupancy-net loss is not supported")
         if cfg.optical_flow:
             raise AssertionError("optical flow loss is not supported")
-        torch.autograd.backward(heads, seeds)
+        # the generator's weight gradients are leaves of this backward pass: collected while it runs, issued after it
+        # as one batch (one slab-reduction launch for all of them instead of one per layer)
+        if not os.environ.get("RGBD_NO_G_DEFER"):       # (+2 % step rate, A/B on one box)
+            wgrads = []
+            with Fn.deferred_wgrads(wgrads):
+                torch.autograd.backward(heads, seeds)
+            Fn.run_deferred_wgrads(wgrads)
+        else:
+            torch.autograd.backward(heads, seeds)
         st["x_fake_data"] = x_fake.detach()
         st["x_fake"] = st["gx"] = None                 # drop the autograd graph
 

@@ -223,6 +223,27 @@ def test_conv_wgrad_matches_autograd(B, H, W, Cin, Cout, K):
     torch.testing.assert_close(dw.cpu(), ref, atol=tol, rtol=1e-4)
 
 
+def test_conv_wgrad_batch_matches_single_calls():
+    """Collected weight gradients (functional.deferred_wgrads): partial MFMA launches + one multi-descriptor slab
+    reduction accumulate exactly what the one-call-per-layer path does (same kernels, same summation order)."""
+    from rgbd_gan_amd import kernels
+    g = torch.Generator().manual_seed(29)
+    shapes = [(2, 8, 64, 128, 3, False), (2, 16, 128, 64, 3, True), (3, 4, 64, 64, 1, False), (1, 32, 64, 64, 3, False)] * 9
+    items, refs = [], []
+    for i, (B, H, Cin, Cout, K, ups) in enumerate(shapes):       # 36 items: more than one reduction launch
+        hs = H // 2 if ups else H
+        x = torch.randn(B, hs, hs, Cin, generator=g).to(dev()).to(torch.bfloat16)
+        dy = torch.randn(B, H, H, Cout, generator=g).to(dev()).to(torch.bfloat16)
+        init = torch.randn(Cout, Cin, K, K, generator=g).to(dev())
+        ref = init.clone()
+        kernels.conv2d_wgrad(x, dy, K, 0.5 + 0.01 * i, out=ref, accumulate=True, upsample=ups)
+        items.append((x, dy, init, K, 0.5 + 0.01 * i, ups))
+        refs.append(ref)
+    kernels.conv2d_wgrad_batch(items)
+    for (_, _, got, _, _, _), ref in zip(items, refs):
+        assert torch.equal(got, ref)
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 4, 4, 64, 64), (3, 8, 8, 128, 64), (2, 32, 32, 64, 128), (1, 64, 64, 64, 64)])
 def test_conv_wgrad_through_the_upsampling(B, H, W, Cin, Cout):
     """c0(upscale2x(h)) of a synthesis block (net.py:148-150, rescale.py:4-5): the weight gradient reads the
