@@ -266,6 +266,11 @@ int rgbd_pixelnorm_bwd(const float* x, const float* dy, float* dx, int M, int C,
 int rgbd_depth_head_fwd(const float* x, float* y, int B, int HW, void* stream);
 int rgbd_depth_head_bwd(const float* x, const float* y, const float* dy, float* dx, int B, int HW, void* stream);
 int rgbd_ema_update(float* dst, const float* src, int64_t n, float tau, void* stream);
+/* Logit heads of the non-saturating GAN loss (loss_functions.py:15-28, updater.py:331-336,404-408) on n logits, one launch:
+ *   losses[0] = mean softplus(-y), losses[1] = mean softplus(y); seed_neg / seed_pos (n) their derivatives w.r.t. y
+ *   (-sigmoid(-y)/n, sigmoid(y)/n, taken at max(y, -60)); ratio (n) = seed_neg / seed_pos = -exp(-max(y, -60)). */
+int rgbd_gan_logit_heads(const float* y, int n, float* losses, float* seed_neg, float* seed_pos, float* ratio,
+                         void* stream);
 /* Clear n floats with a kernel launch (a plain kernel node inside captured HIP graphs, unlike hipMemsetAsync). */
 int rgbd_zero_f32(float* p, int64_t n, void* stream);
 

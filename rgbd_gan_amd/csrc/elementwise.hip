@@ -1172,6 +1172,46 @@ __global__ __launch_bounds__(256) void depth_head_kernel(const float* __restrict
     }
 }
 
+// The logit heads of the non-saturating GAN loss (loss_functions.py:15-28) in one single-block launch:
+//   losses[0] = mean softplus(-y)   (generator's loss on fakes / discriminator's on reals)
+//   losses[1] = mean softplus(+y)   (discriminator's loss on fakes)
+//   seed_neg  = d losses[0] / dy = -sigmoid(-y) / n,   seed_pos = d losses[1] / dy = sigmoid(y) / n
+//   ratio     = seed_neg / seed_pos = -exp(-y)
+// Derivatives are taken at max(y, -60): below that seed_neg is -1/n to fp32 precision and seed_pos < 1e-26/n, while
+// their ratio stays finite.  F.softplus as chainer computes it: max(x, 0) + log1p(exp(-|x|)).
+__global__ __launch_bounds__(256) void gan_logit_heads_kernel(const float* __restrict__ y, int n,
+                                                              float* __restrict__ losses, float* __restrict__ seed_neg,
+                                                              float* __restrict__ seed_pos, float* __restrict__ ratio) {
+    __shared__ float red[2][256];
+    float sn = 0.f, sp = 0.f;
+    const float inv_n = 1.0f / (float)n;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float v = y[i];
+        const float l = log1pf(expf(-fabsf(v)));
+        sn += fmaxf(-v, 0.f) + l;
+        sp += fmaxf(v, 0.f) + l;
+        const float vc = fmaxf(v, -60.f);
+        const float e = expf(-vc);                       // <= e^60, finite in fp32
+        seed_neg[i] = -(e / (1.0f + e)) * inv_n;         // -sigmoid(-vc) / n
+        seed_pos[i] = (1.0f / (1.0f + e)) * inv_n;       //  sigmoid(vc) / n
+        ratio[i] = -e;
+    }
+    red[0][threadIdx.x] = sn;
+    red[1][threadIdx.x] = sp;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + s];
+            red[1][threadIdx.x] += red[1][threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        losses[0] = red[0][0] * inv_n;
+        losses[1] = red[1][0] * inv_n;
+    }
+}
+
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ dst, const float* __restrict__ src, long n,
                                                   float tau) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -1212,6 +1252,14 @@ extern "C" int rgbd_depth_head_bwd(const float* x, const float* y, const float* 
     const long total = (long)B * 4 * HW;
     depth_head_kernel<<<(int)min((long)2048, (total + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, y, dy, dx, HW, total);
     RGBD_CHECK_LAUNCH("depth_head_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_gan_logit_heads(const float* y, int n, float* losses, float* seed_neg, float* seed_pos, float* ratio,
+                                    void* stream) {
+    RGBD_REQUIRE(y && losses && seed_neg && seed_pos && ratio && n > 0, "rgbd_gan_logit_heads: bad arguments");
+    gan_logit_heads_kernel<<<1, 256, 0, (hipStream_t)stream>>>(y, n, losses, seed_neg, seed_pos, ratio);
+    RGBD_CHECK_LAUNCH("gan_logit_heads_kernel");
     return 0;
 }
 

@@ -532,6 +532,18 @@ def pixelnorm(x, dy=None, eps=1e-8):
     return out
 
 
+def gan_logit_heads(y):
+    """y: logits (any shape, fp32) -> (losses (2,) = [mean softplus(-y), mean softplus(y)], seed_neg, seed_pos, ratio),
+    the three vectors shaped like y: derivatives of the two means w.r.t. y (at max(y, -60)) and their quotient."""
+    _chk(y, F32, "y")
+    y = y.contiguous()
+    losses = torch.empty(2, dtype=F32, device=y.device)
+    sn, sp, ratio = torch.empty_like(y), torch.empty_like(y), torch.empty_like(y)
+    rc = _lib.load().rgbd_gan_logit_heads(_ptr(y), y.numel(), _ptr(losses), _ptr(sn), _ptr(sp), _ptr(ratio), _stream())
+    _lib.check(rc, "rgbd_gan_logit_heads")
+    return losses, sn, sp, ratio
+
+
 def depth_head_fwd(x):
     """x (B,4,H,W) fp32 -> [x0, x1, x2, 1 / (softplus(x3) + 1e-4)]."""
     _chk(x, F32, "x")

@@ -296,21 +296,19 @@ class RGBDUpdater:
         # per sample by (dL_G/dy_b) / (dL_D/dy_b), the generator's image gradient.
         x_d = x_fake[:, :3].detach().contiguous().requires_grad_(True)
         y_fake, _ = self.dis(x_d, stage=stage, return_hidden=True)
-        obs["gen/loss_adv"] = loss_func_dcgan_gen(y_fake.detach())
-        # seeds from logits clamped at -60: below that the generator's seed -sigmoid(-y)/B equals -1/B to fp32
-        # precision and the discriminator's sigmoid(y)/B is < 1e-26/B either way, but their ratio stays finite
-        # (an unclamped logit of -90 would give 0 * inf)
-        y_leaf = y_fake.detach().clamp(min=-60.0).requires_grad_(True)
-        seed_g, = torch.autograd.grad(loss_func_dcgan_gen(y_leaf), y_leaf)
+        # losses and seeds of both adversarial terms from the logits in one launch; seeds from logits clamped at -60:
+        # below that the generator's seed -sigmoid(-y)/B equals -1/B to fp32 precision and the discriminator's
+        # sigmoid(y)/B is < 1e-26/B either way, but their ratio stays finite (an unclamped logit of -90 would give 0 * inf)
+        heads, seed_g, seed_d, ratio = kernels.gan_logit_heads(y_fake.detach())
+        obs["gen/loss_adv"] = heads[0]                                      # loss_func_dcgan_gen(y_fake)
         if st.get("share_dfake", True):
-            seed_d, = torch.autograd.grad(torch.sum(F.softplus(y_leaf)) / y_leaf.numel(), y_leaf)
             with contextlib.ExitStack() as stack:
                 if st.get("concurrent"):          # D's real-batch gradients are being written on the other stream
                     for _, store in self.dis.stores:
                         stack.enter_context(store.alt_grads())
                 torch.autograd.backward([y_fake], [seed_d], inputs=[x_d] + list(self.dis.params()))
-            gx = x_d.grad * (seed_g / seed_d).reshape(-1, 1, 1, 1)
-            st["loss_dfake"] = torch.sum(F.softplus(y_fake.detach())) / y_fake.numel()   # fake term of loss_func_dcgan_dis
+            gx = x_d.grad * ratio.reshape(-1, 1, 1, 1)
+            st["loss_dfake"] = heads[1]                                     # fake term of loss_func_dcgan_dis
         else:
             with Fn.weight_grads_frozen(self.dis):
                 gx, = torch.autograd.grad([y_fake], [x_d], [seed_g])
@@ -360,12 +358,14 @@ class RGBDUpdater:
         x_real_v = st["x_real"].detach().requires_grad_(True)
         y_real = self.dis(x_real_v, stage=stage)
         fake_done = bool(st.get("share_dfake", True))
+        real_heads = None
         if fake_done:
             # the fake half of loss_func_dcgan_dis is differentiated in the generator phase (its weight gradients go
             # to D's gradient buffers, which are cleared at the start of the step); its value is added to the report in
             # the optimizer phase, after the two phases have joined
             y_fake = None
-            reported = torch.sum(F.softplus(-y_real.detach())) / y_real.numel()
+            real_heads = kernels.gan_logit_heads(y_real.detach())
+            reported = real_heads[0][0]                                     # mean softplus(-y_real)
         else:
             self.dis.cleargrads()
             y_fake = self.dis(st["x_fake_data"][:, :3].contiguous(), stage=stage)
@@ -378,8 +378,7 @@ class RGBDUpdater:
             # through the recorded forward: its per-sample seeds are folded into the R1 passes
             # (functional.adversarial_injection); only the dense tail after the conv stack (torch ops) takes them
             # the ordinary way.
-            y_leaf = y_real.detach().requires_grad_(True)
-            seed, = torch.autograd.grad(torch.sum(F.softplus(-y_leaf)) / y_leaf.numel(), y_leaf)
+            seed = real_heads[1]                                            # d mean softplus(-y_real) / dy
         if r1:
             with Fn.input_grads_only(), (Fn.adversarial_injection(seed) if inject else contextlib.nullcontext()):
                 grad_x, = torch.autograd.grad([y_real.sum()], [x_real_v], create_graph=True)

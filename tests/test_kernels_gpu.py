@@ -223,6 +223,26 @@ def test_conv_wgrad_matches_autograd(B, H, W, Cin, Cout, K):
     torch.testing.assert_close(dw.cpu(), ref, atol=tol, rtol=1e-4)
 
 
+def test_gan_logit_heads_match_the_loss_functions():
+    """loss_functions.py:15-28 on the logits, values and derivatives, incl. logits far in both tails."""
+    from rgbd_gan_amd import kernels
+    g = torch.Generator().manual_seed(31)
+    y = torch.cat([torch.randn(29, 1, generator=g) * 4, torch.tensor([[-90.0], [75.0], [0.0]])])
+    yl = y.clone().requires_grad_(True)
+    l_neg = torch.sum(F.softplus(-yl)) / yl.numel()
+    l_pos = torch.sum(F.softplus(yl)) / yl.numel()
+    g_neg, = torch.autograd.grad(l_neg, yl)
+    g_pos, = torch.autograd.grad(l_pos, yl)
+    losses, sn, sp, ratio = kernels.gan_logit_heads(y.to(dev()))
+    torch.testing.assert_close(losses.cpu(), torch.stack([l_neg, l_pos]).detach(), atol=1e-6, rtol=1e-5)
+    torch.testing.assert_close(sn.cpu(), g_neg, atol=1e-9, rtol=1e-5)
+    keep = y.reshape(-1) > -60                                   # below the clamp seed_pos is < 1e-26/n either way
+    torch.testing.assert_close(sp.cpu()[keep], g_pos[keep], atol=1e-12, rtol=1e-5)
+    assert float(sp.cpu()[~keep].abs().max()) < 1e-26
+    torch.testing.assert_close(ratio.cpu(), -torch.exp(-y.clamp(min=-60.0)), atol=0, rtol=1e-5)
+    assert torch.isfinite(ratio).all()
+
+
 def test_conv_wgrad_batch_matches_single_calls():
     """Collected weight gradients (functional.deferred_wgrads): partial MFMA launches + one multi-descriptor slab
     reduction accumulate exactly what the one-call-per-layer path does (same kernels, same summation order)."""
