@@ -455,9 +455,12 @@ class Discriminator(_Link):
         pre = f"blocks/{i}"
         if i == 0:
             h = Fn.conv_bias_lrelu(x, self.conv[pre + "/c0"], p[pre + "/c0/c/b"])
-            W = p[pre + "/c1/c/W"]                                     # 4x4 valid conv == linear over (h,w,c)
-            Wm = W.permute(0, 2, 3, 1).reshape(W.shape[0], -1)
-            h = F.linear(h.float().reshape(h.shape[0], -1) * _inv_c(W.shape[1] * 16), Wm, p[pre + "/c1/c/b"])
+            # 4x4 valid conv == linear over (c,h,w).  The ACTIVATION (0.5 MB) is brought into the weight's own
+            # (ci,kh,kw) order, not the 4 MB weight into NHWC order: no weight copy forward, and the weight gradient
+            # comes out in the master layout
+            W = p[pre + "/c1/c/W"]
+            hf = h.float().permute(0, 3, 1, 2).reshape(h.shape[0], -1)
+            h = F.linear(hf * _inv_c(W.shape[1] * 16), W.reshape(W.shape[0], -1), p[pre + "/c1/c/b"])
             h = Fn.lrelu(h)
             return F.linear(h * _inv_c(self.ch, 1.0), p[pre + "/l2/c/W"], p[pre + "/l2/c/b"])
         # net.py:408-426: h = lrelu(c0 x); h = lrelu(c1 h + c_sc x); avg-pool.  Bias, shortcut add and activation
