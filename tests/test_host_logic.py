@@ -157,3 +157,22 @@ def test_param_store_fused_views_share_storage_and_gradient():
     assert float(W.grad.abs().sum()) == 0.0 and W.grad.data_ptr() == st["a/W"].grad.data_ptr()
     with pytest.raises(ValueError):
         st.fused(("a/W", "c/W"), (4 * 8 + 15,))                # not adjacent
+
+
+def test_residual_tie_hand_overs_work_in_either_order():
+    """functional.ResidualTie: a producer parks its term for the consumer when it runs first; when the consumer ran
+    first it is told so and returns the term to autograd the ordinary way.  Both orders leave the tie clean."""
+    from rgbd_gan_amd.functional import ResidualTie
+    tie = ResidualTie(torch.zeros(4, requires_grad=True))
+    term = torch.ones(2)
+    # producer first: parked, consumer takes it
+    assert tie.give("dx_sc", "entry_seen", term) is True
+    assert tie.take("dx_sc", "entry_seen") is term
+    assert tie.dx_sc is None and tie.entry_seen is False
+    # consumer first: nothing parked, producer must keep its term
+    assert tie.take("dx_sc", "entry_seen") is None
+    assert tie.give("dx_sc", "entry_seen", term) is False
+    assert tie.dx_sc is None and tie.entry_seen is False
+    # the two junctions are independent
+    assert tie.give("g_sc", "main_seen", term) is True and tie.dx_sc is None
+    assert tie.take("g_sc", "main_seen") is term
