@@ -223,6 +223,44 @@ def test_conv_wgrad_matches_autograd(B, H, W, Cin, Cout, K):
     torch.testing.assert_close(dw.cpu(), ref, atol=tol, rtol=1e-4)
 
 
+@pytest.mark.parametrize("H,Cin,Cout,ups", [(128, 64, 128, False), (128, 128, 128, False), (64, 256, 256, False),
+                                             (128, 128, 64, True), (32, 256, 256, True)])
+def test_conv_engine_adjoint_identities_at_benchmark_sizes(H, Cin, Cout, ups):
+    """At the benchmark's layer shapes (B = 32, too large for the CPU oracle) the three kernels of a conv check each
+    other through identities that hold for any correct implementation:
+        <fprop(x; W), dy> = <x, dgrad(dy; W)> = <W, wgrad(x, dy)> / scale     (one bilinear form, three evaluations)
+    with the nearest-2x upsample folded in for the generator's c0 (fprop reads through it, dgrad returns 2x2 sums,
+    wgrad reads x through the index map).  Tolerance: bf16 rounding of the stored tensors, averaged over >1e7 terms."""
+    from rgbd_gan_amd import kernels
+    B = 32
+    g = torch.Generator().manual_seed(41)
+    hs = H // 2 if ups else H
+    scale = float(np.sqrt(2.0 / (Cin * 9)))
+    x = torch.randn(B, hs, hs, Cin, generator=g).to(dev()).to(torch.bfloat16)
+    dy = torch.randn(B, H, H, Cout, generator=g).to(dev()).to(torch.bfloat16)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g).to(dev())
+    wf, wd = kernels.pack_weights(w, scale)
+    y = kernels.conv2d_fprop(x, wf, 3, 3, 1, upsample=ups)
+    dx = kernels.conv2d_dgrad(dy, wd, 3, 1, sum_pool2=ups)
+    dw = kernels.conv2d_wgrad(x, dy, 3, scale, upsample=ups)
+    assert tuple(dx.shape) == tuple(x.shape)
+    a = float((y.double() * dy.double()).sum())
+    b = float((x.double() * dx.double()).sum())
+    # wgrad returns scale * sum dy (x) x for the MASTER weight; the packed weights are bf16(scale * W)
+    wq = wf.float().permute(1, 2, 0).reshape(Cout, Cin, 3, 3)            # [tap][co][ci] -> (co, ci, kh, kw), = bf16(scale W)
+    c = float((wq.double() * dw.double()).sum()) / scale
+    ref = max(abs(a), abs(b), abs(c))
+    norm = float(y.float().norm() * dy.float().norm())                    # Cauchy-Schwarz scale of the form
+    assert abs(a - b) < 2e-4 * norm and abs(a - c) < 2e-4 * norm, (a, b, c, norm)
+    assert ref > 0
+    # linearity in x (bf16 outputs: one ulp of the larger side)
+    x2 = torch.randn(B, hs, hs, Cin, generator=g).to(dev()).to(torch.bfloat16)
+    y2 = kernels.conv2d_fprop(x2, wf, 3, 3, 1, upsample=ups)
+    ysum = kernels.conv2d_fprop((x.float() + x2.float()).to(torch.bfloat16), wf, 3, 3, 1, upsample=ups)
+    err = (ysum.float() - (y.float() + y2.float())).abs().max()
+    assert float(err) < 2 ** -5 * float(ysum.float().abs().max())       # x1 + x2 is itself rounded to bf16
+
+
 def test_gan_logit_heads_match_the_loss_functions():
     """loss_functions.py:15-28 on the logits, values and derivatives, incl. logits far in both tails."""
     from rgbd_gan_amd import kernels
