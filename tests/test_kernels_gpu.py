@@ -465,6 +465,32 @@ def test_patch_kernel_agrees_with_gather_kernel(B, H, Cin, Cout, ups):
     torch.testing.assert_close(y_patch.float(), y_gather.float(), atol=2e-2, rtol=8e-3)
 
 
+def test_elementwise_adjoint_identities_at_benchmark_sizes():
+    """B = 32, 128x128 (the benchmark's tensors): pairs of kernels that are each other's adjoint, and the bilinear form
+    of the 1x1 plane convs evaluated three ways, agree to the bf16 rounding of their stored outputs:
+        <pool2_masked(x; y), dp> = <x, unpool2_lrelu_bwd(dp; y)>
+        <from_planes(p; w), t> = <p, to_planes(t; w^T)> = <w, planes_outer(t, p)^T>."""
+    from rgbd_gan_amd import kernels
+    g = torch.Generator().manual_seed(43)
+    B, H, C = 32, 128, 64
+    x = torch.randn(B, H, H, C, generator=g).to(dev()).to(torch.bfloat16)
+    y = torch.randn(B, H, H, C, generator=g).to(dev()).to(torch.bfloat16)
+    dp = torch.randn(B, H // 2, H // 2, C, generator=g).to(dev()).to(torch.bfloat16)
+    a = float((kernels.pool2_masked(x, y).double() * dp.double()).sum())
+    b = float((x.double() * kernels.unpool2_lrelu_bwd(dp, y, (B, H, H, C)).double()).sum())
+    norm = float(x.float().norm() * dp.float().norm())
+    assert abs(a - b) < 2e-4 * norm, (a, b, norm)
+    p = torch.randn(B, 3, H, H, generator=g).to(dev())
+    t = torch.randn(B, H, H, C, generator=g).to(dev()).to(torch.bfloat16)
+    w = torch.randn(C, 3, generator=g).to(dev())
+    f1 = float((kernels.from_planes(p, w, None, 0.7, act=False).double() * t.double()).sum())
+    f2 = float((p.double() * kernels.to_planes(t, w.t().contiguous(), None, 0.7).double()).sum())
+    o, _ = kernels.planes_outer(t, p)                                   # (3, C) = sum_{b,px} p (x) t
+    f3 = 0.7 * float((w.t().double() * o.double()).sum())
+    norm2 = float(p.norm() * t.float().norm()) * float(w.norm()) * 0.7
+    assert abs(f1 - f2) < 2e-4 * norm2 and abs(f2 - f3) < 2e-4 * norm2, (f1, f2, f3, norm2)
+
+
 def test_pool_and_unpool_lrelu_kernels():
     from rgbd_gan_amd import kernels
     g = torch.Generator().manual_seed(4)
