@@ -341,12 +341,19 @@ class Generator(_Link):
     def __call__(self, z, stage, camera_matrices, z2=None, z3=None, z4=None, theta=None):
         idx, coords, counts = self.projection.compute_proj_idcs_batch(camera_matrices)
         z = _as_device_tensor(z, self.device)
-        w = self.mapping(z)
-        voxel = self.voxel_gen(w)
-        novel_feats, depth = self.deepvoxel(idx, coords, counts, voxel)
         if z2 is None:
             z2 = self.make_hidden(z.shape[0])
-        w2 = self.mapping(_as_device_tensor(z2, self.device))
+        z2 = _as_device_tensor(z2, self.device)
+        # :297,309 map z and z2 with the same network in two calls; one batch of 2B rows here (the mapping network has
+        # no cross-row coupling: pixel norm and the linears act per row)
+        n = z.shape[0]
+        if 2 * n <= 64:
+            ww = self.mapping(torch.cat([z.reshape(n, -1), z2.reshape(n, -1)], dim=0))
+            w, w2 = ww[:n], ww[n:]
+        else:
+            w, w2 = self.mapping(z), self.mapping(z2)
+        voxel = self.voxel_gen(w)
+        novel_feats, depth = self.deepvoxel(idx, coords, counts, voxel)
         novel_img = self.style_generator(novel_feats, w2, stage)
         return torch.cat([novel_img, depth], dim=1)
 
