@@ -5,9 +5,13 @@
 
 A "step" is one RGBDUpdater.update_core(): generator step (forward, D forward with frozen weights, warp loss,
 backward, clipped Adam on mapping + synthesis) and discriminator step (fake + real forward, R1 double backward,
-backward, clipped Adam), on synthetic data already resident in HBM.  One process per GPU; for N > 1 launch with
-torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE from the environment), gradients all-reduced over RCCL.
-Rank 0 prints ONE JSON line.
+backward, clipped Adam), on synthetic data already resident in HBM.  One process per GPU, gradients all-reduced
+over RCCL.  Two ways to get N ranks (train_rgbd.py:103-121 of the reference: one MPI process per GPU):
+  * `python bench.py --gpus N` with no WORLD_SIZE in the environment: this process stays off the GPU, starts N
+    children of itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), relays rank 0's JSON line and exits non-zero
+    if any rank fails;
+  * under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` every process is a rank.
+A WORLD_SIZE that disagrees with --gpus is an error, not a silent one-rank run.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -31,9 +35,9 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); default: WORLD_SIZE or 1")
+    ap.add_argument("--steps", type=int, default=100)      # 20 warm-up + 100 timed steps
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the config's batchsize, 32)")
     ap.add_argument("--config", default=os.path.join(ROOT, "configs", "stylegan_shapenet_car.yml"))
     ap.add_argument("--iteration", type=int, default=200000, help="steady state: stage 10, rotation + occlusion on")
@@ -42,15 +46,36 @@ def parse():
     return ap.parse_args()
 
 
+def kernel_source_sha16():
+    """Identity of the kernel sources a profile was taken with (there is no .git on the GPU box)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "rgbd_gan_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(csrc, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes of this same command
-    (profiles/r01/bench_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, corrected as
-    MI355X_MICROARCH.md prescribes: 2 * FETCH_SIZE + WRITE_SIZE, KB).  None when the file or the kernel is absent."""
-    path = os.path.join(ROOT, "profiles", "r01", "bench_pmc_traffic.json")
-    if not os.path.exists(path):
-        return None
+    """HBM bytes per launch of `kernel` from the newest committed PMC passes of this same command
+    (profiles/rNN/bench_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, corrected as
+    MI355X_MICROARCH.md prescribes: 2 * FETCH_SIZE + WRITE_SIZE, KB).  Returns (bytes, provenance): bytes is None when
+    no profile holds the kernel OR the profile was taken with different kernel sources than the ones running now."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_pmc_traffic.json")))
+    if not paths:
+        return None, {"profile": None}
+    path = paths[-1]
     with open(path) as fjson:
-        ks = json.load(fjson)["kernels"]
+        prof = json.load(fjson)
+    prov = {"profile": os.path.relpath(path, ROOT), "profile_source_sha16": prof.get("source_sha16"),
+            "profile_commit": prof.get("commit"), "running_source_sha16": kernel_source_sha16()}
+    if prov["profile_source_sha16"] != prov["running_source_sha16"]:
+        prov["note"] = "kernel sources changed since the PMC passes: traffic withheld"
+        return None, prov
+    ks = prof["kernels"]
     base = kernel.split("<")[0]
     width = kernel.split("<")[1].rstrip(">") if "<" in kernel else ""
     tot = cnt = 0
@@ -58,7 +83,7 @@ def pmc_traffic(kernel):
         if name.startswith(base + "<" + width) or name == kernel:
             tot += v["hbm_bytes_per_launch"] * v["launches"]
             cnt += v["launches"]
-    return round(tot / cnt) if cnt else None
+    return (round(tot / cnt) if cnt else None), prov
 
 
 def cpu_baseline(batch=8, threads=None, budget_s=12.0, max_steps=12):
@@ -96,8 +121,62 @@ def cpu_baseline(batch=8, threads=None, budget_s=12.0, max_steps=12):
                       f"path (Chainer unavailable), {dt:.1f} s"}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` outside any launcher: start N ranks of this script (one per GPU) and relay rank 0's
+    JSON line.  This parent never imports torch and never touches a GPU (a process that has initialised HIP must not
+    fork/exec workers on this pool); the children get what torch.distributed.run would give them."""
+    import signal
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    threads = max(1, (os.cpu_count() or n) // n)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RGBD_BENCH_CHILD="1")
+        env.setdefault("OMP_NUM_THREADS", str(threads))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True,
+                                      start_new_session=True))
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = (r, p.returncode)
+        time.sleep(0.2)
+    for r, p in enumerate(procs):
+        if failed is None and p.returncode != 0:
+            failed = (r, p.returncode)
+    if failed is not None:
+        for p in procs:                        # the exact process groups started above, nothing matched by pattern
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGTERM)
+                except ProcessLookupError:
+                    pass
+        print(f"bench.py: rank {failed[0]} of {n} exited with code {failed[1]}", file=sys.stderr, flush=True)
+        sys.exit(1)
+    out = procs[0].stdout.read()
+    rows = [ln for ln in out.splitlines() if ln.startswith('{"metric"')]
+    if len(rows) != 1 or json.loads(rows[0]).get("n_gpus") != n:
+        print(f"bench.py: expected one JSON line with n_gpus={n} from rank 0, got: {out[-2000:]!r}", file=sys.stderr)
+        sys.exit(1)
+    print(rows[0], flush=True)
+
+
 def main():
     args = parse()
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and (args.gpus or 1) > 1:
+        return launch_ranks(args.gpus)
+    if world_env is not None and args.gpus is not None and int(world_env) != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env}: refusing to report a mislabelled run",
+              file=sys.stderr, flush=True)
+        sys.exit(2)
     # stdout carries exactly ONE line (the JSON): everything else that writes to file descriptor 1 -- RCCL prints its
     # version banner there when a process group is created -- is sent to stderr
     sys.stdout.flush()
@@ -110,13 +189,18 @@ def main():
     from rgbd_gan_amd.training import DeviceImageIterator, build_training
     from rgbd_gan_amd.utils import yaml_utils
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
-    comm = Communicator()
-    local = comm.intra_rank if comm.size > 1 else 0
+    world = int(world_env or "1")
+    args.gpus = world
+    local = 0 if (world == 1 or os.environ.get("RGBD_SHARE_DEVICE")) else int(os.environ.get("LOCAL_RANK", "0"))
+    if local >= torch.cuda.device_count():
+        print(f"bench.py: rank needs cuda:{local} but only {torch.cuda.device_count()} device(s) are visible",
+              file=sys.stderr, flush=True)
+        sys.exit(3)
     torch.cuda.set_device(local)
+    comm = Communicator()
     device = torch.device("cuda", local)
+    if comm.size != world:
+        raise RuntimeError(f"process group reports {comm.size} ranks, WORLD_SIZE={world}")
 
     config = yaml_utils.load(args.config)
     B = args.batch or config.batchsize
@@ -172,12 +256,15 @@ def main():
                      "avg_us": round(t / n * 1e6, 1), "gbps": round(b / t / 1e9, 1)} for k, (n, t, f, b) in summ.items()}
         dom = max(summ, key=lambda k: summ[k][1])
         n, t, f, b = summ[dom]
-        traffic = pmc_traffic(dom)
+        traffic, provenance = pmc_traffic(dom)
         line["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(f / t / 1e12, 2),
                             "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(f / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-                            "traffic": traffic, "launches": n, "avg_launch_us": round(t / n * 1e6, 2),
-                            "flops_per_launch_avg": f / n}
+                            "traffic": traffic, "traffic_provenance": provenance, "launches": n,
+                            "avg_launch_us": round(t / n * 1e6, 2), "flops_per_launch_avg": f / n,
+                            "timing": "HIP events on the launch stream around every launch of this kernel in 2 extra "
+                                      "eager single-stream steps after the timed region"}
         line["kernels"] = table
+        line["kernels_note"] = "per-kernel totals over the 2 extra eager steps of the roofline leg, not per step"
     elif comm.size > 1 and not args.no_roofline:
         for _ in range(2):                      # keep ranks in lock-step with rank 0's extra steps
             upd.update()

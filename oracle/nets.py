@@ -7,6 +7,7 @@ paths (what its .npz snapshots contain), e.g. ``mapping/l/0/c/W``,
 ``gen/blocks/3/c0/c/W``, ``blocks/5/c_sc/c/W``.  All tensors are NCHW float32,
 weights OIHW, exactly as in the reference (net.py, common/networks/component/*).
 """
+import contextlib
 import math
 
 import numpy as np
@@ -14,6 +15,72 @@ import torch
 import torch.nn.functional as F
 
 SQRT2 = float(np.sqrt(2))
+
+# ---------------------------------------------------------------- bf16 storage emulation (optional)
+# The reference computes in fp32 throughout, and so does this restatement by default.  The HIP engine under test keeps
+# activations, activation gradients and packed conv weights in bf16 (fp32 accumulation).  Inside `bf16_emulation()` the
+# restatement rounds at exactly those storage points -- and nowhere else -- so that engine-vs-oracle comparisons are
+# not dominated by leaky-ReLU mask flips of bf16 pre-activations: the remaining difference is summation order.
+# Rounding points (rgbd_gan_amd/net.py, csrc/conv.hip epilogues): output of every 3x3 conv epilogue (after bias, residual
+# and activation), output of AdaIN, the pooled copy of a residual block's output, output of fromRGB, the generator's
+# constant input after bias + activation, the discriminator's fade-in blend; weights as bf16(inv_c * W); gradients at the
+# same tensors plus the activation gradient dz.  fp32 (never rounded): mapping MLP, style affines, toRGB planes, depth
+# head, the discriminator's dense tail, losses, optimizer.
+_EMULATE_BF16 = False
+
+
+@contextlib.contextmanager
+def bf16_emulation(on=True):
+    global _EMULATE_BF16
+    old = _EMULATE_BF16
+    _EMULATE_BF16 = bool(on)
+    try:
+        yield
+    finally:
+        _EMULATE_BF16 = old
+
+
+def _round(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+class _RoundBoth(torch.autograd.Function):
+    """Value stored in bf16, and so is the gradient that arrives for it (differentiable again: R1 double backward)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _round(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _RoundBoth.apply(g)
+
+
+class _RoundGrad(torch.autograd.Function):
+    """Identity whose gradient is stored in bf16 (the activation gradient dz of the engine)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _RoundBoth.apply(g)
+
+
+def rb(x):
+    """stored bf16 tensor: value and incoming gradient rounded."""
+    return _RoundBoth.apply(x) if _EMULATE_BF16 else x
+
+
+def rf(x):
+    """value rounded, gradient passed through (the next rounding of the gradient happens further down a fused pass)."""
+    return x + (_round(x) - x).detach() if _EMULATE_BF16 else x
+
+
+def rg(x):
+    """gradient rounded, value untouched."""
+    return _RoundGrad.apply(x) if _EMULATE_BF16 else x
 
 
 def lrelu(x):
@@ -30,6 +97,8 @@ def eq_conv(x, p, name, pad, gain=SQRT2):
     """pggan.py:13-24 (EqualizedConv2d.forward): c(inv_c * x), cross-correlation."""
     W = p[name + "/c/W"]
     b = p.get(name + "/c/b")
+    if _EMULATE_BF16 and W.shape[2] == 3:          # the engine's 3x3 convs read bf16(inv_c * W); its 1x1 planes convs fp32
+        return F.conv2d(x, rf(inv_c(W.shape[1] * W.shape[2] ** 2, gain) * W), b, padding=pad)
     return F.conv2d(inv_c(W.shape[1] * W.shape[2] ** 2, gain) * x, W, b, padding=pad)
 
 
@@ -213,13 +282,16 @@ def synthesis_block(p, i, w, x):
     if i == 0:
         W = p[pre + "/W"]
         h = W.unsqueeze(0).expand(w.shape[0], *W.shape)
+        h = rb(lrelu(h + p[pre + "/b0/b"].reshape(1, -1, 1, 1)))
     else:
+        # engine: conv epilogue stores bf16(lrelu(acc + b)); the fused AdaIN backward rounds the gradient once, AFTER
+        # the activation mask (rg), not between the two (rf)
         h = eq_conv(up2(x), p, pre + "/c0", 1)
-    h = lrelu(h + p[pre + "/b0/b"].reshape(1, -1, 1, 1))
-    h = style_block(p, pre + "/s0", w, h)
+        h = rf(lrelu(rg(h + p[pre + "/b0/b"].reshape(1, -1, 1, 1))))
+    h = rb(style_block(p, pre + "/s0", w, h))
     h = eq_conv(h, p, pre + "/c1", 1)
-    h = lrelu(h + p[pre + "/b1/b"].reshape(1, -1, 1, 1))
-    h = style_block(p, pre + "/s1", w, h)
+    h = rf(lrelu(rg(h + p[pre + "/b1/b"].reshape(1, -1, 1, 1))))
+    h = rb(style_block(p, pre + "/s1", w, h))
     return h
 
 
@@ -323,14 +395,14 @@ def dis_block(p, i, x, res=True):
     """net.py:408-426 (DiscriminatorBlock.forward) / :372-377 (base block i == 0)."""
     pre = f"blocks/{i}"
     if i == 0:
-        h = lrelu(eq_conv(x, p, pre + "/c0", 1))
-        h = lrelu(eq_conv(h, p, pre + "/c1", 0))
+        h = rb(lrelu(rg(eq_conv(x, p, pre + "/c0", 1))))
+        h = lrelu(eq_conv(h, p, pre + "/c1", 0))          # dense tail: fp32 in the engine too
         return eq_linear(h, p, pre + "/l2", gain=1.0)
-    h = lrelu(eq_conv(x, p, pre + "/c0", 1))
+    h = rb(lrelu(rg(eq_conv(x, p, pre + "/c0", 1))))
     h = eq_conv(h, p, pre + "/c1", 1)
     if res:
-        h = h + eq_conv(x, p, pre + "/c_sc", 1)
-    return down2(lrelu(h))
+        h = h + rb(eq_conv(x, p, pre + "/c_sc", 1))      # the shortcut is stored (bf16) and re-read as the residual
+    return rb(down2(rb(lrelu(rg(h)))))
 
 
 def discriminator(p, x, stage, return_hidden=False, res=True):
@@ -339,16 +411,16 @@ def discriminator(p, x, stage, return_hidden=False, res=True):
     feat = None
     if st % 2 == 0:
         k = (st - 2) // 2
-        h = lrelu(eq_conv(x, p, f"ins/{k + 1}", 0))
+        h = rb(lrelu(rg(eq_conv(x, p, f"ins/{k + 1}", 0))))
         for i in reversed(range(0, k + 2)):
             if i == 3:
                 feat = h
             h = dis_block(p, i, h, res)
     else:
         k = (st - 1) // 2
-        h0 = lrelu(eq_conv(down2(x), p, f"ins/{k}", 0))
-        h1 = dis_block(p, k + 1, lrelu(eq_conv(x, p, f"ins/{k + 1}", 0)), res)
-        h = (1.0 - alpha) * h0 + alpha * h1
+        h0 = rb(lrelu(rg(eq_conv(down2(x), p, f"ins/{k}", 0))))
+        h1 = dis_block(p, k + 1, rb(lrelu(rg(eq_conv(x, p, f"ins/{k + 1}", 0)))), res)
+        h = rb((1.0 - alpha) * h0 + alpha * h1)
         for i in reversed(range(0, k + 1)):
             if i == 3:
                 feat = h

@@ -83,15 +83,22 @@ class DeviceImageIterator:
     def __init__(self, images_u8, batch_size, device, shuffle=True, seed=None):
         self.data = torch.as_tensor(images_u8).to(device)
         self.batch_size, self.shuffle = batch_size, shuffle
+        # chainer's SerialIterator shuffles with the process's own entropy-seeded NumPy RNG, so the ranks of a
+        # data-parallel job draw DIFFERENT real batches (train_rgbd.py:306-310: no scatter_dataset).  A fresh
+        # torch.Generator has a fixed default seed: without one given, seed from the OS so ranks and runs differ.
+        self.seed = int(seed) if seed is not None else int.from_bytes(os.urandom(8), "little") >> 1
         self.gen = torch.Generator(device="cpu")
-        if seed is not None:
-            self.gen.manual_seed(seed)
+        self.gen.manual_seed(self.seed)
         self.epoch, self._pos = 0, 0
         self._order = self._new_order()
 
     def _new_order(self):
+        """One permutation per epoch, drawn on the host and uploaded ONCE: slicing a batch's indices out of it is then
+        a device view, and next() enqueues no host-to-device copy (a pageable upload per step made the launch thread
+        wait for the stream to drain every iteration)."""
         n = self.data.shape[0]
-        return torch.randperm(n, generator=self.gen) if self.shuffle else torch.arange(n)
+        order = torch.randperm(n, generator=self.gen) if self.shuffle else torch.arange(n)
+        return order.to(self.data.device)
 
     def next(self):
         n = self.data.shape[0]
@@ -104,8 +111,7 @@ class DeviceImageIterator:
             if rest > 0:
                 idx = torch.cat([idx, self._order[:rest]])
             self._pos = rest
-        batch = self.data[idx.to(self.data.device)]
-        return batch.to(torch.float32) / 127.5 - 1
+        return self.data[idx].to(torch.float32) / 127.5 - 1
 
     __next__ = next
 

@@ -34,7 +34,10 @@ def main(fetch_dir, write_dir, out, command):
         fk, wk = f[name][0] / max(f[name][1], 1), w[name][0] / max(w[name][1], 1)
         kernels[name] = {"fetch_kb_raw": round(fk, 1), "write_kb": round(wk, 1),
                          "hbm_bytes_per_launch": int((2 * fk + wk) * 1024), "launches": n}
-    json.dump({"command": command,
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_source_sha16
+    json.dump({"command": command, "source_sha16": kernel_source_sha16(), "commit": os.environ.get("RGBD_COMMIT"),
                "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE counts 128-B requests "
                              "as 64 B; unit KB)",
                "kernels": kernels}, open(out, "w"), indent=1)

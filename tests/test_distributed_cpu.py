@@ -85,3 +85,67 @@ def test_two_rank_allreduce_and_first_update_broadcast():
     _cpu_adam(p, gmean, m, v, [0, 16, n], [1e-2, 1e-4], 0.0, 0.999, 1e-8, 5.0, 1.0, stp, None)
     np.testing.assert_allclose(end0, p.numpy(), rtol=1e-6, atol=1e-7)
     assert abs(n0 - float(torch.sqrt((gmean.double() ** 2).sum()))) < 1e-3
+
+
+def _iter_worker(rank, q):
+    from rgbd_gan_amd.training import DeviceImageIterator
+    images = np.arange(64, dtype="uint8").reshape(64, 1, 1, 1).repeat(3, axis=1)       # pixel value = sample index
+    it = DeviceImageIterator(images, 8, "cpu")                                          # no seed given, as train_rgbd.py
+    first = ((it.next()[:, 0, 0, 0] + 1) * 127.5).round().to(torch.int64).tolist()
+    q.put((rank, first, it.seed))
+
+
+def test_ranks_draw_different_real_batches():
+    """train_rgbd.py:306-310 of the reference: no scatter_dataset, every process shuffles the whole data set with its
+    own RNG -- so the ranks of a data-parallel job must not see the same real batch (a fresh torch.Generator has a
+    fixed default seed; DeviceImageIterator seeds from the OS when no seed is given)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_iter_worker, args=(r, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, b0, s0), (_, b1, s1) = res
+    assert s0 != s1 and b0 != b1
+    assert len(set(b0)) == 8 and all(0 <= i < 64 for i in b0)
+    # explicit seeds: reproducible, and one epoch is a permutation
+    from rgbd_gan_amd.training import DeviceImageIterator
+    images = np.arange(64, dtype="uint8").reshape(64, 1, 1, 1).repeat(3, axis=1)
+    a, b = DeviceImageIterator(images, 8, "cpu", seed=5), DeviceImageIterator(images, 8, "cpu", seed=5)
+    seen = []
+    for _ in range(8):
+        xa, xb = a.next(), b.next()
+        assert torch.equal(xa, xb)
+        seen += ((xa[:, 0, 0, 0] + 1) * 127.5).round().to(torch.int64).tolist()
+    assert sorted(seen) == list(range(64)) and a.epoch == 1
+
+
+def test_bench_refuses_a_mislabelled_world():
+    """`--gpus 8` under WORLD_SIZE=1 must not print an n_gpus=1 line (it exits before touching torch or a GPU)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr and '"metric"' not in r.stdout
+
+
+def test_bench_parent_fails_when_a_rank_fails():
+    """`python bench.py --gpus 2` starts two ranks of itself; here (no GPU) each rank exits non-zero, and so must the
+    parent, without printing a JSON line."""
+    import subprocess
+    import sys
+    import torch as _t
+    if _t.cuda.is_available():
+        import pytest
+        pytest.skip("CPU-only property")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0 and '"metric"' not in r.stdout
+    assert "exited with code" in r.stderr

@@ -114,6 +114,76 @@ CFG = dict(lambda_gp=1.0, lambda_depth=10, depth_min=1.0, lambda_geometric=None,
            start_rotation=2000, start_occlusion_aware=2000)
 
 
+def _step_pair(stage, emulate, B=4, seed=2, in_seed=7):
+    """One update_core on the engine and on the oracle (optionally rounding where the engine stores bf16) from identical
+    weights and inputs -> (engine objects, oracle objects)."""
+    from rgbd_gan_amd.optimizer import FlatAdam
+    from rgbd_gan_amd.updater import CameraParamPrior, RGBDUpdater
+    from rgbd_gan_amd.utils.yaml_utils import Config
+    gp, dp, gen, dis = _models(seed=seed)
+    z, thetas, x_real = _inputs(B, seed=in_seed)
+    torch.manual_seed(0)
+    for i in range(6):
+        gp[f"gen/outs/{i}/c/W"][-1] = torch.randn(gp[f"gen/outs/{i}/c/W"][-1].shape) * 0.1
+    gen.load_state_dict(gp)
+    iteration = 200000
+    gpl = {k: v.clone().requires_grad_(True) for k, v in gp.items()}
+    dpl = {k: v.clone().requires_grad_(True) for k, v in dp.items()}
+    omap = {k: v for k, v in gpl.items() if k.startswith("mapping/")}
+    ogen = {k: v for k, v in gpl.items() if k.startswith("gen/")}
+    low = {k: 1e-5 for k in ("gen/l1/c/W", "gen/l1/c/b", "gen/l2/c/W", "gen/l2/c/b")}
+    oopt = {"map": step.ChainerAdam(omap, 1e-5), "gen": step.ChainerAdam(ogen, 1e-3, alpha_override=low),
+            "dis": step.ChainerAdam(dpl, 3e-3)}
+    with nets.bf16_emulation(emulate):
+        ref = step.rgbd_step(gpl, dpl, oopt, x_real, z, thetas, stage, CFG, iteration)
+    cfg = Config(dict(generator_architecture="stylegan", stage_interval="0,0,0,0,0,0,0,100000,150000,160000,180000,300000",
+                      max_stage=11, start_rotation=2000, start_occlusion_aware=2000, lambda_depth=10, depth_min=1.0,
+                      x_rotate=0.3054, y_rotate=1.0472, z_rotate=0, x_translate=0, y_translate=0, z_translate=0,
+                      bigan=False))
+    opt = {"map": FlatAdam(gen.mapping.store, 1e-5), "gen": FlatAdam(gen.gen.store, 1e-3),
+           "dis": FlatAdam(dis.store, 3e-3)}
+    for n in ("l1/c/W", "l1/c/b", "l2/c/W", "l2/c/b"):
+        opt["gen"].set_alpha(n, 1e-5)
+    upd = RGBDUpdater(models=[gen, dis], config=cfg, optimizer=opt, iterator=None, lambda_gp=1.0, smoothing=0.999,
+                      total_gpu=1, prior=CameraParamPrior(cfg), fixed_stage=stage)
+    upd.iteration = iteration
+    upd.update_core(batch=torch.from_numpy(x_real), z_fake_data=torch.from_numpy(z), thetas=thetas)
+    return (gen, dis, opt, upd), (gpl, dpl, ref)
+
+
+@pytest.mark.parametrize("stage", [10.0, 9.5])
+def test_full_training_step_matches_bf16_emulating_oracle(stage):
+    """The tight form of the step test: the oracle rounds to bf16 exactly where the engine stores bf16
+    (oracle/nets.py:bf16_emulation), so leaky-ReLU mask flips no longer separate the two and EVERY parameter gradient
+    of the step can be held to a tight tolerance -- a wrong sign or a dropped contribution in any single bias, style
+    affine or conv weight fails.  What remains is fp32 summation order and where exactly a fused backward pass rounds."""
+    (gen, dis, opt, upd), (gpl, dpl, ref) = _step_pair(stage, emulate=True)
+    obs = {k: float(v) for k, v in upd.observation.items()}
+    for key in ("gen/loss_adv", "gen/loss_rotate", "dis/loss_gp", "dis/loss_adv"):
+        assert abs(obs[key] - ref[key]) < 2e-3 * max(1.0, abs(ref[key])), (key, obs[key], ref[key])
+    rows = []
+    for store, prefix, src in ((gen.mapping.store, "mapping/", gpl), (gen.gen.store, "gen/", gpl), (dis.store, "", dpl)):
+        for n in store.names:
+            b = src[prefix + n].grad
+            a = store[n].grad.cpu()
+            if b is None or float(b.norm()) == 0.0:
+                assert float(a.norm()) == 0.0, (prefix + n, "engine produced a gradient the reference does not")
+                continue
+            rows.append((prefix + n, cosine(a, b), float(a.norm() / b.norm()), b.numel()))
+    assert len(rows) > 120                                        # every live parameter tensor of the three optimizers
+    if os.environ.get("RGBD_TEST_VERBOSE"):
+        for r in sorted(rows, key=lambda r: r[1])[:25]:
+            print(r)
+    worst = min(rows, key=lambda r: r[1])
+    assert worst[1] > 0.995, worst
+    big = [r for r in rows if r[3] >= 4096]
+    assert min(r[1] for r in big) > 0.999, min(big, key=lambda r: r[1])
+    off = max(rows, key=lambda r: abs(r[2] - 1))
+    assert abs(off[2] - 1) < 2e-2, off
+    for k, o in (("norm_map", opt["map"]), ("norm_gen", opt["gen"]), ("norm_dis", opt["dis"])):
+        assert abs(float(o.grad_norm) - ref[k]) < 1e-2 * ref[k], (k, float(o.grad_norm), ref[k])
+
+
 @pytest.mark.parametrize("stage", [10.0, 9.5])
 def test_full_training_step_matches_oracle(stage):
     """One update_core (G step + D step + R1 + 3D loss + clipped Adam) at stage 10 (and in the 64 -> 128 fade-in),

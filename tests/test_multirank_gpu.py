@@ -1,0 +1,147 @@
+"""Arrangements of the SAME training step must agree tensor by tensor (tests/dp_worker.py runs them on fixed inputs):
+
+  * the shipped arrangement -- 7 replayed HIP graphs, generator phase || discriminator phase on two streams, D's
+    fake-batch weight gradients deferred to the side stream and merged from a second gradient buffer -- against the
+    eager single-stream step;
+  * a 2-rank data-parallel job (two processes sharing cuda:0, gloo collectives, the real HIP Adam kernel, graphs)
+    on half-batches against 1 rank on the whole batch: ChainerMN's multi-node optimizer (train_rgbd.py:103-121,154-156)
+    = first update broadcasts, then all-reduce-mean of the flat gradient buffers before the local clipped Adam;
+  * `python bench.py --gpus 2` starts its own two ranks and reports n_gpus = 2.
+
+One step from identical weights is not chaotic: what differs between arrangements is fp32 summation order (atomics,
+slab reductions, per-rank partial sums), so flat gradient buffers agree to ~1e-4 relative L2.  With beta1 = 0 the Adam
+update is alpha * sign(g) wherever |g| >> eps: a rounding-level change flips it only on entries whose gradient is
+~0, which bounds the weight-update mismatch to a tiny fraction of entries.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "dp_worker.py")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _run(out, *flags, env=None, timeout=900):
+    return subprocess.Popen([sys.executable, WORKER, str(out)] + list(flags), env=env or dict(os.environ),
+                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+
+
+def _wait(procs, timeout=900):
+    for p in procs:
+        out, _ = p.communicate(timeout=timeout)
+        assert p.returncode == 0, out[-3000:]
+
+
+def rel(a, b):
+    a, b = a.astype("float64"), b.astype("float64")
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def cosine(a, b):
+    a, b = a.astype("float64").ravel(), b.astype("float64").ravel()
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+
+
+def _compare(a, b, what, grad_tol=1e-3):
+    for k in ("map", "gen", "dis"):
+        ga, gb = a[f"{k}/grad"], b[f"{k}/grad"]
+        assert np.isfinite(ga).all() and np.isfinite(gb).all(), (what, k)
+        assert np.linalg.norm(gb) > 0, (what, k)
+        assert cosine(ga, gb) > 0.9999, (what, k, cosine(ga, gb))
+        assert rel(ga, gb) < grad_tol, (what, k, rel(ga, gb))
+        assert abs(float(a[f"{k}/norm"]) / float(b[f"{k}/norm"]) - 1) < 1e-3, (what, k)
+        assert int(a[f"{k}/t"]) == int(b[f"{k}/t"]), (what, k)
+        assert rel(a[f"{k}/v"], b[f"{k}/v"]) < 10 * grad_tol, (what, k, rel(a[f"{k}/v"], b[f"{k}/v"]))
+        da, db = a[f"{k}/delta"], b[f"{k}/delta"]
+        assert np.abs(db).max() > 0, (what, k)
+        step = np.abs(db).max()
+        mismatch = float((np.abs(da - db) > 0.05 * step).mean())
+        assert mismatch < 2e-3, (what, k, mismatch)
+
+
+def test_graph_replay_two_streams_equals_eager_single_stream(tmp_path):
+    procs = [_run(tmp_path / "eager.npz", "--calls", "4", "--eager", "--sequential"),
+             ]
+    _wait(procs)
+    procs = [_run(tmp_path / "eager2.npz", "--calls", "4", "--eager")]          # eager, two streams + deferred wgrads
+    _wait(procs)
+    procs = [_run(tmp_path / "graph.npz", "--calls", "4")]                      # the shipped arrangement
+    _wait(procs)
+    e, e2, g = (np.load(tmp_path / f) for f in ("eager.npz", "eager2.npz", "graph.npz"))
+    assert int(e["n_graphs"]) == 0 and int(e2["n_graphs"]) == 0 and int(g["n_graphs"]) == 7
+    _compare(e2, e, "eager two-stream vs eager sequential")
+    _compare(g, e, "graph replay vs eager sequential")
+    for key in ("obs/gen/loss_adv", "obs/gen/loss_rotate", "obs/dis/loss_adv", "obs/dis/loss_gp"):
+        assert abs(float(g[key]) - float(e[key])) < 1e-4 * max(1.0, abs(float(e[key]))), (key, float(g[key]), float(e[key]))
+
+
+def test_fade_in_stage_graph_replay_equals_eager(tmp_path):
+    _wait([_run(tmp_path / "eager.npz", "--calls", "4", "--eager", "--sequential", "--stage", "9.5", "--batch", "4")])
+    _wait([_run(tmp_path / "graph.npz", "--calls", "4", "--stage", "9.5", "--batch", "4")])
+    e, g = np.load(tmp_path / "eager.npz"), np.load(tmp_path / "graph.npz")
+    assert int(g["n_graphs"]) == 7
+    _compare(g, e, "fade-in graph replay vs eager")
+
+
+def test_two_ranks_on_half_batches_equal_one_rank_on_the_whole_batch(tmp_path):
+    _wait([_run(tmp_path / "one.npz", "--calls", "4")])
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), RGBD_DIST_BACKEND="gloo", RGBD_SHARE_DEVICE="1")
+        procs.append(_run(tmp_path / f"rank{r}.npz", "--calls", "4", env=env))
+    _wait(procs)
+    one, r0, r1 = (np.load(tmp_path / f) for f in ("one.npz", "rank0.npz", "rank1.npz"))
+    assert int(r0["world"]) == 2 and int(r1["rank"]) == 1
+    assert int(r0["n_graphs"]) > 0                     # the data-parallel ranks replayed graphs too
+    for k in ("map", "gen", "dis"):                    # after the all-reduce every rank holds the same buffers
+        np.testing.assert_array_equal(r0[f"{k}/grad"], r1[f"{k}/grad"])
+        np.testing.assert_array_equal(r0[f"{k}/delta"], r1[f"{k}/delta"])
+    _compare(r0, one, "2 ranks vs 1 rank")
+
+
+def test_seed_ratio_chain_at_the_logit_clamp(tmp_path):
+    """D(x_fake) ~ -40: the discriminator's seed sigmoid(y)/B is ~4e-18/B and the generator's gradient is recovered
+    from that backward pass through the per-sample ratio (updater.py: gan_logit_heads).  The bf16 chain must not flush:
+    generator gradients match a run that back-propagates the generator's own seed (RGBD_NO_SHARE)."""
+    _wait([_run(tmp_path / "shared.npz", "--calls", "1", "--eager", "--sequential", "--batch", "4", "--logit-shift",
+                "-40")])
+    env = dict(os.environ, RGBD_NO_SHARE="1")
+    _wait([_run(tmp_path / "direct.npz", "--calls", "1", "--eager", "--sequential", "--batch", "4", "--logit-shift",
+                "-40", env=env)])
+    a, b = np.load(tmp_path / "shared.npz"), np.load(tmp_path / "direct.npz")
+    assert float(a["obs/gen/loss_adv"]) > 20          # softplus(40): the logits really are at the clamp's side
+    for k in ("map", "gen"):
+        assert np.linalg.norm(b[f"{k}/grad"]) > 0
+        assert cosine(a[f"{k}/grad"], b[f"{k}/grad"]) > 0.999, (k, cosine(a[f"{k}/grad"], b[f"{k}/grad"]))
+        assert abs(np.linalg.norm(a[f"{k}/grad"]) / np.linalg.norm(b[f"{k}/grad"]) - 1) < 2e-2, k
+
+
+def test_bench_starts_its_own_ranks():
+    env = dict(os.environ, RGBD_DIST_BACKEND="gloo", RGBD_SHARE_DEVICE="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "4",
+                        "--batch", "4", "--no-cpu-baseline", "--no-roofline"], capture_output=True, text=True,
+                       timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rows = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(rows) == 1, r.stdout[-2000:]
+    line = json.loads(rows[0])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 8 and line["config"]["parallelism"] == "dp2"
+    assert line["value"] > 0

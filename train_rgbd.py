@@ -46,7 +46,9 @@ def main():
     is_master = comm is None or comm.rank == 0
 
     images = make_dataset(config.dataset_path, config.image_path)       # uint8 (N,3,128,128), images.npy cache
-    iterator = DeviceImageIterator(images, config.batchsize, device)
+    # every rank shuffles the whole data set with its own seed (the reference: no scatter_dataset, per-process RNG)
+    iterator = DeviceImageIterator(images, config.batchsize, device,
+                                   seed=None if config.seed is None else int(config.seed) + (comm.rank if comm else 0))
     if config.nvprof or config.enable_cuda_profiling:
         config.iteration = 10
     generator, discriminator, optimizer, updater = build_training(
@@ -63,6 +65,7 @@ def main():
         os.makedirs(out, exist_ok=True)
     # resume (train_rgbd.py:405-459): explicit iteration or the newest complete set in auto_resume_dir
     resume = config.get_model_from_interation or ""
+    explicit = bool(resume)            # an explicit iteration is always read from config.out (train_rgbd.py:406-415)
     if not resume and config.auto_resume:
         d = config.auto_resume_dir or out
         cands = []
@@ -74,7 +77,7 @@ def main():
                     cands.append(int(it))
         resume = str(max(cands)) if cands else ""
     if resume:
-        d = (config.auto_resume_dir or out) if config.auto_resume else out
+        d = out if explicit else (config.auto_resume_dir or out)
         print(f"Resume from {resume}")
         for name, m in models:
             m.load_state_dict(dict(np.load(f"{d}/{name}_{resume}.npz")), strict=False)
