@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RGBD_ABI_VERSION 3
+#define RGBD_ABI_VERSION 4
 
 int rgbd_abi_version(void);
 const char* rgbd_last_error(void);
@@ -39,11 +39,13 @@ const char* rgbd_last_error(void);
  * coef         : (b, 24) fp32 = A(9, row-major) c(3) A'(9) c'(3) computed on the HOST in NumPy exactly as
  *                loss_functions.py:174,181 associate them (zp' = A (z p) - c ; zp'_rot = A' (z_rot p) + c').
  * flags        : bit0 occlusion_aware, bit1 use max_depth, bit2 use min_depth.
- * partials     : workspace, >= 4 * ceil(b*S*S/256) floats.
+ * partials     : workspace, >= 6 * ceil(b*S*S/256) floats.
  * loss         : 1 float.
  * dbg_*        : optional (NULL to skip). dbg_zp (2,b,S*S,3) fp32; dbg_warped (2,b*S*S,4) fp32 (before the
  *                occlusion mask, like the reference's debug=True return); dbg_idx (2,b*S*S,4) int32 =
  *                masked u0, v0, v1 and the out-of-frame mask.  Index 0 = img->img_rot direction.
+ * hinge_lambda, hinge_min: the depth-range hinge of updater.py:357-359 evaluated in the same pass:
+ *                loss += hinge_lambda * mean over ALL 2b images' pixels of relu(hinge_min - depth)^2  (0 = off).
  * Index math is evaluated unfused (no FMA contraction) left to right so the integer outputs are
  * bit-exact against oracle/warp_loss.py:forward_np.
  */
@@ -52,14 +54,19 @@ const char* rgbd_last_error(void);
 #define RGBD_WARP_MIN_DEPTH 4
 int rgbd_warp_loss_fwd(const float* img, const float* img_rot, const float* coef, int b, int S,
                        int flags, float lambda_geometric, float max_depth, float min_depth,
+                       float hinge_lambda, float hinge_min,
                        float* partials, float* loss,
                        float* dbg_zp, float* dbg_warped, int32_t* dbg_idx, void* stream);
 
-/* Backward of the above.  grad_loss: 1 float on the device (d objective / d loss).
- * grad_img, grad_img_rot: (b,4,S,S) fp32, overwritten (zeroed inside, then accumulated with atomics). */
+/* Backward of the above.  grad_loss: 1 float on the device (d objective / d loss), multiplied by grad_scale (host).
+ * grad_img, grad_img_rot: (b,4,S,S) fp32; accumulate == 0: zeroed inside, then accumulated with atomics;
+ * accumulate != 0: the gradients are ADDED to what the buffers hold (the caller has put the other terms of the image
+ * gradient there, rgbd_image_grad_init).  grad_loss may be NULL (= 1). */
 int rgbd_warp_loss_bwd(const float* img, const float* img_rot, const float* coef, int b, int S,
                        int flags, float lambda_geometric, float max_depth, float min_depth,
-                       const float* grad_loss, float* grad_img, float* grad_img_rot, void* stream);
+                       float hinge_lambda, float hinge_min,
+                       const float* grad_loss, float grad_scale, float* grad_img, float* grad_img_rot, int accumulate,
+                       void* stream);
 
 /* ------------------------------------------------------------------ equalized-LR convolution engine
  * Replaces pggan.py:13-24 (EqualizedConv2d -> L.Convolution2D = cuDNN fprop/dgrad/wgrad) for the
@@ -148,14 +155,16 @@ int rgbd_wgrad_reduce_multi(const rgbd_wgrad_reduce_desc* descs, int n, void* st
  *   x (B,HW,C) bf16 NHWC; scale, shift: B rows of C fp32 values, rows `ld` floats apart (ld = C for plain (B,C)
  *   arrays; ld = 2C with shift = scale + C when one fused linear produced [scale | shift], net.py:96-101);
  *   eps 1e-5; biased variance.
- *   sums: workspace (B,C,2) fp32 that the CALLER has zeroed (per-strip partial sums are added into it; callers carve
- *   it out of one arena cleared once per step instead of paying a clear per call).  mean, rstd: (B,C) fp32 outputs
- *   (saved for backward).  Two launches: strip reduction, normalise + affine.
+ *   sums: workspace of rgbd_adain_workspace(B,HW,C) floats = (ceil(HW/1024), B, C, 2) fp32, no initialisation
+ *   needed: every 1024-pixel strip stores its partial sums with plain stores and the second launch adds the strips in
+ *   index order, so the statistics are bit-reproducible (no atomics).  mean, rstd: (B,C) fp32 outputs (saved for
+ *   backward).  Two launches: strip reduction, normalise + affine.
  */
+int64_t rgbd_adain_workspace(int B, int HW, int C);   /* floats */
 int rgbd_adain_fwd(const void* x, const float* scale, const float* shift, void* y,
                    float* sums, float* mean, float* rstd, int B, int HW, int C, int ld, float eps, void* stream);
 /* dy (B,HW,C) bf16 -> dx bf16, dscale/dshift fp32 rows `ld` apart like scale (overwritten).
- * sums: workspace (B,C,2) fp32, zeroed by the caller.
+ * sums: workspace of rgbd_adain_workspace(B,HW,C) floats, as above.
  * lrelu_slope > 0: x is the output of the leaky ReLU feeding this AdaIN (net.py:150-153: conv -> bias -> lrelu -> style)
  *   and dx additionally carries that activation's gradient, dx *= (x > 0 ? 1 : lrelu_slope); bias_grad (C) fp32 or NULL
  *   then accumulates sum_{b,p} dx (the gradient of the L.Bias in front of the activation). */
@@ -214,6 +223,45 @@ int rgbd_linear_fwd(const float* x, const float* w, const float* bias, float* y,
                     float slope, void* stream);
 int rgbd_linear_bwd(const float* dy, const float* y, const float* x, const float* w, float* dx, float* dw, float* db,
                     int M, int K, int N, float c, int act, float slope, int accumulate_dx, void* stream);
+/* y = (c * x W^T) * lrelu'(mask_y): the derivative of rgbd_linear_bwd's dx w.r.t. its dy -- what the R1 double backward
+ * (updater.py:414-422, chainer.grad(..., enable_double_backprop=True)) sends back through the discriminator's dense tail
+ * (net.py:372-377).  mask_y (M,N): the activation OUTPUT whose slope mask applies. */
+int rgbd_linear_fwd_masked(const float* x, const float* w, const float* mask_y, float* y, int M, int K, int N, float c,
+                           float slope, void* stream);
+
+/* ------------------------------------------------------------------ small fused ops of the training step (step_ops.hip)
+ * Each replaces a run of elementwise / reduction launches of the reference's Chainer graph with one launch.
+ * rgbd_real_batch_u8: SerialIterator + TransformDataset(x/127.5 - 1) (train_rgbd.py:308-310) + downsize_real
+ *   (common/utils/pggan.py:6-50) from the uint8 data set resident in HBM: data (N,C,H,W) u8, idx (B) int64 ->
+ *   out (B,C,S,S) fp32 = s x s block means (s = H/S) of data[idx]/127.5 - 1; fade != 0 (odd progressive stage):
+ *   (1-alpha) * [2s x 2s block mean, nearest-upsampled] + alpha * [s x s block mean], alpha read from alpha_device
+ *   (device float, so a captured graph follows the schedule) or, when that is NULL, the host value.
+ * rgbd_zero_multi_f32: clear up to 8 fp32 buffers (16-byte aligned) in one launch (gradient buffers at step start).
+ * rgbd_hidden_normalize: make_hidden's normalisation (net.py:333-343): out rows = z / sqrt(sum_c z^2 / ch + 1e-8) for
+ *   z (M,C); written `copies` times, copy k at rows [k*M, (k+1)*M) (updater.py:300 repeats the latents per view pair).
+ * rgbd_r1_penalty_fwd: updater.py:416-418 + loss_functions.py:7-8 on g (B,n) fp32:
+ *   loss = coef * mean_b (sqrt(sum g_b^2))^2; workspace >= 16*B floats.  Its gradient w.r.t. g is
+ *   rgbd_scale_by_scalar_f32(g, grad_loss_device, 2*coef/B): out = (scalar_device[0] * k) * x (scalar NULL = 1).
+ * rgbd_image_grad_init: out (B,KP_out,HW) fp32: channels k < KP_in = ratio[b] * gx[b,k,:] (ratio NULL = 1), others 0 --
+ *   the generator's output gradient before rgbd_warp_loss_bwd(accumulate=1) adds the 3-D consistency terms.
+ * rgbd_const_input_{fwd,bwd}: SynthesisBlock 0 (net.py:130-153): out (B,HW,C) bf16 = lrelu(w[c,p] + bias[c]) for every
+ *   sample; bwd ADDS sum_b dh * lrelu' to dw (C,HW) and its sum over p to db (C) (either may be NULL).
+ * rgbd_nhwc_to_rows_f32 / rgbd_rows_to_nhwc_bf16: (B,HW,C) bf16 <-> (B, C*HW) fp32 rows in (c,p) order, the layout the
+ *   4x4-valid conv of the discriminator's base block (net.py:363-365) consumes as a linear layer; mutually adjoint.
+ */
+int rgbd_real_batch_u8(const uint8_t* data, const int64_t* idx, float* out, int B, int C, int H, int W, int S, int fade,
+                       const float* alpha_device, float alpha, void* stream);
+int rgbd_zero_multi_f32(float* const* ptrs /* host array */, const int64_t* counts /* host array */, int n, void* stream);
+int rgbd_hidden_normalize(const float* z, float* out, int M, int C, float ch, int copies, void* stream);
+int rgbd_r1_penalty_fwd(const float* g, int B, int64_t n, float coef, float* workspace, float* loss, void* stream);
+int rgbd_scale_by_scalar_f32(const float* x, const float* scalar_device, float k, float* out, int64_t n, void* stream);
+int rgbd_image_grad_init(const float* gx, const float* ratio, float* out, int B, int KP_in, int KP_out, int HW,
+                         void* stream);
+int rgbd_const_input_fwd(const float* w, const float* bias, void* out, int B, int HW, int C, float slope, void* stream);
+int rgbd_const_input_bwd(const void* dh, const float* w, const float* bias, float* dw, float* db, int B, int HW, int C,
+                         float slope, void* stream);
+int rgbd_nhwc_to_rows_f32(const void* h, float* rows, int B, int HW, int C, void* stream);
+int rgbd_rows_to_nhwc_bf16(const float* rows, void* h, int B, int HW, int C, void* stream);
 
 /* ------------------------------------------------------------------ DeepVoxels frustum path (config 4)
  * rgbd_proj_idcs: deepvoxel/projection.py:48-105 (compute_proj_idcs) for a whole batch of cameras at once.

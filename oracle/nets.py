@@ -347,7 +347,7 @@ def style_generator(p, w, w2, stage, theta9, rgbd=True, return_feature=False):
 def stylegan_generator(p, z, stage, theta9, rgbd=True, return_feature=False):
     """net.py:345-354 (StyleGANGenerator.forward): z (B,2ch,1,1) split in two latents."""
     z = torch.as_tensor(z)
-    theta9 = torch.as_tensor(theta9)
+    theta9 = torch.as_tensor(theta9) if theta9 is not None else None
     half = z.shape[1] // 2
     w = mapping(p, z[:, :half])
     w2 = mapping(p, z[:, half:])
@@ -369,7 +369,7 @@ def dcgan_block(p, i, x):
 def dcgan_generator(p, z, stage, theta9, rgbd=True):
     """net.py:709-773 (DCGANGenerator.forward), train mode."""
     z = torch.as_tensor(z)
-    theta9 = torch.as_tensor(theta9)
+    theta9 = torch.as_tensor(theta9) if theta9 is not None else None
     st, alpha = split_stage(stage)
     h = torch.cat([z, theta9 * 10], dim=1) if rgbd else z
     ch = p["blocks/0/c0/c/W"].shape[1]

@@ -7,6 +7,7 @@ import torch
 import torch.nn.functional as F
 
 from . import camera, nets, warp_loss
+from . import camera as camera_mod
 
 
 def loss_gen_adv(y_fake):
@@ -74,7 +75,7 @@ class ChainerAdam:
 
 
 def rgbd_step(gen_params, dis_params, opt, x_real_full, z, thetas, stage, cfg, iteration,
-              architecture="stylegan"):
+              architecture="stylegan", camera=True):
     """updater.py:274-448 on explicit inputs.
 
     gen_params / dis_params: dicts of leaf tensors (requires_grad).
@@ -85,18 +86,21 @@ def rgbd_step(gen_params, dis_params, opt, x_real_full, z, thetas, stage, cfg, i
     Returns a dict of the reported scalars plus x_fake.
     """
     B = x_real_full.shape[0]
-    use_rotate = iteration > cfg["start_rotation"]
-    cams = camera.camera_matrices(thetas)
-    t9 = torch.from_numpy(camera.theta9(thetas))
+    if camera:
+        use_rotate = iteration > cfg["start_rotation"]
+        cams = camera_mod.camera_matrices(thetas)
+        t9 = torch.from_numpy(camera_mod.theta9(thetas))
+    else:       # RGBUpdater.update_core (updater.py:504-589): gen(z, stage), adversarial + R1 terms only
+        use_rotate, cams, t9 = False, None, None
     for o in opt.values():
         o.zero_grad()
     x_real = nets.downsize_real(torch.as_tensor(x_real_full), stage).detach()
     image_size = x_real.shape[2]
 
     if architecture == "stylegan":
-        x_fake = nets.stylegan_generator(gen_params, z, stage, t9)
+        x_fake = nets.stylegan_generator(gen_params, z, stage, t9, rgbd=camera)
     else:
-        x_fake = nets.dcgan_generator(gen_params, z, stage, t9)
+        x_fake = nets.dcgan_generator(gen_params, z, stage, t9, rgbd=camera)
     y_fake = nets.discriminator(dis_params, x_fake[:, :3], stage)
     loss_adv_g = loss_gen_adv(y_fake)
     loss_gen = loss_adv_g

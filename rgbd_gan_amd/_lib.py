@@ -10,7 +10,7 @@ from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p, POINTER
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RGBD_LIB_PATH: A/B timing of another build of the same ABI (scripts/patch_probe.py); the default is the in-tree library
 LIB_PATH = os.environ.get("RGBD_LIB_PATH") or os.path.join(_HERE, "librgbdgan_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _P = c_void_p
 
@@ -18,8 +18,10 @@ _P = c_void_p
 PROTOTYPES = {
     "rgbd_abi_version": ([], c_int),
     "rgbd_last_error": ([], c_char_p),
-    "rgbd_warp_loss_fwd": ([_P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P, _P, _P], c_int),
-    "rgbd_warp_loss_bwd": ([_P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P, _P], c_int),
+    "rgbd_warp_loss_fwd": ([_P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, _P, _P, _P, _P,
+                            _P, _P], c_int),
+    "rgbd_warp_loss_bwd": ([_P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, _P, c_float, _P,
+                            _P, c_int, _P], c_int),
     "rgbd_pack_weights": ([_P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P], c_int),
     "rgbd_pack_weights_multi": ([_P, c_int, c_int, _P], c_int),
     "rgbd_conv2d_fprop_workspace": ([c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int], c_int64),
@@ -30,6 +32,7 @@ PROTOTYPES = {
     "rgbd_conv2d_wgrad_bf16": ([_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P], c_int),
     "rgbd_conv2d_wgrad_partial_bf16": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P], c_int),
     "rgbd_wgrad_reduce_multi": ([_P, c_int, _P], c_int),
+    "rgbd_adain_workspace": ([c_int, c_int, c_int], c_int64),
     "rgbd_adain_fwd": ([_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P], c_int),
     "rgbd_adain_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P], c_int),
     "rgbd_lrelu_bwd": ([_P, _P, _P, c_int64, c_int, c_int, c_float, _P, _P, c_int64, _P], c_int),
@@ -41,6 +44,17 @@ PROTOTYPES = {
     "rgbd_to_planes": ([_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P], c_int),
     "rgbd_planes_outer": ([_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P], c_int),
     "rgbd_linear_fwd": ([_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_float, _P], c_int),
+    "rgbd_linear_fwd_masked": ([_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P], c_int),
+    "rgbd_real_batch_u8": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_float, _P], c_int),
+    "rgbd_zero_multi_f32": ([POINTER(c_void_p), POINTER(c_int64), c_int, _P], c_int),
+    "rgbd_hidden_normalize": ([_P, _P, c_int, c_int, c_float, c_int, _P], c_int),
+    "rgbd_r1_penalty_fwd": ([_P, c_int, c_int64, c_float, _P, _P, _P], c_int),
+    "rgbd_scale_by_scalar_f32": ([_P, _P, c_float, _P, c_int64, _P], c_int),
+    "rgbd_image_grad_init": ([_P, _P, _P, c_int, c_int, c_int, c_int, _P], c_int),
+    "rgbd_const_input_fwd": ([_P, _P, _P, c_int, c_int, c_int, c_float, _P], c_int),
+    "rgbd_const_input_bwd": ([_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P], c_int),
+    "rgbd_nhwc_to_rows_f32": ([_P, _P, c_int, c_int, c_int, _P], c_int),
+    "rgbd_rows_to_nhwc_bf16": ([_P, _P, c_int, c_int, c_int, _P], c_int),
     "rgbd_linear_bwd": ([_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_float, c_int, _P], c_int),
     "rgbd_proj_idcs": ([_P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_float,
                         _P, _P, _P, _P, _P], c_int),

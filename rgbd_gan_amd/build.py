@@ -18,6 +18,7 @@ SOURCES = [
     ("warp_loss.hip", ["-ffp-contract=off"]),
     ("conv.hip", []),
     ("deepvoxels.hip", ["-ffp-contract=off"]),
+    ("step_ops.hip", []),
 ]
 COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 

@@ -59,7 +59,26 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------------ AdaIN
 // x is (B, HW, C) bf16.  A block owns one batch item, one 64-channel group and a strip of pixels:
 // thread t handles the 8-channel chunk (t & 7) of pixels (t >> 3), (t >> 3) + 32, ...
+// The strip sums leave as PLAIN stores into sums[strip][b][c][2] and the apply kernels add the strips in index order:
+// no atomics, so the statistics -- and with them every activation downstream -- are bit-reproducible run to run
+// (fp32 atomics in arrival order flipped bf16 roundings: ~1e-3 relative run-to-run noise on the generator output).
 constexpr int ADAIN_STRIP = 1024;
+
+// sum over strips of the (first, second) statistics of this thread's 8 channels; `part` points at strip 0's pair
+__device__ __forceinline__ void adain_strip_sum(const float* __restrict__ part, long strip_stride, int nstrips,
+                                                float (&s1)[8], float (&s2)[8]) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+    for (int s = 0; s < nstrips; ++s) {
+        const float* p = part + (long)s * strip_stride;
+        const f32x4 sa = *reinterpret_cast<const f32x4*>(p), sb = *reinterpret_cast<const f32x4*>(p + 4);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(p + 8), sd = *reinterpret_cast<const f32x4*>(p + 12);
+        s1[0] += sa[0]; s2[0] += sa[1]; s1[1] += sa[2]; s2[1] += sa[3];
+        s1[2] += sb[0]; s2[2] += sb[1]; s1[3] += sb[2]; s2[3] += sb[3];
+        s1[4] += sc[0]; s2[4] += sc[1]; s1[5] += sc[2]; s2[5] += sc[3];
+        s1[6] += sd[0]; s2[6] += sd[1]; s1[7] += sd[2]; s2[7] += sd[3];
+    }
+}
 
 template <bool WITH_DY>
 __global__ __launch_bounds__(256) void adain_reduce_kernel(const unsigned short* __restrict__ x,
@@ -109,56 +128,72 @@ __global__ __launch_bounds__(256) void adain_reduce_kernel(const unsigned short*
         float acc = 0.f;
 #pragma unroll 8
         for (int r = 0; r < 32; ++r) acc += red[which][r][c];
-        atomicAdd(sums + ((long)b * C + cg * 64 + c) * 2 + which, acc);
+        sums[(((long)strip * gridDim.z + b) * C + cg * 64 + c) * 2 + which] = acc;
     }
 }
 
-// y = (x - mean) * rstd * scale + shift, mean / rstd derived in place from the (sum x, sum x^2) pairs (adain.py:62-63:
-// biased variance, (var + eps)^-1/2); the thread that handles an image's first pixel also stores them for backward.
+// y = (x - mean) * rstd * scale + shift, mean / rstd derived from the (sum x, sum x^2) strip partials (adain.py:62-63:
+// biased variance, (var + eps)^-1/2).  A block owns a strip of rows of ONE sample and one 64-channel group, so the
+// per-(b,c) constants are formed once per thread; the block of the first strip also stores mean / rstd for backward.
 __global__ __launch_bounds__(256) void adain_apply_kernel(const unsigned short* __restrict__ x,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift,
                                                           const float* __restrict__ sums,
                                                           float* __restrict__ mean, float* __restrict__ rstd,
-                                                          unsigned short* __restrict__ y, long nvec, int HW, int C,
-                                                          int ld, float inv_hw, float eps) {
-    const int cvec = C >> 3;
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nvec; e += (long)gridDim.x * 256) {
-        const int cv = (int)(e % cvec);
-        const long pix = e / cvec;
-        const int b = (int)(pix / HW);
-        const long sidx = (long)b * C + cv * 8;
-        const long aidx = (long)b * ld + cv * 8;        // scale / shift rows are ld floats apart
-        const u32x4 xv = *reinterpret_cast<const u32x4*>(x + e * 8);
-        // 8 channels: (sum, sum of squares) pairs, scale, shift as 16-byte loads
-        const f32x4 sa = *reinterpret_cast<const f32x4*>(sums + 2 * sidx), sb = *reinterpret_cast<const f32x4*>(sums + 2 * sidx + 4);
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(sums + 2 * sidx + 8), sd = *reinterpret_cast<const f32x4*>(sums + 2 * sidx + 12);
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(scale + aidx), g1 = *reinterpret_cast<const f32x4*>(scale + aidx + 4);
-        const f32x4 h0 = *reinterpret_cast<const f32x4*>(shift + aidx), h1 = *reinterpret_cast<const f32x4*>(shift + aidx + 4);
-        const float s1[8] = {sa[0], sa[2], sb[0], sb[2], sc[0], sc[2], sd[0], sd[2]};
-        const float s2[8] = {sa[1], sa[3], sb[1], sb[3], sc[1], sc[3], sd[1], sd[3]};
-        const float gg[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-        const float hh[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-        float m[8], rs[8];
+                                                          unsigned short* __restrict__ y, int HW, int C,
+                                                          int ld, float inv_hw, float eps, int rows_per_block,
+                                                          int nstrips) {
+    const int cg = blockIdx.y, b = blockIdx.z;
+    const int chunk = threadIdx.x & 7, lane_p = threadIdx.x >> 3;
+    const int c0 = cg * 64 + chunk * 8;
+    const long sidx = (long)b * C + c0;
+    const long aidx = (long)b * ld + c0;            // scale / shift rows are ld floats apart
+    float s1[8], s2[8];
+    adain_strip_sum(sums + 2 * sidx, (long)gridDim.z * C * 2, nstrips, s1, s2);
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(scale + aidx), g1 = *reinterpret_cast<const f32x4*>(scale + aidx + 4);
+    const f32x4 h0 = *reinterpret_cast<const f32x4*>(shift + aidx), h1 = *reinterpret_cast<const f32x4*>(shift + aidx + 4);
+    const float gg[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+    const float hh[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+    float m[8], a[8];
+    {
+        float rs[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             m[k] = s1[k] * inv_hw;
             rs[k] = rsqrtf(fmaxf(s2[k] * inv_hw - m[k] * m[k], 0.f) + eps);
+            a[k] = rs[k] * gg[k];
         }
-        if (pix == (long)b * HW) {          // one thread per (image, 8-channel group) keeps the statistics for backward
+        if (blockIdx.x == 0 && lane_p == 0) {       // the statistics for backward
             *reinterpret_cast<f32x4*>(mean + sidx) = f32x4{m[0], m[1], m[2], m[3]};
             *reinterpret_cast<f32x4*>(mean + sidx + 4) = f32x4{m[4], m[5], m[6], m[7]};
             *reinterpret_cast<f32x4*>(rstd + sidx) = f32x4{rs[0], rs[1], rs[2], rs[3]};
             *reinterpret_cast<f32x4*>(rstd + sidx + 4) = f32x4{rs[4], rs[5], rs[6], rs[7]};
         }
-        u32x4 out;
+    }
+    const int r_begin = blockIdx.x * rows_per_block;
+    const int r_end = min(HW, r_begin + rows_per_block);
+    const long base = (long)b * HW;
+    for (int r0 = r_begin + lane_p; r0 < r_end; r0 += 128) {
+        u32x4 xv[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float r0 = (bf16_lo(xv[k]) - m[2 * k]) * (rs[2 * k] * gg[2 * k]) + hh[2 * k];
-            const float r1 = (bf16_hi(xv[k]) - m[2 * k + 1]) * (rs[2 * k + 1] * gg[2 * k + 1]) + hh[2 * k + 1];
-            out[k] = pack_bf16x2(r0, r1);
+        for (int u = 0; u < 4; ++u) {
+            const int r = (r0 + 32 * u) < r_end ? (r0 + 32 * u) : r0;
+            xv[u] = *reinterpret_cast<const u32x4*>(x + (base + r) * C + c0);
         }
-        *reinterpret_cast<u32x4*>(y + e * 8) = out;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + 32 * u;
+            if (r < r_end) {
+                u32x4 out;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float v0 = (bf16_lo(xv[u][k]) - m[2 * k]) * a[2 * k] + hh[2 * k];
+                    const float v1 = (bf16_hi(xv[u][k]) - m[2 * k + 1]) * a[2 * k + 1] + hh[2 * k + 1];
+                    out[k] = pack_bf16x2(v0, v1);
+                }
+                *reinterpret_cast<u32x4*>(y + (base + r) * C + c0) = out;
+            }
+        }
     }
 }
 
@@ -180,19 +215,17 @@ __global__ __launch_bounds__(256) void adain_bwd_apply_kernel(const unsigned sho
                                                               unsigned short* __restrict__ dx,
                                                               float* __restrict__ dscale, float* __restrict__ dshift,
                                                               int HW, int C, float inv_hw, int ld, int rows_per_block,
-                                                              float slope, float* __restrict__ bias_grad) {
+                                                              float slope, float* __restrict__ bias_grad, int nstrips) {
     const int cg = blockIdx.y, b = blockIdx.z;
     const int chunk = threadIdx.x & 7, lane_p = threadIdx.x >> 3;
     const int c0 = cg * 64 + chunk * 8;
     const long sidx = (long)b * C + c0;
     const long aidx = (long)b * ld + c0;
-    const f32x4 sa = *reinterpret_cast<const f32x4*>(sums + 2 * sidx), sb = *reinterpret_cast<const f32x4*>(sums + 2 * sidx + 4);
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(sums + 2 * sidx + 8), sd = *reinterpret_cast<const f32x4*>(sums + 2 * sidx + 12);
+    float s1[8], s2[8];                                 // sum dy, sum dy * xhat
+    adain_strip_sum(sums + 2 * sidx, (long)gridDim.z * C * 2, nstrips, s1, s2);
     const f32x4 g0 = *reinterpret_cast<const f32x4*>(scale + aidx), g1 = *reinterpret_cast<const f32x4*>(scale + aidx + 4);
     const f32x4 m0 = *reinterpret_cast<const f32x4*>(mean + sidx), m1 = *reinterpret_cast<const f32x4*>(mean + sidx + 4);
     const f32x4 r0v = *reinterpret_cast<const f32x4*>(rstd + sidx), r1v = *reinterpret_cast<const f32x4*>(rstd + sidx + 4);
-    const float s1[8] = {sa[0], sa[2], sb[0], sb[2], sc[0], sc[2], sd[0], sd[2]};          // sum dy
-    const float s2[8] = {sa[1], sa[3], sb[1], sb[3], sc[1], sc[3], sd[1], sd[3]};          // sum dy * xhat
     const float gg[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
     const float mm[8] = {m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2], m1[3]};
     const float rr[8] = {r0v[0], r0v[1], r0v[2], r0v[3], r1v[0], r1v[1], r1v[2], r1v[3]};
@@ -672,7 +705,8 @@ constexpr int LIN_MAXM = 64;
 template <bool VEC>
 __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ y, int M,
-                                                         int K, int N, float c, int act, float slope) {
+                                                         int K, int N, float c, int act, float slope,
+                                                         const float* __restrict__ mask_y) {
     const int lane = threadIdx.x & 63, m0 = (threadIdx.x >> 6) * 16;
     if (m0 >= M) return;
     const int r = lane & 15, q = lane >> 4;
@@ -717,6 +751,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
             if (m < M) {
                 float v = acc[t] * c + bv;
                 if (act) v = v > 0.f ? v : v * slope;
+                if (mask_y) v = mask_y[(long)m * N + n] > 0.f ? v : v * slope;   // times lrelu'(.) of a GIVEN activation output
                 y[(long)m * N + n] = v;
             }
         }
@@ -926,6 +961,11 @@ extern "C" int rgbd_pack_weights_multi(const rgbd_pack_desc* descs_device, int n
     return 0;
 }
 
+extern "C" int64_t rgbd_adain_workspace(int B, int HW, int C) {
+    if (B <= 0 || HW <= 0 || C <= 0) return -1;
+    return (int64_t)ceil_div(HW, ADAIN_STRIP) * B * C * 2;
+}
+
 extern "C" int rgbd_adain_fwd(const void* x, const float* scale, const float* shift, void* y, float* sums,
                               float* mean, float* rstd, int B, int HW, int C, int ld, float eps, void* stream) {
     RGBD_REQUIRE(x && scale && shift && y && sums && mean && rstd, "rgbd_adain_fwd: null pointer");
@@ -935,10 +975,10 @@ extern "C" int rgbd_adain_fwd(const void* x, const float* scale, const float* sh
     dim3 grid(ceil_div(HW, ADAIN_STRIP), C / 64, B);
     adain_reduce_kernel<false><<<grid, 256, 0, st>>>((const unsigned short*)x, nullptr, nullptr, nullptr, sums, HW, C);
     RGBD_CHECK_LAUNCH("adain_reduce_kernel");
-    const long nvec = (long)B * HW * C / 8;
-    const int blocks = (int)min((long)4096, (nvec + 255) / 256);
-    adain_apply_kernel<<<blocks, 256, 0, st>>>((const unsigned short*)x, scale, shift, sums, mean, rstd,
-                                               (unsigned short*)y, nvec, HW, C, ld, 1.f / (float)HW, eps);
+    const int rows = HW <= 4096 ? 256 : 512;
+    dim3 agrid(ceil_div(HW, rows), C / 64, B);
+    adain_apply_kernel<<<agrid, 256, 0, st>>>((const unsigned short*)x, scale, shift, sums, mean, rstd,
+                                              (unsigned short*)y, HW, C, ld, 1.f / (float)HW, eps, rows, (int)grid.x);
     RGBD_CHECK_LAUNCH("adain_apply_kernel");
     return 0;
 }
@@ -960,11 +1000,11 @@ extern "C" int rgbd_adain_bwd(const void* x, const void* dy, const float* scale,
     if (lrelu_slope > 0.f)
         adain_bwd_apply_kernel<true><<<agrid, 256, 0, st>>>((const unsigned short*)x, (const unsigned short*)dy, scale,
                                                             mean, rstd, sums, (unsigned short*)dx, dscale, dshift, HW, C,
-                                                            1.f / (float)HW, ld, rows, lrelu_slope, bias_grad);
+                                                            1.f / (float)HW, ld, rows, lrelu_slope, bias_grad, (int)grid.x);
     else
         adain_bwd_apply_kernel<false><<<agrid, 256, 0, st>>>((const unsigned short*)x, (const unsigned short*)dy, scale,
                                                              mean, rstd, sums, (unsigned short*)dx, dscale, dshift, HW,
-                                                             C, 1.f / (float)HW, ld, rows, 0.f, nullptr);
+                                                             C, 1.f / (float)HW, ld, rows, 0.f, nullptr, (int)grid.x);
     RGBD_CHECK_LAUNCH("adain_bwd_apply_kernel");
     return 0;
 }
@@ -1100,16 +1140,26 @@ extern "C" int rgbd_linear_fwd(const float* x, const float* w, const float* bias
                                float c, int act, float slope, void* stream) {
     RGBD_REQUIRE(x && w && y, "rgbd_linear_fwd: null pointer");
     RGBD_REQUIRE(M > 0 && M <= LIN_MAXM && K > 0 && N > 0, "rgbd_linear_fwd: needs 0 < M <= %d (M=%d)", LIN_MAXM, M);
-    if ((K & 3) == 0) linear_fwd_kernel<true><<<(N + 15) / 16, 256, 0, (hipStream_t)stream>>>(x, w, bias, y, M, K, N, c, act, slope);
-    else              linear_fwd_kernel<false><<<(N + 15) / 16, 256, 0, (hipStream_t)stream>>>(x, w, bias, y, M, K, N, c, act, slope);
+    if ((K & 3) == 0) linear_fwd_kernel<true><<<(N + 15) / 16, 256, 0, (hipStream_t)stream>>>(x, w, bias, y, M, K, N, c, act, slope, nullptr);
+    else              linear_fwd_kernel<false><<<(N + 15) / 16, 256, 0, (hipStream_t)stream>>>(x, w, bias, y, M, K, N, c, act, slope, nullptr);
     RGBD_CHECK_LAUNCH("linear_fwd_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_linear_fwd_masked(const float* x, const float* w, const float* mask_y, float* y, int M, int K, int N,
+                                      float c, float slope, void* stream) {
+    RGBD_REQUIRE(x && w && y && mask_y, "rgbd_linear_fwd_masked: null pointer");
+    RGBD_REQUIRE(M > 0 && M <= LIN_MAXM && K > 0 && N > 0, "rgbd_linear_fwd_masked: needs 0 < M <= %d (M=%d)", LIN_MAXM, M);
+    if ((K & 3) == 0) linear_fwd_kernel<true><<<(N + 15) / 16, 256, 0, (hipStream_t)stream>>>(x, w, nullptr, y, M, K, N, c, 0, slope, mask_y);
+    else              linear_fwd_kernel<false><<<(N + 15) / 16, 256, 0, (hipStream_t)stream>>>(x, w, nullptr, y, M, K, N, c, 0, slope, mask_y);
+    RGBD_CHECK_LAUNCH("linear_fwd_kernel<mask>");
     return 0;
 }
 
 extern "C" int rgbd_linear_bwd(const float* dy, const float* y, const float* x, const float* w, float* dx, float* dw,
                                float* db, int M, int K, int N, float c, int act, float slope, int accumulate_dx,
                                void* stream) {
-    RGBD_REQUIRE(dy && x && w, "rgbd_linear_bwd: null pointer");
+    RGBD_REQUIRE(dy && w && (x || !dw), "rgbd_linear_bwd: null pointer (x is needed for dw)");
     RGBD_REQUIRE(!act || y, "rgbd_linear_bwd: the activation output y is needed for its gradient");
     RGBD_REQUIRE(M > 0 && M <= LIN_MAXM && K > 0 && N > 0, "rgbd_linear_bwd: needs 0 < M <= %d (M=%d)", LIN_MAXM, M);
     hipStream_t st = (hipStream_t)stream;

@@ -1,0 +1,305 @@
+// Small fused ops of the training step (RGBDUpdater.update_core, updater.py:274-448 of the reference) that sit between
+// the big kernels: each replaces a run of 4-15 elementwise / reduction launches of the reference's Chainer graph with
+// one launch.  All HBM- or latency-bound and tiny next to the conv engine; what they buy is launch count on the step's
+// dependent chain.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ real batch
+// SerialIterator + TransformDataset(x / 127.5 - 1) (train_rgbd.py:308-310) + downsize_real (common/utils/pggan.py:6-50)
+// from the uint8 data set resident in HBM:  out[b,c,y,x] = blend of s x s block means of data[idx[b]] / 127.5 - 1.
+//   even stage: mean over the s x s block (s = H / S);  fade-in stage: (1 - alpha) * (mean over the 2s x 2s block that
+//   contains the pixel = nearest-upsampled lower resolution) + alpha * (mean over the s x s block).
+__global__ __launch_bounds__(256) void real_batch_kernel(const unsigned char* __restrict__ data,
+                                                         const long* __restrict__ idx, float* __restrict__ out, int B,
+                                                         int C, int H, int W, int S, int fade,
+                                                         const float* __restrict__ alpha_ptr, float alpha_host) {
+    const int s = H / S;
+    const long total = (long)B * C * S * S;
+    const float alpha = fade ? (alpha_ptr ? alpha_ptr[0] : alpha_host) : 1.f;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int x = (int)(e % S);
+        long r = e / S;
+        const int y = (int)(r % S);
+        r /= S;
+        const int c = (int)(r % C);
+        const int b = (int)(r / C);
+        const unsigned char* plane = data + ((idx[b] * C + c) * (long)H) * W;
+        float hi = 0.f;
+        for (int dy = 0; dy < s; ++dy)
+            for (int dx = 0; dx < s; ++dx)
+                hi += __fdiv_rn((float)plane[(long)(y * s + dy) * W + x * s + dx], 127.5f) - 1.f;
+        hi *= 1.f / (float)(s * s);
+        float v = hi;
+        if (fade) {
+            const int s2 = 2 * s, y2 = (y >> 1) * s2, x2 = (x >> 1) * s2;
+            float lo = 0.f;
+            for (int dy = 0; dy < s2; ++dy)
+                for (int dx = 0; dx < s2; ++dx)
+                    lo += __fdiv_rn((float)plane[(long)(y2 + dy) * W + x2 + dx], 127.5f) - 1.f;
+            lo *= 1.f / (float)(s2 * s2);
+            v = (1.f - alpha) * lo + alpha * hi;
+        }
+        out[e] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ zero several buffers
+constexpr int ZERO_MULTI_MAX = 8;
+struct ZeroMultiArgs {
+    float* p[ZERO_MULTI_MAX];
+    long n[ZERO_MULTI_MAX];
+    int count;
+};
+__global__ __launch_bounds__(256) void zero_multi_kernel(ZeroMultiArgs a) {
+    for (int k = 0; k < a.count; ++k) {
+        f32x4* p4 = reinterpret_cast<f32x4*>(a.p[k]);
+        const long n4 = a.n[k] >> 2;                       // buffers are 16-byte aligned, sizes multiples of 4 floats
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256)
+            p4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < a.n[k]; i += (long)gridDim.x * 256)
+            a.p[k][i] = 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ latent normalisation
+// make_hidden (net.py:333-343): z / sqrt(sum_c z^2 / ch + 1e-8), one wave per row; the row is written `copies` times,
+// copy k at row index m + k * M (updater.py:300 repeats the same latents for the second view of every pair).
+__global__ __launch_bounds__(256) void hidden_normalize_kernel(const float* __restrict__ z, float* __restrict__ out,
+                                                               int M, int C, float ch, int copies) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    float acc = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float v = z[(long)row * C + c];
+        acc += v * v;
+    }
+    acc = wave_sum(acc);
+    const float inv = 1.f / sqrtf(acc / ch + 1e-8f);
+    for (int c = lane; c < C; c += 64) {
+        const float v = z[(long)row * C + c] * inv;
+        for (int k = 0; k < copies; ++k) out[((long)k * M + row) * C + c] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ R1 penalty
+// updater.py:416-418 + loss_functions.py:7-8: loss = coef * (1/B) * sum_b (sqrt(sum g_b^2))^2 over g (B, n) fp32.
+constexpr int R1_CHUNKS = 16;
+__global__ __launch_bounds__(256) void r1_partial_kernel(const float* __restrict__ g, long n, float* __restrict__ part) {
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const long n4 = n >> 2;
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(g + (long)b * n);
+    const long per = (n4 + R1_CHUNKS - 1) / R1_CHUNKS;
+    const long i0 = chunk * per, i1 = i0 + per < n4 ? i0 + per : n4;
+    float acc = 0.f;
+    for (long i = i0 + threadIdx.x; i < i1; i += 256) {
+        const f32x4 v = g4[i];
+        acc += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+    if (chunk == R1_CHUNKS - 1)
+        for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) acc += g[(long)b * n + i] * g[(long)b * n + i];
+    acc = wave_sum(acc);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[b * R1_CHUNKS + chunk] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(64) void r1_final_kernel(const float* __restrict__ part, int B, float coef,
+                                                      float* __restrict__ loss) {
+    float acc = 0.f;
+    for (int b = threadIdx.x; b < B; b += 64) {
+        float s = 0.f;
+        for (int k = 0; k < R1_CHUNKS; ++k) s += part[b * R1_CHUNKS + k];
+        const float nrm = sqrtf(s);                        // grad_l2 = F.sqrt(F.sum(g ** 2)); loss_l2 squares it again
+        acc += nrm * nrm;
+    }
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) loss[0] = coef * (acc / (float)B);
+}
+// out = (gl[0] * k) * x : gradient of the penalty w.r.t. g (k = 2 * coef / B), gl = d objective / d loss on the device
+__global__ __launch_bounds__(256) void scale_by_scalar_kernel(const float* __restrict__ x, const float* __restrict__ gl,
+                                                              float k, float* __restrict__ out, long n) {
+    const float s = (gl ? gl[0] : 1.f) * k;
+    const long n4 = n >> 2;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    f32x4* o4 = reinterpret_cast<f32x4*>(out);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) o4[i] = x4[i] * s;
+    for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = x[i] * s;
+}
+
+// ------------------------------------------------------------------------------------------------ image gradient junction
+// The generator's output gradient before the 3-D consistency loss adds its part (updater.py:334,363-365,387):
+//   out[b, k, p] = ratio[b] * gx[b, k, p]  for k < 3  (adversarial image gradient, rescaled per sample -- updater.py of
+//   this engine: one pass through D(x_fake) seeded with the discriminator's loss),  out[b, 3, p] = 0.
+__global__ __launch_bounds__(256) void image_grad_init_kernel(const float* __restrict__ gx, const float* __restrict__ ratio,
+                                                              float* __restrict__ out, int B, int KP_in, int KP_out,
+                                                              int HW) {
+    const long total = (long)B * KP_out * HW;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int p = (int)(e % HW);
+        const long r = e / HW;
+        const int k = (int)(r % KP_out);
+        const int b = (int)(r / KP_out);
+        out[e] = k < KP_in ? gx[((long)b * KP_in + k) * HW + p] * (ratio ? ratio[b] : 1.f) : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ constant input
+// SynthesisBlock 0 (net.py:130-153): h = lrelu(W + b0) broadcast over the batch, W (C, HW) fp32 -> (B, HW, C) bf16.
+__global__ __launch_bounds__(256) void const_input_fwd_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                                              unsigned short* __restrict__ out, int B, int HW, int C,
+                                                              float slope) {
+    const long total = (long)B * HW * C;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const int p = (int)((e / C) % HW);
+        const float v = w[(long)c * HW + p] + bias[c];
+        out[e] = f32_to_bf16_bits(v > 0.f ? v : v * slope);
+    }
+}
+// dW[c,p] += m(c,p) * sum_b dh[b,p,c];  db[c] += sum_p of that  (one thread per channel; 16 positions, <= 64 samples)
+__global__ __launch_bounds__(256) void const_input_bwd_kernel(const unsigned short* __restrict__ dh,
+                                                              const float* __restrict__ w, const float* __restrict__ bias,
+                                                              float* __restrict__ dw, float* __restrict__ db, int B,
+                                                              int HW, int C, float slope) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float bsum = 0.f;
+    for (int p = 0; p < HW; ++p) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += bf16_bits_to_f32(dh[((long)b * HW + p) * C + c]);
+        const float g = (w[(long)c * HW + p] + bias[c]) > 0.f ? s : s * slope;
+        if (dw) dw[(long)c * HW + p] += g;
+        bsum += g;
+    }
+    if (db) db[c] += bsum;
+}
+
+// ------------------------------------------------------------------------------------------------ dense tail layout
+// 4x4-valid conv of the discriminator's base block as a linear layer over (ci, kh, kw) (net.py:363-365,372-377): the
+// activation (B, HW, C) bf16 NHWC is brought into the weight's own (C, HW) order as fp32 rows, and back (adjoint).
+__global__ __launch_bounds__(256) void nhwc_to_rows_kernel(const unsigned short* __restrict__ h, float* __restrict__ out,
+                                                           int B, int HW, int C) {
+    const long total = (long)B * HW * C;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int p = (int)(e % HW);
+        const long r = e / HW;
+        const int c = (int)(r % C);
+        const int b = (int)(r / C);
+        out[e] = bf16_bits_to_f32(h[((long)b * HW + p) * C + c]);
+    }
+}
+__global__ __launch_bounds__(256) void rows_to_nhwc_kernel(const float* __restrict__ rows, unsigned short* __restrict__ h,
+                                                           int B, int HW, int C) {
+    const long total = (long)B * HW * C;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        const long r = e / C;
+        const int p = (int)(r % HW);
+        const int b = (int)(r / HW);
+        h[e] = f32_to_bf16_bits(rows[((long)b * C + c) * HW + p]);
+    }
+}
+
+inline unsigned grid_for(long n, long cap = 4096) {
+    const long b = (n + 255) / 256;
+    return (unsigned)(b < 1 ? 1 : (b < cap ? b : cap));
+}
+
+}  // namespace
+
+extern "C" int rgbd_real_batch_u8(const uint8_t* data, const int64_t* idx, float* out, int B, int C, int H, int W, int S,
+                                  int fade, const float* alpha_device, float alpha, void* stream) {
+    RGBD_REQUIRE(data && idx && out, "rgbd_real_batch_u8: null pointer");
+    RGBD_REQUIRE(B > 0 && C > 0 && H == W && S > 0 && H % S == 0 && (!fade || (S % 2 == 0 && H % S == 0)),
+                 "rgbd_real_batch_u8: bad shape H=%d W=%d S=%d fade=%d", H, W, S, fade);
+    real_batch_kernel<<<grid_for((long)B * C * S * S), 256, 0, (hipStream_t)stream>>>(
+        data, (const long*)idx, out, B, C, H, W, S, fade ? 1 : 0, alpha_device, alpha);
+    RGBD_CHECK_LAUNCH("real_batch_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_zero_multi_f32(float* const* ptrs, const int64_t* counts, int n, void* stream) {
+    RGBD_REQUIRE(ptrs && counts && n > 0 && n <= ZERO_MULTI_MAX, "rgbd_zero_multi_f32: 1..%d buffers", ZERO_MULTI_MAX);
+    ZeroMultiArgs a;
+    long most = 0;
+    for (int k = 0; k < n; ++k) {
+        RGBD_REQUIRE(ptrs[k] && counts[k] > 0 && ((uintptr_t)ptrs[k] & 15) == 0, "rgbd_zero_multi_f32: buffer %d", k);
+        a.p[k] = ptrs[k];
+        a.n[k] = counts[k];
+        if (counts[k] > most) most = counts[k];
+    }
+    a.count = n;
+    zero_multi_kernel<<<grid_for(most / 4, 2048), 256, 0, (hipStream_t)stream>>>(a);
+    RGBD_CHECK_LAUNCH("zero_multi_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_hidden_normalize(const float* z, float* out, int M, int C, float ch, int copies, void* stream) {
+    RGBD_REQUIRE(z && out && M > 0 && C > 0 && ch > 0.f && copies >= 1, "rgbd_hidden_normalize: bad arguments");
+    hidden_normalize_kernel<<<(M + 3) / 4, 256, 0, (hipStream_t)stream>>>(z, out, M, C, ch, copies);
+    RGBD_CHECK_LAUNCH("hidden_normalize_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_r1_penalty_fwd(const float* g, int B, int64_t n, float coef, float* workspace, float* loss,
+                                   void* stream) {
+    RGBD_REQUIRE(g && workspace && loss && B > 0 && n > 0 && ((uintptr_t)g & 15) == 0 && (n & 3) == 0,
+                 "rgbd_r1_penalty_fwd: bad arguments (n must be a multiple of 4)");
+    r1_partial_kernel<<<dim3(R1_CHUNKS, B), 256, 0, (hipStream_t)stream>>>(g, n, workspace);
+    RGBD_CHECK_LAUNCH("r1_partial_kernel");
+    r1_final_kernel<<<1, 64, 0, (hipStream_t)stream>>>(workspace, B, coef, loss);
+    RGBD_CHECK_LAUNCH("r1_final_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_scale_by_scalar_f32(const float* x, const float* scalar_device, float k, float* out, int64_t n,
+                                        void* stream) {
+    RGBD_REQUIRE(x && out && n > 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0,
+                 "rgbd_scale_by_scalar_f32: bad arguments");
+    scale_by_scalar_kernel<<<grid_for(n / 4), 256, 0, (hipStream_t)stream>>>(x, scalar_device, k, out, n);
+    RGBD_CHECK_LAUNCH("scale_by_scalar_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_image_grad_init(const float* gx, const float* ratio, float* out, int B, int KP_in, int KP_out, int HW,
+                                    void* stream) {
+    RGBD_REQUIRE(gx && out && B > 0 && KP_in > 0 && KP_out >= KP_in && HW > 0, "rgbd_image_grad_init: bad arguments");
+    image_grad_init_kernel<<<grid_for((long)B * KP_out * HW), 256, 0, (hipStream_t)stream>>>(gx, ratio, out, B, KP_in,
+                                                                                           KP_out, HW);
+    RGBD_CHECK_LAUNCH("image_grad_init_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_const_input_fwd(const float* w, const float* bias, void* out, int B, int HW, int C, float slope,
+                                    void* stream) {
+    RGBD_REQUIRE(w && bias && out && B > 0 && HW > 0 && C > 0, "rgbd_const_input_fwd: bad arguments");
+    const_input_fwd_kernel<<<grid_for((long)B * HW * C), 256, 0, (hipStream_t)stream>>>(w, bias, (unsigned short*)out, B,
+                                                                                      HW, C, slope);
+    RGBD_CHECK_LAUNCH("const_input_fwd_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_const_input_bwd(const void* dh, const float* w, const float* bias, float* dw, float* db, int B, int HW,
+                                    int C, float slope, void* stream) {
+    RGBD_REQUIRE(dh && w && bias && B > 0 && HW > 0 && C > 0, "rgbd_const_input_bwd: bad arguments");
+    const_input_bwd_kernel<<<(C + 255) / 256, 256, 0, (hipStream_t)stream>>>((const unsigned short*)dh, w, bias, dw, db, B,
+                                                                             HW, C, slope);
+    RGBD_CHECK_LAUNCH("const_input_bwd_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_nhwc_to_rows_f32(const void* h, float* rows, int B, int HW, int C, void* stream) {
+    RGBD_REQUIRE(h && rows && B > 0 && HW > 0 && C > 0, "rgbd_nhwc_to_rows_f32: bad arguments");
+    nhwc_to_rows_kernel<<<grid_for((long)B * HW * C), 256, 0, (hipStream_t)stream>>>((const unsigned short*)h, rows, B, HW, C);
+    RGBD_CHECK_LAUNCH("nhwc_to_rows_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_rows_to_nhwc_bf16(const float* rows, void* h, int B, int HW, int C, void* stream) {
+    RGBD_REQUIRE(h && rows && B > 0 && HW > 0 && C > 0, "rgbd_rows_to_nhwc_bf16: bad arguments");
+    rows_to_nhwc_kernel<<<grid_for((long)B * HW * C), 256, 0, (hipStream_t)stream>>>(rows, (unsigned short*)h, B, HW, C);
+    RGBD_CHECK_LAUNCH("rows_to_nhwc_kernel");
+    return 0;
+}

@@ -58,7 +58,7 @@ __device__ __forceinline__ PixelWarp project_pixel(const float* __restrict__ cf,
 // grid: (ceil(b*hw/256), 2). blockIdx.y = direction (0: sample img_rot at warp(img); 1: the inverse).
 __global__ __launch_bounds__(256) void warp_loss_fwd_kernel(
     const float* __restrict__ img, const float* __restrict__ img_rot, const float* __restrict__ coef,
-    int b, int S, int flags, float max_depth, float min_depth,
+    int b, int S, int flags, float max_depth, float min_depth, float hinge_min,
     float* __restrict__ partials, float* __restrict__ dbg_zp, float* __restrict__ dbg_warped,
     int32_t* __restrict__ dbg_idx) {
     const int dir = blockIdx.y;
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void warp_loss_fwd_kernel(
     const long N = (long)b * hw;
     const float* own = dir == 0 ? img : img_rot;   // image whose depth is projected / whose RGB is the target
     const float* src = dir == 0 ? img_rot : img;   // image that is sampled
-    float l_rgb = 0.f, l_d = 0.f;
+    float l_rgb = 0.f, l_d = 0.f, l_h = 0.f;
     if (n < N) {
         const int bi = (int)(n / hw);
         const int pix = (int)(n - (long)bi * hw);
@@ -76,6 +76,10 @@ __global__ __launch_bounds__(256) void warp_loss_fwd_kernel(
         const float* ob = own + (long)bi * 4 * hw;
         const float* sb = src + (long)bi * 4 * hw;
         const float z = ob[3 * hw + pix];
+        {   // depth-range hinge (updater.py:357-359): the two directions' "own" images cover every pixel of the batch once
+            const float hv = fmaxf(hinge_min - z, 0.f);
+            l_h = hv * hv;
+        }
         const PixelWarp w = project_pixel(cf, dir == 0 ? -1.f : 1.f, z, i, j, S);
         const int o00 = w.u0m * S + w.v0m;
         const int o01 = w.u0m * S + w.v1m;
@@ -114,51 +118,55 @@ __global__ __launch_bounds__(256) void warp_loss_fwd_kernel(
         }
     }
     // deterministic block reduction
-    __shared__ float red[2][4];
+    __shared__ float red[3][4];
     l_rgb = wave_sum(l_rgb);
     l_d = wave_sum(l_d);
+    l_h = wave_sum(l_h);
     const int wid = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { red[0][wid] = l_rgb; red[1][wid] = l_d; }
+    if ((threadIdx.x & 63) == 0) { red[0][wid] = l_rgb; red[1][wid] = l_d; red[2][wid] = l_h; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        float* o = partials + ((long)blockIdx.x * 2 + dir) * 2;
+        float* o = partials + ((long)blockIdx.x * 2 + dir) * 3;
         o[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
         o[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        o[2] = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
     }
 }
 
-// one block: loss = mae_rgb(fwd) + mae_rgb(inv) + lambda * (mae_d(fwd) + mae_d(inv))
+// one block: loss = mae_rgb(fwd) + mae_rgb(inv) + lambda * (mae_d(fwd) + mae_d(inv)) [+ hinge_lambda * mean hinge]
 __global__ __launch_bounds__(256) void warp_loss_final_kernel(const float* __restrict__ partials, int nblocks,
-                                                             float inv_n, float lambda_geo,
+                                                             float inv_n, float lambda_geo, float hinge_lambda,
                                                              float* __restrict__ loss) {
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};  // rgb0, d0, rgb1, d1
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // rgb0, d0, h0, rgb1, d1, h1
     for (int k = threadIdx.x; k < nblocks; k += 256) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] += partials[(long)k * 4 + q];
+        for (int q = 0; q < 6; ++q) acc[q] += partials[(long)k * 6 + q];
     }
-    __shared__ float red[4][4];
+    __shared__ float red[6][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = wave_sum(acc[q]);
+    for (int q = 0; q < 6; ++q) acc[q] = wave_sum(acc[q]);
     const int wid = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) red[q][wid] = acc[q];
+        for (int q = 0; q < 6; ++q) red[q][wid] = acc[q];
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        float t[4];
+        float t[6];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) t[q] = (red[q][0] + red[q][1]) + (red[q][2] + red[q][3]);
-        const float rgb = t[0] * (inv_n / 3.f) + t[2] * (inv_n / 3.f);
-        const float dep = t[1] * inv_n * lambda_geo + t[3] * inv_n * lambda_geo;
-        loss[0] = rgb + dep;
+        for (int q = 0; q < 6; ++q) t[q] = (red[q][0] + red[q][1]) + (red[q][2] + red[q][3]);
+        const float rgb = t[0] * (inv_n / 3.f) + t[3] * (inv_n / 3.f);
+        const float dep = t[1] * inv_n * lambda_geo + t[4] * inv_n * lambda_geo;
+        float total = rgb + dep;
+        if (hinge_lambda != 0.f) total = total + ((t[2] + t[5]) * (0.5f * inv_n)) * hinge_lambda;
+        loss[0] = total;
     }
 }
 
 __global__ __launch_bounds__(256) void warp_loss_bwd_kernel(
     const float* __restrict__ img, const float* __restrict__ img_rot, const float* __restrict__ coef,
-    int b, int S, int flags, float lambda_geo, float max_depth, float min_depth,
-    const float* __restrict__ grad_loss, float* __restrict__ gimg, float* __restrict__ gimg_rot) {
+    int b, int S, int flags, float lambda_geo, float max_depth, float min_depth, float hinge_lambda, float hinge_min,
+    const float* __restrict__ grad_loss, float grad_scale, float* __restrict__ gimg, float* __restrict__ gimg_rot) {
     const int dir = blockIdx.y;
     const int hw = S * S;
     const long n = (long)blockIdx.x * 256 + threadIdx.x;
@@ -177,6 +185,9 @@ __global__ __launch_bounds__(256) void warp_loss_bwd_kernel(
     float* gob = gown + (long)bi * 4 * hw;
     float* gsb = gsrc + (long)bi * 4 * hw;
     const float z = ob[3 * hw + pix];
+    const float go = (grad_loss ? grad_loss[0] : 1.f) * grad_scale;
+    if (hinge_lambda != 0.f && z < hinge_min)      // d/dz of hinge_lambda * mean_{2N} relu(hinge_min - z)^2
+        atomicAdd(gob + 3 * hw + pix, go * hinge_lambda * (0.5f / (float)N) * (-2.f * (hinge_min - z)));
     const PixelWarp w = project_pixel(cf, dir == 0 ? -1.f : 1.f, z, i, j, S);
     if (!w.mask) return;  // masked pixels have zero weights, zero targets and constant taps: no gradient
     const int o00 = w.u0m * S + w.v0m;
@@ -193,7 +204,6 @@ __global__ __launch_bounds__(256) void warp_loss_bwd_kernel(
     if (flags & RGBD_WARP_MAX_DEPTH) vis = vis && (z < max_depth);
     if (flags & RGBD_WARP_MIN_DEPTH) vis = vis && (z > min_depth);
     if (!vis) return;
-    const float go = grad_loss[0];
     const float inv_n = 1.f / (float)N;
     const float k_rgb = go * inv_n / 3.f;
     const float k_d = go * inv_n * lambda_geo;
@@ -239,6 +249,7 @@ __global__ __launch_bounds__(256) void warp_loss_bwd_kernel(
 
 extern "C" int rgbd_warp_loss_fwd(const float* img, const float* img_rot, const float* coef, int b, int S,
                                   int flags, float lambda_geometric, float max_depth, float min_depth,
+                                  float hinge_lambda, float hinge_min,
                                   float* partials, float* loss, float* dbg_zp, float* dbg_warped,
                                   int32_t* dbg_idx, void* stream) {
     RGBD_REQUIRE(img && img_rot && coef && partials && loss, "rgbd_warp_loss_fwd: null pointer");
@@ -247,29 +258,31 @@ extern "C" int rgbd_warp_loss_fwd(const float* img, const float* img_rot, const 
     const int nblocks = ceil_div(N, 256);
     hipStream_t st = (hipStream_t)stream;
     warp_loss_fwd_kernel<<<dim3(nblocks, 2), 256, 0, st>>>(img, img_rot, coef, b, S, flags, max_depth, min_depth,
-                                                           partials, dbg_zp, dbg_warped, dbg_idx);
+                                                           hinge_min, partials, dbg_zp, dbg_warped, dbg_idx);
     RGBD_CHECK_LAUNCH("warp_loss_fwd_kernel");
-    warp_loss_final_kernel<<<1, 256, 0, st>>>(partials, nblocks, 1.f / (float)N, lambda_geometric, loss);
+    warp_loss_final_kernel<<<1, 256, 0, st>>>(partials, nblocks, 1.f / (float)N, lambda_geometric, hinge_lambda, loss);
     RGBD_CHECK_LAUNCH("warp_loss_final_kernel");
     return 0;
 }
 
 extern "C" int rgbd_warp_loss_bwd(const float* img, const float* img_rot, const float* coef, int b, int S,
                                   int flags, float lambda_geometric, float max_depth, float min_depth,
-                                  const float* grad_loss, float* grad_img, float* grad_img_rot, void* stream) {
-    RGBD_REQUIRE(img && img_rot && coef && grad_loss && grad_img && grad_img_rot,
-                 "rgbd_warp_loss_bwd: null pointer");
+                                  float hinge_lambda, float hinge_min,
+                                  const float* grad_loss, float grad_scale, float* grad_img, float* grad_img_rot,
+                                  int accumulate, void* stream) {
+    RGBD_REQUIRE(img && img_rot && coef && grad_img && grad_img_rot, "rgbd_warp_loss_bwd: null pointer");
     RGBD_REQUIRE(b > 0 && S >= 2, "rgbd_warp_loss_bwd: bad shape b=%d S=%d", b, S);
     const long N = (long)b * S * S;
     hipStream_t st = (hipStream_t)stream;
-    if (rgbd_zero_async(grad_img, N * 4 * sizeof(float), st) != hipSuccess ||
-        rgbd_zero_async(grad_img_rot, N * 4 * sizeof(float), st) != hipSuccess) {
+    if (!accumulate && (rgbd_zero_async(grad_img, N * 4 * sizeof(float), st) != hipSuccess ||
+                        rgbd_zero_async(grad_img_rot, N * 4 * sizeof(float), st) != hipSuccess)) {
         rgbd_set_error("rgbd_warp_loss_bwd: memset failed");
         return -2;
     }
     warp_loss_bwd_kernel<<<dim3(ceil_div(N, 256), 2), 256, 0, st>>>(img, img_rot, coef, b, S, flags,
-                                                                    lambda_geometric, max_depth, min_depth,
-                                                                    grad_loss, grad_img, grad_img_rot);
+                                                                    lambda_geometric, max_depth, min_depth, hinge_lambda,
+                                                                    hinge_min, grad_loss, grad_scale, grad_img,
+                                                                    grad_img_rot);
     RGBD_CHECK_LAUNCH("warp_loss_bwd_kernel");
     return 0;
 }

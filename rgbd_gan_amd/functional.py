@@ -819,6 +819,155 @@ def linear_act(x, w, bias, c, act=True):
     return _LinearAct.apply(x, w, bias, float(c), bool(act))
 
 
+class _Dense(torch.autograd.Function):
+    """y = act(c * x W^T + b) on <= 64 fp32 rows, differentiable TWICE (the discriminator's dense tail sits under the R1
+    penalty, updater.py:414-422): the backward is built from _DenseDgrad, whose own backward is again two kernels.
+    `w` is the master parameter in ANY shape with N leading rows (the 4x4-valid conv weight (co,ci,4,4) is used as a
+    (co, ci*16) matrix without a copy); weight / bias gradients go straight into the bound flat gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, c, act):
+        x = x.contiguous()
+        w2 = w.detach().reshape(w.shape[0], -1)
+        y = kernels.linear_fwd(x, w2, bias.detach() if bias is not None else None, c, act)
+        ctx.c, ctx.act = c, act
+        ctx.save_for_backward(x, w, bias, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, bias, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _DenseDgrad.apply(dy, y.detach(), w, ctx.c, ctx.act)
+        if ctx.needs_input_grad[1] and not _skip_grad_of(w):
+            w2 = w.detach().reshape(w.shape[0], -1)
+            want_b = bias is not None and ctx.needs_input_grad[2]
+            if _direct_grad(w) and (not want_b or _direct_grad(bias)):
+                kernels.linear_bwd(dy.detach(), y, x, w2, ctx.c, ctx.act, want_dx=False, dw=w.grad.view_as(w2),
+                                   db=bias.grad if want_b else None)
+            else:
+                dw2 = torch.zeros_like(w2)
+                db = torch.zeros_like(bias) if want_b else None
+                kernels.linear_bwd(dy.detach(), y, x, w2, ctx.c, ctx.act, want_dx=False, dw=dw2, db=db)
+                dw = dw2.view_as(w)
+        return dx, dw, db, None, None
+
+
+class _DenseDgrad(torch.autograd.Function):
+    """dx = c * (dy * act'(y)) W.  Linear in dy: its backward is (c * ddx W^T) * act'(y) for dy and
+    c * (dy * act'(y))^T ddx for W (third order is not supported)."""
+
+    @staticmethod
+    def forward(ctx, dy, y, w, c, act):
+        dy = dy.contiguous()
+        w2 = w.detach().reshape(w.shape[0], -1)
+        ctx.c, ctx.act = c, act
+        ctx.save_for_backward(dy, y, w)
+        return kernels.linear_bwd(dy, y, None, w2, c, act, want_dx=True)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, ddx):
+        dy, y, w = ctx.saved_tensors
+        ddx = ddx.contiguous()
+        w2 = w.reshape(w.shape[0], -1)
+        g_dy = g_w = None
+        if ctx.needs_input_grad[0]:
+            g_dy = kernels.linear_fwd_masked(ddx, w2, y, ctx.c) if ctx.act else kernels.linear_fwd(ddx, w2, None, ctx.c, False)
+        if ctx.needs_input_grad[2] and not _skip_grad_of(w):
+            if _direct_grad(w):
+                kernels.linear_bwd(dy, y, ddx, w2, ctx.c, ctx.act, want_dx=False, dw=w.grad.view_as(w2))
+            else:
+                dw2 = torch.zeros_like(w2)
+                kernels.linear_bwd(dy, y, ddx, w2, ctx.c, ctx.act, want_dx=False, dw=dw2)
+                g_w = dw2.view_as(w)
+        return g_dy, None, g_w, None, None
+
+
+def dense(x, w, bias, c, act=True):
+    """Equalized-LR linear (pggan.py:39-50) [+ leaky ReLU] on <= 64 rows through the HIP linear kernels, twice
+    differentiable."""
+    return _Dense.apply(x, w, bias, float(c), bool(act))
+
+
+class _NhwcToRows(torch.autograd.Function):
+    """(B,H,W,C) bf16 -> (B, C*H*W) fp32 in (c,h,w) order (L.Linear's flattening of an NCHW array, net.py:372-377)."""
+
+    @staticmethod
+    def forward(ctx, h):
+        ctx.shape = tuple(h.shape)
+        return kernels.nhwc_to_rows(h.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return _RowsToNhwc.apply(g, ctx.shape)
+
+
+class _RowsToNhwc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rows, shape):
+        return kernels.rows_to_nhwc(rows.contiguous(), shape[1], shape[2], shape[3])
+
+    @staticmethod
+    def backward(ctx, g):
+        return _NhwcToRows.apply(g), None
+
+
+def nhwc_to_rows(h):
+    return _NhwcToRows.apply(h)
+
+
+class _ConstInput(torch.autograd.Function):
+    """SynthesisBlock 0 (net.py:130-153): lrelu(W + b0) broadcast over the batch as (B,4,4,C) bf16, one launch; the
+    backward adds the batch-summed, masked gradient to W's and b0's bound gradient buffers (first order only)."""
+
+    @staticmethod
+    def forward(ctx, w, bias, B):
+        ctx.save_for_backward(w, bias)
+        return kernels.const_input_fwd(w.detach().contiguous(), bias.detach().contiguous(), B)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dh):
+        w, bias = ctx.saved_tensors
+        want_w = ctx.needs_input_grad[0] and not _skip_grad_of(w)
+        want_b = ctx.needs_input_grad[1] and not _skip_grad_of(bias)
+        direct = (not want_w or _direct_grad(w)) and (not want_b or _direct_grad(bias))
+        dw = (w.grad if direct else torch.zeros_like(w)) if want_w else None
+        db = (bias.grad if direct else torch.zeros_like(bias)) if want_b else None
+        if want_w or want_b:
+            kernels.const_input_bwd(dh.contiguous(), w.detach().contiguous(), bias.detach().contiguous(), dw, db)
+        return (None, None, None) if direct else (dw, db, None)
+
+
+def const_input(w, bias, B):
+    return _ConstInput.apply(w, bias, int(B))
+
+
+class _R1Penalty(torch.autograd.Function):
+    """lambda * mean_b ||g_b||^2 (updater.py:416-418 with loss_functions.py:7-8: sqrt, then squared again) on the image
+    gradient g of the R1 first-order pass; d/dg = 2 lambda / B * g feeds the double backward."""
+
+    @staticmethod
+    def forward(ctx, g, coef):
+        g = g.contiguous()
+        ctx.coef = coef
+        ctx.save_for_backward(g)
+        return kernels.r1_penalty_fwd(g, coef).reshape(())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gl):
+        g, = ctx.saved_tensors
+        return kernels.scale_by_scalar(g, gl.reshape(1).float().contiguous(), 2.0 * ctx.coef / g.shape[0]), None
+
+
+def r1_penalty(grad_x, lambda_gp):
+    return _R1Penalty.apply(grad_x, float(lambda_gp))
+
+
 class _PixelNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

@@ -77,15 +77,17 @@ def _chk(t, dtype, name):
 
 
 # ------------------------------------------------------------------ warp loss
-def warp_loss_fwd(img, img_rot, coef, flags, lambda_geometric, max_depth=0.0, min_depth=0.0, debug=False):
-    """img, img_rot (b,4,S,S) fp32; coef (b,24) fp32 -> loss (1,) [+ debug tensors]."""
+def warp_loss_fwd(img, img_rot, coef, flags, lambda_geometric, max_depth=0.0, min_depth=0.0, debug=False,
+                  hinge_lambda=0.0, hinge_min=0.0):
+    """img, img_rot (b,4,S,S) fp32; coef (b,24) fp32 -> loss (1,) [+ debug tensors].  hinge_lambda > 0: the depth-range
+    hinge of updater.py:357-359 over both image sets is added in the same pass."""
     for t, n in ((img, "img"), (img_rot, "img_rot"), (coef, "coef")):
         _chk(t, F32, n)
     b, C, S, _ = img.shape
     if C != 4 or img_rot.shape != img.shape or coef.shape != (b, 24):
         raise RuntimeError(f"warp_loss_fwd: bad shapes {tuple(img.shape)} {tuple(img_rot.shape)} {tuple(coef.shape)}")
     N = b * S * S
-    partials = torch.empty(4 * ((N + 255) // 256), dtype=F32, device=img.device)
+    partials = torch.empty(6 * ((N + 255) // 256), dtype=F32, device=img.device)
     loss = torch.empty(1, dtype=F32, device=img.device)
     zp = warped = idx = None
     if debug:
@@ -94,19 +96,29 @@ def warp_loss_fwd(img, img_rot, coef, flags, lambda_geometric, max_depth=0.0, mi
         idx = torch.empty(2, N, 4, dtype=torch.int32, device=img.device)
     rc = _lib.load().rgbd_warp_loss_fwd(_ptr(img), _ptr(img_rot), _ptr(coef), b, S, int(flags),
                                         float(lambda_geometric), float(max_depth), float(min_depth),
+                                        float(hinge_lambda), float(hinge_min),
                                         _ptr(partials), _ptr(loss), _ptr(zp), _ptr(warped), _ptr(idx), _stream())
     _lib.check(rc, "rgbd_warp_loss_fwd")
     return (loss, zp, warped, idx) if debug else loss
 
 
-def warp_loss_bwd(img, img_rot, coef, flags, lambda_geometric, max_depth, min_depth, grad_loss):
+def warp_loss_bwd(img, img_rot, coef, flags, lambda_geometric, max_depth, min_depth, grad_loss, hinge_lambda=0.0,
+                  hinge_min=0.0, grad_scale=1.0, out=None):
+    """-> (grad_img, grad_img_rot).  grad_loss: (1,) fp32 device tensor or None (= 1), times the host factor grad_scale.
+    out = (gimg, gimg_rot): ACCUMULATE into these buffers instead of returning fresh ones."""
     _chk(grad_loss, F32, "grad_loss")
     b, _, S, _ = img.shape
-    gimg = torch.empty_like(img)
-    gimg_rot = torch.empty_like(img_rot)
+    if out is None:
+        gimg, gimg_rot, acc = torch.empty_like(img), torch.empty_like(img_rot), 0
+    else:
+        gimg, gimg_rot, acc = out[0], out[1], 1
+        _chk(gimg, F32, "out[0]"); _chk(gimg_rot, F32, "out[1]")
+        if gimg.shape != img.shape or gimg_rot.shape != img_rot.shape:
+            raise RuntimeError("warp_loss_bwd: accumulation buffers must have the images' shape")
     rc = _lib.load().rgbd_warp_loss_bwd(_ptr(img), _ptr(img_rot), _ptr(coef), b, S, int(flags),
                                         float(lambda_geometric), float(max_depth), float(min_depth),
-                                        _ptr(grad_loss), _ptr(gimg), _ptr(gimg_rot), _stream())
+                                        float(hinge_lambda), float(hinge_min), _ptr(grad_loss), float(grad_scale),
+                                        _ptr(gimg), _ptr(gimg_rot), acc, _stream())
     _lib.check(rc, "rgbd_warp_loss_bwd")
     return gimg, gimg_rot
 
@@ -400,13 +412,25 @@ def linear_fwd(x, w, bias, c, act, slope=0.2):
     return y
 
 
-def linear_bwd(dy, y, x, w, c, act, want_dx=True, dw=None, db=None, slope=0.2):
-    """Returns dx (or None); accumulates into dw / db when given."""
-    for t, n in ((dy, "dy"), (y, "y"), (x, "x"), (w, "w"), (dw, "dw"), (db, "db")):
-        _chk(t, F32, n)
+def linear_fwd_masked(x, w, mask_y, c, slope=0.2):
+    """(c * x w^T) * lrelu'(mask_y): x (M,K), w (N,K), mask_y (M,N) an activation OUTPUT -> (M,N)."""
+    _chk(x, F32, "x"); _chk(w, F32, "w"); _chk(mask_y, F32, "mask_y")
     M, K = x.shape
     N = w.shape[0]
-    dx = torch.empty(M, K, dtype=F32, device=x.device) if want_dx else None
+    y = torch.empty(M, N, dtype=F32, device=x.device)
+    rc = _lib.load().rgbd_linear_fwd_masked(_ptr(x), _ptr(w), _ptr(mask_y), _ptr(y), M, K, N, float(c), float(slope),
+                                            _stream())
+    _lib.check(rc, "rgbd_linear_fwd_masked")
+    return y
+
+
+def linear_bwd(dy, y, x, w, c, act, want_dx=True, dw=None, db=None, slope=0.2):
+    """Returns dx (or None); accumulates into dw / db when given.  x may be None when dw is."""
+    for t, n in ((dy, "dy"), (y, "y"), (x, "x"), (w, "w"), (dw, "dw"), (db, "db")):
+        _chk(t, F32, n)
+    M = dy.shape[0]
+    N, K = w.shape
+    dx = torch.empty(M, K, dtype=F32, device=dy.device) if want_dx else None
     rc = _lib.load().rgbd_linear_bwd(_ptr(dy), _ptr(y), _ptr(x), _ptr(w), _ptr(dx), _ptr(dw), _ptr(db), M, K, N,
                                      float(c), int(bool(act)), float(slope), 0, _stream())
     _lib.check(rc, "rgbd_linear_bwd")
@@ -414,52 +438,10 @@ def linear_bwd(dy, y, x, w, c, act, want_dx=True, dw=None, db=None, slope=0.2):
 
 
 # ------------------------------------------------------------------ AdaIN
-class _ZeroArena:
-    """Zero-initialised fp32 scratch handed out in slices while a training phase is active.
-
-    Kernels that accumulate with atomics (the AdaIN strip sums) need cleared memory; inside `with zero_arena.phase(dev)`
-    ONE clear of the arena's used prefix replaces one clear per call.  The clear covers the high-water mark of all
-    earlier phases, which has converged by the time a phase is captured into a HIP graph (two eager runs come first),
-    so every captured phase clears at least what it uses.  Outside a phase `take` returns fresh zeros."""
-
-    def __init__(self, nfloats=1 << 21):
-        self.nfloats = nfloats
-        self.buf, self.high, self.pos, self.active = {}, {}, {}, {}
-
-    def _key(self, device):
-        device = torch.device(device)
-        key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
-        if key not in self.buf:
-            self.buf[key] = torch.zeros(self.nfloats, dtype=F32, device=device)
-            self.high[key], self.pos[key], self.active[key] = 0, 0, False
-        return key
-
-    def phase(self, device):
-        arena, key = self, self._key(device)
-
-        class _Phase:
-            def __enter__(self_):
-                if arena.high[key] > 0:
-                    rc = _lib.load().rgbd_zero_f32(_ptr(arena.buf[key]), arena.high[key], _stream())
-                    _lib.check(rc, "rgbd_zero_f32")
-                arena.pos[key], arena.active[key] = 0, True
-
-            def __exit__(self_, *exc):
-                arena.active[key] = False
-        return _Phase()
-
-    def take(self, n, device):
-        key = self._key(device)
-        n4 = (n + 3) // 4 * 4
-        if not self.active[key] or self.pos[key] + n4 > self.nfloats:
-            return torch.zeros(n, dtype=F32, device=device)
-        out = self.buf[key][self.pos[key]:self.pos[key] + n]
-        self.pos[key] += n4
-        self.high[key] = max(self.high[key], self.pos[key])
-        return out
-
-
-zero_arena = _ZeroArena()
+def _adain_workspace(B, HW, C, device):
+    """Strip-partial sums of the AdaIN kernels (ceil(HW/1024), B, C, 2): plain stores, summed in index order by the second
+    launch -- no atomics and no clearing, so the statistics are bit-reproducible."""
+    return torch.empty(_lib.load().rgbd_adain_workspace(B, HW, C), dtype=F32, device=device)
 
 
 def _off(t, nfloats):
@@ -480,7 +462,7 @@ def adain_fwd(x, scale, shift=None, eps=1e-5, col_off=0):
     elif scale.shape != (B, C):
         raise RuntimeError(f"adain_fwd: scale {tuple(scale.shape)} does not match x {tuple(x.shape)}")
     y = torch.empty_like(x)
-    sums = zero_arena.take(B * C * 2, x.device)
+    sums = _adain_workspace(B, H * W, C, x.device)
     mean = torch.empty(B, C, dtype=F32, device=x.device)
     rstd = torch.empty(B, C, dtype=F32, device=x.device)
     rc = _lib.load().rgbd_adain_fwd(_ptr(x), _off(scale, col_off) if fused else _ptr(scale),
@@ -499,7 +481,7 @@ def adain_bwd(x, dy, scale, mean, rstd, fused=False, col_off=0, out=None, lrelu_
     _chk(bias_grad, F32, "bias_grad")
     B, H, W, C = x.shape
     dx = torch.empty_like(x)
-    sums = zero_arena.take(B * C * 2, x.device)
+    sums = _adain_workspace(B, H * W, C, x.device)
     if fused:
         ld = scale.shape[1]
         dss = out if out is not None else torch.empty(B, ld, dtype=F32, device=x.device)
@@ -570,6 +552,117 @@ def ema_update(dst, src, tau):
     if dst.numel() != src.numel():
         raise RuntimeError("ema_update: size mismatch")
     _lib.check(_lib.load().rgbd_ema_update(_ptr(dst), _ptr(src), dst.numel(), float(tau), _stream()), "rgbd_ema_update")
+
+
+# ------------------------------------------------------------------ fused step ops (csrc/step_ops.hip)
+def real_batch(data_u8, idx, size, alpha=None, out=None):
+    """data (N,C,H,W) uint8, idx (B) int64 on the device -> (B,C,size,size) fp32: block means of data[idx]/127.5 - 1
+    (downsize_real, even stage); alpha (device scalar tensor or float): the fade-in blend of an odd stage."""
+    if data_u8.dtype != torch.uint8 or not data_u8.is_cuda or not data_u8.is_contiguous():
+        raise RuntimeError("real_batch: expected a contiguous uint8 GPU tensor")
+    _chk(idx, torch.int64, "idx")
+    N, C, H, W = data_u8.shape
+    B = idx.numel()
+    if out is None:
+        out = torch.empty(B, C, size, size, dtype=F32, device=data_u8.device)
+    _chk(out, F32, "out")
+    if tuple(out.shape) != (B, C, size, size):
+        raise RuntimeError(f"real_batch: out {tuple(out.shape)} != {(B, C, size, size)}")
+    fade = alpha is not None
+    a_dev = alpha if torch.is_tensor(alpha) else None
+    _chk(a_dev, F32, "alpha")
+    rc = _lib.load().rgbd_real_batch_u8(_ptr(data_u8), _ptr(idx), _ptr(out), B, C, H, W, int(size), int(fade), _ptr(a_dev),
+                                        float(alpha) if fade and a_dev is None else 0.0, _stream())
+    _lib.check(rc, "rgbd_real_batch_u8")
+    return out
+
+
+def zero_multi(tensors):
+    """Clear up to 8 contiguous fp32 tensors per launch."""
+    tensors = [t for t in tensors if t is not None and t.numel() > 0]
+    lib = _lib.load()
+    for i in range(0, len(tensors), 8):
+        group = tensors[i:i + 8]
+        for t in group:
+            _chk(t, F32, "zero_multi")
+        ptrs = (ctypes.c_void_p * len(group))(*[t.data_ptr() for t in group])
+        counts = (ctypes.c_int64 * len(group))(*[t.numel() for t in group])
+        _lib.check(lib.rgbd_zero_multi_f32(ptrs, counts, len(group), _stream()), "rgbd_zero_multi_f32")
+
+
+def hidden_normalize(z, ch, copies=1):
+    """z (M,C) fp32 N(0,1) draws -> (copies*M, C): z / sqrt(sum_c z^2 / ch + 1e-8), repeated `copies` times."""
+    _chk(z, F32, "z")
+    M, C = z.shape
+    out = torch.empty(copies * M, C, dtype=F32, device=z.device)
+    _lib.check(_lib.load().rgbd_hidden_normalize(_ptr(z), _ptr(out), M, C, float(ch), int(copies), _stream()),
+               "rgbd_hidden_normalize")
+    return out
+
+
+def r1_penalty_fwd(g, coef):
+    """g (B, ...) fp32 -> (1,) = coef * mean_b (sqrt(sum g_b^2))^2."""
+    _chk(g, F32, "g")
+    B = g.shape[0]
+    ws = torch.empty(16 * B, dtype=F32, device=g.device)
+    loss = torch.empty(1, dtype=F32, device=g.device)
+    _lib.check(_lib.load().rgbd_r1_penalty_fwd(_ptr(g), B, g.numel() // B, float(coef), _ptr(ws), _ptr(loss), _stream()),
+               "rgbd_r1_penalty_fwd")
+    return loss
+
+
+def scale_by_scalar(x, scalar, k):
+    """(scalar[0] * k) * x with `scalar` a device tensor (or None = 1)."""
+    _chk(x, F32, "x"); _chk(scalar, F32, "scalar")
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().rgbd_scale_by_scalar_f32(_ptr(x), _ptr(scalar), float(k), _ptr(out), x.numel(), _stream()),
+               "rgbd_scale_by_scalar_f32")
+    return out
+
+
+def image_grad_init(gx, ratio, planes_out):
+    """gx (B,KP,H,W) fp32, ratio (B,) or None -> (B,planes_out,H,W): ratio[b] * gx on the first KP planes, zeros after."""
+    _chk(gx, F32, "gx"); _chk(ratio, F32, "ratio")
+    B, KP, H, W = gx.shape
+    out = torch.empty(B, planes_out, H, W, dtype=F32, device=gx.device)
+    _lib.check(_lib.load().rgbd_image_grad_init(_ptr(gx), _ptr(ratio), _ptr(out), B, KP, planes_out, H * W, _stream()),
+               "rgbd_image_grad_init")
+    return out
+
+
+def const_input_fwd(w, bias, B, slope=0.2):
+    """w (C,H,W), bias (C) fp32 -> (B,H,W,C) bf16 = lrelu(w + bias) for every sample."""
+    _chk(w, F32, "w"); _chk(bias, F32, "bias")
+    C, H, W = w.shape
+    out = torch.empty(B, H, W, C, dtype=BF16, device=w.device)
+    _lib.check(_lib.load().rgbd_const_input_fwd(_ptr(w), _ptr(bias), _ptr(out), B, H * W, C, float(slope), _stream()),
+               "rgbd_const_input_fwd")
+    return out
+
+
+def const_input_bwd(dh, w, bias, dw, db, slope=0.2):
+    """Accumulates into dw (C,H,W) / db (C) (either may be None)."""
+    _chk(dh, BF16, "dh"); _chk(w, F32, "w"); _chk(bias, F32, "bias"); _chk(dw, F32, "dw"); _chk(db, F32, "db")
+    B, H, W, C = dh.shape
+    _lib.check(_lib.load().rgbd_const_input_bwd(_ptr(dh), _ptr(w), _ptr(bias), _ptr(dw), _ptr(db), B, H * W, C,
+                                                float(slope), _stream()), "rgbd_const_input_bwd")
+
+
+def nhwc_to_rows(h):
+    """(B,H,W,C) bf16 -> (B, C*H*W) fp32 rows in (c,h,w) order."""
+    _chk(h, BF16, "h")
+    B, H, W, C = h.shape
+    out = torch.empty(B, C * H * W, dtype=F32, device=h.device)
+    _lib.check(_lib.load().rgbd_nhwc_to_rows_f32(_ptr(h), _ptr(out), B, H * W, C, _stream()), "rgbd_nhwc_to_rows_f32")
+    return out
+
+
+def rows_to_nhwc(rows, H, W, C):
+    _chk(rows, F32, "rows")
+    B = rows.shape[0]
+    out = torch.empty(B, H, W, C, dtype=BF16, device=rows.device)
+    _lib.check(_lib.load().rgbd_rows_to_nhwc_bf16(_ptr(rows), _ptr(out), B, H * W, C, _stream()), "rgbd_rows_to_nhwc_bf16")
+    return out
 
 
 # ------------------------------------------------------------------ optimizer

@@ -212,9 +212,7 @@ class StyleGenerator(_Link):
         else:
             style = self._style
         if i == 0:
-            const = p[pre + "/W"].permute(1, 2, 0).unsqueeze(0)                  # (1,4,4,ch)
-            h = Fn.lrelu(const + p[pre + "/b0/b"]).to(BF16).expand(w.shape[0], 4, 4, self.chans[0][1])
-            h = h.contiguous()
+            h = Fn.const_input(p[pre + "/W"], p[pre + "/b0/b"], w.shape[0])      # lrelu(W + b0), (B,4,4,ch) bf16
         elif styles is not None:      # conv -> bias -> lrelu -> style as one node (fused backward)
             h = Fn.conv_bias_lrelu_adain(x, self.c0[i], p[pre + "/b0/b"], *styles[(i, "s0")], upsample=True)
         else:
@@ -304,8 +302,16 @@ class StyleGANGenerator(_Link):
 
     def make_hidden(self, batch_size):
         """net.py:333-343; drawn on the device (the reference draws with cupy when on GPU)."""
-        z = torch.randn(batch_size, self.ch * 2, 1, 1, device=self.device)
-        return z / torch.sqrt(torch.sum(z * z, dim=1, keepdim=True) / self.ch + 1e-8)
+        from . import kernels
+        z = torch.randn(batch_size, self.ch * 2, device=self.device)
+        return kernels.hidden_normalize(z, self.ch).reshape(batch_size, self.ch * 2, 1, 1)
+
+    def make_hidden_pairs(self, half):
+        """The step's latent batch (updater.py:300: the same `half` latents for both views of every pair) in one launch
+        after the draw: rows [0, half) and [half, 2 half) are identical."""
+        from . import kernels
+        z = torch.randn(half, self.ch * 2, device=self.device)
+        return kernels.hidden_normalize(z, self.ch, copies=2).reshape(2 * half, self.ch * 2, 1, 1)
 
     def __call__(self, z, stage, theta=None, return_feature=False):
         z = _as_device_tensor(z, self.device).reshape(-1, 2 * self.ch)
@@ -455,14 +461,17 @@ class Discriminator(_Link):
         pre = f"blocks/{i}"
         if i == 0:
             h = Fn.conv_bias_lrelu(x, self.conv[pre + "/c0"], p[pre + "/c0/c/b"])
-            # 4x4 valid conv == linear over (c,h,w).  The ACTIVATION (0.5 MB) is brought into the weight's own
-            # (ci,kh,kw) order, not the 4 MB weight into NHWC order: no weight copy forward, and the weight gradient
-            # comes out in the master layout
+            # 4x4 valid conv == linear over (c,h,w) (net.py:363-365,372-377).  The ACTIVATION (0.5 MB) is brought into
+            # the weight's own (ci,kh,kw) order as fp32 rows, not the 4 MB weight into NHWC order: no weight copy forward,
+            # and the weight gradient comes out in the master layout.  Both layers run on the small-batch fp32 MFMA
+            # linear kernels (rgbd_linear_*), twice differentiable for the R1 penalty; batches above 64 rows in slices.
             W = p[pre + "/c1/c/W"]
-            hf = h.float().permute(0, 3, 1, 2).reshape(h.shape[0], -1)
-            h = F.linear(hf * _inv_c(W.shape[1] * 16), W.reshape(W.shape[0], -1), p[pre + "/c1/c/b"])
-            h = Fn.lrelu(h)
-            return F.linear(h * _inv_c(self.ch, 1.0), p[pre + "/l2/c/W"], p[pre + "/l2/c/b"])
+            rows = Fn.nhwc_to_rows(h)
+            outs = []
+            for r0 in range(0, rows.shape[0], 64):
+                u = Fn.dense(rows[r0:r0 + 64], W, p[pre + "/c1/c/b"], _inv_c(W.shape[1] * 16), act=True)
+                outs.append(Fn.dense(u, p[pre + "/l2/c/W"], p[pre + "/l2/c/b"], _inv_c(self.ch, 1.0), act=False))
+            return outs[0] if len(outs) == 1 else torch.cat(outs)
         # net.py:408-426: h = lrelu(c0 x); h = lrelu(c1 h + c_sc x); avg-pool.  Bias, shortcut add and activation
         # all ride in the conv epilogues; the 2x2 average pool and its backward are fused with the activation gradient.
         tie = Fn.ResidualTie(p[pre + "/c_sc/c/b"]) if self.res else None

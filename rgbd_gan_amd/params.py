@@ -108,10 +108,17 @@ class ParamStore:
             self._fused[key] = (p, off)
         return self._fused[key][0]
 
-    def zero_grad(self):
-        self.grad.zero_()
-        if self.grad_alt is not None:
-            self.grad_alt.zero_()
+    def zero_grad(self, defer=None):
+        """Clear the flat gradient buffer(s).  defer: a list -- the buffers are appended to it instead of cleared here,
+        so the caller can clear the buffers of several stores with one launch (kernels.zero_multi)."""
+        if defer is not None:
+            defer.append(self.grad)
+            if self.grad_alt is not None:
+                defer.append(self.grad_alt)
+        else:
+            self.grad.zero_()
+            if self.grad_alt is not None:
+                self.grad_alt.zero_()
         for name, p in self.params.items():
             g = p.grad
             if g is None or g.data_ptr() != self.grad.data_ptr() + 4 * self.offsets[name]:

@@ -7,7 +7,7 @@ import torch
 
 from .net import DCGANGenerator, Discriminator, StyleGANGenerator
 from .optimizer import FlatAdam
-from .updater import CameraParamPrior, RGBDUpdater
+from .updater import CameraParamPrior, RGBDUpdater, RGBUpdater
 
 
 def setup_generator(config, device, seed=0):
@@ -101,6 +101,11 @@ class DeviceImageIterator:
         return order.to(self.data.device)
 
     def next(self):
+        return self.data[self.next_indices()].to(torch.float32) / 127.5 - 1
+
+    def next_indices(self):
+        """Indices (device int64) of the next batch: the updater gathers, normalises and down-sizes them in one kernel
+        (rgbd_real_batch_u8) instead of materialising the fp32 batch here."""
         n = self.data.shape[0]
         idx = self._order[self._pos:self._pos + self.batch_size]
         self._pos += self.batch_size
@@ -111,7 +116,7 @@ class DeviceImageIterator:
             if rest > 0:
                 idx = torch.cat([idx, self._order[:rest]])
             self._pos = rest
-        return self.data[idx].to(torch.float32) / 127.5 - 1
+        return idx
 
     __next__ = next
 
@@ -127,6 +132,8 @@ def build_training(config, device, comm=None, iterator=None, **updater_kwargs):
         from .updater_deepvoxels import DeepVoxelsUpdater as Updater
         for k in ("graph_phases", "fixed_stage", "concurrent_phases", "defer_dfake_wgrads"):
             updater_kwargs.pop(k, None)
+    elif config.rgb:                                               # train_rgbd.py:357-358
+        Updater = RGBUpdater
     else:
         Updater = RGBDUpdater
     updater = Updater(models=models, config=config, optimizer=optimizer, iterator=iterator,

@@ -147,6 +147,8 @@ class _HostStager:
 
 
 class RGBDUpdater:
+    camera_conditioned = True       # RGBUpdater: no pose input, no 3-D consistency loss
+
     def __init__(self, models, config, **kwargs):
         if len(models) == 2:
             models = list(models) + [None]
@@ -188,7 +190,7 @@ class RGBDUpdater:
         # in that arrangement D's weight gradients for the fakes (leaves of the backward graph) are moved from the
         # longer generator chain to the tail of the side stream
         self.defer_dfake_wgrads = bool(kwargs.pop("defer_dfake_wgrads", not os.environ.get("RGBD_NO_DEFER")))
-        self._graphs, self._eager_calls, self._stagers = {}, {}, {}
+        self._graphs, self._eager_calls, self._stagers, self._ones = {}, {}, {}, {}
         self.device = self.gen.device
 
     # ---- chainer StandardUpdater surface
@@ -247,7 +249,7 @@ class RGBDUpdater:
     #      sequence)
     def _gen_phase(self, st):
         """G forward, the one pass through D(x_fake), G backward -- as one phase (sequential arrangement)."""
-        with kernels.zero_arena.phase(self.device), _alpha_ctx(st):
+        with _alpha_ctx(st):
             self._gen_phase_body(st)
             self._gen_phase_tail(st)
 
@@ -256,23 +258,35 @@ class RGBDUpdater:
         gradients for the fakes are only COLLECTED here (st['dfw']): they run on the other stream (_dfw_phase) once the
         discriminator phase there has finished, instead of lengthening this stream's dependent chain."""
         st["dfw"] = []
-        with kernels.zero_arena.phase(self.device), _alpha_ctx(st), Fn.deferred_wgrads(st["dfw"]):
+        with _alpha_ctx(st), Fn.deferred_wgrads(st["dfw"]):
             self._gen_phase_body(st)
 
     def _gen_b_phase(self, st):
-        with kernels.zero_arena.phase(self.device), _alpha_ctx(st):
+        with _alpha_ctx(st):
             self._gen_phase_tail(st)
 
     def _dfw_phase(self, st):
         Fn.run_deferred_wgrads(st["dfw"])
 
     def _prep_phase(self, st):
-        """Everything both concurrent phases depend on: cleared gradient buffers, the down-sized real batch, and the
+        """Everything both concurrent phases depend on: cleared gradient buffers, the (down-sized) real batch, and the
         bf16 weight images of both networks (repacked here so neither phase does it behind the other's back)."""
-        self.gen.cleargrads()
-        self.dis.cleargrads()
-        with torch.no_grad():
-            st["x_real"] = downsize_real(st["x_real_full"], st["stage"]).contiguous()
+        bufs = []
+        for link in (self.gen, self.dis):
+            for _, store in link.stores:
+                store.zero_grad(defer=bufs)
+        kernels.zero_multi(bufs)                                   # one launch for all flat gradient buffers
+        if st.get("real_idx") is not None:
+            # the uint8 data set lives in HBM: gather + x/127.5 - 1 + downsize_real (block means, fade-in blend) in ONE
+            # kernel (train_rgbd.py:308-310, common/utils/pggan.py:6-50)
+            fl = math.floor(min(st["stage"], 17 - 1e-8))
+            alpha = None
+            if fl % 2 == 1:
+                alpha = st["alpha"] if st.get("alpha") is not None else float(min(st["stage"], 17 - 1e-8) - fl)
+            st["x_real"] = kernels.real_batch(st["real_data"], st["real_idx"], downsized_size(st["stage"]), alpha)
+        else:
+            with torch.no_grad():
+                st["x_real"] = downsize_real(st["x_real_full"], st["stage"]).contiguous()
         for link in (getattr(self.gen, "gen", self.gen), self.dis):
             group = getattr(link, "pack_group", None)
             if group is not None:
@@ -285,8 +299,11 @@ class RGBDUpdater:
         if st["z"] is not None:
             z = st["z"]
         else:
-            z_half = self.get_z_fake_data(half)
-            z = torch.cat([z_half, z_half], dim=0)                          # same latent for both views
+            if hasattr(self.gen, "make_hidden_pairs"):
+                z = self.gen.make_hidden_pairs(half)                        # same latent for both views, one launch
+            else:
+                z_half = self.get_z_fake_data(half)
+                z = torch.cat([z_half, z_half], dim=0)
         x_fake = self.gen(z, stage, st["theta9"])
         # D(x_fake) is evaluated and differentiated ONCE per step.  The reference runs the discriminator on the same
         # fakes twice with identical weights (updater.py:331,404-405) and back-propagates twice: once from the
@@ -307,31 +324,40 @@ class RGBDUpdater:
                     for _, store in self.dis.stores:
                         stack.enter_context(store.alt_grads())
                 torch.autograd.backward([y_fake], [seed_d], inputs=[x_d] + list(self.dis.params()))
-            gx = x_d.grad * ratio.reshape(-1, 1, 1, 1)
+            gx = x_d.grad                   # d loss_dis / d x_fake; times ratio_b = the generator's adversarial gradient
+            st["ratio"] = ratio.reshape(-1).contiguous()
             st["loss_dfake"] = heads[1]                                     # fake term of loss_func_dcgan_dis
         else:
             with Fn.weight_grads_frozen(self.dis):
                 gx, = torch.autograd.grad([y_fake], [x_d], [seed_g])
+            st["ratio"] = None
             st["loss_dfake"] = None
         st["gx"], st["x_fake"] = gx, x_fake
 
     def _gen_phase_tail(self, st):
-        """3-D consistency loss, depth hinge and the generator's backward from (gx, those losses)."""
+        """3-D consistency loss, depth hinge and the generator's backward.  The output gradient of G is assembled by
+        hand, not by autograd: rgbd_image_grad_init writes the adversarial part (per-sample ratio * dL_D/dx_fake on the
+        RGB planes, zeros on the depth plane), the warp-loss backward ADDS lambda_rotate * d(loss_rotate)/dx_fake with
+        the depth hinge of updater.py:357-359 evaluated in the same two kernels, and x_fake.backward(that) runs G's
+        backward: 4 launches where slicing, hinge, scaling and the gradient sums were ~25."""
         cfg, obs = self.config, self.observation
-        x_fake, gx, half = st["x_fake"], st["gx"], st["B"] // 2
-        heads, seeds = [x_fake[:, :3]], [gx]
+        x_fake, half = st["x_fake"], st["B"] // 2
+        gout = kernels.image_grad_init(st["gx"].contiguous(), st["ratio"], x_fake.shape[1])
         if st["use_rotate"]:
-            loss_rotate = self.loss_func_rotate.loss_from_coefficients(x_fake[:half], x_fake[half:], st["coef"],
-                                                                       st["occlusion"])
             if cfg.rotate_feature:
                 raise AssertionError("rotate_feature is not supported")
-            if cfg.lambda_depth > 0:
-                loss_rotate = loss_rotate + torch.mean(F.relu(cfg.depth_min - x_fake[:, -1]) ** 2) * cfg.lambda_depth
-            obs["gen/loss_rotate"] = loss_rotate.detach()
+            lf = self.loss_func_rotate
+            flags = 1 if st["occlusion"] else 0                      # loss_functions.WARP_OCCLUSION
+            hinge = float(cfg.lambda_depth) if cfg.lambda_depth > 0 else 0.0
             lambda_rotate = cfg.lambda_rotate if cfg.lambda_rotate else 2
             lambda_rotate = lambda_rotate if st["x_real"].shape[2] <= 128 else lambda_rotate * 2
-            heads.append(loss_rotate * lambda_rotate)
-            seeds.append(None)
+            xf = x_fake.detach()
+            loss_rotate = kernels.warp_loss_fwd(xf[:half], xf[half:], st["coef"], flags, lf.lambda_geometric,
+                                                hinge_lambda=hinge, hinge_min=float(cfg.depth_min or 0.0))
+            obs["gen/loss_rotate"] = loss_rotate.reshape(())
+            kernels.warp_loss_bwd(xf[:half], xf[half:], st["coef"], flags, lf.lambda_geometric, 0.0, 0.0, None,
+                                  hinge_lambda=hinge, hinge_min=float(cfg.depth_min or 0.0),
+                                  grad_scale=float(lambda_rotate), out=(gout[:half], gout[half:]))
             if cfg.use_occupancy_net_loss:
                 raise AssertionError("occupancy-net loss is not supported")
         if cfg.optical_flow:
@@ -341,10 +367,10 @@ class RGBDUpdater:
         if not os.environ.get("RGBD_NO_G_DEFER"):       # (+2 % step rate, A/B on one box)
             wgrads = []
             with Fn.deferred_wgrads(wgrads):
-                torch.autograd.backward(heads, seeds)
+                torch.autograd.backward([x_fake], [gout])
             Fn.run_deferred_wgrads(wgrads)
         else:
-            torch.autograd.backward(heads, seeds)
+            torch.autograd.backward([x_fake], [gout])
         st["x_fake_data"] = x_fake.detach()
         st["x_fake"] = st["gx"] = None                 # drop the autograd graph
 
@@ -380,17 +406,22 @@ class RGBDUpdater:
             # the ordinary way.
             seed = real_heads[1]                                            # d mean softplus(-y_real) / dy
         if r1:
+            ones = self._ones.get(tuple(y_real.shape))
+            if ones is None:
+                ones = self._ones[tuple(y_real.shape)] = torch.ones_like(y_real)
             with Fn.input_grads_only(), (Fn.adversarial_injection(seed) if inject else contextlib.nullcontext()):
-                grad_x, = torch.autograd.grad([y_real.sum()], [x_real_v], create_graph=True)
-            grad_l2 = torch.sqrt(torch.sum(grad_x ** 2, dim=(1, 2, 3)))
-            loss_gp = self.lambda_gp * loss_l2(grad_l2, 0.0)
+                grad_x, = torch.autograd.grad([y_real], [x_real_v], [ones], create_graph=True)   # chainer.grad seeds ones
+            # updater.py:416-418 + loss_functions.py:7-8: lambda * mean_b (sqrt(sum g_b^2))^2, one reduction
+            loss_gp = Fn.r1_penalty(grad_x, self.lambda_gp)
             obs["dis/loss_gp"] = loss_gp.detach()
             reported = reported + loss_gp.detach()
         st["dis_reported"] = reported
         if inject:
             torch.autograd.backward([y_real], [seed], inputs=self.dis.tail_params(), retain_graph=True)
             with Fn.adversarial_injection(seed):
-                loss_gp.backward()
+                # d loss_gp / d grad_x = 2 lambda / B * grad_x, handed to the double backward directly
+                ggx = kernels.scale_by_scalar(grad_x.detach().contiguous(), None, 2.0 * self.lambda_gp / grad_x.shape[0])
+                torch.autograd.backward([grad_x], [ggx])
             return
         loss_dis = torch.sum(F.softplus(-y_real)) / y_real.numel()
         if y_fake is not None:
@@ -466,23 +497,43 @@ class RGBDUpdater:
         opt_g_g = self.get_optimizer("gen")
         opt_d = self.get_optimizer("dis")
         stage = self.stage
-        if batch is None:
-            batch = self.get_iterator("main").next()
-        batch_size = len(batch)
+        real_idx = real_data = None
+        it = self.get_iterator("main") if batch is None else None
+        if it is not None and hasattr(it, "next_indices") and it.data.shape[1] == 3 and it.data.shape[2] == it.data.shape[3]:
+            # data set resident in HBM: only the batch's indices move; the gather + normalise + down-size is one kernel
+            # of the prep phase (reading the indices from a fixed buffer, so the phase can be replayed as a graph)
+            idx = it.next_indices()
+            batch_size = int(idx.numel())
+            key_i = ("real_idx", batch_size)
+            if key_i not in self._stagers:
+                self._stagers[key_i] = torch.empty(batch_size, dtype=torch.int64, device=self.device)
+            self._stagers[key_i].copy_(idx)
+            real_idx, real_data = self._stagers[key_i], it.data
+            x_real_data = None
+            full_shape = (batch_size,) + tuple(it.data.shape[1:])
+        else:
+            if batch is None:
+                batch = it.next()
+            batch_size = len(batch)
+            x_real_data = self.get_x_real_data(batch, batch_size)
+            full_shape = tuple(x_real_data.shape)
         half = batch_size // 2
-        x_real_data = self.get_x_real_data(batch, batch_size)
 
         # ---- host side, NumPy, exactly as the reference: pose prior, camera matrices, pose code, warp constants
-        if thetas is None:
-            thetas = self.prior.sample(batch_size)
-        thetas = np.asarray(thetas, dtype="float32")
-        random_camera_matrices = get_camera_matries(thetas)                 # (B,4,4) fp32
-        theta9 = np.concatenate([np.cos(thetas[:, :3]), np.sin(thetas[:, :3]), thetas[:, 3:]], axis=1).astype("float32")
-        use_rotate = self.iteration > cfg.start_rotation
-        occlusion = self.iteration >= cfg.start_occlusion_aware
+        if self.camera_conditioned:
+            if thetas is None:
+                thetas = self.prior.sample(batch_size)
+            thetas = np.asarray(thetas, dtype="float32")
+            random_camera_matrices = get_camera_matries(thetas)             # (B,4,4) fp32
+            theta9 = np.concatenate([np.cos(thetas[:, :3]), np.sin(thetas[:, :3]), thetas[:, 3:]],
+                                    axis=1).astype("float32")
+            use_rotate = self.iteration > cfg.start_rotation
+            occlusion = self.iteration >= cfg.start_occlusion_aware
+        else:                                     # RGBUpdater (updater.py:504-589): the prior is never sampled
+            theta9, use_rotate, occlusion = None, False, False
         st = {"stage": stage, "B": batch_size, "use_rotate": use_rotate, "occlusion": occlusion,
-              "x_real_full": x_real_data, "z": None}
-        st["theta9"] = self._stager("theta9", (batch_size, 9)).upload(theta9)
+              "x_real_full": x_real_data, "z": None, "real_idx": real_idx, "real_data": real_data}
+        st["theta9"] = self._stager("theta9", (batch_size, 9)).upload(theta9) if theta9 is not None else None
         if use_rotate:
             image_size = downsized_size(stage)
             coef = self.loss_func_rotate.coefficients_for_size(image_size, random_camera_matrices[:half],
@@ -506,13 +557,14 @@ class RGBDUpdater:
                 # captured phases read (net.alpha_override); the launch sequence depends on floor(stage) only
                 alpha = float(min(stage, 17 - 1e-8) - fl)
                 st["alpha"] = self._stager("alpha", (1,)).upload(np.array([alpha], dtype="float32"))[0]
-            # graphs read their inputs from fixed addresses: park the batch in a persistent buffer
-            skey = ("x_real_full",) + tuple(x_real_data.shape)
-            if skey not in self._stagers:
-                self._stagers[skey] = torch.empty_like(x_real_data)
-            self._stagers[skey].copy_(x_real_data)
-            st["x_real_full"] = self._stagers[skey]
-            key = (batch_size, fl, use_rotate, occlusion, tuple(x_real_data.shape), z_fake_data is not None)
+            if x_real_data is not None:
+                # graphs read their inputs from fixed addresses: park the batch in a persistent buffer
+                skey = ("x_real_full",) + tuple(x_real_data.shape)
+                if skey not in self._stagers:
+                    self._stagers[skey] = torch.empty_like(x_real_data)
+                self._stagers[skey].copy_(x_real_data)
+                st["x_real_full"] = self._stagers[skey]
+            key = (batch_size, fl, use_rotate, occlusion, full_shape, z_fake_data is not None, real_idx is not None)
 
         # the recorded D(x_fake) forward may only be shared when both phases run the same way (both replayed from
         # graphs captured in the same iteration, or both eager)
@@ -563,3 +615,12 @@ class RGBDUpdater:
         obs["stage"], obs["batch_size"], obs["image_size"] = stage, batch_size, int(st["x_real"].shape[2])
         if self.nan_check_interval > 0 and (self.iteration + 1) % self.nan_check_interval == 0:
             self._check_finite()
+
+
+class RGBUpdater(RGBDUpdater):
+    """updater.py:451-589 of the reference (selected by `config.rgb`, train_rgbd.py:357-358): the same generator step +
+    discriminator step + R1 without camera poses -- the generator is called as gen(z, stage) and produces 3 channels,
+    there is no 3-D consistency loss and no depth hinge, and the pose prior is never sampled.  Everything else (single
+    pass through D(x_fake), injection of the adversarial seeds into the R1 double backward, graphs, two streams, data
+    parallel all-reduce) is RGBDUpdater's."""
+    camera_conditioned = False

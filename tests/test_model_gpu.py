@@ -254,6 +254,57 @@ def test_full_training_step_matches_oracle(stage):
     assert agree > 0.9
 
 
+def test_rgb_updater_step_matches_oracle():
+    """config.rgb (train_rgbd.py:357-358): RGBUpdater = generator without pose input or depth channel, adversarial + R1
+    terms only (updater.py:504-589).  One step at stage 8 (64x64) against the bf16-emulating oracle."""
+    from rgbd_gan_amd.net import Discriminator, StyleGANGenerator
+    from rgbd_gan_amd.optimizer import FlatAdam
+    from rgbd_gan_amd.updater import RGBUpdater
+    from rgbd_gan_amd.utils.yaml_utils import Config
+    gp = nets.init_stylegan(CH, seed=4, rgbd=False)
+    dp = nets.init_discriminator(CH, seed=5)
+    gen = StyleGANGenerator(CH, rgbd=False)
+    dis = Discriminator(CH, res=True)
+    gen.load_state_dict(gp)
+    dis.load_state_dict(dp)
+    assert "l1/c/W" not in gen.gen.store and gen.gen.store["outs/4/c/W"].shape == (3, 128, 1, 1)
+    z, _, x_real = _inputs(4, seed=9)
+    stage, iteration = 8.0, 200000
+    gpl = {k: v.clone().requires_grad_(True) for k, v in gp.items()}
+    dpl = {k: v.clone().requires_grad_(True) for k, v in dp.items()}
+    omap = {k: v for k, v in gpl.items() if k.startswith("mapping/")}
+    ogen = {k: v for k, v in gpl.items() if k.startswith("gen/")}
+    oopt = {"map": step.ChainerAdam(omap, 1e-5), "gen": step.ChainerAdam(ogen, 1e-3), "dis": step.ChainerAdam(dpl, 3e-3)}
+    with nets.bf16_emulation():
+        ref = step.rgbd_step(gpl, dpl, oopt, x_real, z, None, stage, CFG, iteration, camera=False)
+    cfg = Config(dict(generator_architecture="stylegan", stage_interval="0,0,0,0,0,0,0,100000,150000,160000,180000,300000",
+                      max_stage=11, start_rotation=2000, start_occlusion_aware=2000, lambda_depth=10, depth_min=1.0,
+                      x_rotate=0.3054, y_rotate=1.0472, z_rotate=0, x_translate=0, y_translate=0, z_translate=0,
+                      bigan=False, rgb=True))
+    opt = {"map": FlatAdam(gen.mapping.store, 1e-5), "gen": FlatAdam(gen.gen.store, 1e-3), "dis": FlatAdam(dis.store, 3e-3)}
+
+    class NoPrior:
+        def sample(self, n):
+            raise AssertionError("RGBUpdater must not sample the pose prior")
+    upd = RGBUpdater(models=[gen, dis], config=cfg, optimizer=opt, iterator=None, lambda_gp=1.0, smoothing=0.999,
+                     total_gpu=1, prior=NoPrior(), fixed_stage=stage)
+    upd.iteration = iteration
+    upd.update_core(batch=torch.from_numpy(x_real), z_fake_data=torch.from_numpy(z))
+    obs = {k: float(v) for k, v in upd.observation.items() if torch.is_tensor(v)}
+    assert "gen/loss_rotate" not in obs
+    for key in ("gen/loss_adv", "dis/loss_gp", "dis/loss_adv"):
+        assert abs(obs[key] - ref[key]) < 2e-3 * max(1.0, abs(ref[key])), (key, obs[key], ref[key])
+    assert tuple(ref["x_fake"].shape) == (4, 3, 64, 64)
+    for k, o in (("norm_map", opt["map"]), ("norm_gen", opt["gen"]), ("norm_dis", opt["dis"])):
+        assert abs(float(o.grad_norm) - ref[k]) < 1e-2 * ref[k], (k, float(o.grad_norm), ref[k])
+    for store, prefix, src in ((gen.gen.store, "gen/", gpl), (dis.store, "", dpl)):
+        for n in store.names:
+            b = src[prefix + n].grad
+            if b is None or float(b.norm()) == 0.0 or b.numel() < 4096:
+                continue
+            assert cosine(store[n].grad.cpu(), b) > 0.999, (prefix + n, cosine(store[n].grad.cpu(), b))
+
+
 @pytest.mark.parametrize("schedule", ["even stage", "fade-in"])
 def test_graph_replay_matches_eager_steps(schedule):
     """The captured-and-replayed step (HIP graphs: G phase, D phase, optimizer phase) is the same computation as the

@@ -1,0 +1,220 @@
+"""The small fused ops of the training step (rgbd_gan_amd/csrc/step_ops.hip and the ABI-4 additions to the warp-loss,
+AdaIN and linear kernels) against the oracle / the unfused compositions they replace.  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import nets, step, warp_loss
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_real_batch_kernel_is_transform_plus_downsize_real():
+    """train_rgbd.py:308-310 (x / 127.5 - 1) + common/utils/pggan.py:6-50 (downsize_real): even stages and fade-in
+    stages, alpha from a device scalar, against the oracle's restatement on the same uint8 images."""
+    from rgbd_gan_amd import kernels
+    rng = np.random.RandomState(0)
+    data = rng.randint(0, 256, (20, 3, 128, 128)).astype("uint8")
+    idx = np.array([3, 17, 0, 9, 9, 12])
+    dd, di = torch.from_numpy(data).to(DEV), torch.from_numpy(idx).to(DEV)
+    x = torch.from_numpy(data[idx].astype("float32") / 127.5 - 1)
+    for stage, size in ((10.0, 128), (8.0, 64), (6.0, 32), (2.0, 8)):
+        got = kernels.real_batch(dd, di, size).cpu()
+        ref = nets.downsize_real(x, stage)
+        assert got.shape == ref.shape
+        torch.testing.assert_close(got, ref, atol=2e-6, rtol=0)
+    for stage, size in ((9.25, 128), (7.5, 64), (5.9, 32)):
+        alpha = stage - int(stage)
+        ref = nets.downsize_real(x, stage)
+        got = kernels.real_batch(dd, di, size, alpha=torch.tensor(alpha, dtype=torch.float32, device=DEV)).cpu()
+        torch.testing.assert_close(got, ref, atol=2e-6, rtol=0)
+        got = kernels.real_batch(dd, di, size, alpha=alpha).cpu()
+        torch.testing.assert_close(got, ref, atol=2e-6, rtol=0)
+    # identity at full resolution: exactly the transform
+    got = kernels.real_batch(dd, di, 128).cpu()
+    assert float((got - x).abs().max()) <= 6e-8 * 2
+
+
+def test_zero_multi_and_hidden_normalize():
+    from rgbd_gan_amd import kernels
+    bufs = [torch.randn(n, device=DEV) for n in (8, 4096, 526336, 12, 100004)]
+    kernels.zero_multi(bufs)
+    assert all(float(b.abs().max()) == 0.0 for b in bufs)
+    bufs = [torch.randn(16 * (i + 1), device=DEV) for i in range(11)]         # more than one launch group
+    kernels.zero_multi(bufs)
+    assert all(float(b.abs().max()) == 0.0 for b in bufs)
+    z = torch.randn(5, 512, device=DEV)
+    out = kernels.hidden_normalize(z, 256.0, copies=2).cpu()
+    zc = z.cpu().numpy()
+    ref = zc / np.sqrt(np.sum(zc * zc, axis=1, keepdims=True) / 256 + 1e-8)      # net.py:333-343
+    np.testing.assert_allclose(out[:5].numpy(), ref, rtol=2e-6, atol=1e-7)
+    assert torch.equal(out[:5], out[5:])
+
+
+def test_r1_penalty_kernel_and_gradient():
+    from rgbd_gan_amd import functional as Fn
+    g = torch.randn(6, 3, 64, 64, device=DEV) * 0.3
+    gc = g.cpu().clone().requires_grad_(True)
+    norm = torch.sqrt((gc ** 2).sum(dim=(1, 2, 3)))
+    ref = 1.5 * ((norm - 0.0) ** 2).sum() / norm.numel()                          # step.r1_penalty's tail
+    ref.backward()
+    gd = g.clone().requires_grad_(True)
+    got = Fn.r1_penalty(gd, 1.5)
+    (got * 0.7).backward()
+    assert abs(float(got) - float(ref)) < 1e-5 * float(ref)
+    torch.testing.assert_close(gd.grad.cpu(), 0.7 * gc.grad, rtol=1e-5, atol=1e-9)
+
+
+def test_image_grad_init():
+    from rgbd_gan_amd import kernels
+    gx = torch.randn(4, 3, 16, 16, device=DEV)
+    ratio = torch.tensor([-1.0, -0.5, -2.0, -1e3], device=DEV)
+    out = kernels.image_grad_init(gx, ratio, 4)
+    assert torch.equal(out[:, :3], gx * ratio.reshape(-1, 1, 1, 1)) and float(out[:, 3].abs().max()) == 0.0
+    assert torch.equal(kernels.image_grad_init(gx, None, 3), gx)
+
+
+def test_const_input_forward_backward():
+    from rgbd_gan_amd import functional as Fn
+    C, B = 256, 6
+    w = torch.randn(C, 4, 4, device=DEV, requires_grad=True)
+    b = torch.randn(C, device=DEV, requires_grad=True)
+    h = Fn.const_input(w, b, B)
+    assert h.shape == (B, 4, 4, C) and h.dtype == torch.bfloat16
+    wr, br = w.detach().cpu().requires_grad_(True), b.detach().cpu().requires_grad_(True)
+    ref = F.leaky_relu(wr + br.reshape(-1, 1, 1), 0.2).permute(1, 2, 0).unsqueeze(0).expand(B, 4, 4, C)
+    torch.testing.assert_close(h.float().cpu(), ref.to(torch.bfloat16).float(), rtol=0, atol=0)
+    dh = torch.randn(B, 4, 4, C, device=DEV).to(torch.bfloat16)
+    h.backward(dh)
+    ref.backward(dh.float().cpu())
+    torch.testing.assert_close(w.grad.cpu(), wr.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(b.grad.cpu(), br.grad, rtol=1e-5, atol=1e-4)
+
+
+def test_nhwc_rows_roundtrip_and_adjoint():
+    from rgbd_gan_amd import kernels
+    h = torch.randn(5, 4, 4, 256, device=DEV).to(torch.bfloat16)
+    rows = kernels.nhwc_to_rows(h)
+    torch.testing.assert_close(rows.cpu(), h.float().permute(0, 3, 1, 2).reshape(5, -1).cpu(), rtol=0, atol=0)
+    assert torch.equal(kernels.rows_to_nhwc(rows, 4, 4, 256), h)
+
+
+@pytest.mark.parametrize("B", [4, 32, 70])
+def test_dense_tail_twice_differentiable(B):
+    """The discriminator's dense tail (net.py:372-377: 4x4-valid conv as a linear, leaky ReLU, output linear) on the HIP
+    linear kernels: forward, input gradient, weight gradients, and the R1 pattern -- gradient of ||d y / d x||^2 w.r.t.
+    the weights (double backward) -- against torch autograd on the same fp32 math."""
+    from rgbd_gan_amd import functional as Fn
+    C = 256
+    c1, c2 = float(np.sqrt(2) / np.sqrt(C * 16)), float(1 / np.sqrt(C))
+    g = torch.Generator().manual_seed(B)
+    W1 = torch.randn(C, C, 4, 4, generator=g)
+    b1 = torch.randn(C, generator=g) * 0.1
+    W2 = torch.randn(1, C, generator=g)
+    b2 = torch.randn(1, generator=g)
+    x = torch.randn(B, C * 16, generator=g)
+
+    def run(dev, dense):
+        ps = [t.clone().to(dev).requires_grad_(True) for t in (W1, b1, W2, b2)]
+        for p in ps:
+            p.grad = torch.zeros_like(p)
+        xx = x.clone().to(dev).requires_grad_(True)
+        outs = []
+        for r0 in range(0, B, 64):
+            u = dense(xx[r0:r0 + 64], ps[0], ps[1], c1, True)
+            outs.append(dense(u, ps[2], ps[3], c2, False))
+        y = torch.cat(outs)
+        gx, = torch.autograd.grad([y], [xx], [torch.ones_like(y)], create_graph=True)
+        pen = (gx ** 2).sum() / B
+        (pen + (y * torch.linspace(-1, 1, B, device=dev).reshape(-1, 1)).sum()).backward()
+        return y.detach().cpu(), gx.detach().cpu(), [p.grad.cpu() for p in ps], xx.grad.cpu()
+
+    def ref_dense(xx, w, b, c, act):
+        y = F.linear(xx * c, w.reshape(w.shape[0], -1), b)
+        return F.leaky_relu(y, 0.2) if act else y
+
+    y_r, gx_r, gp_r, xg_r = run("cpu", ref_dense)
+    y_d, gx_d, gp_d, xg_d = run(DEV, Fn.dense)
+    torch.testing.assert_close(y_d, y_r, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(gx_d, gx_r, rtol=1e-4, atol=1e-6)
+    for a, b in zip(gp_d, gp_r):
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(xg_d, xg_r, rtol=2e-4, atol=2e-6)
+
+
+def _warp_inputs(b, S, seed):
+    from oracle import camera
+    rng = np.random.RandomState(seed)
+    x = rng.uniform(-1, 1, (2 * b, 4, S, S)).astype("float32")
+    x[:, 3] = rng.uniform(0.7, 1.3, (2 * b, S, S))
+    th = rng.uniform(-0.3, 0.3, (2 * b, 6)).astype("float32")
+    th[:, 2] = 0
+    th[:, 3:] *= 0.1
+    cams = camera.camera_matrices(th)
+    K, inv_K, _ = warp_loss.intrinsics(S)
+    R, t = warp_loss.relative_pose(cams[:b], cams[b:])
+    A, c, A2, c2 = warp_loss.warp_coefficients(K, inv_K, R, t)
+    coef = np.concatenate([A.reshape(b, 9), c, A2.reshape(b, 9), c2], axis=1).astype("float32")
+    return x, cams, coef
+
+
+@pytest.mark.parametrize("b,S", [(2, 16), (3, 32)])
+def test_warp_loss_with_fused_hinge_and_accumulation(b, S):
+    """ABI 4: the depth hinge of updater.py:357-359 evaluated inside the warp-loss kernels, and the backward ADDING
+    lambda_rotate * d loss into a buffer that already holds the adversarial image gradient -- against the oracle's
+    autograd on loss_rotate + hinge."""
+    from rgbd_gan_amd import kernels
+    x, cams, coef = _warp_inputs(b, S, seed=5)
+    lam_geo, lam_depth, dmin, lam_rot = 2.0, 10.0, 1.0, 2.0
+    xt = torch.from_numpy(x).requires_grad_(True)
+    ref, _ = warp_loss.loss_torch(xt[:b], cams[:b], xt[b:], cams[b:], occlusion_aware=True, lambda_geometric=lam_geo)
+    ref = ref + step.depth_hinge(xt, dmin, lam_depth)
+    (ref * lam_rot).backward()
+    xd = torch.from_numpy(x).to(DEV)
+    cf = torch.from_numpy(coef).to(DEV)
+    loss = kernels.warp_loss_fwd(xd[:b], xd[b:], cf, 1, lam_geo, hinge_lambda=lam_depth, hinge_min=dmin)
+    assert abs(float(loss) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+    base = torch.randn(2 * b, 4, S, S, device=DEV)
+    gout = base.clone()
+    kernels.warp_loss_bwd(xd[:b], xd[b:], cf, 1, lam_geo, 0.0, 0.0, None, hinge_lambda=lam_depth, hinge_min=dmin,
+                          grad_scale=lam_rot, out=(gout[:b], gout[b:]))
+    torch.testing.assert_close((gout - base).cpu(), xt.grad, rtol=1e-4, atol=1e-7)
+    # hinge off + no accumulation = the ABI-3 behaviour
+    l0 = kernels.warp_loss_fwd(xd[:b], xd[b:], cf, 1, lam_geo)
+    assert float(l0) < float(loss)
+
+
+def test_adain_statistics_are_bit_reproducible():
+    """Strip partial sums are plain stores added in index order (no atomics): the same input gives the same bits."""
+    from rgbd_gan_amd import kernels
+    x = torch.randn(4, 128, 128, 64, device=DEV).to(torch.bfloat16)
+    ss = torch.randn(4, 128, device=DEV)
+    dy = torch.randn(4, 128, 128, 64, device=DEV).to(torch.bfloat16)
+    runs = []
+    for _ in range(3):
+        y, mean, rstd = kernels.adain_fwd(x, ss)
+        dx, dss, _ = kernels.adain_bwd(x, dy, ss, mean, rstd, fused=True)
+        runs.append((y, mean, rstd, dx, dss))
+    for r in runs[1:]:
+        for a, b in zip(r, runs[0]):
+            assert torch.equal(a, b)
+    xf = x.float()
+    m = xf.mean(dim=(1, 2))
+    torch.testing.assert_close(runs[0][1], m, rtol=1e-4, atol=1e-5)
+
+
+def test_generator_forward_is_bit_reproducible():
+    from rgbd_gan_amd.net import StyleGANGenerator
+    from oracle import camera
+    gen = StyleGANGenerator(256, rgbd=True)
+    rng = np.random.RandomState(0)
+    zh = nets.make_hidden(2, 256, rng)
+    z = np.concatenate([zh, zh])
+    np.random.seed(1)
+    t9 = camera.theta9(camera.PosePrior(0.3054, 1.0472, 0).sample(4))
+    with torch.no_grad():
+        a = gen(z, 10.0, t9)
+        b = gen(z, 10.0, t9)
+    assert torch.equal(a, b)
