@@ -31,6 +31,7 @@ if ROOT not in sys.path:
 # so it EXECUTES 3 F_G + 7 F_D; the whole-step roofline fraction is reported on executed work.
 STEP_GFLOP_PER_IMAGE = 296.6 - 4 * 24.11
 MFMA_BF16_PEAK_TFLOPS = 2500.0
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
 def parse():
@@ -203,6 +204,7 @@ def main():
         raise RuntimeError(f"process group reports {comm.size} ranks, WORLD_SIZE={world}")
 
     config = yaml_utils.load(args.config)
+    deepvoxels = config.generator_architecture == "deepvoxels"      # BASELINE config 4: DeepVoxelsUpdater, 64x64, B=10
     B = args.batch or config.batchsize
     np.random.seed(2 + comm.rank)
     torch.manual_seed(comm.rank)
@@ -244,43 +246,63 @@ def main():
         "metric": "img/s (G+D+3D-loss step) at 128x128", "value": round(value, 2), "unit": "img/s",
         "n_gpus": comm.size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"{os.path.basename(args.config)} stage {upd.stage:.2f} (128x128), RGBDUpdater.update_core, "
-                               f"StyleGAN ch={config.ch}, rotation+occlusion loss on, R1 on",
+        "config": {"workload": (f"{os.path.basename(args.config)} stage {upd.stage:.2f} (64x64), DeepVoxelsUpdater.update_core, "
+                                f"voxel generator 32^3 x 32 features -> frustum 56x64x64 -> occlusion compositing -> 2-D "
+                                f"renderer, rotation loss on, R1 on") if deepvoxels else
+                               (f"{os.path.basename(args.config)} stage {upd.stage:.2f} (128x128), RGBDUpdater.update_core, "
+                                f"StyleGAN ch={config.ch}, rotation+occlusion loss on, R1 on"),
                    "per_gpu_batch": B, "global_batch": B * comm.size, "parallelism": f"dp{comm.size}"},
         "host_enqueue_ms_per_step": round(t_burst / burst * 1e3, 3),
         "host_enqueue_note": f"wall time of the launch thread per step over a {burst}-step burst after a sync (no queue "
                              f"back-pressure); over the timed loop it was {t_enqueue / args.steps * 1e3:.3f} ms",
-        "step_tflops_algorithmic": round(value * STEP_GFLOP_PER_IMAGE / 1e3, 2),
-        "mfma_roofline_frac_whole_step": round(value * STEP_GFLOP_PER_IMAGE / 1e3 / (MFMA_BF16_PEAK_TFLOPS * comm.size), 4),
     }
+    if deepvoxels:
+        line["metric"] = "img/s (G+D+3D-loss step) at 64x64, DeepVoxels generator"
+    else:
+        line["step_tflops_algorithmic"] = round(value * STEP_GFLOP_PER_IMAGE / 1e3, 2)
+        line["mfma_roofline_frac_whole_step"] = round(value * STEP_GFLOP_PER_IMAGE / 1e3 / (MFMA_BF16_PEAK_TFLOPS * comm.size), 4)
 
     if comm.rank == 0 and not args.no_roofline:
         # per-launch HIP-event timing of the conv kernels over extra (untimed) steps, on the launch stream
         # (eager launches: graph replays bypass the Python wrappers that record the events; one stream: with the
         # two-stream phase overlap an event pair would also time the other stream's kernels sharing the CUs)
-        upd.use_graphs, was_concurrent, upd.concurrent_phases = False, upd.concurrent_phases, False
+        was_graphs, was_concurrent = upd.use_graphs, getattr(upd, "concurrent_phases", False)
+        upd.use_graphs, upd.concurrent_phases = False, False
         with kernels.launch_profile() as prof:
             for _ in range(2):
                 upd.update()
         summ = prof.summary()
-        upd.use_graphs, upd.concurrent_phases = True, was_concurrent
+        upd.use_graphs, upd.concurrent_phases = was_graphs, was_concurrent
         table = {k: {"launches": n, "ms": round(t * 1e3, 3), "tflops": round(f / t / 1e12, 1),
                      "avg_us": round(t / n * 1e6, 1), "gbps": round(b / t / 1e9, 1)} for k, (n, t, f, b) in summ.items()}
-        dom = max(summ, key=lambda k: summ[k][1])
-        n, t, f, b = summ[dom]
-        traffic, provenance = pmc_traffic(dom)
-        line["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(f / t / 1e12, 2),
-                            "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(f / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
-                            "traffic": traffic, "traffic_provenance": provenance, "launches": n,
-                            "avg_launch_us": round(t / n * 1e6, 2), "flops_per_launch_avg": f / n,
-                            "timing": "HIP events on the launch stream around every launch of this kernel in 2 extra "
-                                      "eager single-stream steps after the timed region"}
+        timing = ("HIP events on the launch stream around every launch of this kernel in 2 extra eager single-stream "
+                  "steps after the timed region")
+        if deepvoxels:
+            # the path's own kernels are the HBM-bound frustum resampling / occlusion compositing (SURVEY.md section 8(d):
+            # 4.2 MB read + 29.4 MB written per sample, ~2 x 29.4 MB per sample); the conv stack is shared with config 2
+            hbm = {k: v for k, v in summ.items() if k.startswith(("trilinear", "occlusion"))}
+            dom = max(hbm, key=lambda k: hbm[k][1])
+            n, t, f, b = hbm[dom]
+            traffic, provenance = pmc_traffic(dom)
+            line["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(b / t / 1e9, 1), "peak": HBM_PEAK_GBPS,
+                                "unit": "GB/s", "frac": round(b / t / 1e9 / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                                "traffic_provenance": provenance, "launches": n, "avg_launch_us": round(t / n * 1e6, 2),
+                                "bytes_per_launch_avg": b / n, "timing": timing}
+        else:
+            dom = max(summ, key=lambda k: summ[k][1])
+            n, t, f, b = summ[dom]
+            traffic, provenance = pmc_traffic(dom)
+            line["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(f / t / 1e12, 2),
+                                "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(f / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                                "traffic": traffic, "traffic_provenance": provenance, "launches": n,
+                                "avg_launch_us": round(t / n * 1e6, 2), "flops_per_launch_avg": f / n, "timing": timing}
         line["kernels"] = table
         line["kernels_note"] = "per-kernel totals over the 2 extra eager steps of the roofline leg, not per step"
     elif comm.size > 1 and not args.no_roofline:
         for _ in range(2):                      # keep ranks in lock-step with rank 0's extra steps
             upd.update()
-    if comm.rank == 0 and comm.size == 1 and not args.no_cpu_baseline:
+    if comm.rank == 0 and comm.size == 1 and not args.no_cpu_baseline and not deepvoxels:
         line["cpu_baseline"] = cpu_baseline()
     if comm.rank == 0:
         print(json.dumps(line), file=json_out, flush=True)

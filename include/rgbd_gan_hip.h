@@ -202,15 +202,16 @@ int rgbd_pool2_masked(const void* x, const void* y, void* out, int B, int H, int
  *   rgbd_from_planes: y[b,p,co] = act(wscale * sum_k w[co][k] x[b,k,p] + bias[co])   -- Discriminator.ins, net.py:449-455
  *   rgbd_to_planes  : out[b,k,p] = wscale * sum_c w[k][c] h[b,p,c] + bias[k]           -- StyleGenerator.outs, net.py:186-191
  *                     (also the input gradient of from_planes with w transposed)
- *   rgbd_planes_outer: o[k][c] = sum_{b,p} planes[b,k,p] * t[b,p,c]; tsum[c] = sum t   -- their weight / bias gradients
- * w is fp32, row-major as written; bias / tsum may be NULL.
+ *   rgbd_planes_outer: o[k][c] = sum_{b,p} planes[b,k,p] * t[b,p,c]; tsum[c] = sum t   -- their weight / bias gradients;
+ *                     psum[k] += sum_{b,p} planes[b,k,p] (ADDED: it is to_rgb's bias gradient buffer; o / tsum are overwritten)
+ * w is fp32, row-major as written; bias / tsum / psum may be NULL.
  */
 int rgbd_from_planes(const float* x, const float* w, const float* bias, void* y, int B, int HW, int KP, int C,
                      float wscale, int act, float slope, void* stream);
 int rgbd_to_planes(const void* h, const float* w, const float* bias, float* out, int B, int HW, int KP, int C,
                    float wscale, void* stream);
-int rgbd_planes_outer(const void* t, const float* planes, float* o, float* tsum, int B, int HW, int KP, int C,
-                      void* stream);
+int rgbd_planes_outer(const void* t, const float* planes, float* o, float* tsum, float* psum, int B, int HW, int KP,
+                      int C, void* stream);
 
 /* ------------------------------------------------------------------ small equalized-LR linear layers (M <= 64 rows, fp32)
  * Replace pggan.py:39-50 (EqualizedLinear = scale + L.Linear) + F.leaky_relu for the mapping MLP (net.py:58-62), the

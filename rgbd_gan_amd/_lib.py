@@ -42,7 +42,7 @@ PROTOTYPES = {
     "rgbd_pool2_masked": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P], c_int),
     "rgbd_from_planes": ([_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, c_float, _P], c_int),
     "rgbd_to_planes": ([_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P], c_int),
-    "rgbd_planes_outer": ([_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P], c_int),
+    "rgbd_planes_outer": ([_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P], c_int),
     "rgbd_linear_fwd": ([_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_float, _P], c_int),
     "rgbd_linear_fwd_masked": ([_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P], c_int),
     "rgbd_real_batch_u8": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_float, _P], c_int),

@@ -631,18 +631,22 @@ __global__ __launch_bounds__(256) void to_planes_kernel(const unsigned short* __
 }
 
 // planes_outer: o[k][c] += sum_pix p[b,k,pix] * t[b,pix,c] (fp32 atomics; o zeroed by the caller), plus
-// tsum[c] += sum_pix t[b,pix,c] when tsum != NULL.  Weight (and bias) gradients of from_rgb / to_rgb.
+// tsum[c] += sum_pix t[b,pix,c] when tsum != NULL and psum[k] += sum_pix p[b,k,pix] when psum != NULL (NOT zeroed: it is
+// the bias gradient buffer of to_rgb).  Weight (and bias) gradients of from_rgb / to_rgb.
 template <int KP>
 __global__ __launch_bounds__(256) void planes_outer_kernel(const unsigned short* __restrict__ t,
                                                            const float* __restrict__ p, float* __restrict__ o,
-                                                           float* __restrict__ tsum, int B, int HW, int C,
-                                                           int rows_per_block) {
+                                                           float* __restrict__ tsum, float* __restrict__ psum, int B,
+                                                           int HW, int C, int rows_per_block) {
     const int cg = blockIdx.y, b = blockIdx.z;
     const int chunk = threadIdx.x & 7, lane_p = threadIdx.x >> 3;
     const int c0 = cg * 64 + chunk * 8;
     const int r_begin = blockIdx.x * rows_per_block;
     const int r_end = min(HW, r_begin + rows_per_block);
     float acc[KP + 1][8];
+    float ps[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) ps[k] = 0.f;
 #pragma unroll
     for (int k = 0; k <= KP; ++k)
 #pragma unroll
@@ -669,9 +673,23 @@ __global__ __launch_bounds__(256) void planes_outer_kernel(const unsigned short*
                 for (int j = 0; j < 8; ++j) acc[k][j] += pv[u][k] * f[j];
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[KP][j] += f[j];
+#pragma unroll
+            for (int k = 0; k < KP; ++k) ps[k] += pv[u][k];
         }
     }
     __shared__ float red[32][65];
+    if (psum && cg == 0) {               // plane sums: the rows of this block once (chunk 0's lanes hold every row once)
+        if (chunk == 0) {
+#pragma unroll
+            for (int k = 0; k < KP; ++k) red[lane_p][k] = ps[k];
+        }
+        __syncthreads();
+        if (threadIdx.x < KP) {
+            float a2 = 0.f;
+            for (int r = 0; r < 32; ++r) a2 += red[r][threadIdx.x];
+            atomicAdd(psum + threadIdx.x, a2);
+        }
+    }
     for (int k = 0; k <= KP; ++k) {
         if (k == KP && !tsum) break;
         __syncthreads();
@@ -1118,8 +1136,8 @@ extern "C" int rgbd_to_planes(const void* h, const float* w, const float* bias, 
     return 0;
 }
 
-extern "C" int rgbd_planes_outer(const void* t, const float* p, float* o, float* tsum, int B, int HW, int KP, int C,
-                                 void* stream) {
+extern "C" int rgbd_planes_outer(const void* t, const float* p, float* o, float* tsum, float* psum, int B, int HW, int KP,
+                                 int C, void* stream) {
     RGBD_REQUIRE(t && p && o, "rgbd_planes_outer: null pointer");
     RGBD_REQUIRE((KP == 3 || KP == 4) && C % 64 == 0 && B > 0 && HW > 0, "rgbd_planes_outer: bad shape KP=%d C=%d", KP, C);
     hipStream_t st = (hipStream_t)stream;
@@ -1130,8 +1148,8 @@ extern "C" int rgbd_planes_outer(const void* t, const float* p, float* o, float*
     }
     const int rows = 512;
     dim3 grid(ceil_div(HW, rows), C / 64, B);
-    if (KP == 3) planes_outer_kernel<3><<<grid, 256, 0, st>>>((const unsigned short*)t, p, o, tsum, B, HW, C, rows);
-    else         planes_outer_kernel<4><<<grid, 256, 0, st>>>((const unsigned short*)t, p, o, tsum, B, HW, C, rows);
+    if (KP == 3) planes_outer_kernel<3><<<grid, 256, 0, st>>>((const unsigned short*)t, p, o, tsum, psum, B, HW, C, rows);
+    else         planes_outer_kernel<4><<<grid, 256, 0, st>>>((const unsigned short*)t, p, o, tsum, psum, B, HW, C, rows);
     RGBD_CHECK_LAUNCH("planes_outer_kernel");
     return 0;
 }

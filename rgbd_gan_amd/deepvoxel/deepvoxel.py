@@ -4,7 +4,7 @@ import numpy as np
 import torch
 
 from .. import _lib
-from ..kernels import _ptr, _stream
+from ..kernels import _ptr, _stream, _timed
 
 OCC_NF = 4
 
@@ -15,8 +15,10 @@ class _Trilinear(torch.autograd.Function):
         grid = grid.contiguous()
         B, F, G = grid.shape[0], grid.shape[1], grid.shape[2]
         out = torch.empty(B, F, N, dtype=torch.float32, device=grid.device)
-        rc = _lib.load().rgbd_trilinear_fwd(_ptr(grid), _ptr(idx), _ptr(coords), _ptr(counts), _ptr(out), B, F, G, N,
-                                            _stream())
+        # algorithmic bytes: the grid read once + the resampled frustum written once
+        rc = _timed("trilinear_fwd_kernel", 0.0, 4.0 * B * F * (G ** 3 + N),
+                    lambda: _lib.load().rgbd_trilinear_fwd(_ptr(grid), _ptr(idx), _ptr(coords), _ptr(counts), _ptr(out),
+                                                           B, F, G, N, _stream()))
         _lib.check(rc, "rgbd_trilinear_fwd")
         ctx.save_for_backward(idx, coords, counts)
         ctx.dims = (B, F, G, N)
@@ -29,8 +31,10 @@ class _Trilinear(torch.autograd.Function):
         B, F, G, N = ctx.dims
         dgrid = torch.empty(B, F, G, G, G, dtype=torch.float32, device=dout.device)
         ws = torch.empty(B * G * G * G * F, dtype=torch.float32, device=dout.device)
-        rc = _lib.load().rgbd_trilinear_bwd(_ptr(dout.contiguous()), _ptr(idx), _ptr(coords), _ptr(counts), _ptr(dgrid),
-                                            _ptr(ws), B, F, G, N, _stream())
+        dout = dout.contiguous()
+        rc = _timed("trilinear_bwd_kernel", 0.0, 4.0 * B * F * (G ** 3 + N),
+                    lambda: _lib.load().rgbd_trilinear_bwd(_ptr(dout), _ptr(idx), _ptr(coords), _ptr(counts), _ptr(dgrid),
+                                                           _ptr(ws), B, F, G, N, _stream()))
         _lib.check(rc, "rgbd_trilinear_bwd")
         return dgrid, None, None, None, None
 
@@ -65,9 +69,12 @@ class _OcclusionAccum(torch.autograd.Function):
         feat = torch.empty(B, F, H, W, dtype=torch.float32, device=dev)
         depth = torch.empty(B, 1, H, W, dtype=torch.float32, device=dev)
         W1c, b1c, W2c, b2c = (t.contiguous() for t in (W1, b1, W2, b2))
-        rc = _lib.load().rgbd_occlusion_accum_fwd(_ptr(vol), _ptr(W1c), _ptr(b1c), _ptr(W2c), _ptr(b2c), float(threshold),
-                                                  float(voxel_size), float(near_plane), _ptr(s), _ptr(w), _ptr(feat),
-                                                  _ptr(depth), B, F, D, H * W, _stream())
+        # algorithmic bytes: the volume read once, s / w (saved for backward) and the composited planes written once
+        rc = _timed("occlusion_accum_fwd_kernel", 0.0, 4.0 * B * H * W * (F * D + 2 * D + F + 1),
+                    lambda: _lib.load().rgbd_occlusion_accum_fwd(_ptr(vol), _ptr(W1c), _ptr(b1c), _ptr(W2c), _ptr(b2c),
+                                                                 float(threshold), float(voxel_size), float(near_plane),
+                                                                 _ptr(s), _ptr(w), _ptr(feat), _ptr(depth), B, F, D,
+                                                                 H * W, _stream()))
         _lib.check(rc, "rgbd_occlusion_accum_fwd")
         ctx.save_for_backward(vol, W1c, b1c, W2c, s, w)
         ctx.voxel_size = float(voxel_size)
@@ -84,10 +91,13 @@ class _OcclusionAccum(torch.autograd.Function):
         dvol = torch.empty_like(vol)
         nparams = OCC_NF * (F + 1) + 2 * OCC_NF + 1
         dparams = torch.empty((nparams + 3) // 4 * 4, dtype=torch.float32, device=dev)
-        rc = _lib.load().rgbd_occlusion_accum_bwd(_ptr(vol), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(s), _ptr(w),
-                                                  _ptr(dfeat.contiguous()), _ptr(ddepth.contiguous()), ctx.voxel_size,
-                                                  _ptr(dw_ws), _ptr(ds_ws), _ptr(dvol), _ptr(dparams), B, F, D, H * W,
-                                                  _stream())
+        dfeat, ddepth = dfeat.contiguous(), ddepth.contiguous()
+        # algorithmic bytes: the volume read, its gradient written, s / w read, the plane gradients read
+        rc = _timed("occlusion_accum_bwd_kernel", 0.0, 4.0 * B * H * W * (2 * F * D + 2 * D + F + 1),
+                    lambda: _lib.load().rgbd_occlusion_accum_bwd(_ptr(vol), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(s), _ptr(w),
+                                                                 _ptr(dfeat), _ptr(ddepth), ctx.voxel_size, _ptr(dw_ws),
+                                                                 _ptr(ds_ws), _ptr(dvol), _ptr(dparams), B, F, D, H * W,
+                                                                 _stream()))
         _lib.check(rc, "rgbd_occlusion_accum_bwd")
         n1 = OCC_NF * (F + 1)
         return (dvol, dparams[:n1].reshape(OCC_NF, F + 1), dparams[n1:n1 + OCC_NF],

@@ -733,6 +733,7 @@ class _ToPlanes(torch.autograd.Function):
     def forward(ctx, h, w, bias, scale, inj_x=None, inj_bias=None):
         h = h.contiguous()
         ctx.scale, ctx.has_bias = scale, bias is not None
+        ctx.bias_ref = bias
         ctx.inj_x, ctx.inj_bias = inj_x, inj_bias
         ctx.save_for_backward(h, w)
         return kernels.to_planes(h, w.contiguous(), bias.contiguous() if bias is not None else None, scale)
@@ -753,19 +754,32 @@ class _ToPlanes(torch.autograd.Function):
                     if not _direct_grad(b):
                         raise RuntimeError("adversarial injection needs bias gradients bound to the flat buffer")
                     kernels.colsum(h, out=b.grad, row_scale=_INJECT, rows_per_sample=h.shape[1] * h.shape[2])
-            o, _ = _PlanesOuter.apply(h, operand.contiguous(), False)
+            # the bias gradient sum_{b,p} dout rides in the same kernel (straight into the bound gradient buffer): a
+            # torch reduction here is a multi-block kernel with a memset-initialised semaphore, and memset nodes are
+            # unreliable on replays of a captured HIP graph (ROCm 7.2) -- found by the graph == eager step test
+            bias = ctx.bias_ref
+            want_b = ctx.has_bias and ctx.needs_input_grad[2] and not _skip_grad_of(bias)
+            psum = None
+            if want_b and _INJECT is None:
+                psum = bias.grad if _direct_grad(bias) else torch.zeros(dout.shape[1], dtype=torch.float32,
+                                                                        device=dout.device)
+            o, _ = _PlanesOuter.apply(h, operand.contiguous(), False, psum)
             dw = o * ctx.scale
-        if ctx.has_bias and ctx.needs_input_grad[2] and not _skip_grad_of(w):
+            if want_b and psum is not None and not _direct_grad(bias):
+                db = psum
+            elif want_b and psum is None:
+                db = dout.sum(dim=(0, 2, 3))
+        elif ctx.has_bias and ctx.needs_input_grad[2] and not _skip_grad_of(ctx.bias_ref):
             db = dout.sum(dim=(0, 2, 3))
         return dh, dw, db, None, None, None
 
 
 class _PlanesOuter(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, t, planes, want_tsum):
-        o, ts = kernels.planes_outer(t.contiguous(), planes.contiguous(), want_tsum)
+    def forward(ctx, t, planes, want_tsum, psum=None):
+        o, ts = kernels.planes_outer(t.contiguous(), planes.contiguous(), want_tsum, psum)
         if ts is None:
-            ts = o.new_zeros(())
+            ts = o.new_empty(())          # placeholder output, never read (no fill launch)
         return o, ts
 
     @staticmethod

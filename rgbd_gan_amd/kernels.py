@@ -387,14 +387,15 @@ def to_planes(h, w, bias, wscale):
     return out
 
 
-def planes_outer(t, planes, want_tsum=False):
-    """t (B,H,W,C) bf16, planes (B,KP,H,W) fp32 -> o (KP,C) fp32 [, tsum (C,) fp32]."""
-    _chk(t, BF16, "t"); _chk(planes, F32, "planes")
+def planes_outer(t, planes, want_tsum=False, psum=None):
+    """t (B,H,W,C) bf16, planes (B,KP,H,W) fp32 -> o (KP,C) fp32 [, tsum (C,) fp32]; psum (KP,) fp32, if given, has the
+    plane sums sum_{b,p} planes[b,k,p] ADDED to it."""
+    _chk(t, BF16, "t"); _chk(planes, F32, "planes"); _chk(psum, F32, "psum")
     B, H, W, C = t.shape
     KP = planes.shape[1]
     o = torch.empty(KP, C, dtype=F32, device=t.device)
     ts = torch.empty(C, dtype=F32, device=t.device) if want_tsum else None
-    rc = _lib.load().rgbd_planes_outer(_ptr(t), _ptr(planes), _ptr(o), _ptr(ts), B, H * W, KP, C, _stream())
+    rc = _lib.load().rgbd_planes_outer(_ptr(t), _ptr(planes), _ptr(o), _ptr(ts), _ptr(psum), B, H * W, KP, C, _stream())
     _lib.check(rc, "rgbd_planes_outer")
     return o, ts
 

@@ -178,7 +178,8 @@ class RGBDUpdater:
         # a blend factor every iteration and run eagerly.
         self.use_graphs = bool(kwargs.pop("use_graphs", True))
         self.graph_warmup = int(kwargs.pop("graph_warmup", 2))
-        self.graph_phases = tuple(kwargs.pop("graph_phases", ("prep", "gen", "gen_a", "gen_b", "dfw", "dis", "join", "opt")))
+        self.graph_phases = tuple(kwargs.pop("graph_phases", ("prep", "gen", "gen_a", "gen_b", "dfw", "dis", "join", "opt",
+                                                              "opt_g", "opt_d")))
         # the generator phase and the discriminator-on-reals phase are independent until the optimizer phase; on two
         # streams the launch-latency bubbles of one fill with the other's kernels
         # (not when several ranks share one GPU -- the single-GPU test arrangement of the multi-rank path: two
@@ -312,7 +313,7 @@ class RGBDUpdater:
         # seeds dL/dy_b; one pass seeded with the discriminator's dL_D/dy_b yields D's weight gradients AND, rescaled
         # per sample by (dL_G/dy_b) / (dL_D/dy_b), the generator's image gradient.
         x_d = x_fake[:, :3].detach().contiguous().requires_grad_(True)
-        y_fake, _ = self.dis(x_d, stage=stage, return_hidden=True)
+        y_fake = self.dis(x_d, stage=stage)      # (the hidden feature of updater.py:333 feeds only rotate_feature)
         # losses and seeds of both adversarial terms from the logits in one launch; seeds from logits clamped at -60:
         # below that the generator's seed -sigmoid(-y)/B equals -1/B to fp32 precision and the discriminator's
         # sigmoid(y)/B is < 1e-26/B either way, but their ratio stays finite (an unclamped logit of -90 would give 0 * inf)
@@ -440,11 +441,18 @@ class RGBDUpdater:
         self.observation["dis/loss_adv"] = st["dis_reported"] + lf if lf is not None else st["dis_reported"]
 
     def _opt_phase(self, st):
-        for name in ("map", "gen", "dis"):
+        self._opt_g_phase(st)
+        self._opt_d_phase(st)
+
+    def _opt_g_phase(self, st):
+        for name in ("map", "gen"):
             if name in self._optimizers:
                 self._optimizers[name].update()
         if self.smoothed_gen is not None:          # updater.py:397-400 (after the generator update; D never touches G)
             soft_copy_param(self.smoothed_gen, self.gen, 1.0 - self.smoothing)
+
+    def _opt_d_phase(self, st):
+        self._optimizers["dis"].update()
 
     def _run_phase(self, name, fn, st, key):
         """Eager for the first calls of a configuration, then capture once and replay."""
@@ -588,12 +596,14 @@ class RGBDUpdater:
                 self._run_phase("gen_b", self._gen_b_phase, st, key)       # 3-D loss + G backward
             else:
                 self._run_phase("gen", self._gen_phase, st, key)           # G + D on the fakes: main stream
-            main.wait_stream(side)
-            # data parallel: the gradient all-reduces start only after the join, so the communicator never competes
-            # with two compute streams (map + gen 29 MB and dis 34 MB then go out back to back on an idle GPU)
+            # data parallel: the generator's gradients are final here (its deferred weight gradients ran inside gen_b), so
+            # the map + gen all-reduce (29 MB) goes out now, on the communicator's own stream, while the side stream
+            # finishes D's weight gradients for the fakes; the main stream is idle until the join, so the collective
+            # competes with ONE compute stream (train_rgbd.py:154-156: multi-node optimizers all-reduce before update)
             if opt_g_m is not None:
                 opt_g_m.start_allreduce()
             opt_g_g.start_allreduce()
+            main.wait_stream(side)
         else:
             self._run_phase("gen", self._gen_phase, st, key)
             if opt_g_m is not None:
@@ -602,12 +612,18 @@ class RGBDUpdater:
             self._run_phase("dis", self._dis_phase, st, key)               # overlaps the map/gen all-reduce
         self._run_phase("join", self._join_phase, st, key)
         opt_d.start_allreduce()
-        # the collectives are waited for here, eagerly; the optimizer phase itself (clip + Adam + EMA) holds none and is
-        # replayed as a graph also under data parallelism
-        for opt in (opt_g_m, opt_g_g, opt_d):
-            if opt is not None:
-                opt.finish_allreduce()
-        self._run_phase("opt", self._opt_phase, st, key)
+        # the collectives are waited for here, eagerly; the optimizer phases themselves (clip + Adam + EMA) hold none and
+        # are replayed as graphs also under data parallelism
+        if getattr(opt_d, "comm", None) is not None and opt_d.comm.active:
+            # generator first: its Adam step runs while D's 34 MB all-reduce is still in flight
+            for opt in (opt_g_m, opt_g_g):
+                if opt is not None:
+                    opt.finish_allreduce()
+            self._run_phase("opt_g", self._opt_g_phase, st, key)
+            opt_d.finish_allreduce()
+            self._run_phase("opt_d", self._opt_d_phase, st, key)
+        else:
+            self._run_phase("opt", self._opt_phase, st, key)
         if key is not None:
             Fn.bump_weight_epoch()      # replays change the weights behind Python's back: invalidate packed caches
 

@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--stage", type=float, default=10.0)
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--sequential", action="store_true")
+    ap.add_argument("--graph-phases", default=None, help="comma list: capture only these phases (diagnostics)")
     ap.add_argument("--logit-shift", type=float, default=0.0,
                     help="added to the discriminator's output bias: y_fake ~ shift (seed-ratio chain at the clamp)")
     args = ap.parse_args()
@@ -72,6 +73,8 @@ def main():
     kw = dict(fixed_stage=args.stage, use_graphs=not args.eager, graph_warmup=2, nan_check_interval=0)
     if args.sequential:
         kw["concurrent_phases"] = False
+    if args.graph_phases is not None:
+        kw["graph_phases"] = tuple(p for p in args.graph_phases.split(",") if p)
     gen, dis, opt, upd = build_training(Config(CFG), device, comm if comm.active else None, iterator=None, **kw)
     torch.manual_seed(3)
     with torch.no_grad():                               # give the depth head some signal (as the step parity test does)
@@ -104,6 +107,10 @@ def main():
         out[f"{k}/v"] = opt[k].v.cpu().numpy()
         out[f"{k}/norm"] = float(opt[k].grad_norm)
         out[f"{k}/t"] = opt[k].t
+    for k, s in stores.items():                        # parameter table: name -> (offset, numel) in the flat buffers
+        out[f"{k}/names"] = np.array(s.names)
+        out[f"{k}/offsets"] = np.array([s.offsets[n] for n in s.names], dtype=np.int64)
+        out[f"{k}/sizes"] = np.array([int(np.prod(s.shapes[n])) for n in s.names], dtype=np.int64)
     for k, v in upd.observation.items():
         out["obs/" + k] = float(v)
     np.savez(args.out, **out)

@@ -176,11 +176,11 @@ def test_warp_loss_with_fused_hinge_and_accumulation(b, S):
     cf = torch.from_numpy(coef).to(DEV)
     loss = kernels.warp_loss_fwd(xd[:b], xd[b:], cf, 1, lam_geo, hinge_lambda=lam_depth, hinge_min=dmin)
     assert abs(float(loss) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
-    base = torch.randn(2 * b, 4, S, S, device=DEV)
+    base = torch.randn(2 * b, 4, S, S, device=DEV) * 1e-3
     gout = base.clone()
     kernels.warp_loss_bwd(xd[:b], xd[b:], cf, 1, lam_geo, 0.0, 0.0, None, hinge_lambda=lam_depth, hinge_min=dmin,
                           grad_scale=lam_rot, out=(gout[:b], gout[b:]))
-    torch.testing.assert_close((gout - base).cpu(), xt.grad, rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close((gout - base).cpu(), xt.grad, rtol=1e-3, atol=2e-8)
     # hinge off + no accumulation = the ABI-3 behaviour
     l0 = kernels.warp_loss_fwd(xd[:b], xd[b:], cf, 1, lam_geo)
     assert float(l0) < float(loss)
