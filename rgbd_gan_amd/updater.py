@@ -15,8 +15,10 @@ gradients, same Adam updates), arranged for the GPU:
     dis  : D(x_real), R1 first-order pass, double backward with the adversarial seeds on the reals folded in
            (runs on a second stream, concurrently with gen)
     join : merge D's two gradient buffers;  opt : clip + Adam for map / gen / dis (+ EMA generator)
-Each phase is captured once per configuration as a HIP graph and replayed.
-Data-parallel: each optimizer's flat gradient buffer is all-reduced once (RCCL) between join and opt.
+prep .. join ("body") are captured once per configuration as ONE HIP graph with the two-stream fork / join inside it, the
+optimizer phase as a second one; a replayed step is two graph launches.
+Data-parallel: each optimizer's flat gradient buffer is all-reduced once (RCCL) between the body and the optimizer
+graphs (generator optimizers first, so their Adam step overlaps D's all-reduce).
 """
 import contextlib
 import math
@@ -178,8 +180,7 @@ class RGBDUpdater:
         # a blend factor every iteration and run eagerly.
         self.use_graphs = bool(kwargs.pop("use_graphs", True))
         self.graph_warmup = int(kwargs.pop("graph_warmup", 2))
-        self.graph_phases = tuple(kwargs.pop("graph_phases", ("prep", "gen", "gen_a", "gen_b", "dfw", "dis", "join", "opt",
-                                                              "opt_g", "opt_d")))
+        self.graph_phases = tuple(kwargs.pop("graph_phases", ("body", "opt", "opt_g", "opt_d")))
         # the generator phase and the discriminator-on-reals phase are independent until the optimizer phase; on two
         # streams the launch-latency bubbles of one fill with the other's kernels
         # (not when several ranks share one GPU -- the single-GPU test arrangement of the multi-rank path: two
@@ -440,6 +441,32 @@ class RGBDUpdater:
         lf = st.get("loss_dfake")
         self.observation["dis/loss_adv"] = st["dis_reported"] + lf if lf is not None else st["dis_reported"]
 
+    def _body_phase(self, st):
+        """prep, then the generator phase || the discriminator-on-reals phase, then the join: the whole step up to the
+        optimizers.  In the two-stream arrangement the side stream forks off the current stream and rejoins it, both
+        inside this function, so it can be captured as one graph with two branches."""
+        self._prep_phase(st)
+        if st["concurrent"]:
+            main, side = torch.cuda.current_stream(), self._side_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._dis_phase(st)                   # D on the reals: side stream
+            if os.environ.get("RGBD_DEBUG_SERIALIZE"):    # diagnostics: no overlap of the two phases
+                main.wait_stream(side)
+            if self.defer_dfake_wgrads:
+                self._gen_a_phase(st)                 # G fwd, D(x_fake) fwd + input-gradient chain
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self._dfw_phase(st)               # D's fake-batch weight gradients, behind "dis" on the side stream
+                self._gen_b_phase(st)                 # 3-D loss + G backward
+            else:
+                self._gen_phase(st)
+            main.wait_stream(side)
+        else:
+            self._gen_phase(st)
+            self._dis_phase(st)
+        self._join_phase(st)
+
     def _opt_phase(self, st):
         self._opt_g_phase(st)
         self._opt_d_phase(st)
@@ -574,48 +601,23 @@ class RGBDUpdater:
                 st["x_real_full"] = self._stagers[skey]
             key = (batch_size, fl, use_rotate, occlusion, full_shape, z_fake_data is not None, real_idx is not None)
 
-        # the recorded D(x_fake) forward may only be shared when both phases run the same way (both replayed from
-        # graphs captured in the same iteration, or both eager)
-        st["share_dfake"] = (key is None or (("gen" in self.graph_phases) == ("dis" in self.graph_phases))) \
-            and not os.environ.get("RGBD_NO_SHARE")
+        st["share_dfake"] = not os.environ.get("RGBD_NO_SHARE")
         st["concurrent"] = bool(self.concurrent_phases and st["share_dfake"])
-        self._run_phase("prep", self._prep_phase, st, key)
-        if st["concurrent"]:
-            main = torch.cuda.current_stream()
-            if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream(device=self.device)
-            side = self._side_stream
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                self._run_phase("dis", self._dis_phase, st, key)           # D on the reals: side stream
-            if self.defer_dfake_wgrads:
-                self._run_phase("gen_a", self._gen_a_phase, st, key)       # G fwd, D(x_fake) fwd + input-gradient chain
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    self._run_phase("dfw", self._dfw_phase, st, key)       # D's fake-batch weight gradients, after "dis"
-                self._run_phase("gen_b", self._gen_b_phase, st, key)       # 3-D loss + G backward
-            else:
-                self._run_phase("gen", self._gen_phase, st, key)           # G + D on the fakes: main stream
-            # data parallel: the generator's gradients are final here (its deferred weight gradients ran inside gen_b), so
-            # the map + gen all-reduce (29 MB) goes out now, on the communicator's own stream, while the side stream
-            # finishes D's weight gradients for the fakes; the main stream is idle until the join, so the collective
-            # competes with ONE compute stream (train_rgbd.py:154-156: multi-node optimizers all-reduce before update)
-            if opt_g_m is not None:
-                opt_g_m.start_allreduce()
-            opt_g_g.start_allreduce()
-            main.wait_stream(side)
-        else:
-            self._run_phase("gen", self._gen_phase, st, key)
-            if opt_g_m is not None:
-                opt_g_m.start_allreduce()
-            opt_g_g.start_allreduce()
-            self._run_phase("dis", self._dis_phase, st, key)               # overlaps the map/gen all-reduce
-        self._run_phase("join", self._join_phase, st, key)
-        opt_d.start_allreduce()
-        # the collectives are waited for here, eagerly; the optimizer phases themselves (clip + Adam + EMA) hold none and
-        # are replayed as graphs also under data parallelism
-        if getattr(opt_d, "comm", None) is not None and opt_d.comm.active:
-            # generator first: its Adam step runs while D's 34 MB all-reduce is still in flight
+        if st["concurrent"] and self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        # everything up to the merged gradient buffers is ONE captured graph: the two-stream fork / join sits INSIDE the
+        # capture, so a replay is a single launch whose internal dependencies the graph carries (separate graphs per
+        # phase, ordered by stream events between the launches, were not reliably ordered on replay: the graph == eager
+        # step test caught ~1e-2 relative gradient differences in two of five runs)
+        self._run_phase("body", self._body_phase, st, key)
+        dp = getattr(opt_d, "comm", None) is not None and opt_d.comm.active
+        if dp:
+            # data parallel (train_rgbd.py:154-156: the multi-node optimizers all-reduce before they update): one
+            # all-reduce per flat gradient buffer on the communicator's stream, the collectives outside the graphs;
+            # the generator's Adam step runs while D's 34 MB all-reduce is still in flight
+            for opt in (opt_g_m, opt_g_g, opt_d):
+                if opt is not None:
+                    opt.start_allreduce()
             for opt in (opt_g_m, opt_g_g):
                 if opt is not None:
                     opt.finish_allreduce()

@@ -1,8 +1,8 @@
 """Arrangements of the SAME training step must agree tensor by tensor (tests/dp_worker.py runs them on fixed inputs):
 
-  * the shipped arrangement -- 7 replayed HIP graphs, generator phase || discriminator phase on two streams, D's
-    fake-batch weight gradients deferred to the side stream and merged from a second gradient buffer -- against the
-    eager single-stream step;
+  * the shipped arrangement -- the step body replayed as one HIP graph with two branches (generator phase ||
+    discriminator phase), D's fake-batch weight gradients deferred to the side branch and merged from a second gradient
+    buffer, the optimizers as a second graph -- against the eager single-stream step;
   * a 2-rank data-parallel job (two processes sharing cuda:0, gloo collectives, the real HIP Adam kernel, graphs)
     on half-batches against 1 rank on the whole batch: ChainerMN's multi-node optimizer (train_rgbd.py:103-121,154-156)
     = first update broadcasts, then all-reduce-mean of the flat gradient buffers before the local clipped Adam;
@@ -82,7 +82,7 @@ def test_graph_replay_two_streams_equals_eager_single_stream(tmp_path):
     procs = [_run(tmp_path / "graph.npz", "--calls", "4")]                      # the shipped arrangement
     _wait(procs)
     e, e2, g = (np.load(tmp_path / f) for f in ("eager.npz", "eager2.npz", "graph.npz"))
-    assert int(e["n_graphs"]) == 0 and int(e2["n_graphs"]) == 0 and int(g["n_graphs"]) == 7
+    assert int(e["n_graphs"]) == 0 and int(e2["n_graphs"]) == 0 and int(g["n_graphs"]) == 2   # body + optimizers
     _compare(e2, e, "eager two-stream vs eager sequential")
     _compare(g, e, "graph replay vs eager sequential")
     for key in ("obs/gen/loss_adv", "obs/gen/loss_rotate", "obs/dis/loss_adv", "obs/dis/loss_gp"):
@@ -93,7 +93,7 @@ def test_fade_in_stage_graph_replay_equals_eager(tmp_path):
     _wait([_run(tmp_path / "eager.npz", "--calls", "4", "--eager", "--sequential", "--stage", "9.5", "--batch", "4")])
     _wait([_run(tmp_path / "graph.npz", "--calls", "4", "--stage", "9.5", "--batch", "4")])
     e, g = np.load(tmp_path / "eager.npz"), np.load(tmp_path / "graph.npz")
-    assert int(g["n_graphs"]) == 7
+    assert int(g["n_graphs"]) == 2
     _compare(g, e, "fade-in graph replay vs eager")
 
 
