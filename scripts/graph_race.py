@@ -1,0 +1,37 @@
+"""Is the replayed (graph, two-stream) step the eager step?  tests/dp_worker.py under env knobs, each run compared with the
+eager single-stream run: rel-L2 of the flat gradient buffers, worst parameters with their projection coefficient."""
+import os, subprocess, sys, tempfile
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W = os.path.join(ROOT, "tests", "dp_worker.py")
+tmp = tempfile.mkdtemp()
+def run(name, flags=(), env=None):
+    e = dict(os.environ); e.update(env or {})
+    r = subprocess.run([sys.executable, W, f"{tmp}/{name}.npz", "--calls", "4"] + list(flags), capture_output=True, text=True, env=e)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return np.load(f"{tmp}/{name}.npz")
+def rel(a, b):
+    return np.linalg.norm(a.astype("f8") - b.astype("f8")) / (np.linalg.norm(b.astype("f8")) + 1e-30)
+def worst(L, ref, k, top=6):
+    rows = []
+    for n, o, sz in zip(L[f"{k}/names"], L[f"{k}/offsets"], L[f"{k}/sizes"]):
+        a, b = L[f"{k}/grad"][o:o + sz].astype("f8"), ref[f"{k}/grad"][o:o + sz].astype("f8")
+        if np.linalg.norm(b) == 0:
+            continue
+        rows.append((rel(a, b), str(n), float(a @ b / (b @ b))))
+    return " ".join(f"{n}:{r:.1e}(x{p:.2f})" for r, n, p in sorted(rows, reverse=True)[:top])
+ref = run("seq", ["--eager", "--sequential"])
+cases = [("graph seq", ["--sequential"], {}), ("graph 2s, no G defer", [], {"RGBD_NO_G_DEFER": "1"}),
+         ("graph 2s, serialize(event)", [], {"RGBD_DEBUG_SERIALIZE": "1"}), ("graph 2s, no dfw defer", [], {"RGBD_NO_DEFER": "1"})] + \
+        [(f"graph 2s run {i}", [], {}) for i in range(8)]
+for i, (name, flags, env) in enumerate(cases):
+    try:
+        L = run(f"case{i}", flags, env)
+    except AssertionError as exc:
+        print(name, "FAILED", str(exc)[-300:]); continue
+    rels = {k: rel(L[f"{k}/grad"], ref[f"{k}/grad"]) for k in ("map", "gen", "dis")}
+    print(f"{name:28s} graphs {int(L['n_graphs'])} | " + " | ".join(f"{k}: {v:.1e}" for k, v in rels.items()) +
+          f" | loss_adv {float(L['obs/gen/loss_adv']) - float(ref['obs/gen/loss_adv']):+.1e}", flush=True)
+    for k, v in rels.items():
+        if v > 1e-2 or (k == "dis" and v > 1e-5):
+            print(f"      {k}: {worst(L, ref, k)}", flush=True)
