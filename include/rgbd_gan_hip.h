@@ -149,6 +149,20 @@ typedef struct rgbd_wgrad_reduce_desc {
 int rgbd_conv2d_wgrad_partial_bf16(const void* x, const void* dy, void* workspace, int B, int H, int W, int Cin, int Cout,
                                    int K, int upsample, void* stream);
 int rgbd_wgrad_reduce_multi(const rgbd_wgrad_reduce_desc* descs, int n, void* stream);
+/* The partial (slab) kernel for up to 24 weight gradients in ONE launch: a launch per layer costs one slab per CU (38 MB
+ * of write + read at 64x64x9 fp32) whatever the layer's size; one launch for all weight gradients of a backward pass
+ * deals the CUs out over the layers in proportion to their work and costs 38 MB in total.  3x3 pad-1 convs on
+ * power-of-two images of at least 8x16 only.  rgbd_conv2d_wgrad_multi_plan fills `nsplit` of every problem (HOST
+ * arrays; total_workgroups <= 0: one per CU); the caller then provides workspace = nsplit * 9 * Cout * Cin floats per
+ * problem and finishes with rgbd_wgrad_reduce_multi. */
+typedef struct rgbd_wgrad_problem {
+    const void* x;        /* (B,H,W,Cin) bf16, or (B,H/2,W/2,Cin) when upsample != 0 */
+    const void* dy;       /* (B,H,W,Cout) bf16 */
+    void* workspace;      /* nsplit * 9 * Cout * Cin fp32 */
+    int32_t B, H, W, Cin, Cout, K, upsample, nsplit;
+} rgbd_wgrad_problem;
+int rgbd_conv2d_wgrad_multi_plan(rgbd_wgrad_problem* probs, int n, int total_workgroups);
+int rgbd_conv2d_wgrad_partial_multi_bf16(const rgbd_wgrad_problem* probs, int n, void* stream);
 
 /* ------------------------------------------------------------------ AdaIN (instance norm + style affine)
  * Replaces normalization/adain.py:54-73 (reshape + F.batch_normalization + broadcast mul/add) and its backward.

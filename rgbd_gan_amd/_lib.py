@@ -32,6 +32,8 @@ PROTOTYPES = {
     "rgbd_conv2d_wgrad_bf16": ([_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P], c_int),
     "rgbd_conv2d_wgrad_partial_bf16": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P], c_int),
     "rgbd_wgrad_reduce_multi": ([_P, c_int, _P], c_int),
+    "rgbd_conv2d_wgrad_multi_plan": ([_P, c_int, c_int], c_int),
+    "rgbd_conv2d_wgrad_partial_multi_bf16": ([_P, c_int, _P], c_int),
     "rgbd_adain_workspace": ([c_int, c_int, c_int], c_int64),
     "rgbd_adain_fwd": ([_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P], c_int),
     "rgbd_adain_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P], c_int),

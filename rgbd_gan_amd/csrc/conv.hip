@@ -585,7 +585,8 @@ __device__ __forceinline__ s16x4 lds_tr16(const unsigned char* p) {
 }
 
 template <int NT, bool FAST>  // filter taps: 9 (3x3, pad 1) or 1 (1x1); FAST: 8x16 patches (images >= 16x16)
-__global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradArgs a) {
+__device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, const int split_idx, const int ci_tile,
+                                                const int co_tile) {
     // 8 waves, one workgroup per CU.  Wave w owns the 32x32 sub-tile (w>>1 & 1, w & 1) of the 64x64 (co, ci) tile for
     // one half of the filter taps (waves 0-3: taps 0..4, waves 4-7: taps 5..8; waves w and w+4 share a SIMD, so every
     // SIMD carries all nine taps).  LDS is double buffered: patch p+1 is written while patch p is multiplied, patch
@@ -600,7 +601,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];   // [2][X_BYTES + Y_BYTES]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int ci0 = blockIdx.y * 64, co0 = blockIdx.z * 64;
+    const int ci0 = ci_tile * 64, co0 = co_tile * 64;
     const int wc = (wid >> 1) & 1, wi = wid & 1;       // wave -> (co half, ci half) of the 64x64 tile
     const int tg = __builtin_amdgcn_readfirstlane(wid) >> 2;   // tap group (wave-uniform by construction)
     const int HPW = a.PW + 2 * HALO, HPH = a.PH + 2 * HALO;
@@ -697,7 +698,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradArgs a) {
         }
     }
 
-    const int p_begin = blockIdx.x * a.patches_per_wg;
+    const int p_begin = split_idx * a.patches_per_wg;
     const int p_end = min(a.total_patches, p_begin + a.patches_per_wg);
     if (p_begin < p_end) {
         load_patch(p_begin);
@@ -771,7 +772,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradArgs a) {
     //      run at ~1.3 TB/s chip-wide, plain stores at ~6 TB/s: MI355X_MICROARCH.md "Global float atomics");
     //      wgrad_reduce_kernel sums the slabs.  D[row = co][col = ci]: one register = two 128-byte row segments.
     const int col = lane & 31, rhalf = lane >> 5;
-    float* slab = a.dwp + (long)blockIdx.x * NT * a.Cout * a.Cin;
+    float* slab = a.dwp + (long)split_idx * NT * a.Cout * a.Cin;
 #pragma unroll
     for (int tt = 0; tt < TG0; ++tt) {
         const int t = tg * TG0 + tt;
@@ -783,6 +784,33 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradArgs a) {
             }
         }
     }
+}
+
+template <int NT, bool FAST>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradArgs a) {
+    conv_wgrad_body<NT, FAST>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several weight gradients in ONE launch.  Every workgroup costs one (taps x 64 x 64) fp32 slab of reduction traffic
+// (written here, read by the reduction), so a launch per layer with one workgroup per CU moves 256 slabs = 38 MB per
+// layer whatever the layer's size; with all weight gradients of a backward pass in one launch the chip's 256 workgroups
+// are dealt out over the problems in proportion to their work and the pass moves 38 MB in total.  Problems are sorted by
+// work per workgroup (largest first), so the dispatcher back-fills CUs with the small ones.
+constexpr int WGRAD_MULTI_PROBLEMS = 24;
+struct WgradMultiLaunch {
+    WgradArgs p[WGRAD_MULTI_PROBLEMS];
+    int wg_begin[WGRAD_MULTI_PROBLEMS + 1];
+    int n;
+};
+template <int NT, bool FAST>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_multi_kernel(WgradMultiLaunch m) {
+    int i = 0;
+    while (i + 1 < m.n && (int)blockIdx.x >= m.wg_begin[i + 1]) ++i;          // block-uniform scan
+    const WgradArgs& a = m.p[i];
+    const int local = (int)blockIdx.x - m.wg_begin[i];
+    const int tiles_ci = a.Cin >> 6, tiles = tiles_ci * (a.Cout >> 6);
+    const int split = local / tiles, tile = local - split * tiles;
+    conv_wgrad_body<NT, FAST>(a, split, tile % tiles_ci, tile / tiles_ci);
 }
 
 // Slab reduction + layout change in one launch.  A block owns 32 float4 of the packed (tap, co, ci) tile; its 256
@@ -1157,5 +1185,97 @@ extern "C" int rgbd_wgrad_reduce_multi(const rgbd_wgrad_reduce_desc* descs, int 
         wgrad_reduce_multi_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(m);
         RGBD_CHECK_LAUNCH("wgrad_reduce_multi_kernel");
     }
+    return 0;
+}
+
+// ---- several weight gradients per launch (see conv_wgrad_multi_kernel)
+namespace {
+int device_cus() {
+    static int num_cus = 0;
+    if (num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            num_cus = prop.multiProcessorCount;
+        if (num_cus <= 0) num_cus = 256;
+    }
+    return num_cus;
+}
+bool multi_eligible(const rgbd_wgrad_problem& q) {
+    return q.x && q.dy && q.K == 3 && q.Cin > 0 && q.Cout > 0 && q.Cin % 64 == 0 && q.Cout % 64 == 0 && q.B > 0 && q.H >= 8 &&
+           q.W >= 16 && (q.H & (q.H - 1)) == 0 && (q.W & (q.W - 1)) == 0 && (long)q.B * q.H * q.W * q.Cin < 0x3fffffffL &&
+           (long)q.B * q.H * q.W * q.Cout < 0x3fffffffL;
+}
+}  // namespace
+
+extern "C" int rgbd_conv2d_wgrad_multi_plan(rgbd_wgrad_problem* probs, int n, int total_workgroups) {
+    RGBD_REQUIRE(probs && n > 0 && n <= WGRAD_MULTI_PROBLEMS, "rgbd_conv2d_wgrad_multi_plan: 1..%d problems", WGRAD_MULTI_PROBLEMS);
+    if (total_workgroups <= 0) total_workgroups = device_cus();
+    double units = 0.0;
+    for (int i = 0; i < n; ++i) {
+        RGBD_REQUIRE(multi_eligible(probs[i]), "rgbd_conv2d_wgrad_multi_plan: problem %d is not a 3x3 conv on a power-of-two "
+                     "image of at least 8x16 with channels in multiples of 64", i);
+        units += (double)probs[i].B * (probs[i].H / 8) * (probs[i].W / 16) * (probs[i].Cin / 64) * (probs[i].Cout / 64);
+    }
+    for (int i = 0; i < n; ++i) {
+        rgbd_wgrad_problem& q = probs[i];
+        const int patches = q.B * (q.H / 8) * (q.W / 16);
+        const int tiles = (q.Cin / 64) * (q.Cout / 64);
+        int nsplit = (int)((double)total_workgroups * patches / units + 0.5);      // = share of workgroups / tiles
+        if (nsplit < 1) nsplit = 1;
+        if (nsplit > patches) nsplit = patches;
+        const int per_wg = (patches + nsplit - 1) / nsplit;
+        q.nsplit = (patches + per_wg - 1) / per_wg;
+        (void)tiles;
+    }
+    return 0;
+}
+
+extern "C" int rgbd_conv2d_wgrad_partial_multi_bf16(const rgbd_wgrad_problem* probs, int n, void* stream) {
+    RGBD_REQUIRE(probs && n > 0 && n <= WGRAD_MULTI_PROBLEMS, "rgbd_conv2d_wgrad_partial_multi_bf16: 1..%d problems",
+                 WGRAD_MULTI_PROBLEMS);
+    int order[WGRAD_MULTI_PROBLEMS], per_wg[WGRAD_MULTI_PROBLEMS];
+    for (int i = 0; i < n; ++i) {
+        const rgbd_wgrad_problem& q = probs[i];
+        RGBD_REQUIRE(multi_eligible(q) && q.workspace && q.nsplit > 0, "rgbd_conv2d_wgrad_partial_multi_bf16: bad problem %d", i);
+        const int patches = q.B * (q.H / 8) * (q.W / 16);
+        per_wg[i] = (patches + q.nsplit - 1) / q.nsplit;
+        RGBD_REQUIRE((patches + per_wg[i] - 1) / per_wg[i] == q.nsplit,
+                     "rgbd_conv2d_wgrad_partial_multi_bf16: nsplit of problem %d is not from the plan", i);
+        order[i] = i;
+    }
+    for (int i = 1; i < n; ++i)                       // largest work per workgroup first
+        for (int j = i; j > 0 && per_wg[order[j]] > per_wg[order[j - 1]]; --j) {
+            const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t;
+        }
+    WgradMultiLaunch m;
+    m.n = n;
+    long wgs = 0;
+    for (int k = 0; k < n; ++k) {
+        const rgbd_wgrad_problem& q = probs[order[k]];
+        WgradArgs& a = m.p[k];
+        a.x = (const unsigned short*)q.x; a.dy = (const unsigned short*)q.dy; a.dwp = (float*)q.workspace;
+        a.B = q.B; a.H = q.H; a.W = q.W; a.Cin = q.Cin; a.Cout = q.Cout;
+        a.PW = 16; a.PH = 8; a.lgPW = 4; a.npx = q.W / 16; a.npy = q.H / 8;
+        a.total_patches = q.B * a.npx * a.npy;
+        a.patches_per_wg = per_wg[order[k]];
+        a.x_bytes = (int)((long)q.B * q.H * q.W * q.Cin * 2 / (q.upsample ? 4 : 1));
+        a.y_bytes = (int)((long)q.B * q.H * q.W * q.Cout * 2);
+        a.ups = q.upsample ? 1 : 0;
+        m.wg_begin[k] = (int)wgs;
+        wgs += (long)q.nsplit * (q.Cin / 64) * (q.Cout / 64);
+    }
+    m.wg_begin[n] = (int)wgs;
+    RGBD_REQUIRE(wgs < 0x7fffffffL, "rgbd_conv2d_wgrad_partial_multi_bf16: grid too large");
+    const int lds = 2 * (180 * 128 + 128 * 128);
+    static bool attr_done = false;
+    if (!attr_done) {
+        RGBD_REQUIRE(hipFuncSetAttribute((const void*)&conv_wgrad_multi_kernel<9, true>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess,
+                     "rgbd_conv2d_wgrad_partial_multi_bf16: cannot reserve %d B of LDS", lds);
+        attr_done = true;
+    }
+    conv_wgrad_multi_kernel<9, true><<<(unsigned)wgs, 512, lds, (hipStream_t)stream>>>(m);
+    RGBD_CHECK_LAUNCH("conv_wgrad_multi_kernel");
     return 0;
 }

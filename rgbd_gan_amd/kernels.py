@@ -294,16 +294,31 @@ WGRAD_REDUCE_DESC = [("workspace", "<u8"), ("dw", "<u8"), ("nsplit", "<i4"), ("t
                      ("cin", "<i4"), ("scale", "<f4"), ("accumulate", "<i4")]      # struct rgbd_wgrad_reduce_desc, 40 bytes
 
 
+class _WgradProblem(ctypes.Structure):          # struct rgbd_wgrad_problem (include/rgbd_gan_hip.h)
+    _fields_ = [("x", ctypes.c_void_p), ("dy", ctypes.c_void_p), ("workspace", ctypes.c_void_p), ("B", ctypes.c_int32),
+                ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("Cin", ctypes.c_int32), ("Cout", ctypes.c_int32),
+                ("K", ctypes.c_int32), ("upsample", ctypes.c_int32), ("nsplit", ctypes.c_int32)]
+
+
+WGRAD_MULTI_MAX = 24
+
+
+def _multi_ok(H, W, K):
+    return K == 3 and H >= 8 and W >= 16 and H & (H - 1) == 0 and W & (W - 1) == 0
+
+
 def conv2d_wgrad_batch(items):
     """Weight gradients of several convs, `items` = [(x, dy, target dW fp32, K, scale, upsample)], accumulated into their
-    targets: one MFMA launch each (per-workgroup partial slabs) and ONE slab-reduction launch per 32 of them."""
+    targets.  The 3x3 convs on images of 8x16 and larger share ONE partial-sum launch per 24 of them (the chip's
+    workgroups dealt out over the layers by work: 38 MB of slab traffic per launch instead of per layer); the small
+    layers get a launch each; ONE slab-reduction launch per 32 gradients finishes all of them."""
     import numpy as np
     if not items:
         return
     lib = _lib.load()
     tab = np.zeros(len(items), dtype=WGRAD_REDUCE_DESC)
     assert tab.dtype.itemsize == 40
-    keep = []
+    keep, multi = [], []
     for i, (x, dy, target, K, scale, ups) in enumerate(items):
         _chk(x, BF16, "x"); _chk(dy, BF16, "dy"); _chk(target, F32, "target")
         B, H, W, Cin = x.shape
@@ -313,6 +328,9 @@ def conv2d_wgrad_batch(items):
         if tuple(dy.shape[:3]) != (B, H, W) or tuple(target.shape) != (Cout, Cin, K, K):
             raise RuntimeError(f"conv2d_wgrad_batch: shape mismatch x={tuple(x.shape)} dy={tuple(dy.shape)} "
                                f"dW={tuple(target.shape)} upsample={ups}")
+        if _multi_ok(H, W, K) and len(items) > 1:
+            multi.append((i, x, dy, B, H, W, Cin, Cout, bool(ups)))
+            continue
         ws_bytes = lib.rgbd_conv2d_wgrad_workspace(B, H, W, Cin, Cout, K)
         if ws_bytes < 0:
             raise RuntimeError(f"conv2d_wgrad_batch: unsupported shape x={tuple(x.shape)} dy={tuple(dy.shape)} K={K}")
@@ -325,6 +343,26 @@ def conv2d_wgrad_batch(items):
                                                                int(bool(ups)), _stream()))
         _lib.check(rc, "rgbd_conv2d_wgrad_partial_bf16")
         tab[i] = (ws.data_ptr(), target.data_ptr(), ws_bytes // (4 * K * K * Cout * Cin), K * K, Cout, Cin, float(scale), 1)
+    for g0 in range(0, len(multi), WGRAD_MULTI_MAX):
+        group = multi[g0:g0 + WGRAD_MULTI_MAX]
+        probs = (_WgradProblem * len(group))()
+        for q, (i, x, dy, B, H, W, Cin, Cout, ups) in zip(probs, group):
+            q.x, q.dy, q.workspace = x.data_ptr(), dy.data_ptr(), 0
+            q.B, q.H, q.W, q.Cin, q.Cout, q.K, q.upsample, q.nsplit = B, H, W, Cin, Cout, 3, int(ups), 0
+        _lib.check(lib.rgbd_conv2d_wgrad_multi_plan(probs, len(group), 0), "rgbd_conv2d_wgrad_multi_plan")
+        sizes = [q.nsplit * 9 * q.Cout * q.Cin for q in probs]
+        ws = torch.empty(sum(sizes), dtype=F32, device=group[0][1].device)
+        keep.append(ws)
+        off = flops = nbytes = 0
+        for q, n, (i, x, dy, B, H, W, Cin, Cout, ups) in zip(probs, sizes, group):
+            q.workspace = ws.data_ptr() + 4 * off
+            off += n
+            flops += 2.0 * B * H * W * Cout * Cin * 9
+            nbytes += 2.0 * (x.numel() + dy.numel()) + 8.0 * n
+            tab[i] = (q.workspace, items[i][2].data_ptr(), q.nsplit, 9, Cout, Cin, float(items[i][4]), 1)
+        rc = _timed("conv_wgrad_kernel<9>+reduce", flops, nbytes,
+                    lambda: lib.rgbd_conv2d_wgrad_partial_multi_bf16(probs, len(group), _stream()))
+        _lib.check(rc, "rgbd_conv2d_wgrad_partial_multi_bf16")
     rc = lib.rgbd_wgrad_reduce_multi(tab.ctypes.data, len(items), _stream())
     _lib.check(rc, "rgbd_wgrad_reduce_multi")
 

@@ -380,11 +380,18 @@ class RGBDUpdater:
         with _alpha_ctx(st):
             self._dis_phase_body(st)
 
+    def _dbg_sync(self, st, point):
+        """Diagnostics (scripts/graph_race.py): RGBD_DEBUG_SYNC_AT=<point> makes the main stream wait for the side
+        stream's work up to this point of the discriminator phase, so only the rest of it overlaps the generator phase."""
+        if os.environ.get("RGBD_DEBUG_SYNC_AT") == point and st.get("_main") is not None:
+            st["_main"].wait_stream(torch.cuda.current_stream())
+
     def _dis_phase_body(self, st):
         stage = st["stage"]
         obs = self.observation
         x_real_v = st["x_real"].detach().requires_grad_(True)
         y_real = self.dis(x_real_v, stage=stage)
+        self._dbg_sync(st, "dis_fwd")
         fake_done = bool(st.get("share_dfake", True))
         real_heads = None
         if fake_done:
@@ -415,15 +422,21 @@ class RGBDUpdater:
                 grad_x, = torch.autograd.grad([y_real], [x_real_v], [ones], create_graph=True)   # chainer.grad seeds ones
             # updater.py:416-418 + loss_functions.py:7-8: lambda * mean_b (sqrt(sum g_b^2))^2, one reduction
             loss_gp = Fn.r1_penalty(grad_x, self.lambda_gp)
+            self._dbg_sync(st, "dis_r1")
             obs["dis/loss_gp"] = loss_gp.detach()
             reported = reported + loss_gp.detach()
         st["dis_reported"] = reported
         if inject:
             torch.autograd.backward([y_real], [seed], inputs=self.dis.tail_params(), retain_graph=True)
-            with Fn.adversarial_injection(seed):
+            wgrads = []
+            with Fn.adversarial_injection(seed), Fn.deferred_wgrads(wgrads):
                 # d loss_gp / d grad_x = 2 lambda / B * grad_x, handed to the double backward directly
                 ggx = kernels.scale_by_scalar(grad_x.detach().contiguous(), None, 2.0 * self.lambda_gp / grad_x.shape[0])
                 torch.autograd.backward([grad_x], [ggx])
+            self._dbg_sync(st, "dis_bwd2")
+            # D's weight gradients are leaves of the double backward: one partial-sum launch for all of them
+            # (rgbd_conv2d_wgrad_partial_multi_bf16: one slab per CU for the whole pass instead of per layer)
+            Fn.run_deferred_wgrads(wgrads)
             return
         loss_dis = torch.sum(F.softplus(-y_real)) / y_real.numel()
         if y_fake is not None:
@@ -448,6 +461,7 @@ class RGBDUpdater:
         self._prep_phase(st)
         if st["concurrent"]:
             main, side = torch.cuda.current_stream(), self._side_stream
+            st["_main"] = main
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 self._dis_phase(st)                   # D on the reals: side stream

@@ -21,9 +21,9 @@ def worst(L, ref, k, top=6):
         rows.append((rel(a, b), str(n), float(a @ b / (b @ b))))
     return " ".join(f"{n}:{r:.1e}(x{p:.2f})" for r, n, p in sorted(rows, reverse=True)[:top])
 ref = run("seq", ["--eager", "--sequential"])
-cases = [("graph seq", ["--sequential"], {}), ("graph 2s, no G defer", [], {"RGBD_NO_G_DEFER": "1"}),
-         ("graph 2s, serialize(event)", [], {"RGBD_DEBUG_SERIALIZE": "1"}), ("graph 2s, no dfw defer", [], {"RGBD_NO_DEFER": "1"})] + \
-        [(f"graph 2s run {i}", [], {}) for i in range(8)]
+cases = []
+for point in ("dis_fwd", "dis_r1", "dis_bwd2", ""):
+    cases += [(f"sync at {point or 'none':9s} run {i}", [], {"RGBD_DEBUG_SYNC_AT": point} if point else {}) for i in range(5)]
 for i, (name, flags, env) in enumerate(cases):
     try:
         L = run(f"case{i}", flags, env)
