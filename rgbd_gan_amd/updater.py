@@ -428,15 +428,17 @@ class RGBDUpdater:
         st["dis_reported"] = reported
         if inject:
             torch.autograd.backward([y_real], [seed], inputs=self.dis.tail_params(), retain_graph=True)
-            wgrads = []
-            with Fn.adversarial_injection(seed), Fn.deferred_wgrads(wgrads):
+            wgrads = None if os.environ.get("RGBD_NO_D_DEFER") else []
+            with Fn.adversarial_injection(seed), (Fn.deferred_wgrads(wgrads) if wgrads is not None
+                                                  else contextlib.nullcontext()):
                 # d loss_gp / d grad_x = 2 lambda / B * grad_x, handed to the double backward directly
                 ggx = kernels.scale_by_scalar(grad_x.detach().contiguous(), None, 2.0 * self.lambda_gp / grad_x.shape[0])
                 torch.autograd.backward([grad_x], [ggx])
             self._dbg_sync(st, "dis_bwd2")
             # D's weight gradients are leaves of the double backward: one partial-sum launch for all of them
             # (rgbd_conv2d_wgrad_partial_multi_bf16: one slab per CU for the whole pass instead of per layer)
-            Fn.run_deferred_wgrads(wgrads)
+            if wgrads is not None:
+                Fn.run_deferred_wgrads(wgrads)
             return
         loss_dis = torch.sum(F.softplus(-y_real)) / y_real.numel()
         if y_fake is not None:

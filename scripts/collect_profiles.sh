@@ -1,11 +1,14 @@
 #!/bin/bash
-# Collect the round's evidence on the GPU box (run through gpurun): per-kernel time of the default bench command and
-# HBM traffic counters (separate --pmc passes, no trace domains other than --kernel-trace), summaries into profiles/$1.
+# Collect the round's evidence on the GPU box (run through gpurun): per-kernel time of the default bench command, HBM
+# traffic counters (separate --pmc passes, no trace domains other than --kernel-trace) and SQ / LDS / L2 counters of the hot
+# conv kernels on the step's layer shapes; summaries into profiles/$1 (stamped with the kernel sources' hash).
+#   scripts/collect_profiles.sh r02 [commit]
 set -u
-R=${1:-r01}
+R=${1:-r02}
+export RGBD_COMMIT=${2:-unknown}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/$R profiles/$R
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/stats -o b -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/$R/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/stats -o b -- python3 bench.py --no-cpu-baseline > gpurun_out/$R/stats.log 2>&1
 cp gpurun_out/$R/stats/b_kernel_stats.csv profiles/$R/bench_kernel_stats.csv
 grep '"metric"' gpurun_out/$R/stats.log > profiles/$R/bench_line_under_rocprof.json
 rm -f gpurun_out/$R/stats/b_kernel_trace.csv
@@ -15,5 +18,15 @@ done
 python3 scripts/pmc_summary.py gpurun_out/$R/pmc_FETCH_SIZE gpurun_out/$R/pmc_WRITE_SIZE profiles/$R/bench_pmc_traffic.json \
   "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-roofline"
 rm -rf gpurun_out/$R/pmc_FETCH_SIZE gpurun_out/$R/pmc_WRITE_SIZE
+# SQ / LDS / L2 counters of the conv kernels alone (scripts/prof_conv.py: the step's layer shapes at B=32), a few counters per pass
+P=0
+for CS in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" \
+          "SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU" \
+          "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do
+  P=$((P+1))
+  REPS=3 rocprofv3 --kernel-trace --pmc $CS --output-format csv -d gpurun_out/$R/kpmc_$P -o k -- python3 scripts/prof_conv.py > gpurun_out/$R/kpmc_$P.log 2>&1
+done
+python3 scripts/pmc_kernels.py profiles/$R gpurun_out/$R/kpmc_*
+rm -rf gpurun_out/$R/kpmc_*/
 cp profiles/$R/*.csv profiles/$R/*.json gpurun_out/$R/ 2>/dev/null
 ls -la profiles/$R

@@ -21,9 +21,7 @@ def worst(L, ref, k, top=6):
         rows.append((rel(a, b), str(n), float(a @ b / (b @ b))))
     return " ".join(f"{n}:{r:.1e}(x{p:.2f})" for r, n, p in sorted(rows, reverse=True)[:top])
 ref = run("seq", ["--eager", "--sequential"])
-cases = []
-for point in ("dis_fwd", "dis_r1", "dis_bwd2", ""):
-    cases += [(f"sync at {point or 'none':9s} run {i}", [], {"RGBD_DEBUG_SYNC_AT": point} if point else {}) for i in range(5)]
+cases = [(f"plain run {i}", [], {}) for i in range(24)] + [(f"no D wgrad deferral {i}", [], {"RGBD_NO_D_DEFER": "1"}) for i in range(8)]
 for i, (name, flags, env) in enumerate(cases):
     try:
         L = run(f"case{i}", flags, env)

@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--sequential", action="store_true")
     ap.add_argument("--graph-phases", default=None, help="comma list: capture only these phases (diagnostics)")
+    ap.add_argument("--sync-restore", action="store_true", help="host-synchronise after putting the weights back")
     ap.add_argument("--logit-shift", type=float, default=0.0,
                     help="added to the discriminator's output bias: y_fake ~ shift (seed-ratio chain at the clamp)")
     args = ap.parse_args()
@@ -97,6 +98,8 @@ def main():
                 for k, s in stores.items():
                     s.flat.copy_(w0[k])
             Fn.bump_weight_epoch()
+            if args.sync_restore:
+                torch.cuda.synchronize()
     torch.cuda.synchronize()
     out = {"n_graphs": len(upd._graphs), "world": W, "rank": r}
     scale = 1.0 / W                                     # the all-reduce sums; 1/N is folded into the Adam kernel
