@@ -471,10 +471,17 @@ class RGBDUpdater:
                 main.wait_stream(side)
             if self.defer_dfake_wgrads:
                 self._gen_a_phase(st)                 # G fwd, D(x_fake) fwd + input-gradient chain
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    self._dfw_phase(st)               # D's fake-batch weight gradients, behind "dis" on the side stream
-                self._gen_b_phase(st)                 # 3-D loss + G backward
+                dbg = os.environ.get("RGBD_DEBUG_GENB", "")
+                if dbg == "dfw_on_main":              # diagnostics: D's fake wgrads on the main stream, after G's backward
+                    self._gen_b_phase(st)
+                    self._dfw_phase(st)
+                else:
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        self._dfw_phase(st)           # D's fake-batch weight gradients, behind "dis" on the side stream
+                    if dbg == "after_side":           # diagnostics: G's backward overlaps nothing
+                        main.wait_stream(side)
+                    self._gen_b_phase(st)             # 3-D loss + G backward
             else:
                 self._gen_phase(st)
             main.wait_stream(side)

@@ -21,7 +21,9 @@ def worst(L, ref, k, top=6):
         rows.append((rel(a, b), str(n), float(a @ b / (b @ b))))
     return " ".join(f"{n}:{r:.1e}(x{p:.2f})" for r, n, p in sorted(rows, reverse=True)[:top])
 ref = run("seq", ["--eager", "--sequential"])
-cases = [(f"plain run {i}", [], {}) for i in range(24)] + [(f"no D wgrad deferral {i}", [], {"RGBD_NO_D_DEFER": "1"}) for i in range(8)]
+cases = [(f"gen_b after side {i}", [], {"RGBD_DEBUG_GENB": "after_side"}) for i in range(16)] + \
+        [(f"dfw on main {i}", [], {"RGBD_DEBUG_GENB": "dfw_on_main"}) for i in range(16)] + \
+        [(f"no G wgrad deferral {i}", [], {"RGBD_NO_G_DEFER": "1"}) for i in range(12)]
 for i, (name, flags, env) in enumerate(cases):
     try:
         L = run(f"case{i}", flags, env)

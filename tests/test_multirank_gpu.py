@@ -56,37 +56,48 @@ def cosine(a, b):
     return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
 
 
-def _compare(a, b, what, grad_tol=1e-3):
+# Noise floor of the step (scripts/arrangement_noise.py, same arrangement run twice): the discriminator's gradients repeat
+# to ~1e-7 (only the fp32 atomics of its bias sums reorder); the generator's and the mapping network's to 2-6e-3 relative
+# (the warp-loss backward scatters with fp32 atomics, and one reordered sum flips bf16 roundings that the generator's 12
+# layers amplify).  Arrangements of the same step must agree to that floor.
+SAME_STEP = {"dis": 2e-5, "gen": 3e-2, "map": 3e-2}
+
+
+def _compare(a, b, what, tol, upd_tol=5e-2):
+    report = {}
     for k in ("map", "gen", "dis"):
         ga, gb = a[f"{k}/grad"], b[f"{k}/grad"]
         assert np.isfinite(ga).all() and np.isfinite(gb).all(), (what, k)
         assert np.linalg.norm(gb) > 0, (what, k)
-        assert cosine(ga, gb) > 0.9999, (what, k, cosine(ga, gb))
-        assert rel(ga, gb) < grad_tol, (what, k, rel(ga, gb))
-        assert abs(float(a[f"{k}/norm"]) / float(b[f"{k}/norm"]) - 1) < 1e-3, (what, k)
-        assert int(a[f"{k}/t"]) == int(b[f"{k}/t"]), (what, k)
-        assert rel(a[f"{k}/v"], b[f"{k}/v"]) < 10 * grad_tol, (what, k, rel(a[f"{k}/v"], b[f"{k}/v"]))
         da, db = a[f"{k}/delta"], b[f"{k}/delta"]
         assert np.abs(db).max() > 0, (what, k)
-        step = np.abs(db).max()
-        mismatch = float((np.abs(da - db) > 0.05 * step).mean())
-        assert mismatch < 2e-3, (what, k, mismatch)
+        mismatch = float((np.abs(da - db) > 0.05 * np.abs(db).max()).mean())
+        report[k] = dict(rel=rel(ga, gb), cos=cosine(ga, gb), vrel=rel(a[f"{k}/v"], b[f"{k}/v"]),
+                         norm=float(a[f"{k}/norm"]) / float(b[f"{k}/norm"]) - 1, upd_mismatch=mismatch)
+    if os.environ.get("RGBD_TEST_VERBOSE"):
+        print(what, report)
+    for k, r in report.items():
+        assert r["rel"] < tol[k], (what, k, r)
+        assert r["cos"] > 1 - tol[k] ** 2, (what, k, r)              # |a-b| <= tol |b|  =>  1 - cos <= ~tol^2 / 2
+        assert abs(r["norm"]) < tol[k], (what, k, r)
+        assert r["vrel"] < 3 * tol[k], (what, k, r)
+        assert int(a[f"{k}/t"]) == int(b[f"{k}/t"]), (what, k)
+        # beta1 = 0: the update is alpha * g / sqrt(v_hat); entries whose gradient changed by the tolerance move by it
+        assert r["upd_mismatch"] < (upd_tol if tol[k] > 1e-3 else 1e-3), (what, k, r)
 
 
 def test_graph_replay_two_streams_equals_eager_single_stream(tmp_path):
-    procs = [_run(tmp_path / "eager.npz", "--calls", "4", "--eager", "--sequential"),
-             ]
-    _wait(procs)
-    procs = [_run(tmp_path / "eager2.npz", "--calls", "4", "--eager")]          # eager, two streams + deferred wgrads
-    _wait(procs)
-    procs = [_run(tmp_path / "graph.npz", "--calls", "4")]                      # the shipped arrangement
-    _wait(procs)
-    e, e2, g = (np.load(tmp_path / f) for f in ("eager.npz", "eager2.npz", "graph.npz"))
-    assert int(e["n_graphs"]) == 0 and int(e2["n_graphs"]) == 0 and int(g["n_graphs"]) == 2   # body + optimizers
-    _compare(e2, e, "eager two-stream vs eager sequential")
-    _compare(g, e, "graph replay vs eager sequential")
+    _wait([_run(tmp_path / "eager.npz", "--calls", "4", "--eager", "--sequential")])
+    _wait([_run(tmp_path / "eager2.npz", "--calls", "4", "--eager")])          # eager, two streams + deferred wgrads
+    _wait([_run(tmp_path / "graph.npz", "--calls", "4")])                      # the shipped arrangement
+    _wait([_run(tmp_path / "gseq.npz", "--calls", "4", "--sequential")])       # graphs, one stream
+    e, e2, g, gs = (np.load(tmp_path / f) for f in ("eager.npz", "eager2.npz", "graph.npz", "gseq.npz"))
+    assert int(e["n_graphs"]) == 0 and int(e2["n_graphs"]) == 0 and int(g["n_graphs"]) == 2 and int(gs["n_graphs"]) == 2
+    _compare(e2, e, "eager two-stream vs eager sequential", SAME_STEP)
+    _compare(gs, e, "graph replay (one stream) vs eager sequential", SAME_STEP)
+    _compare(g, e, "graph replay (two branches) vs eager sequential", SAME_STEP)
     for key in ("obs/gen/loss_adv", "obs/gen/loss_rotate", "obs/dis/loss_adv", "obs/dis/loss_gp"):
-        assert abs(float(g[key]) - float(e[key])) < 1e-4 * max(1.0, abs(float(e[key]))), (key, float(g[key]), float(e[key]))
+        assert abs(float(g[key]) - float(e[key])) < 1e-5 * max(1.0, abs(float(e[key]))), (key, float(g[key]), float(e[key]))
 
 
 def test_fade_in_stage_graph_replay_equals_eager(tmp_path):
@@ -94,25 +105,33 @@ def test_fade_in_stage_graph_replay_equals_eager(tmp_path):
     _wait([_run(tmp_path / "graph.npz", "--calls", "4", "--stage", "9.5", "--batch", "4")])
     e, g = np.load(tmp_path / "eager.npz"), np.load(tmp_path / "graph.npz")
     assert int(g["n_graphs"]) == 2
-    _compare(g, e, "fade-in graph replay vs eager")
+    _compare(g, e, "fade-in graph replay vs eager", SAME_STEP)
 
 
-def test_two_ranks_on_half_batches_equal_one_rank_on_the_whole_batch(tmp_path):
-    _wait([_run(tmp_path / "one.npz", "--calls", "4")])
+# 2 ranks on half-batches vs 1 rank on the whole batch is NOT the same floating-point computation: the conv engine picks
+# its split-K factors and tile walk by batch size, so fp32 sums associate differently, ~2e-4 of the bf16 roundings per
+# layer differ, and the networks amplify that (one layer pair at stage 4, twelve at stage 10).  Tolerances by depth.
+RANKS_TOL = {4.0: {"dis": 1e-2, "gen": 3e-2, "map": 3e-2}, 10.0: {"dis": 8e-2, "gen": 0.2, "map": 0.2}}
+
+
+@pytest.mark.parametrize("stage", [4.0, 10.0])
+def test_two_ranks_on_half_batches_equal_one_rank_on_the_whole_batch(tmp_path, stage):
+    _wait([_run(tmp_path / "one.npz", "--calls", "4", "--stage", str(stage))])
     port = _free_port()
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), RGBD_DIST_BACKEND="gloo", RGBD_SHARE_DEVICE="1")
-        procs.append(_run(tmp_path / f"rank{r}.npz", "--calls", "4", env=env))
+        procs.append(_run(tmp_path / f"rank{r}.npz", "--calls", "4", "--stage", str(stage), env=env))
     _wait(procs)
     one, r0, r1 = (np.load(tmp_path / f) for f in ("one.npz", "rank0.npz", "rank1.npz"))
     assert int(r0["world"]) == 2 and int(r1["rank"]) == 1
-    assert int(r0["n_graphs"]) > 0                     # the data-parallel ranks replayed graphs too
-    for k in ("map", "gen", "dis"):                    # after the all-reduce every rank holds the same buffers
+    assert int(r0["n_graphs"]) == 3                    # body, generator optimizers, discriminator optimizer: replayed
+    for k in ("map", "gen", "dis"):                    # after the all-reduce every rank holds the same buffers ...
         np.testing.assert_array_equal(r0[f"{k}/grad"], r1[f"{k}/grad"])
-        np.testing.assert_array_equal(r0[f"{k}/delta"], r1[f"{k}/delta"])
-    _compare(r0, one, "2 ranks vs 1 rank")
+        np.testing.assert_array_equal(r0[f"{k}/delta"], r1[f"{k}/delta"])       # ... and takes the same Adam step
+        assert int(r0[f"{k}/t"]) == 4                  # the first of the 5 calls only broadcast (ChainerMN)
+    _compare(r0, one, f"2 ranks vs 1 rank, stage {stage}", RANKS_TOL[stage], upd_tol=0.5)
 
 
 def test_seed_ratio_chain_at_the_logit_clamp(tmp_path):
