@@ -370,6 +370,10 @@ class RGBDUpdater:
             wgrads = []
             with Fn.deferred_wgrads(wgrads):
                 torch.autograd.backward([x_fake], [gout])
+            if st.get("_side") is not None and os.environ.get("RGBD_DEBUG_GENB") != "no_wgrad_wait":
+                # the two weight-gradient batches (this one and D's for the fakes on the side stream) never run
+                # concurrently: see DESIGN.md section 3, "two concurrent weight-gradient batches"
+                torch.cuda.current_stream().wait_stream(st["_side"])
             Fn.run_deferred_wgrads(wgrads)
         else:
             torch.autograd.backward([x_fake], [gout])
@@ -463,7 +467,7 @@ class RGBDUpdater:
         self._prep_phase(st)
         if st["concurrent"]:
             main, side = torch.cuda.current_stream(), self._side_stream
-            st["_main"] = main
+            st["_main"], st["_side"] = main, side
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 self._dis_phase(st)                   # D on the reals: side stream
