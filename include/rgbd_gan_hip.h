@@ -275,6 +275,14 @@ int rgbd_image_grad_init(const float* gx, const float* ratio, float* out, int B,
 int rgbd_const_input_fwd(const float* w, const float* bias, void* out, int B, int HW, int C, float slope, void* stream);
 int rgbd_const_input_bwd(const void* dh, const float* w, const float* bias, float* dw, float* db, int B, int HW, int C,
                          float slope, void* stream);
+/* rgbd_l2norm_{fwd,bwd}: DCGANBlock's F.normalize over channels (net.py:621-648) on (npix, C) bf16 rows, C in
+ *   {128, 256, 512}: y = x / (||x||_2 + eps) with the norm in fp32; dx = dy / d - x (x . dy) / (n d^2), d = n + eps.
+ * rgbd_blur3x3_bf16: rescale.py:20-25 (depthwise [1 2 1]x[1 2 1]/16, zero padding) on NHWC bf16, H x W = the image the
+ *   blur acts on.  mode 0: y = blur(x); mode 1: y = blur(upscale2x(x)), x (B,H/2,W/2,C) (net.py:140-141);
+ *   mode 2: y (B,H/2,W/2,C) = 2x2 sums of blur(x), the adjoint of mode 1.  Mode 0 is its own adjoint. */
+int rgbd_l2norm_fwd(const void* x, void* y, int64_t npix, int C, float eps, void* stream);
+int rgbd_l2norm_bwd(const void* x, const void* dy, void* dx, int64_t npix, int C, float eps, void* stream);
+int rgbd_blur3x3_bf16(const void* x, void* y, int B, int H, int W, int C, int mode, void* stream);
 int rgbd_nhwc_to_rows_f32(const void* h, float* rows, int B, int HW, int C, void* stream);
 int rgbd_rows_to_nhwc_bf16(const float* rows, void* h, int B, int HW, int C, void* stream);
 

@@ -136,6 +136,14 @@ def down2(x):
     return F.avg_pool2d(x, 2, 2)
 
 
+def blur(x):
+    """rescale.py:20-25 with the kernel of net.py:136-139: depthwise [1 2 1] x [1 2 1] / 16, zero padding 1."""
+    k = torch.tensor([1.0, 2.0, 1.0])
+    k = (k[:, None] * k[None, :] / 16.0).reshape(1, 1, 3, 3).to(x.dtype)
+    B, C, H, W = x.shape
+    return F.conv2d(x.reshape(B * C, 1, H, W), k, padding=1).reshape(B, C, H, W)
+
+
 def l2_normalize(x, eps=1e-5):
     """chainer F.normalize(axis=1): x / (||x||_2 + eps)."""
     return x / (torch.sqrt((x * x).sum(dim=1, keepdim=True)) + eps)
@@ -276,8 +284,8 @@ def style_block(p, name, w, h):
     return adain(h, eq_linear(w, p, name + "/s", gain=1.0), eq_linear(w, p, name + "/b", gain=1.0))
 
 
-def synthesis_block(p, i, w, x):
-    """net.py:130-161 (SynthesisBlock.forward) with add_noise=False, enable_blur=False."""
+def synthesis_block(p, i, w, x, enable_blur=False):
+    """net.py:130-161 (SynthesisBlock.forward) with add_noise=False."""
     pre = f"gen/blocks/{i}"
     if i == 0:
         W = p[pre + "/W"]
@@ -286,7 +294,7 @@ def synthesis_block(p, i, w, x):
     else:
         # engine: conv epilogue stores bf16(lrelu(acc + b)); the fused AdaIN backward rounds the gradient once, AFTER
         # the activation mask (rg), not between the two (rf)
-        h = eq_conv(up2(x), p, pre + "/c0", 1)
+        h = eq_conv(rb(blur(up2(x))) if enable_blur else up2(x), p, pre + "/c0", 1)
         h = rf(lrelu(rg(h + p[pre + "/b0/b"].reshape(1, -1, 1, 1))))
     h = rb(style_block(p, pre + "/s0", w, h))
     h = eq_conv(h, p, pre + "/c1", 1)
@@ -307,7 +315,7 @@ def depth_head(h):
     return torch.cat([h[:, :3], 1.0 / (F.softplus(h[:, -1:]) + 1e-4)], dim=1)
 
 
-def style_generator(p, w, w2, stage, theta9, rgbd=True, return_feature=False):
+def style_generator(p, w, w2, stage, theta9, rgbd=True, return_feature=False, enable_blur=False):
     """net.py:232-311 (StyleGenerator.forward), train mode."""
     st, alpha = split_stage(stage)
     feat = None
@@ -315,8 +323,8 @@ def style_generator(p, w, w2, stage, theta9, rgbd=True, return_feature=False):
 
     def run_block(i, w_cur, h):
         if rgbd and i < 2:
-            return synthesis_block(p, i, rotate_w(p, w_cur, theta9), h)
-        return synthesis_block(p, i, w_cur, h)
+            return synthesis_block(p, i, rotate_w(p, w_cur, theta9), h, enable_blur)
+        return synthesis_block(p, i, w_cur, h, enable_blur)
 
     if st % 2 == 0:
         k = (st - 2) // 2
@@ -337,21 +345,21 @@ def style_generator(p, w, w2, stage, theta9, rgbd=True, return_feature=False):
                 feat = h
         h0 = up2(eq_conv(h, p, f"gen/outs/{k}", 0, gain=1.0))
         # net.py:290 -- the faded-in block gets the un-rotated w (whatever `w` is now)
-        h1 = eq_conv(synthesis_block(p, k + 1, w, h), p, f"gen/outs/{k + 1}", 0, gain=1.0)
+        h1 = eq_conv(synthesis_block(p, k + 1, w, h, enable_blur), p, f"gen/outs/{k + 1}", 0, gain=1.0)
         h = (1.0 - alpha) * h0 + alpha * h1
     if rgbd:
         h = depth_head(h)
     return (h, feat) if return_feature else h
 
 
-def stylegan_generator(p, z, stage, theta9, rgbd=True, return_feature=False):
+def stylegan_generator(p, z, stage, theta9, rgbd=True, return_feature=False, enable_blur=False):
     """net.py:345-354 (StyleGANGenerator.forward): z (B,2ch,1,1) split in two latents."""
     z = torch.as_tensor(z)
     theta9 = torch.as_tensor(theta9) if theta9 is not None else None
     half = z.shape[1] // 2
     w = mapping(p, z[:, :half])
     w2 = mapping(p, z[:, half:])
-    return style_generator(p, w, w2, stage, theta9, rgbd, return_feature)
+    return style_generator(p, w, w2, stage, theta9, rgbd, return_feature, enable_blur)
 
 
 # ---------------------------------------------------------------- DCGAN (PGGAN) generator
@@ -391,7 +399,7 @@ def dcgan_generator(p, z, stage, theta9, rgbd=True):
 
 # ---------------------------------------------------------------- discriminator
 
-def dis_block(p, i, x, res=True):
+def dis_block(p, i, x, res=True, enable_blur=False):
     """net.py:408-426 (DiscriminatorBlock.forward) / :372-377 (base block i == 0)."""
     pre = f"blocks/{i}"
     if i == 0:
@@ -402,10 +410,11 @@ def dis_block(p, i, x, res=True):
     h = eq_conv(h, p, pre + "/c1", 1)
     if res:
         h = h + rb(eq_conv(x, p, pre + "/c_sc", 1))      # the shortcut is stored (bf16) and re-read as the residual
-    return rb(down2(rb(lrelu(rg(h)))))
+    h = rb(down2(rb(lrelu(rg(h)))))
+    return rb(blur(h)) if enable_blur else h                # net.py:422-423
 
 
-def discriminator(p, x, stage, return_hidden=False, res=True):
+def discriminator(p, x, stage, return_hidden=False, res=True, enable_blur=False):
     """net.py:469-504 (Discriminator.forward)."""
     st, alpha = split_stage(stage)
     feat = None
@@ -415,16 +424,16 @@ def discriminator(p, x, stage, return_hidden=False, res=True):
         for i in reversed(range(0, k + 2)):
             if i == 3:
                 feat = h
-            h = dis_block(p, i, h, res)
+            h = dis_block(p, i, h, res, enable_blur)
     else:
         k = (st - 1) // 2
         h0 = rb(lrelu(rg(eq_conv(down2(x), p, f"ins/{k}", 0))))
-        h1 = dis_block(p, k + 1, rb(lrelu(rg(eq_conv(x, p, f"ins/{k + 1}", 0)))), res)
+        h1 = dis_block(p, k + 1, rb(lrelu(rg(eq_conv(x, p, f"ins/{k + 1}", 0)))), res, enable_blur)
         h = rb((1.0 - alpha) * h0 + alpha * h1)
         for i in reversed(range(0, k + 1)):
             if i == 3:
                 feat = h
-            h = dis_block(p, i, h, res)
+            h = dis_block(p, i, h, res, enable_blur)
     return (h, feat) if return_hidden else h
 
 

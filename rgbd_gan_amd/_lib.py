@@ -55,6 +55,9 @@ PROTOTYPES = {
     "rgbd_image_grad_init": ([_P, _P, _P, c_int, c_int, c_int, c_int, _P], c_int),
     "rgbd_const_input_fwd": ([_P, _P, _P, c_int, c_int, c_int, c_float, _P], c_int),
     "rgbd_const_input_bwd": ([_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P], c_int),
+    "rgbd_l2norm_fwd": ([_P, _P, c_int64, c_int, c_float, _P], c_int),
+    "rgbd_l2norm_bwd": ([_P, _P, _P, c_int64, c_int, c_float, _P], c_int),
+    "rgbd_blur3x3_bf16": ([_P, _P, c_int, c_int, c_int, c_int, c_int, _P], c_int),
     "rgbd_nhwc_to_rows_f32": ([_P, _P, c_int, c_int, c_int, _P], c_int),
     "rgbd_rows_to_nhwc_bf16": ([_P, _P, c_int, c_int, c_int, _P], c_int),
     "rgbd_linear_bwd": ([_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_float, c_int, _P], c_int),

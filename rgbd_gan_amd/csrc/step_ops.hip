@@ -202,6 +202,102 @@ __global__ __launch_bounds__(256) void rows_to_nhwc_kernel(const float* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------ channel-wise L2 normalise
+// DCGANBlock (net.py:621-648): F.normalize over channels, y = x / (||x||_2 + 1e-5), on NHWC bf16 (fp32 norm).
+// LPP lanes own one pixel (8 channels each); the norm meets through wave shuffles.
+template <int LPP>
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const unsigned short* __restrict__ x,
+                                                         unsigned short* __restrict__ y, long npix, float eps) {
+    constexpr int PPB = 256 / LPP;
+    const int sub = threadIdx.x % LPP;
+    for (long pix = (long)blockIdx.x * PPB + threadIdx.x / LPP; pix < npix; pix += (long)gridDim.x * PPB) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(x + (pix * LPP + sub) * 8);
+        float f[8], ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { f[2 * k] = bf16_lo(v[k]); f[2 * k + 1] = bf16_hi(v[k]); }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ss += f[k] * f[k];
+#pragma unroll
+        for (int off = LPP / 2; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+        const float inv = 1.f / (sqrtf(ss) + eps);
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = pack_bf16x2(f[2 * k] * inv, f[2 * k + 1] * inv);
+        *reinterpret_cast<u32x4*>(y + (pix * LPP + sub) * 8) = o;
+    }
+}
+// dx = dy / d - x * (x . dy) / (n * d^2),  n = ||x||, d = n + eps
+template <int LPP>
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const unsigned short* __restrict__ x,
+                                                         const unsigned short* __restrict__ dy,
+                                                         unsigned short* __restrict__ dx, long npix, float eps) {
+    constexpr int PPB = 256 / LPP;
+    const int sub = threadIdx.x % LPP;
+    for (long pix = (long)blockIdx.x * PPB + threadIdx.x / LPP; pix < npix; pix += (long)gridDim.x * PPB) {
+        const long o8 = (pix * LPP + sub) * 8;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(x + o8), g = *reinterpret_cast<const u32x4*>(dy + o8);
+        float f[8], gg[8], ss = 0.f, dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f[2 * k] = bf16_lo(v[k]); f[2 * k + 1] = bf16_hi(v[k]);
+            gg[2 * k] = bf16_lo(g[k]); gg[2 * k + 1] = bf16_hi(g[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ss += f[k] * f[k]; dot += f[k] * gg[k]; }
+#pragma unroll
+        for (int off = LPP / 2; off > 0; off >>= 1) { ss += __shfl_xor(ss, off, 64); dot += __shfl_xor(dot, off, 64); }
+        const float n = sqrtf(ss), d = n + eps;
+        const float a = 1.f / d, c = n > 0.f ? dot / (n * d * d) : 0.f;
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = pack_bf16x2(gg[2 * k] * a - f[2 * k] * c, gg[2 * k + 1] * a - f[2 * k + 1] * c);
+        *reinterpret_cast<u32x4*>(dx + o8) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ 3x3 binomial blur
+// rescale.py:20-25 (blur = depthwise [1 2 1] x [1 2 1] / 16, zero padding 1) on NHWC bf16, used when enable_blur is set:
+//   mode 0: y = blur(x)                                   (after downscale2x, net.py:422-423; self-adjoint)
+//   mode 1: y = blur(upscale2x(x)), x (B,H/2,W/2,C)       (net.py:140-141; the upsampled tensor is never written)
+//   mode 2: y = sum_{2x2}(blur(x)), y (B,H/2,W/2,C)       (adjoint of mode 1)
+__global__ __launch_bounds__(256) void blur3x3_kernel(const unsigned short* __restrict__ x, unsigned short* __restrict__ y,
+                                                      int B, int H, int W, int C, int mode) {
+    // H, W: size of the image the blur acts on; mode 1 reads (H/2, W/2), mode 2 writes (H/2, W/2)
+    const int cvec = C >> 3;
+    const int Ho = mode == 2 ? H >> 1 : H, Wo = mode == 2 ? W >> 1 : W;
+    const long total = (long)B * Ho * Wo * cvec;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int cv = (int)(e % cvec);
+        long r = e / cvec;
+        const int xo = (int)(r % Wo);
+        r /= Wo;
+        const int yo = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int reps = mode == 2 ? 2 : 1;
+        for (int sy = 0; sy < reps; ++sy)
+            for (int sx = 0; sx < reps; ++sx) {
+                const int cy = mode == 2 ? 2 * yo + sy : yo, cx = mode == 2 ? 2 * xo + sx : xo;
+#pragma unroll
+                for (int i = -1; i <= 1; ++i)
+#pragma unroll
+                    for (int j = -1; j <= 1; ++j) {
+                        const int yy = cy + i, xx = cx + j;
+                        if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) continue;
+                        const float wgt = (float)((2 - (i < 0 ? -i : i)) * (2 - (j < 0 ? -j : j))) * (1.f / 16.f);
+                        const long src = mode == 1 ? (((long)b * (H >> 1) + (yy >> 1)) * (W >> 1) + (xx >> 1))
+                                                   : (((long)b * H + yy) * W + xx);
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(x + (src * cvec + cv) * 8);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { acc[2 * k] += wgt * bf16_lo(v[k]); acc[2 * k + 1] += wgt * bf16_hi(v[k]); }
+                    }
+            }
+        u32x4 o = {pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]), pack_bf16x2(acc[4], acc[5]),
+                   pack_bf16x2(acc[6], acc[7])};
+        *reinterpret_cast<u32x4*>(y + e * 8) = o;
+    }
+}
+
 inline unsigned grid_for(long n, long cap = 4096) {
     const long b = (n + 255) / 256;
     return (unsigned)(b < 1 ? 1 : (b < cap ? b : cap));
@@ -301,5 +397,41 @@ extern "C" int rgbd_rows_to_nhwc_bf16(const float* rows, void* h, int B, int HW,
     RGBD_REQUIRE(h && rows && B > 0 && HW > 0 && C > 0, "rgbd_rows_to_nhwc_bf16: bad arguments");
     rows_to_nhwc_kernel<<<grid_for((long)B * HW * C), 256, 0, (hipStream_t)stream>>>(rows, (unsigned short*)h, B, HW, C);
     RGBD_CHECK_LAUNCH("rows_to_nhwc_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_l2norm_fwd(const void* x, void* y, int64_t npix, int C, float eps, void* stream) {
+    RGBD_REQUIRE(x && y && npix > 0 && (C == 128 || C == 256 || C == 512), "rgbd_l2norm_fwd: C must be 128, 256 or 512 (C=%d)", C);
+    hipStream_t st = (hipStream_t)stream;
+    const int lpp = C / 8;
+    const unsigned blocks = grid_for(npix * lpp);
+    if (lpp == 16)      l2norm_fwd_kernel<16><<<blocks, 256, 0, st>>>((const unsigned short*)x, (unsigned short*)y, npix, eps);
+    else if (lpp == 32) l2norm_fwd_kernel<32><<<blocks, 256, 0, st>>>((const unsigned short*)x, (unsigned short*)y, npix, eps);
+    else                l2norm_fwd_kernel<64><<<blocks, 256, 0, st>>>((const unsigned short*)x, (unsigned short*)y, npix, eps);
+    RGBD_CHECK_LAUNCH("l2norm_fwd_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_l2norm_bwd(const void* x, const void* dy, void* dx, int64_t npix, int C, float eps, void* stream) {
+    RGBD_REQUIRE(x && dy && dx && npix > 0 && (C == 128 || C == 256 || C == 512),
+                 "rgbd_l2norm_bwd: C must be 128, 256 or 512 (C=%d)", C);
+    hipStream_t st = (hipStream_t)stream;
+    const int lpp = C / 8;
+    const unsigned blocks = grid_for(npix * lpp);
+    const unsigned short *xs = (const unsigned short*)x, *gs = (const unsigned short*)dy;
+    if (lpp == 16)      l2norm_bwd_kernel<16><<<blocks, 256, 0, st>>>(xs, gs, (unsigned short*)dx, npix, eps);
+    else if (lpp == 32) l2norm_bwd_kernel<32><<<blocks, 256, 0, st>>>(xs, gs, (unsigned short*)dx, npix, eps);
+    else                l2norm_bwd_kernel<64><<<blocks, 256, 0, st>>>(xs, gs, (unsigned short*)dx, npix, eps);
+    RGBD_CHECK_LAUNCH("l2norm_bwd_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_blur3x3_bf16(const void* x, void* y, int B, int H, int W, int C, int mode, void* stream) {
+    RGBD_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && mode >= 0 && mode <= 2 &&
+                 (mode == 0 || (H % 2 == 0 && W % 2 == 0)), "rgbd_blur3x3_bf16: bad arguments (H=%d W=%d C=%d mode=%d)", H, W, C, mode);
+    const long outs = (long)B * (mode == 2 ? H / 2 : H) * (mode == 2 ? W / 2 : W) * (C / 8);
+    blur3x3_kernel<<<grid_for(outs, 8192), 256, 0, (hipStream_t)stream>>>((const unsigned short*)x, (unsigned short*)y, B, H,
+                                                                        W, C, mode);
+    RGBD_CHECK_LAUNCH("blur3x3_kernel");
     return 0;
 }

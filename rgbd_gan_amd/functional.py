@@ -933,6 +933,11 @@ def nhwc_to_rows(h):
     return _NhwcToRows.apply(h)
 
 
+def rows_to_nhwc(rows, H, W, C):
+    """(B, C*H*W) fp32 rows in (c,h,w) order -> (B,H,W,C) bf16 (DCGAN input layer, net.py:713-719)."""
+    return _RowsToNhwc.apply(rows, (rows.shape[0], H, W, C))
+
+
 class _ConstInput(torch.autograd.Function):
     """SynthesisBlock 0 (net.py:130-153): lrelu(W + b0) broadcast over the batch as (B,4,4,C) bf16, one launch; the
     backward adds the batch-summed, masked gradient to W's and b0's bound gradient buffers (first order only)."""
@@ -980,6 +985,48 @@ class _R1Penalty(torch.autograd.Function):
 
 def r1_penalty(grad_x, lambda_gp):
     return _R1Penalty.apply(grad_x, float(lambda_gp))
+
+
+class _L2Norm(torch.autograd.Function):
+    """F.normalize over channels (DCGANBlock, net.py:621-648) on NHWC bf16, first order."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        return kernels.l2norm_fwd(x)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        return kernels.l2norm_bwd(x, dy.contiguous())
+
+
+def l2_normalize(x):
+    return _L2Norm.apply(x)
+
+
+class _Blur(torch.autograd.Function):
+    """rescale.py:20-25 on NHWC bf16; linear and symmetric, so every order of its derivative is the same kernel family:
+    mode 0 is self-adjoint, modes 1 (blur after the nearest upsample) and 2 (2x2 sums of the blur) are adjoint."""
+
+    @staticmethod
+    def forward(ctx, x, mode):
+        ctx.mode = mode
+        return kernels.blur3x3(x.contiguous(), mode)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _Blur.apply(g.contiguous(), {0: 0, 1: 2, 2: 1}[ctx.mode]), None
+
+
+def blur(x):
+    return _Blur.apply(x, 0)
+
+
+def upsample_blur(x):
+    return _Blur.apply(x, 1)
 
 
 class _PixelNorm(torch.autograd.Function):

@@ -687,6 +687,35 @@ def const_input_bwd(dh, w, bias, dw, db, slope=0.2):
                                                 float(slope), _stream()), "rgbd_const_input_bwd")
 
 
+def l2norm_fwd(x, eps=1e-5):
+    """(.., C) bf16 -> x / (||x||_2 + eps) over the last dim (fp32 norm)."""
+    _chk(x, BF16, "x")
+    y = torch.empty_like(x)
+    C = x.shape[-1]
+    _lib.check(_lib.load().rgbd_l2norm_fwd(_ptr(x), _ptr(y), x.numel() // C, C, float(eps), _stream()), "rgbd_l2norm_fwd")
+    return y
+
+
+def l2norm_bwd(x, dy, eps=1e-5):
+    _chk(x, BF16, "x"); _chk(dy, BF16, "dy")
+    dx = torch.empty_like(x)
+    C = x.shape[-1]
+    _lib.check(_lib.load().rgbd_l2norm_bwd(_ptr(x), _ptr(dy), _ptr(dx), x.numel() // C, C, float(eps), _stream()),
+               "rgbd_l2norm_bwd")
+    return dx
+
+
+def blur3x3(x, mode=0):
+    """NHWC bf16.  mode 0: blur(x); mode 1: blur(upscale2x(x)) -> (B,2H,2W,C); mode 2: 2x2 sums of blur(x) -> (B,H/2,W/2,C)."""
+    _chk(x, BF16, "x")
+    B, H, W, C = x.shape
+    if mode == 1:
+        H, W = 2 * H, 2 * W
+    out = torch.empty((B, H // 2, W // 2, C) if mode == 2 else (B, H, W, C), dtype=BF16, device=x.device)
+    _lib.check(_lib.load().rgbd_blur3x3_bf16(_ptr(x), _ptr(out), B, H, W, C, int(mode), _stream()), "rgbd_blur3x3_bf16")
+    return out
+
+
 def nhwc_to_rows(h):
     """(B,H,W,C) bf16 -> (B, C*H*W) fp32 rows in (c,h,w) order."""
     _chk(h, BF16, "h")

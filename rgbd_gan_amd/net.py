@@ -10,8 +10,8 @@ Inputs / outputs at this surface are NCHW fp32 device tensors like the reference
 are NHWC bf16 and every 3x3 convolution runs in rgbd_gan_amd/csrc/conv.hip.  Parameters carry the reference's
 Chainer names (``namedparams``) so its snapshots load unchanged.
 
-Not supported (unreachable with the shipped configs, asserted): enable_blur, sn, use_encoder (bigan),
-use_occupancy_net, rotate_conv_input.
+enable_blur (rescale.py:20-25) is supported through rgbd_blur3x3_bf16.  Not supported (unreachable with the shipped
+configs, asserted): sn, use_encoder (bigan), use_occupancy_net, rotate_conv_input.
 """
 import contextlib
 import math
@@ -141,8 +141,9 @@ class MappingNetwork(_Link):
 class StyleGenerator(_Link):
     """net.py:164-311.  Channel plan at ch: blocks (ch,ch,ch,ch,ch/2,ch/4) at 4..128 px."""
 
-    def __init__(self, ch, device, rgbd=True, initial_depth=1.0, seed=1):
+    def __init__(self, ch, device, rgbd=True, initial_depth=1.0, seed=1, enable_blur=False):
         self.ch, self.rgbd, self.max_stage = ch, rgbd, 17
+        self.enable_blur = bool(enable_blur)       # net.py:140-141: c0(blur(upscale2x(h))) instead of c0(upscale2x(h))
         self.chans = [(ch, ch), (ch, ch), (ch, ch), (ch, ch), (ch // 2, ch), (ch // 4, ch // 2)]  # (out, in)
         out_ch = 4 if rgbd else 3
         w_init, b_init = depth_row_init(initial_depth, out_ch, rgbd)
@@ -214,7 +215,12 @@ class StyleGenerator(_Link):
         if i == 0:
             h = Fn.const_input(p[pre + "/W"], p[pre + "/b0/b"], w.shape[0])      # lrelu(W + b0), (B,4,4,ch) bf16
         elif styles is not None:      # conv -> bias -> lrelu -> style as one node (fused backward)
-            h = Fn.conv_bias_lrelu_adain(x, self.c0[i], p[pre + "/b0/b"], *styles[(i, "s0")], upsample=True)
+            if self.enable_blur:      # the blurred upsampled tensor is materialised (one HIP pass), the conv reads it plain
+                h = Fn.conv_bias_lrelu_adain(Fn.upsample_blur(x), self.c0[i], p[pre + "/b0/b"], *styles[(i, "s0")])
+            else:
+                h = Fn.conv_bias_lrelu_adain(x, self.c0[i], p[pre + "/b0/b"], *styles[(i, "s0")], upsample=True)
+        elif self.enable_blur:
+            h = Fn.conv_bias_lrelu(Fn.upsample_blur(x), self.c0[i], p[pre + "/b0/b"])
         else:
             h = Fn.conv_bias_lrelu(x, self.c0[i], p[pre + "/b0/b"], upsample=True)
         if i == 0 or styles is None:
@@ -290,13 +296,13 @@ class StyleGenerator(_Link):
 class StyleGANGenerator(_Link):
     def __init__(self, ch, enable_blur=False, rgbd=False, rotate_conv_input=False, use_encoder=False,
                  use_occupancy_net=False, initial_depth=None, device="cuda:0", seed=0):
-        assert not enable_blur, "enable_blur is not supported (False in every shipped config)"
         assert not rotate_conv_input and not use_encoder and not use_occupancy_net, "unsupported generator option"
         assert ch % 256 == 0, "the MFMA conv engine needs ch/4 to be a multiple of 64"
         self.ch = ch
         self.device = torch.device(device)
         self.mapping = MappingNetwork(ch, device, seed)
-        self.gen = StyleGenerator(ch, device, rgbd, 1.0 if initial_depth is None else initial_depth, seed + 1)
+        self.gen = StyleGenerator(ch, device, rgbd, 1.0 if initial_depth is None else initial_depth, seed + 1,
+                                  enable_blur=bool(enable_blur))
         self.stores = (("mapping/", self.mapping.store), ("gen/", self.gen.store))
         self.train = True
 
@@ -335,9 +341,10 @@ class DCGANGenerator(_Link):
 
     def __init__(self, in_ch=128, ch=512, enable_blur=False, rgbd=False, use_encoder=False, use_occupancy_net=False,
                  initial_depth=None, device="cuda:0", seed=0):
-        assert not enable_blur and not use_encoder and not use_occupancy_net, "unsupported generator option"
-        assert ch % 256 == 0
+        assert not use_encoder and not use_occupancy_net, "unsupported generator option"
+        assert ch % 512 == 0, "the channel-wise normalise kernel takes 128, 256 or 512 channels (ch = 512)"
         self.in_ch, self.ch, self.rgbd, self.max_stage = in_ch, ch, rgbd, 17
+        self.enable_blur = bool(enable_blur)
         self.device = torch.device(device)
         self.chans = [(ch, ch), (ch, ch), (ch, ch), (ch // 2, ch), (ch // 4, ch // 2)]
         out_ch = 4 if rgbd else 3
@@ -364,15 +371,17 @@ class DCGANGenerator(_Link):
 
     @staticmethod
     def _normalize(h):
-        """chainer F.normalize over channels: x / (||x||_2 + 1e-5); fp32 norm."""
-        f = h.float()
-        return (f / (torch.sqrt((f * f).sum(dim=3, keepdim=True)) + 1e-5)).to(BF16)
+        """chainer F.normalize over channels: x / (||x||_2 + 1e-5); fp32 norm (rgbd_l2norm_*)."""
+        return Fn.l2_normalize(h)
 
     def _block(self, i, x):
         p = self.store.params
         pre = f"blocks/{i}"
-        h = self._normalize(Fn.conv_bias_lrelu(x, self.c0[i], p[pre + "/b0/b"], upsample=True))
-        return self._normalize(Fn.conv_bias_lrelu(h, self.c1[i], p[pre + "/b1/b"]))
+        if self.enable_blur:
+            h = Fn.conv_bias_lrelu(Fn.upsample_blur(x), self.c0[i], p[pre + "/b0/b"])
+        else:
+            h = Fn.conv_bias_lrelu(x, self.c0[i], p[pre + "/b0/b"], upsample=True)
+        return self._normalize(Fn.conv_bias_lrelu(self._normalize(h), self.c1[i], p[pre + "/b1/b"]))
 
     def _to_rgbd(self, i, h):
         p = self.store.params
@@ -389,8 +398,12 @@ class DCGANGenerator(_Link):
         else:
             h = z
         p = self.store.params
-        h = F.linear(h * _inv_c(h.shape[1]), p["linear/c/W"], p["linear/c/b"])
-        h = h.reshape(z.shape[0], self.ch, 4, 4).permute(0, 2, 3, 1).contiguous().to(BF16)
+        # input layer (net.py:671,713-719): equalized linear to (ch,4,4) on the small-batch HIP linear kernels, rows in
+        # slices of 64; then NCHW fp32 rows -> NHWC bf16 (rgbd_rows_to_nhwc_bf16)
+        k_in = h.shape[1]
+        rows = [Fn.dense(h[r0:r0 + 64].contiguous(), p["linear/c/W"], p["linear/c/b"], _inv_c(k_in), act=False)
+                for r0 in range(0, h.shape[0], 64)]
+        h = Fn.rows_to_nhwc(rows[0] if len(rows) == 1 else torch.cat(rows), 4, 4, self.ch)
         if st % 2 == 0:
             k = (st - 2) // 2
             for i in range(0, k + 1):
@@ -415,10 +428,10 @@ class Discriminator(_Link):
     """net.py:429-504 with res blocks (net.py:380-426) and the 4x4 base block (net.py:357-377)."""
 
     def __init__(self, ch=512, out_dim=1, enable_blur=False, sn=False, res=False, device="cuda:0", seed=100):
-        assert not enable_blur, "enable_blur is not supported"
         assert not sn, "spectral normalisation is not supported (sn: False in every shipped config)"
         assert ch % 256 == 0
         self.ch, self.sn, self.res, self.max_stage = ch, sn, res, 17
+        self.enable_blur = bool(enable_blur)       # net.py:422-423: blur(downscale2x(h)) at the end of every block
         self.device = torch.device(device)
         self.chans = [None, (ch, ch), (ch, ch), (ch, ch), (ch // 2, ch), (ch // 4, ch // 2)]  # (in, out)
         self.in_chans = [ch, ch, ch, ch, ch // 2, ch // 4]
@@ -477,8 +490,9 @@ class Discriminator(_Link):
         tie = Fn.ResidualTie(p[pre + "/c_sc/c/b"]) if self.res else None
         h = Fn.conv_bias_lrelu(x, self.conv[pre + "/c0"], p[pre + "/c0/c/b"], entry_tie=tie)
         sc = Fn.conv_bias(x, self.conv[pre + "/c_sc"], p[pre + "/c_sc/c/b"], tie=tie) if self.res else None
-        return Fn.conv_bias_lrelu(h, self.conv[pre + "/c1"], p[pre + "/c1/c/b"], residual=sc, pool=True,
-                                  residual_tie=tie)
+        h = Fn.conv_bias_lrelu(h, self.conv[pre + "/c1"], p[pre + "/c1/c/b"], residual=sc, pool=True,
+                               residual_tie=tie)
+        return Fn.blur(h) if self.enable_blur else h
 
     def __call__(self, x, stage, return_hidden=False):
         x = _as_device_tensor(x, self.device)
