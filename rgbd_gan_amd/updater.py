@@ -464,35 +464,47 @@ class RGBDUpdater:
         """prep, then the generator phase || the discriminator-on-reals phase, then the join: the whole step up to the
         optimizers.  In the two-stream arrangement the side stream forks off the current stream and rejoins it, both
         inside this function, so it can be captured as one graph with two branches."""
-        self._prep_phase(st)
+        rng = self._range
+        with rng("prep"), _alpha_ctx(st):         # fade-in: downsize_real blends with the device-resident alpha too
+            self._prep_phase(st)
         if st["concurrent"]:
             main, side = torch.cuda.current_stream(), self._side_stream
             st["_main"], st["_side"] = main, side
             side.wait_stream(main)
-            with torch.cuda.stream(side):
+            with torch.cuda.stream(side), rng("dis"):
                 self._dis_phase(st)                   # D on the reals: side stream
             if os.environ.get("RGBD_DEBUG_SERIALIZE"):    # diagnostics: no overlap of the two phases
                 main.wait_stream(side)
             if self.defer_dfake_wgrads:
-                self._gen_a_phase(st)                 # G fwd, D(x_fake) fwd + input-gradient chain
-                dbg = os.environ.get("RGBD_DEBUG_GENB", "")
-                if dbg == "dfw_on_main":              # diagnostics: D's fake wgrads on the main stream, after G's backward
-                    self._gen_b_phase(st)
-                    self._dfw_phase(st)
-                else:
-                    side.wait_stream(main)
-                    with torch.cuda.stream(side):
-                        self._dfw_phase(st)           # D's fake-batch weight gradients, behind "dis" on the side stream
-                    if dbg == "after_side":           # diagnostics: G's backward overlaps nothing
-                        main.wait_stream(side)
+                with rng("gen_a"):
+                    self._gen_a_phase(st)             # G fwd, D(x_fake) fwd + input-gradient chain
+                side.wait_stream(main)
+                with torch.cuda.stream(side), rng("dfw"):
+                    self._dfw_phase(st)               # D's fake-batch weight gradients, behind "dis" on the side stream
+                with rng("gen_b"):
                     self._gen_b_phase(st)             # 3-D loss + G backward
             else:
-                self._gen_phase(st)
+                with rng("gen"):
+                    self._gen_phase(st)
             main.wait_stream(side)
         else:
-            self._gen_phase(st)
-            self._dis_phase(st)
-        self._join_phase(st)
+            with rng("gen"):
+                self._gen_phase(st)
+            with rng("dis"):
+                self._dis_phase(st)
+        with rng("join"):
+            self._join_phase(st)
+
+    @contextlib.contextmanager
+    def _range(self, name):
+        if not self.profile_ranges:
+            yield
+            return
+        torch.cuda.nvtx.range_push(f"rgbd/{name}")
+        try:
+            yield
+        finally:
+            torch.cuda.nvtx.range_pop()
 
     def _opt_phase(self, st):
         self._opt_g_phase(st)
@@ -508,8 +520,21 @@ class RGBDUpdater:
     def _opt_d_phase(self, st):
         self._optimizers["dis"].update()
 
+    profile_ranges = False      # train_rgbd.py sets it for `nvprof` / `enable_cuda_profiling` (train_rgbd.py:100,363-364,462)
+
     def _run_phase(self, name, fn, st, key):
-        """Eager for the first calls of a configuration, then capture once and replay."""
+        """Eager for the first calls of a configuration, then capture once and replay.  With profile_ranges every phase
+        is bracketed by a roctx range (torch.cuda.nvtx maps to roctx on ROCm), visible to rocprofv3 --marker-trace."""
+        if self.profile_ranges:
+            torch.cuda.nvtx.range_push(f"rgbd/{name}")
+            try:
+                self._run_phase_inner(name, fn, st, key)
+            finally:
+                torch.cuda.nvtx.range_pop()
+            return
+        self._run_phase_inner(name, fn, st, key)
+
+    def _run_phase_inner(self, name, fn, st, key):
         if key is None or name not in self.graph_phases:
             fn(st)
             return

@@ -20,12 +20,13 @@ def worst(L, ref, k, top=6):
             continue
         rows.append((rel(a, b), str(n), float(a @ b / (b @ b))))
     return " ".join(f"{n}:{r:.1e}(x{p:.2f})" for r, n, p in sorted(rows, reverse=True)[:top])
-ref = run("seq", ["--eager", "--sequential"])
-cases = [(f"default (G wgrads wait for side) {i}", [], {}) for i in range(40)] + \
-        [(f"no wait {i}", [], {"RGBD_DEBUG_GENB": "no_wgrad_wait"}) for i in range(16)]
+EXTRA = sys.argv[1:]
+ref = run("seq", ["--eager", "--sequential"] + EXTRA)
+cases = [(f"eager 2s {i}", ["--eager"], {}) for i in range(2)] + [(f"graph seq {i}", ["--sequential"], {}) for i in range(3)] + \
+        [(f"graph 2s {i}", [], {}) for i in range(6)]
 for i, (name, flags, env) in enumerate(cases):
     try:
-        L = run(f"case{i}", flags, env)
+        L = run(f"case{i}", list(flags) + EXTRA, env)
     except AssertionError as exc:
         print(name, "FAILED", str(exc)[-300:]); continue
     rels = {k: rel(L[f"{k}/grad"], ref[f"{k}/grad"]) for k in ("map", "gen", "dis")}

@@ -158,7 +158,7 @@ def _step_pair(stage, emulate, B=4, seed=2, in_seed=7):
 # initialisation roughly doubles a perturbation per layer (scripts/diag_emulation.py: forward rel-L2 1.3e-3 after 4
 # convs, 1.5e-2 after 12).  So the shallow stage pins every gradient tightly, the full-depth stages as far as the
 # conditioning of 24 layers allows.
-STEP_TOL = {4.0: (3e-3, 0.995, 0.99, 4e-2, 1.5e-2), 10.0: (2e-2, 0.98, 0.9, 8e-2, 4e-2), 9.5: (2e-2, 0.98, 0.9, 8e-2, 4e-2)}
+STEP_TOL = {4.0: (3e-3, 0.995, 0.99, 4e-2, 1.5e-2), 10.0: (2e-2, 0.98, 0.9, 8e-2, 4e-2), 9.5: (2e-2, 0.96, 0.9, 0.1, 4e-2)}
 # mathematically zero gradient: block 0's bias shifts a constant input that the following instance norm removes again
 # (W = 1, b0 = 0 at initialisation); what the engine and the oracle hold there is rounding noise of different size
 ILL_CONDITIONED = {"gen/blocks/0/b0/b"}

@@ -111,7 +111,7 @@ def test_fade_in_stage_graph_replay_equals_eager(tmp_path):
 # 2 ranks on half-batches vs 1 rank on the whole batch is NOT the same floating-point computation: the conv engine picks
 # its split-K factors and tile walk by batch size, so fp32 sums associate differently, ~2e-4 of the bf16 roundings per
 # layer differ, and the networks amplify that (one layer pair at stage 4, twelve at stage 10).  Tolerances by depth.
-RANKS_TOL = {4.0: {"dis": 1e-2, "gen": 3e-2, "map": 3e-2}, 10.0: {"dis": 8e-2, "gen": 0.2, "map": 0.2}}
+RANKS_TOL = {4.0: {"dis": 4e-2, "gen": 6e-2, "map": 6e-2}, 10.0: {"dis": 8e-2, "gen": 0.2, "map": 0.2}}
 
 
 @pytest.mark.parametrize("stage", [4.0, 10.0])

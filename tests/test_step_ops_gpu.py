@@ -218,3 +218,84 @@ def test_generator_forward_is_bit_reproducible():
         a = gen(z, 10.0, t9)
         b = gen(z, 10.0, t9)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("C", [128, 256, 512])
+def test_l2_normalize_forward_backward(C):
+    """DCGANBlock's F.normalize over channels (net.py:621-648), chainer semantics x / (||x|| + 1e-5)."""
+    from rgbd_gan_amd import functional as Fn
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(3, 8, 8, C, generator=g).to(torch.bfloat16)
+    x[0, 0, 0] = 0                                            # a zero vector: y = 0, dx = dy / eps
+    dy = torch.randn(3, 8, 8, C, generator=g).to(torch.bfloat16)
+    xr = x.float().requires_grad_(True)
+    yr = nets.l2_normalize(xr.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    yr.backward(dy.float())
+    xd = x.to(DEV).requires_grad_(True)
+    yd = Fn.l2_normalize(xd)
+    yd.backward(dy.to(DEV))
+    torch.testing.assert_close(yd.float().cpu(), yr.detach().to(torch.bfloat16).float(), rtol=0, atol=1e-2)
+    ref = xr.grad[1:]
+    torch.testing.assert_close(xd.grad.float().cpu()[1:], ref, rtol=2e-2, atol=2e-2 * float(ref.abs().max()))
+
+
+def test_blur_modes_and_adjoints():
+    """rescale.py:20-25: plain blur, blur of the nearest-upsampled tensor, and its adjoint (2x2 sums of the blur)."""
+    from rgbd_gan_amd import functional as Fn, kernels
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 8, 8, 64, generator=g).to(torch.bfloat16)
+    xn = x.float().permute(0, 3, 1, 2)
+    got = kernels.blur3x3(x.to(DEV), 0).float().cpu().permute(0, 3, 1, 2)
+    torch.testing.assert_close(got, nets.blur(xn).to(torch.bfloat16).float(), rtol=0, atol=2e-2)
+    got = kernels.blur3x3(x.to(DEV), 1).float().cpu().permute(0, 3, 1, 2)
+    torch.testing.assert_close(got, nets.blur(nets.up2(xn)).to(torch.bfloat16).float(), rtol=0, atol=2e-2)
+    # adjoint pairs: <A x, y> = <x, A^T y>
+    y = torch.randn(2, 16, 16, 64, generator=g).to(torch.bfloat16)
+    lhs = float((kernels.blur3x3(x.to(DEV), 1).float() * y.to(DEV).float()).sum())
+    rhs = float((x.to(DEV).float() * kernels.blur3x3(y.to(DEV), 2).float()).sum())
+    assert abs(lhs - rhs) < 2e-2 * (abs(lhs) + 1.0), (lhs, rhs)
+    z = torch.randn(2, 8, 8, 64, generator=g).to(torch.bfloat16)
+    lhs = float((kernels.blur3x3(x.to(DEV), 0).float() * z.to(DEV).float()).sum())
+    rhs = float((x.to(DEV).float() * kernels.blur3x3(z.to(DEV), 0).float()).sum())
+    assert abs(lhs - rhs) < 2e-2 * (abs(lhs) + 1.0), (lhs, rhs)
+    # the autograd Function differentiates twice (R1 goes through the discriminator's blur)
+    xd = x.to(DEV).requires_grad_(True)
+    out = Fn.blur(xd)
+    gx, = torch.autograd.grad([out], [xd], [y[:, :8, :8].to(DEV).contiguous()], create_graph=True)
+    gx.float().pow(2).sum().backward()
+    assert xd.grad is None or torch.isfinite(xd.grad.float()).all()
+
+
+def test_networks_with_enable_blur_match_oracle():
+    """enable_blur (net.py:140-141,422-423): generator c0(blur(upscale2x(h))), discriminator blur(downscale2x(h))."""
+    from oracle import camera
+    from rgbd_gan_amd.net import Discriminator, StyleGANGenerator
+    gp = nets.init_stylegan(256, seed=0)
+    dp = nets.init_discriminator(256, seed=1)
+    gen = StyleGANGenerator(256, rgbd=True, enable_blur=True)
+    dis = Discriminator(256, res=True, enable_blur=True)
+    gen.load_state_dict(gp)
+    dis.load_state_dict(dp)
+    rng = np.random.RandomState(0)
+    zh = nets.make_hidden(1, 256, rng)
+    z = np.concatenate([zh, zh])
+    np.random.seed(1)
+    t9 = camera.theta9(camera.PosePrior(0.3054, 1.0472, 0).sample(2))
+
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm())
+    for stage in (6.0, 7.5):
+        with torch.no_grad():
+            ref = nets.stylegan_generator(gp, z, stage, t9, enable_blur=True)
+            plain = nets.stylegan_generator(gp, z, stage, t9)
+            got = gen(z, stage, t9).cpu()
+        assert rel(got[:, :3], ref[:, :3]) < 4e-2 < rel(plain[:, :3], ref[:, :3])       # the blur is really applied
+        x = ref[:, :3].contiguous()
+        xr = x.clone().requires_grad_(True)
+        yr = nets.discriminator(dp, xr, stage, enable_blur=True)
+        yr.sum().backward()
+        xd = x.to(DEV).requires_grad_(True)
+        yd = dis(xd, stage)
+        yd.sum().backward()
+        assert float((yd.detach().cpu() - yr.detach()).abs().max()) < 4e-2 * max(1.0, float(yr.detach().abs().max()))
+        assert rel(xd.grad.cpu(), xr.grad) < 0.15

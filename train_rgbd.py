@@ -54,6 +54,10 @@ def main():
     generator, discriminator, optimizer, updater = build_training(
         config, device, comm if comm is not None and comm.size > 1 else None, iterator=iterator,
         nan_check_interval=config.display_interval or 100)
+    if config.nvprof or config.enable_cuda_profiling:
+        # the reference wraps trainer.run() in cupy.cuda.profile() (train_rgbd.py:462-464); here the step's phases carry
+        # roctx ranges for rocprofv3 (--marker-trace), and the sub-phases run eagerly so each is its own range
+        updater.profile_ranges = True
     models = [("Generator", generator), ("Discriminator", discriminator)]
     if updater.smoothed_gen is not None:                               # train_rgbd.py:293-295
         models.append(("SmoothedGenerator", updater.smoothed_gen))
