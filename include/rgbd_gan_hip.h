@@ -280,6 +280,20 @@ int rgbd_const_input_bwd(const void* dh, const float* w, const float* bias, floa
  * rgbd_blur3x3_bf16: rescale.py:20-25 (depthwise [1 2 1]x[1 2 1]/16, zero padding) on NHWC bf16, H x W = the image the
  *   blur acts on.  mode 0: y = blur(x); mode 1: y = blur(upscale2x(x)), x (B,H/2,W/2,C) (net.py:140-141);
  *   mode 2: y (B,H/2,W/2,C) = 2x2 sums of blur(x), the adjoint of mode 1.  Mode 0 is its own adjoint. */
+/* Progressive fade-in (odd stages, net.py:283-290,490-497): alpha is read from alpha_device (a device float: a captured
+ *   graph follows the schedule) or, when that is NULL, the host value.  H x W = the HIGH resolution.
+ * rgbd_fade_planes_fwd: out = (1-a) * upscale2x(lo) + a * hi on (planes,H,W) fp32 NCHW planes, lo (planes,H/2,W/2).
+ * rgbd_fade_planes_bwd: dhi = a * dout, dlo = (1-a) * 2x2 sums of dout (either may be NULL).
+ * rgbd_lerp_bf16: mode 0: out = (1-a) p + a q; mode 1: out = (1-a) p, out2 = a p (its adjoint split); n bf16 elements.
+ * rgbd_pool2_planes: adjoint 0: out (planes,H/2,W/2) = 2x2 averages of x (planes,H,W) (downscale2x of the image);
+ *   adjoint != 0: out (planes,H,W) = 0.25 * x[y/2,x/2] with x (planes,H/2,W/2). */
+int rgbd_fade_planes_fwd(const float* lo, const float* hi, float* out, int64_t planes, int H, int W,
+                         const float* alpha_device, float alpha, void* stream);
+int rgbd_fade_planes_bwd(const float* dout, float* dlo, float* dhi, int64_t planes, int H, int W,
+                         const float* alpha_device, float alpha, void* stream);
+int rgbd_lerp_bf16(const void* p, const void* q, void* out, void* out2, int64_t n, int mode, const float* alpha_device,
+                   float alpha, void* stream);
+int rgbd_pool2_planes(const float* x, float* out, int64_t planes, int H, int W, int adjoint, void* stream);
 int rgbd_l2norm_fwd(const void* x, void* y, int64_t npix, int C, float eps, void* stream);
 int rgbd_l2norm_bwd(const void* x, const void* dy, void* dx, int64_t npix, int C, float eps, void* stream);
 int rgbd_blur3x3_bf16(const void* x, void* y, int B, int H, int W, int C, int mode, void* stream);

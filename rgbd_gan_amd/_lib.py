@@ -55,6 +55,10 @@ PROTOTYPES = {
     "rgbd_image_grad_init": ([_P, _P, _P, c_int, c_int, c_int, c_int, _P], c_int),
     "rgbd_const_input_fwd": ([_P, _P, _P, c_int, c_int, c_int, c_float, _P], c_int),
     "rgbd_const_input_bwd": ([_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P], c_int),
+    "rgbd_fade_planes_fwd": ([_P, _P, _P, c_int64, c_int, c_int, _P, c_float, _P], c_int),
+    "rgbd_fade_planes_bwd": ([_P, _P, _P, c_int64, c_int, c_int, _P, c_float, _P], c_int),
+    "rgbd_lerp_bf16": ([_P, _P, _P, _P, c_int64, c_int, _P, c_float, _P], c_int),
+    "rgbd_pool2_planes": ([_P, _P, c_int64, c_int, c_int, c_int, _P], c_int),
     "rgbd_l2norm_fwd": ([_P, _P, c_int64, c_int, c_float, _P], c_int),
     "rgbd_l2norm_bwd": ([_P, _P, _P, c_int64, c_int, c_float, _P], c_int),
     "rgbd_blur3x3_bf16": ([_P, _P, c_int, c_int, c_int, c_int, c_int, _P], c_int),

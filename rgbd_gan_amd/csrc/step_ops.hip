@@ -298,6 +298,90 @@ __global__ __launch_bounds__(256) void blur3x3_kernel(const unsigned short* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------------ progressive fade-in
+// Odd stages blend two resolutions (net.py:283-290 generator, :490-497 discriminator) with alpha = stage - floor(stage),
+// read from a device float when given (a captured graph then follows the schedule) else from the host value.
+//   fade_planes:  out[b,c,y,x] = (1-a) * lo[b,c,y/2,x/2] + a * hi[b,c,y,x]            NCHW fp32 planes (generator)
+//   its backward: dhi = a * dout;  dlo[b,c,y,x] = (1-a) * sum_{2x2} dout
+//   lerp_bf16:    out = (1-a) * p + a * q   on bf16 tensors (discriminator features);  split: (1-a) g, a g
+//   pool2_planes: out[b,c,y,x] = 0.25 * sum_{2x2} x   (downscale2x of the image, net.py:491) and its adjoint
+__device__ __forceinline__ float fade_alpha(const float* dev, float host) { return dev ? dev[0] : host; }
+
+__global__ __launch_bounds__(256) void fade_planes_fwd_kernel(const float* __restrict__ lo, const float* __restrict__ hi,
+                                                              float* __restrict__ out, long planes, int H, int W,
+                                                              const float* __restrict__ adev, float ahost) {
+    const float a = fade_alpha(adev, ahost);
+    const long total = planes * H * W;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int x = (int)(e % W);
+        const long r = e / W;
+        const int y = (int)(r % H);
+        const long pl = r / H;
+        out[e] = (1.f - a) * lo[(pl * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1)] + a * hi[e];
+    }
+}
+__global__ __launch_bounds__(256) void fade_planes_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dlo,
+                                                              float* __restrict__ dhi, long planes, int H, int W,
+                                                              const float* __restrict__ adev, float ahost) {
+    const float a = fade_alpha(adev, ahost);
+    const int h2 = H >> 1, w2 = W >> 1;
+    const long total = planes * h2 * w2;          // one thread per low-resolution pixel: its 2x2 block of dout
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int x = (int)(e % w2);
+        const long r = e / w2;
+        const int y = (int)(r % h2);
+        const long pl = r / h2;
+        const long o = (pl * H + 2 * y) * W + 2 * x;
+        const float g00 = dout[o], g01 = dout[o + 1], g10 = dout[o + W], g11 = dout[o + W + 1];
+        if (dlo) dlo[e] = (1.f - a) * ((g00 + g01) + (g10 + g11));
+        if (dhi) { dhi[o] = a * g00; dhi[o + 1] = a * g01; dhi[o + W] = a * g10; dhi[o + W + 1] = a * g11; }
+    }
+}
+// mode 0: out = (1-a) p + a q;  mode 1: out = (1-a) p, out2 = a p   (8 bf16 per thread)
+__global__ __launch_bounds__(256) void lerp_bf16_kernel(const unsigned short* __restrict__ p, const unsigned short* __restrict__ q,
+                                                        unsigned short* __restrict__ out, unsigned short* __restrict__ out2,
+                                                        long nvec, int mode, const float* __restrict__ adev, float ahost) {
+    const float a = fade_alpha(adev, ahost);
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nvec; e += (long)gridDim.x * 256) {
+        const u32x4 pv = *reinterpret_cast<const u32x4*>(p + e * 8);
+        u32x4 o, o2;
+        if (mode == 0) {
+            const u32x4 qv = *reinterpret_cast<const u32x4*>(q + e * 8);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                o[k] = pack_bf16x2((1.f - a) * bf16_lo(pv[k]) + a * bf16_lo(qv[k]), (1.f - a) * bf16_hi(pv[k]) + a * bf16_hi(qv[k]));
+            *reinterpret_cast<u32x4*>(out + e * 8) = o;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                o[k] = pack_bf16x2((1.f - a) * bf16_lo(pv[k]), (1.f - a) * bf16_hi(pv[k]));
+                o2[k] = pack_bf16x2(a * bf16_lo(pv[k]), a * bf16_hi(pv[k]));
+            }
+            *reinterpret_cast<u32x4*>(out + e * 8) = o;
+            *reinterpret_cast<u32x4*>(out2 + e * 8) = o2;
+        }
+    }
+}
+// adjoint == 0: out (planes,H/2,W/2) = 0.25 * 2x2 sums of x (planes,H,W);  adjoint != 0: out (planes,H,W) = 0.25 * x[y/2,x/2]
+__global__ __launch_bounds__(256) void pool2_planes_kernel(const float* __restrict__ x, float* __restrict__ out, long planes,
+                                                           int H, int W, int adjoint) {
+    const int h2 = H >> 1, w2 = W >> 1;
+    const long total = planes * h2 * w2;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int xx = (int)(e % w2);
+        const long r = e / w2;
+        const int yy = (int)(r % h2);
+        const long pl = r / h2;
+        const long o = (pl * H + 2 * yy) * W + 2 * xx;
+        if (!adjoint) {
+            out[e] = 0.25f * ((x[o] + x[o + 1]) + (x[o + W] + x[o + W + 1]));
+        } else {
+            const float v = 0.25f * x[e];
+            out[o] = v; out[o + 1] = v; out[o + W] = v; out[o + W + 1] = v;
+        }
+    }
+}
+
 inline unsigned grid_for(long n, long cap = 4096) {
     const long b = (n + 255) / 256;
     return (unsigned)(b < 1 ? 1 : (b < cap ? b : cap));
@@ -433,5 +517,39 @@ extern "C" int rgbd_blur3x3_bf16(const void* x, void* y, int B, int H, int W, in
     blur3x3_kernel<<<grid_for(outs, 8192), 256, 0, (hipStream_t)stream>>>((const unsigned short*)x, (unsigned short*)y, B, H,
                                                                         W, C, mode);
     RGBD_CHECK_LAUNCH("blur3x3_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_fade_planes_fwd(const float* lo, const float* hi, float* out, int64_t planes, int H, int W,
+                                    const float* alpha_device, float alpha, void* stream) {
+    RGBD_REQUIRE(lo && hi && out && planes > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "rgbd_fade_planes_fwd: bad arguments");
+    fade_planes_fwd_kernel<<<grid_for(planes * H * W), 256, 0, (hipStream_t)stream>>>(lo, hi, out, planes, H, W, alpha_device, alpha);
+    RGBD_CHECK_LAUNCH("fade_planes_fwd_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_fade_planes_bwd(const float* dout, float* dlo, float* dhi, int64_t planes, int H, int W,
+                                    const float* alpha_device, float alpha, void* stream) {
+    RGBD_REQUIRE(dout && (dlo || dhi) && planes > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "rgbd_fade_planes_bwd: bad arguments");
+    fade_planes_bwd_kernel<<<grid_for(planes * (H / 2) * (W / 2)), 256, 0, (hipStream_t)stream>>>(dout, dlo, dhi, planes, H, W,
+                                                                                               alpha_device, alpha);
+    RGBD_CHECK_LAUNCH("fade_planes_bwd_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_lerp_bf16(const void* p, const void* q, void* out, void* out2, int64_t n, int mode,
+                              const float* alpha_device, float alpha, void* stream) {
+    RGBD_REQUIRE(p && out && n > 0 && n % 8 == 0 && ((mode == 0 && q) || (mode == 1 && out2)), "rgbd_lerp_bf16: bad arguments");
+    lerp_bf16_kernel<<<grid_for(n / 8), 256, 0, (hipStream_t)stream>>>((const unsigned short*)p, (const unsigned short*)q,
+                                                                      (unsigned short*)out, (unsigned short*)out2, n / 8, mode,
+                                                                      alpha_device, alpha);
+    RGBD_CHECK_LAUNCH("lerp_bf16_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_pool2_planes(const float* x, float* out, int64_t planes, int H, int W, int adjoint, void* stream) {
+    RGBD_REQUIRE(x && out && planes > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "rgbd_pool2_planes: bad arguments");
+    pool2_planes_kernel<<<grid_for(planes * (H / 2) * (W / 2)), 256, 0, (hipStream_t)stream>>>(x, out, planes, H, W, adjoint);
+    RGBD_CHECK_LAUNCH("pool2_planes_kernel");
     return 0;
 }

@@ -987,6 +987,73 @@ def r1_penalty(grad_x, lambda_gp):
     return _R1Penalty.apply(grad_x, float(lambda_gp))
 
 
+class _FadePlanes(torch.autograd.Function):
+    """(1-a) * upscale2x(lo) + a * hi on NCHW fp32 planes (generator fade-in, net.py:283-290); first order."""
+
+    @staticmethod
+    def forward(ctx, lo, hi, alpha):
+        ctx.alpha = alpha
+        return kernels.fade_planes_fwd(lo.contiguous(), hi.contiguous(), alpha)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout):
+        dlo, dhi = kernels.fade_planes_bwd(dout.contiguous(), ctx.alpha, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return dlo, dhi, None
+
+
+def fade_planes(lo, hi, alpha):
+    return _FadePlanes.apply(lo, hi, alpha)
+
+
+class _Lerp(torch.autograd.Function):
+    """(1-a) p + a q on NHWC bf16 (discriminator fade-in, net.py:490-497); linear, so with _LerpSplit closed under
+    differentiation (R1 goes through it twice)."""
+
+    @staticmethod
+    def forward(ctx, p, q, alpha):
+        ctx.alpha = alpha
+        return kernels.lerp_bf16(p.contiguous(), q.contiguous(), alpha)
+
+    @staticmethod
+    def backward(ctx, g):
+        gp, gq = _LerpSplit.apply(g, ctx.alpha)
+        return gp, gq, None
+
+
+class _LerpSplit(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g, alpha):
+        ctx.alpha = alpha
+        return kernels.lerp_split_bf16(g.contiguous(), alpha)
+
+    @staticmethod
+    def backward(ctx, gp, gq):
+        return _Lerp.apply(gp, gq, ctx.alpha), None
+
+
+def lerp(p, q, alpha):
+    return _Lerp.apply(p, q, alpha)
+
+
+class _PoolPlanes(torch.autograd.Function):
+    """2x2 average pooling of NCHW fp32 planes (downscale2x of the image in the discriminator's fade-in path,
+    net.py:491) and its adjoint: each is the other's derivative."""
+
+    @staticmethod
+    def forward(ctx, x, adjoint):
+        ctx.adjoint = adjoint
+        return kernels.pool2_planes(x.contiguous(), adjoint)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _PoolPlanes.apply(g, not ctx.adjoint), None
+
+
+def avg_pool2_planes(x):
+    return _PoolPlanes.apply(x, False)
+
+
 class _L2Norm(torch.autograd.Function):
     """F.normalize over channels (DCGANBlock, net.py:621-648) on NHWC bf16, first order."""
 

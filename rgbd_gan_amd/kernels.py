@@ -687,6 +687,69 @@ def const_input_bwd(dh, w, bias, dw, db, slope=0.2):
                                                 float(slope), _stream()), "rgbd_const_input_bwd")
 
 
+def _alpha_args(alpha):
+    """alpha: 0-dim / 1-element fp32 device tensor, or a Python float -> (device pointer or NULL, host value)."""
+    if torch.is_tensor(alpha):
+        _chk(alpha.reshape(1), F32, "alpha")
+        return _ptr(alpha), 0.0
+    return ctypes.c_void_p(0), float(alpha)
+
+
+def fade_planes_fwd(lo, hi, alpha):
+    """(1-a) * upscale2x(lo) + a * hi on NCHW fp32 planes; lo (B,C,H/2,W/2), hi (B,C,H,W)."""
+    _chk(lo, F32, "lo"); _chk(hi, F32, "hi")
+    B, C, H, W = hi.shape
+    if tuple(lo.shape) != (B, C, H // 2, W // 2):
+        raise RuntimeError(f"fade_planes_fwd: shapes {tuple(lo.shape)} {tuple(hi.shape)}")
+    out = torch.empty_like(hi)
+    ap, ah = _alpha_args(alpha)
+    _lib.check(_lib.load().rgbd_fade_planes_fwd(_ptr(lo), _ptr(hi), _ptr(out), B * C, H, W, ap, ah, _stream()),
+               "rgbd_fade_planes_fwd")
+    return out
+
+
+def fade_planes_bwd(dout, alpha, want_lo=True, want_hi=True):
+    _chk(dout, F32, "dout")
+    B, C, H, W = dout.shape
+    dlo = torch.empty(B, C, H // 2, W // 2, dtype=F32, device=dout.device) if want_lo else None
+    dhi = torch.empty_like(dout) if want_hi else None
+    ap, ah = _alpha_args(alpha)
+    _lib.check(_lib.load().rgbd_fade_planes_bwd(_ptr(dout), _ptr(dlo), _ptr(dhi), B * C, H, W, ap, ah, _stream()),
+               "rgbd_fade_planes_bwd")
+    return dlo, dhi
+
+
+def lerp_bf16(p, q, alpha):
+    """(1-a) p + a q on bf16 tensors of one shape."""
+    _chk(p, BF16, "p"); _chk(q, BF16, "q")
+    if p.shape != q.shape:
+        raise RuntimeError("lerp_bf16: shape mismatch")
+    out = torch.empty_like(p)
+    ap, ah = _alpha_args(alpha)
+    _lib.check(_lib.load().rgbd_lerp_bf16(_ptr(p), _ptr(q), _ptr(out), None, p.numel(), 0, ap, ah, _stream()), "rgbd_lerp_bf16")
+    return out
+
+
+def lerp_split_bf16(g, alpha):
+    """-> ((1-a) g, a g): the adjoint of lerp_bf16."""
+    _chk(g, BF16, "g")
+    o1, o2 = torch.empty_like(g), torch.empty_like(g)
+    ap, ah = _alpha_args(alpha)
+    _lib.check(_lib.load().rgbd_lerp_bf16(_ptr(g), None, _ptr(o1), _ptr(o2), g.numel(), 1, ap, ah, _stream()), "rgbd_lerp_bf16")
+    return o1, o2
+
+
+def pool2_planes(x, adjoint=False):
+    """NCHW fp32: 2x2 average pooling (adjoint False) or its adjoint 0.25 * nearest upsampling (adjoint True)."""
+    _chk(x, F32, "x")
+    B, C, H, W = x.shape
+    if adjoint:
+        H, W = 2 * H, 2 * W
+    out = torch.empty((B, C, H, W) if adjoint else (B, C, H // 2, W // 2), dtype=F32, device=x.device)
+    _lib.check(_lib.load().rgbd_pool2_planes(_ptr(x), _ptr(out), B * C, H, W, int(bool(adjoint)), _stream()), "rgbd_pool2_planes")
+    return out
+
+
 def l2norm_fwd(x, eps=1e-5):
     """(.., C) bf16 -> x / (||x||_2 + eps) over the last dim (fp32 norm)."""
     _chk(x, BF16, "x")

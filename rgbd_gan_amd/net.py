@@ -280,9 +280,8 @@ class StyleGenerator(_Link):
                 if return_feature and i == 3:
                     feat = h
             lo = self._to_rgbd(k, h)
-            lo = upsample_planes(lo)
             hi = self._to_rgbd(k + 1, self._block(k + 1, w, h))      # net.py:290: un-rotated w
-            out = (1.0 - alpha) * lo + alpha * hi
+            out = Fn.fade_planes(lo, hi, alpha)                       # (1 - alpha) * upscale2x(lo) + alpha * hi
         if self.rgbd:
             out = Fn.depth_head(out)                                  # net.py:296
         out = out.contiguous()
@@ -413,9 +412,9 @@ class DCGANGenerator(_Link):
             k = (st - 1) // 2
             for i in range(0, k):
                 h = self._block(i, h)
-            lo = upsample_planes(self._to_rgbd(k - 1, h))
+            lo = self._to_rgbd(k - 1, h)
             hi = self._to_rgbd(k, self._block(k, h))
-            out = (1.0 - alpha) * lo + alpha * hi
+            out = Fn.fade_planes(lo, hi, alpha)
         if self.rgbd:
             out = Fn.depth_head(out)
         return out.contiguous()
@@ -507,9 +506,9 @@ class Discriminator(_Link):
                 h = self._block(i, h)
         else:
             k = (st - 1) // 2
-            h0 = self._from_rgb(k, F.avg_pool2d(x, 2, 2))
+            h0 = self._from_rgb(k, Fn.avg_pool2_planes(x))
             h1 = self._block(k + 1, self._from_rgb(k + 1, x))
-            h = ((1.0 - alpha) * h0.float() + alpha * h1.float()).to(BF16)
+            h = Fn.lerp(h0, h1, alpha)                                # (1 - alpha) * h0 + alpha * h1, one rounding
             for i in reversed(range(0, k + 1)):
                 if i == 3:
                     feat = h

@@ -299,3 +299,46 @@ def test_networks_with_enable_blur_match_oracle():
         yd.sum().backward()
         assert float((yd.detach().cpu() - yr.detach()).abs().max()) < 4e-2 * max(1.0, float(yr.detach().abs().max()))
         assert rel(xd.grad.cpu(), xr.grad) < 0.15
+
+
+@pytest.mark.parametrize("alpha_on_device", [False, True])
+def test_fade_in_kernels(alpha_on_device):
+    """Odd progressive stages (net.py:283-290,490-497): generator planes blend, discriminator feature blend, image
+    down-scaling -- against torch autograd on the reference's formulas, alpha from the host or from a device scalar."""
+    from rgbd_gan_amd import functional as Fn
+    a = 0.3125
+    alpha = torch.tensor(a, device=DEV) if alpha_on_device else a
+    g = torch.Generator().manual_seed(4)
+    lo, hi = torch.randn(3, 4, 8, 8, generator=g), torch.randn(3, 4, 16, 16, generator=g)
+    lr, hr = lo.clone().requires_grad_(True), hi.clone().requires_grad_(True)
+    ref = (1 - a) * nets.up2(lr) + a * hr
+    gout = torch.randn(3, 4, 16, 16, generator=g)
+    ref.backward(gout)
+    ld, hd = lo.to(DEV).requires_grad_(True), hi.to(DEV).requires_grad_(True)
+    out = Fn.fade_planes(ld, hd, alpha)
+    out.backward(gout.to(DEV))
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(ld.grad.cpu(), lr.grad, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(hd.grad.cpu(), hr.grad, rtol=1e-6, atol=1e-6)
+    # feature blend, twice differentiable
+    p, q = (torch.randn(2, 8, 8, 64, generator=g).to(torch.bfloat16) for _ in range(2))
+    pd, qd = p.to(DEV).requires_grad_(True), q.to(DEV).requires_grad_(True)
+    h = Fn.lerp(pd, qd, alpha)
+    torch.testing.assert_close(h.float().cpu(), ((1 - a) * p.float() + a * q.float()).to(torch.bfloat16).float(), rtol=0, atol=1e-2)
+    gy = torch.randn(2, 8, 8, 64, generator=g).to(torch.bfloat16).to(DEV)
+    gp, gq = torch.autograd.grad([h], [pd, qd], [gy], create_graph=True)
+    torch.testing.assert_close(gp.float(), ((1 - a) * gy.float()).to(torch.bfloat16).float(), rtol=0, atol=1e-2)
+    torch.testing.assert_close(gq.float(), (a * gy.float()).to(torch.bfloat16).float(), rtol=0, atol=1e-2)
+    (gp.float().sum() + gq.float().sum()).backward()          # goes through _LerpSplit.backward without error
+    # image down-scaling and its adjoint
+    x = torch.randn(2, 3, 16, 16, generator=g)
+    xd = x.to(DEV).requires_grad_(True)
+    y = Fn.avg_pool2_planes(xd)
+    torch.testing.assert_close(y.detach().cpu(), F.avg_pool2d(x, 2, 2), rtol=1e-6, atol=1e-6)
+    gy2 = torch.randn(2, 3, 8, 8, generator=g)
+    gx, = torch.autograd.grad([y], [xd], [gy2.to(DEV)], create_graph=True)
+    xr = x.clone().requires_grad_(True)
+    F.avg_pool2d(xr, 2, 2).backward(gy2)
+    torch.testing.assert_close(gx.detach().cpu(), xr.grad, rtol=1e-6, atol=1e-6)
+    gg, = torch.autograd.grad([gx.sum()], [xd], allow_unused=True)
+    assert gg is None or float(gg.abs().max()) == 0.0          # linear: no dependence on x
