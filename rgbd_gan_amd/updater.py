@@ -192,6 +192,7 @@ class RGBDUpdater:
         # in that arrangement D's weight gradients for the fakes (leaves of the backward graph) are moved from the
         # longer generator chain to the tail of the side stream
         self.defer_dfake_wgrads = bool(kwargs.pop("defer_dfake_wgrads", not os.environ.get("RGBD_NO_DEFER")))
+        self.dfw_on_side = bool(kwargs.pop("dfw_on_side", not os.environ.get("RGBD_DFW_ON_MAIN")))
         self._graphs, self._eager_calls, self._stagers, self._ones = {}, {}, {}, {}
         self.device = self.gen.device
 
@@ -478,11 +479,17 @@ class RGBDUpdater:
             if self.defer_dfake_wgrads:
                 with rng("gen_a"):
                     self._gen_a_phase(st)             # G fwd, D(x_fake) fwd + input-gradient chain
-                side.wait_stream(main)
-                with torch.cuda.stream(side), rng("dfw"):
-                    self._dfw_phase(st)               # D's fake-batch weight gradients, behind "dis" on the side stream
-                with rng("gen_b"):
-                    self._gen_b_phase(st)             # 3-D loss + G backward
+                if self.dfw_on_side:
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side), rng("dfw"):
+                        self._dfw_phase(st)           # D's fake-batch weight gradients, behind "dis" on the side stream
+                    with rng("gen_b"):
+                        self._gen_b_phase(st)         # 3-D loss + G backward
+                else:
+                    with rng("gen_b"):
+                        self._gen_b_phase(st)
+                    with rng("dfw"):
+                        self._dfw_phase(st)           # ... or on the main stream, after G's own weight-gradient batch
             else:
                 with rng("gen"):
                     self._gen_phase(st)

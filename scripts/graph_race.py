@@ -22,11 +22,7 @@ def worst(L, ref, k, top=6):
     return " ".join(f"{n}:{r:.1e}(x{p:.2f})" for r, n, p in sorted(rows, reverse=True)[:top])
 EXTRA = sys.argv[1:]
 ref = run("seq", ["--eager", "--sequential"] + EXTRA)
-cases = []
-for label, env in (("serialize dis|gen_a", {"RGBD_DEBUG_SERIALIZE": "1"}), ("sync at dis_fwd", {"RGBD_DEBUG_SYNC_AT": "dis_fwd"}),
-                   ("sync at dis_r1", {"RGBD_DEBUG_SYNC_AT": "dis_r1"}), ("sync at dis_bwd2", {"RGBD_DEBUG_SYNC_AT": "dis_bwd2"}),
-                   ("no dfw defer", {"RGBD_NO_DEFER": "1"}), ("no G defer", {"RGBD_NO_G_DEFER": "1"}), ("plain", {})):
-    cases += [(f"{label} {i}", [], env) for i in range(2)]
+cases = [(f"dfw on main {i}", [], {"RGBD_DFW_ON_MAIN": "1"}) for i in range(int(os.environ.get("NRUNS", "12")))]
 for i, (name, flags, env) in enumerate(cases):
     try:
         L = run(f"case{i}", list(flags) + EXTRA, env)

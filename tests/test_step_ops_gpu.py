@@ -260,10 +260,12 @@ def test_blur_modes_and_adjoints():
     assert abs(lhs - rhs) < 2e-2 * (abs(lhs) + 1.0), (lhs, rhs)
     # the autograd Function differentiates twice (R1 goes through the discriminator's blur)
     xd = x.to(DEV).requires_grad_(True)
+    seed = y[:, :8, :8].to(DEV).contiguous().requires_grad_(True)
     out = Fn.blur(xd)
-    gx, = torch.autograd.grad([out], [xd], [y[:, :8, :8].to(DEV).contiguous()], create_graph=True)
-    gx.float().pow(2).sum().backward()
-    assert xd.grad is None or torch.isfinite(xd.grad.float()).all()
+    gx, = torch.autograd.grad([out], [xd], [seed], create_graph=True)       # = blur(seed): linear in the seed
+    gx.float().pow(2).sum().backward()                                       # d/d seed goes through blur once more
+    ref = 2 * kernels.blur3x3(kernels.blur3x3(seed.detach(), 0), 0).float()
+    torch.testing.assert_close(seed.grad.float(), ref, rtol=5e-2, atol=5e-2 * float(ref.abs().max()))
 
 
 def test_networks_with_enable_blur_match_oracle():
@@ -325,20 +327,23 @@ def test_fade_in_kernels(alpha_on_device):
     pd, qd = p.to(DEV).requires_grad_(True), q.to(DEV).requires_grad_(True)
     h = Fn.lerp(pd, qd, alpha)
     torch.testing.assert_close(h.float().cpu(), ((1 - a) * p.float() + a * q.float()).to(torch.bfloat16).float(), rtol=0, atol=1e-2)
-    gy = torch.randn(2, 8, 8, 64, generator=g).to(torch.bfloat16).to(DEV)
+    gy = torch.randn(2, 8, 8, 64, generator=g).to(torch.bfloat16).to(DEV).requires_grad_(True)
     gp, gq = torch.autograd.grad([h], [pd, qd], [gy], create_graph=True)
-    torch.testing.assert_close(gp.float(), ((1 - a) * gy.float()).to(torch.bfloat16).float(), rtol=0, atol=1e-2)
-    torch.testing.assert_close(gq.float(), (a * gy.float()).to(torch.bfloat16).float(), rtol=0, atol=1e-2)
-    (gp.float().sum() + gq.float().sum()).backward()          # goes through _LerpSplit.backward without error
+    torch.testing.assert_close(gp.detach().float(), ((1 - a) * gy.detach().float()).to(torch.bfloat16).float(), rtol=0, atol=1e-2)
+    torch.testing.assert_close(gq.detach().float(), (a * gy.detach().float()).to(torch.bfloat16).float(), rtol=0, atol=1e-2)
+    (gp.float().sum() + 2 * gq.float().sum()).backward()      # through _LerpSplit.backward: d/d gy = (1-a) + 2a
+    torch.testing.assert_close(gy.grad.float(), torch.full_like(gy.grad.float(), (1 - a) + 2 * a), rtol=0, atol=1e-2)
     # image down-scaling and its adjoint
     x = torch.randn(2, 3, 16, 16, generator=g)
     xd = x.to(DEV).requires_grad_(True)
     y = Fn.avg_pool2_planes(xd)
     torch.testing.assert_close(y.detach().cpu(), F.avg_pool2d(x, 2, 2), rtol=1e-6, atol=1e-6)
     gy2 = torch.randn(2, 3, 8, 8, generator=g)
-    gx, = torch.autograd.grad([y], [xd], [gy2.to(DEV)], create_graph=True)
+    seed = gy2.to(DEV).requires_grad_(True)
+    gx, = torch.autograd.grad([y], [xd], [seed], create_graph=True)
     xr = x.clone().requires_grad_(True)
     F.avg_pool2d(xr, 2, 2).backward(gy2)
     torch.testing.assert_close(gx.detach().cpu(), xr.grad, rtol=1e-6, atol=1e-6)
-    gg, = torch.autograd.grad([gx.sum()], [xd], allow_unused=True)
-    assert gg is None or float(gg.abs().max()) == 0.0          # linear: no dependence on x
+    wgt = torch.randn(2, 3, 16, 16, generator=g).to(DEV)
+    (gx * wgt).sum().backward()                                # d/d seed of <unpool(seed), wgt> = avg_pool(wgt)
+    torch.testing.assert_close(seed.grad.cpu(), F.avg_pool2d(wgt.cpu(), 2, 2), rtol=1e-6, atol=1e-6)
