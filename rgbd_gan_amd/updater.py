@@ -181,19 +181,20 @@ class RGBDUpdater:
         self.use_graphs = bool(kwargs.pop("use_graphs", True))
         self.graph_warmup = int(kwargs.pop("graph_warmup", 2))
         self.graph_phases = tuple(kwargs.pop("graph_phases", ("body", "opt", "opt_g", "opt_d")))
-        # the generator phase and the discriminator-on-reals phase are independent until the optimizer phase; on two
-        # streams the launch-latency bubbles of one fill with the other's kernels
-        # (not when several ranks share one GPU -- the single-GPU test arrangement of the multi-rank path: two
-        # processes x (two compute streams + the communicator's streams) oversubscribe the hardware queues and
-        # the collectives then take seconds)
-        self.concurrent_phases = bool(kwargs.pop("concurrent_phases", not os.environ.get("RGBD_SEQUENTIAL_PHASES")
+        # The generator phase and the discriminator-on-reals phase are independent until the optimizer phase, and on two
+        # streams the bubbles of one fill with the other's kernels (9.3 vs 11.3 ms per step at B=32).  OFF by default:
+        # on this ROCm 7.2 stack two queues executing replayed graph kernels concurrently intermittently read stale
+        # data ("Two streams": whole cache lines of an activation gradient keep a previous
+        # occupant's values in 1 of 16 runs at B=32, 10 of 16 at B=16; the single-stream replay is bit-reproducible and
+        # equals the eager step).  RGBD_CONCURRENT_PHASES=1 (or concurrent_phases=True) turns the overlap on.
+        self.concurrent_phases = bool(kwargs.pop("concurrent_phases", bool(os.environ.get("RGBD_CONCURRENT_PHASES"))
                                                  and not os.environ.get("RGBD_SHARE_DEVICE")))
         self._side_stream = None
         # in that arrangement D's weight gradients for the fakes (leaves of the backward graph) are moved from the
         # longer generator chain to the tail of the side stream
         self.defer_dfake_wgrads = bool(kwargs.pop("defer_dfake_wgrads", not os.environ.get("RGBD_NO_DEFER")))
         self.dfw_on_side = bool(kwargs.pop("dfw_on_side", not os.environ.get("RGBD_DFW_ON_MAIN")))
-        self._graphs, self._eager_calls, self._stagers, self._ones = {}, {}, {}, {}
+        self._graphs, self._eager_calls, self._stagers, self._ones, self._dbg = {}, {}, {}, {}, {}
         self.device = self.gen.device
 
     # ---- chainer StandardUpdater surface
@@ -346,6 +347,10 @@ class RGBDUpdater:
         cfg, obs = self.config, self.observation
         x_fake, half = st["x_fake"], st["B"] // 2
         gout = kernels.image_grad_init(st["gx"].contiguous(), st["ratio"], x_fake.shape[1])
+        dbg = self._dbg if os.environ.get("RGBD_DEBUG_DUMP") else None
+        if dbg is not None:
+            dbg.update(gx=st["gx"].clone(), gout0=gout.clone(), x_fake=x_fake.detach().clone(),
+                       ratio=st["ratio"].clone() if st["ratio"] is not None else None)
         if st["use_rotate"]:
             if cfg.rotate_feature:
                 raise AssertionError("rotate_feature is not supported")
@@ -363,6 +368,8 @@ class RGBDUpdater:
                                   grad_scale=float(lambda_rotate), out=(gout[:half], gout[half:]))
             if cfg.use_occupancy_net_loss:
                 raise AssertionError("occupancy-net loss is not supported")
+            if dbg is not None:
+                dbg.update(gout1=gout.clone())
         if cfg.optical_flow:
             raise AssertionError("optical flow loss is not supported")
         # the generator's weight gradients are leaves of this backward pass: collected while it runs, issued after it
@@ -495,8 +502,18 @@ class RGBDUpdater:
                     self._gen_phase(st)
             main.wait_stream(side)
         else:
-            with rng("gen"):
-                self._gen_phase(st)
+            # one stream (the default): the same phases back to back; D's weight gradients for the fakes are still
+            # collected during gen_a and issued as ONE batch (rgbd_conv2d_wgrad_partial_multi_bf16) after G's backward
+            if self.defer_dfake_wgrads:
+                with rng("gen_a"):
+                    self._gen_a_phase(st)
+                with rng("gen_b"):
+                    self._gen_b_phase(st)
+                with rng("dfw"):
+                    self._dfw_phase(st)
+            else:
+                with rng("gen"):
+                    self._gen_phase(st)
             with rng("dis"):
                 self._dis_phase(st)
         with rng("join"):

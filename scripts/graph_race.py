@@ -1,5 +1,7 @@
-"""Is the replayed (graph, two-stream) step the eager step?  tests/dp_worker.py under env knobs, each run compared with the
-eager single-stream run: rel-L2 of the flat gradient buffers, worst parameters with their projection coefficient."""
+"""Reproducer of the hazard that keeps the two-stream phase overlap OFF by default: the replayed step
+with RGBD_CONCURRENT_PHASES against the eager single-stream step on fixed inputs (tests/dp_worker.py), N runs each:
+rel-L2 of the flat gradient buffers; with RGBD_DEBUG_DUMP=1 also of intermediates of the generator phase.
+    NRUNS=16 python scripts/graph_race.py --stage 10 --batch 16"""
 import os, subprocess, sys, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,7 +24,9 @@ def worst(L, ref, k, top=6):
     return " ".join(f"{n}:{r:.1e}(x{p:.2f})" for r, n, p in sorted(rows, reverse=True)[:top])
 EXTRA = sys.argv[1:]
 ref = run("seq", ["--eager", "--sequential"] + EXTRA)
-cases = [(f"dfw on main {i}", [], {"RGBD_DFW_ON_MAIN": "1"}) for i in range(int(os.environ.get("NRUNS", "12")))]
+N = int(os.environ.get("NRUNS", "12"))
+cases = [(f"one stream (default) {i}", [], {}) for i in range(max(2, N // 4))] + \
+        [(f"two streams {i}", ["--concurrent"], {}) for i in range(N)]
 for i, (name, flags, env) in enumerate(cases):
     try:
         L = run(f"case{i}", list(flags) + EXTRA, env)
@@ -34,6 +38,13 @@ for i, (name, flags, env) in enumerate(cases):
         continue
     print(f"{name:28s} graphs {int(L['n_graphs'])} | " + " | ".join(f"{k}: {v:.1e}" for k, v in rels.items()) +
           f" | loss_adv {float(L['obs/gen/loss_adv']) - float(ref['obs/gen/loss_adv']):+.1e}", flush=True)
+    dk = [k for k in L.files if k.startswith("dbg/")]
+    if dk and os.environ.get("RGBD_SAVE_BAD"):
+        os.makedirs(os.environ["RGBD_SAVE_BAD"], exist_ok=True)
+        np.savez_compressed(os.path.join(os.environ["RGBD_SAVE_BAD"], f"case{i}.npz"), **{k[4:]: L[k] for k in dk},
+                            **{"ref_" + k[4:]: ref[k] for k in dk})
+    if dk:
+        print("      " + "  ".join(f"{k[4:]}: {rel(L[k], ref[k]):.1e}" for k in sorted(dk)), flush=True)
     for k, v in rels.items():
-        if v > 1e-2 or (k == "dis" and v > 1e-5):
+        if False and (v > 1e-2 or (k == "dis" and v > 1e-5)):
             print(f"      {k}: {worst(L, ref, k)}", flush=True)

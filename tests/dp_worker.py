@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--stage", type=float, default=10.0)
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--sequential", action="store_true")
+    ap.add_argument("--concurrent", action="store_true", help="two-stream phase overlap (off by default)")
     ap.add_argument("--graph-phases", default=None, help="comma list: capture only these phases (diagnostics)")
     ap.add_argument("--sync-restore", action="store_true", help="host-synchronise after putting the weights back")
     ap.add_argument("--logit-shift", type=float, default=0.0,
@@ -74,6 +75,8 @@ def main():
     kw = dict(fixed_stage=args.stage, use_graphs=not args.eager, graph_warmup=2, nan_check_interval=0)
     if args.sequential:
         kw["concurrent_phases"] = False
+    if args.concurrent:
+        kw["concurrent_phases"] = True
     if args.graph_phases is not None:
         kw["graph_phases"] = tuple(p for p in args.graph_phases.split(",") if p)
     gen, dis, opt, upd = build_training(Config(CFG), device, comm if comm.active else None, iterator=None, **kw)
@@ -114,6 +117,9 @@ def main():
         out[f"{k}/names"] = np.array(s.names)
         out[f"{k}/offsets"] = np.array([s.offsets[n] for n in s.names], dtype=np.int64)
         out[f"{k}/sizes"] = np.array([int(np.prod(s.shapes[n])) for n in s.names], dtype=np.int64)
+    for k, v in getattr(upd, "_dbg", {}).items():      # RGBD_DEBUG_DUMP: intermediate tensors of the generator phase
+        if v is not None:
+            out["dbg/" + k] = v.float().cpu().numpy()
     for k, v in upd.observation.items():
         out["obs/" + k] = float(v)
     np.savez(args.out, **out)

@@ -1,8 +1,7 @@
 """Arrangements of the SAME training step must agree tensor by tensor (tests/dp_worker.py runs them on fixed inputs):
 
-  * the shipped arrangement -- the step body replayed as one HIP graph with two branches (generator phase ||
-    discriminator phase), D's fake-batch weight gradients deferred to the side branch and merged from a second gradient
-    buffer, the optimizers as a second graph -- against the eager single-stream step;
+  * the shipped arrangement -- the step body replayed as one HIP graph, the optimizers as a second one -- and the
+    eager two-stream arrangement against the eager single-stream step;
   * a 2-rank data-parallel job (two processes sharing cuda:0, gloo collectives, the real HIP Adam kernel, graphs)
     on half-batches against 1 rank on the whole batch: ChainerMN's multi-node optimizer (train_rgbd.py:103-121,154-156)
     = first update broadcasts, then all-reduce-mean of the flat gradient buffers before the local clipped Adam;
@@ -86,26 +85,36 @@ def _compare(a, b, what, tol, upd_tol=5e-2):
         assert r["upd_mismatch"] < (upd_tol if tol[k] > 1e-3 else 1e-3), (what, k, r)
 
 
-def test_graph_replay_two_streams_equals_eager_single_stream(tmp_path):
+def test_graph_replay_equals_eager_step(tmp_path):
+    """The shipped arrangement (the step body replayed as one HIP graph, the optimizers as a second one, one stream)
+    against the eager step; and the eager two-stream arrangement (RGBD_CONCURRENT_PHASES: generator phase ||
+    discriminator phase, D's fake-batch weight gradients deferred to the side stream and merged from a second gradient
+    buffer) against the eager single-stream step.  Graph replay WITH the two-stream overlap is deliberately not the
+    default and not asserted here: scripts/graph_race.py shows it reading stale cache lines intermittently on this ROCm
+    stack."""
     _wait([_run(tmp_path / "eager.npz", "--calls", "4", "--eager", "--sequential")])
-    _wait([_run(tmp_path / "eager2.npz", "--calls", "4", "--eager")])          # eager, two streams + deferred wgrads
+    _wait([_run(tmp_path / "eager2.npz", "--calls", "4", "--eager", "--concurrent")])
     _wait([_run(tmp_path / "graph.npz", "--calls", "4")])                      # the shipped arrangement
-    _wait([_run(tmp_path / "gseq.npz", "--calls", "4", "--sequential")])       # graphs, one stream
-    e, e2, g, gs = (np.load(tmp_path / f) for f in ("eager.npz", "eager2.npz", "graph.npz", "gseq.npz"))
-    assert int(e["n_graphs"]) == 0 and int(e2["n_graphs"]) == 0 and int(g["n_graphs"]) == 2 and int(gs["n_graphs"]) == 2
+    _wait([_run(tmp_path / "graphB.npz", "--calls", "4")])                     # ... twice: replays are reproducible
+    e, e2, g, g2 = (np.load(tmp_path / f) for f in ("eager.npz", "eager2.npz", "graph.npz", "graphB.npz"))
+    assert int(e["n_graphs"]) == 0 and int(e2["n_graphs"]) == 0 and int(g["n_graphs"]) == 2   # body + optimizers
     _compare(e2, e, "eager two-stream vs eager sequential", SAME_STEP)
-    _compare(gs, e, "graph replay (one stream) vs eager sequential", SAME_STEP)
-    _compare(g, e, "graph replay (two branches) vs eager sequential", SAME_STEP)
+    _compare(g, e, "graph replay vs eager", SAME_STEP)
+    _compare(g2, g, "graph replay, second run vs first", SAME_STEP)
     for key in ("obs/gen/loss_adv", "obs/gen/loss_rotate", "obs/dis/loss_adv", "obs/dis/loss_gp"):
         assert abs(float(g[key]) - float(e[key])) < 1e-5 * max(1.0, abs(float(e[key]))), (key, float(g[key]), float(e[key]))
 
 
-def test_fade_in_stage_graph_replay_equals_eager(tmp_path):
-    _wait([_run(tmp_path / "eager.npz", "--calls", "4", "--eager", "--sequential", "--stage", "9.5", "--batch", "4")])
-    _wait([_run(tmp_path / "graph.npz", "--calls", "4", "--stage", "9.5", "--batch", "4")])
+@pytest.mark.parametrize("stage,batch", [(9.5, 4), (7.5, 8), (8.0, 16)])
+def test_graph_replay_equals_eager_step_other_stages(tmp_path, stage, batch):
+    """Fade-in stages (the blend factor comes from a device scalar in the replay, from the host in the eager step) and
+    another resolution / batch size."""
+    flags = ["--calls", "4", "--stage", str(stage), "--batch", str(batch)]
+    _wait([_run(tmp_path / "eager.npz", *flags, "--eager", "--sequential")])
+    _wait([_run(tmp_path / "graph.npz", *flags)])
     e, g = np.load(tmp_path / "eager.npz"), np.load(tmp_path / "graph.npz")
     assert int(g["n_graphs"]) == 2
-    _compare(g, e, "fade-in graph replay vs eager", SAME_STEP)
+    _compare(g, e, f"graph replay vs eager, stage {stage} batch {batch}", SAME_STEP)
 
 
 # 2 ranks on half-batches vs 1 rank on the whole batch is NOT the same floating-point computation: the conv engine picks
