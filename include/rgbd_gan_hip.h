@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RGBD_ABI_VERSION 4
+#define RGBD_ABI_VERSION 5
 
 int rgbd_abi_version(void);
 const char* rgbd_last_error(void);
@@ -234,15 +234,18 @@ int rgbd_planes_outer(const void* t, const float* planes, float* o, float* tsum,
  *   bwd: dz = dy * lrelu'(y) (when act);  dx (M,K) (+)= c * dz W;  dw (N,K) += c * dz^T x;  db (N) += sum_m dz.
  *        dx / dw / db may be NULL to skip; dw and db ACCUMULATE (they are the optimizer's flat gradient views).
  */
+/* workspace: rgbd_linear_fwd_workspace(M,K,N) floats (0 = none) or NULL: for K >= 1024 (the discriminator's dense tail,
+ * K = 4096) the forward splits K over blocks and a finishing launch applies scale, bias and activation. */
+int64_t rgbd_linear_fwd_workspace(int M, int K, int N);
 int rgbd_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int K, int N, float c, int act,
-                    float slope, void* stream);
+                    float slope, float* workspace, void* stream);
 int rgbd_linear_bwd(const float* dy, const float* y, const float* x, const float* w, float* dx, float* dw, float* db,
                     int M, int K, int N, float c, int act, float slope, int accumulate_dx, void* stream);
 /* y = (c * x W^T) * lrelu'(mask_y): the derivative of rgbd_linear_bwd's dx w.r.t. its dy -- what the R1 double backward
  * (updater.py:414-422, chainer.grad(..., enable_double_backprop=True)) sends back through the discriminator's dense tail
  * (net.py:372-377).  mask_y (M,N): the activation OUTPUT whose slope mask applies. */
 int rgbd_linear_fwd_masked(const float* x, const float* w, const float* mask_y, float* y, int M, int K, int N, float c,
-                           float slope, void* stream);
+                           float slope, float* workspace, void* stream);
 
 /* ------------------------------------------------------------------ small fused ops of the training step (step_ops.hip)
  * Each replaces a run of elementwise / reduction launches of the reference's Chainer graph with one launch.

@@ -10,7 +10,7 @@ from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p, POINTER
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RGBD_LIB_PATH: A/B timing of another build of the same ABI (scripts/patch_probe.py); the default is the in-tree library
 LIB_PATH = os.environ.get("RGBD_LIB_PATH") or os.path.join(_HERE, "librgbdgan_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _P = c_void_p
 
@@ -45,8 +45,9 @@ PROTOTYPES = {
     "rgbd_from_planes": ([_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, c_float, _P], c_int),
     "rgbd_to_planes": ([_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P], c_int),
     "rgbd_planes_outer": ([_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P], c_int),
-    "rgbd_linear_fwd": ([_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_float, _P], c_int),
-    "rgbd_linear_fwd_masked": ([_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P], c_int),
+    "rgbd_linear_fwd_workspace": ([c_int, c_int, c_int], c_int64),
+    "rgbd_linear_fwd": ([_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_float, _P, _P], c_int),
+    "rgbd_linear_fwd_masked": ([_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P, _P], c_int),
     "rgbd_real_batch_u8": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_float, _P], c_int),
     "rgbd_zero_multi_f32": ([POINTER(c_void_p), POINTER(c_int64), c_int, _P], c_int),
     "rgbd_hidden_normalize": ([_P, _P, c_int, c_int, c_float, c_int, _P], c_int),

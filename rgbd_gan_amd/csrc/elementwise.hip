@@ -724,31 +724,38 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ y, int M,
                                                          int K, int N, float c, int act, float slope,
-                                                         const float* __restrict__ mask_y) {
+                                                         const float* __restrict__ mask_y, float* __restrict__ partial) {
+    // blockIdx.y > 0 / gridDim.y > 1: split-K (the discriminator's dense tail has K = 4096 and N = 256: 16 column blocks
+    // each walking 32 dependent-load chunks took ~100 us); every K slice leaves raw fp32 partial sums in
+    // partial[slice][M][N] and linear_splitk_finish_kernel applies scale, bias and activation
     const int lane = threadIdx.x & 63, m0 = (threadIdx.x >> 6) * 16;
     if (m0 >= M) return;
     const int r = lane & 15, q = lane >> 4;
     const int n0 = blockIdx.x * 16;
+    const int kslice = (K + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int kbeg = (kslice * (int)blockIdx.y + 127) / 128 * 128 < K ? ((kslice * (int)blockIdx.y + 127) / 128 * 128) : K;
+    const int kend = gridDim.y == 1 ? K : ((kslice * ((int)blockIdx.y + 1) + 127) / 128 * 128 < K
+                                           ? (kslice * ((int)blockIdx.y + 1) + 127) / 128 * 128 : K);
     const bool mok = m0 + r < M, nok = n0 + r < N;
     const float* xr = x + (long)(mok ? m0 + r : 0) * K;
     const float* wr = w + (long)(nok ? n0 + r : 0) * K;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc = zero;
-    for (int k0 = 0; k0 < K; k0 += 128) {          // 8 K-steps of 16 per chunk: 16 independent loads in flight
+    for (int k0 = kbeg; k0 < kend; k0 += 128) {    // 8 K-steps of 16 per chunk: 16 independent loads in flight
         f32x4 a[8], b[8];
 #pragma unroll
         for (int s2 = 0; s2 < 8; ++s2) {
             const int kb = k0 + 16 * s2 + 4 * q;
             if (VEC) {
-                const int kc = kb < K ? kb : 0;
+                const int kc = kb < kend ? kb : 0;
                 a[s2] = *reinterpret_cast<const f32x4*>(xr + kc);
                 b[s2] = *reinterpret_cast<const f32x4*>(wr + kc);
-                if (kb >= K || !mok) a[s2] = zero;
-                if (kb >= K || !nok) b[s2] = zero;
+                if (kb >= kend || !mok) a[s2] = zero;
+                if (kb >= kend || !nok) b[s2] = zero;
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const bool ok = kb + j < K;
+                    const bool ok = kb + j < kend;
                     const float av = xr[ok ? kb + j : 0], bv = wr[ok ? kb + j : 0];
                     a[s2][j] = ok && mok ? av : 0.f;
                     b[s2][j] = ok && nok ? bv : 0.f;
@@ -762,6 +769,14 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
     }
     const int n = n0 + r;
     if (n < N) {
+        if (gridDim.y > 1) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int m = m0 + 4 * q + t;
+                if (m < M) partial[((long)blockIdx.y * M + m) * N + n] = acc[t];
+            }
+            return;
+        }
         const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -774,6 +789,20 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void linear_splitk_finish_kernel(const float* __restrict__ partial, int S, int M, int N,
+                                                                   const float* __restrict__ bias, float c, int act,
+                                                                   float slope, const float* __restrict__ mask_y,
+                                                                   float* __restrict__ y) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= M * N) return;
+    float v = 0.f;
+    for (int s2 = 0; s2 < S; ++s2) v += partial[(long)s2 * M * N + e];
+    v = v * c + (bias ? bias[e % N] : 0.f);
+    if (act) v = v > 0.f ? v : v * slope;
+    if (mask_y) v = mask_y[e] > 0.f ? v : v * slope;
+    y[e] = v;
 }
 
 template <bool VEC>
@@ -1154,24 +1183,49 @@ extern "C" int rgbd_planes_outer(const void* t, const float* p, float* o, float*
     return 0;
 }
 
+namespace {
+constexpr int LIN_SPLITK_MAX = 16;
+// K slices of the forward linear: 1 below K = 1024; else enough 256-deep slices to put ~256 blocks on the chip
+int linear_ksplit(int K, int N) {
+    if (K < 1024) return 1;
+    int s = 256 / ((N + 15) / 16);
+    if (s > K / 256) s = K / 256;
+    if (s > LIN_SPLITK_MAX) s = LIN_SPLITK_MAX;
+    return s < 1 ? 1 : s;
+}
+int linear_fwd_launch(const float* x, const float* w, const float* bias, const float* mask_y, float* y, int M, int K, int N,
+                      float c, int act, float slope, float* workspace, hipStream_t st) {
+    const int ks = workspace ? linear_ksplit(K, N) : 1;
+    const dim3 grid((N + 15) / 16, ks);
+    if ((K & 3) == 0) linear_fwd_kernel<true><<<grid, 256, 0, st>>>(x, w, bias, y, M, K, N, c, act, slope, mask_y, workspace);
+    else              linear_fwd_kernel<false><<<grid, 256, 0, st>>>(x, w, bias, y, M, K, N, c, act, slope, mask_y, workspace);
+    RGBD_CHECK_LAUNCH("linear_fwd_kernel");
+    if (ks > 1) {
+        linear_splitk_finish_kernel<<<(M * N + 255) / 256, 256, 0, st>>>(workspace, ks, M, N, bias, c, act, slope, mask_y, y);
+        RGBD_CHECK_LAUNCH("linear_splitk_finish_kernel");
+    }
+    return 0;
+}
+}  // namespace
+
+extern "C" int64_t rgbd_linear_fwd_workspace(int M, int K, int N) {
+    if (M <= 0 || K <= 0 || N <= 0) return -1;
+    const int ks = linear_ksplit(K, N);
+    return ks > 1 ? (int64_t)ks * M * N : 0;          /* floats */
+}
+
 extern "C" int rgbd_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int K, int N,
-                               float c, int act, float slope, void* stream) {
+                               float c, int act, float slope, float* workspace, void* stream) {
     RGBD_REQUIRE(x && w && y, "rgbd_linear_fwd: null pointer");
     RGBD_REQUIRE(M > 0 && M <= LIN_MAXM && K > 0 && N > 0, "rgbd_linear_fwd: needs 0 < M <= %d (M=%d)", LIN_MAXM, M);
-    if ((K & 3) == 0) linear_fwd_kernel<true><<<(N + 15) / 16, 256, 0, (hipStream_t)stream>>>(x, w, bias, y, M, K, N, c, act, slope, nullptr);
-    else              linear_fwd_kernel<false><<<(N + 15) / 16, 256, 0, (hipStream_t)stream>>>(x, w, bias, y, M, K, N, c, act, slope, nullptr);
-    RGBD_CHECK_LAUNCH("linear_fwd_kernel");
-    return 0;
+    return linear_fwd_launch(x, w, bias, nullptr, y, M, K, N, c, act, slope, workspace, (hipStream_t)stream);
 }
 
 extern "C" int rgbd_linear_fwd_masked(const float* x, const float* w, const float* mask_y, float* y, int M, int K, int N,
-                                      float c, float slope, void* stream) {
+                                      float c, float slope, float* workspace, void* stream) {
     RGBD_REQUIRE(x && w && y && mask_y, "rgbd_linear_fwd_masked: null pointer");
     RGBD_REQUIRE(M > 0 && M <= LIN_MAXM && K > 0 && N > 0, "rgbd_linear_fwd_masked: needs 0 < M <= %d (M=%d)", LIN_MAXM, M);
-    if ((K & 3) == 0) linear_fwd_kernel<true><<<(N + 15) / 16, 256, 0, (hipStream_t)stream>>>(x, w, nullptr, y, M, K, N, c, 0, slope, mask_y);
-    else              linear_fwd_kernel<false><<<(N + 15) / 16, 256, 0, (hipStream_t)stream>>>(x, w, nullptr, y, M, K, N, c, 0, slope, mask_y);
-    RGBD_CHECK_LAUNCH("linear_fwd_kernel<mask>");
-    return 0;
+    return linear_fwd_launch(x, w, nullptr, mask_y, y, M, K, N, c, 0, slope, workspace, (hipStream_t)stream);
 }
 
 extern "C" int rgbd_linear_bwd(const float* dy, const float* y, const float* x, const float* w, float* dx, float* dw,

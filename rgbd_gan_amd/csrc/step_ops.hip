@@ -158,22 +158,20 @@ __global__ __launch_bounds__(256) void const_input_fwd_kernel(const float* __res
         out[e] = f32_to_bf16_bits(v > 0.f ? v : v * slope);
     }
 }
-// dW[c,p] += m(c,p) * sum_b dh[b,p,c];  db[c] += sum_p of that  (one thread per channel; 16 positions, <= 64 samples)
+// dW[c,p] += m(c,p) * sum_b dh[b,p,c];  db[c] += sum_p of that.  One block per position p, one thread per channel (the
+// reads of a sample row are coalesced); the HW partial bias sums meet through fp32 atomics (16 adders per address).
 __global__ __launch_bounds__(256) void const_input_bwd_kernel(const unsigned short* __restrict__ dh,
                                                               const float* __restrict__ w, const float* __restrict__ bias,
                                                               float* __restrict__ dw, float* __restrict__ db, int B,
                                                               int HW, int C, float slope) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    float bsum = 0.f;
-    for (int p = 0; p < HW; ++p) {
+    const int p = blockIdx.x;
+    for (int c = blockIdx.y * 256 + threadIdx.x; c < C; c += gridDim.y * 256) {
         float s = 0.f;
         for (int b = 0; b < B; ++b) s += bf16_bits_to_f32(dh[((long)b * HW + p) * C + c]);
         const float g = (w[(long)c * HW + p] + bias[c]) > 0.f ? s : s * slope;
         if (dw) dw[(long)c * HW + p] += g;
-        bsum += g;
+        if (db) atomicAdd(db + c, g);
     }
-    if (db) db[c] += bsum;
 }
 
 // ------------------------------------------------------------------------------------------------ dense tail layout
@@ -464,8 +462,8 @@ extern "C" int rgbd_const_input_fwd(const float* w, const float* bias, void* out
 extern "C" int rgbd_const_input_bwd(const void* dh, const float* w, const float* bias, float* dw, float* db, int B, int HW,
                                     int C, float slope, void* stream) {
     RGBD_REQUIRE(dh && w && bias && B > 0 && HW > 0 && C > 0, "rgbd_const_input_bwd: bad arguments");
-    const_input_bwd_kernel<<<(C + 255) / 256, 256, 0, (hipStream_t)stream>>>((const unsigned short*)dh, w, bias, dw, db, B,
-                                                                             HW, C, slope);
+    const_input_bwd_kernel<<<dim3(HW, (C + 255) / 256), 256, 0, (hipStream_t)stream>>>((const unsigned short*)dh, w, bias, dw,
+                                                                                       db, B, HW, C, slope);
     RGBD_CHECK_LAUNCH("const_input_bwd_kernel");
     return 0;
 }

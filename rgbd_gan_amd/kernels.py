@@ -445,8 +445,11 @@ def linear_fwd(x, w, bias, c, act, slope=0.2):
     M, K = x.shape
     N = w.shape[0]
     y = torch.empty(M, N, dtype=F32, device=x.device)
-    rc = _lib.load().rgbd_linear_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), M, K, N, float(c), int(bool(act)),
-                                     float(slope), _stream())
+    lib = _lib.load()
+    nws = lib.rgbd_linear_fwd_workspace(M, K, N)
+    ws = torch.empty(nws, dtype=F32, device=x.device) if nws > 0 else None
+    rc = lib.rgbd_linear_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), M, K, N, float(c), int(bool(act)),
+                             float(slope), _ptr(ws), _stream())
     _lib.check(rc, "rgbd_linear_fwd")
     return y
 
@@ -457,8 +460,11 @@ def linear_fwd_masked(x, w, mask_y, c, slope=0.2):
     M, K = x.shape
     N = w.shape[0]
     y = torch.empty(M, N, dtype=F32, device=x.device)
-    rc = _lib.load().rgbd_linear_fwd_masked(_ptr(x), _ptr(w), _ptr(mask_y), _ptr(y), M, K, N, float(c), float(slope),
-                                            _stream())
+    lib = _lib.load()
+    nws = lib.rgbd_linear_fwd_workspace(M, K, N)
+    ws = torch.empty(nws, dtype=F32, device=x.device) if nws > 0 else None
+    rc = lib.rgbd_linear_fwd_masked(_ptr(x), _ptr(w), _ptr(mask_y), _ptr(y), M, K, N, float(c), float(slope), _ptr(ws),
+                                    _stream())
     _lib.check(rc, "rgbd_linear_fwd_masked")
     return y
 

@@ -526,7 +526,8 @@ def test_pool_and_unpool_lrelu_kernels():
 
 
 @pytest.mark.parametrize("M,K,N,act", [(32, 256, 256, True), (4, 265, 256, True), (64, 256, 128, False), (7, 256, 64, False),
-                                       (100, 256, 256, True)])
+                                       (100, 256, 256, True), (32, 4096, 256, True), (64, 4100, 256, False),
+                                       (16, 1024, 40, True)])
 def test_small_linear_forward_backward(M, K, N, act):
     from rgbd_gan_amd import functional as Fn
     g = torch.Generator().manual_seed(8)
