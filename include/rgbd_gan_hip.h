@@ -119,6 +119,8 @@ int rgbd_conv2d_fprop_bf16(const void* x, const void* wp, const float* bias, con
 /* Test hook: when on != 0, rgbd_conv2d_fprop_bf16 uses the generic gather kernel for every shape (by default 3x3
  * pad-1 convolutions on images of 16x16 and larger run the halo-patch kernel). */
 int rgbd_debug_force_gather_kernel(int on);
+/* Test / tuning hook: 0 = default kernels, 1 = the register-staged 3x3 halo-patch kernel instead of the ping-pong one. */
+int rgbd_debug_conv_variant(int v);
 
 /* Weight gradient: dw[co][ci][kh][kw] (+)= scale * sum_{b,h,w} dy[b,h,w,co] * x[b,h+kh-pad,w+kw-pad,ci]  (fp32).
  *   x  : (B,H,W,Cin) bf16, dy : (B,H,W,Cout) bf16 (same H,W: stride 1, pad = (K-1)/2), K in {1,3}.

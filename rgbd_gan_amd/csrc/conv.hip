@@ -566,6 +566,331 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(ConvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ 3x3 ping-pong kernel
+// The same tiling and LDS images as conv3x3_patch_kernel (16x16 output pixels x BN output channels per 512-thread
+// workgroup, 18x18 halo patch per 64-channel slice, one BN x 64 weight tile per filter tap), restructured so that the
+// matrix pipe never waits for staging:
+//   * global -> LDS by LDS-DMA (`buffer_load_dwordx4 ... offen lds`): no staging registers, no ds_write pass.  The DMA
+//     destination is lane-linear (M0 base + 16 B x lane), so the XOR chunk swizzle of both images is applied to each
+//     lane's SOURCE address; out-of-image halo rows use an out-of-range buffer offset, which the hardware turns into
+//     zeros written to LDS (scripts/hw/lds_dma_probe.hip).  The DMAs are inline asm, i.e. invisible to hipcc's waitcnt
+//     bookkeeping: each wave retires its own pieces with a COUNTED s_waitcnt vmcnt(N) (N = pieces it issued in the
+//     current segment, so everything older has landed) and a barrier publishes them.  Weight tile k+2 and the next
+//     slice's halo patch stay in flight across barriers.
+//   * waves 0-3 and 4-7 (SIMD partners: wave w and w+4 share a SIMD) run half a step apart.  A wave alternates a LOAD
+//     segment (issue DMAs, read this step's A/B fragments into registers, wait, barrier) with an MFMA segment (32
+//     back-to-back MFMAs at raised priority, barrier); waves 4-7 pass one extra barrier up front, so one partner's LOAD
+//     segment always runs under the other's MFMA segment instead of both stalling on LDS latency after a common barrier.
+//   Hazards (slots = intervals between consecutive barriers; G0 = waves 0-3, G1 = waves 4-7; G0: MFMA(t) in slot 2t,
+//   LOAD(t+1) in slot 2t+1; G1: LOAD(t) in slot 2t, MFMA(t) in slot 2t+1):
+//     RAW  W(t+1) is issued in LOAD(t-1), retired by the issuing wave's vmcnt at the end of its LOAD(t) (slots 2t-1 / 2t),
+//          first read in G0's LOAD(t+1) (slot 2t+1) -- one barrier after the last retiring wait.
+//     WAR  W(t+2) overwrites the buffer of W(t-1) from LOAD(t) on (slot 2t-1); W(t-1) was last read in G1's LOAD(t-1)
+//          (slot 2t-2), whose lgkmcnt(0) precedes the barrier ending that slot.
+//     The halo patch of slice g+1 is issued in LOAD(0..PPW-1) of slice g into the other patch buffer (last read in
+//     LOAD(6) of slice g-1) and retired by the vmcnt of LOAD(PPW) <= LOAD(6), two steps before its first read.
+__device__ __forceinline__ void lds_dma16(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+#define RGBD_PP_BARRIER()                         \
+    do {                                          \
+        __builtin_amdgcn_sched_barrier(0);        \
+        asm volatile("s_barrier" ::: "memory");   \
+        __builtin_amdgcn_sched_barrier(0);        \
+    } while (0)
+
+template <int BN, bool UPS>
+__global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(ConvArgs a) {
+    constexpr int HPW = UPS ? 10 : 18;            // halo patch width (and height)
+    constexpr int NROWS = HPW * HPW;
+    constexpr int P_PIECES = (NROWS * 128 + 1023) / 1024;   // 1-KiB DMA pieces per halo patch (41 or 13)
+    constexpr int P_BYTES = P_PIECES * 1024;
+    constexpr int PPW = (P_PIECES + 7) / 8;       // patch pieces per wave per slice (6 or 2)
+    constexpr int W_BYTES = BN * 128;
+    constexpr int WPW = BN / 64;                  // weight pieces per wave per K step
+    constexpr int WAVES_CO = BN / 64;
+    constexpr int WAVES_PX = 8 / WAVES_CO;
+    constexpr int PX_PER_WAVE = 256 / WAVES_PX;   // 64 or 32 pixels = 4 or 2 patch rows
+    constexpr int TPX = PX_PER_WAVE / 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    unsigned char* const patch_lds = dsm;                       // [2][P_BYTES]
+    unsigned char* const w_lds = dsm + 2 * P_BYTES;             // [3][W_BYTES]
+    const unsigned lds0 = (unsigned)(size_t)dsm;                // LDS byte address of dsm (low half of the flat address)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int group = wid >> 2;                                  // 0: waves 0-3, 1: their SIMD partners
+    unsigned bid = blockIdx.x;
+    {
+        const unsigned nwg = gridDim.x, xcd = bid & 7u, q8 = nwg >> 3, r8 = nwg & 7u;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    }
+    const int nt = bid / a.wgs_per_ntile;
+    const int slot = bid - nt * a.wgs_per_ntile;
+    const int pt_begin = (int)((long)slot * a.ptiles / a.wgs_per_ntile);
+    const int pt_end = (int)((long)(slot + 1) * a.ptiles / a.wgs_per_ntile);
+    const int tiles_x = a.Wout >> 4, tiles_per_img = tiles_x * (a.Hout >> 4);
+    const int n0 = nt * BN;
+    const int wave_co = (wid / WAVES_PX) * 64;
+    const int wave_py = (wid % WAVES_PX) * TPX;                  // first patch row of this wave
+
+    const unsigned long xp = (unsigned long)a.x, wpp = (unsigned long)a.wp;
+    const u32x4 xrsrc = {(unsigned)xp, (unsigned)(xp >> 32) & 0xffffu, (unsigned)a.x_bytes, 0x00020000u};
+    const u32x4 wrsrc = {(unsigned)wpp, (unsigned)(wpp >> 32) & 0xffffu, (unsigned)a.w_bytes, 0x00020000u};
+
+    const int nc = a.Cin >> 6;
+    const int g_total = (pt_end - pt_begin) * nc;               // (tile, channel slice) pairs of this workgroup
+    if (g_total <= 0) return;
+
+    // ---- DMA sources.  Halo piece i of this wave covers patch rows 8 pi .. 8 pi + 7 (pi = wid + 8 i, clamped: the last
+    //      pieces are issued twice with identical bytes so that every wave issues the same count); lane l fills LDS chunk
+    //      (l & 7) of row 8 pi + (l >> 3) with SOURCE chunk (l & 7) ^ (halo column & 7).
+    int phy[PPW], phx[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int pi = wid + 8 * i < P_PIECES ? wid + 8 * i : P_PIECES - 1;
+        const int row = pi * 8 + (lane >> 3);
+        const int hy = row / HPW, hx = row - hy * HPW;
+        phy[i] = row < NROWS ? hy : -100000;
+        phx[i] = hx | ((((lane & 7) ^ (hx & 7)) * 16) << 8);     // column | source chunk byte offset << 8
+    }
+    // weight piece i of this wave: LDS rows 8 (wid WPW + i) .. + 7; LDS row (64 w + 16 t + m) holds output channel
+    // 64 w + 16 (m >> 2) + 4 t + (m & 3) (see conv3x3_patch_kernel: every lane then owns 16 consecutive channels)
+    unsigned wvoff[WPW];
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) {
+        const int r = (wid * WPW + i) * 8 + (lane >> 3);
+        const int wm = r & 15, wt = (r >> 4) & 3;
+        const int wperm = (r & ~63) + 16 * (wm >> 2) + 4 * wt + (wm & 3);
+        wvoff[i] = (unsigned)(((n0 + wperm) * a.Cin + ((lane & 7) ^ (r & 7)) * 8) * 2);
+    }
+    const int tap_stride = a.Cout * a.Cin * 2;
+
+    auto tile_origin = [&](int pt, int& b, int& y0, int& x0) {
+        b = pt / tiles_per_img;
+        const int rem = pt - b * tiles_per_img;
+        const int ty = rem / tiles_x;
+        y0 = ty << 4;
+        x0 = (rem - ty * tiles_x) << 4;
+    };
+    auto dma_patch = [&](int i, int buf, int b, int hy0, int hx0, int c) {
+        const int pi = wid + 8 * i < P_PIECES ? wid + 8 * i : P_PIECES - 1;
+        const int yy = hy0 + phy[i], xx = hx0 + (phx[i] & 0xff);
+        const bool ok = (unsigned)yy < (unsigned)a.Hin && (unsigned)xx < (unsigned)a.Win;
+        const unsigned off = ok ? (unsigned)((((b * a.Hin + yy) * a.Win + xx) * a.Cin) * 2) + (unsigned)(phx[i] >> 8)
+                                : 0x80000000u;
+        lds_dma16(xrsrc, off, (unsigned)(c * 128), lds0 + (unsigned)(buf * P_BYTES + pi * 1024));
+    };
+    auto dma_w = [&](int c, int tap, int buf) {
+#pragma unroll
+        for (int i = 0; i < WPW; ++i)
+            lds_dma16(wrsrc, wvoff[i], (unsigned)(tap * tap_stride + c * 128),
+                      lds0 + (unsigned)(2 * P_BYTES + buf * W_BYTES + (wid * WPW + i) * 1024));
+    };
+
+    f32x4 acc[4][TPX];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TPX; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int r16 = lane & 15, q = lane >> 4;
+    int aoff[2], boff[3][2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        aoff[s2] = (wave_co + r16) * 128 + (((4 * s2 + q) ^ (r16 & 7)) << 4);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int colx = UPS ? ((r16 + kw - 1) >> 1) + 1 : r16 + kw;
+            const int row0 = UPS ? (wave_py >> 1) : wave_py;
+            boff[kw][s2] = (row0 * HPW + colx) * 128 + (((4 * s2 + q) ^ (colx & 7)) << 4);
+        }
+    }
+    constexpr int NR = UPS ? TPX / 2 + 2 : TPX + 2;     // halo rows a wave needs per filter column (see the patch kernel)
+    bf16x8 brow[NR][2], af[2][4];
+    auto load_frags = [&](const unsigned char* pbuf, const unsigned char* wbuf, int kh, int kw) {
+        if (kh == 0) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int r = 0; r < NR; ++r)
+                    brow[r][s2] = *reinterpret_cast<const bf16x8*>(pbuf + boff[kw][s2] + r * HPW * 128);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[s2][i] = *reinterpret_cast<const bf16x8*>(wbuf + aoff[s2] + i * 16 * 128);
+    };
+    auto mfmas = [&](int kh) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < TPX; ++j) {
+                    const int rj = UPS ? ((j + kh - 1) >> 1) + 1 : j + kh;   // compile-time after unrolling
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s2][i], brow[rj][s2], acc[i][j], 0, 0, 0);
+                }
+    };
+
+    float* const bias_lds = reinterpret_cast<float*>(dsm + 2 * P_BYTES + 3 * W_BYTES);   // [BN]
+    if (tid < BN) bias_lds[tid] = a.bias ? a.bias[n0 + tid] : 0.f;
+
+    auto epilogue = [&](int pt) {       // bias -> residual -> leaky ReLU -> bf16 NHWC, then clear the accumulators
+        int b, y0, x0;
+        tile_origin(pt, b, y0, x0);
+        const int co = n0 + wave_co + 16 * q;            // this lane's 16 consecutive output channels
+        const bool act = co < a.lrelu_ch;
+        if (a.pool_sum) {
+            const int Hp = a.Hout >> 1, Wp = a.Wout >> 1;
+#pragma unroll
+            for (int j = 0; j < TPX; j += 2) {
+                float v[16];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float t = acc[i][j][r] + acc[i][j + 1][r];
+                        const int o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, false);
+                        v[4 * i + r] = t + __builtin_bit_cast(float, o);
+                    }
+                if ((r16 & 1) == 0) {
+                    const int yy = (y0 + wave_py + j) >> 1, xx = (x0 + r16) >> 1;
+                    const long o = (((long)b * Hp + yy) * Wp + xx) * a.Cout + co;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        u32x4 out = {pack_bf16x2(v[8 * h + 0], v[8 * h + 1]), pack_bf16x2(v[8 * h + 2], v[8 * h + 3]),
+                                     pack_bf16x2(v[8 * h + 4], v[8 * h + 5]), pack_bf16x2(v[8 * h + 6], v[8 * h + 7])};
+                        *reinterpret_cast<u32x4*>(a.y + o + 8 * h) = out;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    acc[i][j + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            return;
+        }
+        float ps[16];                   // ypool: running 2x2 sums of the bf16-rounded outputs of a row pair
+#pragma unroll
+        for (int j = 0; j < TPX; ++j) {
+            const int yy = y0 + wave_py + j, xx = x0 + r16;
+            const long o = (((long)b * a.Hout + yy) * a.Wout + xx) * a.Cout + co;
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_lds + wave_co + 16 * q + 4 * i);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[4 * i + r] = acc[i][j][r] + bq[r];
+            }
+            if (a.resid) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const u32x4 rr = *reinterpret_cast<const u32x4*>(a.resid + o + 8 * h);
+#pragma unroll
+                    for (int w2 = 0; w2 < 4; ++w2) {
+                        v[8 * h + 2 * w2] += bf16_lo(rr[w2]);
+                        v[8 * h + 2 * w2 + 1] += bf16_hi(rr[w2]);
+                    }
+                }
+            }
+            if (act) {
+#pragma unroll
+                for (int k2 = 0; k2 < 16; ++k2) v[k2] = v[k2] > 0.f ? v[k2] : v[k2] * a.slope;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                u32x4 out = {pack_bf16x2(v[8 * h + 0], v[8 * h + 1]), pack_bf16x2(v[8 * h + 2], v[8 * h + 3]),
+                             pack_bf16x2(v[8 * h + 4], v[8 * h + 5]), pack_bf16x2(v[8 * h + 6], v[8 * h + 7])};
+                *reinterpret_cast<u32x4*>(a.y + o + 8 * h) = out;
+                if (a.ypool) {          // the block's downscale2x (rescale.py:12-13) of what was just stored
+#pragma unroll
+                    for (int w2 = 0; w2 < 4; ++w2) {
+                        const float lo = bf16_lo(out[w2]), hi = bf16_hi(out[w2]);
+                        ps[8 * h + 2 * w2] = (j & 1) ? ps[8 * h + 2 * w2] + lo : lo;
+                        ps[8 * h + 2 * w2 + 1] = (j & 1) ? ps[8 * h + 2 * w2 + 1] + hi : hi;
+                    }
+                }
+            }
+            if (a.ypool && (j & 1)) {
+#pragma unroll
+                for (int k2 = 0; k2 < 16; ++k2) {
+                    const int o2 = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ps[k2]), 0xB1, 0xF, 0xF, false);
+                    ps[k2] = 0.25f * (ps[k2] + __builtin_bit_cast(float, o2));
+                }
+                if ((r16 & 1) == 0) {
+                    const long op = (((long)b * (a.Hout >> 1) + (yy >> 1)) * (a.Wout >> 1) + (xx >> 1)) * a.Cout + co;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        u32x4 out = {pack_bf16x2(ps[8 * h + 0], ps[8 * h + 1]), pack_bf16x2(ps[8 * h + 2], ps[8 * h + 3]),
+                                     pack_bf16x2(ps[8 * h + 4], ps[8 * h + 5]), pack_bf16x2(ps[8 * h + 6], ps[8 * h + 7])};
+                        *reinterpret_cast<u32x4*>(a.ypool + op + 8 * h) = out;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+
+    // ---- prologue: halo patch of slice 0, weight tiles of steps 0 and 1 (step t multiplies filter tap
+    //      (kh, kw) = (t % 3, t / 3), i.e. weight image 3 (t % 3) + t / 3)
+    {
+        int b, y0, x0;
+        tile_origin(pt_begin, b, y0, x0);
+        const int hy0 = UPS ? (y0 >> 1) - 1 : y0 - 1, hx0 = UPS ? (x0 >> 1) - 1 : x0 - 1;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) dma_patch(i, 0, b, hy0, hx0, 0);
+        dma_w(0, 0, 0);
+        dma_w(0, 3, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (group == 1) RGBD_PP_BARRIER();                           // the stagger: waves 4-7 run one barrier behind
+
+    int c = 0, pt = pt_begin;
+    bool epi_pending = false;
+    int epi_pt = pt_begin;
+    for (int g = 0; g < g_total; ++g) {
+        const unsigned char* pbuf = patch_lds + (g & 1) * P_BYTES;
+        const int c_next = c + 1 == nc ? 0 : c + 1;
+        const bool last = g + 1 >= g_total;
+        const int pt_next = (c_next == 0 && !last) ? pt + 1 : pt;
+        int nb, ny0, nx0;
+        tile_origin(pt_next, nb, ny0, nx0);
+        const int nhy0 = UPS ? (ny0 >> 1) - 1 : ny0 - 1, nhx0 = UPS ? (nx0 >> 1) - 1 : nx0 - 1;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            // ---- LOAD segment of step t
+            if (t < PPW) dma_patch(t, (g + 1) & 1, nb, nhy0, nhx0, c_next);
+            dma_w(t + 2 >= 9 ? c_next : c, 3 * (((t + 2) % 9) % 3) + ((t + 2) % 9) / 3, (t + 2) % 3);
+            if (t == 0 && epi_pending) {
+                epilogue(epi_pt);
+                epi_pending = false;
+            }
+            load_frags(pbuf, w_lds + (t % 3) * W_BYTES, t % 3, t / 3);
+            if (t < PPW) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + 1) : "memory");
+            else         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            RGBD_PP_BARRIER();
+            // ---- MFMA segment of step t
+            __builtin_amdgcn_s_setprio(1);
+            mfmas(t % 3);
+            __builtin_amdgcn_s_setprio(0);
+            if (!(t == 8 && last && group == 1)) RGBD_PP_BARRIER();
+        }
+        if (c_next == 0) {
+            epi_pending = true;
+            epi_pt = pt;
+        }
+        c = c_next;
+        pt = pt_next;
+    }
+    epilogue(epi_pt);
+}
+
 // ------------------------------------------------------------------------------------------------ wgrad
 struct WgradArgs {
     const unsigned short* x;
@@ -881,6 +1206,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(WgradMultiArgs 
 }
 
 bool g_force_gather = false;   // test hook: route every shape through the generic gather kernel
+int g_conv_variant = 0;        // test / tuning hook: 1 = the register-staged conv3x3_patch_kernel instead of the ping-pong one
 
 int ilog2(int v) {
     int l = 0;
@@ -892,6 +1218,10 @@ int ilog2(int v) {
 
 extern "C" int rgbd_debug_force_gather_kernel(int on) {
     g_force_gather = on != 0;
+    return 0;
+}
+extern "C" int rgbd_debug_conv_variant(int v) {
+    g_conv_variant = v;
     return 0;
 }
 
@@ -1008,6 +1338,21 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
         a.ptiles = (int)ptiles;
         a.wgs_per_ntile = per_nt;
         const long grid = (long)per_nt * n_tiles;
+        if (wide && g_conv_variant != 1) {
+            const int pieces = a.ups ? 13 : 41;
+            const int lds_pp = 2 * pieces * 1024 + 3 * 128 * 128 + 128 * 4;
+            const void* fpp = a.ups ? (const void*)&conv3x3_pp_kernel<128, true> : (const void*)&conv3x3_pp_kernel<128, false>;
+            static bool pp_attr_done[2] = {false, false};
+            if (!pp_attr_done[a.ups]) {
+                RGBD_REQUIRE(hipFuncSetAttribute(fpp, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pp) == hipSuccess,
+                             "rgbd_conv2d_fprop_bf16: cannot reserve %d B of LDS", lds_pp);
+                pp_attr_done[a.ups] = true;
+            }
+            if (a.ups) conv3x3_pp_kernel<128, true><<<(unsigned)grid, 512, lds_pp, st>>>(a);
+            else       conv3x3_pp_kernel<128, false><<<(unsigned)grid, 512, lds_pp, st>>>(a);
+            RGBD_CHECK_LAUNCH("conv3x3_pp_kernel");
+            return 0;
+        }
         const int lds = 2 * 324 * 128 + 3 * (wide ? 128 : 64) * 128 + (wide ? 128 : 64) * 4;
         const void* fn = wide ? (a.ups ? (const void*)&conv3x3_patch_kernel<128, true>
                                        : (const void*)&conv3x3_patch_kernel<128, false>)
