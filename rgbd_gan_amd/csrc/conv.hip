@@ -600,7 +600,7 @@ __device__ __forceinline__ void lds_dma16(u32x4 rsrc, unsigned voff, unsigned so
         __builtin_amdgcn_sched_barrier(0);        \
     } while (0)
 
-template <int BN, bool UPS>
+template <int BN, bool UPS, int KO = 0>   // KO: timing knock-outs (wrong results): 1 no weight DMA, 2 no halo DMA, 3 no LDS reads, 4 no MFMAs
 __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(ConvArgs a) {
     constexpr int HPW = UPS ? 10 : 18;            // halo patch width (and height)
     constexpr int NROWS = HPW * HPW;
@@ -635,37 +635,57 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(ConvArgs a) {
     const int wave_co = (wid / WAVES_PX) * 64;
     const int wave_py = (wid % WAVES_PX) * TPX;                  // first patch row of this wave
 
-    const unsigned long xp = (unsigned long)a.x, wpp = (unsigned long)a.wp;
-    const u32x4 xrsrc = {(unsigned)xp, (unsigned)(xp >> 32) & 0xffffu, (unsigned)a.x_bytes, 0x00020000u};
-    const u32x4 wrsrc = {(unsigned)wpp, (unsigned)(wpp >> 32) & 0xffffu, (unsigned)a.w_bytes, 0x00020000u};
-
     const int nc = a.Cin >> 6;
     const int g_total = (pt_end - pt_begin) * nc;               // (tile, channel slice) pairs of this workgroup
     if (g_total <= 0) return;
 
-    // ---- DMA sources.  Halo piece i of this wave covers patch rows 8 pi .. 8 pi + 7 (pi = wid + 8 i, clamped: the last
-    //      pieces are issued twice with identical bytes so that every wave issues the same count); lane l fills LDS chunk
-    //      (l & 7) of row 8 pi + (l >> 3) with SOURCE chunk (l & 7) ^ (halo column & 7).
-    int phy[PPW], phx[PPW];
+    // ---- DMA roles.  A wave's memory operations retire in issue order, so a weight tile (L2 hit, needed one step
+    //      later) queued behind a halo piece (HBM latency, needed next slice) would inherit its latency: waves 0,1,4,5
+    //      issue ONLY weight pieces, waves 2,3,6,7 ONLY halo pieces (two of each role per SIMD-partner group).
+    const bool w_role = (wid & 2) == 0;
+    const int ridx = (wid & 1) + 2 * (wid >> 2);                 // 0..3 within the role
+    constexpr int WPW4 = BN / 32;                                // weight pieces per weight wave per K step (BN / 8 / 4)
+    constexpr int PPW4 = (P_PIECES + 3) / 4;                     // halo pieces per halo wave per slice (11 or 4)
+    constexpr int PPS = (PPW4 + 5) / 6;                          // ... issued per step (2 or 1), in steps 0 .. PSTEPS-1
+    constexpr int PSTEPS = (PPW4 + PPS - 1) / PPS;               // 6 or 4
+    constexpr int NOFF = PPW4 > WPW4 ? PPW4 : WPW4;
+    static_assert(PPW4 <= 12, "halo border masks are packed 5 bits x 6 pieces x 2 registers");
+    // Per-lane source offsets, constant for the whole kernel.
+    //   halo wave: piece i covers patch rows 8 pi .. 8 pi + 7 (pi = ridx + 4 i, clamped: the last pieces are issued twice
+    //     with identical bytes so that every wave issues the same count); lane l fills LDS chunk (l & 7) of row
+    //     8 pi + (l >> 3) with SOURCE chunk (l & 7) ^ (halo column & 7).  doff = offset relative to the patch's
+    //     top-left halo pixel; the tile-dependent part goes into the (scalar) soffset, against a descriptor whose base
+    //     is one halo row + one pixel BEFORE the tensor (never dereferenced: those lanes are masked off below).
+    //     Out-of-image lanes are known per tile class: pm packs 5 bits per piece (row 0, last row, column 0, last
+    //     column, beyond the patch) that are ANDed with the tile's border bits.
+    //   weight wave: piece i = LDS rows 8 (4 ridx + i) .. + 7; LDS row (64 w + 16 t + m) holds output channel
+    //     64 w + 16 (m >> 2) + 4 t + (m & 3) (see conv3x3_patch_kernel: every lane then owns 16 consecutive channels)
+    unsigned doff[NOFF], pm[2] = {0u, 0u};
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-        const int pi = wid + 8 * i < P_PIECES ? wid + 8 * i : P_PIECES - 1;
-        const int row = pi * 8 + (lane >> 3);
-        const int hy = row / HPW, hx = row - hy * HPW;
-        phy[i] = row < NROWS ? hy : -100000;
-        phx[i] = hx | ((((lane & 7) ^ (hx & 7)) * 16) << 8);     // column | source chunk byte offset << 8
-    }
-    // weight piece i of this wave: LDS rows 8 (wid WPW + i) .. + 7; LDS row (64 w + 16 t + m) holds output channel
-    // 64 w + 16 (m >> 2) + 4 t + (m & 3) (see conv3x3_patch_kernel: every lane then owns 16 consecutive channels)
-    unsigned wvoff[WPW];
-#pragma unroll
-    for (int i = 0; i < WPW; ++i) {
-        const int r = (wid * WPW + i) * 8 + (lane >> 3);
-        const int wm = r & 15, wt = (r >> 4) & 3;
-        const int wperm = (r & ~63) + 16 * (wm >> 2) + 4 * wt + (wm & 3);
-        wvoff[i] = (unsigned)(((n0 + wperm) * a.Cin + ((lane & 7) ^ (r & 7)) * 8) * 2);
+    for (int i = 0; i < NOFF; ++i) {
+        unsigned wv = 0, pv = 0;
+        if (i < WPW4) {
+            const int r = (ridx * WPW4 + i) * 8 + (lane >> 3);
+            const int wm = r & 15, wt = (r >> 4) & 3;
+            const int wperm = (r & ~63) + 16 * (wm >> 2) + 4 * wt + (wm & 3);
+            wv = (unsigned)(((n0 + wperm) * a.Cin + ((lane & 7) ^ (r & 7)) * 8) * 2);
+        }
+        if (i < PPW4) {
+            const int pi = ridx + 4 * i < P_PIECES ? ridx + 4 * i : P_PIECES - 1;
+            const int row = pi * 8 + (lane >> 3);
+            const int hy = row / HPW, hx = row - hy * HPW;
+            pv = (unsigned)((hy * a.Win + hx) * a.Cin * 2 + (((lane & 7) ^ (hx & 7)) << 4));
+            const unsigned m = (hy == 0 ? 1u : 0u) | (hy == HPW - 1 ? 2u : 0u) | (hx == 0 ? 4u : 0u) |
+                               (hx == HPW - 1 ? 8u : 0u) | (row >= NROWS ? 16u : 0u);
+            pm[i / 6] |= m << (5 * (i % 6));
+        }
+        doff[i] = w_role ? wv : pv;
     }
     const int tap_stride = a.Cout * a.Cin * 2;
+    const unsigned x_lead = (unsigned)((a.Win + 1) * a.Cin * 2);
+    const unsigned long xp = (unsigned long)a.x - x_lead, wpp = (unsigned long)a.wp;
+    const u32x4 xrsrc = {(unsigned)xp, (unsigned)(xp >> 32) & 0xffffu, (unsigned)a.x_bytes + x_lead, 0x00020000u};
+    const u32x4 wrsrc = {(unsigned)wpp, (unsigned)(wpp >> 32) & 0xffffu, (unsigned)a.w_bytes, 0x00020000u};
 
     auto tile_origin = [&](int pt, int& b, int& y0, int& x0) {
         b = pt / tiles_per_img;
@@ -674,19 +694,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(ConvArgs a) {
         y0 = ty << 4;
         x0 = (rem - ty * tiles_x) << 4;
     };
-    auto dma_patch = [&](int i, int buf, int b, int hy0, int hx0, int c) {
-        const int pi = wid + 8 * i < P_PIECES ? wid + 8 * i : P_PIECES - 1;
-        const int yy = hy0 + phy[i], xx = hx0 + (phx[i] & 0xff);
-        const bool ok = (unsigned)yy < (unsigned)a.Hin && (unsigned)xx < (unsigned)a.Win;
-        const unsigned off = ok ? (unsigned)((((b * a.Hin + yy) * a.Win + xx) * a.Cin) * 2) + (unsigned)(phx[i] >> 8)
-                                : 0x80000000u;
-        lds_dma16(xrsrc, off, (unsigned)(c * 128), lds0 + (unsigned)(buf * P_BYTES + pi * 1024));
+    // scalar part of a halo patch's source: (offset of the tile's first pixel (+ channel slice), border bits)
+    auto patch_scalar = [&](int pt, int c, unsigned& soff, unsigned& border) {
+        int b, y0, x0;
+        tile_origin(pt, b, y0, x0);
+        const int sy = UPS ? y0 >> 1 : y0, sx = UPS ? x0 >> 1 : x0;
+        soff = (unsigned)((((b * a.Hin + sy) * a.Win + sx) * a.Cin) * 2 + c * 128);
+        border = (y0 == 0 ? 1u : 0u) | (y0 + 16 == a.Hout ? 2u : 0u) | (x0 == 0 ? 4u : 0u) | (x0 + 16 == a.Wout ? 8u : 0u) | 16u;
     };
-    auto dma_w = [&](int c, int tap, int buf) {
+    auto dma_patch = [&](int i, int buf, unsigned soff, unsigned border) {     // halo waves only
+        const int pi = ridx + 4 * i < P_PIECES ? ridx + 4 * i : P_PIECES - 1;
+        const bool ok = (pm[i / 6] & (border << (5 * (i % 6)))) == 0u;
+        lds_dma16(xrsrc, ok ? doff[i] : 0x80000000u, soff, lds0 + (unsigned)(buf * P_BYTES + pi * 1024));
+    };
+    auto dma_w = [&](int c, int tap, int buf) {                                  // weight waves only
 #pragma unroll
-        for (int i = 0; i < WPW; ++i)
-            lds_dma16(wrsrc, wvoff[i], (unsigned)(tap * tap_stride + c * 128),
-                      lds0 + (unsigned)(2 * P_BYTES + buf * W_BYTES + (wid * WPW + i) * 1024));
+        for (int i = 0; i < WPW4; ++i)
+            lds_dma16(wrsrc, doff[i], (unsigned)(tap * tap_stride + c * 128),
+                      lds0 + (unsigned)(2 * P_BYTES + buf * W_BYTES + (ridx * WPW4 + i) * 1024));
     };
 
     f32x4 acc[4][TPX];
@@ -837,16 +862,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(ConvArgs a) {
 
     // ---- prologue: halo patch of slice 0, weight tiles of steps 0 and 1 (step t multiplies filter tap
     //      (kh, kw) = (t % 3, t / 3), i.e. weight image 3 (t % 3) + t / 3)
-    {
-        int b, y0, x0;
-        tile_origin(pt_begin, b, y0, x0);
-        const int hy0 = UPS ? (y0 >> 1) - 1 : y0 - 1, hx0 = UPS ? (x0 >> 1) - 1 : x0 - 1;
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) dma_patch(i, 0, b, hy0, hx0, 0);
+    if (w_role) {
         dma_w(0, 0, 0);
         dma_w(0, 3, 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        unsigned soff, border;
+        patch_scalar(pt_begin, 0, soff, border);
+#pragma unroll
+        for (int i = 0; i < PPW4; ++i) dma_patch(i, 0, soff, border);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (group == 1) RGBD_PP_BARRIER();                           // the stagger: waves 4-7 run one barrier behind
 
@@ -858,28 +883,53 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(ConvArgs a) {
         const int c_next = c + 1 == nc ? 0 : c + 1;
         const bool last = g + 1 >= g_total;
         const int pt_next = (c_next == 0 && !last) ? pt + 1 : pt;
-        int nb, ny0, nx0;
-        tile_origin(pt_next, nb, ny0, nx0);
-        const int nhy0 = UPS ? (ny0 >> 1) - 1 : ny0 - 1, nhx0 = UPS ? (nx0 >> 1) - 1 : nx0 - 1;
+        unsigned nsoff, nborder;
+        patch_scalar(pt_next, c_next, nsoff, nborder);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             // ---- LOAD segment of step t
-            if (t < PPW) dma_patch(t, (g + 1) & 1, nb, nhy0, nhx0, c_next);
-            dma_w(t + 2 >= 9 ? c_next : c, 3 * (((t + 2) % 9) % 3) + ((t + 2) % 9) / 3, (t + 2) % 3);
+            unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, st6 = 0;
+            if (KO == 5) st0 = __builtin_amdgcn_s_memtime();
+            // the tile epilogue (global stores) goes first: whatever this segment's counted wait leaves in flight is
+            // then only this segment's DMAs
             if (t == 0 && epi_pending) {
                 epilogue(epi_pt);
                 epi_pending = false;
             }
-            load_frags(pbuf, w_lds + (t % 3) * W_BYTES, t % 3, t / 3);
-            if (t < PPW) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW + 1) : "memory");
-            else         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
+            if (w_role) {
+                if (KO != 1 && KO != 6) dma_w(t + 2 >= 9 ? c_next : c, 3 * (((t + 2) % 9) % 3) + ((t + 2) % 9) / 3, (t + 2) % 3);
+            } else if (t < PSTEPS && KO != 2 && KO != 6) {
+#pragma unroll
+                for (int i = t * PPS; i < (t + 1) * PPS && i < PPW4; ++i) dma_patch(i, (g + 1) & 1, nsoff, nborder);
+            }
+            if (KO == 5) st1 = __builtin_amdgcn_s_memtime();
+            if ((KO != 3 && KO != 6) || g == 0) load_frags(pbuf, w_lds + (t % 3) * W_BYTES, t % 3, t / 3);
+            if (KO == 5) st2 = __builtin_amdgcn_s_memtime();
+            // weight waves: all but this segment's pieces (tile t + 2) have landed, i.e. tile t + 1; halo waves: the whole
+            // next patch, once, two steps before its first read
+            if (w_role) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KO == 1 || KO == 6 ? 0 : WPW4) : "memory");
+            else if (t == 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (KO == 5) st3 = __builtin_amdgcn_s_memtime();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (KO == 5) st4 = __builtin_amdgcn_s_memtime();
             RGBD_PP_BARRIER();
             // ---- MFMA segment of step t
+            if (KO == 5) st5 = __builtin_amdgcn_s_memtime();
             __builtin_amdgcn_s_setprio(1);
-            mfmas(t % 3);
+            if (KO != 4 || g == 0) mfmas(t % 3);
             __builtin_amdgcn_s_setprio(0);
+            if (KO == 5) {
+                __builtin_amdgcn_sched_barrier(0);
+                st6 = __builtin_amdgcn_s_memtime();
+            }
             if (!(t == 8 && last && group == 1)) RGBD_PP_BARRIER();
+            if (KO == 5 && blockIdx.x == 0 && (wid & 3) == 0 && g < 4 && lane == 0) {
+                // stamps: [group][step][8] = LOAD start, DMAs issued, reads issued, vmcnt done, lgkmcnt done, barrier passed
+                // (MFMA start), MFMAs issued, next barrier passed
+                unsigned long long* o = reinterpret_cast<unsigned long long*>(a.partial) + ((group * 36 + g * 9 + t) * 8);
+                o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = st4; o[5] = st5; o[6] = st6;
+                o[7] = __builtin_amdgcn_s_memtime();
+            }
         }
         if (c_next == 0) {
             epi_pending = true;
@@ -1224,6 +1274,15 @@ extern "C" int rgbd_debug_conv_variant(int v) {
     g_conv_variant = v;
     return 0;
 }
+namespace {
+void* g_stamp_buf = nullptr;
+constexpr size_t STAMP_BYTES = 2 * 36 * 8 * sizeof(unsigned long long);
+}
+extern "C" int rgbd_debug_conv_stamps(unsigned long long* host_out) {   // variant 15: [2 groups][36 steps][8 stamps]
+    RGBD_REQUIRE(g_stamp_buf && host_out, "rgbd_debug_conv_stamps: run a conv with variant 15 first");
+    RGBD_REQUIRE(hipMemcpy(host_out, g_stamp_buf, STAMP_BYTES, hipMemcpyDeviceToHost) == hipSuccess, "stamps: copy failed");
+    return 0;
+}
 
 namespace {
 // Split-K plan of the gather kernel: 1 (no split) when the unsplit launch already fills the chip.
@@ -1347,6 +1406,35 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
                 RGBD_REQUIRE(hipFuncSetAttribute(fpp, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pp) == hipSuccess,
                              "rgbd_conv2d_fprop_bf16: cannot reserve %d B of LDS", lds_pp);
                 pp_attr_done[a.ups] = true;
+            }
+            if (g_conv_variant == 15 && !a.ups) {                               // in-kernel stamps (scripts/conv_stamps.py)
+                if (!g_stamp_buf) RGBD_REQUIRE(hipMalloc(&g_stamp_buf, STAMP_BYTES) == hipSuccess, "stamps: hipMalloc");
+                a.partial = (float*)g_stamp_buf;
+                const void* fk = (const void*)&conv3x3_pp_kernel<128, false, 5>;
+                RGBD_REQUIRE(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pp) == hipSuccess, "lds");
+                conv3x3_pp_kernel<128, false, 5><<<(unsigned)grid, 512, lds_pp, st>>>(a);
+                RGBD_CHECK_LAUNCH("conv3x3_pp_kernel<stamps>");
+                return 0;
+            }
+            if (g_conv_variant == 16 && !a.ups) {
+                const void* fk = (const void*)&conv3x3_pp_kernel<128, false, 6>;
+                RGBD_REQUIRE(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pp) == hipSuccess, "lds");
+                conv3x3_pp_kernel<128, false, 6><<<(unsigned)grid, 512, lds_pp, st>>>(a);
+                RGBD_CHECK_LAUNCH("conv3x3_pp_kernel<KO6>");
+                return 0;
+            }
+            if (g_conv_variant >= 11 && g_conv_variant <= 14 && !a.ups) {      // timing knock-outs (scripts/ab_conv.py)
+                const void* fk = g_conv_variant == 11 ? (const void*)&conv3x3_pp_kernel<128, false, 1>
+                               : g_conv_variant == 12 ? (const void*)&conv3x3_pp_kernel<128, false, 2>
+                               : g_conv_variant == 13 ? (const void*)&conv3x3_pp_kernel<128, false, 3>
+                                                      : (const void*)&conv3x3_pp_kernel<128, false, 4>;
+                RGBD_REQUIRE(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pp) == hipSuccess, "lds");
+                if (g_conv_variant == 11) conv3x3_pp_kernel<128, false, 1><<<(unsigned)grid, 512, lds_pp, st>>>(a);
+                if (g_conv_variant == 12) conv3x3_pp_kernel<128, false, 2><<<(unsigned)grid, 512, lds_pp, st>>>(a);
+                if (g_conv_variant == 13) conv3x3_pp_kernel<128, false, 3><<<(unsigned)grid, 512, lds_pp, st>>>(a);
+                if (g_conv_variant == 14) conv3x3_pp_kernel<128, false, 4><<<(unsigned)grid, 512, lds_pp, st>>>(a);
+                RGBD_CHECK_LAUNCH("conv3x3_pp_kernel<KO>");
+                return 0;
             }
             if (a.ups) conv3x3_pp_kernel<128, true><<<(unsigned)grid, 512, lds_pp, st>>>(a);
             else       conv3x3_pp_kernel<128, false><<<(unsigned)grid, 512, lds_pp, st>>>(a);
