@@ -121,9 +121,6 @@ int rgbd_conv2d_fprop_bf16(const void* x, const void* wp, const float* bias, con
 int rgbd_debug_force_gather_kernel(int on);
 /* Test / tuning hook: 0 = default kernels, 1 = the register-staged 3x3 halo-patch kernel instead of the ping-pong one. */
 int rgbd_debug_conv_variant(int v);
-/* Diagnostic: after a wide 3x3 conv run under variant 15, copies workgroup 0's in-kernel cycle stamps
- * ([2 wave groups][36 K steps][8 stamps], see conv3x3_pp_kernel) to host_out (576 x uint64). */
-int rgbd_debug_conv_stamps(unsigned long long* host_out);
 
 /* Weight gradient: dw[co][ci][kh][kw] (+)= scale * sum_{b,h,w} dy[b,h,w,co] * x[b,h+kh-pad,w+kw-pad,ci]  (fp32).
  *   x  : (B,H,W,Cin) bf16, dy : (B,H,W,Cout) bf16 (same H,W: stride 1, pad = (K-1)/2), K in {1,3}.

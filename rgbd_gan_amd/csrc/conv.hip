@@ -566,29 +566,37 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(ConvArgs a) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------ 3x3 ping-pong kernel
+// ------------------------------------------------------------------------------------------------ 3x3 pipelined kernel
 // The same tiling and LDS images as conv3x3_patch_kernel (16x16 output pixels x BN output channels per 512-thread
 // workgroup, 18x18 halo patch per 64-channel slice, one BN x 64 weight tile per filter tap), restructured so that the
-// matrix pipe never waits for staging:
+// matrix pipe never waits for staging or for LDS latency:
 //   * global -> LDS by LDS-DMA (`buffer_load_dwordx4 ... offen lds`): no staging registers, no ds_write pass.  The DMA
 //     destination is lane-linear (M0 base + 16 B x lane), so the XOR chunk swizzle of both images is applied to each
 //     lane's SOURCE address; out-of-image halo rows use an out-of-range buffer offset, which the hardware turns into
 //     zeros written to LDS (scripts/hw/lds_dma_probe.hip).  The DMAs are inline asm, i.e. invisible to hipcc's waitcnt
-//     bookkeeping: each wave retires its own pieces with a COUNTED s_waitcnt vmcnt(N) (N = pieces it issued in the
-//     current segment, so everything older has landed) and a barrier publishes them.  Weight tile k+2 and the next
-//     slice's halo patch stay in flight across barriers.
-//   * waves 0-3 and 4-7 (SIMD partners: wave w and w+4 share a SIMD) run half a step apart.  A wave alternates a LOAD
-//     segment (issue DMAs, read this step's A/B fragments into registers, wait, barrier) with an MFMA segment (32
-//     back-to-back MFMAs at raised priority, barrier); waves 4-7 pass one extra barrier up front, so one partner's LOAD
-//     segment always runs under the other's MFMA segment instead of both stalling on LDS latency after a common barrier.
-//   Hazards (slots = intervals between consecutive barriers; G0 = waves 0-3, G1 = waves 4-7; G0: MFMA(t) in slot 2t,
-//   LOAD(t+1) in slot 2t+1; G1: LOAD(t) in slot 2t, MFMA(t) in slot 2t+1):
-//     RAW  W(t+1) is issued in LOAD(t-1), retired by the issuing wave's vmcnt at the end of its LOAD(t) (slots 2t-1 / 2t),
-//          first read in G0's LOAD(t+1) (slot 2t+1) -- one barrier after the last retiring wait.
-//     WAR  W(t+2) overwrites the buffer of W(t-1) from LOAD(t) on (slot 2t-1); W(t-1) was last read in G1's LOAD(t-1)
-//          (slot 2t-2), whose lgkmcnt(0) precedes the barrier ending that slot.
-//     The halo patch of slice g+1 is issued in LOAD(0..PPW-1) of slice g into the other patch buffer (last read in
-//     LOAD(6) of slice g-1) and retired by the vmcnt of LOAD(PPW) <= LOAD(6), two steps before its first read.
+//     bookkeeping: each wave retires its own pieces with a COUNTED s_waitcnt vmcnt(N) and the step's barrier publishes
+//     them.  Weight tile t+3 is requested when tile t's buffer falls free (three buffers: two steps to land); the next
+//     slice's halo patch streams in over steps 0-5 of the current one.
+//   * operand fragments are software-pipelined through registers at HALF-step granularity: a K step (one tap x 64
+//     channels) is two blocks of 16 (BN=128) MFMAs over k 0-31 and k 32-63; while a block runs, the ds_reads of the NEXT
+//     block's fragments are in flight into the registers the PREVIOUS block has finished with (A: 4 fragments per
+//     half; B: the halo rows a wave needs live in TPX row slots per half -- vertical tap kh+1 drops one row and adds one,
+//     a new filter column replaces all of them).  A wave therefore never waits on LDS latency, and since the fragment
+//     sets are only 32 + 32 registers the whole kernel stays near 170 VGPRs.
+//   * ONE barrier per K step (after the k 0-31 block): it publishes weight tile t+1 (and, at step 8, the next halo
+//     patch) and certifies that every wave has finished reading tile t, whose buffer the DMA of tile t+3 then reuses.
+//     SIMD partners (wave w and w+4) issue MFMAs concurrently; DMA issue (~60 cycles per piece) and fragment reads of
+//     one partner run under the other's MFMAs.
+//   DMA roles: a wave's memory operations retire in issue order, so a weight piece (L2 hit, needed two steps later)
+//   queued behind a halo piece (HBM latency, needed next slice) would inherit its latency: waves 0,1,6,7 issue ONLY
+//   weight pieces, waves 2,3,4,5 ONLY halo pieces (one of each role per SIMD).
+//   Hazards (B_t = the barrier inside step t):
+//     RAW  W(t+1) is first read right after B_t (A fragments of block (t+1, k 0-31)); it was issued after B_(t-2) and is
+//          retired by the issuing wave's vmcnt(pieces of W(t+2)) before that wave arrives at B_t.
+//     WAR  W(t+3) goes into W(t)'s buffer after B_t; W(t)'s last reads (k 32-63 fragments, issued at the start of step t)
+//          are retired by the lgkmcnt(0) in front of B_t.
+//     The halo patch of slice g+1 is issued after B_0..B_5 of slice g into the other patch buffer (last read before
+//     B_8 of slice g-1), retired by the halo waves' vmcnt(0) in front of B_7, first read after B_8.
 __device__ __forceinline__ void lds_dma16(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :: "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
@@ -600,8 +608,19 @@ __device__ __forceinline__ void lds_dma16(u32x4 rsrc, unsigned voff, unsigned so
         __builtin_amdgcn_sched_barrier(0);        \
     } while (0)
 
-template <int BN, bool UPS, int KO = 0>   // KO: timing knock-outs (wrong results): 1 no weight DMA, 2 no halo DMA, 3 no LDS reads, 4 no MFMAs
-__global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(ConvArgs a) {
+// scheduling hint for one block: one fragment read (of the NEXT block) behind each of the first MFMAs -- LDS instructions
+// issue beside the matrix pipe, so a wave that alternates them keeps the pipe busy on its own
+#define RGBD_SP_INTERLEAVE()                                     \
+    do {                                                         \
+        _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) {       \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   \
+        }                                                        \
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);       \
+    } while (0)
+
+template <int BN, bool UPS, int KO = 0>   // KO: timing knock-outs (wrong results): 1 no weight DMA, 2 no halo DMA, 3 no LDS reads, 4 no MFMAs, 6 MFMAs and barriers only
+__global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
     constexpr int HPW = UPS ? 10 : 18;            // halo patch width (and height)
     constexpr int NROWS = HPW * HPW;
     constexpr int P_PIECES = (NROWS * 128 + 1023) / 1024;   // 1-KiB DMA pieces per halo patch (41 or 13)
@@ -620,7 +639,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int group = wid >> 2;                                  // 0: waves 0-3, 1: their SIMD partners
     unsigned bid = blockIdx.x;
     {
         const unsigned nwg = gridDim.x, xcd = bid & 7u, q8 = nwg >> 3, r8 = nwg & 7u;
@@ -639,10 +657,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(ConvArgs a) {
     const int g_total = (pt_end - pt_begin) * nc;               // (tile, channel slice) pairs of this workgroup
     if (g_total <= 0) return;
 
-    // ---- DMA roles.  A wave's memory operations retire in issue order, so a weight tile (L2 hit, needed one step
-    //      later) queued behind a halo piece (HBM latency, needed next slice) would inherit its latency: waves 0,1,4,5
-    //      issue ONLY weight pieces, waves 2,3,6,7 ONLY halo pieces (two of each role per SIMD-partner group).
-    const bool w_role = (wid & 2) == 0;
+    // ---- DMA roles: weight waves 0,1,6,7, halo waves 2,3,4,5 (wave w and w+4 share a SIMD: one of each per SIMD)
+    const bool w_role = ((wid >> 1) & 1) == (wid >> 2);
     const int ridx = (wid & 1) + 2 * (wid >> 2);                 // 0..3 within the role
     constexpr int WPW4 = BN / 32;                                // weight pieces per weight wave per K step (BN / 8 / 4)
     constexpr int PPW4 = (P_PIECES + 3) / 4;                     // halo pieces per halo wave per slice (11 or 4)
@@ -707,11 +723,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(ConvArgs a) {
         const bool ok = (pm[i / 6] & (border << (5 * (i % 6)))) == 0u;
         lds_dma16(xrsrc, ok ? doff[i] : 0x80000000u, soff, lds0 + (unsigned)(buf * P_BYTES + pi * 1024));
     };
-    auto dma_w = [&](int c, int tap, int buf) {                                  // weight waves only
+    auto dma_w_piece = [&](int c, int tap, int buf, int i) {                     // weight waves only
+        lds_dma16(wrsrc, doff[i], (unsigned)(tap * tap_stride + c * 128),
+                  lds0 + (unsigned)(2 * P_BYTES + buf * W_BYTES + (ridx * WPW4 + i) * 1024));
+    };
+    auto dma_w = [&](int c, int tap, int buf) {
 #pragma unroll
-        for (int i = 0; i < WPW4; ++i)
-            lds_dma16(wrsrc, doff[i], (unsigned)(tap * tap_stride + c * 128),
-                      lds0 + (unsigned)(2 * P_BYTES + buf * W_BYTES + (ridx * WPW4 + i) * 1024));
+        for (int i = 0; i < WPW4; ++i) dma_w_piece(c, tap, buf, i);
     };
 
     f32x4 acc[4][TPX];
@@ -732,31 +750,37 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(ConvArgs a) {
             boff[kw][s2] = (row0 * HPW + colx) * 128 + (((4 * s2 + q) ^ (colx & 7)) << 4);
         }
     }
-    constexpr int NR = UPS ? TPX / 2 + 2 : TPX + 2;     // halo rows a wave needs per filter column (see the patch kernel)
-    bf16x8 brow[NR][2], af[2][4];
-    auto load_frags = [&](const unsigned char* pbuf, const unsigned char* wbuf, int kh, int kw) {
-        if (kh == 0) {
+    constexpr int NR = UPS ? TPX / 2 + 2 : TPX + 2;     // halo rows a wave needs per filter column
+    // output row j at vertical tap kh reads halo row rowidx(j, kh) (the folded upsample halves the row index)
+    auto rowidx = [](int j, int kh) { return UPS ? ((j + kh - 1) >> 1) + 1 : j + kh; };
+    bf16x8 brow[TPX][2], af[2][4];                      // [row slot = halo row % TPX][k half], [k half][16-channel tile]
+    // A fragments of weight tile `wbuf`, k half h
+    auto load_a = [&](const unsigned char* wbuf, int h) {
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int r = 0; r < NR; ++r)
-                    brow[r][s2] = *reinterpret_cast<const bf16x8*>(pbuf + boff[kw][s2] + r * HPW * 128);
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) af[s2][i] = *reinterpret_cast<const bf16x8*>(wbuf + aoff[s2] + i * 16 * 128);
+        for (int i = 0; i < 4; ++i) af[h][i] = *reinterpret_cast<const bf16x8*>(wbuf + aoff[h] + i * 16 * 128);
     };
-    auto mfmas = [&](int kh) {
+    // B fragments: the halo rows (k half h) that tap (kh, kw) uses and tap (kh - 1, kw) did not; a row's slot is
+    // (row % TPX): the row it replaces was last used one vertical tap earlier (or by the previous filter column)
+    auto load_b = [&](const unsigned char* pbuf, int kh, int kw, int h) {
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
+        for (int r = 0; r < NR; ++r) {
+            bool used = false, prev = false;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < TPX; ++j) {
+                used = used || rowidx(j, kh) == r;
+                prev = prev || (kh > 0 && rowidx(j, kh - 1) == r);
+            }
+            if (used && !prev) brow[r % TPX][h] = *reinterpret_cast<const bf16x8*>(pbuf + boff[kw][h] + r * HPW * 128);
+        }
+    };
+    auto mfma_quarter = [&](int kh, int h, int i) {             // 16-channel tile i of the wave's 64 x TPX rows
 #pragma unroll
-                for (int j = 0; j < TPX; ++j) {
-                    const int rj = UPS ? ((j + kh - 1) >> 1) + 1 : j + kh;   // compile-time after unrolling
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s2][i], brow[rj][s2], acc[i][j], 0, 0, 0);
-                }
+        for (int j = 0; j < TPX; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[h][i], brow[rowidx(j, kh) % TPX][h], acc[i][j], 0, 0, 0);
+    };
+    auto mfma_block = [&](int kh, int h) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mfma_quarter(kh, h, i);
     };
 
     float* const bias_lds = reinterpret_cast<float*>(dsm + 2 * P_BYTES + 3 * W_BYTES);   // [BN]
@@ -860,11 +884,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(ConvArgs a) {
         }
     };
 
-    // ---- prologue: halo patch of slice 0, weight tiles of steps 0 and 1 (step t multiplies filter tap
-    //      (kh, kw) = (t % 3, t / 3), i.e. weight image 3 (t % 3) + t / 3)
+    // ---- prologue: halo patch of slice 0, weight tiles of steps 0-2 (step t multiplies filter tap
+    //      (kh, kw) = (t % 3, t / 3), i.e. weight image 3 (t % 3) + t / 3), then the fragments of block (0, k 0-31)
     if (w_role) {
         dma_w(0, 0, 0);
         dma_w(0, 3, 1);
+        dma_w(0, 6, 2);
     } else {
         unsigned soff, border;
         patch_scalar(pt_begin, 0, soff, border);
@@ -873,13 +898,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(ConvArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (group == 1) RGBD_PP_BARRIER();                           // the stagger: waves 4-7 run one barrier behind
+    load_a(w_lds, 0);
+    load_b(patch_lds, 0, 0, 0);
 
     int c = 0, pt = pt_begin;
-    bool epi_pending = false;
-    int epi_pt = pt_begin;
+    bool w_waited = false;             // weight waves: tile 1 of this slice was already waited for (in front of an epilogue)
     for (int g = 0; g < g_total; ++g) {
         const unsigned char* pbuf = patch_lds + (g & 1) * P_BYTES;
+        const unsigned char* pnext = patch_lds + ((g + 1) & 1) * P_BYTES;
         const int c_next = c + 1 == nc ? 0 : c + 1;
         const bool last = g + 1 >= g_total;
         const int pt_next = (c_next == 0 && !last) ? pt + 1 : pt;
@@ -887,58 +913,66 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp_kernel(ConvArgs a) {
         patch_scalar(pt_next, c_next, nsoff, nborder);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            // ---- LOAD segment of step t
-            unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, st6 = 0;
-            if (KO == 5) st0 = __builtin_amdgcn_s_memtime();
-            // the tile epilogue (global stores) goes first: whatever this segment's counted wait leaves in flight is
-            // then only this segment's DMAs
-            if (t == 0 && epi_pending) {
-                epilogue(epi_pt);
-                epi_pending = false;
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int kh = t % 3, kw = t / 3;
+            const int tn = (t + 1) % 9, khn = tn % 3, kwn = tn / 3;
+            // ---- block (t, k 0-31); meanwhile the k 32-63 fragments of this step arrive
+            if (KO != 3 && KO != 6) {
+                load_a(w_lds + (t % 3) * W_BYTES, 1);
+                load_b(pbuf, kh, kw, 1);
             }
+            if (KO != 4) mfma_block(kh, 0);
+            RGBD_SP_INTERLEAVE();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- B_t.  Weight waves: all but the youngest tile (t + 2) have landed, i.e. tile t + 1; halo waves: the
+            //      whole next patch, once, a step before its first read
             if (w_role) {
-                if (KO != 1 && KO != 6) dma_w(t + 2 >= 9 ? c_next : c, 3 * (((t + 2) % 9) % 3) + ((t + 2) % 9) / 3, (t + 2) % 3);
-            } else if (t < PSTEPS && KO != 2 && KO != 6) {
-#pragma unroll
-                for (int i = t * PPS; i < (t + 1) * PPS && i < PPW4; ++i) dma_patch(i, (g + 1) & 1, nsoff, nborder);
+                if (!(t == 0 && w_waited)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KO == 1 || KO == 6 ? 0 : WPW4) : "memory");
+            } else if (t == 7) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            if (KO == 5) st1 = __builtin_amdgcn_s_memtime();
-            if ((KO != 3 && KO != 6) || g == 0) load_frags(pbuf, w_lds + (t % 3) * W_BYTES, t % 3, t / 3);
-            if (KO == 5) st2 = __builtin_amdgcn_s_memtime();
-            // weight waves: all but this segment's pieces (tile t + 2) have landed, i.e. tile t + 1; halo waves: the whole
-            // next patch, once, two steps before its first read
-            if (w_role) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KO == 1 || KO == 6 ? 0 : WPW4) : "memory");
-            else if (t == 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (KO == 5) st3 = __builtin_amdgcn_s_memtime();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (KO == 5) st4 = __builtin_amdgcn_s_memtime();
             RGBD_PP_BARRIER();
-            // ---- MFMA segment of step t
-            if (KO == 5) st5 = __builtin_amdgcn_s_memtime();
-            __builtin_amdgcn_s_setprio(1);
-            if (KO != 4 || g == 0) mfmas(t % 3);
-            __builtin_amdgcn_s_setprio(0);
-            if (KO == 5) {
+            // ---- block (t, k 32-63): the k 0-31 fragments of step t + 1 arrive, and the DMAs go out one per quarter of
+            //      the block (an LDS-DMA holds its wave for ~60 cycles: spread out, the SIMD partner's MFMAs cover it):
+            //      weight tile t + 3 into tile t's buffer / the next halo pieces
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (KO != 3 && KO != 6) {
+                    if (i == 0) load_a(w_lds + (tn % 3) * W_BYTES, 0);
+                    if (i == 1) load_b(t == 8 ? pnext : pbuf, khn, kwn, 0);
+                }
+                if (KO != 4) mfma_quarter(kh, 1, i);
+#pragma unroll
+                for (int k_ = 0; k_ < 4; ++k_) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
-                st6 = __builtin_amdgcn_s_memtime();
-            }
-            if (!(t == 8 && last && group == 1)) RGBD_PP_BARRIER();
-            if (KO == 5 && blockIdx.x == 0 && (wid & 3) == 0 && g < 4 && lane == 0) {
-                // stamps: [group][step][8] = LOAD start, DMAs issued, reads issued, vmcnt done, lgkmcnt done, barrier passed
-                // (MFMA start), MFMAs issued, next barrier passed
-                unsigned long long* o = reinterpret_cast<unsigned long long*>(a.partial) + ((group * 36 + g * 9 + t) * 8);
-                o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = st4; o[5] = st5; o[6] = st6;
-                o[7] = __builtin_amdgcn_s_memtime();
+                if (w_role) {
+                    if (i < WPW4 && KO != 1 && KO != 6)
+                        dma_w_piece(t + 3 >= 9 ? c_next : c, 3 * (((t + 3) % 9) % 3) + ((t + 3) % 9) / 3, t % 3, i);
+                } else if (t < PSTEPS && i < PPS && t * PPS + i < PPW4 && KO != 2 && KO != 6) {
+                    dma_patch(t * PPS + i, (g + 1) & 1, nsoff, nborder);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (c_next == 0) {
-            epi_pending = true;
-            epi_pt = pt;
+        w_waited = false;
+        if (c_next == 0) {             // last slice of this pixel tile: write it out.  The weight waves first retire tile 1
+                                       // of the next slice: behind the epilogue's stores a counted wait would also wait
+                                       // for those
+            if (w_role) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KO == 1 || KO == 6 ? 0 : WPW4) : "memory");
+                w_waited = true;
+            }
+            epilogue(pt);
         }
         c = c_next;
         pt = pt_next;
     }
-    epilogue(epi_pt);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // no DMA may land in LDS after the workgroup has gone
 }
 
 // ------------------------------------------------------------------------------------------------ wgrad
@@ -1275,16 +1309,6 @@ extern "C" int rgbd_debug_conv_variant(int v) {
     return 0;
 }
 namespace {
-void* g_stamp_buf = nullptr;
-constexpr size_t STAMP_BYTES = 2 * 36 * 8 * sizeof(unsigned long long);
-}
-extern "C" int rgbd_debug_conv_stamps(unsigned long long* host_out) {   // variant 15: [2 groups][36 steps][8 stamps]
-    RGBD_REQUIRE(g_stamp_buf && host_out, "rgbd_debug_conv_stamps: run a conv with variant 15 first");
-    RGBD_REQUIRE(hipMemcpy(host_out, g_stamp_buf, STAMP_BYTES, hipMemcpyDeviceToHost) == hipSuccess, "stamps: copy failed");
-    return 0;
-}
-
-namespace {
 // Split-K plan of the gather kernel: 1 (no split) when the unsplit launch already fills the chip.
 struct FpropPlan {
     bool patch;      // 3x3 pad-1 halo-patch kernel
@@ -1400,45 +1424,32 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
         if (wide && g_conv_variant != 1) {
             const int pieces = a.ups ? 13 : 41;
             const int lds_pp = 2 * pieces * 1024 + 3 * 128 * 128 + 128 * 4;
-            const void* fpp = a.ups ? (const void*)&conv3x3_pp_kernel<128, true> : (const void*)&conv3x3_pp_kernel<128, false>;
+            const void* fpp = a.ups ? (const void*)&conv3x3_sp_kernel<128, true> : (const void*)&conv3x3_sp_kernel<128, false>;
             static bool pp_attr_done[2] = {false, false};
             if (!pp_attr_done[a.ups]) {
                 RGBD_REQUIRE(hipFuncSetAttribute(fpp, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pp) == hipSuccess,
                              "rgbd_conv2d_fprop_bf16: cannot reserve %d B of LDS", lds_pp);
                 pp_attr_done[a.ups] = true;
             }
-            if (g_conv_variant == 15 && !a.ups) {                               // in-kernel stamps (scripts/conv_stamps.py)
-                if (!g_stamp_buf) RGBD_REQUIRE(hipMalloc(&g_stamp_buf, STAMP_BYTES) == hipSuccess, "stamps: hipMalloc");
-                a.partial = (float*)g_stamp_buf;
-                const void* fk = (const void*)&conv3x3_pp_kernel<128, false, 5>;
+            if (g_conv_variant >= 11 && g_conv_variant <= 16 && !a.ups) {      // timing knock-outs (scripts/ab_conv.py)
+                const int ko = g_conv_variant - 10;
+                const void* fk = ko == 1 ? (const void*)&conv3x3_sp_kernel<128, false, 1>
+                               : ko == 2 ? (const void*)&conv3x3_sp_kernel<128, false, 2>
+                               : ko == 3 ? (const void*)&conv3x3_sp_kernel<128, false, 3>
+                               : ko == 4 ? (const void*)&conv3x3_sp_kernel<128, false, 4>
+                                         : (const void*)&conv3x3_sp_kernel<128, false, 6>;
                 RGBD_REQUIRE(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pp) == hipSuccess, "lds");
-                conv3x3_pp_kernel<128, false, 5><<<(unsigned)grid, 512, lds_pp, st>>>(a);
-                RGBD_CHECK_LAUNCH("conv3x3_pp_kernel<stamps>");
+                if (ko == 1) conv3x3_sp_kernel<128, false, 1><<<(unsigned)grid, 512, lds_pp, st>>>(a);
+                else if (ko == 2) conv3x3_sp_kernel<128, false, 2><<<(unsigned)grid, 512, lds_pp, st>>>(a);
+                else if (ko == 3) conv3x3_sp_kernel<128, false, 3><<<(unsigned)grid, 512, lds_pp, st>>>(a);
+                else if (ko == 4) conv3x3_sp_kernel<128, false, 4><<<(unsigned)grid, 512, lds_pp, st>>>(a);
+                else conv3x3_sp_kernel<128, false, 6><<<(unsigned)grid, 512, lds_pp, st>>>(a);
+                RGBD_CHECK_LAUNCH("conv3x3_sp_kernel<KO>");
                 return 0;
             }
-            if (g_conv_variant == 16 && !a.ups) {
-                const void* fk = (const void*)&conv3x3_pp_kernel<128, false, 6>;
-                RGBD_REQUIRE(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pp) == hipSuccess, "lds");
-                conv3x3_pp_kernel<128, false, 6><<<(unsigned)grid, 512, lds_pp, st>>>(a);
-                RGBD_CHECK_LAUNCH("conv3x3_pp_kernel<KO6>");
-                return 0;
-            }
-            if (g_conv_variant >= 11 && g_conv_variant <= 14 && !a.ups) {      // timing knock-outs (scripts/ab_conv.py)
-                const void* fk = g_conv_variant == 11 ? (const void*)&conv3x3_pp_kernel<128, false, 1>
-                               : g_conv_variant == 12 ? (const void*)&conv3x3_pp_kernel<128, false, 2>
-                               : g_conv_variant == 13 ? (const void*)&conv3x3_pp_kernel<128, false, 3>
-                                                      : (const void*)&conv3x3_pp_kernel<128, false, 4>;
-                RGBD_REQUIRE(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pp) == hipSuccess, "lds");
-                if (g_conv_variant == 11) conv3x3_pp_kernel<128, false, 1><<<(unsigned)grid, 512, lds_pp, st>>>(a);
-                if (g_conv_variant == 12) conv3x3_pp_kernel<128, false, 2><<<(unsigned)grid, 512, lds_pp, st>>>(a);
-                if (g_conv_variant == 13) conv3x3_pp_kernel<128, false, 3><<<(unsigned)grid, 512, lds_pp, st>>>(a);
-                if (g_conv_variant == 14) conv3x3_pp_kernel<128, false, 4><<<(unsigned)grid, 512, lds_pp, st>>>(a);
-                RGBD_CHECK_LAUNCH("conv3x3_pp_kernel<KO>");
-                return 0;
-            }
-            if (a.ups) conv3x3_pp_kernel<128, true><<<(unsigned)grid, 512, lds_pp, st>>>(a);
-            else       conv3x3_pp_kernel<128, false><<<(unsigned)grid, 512, lds_pp, st>>>(a);
-            RGBD_CHECK_LAUNCH("conv3x3_pp_kernel");
+            if (a.ups) conv3x3_sp_kernel<128, true><<<(unsigned)grid, 512, lds_pp, st>>>(a);
+            else       conv3x3_sp_kernel<128, false><<<(unsigned)grid, 512, lds_pp, st>>>(a);
+            RGBD_CHECK_LAUNCH("conv3x3_sp_kernel");
             return 0;
         }
         const int lds = 2 * 324 * 128 + 3 * (wide ? 128 : 64) * 128 + (wide ? 128 : 64) * 4;
