@@ -28,6 +28,7 @@ PROTOTYPES = {
     "rgbd_conv2d_fprop_bf16": ([_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                 c_int, c_int, c_float, _P, _P], c_int),
     "rgbd_debug_force_gather_kernel": ([c_int], c_int),
+    "rgbd_last_conv_kernel": ([], c_char_p),
     "rgbd_debug_conv_variant": ([c_int], c_int),
     "rgbd_conv2d_wgrad_workspace": ([c_int, c_int, c_int, c_int, c_int, c_int], c_int64),
     "rgbd_conv2d_wgrad_bf16": ([_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P], c_int),
@@ -107,6 +108,8 @@ def load():
     got = lib.rgbd_abi_version()
     if got != ABI_VERSION:
         raise RuntimeError(f"librgbdgan_hip.so ABI {got} != expected {ABI_VERSION}; rebuild")
+    if os.environ.get("RGBD_CONV_VARIANT"):            # tuning aid (scripts/ab_conv.py): see rgbd_debug_conv_variant
+        lib.rgbd_debug_conv_variant(int(os.environ["RGBD_CONV_VARIANT"]))
     _lib = lib
     return lib
 

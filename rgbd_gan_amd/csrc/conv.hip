@@ -576,7 +576,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(ConvArgs a) {
 //     zeros written to LDS (scripts/hw/lds_dma_probe.hip).  The DMAs are inline asm, i.e. invisible to hipcc's waitcnt
 //     bookkeeping: each wave retires its own pieces with a COUNTED s_waitcnt vmcnt(N) and the step's barrier publishes
 //     them.  Weight tile t+3 is requested when tile t's buffer falls free (three buffers: two steps to land); the next
-//     slice's halo patch streams in over steps 0-5 of the current one.
+//     slice's halo patch streams in over steps 0-3 of the current one.
 //   * operand fragments are software-pipelined through registers at HALF-step granularity: a K step (one tap x 64
 //     channels) is two blocks of 16 (BN=128) MFMAs over k 0-31 and k 32-63; while a block runs, the ds_reads of the NEXT
 //     block's fragments are in flight into the registers the PREVIOUS block has finished with (A: 4 fragments per
@@ -595,8 +595,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(ConvArgs a) {
 //          retired by the issuing wave's vmcnt(pieces of W(t+2)) before that wave arrives at B_t.
 //     WAR  W(t+3) goes into W(t)'s buffer after B_t; W(t)'s last reads (k 32-63 fragments, issued at the start of step t)
 //          are retired by the lgkmcnt(0) in front of B_t.
-//     The halo patch of slice g+1 is issued after B_0..B_5 of slice g into the other patch buffer (last read before
-//     B_8 of slice g-1), retired by the halo waves' vmcnt(0) in front of B_7, first read after B_8.
+//     The halo patch of slice g+1 is issued after B_0..B_3 of slice g into the other patch buffer (last read before
+//     B_8 of slice g-1), retired by the halo waves' vmcnt(0) in front of B_8, first read right after B_8.
 __device__ __forceinline__ void lds_dma16(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :: "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
@@ -662,8 +662,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
     const int ridx = (wid & 1) + 2 * (wid >> 2);                 // 0..3 within the role
     constexpr int WPW4 = BN / 32;                                // weight pieces per weight wave per K step (BN / 8 / 4)
     constexpr int PPW4 = (P_PIECES + 3) / 4;                     // halo pieces per halo wave per slice (11 or 4)
-    constexpr int PPS = (PPW4 + 5) / 6;                          // ... issued per step (2 or 1), in steps 0 .. PSTEPS-1
-    constexpr int PSTEPS = (PPW4 + PPS - 1) / PPS;               // 6 or 4
+    constexpr int PPS = (PPW4 + 3) / 4;                          // ... issued per step (3 or 1), in steps 0 .. PSTEPS-1
+    constexpr int PSTEPS = (PPW4 + PPS - 1) / PPS;               // 4
     constexpr int NOFF = PPW4 > WPW4 ? PPW4 : WPW4;
     static_assert(PPW4 <= 12, "halo border masks are packed 5 bits x 6 pieces x 2 registers");
     // Per-lane source offsets, constant for the whole kernel.
@@ -926,10 +926,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
             RGBD_SP_INTERLEAVE();
             __builtin_amdgcn_sched_barrier(0);
             // ---- B_t.  Weight waves: all but the youngest tile (t + 2) have landed, i.e. tile t + 1; halo waves: the
-            //      whole next patch, once, a step before its first read
+            //      whole next patch (issued in steps 0-3: HBM latency under load is a few steps), in front of B_8
             if (w_role) {
                 if (!(t == 0 && w_waited)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KO == 1 || KO == 6 ? 0 : WPW4) : "memory");
-            } else if (t == 7) {
+            } else if (t == 8) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1304,6 +1304,10 @@ extern "C" int rgbd_debug_force_gather_kernel(int on) {
     g_force_gather = on != 0;
     return 0;
 }
+namespace {
+const char* g_last_conv_kernel = "";
+}
+extern "C" const char* rgbd_last_conv_kernel(void) { return g_last_conv_kernel; }
 extern "C" int rgbd_debug_conv_variant(int v) {
     g_conv_variant = v;
     return 0;
@@ -1401,10 +1405,11 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
     a.ksplit = plan.ksplit;
     a.partial = plan.ksplit > 1 ? (float*)workspace : nullptr;
     if (plan.patch) {
-        const bool wide = Cout % 128 == 0;
-        const int n_tiles = wide ? Cout / 128 : Cout / 64;
         const long ptiles = (long)B * (a.Hout / 16) * (a.Wout / 16);
         RGBD_REQUIRE(ptiles < 0x7fffffffL, "rgbd_conv2d_fprop_bf16: too many tiles");
+        // 128 output channels per workgroup unless that leaves more than half of the chip without one (16x16 images)
+        const bool wide = Cout % 128 == 0 && (g_conv_variant == 1 || ptiles * (Cout / 128) >= 128) && g_conv_variant != 2;
+        const int n_tiles = wide ? Cout / 128 : Cout / 64;
         // persistent workgroups: one per CU (the kernel's LDS footprint allows exactly one), split evenly over the
         // output-channel tiles; each walks a contiguous range of pixel tiles
         static int num_cus = 0;
@@ -1421,35 +1426,40 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
         a.ptiles = (int)ptiles;
         a.wgs_per_ntile = per_nt;
         const long grid = (long)per_nt * n_tiles;
-        if (wide && g_conv_variant != 1) {
-            const int pieces = a.ups ? 13 : 41;
-            const int lds_pp = 2 * pieces * 1024 + 3 * 128 * 128 + 128 * 4;
-            const void* fpp = a.ups ? (const void*)&conv3x3_sp_kernel<128, true> : (const void*)&conv3x3_sp_kernel<128, false>;
-            static bool pp_attr_done[2] = {false, false};
-            if (!pp_attr_done[a.ups]) {
-                RGBD_REQUIRE(hipFuncSetAttribute(fpp, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pp) == hipSuccess,
-                             "rgbd_conv2d_fprop_bf16: cannot reserve %d B of LDS", lds_pp);
-                pp_attr_done[a.ups] = true;
+        if (g_conv_variant != 1) {
+            const int pieces = a.ups ? 13 : 41, bn = wide ? 128 : 64;
+            const int lds_sp = 2 * pieces * 1024 + 3 * bn * 128 + bn * 4;
+            const int vi = (wide ? 2 : 0) + a.ups;
+            const void* fsp = vi == 3 ? (const void*)&conv3x3_sp_kernel<128, true> : vi == 2 ? (const void*)&conv3x3_sp_kernel<128, false>
+                            : vi == 1 ? (const void*)&conv3x3_sp_kernel<64, true> : (const void*)&conv3x3_sp_kernel<64, false>;
+            static bool sp_attr_done[4] = {false, false, false, false};   // once per variant (not a stream operation)
+            if (!sp_attr_done[vi]) {
+                RGBD_REQUIRE(hipFuncSetAttribute(fsp, hipFuncAttributeMaxDynamicSharedMemorySize, lds_sp) == hipSuccess,
+                             "rgbd_conv2d_fprop_bf16: cannot reserve %d B of LDS", lds_sp);
+                sp_attr_done[vi] = true;
             }
-            if (g_conv_variant >= 11 && g_conv_variant <= 16 && !a.ups) {      // timing knock-outs (scripts/ab_conv.py)
+            if (g_conv_variant >= 11 && g_conv_variant <= 16 && vi == 2) {     // timing knock-outs (scripts/ab_conv.py)
                 const int ko = g_conv_variant - 10;
                 const void* fk = ko == 1 ? (const void*)&conv3x3_sp_kernel<128, false, 1>
                                : ko == 2 ? (const void*)&conv3x3_sp_kernel<128, false, 2>
                                : ko == 3 ? (const void*)&conv3x3_sp_kernel<128, false, 3>
                                : ko == 4 ? (const void*)&conv3x3_sp_kernel<128, false, 4>
                                          : (const void*)&conv3x3_sp_kernel<128, false, 6>;
-                RGBD_REQUIRE(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, lds_pp) == hipSuccess, "lds");
-                if (ko == 1) conv3x3_sp_kernel<128, false, 1><<<(unsigned)grid, 512, lds_pp, st>>>(a);
-                else if (ko == 2) conv3x3_sp_kernel<128, false, 2><<<(unsigned)grid, 512, lds_pp, st>>>(a);
-                else if (ko == 3) conv3x3_sp_kernel<128, false, 3><<<(unsigned)grid, 512, lds_pp, st>>>(a);
-                else if (ko == 4) conv3x3_sp_kernel<128, false, 4><<<(unsigned)grid, 512, lds_pp, st>>>(a);
-                else conv3x3_sp_kernel<128, false, 6><<<(unsigned)grid, 512, lds_pp, st>>>(a);
+                RGBD_REQUIRE(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, lds_sp) == hipSuccess, "lds");
+                if (ko == 1) conv3x3_sp_kernel<128, false, 1><<<(unsigned)grid, 512, lds_sp, st>>>(a);
+                else if (ko == 2) conv3x3_sp_kernel<128, false, 2><<<(unsigned)grid, 512, lds_sp, st>>>(a);
+                else if (ko == 3) conv3x3_sp_kernel<128, false, 3><<<(unsigned)grid, 512, lds_sp, st>>>(a);
+                else if (ko == 4) conv3x3_sp_kernel<128, false, 4><<<(unsigned)grid, 512, lds_sp, st>>>(a);
+                else conv3x3_sp_kernel<128, false, 6><<<(unsigned)grid, 512, lds_sp, st>>>(a);
                 RGBD_CHECK_LAUNCH("conv3x3_sp_kernel<KO>");
                 return 0;
             }
-            if (a.ups) conv3x3_sp_kernel<128, true><<<(unsigned)grid, 512, lds_pp, st>>>(a);
-            else       conv3x3_sp_kernel<128, false><<<(unsigned)grid, 512, lds_pp, st>>>(a);
+            if (vi == 3)      conv3x3_sp_kernel<128, true><<<(unsigned)grid, 512, lds_sp, st>>>(a);
+            else if (vi == 2) conv3x3_sp_kernel<128, false><<<(unsigned)grid, 512, lds_sp, st>>>(a);
+            else if (vi == 1) conv3x3_sp_kernel<64, true><<<(unsigned)grid, 512, lds_sp, st>>>(a);
+            else              conv3x3_sp_kernel<64, false><<<(unsigned)grid, 512, lds_sp, st>>>(a);
             RGBD_CHECK_LAUNCH("conv3x3_sp_kernel");
+            g_last_conv_kernel = wide ? "conv3x3_sp_kernel<128>" : "conv3x3_sp_kernel<64>";
             return 0;
         }
         const int lds = 2 * 324 * 128 + 3 * (wide ? 128 : 64) * 128 + (wide ? 128 : 64) * 4;
@@ -1472,6 +1482,7 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
             else       conv3x3_patch_kernel<64, false><<<(unsigned)grid, 512, lds, st>>>(a);
         }
         RGBD_CHECK_LAUNCH("conv3x3_patch_kernel");
+        g_last_conv_kernel = wide ? "conv3x3_patch_kernel<128>" : "conv3x3_patch_kernel<64>";
         return 0;
     }
     if (Cout % 128 == 0) {
@@ -1484,6 +1495,7 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
         conv_fprop_kernel<64><<<(unsigned)grid, 256, 0, st>>>(a);
     }
     RGBD_CHECK_LAUNCH("conv_fprop_kernel");
+    g_last_conv_kernel = Cout % 128 == 0 ? "conv_fprop_kernel<128>" : "conv_fprop_kernel<64>";
     if (a.ksplit > 1) {
         const long quads = a.M * Cout / 4;
         conv_splitk_finish_kernel<<<(unsigned)((quads + 255) / 256 < 2048 ? (quads + 255) / 256 : 2048), 256, 0, st>>>(

@@ -1,5 +1,6 @@
 """Thin, typed wrappers: torch device tensors in, C-ABI calls out.  No arithmetic happens here."""
 import ctypes
+import os
 
 import torch
 
@@ -46,6 +47,7 @@ class launch_profile:
 
 
 def _timed(name, flops, nbytes, fn):
+    """name: a label, or a callable evaluated after the launch (the library reports which kernel its planner chose)."""
     if _PROFILE is None:
         return fn()
     e0 = torch.cuda.Event(enable_timing=True)
@@ -53,8 +55,15 @@ def _timed(name, flops, nbytes, fn):
     e0.record()
     rc = fn()
     e1.record()
-    _PROFILE.append((name, flops, nbytes, e0, e1))
+    _PROFILE.append((name() if callable(name) else name, flops, nbytes, e0, e1))
     return rc
+
+
+def _conv_kernel_name(tag=None):
+    """The kernel the library's planner launched last; with RGBD_PROFILE_SHAPES=1 the layer shape is appended (per-shape
+    tables: scripts/step_conv_shapes.py)."""
+    name = _lib.load().rgbd_last_conv_kernel().decode()
+    return f"{name} {tag}" if tag and os.environ.get("RGBD_PROFILE_SHAPES") else name
 
 
 def _stream():
@@ -188,10 +197,9 @@ def conv2d_fprop(x, wp, KH, KW, pad, bias=None, residual=None, upsample=False, l
     fuse_pool = bool(avg_pool2) and KH == 3 and KW == 3 and pad == 1 and Hout % 16 == 0 and Wout % 16 == 0
     yp = torch.empty(B, Hout // 2, Wout // 2, Cout, dtype=BF16, device=x.device) if fuse_pool else None
     ws = None if fuse_pool else _fprop_workspace(lib, B, H, W, Cin, Cout, KH, KW, pad, int(bool(upsample)), x.device)
-    patch = fuse_pool or (KH == 3 and KW == 3 and pad == 1 and Hout % 16 == 0 and Wout % 16 == 0 and ws is None
-                          and B * (Hout // 16) * (Wout // 16) * (Cout // (128 if Cout % 128 == 0 else 64)) >= 64)
-    kname = ("conv3x3_patch_kernel" if patch else "conv_fprop_kernel") + f"<{128 if Cout % 128 == 0 else 64}>"
-    rc = _timed(kname, flops, nbytes,
+    rc = _timed(lambda: _conv_kernel_name(f"fprop {Hout}x{Wout} {Cin}->{Cout}{' ups' if upsample else ''}"
+                                          f"{' pool' if fuse_pool else ''}{' res' if residual is not None else ''}"),
+                flops, nbytes,
                 lambda: lib.rgbd_conv2d_fprop_bf16(_ptr(x), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(y), _ptr(yp), B, H,
                                                    W, Cin, Cout, KH, KW, pad, int(bool(upsample)), int(lrelu_channels),
                                                    float(slope), _ptr(ws), _stream()))
@@ -220,10 +228,8 @@ def conv2d_dgrad(dy, wd, K, pad, sum_pool2=False, residual=None):
     flops = 2.0 * B * Ho * Wo * Cout * Cin * K * K
     nbytes = 2.0 * (dy.numel() + dx.numel() + wd.numel() + (residual.numel() if residual is not None else 0))
     ws = None if fuse else _fprop_workspace(lib, B, H, W, Cout, Cin, K, K, pd, 0, dy.device)
-    patch = fuse or (K == 3 and pd == 1 and Ho % 16 == 0 and Wo % 16 == 0 and ws is None
-                     and B * (Ho // 16) * (Wo // 16) * (Cin // (128 if Cin % 128 == 0 else 64)) >= 64)
-    kname = ("conv3x3_patch_kernel" if patch else "conv_fprop_kernel") + f"<{128 if Cin % 128 == 0 else 64}>"
-    rc = _timed(kname, flops, nbytes,
+    rc = _timed(lambda: _conv_kernel_name(f"dgrad {Ho}x{Wo} {Cout}->{Cin}{' sumpool' if fuse else ''}"
+                                          f"{' res' if residual is not None else ''}"), flops, nbytes,
                 lambda: lib.rgbd_conv2d_dgrad_bf16(_ptr(dy), _ptr(wd), _ptr(residual), _ptr(dx), B, H, W, Cin, Cout, K, pad,
                                                    int(fuse),
                                                    _ptr(ws), _stream()))

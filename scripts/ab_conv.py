@@ -1,5 +1,5 @@
 """A/B the 3x3 conv kernels on the layer shapes of the 128x128 stage in ONE process (same device, same clocks):
-variant 0 = default (ping-pong, LDS-DMA), variant 1 = register-staged halo-patch kernel.  Prints TFLOP/s per shape and
+variant 0 = default (software-pipelined, LDS-DMA), 2 = the same with 64-channel tiles, variant 1 = register-staged halo-patch kernel.  Prints TFLOP/s per shape and
 checks that both variants give identical bytes.
 
     python scripts/ab_conv.py            # B=32
@@ -13,8 +13,8 @@ B = int(os.environ.get("B", "32"))
 REPS = int(os.environ.get("REPS", "30"))
 dev = "cuda:0"
 lib = _lib.load()
-shapes = [(64, 128, 128, 0), (64, 128, 256, 0), (64, 256, 256, 0), (32, 256, 256, 0), (16, 256, 256, 0),
-          (32, 256, 256, 1), (64, 256, 128, 1)]          # (Hout, Cin, Cout, upsample)
+shapes = [(128, 64, 64, 0), (128, 128, 64, 1), (128, 64, 128, 0), (64, 128, 128, 0), (64, 128, 256, 0), (64, 256, 256, 0),
+          (32, 256, 256, 0), (16, 256, 256, 0), (32, 256, 256, 1), (64, 256, 128, 1)]          # (Hout, Cin, Cout, upsample)
 variants = [int(v) for v in os.environ.get("VARIANTS", "1,0").split(",")]
 for H, Cin, Cout, ups in shapes:
     Hin = H // 2 if ups else H
