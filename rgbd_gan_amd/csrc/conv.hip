@@ -1195,9 +1195,233 @@ __device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, const int sp
     }
 }
 
+// ---- 3x3 weight gradient on 8x16-pixel patches (images >= 8x16), the hot variant: every wave runs ALL nine taps.
+// The same 64x64 (co, ci) tile per workgroup, the same LDS images and transposed reads as conv_wgrad_body, but
+//   * waves 0-3 / 4-7 split the patch ROWS (rows 0-3 / 4-7) instead of the taps, each wave accumulating nine 32x32 tap
+//     tiles (144 accumulator registers).  The X fragment of halo row r at horizontal tap kw serves vertical taps 0, 1, 2
+//     of output rows r, r-1, r-2: kept in a three-row register window, one new halo row (3 fragments) per K step instead
+//     of one fragment per tap -- 44 transposed reads per 36 MFMAs where the tap-split body needs 96 per 40, which had the
+//     LDS pipe ~80% busy.  The two row halves meet once, at the end, through LDS.
+//   * operands arrive by LDS-DMA (see conv3x3_sp_kernel) into three buffers: patch p+2 is requested when the barrier of
+//     patch p has certified that buffer (p+2) % 3 is free, and retired two patches later by a counted vmcnt; no
+//     staging registers, no ds_write pass, halo borders by out-of-range offsets chosen from per-lane border bits.
+__device__ __forceinline__ void conv_wgrad9_body(const WgradArgs& a, const int split_idx, const int ci_tile, const int co_tile) {
+    constexpr int HPW = 18, XROWS = 10 * HPW;
+    constexpr int XPIECES = (XROWS * 128 + 1023) / 1024;     // 23
+    constexpr int YPIECES = 16;
+    constexpr int X_BYTES = XPIECES * 1024, BUF = (XPIECES + YPIECES) * 1024;
+    constexpr int XPW = (XPIECES + 7) / 8, YPW = YPIECES / 8;   // pieces per wave per patch: 3 + 2
+    extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];   // [3][BUF]; at the end [2 halves] exchange
+    const unsigned lds0 = (unsigned)(size_t)wsm;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ci0 = ci_tile * 64, co0 = co_tile * 64;
+    const int wc = (wid >> 1) & 1, wi = wid & 1, rh = wid >> 2;   // (co half, ci half) of the tile, row half of the patch
+
+    // transposed-read lane roles (cdna_hip_programming.md T10): see conv_wgrad_body
+    const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+    const int m_base = 16 * (g & 1), k_base = 8 * (g >> 1);
+    const int a_col_bytes = (wc * 32 + m_base + 4 * pp) * 2;
+    const int b_col_bytes = (wi * 32 + m_base + 4 * pp) * 2;
+    int fa[2], fb[3][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int px = k_base + qq + 4 * h;                                   // 0..15 within the patch row
+        fa[h] = (rh * 4 * 16 + px) * 128 + (a_col_bytes ^ (((px >> 1) & 1) << 6));
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int hx = px + kw;                                           // halo column of tap kw
+            fb[kw][h] = (rh * 4 * HPW + hx) * 128 + (b_col_bytes ^ (((hx >> 1) & 1) << 6));
+        }
+    }
+
+    // ---- DMA plan (per-lane source offsets, constant over the kernel).  X piece i of wave w = halo rows 8 pi .. + 7
+    //      (pi = w + 8 i, clamped: duplicates carry identical bytes), dY piece j = pixel rows 8 (w + 8 j) .. + 7; lane l
+    //      fills chunk position (l & 7) of row (l >> 3) with the source chunk the image's swizzle puts there.  Offsets
+    //      are relative to the patch's top-left HALO pixel, against a descriptor based one halo row + one pixel before
+    //      the tensor (never dereferenced: those lanes are masked by the border bits).
+    const int Ws = a.ups ? a.W >> 1 : a.W, Hs = a.ups ? a.H >> 1 : a.H;
+    unsigned xoff[XPW], yoff[YPW], xmask = 0u;
+#pragma unroll
+    for (int i = 0; i < XPW; ++i) {
+        const int pi = wid + 8 * i < XPIECES ? wid + 8 * i : XPIECES - 1;
+        const int row = pi * 8 + (lane >> 3);
+        const int hy = row / HPW, hx = row - hy * HPW;
+        const int chunk = (lane & 7) ^ (((hx >> 1) & 1) << 2);
+        const int sy = a.ups ? ((hy - 1) >> 1) + 1 : hy, sx = a.ups ? ((hx - 1) >> 1) + 1 : hx;
+        xoff[i] = (unsigned)((sy * Ws + sx) * a.Cin * 2 + chunk * 16);
+        const unsigned m = (hy == 0 ? 1u : 0u) | (hy == 9 ? 2u : 0u) | (hx == 0 ? 4u : 0u) | (hx == HPW - 1 ? 8u : 0u) |
+                           (row >= XROWS ? 16u : 0u);
+        xmask |= m << (5 * i);
+    }
+#pragma unroll
+    for (int j = 0; j < YPW; ++j) {
+        const int row = (wid + 8 * j) * 8 + (lane >> 3);
+        const int py = row >> 4, px = row & 15;
+        yoff[j] = (unsigned)((py * a.W + px) * a.Cout * 2 + (((lane & 7) ^ (((px >> 1) & 1) << 2)) << 4));
+    }
+    const unsigned x_lead = (unsigned)((Ws + 1) * a.Cin * 2);
+    const unsigned long xp = (unsigned long)a.x - x_lead, yp = (unsigned long)a.dy;
+    const u32x4 xrsrc = {(unsigned)xp, (unsigned)(xp >> 32) & 0xffffu, (unsigned)a.x_bytes + x_lead, 0x00020000u};
+    const u32x4 yrsrc = {(unsigned)yp, (unsigned)(yp >> 32) & 0xffffu, (unsigned)a.y_bytes, 0x00020000u};
+    const int per_img = a.npx * a.npy;
+    // scalar part of a patch's sources (computed once per patch, used by five DMAs spread over the next patch's rows)
+    struct PatchSrc { unsigned xs_off, ys_off, border, base; };
+    auto patch_src = [&](int patch, int buf) {
+        const int b = patch / per_img;
+        const int rem = patch - b * per_img;
+        const int pyi = rem / a.npx;
+        const int y0 = pyi * 8, x0 = (rem - pyi * a.npx) * 16;
+        const int sy0 = a.ups ? y0 >> 1 : y0, sx0 = a.ups ? x0 >> 1 : x0;
+        PatchSrc ps;
+        ps.xs_off = (unsigned)((((b * Hs + sy0) * Ws + sx0) * a.Cin + ci0) * 2);
+        ps.ys_off = (unsigned)((((b * a.H + y0) * a.W + x0) * a.Cout + co0) * 2);
+        ps.border = (y0 == 0 ? 1u : 0u) | (y0 + 8 == a.H ? 2u : 0u) | (x0 == 0 ? 4u : 0u) | (x0 + 16 == a.W ? 8u : 0u) | 16u;
+        ps.base = lds0 + (unsigned)(buf * BUF);
+        return ps;
+    };
+    auto issue_piece = [&](const PatchSrc& ps, int idx) {     // idx 0 .. XPW-1: X pieces, XPW .. XPW+YPW-1: dY pieces
+        if (idx < XPW) {
+            const int pi = wid + 8 * idx < XPIECES ? wid + 8 * idx : XPIECES - 1;
+            const bool ok = (xmask & (ps.border << (5 * idx))) == 0u;
+            lds_dma16(xrsrc, ok ? xoff[idx] : 0x80000000u, ps.xs_off, ps.base + (unsigned)(pi * 1024));
+        } else {
+            const int j = idx - XPW;
+            lds_dma16(yrsrc, yoff[j], ps.ys_off, ps.base + (unsigned)(X_BYTES + (wid + 8 * j) * 1024));
+        }
+    };
+    constexpr int NPIECE = XPW + YPW;                          // 5 per wave per patch
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int p_begin = split_idx * a.patches_per_wg;
+    const int p_end = min(a.total_patches, p_begin + a.patches_per_wg);
+    const int np = p_end - p_begin;
+    auto frag = [&](const unsigned char* p0, const unsigned char* p1) {
+        const s16x4 v0 = lds_tr16(p0), v1 = lds_tr16(p1);
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto clampp = [&](int k) { return p_begin + (k < np ? k : np - 1); };     // patches past the end: duplicates of the last
+    // Schedule.  The barrier of patch k sits between its rows 2 and 3 (B_k): every LDS read of patch k has been issued
+    // by then (the window runs one row ahead), so B_k frees buffer k % 3 for patch k + 3 and publishes patch k + 1, whose
+    // first fragments are read under the MFMAs of row 3.  The five DMAs of patch k + 3 go out one per row: two in row 3
+    // of patch k, three in rows 0-2 of patch k + 1; at B_k a wave's five youngest pieces are therefore those of patch
+    // k + 2 and vmcnt(5) retires patch k + 1.
+    bf16x8 af[2], brow[3][3];                              // dY fragment of row j (two sets), X window [halo row % 3][kw]
+    PatchSrc pend = patch_src(p_begin, 0);
+    if (np > 0) {
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) issue_piece(pend, i);
+        pend = patch_src(clampp(1), 1);
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) issue_piece(pend, i);
+        pend = patch_src(clampp(2), 2);
+        issue_piece(pend, 0);
+        issue_piece(pend, 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE + 2) : "memory");
+    }
+    __syncthreads();
+    if (np > 0) {
+        af[0] = frag(wsm + X_BYTES + fa[0], wsm + X_BYTES + fa[1]);
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) brow[l][kw] = frag(wsm + fb[kw][0] + l * HPW * 128, wsm + fb[kw][1] + l * HPW * 128);
+    }
+    int bcur = 0, bnext = 1;                               // buffer of patch k / k + 1 (rotating: no k % 3 in the loop)
+#pragma unroll 1
+    for (int k = 0; k < np; ++k) {
+        const unsigned char* xs = wsm + bcur * BUF;
+        const unsigned char* ys = xs + X_BYTES;
+        const unsigned char* xn = wsm + bnext * BUF;
+        const unsigned char* yn = xn + X_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                      // this wave's patch rows 4 rh + j; halo rows j .. j + 2 of its half
+            if (j == 3) {
+                // ---- B_k
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                RGBD_PP_BARRIER();
+                pend = patch_src(clampp(k + 3), bcur);
+            }
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+                    acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[j & 1], brow[(j + kh) % 3][kw],
+                                                                               acc[kh * 3 + kw], 0, 0, 0);
+                if (j < 3) {
+                    if (kh == 0) {                         // halo row j + 3 replaces row j; dY row j + 1; one DMA
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw)
+                            brow[j % 3][kw] = frag(xs + fb[kw][0] + (j + 3) * HPW * 128, xs + fb[kw][1] + (j + 3) * HPW * 128);
+                        af[(j + 1) & 1] = frag(ys + fa[0] + (j + 1) * 16 * 128, ys + fa[1] + (j + 1) * 16 * 128);
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue_piece(pend, 2 + j);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {                                   // row 3: the next patch's first fragments, two DMAs
+                    if (kh == 0) af[0] = frag(yn + fa[0], yn + fa[1]);
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw)
+                        brow[kh][kw] = frag(xn + fb[kw][0] + kh * HPW * 128, xn + fb[kw][1] + kh * HPW * 128);
+                    if (kh < 2) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue_piece(pend, kh);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
+        const int bfree = bcur;
+        bcur = bnext;
+        bnext = 3 - bfree - bnext;
+    }
+    // ---- the two row halves meet through LDS: the upper half hands over taps 0-4 and takes 5-8, then every wave stores
+    //      its taps into the workgroup's slab (plain stores; wgrad_reduce sums the slabs)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // duplicates of the last patch: nothing may land after this point
+    __syncthreads();
+    float* const ex = reinterpret_cast<float*>(wsm);
+    const int sub = wc * 2 + wi;
+    constexpr int GIVE0 = 5;                                // taps [0, 5) end up in the lower-half waves
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const bool give = rh == 1 ? t < GIVE0 : t >= GIVE0;
+        if (give) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ex[((t * 16 + r) * 4 + sub) * 64 + lane] = acc[t][r];
+        }
+    }
+    __syncthreads();
+    const int col = lane & 31, rhalf = lane >> 5;
+    float* slab = a.dwp + (long)split_idx * 9 * a.Cout * a.Cin;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const bool keep = rh == 0 ? t < GIVE0 : t >= GIVE0;
+        if (keep) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * rhalf;
+                slab[((long)t * a.Cout + co0 + wc * 32 + row) * a.Cin + ci0 + wi * 32 + col] =
+                    acc[t][r] + ex[((t * 16 + r) * 4 + sub) * 64 + lane];
+            }
+        }
+    }
+}
+constexpr int WGRAD9_LDS = 9 * 16 * 4 * 64 * 4;            // the final exchange (147456 B) exceeds the three buffers
+
+__global__ __launch_bounds__(512, 2) void conv_wgrad_tapsplit_kernel(WgradArgs a) {    // A/B reference (variant 3)
+    conv_wgrad_body<9, true>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+}
 template <int NT, bool FAST>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradArgs a) {
-    conv_wgrad_body<NT, FAST>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+    if constexpr (NT == 9 && FAST) conv_wgrad9_body(a, blockIdx.x, blockIdx.y, blockIdx.z);
+    else conv_wgrad_body<NT, FAST>(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Several weight gradients in ONE launch.  Every workgroup costs one (taps x 64 x 64) fp32 slab of reduction traffic
@@ -1219,7 +1443,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_multi_kernel(WgradMultiLaun
     const int local = (int)blockIdx.x - m.wg_begin[i];
     const int tiles_ci = a.Cin >> 6, tiles = tiles_ci * (a.Cout >> 6);
     const int split = local / tiles, tile = local - split * tiles;
-    conv_wgrad_body<NT, FAST>(a, split, tile % tiles_ci, tile / tiles_ci);
+    if constexpr (NT == 9 && FAST) conv_wgrad9_body(a, split, tile % tiles_ci, tile / tiles_ci);
+    else conv_wgrad_body<NT, FAST>(a, split, tile % tiles_ci, tile / tiles_ci);
 }
 
 // Slab reduction + layout change in one launch.  A block owns 32 float4 of the packed (tap, co, ci) tile; its 256
@@ -1582,7 +1807,7 @@ static int wgrad_partial_impl(const void* x, const void* dy, void* workspace, in
         static bool attr_done[4] = {false, false, false, false};
         const bool fast = p.PW == 16 && p.PH == 8;
         const int v = (K == 3 ? 0 : 2) + (fast ? 1 : 0);
-        const int lds = K == 3 ? 2 * (180 * 128 + 128 * 128) : 2 * (128 * 128 + 128 * 128);
+        const int lds = K == 3 ? (fast ? WGRAD9_LDS : 2 * (180 * 128 + 128 * 128)) : 2 * (128 * 128 + 128 * 128);
         const void* fn = K == 3 ? (fast ? (const void*)&conv_wgrad_kernel<9, true> : (const void*)&conv_wgrad_kernel<9, false>)
                                 : (fast ? (const void*)&conv_wgrad_kernel<1, true> : (const void*)&conv_wgrad_kernel<1, false>);
         if (!attr_done[v]) {
@@ -1590,7 +1815,12 @@ static int wgrad_partial_impl(const void* x, const void* dy, void* workspace, in
                          "rgbd_conv2d_wgrad_bf16: cannot reserve %d B of LDS", lds);
             attr_done[v] = true;
         }
-        if (K == 3) {
+        if (K == 3 && fast && g_conv_variant == 3) {
+            const int lds_old = 2 * (180 * 128 + 128 * 128);
+            RGBD_REQUIRE(hipFuncSetAttribute((const void*)&conv_wgrad_tapsplit_kernel,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_old) == hipSuccess, "lds");
+            conv_wgrad_tapsplit_kernel<<<grid, 512, lds_old, st>>>(a);
+        } else if (K == 3) {
             if (fast) conv_wgrad_kernel<9, true><<<grid, 512, lds, st>>>(a);
             else      conv_wgrad_kernel<9, false><<<grid, 512, lds, st>>>(a);
         } else {
@@ -1723,7 +1953,7 @@ extern "C" int rgbd_conv2d_wgrad_partial_multi_bf16(const rgbd_wgrad_problem* pr
     }
     m.wg_begin[n] = (int)wgs;
     RGBD_REQUIRE(wgs < 0x7fffffffL, "rgbd_conv2d_wgrad_partial_multi_bf16: grid too large");
-    const int lds = 2 * (180 * 128 + 128 * 128);
+    const int lds = WGRAD9_LDS;
     static bool attr_done = false;
     if (!attr_done) {
         RGBD_REQUIRE(hipFuncSetAttribute((const void*)&conv_wgrad_multi_kernel<9, true>,
