@@ -468,6 +468,71 @@ def test_patch_kernel_agrees_with_gather_kernel(B, H, Cin, Cout, ups):
     torch.testing.assert_close(y_patch.float(), y_gather.float(), atol=2e-2, rtol=8e-3)
 
 
+CONV_VARIANT_CASES = [  # (B, Hout, Cin, Cout, upsample, residual, pooled output)
+    (32, 64, 128, 128, False, False, False),     # two pixel tiles per persistent workgroup, two channel slices each
+    (32, 64, 256, 256, False, True, True),       # four tiles per workgroup, residual + fused 2x2 average
+    (8, 128, 64, 64, False, False, False),       # 64-channel tiles, one channel slice per tile
+    (32, 16, 256, 256, False, True, False),      # 16x16 images: narrow tiles so that half the chip gets work
+    (16, 64, 256, 128, True, False, False),      # upsample folded into the halo gather
+    (6, 32, 128, 192, False, False, False),      # ragged: Cout not a multiple of 128, fewer tiles than workgroups
+]
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,ups,res,pool", CONV_VARIANT_CASES)
+def test_pipelined_conv_matches_register_staged_kernel_bit_for_bit(B, H, Cin, Cout, ups, res, pool):
+    """The LDS-DMA software-pipelined 3x3 kernel and the register-staged halo-patch kernel multiply the same fragments in
+    the same order: identical bytes.  Repeated launches of the pipelined kernel must also agree with each other -- its
+    staging is ordered by hand-counted vmcnt waits and barriers, and a misplaced wait shows up as an occasional stale
+    tile, not as a systematic error."""
+    from rgbd_gan_amd import _lib, kernels
+    g = torch.Generator().manual_seed(B + H + Cin)
+    Hin = H // 2 if ups else H
+    x = torch.randn(B, Hin, Hin, Cin, generator=g).to(dev()).to(torch.bfloat16)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g).to(dev())
+    bias = torch.randn(Cout, generator=g).to(dev())
+    r = torch.randn(B, H, H, Cout, generator=g).to(dev()).to(torch.bfloat16) if res else None
+    wf, _ = kernels.pack_weights(w, float(np.sqrt(2.0 / (Cin * 9))), True, False)
+
+    def run():
+        out = kernels.conv2d_fprop(x, wf, 3, 3, 1, bias=bias, residual=r, upsample=ups, lrelu_channels=Cout, avg_pool2=pool)
+        return out if pool else (out,)
+    lib = _lib.load()
+    lib.rgbd_debug_conv_variant(1)
+    try:
+        ref = run()
+        assert lib.rgbd_last_conv_kernel().decode().startswith("conv3x3_patch_kernel")
+    finally:
+        lib.rgbd_debug_conv_variant(0)
+    for rep in range(12):
+        got = run()
+        assert lib.rgbd_last_conv_kernel().decode().startswith("conv3x3_sp_kernel")
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b), f"launch {rep}: {int((a != b).sum())} of {a.numel()} values differ"
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,ups", [(32, 64, 128, 256, False), (4, 128, 64, 64, False), (16, 64, 256, 128, True),
+                                              (2, 16, 192, 64, False), (32, 8, 256, 256, False)])
+def test_wgrad_bodies_agree_and_repeat(B, H, Cin, Cout, ups):
+    """All-taps-per-wave LDS-DMA body vs the tap-split register-staged body (different summation trees: fp32 rounding
+    apart), and the DMA body against itself over repeated launches (bit for bit: its partial sums are ordered)."""
+    from rgbd_gan_amd import _lib, kernels
+    g = torch.Generator().manual_seed(H + Cin + Cout)
+    Hx = H // 2 if ups else H
+    x = torch.randn(B, Hx, Hx, Cin, generator=g).to(dev()).to(torch.bfloat16)
+    dy = torch.randn(B, H, H, Cout, generator=g).to(dev()).to(torch.bfloat16)
+    lib = _lib.load()
+    lib.rgbd_debug_conv_variant(3)
+    try:
+        ref = kernels.conv2d_wgrad(x, dy, 3, 1.0, upsample=ups)
+    finally:
+        lib.rgbd_debug_conv_variant(0)
+    first = kernels.conv2d_wgrad(x, dy, 3, 1.0, upsample=ups)
+    torch.testing.assert_close(first, ref, rtol=2e-5, atol=2e-5 * float(ref.abs().max()))
+    for rep in range(8):
+        again = kernels.conv2d_wgrad(x, dy, 3, 1.0, upsample=ups)
+        assert torch.equal(again, first), f"launch {rep}: {int((again != first).sum())} values differ"
+
+
 def test_elementwise_adjoint_identities_at_benchmark_sizes():
     """B = 32, 128x128 (the benchmark's tensors): pairs of kernels that are each other's adjoint, and the bilinear form
     of the 1x1 plane convs evaluated three ways, agree to the bf16 rounding of their stored outputs:
