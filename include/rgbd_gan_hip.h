@@ -125,6 +125,8 @@ const char* rgbd_last_conv_kernel(void);
 /* Test / tuning hook: 0 = default kernels, 1 = the register-staged 3x3 halo-patch kernel instead of the pipelined LDS-DMA
  * one, 2 = the pipelined kernel with 64-channel output tiles everywhere, 11-16 = timing knock-outs (wrong results). */
 int rgbd_debug_conv_variant(int v);
+/* Diagnostic: a launch that writes back and invalidates every XCD's L2 (buffer_wbl2 / buffer_inv, system scope). */
+int rgbd_debug_l2_sync(void* stream);
 
 /* Weight gradient: dw[co][ci][kh][kw] (+)= scale * sum_{b,h,w} dy[b,h,w,co] * x[b,h+kh-pad,w+kw-pad,ci]  (fp32).
  *   x  : (B,H,W,Cin) bf16, dy : (B,H,W,Cout) bf16 (same H,W: stride 1, pad = (K-1)/2), K in {1,3}.

@@ -30,6 +30,7 @@ PROTOTYPES = {
     "rgbd_debug_force_gather_kernel": ([c_int], c_int),
     "rgbd_last_conv_kernel": ([], c_char_p),
     "rgbd_debug_conv_variant": ([c_int], c_int),
+    "rgbd_debug_l2_sync": ([_P], c_int),
     "rgbd_conv2d_wgrad_workspace": ([c_int, c_int, c_int, c_int, c_int, c_int], c_int64),
     "rgbd_conv2d_wgrad_bf16": ([_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P], c_int),
     "rgbd_conv2d_wgrad_partial_bf16": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P], c_int),

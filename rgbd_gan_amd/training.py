@@ -130,7 +130,7 @@ def build_training(config, device, comm=None, iterator=None, **updater_kwargs):
         models.append(setup_generator(config, device, seed=1000))    # its own random init, like the reference
     if config.generator_architecture == "deepvoxels":             # train_rgbd.py:355-356
         from .updater_deepvoxels import DeepVoxelsUpdater as Updater
-        for k in ("graph_phases", "fixed_stage", "concurrent_phases", "defer_dfake_wgrads", "dfw_on_side"):
+        for k in ("graph_phases", "fixed_stage", "concurrent_phases", "defer_dfake_wgrads", "dfw_on_side", "hybrid"):
             updater_kwargs.pop(k, None)
     elif config.rgb:                                               # train_rgbd.py:357-358
         Updater = RGBUpdater

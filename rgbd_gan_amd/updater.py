@@ -180,7 +180,8 @@ class RGBDUpdater:
         # a blend factor every iteration and run eagerly.
         self.use_graphs = bool(kwargs.pop("use_graphs", True))
         self.graph_warmup = int(kwargs.pop("graph_warmup", 2))
-        self.graph_phases = tuple(kwargs.pop("graph_phases", ("body", "opt", "opt_g", "opt_d")))
+        self.graph_phases = tuple(kwargs.pop("graph_phases", ("body", "opt", "opt_g", "opt_d",
+                                                              "prep", "gen_a", "gen_b", "gen_w")))
         # The generator phase and the discriminator-on-reals phase are independent until the optimizer phase, and on two
         # streams the bubbles of one fill with the other's kernels (9.3 vs 11.3 ms per step at B=32).  OFF by default:
         # on this ROCm 7.2 stack two queues executing replayed graph kernels concurrently intermittently read stale
@@ -192,6 +193,10 @@ class RGBDUpdater:
         self._side_stream = None
         # in that arrangement D's weight gradients for the fakes (leaves of the backward graph) are moved from the
         # longer generator chain to the tail of the side stream
+        # hybrid two-stream arrangement (experimental, RGBD_HYBRID=1 with RGBD_CONCURRENT_PHASES=1): the generator phase is
+        # replayed from graphs on the main stream while the discriminator-on-reals phase is launched EAGERLY on the side
+        # stream -- only one of the two concurrent queues then carries graph launches
+        self.hybrid = int(kwargs.pop("hybrid", int(os.environ.get("RGBD_HYBRID", "0") or 0)))
         self.defer_dfake_wgrads = bool(kwargs.pop("defer_dfake_wgrads", not os.environ.get("RGBD_NO_DEFER")))
         self.dfw_on_side = bool(kwargs.pop("dfw_on_side", not os.environ.get("RGBD_DFW_ON_MAIN")))
         self._graphs, self._eager_calls, self._stagers, self._ones, self._dbg = {}, {}, {}, {}, {}
@@ -271,6 +276,45 @@ class RGBDUpdater:
 
     def _dfw_phase(self, st):
         Fn.run_deferred_wgrads(st["dfw"])
+
+    def _gen_w_phase(self, st):
+        """Hybrid arrangement: both weight-gradient batches of the generator phase (G's own, D's for the fakes), after
+        the side stream has been joined (the batches share the slab workspace with the discriminator phase's)."""
+        Fn.run_deferred_wgrads(st["gwgrads"])
+        Fn.run_deferred_wgrads(st["dfw"])
+
+    def _prep_only_phase(self, st):
+        with _alpha_ctx(st):
+            self._prep_phase(st)
+
+    def _hybrid_body(self, st, key):
+        main, side = torch.cuda.current_stream(), self._side_stream
+        if self.hybrid >= 2:
+            # nothing serialised beyond the data dependencies: G's weight-gradient batch runs inside gen_b, D's batch for
+            # the fakes follows the discriminator phase on the side stream (eagerly, from the list gen_a's capture left)
+            st["_main"], st["_side"], st["split_gw"] = None, None, False
+            self._run_phase("prep", self._prep_only_phase, st, key)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._dis_phase(st)
+            self._run_phase("gen_a", self._gen_a_phase, st, key)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._dfw_phase(st)
+            self._run_phase("gen_b", self._gen_b_phase, st, key)
+            main.wait_stream(side)
+            self._join_phase(st)
+            return
+        st["_main"], st["_side"], st["split_gw"] = main, side, True
+        self._run_phase("prep", self._prep_only_phase, st, key)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self._dis_phase(st)                       # eager launches on the side stream
+        self._run_phase("gen_a", self._gen_a_phase, st, key)
+        self._run_phase("gen_b", self._gen_b_phase, st, key)
+        main.wait_stream(side)
+        self._run_phase("gen_w", self._gen_w_phase, st, key)
+        self._join_phase(st)
 
     def _prep_phase(self, st):
         """Everything both concurrent phases depend on: cleared gradient buffers, the (down-sized) real batch, and the
@@ -366,6 +410,8 @@ class RGBDUpdater:
             kernels.warp_loss_bwd(xf[:half], xf[half:], st["coef"], flags, lf.lambda_geometric, 0.0, 0.0, None,
                                   hinge_lambda=hinge, hinge_min=float(cfg.depth_min or 0.0),
                                   grad_scale=float(lambda_rotate), out=(gout[:half], gout[half:]))
+            if "warp" in st.get("_l2s", ()):
+                kernels.l2_sync()
             if cfg.use_occupancy_net_loss:
                 raise AssertionError("occupancy-net loss is not supported")
             if dbg is not None:
@@ -378,11 +424,14 @@ class RGBDUpdater:
             wgrads = []
             with Fn.deferred_wgrads(wgrads):
                 torch.autograd.backward([x_fake], [gout])
-            if st.get("_side") is not None and os.environ.get("RGBD_DEBUG_GENB") != "no_wgrad_wait":
-                # the two weight-gradient batches (this one and D's for the fakes on the side stream) never run
-                # concurrently: see DESIGN.md section 3, "two concurrent weight-gradient batches"
-                torch.cuda.current_stream().wait_stream(st["_side"])
-            Fn.run_deferred_wgrads(wgrads)
+            if st.get("split_gw"):
+                st["gwgrads"] = wgrads                  # hybrid arrangement: issued by _gen_w_phase, after the join
+            else:
+                if st.get("_side") is not None and os.environ.get("RGBD_DEBUG_GENB") != "no_wgrad_wait":
+                    # the two weight-gradient batches (this one and D's for the fakes on the side stream) never run
+                    # concurrently: see DESIGN.md section 3, "two concurrent weight-gradient batches"
+                    torch.cuda.current_stream().wait_stream(st["_side"])
+                Fn.run_deferred_wgrads(wgrads)
         else:
             torch.autograd.backward([x_fake], [gout])
         st["x_fake_data"] = x_fake.detach()
@@ -478,9 +527,17 @@ class RGBDUpdater:
         if st["concurrent"]:
             main, side = torch.cuda.current_stream(), self._side_stream
             st["_main"], st["_side"] = main, side
+            l2s = set(filter(None, os.environ.get("RGBD_L2_SYNC", "").split(",")))   # diagnostics: explicit L2 maintenance
+            st["_l2s"] = l2s
+            if "fork" in l2s:
+                kernels.l2_sync()
             side.wait_stream(main)
             with torch.cuda.stream(side), rng("dis"):
+                if "fork" in l2s:
+                    kernels.l2_sync()
                 self._dis_phase(st)                   # D on the reals: side stream
+                if "join" in l2s:
+                    kernels.l2_sync()
             if os.environ.get("RGBD_DEBUG_SERIALIZE"):    # diagnostics: no overlap of the two phases
                 main.wait_stream(side)
             if self.defer_dfake_wgrads:
@@ -500,7 +557,11 @@ class RGBDUpdater:
             else:
                 with rng("gen"):
                     self._gen_phase(st)
+            if "join" in l2s:
+                kernels.l2_sync()
             main.wait_stream(side)
+            if "join" in l2s:
+                kernels.l2_sync()
         else:
             # one stream (the default): the same phases back to back; D's weight gradients for the fakes are still
             # collected during gen_a and issued as ONE batch (rgbd_conv2d_wgrad_partial_multi_bf16) after G's backward
@@ -594,7 +655,7 @@ class RGBDUpdater:
                                                              if saved.get(k) is not v}}
             self._graphs[gkey] = entry
         else:
-            st.update({k: v for k, v in entry["st"].items() if k in ("x_real", "x_fake_data")})
+            st.update({k: v for k, v in entry["st"].items() if k in ("x_real", "x_fake_data", "loss_dfake", "dfw")})
             self.observation.update(entry["obs"])
         entry["graph"].replay()
 
@@ -685,7 +746,10 @@ class RGBDUpdater:
         # capture, so a replay is a single launch whose internal dependencies the graph carries (separate graphs per
         # phase, ordered by stream events between the launches, were not reliably ordered on replay: the graph == eager
         # step test caught ~1e-2 relative gradient differences in two of five runs)
-        self._run_phase("body", self._body_phase, st, key)
+        if st["concurrent"] and self.hybrid and key is not None and self.defer_dfake_wgrads:
+            self._hybrid_body(st, key)
+        else:
+            self._run_phase("body", self._body_phase, st, key)
         dp = getattr(opt_d, "comm", None) is not None and opt_d.comm.active
         if dp:
             # data parallel (train_rgbd.py:154-156: the multi-node optimizers all-reduce before they update): one

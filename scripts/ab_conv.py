@@ -23,16 +23,17 @@ for H, Cin, Cout, ups in shapes:
     bias = torch.randn(Cout, device=dev)
     wf, wd = kernels.pack_weights(w, float(np.sqrt(2.0 / (Cin * 9))))
     flops = 2.0 * B * H * H * Cout * Cin * 9
+    res = torch.randn(B, H, H, Cout, device=dev).to(torch.bfloat16) if os.environ.get("RES") else None
     outs, line = {}, f"H={H:3d} Cin={Cin:3d} Cout={Cout:3d} ups={ups}:"
     for rnd in range(2):
         for v in variants:
             lib.rgbd_debug_conv_variant(v)
             for _ in range(3):
-                y = kernels.conv2d_fprop(x, wf, 3, 3, 1, bias=bias, lrelu_channels=Cout, upsample=bool(ups))
+                y = kernels.conv2d_fprop(x, wf, 3, 3, 1, bias=bias, residual=res, lrelu_channels=Cout, upsample=bool(ups))
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(REPS):
-                y = kernels.conv2d_fprop(x, wf, 3, 3, 1, bias=bias, lrelu_channels=Cout, upsample=bool(ups))
+                y = kernels.conv2d_fprop(x, wf, 3, 3, 1, bias=bias, residual=res, lrelu_channels=Cout, upsample=bool(ups))
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / REPS

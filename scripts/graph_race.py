@@ -25,8 +25,13 @@ def worst(L, ref, k, top=6):
 EXTRA = sys.argv[1:]
 ref = run("seq", ["--eager", "--sequential"] + EXTRA)
 N = int(os.environ.get("NRUNS", "12"))
-cases = [(f"one stream (default) {i}", [], {}) for i in range(max(2, N // 4))] + \
-        [(f"two streams {i}", ["--concurrent"], {}) for i in range(N)]
+if os.environ.get("HYBRID"):         # generator phase from graphs, discriminator phase eager on the side stream
+    cases = [(f"hybrid {os.environ['HYBRID']} two streams {i}", ["--hybrid", os.environ["HYBRID"]], {}) for i in range(N)]
+elif os.environ.get("EAGER_TWO"):      # screen the EAGER two-stream arrangement instead (launches from Python, no graphs)
+    cases = [(f"eager two streams {i}", ["--eager", "--concurrent"], {}) for i in range(N)]
+else:
+    cases = [(f"one stream (default) {i}", [], {}) for i in range(max(2, N // 4))] + \
+            [(f"two streams {i}", ["--concurrent"], {}) for i in range(N)]
 for i, (name, flags, env) in enumerate(cases):
     try:
         L = run(f"case{i}", list(flags) + EXTRA, env)
@@ -46,5 +51,5 @@ for i, (name, flags, env) in enumerate(cases):
     if dk:
         print("      " + "  ".join(f"{k[4:]}: {rel(L[k], ref[k]):.1e}" for k in sorted(dk)), flush=True)
     for k, v in rels.items():
-        if False and (v > 1e-2 or (k == "dis" and v > 1e-5)):
+        if os.environ.get("WORST") and (v > 1e-2 or (k == "dis" and v > 1e-5)):
             print(f"      {k}: {worst(L, ref, k)}", flush=True)

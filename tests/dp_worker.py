@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--sequential", action="store_true")
     ap.add_argument("--concurrent", action="store_true", help="two-stream phase overlap (off by default)")
+    ap.add_argument("--hybrid", type=int, default=0, help="two streams: generator phase from graphs, D-on-reals eager")
     ap.add_argument("--graph-phases", default=None, help="comma list: capture only these phases (diagnostics)")
     ap.add_argument("--sync-restore", action="store_true", help="host-synchronise after putting the weights back")
     ap.add_argument("--logit-shift", type=float, default=0.0,
@@ -77,6 +78,8 @@ def main():
         kw["concurrent_phases"] = False
     if args.concurrent:
         kw["concurrent_phases"] = True
+    if args.hybrid:
+        kw["concurrent_phases"], kw["hybrid"] = True, args.hybrid
     if args.graph_phases is not None:
         kw["graph_phases"] = tuple(p for p in args.graph_phases.split(",") if p)
     gen, dis, opt, upd = build_training(Config(CFG), device, comm if comm.active else None, iterator=None, **kw)
