@@ -302,6 +302,30 @@ def main():
     elif comm.size > 1 and not args.no_roofline:
         for _ in range(2):                      # keep ranks in lock-step with rank 0's extra steps
             upd.update()
+    if comm.rank == 0 and comm.size == 1 and not args.no_roofline and not deepvoxels:
+        # the opt-in two-stream arrangement, timed beside the default one on the same box (never `value`): generator
+        # phase replayed from graphs on the main stream || discriminator-on-reals phase launched eagerly on a side
+        # stream, weight-gradient batches after the join (DESIGN.md section 3 says why it is not the default)
+        it2 = DeviceImageIterator(images, B, device, seed=1)
+        _, _, _, upd2 = build_training(config, device, None, iterator=it2, nan_check_interval=0,
+                                       concurrent_phases=True, hybrid=1)
+        upd2.iteration = args.iteration
+        n2 = max(10, min(40, args.steps))
+        for _ in range(8):
+            upd2.update()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(n2):
+            upd2.update()
+        torch.cuda.synchronize()
+        ms2 = (time.perf_counter() - t2) / n2 * 1e3
+        line["opt_in_arrangement"] = {
+            "name": "hybrid two streams (RGBD_CONCURRENT_PHASES=1 RGBD_HYBRID=1)", "ms_per_step": round(ms2, 3),
+            "img_per_s": round(B / ms2 * 1e3, 1), "steps": n2,
+            "note": "same step, same kernels; off by default: graph-replayed launches racing a second queue gave wrong "
+                    "gradients in other arrangements on this ROCm stack (scripts/graph_race.py), this one was clean in "
+                    "every screened run but the cause is not understood"}
+        del upd2
     if comm.rank == 0 and comm.size == 1 and not args.no_cpu_baseline and not deepvoxels:
         line["cpu_baseline"] = cpu_baseline()
     if comm.rank == 0:

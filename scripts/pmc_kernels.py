@@ -2,12 +2,14 @@
 kernel, grid_threads, counter, mean_per_dispatch, dispatches -- profiles/<round>/pmc_<family>.csv.
 
     python scripts/pmc_kernels.py OUT_DIR PASS_DIR [PASS_DIR ...]
-Families: conv3x3_patch_kernel, conv_wgrad (main + multi), conv_fprop_kernel."""
+Families: conv3x3_sp_kernel (pipelined LDS-DMA), conv3x3_patch_kernel (register-staged A/B reference), conv_wgrad (all-taps
+body `conv_wgrad_kernel<9, true>` and the tap-split A/B reference `conv_wgrad_tapsplit_kernel`), conv_fprop_kernel."""
 import collections, csv, glob, os, re, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import kernel_source_sha16
 
-FAMILIES = {"conv3x3_patch_kernel": "conv3x3_patch_kernel", "conv_wgrad": "conv_wgrad", "conv_fprop_kernel": "conv_fprop_kernel"}
+FAMILIES = {"conv3x3_sp_kernel": "conv3x3_sp_kernel", "conv3x3_patch_kernel": "conv3x3_patch_kernel", "conv_wgrad": "conv_wgrad",
+            "conv_fprop_kernel": "conv_fprop_kernel"}
 
 
 def main(out_dir, *pass_dirs):

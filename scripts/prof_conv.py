@@ -2,7 +2,8 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from rgbd_gan_amd import kernels
+from rgbd_gan_amd import kernels, _lib
+lib = _lib.load()
 B = int(os.environ.get("B", "32"))
 reps = int(os.environ.get("REPS", "5"))
 dev = "cuda:0"
@@ -14,10 +15,15 @@ for H, Cin, Cout in shapes:
     w = torch.randn(Cout, Cin, 3, 3, device=dev)
     bias = torch.zeros(Cout, device=dev)
     wf, wd = kernels.pack_weights(w, float(np.sqrt(2.0 / (Cin * 9))))
-    for _ in range(reps):
-        if "fprop" in which:
-            kernels.conv2d_fprop(x, wf, 3, 3, 1, bias=bias, lrelu_channels=Cout)
-        if "wgrad" in which:
-            kernels.conv2d_wgrad(x, dy, 3, 1.0)
-    torch.cuda.synchronize()
+    # both generations of each kernel in the same pass (same box, same counters): the register-staged references
+    # (variants 1 / 3) first, then the shipped LDS-DMA kernels (variant 0)
+    for variant in (1, 3, 0):
+        lib.rgbd_debug_conv_variant(variant)
+        for _ in range(reps):
+            if "fprop" in which and variant != 3:
+                kernels.conv2d_fprop(x, wf, 3, 3, 1, bias=bias, lrelu_channels=Cout)
+            if "wgrad" in which and variant != 1:
+                kernels.conv2d_wgrad(x, dy, 3, 1.0)
+        torch.cuda.synchronize()
+    lib.rgbd_debug_conv_variant(0)
 print("done")
