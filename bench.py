@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--iteration", type=int, default=200000, help="steady state: stage 10, rotation + occlusion on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--arrangements", action="store_true",
+                    help="also time the opt-in hybrid two-stream arrangement on the same box (extra key, never `value`)")
     return ap.parse_args()
 
 
@@ -302,7 +304,7 @@ def main():
     elif comm.size > 1 and not args.no_roofline:
         for _ in range(2):                      # keep ranks in lock-step with rank 0's extra steps
             upd.update()
-    if comm.rank == 0 and comm.size == 1 and not args.no_roofline and not deepvoxels:
+    if comm.rank == 0 and comm.size == 1 and args.arrangements and not deepvoxels:
         # the opt-in two-stream arrangement, timed beside the default one on the same box (never `value`): generator
         # phase replayed from graphs on the main stream || discriminator-on-reals phase launched eagerly on a side
         # stream, weight-gradient batches after the join (DESIGN.md section 3 says why it is not the default)
