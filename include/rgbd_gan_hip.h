@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RGBD_ABI_VERSION 5
+#define RGBD_ABI_VERSION 6
 
 int rgbd_abi_version(void);
 const char* rgbd_last_error(void);
