@@ -140,7 +140,11 @@ def test_two_ranks_on_half_batches_equal_one_rank_on_the_whole_batch(tmp_path, s
         np.testing.assert_array_equal(r0[f"{k}/grad"], r1[f"{k}/grad"])
         np.testing.assert_array_equal(r0[f"{k}/delta"], r1[f"{k}/delta"])       # ... and takes the same Adam step
         assert int(r0[f"{k}/t"]) == 4                  # the first of the 5 calls only broadcast (ChainerMN)
-    _compare(r0, one, f"2 ranks vs 1 rank, stage {stage}", RANKS_TOL[stage], upd_tol=0.5)
+    # upd_tol: with beta1 = 0 an Adam step is ~alpha * sign(g) wherever |g| is steady, so every entry whose tiny gradient
+    # changes sign between the two arrangements (6 % relative gradient error at stage 10: half-batches round their bf16
+    # activations differently) counts as a full mismatch; measured over 30 runs: 0.35-0.62 for the mapping network.  The
+    # gradient, second-moment and norm checks above carry the comparison; this one only catches a step that went elsewhere.
+    _compare(r0, one, f"2 ranks vs 1 rank, stage {stage}", RANKS_TOL[stage], upd_tol=0.8)
 
 
 def test_seed_ratio_chain_at_the_logit_clamp(tmp_path):
