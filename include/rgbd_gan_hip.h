@@ -160,7 +160,8 @@ int rgbd_wgrad_reduce_multi(const rgbd_wgrad_reduce_desc* descs, int n, void* st
 /* The partial (slab) kernel for up to 24 weight gradients in ONE launch: a launch per layer costs one slab per CU (38 MB
  * of write + read at 64x64x9 fp32) whatever the layer's size; one launch for all weight gradients of a backward pass
  * deals the CUs out over the layers in proportion to their work and costs 38 MB in total.  3x3 pad-1 convs on
- * power-of-two images of at least 8x16 only.  rgbd_conv2d_wgrad_multi_plan fills `nsplit` of every problem (HOST
+ * power-of-two images; one call takes either problems of at least 8x16 pixels or smaller ones (4x4 .. 8x8: each planned
+ * on its own, one launch instead of a dozen latency-bound ones), not a mix.  rgbd_conv2d_wgrad_multi_plan fills `nsplit` of every problem (HOST
  * arrays; total_workgroups <= 0: one per CU); the caller then provides workspace = nsplit * 9 * Cout * Cin floats per
  * problem and finishes with rgbd_wgrad_reduce_multi. */
 typedef struct rgbd_wgrad_problem {

@@ -1892,10 +1892,25 @@ bool multi_eligible(const rgbd_wgrad_problem& q) {
            q.W >= 16 && (q.H & (q.H - 1)) == 0 && (q.W & (q.W - 1)) == 0 && (long)q.B * q.H * q.W * q.Cin < 0x3fffffffL &&
            (long)q.B * q.H * q.W * q.Cout < 0x3fffffffL;
 }
+// small images (4x4, 8x8, 8x... below the 8x16 patch): generic body, every problem planned on its own (plan_wgrad); one
+// launch for all of them replaces a dozen latency-bound ones
+bool multi_eligible_small(const rgbd_wgrad_problem& q) {
+    return q.x && q.dy && q.K == 3 && q.Cin > 0 && q.Cout > 0 && q.Cin % 64 == 0 && q.Cout % 64 == 0 && q.B > 0 && q.H >= 4 &&
+           q.W >= 4 && !(q.H >= 8 && q.W >= 16) && (q.H & (q.H - 1)) == 0 && (q.W & (q.W - 1)) == 0 &&
+           (long)q.B * q.H * q.W * q.Cin < 0x3fffffffL && (long)q.B * q.H * q.W * q.Cout < 0x3fffffffL;
+}
 }  // namespace
 
 extern "C" int rgbd_conv2d_wgrad_multi_plan(rgbd_wgrad_problem* probs, int n, int total_workgroups) {
     RGBD_REQUIRE(probs && n > 0 && n <= WGRAD_MULTI_PROBLEMS, "rgbd_conv2d_wgrad_multi_plan: 1..%d problems", WGRAD_MULTI_PROBLEMS);
+    if (multi_eligible_small(probs[0])) {
+        for (int i = 0; i < n; ++i) {
+            RGBD_REQUIRE(multi_eligible_small(probs[i]), "rgbd_conv2d_wgrad_multi_plan: problem %d: small-image (below 8x16) "
+                         "and large-image problems go into separate launches", i);
+            probs[i].nsplit = plan_wgrad(probs[i].B, probs[i].H, probs[i].W, probs[i].Cin, probs[i].Cout).nsplit;
+        }
+        return 0;
+    }
     if (total_workgroups <= 0) total_workgroups = device_cus();
     double units = 0.0;
     for (int i = 0; i < n; ++i) {
@@ -1921,6 +1936,39 @@ extern "C" int rgbd_conv2d_wgrad_partial_multi_bf16(const rgbd_wgrad_problem* pr
     RGBD_REQUIRE(probs && n > 0 && n <= WGRAD_MULTI_PROBLEMS, "rgbd_conv2d_wgrad_partial_multi_bf16: 1..%d problems",
                  WGRAD_MULTI_PROBLEMS);
     int order[WGRAD_MULTI_PROBLEMS], per_wg[WGRAD_MULTI_PROBLEMS];
+    if (multi_eligible_small(probs[0])) {
+        WgradMultiLaunch m;
+        m.n = n;
+        long wgs = 0;
+        for (int k = 0; k < n; ++k) {
+            const rgbd_wgrad_problem& q = probs[k];
+            RGBD_REQUIRE(multi_eligible_small(q) && q.workspace, "rgbd_conv2d_wgrad_partial_multi_bf16: bad small problem %d", k);
+            const WgradPlan p = plan_wgrad(q.B, q.H, q.W, q.Cin, q.Cout);
+            RGBD_REQUIRE(p.nsplit == q.nsplit, "rgbd_conv2d_wgrad_partial_multi_bf16: nsplit of problem %d is not from the plan", k);
+            WgradArgs& a = m.p[k];
+            a.x = (const unsigned short*)q.x; a.dy = (const unsigned short*)q.dy; a.dwp = (float*)q.workspace;
+            a.B = q.B; a.H = q.H; a.W = q.W; a.Cin = q.Cin; a.Cout = q.Cout;
+            a.PW = p.PW; a.PH = p.PH; a.lgPW = p.lgPW; a.npx = p.npx; a.npy = p.npy;
+            a.total_patches = p.total_patches; a.patches_per_wg = p.patches_per_wg;
+            a.x_bytes = (int)((long)q.B * q.H * q.W * q.Cin * 2 / (q.upsample ? 4 : 1));
+            a.y_bytes = (int)((long)q.B * q.H * q.W * q.Cout * 2);
+            a.ups = q.upsample ? 1 : 0;
+            m.wg_begin[k] = (int)wgs;
+            wgs += (long)q.nsplit * (q.Cin / 64) * (q.Cout / 64);
+        }
+        m.wg_begin[n] = (int)wgs;
+        const int lds_small = 2 * (180 * 128 + 128 * 128);
+        static bool small_attr_done = false;
+        if (!small_attr_done) {
+            RGBD_REQUIRE(hipFuncSetAttribute((const void*)&conv_wgrad_multi_kernel<9, false>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_small) == hipSuccess,
+                         "rgbd_conv2d_wgrad_partial_multi_bf16: cannot reserve %d B of LDS", lds_small);
+            small_attr_done = true;
+        }
+        conv_wgrad_multi_kernel<9, false><<<(unsigned)wgs, 512, lds_small, (hipStream_t)stream>>>(m);
+        RGBD_CHECK_LAUNCH("conv_wgrad_multi_kernel<small>");
+        return 0;
+    }
     for (int i = 0; i < n; ++i) {
         const rgbd_wgrad_problem& q = probs[i];
         RGBD_REQUIRE(multi_eligible(q) && q.workspace && q.nsplit > 0, "rgbd_conv2d_wgrad_partial_multi_bf16: bad problem %d", i);

@@ -313,18 +313,23 @@ def _multi_ok(H, W, K):
     return K == 3 and H >= 8 and W >= 16 and H & (H - 1) == 0 and W & (W - 1) == 0
 
 
+def _multi_small_ok(H, W, K):
+    return K == 3 and H >= 4 and W >= 4 and not (H >= 8 and W >= 16) and H & (H - 1) == 0 and W & (W - 1) == 0
+
+
 def conv2d_wgrad_batch(items):
     """Weight gradients of several convs, `items` = [(x, dy, target dW fp32, K, scale, upsample)], accumulated into their
     targets.  The 3x3 convs on images of 8x16 and larger share ONE partial-sum launch per 24 of them (the chip's
-    workgroups dealt out over the layers by work: 38 MB of slab traffic per launch instead of per layer); the small
-    layers get a launch each; ONE slab-reduction launch per 32 gradients finishes all of them."""
+    workgroups dealt out over the layers by work: 38 MB of slab traffic per launch instead of per layer); the 3x3 convs on
+    smaller images share another one; 1x1 convs get a launch each; ONE slab-reduction launch per 32 gradients finishes
+    all of them."""
     import numpy as np
     if not items:
         return
     lib = _lib.load()
     tab = np.zeros(len(items), dtype=WGRAD_REDUCE_DESC)
     assert tab.dtype.itemsize == 40
-    keep, multi = [], []
+    keep, multi, multi_small = [], [], []
     for i, (x, dy, target, K, scale, ups) in enumerate(items):
         _chk(x, BF16, "x"); _chk(dy, BF16, "dy"); _chk(target, F32, "target")
         B, H, W, Cin = x.shape
@@ -347,6 +352,9 @@ def conv2d_wgrad_batch(items):
         if _multi_ok(H, W, K) and len(items) > 1:
             multi.append((i, x, dy, B, H, W, Cin, Cout, bool(ups)))
             continue
+        if _multi_small_ok(H, W, K) and len(items) > 1 and not os.environ.get("RGBD_NO_WGRAD_MULTI_SMALL"):
+            multi_small.append((i, x, dy, B, H, W, Cin, Cout, bool(ups)))
+            continue
         ws_bytes = lib.rgbd_conv2d_wgrad_workspace(B, H, W, Cin, Cout, K)
         if ws_bytes < 0:
             raise RuntimeError(f"conv2d_wgrad_batch: unsupported shape x={tuple(x.shape)} dy={tuple(dy.shape)} K={K}")
@@ -359,8 +367,9 @@ def conv2d_wgrad_batch(items):
                                                                int(bool(ups)), _stream()))
         _lib.check(rc, "rgbd_conv2d_wgrad_partial_bf16")
         tab[i] = (ws.data_ptr(), target.data_ptr(), ws_bytes // (4 * K * K * Cout * Cin), K * K, Cout, Cin, float(scale), 1)
-    for g0 in range(0, len(multi), WGRAD_MULTI_MAX):
-        group = multi[g0:g0 + WGRAD_MULTI_MAX]
+    groups = [multi[g0:g0 + WGRAD_MULTI_MAX] for g0 in range(0, len(multi), WGRAD_MULTI_MAX)] + \
+             [multi_small[g0:g0 + WGRAD_MULTI_MAX] for g0 in range(0, len(multi_small), WGRAD_MULTI_MAX)]
+    for group in groups:
         probs = (_WgradProblem * len(group))()
         for q, (i, x, dy, B, H, W, Cin, Cout, ups) in zip(probs, group):
             q.x, q.dy, q.workspace = x.data_ptr(), dy.data_ptr(), 0

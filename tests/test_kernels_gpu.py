@@ -283,15 +283,17 @@ def test_gan_logit_heads_match_the_loss_functions():
 
 def test_conv_wgrad_batch_matches_single_calls():
     """Collected weight gradients (functional.deferred_wgrads): the 3x3 layers on images >= 8x16 share one partial-sum
-    launch (workgroups dealt out over the layers by work), the small ones get a launch each, one multi-descriptor slab
+    launch (workgroups dealt out over the layers by work), the 3x3 layers on 4x4 / 8x8 images share another, 1x1 convs get
+    a launch each, one multi-descriptor slab
     reduction finishes all: the same sums as the one-call-per-layer path, split differently over workgroups (fp32
     summation order differs)."""
     from rgbd_gan_amd import kernels
     g = torch.Generator().manual_seed(29)
     shapes = [(2, 8, 64, 128, 3, False), (2, 16, 128, 64, 3, True), (3, 4, 64, 64, 1, False), (1, 32, 64, 64, 3, False),
-              (2, 64, 64, 128, 3, True), (1, 128, 128, 64, 3, False), (4, 16, 256, 256, 3, False)] * 5
+              (2, 64, 64, 128, 3, True), (1, 128, 128, 64, 3, False), (4, 16, 256, 256, 3, False), (5, 4, 128, 64, 3, False),
+              (2, 8, 64, 64, 3, True)] * 4
     items, refs = [], []
-    for i, (B, H, Cin, Cout, K, ups) in enumerate(shapes):       # 35 items: more than one reduction / multi launch
+    for i, (B, H, Cin, Cout, K, ups) in enumerate(shapes):       # 36 items: more than one reduction / multi launch
         hs = H // 2 if ups else H
         x = torch.randn(B, hs, hs, Cin, generator=g).to(dev()).to(torch.bfloat16)
         dy = torch.randn(B, H, H, Cout, generator=g).to(dev()).to(torch.bfloat16)
