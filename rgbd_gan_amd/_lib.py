@@ -8,7 +8,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# RGBD_LIB_PATH: A/B timing of another build of the same ABI (scripts/patch_probe.py); the default is the in-tree library
+# RGBD_LIB_PATH: A/B timing of another build of the same ABI; the default is the in-tree library
 LIB_PATH = os.environ.get("RGBD_LIB_PATH") or os.path.join(_HERE, "librgbdgan_hip.so")
 ABI_VERSION = 6
 

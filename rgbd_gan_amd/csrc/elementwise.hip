@@ -739,14 +739,26 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
     // blockIdx.y > 0 / gridDim.y > 1: split-K (the discriminator's dense tail has K = 4096 and N = 256: 16 column blocks
     // each walking 32 dependent-load chunks took ~100 us); every K slice leaves raw fp32 partial sums in
     // partial[slice][M][N] and linear_splitk_finish_kernel applies scale, bias and activation
-    const int lane = threadIdx.x & 63, m0 = (threadIdx.x >> 6) * 16;
-    if (m0 >= M) return;
+    // Waves a small M leaves without a row tile take a share of K instead (M <= 16: four K parts, M <= 32: two): these
+    // launches are chains of dependent load round trips, and the parts meet through LDS at the end.
+    __shared__ f32x4 kred[3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int mtiles = (M + 15) >> 4;
+    const int kparts = gridDim.y == 1 ? (mtiles == 1 ? 4 : mtiles == 2 ? 2 : 1) : 1;
+    const int mt = kparts == 4 ? 0 : kparts == 2 ? (wave & 1) : wave, kp = kparts == 4 ? wave : kparts == 2 ? (wave >> 1) : 0;
+    const int m0 = mt * 16;
+    if (kparts == 1 && m0 >= M) return;
     const int r = lane & 15, q = lane >> 4;
     const int n0 = blockIdx.x * 16;
     const int kslice = (K + (int)gridDim.y - 1) / (int)gridDim.y;
-    const int kbeg = (kslice * (int)blockIdx.y + 127) / 128 * 128 < K ? ((kslice * (int)blockIdx.y + 127) / 128 * 128) : K;
-    const int kend = gridDim.y == 1 ? K : ((kslice * ((int)blockIdx.y + 1) + 127) / 128 * 128 < K
-                                           ? (kslice * ((int)blockIdx.y + 1) + 127) / 128 * 128 : K);
+    int kbeg = (kslice * (int)blockIdx.y + 127) / 128 * 128 < K ? ((kslice * (int)blockIdx.y + 127) / 128 * 128) : K;
+    int kend = gridDim.y == 1 ? K : ((kslice * ((int)blockIdx.y + 1) + 127) / 128 * 128 < K
+                                     ? (kslice * ((int)blockIdx.y + 1) + 127) / 128 * 128 : K);
+    if (kparts > 1) {
+        const int chunks = (K + 127) >> 7;
+        kbeg = min(K, (chunks * kp / kparts) << 7);
+        kend = min(K, (chunks * (kp + 1) / kparts) << 7);
+    }
     const bool mok = m0 + r < M, nok = n0 + r < N;
     const float* xr = x + (long)(mok ? m0 + r : 0) * K;
     const float* wr = w + (long)(nok ? n0 + r : 0) * K;
@@ -777,6 +789,14 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
         for (int s2 = 0; s2 < 8; ++s2)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s2][j], b[s2][j], acc, 0, 0, 0);
+    }
+    if (kparts > 1) {                                  // block-uniform
+        // kparts 4: waves 1-3 -> slots 0-2, wave 0 adds all three; kparts 2: waves 2,3 -> slots 0,1, waves 0,1 add theirs
+        if (kp > 0) kred[kparts == 4 ? wave - 1 : wave - 2][lane] = acc;
+        __syncthreads();
+        if (kp > 0) return;
+        if (kparts == 4) acc += (kred[0][lane] + kred[1][lane]) + kred[2][lane];
+        else acc += kred[mt][lane];
     }
     const int n = n0 + r;
     if (n < N) {
@@ -820,8 +840,14 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void linear_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                            const float* __restrict__ w, float* __restrict__ dx, int M,
                                                            int K, int N, float c, int act, float slope, int accumulate) {
-    const int lane = threadIdx.x & 63, m0 = (threadIdx.x >> 6) * 16;
-    if (m0 >= M) return;
+    // as linear_fwd_kernel: waves without a row tile take a share of the reduction (here over N)
+    __shared__ f32x4 nred[3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int mtiles = (M + 15) >> 4;
+    const int nparts = mtiles == 1 ? 4 : mtiles == 2 ? 2 : 1;
+    const int mt = nparts == 4 ? 0 : nparts == 2 ? (wave & 1) : wave, np = nparts == 4 ? wave : nparts == 2 ? (wave >> 1) : 0;
+    const int m0 = mt * 16;
+    if (nparts == 1 && m0 >= M) return;
     const int r = lane & 15, q = lane >> 4;
     const int k0 = blockIdx.x * 16;
     const bool mok = m0 + r < M, kok = k0 + r < K;
@@ -829,7 +855,9 @@ __global__ __launch_bounds__(256) void linear_dgrad_kernel(const float* __restri
     const float* wc = w + (kok ? k0 + r : 0);
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc = zero;
-    for (int n0 = 0; n0 < N; n0 += 64) {           // 4 N-steps of 16 per chunk
+    const int nchunks = (N + 63) >> 6;
+    const int nbeg = (nchunks * np / nparts) << 6, nend = min(N, (nchunks * (np + 1) / nparts) << 6);
+    for (int n0 = nbeg; n0 < nend; n0 += 64) {     // 4 N-steps of 16 per chunk
         f32x4 a[4], yy[4], b[4];
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) {
@@ -862,6 +890,13 @@ __global__ __launch_bounds__(256) void linear_dgrad_kernel(const float* __restri
                 const float g = yy[s2][j] > 0.f ? a[s2][j] : a[s2][j] * slope;
                 acc = __builtin_amdgcn_mfma_f32_16x16x4f32(g, b[s2][j], acc, 0, 0, 0);
             }
+    }
+    if (nparts > 1) {                                  // block-uniform
+        if (np > 0) nred[nparts == 4 ? wave - 1 : wave - 2][lane] = acc;
+        __syncthreads();
+        if (np > 0) return;
+        if (nparts == 4) acc += (nred[0][lane] + nred[1][lane]) + nred[2][lane];
+        else acc += nred[mt][lane];
     }
     const int k = k0 + r;
     if (k < K) {
