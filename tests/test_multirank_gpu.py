@@ -105,6 +105,22 @@ def test_graph_replay_equals_eager_step(tmp_path):
         assert abs(float(g[key]) - float(e[key])) < 1e-5 * max(1.0, abs(float(e[key]))), (key, float(g[key]), float(e[key]))
 
 
+@pytest.mark.parametrize("stage,batch", [(10.0, 16)])
+def test_hybrid_two_stream_arrangement_equals_eager_step(tmp_path, stage, batch):
+    """The opt-in arrangement (RGBD_CONCURRENT_PHASES=1 RGBD_HYBRID=1): generator phase replayed from graphs on the main
+    stream, discriminator-on-reals phase launched eagerly on a side stream, both weight-gradient batches of the generator
+    phase after the join.  At these sizes the one-graph two-branch arrangement is wrong in most runs
+    (scripts/graph_race.py); this one has to equal the eager single-stream step."""
+    flags = ["--calls", "4", "--stage", str(stage), "--batch", str(batch)]
+    _wait([_run(tmp_path / "eager.npz", *flags, "--eager", "--sequential")])
+    e = np.load(tmp_path / "eager.npz")
+    for rep in range(2):
+        _wait([_run(tmp_path / f"hyb{rep}.npz", *flags, "--hybrid", "1")])
+        h = np.load(tmp_path / f"hyb{rep}.npz")
+        assert int(h["n_graphs"]) == 5                     # prep, gen_a, gen_b, gen_w, optimizers
+        _compare(h, e, f"hybrid two streams vs eager, stage {stage} batch {batch}, run {rep}", SAME_STEP)
+
+
 @pytest.mark.parametrize("stage,batch", [(9.5, 4), (7.5, 8), (8.0, 16)])
 def test_graph_replay_equals_eager_step_other_stages(tmp_path, stage, batch):
     """Fade-in stages (the blend factor comes from a device scalar in the replay, from the host in the eager step) and
