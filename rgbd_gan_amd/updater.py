@@ -305,6 +305,27 @@ class RGBDUpdater:
             main.wait_stream(side)
             self._join_phase(st)
             return
+        if self.hybrid in (3, 4):
+            # diagnostics: 3 = G's weight-gradient batch inside gen_b (concurrent with the eager side stream), D's batch for
+            # the fakes after the join; 4 = G's batch after the join, D's batch for the fakes eagerly on the side stream
+            st["_main"], st["_side"], st["split_gw"] = None, None, self.hybrid == 4
+            self._run_phase("prep", self._prep_only_phase, st, key)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._dis_phase(st)
+            self._run_phase("gen_a", self._gen_a_phase, st, key)
+            if self.hybrid == 4:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self._dfw_phase(st)
+            self._run_phase("gen_b", self._gen_b_phase, st, key)
+            main.wait_stream(side)
+            if self.hybrid == 4:
+                self._run_phase("gen_w", self._gen_w4_phase, st, key)
+            else:
+                self._run_phase("gen_w", self._dfw_phase, st, key)
+            self._join_phase(st)
+            return
         st["_main"], st["_side"], st["split_gw"] = main, side, True
         self._run_phase("prep", self._prep_only_phase, st, key)
         side.wait_stream(main)
@@ -315,6 +336,9 @@ class RGBDUpdater:
         main.wait_stream(side)
         self._run_phase("gen_w", self._gen_w_phase, st, key)
         self._join_phase(st)
+
+    def _gen_w4_phase(self, st):
+        Fn.run_deferred_wgrads(st["gwgrads"])
 
     def _prep_phase(self, st):
         """Everything both concurrent phases depend on: cleared gradient buffers, the (down-sized) real batch, and the
