@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RGBD_ABI_VERSION 6
+#define RGBD_ABI_VERSION 7
 
 int rgbd_abi_version(void);
 const char* rgbd_last_error(void);
@@ -328,6 +328,17 @@ int rgbd_rows_to_nhwc_bf16(const float* rows, void* h, int B, int HW, int C, voi
 int rgbd_proj_idcs(const float* cam2world, int B, int W, int H, int D, int G, float voxel_size, float near_plane,
                    float fx, float fy, float cx, float cy, int32_t* idx, float* coords, int32_t* counts,
                    int32_t* workspace, void* stream);
+/* Layout folds that put the DeepVoxels networks on the 2-D conv engine (deepvoxels_generator.py:112-222: 3x3x3 convs as
+ * 3x3 convs over depth slices with the three depth taps folded into channels, 4x4 stride-2 convs as 1x1 convs over 16 folded
+ * taps, channel counts padded to the engine's multiples).  One launch each, adjoint != 0 = the backward gather:
+ *   rgbd_fold_depth_taps_bf16: x (B,D0,H,W,C) -> y (B*D,H,W,3C), D = 2 D0 when upsample_depth (nearest depth repeat folded in);
+ *     adjoint: x = dy (B*D,H,W,3C) -> y = dx (B,D0,H,W,C).
+ *   rgbd_fold_4x4s2_bf16: x (B,H,W,C) -> y (B,H/2,W/2,16C), channel (ky*4+kx)*C+c = x_pad1[2i+ky, 2j+kx, c]; adjoint likewise.
+ *   rgbd_pad_last: rows x C0 -> rows x C1 elements of 2 or 4 bytes; C1 > C0 zero-fills the tail, C1 < C0 slices. */
+int rgbd_fold_depth_taps_bf16(const void* x, void* y, int B, int D0, int H, int W, int C, int upsample_depth, int adjoint,
+                              void* stream);
+int rgbd_fold_4x4s2_bf16(const void* x, void* y, int B, int H, int W, int C, int adjoint, void* stream);
+int rgbd_pad_last(const void* x, void* y, int64_t rows, int C0, int C1, int elem_bytes, void* stream);
 int rgbd_trilinear_fwd(const float* grid, const int32_t* idx, const float* coords, const int32_t* counts, float* out,
                        int B, int F, int G, int N, void* stream);
 int rgbd_trilinear_bwd(const float* dout, const int32_t* idx, const float* coords, const int32_t* counts, float* dgrid,

@@ -10,7 +10,7 @@ from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p, POINTER
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RGBD_LIB_PATH: A/B timing of another build of the same ABI; the default is the in-tree library
 LIB_PATH = os.environ.get("RGBD_LIB_PATH") or os.path.join(_HERE, "librgbdgan_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _P = c_void_p
 
@@ -30,6 +30,9 @@ PROTOTYPES = {
     "rgbd_debug_force_gather_kernel": ([c_int], c_int),
     "rgbd_last_conv_kernel": ([], c_char_p),
     "rgbd_debug_conv_variant": ([c_int], c_int),
+    "rgbd_fold_depth_taps_bf16": ([_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P], c_int),
+    "rgbd_fold_4x4s2_bf16": ([_P, _P, c_int, c_int, c_int, c_int, c_int, _P], c_int),
+    "rgbd_pad_last": ([_P, _P, c_int64, c_int, c_int, c_int, _P], c_int),
     "rgbd_debug_l2_sync": ([_P], c_int),
     "rgbd_conv2d_wgrad_workspace": ([c_int, c_int, c_int, c_int, c_int, c_int], c_int64),
     "rgbd_conv2d_wgrad_bf16": ([_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P], c_int),

@@ -506,3 +506,153 @@ extern "C" int rgbd_occlusion_accum_bwd(const float* vol, const float* W1, const
     RGBD_CHECK_LAUNCH("occ_bwd_mlp_kernel");
     return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------------ layout folds
+// The DeepVoxels networks reach the 2-D conv engine through three data rearrangements (deepvoxels_generator.py): each is
+// ONE launch forward and ONE backward here (gathers, no atomics) instead of pad + slice + cat chains of framework copies.
+namespace {
+// fold_depth_taps: x (B,D0,H,W,C) bf16 [read through a 2x depth repeat when up] -> y (B*D,H,W,3C):
+//   y[b,d,h,w,k*C+c] = xs[b,d+k-1,h,w,c] (zero outside 0 <= d+k-1 < D), xs[d] = x[up ? d >> 1 : d].  16 bytes per thread.
+__global__ __launch_bounds__(256) void fold_depth_fwd_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ y, int B, int D0,
+                                                             long HW, int C8, int up) {
+    const int D = up ? 2 * D0 : D0;
+    const long total = (long)B * D * HW * 3 * C8;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c8 = (int)(e % C8);
+        long r = e / C8;
+        const int k = (int)(r % 3); r /= 3;
+        const long p = r % HW; r /= HW;
+        const int d = (int)(r % D);
+        const int b = (int)(r / D);
+        const int ds = d + k - 1;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (ds >= 0 && ds < D) v = x[(((long)b * D0 + (up ? ds >> 1 : ds)) * HW + p) * C8 + c8];
+        y[e] = v;
+    }
+}
+// adjoint: dx[b,d0,h,w,c] = sum over repeated depths ds of d0 and taps k of dy[b, ds - k + 1, h, w, k*C + c]
+__global__ __launch_bounds__(256) void fold_depth_bwd_kernel(const u32x4* __restrict__ dy, u32x4* __restrict__ dx, int B, int D0,
+                                                             long HW, int C8, int up) {
+    const int D = up ? 2 * D0 : D0;
+    const long total = (long)B * D0 * HW * C8;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c8 = (int)(e % C8);
+        long r = e / C8;
+        const long p = r % HW; r /= HW;
+        const int d0 = (int)(r % D0);
+        const int b = (int)(r / D0);
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int rep = 0; rep < (up ? 2 : 1); ++rep) {
+            const int ds = up ? 2 * d0 + rep : d0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int d = ds - k + 1;
+                if (d < 0 || d >= D) continue;
+                const u32x4 v = dy[((((long)b * D + d) * HW + p) * 3 + k) * C8 + c8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { acc[2 * j] += bf16_lo(v[j]); acc[2 * j + 1] += bf16_hi(v[j]); }
+            }
+        }
+        dx[e] = u32x4{pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]), pack_bf16x2(acc[4], acc[5]),
+                      pack_bf16x2(acc[6], acc[7])};
+    }
+}
+// fold_4x4s2: x (B,H,W,C) -> y (B,H/2,W/2,16C): y[b,i,j,(ky*4+kx)*C+c] = x[b,2i+ky-1,2j+kx-1,c] (zero outside)
+__global__ __launch_bounds__(256) void fold_4x4s2_fwd_kernel(const u32x4* __restrict__ x, u32x4* __restrict__ y, int B, int H, int W,
+                                                             int C8) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long total = (long)B * Ho * Wo * 16 * C8;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c8 = (int)(e % C8);
+        long r = e / C8;
+        const int t = (int)(r % 16); r /= 16;
+        const int j = (int)(r % Wo); r /= Wo;
+        const int i = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        const int yy = 2 * i + (t >> 2) - 1, xx = 2 * j + (t & 3) - 1;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) v = x[(((long)b * H + yy) * W + xx) * C8 + c8];
+        y[e] = v;
+    }
+}
+// adjoint: dx[b,y,x,c] = sum over the (ky,kx) with 2i+ky-1 = y, 2j+kx-1 = x  (two ky of the right parity, two kx)
+__global__ __launch_bounds__(256) void fold_4x4s2_bwd_kernel(const u32x4* __restrict__ dy, u32x4* __restrict__ dx, int B, int H,
+                                                             int W, int C8) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    const long total = (long)B * H * W * C8;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c8 = (int)(e % C8);
+        long r = e / C8;
+        const int xx = (int)(r % W); r /= W;
+        const int yy = (int)(r % H);
+        const int b = (int)(r / H);
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2) {
+            const int ky = ((yy + 1) & 1) + 2 * a2;          // ky = y + 1 (mod 2)
+            const int i = (yy + 1 - ky) >> 1;
+            if (i < 0 || i >= Ho || yy + 1 - ky < 0) continue;
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2) {
+                const int kx = ((xx + 1) & 1) + 2 * b2;
+                const int j = (xx + 1 - kx) >> 1;
+                if (j < 0 || j >= Wo || xx + 1 - kx < 0) continue;
+                const u32x4 v = dy[((((long)b * Ho + i) * Wo + j) * 16 + ky * 4 + kx) * C8 + c8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { acc[2 * q] += bf16_lo(v[q]); acc[2 * q + 1] += bf16_hi(v[q]); }
+            }
+        }
+        dx[e] = u32x4{pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]), pack_bf16x2(acc[4], acc[5]),
+                      pack_bf16x2(acc[6], acc[7])};
+    }
+}
+// pad_last: rows of C0 elements -> rows of C1 >= C0 elements (zero tail), or the adjoint slice (C1 < C0); 2- or 4-byte elements
+template <typename T>
+__global__ __launch_bounds__(256) void pad_last_kernel(const T* __restrict__ x, T* __restrict__ y, long rows, int C0, int C1) {
+    const long total = rows * C1;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % C1);
+        const long r = e / C1;
+        y[e] = c < C0 ? x[r * C0 + c] : (T)0;
+    }
+}
+int fold_blocks(long total) { return (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096); }
+}  // namespace
+
+extern "C" int rgbd_fold_depth_taps_bf16(const void* x, void* y, int B, int D0, int H, int W, int C, int upsample_depth,
+                                         int adjoint, void* stream) {
+    RGBD_REQUIRE(x && y && B > 0 && D0 > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "rgbd_fold_depth_taps_bf16: bad arguments");
+    const long HW = (long)H * W;
+    const int D = upsample_depth ? 2 * D0 : D0;
+    if (adjoint) {      // x = dy (B*D,H,W,3C), y = dx (B,D0,H,W,C)
+        fold_depth_bwd_kernel<<<fold_blocks((long)B * D0 * HW * (C / 8)), 256, 0, (hipStream_t)stream>>>(
+            (const u32x4*)x, (u32x4*)y, B, D0, HW, C / 8, upsample_depth ? 1 : 0);
+    } else {
+        fold_depth_fwd_kernel<<<fold_blocks((long)B * D * HW * 3 * (C / 8)), 256, 0, (hipStream_t)stream>>>(
+            (const u32x4*)x, (u32x4*)y, B, D0, HW, C / 8, upsample_depth ? 1 : 0);
+    }
+    RGBD_CHECK_LAUNCH("fold_depth_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_fold_4x4s2_bf16(const void* x, void* y, int B, int H, int W, int C, int adjoint, void* stream) {
+    RGBD_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 8 == 0,
+                 "rgbd_fold_4x4s2_bf16: bad arguments");
+    if (adjoint) fold_4x4s2_bwd_kernel<<<fold_blocks((long)B * H * W * (C / 8)), 256, 0, (hipStream_t)stream>>>(
+                     (const u32x4*)x, (u32x4*)y, B, H, W, C / 8);
+    else fold_4x4s2_fwd_kernel<<<fold_blocks((long)B * (H / 2) * (W / 2) * 16 * (C / 8)), 256, 0, (hipStream_t)stream>>>(
+             (const u32x4*)x, (u32x4*)y, B, H, W, C / 8);
+    RGBD_CHECK_LAUNCH("fold_4x4s2_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_pad_last(const void* x, void* y, int64_t rows, int C0, int C1, int elem_bytes, void* stream) {
+    RGBD_REQUIRE(x && y && rows > 0 && C0 > 0 && C1 > 0 && (elem_bytes == 2 || elem_bytes == 4), "rgbd_pad_last: bad arguments");
+    const int blocks = fold_blocks(rows * C1);
+    if (elem_bytes == 2) pad_last_kernel<unsigned short><<<blocks, 256, 0, (hipStream_t)stream>>>(
+                             (const unsigned short*)x, (unsigned short*)y, rows, C0, C1);
+    else pad_last_kernel<unsigned int><<<blocks, 256, 0, (hipStream_t)stream>>>((const unsigned int*)x, (unsigned int*)y, rows, C0, C1);
+    RGBD_CHECK_LAUNCH("pad_last_kernel");
+    return 0;
+}

@@ -38,11 +38,14 @@ OCC_NF = 4
 
 
 def _pad_to(t, n, dim=-1):
-    """Zero-pad dimension `dim` of t up to n entries (differentiable)."""
+    """Zero-pad dimension `dim` of t up to n entries (differentiable).  The common case -- the last dimension of a bf16 /
+    fp32 device tensor -- is one HIP launch forward and one backward (rgbd_pad_last)."""
     extra = n - t.shape[dim]
     if extra == 0:
         return t
     dim = dim % t.dim()
+    if dim == t.dim() - 1 and t.is_cuda and t.dtype in (torch.bfloat16, torch.float32):
+        return Fn.pad_last(t, n)
     pads = [0, 0] * (t.dim() - 1 - dim) + [0, extra]
     return F.pad(t, pads)
 
@@ -169,11 +172,14 @@ class VoxelGenerator(_Link, _StyleMixin):
     @staticmethod
     def _conv3d(x, layer, bias, upsample):
         """x (B,D,H,W,C) -> lrelu(conv3d(up(x)) + bias) as one 2-D conv over (B*D) depth slices."""
-        if upsample:
-            B0, D0 = x.shape[:2]
-            x = x.unsqueeze(2).expand(B0, D0, 2, *x.shape[2:]).reshape(B0, 2 * D0, *x.shape[2:])
-        B, D = x.shape[:2]
-        y = Fn.conv_bias_lrelu(fold_depth_taps(x), layer, bias, upsample=upsample)
+        B, D = x.shape[0], (2 * x.shape[1] if upsample else x.shape[1])
+        if x.is_cuda:                                  # depth repeat + tap fold: one launch (rgbd_fold_depth_taps_bf16)
+            folded = Fn.fold_depth_taps(x, upsample)
+        else:
+            if upsample:
+                x = x.unsqueeze(2).expand(B, D // 2, 2, *x.shape[2:]).reshape(B, D, *x.shape[2:])
+            folded = fold_depth_taps(x)
+        y = Fn.conv_bias_lrelu(folded, layer, bias, upsample=upsample)
         return y.reshape(B, D, y.shape[1], y.shape[2], y.shape[3])
 
     def _block(self, i, w, x):
@@ -252,8 +258,9 @@ class StyleGenerator(_Link, _StyleMixin):
         p = self.p
         L = self.layers
         x = h.permute(0, 2, 3, 1).to(BF16).contiguous()                                     # (B,64,64,32)
-        h1 = self._style("s0", w, Fn.conv_bias_lrelu(fold_4x4s2(x), L["c0"], p["c0/c/b"]))
-        h2 = self._style("s1", w, Fn.conv_bias_lrelu(fold_4x4s2(h1), L["c1"], p["c1/c/b"]))
+        fold = Fn.fold_4x4s2 if x.is_cuda else fold_4x4s2
+        h1 = self._style("s0", w, Fn.conv_bias_lrelu(fold(x), L["c0"], p["c0/c/b"]))
+        h2 = self._style("s1", w, Fn.conv_bias_lrelu(fold(h1), L["c1"], p["c1/c/b"]))
         h3 = self._style("s4", w, Fn.conv_bias_lrelu(h2, L["c4"], p["c4/c/b"]))
         h3 = Fn.conv_bias_lrelu(h3, L["c5"], p["c5/c/b"], upsample=True)
         h3 = torch.cat([self._style("s5", w, h3), h1], dim=-1)

@@ -1133,3 +1133,55 @@ class _DepthHead(torch.autograd.Function):
 def depth_head(x):
     """net.py:296: (B,4,H,W) fp32 planes -> RGB unchanged, depth = 1 / (softplus(x3) + 1e-4)."""
     return _DepthHead.apply(x)
+
+
+# ---- DeepVoxels layout folds (deepvoxels_generator.py): one launch forward, one backward; each op's backward is its adjoint
+class _FoldDepthTaps(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, up):
+        ctx.shape, ctx.up = tuple(x.shape), bool(up)
+        return kernels.fold_depth_taps(x.contiguous(), ctx.up)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        return kernels.fold_depth_taps(dy.contiguous(), ctx.up, adjoint_shape=ctx.shape), None
+
+
+class _Fold4x4s2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = tuple(x.shape)
+        return kernels.fold_4x4s2(x.contiguous())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        return kernels.fold_4x4s2(dy.contiguous(), adjoint_shape=ctx.shape)
+
+
+class _PadLast(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.c0 = x.shape[-1]
+        return kernels.pad_last(x.contiguous(), n)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        return kernels.pad_last(dy.contiguous(), ctx.c0), None
+
+
+def fold_depth_taps(x, upsample_depth=False):
+    """(B,D0,H,W,C) -> (B*D,H,W,3C): every depth slice next to its two zero-padded neighbours (behind a 2x depth repeat)."""
+    return _FoldDepthTaps.apply(x, upsample_depth)
+
+
+def fold_4x4s2(x):
+    """(B,H,W,C) -> (B,H/2,W/2,16C): channel (ky*4 + kx)*C + c holds x_pad[2i+ky, 2j+kx, c] (pad 1)."""
+    return _Fold4x4s2.apply(x)
+
+
+def pad_last(x, n):
+    """Zero-pad the last dimension to n entries."""
+    return x if x.shape[-1] == n else _PadLast.apply(x, n)

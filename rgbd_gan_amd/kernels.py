@@ -849,3 +849,49 @@ def adam_clip_multi(p, g, m, v, seg_begin, seg_alpha, beta1, beta2, eps, clip, g
                                           float(beta2), float(eps), float(clip), float(grad_scale), _ptr(step),
                                           _ptr(workspace), _ptr(norm_out), _stream())
     _lib.check(rc, "rgbd_adam_clip_multi")
+
+
+# ------------------------------------------------------------------ DeepVoxels layout folds
+def fold_depth_taps(x, upsample_depth=False, adjoint_shape=None):
+    """(B,D0,H,W,C) bf16 -> (B*D,H,W,3C) with the depth taps -1, 0, +1 folded into channels (D = 2 D0 behind a nearest depth
+    repeat).  adjoint_shape = (B,D0,H,W,C): x is the gradient (B*D,H,W,3C), the result the gradient w.r.t. the input."""
+    _chk(x, BF16, "x")
+    lib = _lib.load()
+    if adjoint_shape is None:
+        B, D0, H, W, C = x.shape
+        D = 2 * D0 if upsample_depth else D0
+        y = torch.empty(B * D, H, W, 3 * C, dtype=BF16, device=x.device)
+        adj = 0
+    else:
+        B, D0, H, W, C = adjoint_shape
+        y = torch.empty(B, D0, H, W, C, dtype=BF16, device=x.device)
+        adj = 1
+    _lib.check(lib.rgbd_fold_depth_taps_bf16(_ptr(x), _ptr(y), B, D0, H, W, C, int(bool(upsample_depth)), adj, _stream()),
+               "rgbd_fold_depth_taps_bf16")
+    return y
+
+
+def fold_4x4s2(x, adjoint_shape=None):
+    """(B,H,W,C) bf16 -> (B,H/2,W/2,16C): the 16 taps of a 4x4 stride-2 pad-1 window folded into channels; adjoint_shape =
+    (B,H,W,C): the backward gather."""
+    _chk(x, BF16, "x")
+    if adjoint_shape is None:
+        B, H, W, C = x.shape
+        y = torch.empty(B, H // 2, W // 2, 16 * C, dtype=BF16, device=x.device)
+        adj = 0
+    else:
+        B, H, W, C = adjoint_shape
+        y = torch.empty(B, H, W, C, dtype=BF16, device=x.device)
+        adj = 1
+    _lib.check(_lib.load().rgbd_fold_4x4s2_bf16(_ptr(x), _ptr(y), B, H, W, C, adj, _stream()), "rgbd_fold_4x4s2_bf16")
+    return y
+
+
+def pad_last(x, C1):
+    """Last dimension C0 -> C1 (zero tail when C1 > C0, slice when C1 < C0); bf16 or fp32, contiguous."""
+    if not x.is_cuda or not x.is_contiguous() or x.dtype not in (BF16, F32):
+        raise RuntimeError("pad_last: expected a contiguous bf16 / fp32 GPU tensor")
+    C0 = x.shape[-1]
+    y = torch.empty(*x.shape[:-1], C1, dtype=x.dtype, device=x.device)
+    _lib.check(_lib.load().rgbd_pad_last(_ptr(x), _ptr(y), x.numel() // C0, C0, C1, x.element_size(), _stream()), "rgbd_pad_last")
+    return y

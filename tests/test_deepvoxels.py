@@ -121,3 +121,56 @@ def test_hip_accumulative_occlusion_forward_backward():
     for got, ref in zip(pd, params):
         scale = float(ref.grad.abs().max())
         torch.testing.assert_close(got.grad.cpu(), ref.grad, atol=2e-3 * scale, rtol=2e-3)
+
+
+# ---- layout folds of the DeepVoxels networks (deepvoxels_generator.py): HIP ops against the torch formulations
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,D0,H,C,up", [(2, 4, 4, 64, True), (3, 8, 8, 64, False), (1, 16, 16, 128, True), (2, 32, 32, 64, False)])
+def test_fold_depth_taps_matches_torch_and_its_backward_is_the_adjoint(B, D0, H, C, up):
+    from rgbd_gan_amd import functional as Fn
+    from rgbd_gan_amd.deepvoxels_generator import fold_depth_taps
+    g = torch.Generator().manual_seed(B + D0 + C)
+    x = torch.randn(B, D0, H, H, C, generator=g).to(torch.bfloat16)
+    xr = x.float().requires_grad_(True)
+    xs = xr.unsqueeze(2).expand(B, D0, 2, H, H, C).reshape(B, 2 * D0, H, H, C) if up else xr
+    ref = fold_depth_taps(xs)
+    dy = torch.randn(ref.shape, generator=g).to(torch.bfloat16)
+    ref.backward(dy.float())
+    xd = x.cuda().requires_grad_(True)
+    got = Fn.fold_depth_taps(xd, up)
+    assert torch.equal(got.cpu().float(), ref.detach())                      # a pure rearrangement: exact
+    got.backward(dy.cuda())
+    torch.testing.assert_close(xd.grad.float().cpu(), xr.grad.to(torch.bfloat16).float(), rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,C", [(2, 8, 64), (3, 64, 32), (1, 32, 512)])
+def test_fold_4x4s2_matches_torch_and_its_backward_is_the_adjoint(B, H, C):
+    from rgbd_gan_amd import functional as Fn
+    from rgbd_gan_amd.deepvoxels_generator import fold_4x4s2
+    g = torch.Generator().manual_seed(B + H + C)
+    x = torch.randn(B, H, H, C, generator=g).to(torch.bfloat16)
+    xr = x.float().requires_grad_(True)
+    ref = fold_4x4s2(xr)
+    dy = torch.randn(ref.shape, generator=g).to(torch.bfloat16)
+    ref.backward(dy.float())
+    xd = x.cuda().requires_grad_(True)
+    got = Fn.fold_4x4s2(xd)
+    assert torch.equal(got.cpu().float(), ref.detach())
+    got.backward(dy.cuda())
+    torch.testing.assert_close(xd.grad.float().cpu(), xr.grad.to(torch.bfloat16).float(), rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,n,dtype", [((5, 32), 64, torch.float32), ((2, 4, 4, 4, 32), 64, torch.bfloat16),
+                                           ((7, 3), 64, torch.bfloat16), ((1, 288), 320, torch.float32)])
+def test_pad_last_and_its_backward(shape, n, dtype):
+    from rgbd_gan_amd import functional as Fn
+    x = torch.randn(*shape).to(dtype)
+    xd = x.cuda().requires_grad_(True)
+    y = Fn.pad_last(xd, n)
+    assert y.shape == shape[:-1] + (n,) and torch.equal(y[..., :shape[-1]].cpu(), x)
+    assert float(y[..., shape[-1]:].abs().max()) == 0.0
+    dy = torch.randn(*y.shape).to(dtype).cuda()
+    y.backward(dy)
+    assert torch.equal(xd.grad, dy[..., :shape[-1]])
