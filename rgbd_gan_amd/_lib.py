@@ -33,6 +33,7 @@ PROTOTYPES = {
     "rgbd_fold_depth_taps_bf16": ([_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P], c_int),
     "rgbd_fold_4x4s2_bf16": ([_P, _P, c_int, c_int, c_int, c_int, c_int, _P], c_int),
     "rgbd_pad_last": ([_P, _P, c_int64, c_int, c_int, c_int, _P], c_int),
+    "rgbd_fold_weight_f32": ([_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P], c_int),
     "rgbd_debug_l2_sync": ([_P], c_int),
     "rgbd_conv2d_wgrad_workspace": ([c_int, c_int, c_int, c_int, c_int, c_int], c_int64),
     "rgbd_conv2d_wgrad_bf16": ([_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P], c_int),

@@ -656,3 +656,71 @@ extern "C" int rgbd_pad_last(const void* x, void* y, int64_t rows, int C0, int C
     RGBD_CHECK_LAUNCH("pad_last_kernel");
     return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------------ weight folds
+// Master parameter (reference shape) -> the (Cop, Cfp, KH, KW) fp32 weight the 2-D conv engine packs, and the adjoint
+// (gradient of the folded weight -> gradient of the master).  The maps are injective, so both directions are gathers.
+//   mode 0: (Co,Ci,3,3,3) -> (Cop, 3*Cip, 3, 3), input channel kd*Cip + ci   (3x3x3 conv over depth slices)
+//   mode 1: (Co,Ci,4,4)   -> (Cop, 16*Cip, 1, 1), input channel (ky*4+kx)*Cip + ci   (4x4 stride-2 conv as a 1x1)
+//   mode 2: (Co,Ci,K,K)   -> (Cop, Cip, K, K)   (channel padding only)
+namespace {
+struct FoldW { int mode, Co, Ci, K, Cop, Cip; };
+__device__ __forceinline__ long fold_w_master_index(const FoldW& f, long e) {      // folded element -> master element or -1
+    if (f.mode == 0) {
+        const int kw = (int)(e % 3), kh = (int)(e / 3 % 3);
+        const int cf = (int)(e / 9 % (3 * f.Cip)), co = (int)(e / 9 / (3 * f.Cip));
+        const int kd = cf / f.Cip, ci = cf - kd * f.Cip;
+        return (co < f.Co && ci < f.Ci) ? ((((long)co * f.Ci + ci) * 3 + kd) * 3 + kh) * 3 + kw : -1;
+    }
+    if (f.mode == 1) {
+        const int cf = (int)(e % (16 * f.Cip)), co = (int)(e / (16 * f.Cip));
+        const int t = cf / f.Cip, ci = cf - t * f.Cip;
+        return (co < f.Co && ci < f.Ci) ? (((long)co * f.Ci + ci) * 4 + (t >> 2)) * 4 + (t & 3) : -1;
+    }
+    const int kk = f.K * f.K;
+    const int k = (int)(e % kk), ci = (int)(e / kk % f.Cip), co = (int)(e / kk / f.Cip);
+    return (co < f.Co && ci < f.Ci) ? ((long)co * f.Ci + ci) * kk + k : -1;
+}
+__device__ __forceinline__ long fold_w_folded_index(const FoldW& f, long m) {      // master element -> folded element
+    if (f.mode == 0) {
+        const int kw = (int)(m % 3), kh = (int)(m / 3 % 3), kd = (int)(m / 9 % 3);
+        const int ci = (int)(m / 27 % f.Ci), co = (int)(m / 27 / f.Ci);
+        return (((long)co * 3 * f.Cip + kd * f.Cip + ci) * 3 + kh) * 3 + kw;
+    }
+    if (f.mode == 1) {
+        const int kx = (int)(m % 4), ky = (int)(m / 4 % 4), ci = (int)(m / 16 % f.Ci), co = (int)(m / 16 / f.Ci);
+        return (long)co * 16 * f.Cip + (ky * 4 + kx) * f.Cip + ci;
+    }
+    const int kk = f.K * f.K;
+    const int k = (int)(m % kk), ci = (int)(m / kk % f.Ci), co = (int)(m / kk / f.Ci);
+    return ((long)co * f.Cip + ci) * kk + k;
+}
+__global__ __launch_bounds__(256) void fold_weight_kernel(const float* __restrict__ src, float* __restrict__ dst, FoldW f,
+                                                          long n_folded, long n_master, int adjoint) {
+    const long total = adjoint ? n_master : n_folded;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        if (adjoint) {
+            dst[e] = src[fold_w_folded_index(f, e)];
+        } else {
+            const long m = fold_w_master_index(f, e);
+            dst[e] = m >= 0 ? src[m] : 0.f;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int rgbd_fold_weight_f32(const float* src, float* dst, int mode, int Co, int Ci, int K, int Cop, int Cip, int adjoint,
+                                    void* stream) {
+    RGBD_REQUIRE(src && dst && mode >= 0 && mode <= 2 && Co > 0 && Ci > 0 && Cop >= Co && Cip >= Ci && K > 0,
+                 "rgbd_fold_weight_f32: bad arguments");
+    RGBD_REQUIRE(mode != 0 || K == 3, "rgbd_fold_weight_f32: mode 0 folds 3x3x3 kernels");
+    RGBD_REQUIRE(mode != 1 || K == 4, "rgbd_fold_weight_f32: mode 1 folds 4x4 kernels");
+    const FoldW f = {mode, Co, Ci, K, Cop, Cip};
+    const long n_master = (long)Co * Ci * (mode == 0 ? 27 : K * K);
+    const long n_folded = mode == 0 ? (long)Cop * 3 * Cip * 9 : mode == 1 ? (long)Cop * 16 * Cip : (long)Cop * Cip * K * K;
+    fold_weight_kernel<<<fold_blocks(adjoint ? n_master : n_folded), 256, 0, (hipStream_t)stream>>>(src, dst, f, n_folded, n_master,
+                                                                                                     adjoint ? 1 : 0);
+    RGBD_CHECK_LAUNCH("fold_weight_kernel");
+    return 0;
+}

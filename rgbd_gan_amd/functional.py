@@ -1185,3 +1185,20 @@ def fold_4x4s2(x):
 def pad_last(x, n):
     """Zero-pad the last dimension to n entries."""
     return x if x.shape[-1] == n else _PadLast.apply(x, n)
+
+
+class _FoldWeight(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, W, mode, Cop, Cip):
+        ctx.args = (mode, W.shape[0], W.shape[1], W.shape[-1], Cop, Cip)
+        return kernels.fold_weight(W.contiguous(), *ctx.args)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        return kernels.fold_weight(g.contiguous(), *ctx.args, adjoint=True), None, None, None
+
+
+def fold_weight(W, mode, Cop, Cip):
+    """Master conv parameter -> the weight the 2-D conv engine packs (kernels.fold_weight), differentiable."""
+    return _FoldWeight.apply(W, mode, Cop, Cip)

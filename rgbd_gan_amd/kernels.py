@@ -895,3 +895,17 @@ def pad_last(x, C1):
     y = torch.empty(*x.shape[:-1], C1, dtype=x.dtype, device=x.device)
     _lib.check(_lib.load().rgbd_pad_last(_ptr(x), _ptr(y), x.numel() // C0, C0, C1, x.element_size(), _stream()), "rgbd_pad_last")
     return y
+
+
+def fold_weight(src, mode, Co, Ci, K, Cop, Cip, adjoint=False):
+    """mode 0: (Co,Ci,3,3,3) -> (Cop,3*Cip,3,3); 1: (Co,Ci,4,4) -> (Cop,16*Cip,1,1); 2: (Co,Ci,K,K) -> (Cop,Cip,K,K); fp32.
+    adjoint: src is the folded weight's gradient, the result the master's."""
+    _chk(src, F32, "src")
+    folded = (Cop, 3 * Cip, 3, 3) if mode == 0 else (Cop, 16 * Cip, 1, 1) if mode == 1 else (Cop, Cip, K, K)
+    master = (Co, Ci, 3, 3, 3) if mode == 0 else (Co, Ci, K, K)
+    if tuple(src.shape) != (folded if adjoint else master):
+        raise RuntimeError(f"fold_weight: mode {mode} expects {folded if adjoint else master}, got {tuple(src.shape)}")
+    dst = torch.empty(master if adjoint else folded, dtype=F32, device=src.device)
+    _lib.check(_lib.load().rgbd_fold_weight_f32(_ptr(src), _ptr(dst), mode, Co, Ci, K, Cop, Cip, int(bool(adjoint)), _stream()),
+               "rgbd_fold_weight_f32")
+    return dst
