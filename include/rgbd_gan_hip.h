@@ -340,7 +340,7 @@ int rgbd_fold_depth_taps_bf16(const void* x, void* y, int B, int D0, int H, int 
 int rgbd_fold_4x4s2_bf16(const void* x, void* y, int B, int H, int W, int C, int adjoint, void* stream);
 int rgbd_pad_last(const void* x, void* y, int64_t rows, int C0, int C1, int elem_bytes, void* stream);
 /* Master parameter (reference shape, fp32) -> the (Cop,Cfp,KH,KW) weight the conv engine packs; adjoint != 0: gradient of the
- * folded weight -> gradient of the master.  mode 0: (Co,Ci,3,3,3) -> (Cop,3*Cip,3,3) [deepvoxels_generator.py:112-168,
+ * folded weight -> gradient of the master (adjoint == 2: added to dst).  mode 0: (Co,Ci,3,3,3) -> (Cop,3*Cip,3,3) [deepvoxels_generator.py:112-168,
  * pggan.py:27-38]; mode 1: (Co,Ci,4,4) -> (Cop,16*Cip,1,1) [:191-205]; mode 2: (Co,Ci,K,K) -> (Cop,Cip,K,K) (zero padding). */
 int rgbd_fold_weight_f32(const float* src, float* dst, int mode, int Co, int Ci, int K, int Cop, int Cip, int adjoint,
                          void* stream);

@@ -701,7 +701,8 @@ __global__ __launch_bounds__(256) void fold_weight_kernel(const float* __restric
     const long total = adjoint ? n_master : n_folded;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
         if (adjoint) {
-            dst[e] = src[fold_w_folded_index(f, e)];
+            const float v = src[fold_w_folded_index(f, e)];
+            dst[e] = adjoint == 2 ? dst[e] + v : v;       // 2: accumulate into the master's gradient buffer
         } else {
             const long m = fold_w_master_index(f, e);
             dst[e] = m >= 0 ? src[m] : 0.f;
@@ -720,7 +721,7 @@ extern "C" int rgbd_fold_weight_f32(const float* src, float* dst, int mode, int 
     const long n_master = (long)Co * Ci * (mode == 0 ? 27 : K * K);
     const long n_folded = mode == 0 ? (long)Cop * 3 * Cip * 9 : mode == 1 ? (long)Cop * 16 * Cip : (long)Cop * Cip * K * K;
     fold_weight_kernel<<<fold_blocks(adjoint ? n_master : n_folded), 256, 0, (hipStream_t)stream>>>(src, dst, f, n_folded, n_master,
-                                                                                                     adjoint ? 1 : 0);
+                                                                                                     adjoint);
     RGBD_CHECK_LAUNCH("fold_weight_kernel");
     return 0;
 }

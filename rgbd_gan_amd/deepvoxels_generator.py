@@ -67,13 +67,16 @@ def fold_depth_taps(x):
     return torch.cat([xp[:, 0:D], xp[:, 1:D + 1], xp[:, 2:D + 2]], dim=-1).reshape(B * D, H, W, 3 * C)
 
 
+def _fold_args(W, mode):
+    """(mode, Cop, Cip) of kernels.fold_weight for master parameter W."""
+    return (mode, _ceil64(W.shape[0]) if mode != 1 else W.shape[0], _ceil64(W.shape[1]) if mode != 1 else W.shape[1])
+
+
 def _fold_w(W, mode):
     """Master parameter -> the conv engine's weight: mode 0 3x3x3 depth-tap fold, 1 4x4 stride-2 tap fold, 2 channel padding
     only; on the device one launch each way (rgbd_fold_weight_f32), on the CPU the torch formulations below."""
     if W.is_cuda:
-        cop = _ceil64(W.shape[0]) if mode != 1 else W.shape[0]
-        cip = _ceil64(W.shape[1]) if mode != 1 else W.shape[1]
-        return Fn.fold_weight(W, mode, cop, cip)
+        return Fn.fold_weight(W, *_fold_args(W, mode))
     if mode == 0:
         return fold_conv3d_weight(W)
     if mode == 1:
@@ -174,13 +177,13 @@ class VoxelGenerator(_Link, _StyleMixin):
             self.c1.append(self._conv3d_layer(f"net/{i}/c1/c/W", co))
         W = self.p["out/c/W"]
         self.out = Fn.DerivedConvLayer(
-            lambda: _fold_w(W.reshape(W.shape[0], W.shape[1], 1, 1), 2), _inv_c(W.shape[1]), 1, 0)
+            lambda: _fold_w(W.reshape(W.shape[0], W.shape[1], 1, 1), 2), _inv_c(W.shape[1]), 1, 0)      # (5-D master: autograd path)
 
     def _conv3d_layer(self, name, cin):
         """(Cout,Cin,3,3,3) -> (Cout64, 3*Cin64, 3, 3) with input channel index kd*Cin64 + ci.
         pggan.py:31: inv_c = sqrt(2) * sqrt(1 / (in_ch * ksize**2)) -- ksize squared, also in 3-D."""
         W = self.p[name]
-        return Fn.DerivedConvLayer(lambda: _fold_w(W, 0), _inv_c(cin * 9), 3, 1)
+        return Fn.DerivedConvLayer(lambda: _fold_w(W, 0), _inv_c(cin * 9), 3, 1, master=W, fold=_fold_args(W, 0))
 
     @staticmethod
     def _conv3d(x, layer, bias, upsample):
@@ -259,12 +262,14 @@ class StyleGenerator(_Link, _StyleMixin):
         self.layers = {}
         for name in ("c0", "c1"):                       # 4x4 stride 2 pad 1 -> 1x1 over 16 folded taps
             W = p[name + "/c/W"]
-            self.layers[name] = Fn.DerivedConvLayer(lambda W=W: _fold_w(W, 1), _inv_c(W.shape[1] * 16), 1, 0)
+            self.layers[name] = Fn.DerivedConvLayer(lambda W=W: _fold_w(W, 1), _inv_c(W.shape[1] * 16), 1, 0, master=W,
+                                                    fold=_fold_args(W, 1))
         for name in ("c4", "c5", "c6"):
             W = p[name + "/c/W"]
             self.layers[name] = Fn.ConvLayer(W, _inv_c(W.shape[1] * 9), 1)
         W7 = p["c7/c/W"]
-        self.layers["c7"] = Fn.DerivedConvLayer(lambda: _fold_w(W7, 2), _inv_c(W7.shape[1] * 9, 0.5), 3, 1)
+        self.layers["c7"] = Fn.DerivedConvLayer(lambda: _fold_w(W7, 2), _inv_c(W7.shape[1] * 9, 0.5), 3, 1, master=W7,
+                                                fold=_fold_args(W7, 2))
 
     def __call__(self, h, w, stage=None):
         p = self.p

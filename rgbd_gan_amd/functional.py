@@ -138,10 +138,14 @@ class DerivedConvLayer(ConvLayer):
     `derive()` returns the (Cout',Cin',K,K) fp32 tensor attached to the master, so weight gradients flow back through
     ordinary autograd instead of the direct flat-buffer accumulation."""
 
-    def __init__(self, derive, inv_c, K, pad):
+    def __init__(self, derive, inv_c, K, pad, master=None, fold=None):
+        """master / fold = (mode, Cop, Cip) of kernels.fold_weight: when given, a backward pass run under deferred_wgrads
+        routes this layer's weight gradient around autograd -- into a temporary through the batched weight-gradient launch,
+        then through the fold's adjoint straight into master.grad."""
         self.derive = derive
         self.inv_c = float(inv_c)
         self.K, self.pad = K, pad
+        self.master, self.fold = master, fold
         self._epoch = -1
         self._wf = self._wd = None
 
@@ -176,12 +180,31 @@ def deferred_wgrads(items):
 
 
 def run_deferred_wgrads(items):
-    kernels.conv2d_wgrad_batch(items)
+    kernels.conv2d_wgrad_batch([it[:7] for it in items])
+    for it in items:
+        if len(it) > 7:                       # derived layer: folded gradient -> master gradient (accumulating adjoint)
+            master, (mode, cop, cip) = it[7]
+            kernels.fold_weight(it[2], mode, master.shape[0], master.shape[1], master.shape[-1], cop, cip, adjoint=True,
+                                out=master.grad)
+
+
+def _derived_deferrable(layer):
+    """A DerivedConvLayer whose master parameter is bound to a flat gradient buffer, in a plain backward pass that is
+    collecting its weight-gradient launches."""
+    m = getattr(layer, "master", None)
+    return (_DEFERRED is not None and m is not None and layer.fold is not None and not torch.is_grad_enabled()
+            and m.is_leaf and m.grad is not None and m.grad.is_contiguous() and m.data_ptr() not in _FROZEN_PTRS)
+
+
+def _wgrad_derived_deferred(x, dy, w, layer, ups):
+    temp = torch.empty(tuple(w.shape), dtype=torch.float32, device=w.device)
+    _DEFERRED.append((x.contiguous(), dy.contiguous(), temp, layer.K, layer.inv_c, bool(ups), False,
+                      (layer.master, layer.fold)))
 
 
 def _wgrad_into(x, dy, w, layer, ups):
     if _DEFERRED is not None:
-        _DEFERRED.append((x.contiguous(), dy.contiguous(), w.grad, layer.K, layer.inv_c, bool(ups)))
+        _DEFERRED.append((x.contiguous(), dy.contiguous(), w.grad, layer.K, layer.inv_c, bool(ups), True))
         return
     kernels.conv2d_wgrad(x.contiguous(), dy.contiguous(), layer.K, layer.inv_c, out=w.grad, accumulate=True,
                          upsample=bool(ups))
@@ -217,6 +240,8 @@ class _ConvFprop(torch.autograd.Function):
         if ctx.needs_input_grad[1] and not _skip_grad_of(w):
             if _direct_grad(w):
                 _wgrad_into(x, dy, w, ctx.layer, ctx.ups)
+            elif _derived_deferrable(ctx.layer):
+                _wgrad_derived_deferred(x, dy, w, ctx.layer, ctx.ups)
             else:
                 dw = _ConvWgrad.apply(x, dy, ctx.layer, ctx.ups)
         return dx, dw, None, None, (dy if ctx.needs_input_grad[4:5] == (True,) else None)
@@ -629,6 +654,8 @@ class _ConvBiasAct(torch.autograd.Function):
         if ctx.needs_input_grad[1] and not _skip_grad_of(w):
             if _direct_grad(w):
                 _wgrad_into(x, dz, w, layer, ups)
+            elif _derived_deferrable(layer):
+                _wgrad_derived_deferred(x, dz, w, layer, ups)
             else:
                 dw = _ConvWgrad.apply(x, dz, layer, ups)
         if ctx.needs_input_grad[3]:
@@ -1191,11 +1218,14 @@ class _FoldWeight(torch.autograd.Function):
     @staticmethod
     def forward(ctx, W, mode, Cop, Cip):
         ctx.args = (mode, W.shape[0], W.shape[1], W.shape[-1], Cop, Cip)
+        ctx.set_materialize_grads(False)       # a deferred weight gradient reaches the master around autograd: no zeros here
         return kernels.fold_weight(W.contiguous(), *ctx.args)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
+        if g is None:
+            return None, None, None, None
         return kernels.fold_weight(g.contiguous(), *ctx.args, adjoint=True), None, None, None
 
 

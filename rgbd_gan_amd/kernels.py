@@ -329,8 +329,10 @@ def conv2d_wgrad_batch(items):
     lib = _lib.load()
     tab = np.zeros(len(items), dtype=WGRAD_REDUCE_DESC)
     assert tab.dtype.itemsize == 40
-    keep, multi, multi_small = [], [], []
-    for i, (x, dy, target, K, scale, ups) in enumerate(items):
+    keep, multi, multi_small, accs = [], [], [], {}
+    for i, item in enumerate(items):
+        x, dy, target, K, scale, ups = item[:6]
+        acc_flag = int(bool(item[6])) if len(item) > 6 else 1
         _chk(x, BF16, "x"); _chk(dy, BF16, "dy"); _chk(target, F32, "target")
         B, H, W, Cin = x.shape
         if ups:
@@ -351,9 +353,11 @@ def conv2d_wgrad_batch(items):
             continue
         if _multi_ok(H, W, K) and len(items) > 1:
             multi.append((i, x, dy, B, H, W, Cin, Cout, bool(ups)))
+            accs[i] = acc_flag
             continue
         if _multi_small_ok(H, W, K) and len(items) > 1 and not os.environ.get("RGBD_NO_WGRAD_MULTI_SMALL"):
             multi_small.append((i, x, dy, B, H, W, Cin, Cout, bool(ups)))
+            accs[i] = acc_flag
             continue
         ws_bytes = lib.rgbd_conv2d_wgrad_workspace(B, H, W, Cin, Cout, K)
         if ws_bytes < 0:
@@ -366,7 +370,7 @@ def conv2d_wgrad_batch(items):
                     lambda: lib.rgbd_conv2d_wgrad_partial_bf16(_ptr(x), _ptr(dy), _ptr(ws), B, H, W, Cin, Cout, K,
                                                                int(bool(ups)), _stream()))
         _lib.check(rc, "rgbd_conv2d_wgrad_partial_bf16")
-        tab[i] = (ws.data_ptr(), target.data_ptr(), ws_bytes // (4 * K * K * Cout * Cin), K * K, Cout, Cin, float(scale), 1)
+        tab[i] = (ws.data_ptr(), target.data_ptr(), ws_bytes // (4 * K * K * Cout * Cin), K * K, Cout, Cin, float(scale), acc_flag)
     groups = [multi[g0:g0 + WGRAD_MULTI_MAX] for g0 in range(0, len(multi), WGRAD_MULTI_MAX)] + \
              [multi_small[g0:g0 + WGRAD_MULTI_MAX] for g0 in range(0, len(multi_small), WGRAD_MULTI_MAX)]
     for group in groups:
@@ -384,7 +388,7 @@ def conv2d_wgrad_batch(items):
             off += n
             flops += 2.0 * B * H * W * Cout * Cin * 9
             nbytes += 2.0 * (x.numel() + dy.numel()) + 8.0 * n
-            tab[i] = (q.workspace, items[i][2].data_ptr(), q.nsplit, 9, Cout, Cin, float(items[i][4]), 1)
+            tab[i] = (q.workspace, items[i][2].data_ptr(), q.nsplit, 9, Cout, Cin, float(items[i][4]), accs[i])
         rc = _timed("conv_wgrad_kernel<9>+reduce", flops, nbytes,
                     lambda: lib.rgbd_conv2d_wgrad_partial_multi_bf16(probs, len(group), _stream()))
         _lib.check(rc, "rgbd_conv2d_wgrad_partial_multi_bf16")
@@ -897,15 +901,19 @@ def pad_last(x, C1):
     return y
 
 
-def fold_weight(src, mode, Co, Ci, K, Cop, Cip, adjoint=False):
+def fold_weight(src, mode, Co, Ci, K, Cop, Cip, adjoint=False, out=None):
     """mode 0: (Co,Ci,3,3,3) -> (Cop,3*Cip,3,3); 1: (Co,Ci,4,4) -> (Cop,16*Cip,1,1); 2: (Co,Ci,K,K) -> (Cop,Cip,K,K); fp32.
-    adjoint: src is the folded weight's gradient, the result the master's."""
-    _chk(src, F32, "src")
+    adjoint: src is the folded weight's gradient, the result the master's; with `out` (master-shaped, contiguous) the adjoint is
+    ADDED to it."""
+    _chk(src, F32, "src"); _chk(out, F32, "out")
     folded = (Cop, 3 * Cip, 3, 3) if mode == 0 else (Cop, 16 * Cip, 1, 1) if mode == 1 else (Cop, Cip, K, K)
     master = (Co, Ci, 3, 3, 3) if mode == 0 else (Co, Ci, K, K)
     if tuple(src.shape) != (folded if adjoint else master):
         raise RuntimeError(f"fold_weight: mode {mode} expects {folded if adjoint else master}, got {tuple(src.shape)}")
-    dst = torch.empty(master if adjoint else folded, dtype=F32, device=src.device)
-    _lib.check(_lib.load().rgbd_fold_weight_f32(_ptr(src), _ptr(dst), mode, Co, Ci, K, Cop, Cip, int(bool(adjoint)), _stream()),
+    if out is not None and (not adjoint or tuple(out.shape) != master or not out.is_contiguous()):
+        raise RuntimeError("fold_weight: `out` is the master-shaped, contiguous accumulation target of the adjoint")
+    dst = out if out is not None else torch.empty(master if adjoint else folded, dtype=F32, device=src.device)
+    flag = 2 if out is not None else int(bool(adjoint))
+    _lib.check(_lib.load().rgbd_fold_weight_f32(_ptr(src), _ptr(dst), mode, Co, Ci, K, Cop, Cip, flag, _stream()),
                "rgbd_fold_weight_f32")
     return dst

@@ -95,7 +95,12 @@ class DeepVoxelsUpdater(RGBDUpdater):
             obs["gen/loss_rotate"] = rot.detach()
             weight = cfg.lambda_loss_rotate if cfg.lambda_loss_rotatec else 0.3          # sic (:202)
             loss = loss + weight * rot
-        loss.backward()
+        # weight gradients are leaves of the backward pass: collected while it runs, issued as one batch afterwards (the
+        # folded 3-D / stride-2 layers go through temporaries and the folds' adjoints into their masters' gradients)
+        wgrads = []
+        with Fn.deferred_wgrads(wgrads):
+            loss.backward()
+        Fn.run_deferred_wgrads(wgrads)
         for name in ("map", "gen"):
             self.get_optimizer(name).update()
 
@@ -120,7 +125,10 @@ class DeepVoxelsUpdater(RGBDUpdater):
             gp = self.lambda_gp * loss_l2(torch.sqrt(torch.sum(g ** 2, dim=(1, 2, 3))), 0.0)
             obs["dis/loss_gp"] = gp.detach()
             total = adv + gp
-        total.backward()
+        wgrads = []
+        with Fn.deferred_wgrads(wgrads):
+            total.backward()
+        Fn.run_deferred_wgrads(wgrads)
         self.get_optimizer("dis").update()
 
     def update_core(self, batch=None, z_fake=None, thetas=None):
