@@ -151,7 +151,14 @@ class DerivedConvLayer(ConvLayer):
 
     @property
     def weight(self):
-        return self.derive()
+        # one derivation per weight epoch and autograd context: the conv node and packed() ask for it in the same forward
+        # pass (a tensor derived with autograd history also serves a later no-grad caller of the same epoch)
+        c = getattr(self, "_derived", None)
+        if c is not None and c[0] == _WEIGHT_EPOCH and (c[1].requires_grad or not torch.is_grad_enabled()):
+            return c[1]
+        w = self.derive()
+        self._derived = (_WEIGHT_EPOCH, w)
+        return w
 
 
 def _direct_grad(p):
