@@ -184,15 +184,35 @@ __global__ __launch_bounds__(256) void trilinear_bwd_scatter_kernel(const float*
         }
     }
     __syncthreads();
-    const int f = tid & 31, e0 = tid >> 5;                        // 8 samples in flight, 32 feature lanes each
+    // 32 feature lanes x 8 runs of 8 CONSECUTIVE samples: consecutive compacted samples are neighbouring pixels of one
+    // frustum row, whose corner voxels change every 2-3 pixels, so a lane adds up the contributions to the same voxel (per
+    // corner slot) in a register and issues one atomic per run of equal voxels instead of one per sample
+    const int f = tid & 31, e0 = (tid >> 5) * 8;
     if (f >= F) return;
     const long g3 = (long)G * G * G;
     float* base = ws + (long)b * g3 * F + f;
-    for (int e = e0; e < TRI_S; e += 8) {
-        if (p0 + e >= cnt) break;
-        const float go = tile[e][f];
+    const int e1 = min(e0 + 8, cnt - p0);
+    if (e0 >= e1) return;
+    float go[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) atomicAdd(base + (long)co[e][k] * F, go * cw[e][k]);
+    for (int i = 0; i < 8; ++i) go[i] = e0 + i < e1 ? tile[e0 + i][f] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        int cur = co[e0][k];
+        float acc = go[0] * cw[e0][k];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) {
+            if (e0 + i < e1) {
+                const int v = co[e0 + i][k];
+                if (v != cur) {
+                    atomicAdd(base + (long)cur * F, acc);
+                    cur = v;
+                    acc = 0.f;
+                }
+                acc += go[i] * cw[e0 + i][k];
+            }
+        }
+        atomicAdd(base + (long)cur * F, acc);
     }
 }
 
