@@ -349,6 +349,12 @@ int rgbd_trilinear_fwd(const float* grid, const int32_t* idx, const float* coord
 int rgbd_trilinear_bwd(const float* dout, const int32_t* idx, const float* coords, const int32_t* counts, float* dgrid,
                        float* workspace /* B*G^3*F floats: feature-major scatter target */, int B, int F, int G, int N,
                        void* stream);
+/* The same resampling on a FEATURE-MINOR grid (B,G,G,G,F) -- what the voxel generator's NHWC conv stack produces, no
+ * transposition on either side: 8 line reads per sample forward, and the backward's scatter target IS the gradient. */
+int rgbd_trilinear_fwd_fm(const float* grid_fm, const int32_t* idx, const float* coords, const int32_t* counts, float* out,
+                          int B, int F, int G, int N, void* stream);
+int rgbd_trilinear_bwd_fm(const float* dout, const int32_t* idx, const float* coords, const int32_t* counts, float* dgrid_fm,
+                          int B, int F, int G, int N, void* stream);
 int rgbd_occlusion_accum_fwd(const float* vol, const float* W1, const float* b1, const float* W2, const float* b2,
                              float threshold, float voxel_size, float near_plane, float* s, float* w, float* feat,
                              float* depth, int B, int F, int D, int HW, void* stream);

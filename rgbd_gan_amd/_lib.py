@@ -76,6 +76,8 @@ PROTOTYPES = {
     "rgbd_proj_idcs": ([_P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_float,
                         _P, _P, _P, _P, _P], c_int),
     "rgbd_trilinear_fwd": ([_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P], c_int),
+    "rgbd_trilinear_fwd_fm": ([_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P], c_int),
+    "rgbd_trilinear_bwd_fm": ([_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P], c_int),
     "rgbd_trilinear_bwd": ([_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P], c_int),
     "rgbd_occlusion_accum_fwd": ([_P, _P, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P, _P, c_int, c_int, c_int,
                                   c_int, _P], c_int),

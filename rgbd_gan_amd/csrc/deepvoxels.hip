@@ -216,6 +216,56 @@ __global__ __launch_bounds__(256) void trilinear_bwd_scatter_kernel(const float*
     }
 }
 
+// Forward from a FEATURE-MINOR grid (B, G^3, F) -- the layout the voxel generator's NHWC conv stack produces: the 32
+// features of a corner are one 128-byte line, so a sample costs 8 line reads instead of 256 scattered 4-byte gathers.  A
+// block takes 64 compacted samples: 32 feature lanes x 8 sample groups accumulate (same term order as
+// trilinear_fwd_kernel: bit-identical values), the tile turns in LDS and leaves sample-major.
+__global__ __launch_bounds__(256) void trilinear_fwd_fm_kernel(const float* __restrict__ grid, const int* __restrict__ idx,
+                                                               const float* __restrict__ coords,
+                                                               const int* __restrict__ counts, float* __restrict__ out, int F,
+                                                               int G, int N) {
+    __shared__ float tile[TRI_S][33];
+    __shared__ int co[TRI_S][8], nn[TRI_S];
+    __shared__ float cw[TRI_S][8];
+    const int b = blockIdx.y;
+    const int p0 = blockIdx.x * TRI_S;
+    const int cnt = counts[b];
+    if (p0 >= cnt) return;
+    const int tid = threadIdx.x;
+    if (tid < TRI_S) {
+        const int pos = p0 + tid;
+        if (pos < cnt) {
+            const Corners c = trilinear_corners(coords, (long)b * 3 * N, N, pos, G);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { co[tid][k] = c.o[k]; cw[tid][k] = c.w[k]; }
+            nn[tid] = idx[(long)b * N + pos];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { co[tid][k] = 0; cw[tid][k] = 0.f; }
+            nn[tid] = -1;
+        }
+    }
+    __syncthreads();
+    const long g3 = (long)G * G * G;
+    {
+        const int f = tid & 31, e0 = tid >> 5;
+        if (f < F) {
+            const float* g = grid + (long)b * g3 * F + f;
+            for (int e = e0; e < TRI_S; e += 8) {
+                float acc = g[(long)co[e][0] * F] * cw[e][0];
+#pragma unroll
+                for (int k = 1; k < 8; ++k) acc = acc + g[(long)co[e][k] * F] * cw[e][k];
+                tile[e][f] = acc;
+            }
+        }
+    }
+    __syncthreads();
+    const int p = tid & (TRI_S - 1), fq = tid >> 6;
+    const int n = nn[p];
+    if (n >= 0)
+        for (int f = fq; f < F; f += 4) out[((long)b * F + f) * N + n] = tile[p][f];
+}
+
 // (B, V, F) -> (B, F, V) through a 32 x 32 LDS tile
 __global__ __launch_bounds__(256) void transpose_vf_kernel(const float* __restrict__ in, float* __restrict__ out, long V,
                                                            int F) {
@@ -462,6 +512,34 @@ extern "C" int rgbd_trilinear_fwd(const float* grid, const int32_t* idx, const f
     }
     trilinear_fwd_kernel<<<dim3((N + 255) / 256, B), 256, 0, st>>>(grid, idx, coords, counts, out, F, G, N);
     RGBD_CHECK_LAUNCH("trilinear_fwd_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_trilinear_fwd_fm(const float* grid_fm, const int32_t* idx, const float* coords, const int32_t* counts,
+                                     float* out, int B, int F, int G, int N, void* stream) {
+    RGBD_REQUIRE(grid_fm && idx && coords && counts && out, "rgbd_trilinear_fwd_fm: null pointer");
+    RGBD_REQUIRE(B > 0 && F > 0 && F <= 32 && G > 0 && N > 0, "rgbd_trilinear_fwd_fm: needs 0 < F <= 32 (F=%d)", F);
+    hipStream_t st = (hipStream_t)stream;
+    if (rgbd_zero_async(out, (size_t)B * F * N * sizeof(float), st) != hipSuccess) {
+        rgbd_set_error("rgbd_trilinear_fwd_fm: zero fill failed");
+        return -2;
+    }
+    trilinear_fwd_fm_kernel<<<dim3((N + TRI_S - 1) / TRI_S, B), 256, 0, st>>>(grid_fm, idx, coords, counts, out, F, G, N);
+    RGBD_CHECK_LAUNCH("trilinear_fwd_fm_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_trilinear_bwd_fm(const float* dout, const int32_t* idx, const float* coords, const int32_t* counts,
+                                     float* dgrid_fm, int B, int F, int G, int N, void* stream) {
+    RGBD_REQUIRE(dout && idx && coords && counts && dgrid_fm, "rgbd_trilinear_bwd_fm: null pointer");
+    RGBD_REQUIRE(B > 0 && F > 0 && F <= 32 && G > 0 && N > 0, "rgbd_trilinear_bwd_fm: needs 0 < F <= 32 (F=%d)", F);
+    hipStream_t st = (hipStream_t)stream;
+    if (rgbd_zero_async(dgrid_fm, (size_t)B * G * G * G * F * sizeof(float), st) != hipSuccess) {
+        rgbd_set_error("rgbd_trilinear_bwd_fm: zero fill failed");
+        return -2;
+    }
+    trilinear_bwd_scatter_kernel<<<dim3((N + TRI_S - 1) / TRI_S, B), 256, 0, st>>>(dout, idx, coords, counts, dgrid_fm, F, G, N);
+    RGBD_CHECK_LAUNCH("trilinear_bwd_scatter_kernel");
     return 0;
 }
 

@@ -39,9 +39,44 @@ class _Trilinear(torch.autograd.Function):
         return dgrid, None, None, None, None
 
 
-def interpolate_trilinear_batch(grid, idx, coords, counts, img_shape, frustrum_depth):
-    """grid (B,F,G,G,G); idx/coords/counts from ProjectionHelper.compute_proj_idcs_batch -> (B,F,depth,H,W)."""
+class _TrilinearFM(torch.autograd.Function):
+    """The same resampling on a feature-minor grid (B,G,G,G,F): the layout of the voxel generator's NHWC conv stack, so no
+    transposition before the gather and none after the backward's scatter (its target IS the gradient)."""
+
+    @staticmethod
+    def forward(ctx, grid, idx, coords, counts, N):
+        grid = grid.contiguous()
+        B, G, F = grid.shape[0], grid.shape[1], grid.shape[4]
+        out = torch.empty(B, F, N, dtype=torch.float32, device=grid.device)
+        rc = _timed("trilinear_fwd_kernel", 0.0, 4.0 * B * F * (G ** 3 + N),
+                    lambda: _lib.load().rgbd_trilinear_fwd_fm(_ptr(grid), _ptr(idx), _ptr(coords), _ptr(counts), _ptr(out),
+                                                              B, F, G, N, _stream()))
+        _lib.check(rc, "rgbd_trilinear_fwd_fm")
+        ctx.save_for_backward(idx, coords, counts)
+        ctx.dims = (B, F, G, N)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout):
+        idx, coords, counts = ctx.saved_tensors
+        B, F, G, N = ctx.dims
+        dgrid = torch.empty(B, G, G, G, F, dtype=torch.float32, device=dout.device)
+        dout = dout.contiguous()
+        rc = _timed("trilinear_bwd_kernel", 0.0, 4.0 * B * F * (G ** 3 + N),
+                    lambda: _lib.load().rgbd_trilinear_bwd_fm(_ptr(dout), _ptr(idx), _ptr(coords), _ptr(counts), _ptr(dgrid),
+                                                              B, F, G, N, _stream()))
+        _lib.check(rc, "rgbd_trilinear_bwd_fm")
+        return dgrid, None, None, None, None
+
+
+def interpolate_trilinear_batch(grid, idx, coords, counts, img_shape, frustrum_depth, feature_minor=False):
+    """grid (B,F,G,G,G) [feature_minor: (B,G,G,G,F)]; idx/coords/counts from ProjectionHelper.compute_proj_idcs_batch ->
+    (B,F,depth,H,W)."""
     N = img_shape[0] * img_shape[1] * frustrum_depth
+    if feature_minor:
+        out = _TrilinearFM.apply(grid, idx, coords, counts, N)
+        return out.reshape(grid.shape[0], grid.shape[4], frustrum_depth, img_shape[0], img_shape[1])
     out = _Trilinear.apply(grid, idx, coords, counts, N)
     return out.reshape(grid.shape[0], grid.shape[1], frustrum_depth, img_shape[0], img_shape[1])
 

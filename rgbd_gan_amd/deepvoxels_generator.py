@@ -213,13 +213,17 @@ class VoxelGenerator(_Link, _StyleMixin):
         h = self._conv3d(h, self.c1[i], _pad_to(p[pre + "/b1/b"], C), False)
         return self._style(pre + "/s1", w, h)
 
-    def __call__(self, w):
+    def __call__(self, w, feature_minor=False):
+        """feature_minor: return (B,32,32,32,ch_out) fp32 -- the conv stack's own layout, which the frustum resampling reads
+        directly (rgbd_trilinear_fwd_fm) -- instead of the reference's (B,ch_out,32,32,32)."""
         h = None
         for i in range(4):
             h = self._block(i, w, h)
         B, D, H, W, C = h.shape
         y = Fn.conv_bias(h.reshape(B * D, H, W, C), self.out, _pad_to(self.p["out/c/b"], _ceil64(self.ch_out)))
         y = y.reshape(B, D, H, W, -1)[..., :self.ch_out]
+        if feature_minor:
+            return y.float().contiguous()
         return y.permute(0, 4, 1, 2, 3).float().contiguous()                            # b x ch_out x 32 x 32 x 32
 
     forward = __call__
@@ -301,8 +305,9 @@ class DeepVoxels:
         self.voxel_size, self.near_plane = voxel_size, near_plane
         self.threshold = threshold if threshold else 4           # deepvoxel.py:555
 
-    def __call__(self, idx, coords, counts, deepvoxels):
-        vol = interpolate_trilinear_batch(deepvoxels, idx, coords, counts, self.frustrum_img_dims, self.frustrum_depth)
+    def __call__(self, idx, coords, counts, deepvoxels, feature_minor=False):
+        vol = interpolate_trilinear_batch(deepvoxels, idx, coords, counts, self.frustrum_img_dims, self.frustrum_depth,
+                                          feature_minor=feature_minor)
         p = self.p
         W1, W2 = p["0/net/1/c/W"], p["2/net/1/c/W"]
         feats, depth, _ = accumulative_occlusion(vol, W1.reshape(W1.shape[0], W1.shape[1]), p["0/net/1/c/b"],
@@ -376,8 +381,9 @@ class Generator(_Link):
             w, w2 = ww[:n], ww[n:]
         else:
             w, w2 = self.mapping(z), self.mapping(z2)
-        voxel = self.voxel_gen(w)
-        novel_feats, depth = self.deepvoxel(idx, coords, counts, voxel)
+        fm = w.is_cuda
+        voxel = self.voxel_gen(w, feature_minor=fm)
+        novel_feats, depth = self.deepvoxel(idx, coords, counts, voxel, feature_minor=fm)
         novel_img = self.style_generator(novel_feats, w2, stage)
         return torch.cat([novel_img, depth], dim=1)
 

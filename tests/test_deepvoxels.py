@@ -82,6 +82,13 @@ def test_hip_trilinear_forward_backward():
     od.backward(dout.cuda())
     torch.testing.assert_close(od.detach().cpu(), torch.cat(outs), atol=1e-5, rtol=1e-5)
     torch.testing.assert_close(gd.grad.cpu(), torch.cat(grads), atol=1e-3, rtol=1e-4)
+    # feature-minor grid (B,G,G,G,F), the voxel generator's own layout: bit-identical forward (same term order), the same
+    # gradient in the transposed layout
+    gfm = grid.permute(0, 2, 3, 4, 1).contiguous().cuda().requires_grad_(True)
+    ofm = dv.interpolate_trilinear_batch(gfm, idx, coords, counts, [64, 64], fr.depth, feature_minor=True)
+    assert torch.equal(ofm.detach(), od.detach())
+    ofm.backward(dout.cuda())
+    torch.testing.assert_close(gfm.grad.permute(0, 4, 1, 2, 3).cpu(), torch.cat(grads), atol=1e-3, rtol=1e-4)
     # reference signature, one sample
     lin, v = odv.proj_idcs_np(cams[0], fr)
     o1 = dv.interpolate_trilinear(grid[:1].cuda(), torch.from_numpy(lin).cuda(), torch.from_numpy(v).cuda(), [64, 64], fr.depth)
