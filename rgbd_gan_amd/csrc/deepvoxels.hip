@@ -599,7 +599,7 @@ extern "C" int rgbd_occlusion_accum_bwd(const float* vol, const float* W1, const
     RGBD_CHECK_LAUNCH("occ_bwd_dw_kernel");
     occ_bwd_scan_kernel<<<(unsigned)(((long)B * HW + 255) / 256), 256, 0, st>>>(a, s, dw_ws, ds_ws);
     RGBD_CHECK_LAUNCH("occ_bwd_scan_kernel");
-    occ_bwd_mlp_kernel<<<(unsigned)((nv + 255) / 256 < 1024 ? (nv + 255) / 256 : 1024), 256, 0, st>>>(a, vol, W1, b1, W2, s,
+    occ_bwd_mlp_kernel<<<(unsigned)((nv + 255) / 256 < 512 ? (nv + 255) / 256 : 512), 256, 0, st>>>(a, vol, W1, b1, W2, s,
                                                                                                          ds_ws, w, dfeat, dvol, dparams);
     RGBD_CHECK_LAUNCH("occ_bwd_mlp_kernel");
     return 0;
