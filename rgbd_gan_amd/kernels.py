@@ -348,7 +348,7 @@ def conv2d_wgrad_batch(items):
             ws = torch.empty(ws_bytes // 4, dtype=F32, device=x.device)
             keep.append(ws)
             _lib.check(lib.rgbd_conv2d_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(ws), _ptr(target), B, H, W, Cin, Cout, K,
-                                                  float(scale), 1, int(bool(ups)), _stream()), "rgbd_conv2d_wgrad_bf16")
+                                                  float(scale), acc_flag, int(bool(ups)), _stream()), "rgbd_conv2d_wgrad_bf16")
             tab[i] = (0, 0, 0, 0, 0, 0, 0.0, 0)
             continue
         if _multi_ok(H, W, K) and len(items) > 1:
