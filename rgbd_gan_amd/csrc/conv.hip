@@ -8,6 +8,9 @@
 //   upsampling (rescale.py:4-5) is folded into that gather's address arithmetic.
 //   Roofline: MFMA (bf16 dense ~2.5 PFLOP/s) for Cin,Cout >= 128; the 64-channel 128x128 layers sit at
 //   ~290-380 FLOP/B, i.e. at the HBM/MFMA ridge, so they are HBM-bound unless epilogues stay fused.
+//   Kernels: conv_fprop_kernel (generic gather, any K / pad, split-K for the 4x4 / 8x8 layers); conv3x3_sp_kernel (3x3
+//   pad-1 on images >= 16x16, the hot one: halo patch per 64-channel slice, LDS-DMA staging, register-pipelined
+//   fragments); conv3x3_patch_kernel (round 1's register-staged version of the same tiling, kept as the A/B reference).
 //
 // wgrad : dW[tap][co][ci] = sum_pixel dY[pixel][co] * X[pixel + tap][ci]
 //   The reduction index is the pixel, which is the *strided* index of both NHWC operands.  gfx950's
@@ -16,6 +19,8 @@
 //   a 64x64 (co,ci) tile in registers (144 accumulator VGPRs per lane), stages an 8x16-pixel patch of dY and the
 //   10x18 halo patch of X once, and sweeps its share of patches; partial sums leave as plain fp32 stores into
 //   one slab per workgroup (two 128-byte row segments per wave instruction) and a second kernel sums the slabs.
+//   Kernels: conv_wgrad9_body (3x3 on 8x16 patches, the hot one: every wave runs all nine taps over a three-row register
+//   window of X fragments, operands by LDS-DMA), conv_wgrad_body (1x1, small images, and the tap-split A/B reference).
 #include "common.h"
 
 #include <stdlib.h>
@@ -1530,7 +1535,7 @@ extern "C" int rgbd_debug_force_gather_kernel(int on) {
     return 0;
 }
 namespace {
-const char* g_last_conv_kernel = "";
+thread_local const char* g_last_conv_kernel = "";     // per calling thread: profiling label of its last conv launch
 }
 extern "C" const char* rgbd_last_conv_kernel(void) { return g_last_conv_kernel; }
 extern "C" int rgbd_debug_conv_variant(int v) {
@@ -1562,8 +1567,12 @@ FpropPlan plan_fprop(int B, int Hout, int Wout, int Cin, int Cout, int KH, int K
         if (s > nk / 2) s = nk / 2;
         if (s > 1) p.ksplit = (int)s;
     }
-    if (const char* e = getenv("RGBD_DEBUG_KSPLIT")) {          // tuning aid: 0 = patch kernel where eligible, n = force n
-        const int v = atoi(e);
+    static const int ksplit_env = [] {                          // tuning aid, read ONCE: 0 = patch kernel where eligible, n = force n
+        const char* e = getenv("RGBD_DEBUG_KSPLIT");
+        return e ? atoi(e) : -1;
+    }();
+    if (ksplit_env >= 0) {
+        const int v = ksplit_env;
         if (v == 0) { p.patch = eligible; p.ksplit = 1; }
         else if (v > 0) { p.patch = false; p.ksplit = v > nk / 2 ? (nk / 2 > 0 ? nk / 2 : 1) : v; }
     }
