@@ -130,6 +130,13 @@ class _StyleMixin:
         p = self.p
         c = _inv_c(self.w_ch, 1.0)
         C = h.shape[-1]
+        full = p.prefix + name
+        if h.is_cuda and self.store.shapes[full + "/s/c/W"][0] == C:
+            # scale and shift affines sit back to back in the flat buffer: one linear, [scale | shift] read in place
+            W = self.store.fused((full + "/s/c/W", full + "/b/c/W"), (2 * C, self.w_ch))
+            b = self.store.fused((full + "/s/c/b", full + "/b/c/b"), (2 * C,))
+            shp = h.shape
+            return Fn.adain_fused(h.reshape(shp[0], -1, 1, C), Fn.linear_act(w, W, b, c, act=False)).reshape(shp)
         scale = _pad_to(Fn.linear_act(w, p[name + "/s/c/W"], p[name + "/s/c/b"], c, act=False), C)
         shift = _pad_to(Fn.linear_act(w, p[name + "/b/c/W"], p[name + "/b/c/b"], c, act=False), C)
         shp = h.shape
@@ -149,9 +156,9 @@ def voxel_specs(prefix, ch, ch_out):
             specs.append((pre + "/W", (ci, 4, 4, 4), "ones"))
         specs += [(pre + "/b0/b", (co,), "zeros"), (pre + "/b1/b", (co,), "zeros"),
                   (pre + "/n0/b/W", (co,), "zeros"), (pre + "/n1/b/W", (co,), "zeros")]
-        for s in ("s0", "s1"):
-            specs += [(f"{pre}/{s}/s/c/W", (co, ch), "normal"), (f"{pre}/{s}/s/c/b", (co,), "ones"),
-                      (f"{pre}/{s}/b/c/W", (co, ch), "normal"), (f"{pre}/{s}/b/c/b", (co,), "zeros")]
+        for s in ("s0", "s1"):          # [scale W | shift W], then [scale b | shift b]: adjacent pairs (ParamStore.fused)
+            specs += [(f"{pre}/{s}/s/c/W", (co, ch), "normal"), (f"{pre}/{s}/b/c/W", (co, ch), "normal"),
+                      (f"{pre}/{s}/s/c/b", (co,), "ones"), (f"{pre}/{s}/b/c/b", (co,), "zeros")]
         specs += [(pre + "/c0/c/W", (co, ci, 3, 3, 3), "normal"), (pre + "/c1/c/W", (co, co, 3, 3, 3), "normal")]
     specs += [(prefix + "out/c/W", (ch_out, ch // 8, 1, 1, 1), "normal"), (prefix + "out/c/b", (ch_out,), "zeros")]
     return specs
@@ -248,8 +255,8 @@ def renderer_specs(prefix, w_ch, in_ch, hidden):
         specs += [(f"{prefix}{name}/c/W", (co, ci, k, k), "normal"), (f"{prefix}{name}/c/b", (co,), "zeros")]
     for name, co in {"s0": 2 * h, "s1": 4 * h, "s4": 4 * h, "s5": 2 * h, "s6": h}.items():
         pre = f"{prefix}{name}"
-        specs += [(pre + "/s/c/W", (co, w_ch), "normal"), (pre + "/s/c/b", (co,), "ones"),
-                  (pre + "/b/c/W", (co, w_ch), "normal"), (pre + "/b/c/b", (co,), "zeros")]
+        specs += [(pre + "/s/c/W", (co, w_ch), "normal"), (pre + "/b/c/W", (co, w_ch), "normal"),
+                  (pre + "/s/c/b", (co,), "ones"), (pre + "/b/c/b", (co,), "zeros")]
     return specs
 
 
