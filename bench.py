@@ -263,6 +263,10 @@ def main():
     else:
         line["step_tflops_algorithmic"] = round(value * STEP_GFLOP_PER_IMAGE / 1e3, 2)
         line["mfma_roofline_frac_whole_step"] = round(value * STEP_GFLOP_PER_IMAGE / 1e3 / (MFMA_BF16_PEAK_TFLOPS * comm.size), 4)
+        # the same throughput priced at the work the REFERENCE's dataflow spends per image (3 F_G +
+        # 11 F_D = 296.6 GFLOP, the accounting behind "40 % of MFMA peak = 3372 img/s per GPU"); the two lines above count
+        # only what this engine executes (3 F_G + 7 F_D)
+        line["mfma_roofline_frac_reference_accounting"] = round(value * 296.6 / 1e3 / (MFMA_BF16_PEAK_TFLOPS * comm.size), 4)
 
     if comm.rank == 0 and not args.no_roofline:
         # per-launch HIP-event timing of the conv kernels over extra (untimed) steps, on the launch stream
