@@ -1519,6 +1519,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(WgradMultiArgs 
                        (long)blockIdx.x - m.block_begin[i]);
 }
 
+// compute units of the CURRENT device (a process may drive several): looked up once per device, immutable afterwards
+int device_cus() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cus[dev] == 0) {
+        hipDeviceProp_t prop;
+        cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return cus[dev];
+}
 bool g_force_gather = false;   // test hook: route every shape through the generic gather kernel
 int g_conv_variant = 0;        // test / tuning hook: 1 = the register-staged conv3x3_patch_kernel instead of the ping-pong one
 
@@ -1646,14 +1657,7 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
         const int n_tiles = wide ? Cout / 128 : Cout / 64;
         // persistent workgroups: one per CU (the kernel's LDS footprint allows exactly one), split evenly over the
         // output-channel tiles; each walks a contiguous range of pixel tiles
-        static int num_cus = 0;
-        if (num_cus == 0) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-                num_cus = prop.multiProcessorCount;
-            if (num_cus <= 0) num_cus = 256;
-        }
+        const int num_cus = device_cus();
         int per_nt = num_cus / n_tiles;
         if (per_nt < 1) per_nt = 1;
         if (per_nt > ptiles) per_nt = (int)ptiles;
@@ -1885,17 +1889,6 @@ extern "C" int rgbd_wgrad_reduce_multi(const rgbd_wgrad_reduce_desc* descs, int 
 
 // ---- several weight gradients per launch (see conv_wgrad_multi_kernel)
 namespace {
-int device_cus() {
-    static int num_cus = 0;
-    if (num_cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            num_cus = prop.multiProcessorCount;
-        if (num_cus <= 0) num_cus = 256;
-    }
-    return num_cus;
-}
 bool multi_eligible(const rgbd_wgrad_problem& q) {
     return q.x && q.dy && q.K == 3 && q.Cin > 0 && q.Cout > 0 && q.Cin % 64 == 0 && q.Cout % 64 == 0 && q.B > 0 && q.H >= 8 &&
            q.W >= 16 && (q.H & (q.H - 1)) == 0 && (q.W & (q.W - 1)) == 0 && (long)q.B * q.H * q.W * q.Cin < 0x3fffffffL &&
