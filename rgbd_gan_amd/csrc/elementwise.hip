@@ -612,6 +612,50 @@ __global__ __launch_bounds__(256) void to_planes_kernel(const unsigned short* __
                                                         float* __restrict__ out, int B, int HW, int C, float wscale) {
     const int sub = threadIdx.x & 7;
     const long npix = (long)B * HW;
+    if (C == 64) {
+        // the common case (64 feature channels): a lane's 8 x KP weights are loop invariants -- in registers; two pixels'
+        // loads in flight per lane
+        float wr[KP][8];
+#pragma unroll
+        for (int k = 0; k < KP; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wr[k][j] = w[k * 64 + sub * 8 + j] * wscale;
+        float bk[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) bk[k] = bias ? bias[k] : 0.f;
+        const long step = (long)gridDim.x * 32;
+        for (long pix0 = (long)blockIdx.x * 32 + (threadIdx.x >> 3); pix0 < npix; pix0 += 2 * step) {
+            u32x4 v[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const long pix = pix0 + u * step < npix ? pix0 + u * step : pix0;
+                v[u] = *reinterpret_cast<const u32x4*>(h + pix * 64 + sub * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const long pix = pix0 + u * step;
+                float f[8], acc[KP];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { f[2 * q] = bf16_lo(v[u][q]); f[2 * q + 1] = bf16_hi(v[u][q]); }
+#pragma unroll
+                for (int k = 0; k < KP; ++k) {
+                    acc[k] = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[k] += wr[k][j] * f[j];
+                    acc[k] += __shfl_xor(acc[k], 1, 64);
+                    acc[k] += __shfl_xor(acc[k], 2, 64);
+                    acc[k] += __shfl_xor(acc[k], 4, 64);
+                }
+                if (sub == 0 && pix < npix) {
+                    const int b = (int)(pix / HW);
+                    const int p = (int)(pix - (long)b * HW);
+#pragma unroll
+                    for (int k = 0; k < KP; ++k) out[((long)b * KP + k) * HW + p] = acc[k] + bk[k];
+                }
+            }
+        }
+        return;
+    }
     for (long pix = (long)blockIdx.x * 32 + (threadIdx.x >> 3); pix < npix; pix += (long)gridDim.x * 32) {
         float acc[KP];
 #pragma unroll
@@ -1190,7 +1234,7 @@ extern "C" int rgbd_from_planes(const float* x, const float* w, const float* bia
     RGBD_REQUIRE(x && w && y, "rgbd_from_planes: null pointer");
     RGBD_REQUIRE((KP == 3 || KP == 4) && C % 8 == 0 && B > 0 && HW > 0, "rgbd_from_planes: bad shape KP=%d C=%d", KP, C);
     const long nvec = (long)B * HW * C / 8;
-    const int blocks = (int)min((long)8192, (nvec + 255) / 256);
+    const int blocks = (int)min((long)8192, (nvec + 1023) / 1024);       // four items per thread: the kernel's unroll
     hipStream_t st = (hipStream_t)stream;
     if (KP == 3) from_planes_kernel<3><<<blocks, 256, 0, st>>>(x, w, bias, (unsigned short*)y, B, HW, C, wscale, act, slope);
     else         from_planes_kernel<4><<<blocks, 256, 0, st>>>(x, w, bias, (unsigned short*)y, B, HW, C, wscale, act, slope);
@@ -1221,7 +1265,10 @@ extern "C" int rgbd_planes_outer(const void* t, const float* p, float* o, float*
         rgbd_set_error("rgbd_planes_outer: memset failed");
         return -2;
     }
-    const int rows = 512;
+    // rows per block: every block ends with (KP + 1) * 64 atomics on the same (KP + 1) * C addresses, so few, long blocks
+    // (512-row blocks: 327 K atomics, ~1000 deep per address, were 30 of the launch's 38 us) -- but at least ~256 of them
+    int rows = 512;
+    while (rows < 4096 && (long)ceil_div(HW, 2 * rows) * (C / 64) * B >= 256) rows *= 2;
     dim3 grid(ceil_div(HW, rows), C / 64, B);
     if (KP == 3) planes_outer_kernel<3><<<grid, 256, 0, st>>>((const unsigned short*)t, p, o, tsum, psum, B, HW, C, rows);
     else         planes_outer_kernel<4><<<grid, 256, 0, st>>>((const unsigned short*)t, p, o, tsum, psum, B, HW, C, rows);
