@@ -1070,7 +1070,9 @@ extern "C" int rgbd_pack_weights(const float* w, int cout, int cin, int kh, int 
 }
 
 namespace {
+constexpr int PACK_TCO = 8, PACK_TCI = 64;          // tile of the tiled path: 8 x 64 (co, ci) x up to 9 taps = 18 KB of LDS
 __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const rgbd_pack_desc* __restrict__ descs, int n) {
+    extern __shared__ float ptile[];                // [PACK_TCO][PACK_TCI * taps], as the master stores it
     int d = 0;
     for (int i = 1; i < n; ++i)
         if (descs[i].block_begin <= (int)blockIdx.x) d = i;
@@ -1079,6 +1081,33 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const rgbd_pack
     const long total = (long)D.cout * D.cin * D.taps;
     unsigned short* wf = (unsigned short*)D.w_fprop;
     unsigned short* wd = (unsigned short*)D.w_dgrad;
+    if (D.taps <= 9 && D.cin % PACK_TCI == 0 && D.cout % PACK_TCO == 0) {
+        // Tiled: the master's rows (one co: cin x taps contiguous) are read coalesced into LDS, the fprop image leaves in
+        // 128-byte runs along ci and the dgrad image in 16-byte runs along co -- the element-wise form below gathers the
+        // master with a stride of `taps` floats and scatters the dgrad image 2 bytes at a time.
+        const int T = D.taps, row = PACK_TCI * T + 1;     // odd row pitch: the co-fastest reads below stay conflict-free
+        const int tiles_ci = D.cin / PACK_TCI, tiles = tiles_ci * (D.cout / PACK_TCO);
+        for (int tile = (int)blockIdx.x - D.block_begin; tile < tiles; tile += nblk) {
+            const int co0 = (tile / tiles_ci) * PACK_TCO, ci0 = (tile % tiles_ci) * PACK_TCI;
+            for (int e = threadIdx.x; e < PACK_TCO * PACK_TCI * T; e += 256) {
+                const int r = e / (PACK_TCI * T), c = e - r * (PACK_TCI * T);
+                ptile[r * row + c] = D.w[((long)(co0 + r) * D.cin + ci0) * T + c] * D.scale;
+            }
+            __syncthreads();
+            if (wf)
+                for (int e = threadIdx.x; e < T * PACK_TCO * PACK_TCI; e += 256) {          // (tap, co, ci), ci fastest
+                    const int ci = e % PACK_TCI, r = e / PACK_TCI % PACK_TCO, tap = e / (PACK_TCI * PACK_TCO);
+                    wf[((long)tap * D.cout + co0 + r) * D.cin + ci0 + ci] = f32_to_bf16_bits(ptile[r * row + ci * T + tap]);
+                }
+            if (wd)
+                for (int e = threadIdx.x; e < T * PACK_TCO * PACK_TCI; e += 256) {          // (tap, ci, co), co fastest
+                    const int r = e % PACK_TCO, ci = e / PACK_TCO % PACK_TCI, tap = e / (PACK_TCO * PACK_TCI);
+                    wd[((long)(T - 1 - tap) * D.cin + ci0 + ci) * D.cout + co0 + r] = f32_to_bf16_bits(ptile[r * row + ci * T + tap]);
+                }
+            __syncthreads();
+        }
+        return;
+    }
     for (long e = (long)((int)blockIdx.x - D.block_begin) * 256 + threadIdx.x; e < total; e += (long)nblk * 256) {
         const int ci = (int)(e % D.cin);
         const long r = e / D.cin;
@@ -1093,7 +1122,14 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const rgbd_pack
 
 extern "C" int rgbd_pack_weights_multi(const rgbd_pack_desc* descs_device, int n, int total_blocks, void* stream) {
     RGBD_REQUIRE(descs_device && n > 0 && total_blocks > 0, "rgbd_pack_weights_multi: bad arguments");
-    pack_weights_multi_kernel<<<total_blocks, 256, 0, (hipStream_t)stream>>>(descs_device, n);
+    constexpr int lds = PACK_TCO * (PACK_TCI * 9 + 1) * (int)sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        RGBD_REQUIRE(hipFuncSetAttribute((const void*)&pack_weights_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         lds) == hipSuccess, "rgbd_pack_weights_multi: cannot reserve %d B of LDS", lds);
+        attr_done = true;
+    }
+    pack_weights_multi_kernel<<<total_blocks, 256, lds, (hipStream_t)stream>>>(descs_device, n);
     RGBD_CHECK_LAUNCH("pack_weights_multi_kernel");
     return 0;
 }

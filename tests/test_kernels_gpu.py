@@ -535,6 +535,25 @@ def test_wgrad_bodies_agree_and_repeat(B, H, Cin, Cout, ups):
         assert torch.equal(again, first), f"launch {rep}: {int((again != first).sum())} values differ"
 
 
+def test_pack_weights_multi_matches_single_layer_packing():
+    """One launch for all layers of a network (tiled through LDS for 3x3 / 1x1 layers, element-wise for the rest) gives the
+    bytes of the per-layer kernel."""
+    from rgbd_gan_amd import kernels
+    g = torch.Generator().manual_seed(3)
+    shapes = [(64, 64, 3), (128, 64, 3), (256, 256, 3), (64, 128, 1), (96, 64, 3), (256, 64, 4), (32, 192, 3)]
+    entries, refs = [], []
+    for i, (co, ci, k) in enumerate(shapes):
+        w = torch.randn(co, ci, k, k, generator=g).to(dev())
+        scale = 0.1 + 0.01 * i
+        wf = torch.zeros(k * k, co, ci, dtype=torch.bfloat16, device=dev())
+        wd = torch.zeros(k * k, ci, co, dtype=torch.bfloat16, device=dev())
+        entries.append((w, scale, wf, wd))
+        refs.append(kernels.pack_weights(w, scale))
+    kernels.pack_weights_multi(kernels.build_pack_table(entries))
+    for (w, scale, wf, wd), (rf, rd) in zip(entries, refs):
+        assert torch.equal(wf, rf) and torch.equal(wd, rd), tuple(w.shape)
+
+
 def test_elementwise_adjoint_identities_at_benchmark_sizes():
     """B = 32, 128x128 (the benchmark's tensors): pairs of kernels that are each other's adjoint, and the bilinear form
     of the 1x1 plane convs evaluated three ways, agree to the bf16 rounding of their stored outputs:
