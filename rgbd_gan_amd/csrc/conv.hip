@@ -1452,47 +1452,81 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_multi_kernel(WgradMultiLaun
     else conv_wgrad_body<NT, FAST>(a, split, tile % tiles_ci, tile / tiles_ci);
 }
 
-// Slab reduction + layout change in one launch.  A block owns 32 float4 of the packed (tap, co, ci) tile; its 256
-// threads are 32 quads x 8 slab groups: every thread sums its group's slabs with four independent loads in flight,
-// the eight partials meet in LDS, and the quad's owner writes scale * sum to the master layout dw[co][ci][tap]
-// (plain stores or read-add-write: dw is the optimizer's accumulating gradient buffer).
+// Slab reduction + layout change in one launch.  1x1 weights: a block owns 32 float4 of the packed (co, ci) tile and its
+// 256 threads are 32 quads x 8 slab groups.  3x3 weights: a block owns (one co, 32 ci, all nine taps) = 72 float4 of
+// the packed (tap, co, ci) tile as 72 quads x 3 slab groups, so that after the sum the 288 values are one contiguous run
+// of the master layout dw[co][ci][tap] -- they turn through LDS and leave as 72 float4 (the tap-strided scalar
+// read-add-write this replaces touched every 128-byte line of dw from nine different blocks).  Every thread sums its
+// group's slabs with four independent loads in flight; the owner writes scale * sum (plain stores or read-add-write: dw
+// is the optimizer's accumulating gradient buffer).
+__host__ __device__ __forceinline__ long wgrad_reduce_blocks(int taps, int cout, int cin) {
+    return taps == 9 ? (long)cout * (cin >> 5) : ((long)cout * cin / 4 + 31) / 32;
+}
+__device__ __forceinline__ f32x4 wgrad_reduce_slabs(const float* __restrict__ slabs, long total, long e4, int s_begin, int s_end) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int s2 = s_begin;
+    for (; s2 + 4 <= s_end; s2 += 4) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(slabs + (long)(s2 + 0) * total + e4);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(slabs + (long)(s2 + 1) * total + e4);
+        const f32x4 v2 = *reinterpret_cast<const f32x4*>(slabs + (long)(s2 + 2) * total + e4);
+        const f32x4 v3 = *reinterpret_cast<const f32x4*>(slabs + (long)(s2 + 3) * total + e4);
+        acc += (v0 + v1) + (v2 + v3);
+    }
+    for (; s2 < s_end; ++s2) acc += *reinterpret_cast<const f32x4*>(slabs + (long)s2 * total + e4);
+    return acc;
+}
 __device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ slabs, int nslab, float* __restrict__ dw,
                                                    int taps, int cout, int cin, float scale, int accumulate, long block) {
-    __shared__ f32x4 part[8][32];
+    __shared__ f32x4 part[8][32];                                  // 1x1: [group][quad]; 3x3: [2][72] partials, then [288] floats
     const long total = (long)taps * cout * cin;
+    if (taps == 9) {
+        const int chunks = cin >> 5;
+        const int co = (int)(block / chunks), ci0 = (int)(block - (long)co * chunks) << 5;
+        const int quad = threadIdx.x % 72, grp = threadIdx.x / 72;  // threads 216..255 idle
+        const int tap = quad >> 3, c4 = (quad & 7) << 2;
+        f32x4* part9 = &part[0][0];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (grp < 3) {
+            const int per_group = (nslab + 2) / 3;
+            const int s_begin = grp * per_group;
+            acc = wgrad_reduce_slabs(slabs, total, ((long)tap * cout + co) * cin + ci0 + c4, s_begin, min(nslab, s_begin + per_group));
+            if (grp > 0) part9[(grp - 1) * 72 + quad] = acc;
+        }
+        __syncthreads();
+        if (grp == 0) acc += part9[quad] + part9[72 + quad];
+        __syncthreads();
+        float* turn = reinterpret_cast<float*>(part9);             // [32 ci][9 taps]
+        if (grp == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) turn[(c4 + k) * 9 + tap] = acc[k] * scale;
+        }
+        __syncthreads();
+        if (grp == 0) {
+            f32x4 v = part9[quad];
+            f32x4* o = reinterpret_cast<f32x4*>(dw + ((long)co * cin + ci0) * 9) + quad;
+            if (accumulate) v += *o;
+            *o = v;
+        }
+        return;
+    }
     const int quad = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const long e4 = (block * 32 + quad) * 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (e4 < total) {
         const int per_group = (nslab + 7) >> 3;
         const int s_begin = grp * per_group;
-        const int s_end = min(nslab, s_begin + per_group);
-        int s2 = s_begin;
-        for (; s2 + 4 <= s_end; s2 += 4) {
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(slabs + (long)(s2 + 0) * total + e4);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(slabs + (long)(s2 + 1) * total + e4);
-            const f32x4 v2 = *reinterpret_cast<const f32x4*>(slabs + (long)(s2 + 2) * total + e4);
-            const f32x4 v3 = *reinterpret_cast<const f32x4*>(slabs + (long)(s2 + 3) * total + e4);
-            acc += (v0 + v1) + (v2 + v3);
-        }
-        for (; s2 < s_end; ++s2) acc += *reinterpret_cast<const f32x4*>(slabs + (long)s2 * total + e4);
+        acc = wgrad_reduce_slabs(slabs, total, e4, s_begin, min(nslab, s_begin + per_group));
     }
     part[grp][quad] = acc;
     __syncthreads();
     if (grp == 0 && e4 < total) {
 #pragma unroll
         for (int g = 1; g < 8; ++g) acc += part[g][quad];
-        // packed (tap, co, ci) -> master (co, ci, tap); cin is a multiple of 64, so the four elements share (tap, co)
-        const int ci = (int)(e4 % cin);
-        const long r = e4 / cin;
-        const int co = (int)(r % cout);
-        const int tap = (int)(r / cout);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const long o = ((long)co * cin + ci + k) * taps + tap;
-            const float v = acc[k] * scale;
-            dw[o] = accumulate ? dw[o] + v : v;
-        }
+        // taps == 1: packed (co, ci) is the master layout
+        f32x4* o = reinterpret_cast<f32x4*>(dw + e4);
+        f32x4 v = acc * scale;
+        if (accumulate) v += *o;
+        *o = v;
     }
 }
 
@@ -1852,8 +1886,7 @@ extern "C" int rgbd_conv2d_wgrad_bf16(const void* x, const void* dy, void* works
     int nsplit = 0;
     const int rc = wgrad_partial_impl(x, dy, workspace, B, H, W, Cin, Cout, K, upsample, stream, &nsplit);
     if (rc != 0) return rc;
-    const long total = (long)K * K * Cout * Cin;
-    wgrad_reduce_finish_kernel<<<(unsigned)((total / 4 + 31) / 32), 256, 0, (hipStream_t)stream>>>(
+    wgrad_reduce_finish_kernel<<<(unsigned)wgrad_reduce_blocks(K * K, Cout, Cin), 256, 0, (hipStream_t)stream>>>(
         (const float*)workspace, nsplit, dw, K * K, Cout, Cin, scale, accumulate);
     RGBD_CHECK_LAUNCH("wgrad_reduce_finish_kernel");
     return 0;
@@ -1877,7 +1910,7 @@ extern "C" int rgbd_wgrad_reduce_multi(const rgbd_wgrad_reduce_desc* descs, int 
                          d.cin % 64 == 0 && d.cout % 64 == 0, "rgbd_wgrad_reduce_multi: bad descriptor %d", base + i);
             m.d[i] = d;
             m.block_begin[i] = (int)blocks;
-            blocks += ((long)d.taps * d.cout * d.cin / 4 + 31) / 32;
+            blocks += wgrad_reduce_blocks(d.taps, d.cout, d.cin);
         }
         RGBD_REQUIRE(blocks < 0x7fffffffL, "rgbd_wgrad_reduce_multi: grid too large");
         m.block_begin[m.n] = (int)blocks;
