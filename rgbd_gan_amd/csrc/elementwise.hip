@@ -80,14 +80,25 @@ __device__ __forceinline__ void adain_strip_sum(const float* __restrict__ part, 
                                                 float (&s1)[8], float (&s2)[8]) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
-    for (int s = 0; s < nstrips; ++s) {
-        const float* p = part + (long)s * strip_stride;
-        const f32x4 sa = *reinterpret_cast<const f32x4*>(p), sb = *reinterpret_cast<const f32x4*>(p + 4);
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(p + 8), sd = *reinterpret_cast<const f32x4*>(p + 12);
-        s1[0] += sa[0]; s2[0] += sa[1]; s1[1] += sa[2]; s2[1] += sa[3];
-        s1[2] += sb[0]; s2[2] += sb[1]; s1[3] += sb[2]; s2[3] += sb[3];
-        s1[4] += sc[0]; s2[4] += sc[1]; s1[5] += sc[2]; s2[5] += sc[3];
-        s1[6] += sd[0]; s2[6] += sd[1]; s1[7] += sd[2]; s2[7] += sd[3];
+    // four strips' loads in flight at a time (a 128x128 image has 16 strips: one dependent L2 round trip per strip
+    // was several microseconds of prologue in every block); the adds stay in strip order
+    for (int s = 0; s < nstrips; s += 4) {
+        f32x4 q[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float* p = part + (long)(s + u < nstrips ? s + u : s) * strip_stride;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) q[u][v] = *reinterpret_cast<const f32x4*>(p + 4 * v);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (s + u >= nstrips) break;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                s1[2 * v] += q[u][v][0]; s2[2 * v] += q[u][v][1];
+                s1[2 * v + 1] += q[u][v][2]; s2[2 * v + 1] += q[u][v][3];
+            }
+        }
     }
 }
 
@@ -108,22 +119,35 @@ __global__ __launch_bounds__(256) void adain_reduce_kernel(const unsigned short*
         s0[k] = 0.f; s1[k] = 0.f;
         if (WITH_DY) { mu[k] = mean[(long)b * C + c0 + k]; rs[k] = rstd[(long)b * C + c0 + k]; }
     }
-    for (int p = p_begin + lane_p; p < p_end; p += 32) {
-        const long off = ((long)b * HW + p) * C + c0;
-        const u32x4 xv = *reinterpret_cast<const u32x4*>(x + off);
-        u32x4 gv;
-        if (WITH_DY) gv = *reinterpret_cast<const u32x4*>(dy + off);
+    // NB passes' loads issued before any is used: 8 independent 16-byte loads in flight per lane either way
+    constexpr int NB = WITH_DY ? 4 : 8;
+    for (int p0 = p_begin + lane_p; p0 < p_end; p0 += 32 * NB) {
+        u32x4 xq[NB], gq[WITH_DY ? NB : 1];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float xl = bf16_lo(xv[k]), xh = bf16_hi(xv[k]);
-            if (WITH_DY) {
-                const float gl = bf16_lo(gv[k]), gh = bf16_hi(gv[k]);
-                s0[2 * k] += gl; s0[2 * k + 1] += gh;
-                s1[2 * k] += gl * ((xl - mu[2 * k]) * rs[2 * k]);
-                s1[2 * k + 1] += gh * ((xh - mu[2 * k + 1]) * rs[2 * k + 1]);
-            } else {
-                s0[2 * k] += xl; s0[2 * k + 1] += xh;
-                s1[2 * k] += xl * xl; s1[2 * k + 1] += xh * xh;
+        for (int u = 0; u < NB; ++u) {
+            const int p = p0 + 32 * u < p_end ? p0 + 32 * u : p0;
+            const long off = ((long)b * HW + p) * C + c0;
+            xq[u] = *reinterpret_cast<const u32x4*>(x + off);
+            if constexpr (WITH_DY) gq[u] = *reinterpret_cast<const u32x4*>(dy + off);
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            if (p0 + 32 * u >= p_end) break;
+            const u32x4 xv = xq[u];
+            u32x4 gv = {0u, 0u, 0u, 0u};
+            if constexpr (WITH_DY) gv = gq[u];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float xl = bf16_lo(xv[k]), xh = bf16_hi(xv[k]);
+                if (WITH_DY) {
+                    const float gl = bf16_lo(gv[k]), gh = bf16_hi(gv[k]);
+                    s0[2 * k] += gl; s0[2 * k + 1] += gh;
+                    s1[2 * k] += gl * ((xl - mu[2 * k]) * rs[2 * k]);
+                    s1[2 * k + 1] += gh * ((xh - mu[2 * k + 1]) * rs[2 * k + 1]);
+                } else {
+                    s0[2 * k] += xl; s0[2 * k + 1] += xh;
+                    s1[2 * k] += xl * xl; s1[2 * k + 1] += xh * xh;
+                }
             }
         }
     }
@@ -159,6 +183,20 @@ __global__ __launch_bounds__(256) void adain_apply_kernel(const unsigned short* 
     const int c0 = cg * 64 + chunk * 8;
     const long sidx = (long)b * C + c0;
     const long aidx = (long)b * ld + c0;            // scale / shift rows are ld floats apart
+    // the first batch of x is requested BEFORE the statistics (a chain of dependent L2 round trips) are formed, and
+    // every later batch while the previous one is computed
+    const int r_begin = blockIdx.x * rows_per_block;
+    const int r_end = min(HW, r_begin + rows_per_block);
+    const long base = (long)b * HW;
+    u32x4 xn[4];
+    auto request = [&](int r0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = (r0 + 32 * u) < r_end ? (r0 + 32 * u) : r0;
+            xn[u] = *reinterpret_cast<const u32x4*>(x + (base + r) * C + c0);
+        }
+    };
+    if (r_begin + lane_p < r_end) request(r_begin + lane_p);
     float s1[8], s2[8];
     adain_strip_sum(sums + 2 * sidx, (long)gridDim.z * C * 2, nstrips, s1, s2);
     const f32x4 g0 = *reinterpret_cast<const f32x4*>(scale + aidx), g1 = *reinterpret_cast<const f32x4*>(scale + aidx + 4);
@@ -181,16 +219,11 @@ __global__ __launch_bounds__(256) void adain_apply_kernel(const unsigned short* 
             *reinterpret_cast<f32x4*>(rstd + sidx + 4) = f32x4{rs[4], rs[5], rs[6], rs[7]};
         }
     }
-    const int r_begin = blockIdx.x * rows_per_block;
-    const int r_end = min(HW, r_begin + rows_per_block);
-    const long base = (long)b * HW;
     for (int r0 = r_begin + lane_p; r0 < r_end; r0 += 128) {
         u32x4 xv[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int r = (r0 + 32 * u) < r_end ? (r0 + 32 * u) : r0;
-            xv[u] = *reinterpret_cast<const u32x4*>(x + (base + r) * C + c0);
-        }
+        for (int u = 0; u < 4; ++u) xv[u] = xn[u];
+        if (r0 + 128 < r_end) request(r0 + 128);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int r = r0 + 32 * u;
@@ -216,8 +249,8 @@ __global__ __launch_bounds__(256) void adain_apply_kernel(const unsigned short* 
 // so the activation gradient is applied in the same pass, dz = dx * (x > 0 ? 1 : slope), and the bias gradient
 // bias_grad[c] += sum dz rides along: one pass over HBM instead of the AdaIN backward plus a separate
 // activation-gradient pass.
-template <bool MASK>
-__global__ __launch_bounds__(256) void adain_bwd_apply_kernel(const unsigned short* __restrict__ x,
+template <bool MASK, int NT = 256>   // NT 1024 with the bias gradient on large images: fewer blocks, fewer same-address atomics
+__global__ __launch_bounds__(NT) void adain_bwd_apply_kernel(const unsigned short* __restrict__ x,
                                                               const unsigned short* __restrict__ dy,
                                                               const float* __restrict__ scale,
                                                               const float* __restrict__ mean,
@@ -232,6 +265,21 @@ __global__ __launch_bounds__(256) void adain_bwd_apply_kernel(const unsigned sho
     const int c0 = cg * 64 + chunk * 8;
     const long sidx = (long)b * C + c0;
     const long aidx = (long)b * ld + c0;
+    // first batch of x / dy requested before the per-(b,c) constants, later ones while the previous batch is computed
+    const int r_begin = blockIdx.x * rows_per_block;
+    const int r_end = min(HW, r_begin + rows_per_block);
+    const long base = (long)b * HW;
+    u32x4 xn[4], gn[4];
+    auto request = [&](int r0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = (r0 + (NT / 8) * u) < r_end ? (r0 + (NT / 8) * u) : r0;
+            const long off = (base + r) * C + c0;
+            xn[u] = *reinterpret_cast<const u32x4*>(x + off);
+            gn[u] = *reinterpret_cast<const u32x4*>(dy + off);
+        }
+    };
+    if (r_begin + lane_p < r_end) request(r_begin + lane_p);
     float s1[8], s2[8];                                 // sum dy, sum dy * xhat
     adain_strip_sum(sums + 2 * sidx, (long)gridDim.z * C * 2, nstrips, s1, s2);
     const f32x4 g0 = *reinterpret_cast<const f32x4*>(scale + aidx), g1 = *reinterpret_cast<const f32x4*>(scale + aidx + 4);
@@ -246,22 +294,15 @@ __global__ __launch_bounds__(256) void adain_bwd_apply_kernel(const unsigned sho
         *reinterpret_cast<f32x4*>(dscale + aidx) = f32x4{s2[0], s2[1], s2[2], s2[3]};
         *reinterpret_cast<f32x4*>(dscale + aidx + 4) = f32x4{s2[4], s2[5], s2[6], s2[7]};
     }
-    const int r_begin = blockIdx.x * rows_per_block;
-    const int r_end = min(HW, r_begin + rows_per_block);
-    const long base = (long)b * HW;
     float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int r0 = r_begin + lane_p; r0 < r_end; r0 += 128) {
+    for (int r0 = r_begin + lane_p; r0 < r_end; r0 += 4 * (NT / 8)) {
         u32x4 xv[4], gv[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int r = (r0 + 32 * u) < r_end ? (r0 + 32 * u) : r0;
-            const long off = (base + r) * C + c0;
-            xv[u] = *reinterpret_cast<const u32x4*>(x + off);
-            gv[u] = *reinterpret_cast<const u32x4*>(dy + off);
-        }
+        for (int u = 0; u < 4; ++u) { xv[u] = xn[u]; gv[u] = gn[u]; }
+        if (r0 + 4 * (NT / 8) < r_end) request(r0 + 4 * (NT / 8));
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int r = r0 + 32 * u;
+            const int r = r0 + (NT / 8) * u;
             if (r < r_end) {
                 u32x4 out;
 #pragma unroll
@@ -287,14 +328,14 @@ __global__ __launch_bounds__(256) void adain_bwd_apply_kernel(const unsigned sho
         }
     }
     if (MASK && bias_grad) {
-        __shared__ float red[32][65];
+        __shared__ float red[NT / 8][65];
 #pragma unroll
         for (int k = 0; k < 8; ++k) red[lane_p][chunk * 8 + k] = bs[k];
         __syncthreads();
         if (threadIdx.x < 64) {
             float acc = 0.f;
 #pragma unroll 8
-            for (int r = 0; r < 32; ++r) acc += red[r][threadIdx.x];
+            for (int r = 0; r < NT / 8; ++r) acc += red[r][threadIdx.x];
             atomicAdd(bias_grad + cg * 64 + threadIdx.x, acc);
         }
     }
@@ -328,7 +369,8 @@ __global__ __launch_bounds__(256) void lrelu_bwd_kernel(const unsigned short* __
 
 // Same, fused with the bias gradient: bias_grad[c] += sum_m dz[m][c] (fp32 atomics into the caller's buffer).
 // A block owns a strip of rows and one 64-channel group so the column sums reduce on chip; one pass over HBM.
-__global__ __launch_bounds__(256) void lrelu_bwd_colsum_kernel(const unsigned short* __restrict__ dy,
+template <int NT>   // threads: 256 (small tensors) or 1024 (large: a quarter of the blocks, a quarter of the atomics)
+__global__ __launch_bounds__(NT) void lrelu_bwd_colsum_kernel(const unsigned short* __restrict__ dy,
                                                                const unsigned short* __restrict__ y,
                                                                unsigned short* __restrict__ dz, long M, int C,
                                                                int act_channels, float slope, int rows_per_block,
@@ -336,7 +378,7 @@ __global__ __launch_bounds__(256) void lrelu_bwd_colsum_kernel(const unsigned sh
                                                                const float* __restrict__ row_scale,
                                                                long rows_per_sample) {
     // bias_grad[c] += sum_r w(r) dz[r][c], w(r) = row_scale[r / rows_per_sample] (1 when row_scale is null).
-    // 8 lanes cover one row's 64-channel group (128 B), 32 rows per pass, FOUR passes' loads issued before any is
+    // 8 lanes cover one row's 64-channel group (128 B), NT/8 rows per pass, FOUR passes' loads issued before any is
     // used: 8 independent 16-byte loads in flight per lane keep HBM busy with a handful of waves per CU.
     const int cg = blockIdx.y;
     const int chunk = threadIdx.x & 7, lane_p = threadIdx.x >> 3;
@@ -345,18 +387,18 @@ __global__ __launch_bounds__(256) void lrelu_bwd_colsum_kernel(const unsigned sh
     const long r_begin = (long)blockIdx.x * rows_per_block;
     const long r_end = min(M, r_begin + rows_per_block);
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (long r0 = r_begin + lane_p; r0 < r_end; r0 += 128) {
+    for (long r0 = r_begin + lane_p; r0 < r_end; r0 += 4 * (NT / 8)) {
         u32x4 g[4], yy[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const long r = r0 + 32 * u;
+            const long r = r0 + (NT / 8) * u;
             const long off = (r < r_end ? r : r0) * C + c0;
             g[u] = *reinterpret_cast<const u32x4*>(dy + off);
             yy[u] = act ? *reinterpret_cast<const u32x4*>(y + off) : u32x4{0u, 0u, 0u, 0u};
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const long r = r0 + 32 * u;
+            const long r = r0 + (NT / 8) * u;
             if (r < r_end) {
                 u32x4 out = g[u];
                 if (act) {
@@ -375,19 +417,20 @@ __global__ __launch_bounds__(256) void lrelu_bwd_colsum_kernel(const unsigned sh
             }
         }
     }
-    __shared__ float red[32][65];
+    __shared__ float red[NT / 8][65];
 #pragma unroll
     for (int k = 0; k < 8; ++k) red[lane_p][chunk * 8 + k] = s[k];
     __syncthreads();
     if (threadIdx.x < 64) {
         float acc = 0.f;
 #pragma unroll 8
-        for (int r = 0; r < 32; ++r) acc += red[r][threadIdx.x];
+        for (int r = 0; r < NT / 8; ++r) acc += red[r][threadIdx.x];
         atomicAdd(bias_grad + cg * 64 + threadIdx.x, acc);
     }
 }
 
-__global__ __launch_bounds__(256) void unpool_lrelu_bwd_kernel(const unsigned short* __restrict__ dp,
+template <int NT>
+__global__ __launch_bounds__(NT) void unpool_lrelu_bwd_kernel(const unsigned short* __restrict__ dp,
                                                                const unsigned short* __restrict__ y,
                                                                unsigned short* __restrict__ dz, long M, int H, int W,
                                                                int C, float slope, int rows_per_block,
@@ -402,11 +445,11 @@ __global__ __launch_bounds__(256) void unpool_lrelu_bwd_kernel(const unsigned sh
     const long r_end = min(M, r_begin + rows_per_block);
     const int Wp = W >> 1, Hp = H >> 1;
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (long r0 = r_begin + lane_p; r0 < r_end; r0 += 128) {
+    for (long r0 = r_begin + lane_p; r0 < r_end; r0 += 4 * (NT / 8)) {
         u32x4 g[4], yy[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const long r = (r0 + 32 * u) < r_end ? (r0 + 32 * u) : r0;
+            const long r = (r0 + (NT / 8) * u) < r_end ? (r0 + (NT / 8) * u) : r0;
             const int w = (int)(r % W);
             const long t = r / W;
             const int h = (int)(t % H);
@@ -417,7 +460,7 @@ __global__ __launch_bounds__(256) void unpool_lrelu_bwd_kernel(const unsigned sh
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const long r = r0 + 32 * u;
+            const long r = r0 + (NT / 8) * u;
             if (r < r_end) {
                 u32x4 out;
                 const float wr = row_scale ? row_scale[r / ((long)H * W)] : 1.f;
@@ -437,14 +480,14 @@ __global__ __launch_bounds__(256) void unpool_lrelu_bwd_kernel(const unsigned sh
         }
     }
     if (bias_grad) {
-        __shared__ float red[32][65];
+        __shared__ float red[NT / 8][65];
 #pragma unroll
         for (int k = 0; k < 8; ++k) red[lane_p][chunk * 8 + k] = s[k];
         __syncthreads();
         if (threadIdx.x < 64) {
             float acc = 0.f;
 #pragma unroll 8
-            for (int r = 0; r < 32; ++r) acc += red[r][threadIdx.x];
+            for (int r = 0; r < NT / 8; ++r) acc += red[r][threadIdx.x];
             atomicAdd(bias_grad + cg * 64 + threadIdx.x, acc);
             if (bias_grad2) atomicAdd(bias_grad2 + cg * 64 + threadIdx.x, acc);
         }
@@ -493,7 +536,8 @@ __global__ __launch_bounds__(256) void pool2_masked_kernel(const unsigned short*
 }
 
 // column sums of an (M, C) bf16 matrix -> out[C] fp32 (atomics; out zeroed by the caller): bias gradients.
-__global__ __launch_bounds__(256) void colsum_kernel(const unsigned short* __restrict__ x, float* __restrict__ out,
+template <int NT>
+__global__ __launch_bounds__(NT) void colsum_kernel(const unsigned short* __restrict__ x, float* __restrict__ out,
                                                      long M, int C, int rows_per_block,
                                                      const float* __restrict__ row_scale, long rows_per_sample) {
     // out[c] += sum_r w(r) * x[r][c], w(r) = row_scale[r / rows_per_sample] (1 when row_scale is null)
@@ -503,12 +547,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const unsigned short* __res
     const long r_begin = (long)blockIdx.x * rows_per_block;
     const long r_end = min(M, r_begin + rows_per_block);
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (long r0 = r_begin + lane_p; r0 < r_end; r0 += 128) {
+    for (long r0 = r_begin + lane_p; r0 < r_end; r0 += 4 * (NT / 8)) {
         u32x4 v[4];
         float wgt[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const long r = r0 + 32 * u;
+            const long r = r0 + (NT / 8) * u;
             const long rc = r < r_end ? r : r0;
             v[u] = *reinterpret_cast<const u32x4*>(x + rc * C + c0);
             wgt[u] = r < r_end ? (row_scale ? row_scale[rc / rows_per_sample] : 1.f) : 0.f;
@@ -521,14 +565,14 @@ __global__ __launch_bounds__(256) void colsum_kernel(const unsigned short* __res
                 s[2 * k + 1] += wgt[u] * bf16_hi(v[u][k]);
             }
     }
-    __shared__ float red[32][65];
+    __shared__ float red[NT / 8][65];
 #pragma unroll
     for (int k = 0; k < 8; ++k) red[lane_p][chunk * 8 + k] = s[k];
     __syncthreads();
     if (threadIdx.x < 64) {
         float acc = 0.f;
 #pragma unroll 8
-        for (int r = 0; r < 32; ++r) acc += red[r][threadIdx.x];
+        for (int r = 0; r < NT / 8; ++r) acc += red[r][threadIdx.x];
         atomicAdd(out + cg * 64 + threadIdx.x, acc);
     }
 }
@@ -1170,7 +1214,14 @@ extern "C" int rgbd_adain_bwd(const void* x, const void* dy, const float* scale,
     RGBD_CHECK_LAUNCH("adain_reduce_kernel<dy>");
     const int rows = HW <= 4096 ? 256 : 512;
     dim3 agrid(ceil_div(HW, rows), C / 64, B);
-    if (lrelu_slope > 0.f)
+    if (lrelu_slope > 0.f && bias_grad && HW >= 4096) {
+        const int big_rows = 2048;
+        dim3 bgrid(ceil_div(HW, big_rows), C / 64, B);
+        adain_bwd_apply_kernel<true, 1024><<<bgrid, 1024, 0, st>>>((const unsigned short*)x, (const unsigned short*)dy, scale,
+                                                                   mean, rstd, sums, (unsigned short*)dx, dscale, dshift, HW,
+                                                                   C, 1.f / (float)HW, ld, big_rows, lrelu_slope, bias_grad,
+                                                                   (int)grid.x);
+    } else if (lrelu_slope > 0.f)
         adain_bwd_apply_kernel<true><<<agrid, 256, 0, st>>>((const unsigned short*)x, (const unsigned short*)dy, scale,
                                                             mean, rstd, sums, (unsigned short*)dx, dscale, dshift, HW, C,
                                                             1.f / (float)HW, ld, rows, lrelu_slope, bias_grad, (int)grid.x);
@@ -1182,6 +1233,18 @@ extern "C" int rgbd_adain_bwd(const void* x, const void* dy, const float* scale,
     return 0;
 }
 
+// Strip size of the passes that carry a column sum (one atomic per channel per block at the end: with 512-row strips the
+// 128x128 layers ended in 1024 x 64 same-address atomics, ~15 us of serialised tail).  Large tensors: 1024-thread
+// blocks on 2048-row strips; small ones: 256 threads on strips short enough to give every CU a block.
+struct ColsumPlan { int threads, rows; };
+static ColsumPlan plan_colsum(long M) {
+    static const int dbg_rows = [] { const char* e = getenv("RGBD_DEBUG_COLSUM_ROWS"); return e ? atoi(e) : 0; }();
+    if (dbg_rows > 0) return ColsumPlan{dbg_rows >= 1024 ? 1024 : 256, dbg_rows};
+    if (M >= 131072) return ColsumPlan{1024, 2048};
+    if (M >= 32768) return ColsumPlan{256, 256};
+    return ColsumPlan{256, 128};
+}
+
 extern "C" int rgbd_lrelu_bwd(const void* dy, const void* y, void* dz, int64_t M, int C, int act_channels,
                               float slope, float* bias_grad, const float* row_scale, int64_t rows_per_sample,
                               void* stream) {
@@ -1191,11 +1254,16 @@ extern "C" int rgbd_lrelu_bwd(const void* dy, const void* y, void* dz, int64_t M
     if (bias_grad) {
         RGBD_REQUIRE(C % 64 == 0, "rgbd_lrelu_bwd: the fused bias gradient needs C %% 64 == 0 (C=%d)", C);
         RGBD_REQUIRE(!row_scale || rows_per_sample > 0, "rgbd_lrelu_bwd: rows_per_sample must be positive with row_scale");
-        const int rows = 512;
-        dim3 grid(ceil_div(M, rows), C / 64);
-        lrelu_bwd_colsum_kernel<<<grid, 256, 0, st>>>((const unsigned short*)dy, (const unsigned short*)y,
-                                                      (unsigned short*)dz, M, C, act_channels, slope, rows, bias_grad,
-                                                      row_scale, row_scale ? rows_per_sample : 1);
+        const ColsumPlan cp = plan_colsum(M);
+        dim3 grid(ceil_div(M, cp.rows), C / 64);
+        if (cp.threads == 1024)
+            lrelu_bwd_colsum_kernel<1024><<<grid, 1024, 0, st>>>((const unsigned short*)dy, (const unsigned short*)y,
+                                                                 (unsigned short*)dz, M, C, act_channels, slope, cp.rows,
+                                                                 bias_grad, row_scale, row_scale ? rows_per_sample : 1);
+        else
+            lrelu_bwd_colsum_kernel<256><<<grid, 256, 0, st>>>((const unsigned short*)dy, (const unsigned short*)y,
+                                                               (unsigned short*)dz, M, C, act_channels, slope, cp.rows,
+                                                               bias_grad, row_scale, row_scale ? rows_per_sample : 1);
         RGBD_CHECK_LAUNCH("lrelu_bwd_colsum_kernel");
         return 0;
     }
@@ -1217,10 +1285,14 @@ extern "C" int rgbd_colsum_bf16(const void* x, float* out, int64_t M, int C, int
         rgbd_set_error("rgbd_colsum_bf16: memset failed");
         return -2;
     }
-    const int rows = 512;
-    dim3 grid(ceil_div(M, rows), C / 64);
-    colsum_kernel<<<grid, 256, 0, st>>>((const unsigned short*)x, out, M, C, rows, row_scale,
-                                        row_scale ? rows_per_sample : 1);
+    const ColsumPlan cp = plan_colsum(M);
+    dim3 grid(ceil_div(M, cp.rows), C / 64);
+    if (cp.threads == 1024)
+        colsum_kernel<1024><<<grid, 1024, 0, st>>>((const unsigned short*)x, out, M, C, cp.rows, row_scale,
+                                                   row_scale ? rows_per_sample : 1);
+    else
+        colsum_kernel<256><<<grid, 256, 0, st>>>((const unsigned short*)x, out, M, C, cp.rows, row_scale,
+                                                 row_scale ? rows_per_sample : 1);
     RGBD_CHECK_LAUNCH("colsum_kernel");
     return 0;
 }
@@ -1243,11 +1315,16 @@ extern "C" int rgbd_unpool2_lrelu_bwd(const void* dp, const void* y, void* dz, i
     RGBD_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C % 64 == 0,
                  "rgbd_unpool2_lrelu_bwd: H, W must be even and C a multiple of 64 (H=%d W=%d C=%d)", H, W, C);
     const long M = (long)B * H * W;
-    const int rows = 512;
-    dim3 grid(ceil_div(M, rows), C / 64);
-    unpool_lrelu_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const unsigned short*)dp, (const unsigned short*)y,
-                                                                  (unsigned short*)dz, M, H, W, C, slope, rows, bias_grad,
-                                                                  bias_grad ? bias_grad2 : nullptr, row_scale);
+    const ColsumPlan cp = plan_colsum(M);
+    dim3 grid(ceil_div(M, cp.rows), C / 64);
+    if (cp.threads == 1024)
+        unpool_lrelu_bwd_kernel<1024><<<grid, 1024, 0, (hipStream_t)stream>>>(
+            (const unsigned short*)dp, (const unsigned short*)y, (unsigned short*)dz, M, H, W, C, slope, cp.rows, bias_grad,
+            bias_grad ? bias_grad2 : nullptr, row_scale);
+    else
+        unpool_lrelu_bwd_kernel<256><<<grid, 256, 0, (hipStream_t)stream>>>(
+            (const unsigned short*)dp, (const unsigned short*)y, (unsigned short*)dz, M, H, W, C, slope, cp.rows, bias_grad,
+            bias_grad ? bias_grad2 : nullptr, row_scale);
     RGBD_CHECK_LAUNCH("unpool_lrelu_bwd_kernel");
     return 0;
 }
