@@ -17,8 +17,10 @@ gradients, same Adam updates), arranged for the GPU:
     join : merge D's two gradient buffers;  opt : clip + Adam for map / gen / dis (+ EMA generator)
 prep .. join ("body") are captured once per configuration as ONE HIP graph with the two-stream fork / join inside it, the
 optimizer phase as a second one; a replayed step is two graph launches.
-Data-parallel: each optimizer's flat gradient buffer is all-reduced once (RCCL) between the body and the optimizer
-graphs (generator optimizers first, so their Adam step overlaps D's all-reduce).
+Data-parallel: each optimizer's flat gradient buffer is all-reduced once (RCCL), outside the graphs.  The body is then
+captured as TWO graphs, split where the generator's gradients are final (after gen_b): the map + gen all-reduces start
+there on the communicator's stream and run under the discriminator half of the step (dfw, dis, join); D's all-reduce
+starts after that half and runs under the generator's Adam step (train_rgbd.py:154-156).
 """
 import contextlib
 import math
@@ -180,8 +182,10 @@ class RGBDUpdater:
         # a blend factor every iteration and run eagerly.
         self.use_graphs = bool(kwargs.pop("use_graphs", True))
         self.graph_warmup = int(kwargs.pop("graph_warmup", 2))
-        self.graph_phases = tuple(kwargs.pop("graph_phases", ("body", "opt", "opt_g", "opt_d",
+        self.graph_phases = tuple(kwargs.pop("graph_phases", ("body", "body_g", "body_d", "opt", "opt_g", "opt_d",
                                                               "prep", "gen_a", "gen_b", "gen_w")))
+        # data parallel, one stream: split the body graph after G's backward so G's all-reduce overlaps the D half
+        self.dp_split_body = bool(kwargs.pop("dp_split_body", not os.environ.get("RGBD_DP_NO_SPLIT")))
         # The generator phase and the discriminator-on-reals phase are independent until the optimizer phase, and on two
         # streams the bubbles of one fill with the other's kernels (9.3 vs 11.3 ms per step at B=32).  OFF by default:
         # on this ROCm 7.2 stack two queues executing replayed graph kernels concurrently intermittently read stale
@@ -604,6 +608,31 @@ class RGBDUpdater:
         with rng("join"):
             self._join_phase(st)
 
+    def _body_g_phase(self, st):
+        """Data parallel, one stream: the body up to the point where map / gen gradients are final."""
+        rng = self._range
+        with rng("prep"), _alpha_ctx(st):
+            self._prep_phase(st)
+        if self.defer_dfake_wgrads:
+            with rng("gen_a"):
+                self._gen_a_phase(st)
+            with rng("gen_b"):
+                self._gen_b_phase(st)
+        else:
+            with rng("gen"):
+                self._gen_phase(st)
+
+    def _body_d_phase(self, st):
+        """... and the rest of it: everything that writes D's gradients."""
+        rng = self._range
+        if self.defer_dfake_wgrads:
+            with rng("dfw"):
+                self._dfw_phase(st)
+        with rng("dis"):
+            self._dis_phase(st)
+        with rng("join"):
+            self._join_phase(st)
+
     @contextlib.contextmanager
     def _range(self, name):
         if not self.profile_ranges:
@@ -643,9 +672,34 @@ class RGBDUpdater:
             return
         self._run_phase_inner(name, fn, st, key)
 
+    @contextlib.contextmanager
+    def _device_turn(self):
+        """Test arrangement only (RGBD_SHARE_DEVICE=1: several ranks on ONE GPU): with RGBD_SHARE_DEVICE_LOCK=<path> the
+        ranks take turns on the device, one phase at a time (an exclusive file lock held until the phase has drained).
+        Two processes replaying the step on the same GPU at the same time corrupt each other's generator backward in
+        ~20 % of the runs on this ROCm stack (scripts/dp_split_check.py) -- that is the platform's
+        hazard, not the data-parallel logic those tests are about.  Never held across a collective."""
+        path = os.environ.get("RGBD_SHARE_DEVICE_LOCK") if os.environ.get("RGBD_SHARE_DEVICE") else None
+        if path and any(getattr(o, "_needs_broadcast", False) for o in self._optimizers.values()):
+            path = None                   # the first update() of every optimizer is a broadcast: a collective
+        if not path:
+            yield
+            return
+        import fcntl
+        if getattr(self, "_turn_file", None) is None:
+            self._turn_file = open(path, "a+")
+        torch.cuda.synchronize()
+        fcntl.flock(self._turn_file, fcntl.LOCK_EX)
+        try:
+            yield
+            torch.cuda.synchronize()
+        finally:
+            fcntl.flock(self._turn_file, fcntl.LOCK_UN)
+
     def _run_phase_inner(self, name, fn, st, key):
         if key is None or name not in self.graph_phases:
-            fn(st)
+            with self._device_turn():
+                fn(st)
             return
         gkey = key + (name,)
         entry = self._graphs.get(gkey)
@@ -653,7 +707,8 @@ class RGBDUpdater:
             n = self._eager_calls.get(gkey, 0)
             if n < self.graph_warmup:
                 self._eager_calls[gkey] = n + 1
-                fn(st)
+                with self._device_turn():
+                    fn(st)
                 return
             graph = torch.cuda.CUDAGraph()
             saved = dict(self.observation)
@@ -663,8 +718,9 @@ class RGBDUpdater:
                 if getattr(opt, "_pending", None) is not None:
                     opt.comm.wait(opt._pending)
             try:
-                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    fn(st)
+                with self._device_turn():
+                    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                        fn(st)
             except Exception as exc:      # capture refused (driver / collective library state): stay correct, go eager
                 import sys
                 print(f"[rgbd_gan_amd] HIP graph capture of phase '{name}' failed ({type(exc).__name__}: {exc}); "
@@ -672,7 +728,8 @@ class RGBDUpdater:
                 self.use_graphs = False
                 self._graphs.clear()
                 torch.cuda.synchronize()
-                fn(st)
+                with self._device_turn():
+                    fn(st)
                 return
             # keep every tensor the phase handed over alive: it lives in the graph's private pool
             entry = {"graph": graph, "st": dict(st), "obs": {k: v for k, v in self.observation.items()
@@ -681,7 +738,8 @@ class RGBDUpdater:
         else:
             st.update({k: v for k, v in entry["st"].items() if k in ("x_real", "x_fake_data", "loss_dfake", "dfw")})
             self.observation.update(entry["obs"])
-        entry["graph"].replay()
+        with self._device_turn():
+            entry["graph"].replay()
 
     # ---- the step
     def update_core(self, batch=None, z_fake_data=None, thetas=None):
@@ -770,17 +828,23 @@ class RGBDUpdater:
         # capture, so a replay is a single launch whose internal dependencies the graph carries (separate graphs per
         # phase, ordered by stream events between the launches, were not reliably ordered on replay: the graph == eager
         # step test caught ~1e-2 relative gradient differences in two of five runs)
+        dp = getattr(opt_d, "comm", None) is not None and opt_d.comm.active
         if st["concurrent"] and self.hybrid and key is not None and self.defer_dfake_wgrads:
             self._hybrid_body(st, key)
+        elif dp and self.dp_split_body and not st["concurrent"]:
+            self._run_phase("body_g", self._body_g_phase, st, key)
+            for opt in (opt_g_m, opt_g_g):          # ~42 MB of generator gradients travel while D's half of the step runs
+                if opt is not None:
+                    opt.start_allreduce()
+            self._run_phase("body_d", self._body_d_phase, st, key)
         else:
             self._run_phase("body", self._body_phase, st, key)
-        dp = getattr(opt_d, "comm", None) is not None and opt_d.comm.active
         if dp:
             # data parallel (train_rgbd.py:154-156: the multi-node optimizers all-reduce before they update): one
             # all-reduce per flat gradient buffer on the communicator's stream, the collectives outside the graphs;
             # the generator's Adam step runs while D's 34 MB all-reduce is still in flight
             for opt in (opt_g_m, opt_g_g, opt_d):
-                if opt is not None:
+                if opt is not None and getattr(opt, "_pending", None) is None:
                     opt.start_allreduce()
             for opt in (opt_g_m, opt_g_g):
                 if opt is not None:

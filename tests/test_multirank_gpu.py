@@ -145,13 +145,16 @@ def test_two_ranks_on_half_batches_equal_one_rank_on_the_whole_batch(tmp_path, s
     port = _free_port()
     procs = []
     for r in range(2):
+        # RGBD_SHARE_DEVICE_LOCK: the two processes take turns on the one GPU (updater._device_turn): run at the same
+        # time they corrupt each other's generator backward in ~20 % of the runs on this stack, whatever the arrangement
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), RGBD_DIST_BACKEND="gloo", RGBD_SHARE_DEVICE="1")
+                   MASTER_PORT=str(port), RGBD_DIST_BACKEND="gloo", RGBD_SHARE_DEVICE="1",
+                   RGBD_SHARE_DEVICE_LOCK=str(tmp_path / "turn.lock"))
         procs.append(_run(tmp_path / f"rank{r}.npz", "--calls", "4", "--stage", str(stage), env=env))
     _wait(procs)
     one, r0, r1 = (np.load(tmp_path / f) for f in ("one.npz", "rank0.npz", "rank1.npz"))
     assert int(r0["world"]) == 2 and int(r1["rank"]) == 1
-    assert int(r0["n_graphs"]) == 3                    # body, generator optimizers, discriminator optimizer: replayed
+    assert int(r0["n_graphs"]) == 4     # body up to G's gradients, D's half of the body, generator optimizers, D optimizer
     for k in ("map", "gen", "dis"):                    # after the all-reduce every rank holds the same buffers ...
         np.testing.assert_array_equal(r0[f"{k}/grad"], r1[f"{k}/grad"])
         np.testing.assert_array_equal(r0[f"{k}/delta"], r1[f"{k}/delta"])       # ... and takes the same Adam step
@@ -161,6 +164,31 @@ def test_two_ranks_on_half_batches_equal_one_rank_on_the_whole_batch(tmp_path, s
     # activations differently) counts as a full mismatch; measured over 30 runs: 0.35-0.62 for the mapping network.  The
     # gradient, second-moment and norm checks above carry the comparison; this one only catches a step that went elsewhere.
     _compare(r0, one, f"2 ranks vs 1 rank, stage {stage}", RANKS_TOL[stage], upd_tol=0.8)
+
+
+def _two_ranks(tmp_path, tag, stage, extra_env=None):
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), RGBD_DIST_BACKEND="gloo", RGBD_SHARE_DEVICE="1",
+                   RGBD_SHARE_DEVICE_LOCK=str(tmp_path / "turn.lock"), **(extra_env or {}))
+        procs.append(_run(tmp_path / f"{tag}{r}.npz", "--calls", "4", "--stage", str(stage), env=env))
+    _wait(procs)
+    return np.load(tmp_path / f"{tag}0.npz")
+
+
+def test_generator_allreduce_under_the_discriminator_half_changes_nothing(tmp_path):
+    """Data parallel: the body is replayed as two graphs with the map / gen all-reduces started between them, so that they
+    travel while the discriminator half runs (updater.py, dp_split_body).  Same kernels in the same order as the single
+    body graph followed by all three all-reduces (RGBD_DP_NO_SPLIT=1): the reduced gradients have to agree to the
+    same-arrangement noise floor, every time."""
+    ref = _two_ranks(tmp_path, "whole", 10.0, {"RGBD_DP_NO_SPLIT": "1"})
+    assert int(ref["n_graphs"]) == 3
+    for rep in range(3):
+        got = _two_ranks(tmp_path, f"split{rep}", 10.0)
+        assert int(got["n_graphs"]) == 4
+        _compare(got, ref, f"split body vs whole body, 2 ranks, run {rep}", SAME_STEP)
 
 
 def test_seed_ratio_chain_at_the_logit_clamp(tmp_path):
