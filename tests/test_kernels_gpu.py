@@ -349,7 +349,7 @@ def test_adain_forward_backward(B, H, C):
     torch.testing.assert_close(dt.cpu(), t.grad, atol=1e-3 * H * H, rtol=1e-3)
 
 
-@pytest.mark.parametrize("B,H,C", [(2, 8, 64), (3, 32, 128), (2, 16, 256)])
+@pytest.mark.parametrize("B,H,C", [(2, 8, 64), (3, 32, 128), (2, 16, 256), (2, 64, 128), (1, 96, 64)])
 def test_adain_backward_with_fused_activation_gradient(B, H, C):
     """conv -> bias -> lrelu -> AdaIN (net.py:150-153): the AdaIN input IS the activation output, so rgbd_adain_bwd can
     apply the slope mask and take the bias sums in the same pass.  Oracle: autograd through lrelu + oracle AdaIN."""
@@ -421,6 +421,44 @@ def test_lrelu_bwd_and_colsum():
     dz2 = kernels.lrelu_bwd(dy.to(dev()).to(torch.bfloat16), y.to(dev()).to(torch.bfloat16), 64, bias_grad=bg)
     assert torch.equal(dz2, dz)
     torch.testing.assert_close(bg.cpu(), dz.float().cpu().reshape(-1, 128).sum(0) + 2.0, atol=1e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("shape,act", [((5, 168, 160, 64), 64), ((3, 200, 232, 128), 64), ((2, 100, 180, 64), 64)])
+def test_column_sum_passes_on_large_ragged_tensors(shape, act):
+    """The strip plans of the passes that carry a column sum (elementwise.hip:plan_colsum): 1024-thread blocks on 2048-row
+    strips from 131072 rows, 256-row strips from 32768, with row counts that are multiples of neither -- values bit-exact,
+    sums to fp32 accumulation accuracy, per-sample weights included."""
+    from rgbd_gan_amd import kernels
+    g = torch.Generator().manual_seed(12)
+    B, H, W, C = shape
+    y = bf16_round(torch.randn(*shape, generator=g))
+    dy = bf16_round(torch.randn(*shape, generator=g))
+    yd, dyd = y.to(dev()).to(torch.bfloat16), dy.to(dev()).to(torch.bfloat16)
+    ref = dy.clone()
+    ref[..., :act] = torch.where(y[..., :act] > 0, dy[..., :act], dy[..., :act] * 0.2)
+    ref = bf16_round(ref)
+    tol = dict(atol=2e-4 * np.sqrt(B * H * W), rtol=1e-4)
+    bg = torch.full((C,), 1.0, device=dev())
+    dz = kernels.lrelu_bwd(dyd, yd, act, bias_grad=bg)
+    assert torch.equal(dz.float().cpu(), ref)
+    torch.testing.assert_close(bg.cpu() - 1.0, ref.double().reshape(-1, C).sum(0).float(), **tol)
+    rs = torch.randn(B, generator=g)
+    bg = torch.zeros(C, device=dev())
+    kernels.lrelu_bwd(dyd, yd, act, bias_grad=bg, row_scale=rs.to(dev()))
+    want = (ref.double() * rs.double().reshape(B, 1, 1, 1)).reshape(-1, C).sum(0).float()
+    torch.testing.assert_close(bg.cpu(), want, **tol)
+    cs = kernels.colsum(dyd, row_scale=rs.to(dev()), rows_per_sample=H * W)
+    torch.testing.assert_close(cs.cpu(), (dy.double() * rs.double().reshape(B, 1, 1, 1)).reshape(-1, C).sum(0).float(), **tol)
+    # unpool form: dp at half resolution
+    dp = bf16_round(torch.randn(B, H // 2, W // 2, C, generator=g))
+    up = dp.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+    mask = torch.where(y > 0, torch.ones_like(y), torch.full_like(y, 0.2))
+    bg, bg2 = torch.zeros(C, device=dev()), torch.zeros(C, device=dev())
+    dzu = kernels.unpool2_lrelu_bwd(dp.to(dev()).to(torch.bfloat16), yd, shape, bias_grad=bg, bias_grad2=bg2)
+    refu = bf16_round(0.25 * up * mask)
+    assert torch.equal(dzu.float().cpu(), refu)
+    torch.testing.assert_close(bg.cpu(), refu.double().reshape(-1, C).sum(0).float(), **tol)
+    torch.testing.assert_close(bg2.cpu(), bg.cpu(), **tol)         # same sums, atomics in their own arrival order
 
 
 @pytest.mark.parametrize("B,H,C,KP", [(2, 16, 64, 3), (3, 8, 256, 3), (2, 32, 128, 4)])
