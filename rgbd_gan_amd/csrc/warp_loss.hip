@@ -163,6 +163,14 @@ __global__ __launch_bounds__(256) void warp_loss_final_kernel(const float* __res
     }
 }
 
+// The scatter of the backward pass.  SYSTEM-scope fp32 atomics (global_atomic_add_f32 ... sc1: performed at the memory side
+// instead of in the issuing XCD's L2): with the default agent scope, contributions went missing -- or arrived as garbage --
+// whenever a second queue kept the GPU busy (another stream, another process: scripts/dp_split_check.py, DESIGN.md
+// section 3), and every gradient of the generator inherited the damage.
+__device__ __forceinline__ void scatter_add(float* p, float v) {
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ __launch_bounds__(256) void warp_loss_bwd_kernel(
     const float* __restrict__ img, const float* __restrict__ img_rot, const float* __restrict__ coef,
     int b, int S, int flags, float lambda_geo, float max_depth, float min_depth, float hinge_lambda, float hinge_min,
@@ -187,7 +195,7 @@ __global__ __launch_bounds__(256) void warp_loss_bwd_kernel(
     const float z = ob[3 * hw + pix];
     const float go = (grad_loss ? grad_loss[0] : 1.f) * grad_scale;
     if (hinge_lambda != 0.f && z < hinge_min)      // d/dz of hinge_lambda * mean_{2N} relu(hinge_min - z)^2
-        atomicAdd(gob + 3 * hw + pix, go * hinge_lambda * (0.5f / (float)N) * (-2.f * (hinge_min - z)));
+        scatter_add(gob + 3 * hw + pix, go * hinge_lambda * (0.5f / (float)N) * (-2.f * (hinge_min - z)));
     const PixelWarp w = project_pixel(cf, dir == 0 ? -1.f : 1.f, z, i, j, S);
     if (!w.mask) return;  // masked pixels have zero weights, zero targets and constant taps: no gradient
     const int o00 = w.u0m * S + w.v0m;
@@ -222,14 +230,14 @@ __global__ __launch_bounds__(256) void warp_loss_bwd_kernel(
     float gw_a = 0.f, gw_d = 0.f;  // sum_c g[c] * tap value
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        atomicAdd(gsb + c * hw + o00, g[c] * wl);
-        atomicAdd(gsb + c * hw + o01, g[c] * wr);
+        scatter_add(gsb + c * hw + o00, g[c] * wl);
+        scatter_add(gsb + c * hw + o01, g[c] * wr);
         gw_a += g[c] * a[c];
         gw_d += g[c] * d[c];
     }
     // (2) targets: own RGB and projected depth
 #pragma unroll
-    for (int c = 0; c < 3; ++c) atomicAdd(gob + c * hw + pix, -g[c]);
+    for (int c = 0; c < 3; ++c) scatter_add(gob + c * hw + pix, -g[c]);
     float gzp2 = -g[3];
     // (3) interpolation weights -> (u, v) -> zp -> own depth.  dL/dw1 = dL/dw2 = gw_a, dL/dw3 = dL/dw4 = gw_d.
     const float du1 = w.u1f - w.u, du0 = w.u - w.u0f, dv1 = w.v1f - w.v, dv0 = w.v - w.v0f;
@@ -242,7 +250,7 @@ __global__ __launch_bounds__(256) void warp_loss_bwd_kernel(
     const float p0 = (float)j, p1 = (float)i;
     const float gz = gzp0 * (cf[0] * p0 + cf[1] * p1 + cf[2]) + gzp1 * (cf[3] * p0 + cf[4] * p1 + cf[5]) +
                      gzp2 * (cf[6] * p0 + cf[7] * p1 + cf[8]);
-    atomicAdd(gob + 3 * hw + pix, gz);
+    scatter_add(gob + 3 * hw + pix, gz);
 }
 
 }  // namespace
@@ -279,7 +287,19 @@ extern "C" int rgbd_warp_loss_bwd(const float* img, const float* img_rot, const 
         rgbd_set_error("rgbd_warp_loss_bwd: memset failed");
         return -2;
     }
-    warp_loss_bwd_kernel<<<dim3(ceil_div(N, 256), 2), 256, 0, st>>>(img, img_rot, coef, b, S, flags,
+    // Launched with ALL of a CU's LDS reserved (never touched): a workgroup of this kernel then cannot share a compute unit
+    // with a workgroup of any kernel that uses LDS, in particular the convolution kernels (48-147 KB each).  Sharing one is what corrupted the scatter --
+    // contributions missing or wrong by orders of magnitude in ~30 % of the launches while another queue or process ran
+    // conv3x3_sp_kernel / conv_fprop_kernel on the same GPU, none in 10^5 launches next to anything else
+    // (scripts/hw/atomic_share_stress.py).
+    static const int lds_reserve = [] {
+        const char* e = getenv("RGBD_DEBUG_WARP_LDS");
+        const int v = e ? atoi(e) : 160 * 1024;
+        if (v > 0) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(warp_loss_bwd_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, v);
+        return v;
+    }();
+    warp_loss_bwd_kernel<<<dim3(ceil_div(N, 256), 2), 256, lds_reserve, st>>>(img, img_rot, coef, b, S, flags,
                                                                     lambda_geometric, max_depth, min_depth, hinge_lambda,
                                                                     hinge_min, grad_loss, grad_scale, grad_img,
                                                                     grad_img_rot);

@@ -443,7 +443,12 @@ class RGBDUpdater:
             if cfg.use_occupancy_net_loss:
                 raise AssertionError("occupancy-net loss is not supported")
             if dbg is not None:
-                dbg.update(gout1=gout.clone())
+                dbg.update(gout1=gout.clone(), coef_after=st["coef"].clone(), x_fake_after=xf.clone())
+                again = dbg["gout0"].clone()          # the same scatter once more, same inputs, a few kernels later
+                kernels.warp_loss_bwd(xf[:half], xf[half:], st["coef"], flags, lf.lambda_geometric, 0.0, 0.0, None,
+                                      hinge_lambda=hinge, hinge_min=float(cfg.depth_min or 0.0),
+                                      grad_scale=float(lambda_rotate), out=(again[:half], again[half:]))
+                dbg.update(gout1_again=again)
         if cfg.optical_flow:
             raise AssertionError("optical flow loss is not supported")
         # the generator's weight gradients are leaves of this backward pass: collected while it runs, issued after it
@@ -462,6 +467,9 @@ class RGBDUpdater:
                 Fn.run_deferred_wgrads(wgrads)
         else:
             torch.autograd.backward([x_fake], [gout])
+        if dbg is not None:
+            from . import net as _net
+            dbg.update(_net.DEBUG_GRADS)
         st["x_fake_data"] = x_fake.detach()
         st["x_fake"] = st["gx"] = None                 # drop the autograd graph
 

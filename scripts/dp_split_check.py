@@ -49,7 +49,7 @@ with tempfile.TemporaryDirectory() as tmp:
                 r = rel(ga, gb)
                 if r > 0.02:
                     print(f"   {k}/{nm:28s} rel {r:9.3e}  |a| {np.linalg.norm(ga):9.3e} |b| {np.linalg.norm(gb):9.3e}")
-        for key in a.files:
+        for key in sorted(a.files):
             if key.startswith("dbg/"):
                 d = a[key].astype("float64") - b[key].astype("float64")
                 bad = np.flatnonzero(np.abs(d).ravel() > 1e-6 * np.abs(b[key]).max())
@@ -57,6 +57,10 @@ with tempfile.TemporaryDirectory() as tmp:
                       + (f"  first {bad[:6].tolist()} last {bad[-3:].tolist()}" if bad.size else ""))
                 if bad.size and key == "dbg/gout1":
                     fa, fb, f0 = a[key].ravel(), b[key].ravel(), a["dbg/gout0"].ravel()
+                    xf = a["dbg/x_fake"].ravel()
+                    for e in bad[:24]:
+                        print(f"      [{e}] b,c,i,j = {np.unravel_index(e, a[key].shape)}  bad {fa[e]:.6e}  clean {fb[e]:.6e}  "
+                              f"pre {f0[e]:.6e}  x_fake {xf[e]:.5f}")
                     pre = np.mean(np.abs(fa[bad] - f0[bad]) < 1e-12)
                     print(f"      bad entries equal to the pre-atomic value: {pre:.3f}; runs of consecutive indices: "
                           f"{np.sum(np.diff(bad) > 1) + 1}; shape {a[key].shape}")

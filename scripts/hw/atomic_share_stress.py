@@ -1,0 +1,149 @@
+"""Stress of the warp-loss backward scatter while ANOTHER PROCESS keeps the same GPU busy.
+  python scripts/hw/atomic_share_stress.py [--procs 2] [--iters 3000] [--partner warp|conv|idle]
+Every process repeats rgbd_warp_loss_bwd on fixed inputs into a freshly initialised buffer and counts the repetitions
+whose result differs from its own first one by more than the rounding of re-ordered fp32 atomics."""
+import argparse, os, subprocess, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+
+
+def worker(args):
+    import numpy as np, torch
+    from rgbd_gan_amd import kernels
+    from rgbd_gan_amd.common.loss_functions import LossFuncRotate
+    from rgbd_gan_amd.updater import get_camera_matries
+    dev = "cuda:0"
+    rng = np.random.RandomState(5 + args.seed)
+    b, S = args.half, 128
+    th = rng.uniform(-0.3, 0.3, (2 * b, 6)).astype("float32")
+    th[:, 2] = 0; th[:, 3:] *= 0.1
+    cams = get_camera_matries(th)
+    lf = LossFuncRotate(np, lambda_geometric=3.0)
+    coef = torch.from_numpy(np.asarray(lf.coefficients_for_size(S, cams[:b], cams[b:]), dtype="float32")).to(dev)
+    x = torch.from_numpy(rng.uniform(-1, 1, (2 * b, 4, S, S)).astype("float32"))
+    x[:, 3] = torch.from_numpy(rng.uniform(0.7, 1.3, (2 * b, S, S)).astype("float32"))
+    x = x.to(dev)
+    g0 = torch.from_numpy(rng.uniform(-1e-5, 1e-5, (2 * b, 4, S, S)).astype("float32")).to(dev)
+    if args.role in ("step", "step_eager"):      # a partner that runs the training step (stylegan config, stage 10, B=8)
+        from rgbd_gan_amd.training import DeviceImageIterator, build_training
+        from rgbd_gan_amd.utils import yaml_utils
+        root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        config = yaml_utils.load(os.path.join(root, "configs", "stylegan_shapenet_car.yml"))
+        config.batchsize = 8
+        images = np.random.RandomState(0).randint(0, 256, (64, 3, 128, 128)).astype("uint8")
+        it = DeviceImageIterator(images, config.batchsize, torch.device(dev), seed=0)
+        gen, dis, opt, upd = build_training(config, torch.device(dev), None, iterator=it, nan_check_interval=0)
+        upd.iteration = 200000
+        upd.use_graphs = args.role == "step"
+        t0, n = time.time(), 0
+        while time.time() - t0 < args.seconds + 3:
+            upd.update(); n += 1
+        torch.cuda.synchronize()
+        print(f"[{args.role} pid {os.getpid()}] {n} training steps", flush=True)
+        return
+    if args.role.startswith("k_"):      # a partner that repeats ONE of the library's kernels
+        B = 32
+        def t(*shape):
+            return torch.randn(*shape, device=dev).to(torch.bfloat16)
+        name = args.role[2:]
+        if name in ("sp", "patch"):
+            if name == "patch":
+                from rgbd_gan_amd import _lib
+                _lib.load().rgbd_debug_conv_variant(1)
+            xx = t(B, 64, 64, 256); w = torch.randn(256, 256, 3, 3, device=dev)
+            wf, wd = kernels.pack_weights(w, 0.02)
+            fn = lambda: kernels.conv2d_fprop(xx, wf, 3, 3, 1)
+        elif name == "gather":
+            xx = t(B, 8, 8, 256); w = torch.randn(256, 256, 3, 3, device=dev)
+            wf, wd = kernels.pack_weights(w, 0.02)
+            fn = lambda: kernels.conv2d_fprop(xx, wf, 3, 3, 1)
+        elif name == "wgrad":
+            xx, dy = t(B, 64, 64, 256), t(B, 64, 64, 256)
+            fn = lambda: kernels.conv2d_wgrad(xx, dy, 3, 0.02)
+        elif name == "lrelu":
+            xx, dy = t(B, 128, 128, 64), t(B, 128, 128, 64); bg = torch.zeros(64, device=dev)
+            fn = lambda: kernels.lrelu_bwd(dy, xx, 64, bias_grad=bg)
+        elif name == "adain":
+            xx = t(B, 64, 64, 256); ss = torch.randn(B, 512, device=dev)
+            fn = lambda: kernels.adain_fwd(xx, ss)
+        else:
+            raise SystemExit("unknown kernel " + name)
+        t0, n = time.time(), 0
+        while time.time() - t0 < args.seconds + 2:
+            for _ in range(20):
+                fn()
+            torch.cuda.synchronize(); n += 20
+        print(f"[{args.role} pid {os.getpid()}] {n} launches", flush=True)
+        return
+    if args.role == "conv":      # a partner that only keeps the GPU busy with matrix work
+        a = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)
+        t0 = time.time()
+        while time.time() - t0 < args.seconds:
+            for _ in range(50):
+                a @ a
+            torch.cuda.synchronize()
+        return
+    def once():
+        out = g0.clone()
+        kernels.warp_loss_bwd(x[:b], x[b:], coef, 1, 3.0, 0.0, 0.0, None, hinge_lambda=1.0, hinge_min=0.9, grad_scale=2.0,
+                              out=(out[:b], out[b:]))
+        return out
+    if args.victim == "warpfwd":   # the forward kernel: the same projection arithmetic and gathers, NO atomics
+        def once():
+            loss, zp, warped, idx = kernels.warp_loss_fwd(x[:b], x[b:], coef, 1, 3.0, debug=True, hinge_lambda=1.0, hinge_min=0.9)
+            return torch.cat([zp.reshape(-1), warped.reshape(-1), idx.reshape(-1).float(), loss.reshape(-1)])
+        g0 = torch.zeros_like(once())
+    elif args.victim != "warp":      # torch-only victims: which kind of memory operation is the one that gets hurt?
+        n_el = 1 << 20
+        src = torch.randn(n_el, device=dev)
+        idx = torch.randint(0, n_el // 4, (n_el,), device=dev)
+        base = torch.randn(n_el // 4, device=dev)
+        if args.victim == "scatter":        # fp32 atomics (index_add_)
+            once = lambda: base.clone().index_add_(0, idx, src)
+        elif args.victim == "gather":       # scattered reads, plain coalesced writes
+            once = lambda: src[idx] + 1.0
+        elif args.victim == "copy":         # streaming read-modify-write
+            once = lambda: src * 2.0 + 1.0
+        elif args.victim == "div":          # IEEE division (v_div_scale / v_rcp / v_div_fmas / v_div_fixup)
+            den = src.abs() + 0.5
+            once = lambda: src / den
+        elif args.victim == "trans":        # transcendental unit
+            once = lambda: torch.exp(src) * torch.rsqrt(src.abs() + 1.0) + torch.log(src.abs() + 1.0)
+        elif args.victim == "fma":          # plain VALU arithmetic, many operations per element
+            def once():
+                y = src
+                for _ in range(6):
+                    y = y * 1.0001 + 0.5 * src
+                return y
+        g0 = torch.zeros_like(once())
+    ref = once()
+    scale = float((ref - g0).abs().max())
+    bad, worst, t0, n = 0, 0.0, time.time(), 0
+    while time.time() - t0 < args.seconds:
+        for _ in range(100):
+            d = float((once() - ref).abs().max())
+            n += 1
+            if d > (1e-3 * scale if args.victim in ('warp', 'scatter') else 0.0):
+                bad += 1
+                worst = max(worst, d / scale)
+    print(f"[{args.role} pid {os.getpid()}] {n} repetitions, {bad} differ from the first by > 1e-3 of the largest "
+          f"contribution (worst {worst:.3g}x)", flush=True)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--procs", type=int, default=2)
+    ap.add_argument("--seconds", type=float, default=20.0)
+    ap.add_argument("--half", type=int, default=2)
+    ap.add_argument("--partner", default="warp", help="warp | conv | idle | step | step_eager | k_sp | k_patch | k_gather | k_wgrad | k_lrelu | k_adain")
+    ap.add_argument("--role", default=None)
+    ap.add_argument("--victim", default="warp", choices=["warp", "warpfwd", "scatter", "gather", "copy", "div", "trans", "fma"])
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--same-seed", action="store_true", help="every process works on identical data")
+    args = ap.parse_args()
+    if args.role:
+        worker(args)
+    else:
+        roles = ["warp"] + ([] if args.partner == "idle" else [args.partner] * (args.procs - 1))
+        ps = [subprocess.Popen([sys.executable, __file__, "--role", r, "--seconds", str(args.seconds), "--half", str(args.half),
+                                "--seed", str(0 if args.same_seed else i), "--victim", args.victim]) for i, r in enumerate(roles)]
+        sys.exit(max(p.wait() for p in ps))
