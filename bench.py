@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--arrangements", action="store_true",
-                    help="also time the opt-in hybrid two-stream arrangement on the same box (extra key, never `value`)")
+                    help="also time the single-stream arrangement on the same box (extra key, never `value`)")
     return ap.parse_args()
 
 
@@ -253,7 +253,8 @@ def main():
                                 f"renderer, rotation loss on, R1 on") if deepvoxels else
                                (f"{os.path.basename(args.config)} stage {upd.stage:.2f} (128x128), RGBDUpdater.update_core, "
                                 f"StyleGAN ch={config.ch}, rotation+occlusion loss on, R1 on"),
-                   "per_gpu_batch": B, "global_batch": B * comm.size, "parallelism": f"dp{comm.size}"},
+                   "per_gpu_batch": B, "global_batch": B * comm.size, "parallelism": f"dp{comm.size}",
+                   "arrangement": "two streams inside one graph" if getattr(upd, "concurrent_phases", False) else "one stream"},
         "host_enqueue_ms_per_step": round(t_burst / burst * 1e3, 3),
         "host_enqueue_note": f"wall time of the launch thread per step over a {burst}-step burst after a sync (no queue "
                              f"back-pressure); over the timed loop it was {t_enqueue / args.steps * 1e3:.3f} ms",
@@ -309,12 +310,11 @@ def main():
         for _ in range(2):                      # keep ranks in lock-step with rank 0's extra steps
             upd.update()
     if comm.rank == 0 and comm.size == 1 and args.arrangements and not deepvoxels:
-        # the opt-in two-stream arrangement, timed beside the default one on the same box (never `value`): generator
-        # phase replayed from graphs on the main stream || discriminator-on-reals phase launched eagerly on a side
-        # stream, weight-gradient batches after the join (DESIGN.md section 3 says why it is not the default)
+        # the single-stream arrangement (RGBD_CONCURRENT_PHASES=0), timed beside the default two-stream one on the same
+        # box (never `value`)
         it2 = DeviceImageIterator(images, B, device, seed=1)
         _, _, _, upd2 = build_training(config, device, None, iterator=it2, nan_check_interval=0,
-                                       concurrent_phases=True, hybrid=1)
+                                       concurrent_phases=False)
         upd2.iteration = args.iteration
         n2 = max(10, min(40, args.steps))
         for _ in range(8):
@@ -325,12 +325,10 @@ def main():
             upd2.update()
         torch.cuda.synchronize()
         ms2 = (time.perf_counter() - t2) / n2 * 1e3
-        line["opt_in_arrangement"] = {
-            "name": "hybrid two streams (RGBD_CONCURRENT_PHASES=1 RGBD_HYBRID=1)", "ms_per_step": round(ms2, 3),
+        line["other_arrangement"] = {
+            "name": "one stream (RGBD_CONCURRENT_PHASES=0)", "ms_per_step": round(ms2, 3),
             "img_per_s": round(B / ms2 * 1e3, 1), "steps": n2,
-            "note": "same step, same kernels; off by default: graph-replayed launches racing a second queue gave wrong "
-                    "gradients in other arrangements on this ROCm stack (scripts/graph_race.py), this one was clean in "
-                    "every screened run but the cause is not understood"}
+            "note": "same step, same kernels, generator and discriminator phases back to back instead of on two streams"}
         del upd2
     if comm.rank == 0 and comm.size == 1 and not args.no_cpu_baseline and not deepvoxels:
         line["cpu_baseline"] = cpu_baseline()

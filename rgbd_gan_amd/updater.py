@@ -187,12 +187,13 @@ class RGBDUpdater:
         # data parallel, one stream: split the body graph after G's backward so G's all-reduce overlaps the D half
         self.dp_split_body = bool(kwargs.pop("dp_split_body", not os.environ.get("RGBD_DP_NO_SPLIT")))
         # The generator phase and the discriminator-on-reals phase are independent until the optimizer phase, and on two
-        # streams the bubbles of one fill with the other's kernels (9.3 vs 11.3 ms per step at B=32).  OFF by default:
-        # on this ROCm 7.2 stack two queues executing replayed graph kernels concurrently intermittently read stale
-        # data ("Two streams": whole cache lines of an activation gradient keep a previous
-        # occupant's values in 1 of 16 runs at B=32, 10 of 16 at B=16; the single-stream replay is bit-reproducible and
-        # equals the eager step).  RGBD_CONCURRENT_PHASES=1 (or concurrent_phases=True) turns the overlap on.
-        self.concurrent_phases = bool(kwargs.pop("concurrent_phases", bool(os.environ.get("RGBD_CONCURRENT_PHASES"))
+        # streams the bubbles of one fill with the other's kernels (8.5 vs 9.7 ms per step at B=32): the default.  It was
+        # off until the cause of the wrong generator gradients it produced was found -- the warp-loss backward's scatter
+        # sharing a compute unit with convolution workgroups, cured in that kernel's launch (warp_loss.hip, DESIGN.md
+        # section 3).  RGBD_CONCURRENT_PHASES=0 (or concurrent_phases=False) runs the phases back to back on one stream;
+        # the shared-device test arrangement always does.
+        env = os.environ.get("RGBD_CONCURRENT_PHASES")
+        self.concurrent_phases = bool(kwargs.pop("concurrent_phases", (env is None or env not in ("", "0"))
                                                  and not os.environ.get("RGBD_SHARE_DEVICE")))
         self._side_stream = None
         # in that arrangement D's weight gradients for the fakes (leaves of the backward graph) are moved from the
@@ -829,7 +830,11 @@ class RGBDUpdater:
             key = (batch_size, fl, use_rotate, occlusion, full_shape, z_fake_data is not None, real_idx is not None)
 
         st["share_dfake"] = not os.environ.get("RGBD_NO_SHARE")
-        st["concurrent"] = bool(self.concurrent_phases and st["share_dfake"])
+        # two streams on the even (steady) stages only: at fade-in stages the two-stream replay showed a coherent 1-2 %
+        # perturbation of all gradients (forward losses off by 1e-4 .. 1e-3) in 3 of 11 screened runs, not yet explained
+        # (scripts/graph_race.py --stage 7.5; RGBD_CONCURRENT_FADE_IN=1 to reproduce); one stream there is exact
+        st["concurrent"] = bool(self.concurrent_phases and st["share_dfake"] and
+                                (fl % 2 == 0 or os.environ.get("RGBD_CONCURRENT_FADE_IN")))
         if st["concurrent"] and self._side_stream is None:
             self._side_stream = torch.cuda.Stream(device=self.device)
         # everything up to the merged gradient buffers is ONE captured graph: the two-stream fork / join sits INSIDE the

@@ -86,31 +86,43 @@ def _compare(a, b, what, tol, upd_tol=5e-2):
 
 
 def test_graph_replay_equals_eager_step(tmp_path):
-    """The shipped arrangement (the step body replayed as one HIP graph, the optimizers as a second one, one stream)
-    against the eager step; and the eager two-stream arrangement (RGBD_CONCURRENT_PHASES: generator phase ||
-    discriminator phase, D's fake-batch weight gradients deferred to the side stream and merged from a second gradient
-    buffer) against the eager single-stream step.  Graph replay WITH the two-stream overlap is deliberately not the
-    default and not asserted here: scripts/graph_race.py shows it reading stale cache lines intermittently on this ROCm
-    stack."""
+    """The shipped arrangement (the step body replayed as ONE HIP graph with the generator phase || discriminator phase
+    fork inside it, the optimizers as a second graph) against the eager single-stream step; the same for the
+    single-stream replay (RGBD_CONCURRENT_PHASES=0) and for eager launches on two streams."""
     _wait([_run(tmp_path / "eager.npz", "--calls", "4", "--eager", "--sequential")])
     _wait([_run(tmp_path / "eager2.npz", "--calls", "4", "--eager", "--concurrent")])
     _wait([_run(tmp_path / "graph.npz", "--calls", "4")])                      # the shipped arrangement
     _wait([_run(tmp_path / "graphB.npz", "--calls", "4")])                     # ... twice: replays are reproducible
-    e, e2, g, g2 = (np.load(tmp_path / f) for f in ("eager.npz", "eager2.npz", "graph.npz", "graphB.npz"))
+    _wait([_run(tmp_path / "graph1.npz", "--calls", "4", "--sequential")])     # one stream
+    e, e2, g, g2, g1 = (np.load(tmp_path / f) for f in ("eager.npz", "eager2.npz", "graph.npz", "graphB.npz", "graph1.npz"))
     assert int(e["n_graphs"]) == 0 and int(e2["n_graphs"]) == 0 and int(g["n_graphs"]) == 2   # body + optimizers
+    assert int(g1["n_graphs"]) == 2
     _compare(e2, e, "eager two-stream vs eager sequential", SAME_STEP)
-    _compare(g, e, "graph replay vs eager", SAME_STEP)
-    _compare(g2, g, "graph replay, second run vs first", SAME_STEP)
+    _compare(g, e, "two-stream graph replay vs eager", SAME_STEP)
+    _compare(g2, g, "two-stream graph replay, second run vs first", SAME_STEP)
+    _compare(g1, e, "single-stream graph replay vs eager", SAME_STEP)
     for key in ("obs/gen/loss_adv", "obs/gen/loss_rotate", "obs/dis/loss_adv", "obs/dis/loss_gp"):
         assert abs(float(g[key]) - float(e[key])) < 1e-5 * max(1.0, abs(float(e[key]))), (key, float(g[key]), float(e[key]))
 
 
+@pytest.mark.parametrize("batch", [16, 4])
+def test_two_stream_replay_at_the_sizes_that_used_to_fail(tmp_path, batch):
+    """Before the warp-loss backward kept compute units to itself (warp_loss.hip: LDS reservation), the two-stream replay
+    gave wrong generator gradients in 9-11 of 12 runs at these batch sizes (scripts/graph_race.py).
+    Three runs each against the eager single-stream step."""
+    flags = ["--calls", "4", "--stage", "10.0", "--batch", str(batch)]
+    _wait([_run(tmp_path / "eager.npz", *flags, "--eager", "--sequential")])
+    e = np.load(tmp_path / "eager.npz")
+    for rep in range(3):
+        _wait([_run(tmp_path / f"two{rep}.npz", *flags, "--concurrent")])
+        _compare(np.load(tmp_path / f"two{rep}.npz"), e, f"two-stream replay vs eager, batch {batch}, run {rep}", SAME_STEP)
+
+
 @pytest.mark.parametrize("stage,batch", [(10.0, 16)])
 def test_hybrid_two_stream_arrangement_equals_eager_step(tmp_path, stage, batch):
-    """The opt-in arrangement (RGBD_CONCURRENT_PHASES=1 RGBD_HYBRID=1): generator phase replayed from graphs on the main
-    stream, discriminator-on-reals phase launched eagerly on a side stream, both weight-gradient batches of the generator
-    phase after the join.  At these sizes the one-graph two-branch arrangement is wrong in most runs
-    (scripts/graph_race.py); this one has to equal the eager single-stream step."""
+    """The hybrid arrangement (RGBD_HYBRID=1): generator phase replayed from graphs on the main stream,
+    discriminator-on-reals phase launched eagerly on a side stream, both weight-gradient batches of the generator phase
+    after the join (a diagnostic of the former two-queue hazard, kept as a switch)."""
     flags = ["--calls", "4", "--stage", str(stage), "--batch", str(batch)]
     _wait([_run(tmp_path / "eager.npz", *flags, "--eager", "--sequential")])
     e = np.load(tmp_path / "eager.npz")
