@@ -17,10 +17,10 @@ gradients, same Adam updates), arranged for the GPU:
     join : merge D's two gradient buffers;  opt : clip + Adam for map / gen / dis (+ EMA generator)
 prep .. join ("body") are captured once per configuration as ONE HIP graph with the two-stream fork / join inside it, the
 optimizer phase as a second one; a replayed step is two graph launches.
-Data-parallel: each optimizer's flat gradient buffer is all-reduced once (RCCL), outside the graphs.  The body is then
-captured as TWO graphs, split where the generator's gradients are final (after gen_b): the map + gen all-reduces start
-there on the communicator's stream and run under the discriminator half of the step (dfw, dis, join); D's all-reduce
-starts after that half and runs under the generator's Adam step (train_rgbd.py:154-156).
+Data-parallel: each optimizer's flat gradient buffer is all-reduced once (RCCL), outside the graphs: after the body, the
+generator's first, so that its Adam step runs under D's all-reduce (train_rgbd.py:154-156).  On ONE stream
+(RGBD_CONCURRENT_PHASES=0, fade-in stages, the shared-device tests) the body is captured as two graphs, split where the
+generator's gradients are final (after gen_b), and the map + gen all-reduces run under the discriminator half.
 """
 import contextlib
 import math
