@@ -600,7 +600,7 @@ class RGBDUpdater:
             if "join" in l2s:
                 kernels.l2_sync()
         else:
-            # one stream (the default): the same phases back to back; D's weight gradients for the fakes are still
+            # one stream (RGBD_CONCURRENT_PHASES=0, fade-in stages, shared-device tests): the same phases back to back; D's weight gradients for the fakes are still
             # collected during gen_a and issued as ONE batch (rgbd_conv2d_wgrad_partial_multi_bf16) after G's backward
             if self.defer_dfake_wgrads:
                 with rng("gen_a"):
@@ -846,7 +846,7 @@ class RGBDUpdater:
             self._hybrid_body(st, key)
         elif dp and self.dp_split_body and not st["concurrent"]:
             self._run_phase("body_g", self._body_g_phase, st, key)
-            for opt in (opt_g_m, opt_g_g):          # ~42 MB of generator gradients travel while D's half of the step runs
+            for opt in (opt_g_m, opt_g_g):          # ~29 MB of generator gradients travel while D's half of the step runs
                 if opt is not None:
                     opt.start_allreduce()
             self._run_phase("body_d", self._body_d_phase, st, key)

@@ -1,5 +1,5 @@
-"""Reproducer of the hazard that keeps the two-stream phase overlap OFF by default: the replayed step
-with RGBD_CONCURRENT_PHASES against the eager single-stream step on fixed inputs (tests/dp_worker.py), N runs each:
+"""Screen of the two-stream phase overlap (the default since its hazard was cured; RGBD_DEBUG_WARP_LDS=0
+brings the hazard back): the replayed step against the eager single-stream step on fixed inputs (tests/dp_worker.py), N runs each:
 rel-L2 of the flat gradient buffers; with RGBD_DEBUG_DUMP=1 also of intermediates of the generator phase.
     NRUNS=16 python scripts/graph_race.py --stage 10 --batch 16"""
 import os, subprocess, sys, tempfile
@@ -30,7 +30,7 @@ if os.environ.get("HYBRID"):         # generator phase from graphs, discriminato
 elif os.environ.get("EAGER_TWO"):      # screen the EAGER two-stream arrangement instead (launches from Python, no graphs)
     cases = [(f"eager two streams {i}", ["--eager", "--concurrent"], {}) for i in range(N)]
 else:
-    cases = [(f"one stream (default) {i}", [], {}) for i in range(max(2, N // 4))] + \
+    cases = [(f"one stream {i}", ["--sequential"], {}) for i in range(max(2, N // 4))] + \
             [(f"two streams {i}", ["--concurrent"], {}) for i in range(N)]
 for i, (name, flags, env) in enumerate(cases):
     try:

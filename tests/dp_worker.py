@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--stage", type=float, default=10.0)
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--sequential", action="store_true")
-    ap.add_argument("--concurrent", action="store_true", help="two-stream phase overlap (off by default)")
+    ap.add_argument("--concurrent", action="store_true", help="two-stream phase overlap (the default on even stages)")
     ap.add_argument("--hybrid", type=int, default=0, help="two streams: generator phase from graphs, D-on-reals eager")
     ap.add_argument("--graph-phases", default=None, help="comma list: capture only these phases (diagnostics)")
     ap.add_argument("--sync-restore", action="store_true", help="host-synchronise after putting the weights back")
