@@ -840,7 +840,8 @@ class RGBDUpdater:
         # everything up to the merged gradient buffers is ONE captured graph: the two-stream fork / join sits INSIDE the
         # capture, so a replay is a single launch whose internal dependencies the graph carries (separate graphs per
         # phase, ordered by stream events between the launches, were not reliably ordered on replay: the graph == eager
-        # step test caught ~1e-2 relative gradient differences in two of five runs)
+        # step test caught ~1e-2 relative gradient differences in two of five runs -- in hindsight most likely the scatter
+        # hazard of DESIGN.md section 3, but the single launch is also the cheaper one)
         dp = getattr(opt_d, "comm", None) is not None and opt_d.comm.active
         if st["concurrent"] and self.hybrid and key is not None and self.defer_dfake_wgrads:
             self._hybrid_body(st, key)
