@@ -92,6 +92,16 @@ def worker(args):
             loss, zp, warped, idx = kernels.warp_loss_fwd(x[:b], x[b:], coef, 1, 3.0, debug=True, hinge_lambda=1.0, hinge_min=0.9)
             return torch.cat([zp.reshape(-1), warped.reshape(-1), idx.reshape(-1).float(), loss.reshape(-1)])
         g0 = torch.zeros_like(once())
+    elif args.victim == "bias":    # the library's other atomics: per-block column sums added to a bias gradient
+        yv = torch.randn(8, 64, 64, 128, device=dev).to(torch.bfloat16)
+        dv = torch.randn(8, 64, 64, 128, device=dev).to(torch.bfloat16)
+        pv = torch.randn(8, 32, 32, 128, device=dev).to(torch.bfloat16)
+        def once():
+            bg, bg2 = torch.zeros(128, device=dev), torch.zeros(128, device=dev)
+            dz = kernels.lrelu_bwd(dv, yv, 128, bias_grad=bg)
+            dz2 = kernels.unpool2_lrelu_bwd(pv, yv, (8, 64, 64, 128), bias_grad=bg2)
+            return torch.cat([bg, bg2, dz.float().sum().reshape(1), dz2.float().sum().reshape(1)])
+        g0 = torch.zeros_like(once())
     elif args.victim != "warp":      # torch-only victims: which kind of memory operation is the one that gets hurt?
         n_el = 1 << 20
         src = torch.randn(n_el, device=dev)
@@ -122,7 +132,7 @@ def worker(args):
         for _ in range(100):
             d = float((once() - ref).abs().max())
             n += 1
-            if d > (1e-3 * scale if args.victim in ('warp', 'scatter') else 0.0):
+            if d > (1e-3 * scale if args.victim in ('warp', 'scatter', 'bias') else 0.0):
                 bad += 1
                 worst = max(worst, d / scale)
     print(f"[{args.role} pid {os.getpid()}] {n} repetitions, {bad} differ from the first by > 1e-3 of the largest "
@@ -136,7 +146,7 @@ if __name__ == "__main__":
     ap.add_argument("--half", type=int, default=2)
     ap.add_argument("--partner", default="warp", help="warp | conv | idle | step | step_eager | k_sp | k_patch | k_gather | k_wgrad | k_lrelu | k_adain")
     ap.add_argument("--role", default=None)
-    ap.add_argument("--victim", default="warp", choices=["warp", "warpfwd", "scatter", "gather", "copy", "div", "trans", "fma"])
+    ap.add_argument("--victim", default="warp", choices=["warp", "warpfwd", "bias", "scatter", "gather", "copy", "div", "trans", "fma"])
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--same-seed", action="store_true", help="every process works on identical data")
     args = ap.parse_args()
