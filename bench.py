@@ -254,7 +254,10 @@ def main():
                                (f"{os.path.basename(args.config)} stage {upd.stage:.2f} (128x128), RGBDUpdater.update_core, "
                                 f"StyleGAN ch={config.ch}, rotation+occlusion loss on, R1 on"),
                    "per_gpu_batch": B, "global_batch": B * comm.size, "parallelism": f"dp{comm.size}",
-                   "arrangement": "two streams inside one graph" if getattr(upd, "concurrent_phases", False) else "one stream"},
+                   "arrangement": "two streams inside one graph" if getattr(upd, "concurrent_phases", False) else "one stream",
+                   # True only if the timed steps were replays of captured HIP graphs (a refused capture is fatal in the
+                   # updater: graph_fallback is off)
+                   "graphs": bool(getattr(upd, "graphs_in_use", upd.use_graphs))},
         "host_enqueue_ms_per_step": round(t_burst / burst * 1e3, 3),
         "host_enqueue_note": f"wall time of the launch thread per step over a {burst}-step burst after a sync (no queue "
                              f"back-pressure); over the timed loop it was {t_enqueue / args.steps * 1e3:.3f} ms",
@@ -264,10 +267,9 @@ def main():
     else:
         line["step_tflops_algorithmic"] = round(value * STEP_GFLOP_PER_IMAGE / 1e3, 2)
         line["mfma_roofline_frac_whole_step"] = round(value * STEP_GFLOP_PER_IMAGE / 1e3 / (MFMA_BF16_PEAK_TFLOPS * comm.size), 4)
-        # the same throughput priced at the work the REFERENCE's dataflow spends per image (3 F_G +
-        # 11 F_D = 296.6 GFLOP, the accounting behind "40 % of MFMA peak = 3372 img/s per GPU"); the two lines above count
-        # only what this engine executes (3 F_G + 7 F_D)
-        line["mfma_roofline_frac_reference_accounting"] = round(value * 296.6 / 1e3 / (MFMA_BF16_PEAK_TFLOPS * comm.size), 4)
+        if comm.size > 1:
+            line["config"]["collectives"] = {"backend": torch.distributed.get_backend(),
+                                             "world_size_reported_by_group": torch.distributed.get_world_size()}
 
     if comm.rank == 0 and not args.no_roofline:
         # per-launch HIP-event timing of the conv kernels over extra (untimed) steps, on the launch stream

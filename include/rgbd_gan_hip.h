@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RGBD_ABI_VERSION 7
+#define RGBD_ABI_VERSION 8
 
 int rgbd_abi_version(void);
 const char* rgbd_last_error(void);
@@ -58,15 +58,21 @@ int rgbd_warp_loss_fwd(const float* img, const float* img_rot, const float* coef
                        float* partials, float* loss,
                        float* dbg_zp, float* dbg_warped, int32_t* dbg_idx, void* stream);
 
-/* Backward of the above.  grad_loss: 1 float on the device (d objective / d loss), multiplied by grad_scale (host).
- * grad_img, grad_img_rot: (b,4,S,S) fp32; accumulate == 0: zeroed inside, then accumulated with atomics;
- * accumulate != 0: the gradients are ADDED to what the buffers hold (the caller has put the other terms of the image
- * gradient there, rgbd_image_grad_init).  grad_loss may be NULL (= 1). */
+/* Backward of the above.  grad_loss: 1 float on the device (d objective / d loss), multiplied by grad_scale (host);
+ * may be NULL (= 1).
+ * grad_img, grad_img_rot: (b,4,S,S) fp32, 16-byte aligned; accumulate == 0: zeroed inside; accumulate != 0: the
+ * gradients are ADDED to what the buffers hold (the caller has put the other terms of the image gradient there,
+ * rgbd_image_grad_init).
+ * workspace: rgbd_warp_loss_bwd_workspace(b, S) bytes of device scratch, 16-byte aligned, no initialisation needed.
+ * The bilinear taps' scatter-add (the backward of the advanced-index gathers, loss_functions.py:221-226) is accumulated
+ * there as 64-bit fixed point with INTEGER atomics and converted once: the result is bit-reproducible from run to run
+ * (an fp32 atomic scatter is not).  S*S must be a multiple of 4. */
+int64_t rgbd_warp_loss_bwd_workspace(int b, int S);
 int rgbd_warp_loss_bwd(const float* img, const float* img_rot, const float* coef, int b, int S,
                        int flags, float lambda_geometric, float max_depth, float min_depth,
                        float hinge_lambda, float hinge_min,
                        const float* grad_loss, float grad_scale, float* grad_img, float* grad_img_rot, int accumulate,
-                       void* stream);
+                       void* workspace, void* stream);
 
 /* ------------------------------------------------------------------ equalized-LR convolution engine
  * Replaces pggan.py:13-24 (EqualizedConv2d -> L.Convolution2D = cuDNN fprop/dgrad/wgrad) for the
@@ -115,18 +121,6 @@ int64_t rgbd_conv2d_fprop_workspace(int B, int Hin, int Win, int Cin, int Cout, 
 int rgbd_conv2d_fprop_bf16(const void* x, const void* wp, const float* bias, const void* residual, void* y,
                            void* y_pooled, int B, int Hin, int Win, int Cin, int Cout, int KH, int KW, int pad,
                            int upsample, int lrelu_channels, float slope, void* workspace, void* stream);
-
-/* Test hook: when on != 0, rgbd_conv2d_fprop_bf16 uses the generic gather kernel for every shape (by default 3x3
- * pad-1 convolutions on images of 16x16 and larger run the halo-patch kernel). */
-int rgbd_debug_force_gather_kernel(int on);
-/* Name of the kernel the last rgbd_conv2d_fprop_bf16 / rgbd_conv2d_dgrad_bf16 call of this process launched (the planner
- * picks between the pipelined 3x3 kernel and the gather kernel by shape); for profiling labels. */
-const char* rgbd_last_conv_kernel(void);
-/* Test / tuning hook: 0 = default kernels, 1 = the register-staged 3x3 halo-patch kernel instead of the pipelined LDS-DMA
- * one, 2 = the pipelined kernel with 64-channel output tiles everywhere, 11-16 = timing knock-outs (wrong results). */
-int rgbd_debug_conv_variant(int v);
-/* Diagnostic: a launch that writes back and invalidates every XCD's L2 (buffer_wbl2 / buffer_inv, system scope). */
-int rgbd_debug_l2_sync(void* stream);
 
 /* Weight gradient: dw[co][ci][kh][kw] (+)= scale * sum_{b,h,w} dy[b,h,w,co] * x[b,h+kh-pad,w+kw-pad,ci]  (fp32).
  *   x  : (B,H,W,Cin) bf16, dy : (B,H,W,Cout) bf16 (same H,W: stride 1, pad = (K-1)/2), K in {1,3}.

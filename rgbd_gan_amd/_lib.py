@@ -10,7 +10,7 @@ from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p, POINTER
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RGBD_LIB_PATH: A/B timing of another build of the same ABI; the default is the in-tree library
 LIB_PATH = os.environ.get("RGBD_LIB_PATH") or os.path.join(_HERE, "librgbdgan_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _P = c_void_p
 
@@ -20,21 +20,18 @@ PROTOTYPES = {
     "rgbd_last_error": ([], c_char_p),
     "rgbd_warp_loss_fwd": ([_P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, _P, _P, _P, _P,
                             _P, _P], c_int),
+    "rgbd_warp_loss_bwd_workspace": ([c_int, c_int], c_int64),
     "rgbd_warp_loss_bwd": ([_P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, _P, c_float, _P,
-                            _P, c_int, _P], c_int),
+                            _P, c_int, _P, _P], c_int),
     "rgbd_pack_weights": ([_P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P], c_int),
     "rgbd_pack_weights_multi": ([_P, c_int, c_int, _P], c_int),
     "rgbd_conv2d_fprop_workspace": ([c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int], c_int64),
     "rgbd_conv2d_fprop_bf16": ([_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                 c_int, c_int, c_float, _P, _P], c_int),
-    "rgbd_debug_force_gather_kernel": ([c_int], c_int),
-    "rgbd_last_conv_kernel": ([], c_char_p),
-    "rgbd_debug_conv_variant": ([c_int], c_int),
     "rgbd_fold_depth_taps_bf16": ([_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P], c_int),
     "rgbd_fold_4x4s2_bf16": ([_P, _P, c_int, c_int, c_int, c_int, c_int, _P], c_int),
     "rgbd_pad_last": ([_P, _P, c_int64, c_int, c_int, c_int, _P], c_int),
     "rgbd_fold_weight_f32": ([_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P], c_int),
-    "rgbd_debug_l2_sync": ([_P], c_int),
     "rgbd_conv2d_wgrad_workspace": ([c_int, c_int, c_int, c_int, c_int, c_int], c_int64),
     "rgbd_conv2d_wgrad_bf16": ([_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P], c_int),
     "rgbd_conv2d_wgrad_partial_bf16": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P], c_int),
@@ -98,6 +95,13 @@ PROTOTYPES = {
 _lib = None
 
 
+# test / tuning hooks (rgbd_gan_amd/csrc/rgbd_debug.h): exported by the library, NOT part of the drop-in ABI
+DEBUG_PROTOTYPES = {
+    "rgbd_debug_force_gather_kernel": ([c_int], c_int),
+    "rgbd_last_conv_kernel": ([], c_char_p),
+    "rgbd_debug_conv_variant": ([c_int], c_int),
+}
+
 def load():
     """Load the library once; raise (never fall back) when it is absent or has the wrong ABI."""
     global _lib
@@ -108,7 +112,7 @@ def load():
             f"{LIB_PATH} not found: build it with `python -m rgbd_gan_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU or PyTorch fallback for the hot path.")
     lib = ctypes.CDLL(LIB_PATH)
-    for name, (argtypes, restype) in PROTOTYPES.items():
+    for name, (argtypes, restype) in list(PROTOTYPES.items()) + list(DEBUG_PROTOTYPES.items()):
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.argtypes = argtypes
         fn.restype = restype

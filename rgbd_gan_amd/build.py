@@ -1,6 +1,7 @@
 """Build librgbdgan_hip.so (gfx950) in-tree with hipcc.  No torch involved: the library is a plain C ABI.
 
     python -m rgbd_gan_amd.build [--force]
+    python -m rgbd_gan_amd.build --packed-fp32 --out /tmp/librgbdgan_pk.so     # A/B library for scripts/hw/ (never shipped)
 """
 import os
 import subprocess
@@ -16,11 +17,19 @@ ARCH = "gfx950"
 SOURCES = [
     ("elementwise.hip", []),
     ("warp_loss.hip", ["-ffp-contract=off"]),
-    ("conv.hip", []),
+    ("conv.hip", ["-Wno-inline-asm"]),      # the M0 clobber of lds_dma16 (reserved register: see the comment there)
     ("deepvoxels.hip", ["-ffp-contract=off"]),
     ("step_ops.hip", []),
 ]
-COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
+# NO packed-fp32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) anywhere in the library: on MI355X a wave
+# that executes them while ANOTHER wave on the same SIMD issues MFMAs gets wrong results in lanes 48-63 now and then
+# (found with scripts/hw/atomic_share_stress.py: the warp-loss backward next to the convolution kernels of a second stream
+# or process, 36-56 % of its launches wrong; the same source compiled without the feature: 0 of 560 000.  DESIGN.md
+# section 3).  hipcc vectorises pairs of fp32 operations into these instructions by default on gfx90a and later; the
+# feature is switched off for the device compilation (the host half of the same command prints a note that it does not
+# know the feature, which _run() drops).  tests/test_isa_cpu.py checks the built code objects.
+NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+COMMON = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"] + NO_PACKED_FP32
 
 
 def _hipcc():
@@ -37,27 +46,44 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def _run(cmd):
+    r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+    err = "\n".join(ln for ln in r.stderr.splitlines() if "is not a recognized feature for this target" not in ln)
+    if err.strip():
+        print(err, file=sys.stderr, flush=True)
+    if r.returncode != 0:
+        raise subprocess.CalledProcessError(r.returncode, cmd)
+
+
+def build(force=False, verbose=True, out=OUT, packed_fp32=False):
+    """packed_fp32=True (with another `out`): the compiler's default code generation, for the A/B of DESIGN.md section 3
+    (scripts/hw/atomic_share_stress.py with RGBD_LIB_PATH); objects go to a directory next to `out`."""
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "rgbd_gan_hip.h")]
+    common = [f for f in COMMON if packed_fp32 is False or f not in NO_PACKED_FP32]
+    objdir = CSRC if out == OUT else os.path.splitext(out)[0] + "_obj"
+    if packed_fp32 and out == OUT:
+        raise ValueError("the shipped library is built without packed-fp32 instructions; give another --out")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "rgbd_debug.h"),
+               os.path.join(HERE, "..", "include", "rgbd_gan_hip.h")]
     objs = []
     for src, extra in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        o = os.path.join(objdir, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + COMMON + extra + ["-c", s, "-o", o]
+            cmd = [hipcc] + common + extra + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            _run(cmd)
         objs.append(o)
-    if force or _stale(OUT, objs):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", OUT] + objs
+    if force or _stale(out, objs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", out] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(OUT)
+    target = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else OUT
+    print(build(force="--force" in sys.argv, out=target, packed_fp32="--packed-fp32" in sys.argv))

@@ -101,7 +101,7 @@ class LossFuncRotate:
                 (WARP_MIN_DEPTH if min_depth is not None else 0)
         return Fn.warp_loss(img, img_rot, coef, flags, self.lambda_geometric,
                             0.0 if max_depth is None else float(max_depth),
-                            0.0 if min_depth is None else float(min_depth))
+                            0.0 if min_depth is None else float(min_depth))[0]
 
     def __call__(self, img, theta, img_rot, theta_rot, occlusion_aware=False, debug=False, max_depth=None,
                  min_depth=None):
@@ -123,5 +123,7 @@ class LossFuncRotate:
                                                        flags, self.lambda_geometric, mx, mn, debug=True)
             mask = idx[..., 3].bool()
             return warped[0], mask[0], zp[0], warped[1], mask[1], zp[1]
-        loss = Fn.warp_loss(img, img_rot, coef, flags, self.lambda_geometric, mx, mn)
-        return loss, None
+        loss, zp = Fn.warp_loss(img, img_rot, coef, flags, self.lambda_geometric, mx, mn, want_zp=True)
+        # loss_functions.py:146: F.concat([new_zp, new_zp_rot], axis=0) -> (2b, hw, 3); a by-product of the fused forward
+        # here, detached (no caller of the reference differentiates it)
+        return loss, zp.reshape(-1, zp.shape[2], 3)

@@ -6,6 +6,7 @@
 #include <stdarg.h>
 
 #include "../../include/rgbd_gan_hip.h"
+#include "rgbd_debug.h"
 
 typedef __bf16 bf16_t;
 typedef bf16_t bf16x8 __attribute__((ext_vector_type(8)));

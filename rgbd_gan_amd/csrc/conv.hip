@@ -602,9 +602,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(ConvArgs a) {
 //          are retired by the lgkmcnt(0) in front of B_t.
 //     The halo patch of slice g+1 is issued after B_0..B_3 of slice g into the other patch buffer (last read before
 //     B_8 of slice g-1), retired by the halo waves' vmcnt(0) in front of B_8, first read right after B_8.
+// M0 (the DMA's LDS base) is written here.  LLVM reserves M0 on AMDGPU, so the clobber below is accepted but not
+// tracked (-Winline-asm says so); what makes this safe is that nothing hipcc generates for gfx950 in this file reads
+// M0 -- tests/test_isa_cpu.py checks the emitted code: every M0 reference is one of these moves, consumed by the
+// buffer_load ... lds right behind it.
 __device__ __forceinline__ void lds_dma16(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :: "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+                 :: "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
 }
 #define RGBD_PP_BARRIER()                         \
     do {                                          \

@@ -11,17 +11,6 @@ void rgbd_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-// Diagnostic (two-queue hazard): write back and invalidate the L2 of every XCD -- one wave per
-// workgroup, 256 workgroups, so that each XCD's dispatcher gets some.
-__global__ __launch_bounds__(64) void l2_sync_kernel() {
-    asm volatile("buffer_wbl2 sc0 sc1\n\ts_waitcnt vmcnt(0)\n\tbuffer_inv sc0 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
-}
-extern "C" int rgbd_debug_l2_sync(void* stream) {
-    l2_sync_kernel<<<256, 64, 0, (hipStream_t)stream>>>();
-    RGBD_CHECK_LAUNCH("l2_sync_kernel");
-    return 0;
-}
-
 __global__ __launch_bounds__(256) void zero_kernel(unsigned int* __restrict__ p, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0u;
 }

@@ -1,0 +1,23 @@
+/*
+ * rgbd_debug.h -- test / tuning hooks of librgbdgan_hip.so.  NOT part of the drop-in C ABI (include/rgbd_gan_hip.h): nothing
+ * on the training path calls these; tests/ and scripts/ do (A/B timing of kernel variants, cross-checks of the conv planner's
+ * choices, profiling labels).  They set process-wide switches, which the ABI proper never does.
+ */
+#pragma once
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Test hook: when on != 0, rgbd_conv2d_fprop_bf16 uses the generic gather kernel for every shape (by default 3x3
+ * pad-1 convolutions on images of 16x16 and larger run the halo-patch kernel). */
+int rgbd_debug_force_gather_kernel(int on);
+/* Name of the kernel the last rgbd_conv2d_fprop_bf16 / rgbd_conv2d_dgrad_bf16 call of this process launched (the planner
+ * picks between the pipelined 3x3 kernel and the gather kernel by shape); for profiling labels. */
+const char* rgbd_last_conv_kernel(void);
+/* Test / tuning hook: 0 = default kernels, 1 = the register-staged 3x3 halo-patch kernel instead of the pipelined LDS-DMA
+ * one, 2 = the pipelined kernel with 64-channel output tiles everywhere, 11-16 = timing knock-outs (wrong results). */
+int rgbd_debug_conv_variant(int v);
+
+#ifdef __cplusplus
+}
+#endif

@@ -163,18 +163,25 @@ __global__ __launch_bounds__(256) void warp_loss_final_kernel(const float* __res
     }
 }
 
-// The scatter of the backward pass.  SYSTEM-scope fp32 atomics (global_atomic_add_f32 ... sc1: performed at the memory side
-// instead of in the issuing XCD's L2): with the default agent scope, contributions went missing -- or arrived as garbage --
-// whenever a second queue kept the GPU busy (another stream, another process: scripts/dp_split_check.py, DESIGN.md
-// section 3), and every gradient of the generator inherited the damage.
-__device__ __forceinline__ void scatter_add(float* p, float v) {
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+// The scatter of the backward pass, ORDER-INDEPENDENT: a tap's contribution is  g_c * w  with  g_c in {-k_c, 0, +k_c}
+// (k_c = the constant L1 seed of channel c) and an interpolation weight w in [0,1], so what is accumulated is the
+// signed weight in fixed point (2^-40 steps: exact for every fp32 weight >= 2^-17) with 64-bit INTEGER atomics --
+// integer addition is associative, the sums are the same bits whatever the interleaving of the waves -- and the finish
+// kernel multiplies by k_c once.  (Rounds 1-2 scattered with fp32 atomics: different from run to run, which hid the real
+// fault of those rounds behind "atomic noise" -- packed-fp32 arithmetic going wrong next to another queue's MFMA waves,
+// DESIGN.md section 3; the library is built without those instructions now.)  The own-pixel terms (target colours, projected
+// depth, interpolation weights -> depth, depth hinge) belong to exactly one thread each: plain read-modify-writes.
+#define RGBD_WARP_FIX_BITS 40
+__device__ __forceinline__ void scatter_fix(long long* p, float signed_w) {
+    const long long q = __double2ll_rn((double)signed_w * 1099511627776.0);   // 2^40; the product is exact
+    if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)q);
 }
 
 __global__ __launch_bounds__(256) void warp_loss_bwd_kernel(
     const float* __restrict__ img, const float* __restrict__ img_rot, const float* __restrict__ coef,
     int b, int S, int flags, float lambda_geo, float max_depth, float min_depth, float hinge_lambda, float hinge_min,
-    const float* __restrict__ grad_loss, float grad_scale, float* __restrict__ gimg, float* __restrict__ gimg_rot) {
+    const float* __restrict__ grad_loss, float grad_scale, float* __restrict__ gimg, float* __restrict__ gimg_rot,
+    long long* __restrict__ acc) {
     const int dir = blockIdx.y;
     const int hw = S * S;
     const long n = (long)blockIdx.x * 256 + threadIdx.x;
@@ -183,7 +190,6 @@ __global__ __launch_bounds__(256) void warp_loss_bwd_kernel(
     const float* own = dir == 0 ? img : img_rot;
     const float* src = dir == 0 ? img_rot : img;
     float* gown = dir == 0 ? gimg : gimg_rot;
-    float* gsrc = dir == 0 ? gimg_rot : gimg;
     const int bi = (int)(n / hw);
     const int pix = (int)(n - (long)bi * hw);
     const int i = pix / S, j = pix - i * S;
@@ -191,13 +197,14 @@ __global__ __launch_bounds__(256) void warp_loss_bwd_kernel(
     const float* ob = own + (long)bi * 4 * hw;
     const float* sb = src + (long)bi * 4 * hw;
     float* gob = gown + (long)bi * 4 * hw;
-    float* gsb = gsrc + (long)bi * 4 * hw;
+    long long* asb = acc + ((long)(dir == 0 ? b : 0) + bi) * 4 * hw;    // acc: (2b,4,hw), images first, then rotated images
     const float z = ob[3 * hw + pix];
     const float go = (grad_loss ? grad_loss[0] : 1.f) * grad_scale;
+    float gz_own = 0.f;
     if (hinge_lambda != 0.f && z < hinge_min)      // d/dz of hinge_lambda * mean_{2N} relu(hinge_min - z)^2
-        scatter_add(gob + 3 * hw + pix, go * hinge_lambda * (0.5f / (float)N) * (-2.f * (hinge_min - z)));
+        gz_own = go * hinge_lambda * (0.5f / (float)N) * (-2.f * (hinge_min - z));
     const PixelWarp w = project_pixel(cf, dir == 0 ? -1.f : 1.f, z, i, j, S);
-    if (!w.mask) return;  // masked pixels have zero weights, zero targets and constant taps: no gradient
+    bool vis = w.mask;   // masked pixels have zero weights, zero targets and constant taps: no gradient
     const int o00 = w.u0m * S + w.v0m;
     const int o01 = w.u0m * S + w.v1m;
     float a[4], d[4], warped[4];
@@ -207,37 +214,42 @@ __global__ __launch_bounds__(256) void warp_loss_bwd_kernel(
         d[c] = sb[c * hw + o01];
         warped[c] = ((w.w1 * a[c] + w.w2 * a[c]) + w.w3 * d[c]) + w.w4 * d[c];
     }
-    bool vis = true;
     if (flags & RGBD_WARP_OCCLUSION) vis = vis && (warped[3] > w.zp2);
     if (flags & RGBD_WARP_MAX_DEPTH) vis = vis && (z < max_depth);
     if (flags & RGBD_WARP_MIN_DEPTH) vis = vis && (z > min_depth);
-    if (!vis) return;
+    if (!vis) {
+        if (gz_own != 0.f) gob[3 * hw + pix] += gz_own;
+        return;
+    }
     const float inv_n = 1.f / (float)N;
     const float k_rgb = go * inv_n / 3.f;
     const float k_d = go * inv_n * lambda_geo;
-    float g[4];
+    float sg[4], g[4];   // sign of the L1 term's derivative, and the derivative
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float diff = warped[c] - ob[c * hw + pix];
-        g[c] = diff > 0.f ? k_rgb : (diff < 0.f ? -k_rgb : 0.f);
+        sg[c] = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+        g[c] = sg[c] * k_rgb;
     }
     {
         const float diff = warped[3] - w.zp2;
-        g[3] = diff > 0.f ? k_d : (diff < 0.f ? -k_d : 0.f);
+        sg[3] = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+        g[3] = sg[3] * k_d;
     }
-    // (1) gathered values -> scatter-add into the sampled image (two distinct taps; rows u0 and "u1" coincide)
+    // (1) gathered values -> scatter into the sampled image (two distinct taps; rows u0 and "u1" coincide)
     const float wl = w.w1 + w.w2, wr = w.w3 + w.w4;
     float gw_a = 0.f, gw_d = 0.f;  // sum_c g[c] * tap value
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        scatter_add(gsb + c * hw + o00, g[c] * wl);
-        scatter_add(gsb + c * hw + o01, g[c] * wr);
+        scatter_fix(asb + c * hw + o00, sg[c] * wl);
+        scatter_fix(asb + c * hw + o01, sg[c] * wr);
         gw_a += g[c] * a[c];
         gw_d += g[c] * d[c];
     }
     // (2) targets: own RGB and projected depth
 #pragma unroll
-    for (int c = 0; c < 3; ++c) scatter_add(gob + c * hw + pix, -g[c]);
+    for (int c = 0; c < 3; ++c)
+        if (sg[c] != 0.f) gob[c * hw + pix] -= g[c];
     float gzp2 = -g[3];
     // (3) interpolation weights -> (u, v) -> zp -> own depth.  dL/dw1 = dL/dw2 = gw_a, dL/dw3 = dL/dw4 = gw_d.
     const float du1 = w.u1f - w.u, du0 = w.u - w.u0f, dv1 = w.v1f - w.v, dv0 = w.v - w.v0f;
@@ -250,7 +262,31 @@ __global__ __launch_bounds__(256) void warp_loss_bwd_kernel(
     const float p0 = (float)j, p1 = (float)i;
     const float gz = gzp0 * (cf[0] * p0 + cf[1] * p1 + cf[2]) + gzp1 * (cf[3] * p0 + cf[4] * p1 + cf[5]) +
                      gzp2 * (cf[6] * p0 + cf[7] * p1 + cf[8]);
-    scatter_add(gob + 3 * hw + pix, gz);
+    gob[3 * hw + pix] += gz_own + gz;
+}
+
+// grad[(image, c, pixel)] += k_c * acc * 2^-40 : the scattered sums, converted once.  Four pixels per thread.
+__global__ __launch_bounds__(256) void warp_loss_bwd_finish_kernel(
+    const long long* __restrict__ acc, int b, int hw, float lambda_geo, const float* __restrict__ grad_loss,
+    float grad_scale, float* __restrict__ gimg, float* __restrict__ gimg_rot) {
+    const long N = (long)b * hw;
+    const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4;        // element of the (2b,4,hw) accumulator
+    if (e >= 8 * N) return;
+    const long img_i = e / (4 * (long)hw);
+    const int c = (int)((e / hw) & 3);
+    const float go = (grad_loss ? grad_loss[0] : 1.f) * grad_scale;
+    const float inv_n = 1.f / (float)N;
+    const float k = c < 3 ? go * inv_n / 3.f : go * inv_n * lambda_geo;
+    float* g = (img_i < b ? gimg : gimg_rot - 4 * N) + e;
+    const long long* a = acc + e;
+    const long long q0 = a[0], q1 = a[1], q2 = a[2], q3 = a[3];
+    if ((q0 | q1 | q2 | q3) == 0) return;
+    f32x4 v = *reinterpret_cast<f32x4*>(g);
+    v[0] += k * ((float)((double)q0 * 9.094947017729282e-13));
+    v[1] += k * ((float)((double)q1 * 9.094947017729282e-13));
+    v[2] += k * ((float)((double)q2 * 9.094947017729282e-13));
+    v[3] += k * ((float)((double)q3 * 9.094947017729282e-13));
+    *reinterpret_cast<f32x4*>(g) = v;
 }
 
 }  // namespace
@@ -273,36 +309,36 @@ extern "C" int rgbd_warp_loss_fwd(const float* img, const float* img_rot, const 
     return 0;
 }
 
+extern "C" int64_t rgbd_warp_loss_bwd_workspace(int b, int S) {
+    return b > 0 && S > 0 ? (int64_t)2 * b * 4 * S * S * (int64_t)sizeof(long long) : 0;
+}
+
 extern "C" int rgbd_warp_loss_bwd(const float* img, const float* img_rot, const float* coef, int b, int S,
                                   int flags, float lambda_geometric, float max_depth, float min_depth,
                                   float hinge_lambda, float hinge_min,
                                   const float* grad_loss, float grad_scale, float* grad_img, float* grad_img_rot,
-                                  int accumulate, void* stream) {
-    RGBD_REQUIRE(img && img_rot && coef && grad_img && grad_img_rot, "rgbd_warp_loss_bwd: null pointer");
-    RGBD_REQUIRE(b > 0 && S >= 2, "rgbd_warp_loss_bwd: bad shape b=%d S=%d", b, S);
+                                  int accumulate, void* workspace, void* stream) {
+    RGBD_REQUIRE(img && img_rot && coef && grad_img && grad_img_rot && workspace, "rgbd_warp_loss_bwd: null pointer");
+    RGBD_REQUIRE(b > 0 && S >= 2 && (S * S) % 4 == 0, "rgbd_warp_loss_bwd: bad shape b=%d S=%d", b, S);
+    RGBD_REQUIRE(((uintptr_t)workspace & 15) == 0 && ((uintptr_t)grad_img & 15) == 0 && ((uintptr_t)grad_img_rot & 15) == 0,
+                 "rgbd_warp_loss_bwd: workspace and gradient buffers must be 16-byte aligned");
     const long N = (long)b * S * S;
     hipStream_t st = (hipStream_t)stream;
-    if (!accumulate && (rgbd_zero_async(grad_img, N * 4 * sizeof(float), st) != hipSuccess ||
-                        rgbd_zero_async(grad_img_rot, N * 4 * sizeof(float), st) != hipSuccess)) {
-        rgbd_set_error("rgbd_warp_loss_bwd: memset failed");
+    long long* acc = static_cast<long long*>(workspace);
+    bool ok = rgbd_zero_async(acc, (size_t)rgbd_warp_loss_bwd_workspace(b, S), st) == hipSuccess;
+    if (!accumulate)
+        ok = ok && rgbd_zero_async(grad_img, N * 4 * sizeof(float), st) == hipSuccess &&
+             rgbd_zero_async(grad_img_rot, N * 4 * sizeof(float), st) == hipSuccess;
+    if (!ok) {
+        rgbd_set_error("rgbd_warp_loss_bwd: clearing the accumulators failed");
         return -2;
     }
-    // Launched with ALL of a CU's LDS reserved (never touched): a workgroup of this kernel then cannot share a compute unit
-    // with a workgroup of any kernel that uses LDS, in particular the convolution kernels (48-147 KB each).  Sharing one is what corrupted the scatter --
-    // contributions missing or wrong by orders of magnitude in ~30 % of the launches while another queue or process ran
-    // conv3x3_sp_kernel / conv_fprop_kernel on the same GPU, none in 10^5 launches next to anything else
-    // (scripts/hw/atomic_share_stress.py).
-    static const int lds_reserve = [] {
-        const char* e = getenv("RGBD_DEBUG_WARP_LDS");
-        const int v = e ? atoi(e) : 160 * 1024;
-        if (v > 0) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(warp_loss_bwd_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, v);
-        return v;
-    }();
-    warp_loss_bwd_kernel<<<dim3(ceil_div(N, 256), 2), 256, lds_reserve, st>>>(img, img_rot, coef, b, S, flags,
-                                                                    lambda_geometric, max_depth, min_depth, hinge_lambda,
-                                                                    hinge_min, grad_loss, grad_scale, grad_img,
-                                                                    grad_img_rot);
+    warp_loss_bwd_kernel<<<dim3(ceil_div(N, 256), 2), 256, 0, st>>>(img, img_rot, coef, b, S, flags, lambda_geometric,
+                                                                    max_depth, min_depth, hinge_lambda, hinge_min,
+                                                                    grad_loss, grad_scale, grad_img, grad_img_rot, acc);
     RGBD_CHECK_LAUNCH("warp_loss_bwd_kernel");
+    warp_loss_bwd_finish_kernel<<<ceil_div(2 * N, 256), 256, 0, st>>>(acc, b, S * S, lambda_geometric, grad_loss,
+                                                                      grad_scale, grad_img, grad_img_rot);
+    RGBD_CHECK_LAUNCH("warp_loss_bwd_finish_kernel");
     return 0;
 }

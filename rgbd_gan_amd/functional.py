@@ -457,24 +457,31 @@ def conv_bias_lrelu_adain(x, layer, bias, group, j, upsample=False):
 
 class _WarpLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, img, img_rot, coef, flags, lam, max_depth, min_depth):
+    def forward(ctx, img, img_rot, coef, flags, lam, max_depth, min_depth, want_zp):
         ctx.cfg = (flags, lam, max_depth, min_depth)
         ctx.save_for_backward(img, img_rot, coef)
-        return kernels.warp_loss_fwd(img, img_rot, coef, flags, lam, max_depth, min_depth).reshape(())
+        if want_zp:
+            loss, zp = kernels.warp_loss_fwd(img, img_rot, coef, flags, lam, max_depth, min_depth, want_zp=True)
+        else:
+            loss, zp = kernels.warp_loss_fwd(img, img_rot, coef, flags, lam, max_depth, min_depth), img.new_empty(0)
+        ctx.mark_non_differentiable(zp)
+        return loss.reshape(()), zp
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, gl):
+    def backward(ctx, gl, _gzp):
         img, img_rot, coef = ctx.saved_tensors
         flags, lam, max_depth, min_depth = ctx.cfg
         gi, gr = kernels.warp_loss_bwd(img, img_rot, coef, flags, lam, max_depth, min_depth,
                                        gl.reshape(1).float().contiguous())
-        return gi, gr, None, None, None, None, None
+        return gi, gr, None, None, None, None, None, None
 
 
-def warp_loss(img, img_rot, coef, flags, lambda_geometric, max_depth=0.0, min_depth=0.0):
+def warp_loss(img, img_rot, coef, flags, lambda_geometric, max_depth=0.0, min_depth=0.0, want_zp=False):
+    """-> (loss, zp): the differentiable loss and, with want_zp, the projected points (2,b,S*S,3) of both directions (a
+    by-product the reference returns as its second value, loss_functions.py:146; not differentiable here; else empty)."""
     return _WarpLoss.apply(img.contiguous(), img_rot.contiguous(), coef, int(flags), float(lambda_geometric),
-                           float(max_depth), float(min_depth))
+                           float(max_depth), float(min_depth), bool(want_zp))
 
 
 def avg_pool2_nhwc(x):

@@ -87,9 +87,10 @@ def _chk(t, dtype, name):
 
 # ------------------------------------------------------------------ warp loss
 def warp_loss_fwd(img, img_rot, coef, flags, lambda_geometric, max_depth=0.0, min_depth=0.0, debug=False,
-                  hinge_lambda=0.0, hinge_min=0.0):
+                  hinge_lambda=0.0, hinge_min=0.0, want_zp=False):
     """img, img_rot (b,4,S,S) fp32; coef (b,24) fp32 -> loss (1,) [+ debug tensors].  hinge_lambda > 0: the depth-range
-    hinge of updater.py:357-359 over both image sets is added in the same pass."""
+    hinge of updater.py:357-359 over both image sets is added in the same pass.  want_zp: also return the projected
+    points (2,b,S*S,3) = [new_zp, new_zp_rot] (loss_functions.py:146)."""
     for t, n in ((img, "img"), (img_rot, "img_rot"), (coef, "coef")):
         _chk(t, F32, n)
     b, C, S, _ = img.shape
@@ -99,8 +100,9 @@ def warp_loss_fwd(img, img_rot, coef, flags, lambda_geometric, max_depth=0.0, mi
     partials = torch.empty(6 * ((N + 255) // 256), dtype=F32, device=img.device)
     loss = torch.empty(1, dtype=F32, device=img.device)
     zp = warped = idx = None
-    if debug:
+    if debug or want_zp:
         zp = torch.empty(2, b, S * S, 3, dtype=F32, device=img.device)
+    if debug:
         warped = torch.empty(2, N, 4, dtype=F32, device=img.device)
         idx = torch.empty(2, N, 4, dtype=torch.int32, device=img.device)
     rc = _lib.load().rgbd_warp_loss_fwd(_ptr(img), _ptr(img_rot), _ptr(coef), b, S, int(flags),
@@ -108,7 +110,9 @@ def warp_loss_fwd(img, img_rot, coef, flags, lambda_geometric, max_depth=0.0, mi
                                         float(hinge_lambda), float(hinge_min),
                                         _ptr(partials), _ptr(loss), _ptr(zp), _ptr(warped), _ptr(idx), _stream())
     _lib.check(rc, "rgbd_warp_loss_fwd")
-    return (loss, zp, warped, idx) if debug else loss
+    if debug:
+        return loss, zp, warped, idx
+    return (loss, zp) if want_zp else loss
 
 
 def warp_loss_bwd(img, img_rot, coef, flags, lambda_geometric, max_depth, min_depth, grad_loss, hinge_lambda=0.0,
@@ -124,10 +128,12 @@ def warp_loss_bwd(img, img_rot, coef, flags, lambda_geometric, max_depth, min_de
         _chk(gimg, F32, "out[0]"); _chk(gimg_rot, F32, "out[1]")
         if gimg.shape != img.shape or gimg_rot.shape != img_rot.shape:
             raise RuntimeError("warp_loss_bwd: accumulation buffers must have the images' shape")
-    rc = _lib.load().rgbd_warp_loss_bwd(_ptr(img), _ptr(img_rot), _ptr(coef), b, S, int(flags),
-                                        float(lambda_geometric), float(max_depth), float(min_depth),
-                                        float(hinge_lambda), float(hinge_min), _ptr(grad_loss), float(grad_scale),
-                                        _ptr(gimg), _ptr(gimg_rot), acc, _stream())
+    lib = _lib.load()
+    ws = torch.empty(lib.rgbd_warp_loss_bwd_workspace(b, S) // 8, dtype=torch.int64, device=img.device)
+    rc = lib.rgbd_warp_loss_bwd(_ptr(img), _ptr(img_rot), _ptr(coef), b, S, int(flags),
+                                float(lambda_geometric), float(max_depth), float(min_depth),
+                                float(hinge_lambda), float(hinge_min), _ptr(grad_loss), float(grad_scale),
+                                _ptr(gimg), _ptr(gimg_rot), acc, _ptr(ws), _stream())
     _lib.check(rc, "rgbd_warp_loss_bwd")
     return gimg, gimg_rot
 
@@ -651,11 +657,6 @@ def real_batch(data_u8, idx, size, alpha=None, out=None):
                                         float(alpha) if fade and a_dev is None else 0.0, _stream())
     _lib.check(rc, "rgbd_real_batch_u8")
     return out
-
-
-def l2_sync():
-    """Diagnostic launch: write back + invalidate all L2s (see rgbd_debug_l2_sync)."""
-    _lib.check(_lib.load().rgbd_debug_l2_sync(_stream()), "rgbd_debug_l2_sync")
 
 
 def zero_multi(tensors):

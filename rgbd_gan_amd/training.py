@@ -121,7 +121,7 @@ class DeviceImageIterator:
     __next__ = next
 
 
-def build_training(config, device, comm=None, iterator=None, **updater_kwargs):
+def build_training(config, device, comm=None, iterator=None, updater_class=None, **updater_kwargs):
     generator = setup_generator(config, device)
     discriminator = setup_discriminator(config, device)
     optimizer = make_optimizers(config, generator, discriminator, comm)
@@ -130,12 +130,14 @@ def build_training(config, device, comm=None, iterator=None, **updater_kwargs):
         models.append(setup_generator(config, device, seed=1000))    # its own random init, like the reference
     if config.generator_architecture == "deepvoxels":             # train_rgbd.py:355-356
         from .updater_deepvoxels import DeepVoxelsUpdater as Updater
-        for k in ("graph_phases", "fixed_stage", "concurrent_phases", "defer_dfake_wgrads", "dfw_on_side", "hybrid"):
+        for k in ("fixed_stage", "concurrent_phases", "dp_split_body", "graph_fallback"):
             updater_kwargs.pop(k, None)
     elif config.rgb:                                               # train_rgbd.py:357-358
         Updater = RGBUpdater
     else:
         Updater = RGBDUpdater
+    if updater_class is not None:                                  # tests: a subclass with one phase overridden
+        Updater = updater_class
     updater = Updater(models=models, config=config, optimizer=optimizer, iterator=iterator,
                       lambda_gp=config.lambda_gp, smoothing=config.smoothing,
                       total_gpu=comm.size if comm is not None else 1, prior=CameraParamPrior(config),

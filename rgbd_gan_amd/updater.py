@@ -177,34 +177,27 @@ class RGBDUpdater:
         # stay on the device and are checked every `nan_check_interval` iterations (1 = the reference's behaviour)
         self.nan_check_interval = int(kwargs.pop("nan_check_interval", 100))
         self.fixed_stage = kwargs.pop("fixed_stage", None)   # bench / tests: pin the stage
-        # HIP graphs: the G phase, the D phase and the optimizer phase of a step are captured once per
-        # (batch, stage, loss flags) and replayed; collectives stay outside the graphs.  Fade-in (odd) stages change
-        # a blend factor every iteration and run eagerly.
+        # HIP graphs: the step body and the optimizer phase are captured once per (batch, stage, loss flags) and
+        # replayed; collectives stay outside the graphs.  A refused capture is an error unless graph_fallback is set.
         self.use_graphs = bool(kwargs.pop("use_graphs", True))
         self.graph_warmup = int(kwargs.pop("graph_warmup", 2))
-        self.graph_phases = tuple(kwargs.pop("graph_phases", ("body", "body_g", "body_d", "opt", "opt_g", "opt_d",
-                                                              "prep", "gen_a", "gen_b", "gen_w")))
-        # data parallel, one stream: split the body graph after G's backward so G's all-reduce overlaps the D half
-        self.dp_split_body = bool(kwargs.pop("dp_split_body", not os.environ.get("RGBD_DP_NO_SPLIT")))
-        # The generator phase and the discriminator-on-reals phase are independent until the optimizer phase, and on two
-        # streams the bubbles of one fill with the other's kernels (8.5 vs 9.7 ms per step at B=32): the default.  It was
-        # off until the cause of the wrong generator gradients it produced was found -- the warp-loss backward's scatter
-        # sharing a compute unit with convolution workgroups, cured in that kernel's launch (warp_loss.hip, DESIGN.md
-        # section 3).  RGBD_CONCURRENT_PHASES=0 (or concurrent_phases=False) runs the phases back to back on one stream;
-        # the shared-device test arrangement always does.
+        self.graph_fallback = bool(kwargs.pop("graph_fallback", False))
+        # TWO arrangements of the same phases:
+        #   two streams (default): the generator phase and the discriminator-on-reals phase are independent until the
+        #     optimizer phase; on two streams the bubbles of one fill with the other's kernels.  One graph, fork and
+        #     join inside it.
+        #   one stream (concurrent_phases=False / RGBD_CONCURRENT_PHASES=0; always in the shared-device test arrangement):
+        #     the phases back to back; under data parallelism the body is split where G's gradients are final so that
+        #     the map + gen all-reduces travel under D's half (dp_split_body).
         env = os.environ.get("RGBD_CONCURRENT_PHASES")
         self.concurrent_phases = bool(kwargs.pop("concurrent_phases", (env is None or env not in ("", "0"))
                                                  and not os.environ.get("RGBD_SHARE_DEVICE")))
+        self.dp_split_body = bool(kwargs.pop("dp_split_body", True))
+        if kwargs:
+            raise TypeError(f"RGBDUpdater: unknown arguments {sorted(kwargs)}")
         self._side_stream = None
-        # in that arrangement D's weight gradients for the fakes (leaves of the backward graph) are moved from the
-        # longer generator chain to the tail of the side stream
-        # hybrid two-stream arrangement (experimental, RGBD_HYBRID=1 with RGBD_CONCURRENT_PHASES=1): the generator phase is
-        # replayed from graphs on the main stream while the discriminator-on-reals phase is launched EAGERLY on the side
-        # stream -- only one of the two concurrent queues then carries graph launches
-        self.hybrid = int(kwargs.pop("hybrid", int(os.environ.get("RGBD_HYBRID", "0") or 0)))
-        self.defer_dfake_wgrads = bool(kwargs.pop("defer_dfake_wgrads", not os.environ.get("RGBD_NO_DEFER")))
-        self.dfw_on_side = bool(kwargs.pop("dfw_on_side", not os.environ.get("RGBD_DFW_ON_MAIN")))
-        self._graphs, self._eager_calls, self._stagers, self._ones, self._dbg = {}, {}, {}, {}, {}
+        self._graphs, self._eager_calls, self._stagers, self._ones = {}, {}, {}, {}
+        self._warp_ws = {}
         self.device = self.gen.device
 
     # ---- chainer StandardUpdater surface
@@ -259,92 +252,8 @@ class RGBDUpdater:
             self._stagers[key] = _HostStager(shape, dtype, self.device)
         return self._stagers[key]
 
-    # ---- the phases of a step: prep, gen || dis, join, opt (each one is capturable: device work only, fixed launch
-    #      sequence)
-    def _gen_phase(self, st):
-        """G forward, the one pass through D(x_fake), G backward -- as one phase (sequential arrangement)."""
-        with _alpha_ctx(st):
-            self._gen_phase_body(st)
-            self._gen_phase_tail(st)
-
-    def _gen_a_phase(self, st):
-        """First part of the generator phase in the two-stream arrangement: up to the image gradient gx.  D's weight
-        gradients for the fakes are only COLLECTED here (st['dfw']): they run on the other stream (_dfw_phase) once the
-        discriminator phase there has finished, instead of lengthening this stream's dependent chain."""
-        st["dfw"] = []
-        with _alpha_ctx(st), Fn.deferred_wgrads(st["dfw"]):
-            self._gen_phase_body(st)
-
-    def _gen_b_phase(self, st):
-        with _alpha_ctx(st):
-            self._gen_phase_tail(st)
-
-    def _dfw_phase(self, st):
-        Fn.run_deferred_wgrads(st["dfw"])
-
-    def _gen_w_phase(self, st):
-        """Hybrid arrangement: both weight-gradient batches of the generator phase (G's own, D's for the fakes), after
-        the side stream has been joined (the batches share the slab workspace with the discriminator phase's)."""
-        Fn.run_deferred_wgrads(st["gwgrads"])
-        Fn.run_deferred_wgrads(st["dfw"])
-
-    def _prep_only_phase(self, st):
-        with _alpha_ctx(st):
-            self._prep_phase(st)
-
-    def _hybrid_body(self, st, key):
-        main, side = torch.cuda.current_stream(), self._side_stream
-        if self.hybrid >= 2:
-            # nothing serialised beyond the data dependencies: G's weight-gradient batch runs inside gen_b, D's batch for
-            # the fakes follows the discriminator phase on the side stream (eagerly, from the list gen_a's capture left)
-            st["_main"], st["_side"], st["split_gw"] = None, None, False
-            self._run_phase("prep", self._prep_only_phase, st, key)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                self._dis_phase(st)
-            self._run_phase("gen_a", self._gen_a_phase, st, key)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                self._dfw_phase(st)
-            self._run_phase("gen_b", self._gen_b_phase, st, key)
-            main.wait_stream(side)
-            self._join_phase(st)
-            return
-        if self.hybrid in (3, 4):
-            # diagnostics: 3 = G's weight-gradient batch inside gen_b (concurrent with the eager side stream), D's batch for
-            # the fakes after the join; 4 = G's batch after the join, D's batch for the fakes eagerly on the side stream
-            st["_main"], st["_side"], st["split_gw"] = None, None, self.hybrid == 4
-            self._run_phase("prep", self._prep_only_phase, st, key)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                self._dis_phase(st)
-            self._run_phase("gen_a", self._gen_a_phase, st, key)
-            if self.hybrid == 4:
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    self._dfw_phase(st)
-            self._run_phase("gen_b", self._gen_b_phase, st, key)
-            main.wait_stream(side)
-            if self.hybrid == 4:
-                self._run_phase("gen_w", self._gen_w4_phase, st, key)
-            else:
-                self._run_phase("gen_w", self._dfw_phase, st, key)
-            self._join_phase(st)
-            return
-        st["_main"], st["_side"], st["split_gw"] = main, side, True
-        self._run_phase("prep", self._prep_only_phase, st, key)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            self._dis_phase(st)                       # eager launches on the side stream
-        self._run_phase("gen_a", self._gen_a_phase, st, key)
-        self._run_phase("gen_b", self._gen_b_phase, st, key)
-        main.wait_stream(side)
-        self._run_phase("gen_w", self._gen_w_phase, st, key)
-        self._join_phase(st)
-
-    def _gen_w4_phase(self, st):
-        Fn.run_deferred_wgrads(st["gwgrads"])
-
+    # ---- the phases of a step: prep, gen_a -> gen_b || dis -> dfw, join, opt (each one is capturable: device work only,
+    #      fixed launch sequence)
     def _prep_phase(self, st):
         """Everything both concurrent phases depend on: cleared gradient buffers, the (down-sized) real batch, and the
         bf16 weight images of both networks (repacked here so neither phase does it behind the other's back)."""
@@ -369,25 +278,47 @@ class RGBDUpdater:
             if group is not None:
                 group.layers[0].packed()
 
-    def _gen_phase_body(self, st):
-        cfg = self.config
-        stage, B, half = st["stage"], st["B"], st["B"] // 2
+    def _gen_a_phase(self, st):
+        """G forward and the ONE pass through D(x_fake), up to the image gradient gx.  D's weight gradients for the fakes
+        are only COLLECTED here (st['dfw']): they are issued as one batch by _dfw_phase -- behind the discriminator
+        phase on the second stream, or after G's backward on one stream -- instead of lengthening G's dependent chain."""
+        st["dfw"] = []
+        with _alpha_ctx(st), Fn.deferred_wgrads(st["dfw"]):
+            self._gen_forward_and_dfake(st)
+
+    def _gen_b_phase(self, st):
+        with _alpha_ctx(st):
+            self._gen_backward(st)
+
+    def _dfw_phase(self, st):
+        Fn.run_deferred_wgrads(st["dfw"])
+
+    def _gen_seeds(self, st, x_d, y_fake, seed_g, seed_d, ratio):
+        """D(x_fake) is evaluated and differentiated ONCE per step.  The reference runs the discriminator on the same
+        fakes twice with identical weights (updater.py:331,404-405) and back-propagates twice: once from the
+        generator's loss (to the image) and once from the discriminator's loss (to D's weights).  D treats samples
+        independently (no batch statistics), so both backward passes are the same linear map applied to per-sample
+        seeds dL/dy_b; one pass seeded with the discriminator's dL_D/dy_b yields D's weight gradients AND, rescaled
+        per sample by (dL_G/dy_b) / (dL_D/dy_b), the generator's image gradient.  -> (gx, ratio)
+        (tests/dp_worker.py overrides this with the generator's own seed to check the ratio chain at the logit clamp.)"""
+        with contextlib.ExitStack() as stack:
+            if st.get("concurrent"):          # D's real-batch gradients are being written on the other stream
+                for _, store in self.dis.stores:
+                    stack.enter_context(store.alt_grads())
+            torch.autograd.backward([y_fake], [seed_d], inputs=[x_d] + list(self.dis.params()))
+        return x_d.grad, ratio.reshape(-1).contiguous()
+
+    def _gen_forward_and_dfake(self, st):
+        stage, half = st["stage"], st["B"] // 2
         obs = self.observation
         if st["z"] is not None:
             z = st["z"]
+        elif hasattr(self.gen, "make_hidden_pairs"):
+            z = self.gen.make_hidden_pairs(half)                        # same latent for both views, one launch
         else:
-            if hasattr(self.gen, "make_hidden_pairs"):
-                z = self.gen.make_hidden_pairs(half)                        # same latent for both views, one launch
-            else:
-                z_half = self.get_z_fake_data(half)
-                z = torch.cat([z_half, z_half], dim=0)
+            z_half = self.get_z_fake_data(half)
+            z = torch.cat([z_half, z_half], dim=0)
         x_fake = self.gen(z, stage, st["theta9"])
-        # D(x_fake) is evaluated and differentiated ONCE per step.  The reference runs the discriminator on the same
-        # fakes twice with identical weights (updater.py:331,404-405) and back-propagates twice: once from the
-        # generator's loss (to the image) and once from the discriminator's loss (to D's weights).  D treats samples
-        # independently (no batch statistics), so both backward passes are the same linear map applied to per-sample
-        # seeds dL/dy_b; one pass seeded with the discriminator's dL_D/dy_b yields D's weight gradients AND, rescaled
-        # per sample by (dL_G/dy_b) / (dL_D/dy_b), the generator's image gradient.
         x_d = x_fake[:, :3].detach().contiguous().requires_grad_(True)
         y_fake = self.dis(x_d, stage=stage)      # (the hidden feature of updater.py:333 feeds only rotate_feature)
         # losses and seeds of both adversarial terms from the logits in one launch; seeds from logits clamped at -60:
@@ -395,35 +326,19 @@ class RGBDUpdater:
         # sigmoid(y)/B is < 1e-26/B either way, but their ratio stays finite (an unclamped logit of -90 would give 0 * inf)
         heads, seed_g, seed_d, ratio = kernels.gan_logit_heads(y_fake.detach())
         obs["gen/loss_adv"] = heads[0]                                      # loss_func_dcgan_gen(y_fake)
-        if st.get("share_dfake", True):
-            with contextlib.ExitStack() as stack:
-                if st.get("concurrent"):          # D's real-batch gradients are being written on the other stream
-                    for _, store in self.dis.stores:
-                        stack.enter_context(store.alt_grads())
-                torch.autograd.backward([y_fake], [seed_d], inputs=[x_d] + list(self.dis.params()))
-            gx = x_d.grad                   # d loss_dis / d x_fake; times ratio_b = the generator's adversarial gradient
-            st["ratio"] = ratio.reshape(-1).contiguous()
-            st["loss_dfake"] = heads[1]                                     # fake term of loss_func_dcgan_dis
-        else:
-            with Fn.weight_grads_frozen(self.dis):
-                gx, = torch.autograd.grad([y_fake], [x_d], [seed_g])
-            st["ratio"] = None
-            st["loss_dfake"] = None
-        st["gx"], st["x_fake"] = gx, x_fake
+        st["loss_dfake"] = heads[1]                                         # fake term of loss_func_dcgan_dis
+        st["gx"], st["ratio"] = self._gen_seeds(st, x_d, y_fake, seed_g, seed_d, ratio)
+        st["x_fake"] = x_fake
 
-    def _gen_phase_tail(self, st):
+    def _gen_backward(self, st):
         """3-D consistency loss, depth hinge and the generator's backward.  The output gradient of G is assembled by
         hand, not by autograd: rgbd_image_grad_init writes the adversarial part (per-sample ratio * dL_D/dx_fake on the
         RGB planes, zeros on the depth plane), the warp-loss backward ADDS lambda_rotate * d(loss_rotate)/dx_fake with
-        the depth hinge of updater.py:357-359 evaluated in the same two kernels, and x_fake.backward(that) runs G's
-        backward: 4 launches where slicing, hinge, scaling and the gradient sums were ~25."""
+        the depth hinge of updater.py:357-359 evaluated in the same kernels, and x_fake.backward(that) runs G's
+        backward: a handful of launches where slicing, hinge, scaling and the gradient sums were ~25."""
         cfg, obs = self.config, self.observation
         x_fake, half = st["x_fake"], st["B"] // 2
         gout = kernels.image_grad_init(st["gx"].contiguous(), st["ratio"], x_fake.shape[1])
-        dbg = self._dbg if os.environ.get("RGBD_DEBUG_DUMP") else None
-        if dbg is not None:
-            dbg.update(gx=st["gx"].clone(), gout0=gout.clone(), x_fake=x_fake.detach().clone(),
-                       ratio=st["ratio"].clone() if st["ratio"] is not None else None)
         if st["use_rotate"]:
             if cfg.rotate_feature:
                 raise AssertionError("rotate_feature is not supported")
@@ -439,38 +354,20 @@ class RGBDUpdater:
             kernels.warp_loss_bwd(xf[:half], xf[half:], st["coef"], flags, lf.lambda_geometric, 0.0, 0.0, None,
                                   hinge_lambda=hinge, hinge_min=float(cfg.depth_min or 0.0),
                                   grad_scale=float(lambda_rotate), out=(gout[:half], gout[half:]))
-            if "warp" in st.get("_l2s", ()):
-                kernels.l2_sync()
             if cfg.use_occupancy_net_loss:
                 raise AssertionError("occupancy-net loss is not supported")
-            if dbg is not None:
-                dbg.update(gout1=gout.clone(), coef_after=st["coef"].clone(), x_fake_after=xf.clone())
-                again = dbg["gout0"].clone()          # the same scatter once more, same inputs, a few kernels later
-                kernels.warp_loss_bwd(xf[:half], xf[half:], st["coef"], flags, lf.lambda_geometric, 0.0, 0.0, None,
-                                      hinge_lambda=hinge, hinge_min=float(cfg.depth_min or 0.0),
-                                      grad_scale=float(lambda_rotate), out=(again[:half], again[half:]))
-                dbg.update(gout1_again=again)
         if cfg.optical_flow:
             raise AssertionError("optical flow loss is not supported")
         # the generator's weight gradients are leaves of this backward pass: collected while it runs, issued after it
         # as one batch (one slab-reduction launch for all of them instead of one per layer)
-        if not os.environ.get("RGBD_NO_G_DEFER"):       # (+2 % step rate, A/B on one box)
-            wgrads = []
-            with Fn.deferred_wgrads(wgrads):
-                torch.autograd.backward([x_fake], [gout])
-            if st.get("split_gw"):
-                st["gwgrads"] = wgrads                  # hybrid arrangement: issued by _gen_w_phase, after the join
-            else:
-                if st.get("_side") is not None and os.environ.get("RGBD_DEBUG_GENB") != "no_wgrad_wait":
-                    # the two weight-gradient batches (this one and D's for the fakes on the side stream) never run
-                    # concurrently: see DESIGN.md section 3, "two concurrent weight-gradient batches"
-                    torch.cuda.current_stream().wait_stream(st["_side"])
-                Fn.run_deferred_wgrads(wgrads)
-        else:
+        wgrads = []
+        with Fn.deferred_wgrads(wgrads):
             torch.autograd.backward([x_fake], [gout])
-        if dbg is not None:
-            from . import net as _net
-            dbg.update(_net.DEBUG_GRADS)
+        if st.get("_side") is not None:
+            # the two weight-gradient batches (this one and D's for the fakes on the side stream) share the slab
+            # workspace: they never run concurrently
+            torch.cuda.current_stream().wait_stream(st["_side"])
+        Fn.run_deferred_wgrads(wgrads)
         st["x_fake_data"] = x_fake.detach()
         st["x_fake"] = st["gx"] = None                 # drop the autograd graph
 
@@ -478,72 +375,43 @@ class RGBDUpdater:
         with _alpha_ctx(st):
             self._dis_phase_body(st)
 
-    def _dbg_sync(self, st, point):
-        """Diagnostics (scripts/graph_race.py): RGBD_DEBUG_SYNC_AT=<point> makes the main stream wait for the side
-        stream's work up to this point of the discriminator phase, so only the rest of it overlaps the generator phase."""
-        if os.environ.get("RGBD_DEBUG_SYNC_AT") == point and st.get("_main") is not None:
-            st["_main"].wait_stream(torch.cuda.current_stream())
-
     def _dis_phase_body(self, st):
+        """D on the reals.  The fake half of loss_func_dcgan_dis is differentiated in the generator phase (its weight
+        gradients go to D's gradient buffers, which are cleared at the start of the step); its value is added to the
+        report at the join."""
         stage = st["stage"]
         obs = self.observation
         x_real_v = st["x_real"].detach().requires_grad_(True)
         y_real = self.dis(x_real_v, stage=stage)
-        self._dbg_sync(st, "dis_fwd")
-        fake_done = bool(st.get("share_dfake", True))
-        real_heads = None
-        if fake_done:
-            # the fake half of loss_func_dcgan_dis is differentiated in the generator phase (its weight gradients go
-            # to D's gradient buffers, which are cleared at the start of the step); its value is added to the report in
-            # the optimizer phase, after the two phases have joined
-            y_fake = None
-            real_heads = kernels.gan_logit_heads(y_real.detach())
-            reported = real_heads[0][0]                                     # mean softplus(-y_real)
-        else:
-            self.dis.cleargrads()
-            y_fake = self.dis(st["x_fake_data"][:, :3].contiguous(), stage=stage)
-            reported = loss_func_dcgan_dis(y_fake.detach(), y_real.detach())
-        r1 = not self.dis.sn and self.lambda_gp > 0
-        inject = r1 and fake_done and not os.environ.get("RGBD_NO_INJECT")
-        seed = None
-        if inject:
-            # loss_dis = softplus(-y_real).mean() + loss_gp.  The adversarial term on the reals is not back-propagated
-            # through the recorded forward: its per-sample seeds are folded into the R1 passes
-            # (functional.adversarial_injection); only the dense tail after the conv stack (torch ops) takes them
-            # the ordinary way.
-            seed = real_heads[1]                                            # d mean softplus(-y_real) / dy
-        if r1:
-            ones = self._ones.get(tuple(y_real.shape))
-            if ones is None:
-                ones = self._ones[tuple(y_real.shape)] = torch.ones_like(y_real)
-            with Fn.input_grads_only(), (Fn.adversarial_injection(seed) if inject else contextlib.nullcontext()):
-                grad_x, = torch.autograd.grad([y_real], [x_real_v], [ones], create_graph=True)   # chainer.grad seeds ones
-            # updater.py:416-418 + loss_functions.py:7-8: lambda * mean_b (sqrt(sum g_b^2))^2, one reduction
-            loss_gp = Fn.r1_penalty(grad_x, self.lambda_gp)
-            self._dbg_sync(st, "dis_r1")
-            obs["dis/loss_gp"] = loss_gp.detach()
-            reported = reported + loss_gp.detach()
-        st["dis_reported"] = reported
-        if inject:
-            torch.autograd.backward([y_real], [seed], inputs=self.dis.tail_params(), retain_graph=True)
-            wgrads = None if os.environ.get("RGBD_NO_D_DEFER") else []
-            with Fn.adversarial_injection(seed), (Fn.deferred_wgrads(wgrads) if wgrads is not None
-                                                  else contextlib.nullcontext()):
-                # d loss_gp / d grad_x = 2 lambda / B * grad_x, handed to the double backward directly
-                ggx = kernels.scale_by_scalar(grad_x.detach().contiguous(), None, 2.0 * self.lambda_gp / grad_x.shape[0])
-                torch.autograd.backward([grad_x], [ggx])
-            self._dbg_sync(st, "dis_bwd2")
-            # D's weight gradients are leaves of the double backward: one partial-sum launch for all of them
-            # (rgbd_conv2d_wgrad_partial_multi_bf16: one slab per CU for the whole pass instead of per layer)
-            if wgrads is not None:
-                Fn.run_deferred_wgrads(wgrads)
+        real_heads = kernels.gan_logit_heads(y_real.detach())
+        reported = real_heads[0][0]                                     # mean softplus(-y_real)
+        seed = real_heads[1]                                            # d mean softplus(-y_real) / dy
+        if self.dis.sn or not self.lambda_gp > 0:
+            # no R1 penalty (updater.py:414): the adversarial term on the reals is back-propagated the ordinary way
+            st["dis_reported"] = reported
+            torch.autograd.backward([y_real], [seed])
             return
-        loss_dis = torch.sum(F.softplus(-y_real)) / y_real.numel()
-        if y_fake is not None:
-            loss_dis = loss_dis + torch.sum(F.softplus(y_fake)) / y_fake.numel()
-        if r1:
-            loss_dis = loss_dis + loss_gp
-        loss_dis.backward()
+        # loss_dis = softplus(-y_real).mean() + loss_gp.  The adversarial term on the reals is not back-propagated through
+        # the recorded forward: its per-sample seeds are folded into the R1 passes (functional.adversarial_injection);
+        # only the dense tail after the conv stack takes them the ordinary way.
+        ones = self._ones.get(tuple(y_real.shape))
+        if ones is None:
+            ones = self._ones[tuple(y_real.shape)] = torch.ones_like(y_real)
+        with Fn.input_grads_only(), Fn.adversarial_injection(seed):
+            grad_x, = torch.autograd.grad([y_real], [x_real_v], [ones], create_graph=True)   # chainer.grad seeds ones
+        # updater.py:416-418 + loss_functions.py:7-8: lambda * mean_b (sqrt(sum g_b^2))^2, one reduction
+        loss_gp = Fn.r1_penalty(grad_x, self.lambda_gp)
+        obs["dis/loss_gp"] = loss_gp.detach()
+        st["dis_reported"] = reported + loss_gp.detach()
+        torch.autograd.backward([y_real], [seed], inputs=self.dis.tail_params(), retain_graph=True)
+        wgrads = []
+        with Fn.adversarial_injection(seed), Fn.deferred_wgrads(wgrads):
+            # d loss_gp / d grad_x = 2 lambda / B * grad_x, handed to the double backward directly
+            ggx = kernels.scale_by_scalar(grad_x.detach().contiguous(), None, 2.0 * self.lambda_gp / grad_x.shape[0])
+            torch.autograd.backward([grad_x], [ggx])
+        # D's weight gradients are leaves of the double backward: one partial-sum launch for all of them
+        # (rgbd_conv2d_wgrad_partial_multi_bf16: one slab per CU for the whole pass instead of per layer)
+        Fn.run_deferred_wgrads(wgrads)
 
     def _join_phase(self, st):
         """After both phases: D's gradients from the fakes (generator phase, second buffer) join those from the reals,
@@ -551,8 +419,7 @@ class RGBDUpdater:
         if st.get("concurrent"):
             for _, store in self.dis.stores:
                 store.merge_alt()
-        lf = st.get("loss_dfake")
-        self.observation["dis/loss_adv"] = st["dis_reported"] + lf if lf is not None else st["dis_reported"]
+        self.observation["dis/loss_adv"] = st["dis_reported"] + st["loss_dfake"]
 
     def _body_phase(self, st):
         """prep, then the generator phase || the discriminator-on-reals phase, then the join: the whole step up to the
@@ -563,84 +430,47 @@ class RGBDUpdater:
             self._prep_phase(st)
         if st["concurrent"]:
             main, side = torch.cuda.current_stream(), self._side_stream
-            st["_main"], st["_side"] = main, side
-            l2s = set(filter(None, os.environ.get("RGBD_L2_SYNC", "").split(",")))   # diagnostics: explicit L2 maintenance
-            st["_l2s"] = l2s
-            if "fork" in l2s:
-                kernels.l2_sync()
+            st["_side"] = side
             side.wait_stream(main)
             with torch.cuda.stream(side), rng("dis"):
-                if "fork" in l2s:
-                    kernels.l2_sync()
                 self._dis_phase(st)                   # D on the reals: side stream
-                if "join" in l2s:
-                    kernels.l2_sync()
-            if os.environ.get("RGBD_DEBUG_SERIALIZE"):    # diagnostics: no overlap of the two phases
-                main.wait_stream(side)
-            if self.defer_dfake_wgrads:
-                with rng("gen_a"):
-                    self._gen_a_phase(st)             # G fwd, D(x_fake) fwd + input-gradient chain
-                if self.dfw_on_side:
-                    side.wait_stream(main)
-                    with torch.cuda.stream(side), rng("dfw"):
-                        self._dfw_phase(st)           # D's fake-batch weight gradients, behind "dis" on the side stream
-                    with rng("gen_b"):
-                        self._gen_b_phase(st)         # 3-D loss + G backward
-                else:
-                    with rng("gen_b"):
-                        self._gen_b_phase(st)
-                    with rng("dfw"):
-                        self._dfw_phase(st)           # ... or on the main stream, after G's own weight-gradient batch
-            else:
-                with rng("gen"):
-                    self._gen_phase(st)
-            if "join" in l2s:
-                kernels.l2_sync()
+            with rng("gen_a"):
+                self._gen_a_phase(st)                 # G fwd, D(x_fake) fwd + input-gradient chain
+            side.wait_stream(main)
+            with torch.cuda.stream(side), rng("dfw"):
+                self._dfw_phase(st)                   # D's fake-batch weight gradients, behind "dis" on the side stream
+            with rng("gen_b"):
+                self._gen_b_phase(st)                 # 3-D loss + G backward
             main.wait_stream(side)
-            if "join" in l2s:
-                kernels.l2_sync()
         else:
-            # one stream (RGBD_CONCURRENT_PHASES=0, fade-in stages, shared-device tests): the same phases back to back; D's weight gradients for the fakes are still
-            # collected during gen_a and issued as ONE batch (rgbd_conv2d_wgrad_partial_multi_bf16) after G's backward
-            if self.defer_dfake_wgrads:
-                with rng("gen_a"):
-                    self._gen_a_phase(st)
-                with rng("gen_b"):
-                    self._gen_b_phase(st)
-                with rng("dfw"):
-                    self._dfw_phase(st)
-            else:
-                with rng("gen"):
-                    self._gen_phase(st)
-            with rng("dis"):
-                self._dis_phase(st)
+            self._body_g_tail(st)
+            self._body_d_phase(st, join=False)
         with rng("join"):
             self._join_phase(st)
+
+    def _body_g_tail(self, st):
+        rng = self._range
+        with rng("gen_a"):
+            self._gen_a_phase(st)
+        with rng("gen_b"):
+            self._gen_b_phase(st)
 
     def _body_g_phase(self, st):
         """Data parallel, one stream: the body up to the point where map / gen gradients are final."""
-        rng = self._range
-        with rng("prep"), _alpha_ctx(st):
+        with self._range("prep"), _alpha_ctx(st):
             self._prep_phase(st)
-        if self.defer_dfake_wgrads:
-            with rng("gen_a"):
-                self._gen_a_phase(st)
-            with rng("gen_b"):
-                self._gen_b_phase(st)
-        else:
-            with rng("gen"):
-                self._gen_phase(st)
+        self._body_g_tail(st)
 
-    def _body_d_phase(self, st):
+    def _body_d_phase(self, st, join=True):
         """... and the rest of it: everything that writes D's gradients."""
         rng = self._range
-        if self.defer_dfake_wgrads:
-            with rng("dfw"):
-                self._dfw_phase(st)
+        with rng("dfw"):
+            self._dfw_phase(st)
         with rng("dis"):
             self._dis_phase(st)
-        with rng("join"):
-            self._join_phase(st)
+        if join:
+            with rng("join"):
+                self._join_phase(st)
 
     @contextlib.contextmanager
     def _range(self, name):
@@ -669,25 +499,23 @@ class RGBDUpdater:
 
     profile_ranges = False      # train_rgbd.py sets it for `nvprof` / `enable_cuda_profiling` (train_rgbd.py:100,363-364,462)
 
+    @property
+    def graphs_in_use(self):
+        """True once the step is being replayed from captured HIP graphs (bench.py reports it)."""
+        return bool(self.use_graphs and self._graphs)
+
     def _run_phase(self, name, fn, st, key):
         """Eager for the first calls of a configuration, then capture once and replay.  With profile_ranges every phase
         is bracketed by a roctx range (torch.cuda.nvtx maps to roctx on ROCm), visible to rocprofv3 --marker-trace."""
-        if self.profile_ranges:
-            torch.cuda.nvtx.range_push(f"rgbd/{name}")
-            try:
-                self._run_phase_inner(name, fn, st, key)
-            finally:
-                torch.cuda.nvtx.range_pop()
-            return
-        self._run_phase_inner(name, fn, st, key)
+        with self._range(name):
+            self._run_phase_inner(name, fn, st, key)
 
     @contextlib.contextmanager
     def _device_turn(self):
         """Test arrangement only (RGBD_SHARE_DEVICE=1: several ranks on ONE GPU): with RGBD_SHARE_DEVICE_LOCK=<path> the
-        ranks take turns on the device, one phase at a time (an exclusive file lock held until the phase has drained).
-        Two processes replaying the step on the same GPU at the same time corrupt each other's generator backward in
-        ~20 % of the runs on this ROCm stack (scripts/dp_split_check.py) -- that is the platform's
-        hazard, not the data-parallel logic those tests are about.  Never held across a collective."""
+        ranks take turns on the device, one phase at a time (an exclusive file lock held until the phase has drained), so
+        that a two-rank job on a one-GPU box times and behaves like ranks that own their GPU.  Never held across a
+        collective."""
         path = os.environ.get("RGBD_SHARE_DEVICE_LOCK") if os.environ.get("RGBD_SHARE_DEVICE") else None
         if path and any(getattr(o, "_needs_broadcast", False) for o in self._optimizers.values()):
             path = None                   # the first update() of every optimizer is a broadcast: a collective
@@ -706,7 +534,7 @@ class RGBDUpdater:
             fcntl.flock(self._turn_file, fcntl.LOCK_UN)
 
     def _run_phase_inner(self, name, fn, st, key):
-        if key is None or name not in self.graph_phases:
+        if key is None:
             with self._device_turn():
                 fn(st)
             return
@@ -730,8 +558,11 @@ class RGBDUpdater:
                 with self._device_turn():
                     with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                         fn(st)
-            except Exception as exc:      # capture refused (driver / collective library state): stay correct, go eager
-                import sys
+            except Exception as exc:
+                if not self.graph_fallback:
+                    raise RuntimeError(f"HIP graph capture of phase '{name}' failed ({type(exc).__name__}: {exc}); pass "
+                                       "use_graphs=False (eager step) or graph_fallback=True to continue") from exc
+                import sys                # capture refused (driver / collective library state): stay correct, go eager
                 print(f"[rgbd_gan_amd] HIP graph capture of phase '{name}' failed ({type(exc).__name__}: {exc}); "
                       "continuing without graphs", file=sys.stderr, flush=True)
                 self.use_graphs = False
@@ -811,10 +642,9 @@ class RGBDUpdater:
             st["z"] = self._stagers[zkey]
 
         fl = math.floor(min(stage, 17 - 1e-8))
-        graphable = self.use_graphs
         key = None
         st["alpha"] = None
-        if graphable:
+        if self.use_graphs:
             if fl % 2 == 1:
                 # fade-in stage: the blend factor changes every iteration, so it lives in a device scalar that the
                 # captured phases read (net.alpha_override); the launch sequence depends on floor(stage) only
@@ -829,23 +659,13 @@ class RGBDUpdater:
                 st["x_real_full"] = self._stagers[skey]
             key = (batch_size, fl, use_rotate, occlusion, full_shape, z_fake_data is not None, real_idx is not None)
 
-        st["share_dfake"] = not os.environ.get("RGBD_NO_SHARE")
-        # two streams on the even (steady) stages only: at fade-in stages the two-stream replay showed a coherent 1-2 %
-        # perturbation of all gradients (forward losses off by 1e-4 .. 1e-3) in 3 of 11 screened runs, not yet explained
-        # (scripts/graph_race.py --stage 7.5; RGBD_CONCURRENT_FADE_IN=1 to reproduce); one stream there is exact
-        st["concurrent"] = bool(self.concurrent_phases and st["share_dfake"] and
-                                (fl % 2 == 0 or os.environ.get("RGBD_CONCURRENT_FADE_IN")))
+        st["concurrent"] = self.concurrent_phases
         if st["concurrent"] and self._side_stream is None:
             self._side_stream = torch.cuda.Stream(device=self.device)
         # everything up to the merged gradient buffers is ONE captured graph: the two-stream fork / join sits INSIDE the
-        # capture, so a replay is a single launch whose internal dependencies the graph carries (separate graphs per
-        # phase, ordered by stream events between the launches, were not reliably ordered on replay: the graph == eager
-        # step test caught ~1e-2 relative gradient differences in two of five runs -- in hindsight most likely the scatter
-        # hazard of DESIGN.md section 3, but the single launch is also the cheaper one)
+        # capture, so a replay is a single launch whose internal dependencies the graph carries
         dp = getattr(opt_d, "comm", None) is not None and opt_d.comm.active
-        if st["concurrent"] and self.hybrid and key is not None and self.defer_dfake_wgrads:
-            self._hybrid_body(st, key)
-        elif dp and self.dp_split_body and not st["concurrent"]:
+        if dp and self.dp_split_body and not st["concurrent"]:
             self._run_phase("body_g", self._body_g_phase, st, key)
             for opt in (opt_g_m, opt_g_g):          # ~29 MB of generator gradients travel while D's half of the step runs
                 if opt is not None:

@@ -6,7 +6,7 @@
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void dma16(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :: "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+                 :: "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
 }
 __global__ void k(const float* x, float* out, int nbytes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];

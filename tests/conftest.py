@@ -20,7 +20,14 @@ def _has_gpu():
         return False
 
 
+# multi-process arrangement tests go LAST: with `pytest -x` (how the driver runs the suite) one of them failing must not
+# hide the single-kernel parity tests
+RUN_LAST = ("test_configs_gpu.py", "test_multirank_gpu.py")
+
+
 def pytest_collection_modifyitems(config, items):
+    items.sort(key=lambda item: RUN_LAST.index(os.path.basename(str(item.fspath))) + 1
+               if os.path.basename(str(item.fspath)) in RUN_LAST else 0)
     if _has_gpu():
         return
     skip = pytest.mark.skip(reason="no GPU visible")

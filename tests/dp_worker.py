@@ -6,6 +6,11 @@ dumps what the optimizers saw, so that arrangements of the same step can be comp
 Single process: the whole batch.  Under RANK / WORLD_SIZE (test: two ranks sharing cuda:0 over gloo): rank r takes the
 view pairs r, r + W, ... of the same batch, i.e. the N-rank job and the 1-rank job see the same samples.
 
+--virtual-rank R --virtual-world W [--peer-grads F.npz ...] [--dump-reduce-inputs F.npz]: ONE process plays rank R of a
+W-rank job through a loop-back communicator (same half-batch, same kernels, same graphs as the real rank): its all-reduce
+adds the gradients the peers dumped (--dump-reduce-inputs of their own run) instead of talking to them.  The real 2-rank
+job has to reproduce this to fp32 rounding: only the transport differs.
+
 Protocol (makes a multi-step comparison well-posed although a GAN step is chaotic): after every call except the last
 the master weights are put back to their initial values, so every call differentiates at the SAME weights with the
 SAME inputs while Adam's moments and step counter advance as usual; the last call is then a replayed-graph step (calls
@@ -43,6 +48,38 @@ def fixed_inputs(B, seed=7):
     return z, thetas, x_real
 
 
+class LoopbackComm:
+    """A W-rank communicator played by one process: all-reduce(sum) adds the peers' recorded buffers (the three flat
+    gradient buffers are told apart by their sizes)."""
+
+    def __init__(self, rank, size, peer_files, dump_path):
+        self.rank, self.size, self.intra_rank, self.active = rank, size, 0, True
+        self.peers = [np.load(f) for f in peer_files]
+        self.dump_path, self.seen, self.names = dump_path, {}, {}
+
+    def allreduce_async(self, flat):
+        name = self.names[flat.numel()]
+        torch.cuda.current_stream().synchronize()
+        self.seen[name] = flat.detach().cpu().numpy().copy()          # what this rank contributes (last call wins)
+        for peer in self.peers:
+            assert peer[name].shape == tuple(flat.shape), name
+            flat.add_(torch.from_numpy(peer[name]).to(flat.device))
+        return "done"                                                 # a non-None work handle (FlatAdam._pending)
+
+    def wait(self, work):
+        pass
+
+    def broadcast(self, flat, src=0):
+        pass                                                          # every virtual rank builds rank 0's weights
+
+    def barrier(self):
+        pass
+
+    def close(self):
+        if self.dump_path:
+            np.savez(self.dump_path, **self.seen)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("out")
@@ -52,8 +89,14 @@ def main():
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--sequential", action="store_true")
     ap.add_argument("--concurrent", action="store_true", help="two-stream phase overlap (the default on even stages)")
-    ap.add_argument("--hybrid", type=int, default=0, help="two streams: generator phase from graphs, D-on-reals eager")
-    ap.add_argument("--graph-phases", default=None, help="comma list: capture only these phases (diagnostics)")
+    ap.add_argument("--no-dp-split", action="store_true", help="data parallel, one stream: one body graph, then all three "
+                    "all-reduces (default: body split where G's gradients are final)")
+    ap.add_argument("--direct-seed", action="store_true", help="back-propagate the generator's OWN seed through D(x_fake) "
+                    "instead of rescaling the discriminator-seeded pass (reference for the seed-ratio chain)")
+    ap.add_argument("--virtual-rank", type=int, default=None)
+    ap.add_argument("--virtual-world", type=int, default=2)
+    ap.add_argument("--peer-grads", nargs="*", default=[])
+    ap.add_argument("--dump-reduce-inputs", default=None)
     ap.add_argument("--sync-restore", action="store_true", help="host-synchronise after putting the weights back")
     ap.add_argument("--logit-shift", type=float, default=0.0,
                     help="added to the discriminator's output bias: y_fake ~ shift (seed-ratio chain at the clamp)")
@@ -63,7 +106,11 @@ def main():
     from rgbd_gan_amd.dist import Communicator
     from rgbd_gan_amd.training import build_training
     from rgbd_gan_amd.utils.yaml_utils import Config
-    comm = Communicator()
+    from rgbd_gan_amd.updater import RGBDUpdater
+    if args.virtual_rank is not None:
+        comm = LoopbackComm(args.virtual_rank, args.virtual_world, args.peer_grads, args.dump_reduce_inputs)
+    else:
+        comm = Communicator()
     torch.cuda.set_device(0 if os.environ.get("RGBD_SHARE_DEVICE") else comm.intra_rank)
     device = torch.device("cuda", torch.cuda.current_device())
     W, r = comm.size, comm.rank
@@ -78,10 +125,15 @@ def main():
         kw["concurrent_phases"] = False
     if args.concurrent:
         kw["concurrent_phases"] = True
-    if args.hybrid:
-        kw["concurrent_phases"], kw["hybrid"] = True, args.hybrid
-    if args.graph_phases is not None:
-        kw["graph_phases"] = tuple(p for p in args.graph_phases.split(",") if p)
+    if args.no_dp_split:
+        kw["dp_split_body"] = False
+    if args.direct_seed:
+        class DirectSeed(RGBDUpdater):
+            def _gen_seeds(self, st, x_d, y_fake, seed_g, seed_d, ratio):
+                with Fn.weight_grads_frozen(self.dis):
+                    gx, = torch.autograd.grad([y_fake], [x_d], [seed_g])
+                return gx, None
+        kw["updater_class"] = DirectSeed
     gen, dis, opt, upd = build_training(Config(CFG), device, comm if comm.active else None, iterator=None, **kw)
     torch.manual_seed(3)
     with torch.no_grad():                               # give the depth head some signal (as the step parity test does)
@@ -92,6 +144,9 @@ def main():
             dis.store["blocks/0/l2/c/b"].add_(args.logit_shift)
     Fn.bump_weight_epoch()
     stores = {"map": gen.mapping.store, "gen": gen.gen.store, "dis": dis.store}
+    if isinstance(comm, LoopbackComm):
+        comm.names = {s.flat.numel(): k for k, s in stores.items()}
+        assert len(comm.names) == 3
     w0 = {k: s.flat.clone() for k, s in stores.items()}
     upd.iteration = 200000
     calls = args.calls + (1 if comm.active else 0)      # data parallel: the first call only broadcasts
@@ -120,9 +175,6 @@ def main():
         out[f"{k}/names"] = np.array(s.names)
         out[f"{k}/offsets"] = np.array([s.offsets[n] for n in s.names], dtype=np.int64)
         out[f"{k}/sizes"] = np.array([int(np.prod(s.shapes[n])) for n in s.names], dtype=np.int64)
-    for k, v in getattr(upd, "_dbg", {}).items():      # RGBD_DEBUG_DUMP: intermediate tensors of the generator phase
-        if v is not None:
-            out["dbg/" + k] = v.float().cpu().numpy()
     for k, v in upd.observation.items():
         out["obs/" + k] = float(v)
     np.savez(args.out, **out)

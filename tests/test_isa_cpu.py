@@ -1,0 +1,53 @@
+"""Static checks of the generated gfx950 code (hipcc cross-compiles without a GPU).
+
+The LDS-DMA staging of the conv kernels (csrc/conv.hip:lds_dma16) is inline asm that writes M0 (the LDS base of the
+`buffer_load_dwordx4 ... lds` that follows it).  LLVM treats M0 as a reserved register on AMDGPU: an asm clobber of it is
+accepted but not tracked, so the guarantee that no compiler-generated instruction depends on M0 has to come from the
+code itself -- on gfx9 and later nothing hipcc emits for these kernels reads M0 (LDS instructions do not need it).
+This test pins that: every mention of M0 in the device code is one of the staging moves, and each is consumed by the
+LDS-DMA right behind it.
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="llvm-objdump not installed")
+def test_built_library_has_no_packed_fp32_instructions(tmp_path):
+    """v_pk_{mul,add,fma}_f32 executed next to another wave's MFMAs on the same SIMD return wrong values in lanes 48-63 on
+    MI355X (rgbd_gan_amd/build.py:NO_PACKED_FP32): the shipped code objects must not contain them."""
+    from rgbd_gan_amd import _lib
+    so = tmp_path / "lib.so"
+    shutil.copy(_lib.LIB_PATH, so)
+    subprocess.check_call([OBJDUMP, "--offloading", str(so)], stdout=subprocess.DEVNULL)
+    objs = [f for f in os.listdir(tmp_path) if "amdgcn" in f]
+    assert len(objs) >= 5                       # one code object per source file
+    n_insts = 0
+    for f in objs:
+        text = subprocess.check_output([OBJDUMP, "-d", str(tmp_path / f)], text=True)
+        n_insts += text.count("v_mfma_") + text.count("global_load") + text.count("buffer_load")
+        bad = sorted(set(re.findall(r"\bv_pk_[a-z]+_f32\b", text)))
+        assert not bad, (f, bad)
+    assert n_insts > 1000                       # the disassembly really is the device code
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_m0_is_touched_only_by_the_lds_dma_staging(tmp_path):
+    out = tmp_path / "conv.s"
+    subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only",
+                           "-Wno-everything", "-o", str(out), os.path.join(ROOT, "rgbd_gan_amd", "csrc", "conv.hip")])
+    lines = [ln.split(";")[0].strip() for ln in open(out)]
+    lines = [ln for ln in lines if ln and not ln.startswith(".")]
+    hits = [i for i, ln in enumerate(lines) if re.search(r"\bm0\b", ln)]
+    assert len(hits) > 100                      # the staging is there (unrolled)
+    for i in hits:
+        assert lines[i].startswith("s_mov_b32 m0,"), lines[i]
+        nxt = [ln for ln in lines[i + 1:i + 4] if not ln.startswith("s_nop")]
+        assert nxt and nxt[0].startswith("buffer_load_dwordx4") and nxt[0].endswith("lds"), (lines[i], nxt[:1])

@@ -818,3 +818,17 @@ def test_loss_func_rotate_debug_tuple():
     np.testing.assert_array_equal(warped_rot.view(np.uint32), ref["warped_rot"].view(np.uint32))
     np.testing.assert_array_equal(mask_rot, ref["mask_rot"])
     np.testing.assert_array_equal(zp_rot.view(np.uint32), ref["zp_rot"].view(np.uint32))
+
+
+def test_loss_func_rotate_second_value_is_the_projected_points():
+    """loss_functions.py:146: the call returns (loss, F.concat([new_zp, new_zp_rot], axis=0)) -- (2b, hw, 3)."""
+    from rgbd_gan_amd.common.loss_functions import LossFuncRotate
+    b, S = 2, 16
+    img, img_rot, cam, cam_rot = _warp_case(b, S, seed=6)
+    ref = warp_loss.forward_np(img, cam, img_rot, cam_rot, occlusion_aware=True, lambda_geometric=3.0)
+    loss, zp_cat = LossFuncRotate(torch)(torch.from_numpy(img).to(dev()), cam, torch.from_numpy(img_rot).to(dev()), cam_rot,
+                                         occlusion_aware=True)
+    assert tuple(zp_cat.shape) == (2 * b, S * S, 3) and not zp_cat.requires_grad
+    want = np.concatenate([ref["zp"], ref["zp_rot"]], axis=0)
+    np.testing.assert_array_equal(zp_cat.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    assert abs(float(loss) - ref["loss"]) < 1e-4 * max(1.0, abs(ref["loss"]))

@@ -123,21 +123,6 @@ def test_two_stream_replay_at_the_sizes_that_used_to_fail(tmp_path, batch):
                  exact_upd=0.15)
 
 
-@pytest.mark.parametrize("stage,batch", [(10.0, 16)])
-def test_hybrid_two_stream_arrangement_equals_eager_step(tmp_path, stage, batch):
-    """The hybrid arrangement (RGBD_HYBRID=1): generator phase replayed from graphs on the main stream,
-    discriminator-on-reals phase launched eagerly on a side stream, both weight-gradient batches of the generator phase
-    after the join (a diagnostic of the former two-queue hazard, kept as a switch)."""
-    flags = ["--calls", "4", "--stage", str(stage), "--batch", str(batch)]
-    _wait([_run(tmp_path / "eager.npz", *flags, "--eager", "--sequential")])
-    e = np.load(tmp_path / "eager.npz")
-    for rep in range(2):
-        _wait([_run(tmp_path / f"hyb{rep}.npz", *flags, "--hybrid", "1")])
-        h = np.load(tmp_path / f"hyb{rep}.npz")
-        assert int(h["n_graphs"]) == 5                     # prep, gen_a, gen_b, gen_w, optimizers
-        _compare(h, e, f"hybrid two streams vs eager, stage {stage} batch {batch}, run {rep}", SAME_STEP)
-
-
 @pytest.mark.parametrize("stage,batch", [(9.5, 4), (7.5, 8), (8.0, 16)])
 def test_graph_replay_equals_eager_step_other_stages(tmp_path, stage, batch):
     """Fade-in stages (the blend factor comes from a device scalar in the replay, from the host in the eager step) and
@@ -152,57 +137,65 @@ def test_graph_replay_equals_eager_step_other_stages(tmp_path, stage, batch):
              exact_upd=0.15 if float(stage).is_integer() else 1e-3)
 
 
-# 2 ranks on half-batches vs 1 rank on the whole batch is NOT the same floating-point computation: the conv engine picks
-# its split-K factors and tile walk by batch size, so fp32 sums associate differently, ~2e-4 of the bf16 roundings per
-# layer differ, and the networks amplify that (one layer pair at stage 4, twelve at stage 10).  Tolerances by depth.
-RANKS_TOL = {4.0: {"dis": 4e-2, "gen": 6e-2, "map": 6e-2}, 10.0: {"dis": 8e-2, "gen": 0.2, "map": 0.2}}
+def _rank_env(tmp_path, r, port):
+    # RGBD_SHARE_DEVICE_LOCK: the two processes take turns on the one GPU (updater._device_turn), like ranks that own theirs
+    return dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                MASTER_PORT=str(port), RGBD_DIST_BACKEND="gloo", RGBD_SHARE_DEVICE="1",
+                RGBD_SHARE_DEVICE_LOCK=str(tmp_path / "turn.lock"))
+
+
+# The 2-rank job against ONE process that plays rank 0 of it: same half-batch, same kernels, same graphs, and a loop-back
+# all-reduce that adds the gradients rank 1's half-batch produces (tests/dp_worker.py --virtual-rank).  Only the transport
+# differs, so everything the optimizers see must agree to fp32 rounding (the discriminator's bias sums are fp32 atomics:
+# 1e-7): a missing 1/N, a dropped or doubled contribution, a stale buffer would all be O(1).
+TRANSPORT = {"dis": 2e-5, "gen": 2e-5, "map": 2e-5}
+# ... and, as a loose sanity bound only, against 1 rank on the WHOLE batch.  That is a different floating-point computation
+# (the conv engine picks split-K factors and tile walks by batch size, ~2e-4 of the bf16 roundings per layer differ and the
+# N(0,1)-initialised networks amplify them: one layer pair at stage 4, twelve at stage 10); bounds = 2.5x the worst of 30
+# runs on the builder's boxes + the driver's round-2 run (gen 0.064 at stage 4).
+WHOLE_BATCH = {4.0: {"dis": 0.1, "gen": 0.16, "map": 0.16}, 10.0: {"dis": 0.2, "gen": 0.5, "map": 0.5}}
 
 
 @pytest.mark.parametrize("stage", [4.0, 10.0])
-def test_two_ranks_on_half_batches_equal_one_rank_on_the_whole_batch(tmp_path, stage):
-    _wait([_run(tmp_path / "one.npz", "--calls", "4", "--stage", str(stage))])
+def test_two_ranks_equal_their_single_process_emulation(tmp_path, stage):
+    flags = ["--calls", "4", "--stage", str(stage)]
     port = _free_port()
-    procs = []
-    for r in range(2):
-        # RGBD_SHARE_DEVICE_LOCK: the two processes take turns on the one GPU (updater._device_turn): run at the same
-        # time they corrupt each other's generator backward in ~20 % of the runs on this stack, whatever the arrangement
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), RGBD_DIST_BACKEND="gloo", RGBD_SHARE_DEVICE="1",
-                   RGBD_SHARE_DEVICE_LOCK=str(tmp_path / "turn.lock"))
-        procs.append(_run(tmp_path / f"rank{r}.npz", "--calls", "4", "--stage", str(stage), env=env))
-    _wait(procs)
-    one, r0, r1 = (np.load(tmp_path / f) for f in ("one.npz", "rank0.npz", "rank1.npz"))
-    assert int(r0["world"]) == 2 and int(r1["rank"]) == 1
-    assert int(r0["n_graphs"]) == 4     # body up to G's gradients, D's half of the body, generator optimizers, D optimizer
+    _wait([_run(tmp_path / f"rank{r}.npz", *flags, env=_rank_env(tmp_path, r, port)) for r in range(2)])
+    env1 = dict(os.environ, RGBD_SHARE_DEVICE="1")          # same (one-stream, split-body) arrangement as the real ranks
+    _wait([_run(tmp_path / "v1.npz", *flags, "--virtual-rank", "1", "--dump-reduce-inputs", str(tmp_path / "g1.npz"),
+                env=env1)])
+    _wait([_run(tmp_path / "v0.npz", *flags, "--virtual-rank", "0", "--peer-grads", str(tmp_path / "g1.npz"), env=env1)])
+    r0, r1, v0 = (np.load(tmp_path / f) for f in ("rank0.npz", "rank1.npz", "v0.npz"))
+    assert int(r0["world"]) == 2 and int(r1["rank"]) == 1 and int(v0["world"]) == 2
+    assert int(r0["n_graphs"]) == 4 and int(v0["n_graphs"]) == 4   # body up to G's gradients, D's half, opt_g, opt_d
     for k in ("map", "gen", "dis"):                    # after the all-reduce every rank holds the same buffers ...
         np.testing.assert_array_equal(r0[f"{k}/grad"], r1[f"{k}/grad"])
         np.testing.assert_array_equal(r0[f"{k}/delta"], r1[f"{k}/delta"])       # ... and takes the same Adam step
         assert int(r0[f"{k}/t"]) == 4                  # the first of the 5 calls only broadcast (ChainerMN)
-    # upd_tol: with beta1 = 0 an Adam step is ~alpha * sign(g) wherever |g| is steady, so every entry whose tiny gradient
-    # changes sign between the two arrangements (6 % relative gradient error at stage 10: half-batches round their bf16
-    # activations differently) counts as a full mismatch; measured over 30 runs: 0.35-0.62 for the mapping network.  The
-    # gradient, second-moment and norm checks above carry the comparison; this one only catches a step that went elsewhere.
-    _compare(r0, one, f"2 ranks vs 1 rank, stage {stage}", RANKS_TOL[stage], upd_tol=0.8)
+    _compare(r0, v0, f"2 ranks vs their emulation, stage {stage}", TRANSPORT, exact_upd=2e-2)
+    g1 = np.load(tmp_path / "g1.npz")                  # what rank 1's half-batch contributed to the sums
+    for k in ("map", "gen", "dis"):
+        assert np.linalg.norm(g1[k]) > 0.1 * np.linalg.norm(r0[f"{k}/grad"] * 2), k
+    _wait([_run(tmp_path / "one.npz", *flags)])
+    # upd_tol: with beta1 = 0 an Adam step is ~alpha * sign(g), so every entry whose tiny gradient changes sign between
+    # the two batchings counts as a full mismatch (0.35-0.62 measured for the mapping network): not asserted tightly
+    _compare(r0, np.load(tmp_path / "one.npz"), f"2 ranks vs 1 rank on the whole batch, stage {stage}", WHOLE_BATCH[stage],
+             upd_tol=0.9)
 
 
-def _two_ranks(tmp_path, tag, stage, extra_env=None):
+def _two_ranks(tmp_path, tag, stage, *flags):
     port = _free_port()
-    procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), RGBD_DIST_BACKEND="gloo", RGBD_SHARE_DEVICE="1",
-                   RGBD_SHARE_DEVICE_LOCK=str(tmp_path / "turn.lock"), **(extra_env or {}))
-        procs.append(_run(tmp_path / f"{tag}{r}.npz", "--calls", "4", "--stage", str(stage), env=env))
-    _wait(procs)
+    _wait([_run(tmp_path / f"{tag}{r}.npz", "--calls", "4", "--stage", str(stage), *flags, env=_rank_env(tmp_path, r, port))
+           for r in range(2)])
     return np.load(tmp_path / f"{tag}0.npz")
 
 
 def test_generator_allreduce_under_the_discriminator_half_changes_nothing(tmp_path):
     """Data parallel: the body is replayed as two graphs with the map / gen all-reduces started between them, so that they
     travel while the discriminator half runs (updater.py, dp_split_body).  Same kernels in the same order as the single
-    body graph followed by all three all-reduces (RGBD_DP_NO_SPLIT=1): the reduced gradients have to agree to the
+    body graph followed by all three all-reduces (dp_split_body=False): the reduced gradients have to agree to the
     same-arrangement noise floor, every time."""
-    ref = _two_ranks(tmp_path, "whole", 10.0, {"RGBD_DP_NO_SPLIT": "1"})
+    ref = _two_ranks(tmp_path, "whole", 10.0, "--no-dp-split")
     assert int(ref["n_graphs"]) == 3
     for rep in range(3):
         got = _two_ranks(tmp_path, f"split{rep}", 10.0)
@@ -213,12 +206,11 @@ def test_generator_allreduce_under_the_discriminator_half_changes_nothing(tmp_pa
 def test_seed_ratio_chain_at_the_logit_clamp(tmp_path):
     """D(x_fake) ~ -40: the discriminator's seed sigmoid(y)/B is ~4e-18/B and the generator's gradient is recovered
     from that backward pass through the per-sample ratio (updater.py: gan_logit_heads).  The bf16 chain must not flush:
-    generator gradients match a run that back-propagates the generator's own seed (RGBD_NO_SHARE)."""
+    generator gradients match a run that back-propagates the generator's own seed (dp_worker.py --direct-seed)."""
     _wait([_run(tmp_path / "shared.npz", "--calls", "1", "--eager", "--sequential", "--batch", "4", "--logit-shift",
                 "-40")])
-    env = dict(os.environ, RGBD_NO_SHARE="1")
     _wait([_run(tmp_path / "direct.npz", "--calls", "1", "--eager", "--sequential", "--batch", "4", "--logit-shift",
-                "-40", env=env)])
+                "-40", "--direct-seed")])
     a, b = np.load(tmp_path / "shared.npz"), np.load(tmp_path / "direct.npz")
     assert float(a["obs/gen/loss_adv"]) > 20          # softplus(40): the logits really are at the clamp's side
     for k in ("map", "gen"):
