@@ -347,21 +347,11 @@ def conv2d_wgrad_batch(items):
         if tuple(dy.shape[:3]) != (B, H, W) or tuple(target.shape) != (Cout, Cin, K, K):
             raise RuntimeError(f"conv2d_wgrad_batch: shape mismatch x={tuple(x.shape)} dy={tuple(dy.shape)} "
                                f"dW={tuple(target.shape)} upsample={ups}")
-        if os.environ.get("RGBD_NO_WGRAD_MULTI"):
-            # diagnostics (two-queue hazard): per-layer launches only -- every kernel argument block stays under 100 B,
-            # where the multi-problem kernels take their descriptor tables (1.3-2.3 KB) by value
-            ws_bytes = lib.rgbd_conv2d_wgrad_workspace(B, H, W, Cin, Cout, K)
-            ws = torch.empty(ws_bytes // 4, dtype=F32, device=x.device)
-            keep.append(ws)
-            _lib.check(lib.rgbd_conv2d_wgrad_bf16(_ptr(x), _ptr(dy), _ptr(ws), _ptr(target), B, H, W, Cin, Cout, K,
-                                                  float(scale), acc_flag, int(bool(ups)), _stream()), "rgbd_conv2d_wgrad_bf16")
-            tab[i] = (0, 0, 0, 0, 0, 0, 0.0, 0)
-            continue
         if _multi_ok(H, W, K) and len(items) > 1:
             multi.append((i, x, dy, B, H, W, Cin, Cout, bool(ups)))
             accs[i] = acc_flag
             continue
-        if _multi_small_ok(H, W, K) and len(items) > 1 and not os.environ.get("RGBD_NO_WGRAD_MULTI_SMALL"):
+        if _multi_small_ok(H, W, K) and len(items) > 1:
             multi_small.append((i, x, dy, B, H, W, Cin, Cout, bool(ups)))
             accs[i] = acc_flag
             continue
@@ -398,8 +388,6 @@ def conv2d_wgrad_batch(items):
         rc = _timed("conv_wgrad_kernel<9>+reduce", flops, nbytes,
                     lambda: lib.rgbd_conv2d_wgrad_partial_multi_bf16(probs, len(group), _stream()))
         _lib.check(rc, "rgbd_conv2d_wgrad_partial_multi_bf16")
-    if os.environ.get("RGBD_NO_WGRAD_MULTI"):
-        return
     rc = lib.rgbd_wgrad_reduce_multi(tab.ctypes.data, len(items), _stream())
     _lib.check(rc, "rgbd_wgrad_reduce_multi")
 

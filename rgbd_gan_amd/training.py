@@ -120,6 +120,22 @@ class DeviceImageIterator:
 
     __next__ = next
 
+    def state_dict(self):
+        """What chainer's SerialIterator.serialize keeps (current_position, epoch, the epoch's order), plus the state of
+        the generator that draws the next permutations: a resumed run continues the same sample sequence."""
+        return {"pos": np.int64(self._pos), "epoch": np.int64(self.epoch), "order": self._order.cpu().numpy(),
+                "rng_state": self.gen.get_state().numpy(), "seed": np.int64(self.seed)}
+
+    def load_state_dict(self, sd):
+        order = torch.as_tensor(np.asarray(sd["order"]))
+        if order.numel() != self.data.shape[0]:
+            raise ValueError(f"iterator snapshot holds an order over {order.numel()} samples, the data set has "
+                             f"{self.data.shape[0]}")
+        self._pos, self.epoch = int(sd["pos"]), int(sd["epoch"])
+        self._order = order.to(self.data.device)
+        self.gen.set_state(torch.as_tensor(np.asarray(sd["rng_state"]), dtype=torch.uint8))
+        self.seed = int(sd["seed"])
+
 
 def build_training(config, device, comm=None, iterator=None, updater_class=None, **updater_kwargs):
     generator = setup_generator(config, device)

@@ -510,33 +510,9 @@ class RGBDUpdater:
         with self._range(name):
             self._run_phase_inner(name, fn, st, key)
 
-    @contextlib.contextmanager
-    def _device_turn(self):
-        """Test arrangement only (RGBD_SHARE_DEVICE=1: several ranks on ONE GPU): with RGBD_SHARE_DEVICE_LOCK=<path> the
-        ranks take turns on the device, one phase at a time (an exclusive file lock held until the phase has drained), so
-        that a two-rank job on a one-GPU box times and behaves like ranks that own their GPU.  Never held across a
-        collective."""
-        path = os.environ.get("RGBD_SHARE_DEVICE_LOCK") if os.environ.get("RGBD_SHARE_DEVICE") else None
-        if path and any(getattr(o, "_needs_broadcast", False) for o in self._optimizers.values()):
-            path = None                   # the first update() of every optimizer is a broadcast: a collective
-        if not path:
-            yield
-            return
-        import fcntl
-        if getattr(self, "_turn_file", None) is None:
-            self._turn_file = open(path, "a+")
-        torch.cuda.synchronize()
-        fcntl.flock(self._turn_file, fcntl.LOCK_EX)
-        try:
-            yield
-            torch.cuda.synchronize()
-        finally:
-            fcntl.flock(self._turn_file, fcntl.LOCK_UN)
-
     def _run_phase_inner(self, name, fn, st, key):
         if key is None:
-            with self._device_turn():
-                fn(st)
+            fn(st)
             return
         gkey = key + (name,)
         entry = self._graphs.get(gkey)
@@ -544,8 +520,7 @@ class RGBDUpdater:
             n = self._eager_calls.get(gkey, 0)
             if n < self.graph_warmup:
                 self._eager_calls[gkey] = n + 1
-                with self._device_turn():
-                    fn(st)
+                fn(st)
                 return
             graph = torch.cuda.CUDAGraph()
             saved = dict(self.observation)
@@ -555,9 +530,8 @@ class RGBDUpdater:
                 if getattr(opt, "_pending", None) is not None:
                     opt.comm.wait(opt._pending)
             try:
-                with self._device_turn():
-                    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                        fn(st)
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    fn(st)
             except Exception as exc:
                 if not self.graph_fallback:
                     raise RuntimeError(f"HIP graph capture of phase '{name}' failed ({type(exc).__name__}: {exc}); pass "
@@ -568,8 +542,7 @@ class RGBDUpdater:
                 self.use_graphs = False
                 self._graphs.clear()
                 torch.cuda.synchronize()
-                with self._device_turn():
-                    fn(st)
+                fn(st)
                 return
             # keep every tensor the phase handed over alive: it lives in the graph's private pool
             entry = {"graph": graph, "st": dict(st), "obs": {k: v for k, v in self.observation.items()
@@ -578,8 +551,7 @@ class RGBDUpdater:
         else:
             st.update({k: v for k, v in entry["st"].items() if k in ("x_real", "x_fake_data", "loss_dfake", "dfw")})
             self.observation.update(entry["obs"])
-        with self._device_turn():
-            entry["graph"].replay()
+        entry["graph"].replay()
 
     # ---- the step
     def update_core(self, batch=None, z_fake_data=None, thetas=None):

@@ -16,7 +16,6 @@ images = np.random.RandomState(0).randint(0, 256, (256, 3, 128, 128)).astype("ui
 it = DeviceImageIterator(images, cfg.batchsize, "cuda:0", seed=0)
 gen, dis, opt, upd = build_training(cfg, "cuda:0", iterator=it, nan_check_interval=0)
 upd.iteration = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
-upd.graph_phases = ()
 upd.use_graphs = False
 for i in range(2):
     upd.update()

@@ -68,6 +68,7 @@ def main():
     if is_master:
         os.makedirs(out, exist_ok=True)
     # resume (train_rgbd.py:405-459): explicit iteration or the newest complete set in auto_resume_dir
+    log_resumed, elapsed_resumed = [], 0.0
     resume = config.get_model_from_interation or ""
     explicit = bool(resume)            # an explicit iteration is always read from config.out (train_rgbd.py:406-415)
     if not resume and config.auto_resume:
@@ -89,6 +90,13 @@ def main():
         updater.iteration = int(snap["iteration"])
         for k, o in optimizer.items():
             o.load_state_dict({"t": snap[f"{k}/t"], "m": snap[f"{k}/m"], "v": snap[f"{k}/v"]})
+        # the trainer snapshot of the reference also carries the iterator (position, epoch, order) and LogReport's entries
+        # (chainer serializes trainer -> updater -> iterators, extensions); older snapshots of this engine lack them
+        if "iterator/pos" in snap.files:
+            iterator.load_state_dict({k[len("iterator/"):]: snap[k] for k in snap.files if k.startswith("iterator/")})
+        if "log" in snap.files:
+            log_resumed = json.loads(str(snap["log"]))
+            elapsed_resumed = float(snap["elapsed_time"])
 
     previews = []
     if is_master and config.evaluation_sample_interval:                # train_rgbd.py:386-396
@@ -97,7 +105,7 @@ def main():
         if updater.smoothed_gen is not None:
             previews.append(PreviewSampler(updater.smoothed_gen, out, config, rows=8, cols=8, subdir="preview_smoothed"))
 
-    log, t0 = [], time.time()
+    log, t0 = log_resumed, time.time() - elapsed_resumed       # a resumed run appends to the log it left (LogReport)
     while updater.iteration < config.iteration:
         updater.update()
         it = updater.iteration
@@ -114,7 +122,8 @@ def main():
         if is_master and it % (config.snapshot_interval or 10000) == 0:
             for name, m in models:
                 save_npz(f"{out}/{name}_{it}.npz", m)
-            snap = {"iteration": it}
+            snap = {"iteration": it, "log": json.dumps(log), "elapsed_time": time.time() - t0}
+            snap.update({f"iterator/{k}": v for k, v in iterator.state_dict().items()})
             for k, o in optimizer.items():
                 sd = o.state_dict()
                 snap.update({f"{k}/t": sd["t"], f"{k}/m": sd["m"], f"{k}/v": sd["v"]})
