@@ -254,7 +254,7 @@ def main():
                                (f"{os.path.basename(args.config)} stage {upd.stage:.2f} (128x128), RGBDUpdater.update_core, "
                                 f"StyleGAN ch={config.ch}, rotation+occlusion loss on, R1 on"),
                    "per_gpu_batch": B, "global_batch": B * comm.size, "parallelism": f"dp{comm.size}",
-                   "arrangement": "two streams inside one graph" if getattr(upd, "concurrent_phases", False) else "one stream",
+                   "arrangement": "two streams, one graph per phase" if getattr(upd, "concurrent_phases", False) else "one stream",
                    # True only if the timed steps were replays of captured HIP graphs (a refused capture is fatal in the
                    # updater: graph_fallback is off)
                    "graphs": bool(getattr(upd, "graphs_in_use", upd.use_graphs))},

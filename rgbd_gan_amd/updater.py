@@ -195,7 +195,7 @@ class RGBDUpdater:
         self.dp_split_body = bool(kwargs.pop("dp_split_body", True))
         if kwargs:
             raise TypeError(f"RGBDUpdater: unknown arguments {sorted(kwargs)}")
-        self._side_stream = None
+        self._side_stream = self._capture_stream = None
         self._graphs, self._eager_calls, self._stagers, self._ones = {}, {}, {}, {}
         self._warp_ws = {}
         self.device = self.gen.device
@@ -363,10 +363,6 @@ class RGBDUpdater:
         wgrads = []
         with Fn.deferred_wgrads(wgrads):
             torch.autograd.backward([x_fake], [gout])
-        if st.get("_side") is not None:
-            # the two weight-gradient batches (this one and D's for the fakes on the side stream) share the slab
-            # workspace: they never run concurrently
-            torch.cuda.current_stream().wait_stream(st["_side"])
         Fn.run_deferred_wgrads(wgrads)
         st["x_fake_data"] = x_fake.detach()
         st["x_fake"] = st["gx"] = None                 # drop the autograd graph
@@ -421,32 +417,15 @@ class RGBDUpdater:
                 store.merge_alt()
         self.observation["dis/loss_adv"] = st["dis_reported"] + st["loss_dfake"]
 
-    def _body_phase(self, st):
-        """prep, then the generator phase || the discriminator-on-reals phase, then the join: the whole step up to the
-        optimizers.  In the two-stream arrangement the side stream forks off the current stream and rejoins it, both
-        inside this function, so it can be captured as one graph with two branches."""
-        rng = self._range
-        with rng("prep"), _alpha_ctx(st):         # fade-in: downsize_real blends with the device-resident alpha too
+    def _prep_only_phase(self, st):
+        with self._range("prep"), _alpha_ctx(st):     # fade-in: downsize_real blends with the device-resident alpha too
             self._prep_phase(st)
-        if st["concurrent"]:
-            main, side = torch.cuda.current_stream(), self._side_stream
-            st["_side"] = side
-            side.wait_stream(main)
-            with torch.cuda.stream(side), rng("dis"):
-                self._dis_phase(st)                   # D on the reals: side stream
-            with rng("gen_a"):
-                self._gen_a_phase(st)                 # G fwd, D(x_fake) fwd + input-gradient chain
-            side.wait_stream(main)
-            with torch.cuda.stream(side), rng("dfw"):
-                self._dfw_phase(st)                   # D's fake-batch weight gradients, behind "dis" on the side stream
-            with rng("gen_b"):
-                self._gen_b_phase(st)                 # 3-D loss + G backward
-            main.wait_stream(side)
-        else:
-            self._body_g_tail(st)
-            self._body_d_phase(st, join=False)
-        with rng("join"):
-            self._join_phase(st)
+
+    def _body_phase(self, st):
+        """One stream: prep, generator phase, D's weight gradients for the fakes, discriminator-on-reals phase, join."""
+        self._prep_only_phase(st)
+        self._body_g_tail(st)
+        self._body_d_phase(st)
 
     def _body_g_tail(self, st):
         rng = self._range
@@ -457,20 +436,18 @@ class RGBDUpdater:
 
     def _body_g_phase(self, st):
         """Data parallel, one stream: the body up to the point where map / gen gradients are final."""
-        with self._range("prep"), _alpha_ctx(st):
-            self._prep_phase(st)
+        self._prep_only_phase(st)
         self._body_g_tail(st)
 
-    def _body_d_phase(self, st, join=True):
+    def _body_d_phase(self, st):
         """... and the rest of it: everything that writes D's gradients."""
         rng = self._range
         with rng("dfw"):
             self._dfw_phase(st)
         with rng("dis"):
             self._dis_phase(st)
-        if join:
-            with rng("join"):
-                self._join_phase(st)
+        with rng("join"):
+            self._join_phase(st)
 
     @contextlib.contextmanager
     def _range(self, name):
@@ -504,10 +481,11 @@ class RGBDUpdater:
         """True once the step is being replayed from captured HIP graphs (bench.py reports it)."""
         return bool(self.use_graphs and self._graphs)
 
-    def _run_phase(self, name, fn, st, key):
-        """Eager for the first calls of a configuration, then capture once and replay.  With profile_ranges every phase
-        is bracketed by a roctx range (torch.cuda.nvtx maps to roctx on ROCm), visible to rocprofv3 --marker-trace."""
-        with self._range(name):
+    def _run_phase(self, name, fn, st, key, stream=None):
+        """Eager for the first calls of a configuration, then capture once and replay -- on `stream` (default: the current
+        one).  With profile_ranges every phase is bracketed by a roctx range (torch.cuda.nvtx maps to roctx on ROCm),
+        visible to rocprofv3 --marker-trace."""
+        with self._range(name), (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
             self._run_phase_inner(name, fn, st, key)
 
     def _run_phase_inner(self, name, fn, st, key):
@@ -530,7 +508,13 @@ class RGBDUpdater:
                 if getattr(opt, "_pending", None) is not None:
                     opt.comm.wait(opt._pending)
             try:
-                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                # ONE capture stream for every phase, whichever stream replays it: autograd runs a leaf's AccumulateGrad on
+                # the stream that leaf's accumulator was created on, so phases captured on different streams that share
+                # parameters (D in gen_a and in dis) could come out with a fork / join around an accumulation; captured
+                # on one stream every phase is a plain chain of kernel nodes (checked: hipGraphGetEdges = nodes - 1)
+                if self._capture_stream is None:
+                    self._capture_stream = torch.cuda.Stream(device=self.device)
+                with torch.cuda.graph(graph, stream=self._capture_stream, capture_error_mode="thread_local"):
                     fn(st)
             except Exception as exc:
                 if not self.graph_fallback:
@@ -632,16 +616,36 @@ class RGBDUpdater:
             key = (batch_size, fl, use_rotate, occlusion, full_shape, z_fake_data is not None, real_idx is not None)
 
         st["concurrent"] = self.concurrent_phases
-        if st["concurrent"] and self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(device=self.device)
-        # everything up to the merged gradient buffers is ONE captured graph: the two-stream fork / join sits INSIDE the
-        # capture, so a replay is a single launch whose internal dependencies the graph carries
         dp = getattr(opt_d, "comm", None) is not None and opt_d.comm.active
-        if dp and self.dp_split_body and not st["concurrent"]:
-            self._run_phase("body_g", self._body_g_phase, st, key)
-            for opt in (opt_g_m, opt_g_g):          # ~29 MB of generator gradients travel while D's half of the step runs
-                if opt is not None:
+        g_opts = [o for o in (opt_g_m, opt_g_g) if o is not None]
+        if st["concurrent"]:
+            # TWO STREAMS.  Every phase is its own captured graph, launched on the stream it belongs to, and the fork / join
+            # dependencies are stream events between the launches:
+            #     main:  prep -> gen_a ----------> gen_b -> [all-reduce map, gen] -> join -> optimizers
+            #     side:       \-> dis ------\-> dfw ------------------------------/
+            # Same step time as ONE graph with the fork inside it (rounds 1-2); per-phase graphs let the data-parallel job
+            # start the generator's all-reduces at the end of gen_b instead of after the join.  (Measure overlap with
+            # events, scripts/phase_timeline.py: rocprofv3's kernel trace serialises the queues of a process, its
+            # timelines show the second stream idle until the first one's last kernels.)
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=self.device)
+            main, side = torch.cuda.current_stream(), self._side_stream
+            self._run_phase("prep", self._prep_only_phase, st, key)
+            side.wait_stream(main)
+            self._run_phase("dis", self._dis_phase, st, key, stream=side)        # D on the reals, R1, its weight gradients
+            self._run_phase("gen_a", self._gen_a_phase, st, key)                 # G forward, the one pass through D(x_fake)
+            side.wait_stream(main)
+            self._run_phase("dfw", self._dfw_phase, st, key, stream=side)        # D's weight gradients for the fakes
+            self._run_phase("gen_b", self._gen_b_phase, st, key)                 # 3-D loss, G backward, G's weight gradients
+            if dp:
+                for opt in g_opts:          # ~29 MB of generator gradients travel while the side stream finishes
                     opt.start_allreduce()
+            main.wait_stream(side)
+            self._run_phase("join", self._join_phase, st, key)
+        elif dp and self.dp_split_body:
+            self._run_phase("body_g", self._body_g_phase, st, key)
+            for opt in g_opts:              # ~29 MB of generator gradients travel while D's half of the step runs
+                opt.start_allreduce()
             self._run_phase("body_d", self._body_d_phase, st, key)
         else:
             self._run_phase("body", self._body_phase, st, key)
@@ -649,12 +653,11 @@ class RGBDUpdater:
             # data parallel (train_rgbd.py:154-156: the multi-node optimizers all-reduce before they update): one
             # all-reduce per flat gradient buffer on the communicator's stream, the collectives outside the graphs;
             # the generator's Adam step runs while D's 34 MB all-reduce is still in flight
-            for opt in (opt_g_m, opt_g_g, opt_d):
-                if opt is not None and getattr(opt, "_pending", None) is None:
+            for opt in g_opts + [opt_d]:
+                if getattr(opt, "_pending", None) is None:
                     opt.start_allreduce()
-            for opt in (opt_g_m, opt_g_g):
-                if opt is not None:
-                    opt.finish_allreduce()
+            for opt in g_opts:
+                opt.finish_allreduce()
             self._run_phase("opt_g", self._opt_g_phase, st, key)
             opt_d.finish_allreduce()
             self._run_phase("opt_d", self._opt_d_phase, st, key)

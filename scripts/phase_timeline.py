@@ -14,9 +14,10 @@ for i in range(8):
     upd.update()
 torch.cuda.synchronize()
 marks, orig = [], upd._run_phase
-def rp(name, fn, st, key):
+def rp(name, fn, st, key, stream=None):
+    s = stream if stream is not None else torch.cuda.current_stream()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); orig(name, fn, st, key); e1.record()
+    e0.record(s); orig(name, fn, st, key, stream); e1.record(s)
     marks.append((name, e0, e1))
 upd._run_phase = rp
 steps = 4
