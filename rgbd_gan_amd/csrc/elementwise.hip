@@ -800,6 +800,7 @@ __global__ __launch_bounds__(256) void planes_outer_kernel(const unsigned short*
 // launch-latency bound (2 MFLOP each): one launch per layer forward, two backward, instead of ~10 library / elementwise
 // launches.  x (M,K), W (N,K), y (M,N) row-major.
 constexpr int LIN_MAXM = 64;
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));   // a quad of floats on a 4-byte boundary
 
 // block = 256 threads -> 8 output columns for all rows: thread = (row m = tid & 63, column pair tid >> 6).
 // Few, long phases (K in chunks of 128): the kernel's time is load latency, so it uses N/8 blocks instead of N/32.
@@ -853,12 +854,23 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
                 if (kb >= kend || !mok) a[s2] = zero;
                 if (kb >= kend || !nok) b[s2] = zero;
             } else {
+                // K not a multiple of 4 (the pose style: K = 265): rows start on 4-byte boundaries only.  Whole quads are
+                // still fetched with ONE 16-byte load each (global_load_dwordx4 needs dword alignment only), the
+                // ragged last quad element by element: 64 scalar loads per chunk per lane made this launch 190 us next
+                // to the other stream's convolutions.
+                if (kb + 3 < kend) {
+                    a[s2] = *reinterpret_cast<const f32x4_u*>(xr + kb);
+                    b[s2] = *reinterpret_cast<const f32x4_u*>(wr + kb);
+                    if (!mok) a[s2] = zero;
+                    if (!nok) b[s2] = zero;
+                } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bool ok = kb + j < kend;
-                    const float av = xr[ok ? kb + j : 0], bv = wr[ok ? kb + j : 0];
-                    a[s2][j] = ok && mok ? av : 0.f;
-                    b[s2][j] = ok && nok ? bv : 0.f;
+                    for (int j = 0; j < 4; ++j) {
+                        const bool ok = kb + j < kend;
+                        const float av = xr[ok ? kb + j : 0], bv = wr[ok ? kb + j : 0];
+                        a[s2][j] = ok && mok ? av : 0.f;
+                        b[s2][j] = ok && nok ? bv : 0.f;
+                    }
                 }
             }
         }

@@ -4,7 +4,7 @@
 # conv kernels on the step's layer shapes; summaries into profiles/$1 (stamped with the kernel sources' hash).
 #   scripts/collect_profiles.sh r02 [commit]
 set -u
-R=${1:-r02}
+R=${1:-r03}
 export RGBD_COMMIT=${2:-unknown}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/$R profiles/$R
