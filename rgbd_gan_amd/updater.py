@@ -291,7 +291,12 @@ class RGBDUpdater:
             self._gen_backward(st)
 
     def _dfw_phase(self, st):
+        """D's weight gradients for the fakes; on two streams this is the last writer of D's gradients (it follows `dis` on
+        the side stream), so the two gradient buffers are merged here and D's all-reduce can start behind it."""
         Fn.run_deferred_wgrads(st["dfw"])
+        if st.get("concurrent"):
+            for _, store in self.dis.stores:
+                store.merge_alt()
 
     def _gen_seeds(self, st, x_d, y_fake, seed_g, seed_d, ratio):
         """D(x_fake) is evaluated and differentiated ONCE per step.  The reference runs the discriminator on the same
@@ -410,11 +415,7 @@ class RGBDUpdater:
         Fn.run_deferred_wgrads(wgrads)
 
     def _join_phase(self, st):
-        """After both phases: D's gradients from the fakes (generator phase, second buffer) join those from the reals,
-        and the reported discriminator loss gets its fake half."""
-        if st.get("concurrent"):
-            for _, store in self.dis.stores:
-                store.merge_alt()
+        """After both phases: the reported discriminator loss gets its fake half."""
         self.observation["dis/loss_adv"] = st["dis_reported"] + st["loss_dfake"]
 
     def _prep_only_phase(self, st):
@@ -474,6 +475,16 @@ class RGBDUpdater:
     def _opt_d_phase(self, st):
         self._optimizers["dis"].update()
 
+    timeline = None             # set to a dict: update_core leaves timing events of its last step there (tests, scripts)
+
+    def _mark(self, name, stream):
+        if self.timeline is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(stream)
+            self.timeline[name] = ev
+
+    graph_fallback = False      # class defaults shared with DeepVoxelsUpdater (its own __init__)
+    _capture_stream = None
     profile_ranges = False      # train_rgbd.py sets it for `nvprof` / `enable_cuda_profiling` (train_rgbd.py:100,363-364,462)
 
     @property
@@ -635,10 +646,15 @@ class RGBDUpdater:
             self._run_phase("dis", self._dis_phase, st, key, stream=side)        # D on the reals, R1, its weight gradients
             self._run_phase("gen_a", self._gen_a_phase, st, key)                 # G forward, the one pass through D(x_fake)
             side.wait_stream(main)
-            self._run_phase("dfw", self._dfw_phase, st, key, stream=side)        # D's weight gradients for the fakes
-            self._run_phase("gen_b", self._gen_b_phase, st, key)                 # 3-D loss, G backward, G's weight gradients
+            self._run_phase("dfw", self._dfw_phase, st, key, stream=side)        # D's weight gradients for the fakes, merge
+            self._mark("side_end", side)
             if dp:
-                for opt in g_opts:          # ~29 MB of generator gradients travel while the side stream finishes
+                with torch.cuda.stream(side):   # D's gradients are final: 34 MB travel under the generator's backward
+                    opt_d.start_allreduce()
+            self._run_phase("gen_b", self._gen_b_phase, st, key)                 # 3-D loss, G backward, G's weight gradients
+            self._mark("gen_b_end", main)
+            if dp:
+                for opt in g_opts:          # ... and the generator's 29 MB under whatever the side stream still has to do
                     opt.start_allreduce()
             main.wait_stream(side)
             self._run_phase("join", self._join_phase, st, key)

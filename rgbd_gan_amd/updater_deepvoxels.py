@@ -60,7 +60,7 @@ class DeepVoxelsUpdater(RGBDUpdater):
         comm = getattr(self._optimizers["gen"], "comm", None)
         self.use_graphs = bool(kwargs.pop("use_graphs", True)) and not (comm is not None and comm.active)
         self.graph_warmup = int(kwargs.pop("graph_warmup", 2))
-        self.graph_phases = ("dv_gen", "dv_dis")
+        self.graph_fallback = bool(kwargs.pop("graph_fallback", False))
         self._graphs, self._eager_calls, self._stagers = {}, {}, {}
 
     def get_stage(self):

@@ -238,3 +238,46 @@ def test_data_parallel_path_on_a_one_rank_rccl_group():
     assert len(rows) == 1, r.stdout[-2000:]
     line = json.loads(rows[0])
     assert line["n_gpus"] == 1 and line["value"] > 0 and np.isfinite(line["ms_per_step"])
+
+
+OVERLAP_SCRIPT = r"""
+import os, sys, json
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+from rgbd_gan_amd.dist import Communicator
+from rgbd_gan_amd.training import DeviceImageIterator, build_training
+from rgbd_gan_amd.utils import yaml_utils
+comm = Communicator()
+assert comm.active and torch.distributed.get_backend() == "nccl" and torch.distributed.get_world_size() == 1
+cfg = yaml_utils.load("configs/stylegan_shapenet_car.yml")
+images = np.random.RandomState(0).randint(0, 256, (64, 3, 128, 128)).astype("uint8")
+it = DeviceImageIterator(images, 16, "cuda:0", seed=0)
+gen, dis, opt, upd = build_training(cfg, "cuda:0", comm, iterator=it, nan_check_interval=0)
+upd.iteration = 200000
+for _ in range(6):
+    upd.update()
+rows = []
+for _ in range(5):
+    upd.timeline = {}
+    upd.update()
+    torch.cuda.synchronize()
+    rows.append(upd.timeline["side_end"].elapsed_time(upd.timeline["gen_b_end"]))
+print("RESULT " + json.dumps({"lead_ms": rows, "graphs": sorted(k[-1] for k in upd._graphs), "t": opt["gen"].t}))
+comm.close()
+"""
+
+
+def test_generator_allreduce_starts_while_the_side_stream_is_still_working():
+    """Data parallel on two streams (real RCCL, one-rank group): each stream's all-reduces are enqueued the moment ITS
+    gradients are final -- D's behind dfw + merge on the side stream, map + gen behind gen_b on the main stream -- so the
+    one that is ready first travels under the other stream's remaining compute.  Event timestamps of the two moments:
+    they are at least 50 us apart in every step (at these sizes the side stream finishes first: D's 34 MB are hidden
+    under the generator's backward)."""
+    env = dict(os.environ, RGBD_DEBUG_FORCE_COLLECTIVES="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", RANK="0",
+               WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "-c", OVERLAP_SCRIPT], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][0][7:])
+    assert res["graphs"] == sorted(["prep", "dis", "gen_a", "dfw", "gen_b", "join", "opt_g", "opt_d"])
+    assert res["t"] == 10                                   # 11 calls, the first one only broadcast
+    assert all(abs(ms) > 0.05 for ms in res["lead_ms"]), res

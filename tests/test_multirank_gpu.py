@@ -180,6 +180,12 @@ def test_two_ranks_equal_their_single_process_emulation(tmp_path, stage):
         np.testing.assert_array_equal(r0[f"{k}/delta"], r1[f"{k}/delta"])       # ... and takes the same Adam step
         assert int(r0[f"{k}/t"]) == 4                  # the first of the 5 calls only broadcast (ChainerMN)
     _compare(r0, v0, f"2 ranks vs their emulation, stage {stage}", TRANSPORT, exact_upd=2e-2)
+    # the same virtual rank in the TWO-STREAM data-parallel arrangement (D's all-reduce behind dfw on the side stream, the
+    # generator's behind gen_b on the main stream): same kernels, same sums
+    _wait([_run(tmp_path / "v0c.npz", *flags, "--virtual-rank", "0", "--peer-grads", str(tmp_path / "g1.npz"), "--concurrent")])
+    v0c = np.load(tmp_path / "v0c.npz")
+    assert int(v0c["n_graphs"]) == 8                   # prep, dis, gen_a, dfw, gen_b, join, opt_g, opt_d
+    _compare(v0c, v0, f"two-stream vs one-stream data-parallel step, stage {stage}", TRANSPORT, exact_upd=2e-2)
     g1 = np.load(tmp_path / "g1.npz")                  # what rank 1's half-batch contributed to the sums
     for k in ("map", "gen", "dis"):
         assert np.linalg.norm(g1[k]) > 0.1 * np.linalg.norm(r0[f"{k}/grad"] * 2), k
