@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RGBD_ABI_VERSION 8
+#define RGBD_ABI_VERSION 9
 
 int rgbd_abi_version(void);
 const char* rgbd_last_error(void);
@@ -276,6 +276,10 @@ int rgbd_zero_multi_f32(float* const* ptrs /* host array */, const int64_t* coun
 int rgbd_hidden_normalize(const float* z, float* out, int M, int C, float ch, int copies, void* stream);
 int rgbd_r1_penalty_fwd(const float* g, int B, int64_t n, float coef, float* workspace, float* loss, void* stream);
 int rgbd_scale_by_scalar_f32(const float* x, const float* scalar_device, float k, float* out, int64_t n, void* stream);
+/* out[r, :] = a[r, :] + s[r] * x[r, :] over (rows, row_len) fp32, row_len % 4 == 0, 16-byte aligned; s NULL = 1; out may
+ * alias a.  The sum of two gradient buffers (rows = 1) and the per-sample operand update of the adversarial injection
+ * (updater.py:405-422 folded into the R1 double backward) at the image planes. */
+int rgbd_axpy_rows_f32(const float* a, const float* x, const float* s, float* out, int64_t rows, int64_t row_len, void* stream);
 int rgbd_image_grad_init(const float* gx, const float* ratio, float* out, int B, int KP_in, int KP_out, int HW,
                          void* stream);
 int rgbd_const_input_fwd(const float* w, const float* bias, void* out, int B, int HW, int C, float slope, void* stream);

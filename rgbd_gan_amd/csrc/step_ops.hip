@@ -128,6 +128,24 @@ __global__ __launch_bounds__(256) void scale_by_scalar_kernel(const float* __res
     for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = x[i] * s;
 }
 
+// out = a + s[row] * x over (rows, row_len) fp32 (s NULL: s = 1; out may alias a): the merge of D's two gradient buffers at
+// the join, and the operand  dout + s_b * x_real  of the adversarial injection at the image planes (functional._ToPlanes).
+// (torch's add / mul kernels did this in rounds 1-2; the library's own kernels are built without packed-fp32
+// instructions)
+__global__ __launch_bounds__(256) void axpy_rows_f32_kernel(const float* __restrict__ a, const float* __restrict__ x,
+                                                            const float* __restrict__ s, float* __restrict__ out,
+                                                            long rows, long row_len) {
+    const long n4 = rows * row_len >> 2, r4 = row_len >> 2;
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(a);
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    f32x4* o4 = reinterpret_cast<f32x4*>(out);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float sv = s ? s[i / r4] : 1.f;
+        const f32x4 av = a4[i], xv = x4[i];
+        o4[i] = f32x4{av[0] + sv * xv[0], av[1] + sv * xv[1], av[2] + sv * xv[2], av[3] + sv * xv[3]};
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ image gradient junction
 // The generator's output gradient before the 3-D consistency loss adds its part (updater.py:334,363-365,387):
 //   out[b, k, p] = ratio[b] * gx[b, k, p]  for k < 3  (adversarial image gradient, rescaled per sample -- updater.py of
@@ -438,6 +456,15 @@ extern "C" int rgbd_scale_by_scalar_f32(const float* x, const float* scalar_devi
                  "rgbd_scale_by_scalar_f32: bad arguments");
     scale_by_scalar_kernel<<<grid_for(n / 4), 256, 0, (hipStream_t)stream>>>(x, scalar_device, k, out, n);
     RGBD_CHECK_LAUNCH("scale_by_scalar_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_axpy_rows_f32(const float* a, const float* x, const float* s, float* out, int64_t rows, int64_t row_len,
+                                  void* stream) {
+    RGBD_REQUIRE(a && x && out && rows > 0 && row_len > 0 && row_len % 4 == 0, "rgbd_axpy_rows_f32: bad arguments");
+    RGBD_REQUIRE((((uintptr_t)a | (uintptr_t)x | (uintptr_t)out) & 15) == 0, "rgbd_axpy_rows_f32: buffers must be 16-byte aligned");
+    axpy_rows_f32_kernel<<<grid_for(rows * row_len / 4), 256, 0, (hipStream_t)stream>>>(a, x, s, out, rows, row_len);
+    RGBD_CHECK_LAUNCH("axpy_rows_f32_kernel");
     return 0;
 }
 

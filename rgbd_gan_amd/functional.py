@@ -789,7 +789,7 @@ class _ToPlanes(torch.autograd.Function):
         if ctx.needs_input_grad[1] and not _skip_grad_of(w):
             operand = dout
             if _INJECT is not None and ctx.inj_x is not None:
-                operand = dout + _INJECT.reshape(-1, 1, 1, 1) * ctx.inj_x.detach()
+                operand = kernels.axpy_rows_f32(dout, ctx.inj_x.detach().contiguous(), _INJECT)
                 b = ctx.inj_bias
                 if b is not None and not _skip_grad_of(b):
                     if not _direct_grad(b):

@@ -681,6 +681,22 @@ def r1_penalty_fwd(g, coef):
     return loss
 
 
+def axpy_rows_f32(a, x, s=None, out=None):
+    """a + s[r] * x row by row (fp32, contiguous, trailing dimensions flattened); s None = 1; out=a accumulates in place."""
+    _chk(a, F32, "a"); _chk(x, F32, "x"); _chk(s, F32, "s")
+    if a.shape != x.shape:
+        raise RuntimeError(f"axpy_rows_f32: shapes {tuple(a.shape)} vs {tuple(x.shape)}")
+    rows = int(s.numel()) if s is not None else 1
+    row_len = a.numel() // rows
+    if rows * row_len != a.numel() or row_len % 4:
+        raise RuntimeError(f"axpy_rows_f32: {a.numel()} elements do not split into {rows} rows of a multiple of 4")
+    if out is None:
+        out = torch.empty_like(a)
+    _lib.check(_lib.load().rgbd_axpy_rows_f32(_ptr(a), _ptr(x), _ptr(s), _ptr(out), rows, row_len, _stream()),
+               "rgbd_axpy_rows_f32")
+    return out
+
+
 def scale_by_scalar(x, scalar, k):
     """(scalar[0] * k) * x with `scalar` a device tensor (or None = 1)."""
     _chk(x, F32, "x"); _chk(scalar, F32, "scalar")

@@ -83,7 +83,11 @@ class ParamStore:
 
     def merge_alt(self):
         if self.grad_alt is not None:
-            self.grad.add_(self.grad_alt)
+            from . import kernels
+            n4 = self.grad.numel() // 4 * 4          # flat buffers are padded to 16-byte granules per tensor
+            kernels.axpy_rows_f32(self.grad[:n4], self.grad_alt[:n4], out=self.grad[:n4])
+            if n4 != self.grad.numel():
+                self.grad[n4:].add_(self.grad_alt[n4:])
 
     def fused(self, names, shape):
         """One leaf tensor over several parameters that sit back to back in the flat buffer (e.g. the scale and shift

@@ -67,6 +67,23 @@ def test_r1_penalty_kernel_and_gradient():
     torch.testing.assert_close(gd.grad.cpu(), 0.7 * gc.grad, rtol=1e-5, atol=1e-9)
 
 
+def test_axpy_rows_f32():
+    """a + s[b] * x per sample (the adversarial injection's operand at the image planes) and, without s, the in-place sum
+    of two flat gradient buffers (the join of D's two buffers)."""
+    from rgbd_gan_amd import kernels
+    g = torch.Generator().manual_seed(3)
+    a, x = torch.randn(5, 3, 8, 8, generator=g).cuda(), torch.randn(5, 3, 8, 8, generator=g).cuda()
+    sc = torch.randn(5, generator=g).cuda()
+    got = kernels.axpy_rows_f32(a, x, sc)
+    torch.testing.assert_close(got, a + sc.reshape(-1, 1, 1, 1) * x, rtol=0, atol=1e-6)
+    flat, other = torch.randn(1000, generator=g).cuda(), torch.randn(1000, generator=g).cuda()
+    want = flat + other
+    kernels.axpy_rows_f32(flat, other, out=flat)
+    assert torch.equal(flat, want)
+    with pytest.raises(RuntimeError):
+        kernels.axpy_rows_f32(a[:, :1, :1, :3].contiguous(), x[:, :1, :1, :3].contiguous(), sc)     # rows of 3 floats
+
+
 def test_image_grad_init():
     from rgbd_gan_amd import kernels
     gx = torch.randn(4, 3, 16, 16, device=DEV)
