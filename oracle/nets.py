@@ -93,8 +93,35 @@ def inv_c(fan_in, gain=SQRT2):
     return float(gain * np.sqrt(1.0 / fan_in))
 
 
+SN_TRAIN = True      # chainer.config.train: the hook moves the persistent vector u only in train mode
+
+
+def sn_weight(p, name, eps=1e-6):
+    """chainer.link_hooks.SpectralNormalization (chainer >= 7.0.0, the pin of the reference's README; third-party code that
+    is not in /root/reference, restated from its published algorithm) as net.py:366-370,391-396,455-463 attach it:
+    n_power_iteration=1, eps=1e-6, use_gamma=False, factor=None.  Per forward call of the layer:
+        W_m = W.reshape(Cout, -1);  v = l2n(u W_m);  u' = l2n(W_m v)   (arrays, no gradient; l2n(x) = x / (|x|_2 + eps))
+        sigma = (u' W_m) v   (a Variable: differentiable in W, u' and v constants);  the layer runs with W / sigma;
+        in train mode the persistent vector (saved as <link>/W_u) becomes u'."""
+    W, u = p[name + "/W"], p[name + "/W_u"]
+    Wm = W.reshape(W.shape[0], -1)
+    with torch.no_grad():
+        v = u @ Wm
+        v = v / (torch.linalg.vector_norm(v) + eps)
+        u_new = Wm @ v
+        u_new = u_new / (torch.linalg.vector_norm(u_new) + eps)
+        if SN_TRAIN:
+            u.copy_(u_new)
+    sigma = torch.dot(u_new @ Wm, v)
+    return W / sigma
+
+
 def eq_conv(x, p, name, pad, gain=SQRT2):
-    """pggan.py:13-24 (EqualizedConv2d.forward): c(inv_c * x), cross-correlation."""
+    """pggan.py:13-24 (EqualizedConv2d.forward): c(inv_c * x), cross-correlation.  Spectral-norm discriminators
+    (net.py:366-370 ...) hold plain L.Convolution2D links under the same names: W / sigma, no input scaling."""
+    if name + "/c/W" not in p and name + "/W" in p:
+        Wn = sn_weight(p, name)
+        return F.conv2d(x, rf(Wn) if _EMULATE_BF16 and Wn.shape[2] == 3 else Wn, p[name + "/b"], padding=pad)
     W = p[name + "/c/W"]
     b = p.get(name + "/c/b")
     if _EMULATE_BF16 and W.shape[2] == 3:          # the engine's 3x3 convs read bf16(inv_c * W); its 1x1 planes convs fp32
@@ -104,6 +131,8 @@ def eq_conv(x, p, name, pad, gain=SQRT2):
 
 def eq_linear(x, p, name, gain=SQRT2):
     """pggan.py:39-50 (EqualizedLinear.forward); L.Linear flattens trailing dims."""
+    if name + "/c/W" not in p and name + "/W" in p:
+        return F.linear(x.reshape(x.shape[0], -1), sn_weight(p, name), p[name + "/b"])
     W = p[name + "/c/W"]
     b = p.get(name + "/c/b")
     return F.linear(inv_c(W.shape[1], gain) * x.reshape(x.shape[0], -1), W, b)
@@ -251,6 +280,29 @@ def init_discriminator(ch=256, seed=1, out_dim=1, res=True):
     for i, co in enumerate(ins):
         p[f"ins/{i}/c/W"] = _normal(g, co, 3, 1, 1)
         p[f"ins/{i}/c/b"] = torch.zeros(co)
+    return p
+
+
+def init_discriminator_sn(ch=256, seed=1, out_dim=1, res=True):
+    """net.py:429-463 with sn=True: plain convolutions / linear with bias, W ~ chainer.initializers.Uniform(1) = U(-1, 1),
+    b = 0, and the hook's persistent vector u ~ N(0, 1) per link (spectral_normalization.py:_prepare_parameters)."""
+    g = torch.Generator().manual_seed(seed)
+    p = {}
+
+    def add(name, *shape):
+        p[name + "/W"] = torch.rand(*shape, generator=g) * 2 - 1
+        p[name + "/b"] = torch.zeros(shape[0])
+        p[name + "/W_u"] = torch.randn(shape[0], generator=g)
+    add("blocks/0/c0", ch, ch, 3, 3)
+    add("blocks/0/c1", ch, ch, 4, 4)
+    add("blocks/0/l2", out_dim, ch)
+    chans = [None, (ch, ch), (ch, ch), (ch, ch), (ch // 2, ch), (ch // 4, ch // 2)]
+    for i in range(1, 6):
+        ci, co = chans[i]
+        for nm in (("c0", "c1", "c_sc") if res else ("c0", "c1")):
+            add(f"blocks/{i}/{nm}", co, co if nm == "c1" else ci, 3, 3)
+    for i, co in enumerate([ch, ch, ch, ch, ch // 2, ch // 4]):
+        add(f"ins/{i}", co, 3, 1, 1)
     return p
 
 

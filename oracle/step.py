@@ -129,7 +129,8 @@ def rgbd_step(gen_params, dis_params, opt, x_real_full, z, thetas, stage, cfg, i
     y_real = nets.discriminator(dis_params, x_real, stage)
     loss_dis = loss_dis_adv(y_fake, y_real)
     out["dis/loss_adv_only"] = float(loss_dis.detach())
-    if cfg["lambda_gp"] > 0:
+    sn = "blocks/0/c0/W_u" in dis_params                   # updater.py:414: `if not self.dis.sn and self.lambda_gp > 0`
+    if cfg["lambda_gp"] > 0 and not sn:
         loss_gp = r1_penalty(y_real, x_real, cfg["lambda_gp"])
         out["dis/loss_gp"] = float(loss_gp.detach())
         loss_dis = loss_dis + loss_gp

@@ -439,9 +439,11 @@ class Discriminator(_Link):
     """net.py:429-504 with res blocks (net.py:380-426) and the 4x4 base block (net.py:357-377)."""
 
     def __init__(self, ch=512, out_dim=1, enable_blur=False, sn=False, res=False, device="cuda:0", seed=100):
-        assert not sn, "spectral normalisation is not supported (sn: False in every shipped config)"
         assert ch % 256 == 0
-        self.ch, self.sn, self.res, self.max_stage = ch, sn, res, 17
+        self.ch, self.sn, self.res, self.max_stage = ch, bool(sn), res, 17
+        if self.sn:
+            self._init_sn(ch, out_dim, enable_blur, res, device, seed)
+            return
         self.enable_blur = bool(enable_blur)       # net.py:422-423: blur(downscale2x(h)) at the end of every block
         self.device = torch.device(device)
         self.chans = [None, (ch, ch), (ch, ch), (ch, ch), (ch // 2, ch), (ch // 4, ch // 2)]  # (in, out)
@@ -467,6 +469,135 @@ class Discriminator(_Link):
                 cin = co if nm == "c1" else ci
                 self.conv[f"blocks/{i}/{nm}"] = Fn.ConvLayer(p[f"blocks/{i}/{nm}/c/W"], _inv_c(cin * 9), 1)
         self.pack_group = Fn.PackGroup(list(self.conv.values()))
+
+    # ---------------------------------------------------------------- spectral-norm variant (net.py:366-370,391-396,455-463)
+    # Every convolution / linear is a plain (NOT equalized-LR) layer with bias, W ~ U(-1, 1), wrapped by chainer's
+    # SpectralNormalization link hook (chainer >= 7, n_power_iteration=1, eps=1e-6, no gamma): at every forward call of a
+    # layer, in train mode,   v = l2n(u W_m), u <- l2n(W_m v)   (W_m = W reshaped (Cout, -1), u persistent, l2n(x) =
+    # x / (|x| + eps), no gradient), sigma = u^T W_m v (differentiable in W), and the layer runs with W / sigma.
+    # The normalised weights are derived tensors (functional.DerivedConvLayer): weight gradients flow back to the
+    # masters through the division by sigma.  RGBDUpdater runs the reference's literal three-forward step for such a
+    # discriminator (no R1 penalty: updater.py:414), because every forward call moves u and with it the function.
+    SN_EPS = 1e-6
+
+    def _init_sn(self, ch, out_dim, enable_blur, res, device, seed):
+        self.enable_blur = bool(enable_blur)
+        self.device = torch.device(device)
+        self.chans = [None, (ch, ch), (ch, ch), (ch, ch), (ch // 2, ch), (ch // 4, ch // 2)]
+        self.in_chans = [ch, ch, ch, ch, ch // 2, ch // 4]
+        uni = lambda shape, gen: torch.rand(shape, generator=gen) * 2 - 1           # chainer.initializers.Uniform(1)
+        specs, self.sn_layers = [], []
+        def add(name, shape):
+            specs.extend([(name + "/W", shape, uni), (name + "/b", (shape[0],), "zeros")])
+            self.sn_layers.append(name)
+        add("blocks/0/c0", (ch, ch, 3, 3))
+        add("blocks/0/c1", (ch, ch, 4, 4))
+        add("blocks/0/l2", (out_dim, ch))
+        for i in range(1, 6):
+            ci, co = self.chans[i]
+            for nm in (("c0", "c1", "c_sc") if res else ("c0", "c1")):
+                add(f"blocks/{i}/{nm}", (co, co if nm == "c1" else ci, 3, 3))
+        for i, co in enumerate(self.in_chans):
+            add(f"ins/{i}", (co, 3, 1, 1))
+        self.store = ParamStore(specs, device, seed)
+        self.stores = (("", self.store),)
+        gen = torch.Generator().manual_seed(seed + 1)
+        # the hook's persistent vector, one per layer (saved with the link as <layer>/W_u)
+        self.sn_u = {n: torch.randn(self.store.shapes[n + "/W"][0], generator=gen).to(self.device) for n in self.sn_layers}
+        self.pack_group = None
+        self.train = True
+
+    def _sn_normalize(self, names):
+        """One power iteration + W / sigma for the layers a forward call is about to run (what the link hook's
+        forward_preprocess does layer by layer) -> ({layer: W / sigma}, {layer: conv-engine layer object}).  The layer
+        objects are per CALL: a call's backward must read the bf16 images of ITS normalised weights, not those of a
+        later call (the discriminator step differentiates two calls after both have run)."""
+        p = self.store.params
+        w, conv = {}, {}
+        for n in names:
+            W = p[n + "/W"]
+            Wm = W.reshape(W.shape[0], -1)
+            with torch.no_grad():
+                u = self.sn_u[n]
+                v = u @ Wm
+                v = v / (torch.linalg.vector_norm(v) + self.SN_EPS)
+                u_new = Wm @ v
+                u_new = u_new / (torch.linalg.vector_norm(u_new) + self.SN_EPS)
+                if self.train:
+                    u.copy_(u_new)
+            sigma = torch.dot(u_new @ Wm, v)
+            w[n] = W / sigma
+            if W.dim() == 4 and W.shape[2] == 3:
+                conv[n] = Fn.DerivedConvLayer(lambda t=w[n]: t, 1.0, 3, 1)
+        return w, conv
+
+    def _sn_call(self, x, stage, return_hidden):
+        x = _as_device_tensor(x, self.device)
+        st, alpha = _split_stage(stage, self.max_stage)
+        p, blocks_of = self.store.params, lambda i: [f"blocks/{i}/{nm}" for nm in
+                                                     (("c0", "c1", "l2") if i == 0 else
+                                                      (("c0", "c1", "c_sc") if self.res else ("c0", "c1")))]
+        if st % 2 == 0:
+            k = (st - 2) // 2
+            used = [f"ins/{k + 1}"] + [n for i in range(0, k + 2) for n in blocks_of(i)]
+        else:
+            k = (st - 1) // 2
+            used = [f"ins/{k}", f"ins/{k + 1}"] + [n for i in range(0, k + 2) for n in blocks_of(i)]
+        w, conv = self._sn_normalize(used)
+
+        def from_rgb(i, img):
+            W = w[f"ins/{i}"]
+            return Fn.from_planes(img, W.reshape(W.shape[0], 3), p[f"ins/{i}/b"], 1.0, act=True)
+
+        def block(i, h):
+            pre = f"blocks/{i}"
+            if i == 0:
+                h = Fn.conv_bias_lrelu(h, conv[pre + "/c0"], p[pre + "/c0/b"])
+                rows = Fn.nhwc_to_rows(h)
+                outs = []
+                for r0 in range(0, rows.shape[0], 64):
+                    u = Fn.dense(rows[r0:r0 + 64], w[pre + "/c1"], p[pre + "/c1/b"], 1.0, act=True)
+                    outs.append(Fn.dense(u, w[pre + "/l2"], p[pre + "/l2/b"], 1.0, act=False))
+                return outs[0] if len(outs) == 1 else torch.cat(outs)
+            hh = Fn.conv_bias_lrelu(h, conv[pre + "/c0"], p[pre + "/c0/b"])
+            sc = Fn.conv_bias(h, conv[pre + "/c_sc"], p[pre + "/c_sc/b"]) if self.res else None
+            hh = Fn.conv_bias_lrelu(hh, conv[pre + "/c1"], p[pre + "/c1/b"], residual=sc, pool=True)
+            return Fn.blur(hh) if self.enable_blur else hh
+
+        feat = None
+        if st % 2 == 0:
+            h = from_rgb(k + 1, x)
+            for i in reversed(range(0, k + 2)):
+                if i == 3:
+                    feat = h
+                h = block(i, h)
+        else:
+            h0 = from_rgb(k, Fn.avg_pool2_planes(x))
+            h1 = block(k + 1, from_rgb(k + 1, x))
+            h = Fn.lerp(h0, h1, alpha)
+            for i in reversed(range(0, k + 1)):
+                if i == 3:
+                    feat = h
+                h = block(i, h)
+        if return_hidden:
+            return h, (feat.permute(0, 3, 1, 2).float() if feat is not None else None)
+        return h
+
+    def state_dict(self):
+        out = super().state_dict()
+        if self.sn:
+            out.update({n + "/W_u": u.detach().cpu().numpy().copy() for n, u in self.sn_u.items()})
+        return out
+
+    def load_state_dict(self, arrays, strict=True):
+        super().load_state_dict(arrays, strict=strict)
+        if self.sn:
+            for n, u in self.sn_u.items():
+                if n + "/W_u" in arrays:
+                    u.copy_(torch.as_tensor(np.asarray(arrays[n + "/W_u"])).to(self.device, torch.float32))
+                elif strict:
+                    raise KeyError(n + "/W_u")
+
 
     def tail_params(self):
         """Parameters of the dense tail after the conv stack (4x4 valid conv as a linear + the output linear), the part
@@ -506,6 +637,8 @@ class Discriminator(_Link):
         return Fn.blur(h) if self.enable_blur else h
 
     def __call__(self, x, stage, return_hidden=False):
+        if self.sn:
+            return self._sn_call(x, stage, return_hidden)
         x = _as_device_tensor(x, self.device)
         st, alpha = _split_stage(stage, self.max_stage)
         feat = None

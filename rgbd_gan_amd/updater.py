@@ -548,6 +548,48 @@ class RGBDUpdater:
             self.observation.update(entry["obs"])
         entry["graph"].replay()
 
+    def _sn_step(self, st, opt_g_m, opt_g_g, opt_d, cams):
+        """Spectral-norm discriminator (config `sn: True`, net.py:366-370; updater.py:414 then skips the R1 penalty): the
+        reference's LITERAL step -- D on the fakes in the generator step, D on the same fakes again and on the reals in
+        the discriminator step.  Every forward call of an SN layer runs a power iteration and moves its persistent
+        vector, i.e. changes the function, so the single pass through D(x_fake) that the default step shares between
+        the two losses is not the same computation here.  Plain autograd over the engine's differentiable ops, eager,
+        one stream; gradients reach the master weights through W / sigma."""
+        cfg, obs = self.config, self.observation
+        stage, B, half = st["stage"], st["B"], st["B"] // 2
+        self._prep_phase(st)
+        x_real = st["x_real"]
+        z = st["z"]
+        if z is None:
+            z_half = self.get_z_fake_data(half)
+            z = torch.cat([z_half, z_half], dim=0)
+        x_fake = self.gen(z, stage, st["theta9"])
+        y_fake = self.dis(x_fake[:, :3].contiguous(), stage=stage)
+        loss_gen = loss_func_dcgan_gen(y_fake)
+        obs["gen/loss_adv"] = loss_gen.detach()
+        if st["use_rotate"]:
+            loss_rotate, _ = self.loss_func_rotate(x_fake[:half], cams[:half], x_fake[half:], cams[half:], st["occlusion"])
+            if cfg.lambda_depth > 0:
+                loss_rotate = loss_rotate + torch.mean(F.relu(cfg.depth_min - x_fake[:, -1]) ** 2) * cfg.lambda_depth
+            obs["gen/loss_rotate"] = loss_rotate.detach()
+            lambda_rotate = cfg.lambda_rotate if cfg.lambda_rotate else 2
+            lambda_rotate = lambda_rotate if x_real.shape[2] <= 128 else lambda_rotate * 2
+            loss_gen = loss_gen + loss_rotate * lambda_rotate
+        with Fn.weight_grads_frozen(self.dis):          # the reference clears D's gradients right after (updater.py:395)
+            loss_gen.backward()
+        for opt in (opt_g_m, opt_g_g):
+            if opt is not None:
+                opt.update()
+        self.dis.cleargrads()                           # updater.py:395
+        if self.smoothed_gen is not None:
+            soft_copy_param(self.smoothed_gen, self.gen, 1.0 - self.smoothing)
+        y_fake = self.dis(x_fake.detach()[:, :3].contiguous(), stage=stage)
+        y_real = self.dis(x_real, stage=stage)
+        loss_dis = loss_func_dcgan_dis(y_fake, y_real)
+        obs["dis/loss_adv"] = loss_dis.detach()
+        loss_dis.backward()
+        opt_d.update()
+
     # ---- the step
     def update_core(self, batch=None, z_fake_data=None, thetas=None):
         """Optional arguments let tests and the benchmark inject fixed inputs; by default they are drawn exactly as
@@ -607,6 +649,12 @@ class RGBDUpdater:
                 self._stagers[zkey] = torch.empty_like(z_in)
             self._stagers[zkey].copy_(z_in)
             st["z"] = self._stagers[zkey]
+
+        if getattr(self.dis, "sn", False):
+            self._sn_step(st, opt_g_m, opt_g_g, opt_d, random_camera_matrices if self.camera_conditioned else None)
+            obs = self.observation
+            obs["stage"], obs["batch_size"], obs["image_size"] = stage, batch_size, int(st["x_real"].shape[2])
+            return
 
         fl = math.floor(min(stage, 17 - 1e-8))
         key = None
