@@ -1449,7 +1449,17 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_multi_kernel(WgradMultiLaun
     int i = 0;
     while (i + 1 < m.n && (int)blockIdx.x >= m.wg_begin[i + 1]) ++i;          // block-uniform scan
     const WgradArgs& a = m.p[i];
-    const int local = (int)blockIdx.x - m.wg_begin[i];
+    int local = (int)blockIdx.x - m.wg_begin[i];
+    // XCD-aware order WITHIN a problem: hardware deals consecutive blockIdx round-robin over the 8 XCDs (each with its own
+    // L2), so the (co, ci) tiles of one patch range -- which read the same x slices (per ci tile) and dy slices (per co
+    // tile) -- would sit on different XCDs and each fetch its own copy.  When the problem's workgroup range is aligned
+    // to 8 (the planner rounds to that), XCD k takes the k-th contiguous eighth of the problem's (split, tile) list: whole
+    // tile grids run on one XCD at the same time and share their slices through its L2, and every XCD still gets an
+    // eighth of every problem (a chip-wide contiguous renumbering was 1.5x SLOWER: problems differ in patches per workgroup).
+    {
+        const int n_i = m.wg_begin[i + 1] - m.wg_begin[i];
+        if (((m.wg_begin[i] | n_i) & 7) == 0) local = (local & 7) * (n_i >> 3) + (local >> 3);
+    }
     const int tiles_ci = a.Cin >> 6, tiles = tiles_ci * (a.Cout >> 6);
     const int split = local / tiles, tile = local - split * tiles;
     if constexpr (NT == 9 && FAST) conv_wgrad9_body(a, split, tile % tiles_ci, tile / tiles_ci);
@@ -1964,9 +1974,17 @@ extern "C" int rgbd_conv2d_wgrad_multi_plan(rgbd_wgrad_problem* probs, int n, in
         int nsplit = (int)((double)total_workgroups * patches / units + 0.5);      // = share of workgroups / tiles
         if (nsplit < 1) nsplit = 1;
         if (nsplit > patches) nsplit = patches;
+        // workgroups per problem in multiples of 8 where the patch count allows it (conv_wgrad_multi_kernel: one eighth of
+        // every problem per XCD): nsplit becomes a multiple of 8 / gcd(tiles, 8)
+        const int step = tiles >= 8 ? 1 : 8 / tiles;
+        if (step > 1 && patches % step == 0) {
+            int cand = (nsplit + step / 2) / step * step;
+            if (cand < step) cand = step;
+            while (cand > step && patches % cand != 0 && (patches + cand - 1) / cand * (cand - 1) >= patches) cand -= step;
+            if (cand <= patches && (patches + (patches + cand - 1) / cand - 1) / ((patches + cand - 1) / cand) == cand) nsplit = cand;
+        }
         const int per_wg = (patches + nsplit - 1) / nsplit;
         q.nsplit = (patches + per_wg - 1) / per_wg;
-        (void)tiles;
     }
     return 0;
 }

@@ -50,16 +50,6 @@ def alpha_override(alpha):
         _ALPHA_OVERRIDE = old
 
 
-DEBUG_GRADS = {}      # RGBD_DEBUG_DUMP=1: activation gradients at the block boundaries of the generator's backward
-
-
-def _dbg_grad(h, key):
-    """Diagnostics of the two-queue hazard (scripts/dp_split_check.py): keep a copy of the gradient that reaches `h`."""
-    if os.environ.get("RGBD_DEBUG_DUMP") and h.requires_grad:
-        h.register_hook(lambda g, k=key: DEBUG_GRADS.__setitem__(k, g.detach().clone()))
-    return h
-
-
 def _split_stage(stage, max_stage):
     stage = min(stage, max_stage - 1e-8)
     fl = math.floor(stage)
@@ -236,7 +226,6 @@ class StyleGenerator(_Link):
             h = Fn.conv_bias_lrelu(x, self.c0[i], p[pre + "/b0/b"], upsample=True)
         if i == 0 or styles is None:
             h = style(pre + "/s0", w, h)
-        h = _dbg_grad(h, f"d_block{i}_mid")
         if styles is not None:
             return Fn.conv_bias_lrelu_adain(h, self.c1[i], p[pre + "/b1/b"], *styles[(i, "s1")])
         h = Fn.conv_bias_lrelu(h, self.c1[i], p[pre + "/b1/b"])
@@ -279,10 +268,10 @@ class StyleGenerator(_Link):
             for i in range(0, k + 2):
                 if i == 3:
                     w = w2
-                h = _dbg_grad(run(i, w, h), f"d_block{i}_out")
+                h = run(i, w, h)
                 if return_feature and i == 3:
                     feat = h
-            out = _dbg_grad(self._to_rgbd(k + 1, h), "d_planes")
+            out = self._to_rgbd(k + 1, h)
         else:
             k = (st - 1) // 2
             for i in range(0, k + 1):
