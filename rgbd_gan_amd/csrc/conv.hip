@@ -239,6 +239,113 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(ConvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ small images (4x4, 8x8)
+// 3x3 pad-1 convolutions on 4x4 / 8x8 images (generator blocks 0-1, discriminator blocks 1-0 and their backward passes:
+// 25 launches per step, 2.4 / 0.6 GFLOP each).  The gather kernel above walks a long K loop in which every step waits
+// for global loads issued three steps earlier (~0.9 us per step): 14-19 us per launch at 4-13 % of the MFMA peak.  These
+// layers are one load round trip long if nothing depends on anything: a workgroup takes a 128-pixel tile (whole images:
+// 2 of 8x8, 8 of 4x4) x 64 output channels x ONE 64-channel input slice, requests its whole operand set at once -- the
+// images with their zero halo (25-37 KB) and the nine 64x64 weight tiles (72 KB) -- and after a single wait runs the nine
+// taps out of LDS (144 MFMAs per wave).  Grid = (M / 128) x (Cout / 64) x (Cin / 64) workgroups (256 for 8x8 at B = 32),
+// fp32 partial sums per input slice into the split-K scratch, epilogue by conv_splitk_finish_kernel as before.
+template <int S>   // image side: 4 or 8
+__global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvArgs a) {
+    constexpr int HP = S + 2, IM = 128 / (S * S), NH = IM * HP * HP;     // halo side, images per tile, halo pixels per tile
+    constexpr int X_BYTES = NH * 128, W_BYTES = 9 * 64 * 128;
+    constexpr int XL = (NH * 8 + 255) / 256, WL = 9 * 64 * 8 / 256;      // 16-byte pieces per thread: 7 or 9, and 18
+    extern __shared__ __attribute__((aligned(16))) unsigned char ssm[];  // [X_BYTES] halo images, [W_BYTES] nine weight tiles
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int nci = a.Cin >> 6, nco = a.Cout >> 6;
+    unsigned bid = blockIdx.x;
+    const int slice = (int)(bid % (unsigned)nci);
+    bid /= (unsigned)nci;
+    const int ct = (int)(bid % (unsigned)nco);
+    const int mt = (int)(bid / (unsigned)nco);
+    const int ci0 = slice * 64, co0 = ct * 64, img0 = mt * IM;
+    const auto xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.x), 0, a.x_bytes, 0x00020000);
+    const auto wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.wp), 0, a.w_bytes, 0x00020000);
+
+    // ---- everything this workgroup will ever read, requested at once (range-checked loads: halo pixels read zeros)
+    u32x4 rx[XL], rw[WL];
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+        const int pc = tid + 256 * i, row = pc >> 3, chunk = pc & 7;
+        const int im = row / (HP * HP), rem = row - im * (HP * HP);
+        const int hy = rem / HP, hx = rem - hy * HP;
+        const bool ok = row < NH && hy >= 1 && hy <= S && hx >= 1 && hx <= S;
+        const unsigned off = (unsigned)(((((img0 + im) * S + hy - 1) * S + hx - 1) * a.Cin + ci0 + chunk * 8) * 2);
+        rx[i] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, ok ? off : 0x80000000u, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < WL; ++i) {
+        const int pc = tid + 256 * i, row = pc >> 3, chunk = pc & 7;       // row = tap * 64 + output channel
+        const int tap = row >> 6, co = row & 63;
+        rw[i] = __builtin_amdgcn_raw_buffer_load_b128(
+            wrsrc, (unsigned)((((tap * a.Cout + co0 + co) * a.Cin) + ci0 + chunk * 8) * 2), 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+        const int pc = tid + 256 * i, row = pc >> 3, chunk = pc & 7;
+        const int hx = row % HP;
+        if (row < NH) *reinterpret_cast<u32x4*>(ssm + row * 128 + ((chunk ^ (hx & 7)) << 4)) = rx[i];
+    }
+#pragma unroll
+    for (int i = 0; i < WL; ++i) {
+        const int pc = tid + 256 * i, row = pc >> 3, chunk = pc & 7;
+        *reinterpret_cast<u32x4*>(ssm + X_BYTES + row * 128 + ((chunk ^ (row & 7)) << 4)) = rw[i];
+    }
+    __syncthreads();
+
+    // ---- wave w: pixels 32 w .. 32 w + 31 of the tile x 64 output channels, nine taps x two k halves
+    const int r16 = lane & 15, q = lane >> 4;
+    int prow[2], pcol[2];                         // halo row index of tap (0,0) and image column of this lane's two pixels
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = 32 * wid + 16 * j + r16;
+        const int im = p / (S * S), y = (p / S) % S, x = p % S;
+        prow[j] = (im * HP + y) * HP + x;
+        pcol[j] = x;
+    }
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int kh = tap / 3, kw = tap - 3 * kh;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            bf16x8 af[4], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = tap * 64 + 16 * i + r16;
+                af[i] = *reinterpret_cast<const bf16x8*>(ssm + X_BYTES + row * 128 + (((4 * h + q) ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = prow[j] + kh * HP + kw;
+                bfr[j] = *reinterpret_cast<const bf16x8*>(ssm + row * 128 + (((4 * h + q) ^ ((pcol[j] + kw) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    float* pp = a.partial + (long)slice * a.M * a.Cout;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int co = co0 + 16 * i + 4 * q;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long m = (long)mt * 128 + 32 * wid + 16 * j + r16;
+            *reinterpret_cast<f32x4*>(pp + m * a.Cout + co) = acc[i][j];
+        }
+    }
+}
+
 // Epilogue of the split-K path: sum the K-slice partials, then bias -> residual -> leaky ReLU -> bf16 NHWC.
 __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const float* __restrict__ partial, int S, long M,
                                                                  int Cout, const float* __restrict__ bias,
@@ -1606,10 +1713,19 @@ namespace {
 struct FpropPlan {
     bool patch;      // 3x3 pad-1 halo-patch kernel
     int ksplit;
+    bool small;      // conv3x3_small_kernel: 4x4 / 8x8 images, one workgroup per (128 pixels, 64 co, 64 ci), ksplit = Cin / 64
 };
-FpropPlan plan_fprop(int B, int Hout, int Wout, int Cin, int Cout, int KH, int KW, int pad) {
+FpropPlan plan_fprop(int B, int Hout, int Wout, int Cin, int Cout, int KH, int KW, int pad, bool allow_small = false) {
     FpropPlan p;
+    p.small = false;
     const long M = (long)B * Hout * Wout;
+    if (allow_small && KH == 3 && KW == 3 && pad == 1 && Hout == Wout && (Hout == 4 || Hout == 8) && M % 128 == 0 &&
+        Cin <= 512 && !g_force_gather && g_conv_variant != 4) {
+        p.patch = false;
+        p.small = true;
+        p.ksplit = Cin / 64;       // (1 for Cin = 64: the finish kernel still applies the epilogue)
+        return p;
+    }
     const int bn = Cout % 128 == 0 ? 128 : 64;
     const long tiles = ((M + 127) / 128) * (Cout / bn);
     const int nk = KH * KW * (Cin / 64);
@@ -1644,8 +1760,8 @@ extern "C" int64_t rgbd_conv2d_fprop_workspace(int B, int Hin, int Win, int Cin,
     if (B <= 0 || Hin <= 0 || Win <= 0 || Cin % 64 || Cout % 64 || KH <= 0 || KW <= 0 || pad < 0) return -1;
     const int Hout = (upsample ? 2 * Hin : Hin) + 2 * pad - KH + 1, Wout = (upsample ? 2 * Win : Win) + 2 * pad - KW + 1;
     if (Hout <= 0 || Wout <= 0) return -1;
-    const FpropPlan p = plan_fprop(B, Hout, Wout, Cin, Cout, KH, KW, pad);
-    return p.ksplit > 1 ? (int64_t)p.ksplit * B * Hout * Wout * Cout * (int64_t)sizeof(float) : 0;
+    const FpropPlan p = plan_fprop(B, Hout, Wout, Cin, Cout, KH, KW, pad, !upsample);
+    return p.ksplit > 1 || p.small ? (int64_t)p.ksplit * B * Hout * Wout * Cout * (int64_t)sizeof(float) : 0;
 }
 
 static int conv_fprop_impl(const void* x, const void* wp, const float* bias, const void* residual,
@@ -1675,7 +1791,8 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
     a.M = (long)B * a.Hout * a.Wout;
     const long mtiles = (a.M + 127) / 128;
     hipStream_t st = (hipStream_t)stream;
-    FpropPlan plan = plan_fprop(B, a.Hout, a.Wout, Cin, Cout, KH, KW, pad);
+    FpropPlan plan = plan_fprop(B, a.Hout, a.Wout, Cin, Cout, KH, KW, pad,
+                                !upsample && workspace && !pool_sum && !y_pooled);
     if (!workspace && plan.ksplit > 1) {       // no scratch from the caller: unsplit (the halo-patch kernel if it applies)
         plan.ksplit = 1;
         plan.patch = KH == 3 && KW == 3 && pad == 1 && a.Hout % 16 == 0 && a.Wout % 16 == 0 && !g_force_gather;
@@ -1696,7 +1813,29 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
         plan.ksplit = 1;
     }
     a.ksplit = plan.ksplit;
-    a.partial = plan.ksplit > 1 ? (float*)workspace : nullptr;
+    a.partial = plan.ksplit > 1 || plan.small ? (float*)workspace : nullptr;
+    if (plan.small) {
+        const int S = a.Hout;
+        const int lds = (128 / (S * S)) * (S + 2) * (S + 2) * 128 + 9 * 64 * 128;
+        static bool small_attr_done[2] = {false, false};
+        if (!small_attr_done[S == 8]) {
+            const void* fn = S == 8 ? (const void*)&conv3x3_small_kernel<8> : (const void*)&conv3x3_small_kernel<4>;
+            RGBD_REQUIRE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess,
+                         "rgbd_conv2d_fprop_bf16: cannot reserve %d B of LDS", lds);
+            small_attr_done[S == 8] = true;
+        }
+        const unsigned grid = (unsigned)((a.M / 128) * (Cout / 64) * (Cin / 64));
+        if (S == 8) conv3x3_small_kernel<8><<<grid, 256, lds, st>>>(a);
+        else        conv3x3_small_kernel<4><<<grid, 256, lds, st>>>(a);
+        RGBD_CHECK_LAUNCH("conv3x3_small_kernel");
+        g_last_conv_kernel = S == 8 ? "conv3x3_small_kernel<8>" : "conv3x3_small_kernel<4>";
+        const long quads = a.M * Cout / 4;
+        conv_splitk_finish_kernel<<<(unsigned)((quads + 255) / 256 < 2048 ? (quads + 255) / 256 : 2048), 256, 0, st>>>(
+            a.partial, a.ksplit, a.M, Cout, bias, (const unsigned short*)residual, lrelu_channels, slope,
+            (unsigned short*)y);
+        RGBD_CHECK_LAUNCH("conv_splitk_finish_kernel");
+        return 0;
+    }
     if (plan.patch) {
         const long ptiles = (long)B * (a.Hout / 16) * (a.Wout / 16);
         RGBD_REQUIRE(ptiles < 0x7fffffffL, "rgbd_conv2d_fprop_bf16: too many tiles");

@@ -508,6 +508,46 @@ def test_patch_kernel_agrees_with_gather_kernel(B, H, Cin, Cout, ups):
     torch.testing.assert_close(y_patch.float(), y_gather.float(), atol=2e-2, rtol=8e-3)
 
 
+@pytest.mark.parametrize("B,H,Cin,Cout,res", [(32, 8, 256, 256, False), (32, 4, 256, 256, True), (2, 8, 64, 128, True),
+                                             (8, 4, 128, 64, False), (32, 8, 256, 512, False)])
+def test_small_image_kernel_matches_gather_kernel_and_fp32_conv(B, H, Cin, Cout, res):
+    """conv3x3_small_kernel (4x4 / 8x8 images: whole images + nine weight tiles staged at once, one 64-channel input slice
+    per workgroup, fp32 partials per slice) against the generic gather kernel on the same operands, against an fp32
+    convolution of the same bf16 operands, and against itself over repeated launches; dgrad goes through the same kernel."""
+    from rgbd_gan_amd import _lib, kernels
+    g = torch.Generator().manual_seed(B + H + Cin + Cout)
+    x = torch.randn(B, H, H, Cin, generator=g).to(dev()).to(torch.bfloat16)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g).to(dev())
+    bias = torch.randn(Cout, generator=g).to(dev())
+    r = torch.randn(B, H, H, Cout, generator=g).to(dev()).to(torch.bfloat16) if res else None
+    scale = float(np.sqrt(2.0 / (Cin * 9)))
+    wf, wd = kernels.pack_weights(w, scale)
+    lib = _lib.load()
+    y = kernels.conv2d_fprop(x, wf, 3, 3, 1, bias=bias, residual=r, lrelu_channels=Cout)
+    assert lib.rgbd_last_conv_kernel().decode() == f"conv3x3_small_kernel<{H}>"
+    for _ in range(5):
+        assert torch.equal(kernels.conv2d_fprop(x, wf, 3, 3, 1, bias=bias, residual=r, lrelu_channels=Cout), y)
+    lib.rgbd_debug_force_gather_kernel(1)
+    try:
+        y_gather = kernels.conv2d_fprop(x, wf, 3, 3, 1, bias=bias, residual=r, lrelu_channels=Cout)
+        assert lib.rgbd_last_conv_kernel().decode().startswith("conv_fprop_kernel")
+    finally:
+        lib.rgbd_debug_force_gather_kernel(0)
+    torch.testing.assert_close(y.float(), y_gather.float(), atol=2e-2, rtol=8e-3)
+    wb = (w * scale).to(torch.bfloat16).float()
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), wb, bias, padding=1)
+    if res:
+        ref = ref + r.float().permute(0, 3, 1, 2)
+    ref = F.leaky_relu(ref, 0.2).permute(0, 2, 3, 1)
+    torch.testing.assert_close(y.float(), ref, atol=2e-2, rtol=8e-3)
+    # dgrad = the same kernel on the flipped / transposed image
+    dy = torch.randn(B, H, H, Cout, generator=g).to(dev()).to(torch.bfloat16)
+    dx = kernels.conv2d_dgrad(dy, wd, 3, 1)
+    assert lib.rgbd_last_conv_kernel().decode() == f"conv3x3_small_kernel<{H}>"
+    ref_dx = F.conv_transpose2d(dy.float().permute(0, 3, 1, 2), wb, padding=1).permute(0, 2, 3, 1)
+    torch.testing.assert_close(dx.float(), ref_dx, atol=2e-2 * float(ref_dx.abs().max()) / 4, rtol=1e-2)
+
+
 CONV_VARIANT_CASES = [  # (B, Hout, Cin, Cout, upsample, residual, pooled output)
     (32, 64, 128, 128, False, False, False),     # two pixel tiles per persistent workgroup, two channel slices each
     (32, 64, 256, 256, False, True, True),       # four tiles per workgroup, residual + fused 2x2 average
