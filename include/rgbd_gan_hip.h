@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RGBD_ABI_VERSION 9
+#define RGBD_ABI_VERSION 10
 
 int rgbd_abi_version(void);
 const char* rgbd_last_error(void);
@@ -73,6 +73,18 @@ int rgbd_warp_loss_bwd(const float* img, const float* img_rot, const float* coef
                        float hinge_lambda, float hinge_min,
                        const float* grad_loss, float grad_scale, float* grad_img, float* grad_img_rot, int accumulate,
                        void* workspace, void* stream);
+
+/* The same loss for ANY channel count C >= 2 (the last channel is the depth) and either criterion: norm_l2 == 0
+ * F.mean_absolute_error, != 0 F.mean_squared_error (loss_functions.py:137-145; `LossFuncRotate(norm="l2")` on the
+ * 257-channel feature maps of updater.py:345-354).  img, img_rot, grad_*: (b,C,S,S) fp32; partials as above; no depth hinge,
+ * no debug outputs.  The backward scatters with fp32 atomics (not bit-reproducible); accumulate as above. */
+int rgbd_warp_loss_nc_fwd(const float* img, const float* img_rot, const float* coef, int b, int C, int S, int flags,
+                          int norm_l2, float lambda_geometric, float max_depth, float min_depth,
+                          float* partials, float* loss, void* stream);
+int rgbd_warp_loss_nc_bwd(const float* img, const float* img_rot, const float* coef, int b, int C, int S, int flags,
+                          int norm_l2, float lambda_geometric, float max_depth, float min_depth,
+                          const float* grad_loss, float grad_scale, float* grad_img, float* grad_img_rot, int accumulate,
+                          void* stream);
 
 /* ------------------------------------------------------------------ equalized-LR convolution engine
  * Replaces pggan.py:13-24 (EqualizedConv2d -> L.Convolution2D = cuDNN fprop/dgrad/wgrad) for the

@@ -203,7 +203,7 @@ def _bilinear_torch(img, zp):
 
 
 def loss_torch(img, cam, img_rot, cam_rot, occlusion_aware=False, lambda_geometric=3.0, K=None,
-               max_depth=None, min_depth=None):
+               max_depth=None, min_depth=None, norm="l1"):
     """Differentiable restatement of LossFuncRotate.__call__ (loss_functions.py:63-146).
 
     img, img_rot: torch (b,4,S,S), may require grad; cam, cam_rot: numpy (b,4,4).
@@ -237,7 +237,9 @@ def loss_torch(img, cam, img_rot, cam_rot, occlusion_aware=False, lambda_geometr
         ldr = (z_rot.detach().transpose(1, 2).reshape(-1, 1) > min_depth).to(img.dtype)
         warped, tgt, warped_rot, tgt_rot = warped * ld, tgt * ld, warped_rot * ldr, tgt_rot * ldr
 
-    def mae(a, bb):
+    def mae(a, bb):          # loss_functions.py:137-140: F.mean_absolute_error for norm == "l1", else F.mean_squared_error
+        if norm != "l1":
+            return ((a - bb) ** 2).sum() / a.numel()
         return (a - bb).abs().sum() / a.numel()
 
     loss = mae(warped[:, :-1], tgt[:, :-1]) + mae(warped_rot[:, :-1], tgt_rot[:, :-1])

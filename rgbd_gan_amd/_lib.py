@@ -10,7 +10,7 @@ from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p, POINTER
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RGBD_LIB_PATH: A/B timing of another build of the same ABI; the default is the in-tree library
 LIB_PATH = os.environ.get("RGBD_LIB_PATH") or os.path.join(_HERE, "librgbdgan_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _P = c_void_p
 
@@ -23,6 +23,9 @@ PROTOTYPES = {
     "rgbd_warp_loss_bwd_workspace": ([c_int, c_int], c_int64),
     "rgbd_warp_loss_bwd": ([_P, _P, _P, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, _P, c_float, _P,
                             _P, c_int, _P, _P], c_int),
+    "rgbd_warp_loss_nc_fwd": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P], c_int),
+    "rgbd_warp_loss_nc_bwd": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, _P, c_float, _P, _P,
+                               c_int, _P], c_int),
     "rgbd_pack_weights": ([_P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P], c_int),
     "rgbd_pack_weights_multi": ([_P, c_int, c_int, _P], c_int),
     "rgbd_conv2d_fprop_workspace": ([c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int], c_int64),

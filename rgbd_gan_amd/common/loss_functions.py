@@ -103,13 +103,29 @@ class LossFuncRotate:
                             0.0 if max_depth is None else float(max_depth),
                             0.0 if min_depth is None else float(min_depth))[0]
 
+    @staticmethod
+    def _projected_points(img, img_rot, coef):
+        """(2b, hw, 3): [new_zp, new_zp_rot] (loss_functions.py:94-95,146) from the depth channels and the warp constants
+        -- the second return value for inputs the 4-channel kernels do not take; same association as the kernels
+        ((A0 zp0 + A1 zp1) + A2 zp2) -/+ c, torch ops (not differentiable here: detached)."""
+        with torch.no_grad():
+            b, _, S, _ = img.shape
+            jj = torch.arange(S, device=img.device, dtype=torch.float32).repeat(S)
+            ii = torch.arange(S, device=img.device, dtype=torch.float32).repeat_interleave(S)
+            out = []
+            for x, off, sign in ((img, 0, -1.0), (img_rot, 12, 1.0)):
+                z = x[:, -1].reshape(b, -1)
+                a0, a1, a2 = z * jj, z * ii, z * 1.0
+                cf = coef[:, off:off + 12]
+                rows = []
+                for k in range(3):
+                    v = (cf[:, 3 * k:3 * k + 1] * a0 + cf[:, 3 * k + 1:3 * k + 2] * a1) + cf[:, 3 * k + 2:3 * k + 3] * a2
+                    rows.append(v + sign * cf[:, 9 + k:10 + k])
+                out.append(torch.stack(rows, dim=2))
+            return torch.cat(out, dim=0)
+
     def __call__(self, img, theta, img_rot, theta_rot, occlusion_aware=False, debug=False, max_depth=None,
                  min_depth=None):
-        if self.norm != "l1":
-            raise NotImplementedError("only norm='l1' runs on the HIP path (the l2 variant is used only by the "
-                                      "rotate_feature option, unset in every shipped config)")
-        if img.shape[1] != 4:
-            raise NotImplementedError("the HIP warp loss takes RGB-D images (4 channels)")
         if self.size != img.shape[-1]:
             self.init_params(self.xp, size=img.shape[-1])
         coef = torch.from_numpy(self.coefficients(theta, theta_rot)).to(img.device)
@@ -117,6 +133,14 @@ class LossFuncRotate:
                 (WARP_MIN_DEPTH if min_depth is not None else 0)
         mx = 0.0 if max_depth is None else float(max_depth)
         mn = 0.0 if min_depth is None else float(min_depth)
+        if self.norm != "l1" or img.shape[1] != 4:
+            # loss_functions.py:137-140 (criteria = F.mean_squared_error unless norm == "l1") and inputs other than RGB-D
+            # (updater.py:345-354 feeds 257-channel features): the generic kernels, fp32 atomic scatter
+            if debug:
+                raise NotImplementedError("debug=True is served by the 4-channel kernels only")
+            loss = Fn.warp_loss_nc(img, img_rot, coef, flags, self.norm != "l1", self.lambda_geometric, mx, mn)
+            zp = self._projected_points(img, img_rot, coef)
+            return loss, zp
         if debug:
             b, _, S, _ = img.shape
             _, zp, warped, idx = kernels.warp_loss_fwd(img.detach().contiguous(), img_rot.detach().contiguous(), coef,

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void warp_loss_fwd_kernel(
 
 // one block: loss = mae_rgb(fwd) + mae_rgb(inv) + lambda * (mae_d(fwd) + mae_d(inv)) [+ hinge_lambda * mean hinge]
 __global__ __launch_bounds__(256) void warp_loss_final_kernel(const float* __restrict__ partials, int nblocks,
-                                                             float inv_n, float lambda_geo, float hinge_lambda,
+                                                             float inv_n, float inv_n_rgb, float lambda_geo, float hinge_lambda,
                                                              float* __restrict__ loss) {
     float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // rgb0, d0, h0, rgb1, d1, h1
     for (int k = threadIdx.x; k < nblocks; k += 256) {
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void warp_loss_final_kernel(const float* __res
         float t[6];
 #pragma unroll
         for (int q = 0; q < 6; ++q) t[q] = (red[q][0] + red[q][1]) + (red[q][2] + red[q][3]);
-        const float rgb = t[0] * (inv_n / 3.f) + t[3] * (inv_n / 3.f);
+        const float rgb = t[0] * inv_n_rgb + t[3] * inv_n_rgb;      // inv_n_rgb = inv_n / (C - 1): mean over N x (C - 1) elements
         const float dep = t[1] * inv_n * lambda_geo + t[4] * inv_n * lambda_geo;
         float total = rgb + dep;
         if (hinge_lambda != 0.f) total = total + ((t[2] + t[5]) * (0.5f * inv_n)) * hinge_lambda;
@@ -289,6 +289,131 @@ __global__ __launch_bounds__(256) void warp_loss_bwd_finish_kernel(
     *reinterpret_cast<f32x4*>(g) = v;
 }
 
+// ---- any number of channels (the last one is the depth), L1 or L2 criterion: loss_functions.py:137-145 with norm="l2" and
+//      the 257-channel feature maps of updater.py:345-354.  Same projection / taps / masks as above; a thread loops over the
+//      channels of its pixel.  The backward scatters with fp32 atomics (the L2 seed 2 (warped - target) k is not a constant
+//      per channel, so the fixed-point accumulation of the RGB-D kernels does not apply): not bit-reproducible, and off the
+//      training step of every shipped config.
+__global__ __launch_bounds__(256) void warp_loss_nc_fwd_kernel(
+    const float* __restrict__ img, const float* __restrict__ img_rot, const float* __restrict__ coef,
+    int b, int C, int S, int flags, int l2, float max_depth, float min_depth, float* __restrict__ partials) {
+    const int dir = blockIdx.y;
+    const int hw = S * S;
+    const long n = (long)blockIdx.x * 256 + threadIdx.x;
+    const long N = (long)b * hw;
+    const float* own = dir == 0 ? img : img_rot;
+    const float* src = dir == 0 ? img_rot : img;
+    float l_rgb = 0.f, l_d = 0.f;
+    if (n < N) {
+        const int bi = (int)(n / hw);
+        const int pix = (int)(n - (long)bi * hw);
+        const int i = pix / S, j = pix - i * S;
+        const float* cf = coef + bi * 24 + dir * 12;
+        const float* ob = own + (long)bi * C * hw;
+        const float* sb = src + (long)bi * C * hw;
+        const float z = ob[(long)(C - 1) * hw + pix];
+        const PixelWarp w = project_pixel(cf, dir == 0 ? -1.f : 1.f, z, i, j, S);
+        const int o00 = w.u0m * S + w.v0m, o01 = w.u0m * S + w.v1m;
+        const float mf = w.mask ? 1.f : 0.f;
+        auto sample = [&](int c) {
+            const float a = sb[(long)c * hw + o00], d = sb[(long)c * hw + o01];
+            return ((w.w1 * a + w.w2 * a) + w.w3 * d) + w.w4 * d;
+        };
+        const float wd = sample(C - 1);
+        bool vis = true;
+        if (flags & RGBD_WARP_OCCLUSION) vis = vis && (wd > w.zp2);
+        if (flags & RGBD_WARP_MAX_DEPTH) vis = vis && (z < max_depth);
+        if (flags & RGBD_WARP_MIN_DEPTH) vis = vis && (z > min_depth);
+        const float vf = vis ? 1.f : 0.f;
+        for (int c = 0; c < C - 1; ++c) {
+            const float diff = sample(c) * vf - (ob[(long)c * hw + pix] * mf) * vf;
+            l_rgb += l2 ? diff * diff : fabsf(diff);
+        }
+        const float dd = wd * vf - (w.zp2 * mf) * vf;
+        l_d = l2 ? dd * dd : fabsf(dd);
+    }
+    __shared__ float red[2][4];
+    l_rgb = wave_sum(l_rgb);
+    l_d = wave_sum(l_d);
+    const int wid = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wid] = l_rgb; red[1][wid] = l_d; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float* o = partials + ((long)blockIdx.x * 2 + dir) * 3;
+        o[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        o[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        o[2] = 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void warp_loss_nc_bwd_kernel(
+    const float* __restrict__ img, const float* __restrict__ img_rot, const float* __restrict__ coef,
+    int b, int C, int S, int flags, int l2, float lambda_geo, float max_depth, float min_depth,
+    const float* __restrict__ grad_loss, float grad_scale, float* __restrict__ gimg, float* __restrict__ gimg_rot) {
+    const int dir = blockIdx.y;
+    const int hw = S * S;
+    const long n = (long)blockIdx.x * 256 + threadIdx.x;
+    const long N = (long)b * hw;
+    if (n >= N) return;
+    const float* own = dir == 0 ? img : img_rot;
+    const float* src = dir == 0 ? img_rot : img;
+    float* gown = dir == 0 ? gimg : gimg_rot;
+    float* gsrc = dir == 0 ? gimg_rot : gimg;
+    const int bi = (int)(n / hw);
+    const int pix = (int)(n - (long)bi * hw);
+    const int i = pix / S, j = pix - i * S;
+    const float* cf = coef + bi * 24 + dir * 12;
+    const float* ob = own + (long)bi * C * hw;
+    const float* sb = src + (long)bi * C * hw;
+    float* gob = gown + (long)bi * C * hw;
+    float* gsb = gsrc + (long)bi * C * hw;
+    const float z = ob[(long)(C - 1) * hw + pix];
+    const PixelWarp w = project_pixel(cf, dir == 0 ? -1.f : 1.f, z, i, j, S);
+    if (!w.mask) return;
+    const int o00 = w.u0m * S + w.v0m, o01 = w.u0m * S + w.v1m;
+    const float wl = w.w1 + w.w2, wr = w.w3 + w.w4;
+    const float a3 = sb[(long)(C - 1) * hw + o00], d3 = sb[(long)(C - 1) * hw + o01];
+    const float wd = ((w.w1 * a3 + w.w2 * a3) + w.w3 * d3) + w.w4 * d3;
+    bool vis = true;
+    if (flags & RGBD_WARP_OCCLUSION) vis = vis && (wd > w.zp2);
+    if (flags & RGBD_WARP_MAX_DEPTH) vis = vis && (z < max_depth);
+    if (flags & RGBD_WARP_MIN_DEPTH) vis = vis && (z > min_depth);
+    if (!vis) return;
+    const float go = (grad_loss ? grad_loss[0] : 1.f) * grad_scale;
+    const float k_rgb = go / ((float)N * (float)(C - 1));
+    const float k_d = go * lambda_geo / (float)N;
+    auto seed = [&](float diff, float k) { return l2 ? 2.f * diff * k : (diff > 0.f ? k : (diff < 0.f ? -k : 0.f)); };
+    float gw_a = 0.f, gw_d = 0.f;
+    for (int c = 0; c < C - 1; ++c) {
+        const float a = sb[(long)c * hw + o00], d = sb[(long)c * hw + o01];
+        const float wv = ((w.w1 * a + w.w2 * a) + w.w3 * d) + w.w4 * d;
+        const float g = seed(wv - ob[(long)c * hw + pix], k_rgb);
+        if (g != 0.f) {
+            atomicAdd(gsb + (long)c * hw + o00, g * wl);
+            atomicAdd(gsb + (long)c * hw + o01, g * wr);
+            atomicAdd(gob + (long)c * hw + pix, -g);
+        }
+        gw_a += g * a;
+        gw_d += g * d;
+    }
+    const float g3 = seed(wd - w.zp2, k_d);
+    atomicAdd(gsb + (long)(C - 1) * hw + o00, g3 * wl);
+    atomicAdd(gsb + (long)(C - 1) * hw + o01, g3 * wr);
+    gw_a += g3 * a3;
+    gw_d += g3 * d3;
+    float gzp2 = -g3;
+    const float du1 = w.u1f - w.u, du0 = w.u - w.u0f, dv1 = w.v1f - w.v, dv0 = w.v - w.v0f;
+    const float gu = (gw_a * (-dv1) + gw_a * dv1) + (gw_d * (-dv0) + gw_d * dv0);
+    const float gv = (gw_a * (-du1) + gw_a * (-du0)) + (gw_d * du1 + gw_d * du0);
+    const float gzp1 = gu / w.den, gzp0 = gv / w.den;
+    const float gden = -(gu * w.u + gv * w.v) / w.den;
+    if (w.zp2 >= 1e-4f && w.zp2 <= 10000.f) gzp2 += gden;
+    const float p0 = (float)j, p1 = (float)i;
+    const float gz = gzp0 * (cf[0] * p0 + cf[1] * p1 + cf[2]) + gzp1 * (cf[3] * p0 + cf[4] * p1 + cf[5]) +
+                     gzp2 * (cf[6] * p0 + cf[7] * p1 + cf[8]);
+    atomicAdd(gob + (long)(C - 1) * hw + pix, gz);
+}
+
 }  // namespace
 
 extern "C" int rgbd_warp_loss_fwd(const float* img, const float* img_rot, const float* coef, int b, int S,
@@ -304,7 +429,8 @@ extern "C" int rgbd_warp_loss_fwd(const float* img, const float* img_rot, const 
     warp_loss_fwd_kernel<<<dim3(nblocks, 2), 256, 0, st>>>(img, img_rot, coef, b, S, flags, max_depth, min_depth,
                                                            hinge_min, partials, dbg_zp, dbg_warped, dbg_idx);
     RGBD_CHECK_LAUNCH("warp_loss_fwd_kernel");
-    warp_loss_final_kernel<<<1, 256, 0, st>>>(partials, nblocks, 1.f / (float)N, lambda_geometric, hinge_lambda, loss);
+    warp_loss_final_kernel<<<1, 256, 0, st>>>(partials, nblocks, 1.f / (float)N, (1.f / (float)N) / 3.f, lambda_geometric,
+                                              hinge_lambda, loss);
     RGBD_CHECK_LAUNCH("warp_loss_final_kernel");
     return 0;
 }
@@ -340,5 +466,42 @@ extern "C" int rgbd_warp_loss_bwd(const float* img, const float* img_rot, const 
     warp_loss_bwd_finish_kernel<<<ceil_div(2 * N, 256), 256, 0, st>>>(acc, b, S * S, lambda_geometric, grad_loss,
                                                                       grad_scale, grad_img, grad_img_rot);
     RGBD_CHECK_LAUNCH("warp_loss_bwd_finish_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_warp_loss_nc_fwd(const float* img, const float* img_rot, const float* coef, int b, int C, int S, int flags,
+                                     int norm_l2, float lambda_geometric, float max_depth, float min_depth,
+                                     float* partials, float* loss, void* stream) {
+    RGBD_REQUIRE(img && img_rot && coef && partials && loss, "rgbd_warp_loss_nc_fwd: null pointer");
+    RGBD_REQUIRE(b > 0 && S >= 2 && C >= 2, "rgbd_warp_loss_nc_fwd: bad shape b=%d C=%d S=%d", b, C, S);
+    const long N = (long)b * S * S;
+    const int nblocks = ceil_div(N, 256);
+    hipStream_t st = (hipStream_t)stream;
+    warp_loss_nc_fwd_kernel<<<dim3(nblocks, 2), 256, 0, st>>>(img, img_rot, coef, b, C, S, flags, norm_l2 ? 1 : 0, max_depth,
+                                                              min_depth, partials);
+    RGBD_CHECK_LAUNCH("warp_loss_nc_fwd_kernel");
+    warp_loss_final_kernel<<<1, 256, 0, st>>>(partials, nblocks, 1.f / (float)N, 1.f / ((float)N * (float)(C - 1)),
+                                              lambda_geometric, 0.f, loss);
+    RGBD_CHECK_LAUNCH("warp_loss_final_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_warp_loss_nc_bwd(const float* img, const float* img_rot, const float* coef, int b, int C, int S, int flags,
+                                     int norm_l2, float lambda_geometric, float max_depth, float min_depth,
+                                     const float* grad_loss, float grad_scale, float* grad_img, float* grad_img_rot,
+                                     int accumulate, void* stream) {
+    RGBD_REQUIRE(img && img_rot && coef && grad_img && grad_img_rot, "rgbd_warp_loss_nc_bwd: null pointer");
+    RGBD_REQUIRE(b > 0 && S >= 2 && C >= 2, "rgbd_warp_loss_nc_bwd: bad shape b=%d C=%d S=%d", b, C, S);
+    const long N = (long)b * S * S;
+    hipStream_t st = (hipStream_t)stream;
+    if (!accumulate && (rgbd_zero_async(grad_img, (size_t)N * C * sizeof(float), st) != hipSuccess ||
+                        rgbd_zero_async(grad_img_rot, (size_t)N * C * sizeof(float), st) != hipSuccess)) {
+        rgbd_set_error("rgbd_warp_loss_nc_bwd: clearing the gradients failed");
+        return -2;
+    }
+    warp_loss_nc_bwd_kernel<<<dim3(ceil_div(N, 256), 2), 256, 0, st>>>(img, img_rot, coef, b, C, S, flags, norm_l2 ? 1 : 0,
+                                                                       lambda_geometric, max_depth, min_depth, grad_loss,
+                                                                       grad_scale, grad_img, grad_img_rot);
+    RGBD_CHECK_LAUNCH("warp_loss_nc_bwd_kernel");
     return 0;
 }

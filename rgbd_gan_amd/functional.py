@@ -477,6 +477,30 @@ class _WarpLoss(torch.autograd.Function):
         return gi, gr, None, None, None, None, None, None
 
 
+class _WarpLossNC(torch.autograd.Function):
+    """Any channel count (last = depth), L1 or L2 criterion (kernels.warp_loss_nc_*)."""
+
+    @staticmethod
+    def forward(ctx, img, img_rot, coef, flags, l2, lam, max_depth, min_depth):
+        ctx.cfg = (flags, l2, lam, max_depth, min_depth)
+        ctx.save_for_backward(img, img_rot, coef)
+        return kernels.warp_loss_nc_fwd(img, img_rot, coef, flags, l2, lam, max_depth, min_depth).reshape(())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gl):
+        img, img_rot, coef = ctx.saved_tensors
+        flags, l2, lam, max_depth, min_depth = ctx.cfg
+        gi, gr = kernels.warp_loss_nc_bwd(img, img_rot, coef, flags, l2, lam, max_depth, min_depth,
+                                          gl.reshape(1).float().contiguous())
+        return gi, gr, None, None, None, None, None, None
+
+
+def warp_loss_nc(img, img_rot, coef, flags, norm_l2, lambda_geometric, max_depth=0.0, min_depth=0.0):
+    return _WarpLossNC.apply(img.contiguous(), img_rot.contiguous(), coef, int(flags), bool(norm_l2), float(lambda_geometric),
+                             float(max_depth), float(min_depth))
+
+
 def warp_loss(img, img_rot, coef, flags, lambda_geometric, max_depth=0.0, min_depth=0.0, want_zp=False):
     """-> (loss, zp): the differentiable loss and, with want_zp, the projected points (2,b,S*S,3) of both directions (a
     by-product the reference returns as its second value, loss_functions.py:146; not differentiable here; else empty)."""

@@ -138,6 +138,34 @@ def warp_loss_bwd(img, img_rot, coef, flags, lambda_geometric, max_depth, min_de
     return gimg, gimg_rot
 
 
+def warp_loss_nc_fwd(img, img_rot, coef, flags, norm_l2, lambda_geometric, max_depth=0.0, min_depth=0.0):
+    """The warp loss for any channel count (last channel = depth), L1 or L2 criterion -> loss (1,)."""
+    for t, n in ((img, "img"), (img_rot, "img_rot"), (coef, "coef")):
+        _chk(t, F32, n)
+    b, C, S, _ = img.shape
+    if C < 2 or img_rot.shape != img.shape or coef.shape != (b, 24):
+        raise RuntimeError(f"warp_loss_nc_fwd: bad shapes {tuple(img.shape)} {tuple(img_rot.shape)} {tuple(coef.shape)}")
+    N = b * S * S
+    partials = torch.empty(6 * ((N + 255) // 256), dtype=F32, device=img.device)
+    loss = torch.empty(1, dtype=F32, device=img.device)
+    rc = _lib.load().rgbd_warp_loss_nc_fwd(_ptr(img), _ptr(img_rot), _ptr(coef), b, C, S, int(flags), int(bool(norm_l2)),
+                                           float(lambda_geometric), float(max_depth), float(min_depth), _ptr(partials),
+                                           _ptr(loss), _stream())
+    _lib.check(rc, "rgbd_warp_loss_nc_fwd")
+    return loss
+
+
+def warp_loss_nc_bwd(img, img_rot, coef, flags, norm_l2, lambda_geometric, max_depth, min_depth, grad_loss, grad_scale=1.0):
+    _chk(grad_loss, F32, "grad_loss")
+    b, C, S, _ = img.shape
+    gimg, gimg_rot = torch.empty_like(img), torch.empty_like(img_rot)
+    rc = _lib.load().rgbd_warp_loss_nc_bwd(_ptr(img), _ptr(img_rot), _ptr(coef), b, C, S, int(flags), int(bool(norm_l2)),
+                                           float(lambda_geometric), float(max_depth), float(min_depth), _ptr(grad_loss),
+                                           float(grad_scale), _ptr(gimg), _ptr(gimg_rot), 0, _stream())
+    _lib.check(rc, "rgbd_warp_loss_nc_bwd")
+    return gimg, gimg_rot
+
+
 # ------------------------------------------------------------------ conv engine
 def pack_weights(w, scale, want_fprop=True, want_dgrad=True):
     """w (Cout,Cin,KH,KW) fp32 -> (w_fprop [T][Cout][Cin], w_dgrad [T][Cin][Cout]) bf16 with `scale` folded in."""

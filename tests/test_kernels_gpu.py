@@ -842,6 +842,35 @@ def test_warp_loss_depth_range_masks(max_depth, min_depth, occ):
     assert abs(base - ref["loss"]) > 1e-3
 
 
+@pytest.mark.parametrize("C,norm,occ", [(4, "l2", True), (6, "l2", False), (9, "l1", True), (2, "l1", False)])
+def test_loss_func_rotate_any_channel_count_and_l2(C, norm, occ):
+    """LossFuncRotate(norm="l2") (loss_functions.py:137-140: F.mean_squared_error) and inputs with other channel counts
+    than RGB-D (the last channel is the depth; updater.py:345-354 feeds 257-channel features): value, both gradients and the
+    second return value against the oracle's differentiable restatement."""
+    from rgbd_gan_amd.common.loss_functions import LossFuncRotate
+    b, S = 2, 32
+    img4, img_rot4, cam, cam_rot = _warp_case(b, S, seed=31)
+    rng = np.random.RandomState(C)
+    def widen(x):        # C - 1 feature channels + the depth channel of the 4-channel case
+        feats = rng.uniform(-1, 1, (b, C - 1, S, S)).astype("float32")
+        return np.concatenate([feats, x[:, 3:]], axis=1)
+    img, img_rot = widen(img4), widen(img_rot4)
+    ti = torch.from_numpy(img).requires_grad_(True)
+    tr = torch.from_numpy(img_rot).requires_grad_(True)
+    lt, zp_ref = warp_loss.loss_torch(ti, cam, tr, cam_rot, occlusion_aware=occ, lambda_geometric=3.0, norm=norm)
+    lt.backward()
+    di = torch.from_numpy(img).to(dev()).requires_grad_(True)
+    dr = torch.from_numpy(img_rot).to(dev()).requires_grad_(True)
+    loss, zp = LossFuncRotate(torch, norm=norm, lambda_geometric=3)(di, cam, dr, cam_rot, occlusion_aware=occ)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(lt.detach())) < 1e-4 * max(1.0, abs(float(lt.detach())))
+    scale = float(ti.grad.abs().max())
+    torch.testing.assert_close(di.grad.cpu(), ti.grad, atol=2e-5 * scale, rtol=1e-4)
+    torch.testing.assert_close(dr.grad.cpu(), tr.grad, atol=2e-5 * scale, rtol=1e-4)
+    assert tuple(zp.shape) == (2 * b, S * S, 3)
+    torch.testing.assert_close(zp.cpu(), zp_ref.detach(), atol=1e-4, rtol=1e-5)
+
+
 def test_loss_func_rotate_debug_tuple():
     """debug=True returns (warped, mask, zp, warped_rot, mask_rot, zp_rot) like loss_functions.py:100-102."""
     from rgbd_gan_amd.common.loss_functions import LossFuncRotate
