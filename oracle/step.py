@@ -101,7 +101,11 @@ def rgbd_step(gen_params, dis_params, opt, x_real_full, z, thetas, stage, cfg, i
         x_fake = nets.stylegan_generator(gen_params, z, stage, t9, rgbd=camera)
     else:
         x_fake = nets.dcgan_generator(gen_params, z, stage, t9, rgbd=camera)
-    y_fake = nets.discriminator(dis_params, x_fake[:, :3], stage)
+    rf = bool(cfg.get("rotate_feature")) and use_rotate          # updater.py:345,423
+    if rf:
+        y_fake, feat = nets.discriminator(dis_params, x_fake[:, :3], stage, return_hidden=True)
+    else:
+        y_fake = nets.discriminator(dis_params, x_fake[:, :3], stage)
     loss_adv_g = loss_gen_adv(y_fake)
     loss_gen = loss_adv_g
     out = {"gen/loss_adv": float(loss_adv_g.detach())}
@@ -110,6 +114,8 @@ def rgbd_step(gen_params, dis_params, opt, x_real_full, z, thetas, stage, cfg, i
         loss_rot, _ = warp_loss.loss_torch(x_fake[:B // 2], cams[:B // 2], x_fake[B // 2:], cams[B // 2:],
                                            occlusion_aware=iteration >= cfg["start_occlusion_aware"],
                                            lambda_geometric=lam_geo)
+        if rf:
+            loss_rot = loss_rot + feature_rotation_loss(feat, x_real, cams, iteration >= cfg["start_occlusion_aware"], lam_geo)[0]
         if cfg["lambda_depth"] > 0:
             loss_rot = loss_rot + depth_hinge(x_fake, cfg["depth_min"], cfg["lambda_depth"])
         out["gen/loss_rotate"] = float(loss_rot.detach())
@@ -123,8 +129,11 @@ def rgbd_step(gen_params, dis_params, opt, x_real_full, z, thetas, stage, cfg, i
     out["norm_gen"] = opt["gen"].update()
     opt["dis"].zero_grad()
 
-    v_x_fake = x_fake.detach()[:, :3]
-    y_fake = nets.discriminator(dis_params, v_x_fake, stage)
+    v_x_fake = x_fake.detach()[:, :3].clone().requires_grad_(rf)
+    if rf:
+        y_fake, feat = nets.discriminator(dis_params, v_x_fake, stage, return_hidden=True)
+    else:
+        y_fake = nets.discriminator(dis_params, v_x_fake, stage)
     x_real = x_real.clone().requires_grad_(True)
     y_real = nets.discriminator(dis_params, x_real, stage)
     loss_dis = loss_dis_adv(y_fake, y_real)
@@ -134,12 +143,32 @@ def rgbd_step(gen_params, dis_params, opt, x_real_full, z, thetas, stage, cfg, i
         loss_gp = r1_penalty(y_real, x_real, cfg["lambda_gp"])
         out["dis/loss_gp"] = float(loss_gp.detach())
         loss_dis = loss_dis + loss_gp
+    if rf:                                                 # updater.py:423-437
+        lam_geo = cfg.get("lambda_geometric") or 3
+        loss_rf, f257 = feature_rotation_loss(feat, x_real.detach(), cams, iteration >= cfg["start_occlusion_aware"], lam_geo)
+        loss_dis = loss_dis - loss_rf
+        if cfg["lambda_gp"] > 0 and not sn:
+            g, = torch.autograd.grad([f257], [v_x_fake], [torch.ones_like(f257)], create_graph=True)   # chainer.grad seeds ones
+            loss_dis = loss_dis + cfg["lambda_gp"] * ((torch.sqrt((g ** 2).sum(dim=(1, 2, 3))) - 0.0) ** 2).sum() / g.shape[0]
     out["dis/loss_adv"] = float(loss_dis.detach())
     loss_dis.backward()
     out["norm_dis"] = opt["dis"].update()
     out["x_fake"] = x_fake.detach()
     out["stage"], out["batch_size"], out["image_size"] = stage, B, image_size
     return out
+
+
+def feature_rotation_loss(feat, x_real, cams, occlusion_aware, lambda_geometric):
+    """updater.py:345-353 = 423-431: the warp loss with norm="l2" (updater.py:240) on the discriminator's hidden features of
+    the two views, with the average-pooled LAST CHANNEL OF THE REAL BATCH appended as the "depth" channel (as written:
+    x_real has three colour planes, so this is the pooled blue plane of unrelated real images)."""
+    B = feat.shape[0]
+    rate = x_real.shape[2] // feat.shape[2]
+    depth = F.avg_pool2d(x_real[:, -1:], rate, rate)
+    f = torch.cat([feat, depth], dim=1)
+    loss, _ = warp_loss.loss_torch(f[:B // 2], cams[:B // 2], f[B // 2:], cams[B // 2:], occlusion_aware=occlusion_aware,
+                                   lambda_geometric=lambda_geometric, norm="l2")
+    return loss, f
 
 
 def loss_gen_adv_focal(y_fake, gamma):

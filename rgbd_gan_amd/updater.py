@@ -168,6 +168,7 @@ class RGBDUpdater:
         self._iterators = {"main": kwargs.pop("iterator")}
         lambda_geometric = config.lambda_geometric if config.lambda_geometric else 3
         self.loss_func_rotate = LossFuncRotate(torch, lambda_geometric=lambda_geometric)
+        self.loss_func_rotate_feature = LossFuncRotate(torch, norm="l2", lambda_geometric=lambda_geometric)   # updater.py:240
         self.stage_interval = list(map(int, str(config.stage_interval).split(",")))
         self.camera_param_range = np.array([config.x_rotate, config.y_rotate, config.z_rotate,
                                             config.x_translate, config.y_translate, config.z_translate])
@@ -345,8 +346,6 @@ class RGBDUpdater:
         x_fake, half = st["x_fake"], st["B"] // 2
         gout = kernels.image_grad_init(st["gx"].contiguous(), st["ratio"], x_fake.shape[1])
         if st["use_rotate"]:
-            if cfg.rotate_feature:
-                raise AssertionError("rotate_feature is not supported")
             lf = self.loss_func_rotate
             flags = 1 if st["occlusion"] else 0                      # loss_functions.WARP_OCCLUSION
             hinge = float(cfg.lambda_depth) if cfg.lambda_depth > 0 else 0.0
@@ -548,15 +547,33 @@ class RGBDUpdater:
             self.observation.update(entry["obs"])
         entry["graph"].replay()
 
-    def _sn_step(self, st, opt_g_m, opt_g_g, opt_d, cams):
-        """Spectral-norm discriminator (config `sn: True`, net.py:366-370; updater.py:414 then skips the R1 penalty): the
-        reference's LITERAL step -- D on the fakes in the generator step, D on the same fakes again and on the reals in
-        the discriminator step.  Every forward call of an SN layer runs a power iteration and moves its persistent
-        vector, i.e. changes the function, so the single pass through D(x_fake) that the default step shares between
-        the two losses is not the same computation here.  Plain autograd over the engine's differentiable ops, eager,
-        one stream; gradients reach the master weights through W / sigma."""
+    def _feature_rotation_loss(self, feat, x_real, cams, occlusion):
+        """updater.py:345-353 / 423-431 (`rotate_feature`): the 3-D consistency loss, L2 criterion, on the discriminator's
+        hidden features of the two views (input of block 3: 256 x 32 x 32) with ONE more channel appended as their
+        "depth" -- the reference takes it from the average-pooled last channel of the REAL batch (x_real[:, -1:], i.e. the
+        blue plane of unrelated real images); restated as written."""
+        half = feat.shape[0] // 2
+        rate = x_real.shape[2] // feat.shape[2]
+        depth = F.avg_pool2d(x_real[:, -1:], rate, rate) if rate > 1 else x_real[:, -1:]
+        f = torch.cat([feat, depth], dim=1)
+        loss, _ = self.loss_func_rotate_feature(f[:half], cams[:half], f[half:], cams[half:], occlusion)
+        return loss, f
+
+    def _literal_step(self, st, opt_g_m, opt_g_g, opt_d, cams):
+        """The reference's LITERAL step (updater.py:274-448) over the engine's differentiable ops -- D on the fakes in the
+        generator step, D on the same fakes again and on the reals in the discriminator step, R1 through autograd's
+        double backward -- for the options the single-pass dataflow of the default step does not cover:
+          * a spectral-norm discriminator (`sn: True`): every forward call of an SN layer runs a power iteration and moves
+            its persistent vector, i.e. changes the function, so D(x_fake) evaluated once is not what the reference
+            computes; no R1 penalty then (updater.py:414);
+          * `rotate_feature` (updater.py:345-354,423-437): the feature-consistency term enters the generator's and (negated)
+            the discriminator's loss at D's hidden layer, with a second gradient penalty on the features -- two
+            differently seeded backward passes through D's first blocks.
+        Eager, one stream; both options are off in every shipped config."""
         cfg, obs = self.config, self.observation
-        stage, B, half = st["stage"], st["B"], st["B"] // 2
+        stage, half = st["stage"], st["B"] // 2
+        rf = bool(cfg.rotate_feature) and st["use_rotate"]
+        r1 = not self.dis.sn and self.lambda_gp > 0
         self._prep_phase(st)
         x_real = st["x_real"]
         z = st["z"]
@@ -564,28 +581,53 @@ class RGBDUpdater:
             z_half = self.get_z_fake_data(half)
             z = torch.cat([z_half, z_half], dim=0)
         x_fake = self.gen(z, stage, st["theta9"])
-        y_fake = self.dis(x_fake[:, :3].contiguous(), stage=stage)
+        if rf:
+            y_fake, feat = self.dis(x_fake[:, :3].contiguous(), stage=stage, return_hidden=True)
+            if feat is None:
+                raise AssertionError("rotate_feature needs the hidden features of block 3: stage >= 6")
+        else:
+            y_fake = self.dis(x_fake[:, :3].contiguous(), stage=stage)
         loss_gen = loss_func_dcgan_gen(y_fake)
         obs["gen/loss_adv"] = loss_gen.detach()
         if st["use_rotate"]:
             loss_rotate, _ = self.loss_func_rotate(x_fake[:half], cams[:half], x_fake[half:], cams[half:], st["occlusion"])
+            if rf:
+                loss_rotate = loss_rotate + self._feature_rotation_loss(feat, x_real, cams, st["occlusion"])[0]
             if cfg.lambda_depth > 0:
                 loss_rotate = loss_rotate + torch.mean(F.relu(cfg.depth_min - x_fake[:, -1]) ** 2) * cfg.lambda_depth
             obs["gen/loss_rotate"] = loss_rotate.detach()
             lambda_rotate = cfg.lambda_rotate if cfg.lambda_rotate else 2
             lambda_rotate = lambda_rotate if x_real.shape[2] <= 128 else lambda_rotate * 2
             loss_gen = loss_gen + loss_rotate * lambda_rotate
-        with Fn.weight_grads_frozen(self.dis):          # the reference clears D's gradients right after (updater.py:395)
-            loss_gen.backward()
+        loss_gen.backward()
         for opt in (opt_g_m, opt_g_g):
             if opt is not None:
                 opt.update()
         self.dis.cleargrads()                           # updater.py:395
         if self.smoothed_gen is not None:
             soft_copy_param(self.smoothed_gen, self.gen, 1.0 - self.smoothing)
-        y_fake = self.dis(x_fake.detach()[:, :3].contiguous(), stage=stage)
-        y_real = self.dis(x_real, stage=stage)
+
+        v_x_fake = x_fake.detach()[:, :3].contiguous().requires_grad_(rf and r1)
+        if rf:
+            y_fake, feat = self.dis(v_x_fake, stage=stage, return_hidden=True)
+        else:
+            y_fake = self.dis(v_x_fake, stage=stage)
+        x_real_v = x_real.detach().requires_grad_(r1)
+        y_real = self.dis(x_real_v, stage=stage)
         loss_dis = loss_func_dcgan_dis(y_fake, y_real)
+        if r1:
+            with Fn.input_grads_only():
+                grad_x, = torch.autograd.grad([y_real], [x_real_v], [torch.ones_like(y_real)], create_graph=True)
+            loss_gp = self.lambda_gp * torch.mean(torch.sum(grad_x ** 2, dim=(1, 2, 3)))   # loss_l2(sqrt(sum g^2), 0)
+            obs["dis/loss_gp"] = loss_gp.detach()
+            loss_dis = loss_dis + loss_gp
+        if rf:
+            loss_rf, f257 = self._feature_rotation_loss(feat, x_real, cams, st["occlusion"])
+            loss_dis = loss_dis - loss_rf
+            if r1:
+                with Fn.input_grads_only():
+                    grad_f, = torch.autograd.grad([f257], [v_x_fake], [torch.ones_like(f257)], create_graph=True)
+                loss_dis = loss_dis + self.lambda_gp * torch.mean(torch.sum(grad_f ** 2, dim=(1, 2, 3)))
         obs["dis/loss_adv"] = loss_dis.detach()
         loss_dis.backward()
         opt_d.update()
@@ -650,8 +692,8 @@ class RGBDUpdater:
             self._stagers[zkey].copy_(z_in)
             st["z"] = self._stagers[zkey]
 
-        if getattr(self.dis, "sn", False):
-            self._sn_step(st, opt_g_m, opt_g_g, opt_d, random_camera_matrices if self.camera_conditioned else None)
+        if getattr(self.dis, "sn", False) or (self.camera_conditioned and cfg.rotate_feature):
+            self._literal_step(st, opt_g_m, opt_g_g, opt_d, random_camera_matrices if self.camera_conditioned else None)
             obs = self.observation
             obs["stage"], obs["batch_size"], obs["image_size"] = stage, batch_size, int(st["x_real"].shape[2])
             return

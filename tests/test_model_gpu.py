@@ -486,3 +486,58 @@ def test_sn_training_step_matches_oracle():
     # the discriminator step differentiates two calls after both have run -- showed up here as 0.83 on the early layers)
     assert min(r[1] for r in rows) > 0.995, min(rows, key=lambda r: r[1])
     assert max(abs(r[2] - 1) for r in rows) < 3e-2, max(rows, key=lambda r: abs(r[2] - 1))
+
+
+def test_rotate_feature_training_step_matches_oracle():
+    """`rotate_feature` (updater.py:345-354,423-437; unset in every shipped config): the L2 warp loss on the discriminator's
+    hidden features (257 channels with the pooled last plane of the real batch as "depth") in the generator's loss, its
+    negative plus a second gradient penalty (double backward through D's first blocks) in the discriminator's.  RGBDUpdater
+    runs the reference's literal step for it; one step at stage 8 (64x64, features 32x32), B=4, against the oracle."""
+    from rgbd_gan_amd.optimizer import FlatAdam
+    from rgbd_gan_amd.updater import CameraParamPrior, RGBDUpdater
+    from rgbd_gan_amd.utils.yaml_utils import Config
+    gp, dp, gen, dis = _models(seed=6)
+    torch.manual_seed(0)
+    for i in range(6):
+        gp[f"gen/outs/{i}/c/W"][-1] = torch.randn(gp[f"gen/outs/{i}/c/W"][-1].shape) * 0.1
+    gen.load_state_dict(gp)
+    z, thetas, x_real = _inputs(4, seed=8)
+    stage, iteration = 8.0, 200000
+    gpl = {k: v.clone().requires_grad_(True) for k, v in gp.items()}
+    dpl = {k: v.clone().requires_grad_(True) for k, v in dp.items()}
+    omap = {k: v for k, v in gpl.items() if k.startswith("mapping/")}
+    ogen = {k: v for k, v in gpl.items() if k.startswith("gen/")}
+    low = {k: 1e-5 for k in ("gen/l1/c/W", "gen/l1/c/b", "gen/l2/c/W", "gen/l2/c/b")}
+    oopt = {"map": step.ChainerAdam(omap, 1e-5), "gen": step.ChainerAdam(ogen, 1e-3, alpha_override=low),
+            "dis": step.ChainerAdam(dpl, 3e-3)}
+    ref = step.rgbd_step(gpl, dpl, oopt, x_real, z, thetas, stage, dict(CFG, rotate_feature=True), iteration)
+    cfg = Config(dict(generator_architecture="stylegan", stage_interval="0,0,0,0,0,0,0,100000,150000,160000,180000,300000",
+                      max_stage=11, start_rotation=2000, start_occlusion_aware=2000, lambda_depth=10, depth_min=1.0,
+                      x_rotate=0.3054, y_rotate=1.0472, z_rotate=0, x_translate=0, y_translate=0, z_translate=0,
+                      bigan=False, rotate_feature=True))
+    opt = {"map": FlatAdam(gen.mapping.store, 1e-5), "gen": FlatAdam(gen.gen.store, 1e-3), "dis": FlatAdam(dis.store, 3e-3)}
+    for n in ("l1/c/W", "l1/c/b", "l2/c/W", "l2/c/b"):
+        opt["gen"].set_alpha(n, 1e-5)
+    upd = RGBDUpdater(models=[gen, dis], config=cfg, optimizer=opt, iterator=None, lambda_gp=1.0, smoothing=0.999,
+                      total_gpu=1, prior=CameraParamPrior(cfg), fixed_stage=stage)
+    upd.iteration = iteration
+    upd.update_core(batch=torch.from_numpy(x_real), z_fake_data=torch.from_numpy(z), thetas=thetas)
+    obs = {k: float(v) for k, v in upd.observation.items()}
+    if os.environ.get("RGBD_TEST_VERBOSE"):
+        print(obs, {k: v for k, v in ref.items() if k != "x_fake"})
+    for key in ("gen/loss_adv", "gen/loss_rotate", "dis/loss_gp", "dis/loss_adv"):
+        assert abs(obs[key] - ref[key]) < 6e-2 * max(1.0, abs(ref[key])), (key, obs[key], ref[key])
+    for k, o in (("norm_map", opt["map"]), ("norm_gen", opt["gen"]), ("norm_dis", opt["dis"])):
+        assert abs(float(o.grad_norm) - ref[k]) < 0.1 * ref[k], (k, float(o.grad_norm), ref[k])
+    rows = []
+    for store, prefix, src in ((gen.gen.store, "gen/", gpl), (dis.store, "", dpl)):
+        for n in store.names:
+            b = src[prefix + n].grad
+            if b is None or float(b.norm()) == 0.0 or b.numel() < 4096:
+                continue
+            rows.append((prefix + n, cosine(store[n].grad.cpu(), b)))
+    if os.environ.get("RGBD_TEST_VERBOSE"):
+        print(sorted(rows, key=lambda r: r[1])[:8])
+    assert len(rows) > 40
+    assert min(r[1] for r in rows) > 0.9, min(rows, key=lambda r: r[1])
+    assert np.median([r[1] for r in rows]) > 0.98
