@@ -65,7 +65,9 @@ class FlatAdam:
             self._reduced = True
 
     @torch.no_grad()
-    def update(self):
+    def update(self, bump=True):
+        """bump=False: the caller invalidates the packed-weight caches itself (RGBDUpdater steps D on the side stream while
+        the generator's backward is still reading ITS packed weights on the main stream)."""
         if self._needs_broadcast:                      # ChainerMN: first update() = broadcast, no step
             self.comm.broadcast(self.store.flat)
             self._needs_broadcast = False
@@ -80,7 +82,8 @@ class FlatAdam:
         begins, alphas = self._segments()
         kernels.adam_clip_multi(self.store.flat, self.store.grad, self.m, self.v, begins, alphas, self.beta1,
                                 self.beta2, self.eps, self.clip, grad_scale, self.step, self.workspace, self.grad_norm)
-        functional.bump_weight_epoch()
+        if bump:
+            functional.bump_weight_epoch()
 
     @property
     def t(self):

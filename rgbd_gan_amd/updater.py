@@ -472,7 +472,7 @@ class RGBDUpdater:
             soft_copy_param(self.smoothed_gen, self.gen, 1.0 - self.smoothing)
 
     def _opt_d_phase(self, st):
-        self._optimizers["dis"].update()
+        self._optimizers["dis"].update(bump=not st.get("d_step_on_side"))
 
     timeline = None             # set to a dict: update_core leaves timing events of its last step there (tests, scripts)
 
@@ -741,6 +741,11 @@ class RGBDUpdater:
             if dp:
                 with torch.cuda.stream(side):   # D's gradients are final: 34 MB travel under the generator's backward
                     opt_d.start_allreduce()
+            else:
+                # ... or, on one GPU, D's clip + Adam step itself runs here, under the generator's backward (nothing on the
+                # main stream reads D's weights any more: D(x_fake)'s backward finished in gen_a)
+                st["d_step_on_side"] = True
+                self._run_phase("opt_d", self._opt_d_phase, st, key, stream=side)
             self._run_phase("gen_b", self._gen_b_phase, st, key)                 # 3-D loss, G backward, G's weight gradients
             self._mark("gen_b_end", main)
             if dp:
@@ -767,9 +772,11 @@ class RGBDUpdater:
             self._run_phase("opt_g", self._opt_g_phase, st, key)
             opt_d.finish_allreduce()
             self._run_phase("opt_d", self._opt_d_phase, st, key)
+        elif st.get("d_step_on_side"):
+            self._run_phase("opt_g", self._opt_g_phase, st, key)
         else:
             self._run_phase("opt", self._opt_phase, st, key)
-        if key is not None:
+        if key is not None or st.get("d_step_on_side"):
             Fn.bump_weight_epoch()      # replays change the weights behind Python's back: invalidate packed caches
 
         obs = self.observation

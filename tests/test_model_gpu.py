@@ -372,7 +372,7 @@ def test_graph_replay_matches_eager_steps(schedule):
         hist[use_graphs] = (rows, len(upd._graphs), bool(torch.isfinite(dis.store.flat).all()),
                             bool(torch.isfinite(gen.gen.store.flat).all()))
     (e_rows, e_n, e_fd, e_fg), (g_rows, g_n, g_fd, g_fg) = hist[False], hist[True]
-    assert e_n == 0 and g_n == 7          # prep, dis, gen_a, dfw, gen_b, join and the optimizer phase were captured
+    assert e_n == 0 and g_n == 8          # prep, dis, gen_a, dfw, opt_d, gen_b, join, opt_g were captured
     assert g_fd and g_fg and e_fd and e_fg
     for step, (e, g) in enumerate(zip(e_rows, g_rows)):
         assert e[-1] == g[-1] == step + 1                  # Adam's device-side step counter advanced in the replays

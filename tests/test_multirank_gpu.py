@@ -104,8 +104,8 @@ def test_graph_replay_equals_eager_step(tmp_path):
     _wait([_run(tmp_path / "graphB.npz", "--calls", "4")])                     # ... twice: replays are reproducible
     _wait([_run(tmp_path / "graph1.npz", "--calls", "4", "--sequential")])     # one stream
     e, e2, g, g2, g1 = (np.load(tmp_path / f) for f in ("eager.npz", "eager2.npz", "graph.npz", "graphB.npz", "graph1.npz"))
-    # two streams: prep, dis, gen_a, dfw, gen_b, join, optimizers -- one graph per phase; one stream: body + optimizers
-    assert int(e["n_graphs"]) == 0 and int(e2["n_graphs"]) == 0 and int(g["n_graphs"]) == 7
+    # two streams: prep, dis, gen_a, dfw, opt_d, gen_b, join, opt_g -- one graph per phase; one stream: body + optimizers
+    assert int(e["n_graphs"]) == 0 and int(e2["n_graphs"]) == 0 and int(g["n_graphs"]) == 8
     assert int(g1["n_graphs"]) == 2
     _compare(e2, e, "eager two-stream vs eager sequential", SAME_STEP, exact_upd=2e-2)
     _compare(g, e, "two-stream graph replay vs eager", SAME_STEP, exact_upd=2e-2)
@@ -138,7 +138,7 @@ def test_graph_replay_equals_eager_step_other_stages(tmp_path, stage, batch):
     _wait([_run(tmp_path / "eager.npz", *flags, "--eager", "--sequential")])
     _wait([_run(tmp_path / "graph.npz", *flags)])
     e, g = np.load(tmp_path / "eager.npz"), np.load(tmp_path / "graph.npz")
-    assert int(g["n_graphs"]) == 7
+    assert int(g["n_graphs"]) == 8
     # every stage replays on two streams, fade-in stages included (rounds 1-2 kept those on one stream)
     _compare(g, e, f"graph replay vs eager, stage {stage} batch {batch}", SAME_STEP, exact_upd=2e-2)
     _same_losses(g, e)
