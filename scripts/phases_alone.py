@@ -1,0 +1,32 @@
+"""Each captured phase of the step replayed ALONE (nothing on the other stream), timed with events: the phases' own cost,
+against which the overlapped step (scripts/phase_timeline.py) is read.  RGBD_FORK_GEN_WGRADS=0/1 etc. apply."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from rgbd_gan_amd.training import DeviceImageIterator, build_training
+from rgbd_gan_amd.utils import yaml_utils
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+cfg = yaml_utils.load(os.path.join(root, "configs", "stylegan_shapenet_car.yml"))
+images = np.random.RandomState(0).randint(0, 256, (256, 3, 128, 128)).astype("uint8")
+it = DeviceImageIterator(images, 32, "cuda:0", seed=0)
+gen, dis, opt, upd = build_training(cfg, "cuda:0", iterator=it, nan_check_interval=0)
+upd.iteration = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
+for i in range(8):
+    upd.update()
+torch.cuda.synchronize()
+reps, total = 20, 0.0
+for gkey, entry in upd._graphs.items():
+    g = entry["graph"]
+    for _ in range(3):
+        g.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    total += ms
+    print(f"{gkey[-1]:8s} {ms:7.3f} ms")
+print(f"sum      {total:7.3f} ms")
