@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RGBD_ABI_VERSION 10
+#define RGBD_ABI_VERSION 11
 
 int rgbd_abi_version(void);
 const char* rgbd_last_error(void);
@@ -382,6 +382,14 @@ int rgbd_occlusion_accum_bwd(const float* vol, const float* W1, const float* b1,
  *   sum_pool2 != 0: dx is (B,H/2,W/2,Cin), the 2x2 sums of the input gradient -- the adjoint of the nearest-2x
  *   upsampling in front of the generator's c0 (net.py:148-150, rescale.py:4-5) taken in the conv epilogue; needs
  *   K = 3, pad = 1 and H, W multiples of 16.
+ * rgbd_conv3x3_actgrad_bf16: y = (conv3x3_pad1(x, wp) + residual) * lrelu'(act_y), wp a packed image in the kernel's
+ *   [9][Cout][Cin] order (the fprop image, or the dgrad image with Cin / Cout exchanged), act_y a GIVEN leaky-ReLU output
+ *   of y's shape: the input gradient of a convolution and the activation gradient of the layer in front of it in ONE
+ *   epilogue (net.py:408-416, h = lrelu(c0 x) -> c1: dz0 = dgrad_c1(dz1) * lrelu'(h)), instead of a conv launch and a
+ *   3-tensor elementwise pass.  colsum (NULL or Cout floats, ACCUMULATED with fp32 atomics): the weighted column sums
+ *   sum_b row_scale[b] sum_pixels y -- the bias gradient of that layer (row_scale NULL = 1; per-sample seeds of
+ *   updater.py:405-422 otherwise).  Runs on the pipelined 3x3 kernel: H, W multiples of 16, Cin, Cout multiples of 64
+ *   (rgbd_conv3x3_actgrad_supported tells, as a pure function of the shape).
  * rgbd_pixelnorm_{fwd,bwd}: pggan.py:7-10 (feature_vector_normalization) on (M,C) fp32 rows:
  *   y = x * rsqrt(mean_c x^2 + eps);  dx = r * (dy - y * mean_c(dy * y)).
  * rgbd_depth_head_{fwd,bwd}: net.py:296 on (B,4,HW) fp32 planes: channels 0-2 pass through,
@@ -390,6 +398,10 @@ int rgbd_occlusion_accum_bwd(const float* vol, const float* W1, const float* b1,
  */
 int rgbd_conv2d_dgrad_bf16(const void* dy, const void* wp_dgrad, const void* residual, void* dx, int B, int H, int W,
                            int Cin, int Cout, int K, int pad, int sum_pool2, void* workspace, void* stream);
+int rgbd_conv3x3_actgrad_supported(int B, int H, int W, int Cin, int Cout);
+int rgbd_conv3x3_actgrad_bf16(const void* x, const void* wp, const void* residual, const void* act_y, float slope,
+                              float* colsum, const float* row_scale, void* y, int B, int H, int W, int Cin, int Cout,
+                              void* stream);
 int rgbd_pixelnorm_fwd(const float* x, float* y, int M, int C, float eps, void* stream);
 int rgbd_pixelnorm_bwd(const float* x, const float* dy, float* dx, int M, int C, float eps, void* stream);
 int rgbd_depth_head_fwd(const float* x, float* y, int B, int HW, void* stream);

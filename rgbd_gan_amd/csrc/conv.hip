@@ -43,6 +43,12 @@ struct ConvArgs {
     unsigned short* ypool;          // patch kernel: also write the 2x2 AVERAGE of y to (B,Hout/2,Wout/2,Cout) (or null)
     int ksplit;                     // gather kernel: workgroups per output tile along K (1 = no split)
     float* partial;                 // gather kernel, ksplit > 1: [ksplit][M][Cout] fp32 partial sums
+    // pipelined 3x3 kernel, MASKED variant: the result times lrelu'(.) of a GIVEN activation output of y's shape (the
+    // activation gradient of the layer in front, taken where the input gradient is produced), and its weighted column
+    // sums colsum[co] += sum_b row_scale[b] sum_pixels y (that layer's bias gradient; row_scale null = 1)
+    const unsigned short* mask_y;
+    float* colsum;
+    const float* row_scale;
 };
 
 __device__ __forceinline__ u32x4 ldg16(const unsigned short* p) { return *reinterpret_cast<const u32x4*>(p); }
@@ -735,7 +741,7 @@ __device__ __forceinline__ void lds_dma16(u32x4 rsrc, unsigned voff, unsigned so
         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);       \
     } while (0)
 
-template <int BN, bool UPS, int KO = 0>   // KO: timing knock-outs (wrong results): 1 no weight DMA, 2 no halo DMA, 3 no LDS reads, 4 no MFMAs, 6 MFMAs and barriers only
+template <int BN, bool UPS, int KO = 0, bool MASKED = false>   // KO: timing knock-outs (wrong results): 1 no weight DMA, 2 no halo DMA, 3 no LDS reads, 4 no MFMAs, 6 MFMAs and barriers only
 __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
     constexpr int HPW = UPS ? 10 : 18;            // halo patch width (and height)
     constexpr int NROWS = HPW * HPW;
@@ -902,11 +908,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
     float* const bias_lds = reinterpret_cast<float*>(dsm + 2 * P_BYTES + 3 * W_BYTES);   // [BN]
     if (tid < BN) bias_lds[tid] = a.bias ? a.bias[n0 + tid] : 0.f;
 
-    auto epilogue = [&](int pt) {       // bias -> residual -> leaky ReLU -> bf16 NHWC, then clear the accumulators
+    float cs[MASKED ? 16 : 1];          // MASKED: this lane's share of the weighted column sums, over all of its tiles
+#pragma unroll
+    for (int k2 = 0; k2 < (MASKED ? 16 : 1); ++k2) cs[k2] = 0.f;
+
+    auto epilogue = [&](int pt) {       // bias -> residual -> leaky ReLU (or a given mask) -> bf16 NHWC, then clear the accumulators
         int b, y0, x0;
         tile_origin(pt, b, y0, x0);
         const int co = n0 + wave_co + 16 * q;            // this lane's 16 consecutive output channels
         const bool act = co < a.lrelu_ch;
+        const float cw = MASKED && a.colsum && a.row_scale ? a.row_scale[b] : 1.f;
         if (a.pool_sum) {
             const int Hp = a.Hout >> 1, Wp = a.Wout >> 1;
 #pragma unroll
@@ -965,11 +976,29 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
 #pragma unroll
                 for (int k2 = 0; k2 < 16; ++k2) v[k2] = v[k2] > 0.f ? v[k2] : v[k2] * a.slope;
             }
+            if (MASKED) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const u32x4 mm = *reinterpret_cast<const u32x4*>(a.mask_y + o + 8 * h);
+#pragma unroll
+                    for (int w2 = 0; w2 < 4; ++w2) {
+                        v[8 * h + 2 * w2] = bf16_lo(mm[w2]) > 0.f ? v[8 * h + 2 * w2] : v[8 * h + 2 * w2] * a.slope;
+                        v[8 * h + 2 * w2 + 1] = bf16_hi(mm[w2]) > 0.f ? v[8 * h + 2 * w2 + 1] : v[8 * h + 2 * w2 + 1] * a.slope;
+                    }
+                }
+            }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 u32x4 out = {pack_bf16x2(v[8 * h + 0], v[8 * h + 1]), pack_bf16x2(v[8 * h + 2], v[8 * h + 3]),
                              pack_bf16x2(v[8 * h + 4], v[8 * h + 5]), pack_bf16x2(v[8 * h + 6], v[8 * h + 7])};
                 *reinterpret_cast<u32x4*>(a.y + o + 8 * h) = out;
+                if (MASKED) {           // column sums of what was stored (the rounded values, as the separate pass took them)
+#pragma unroll
+                    for (int w2 = 0; w2 < 4; ++w2) {
+                        cs[8 * h + 2 * w2] += cw * bf16_lo(out[w2]);
+                        cs[8 * h + 2 * w2 + 1] += cw * bf16_hi(out[w2]);
+                    }
+                }
                 if (a.ypool) {          // the block's downscale2x (rescale.py:12-13) of what was just stored
 #pragma unroll
                     for (int w2 = 0; w2 < 4; ++w2) {
@@ -1089,6 +1118,34 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
         pt = pt_next;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // no DMA may land in LDS after the workgroup has gone
+    if (MASKED && a.colsum) {
+        // 16 pixel columns (lanes r16) -> one value per channel per wave; the WAVES_PX waves that share channels meet
+        // through LDS (idle by now: every wave has retired its DMAs, the barrier says so for all of them); then ONE fp32
+        // atomic per channel per workgroup, BN consecutive addresses per instruction (4 lanes x 16 instructions per wave
+        // on the same 64 addresses, all workgroups at once, serialised for 0.8 ms)
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) {
+            float t = cs[k2];
+            t += __shfl_xor(t, 1);
+            t += __shfl_xor(t, 2);
+            t += __shfl_xor(t, 4);
+            t += __shfl_xor(t, 8);
+            cs[k2] = t;
+        }
+        __syncthreads();
+        float* const red = reinterpret_cast<float*>(dsm);              // [WAVES_PX][BN]
+        if (r16 == 0) {
+#pragma unroll
+            for (int k2 = 0; k2 < 16; ++k2) red[(wid % WAVES_PX) * BN + wave_co + 16 * q + k2] = cs[k2];
+        }
+        __syncthreads();
+        if (tid < BN) {
+            float t = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < WAVES_PX; ++w2) t += red[w2 * BN + tid];
+            atomicAdd(a.colsum + n0 + tid, t);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ wgrad
@@ -1767,7 +1824,8 @@ extern "C" int64_t rgbd_conv2d_fprop_workspace(int B, int Hin, int Win, int Cin,
 static int conv_fprop_impl(const void* x, const void* wp, const float* bias, const void* residual,
                            void* y, int B, int Hin, int Win, int Cin, int Cout, int KH, int KW, int pad,
                            int upsample, int lrelu_channels, float slope, void* workspace, void* stream, int pool_sum,
-                           void* y_pooled = nullptr) {
+                           void* y_pooled = nullptr, const void* mask_y = nullptr, float* colsum = nullptr,
+                           const float* row_scale = nullptr) {
     RGBD_REQUIRE(x && wp && y, "rgbd_conv2d_fprop_bf16: null pointer");
     RGBD_REQUIRE(B > 0 && Hin > 0 && Win > 0 && KH > 0 && KW > 0 && pad >= 0, "rgbd_conv2d_fprop_bf16: bad shape");
     RGBD_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0,
@@ -1799,6 +1857,15 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
     }
     a.pool_sum = pool_sum ? 1 : 0;
     a.ypool = (unsigned short*)y_pooled;
+    a.mask_y = (const unsigned short*)mask_y; a.colsum = colsum; a.row_scale = row_scale;
+    if (mask_y) {
+        RGBD_REQUIRE(KH == 3 && KW == 3 && pad == 1 && a.Hout % 16 == 0 && a.Wout % 16 == 0 && !upsample && !pool_sum &&
+                     !y_pooled && !bias && lrelu_channels == 0 && !g_force_gather && g_conv_variant != 1,
+                     "rgbd_conv3x3_actgrad_bf16: needs a plain 3x3 pad-1 conv on images that are multiples of 16x16");
+        plan.patch = true;
+        plan.ksplit = 1;
+        plan.small = false;
+    }
     if (y_pooled) {
         RGBD_REQUIRE(KH == 3 && KW == 3 && pad == 1 && a.Hout % 16 == 0 && a.Wout % 16 == 0 && !pool_sum && !g_force_gather,
                      "rgbd_conv2d_fprop_bf16: y_pooled needs a 3x3 pad-1 conv on images that are multiples of 16x16");
@@ -1877,6 +1944,21 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
                 else if (ko == 4) conv3x3_sp_kernel<128, false, 4><<<(unsigned)grid, 512, lds_sp, st>>>(a);
                 else conv3x3_sp_kernel<128, false, 6><<<(unsigned)grid, 512, lds_sp, st>>>(a);
                 RGBD_CHECK_LAUNCH("conv3x3_sp_kernel<KO>");
+                return 0;
+            }
+            if (mask_y) {
+                const void* fm = wide ? (const void*)&conv3x3_sp_kernel<128, false, 0, true>
+                                      : (const void*)&conv3x3_sp_kernel<64, false, 0, true>;
+                static bool spm_attr_done[2] = {false, false};
+                if (!spm_attr_done[wide]) {
+                    RGBD_REQUIRE(hipFuncSetAttribute(fm, hipFuncAttributeMaxDynamicSharedMemorySize, lds_sp) == hipSuccess,
+                                 "rgbd_conv3x3_actgrad_bf16: cannot reserve %d B of LDS", lds_sp);
+                    spm_attr_done[wide] = true;
+                }
+                if (wide) conv3x3_sp_kernel<128, false, 0, true><<<(unsigned)grid, 512, lds_sp, st>>>(a);
+                else      conv3x3_sp_kernel<64, false, 0, true><<<(unsigned)grid, 512, lds_sp, st>>>(a);
+                RGBD_CHECK_LAUNCH("conv3x3_sp_kernel<masked>");
+                g_last_conv_kernel = wide ? "conv3x3_sp_kernel<128>" : "conv3x3_sp_kernel<64>";
                 return 0;
             }
             if (vi == 3)      conv3x3_sp_kernel<128, true><<<(unsigned)grid, 512, lds_sp, st>>>(a);
@@ -1974,6 +2056,20 @@ extern "C" int rgbd_conv2d_dgrad_bf16(const void* dy, const void* wp_dgrad, cons
     // dx = correlation of dy with the flipped, transposed kernel at padding K-1-pad
     return conv_fprop_impl(dy, wp_dgrad, nullptr, residual, dx, B, H, W, Cout, Cin, K, K, K - 1 - pad, 0, 0, 0.2f,
                            workspace, stream, sum_pool2);
+}
+
+extern "C" int rgbd_conv3x3_actgrad_supported(int B, int H, int W, int Cin, int Cout) {
+    return B > 0 && H > 0 && W > 0 && H % 16 == 0 && W % 16 == 0 && Cin > 0 && Cout > 0 && Cin % 64 == 0 && Cout % 64 == 0 &&
+           (long)B * H * W * (Cin > Cout ? Cin : Cout) < 0x3fffffffL && !g_force_gather && g_conv_variant != 1;
+}
+
+extern "C" int rgbd_conv3x3_actgrad_bf16(const void* x, const void* wp, const void* residual, const void* act_y, float slope,
+                                         float* colsum, const float* row_scale, void* y, int B, int H, int W, int Cin,
+                                         int Cout, void* stream) {
+    RGBD_REQUIRE(act_y, "rgbd_conv3x3_actgrad_bf16: null pointer");
+    RGBD_REQUIRE(colsum || !row_scale, "rgbd_conv3x3_actgrad_bf16: row_scale without colsum");
+    return conv_fprop_impl(x, wp, nullptr, residual, y, B, H, W, Cin, Cout, 3, 3, 1, 0, 0, slope, nullptr, stream, 0, nullptr,
+                           act_y, colsum, row_scale);
 }
 
 extern "C" int64_t rgbd_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int K) {

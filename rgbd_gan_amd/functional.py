@@ -230,16 +230,23 @@ def upsample2(x):
 
 
 class _ConvFprop(torch.autograd.Function):
+    """y = conv(x, W) (+ residual).  mask_y (only inside the R1 double backward, see ResidualTie.fused_mask): the result
+    times lrelu'(.) of that activation output, in the same epilogue."""
+
     @staticmethod
-    def forward(ctx, x, w, layer, ups, residual=None):
-        ctx.layer, ctx.ups = layer, ups
+    def forward(ctx, x, w, layer, ups, residual=None, mask_y=None):
+        ctx.layer, ctx.ups, ctx.masked = layer, ups, mask_y is not None
         ctx.save_for_backward(x, w)
         wf, _ = layer.packed()
-        return kernels.conv2d_fprop(x.contiguous(), wf, layer.K, layer.K, layer.pad, upsample=ups,
-                                    residual=residual.contiguous() if residual is not None else None)
+        residual = residual.contiguous() if residual is not None else None
+        if mask_y is not None:
+            return kernels.conv3x3_actgrad(x.contiguous(), wf, mask_y, residual=residual)
+        return kernels.conv2d_fprop(x.contiguous(), wf, layer.K, layer.K, layer.pad, upsample=ups, residual=residual)
 
     @staticmethod
     def backward(ctx, dy):
+        if ctx.masked:
+            raise NotImplementedError("third-order derivatives through the conv engine are not supported")
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
         dx = _ConvDgrad.apply(dy, w, ctx.layer, ctx.ups) if ctx.needs_input_grad[0] else None
@@ -251,7 +258,7 @@ class _ConvFprop(torch.autograd.Function):
                 _wgrad_derived_deferred(x, dy, w, ctx.layer, ctx.ups)
             else:
                 dw = _ConvWgrad.apply(x, dy, ctx.layer, ctx.ups)
-        return dx, dw, None, None, (dy if ctx.needs_input_grad[4:5] == (True,) else None)
+        return dx, dw, None, None, (dy if ctx.needs_input_grad[4:5] == (True,) else None), None
 
 
 class _ConvDgrad(torch.autograd.Function):
@@ -261,26 +268,48 @@ class _ConvDgrad(torch.autograd.Function):
     conv (ROLE_MAIN) or entry conv (ROLE_ENTRY); see ResidualTie for what the three share."""
 
     @staticmethod
-    def forward(ctx, dy, w, layer, ups, x_fwd=None, bias=None, tie=None, role=0, resid=None):
+    def forward(ctx, dy, w, layer, ups, x_fwd=None, bias=None, tie=None, role=0, resid=None, mask_y=None, mask_bias=None,
+                mask_scale=None):
+        """mask_y: the activation OUTPUT that fed the convolution (its forward input, when that is a leaky ReLU's result):
+        dx comes out times lrelu'(mask_y), i.e. as the gradient of the pre-activation in front, and the (mask_scale-weighted)
+        column sums of that go to mask_bias.grad -- the activation-gradient pass of the layer in front, in this epilogue."""
         ctx.layer, ctx.ups = layer, ups
         ctx.x_fwd, ctx.bias = x_fwd, bias
         ctx.tie, ctx.role = tie, role
+        ctx.mask_y = mask_y
         ctx.save_for_backward(dy, w)
         _, wd = layer.packed()
-        return kernels.conv2d_dgrad(dy.contiguous(), wd, layer.K, layer.pad, sum_pool2=ups,
-                                    residual=resid.contiguous() if resid is not None else None)
+        resid = resid.contiguous() if resid is not None else None
+        if mask_y is not None:
+            return kernels.conv3x3_actgrad(dy.contiguous(), wd, mask_y, residual=resid,
+                                           bias_grad=mask_bias.grad if mask_bias is not None else None, row_scale=mask_scale)
+        return kernels.conv2d_dgrad(dy.contiguous(), wd, layer.K, layer.pad, sum_pool2=ups, residual=resid)
 
     @staticmethod
     def backward(ctx, ddx):
         dy, w = ctx.saved_tensors
         ddx = ddx.contiguous()
         tie, role = ctx.tie, ctx.role
+        if ctx.mask_y is not None:
+            # the node's output was mask * dgrad(dy, W): its adjoint starts with the same mask -- unless the node that
+            # produced ddx (the entry conv's double-backward fprop) has applied it in its epilogue already
+            if tie is not None and tie.dd_premasked:
+                tie.dd_premasked = False
+            else:
+                ddx = _LreluGrad.apply(ddx, ctx.mask_y, ddx.shape[-1])
         g_dy = None
         if ctx.needs_input_grad[0]:
             if tie is not None and role == ROLE_MAIN:
                 # d/d dz1 has two terms, c1(dd h0) here and c_sc(dd x) from the shortcut's node: one launch, the
                 # shortcut's term riding in the epilogue, when that node ran first
                 g_dy = _ConvFprop.apply(ddx, w, ctx.layer, ctx.ups, tie.take("g_sc", "main_seen"))
+            elif tie is not None and role == ROLE_ENTRY and tie.fused_mask is not None and not ctx.ups and \
+                    ctx.layer.K == 3 and ctx.layer.pad == 1 and tuple(tie.fused_mask.shape[:3]) == tuple(ddx.shape[:3]) and \
+                    tie.fused_mask.shape[3] == w.shape[0] and kernels.conv3x3_actgrad_supported(*ddx.shape, w.shape[0]):
+                # this node's dy is the OUTPUT of the main conv's fused (dgrad, activation-gradient) node, whose backward
+                # masks what arrives with lrelu'(h0): applied here, in the epilogue of the conv that produces it
+                g_dy = _ConvFprop.apply(ddx, w, ctx.layer, ctx.ups, None, tie.fused_mask)
+                tie.dd_premasked = True
             else:
                 g_dy = _ConvFprop.apply(ddx, w, ctx.layer, ctx.ups)
                 if tie is not None and role == ROLE_SHORTCUT and tie.give("g_sc", "main_seen", g_dy):
@@ -309,7 +338,8 @@ class _ConvDgrad(torch.autograd.Function):
                 _wgrad_into(operand, dy, w, ctx.layer, ctx.ups)
             else:
                 g_w = _ConvWgrad.apply(operand, dy, ctx.layer, ctx.ups)
-        return g_dy, g_w, None, None, None, None, None, None, (ddx if ctx.needs_input_grad[8:9] == (True,) else None)
+        return (g_dy, g_w, None, None, None, None, None, None, (ddx if ctx.needs_input_grad[8:9] == (True,) else None),
+                None, None, None)
 
 
 class _ConvWgrad(torch.autograd.Function):
@@ -630,6 +660,8 @@ class _ConvBiasAct(torch.autograd.Function):
             y, pooled = y
         ctx.layer, ctx.ups, ctx.act, ctx.pool = layer, ups, act, pool
         ctx.tie, ctx.role = tie, role
+        if tie is not None and role == ROLE_ENTRY and act and not pool:
+            tie.entry_bias, tie.entry_ptr = bias, y.data_ptr()       # see ResidualTie: premasked
         ctx.save_for_backward(x, w, y, bias)
         return pooled if pool else y
 
@@ -667,6 +699,11 @@ class _ConvBiasAct(torch.autograd.Function):
                                             tb if inj_b is not None else None)
                 if tb is not None and inj_b is not None:
                     tie.done = True
+        elif ctx.act and tie is not None and role == ROLE_ENTRY and tie.premasked:
+            # the main conv's backward produced dy in a fused (input gradient, activation gradient) launch: dy IS dz, and
+            # this bias has its column sums (it decided with the same rules as above: fast_b or inj_b or no gradient)
+            tie.premasked = False
+            dz = dy
         elif ctx.act:
             dz = kernels.lrelu_bwd(dy, y, w.shape[0], bias_grad=bias.grad) if fast_b else \
                 _LreluGrad.apply(dy, y.detach(), w.shape[0], inj_b)
@@ -685,6 +722,13 @@ class _ConvBiasAct(torch.autograd.Function):
                 # block input gradient = dgrad_c0(dz0) + dgrad_c_sc(dz1): the shortcut's term (its node ran first) is
                 # added in this conv's epilogue instead of by the autograd engine
                 dx = _ConvDgrad.apply(dz, w, layer, ups, x.detach(), inj_bias, tie, role, tie.take("dx_sc", "entry_seen"))
+            elif tie is not None and role == ROLE_MAIN and _entry_fusable(tie, x, dz, layer, ups):
+                # x is the entry conv's activation output h0 and nothing else reads it: the entry conv's activation
+                # gradient (and bias gradient) ride in this input gradient's epilogue (ResidualTie: premasked)
+                b0, scale0 = _entry_bias_mode(tie.entry_bias)
+                h0 = x.detach()
+                dx = _ConvDgrad.apply(dz, w, layer, ups, h0, inj_bias, tie, role, None, h0, b0, scale0)
+                tie.premasked, tie.fused_mask = True, h0
             else:
                 dx = _ConvDgrad.apply(dz, w, layer, ups, x.detach(), inj_bias, tie, role)
                 if tie is not None and role == ROLE_SHORTCUT and tie.give("dx_sc", "entry_seen", dx):
@@ -704,6 +748,27 @@ class _ConvBiasAct(torch.autograd.Function):
 ROLE_SHORTCUT, ROLE_MAIN, ROLE_ENTRY = 1, 2, 3
 
 
+def _entry_bias_mode(b0):
+    """How the entry conv's backward would take its bias gradient (the rules of _ConvBiasAct.backward, evaluated on its
+    bias): (bias whose .grad receives the column sums or None, per-sample weights or None); False when it would return the
+    gradient through autograd (_ColSum), which a fused launch cannot."""
+    want = b0.requires_grad and not _skip_grad_of(b0)
+    fast = want and _direct_grad(b0)
+    if want and not fast:
+        return False
+    inject = (_INJECT is not None and torch.is_grad_enabled() and b0.requires_grad and b0.is_leaf
+              and b0.grad is not None and b0.data_ptr() not in _FROZEN_PTRS)
+    if fast:
+        return b0, None
+    return (b0, _INJECT) if inject else (None, None)
+
+
+def _entry_fusable(tie, x, dz, layer, ups):
+    return (tie.entry_bias is not None and tie.entry_ptr == x.data_ptr() and not ups and layer.K == 3 and layer.pad == 1
+            and _entry_bias_mode(tie.entry_bias) is not False
+            and kernels.conv3x3_actgrad_supported(dz.shape[0], dz.shape[1], dz.shape[2], dz.shape[3], x.shape[3]))
+
+
 class ResidualTie:
     """What the three convs of a residual block (net.py:408-416: h = lrelu(c0 x); y = lrelu(c1 h + c_sc x)) share in the
     backward passes, so that sums the autograd engine would form with add kernels ride in conv epilogues instead:
@@ -713,7 +778,12 @@ class ResidualTie:
     * dx_sc: the block input gradient dgrad_c0(dz0) + dgrad_c_sc(dz1) -- the shortcut's node (created later in the
       forward, so run earlier by the engine) parks its term here and the entry conv adds it as an epilogue residual;
     * g_sc: in the R1 double backward d/d dz1 = c1(dd h0) + c_sc(dd x), same arrangement one order up;
-    * operand: the injection operand dd x + s_b x is the same tensor for c0 and c_sc, formed once.
+    * operand: the injection operand dd x + s_b x is the same tensor for c0 and c_sc, formed once;
+    * premasked: h0 = lrelu(c0 x) is read by c1 alone, so dz0 = dgrad_c1(dz1) * lrelu'(h0) and c0's bias gradient are
+      taken in the epilogue of c1's input gradient (rgbd_conv3x3_actgrad_bf16; entry_bias / entry_ptr are left by c0's
+      forward) and c0's backward skips its activation-gradient pass; fused_mask / dd_premasked: the same one order up --
+      in the R1 double backward c0's fprop of dd x applies lrelu'(h0) in its epilogue and the fused node's backward
+      skips its own mask.
 
     Every hand-over has a fallback: if the consumer ran first it flags that, and the producer then returns its term to
     autograd the ordinary way (the engine adds)."""
@@ -722,6 +792,8 @@ class ResidualTie:
         self.bias, self.done = bias, False
         self.dx_sc = self.g_sc = self.operand = None
         self.entry_seen = self.main_seen = False
+        self.entry_bias = self.entry_ptr = self.fused_mask = None
+        self.premasked = self.dd_premasked = False
 
     def usable(self, inject):
         """Mirrors the conditions under which _ConvBiasAct.backward takes its own bias sums in the fused pass."""

@@ -273,6 +273,38 @@ def conv2d_dgrad(dy, wd, K, pad, sum_pool2=False, residual=None):
     return dx
 
 
+def conv3x3_actgrad_supported(B, H, W, Cin, Cout):
+    """Shapes the fused (3x3 conv, activation gradient of the layer in front) launch covers: the pipelined kernel's."""
+    return bool(_lib.load().rgbd_conv3x3_actgrad_supported(int(B), int(H), int(W), int(Cin), int(Cout)))
+
+
+def conv3x3_actgrad(x, wp, act_y, residual=None, bias_grad=None, row_scale=None, slope=0.2):
+    """(conv3x3_pad1(x, wp) + residual) * lrelu'(act_y) in one launch; x (B,H,W,Cin) bf16, wp [9][Cout][Cin] bf16 (the fprop
+    image, or the dgrad image of a Cout->Cin convolution), act_y / residual (B,H,W,Cout) bf16.  bias_grad (Cout fp32,
+    accumulated): += sum_b row_scale[b] * column sums of the result (row_scale None = 1)."""
+    _chk(x, BF16, "x"); _chk(wp, BF16, "wp"); _chk(act_y, BF16, "act_y"); _chk(residual, BF16, "residual")
+    _chk(bias_grad, F32, "bias_grad"); _chk(row_scale, F32, "row_scale")
+    B, H, W, Cin = x.shape
+    T, Cout, Cin2 = wp.shape
+    if T != 9 or Cin2 != Cin or tuple(act_y.shape) != (B, H, W, Cout):
+        raise RuntimeError(f"conv3x3_actgrad: x {tuple(x.shape)}, weights {tuple(wp.shape)}, act_y {tuple(act_y.shape)}")
+    if residual is not None and residual.shape != act_y.shape:
+        raise RuntimeError("conv3x3_actgrad: residual shape mismatch")
+    if bias_grad is not None and bias_grad.numel() != Cout or (row_scale is not None and row_scale.numel() != B):
+        raise RuntimeError("conv3x3_actgrad: bias_grad needs Cout entries, row_scale B")
+    y = torch.empty(B, H, W, Cout, dtype=BF16, device=x.device)
+    lib = _lib.load()
+    flops = 2.0 * B * H * W * Cout * Cin * 9
+    nbytes = 2.0 * (x.numel() + 2 * y.numel() + wp.numel() + (residual.numel() if residual is not None else 0))
+    rc = _timed(lambda: _conv_kernel_name(f"actgrad {H}x{W} {Cin}->{Cout}{' res' if residual is not None else ''}"),
+                flops, nbytes,
+                lambda: lib.rgbd_conv3x3_actgrad_bf16(_ptr(x), _ptr(wp), _ptr(residual), _ptr(act_y), float(slope),
+                                                      _ptr(bias_grad), _ptr(row_scale), _ptr(y), B, H, W, Cin, Cout,
+                                                      _stream()))
+    _lib.check(rc, "rgbd_conv3x3_actgrad_bf16")
+    return y
+
+
 def conv2d_wgrad(x, dy, K, scale, out=None, accumulate=False, upsample=False):
     """x (B,H,W,Cin) bf16, dy (B,H,W,Cout) bf16 -> dW (Cout,Cin,K,K) fp32 = scale * sum dy (x) x.
     upsample: x is (B,H/2,W/2,Cin) and stands for its nearest-2x upsampling (read through the index map, not copied)."""

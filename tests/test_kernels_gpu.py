@@ -548,6 +548,51 @@ def test_small_image_kernel_matches_gather_kernel_and_fp32_conv(B, H, Cin, Cout,
     torch.testing.assert_close(dx.float(), ref_dx, atol=2e-2 * float(ref_dx.abs().max()) / 4, rtol=1e-2)
 
 
+@pytest.mark.parametrize("B,S,Cin,Cout,res,weighted", [(4, 32, 128, 128, False, False), (2, 64, 64, 128, True, True),
+                                                      (8, 16, 256, 256, False, True), (3, 32, 128, 64, True, False),
+                                                      (32, 128, 64, 64, False, True)])
+def test_conv3x3_actgrad_matches_conv_then_activation_gradient(B, S, Cin, Cout, res, weighted):
+    """rgbd_conv3x3_actgrad_bf16 (3x3 conv + residual, times lrelu'(.) of a given activation output, weighted column sums:
+    one epilogue) against the two launches it replaces -- the conv, then rgbd_lrelu_bwd with its fused bias gradient --
+    and against fp32 torch on the same bf16 operands; through the dgrad image too (how the discriminator's backward uses it)."""
+    from rgbd_gan_amd import kernels
+    assert kernels.conv3x3_actgrad_supported(B, S, S, Cin, Cout)
+    assert not kernels.conv3x3_actgrad_supported(B, 8, 8, Cin, Cout)
+    g = torch.Generator().manual_seed(B + S + Cin + Cout)
+    x = torch.randn(B, S, S, Cin, generator=g).to(dev()).to(torch.bfloat16)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g).to(dev())
+    act_y = torch.randn(B, S, S, Cout, generator=g).to(dev()).to(torch.bfloat16)
+    r = torch.randn(B, S, S, Cout, generator=g).to(dev()).to(torch.bfloat16) if res else None
+    rs = (torch.rand(B, generator=g) + 0.5).to(dev()) if weighted else None
+    scale = float(np.sqrt(2.0 / (Cin * 9)))
+    wf, wd = kernels.pack_weights(w, scale)
+    two = kernels.conv2d_fprop(x, wf, 3, 3, 1, residual=r)
+    bias_two = torch.zeros(Cout, device=dev())
+    two = kernels.lrelu_bwd(two, act_y, Cout, bias_grad=bias_two, row_scale=rs)
+    bias_one = torch.full((Cout,), 3.0, device=dev())            # accumulated, not overwritten
+    one = kernels.conv3x3_actgrad(x, wf, act_y, residual=r, bias_grad=bias_one, row_scale=rs)
+    # the fused launch rounds once (fp32 -> mask -> bf16), the pair twice: a bf16 ulp on the slope branch
+    torch.testing.assert_close(one.float(), two.float(), atol=1e-2, rtol=8e-3)
+    torch.testing.assert_close(bias_one - 3.0, bias_two, atol=2e-2 * float(bias_two.abs().max()), rtol=1e-2)
+    wb = (w * scale).to(torch.bfloat16).float()
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), wb, None, padding=1).permute(0, 2, 3, 1)
+    if res:
+        ref = ref + r.float()
+    ref = torch.where(act_y.float() > 0, ref, 0.2 * ref)
+    torch.testing.assert_close(one.float(), ref, atol=2e-2, rtol=8e-3)
+    wts = rs if weighted else torch.ones(B, device=dev())
+    ref_b = (one.float() * wts[:, None, None, None]).sum(dim=(0, 1, 2))
+    torch.testing.assert_close(bias_one - 3.0, ref_b, atol=1e-3 * float(ref_b.abs().max()) + 1e-3, rtol=1e-3)
+    assert torch.equal(kernels.conv3x3_actgrad(x, wf, act_y, residual=r), one)       # no column sums: same image
+    # as an input gradient: dy (B,S,S,Cout) through the dgrad image, masked by an activation output of x's shape
+    dy = torch.randn(B, S, S, Cout, generator=g).to(dev()).to(torch.bfloat16)
+    h0 = torch.randn(B, S, S, Cin, generator=g).to(dev()).to(torch.bfloat16)
+    dz = kernels.conv3x3_actgrad(dy, wd, h0)
+    ref_dx = F.conv_transpose2d(dy.float().permute(0, 3, 1, 2), wb, padding=1).permute(0, 2, 3, 1)
+    ref_dz = torch.where(h0.float() > 0, ref_dx, 0.2 * ref_dx)
+    torch.testing.assert_close(dz.float(), ref_dz, atol=2e-2 * float(ref_dx.abs().max()) / 4, rtol=1e-2)
+
+
 CONV_VARIANT_CASES = [  # (B, Hout, Cin, Cout, upsample, residual, pooled output)
     (32, 64, 128, 128, False, False, False),     # two pixel tiles per persistent workgroup, two channel slices each
     (32, 64, 256, 256, False, True, True),       # four tiles per workgroup, residual + fused 2x2 average
