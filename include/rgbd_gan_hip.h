@@ -390,6 +390,12 @@ int rgbd_occlusion_accum_bwd(const float* vol, const float* W1, const float* b1,
  *   sum_b row_scale[b] sum_pixels y -- the bias gradient of that layer (row_scale NULL = 1; per-sample seeds of
  *   updater.py:405-422 otherwise).  Runs on the pipelined 3x3 kernel: H, W multiples of 16, Cin, Cout multiples of 64
  *   (rgbd_conv3x3_actgrad_supported tells, as a pure function of the shape).
+ * rgbd_conv2d_fprop_stats_bf16: the generator's conv -> bias -> leaky ReLU (net.py:148-153,157-160; upsample != 0: nearest
+ *   2x in front, rescale.py:4-5) as rgbd_conv2d_fprop_bf16 computes it, 3x3 pad 1 on output images that are multiples of
+ *   16x16, PLUS the instance-norm statistics of the AdaIN that follows (adain.py:62-63): stats (B,Cout,2) int64, ZEROED
+ *   by the caller, receives (sum y, sum y^2) over each image's pixels of the bf16 values stored, in units of 2^-32, by
+ *   64-bit integer atomics -- order-independent, so the statistics are bit-reproducible.  rgbd_adain_apply_fixed is
+ *   rgbd_adain_fwd without its reduction pass, reading those (same outputs: y, mean, rstd).
  * rgbd_pixelnorm_{fwd,bwd}: pggan.py:7-10 (feature_vector_normalization) on (M,C) fp32 rows:
  *   y = x * rsqrt(mean_c x^2 + eps);  dx = r * (dy - y * mean_c(dy * y)).
  * rgbd_depth_head_{fwd,bwd}: net.py:296 on (B,4,HW) fp32 planes: channels 0-2 pass through,
@@ -402,6 +408,10 @@ int rgbd_conv3x3_actgrad_supported(int B, int H, int W, int Cin, int Cout);
 int rgbd_conv3x3_actgrad_bf16(const void* x, const void* wp, const void* residual, const void* act_y, float slope,
                               float* colsum, const float* row_scale, void* y, int B, int H, int W, int Cin, int Cout,
                               void* stream);
+int rgbd_conv2d_fprop_stats_bf16(const void* x, const void* wp, const float* bias, void* y, int64_t* stats, int B, int Hin,
+                                 int Win, int Cin, int Cout, int upsample, int lrelu_channels, float slope, void* stream);
+int rgbd_adain_apply_fixed(const void* x, const float* scale, const float* shift, void* y, const int64_t* stats, float* mean,
+                           float* rstd, int B, int HW, int C, int ld, float eps, void* stream);
 int rgbd_pixelnorm_fwd(const float* x, float* y, int M, int C, float eps, void* stream);
 int rgbd_pixelnorm_bwd(const float* x, const float* dy, float* dx, int M, int C, float eps, void* stream);
 int rgbd_depth_head_fwd(const float* x, float* y, int B, int HW, void* stream);

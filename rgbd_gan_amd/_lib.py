@@ -87,6 +87,8 @@ PROTOTYPES = {
     "rgbd_conv2d_dgrad_bf16": ([_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P], c_int),
     "rgbd_conv3x3_actgrad_supported": ([c_int, c_int, c_int, c_int, c_int], c_int),
     "rgbd_conv3x3_actgrad_bf16": ([_P, _P, _P, _P, c_float, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P], c_int),
+    "rgbd_conv2d_fprop_stats_bf16": ([_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P], c_int),
+    "rgbd_adain_apply_fixed": ([_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P], c_int),
     "rgbd_pixelnorm_fwd": ([_P, _P, c_int, c_int, c_float, _P], c_int),
     "rgbd_pixelnorm_bwd": ([_P, _P, _P, c_int, c_int, c_float, _P], c_int),
     "rgbd_depth_head_fwd": ([_P, _P, c_int, c_int, _P], c_int),

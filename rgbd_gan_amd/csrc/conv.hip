@@ -49,6 +49,9 @@ struct ConvArgs {
     const unsigned short* mask_y;
     float* colsum;
     const float* row_scale;
+    // pipelined 3x3 kernel, STATS variant: stats[b][co][0..1] += (sum y, sum y^2) over the image's pixels, as 64-bit
+    // integers in units of 2^-32 (integer adds commute: the result does not depend on which workgroup adds first)
+    long long* stats;
 };
 
 __device__ __forceinline__ u32x4 ldg16(const unsigned short* p) { return *reinterpret_cast<const u32x4*>(p); }
@@ -741,8 +744,12 @@ __device__ __forceinline__ void lds_dma16(u32x4 rsrc, unsigned voff, unsigned so
         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);       \
     } while (0)
 
-template <int BN, bool UPS, int KO = 0, bool MASKED = false>   // KO: timing knock-outs (wrong results): 1 no weight DMA, 2 no halo DMA, 3 no LDS reads, 4 no MFMAs, 6 MFMAs and barriers only
+// EPI: 0 plain epilogue, 1 MASKED (activation gradient of the layer in front + its bias gradient, ConvArgs::mask_y),
+//      2 STATS (per-(sample, channel) sum y, sum y^2 of what is stored: the instance-norm statistics of the AdaIN behind
+//        this conv, ConvArgs::stats)
+template <int BN, bool UPS, int KO = 0, int EPI = 0>   // KO: timing knock-outs (wrong results): 1 no weight DMA, 2 no halo DMA, 3 no LDS reads, 4 no MFMAs, 6 MFMAs and barriers only
 __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
+    constexpr bool MASKED = EPI == 1, STATS = EPI == 2;
     constexpr int HPW = UPS ? 10 : 18;            // halo patch width (and height)
     constexpr int NROWS = HPW * HPW;
     constexpr int P_PIECES = (NROWS * 128 + 1023) / 1024;   // 1-KiB DMA pieces per halo patch (41 or 13)
@@ -911,6 +918,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
     float cs[MASKED ? 16 : 1];          // MASKED: this lane's share of the weighted column sums, over all of its tiles
 #pragma unroll
     for (int k2 = 0; k2 < (MASKED ? 16 : 1); ++k2) cs[k2] = 0.f;
+    // STATS: this lane's share of (sum y, sum y^2) of its 16 channels over the tiles of image st_b walked so far; a
+    // workgroup's tiles are consecutive, so it flushes once per image it touches (and at the end)
+    float st1[STATS ? 16 : 1], st2[STATS ? 16 : 1];
+    int st_b = -1;
+#pragma unroll
+    for (int k2 = 0; k2 < (STATS ? 16 : 1); ++k2) { st1[k2] = 0.f; st2[k2] = 0.f; }
+    auto stats_flush = [&]() {          // 16 pixel columns -> per-wave totals; lane r16 then owns channel co + r16
+        float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) {
+            float t1 = st1[k2], t2 = st2[k2];
+            t1 += __shfl_xor(t1, 1); t2 += __shfl_xor(t2, 1);
+            t1 += __shfl_xor(t1, 2); t2 += __shfl_xor(t2, 2);
+            t1 += __shfl_xor(t1, 4); t2 += __shfl_xor(t2, 4);
+            t1 += __shfl_xor(t1, 8); t2 += __shfl_xor(t2, 8);
+            v1 = r16 == k2 ? t1 : v1;
+            v2 = r16 == k2 ? t2 : v2;
+            st1[k2] = 0.f; st2[k2] = 0.f;
+        }
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.stats) +
+                                  ((long)st_b * a.Cout + n0 + wave_co + 16 * q + r16) * 2;
+        atomicAdd(dst, (unsigned long long)__double2ll_rn((double)v1 * 4294967296.0));
+        atomicAdd(dst + 1, (unsigned long long)__double2ll_rn((double)v2 * 4294967296.0));
+    };
 
     auto epilogue = [&](int pt) {       // bias -> residual -> leaky ReLU (or a given mask) -> bf16 NHWC, then clear the accumulators
         int b, y0, x0;
@@ -918,6 +949,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
         const int co = n0 + wave_co + 16 * q;            // this lane's 16 consecutive output channels
         const bool act = co < a.lrelu_ch;
         const float cw = MASKED && a.colsum && a.row_scale ? a.row_scale[b] : 1.f;
+        if (STATS && b != st_b) {
+            if (st_b >= 0) stats_flush();
+            st_b = b;
+        }
         if (a.pool_sum) {
             const int Hp = a.Hout >> 1, Wp = a.Wout >> 1;
 #pragma unroll
@@ -997,6 +1032,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
                     for (int w2 = 0; w2 < 4; ++w2) {
                         cs[8 * h + 2 * w2] += cw * bf16_lo(out[w2]);
                         cs[8 * h + 2 * w2 + 1] += cw * bf16_hi(out[w2]);
+                    }
+                }
+                if (STATS) {
+#pragma unroll
+                    for (int w2 = 0; w2 < 4; ++w2) {
+                        const float lo = bf16_lo(out[w2]), hi = bf16_hi(out[w2]);
+                        st1[8 * h + 2 * w2] += lo;
+                        st2[8 * h + 2 * w2] += lo * lo;
+                        st1[8 * h + 2 * w2 + 1] += hi;
+                        st2[8 * h + 2 * w2 + 1] += hi * hi;
                     }
                 }
                 if (a.ypool) {          // the block's downscale2x (rescale.py:12-13) of what was just stored
@@ -1118,6 +1163,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
         pt = pt_next;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // no DMA may land in LDS after the workgroup has gone
+    if (STATS && st_b >= 0) stats_flush();
     if (MASKED && a.colsum) {
         // 16 pixel columns (lanes r16) -> one value per channel per wave; the WAVES_PX waves that share channels meet
         // through LDS (idle by now: every wave has retired its DMAs, the barrier says so for all of them); then ONE fp32
@@ -1825,7 +1871,7 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
                            void* y, int B, int Hin, int Win, int Cin, int Cout, int KH, int KW, int pad,
                            int upsample, int lrelu_channels, float slope, void* workspace, void* stream, int pool_sum,
                            void* y_pooled = nullptr, const void* mask_y = nullptr, float* colsum = nullptr,
-                           const float* row_scale = nullptr) {
+                           const float* row_scale = nullptr, long long* stats = nullptr) {
     RGBD_REQUIRE(x && wp && y, "rgbd_conv2d_fprop_bf16: null pointer");
     RGBD_REQUIRE(B > 0 && Hin > 0 && Win > 0 && KH > 0 && KW > 0 && pad >= 0, "rgbd_conv2d_fprop_bf16: bad shape");
     RGBD_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0,
@@ -1858,6 +1904,15 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
     a.pool_sum = pool_sum ? 1 : 0;
     a.ypool = (unsigned short*)y_pooled;
     a.mask_y = (const unsigned short*)mask_y; a.colsum = colsum; a.row_scale = row_scale;
+    a.stats = stats;
+    if (stats) {
+        RGBD_REQUIRE(KH == 3 && KW == 3 && pad == 1 && a.Hout % 16 == 0 && a.Wout % 16 == 0 && !pool_sum && !y_pooled &&
+                     !mask_y && !g_force_gather && g_conv_variant != 1,
+                     "rgbd_conv2d_fprop_stats_bf16: needs a 3x3 pad-1 conv on output images that are multiples of 16x16");
+        plan.patch = true;
+        plan.ksplit = 1;
+        plan.small = false;
+    }
     if (mask_y) {
         RGBD_REQUIRE(KH == 3 && KW == 3 && pad == 1 && a.Hout % 16 == 0 && a.Wout % 16 == 0 && !upsample && !pool_sum &&
                      !y_pooled && !bias && lrelu_channels == 0 && !g_force_gather && g_conv_variant != 1,
@@ -1946,17 +2001,36 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
                 RGBD_CHECK_LAUNCH("conv3x3_sp_kernel<KO>");
                 return 0;
             }
+            if (stats) {
+                const void* fs = vi == 3 ? (const void*)&conv3x3_sp_kernel<128, true, 0, 2>
+                               : vi == 2 ? (const void*)&conv3x3_sp_kernel<128, false, 0, 2>
+                               : vi == 1 ? (const void*)&conv3x3_sp_kernel<64, true, 0, 2>
+                                         : (const void*)&conv3x3_sp_kernel<64, false, 0, 2>;
+                static bool sps_attr_done[4] = {false, false, false, false};
+                if (!sps_attr_done[vi]) {
+                    RGBD_REQUIRE(hipFuncSetAttribute(fs, hipFuncAttributeMaxDynamicSharedMemorySize, lds_sp) == hipSuccess,
+                                 "rgbd_conv2d_fprop_stats_bf16: cannot reserve %d B of LDS", lds_sp);
+                    sps_attr_done[vi] = true;
+                }
+                if (vi == 3)      conv3x3_sp_kernel<128, true, 0, 2><<<(unsigned)grid, 512, lds_sp, st>>>(a);
+                else if (vi == 2) conv3x3_sp_kernel<128, false, 0, 2><<<(unsigned)grid, 512, lds_sp, st>>>(a);
+                else if (vi == 1) conv3x3_sp_kernel<64, true, 0, 2><<<(unsigned)grid, 512, lds_sp, st>>>(a);
+                else              conv3x3_sp_kernel<64, false, 0, 2><<<(unsigned)grid, 512, lds_sp, st>>>(a);
+                RGBD_CHECK_LAUNCH("conv3x3_sp_kernel<stats>");
+                g_last_conv_kernel = wide ? "conv3x3_sp_kernel<128>" : "conv3x3_sp_kernel<64>";
+                return 0;
+            }
             if (mask_y) {
-                const void* fm = wide ? (const void*)&conv3x3_sp_kernel<128, false, 0, true>
-                                      : (const void*)&conv3x3_sp_kernel<64, false, 0, true>;
+                const void* fm = wide ? (const void*)&conv3x3_sp_kernel<128, false, 0, 1>
+                                      : (const void*)&conv3x3_sp_kernel<64, false, 0, 1>;
                 static bool spm_attr_done[2] = {false, false};
                 if (!spm_attr_done[wide]) {
                     RGBD_REQUIRE(hipFuncSetAttribute(fm, hipFuncAttributeMaxDynamicSharedMemorySize, lds_sp) == hipSuccess,
                                  "rgbd_conv3x3_actgrad_bf16: cannot reserve %d B of LDS", lds_sp);
                     spm_attr_done[wide] = true;
                 }
-                if (wide) conv3x3_sp_kernel<128, false, 0, true><<<(unsigned)grid, 512, lds_sp, st>>>(a);
-                else      conv3x3_sp_kernel<64, false, 0, true><<<(unsigned)grid, 512, lds_sp, st>>>(a);
+                if (wide) conv3x3_sp_kernel<128, false, 0, 1><<<(unsigned)grid, 512, lds_sp, st>>>(a);
+                else      conv3x3_sp_kernel<64, false, 0, 1><<<(unsigned)grid, 512, lds_sp, st>>>(a);
                 RGBD_CHECK_LAUNCH("conv3x3_sp_kernel<masked>");
                 g_last_conv_kernel = wide ? "conv3x3_sp_kernel<128>" : "conv3x3_sp_kernel<64>";
                 return 0;
@@ -2070,6 +2144,14 @@ extern "C" int rgbd_conv3x3_actgrad_bf16(const void* x, const void* wp, const vo
     RGBD_REQUIRE(colsum || !row_scale, "rgbd_conv3x3_actgrad_bf16: row_scale without colsum");
     return conv_fprop_impl(x, wp, nullptr, residual, y, B, H, W, Cin, Cout, 3, 3, 1, 0, 0, slope, nullptr, stream, 0, nullptr,
                            act_y, colsum, row_scale);
+}
+
+extern "C" int rgbd_conv2d_fprop_stats_bf16(const void* x, const void* wp, const float* bias, void* y, int64_t* stats, int B,
+                                            int Hin, int Win, int Cin, int Cout, int upsample, int lrelu_channels, float slope,
+                                            void* stream) {
+    RGBD_REQUIRE(stats, "rgbd_conv2d_fprop_stats_bf16: null pointer");
+    return conv_fprop_impl(x, wp, bias, nullptr, y, B, Hin, Win, Cin, Cout, 3, 3, 1, upsample, lrelu_channels, slope, nullptr,
+                           stream, 0, nullptr, nullptr, nullptr, nullptr, (long long*)stats);
 }
 
 extern "C" int64_t rgbd_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int K) {

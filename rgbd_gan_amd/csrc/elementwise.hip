@@ -64,11 +64,25 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 // (fp32 atomics in arrival order flipped bf16 roundings: ~1e-3 relative run-to-run noise on the generator output).
 constexpr int ADAIN_STRIP = 1024;
 
-// sum over strips of the (first, second) statistics of this thread's 8 channels; `part` points at strip 0's pair
-__device__ __forceinline__ void adain_strip_sum(const float* __restrict__ part, long strip_stride, int nstrips,
+// sum over strips of the (first, second) statistics of this thread's 8 channels, (sample, channel) pair index sidx.
+// nstrips > 0: float pairs, sums[strip][B][C][2] (adain_reduce_kernel).  nstrips < 0: the statistics came out of the
+// producing convolution's epilogue (rgbd_conv2d_fprop_stats_bf16): ONE pair of 64-bit integers per (sample, channel) in
+// units of 2^nstrips, `sums` pointing at int64 [B][C][2].
+__device__ __forceinline__ void adain_strip_sum(const float* __restrict__ sums, long sidx, long strip_stride, int nstrips,
                                                 float (&s1)[8], float (&s2)[8]) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) { s1[k] = 0.f; s2[k] = 0.f; }
+    if (nstrips < 0) {
+        const double unit = __builtin_ldexp(1.0, nstrips);
+        const long long* q8 = reinterpret_cast<const long long*>(sums) + 2 * sidx;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            s1[k] = (float)((double)q8[2 * k] * unit);
+            s2[k] = (float)((double)q8[2 * k + 1] * unit);
+        }
+        return;
+    }
+    const float* part = sums + 2 * sidx;
     // four strips' loads in flight at a time (a 128x128 image has 16 strips: one dependent L2 round trip per strip
     // was several microseconds of prologue in every block); the adds stay in strip order
     for (int s = 0; s < nstrips; s += 4) {
@@ -187,7 +201,7 @@ __global__ __launch_bounds__(256) void adain_apply_kernel(const unsigned short* 
     };
     if (r_begin + lane_p < r_end) request(r_begin + lane_p);
     float s1[8], s2[8];
-    adain_strip_sum(sums + 2 * sidx, (long)gridDim.z * C * 2, nstrips, s1, s2);
+    adain_strip_sum(sums, sidx, (long)gridDim.z * C * 2, nstrips, s1, s2);
     const f32x4 g0 = *reinterpret_cast<const f32x4*>(scale + aidx), g1 = *reinterpret_cast<const f32x4*>(scale + aidx + 4);
     const f32x4 h0 = *reinterpret_cast<const f32x4*>(shift + aidx), h1 = *reinterpret_cast<const f32x4*>(shift + aidx + 4);
     const float gg[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
@@ -270,7 +284,7 @@ __global__ __launch_bounds__(NT) void adain_bwd_apply_kernel(const unsigned shor
     };
     if (r_begin + lane_p < r_end) request(r_begin + lane_p);
     float s1[8], s2[8];                                 // sum dy, sum dy * xhat
-    adain_strip_sum(sums + 2 * sidx, (long)gridDim.z * C * 2, nstrips, s1, s2);
+    adain_strip_sum(sums, sidx, (long)gridDim.z * C * 2, nstrips, s1, s2);
     const f32x4 g0 = *reinterpret_cast<const f32x4*>(scale + aidx), g1 = *reinterpret_cast<const f32x4*>(scale + aidx + 4);
     const f32x4 m0 = *reinterpret_cast<const f32x4*>(mean + sidx), m1 = *reinterpret_cast<const f32x4*>(mean + sidx + 4);
     const f32x4 r0v = *reinterpret_cast<const f32x4*>(rstd + sidx), r1v = *reinterpret_cast<const f32x4*>(rstd + sidx + 4);
@@ -1197,6 +1211,20 @@ extern "C" int rgbd_adain_fwd(const void* x, const float* scale, const float* sh
     dim3 agrid(ceil_div(HW, rows), C / 64, B);
     adain_apply_kernel<<<agrid, 256, 0, st>>>((const unsigned short*)x, scale, shift, sums, mean, rstd,
                                               (unsigned short*)y, HW, C, ld, 1.f / (float)HW, eps, rows, (int)grid.x);
+    RGBD_CHECK_LAUNCH("adain_apply_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_adain_apply_fixed(const void* x, const float* scale, const float* shift, void* y, const int64_t* stats,
+                                      float* mean, float* rstd, int B, int HW, int C, int ld, float eps, void* stream) {
+    RGBD_REQUIRE(x && scale && shift && y && stats && mean && rstd, "rgbd_adain_apply_fixed: null pointer");
+    RGBD_REQUIRE(ld >= C, "rgbd_adain_apply_fixed: ld must be >= C");
+    RGBD_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 64 == 0, "rgbd_adain_apply_fixed: C must be a multiple of 64 (C=%d)", C);
+    const int rows = HW <= 4096 ? 256 : 512;
+    dim3 agrid(ceil_div(HW, rows), C / 64, B);
+    adain_apply_kernel<<<agrid, 256, 0, (hipStream_t)stream>>>((const unsigned short*)x, scale, shift, (const float*)stats,
+                                                                mean, rstd, (unsigned short*)y, HW, C, ld, 1.f / (float)HW,
+                                                                eps, rows, -32);
     RGBD_CHECK_LAUNCH("adain_apply_kernel");
     return 0;
 }

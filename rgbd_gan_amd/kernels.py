@@ -305,6 +305,53 @@ def conv3x3_actgrad(x, wp, act_y, residual=None, bias_grad=None, row_scale=None,
     return y
 
 
+def conv2d_fprop_stats(x, wp, bias, upsample=False, lrelu_channels=0, slope=0.2):
+    """3x3 pad-1 conv (+ nearest-2x upsample in front) + bias + leaky ReLU like conv2d_fprop, and the per-(sample, channel)
+    (sum y, sum y^2) of the stored values as (B,Cout,2) int64 in units of 2^-32 (for adain_apply_fixed).  Output images must
+    be multiples of 16x16 (conv3x3_actgrad_supported(B, Hout, Wout, Cin, Cout))."""
+    _chk(x, BF16, "x"); _chk(wp, BF16, "wp"); _chk(bias, F32, "bias")
+    B, H, W, Cin = x.shape
+    T, Cout, Cin2 = wp.shape
+    if T != 9 or Cin2 != Cin:
+        raise RuntimeError(f"conv2d_fprop_stats: weights {tuple(wp.shape)} do not match x {tuple(x.shape)}")
+    Hout, Wout = (2 * H, 2 * W) if upsample else (H, W)
+    y = torch.empty(B, Hout, Wout, Cout, dtype=BF16, device=x.device)
+    stats = torch.zeros(B, Cout, 2, dtype=torch.int64, device=x.device)
+    lib = _lib.load()
+    flops = 2.0 * B * Hout * Wout * Cout * Cin * 9
+    nbytes = 2.0 * (x.numel() + y.numel() + wp.numel())
+    rc = _timed(lambda: _conv_kernel_name(f"fprop {Hout}x{Wout} {Cin}->{Cout}{' ups' if upsample else ''} stats"),
+                flops, nbytes,
+                lambda: lib.rgbd_conv2d_fprop_stats_bf16(_ptr(x), _ptr(wp), _ptr(bias), _ptr(y), _ptr(stats), B, H, W, Cin,
+                                                         Cout, int(bool(upsample)), int(lrelu_channels), float(slope),
+                                                         _stream()))
+    _lib.check(rc, "rgbd_conv2d_fprop_stats_bf16")
+    return y, stats
+
+
+def adain_apply_fixed(x, stats, scale, shift=None, eps=1e-5, col_off=0):
+    """adain_fwd with the statistics given (conv2d_fprop_stats) instead of reduced from x -> y, mean, rstd."""
+    _chk(x, BF16, "x"); _chk(scale, F32, "scale"); _chk(shift, F32, "shift")
+    B, H, W, C = x.shape
+    if stats.dtype != torch.int64 or tuple(stats.shape) != (B, C, 2) or not stats.is_contiguous():
+        raise RuntimeError(f"adain_apply_fixed: statistics {tuple(stats.shape)} {stats.dtype} do not match x {tuple(x.shape)}")
+    fused = shift is None
+    if fused:
+        if scale.dim() != 2 or scale.shape[0] != B or col_off % 4 or col_off + 2 * C > scale.shape[1]:
+            raise RuntimeError(f"adain_apply_fixed: window [{col_off},{col_off + 2 * C}) outside {tuple(scale.shape)}")
+        ld = scale.shape[1]
+    elif scale.shape != (B, C):
+        raise RuntimeError(f"adain_apply_fixed: scale {tuple(scale.shape)} does not match x {tuple(x.shape)}")
+    y = torch.empty_like(x)
+    mean = torch.empty(B, C, dtype=F32, device=x.device)
+    rstd = torch.empty(B, C, dtype=F32, device=x.device)
+    rc = _lib.load().rgbd_adain_apply_fixed(_ptr(x), _off(scale, col_off) if fused else _ptr(scale),
+                                            _off(scale, col_off + C) if fused else _ptr(shift), _ptr(y), _ptr(stats),
+                                            _ptr(mean), _ptr(rstd), B, H * W, C, ld if fused else C, float(eps), _stream())
+    _lib.check(rc, "rgbd_adain_apply_fixed")
+    return y, mean, rstd
+
+
 def conv2d_wgrad(x, dy, K, scale, out=None, accumulate=False, upsample=False):
     """x (B,H,W,Cin) bf16, dy (B,H,W,Cout) bf16 -> dW (Cout,Cin,K,K) fp32 = scale * sum dy (x) x.
     upsample: x is (B,H/2,W/2,Cin) and stands for its nearest-2x upsampling (read through the index map, not copied)."""

@@ -593,6 +593,42 @@ def test_conv3x3_actgrad_matches_conv_then_activation_gradient(B, S, Cin, Cout, 
     torch.testing.assert_close(dz.float(), ref_dz, atol=2e-2 * float(ref_dx.abs().max()) / 4, rtol=1e-2)
 
 
+@pytest.mark.parametrize("B,S,Cin,Cout,ups", [(4, 32, 128, 128, False), (3, 64, 128, 64, True), (8, 16, 256, 256, False),
+                                            (6, 32, 256, 192, True), (64, 128, 64, 64, False)])
+def test_conv_epilogue_statistics_feed_adain(B, S, Cin, Cout, ups):
+    """rgbd_conv2d_fprop_stats_bf16 + rgbd_adain_apply_fixed (instance-norm statistics out of the conv epilogue as 2^-32
+    fixed-point integer sums) against rgbd_conv2d_fprop_bf16 + rgbd_adain_fwd (a reduction pass over the stored tensor): the
+    same image, the same statistics to fp32 rounding, bit-identical from launch to launch."""
+    from rgbd_gan_amd import kernels
+    g = torch.Generator().manual_seed(B + S + Cin + Cout)
+    Sin = S // 2 if ups else S
+    x = torch.randn(B, Sin, Sin, Cin, generator=g).to(dev()).to(torch.bfloat16)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g).to(dev())
+    bias = torch.randn(Cout, generator=g).to(dev())
+    ss = torch.randn(B, 2 * Cout + 8, generator=g).to(dev())
+    wf, _ = kernels.pack_weights(w, float(np.sqrt(2.0 / (Cin * 9))), True, False)
+    y_ref = kernels.conv2d_fprop(x, wf, 3, 3, 1, bias=bias, upsample=ups, lrelu_channels=Cout)
+    out_ref, mean_ref, rstd_ref = kernels.adain_fwd(y_ref, ss, col_off=4)
+    y, stats = kernels.conv2d_fprop_stats(x, wf, bias, upsample=ups, lrelu_channels=Cout)
+    # (small problems take the split-K gather kernel without statistics: another summation order, a bf16 ulp)
+    torch.testing.assert_close(y.float(), y_ref.float(), atol=2e-2, rtol=8e-3)
+    out_ref, mean_ref, rstd_ref = kernels.adain_fwd(y, ss, col_off=4)
+    yf = y.float()
+    s1 = yf.sum(dim=(1, 2)).double()
+    s2 = (yf * yf).sum(dim=(1, 2)).double()
+    got = stats.double() * 2.0 ** -32
+    torch.testing.assert_close(got[..., 0], s1, atol=1e-2, rtol=1e-5)       # the fp32 reference sums carry the error here
+    torch.testing.assert_close(got[..., 1], s2, atol=1e-2, rtol=1e-5)
+    out, mean, rstd = kernels.adain_apply_fixed(y, stats, ss, col_off=4)
+    torch.testing.assert_close(mean, mean_ref, atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(rstd, rstd_ref, atol=1e-5, rtol=2e-5)
+    torch.testing.assert_close(out.float(), out_ref.float(), atol=2e-2, rtol=8e-3)
+    for _ in range(5):
+        y2, stats2 = kernels.conv2d_fprop_stats(x, wf, bias, upsample=ups, lrelu_channels=Cout)
+        assert torch.equal(stats2, stats) and torch.equal(y2, y)
+    assert torch.equal(kernels.adain_apply_fixed(y, stats, ss, col_off=4)[0], out)
+
+
 CONV_VARIANT_CASES = [  # (B, Hout, Cin, Cout, upsample, residual, pooled output)
     (32, 64, 128, 128, False, False, False),     # two pixel tiles per persistent workgroup, two channel slices each
     (32, 64, 256, 256, False, True, True),       # four tiles per workgroup, residual + fused 2x2 average
