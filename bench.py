@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--iteration", type=int, default=200000, help="steady state: stage 10, rotation + occlusion on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--res256", action="store_true",
+                    help="BASELINE configuration 5's networks (ch=512, the 256x256 block, stage 12, per-GPU batch 16) with "
+                         "bf16 convs -- the fp8 conv kernels of that configuration are not built; never the default line")
     ap.add_argument("--arrangements", action="store_true",
                     help="also time the single-stream arrangement on the same box (extra key, never `value`)")
     return ap.parse_args()
@@ -208,12 +211,17 @@ def main():
     config = yaml_utils.load(args.config)
     deepvoxels = config.generator_architecture == "deepvoxels"      # BASELINE config 4: DeepVoxelsUpdater, 64x64, B=10
     B = args.batch or config.batchsize
+    side, extra = 128, {}
+    if args.res256:
+        config.ch, config.max_resolution, config.max_stage = 512, 256, 13
+        B = args.batch or 16
+        side, extra = 256, {"fixed_stage": 12.0}
     np.random.seed(2 + comm.rank)
     torch.manual_seed(comm.rank)
-    images = np.random.RandomState(comm.rank).randint(0, 256, (256, 3, 128, 128)).astype("uint8")
+    images = np.random.RandomState(comm.rank).randint(0, 256, (256 if side == 128 else 64, 3, side, side)).astype("uint8")
     it = DeviceImageIterator(images, B, device, seed=comm.rank)
     gen, dis, opt, upd = build_training(config, device, comm if comm.active else None, iterator=it,
-                                        nan_check_interval=0)
+                                        nan_check_interval=0, **extra)
     upd.iteration = args.iteration
 
     def sync():
@@ -251,8 +259,10 @@ def main():
         "config": {"workload": (f"{os.path.basename(args.config)} stage {upd.stage:.2f} (64x64), DeepVoxelsUpdater.update_core, "
                                 f"voxel generator 32^3 x 32 features -> frustum 56x64x64 -> occlusion compositing -> 2-D "
                                 f"renderer, rotation loss on, R1 on") if deepvoxels else
-                               (f"{os.path.basename(args.config)} stage {upd.stage:.2f} (128x128), RGBDUpdater.update_core, "
-                                f"StyleGAN ch={config.ch}, rotation+occlusion loss on, R1 on"),
+                               (f"{os.path.basename(args.config)} stage {upd.stage:.2f} ({side}x{side}), RGBDUpdater.update_core, "
+                                f"StyleGAN ch={config.ch}, rotation+occlusion loss on, R1 on"
+                                + (", max_resolution=256 (BASELINE configuration 5's networks; bf16 convs, its fp8 kernels are "
+                                   "not built)" if args.res256 else "")),
                    "per_gpu_batch": B, "global_batch": B * comm.size, "parallelism": f"dp{comm.size}",
                    "arrangement": "two streams, one graph per phase" if getattr(upd, "concurrent_phases", False) else "one stream",
                    # True only if the timed steps were replays of captured HIP graphs (a refused capture is fatal in the
@@ -264,6 +274,8 @@ def main():
     }
     if deepvoxels:
         line["metric"] = "img/s (G+D+3D-loss step) at 64x64, DeepVoxels generator"
+    elif args.res256:
+        line["metric"] = "img/s (G+D+3D-loss step) at 256x256"
     else:
         line["step_tflops_algorithmic"] = round(value * STEP_GFLOP_PER_IMAGE / 1e3, 2)
         line["mfma_roofline_frac_whole_step"] = round(value * STEP_GFLOP_PER_IMAGE / 1e3 / (MFMA_BF16_PEAK_TFLOPS * comm.size), 4)

@@ -178,6 +178,26 @@ def l2_normalize(x, eps=1e-5):
     return x / (torch.sqrt((x * x).sum(dim=1, keepdim=True)) + eps)
 
 
+def block_count(max_resolution):
+    """6 blocks for the reference's 128 px networks (net.py:175-180); its commented-out 256 / 512 px blocks (net.py:181-183,
+    192-194: ch//8, ch//16 channels) are blocks 6 and 7."""
+    nb = int(max_resolution).bit_length() - 2
+    assert max_resolution >= 128 and (1 << (nb + 1)) == max_resolution
+    return nb
+
+
+def synthesis_chans(ch, nb):
+    return [(ch, ch)] * 4 + [(ch >> (i - 3), ch >> (i - 4)) for i in range(4, nb)]     # (out, in)
+
+
+def max_stage_of(p, outs_prefix):
+    """Stage ceiling of a parameter set: 2 * blocks + 5 (17 for the reference's six, net.py:166,433)."""
+    n = 0
+    while f"{outs_prefix}/{n}/c/W" in p:
+        n += 1
+    return 2 * n + 5
+
+
 def split_stage(stage, max_stage=17):
     stage = min(stage, max_stage - 1e-8)
     fl = math.floor(stage)
@@ -190,7 +210,7 @@ def _normal(gen, *shape):
     return torch.randn(*shape, generator=gen, dtype=torch.float32)
 
 
-def init_stylegan(ch=256, seed=0, initial_depth=1.0, rgbd=True):
+def init_stylegan(ch=256, seed=0, initial_depth=1.0, rgbd=True, max_resolution=128):
     """Random-init parameters with the reference's initialisers (net.py:22-216):
     W ~ N(0,1), biases 0, style-scale bias 1, const input 1, noise scale 0,
     depth row of every `outs` conv W=0, b=log(e^initial_depth - 1)."""
@@ -199,7 +219,7 @@ def init_stylegan(ch=256, seed=0, initial_depth=1.0, rgbd=True):
     for i in range(0, 16, 2):
         p[f"mapping/l/{i}/c/W"] = _normal(g, ch, ch)
         p[f"mapping/l/{i}/c/b"] = torch.zeros(ch)
-    chans = [(ch, ch), (ch, ch), (ch, ch), (ch, ch), (ch // 2, ch), (ch // 4, ch // 2)]  # (out, in)
+    chans = synthesis_chans(ch, block_count(max_resolution))
     out_ch = 4 if rgbd else 3
     for i, (co, ci) in enumerate(chans):
         pre = f"gen/blocks/{i}"
@@ -258,8 +278,10 @@ def init_dcgan(in_ch=256, ch=512, seed=0, initial_depth=1.0, rgbd=True):
     return p
 
 
-def init_discriminator(ch=256, seed=1, out_dim=1, res=True):
+def init_discriminator(ch=256, seed=1, out_dim=1, res=True, max_resolution=128):
     """net.py:429-455 (Discriminator.__init__, sn=False)."""
+    nb = block_count(max_resolution)
+    gch = synthesis_chans(ch, nb)
     g = torch.Generator().manual_seed(seed)
     p = {}
     p["blocks/0/c0/c/W"] = _normal(g, ch, ch, 3, 3)
@@ -268,15 +290,15 @@ def init_discriminator(ch=256, seed=1, out_dim=1, res=True):
     p["blocks/0/c1/c/b"] = torch.zeros(ch)
     p["blocks/0/l2/c/W"] = _normal(g, out_dim, ch)
     p["blocks/0/l2/c/b"] = torch.zeros(out_dim)
-    chans = [None, (ch, ch), (ch, ch), (ch, ch), (ch // 2, ch), (ch // 4, ch // 2)]  # (in, out)
-    for i in range(1, 6):
+    chans = [None] + [gch[i] for i in range(1, nb)]      # (in, out): the generator's (out, in)
+    for i in range(1, nb):
         ci, co = chans[i]
         names = ("c0", "c1", "c_sc") if res else ("c0", "c1")
         for nm in names:
             cin = co if nm == "c1" else ci
             p[f"blocks/{i}/{nm}/c/W"] = _normal(g, co, cin, 3, 3)
             p[f"blocks/{i}/{nm}/c/b"] = torch.zeros(co)
-    ins = [ch, ch, ch, ch, ch // 2, ch // 4]
+    ins = [c[0] for c in gch]
     for i, co in enumerate(ins):
         p[f"ins/{i}/c/W"] = _normal(g, co, 3, 1, 1)
         p[f"ins/{i}/c/b"] = torch.zeros(co)
@@ -369,7 +391,7 @@ def depth_head(h):
 
 def style_generator(p, w, w2, stage, theta9, rgbd=True, return_feature=False, enable_blur=False):
     """net.py:232-311 (StyleGenerator.forward), train mode."""
-    st, alpha = split_stage(stage)
+    st, alpha = split_stage(stage, max_stage_of(p, "gen/outs"))
     feat = None
     h = None
 
@@ -468,7 +490,7 @@ def dis_block(p, i, x, res=True, enable_blur=False):
 
 def discriminator(p, x, stage, return_hidden=False, res=True, enable_blur=False):
     """net.py:469-504 (Discriminator.forward)."""
-    st, alpha = split_stage(stage)
+    st, alpha = split_stage(stage, max_stage_of(p, "ins"))
     feat = None
     if st % 2 == 0:
         k = (st - 2) // 2

@@ -50,6 +50,20 @@ def alpha_override(alpha):
         _ALPHA_OVERRIDE = old
 
 
+def _block_count(max_resolution):
+    """Blocks of a progressive network that ends at max_resolution x max_resolution: 6 for the reference's 128 (net.py:175-
+    180); its commented-out 256 / 512 / 1024 blocks (net.py:181-183,192-194: ch//8, ch//16, ch//32 channels) are blocks 6-8."""
+    nb = int(max_resolution).bit_length() - 2
+    if max_resolution < 128 or (1 << (nb + 1)) != max_resolution:
+        raise ValueError(f"max_resolution must be a power of two >= 128 (got {max_resolution})")
+    return nb
+
+
+def _synthesis_chans(ch, nb):
+    """(out, in) channels of generator blocks 0..nb-1: ch up to 32 px, then halving (net.py:175-183)."""
+    return [(ch, ch)] * 4 + [(ch >> (i - 3), ch >> (i - 4)) for i in range(4, nb)]
+
+
 def _split_stage(stage, max_stage):
     stage = min(stage, max_stage - 1e-8)
     fl = math.floor(stage)
@@ -140,12 +154,15 @@ class MappingNetwork(_Link):
 
 
 class StyleGenerator(_Link):
-    """net.py:164-311.  Channel plan at ch: blocks (ch,ch,ch,ch,ch/2,ch/4) at 4..128 px."""
+    """net.py:164-311.  Channel plan at ch: blocks (ch,ch,ch,ch,ch/2,ch/4) at 4..128 px; max_resolution 256 / 512 adds
+    the blocks the reference keeps commented out (ch/8 at 256 px, ch/16 at 512 px: net.py:181-183,192-194)."""
 
-    def __init__(self, ch, device, rgbd=True, initial_depth=1.0, seed=1, enable_blur=False):
-        self.ch, self.rgbd, self.max_stage = ch, rgbd, 17
+    def __init__(self, ch, device, rgbd=True, initial_depth=1.0, seed=1, enable_blur=False, max_resolution=128):
+        nb = _block_count(max_resolution)
+        self.ch, self.rgbd, self.max_stage = ch, rgbd, 2 * nb + 5     # 17 for the reference's six blocks (net.py:166)
         self.enable_blur = bool(enable_blur)       # net.py:140-141: c0(blur(upscale2x(h))) instead of c0(upscale2x(h))
-        self.chans = [(ch, ch), (ch, ch), (ch, ch), (ch, ch), (ch // 2, ch), (ch // 4, ch // 2)]  # (out, in)
+        self.chans = _synthesis_chans(ch, nb)      # (out, in)
+        assert self.chans[-1][0] % 64 == 0, "the MFMA conv engine needs the last block's channels to be a multiple of 64"
         out_ch = 4 if rgbd else 3
         w_init, b_init = depth_row_init(initial_depth, out_ch, rgbd)
         specs = []
@@ -174,8 +191,8 @@ class StyleGenerator(_Link):
         self.stores = (("", self.store),)
         p = self.store.params
         self.c0 = [None] + [Fn.ConvLayer(p[f"blocks/{i}/c0/c/W"], _inv_c(self.chans[i][1] * 9), 1)
-                            for i in range(1, 6)]
-        self.c1 = [Fn.ConvLayer(p[f"blocks/{i}/c1/c/W"], _inv_c(self.chans[i][0] * 9), 1) for i in range(6)]
+                            for i in range(1, nb)]
+        self.c1 = [Fn.ConvLayer(p[f"blocks/{i}/c1/c/W"], _inv_c(self.chans[i][0] * 9), 1) for i in range(nb)]
         self.pack_group = Fn.PackGroup(self.c0 + self.c1)
 
     # -- pieces
@@ -295,14 +312,16 @@ class StyleGenerator(_Link):
 
 class StyleGANGenerator(_Link):
     def __init__(self, ch, enable_blur=False, rgbd=False, rotate_conv_input=False, use_encoder=False,
-                 use_occupancy_net=False, initial_depth=None, device="cuda:0", seed=0):
+                 use_occupancy_net=False, initial_depth=None, device="cuda:0", seed=0, max_resolution=128):
+        """max_resolution (not a reference argument: its 256+ blocks are commented out in the source, net.py:181-183): 256
+        needs ch = 512 (ch/8 = 64 channels in the last block)."""
         assert not rotate_conv_input and not use_encoder and not use_occupancy_net, "unsupported generator option"
         assert ch % 256 == 0, "the MFMA conv engine needs ch/4 to be a multiple of 64"
         self.ch = ch
         self.device = torch.device(device)
         self.mapping = MappingNetwork(ch, device, seed)
         self.gen = StyleGenerator(ch, device, rgbd, 1.0 if initial_depth is None else initial_depth, seed + 1,
-                                  enable_blur=bool(enable_blur))
+                                  enable_blur=bool(enable_blur), max_resolution=max_resolution)
         self.stores = (("mapping/", self.mapping.store), ("gen/", self.gen.store))
         self.train = True
 
@@ -427,20 +446,24 @@ class DCGANGenerator(_Link):
 class Discriminator(_Link):
     """net.py:429-504 with res blocks (net.py:380-426) and the 4x4 base block (net.py:357-377)."""
 
-    def __init__(self, ch=512, out_dim=1, enable_blur=False, sn=False, res=False, device="cuda:0", seed=100):
+    def __init__(self, ch=512, out_dim=1, enable_blur=False, sn=False, res=False, device="cuda:0", seed=100,
+                 max_resolution=128):
         assert ch % 256 == 0
-        self.ch, self.sn, self.res, self.max_stage = ch, bool(sn), res, 17
+        nb = self.n_blocks = _block_count(max_resolution)      # 6: the reference's (net.py:437-452); 7: + its commented 256 block
+        self.ch, self.sn, self.res, self.max_stage = ch, bool(sn), res, 2 * nb + 5
+        gch = _synthesis_chans(ch, nb)
+        assert gch[-1][0] % 64 == 0, "the MFMA conv engine needs the first block's channels to be a multiple of 64"
+        self.chans = [None] + [(gch[i][0], gch[i][1]) for i in range(1, nb)]       # (in, out): the generator's, mirrored
+        self.in_chans = [c[0] for c in gch]
         if self.sn:
             self._init_sn(ch, out_dim, enable_blur, res, device, seed)
             return
         self.enable_blur = bool(enable_blur)       # net.py:422-423: blur(downscale2x(h)) at the end of every block
         self.device = torch.device(device)
-        self.chans = [None, (ch, ch), (ch, ch), (ch, ch), (ch // 2, ch), (ch // 4, ch // 2)]  # (in, out)
-        self.in_chans = [ch, ch, ch, ch, ch // 2, ch // 4]
         specs = [("blocks/0/c0/c/W", (ch, ch, 3, 3), "normal"), ("blocks/0/c0/c/b", (ch,), "zeros"),
                  ("blocks/0/c1/c/W", (ch, ch, 4, 4), "normal"), ("blocks/0/c1/c/b", (ch,), "zeros"),
                  ("blocks/0/l2/c/W", (out_dim, ch), "normal"), ("blocks/0/l2/c/b", (out_dim,), "zeros")]
-        for i in range(1, 6):
+        for i in range(1, nb):
             ci, co = self.chans[i]
             for nm in (("c0", "c1", "c_sc") if res else ("c0", "c1")):
                 cin = co if nm == "c1" else ci
@@ -452,7 +475,7 @@ class Discriminator(_Link):
         p = self.store.params
         self.conv = {}
         self.conv["blocks/0/c0"] = Fn.ConvLayer(p["blocks/0/c0/c/W"], _inv_c(ch * 9), 1)
-        for i in range(1, 6):
+        for i in range(1, nb):
             ci, co = self.chans[i]
             for nm in (("c0", "c1", "c_sc") if res else ("c0", "c1")):
                 cin = co if nm == "c1" else ci
@@ -472,8 +495,6 @@ class Discriminator(_Link):
     def _init_sn(self, ch, out_dim, enable_blur, res, device, seed):
         self.enable_blur = bool(enable_blur)
         self.device = torch.device(device)
-        self.chans = [None, (ch, ch), (ch, ch), (ch, ch), (ch // 2, ch), (ch // 4, ch // 2)]
-        self.in_chans = [ch, ch, ch, ch, ch // 2, ch // 4]
         uni = lambda shape, gen: torch.rand(shape, generator=gen) * 2 - 1           # chainer.initializers.Uniform(1)
         specs, self.sn_layers = [], []
         def add(name, shape):
@@ -482,7 +503,7 @@ class Discriminator(_Link):
         add("blocks/0/c0", (ch, ch, 3, 3))
         add("blocks/0/c1", (ch, ch, 4, 4))
         add("blocks/0/l2", (out_dim, ch))
-        for i in range(1, 6):
+        for i in range(1, self.n_blocks):
             ci, co = self.chans[i]
             for nm in (("c0", "c1", "c_sc") if res else ("c0", "c1")):
                 add(f"blocks/{i}/{nm}", (co, co if nm == "c1" else ci, 3, 3))

@@ -18,7 +18,7 @@ def setup_generator(config, device, seed=0):
         return StyleGANGenerator(config.ch, enable_blur=config.enable_blur, rgbd=rgbd,
                                  rotate_conv_input=config.rotate_conv_input, use_encoder=config.bigan,
                                  use_occupancy_net=config.use_occupancy_net_loss, initial_depth=config.initial_depth,
-                                 device=device, seed=seed)
+                                 device=device, seed=seed, max_resolution=config.max_resolution or 128)
     if arch == "dcgan":
         # NB the reference passes config.ch as in_ch and leaves ch at its default 512 (train_rgbd.py:230)
         return DCGANGenerator(config.ch, enable_blur=config.enable_blur, rgbd=rgbd, use_encoder=config.bigan,
@@ -41,7 +41,10 @@ def setup_discriminator(config, device):
     """train_rgbd.py:249-258."""
     if config.bigan:
         raise AssertionError("bigan is not supported")
-    return Discriminator(ch=config.ch, enable_blur=config.enable_blur, sn=config.sn, res=config.res_dis, device=device)
+    # max_resolution: optional YAML key of this engine (default 128 = the reference's six blocks); 256 builds the block the
+    # reference keeps commented out (net.py:181,192,437-452) -- BASELINE configuration 5
+    return Discriminator(ch=config.ch, enable_blur=config.enable_blur, sn=config.sn, res=config.res_dis, device=device,
+                         max_resolution=config.max_resolution or 128)
 
 
 def make_optimizers(config, generator, discriminator, comm=None):

@@ -266,14 +266,15 @@ class RGBDUpdater:
         if st.get("real_idx") is not None:
             # the uint8 data set lives in HBM: gather + x/127.5 - 1 + downsize_real (block means, fade-in blend) in ONE
             # kernel (train_rgbd.py:308-310, common/utils/pggan.py:6-50)
-            fl = math.floor(min(st["stage"], 17 - 1e-8))
+            top = self._net_max_stage
+            fl = math.floor(min(st["stage"], top - 1e-8))
             alpha = None
             if fl % 2 == 1:
-                alpha = st["alpha"] if st.get("alpha") is not None else float(min(st["stage"], 17 - 1e-8) - fl)
-            st["x_real"] = kernels.real_batch(st["real_data"], st["real_idx"], downsized_size(st["stage"]), alpha)
+                alpha = st["alpha"] if st.get("alpha") is not None else float(min(st["stage"], top - 1e-8) - fl)
+            st["x_real"] = kernels.real_batch(st["real_data"], st["real_idx"], downsized_size(st["stage"], top), alpha)
         else:
             with torch.no_grad():
-                st["x_real"] = downsize_real(st["x_real_full"], st["stage"]).contiguous()
+                st["x_real"] = downsize_real(st["x_real_full"], st["stage"], self._net_max_stage).contiguous()
         for link in (getattr(self.gen, "gen", self.gen), self.dis):
             group = getattr(link, "pack_group", None)
             if group is not None:
@@ -482,6 +483,11 @@ class RGBDUpdater:
             ev.record(stream)
             self.timeline[name] = ev
 
+    @property
+    def _net_max_stage(self):
+        """The networks' own stage ceiling: 17 for the reference's six blocks (net.py:166,433), 19 with a 256 px block."""
+        return getattr(self.dis, "max_stage", 17)
+
     graph_fallback = False      # class defaults shared with DeepVoxelsUpdater (its own __init__)
     _capture_stream = None
     profile_ranges = False      # train_rgbd.py sets it for `nvprof` / `enable_cuda_profiling` (train_rgbd.py:100,363-364,462)
@@ -680,7 +686,7 @@ class RGBDUpdater:
               "x_real_full": x_real_data, "z": None, "real_idx": real_idx, "real_data": real_data}
         st["theta9"] = self._stager("theta9", (batch_size, 9)).upload(theta9) if theta9 is not None else None
         if use_rotate:
-            image_size = downsized_size(stage)
+            image_size = downsized_size(stage, self._net_max_stage)
             coef = self.loss_func_rotate.coefficients_for_size(image_size, random_camera_matrices[:half],
                                                                random_camera_matrices[half:])
             st["coef"] = self._stager("coef", (half, 24)).upload(coef)
@@ -698,14 +704,14 @@ class RGBDUpdater:
             obs["stage"], obs["batch_size"], obs["image_size"] = stage, batch_size, int(st["x_real"].shape[2])
             return
 
-        fl = math.floor(min(stage, 17 - 1e-8))
+        fl = math.floor(min(stage, self._net_max_stage - 1e-8))
         key = None
         st["alpha"] = None
         if self.use_graphs:
             if fl % 2 == 1:
                 # fade-in stage: the blend factor changes every iteration, so it lives in a device scalar that the
                 # captured phases read (net.alpha_override); the launch sequence depends on floor(stage) only
-                alpha = float(min(stage, 17 - 1e-8) - fl)
+                alpha = float(min(stage, self._net_max_stage - 1e-8) - fl)
                 st["alpha"] = self._stager("alpha", (1,)).upload(np.array([alpha], dtype="float32"))[0]
             if x_real_data is not None:
                 # graphs read their inputs from fixed addresses: park the batch in a persistent buffer
