@@ -397,88 +397,123 @@ __global__ __launch_bounds__(256) void occ_bwd_scan_kernel(OccArgs a, const floa
     }
 }
 
-// backward 3: through the per-voxel MLP; dvol = w * dfeat (compositing) + MLP path; weight gradients via block
-// reduction + atomics (dW1 nf x (F+1), db1 nf, dW2 nf, db2 1 -> packed in dparams)
+// backward 3: through the per-voxel MLP; dvol = w * dfeat (compositing) + MLP path, and the 141 parameter gradients
+// (dW1 nf x (F+1), db1 nf, dW2 nf, db2 1 -> packed in dparams).
+// A block is 64 voxels x 4 feature groups: wave g owns features 8g .. 8g+7 of the block's 64 consecutive voxels (one
+// coalesced 256-byte run per feature plane), so a thread carries 32 + 13 gradient accumulators instead of 141 -- the
+// one-thread-per-voxel version sat at 255 registers, two waves per SIMD, and took 790 us for 1.2 GB of traffic.  The hidden
+// pre-activations need all 32 features: the four partial dot products meet in LDS (double buffered, one barrier per
+// 64-voxel chunk).  Blocks are persistent; each leaves its 141 sums in a row of `partial` with plain stores and
+// occ_bwd_params_kernel adds the rows in index order: no atomics, the parameter gradients are bit-reproducible.
+constexpr int OCC_FG = 8;
+constexpr int OCC_NPARAM_MAX = OCC_NF * (OCC_MAXF + 1) + 2 * OCC_NF + 1;
 __global__ __launch_bounds__(256) void occ_bwd_mlp_kernel(OccArgs a, const float* __restrict__ vol,
                                                           const float* __restrict__ W1, const float* __restrict__ b1,
                                                           const float* __restrict__ W2, const float* __restrict__ s,
                                                           const float* __restrict__ ds, const float* __restrict__ w,
                                                           const float* __restrict__ dfeat, float* __restrict__ dvol,
-                                                          float* __restrict__ dparams) {
-    // Persistent blocks walk the (b, d, pixel) samples; the 141 parameter gradients are accumulated per thread in
-    // registers over the whole walk and reduced ONCE per block (wave shuffles -> LDS -> one atomic per parameter per
-    // block).  One wave-level atomic per parameter per 64 samples was 5 M atomics on 141 addresses: 14 ms per step.
+                                                          float* __restrict__ partial) {
+    __shared__ float hp[2][4][OCC_NF][64];
+    __shared__ float red[OCC_NPARAM_MAX];
+    const int v = threadIdx.x & 63;
+    const int fg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), f0 = fg * OCC_FG;   // wave-uniform: W1's slice sits in SGPRs
     const long vox = (long)a.D * a.HW;
     const long total = (long)a.B * vox;
-    const int nW1 = OCC_NF * (a.F + 1);
-    float gW1[OCC_NF][OCC_MAXF + 1], gb1[OCC_NF], gW2[OCC_NF], gb2 = 0.f;
+    const int F1 = a.F + 1, nW1 = OCC_NF * F1;
+    float w1[OCC_NF][OCC_FG], w10[OCC_NF], bb[OCC_NF], w2[OCC_NF];
+    float g[OCC_NF][OCC_FG], g0[OCC_NF], gb1[OCC_NF], gW2[OCC_NF], gb2 = 0.f;
 #pragma unroll
     for (int j = 0; j < OCC_NF; ++j) {
-        gb1[j] = 0.f; gW2[j] = 0.f;
+        w10[j] = W1[j * F1]; bb[j] = b1[j]; w2[j] = W2[j] * a.c2;
+        g0[j] = 0.f; gb1[j] = 0.f; gW2[j] = 0.f;
 #pragma unroll
-        for (int f = 0; f <= OCC_MAXF; ++f) gW1[j][f] = 0.f;
+        for (int k = 0; k < OCC_FG; ++k) {
+            w1[j][k] = f0 + k < a.F ? W1[j * F1 + 1 + f0 + k] : 0.f;
+            g[j][k] = 0.f;
+        }
     }
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int b = (int)(i / vox);
-        const long r = i - (long)b * vox;
+    const long nchunks = (total + 63) / 64;
+    int buf = 0;
+    for (long c = blockIdx.x; c < nchunks; c += gridDim.x, buf ^= 1) {      // block-uniform trip count
+        const long i = c * 64 + v;
+        const bool live = i < total;
+        const long ii = live ? i : total - 1;
+        const int b = (int)(ii / vox);
+        const long r = ii - (long)b * vox;
         const int d = (int)(r / a.HW);
         const int p = (int)(r - (long)d * a.HW);
-        const float xc = depth_coord(d, a.D) * a.c1;
-        float x[OCC_MAXF], h[OCC_NF];
+        float x[OCC_FG], df[OCC_FG];
 #pragma unroll
-        for (int j = 0; j < OCC_NF; ++j) h[j] = b1[j] + W1[j * (a.F + 1)] * xc;
-#pragma unroll
-        for (int f = 0; f < OCC_MAXF; ++f) {
-            x[f] = f < a.F ? vol[((long)b * a.F + f) * vox + r] * a.c1 : 0.f;
-#pragma unroll
-            for (int j = 0; j < OCC_NF; ++j) h[j] += (f < a.F ? W1[j * (a.F + 1) + 1 + f] : 0.f) * x[f];
+        for (int k = 0; k < OCC_FG; ++k) {
+            const bool ok = f0 + k < a.F;
+            const long plane = (long)b * a.F + (ok ? f0 + k : 0);
+            x[k] = ok ? vol[plane * vox + r] * a.c1 : 0.f;
+            df[k] = ok ? dfeat[plane * a.HW + p] : 0.f;
         }
-        const float sv = s[i];
-        const float dpre2 = ds[i] * sv * (1.f - sv);
+        const float sv = s[ii], dsv = ds[ii], wd = w[ii];
+#pragma unroll
+        for (int j = 0; j < OCC_NF; ++j) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < OCC_FG; ++k) t += w1[j][k] * x[k];
+            hp[buf][fg][j][v] = t;
+        }
+        __syncthreads();
+        const float xc = depth_coord(d, a.D) * a.c1;
+        const float dpre2 = live ? dsv * sv * (1.f - sv) : 0.f;
         float dpre1[OCC_NF];
 #pragma unroll
         for (int j = 0; j < OCC_NF; ++j) {
-            const float ha = h[j] > 0.f ? h[j] : 0.2f * h[j];
-            dpre1[j] = W2[j] * a.c2 * dpre2 * (h[j] > 0.f ? 1.f : 0.2f);
-            gW1[j][0] += dpre1[j] * xc;
+            const float h = (bb[j] + w10[j] * xc) + ((hp[buf][0][j][v] + hp[buf][1][j][v]) + (hp[buf][2][j][v] + hp[buf][3][j][v]));
+            const float ha = h > 0.f ? h : 0.2f * h;
+            dpre1[j] = w2[j] * dpre2 * (h > 0.f ? 1.f : 0.2f);
+            g0[j] += dpre1[j] * xc;              // (these four are read from wave 0 only)
             gb1[j] += dpre1[j];
             gW2[j] += dpre2 * a.c2 * ha;
         }
         gb2 += dpre2;
-        const float wd = w[i];
 #pragma unroll
-        for (int f = 0; f < OCC_MAXF; ++f) {
-            if (f < a.F) {
-                float dx = 0.f;
+        for (int k = 0; k < OCC_FG; ++k) {
+            float dx = 0.f;
 #pragma unroll
-                for (int j = 0; j < OCC_NF; ++j) {
-                    dx += W1[j * (a.F + 1) + 1 + f] * dpre1[j];
-                    gW1[j][1 + f] += dpre1[j] * x[f];
-                }
-                dvol[((long)b * a.F + f) * vox + r] = wd * dfeat[((long)b * a.F + f) * a.HW + p] + dx * a.c1;
+            for (int j = 0; j < OCC_NF; ++j) {
+                dx += w1[j][k] * dpre1[j];
+                g[j][k] += dpre1[j] * x[k];
             }
+            if (live && f0 + k < a.F) dvol[((long)b * a.F + f0 + k) * vox + r] = wd * df[k] + dx * a.c1;
         }
     }
-    __shared__ float red[OCC_NF * (OCC_MAXF + 1) + 2 * OCC_NF + 1];
-    for (int t = threadIdx.x; t < OCC_NF * (OCC_MAXF + 1) + 2 * OCC_NF + 1; t += 256) red[t] = 0.f;
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
+    // every parameter has ONE owner wave: plain stores into the block's LDS row, then the block's row of `partial`
 #pragma unroll
     for (int j = 0; j < OCC_NF; ++j) {
 #pragma unroll
-        for (int f = 0; f <= OCC_MAXF; ++f) {
-            const float v = wave_sum(gW1[j][f]);
-            if (lane == 0 && f <= a.F) atomicAdd(&red[j * (a.F + 1) + f], v);
+        for (int k = 0; k < OCC_FG; ++k) {
+            const float t = wave_sum(g[j][k]);
+            if (v == 0 && f0 + k < a.F) red[j * F1 + 1 + f0 + k] = t;
         }
-        const float v1 = wave_sum(gb1[j]), v2 = wave_sum(gW2[j]);
-        if (lane == 0) { atomicAdd(&red[nW1 + j], v1); atomicAdd(&red[nW1 + OCC_NF + j], v2); }
+        const float t0 = wave_sum(g0[j]), t1 = wave_sum(gb1[j]), t2 = wave_sum(gW2[j]);
+        if (v == 0 && fg == 0) { red[j * F1] = t0; red[nW1 + j] = t1; red[nW1 + OCC_NF + j] = t2; }
     }
     {
-        const float v3 = wave_sum(gb2);
-        if (lane == 0) atomicAdd(&red[nW1 + 2 * OCC_NF], v3);
+        const float t3 = wave_sum(gb2);
+        if (v == 0 && fg == 0) red[nW1 + 2 * OCC_NF] = t3;
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < nW1 + 2 * OCC_NF + 1; t += 256) atomicAdd(dparams + t, red[t]);
+    const int nparams = nW1 + 2 * OCC_NF + 1;
+    for (int t = threadIdx.x; t < nparams; t += 256) partial[(long)blockIdx.x * nparams + t] = red[t];
+}
+
+// dparams[t] = sum over the rows of `partial` (one per block of occ_bwd_mlp_kernel), in row order
+__global__ __launch_bounds__(256) void occ_bwd_params_kernel(const float* __restrict__ partial, int nrows, int nparams,
+                                                             float* __restrict__ dparams) {
+    __shared__ float red[4];
+    const int t = blockIdx.x;
+    float acc = 0.f;
+    for (int r = threadIdx.x; r < nrows; r += 256) acc += partial[(long)r * nparams + t];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) dparams[t] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 }  // namespace
@@ -599,9 +634,15 @@ extern "C" int rgbd_occlusion_accum_bwd(const float* vol, const float* W1, const
     RGBD_CHECK_LAUNCH("occ_bwd_dw_kernel");
     occ_bwd_scan_kernel<<<(unsigned)(((long)B * HW + 255) / 256), 256, 0, st>>>(a, s, dw_ws, ds_ws);
     RGBD_CHECK_LAUNCH("occ_bwd_scan_kernel");
-    occ_bwd_mlp_kernel<<<(unsigned)((nv + 255) / 256 < 512 ? (nv + 255) / 256 : 512), 256, 0, st>>>(a, vol, W1, b1, W2, s,
-                                                                                                         ds_ws, w, dfeat, dvol, dparams);
+    // dw_ws has been consumed by the scan: its first rows now take the blocks' parameter-gradient sums
+    const long nchunks = (nv + 63) / 64;
+    long nblocks = nchunks < 1024 ? nchunks : 1024;
+    if (nblocks * nparams > nv) nblocks = nv / nparams;          // (tiny volumes: as many rows as dw_ws holds)
+    RGBD_REQUIRE(nblocks >= 1, "rgbd_occlusion_accum_bwd: volume smaller than the parameter-gradient row (%ld < %d)", nv, nparams);
+    occ_bwd_mlp_kernel<<<(unsigned)nblocks, 256, 0, st>>>(a, vol, W1, b1, W2, s, ds_ws, w, dfeat, dvol, dw_ws);
     RGBD_CHECK_LAUNCH("occ_bwd_mlp_kernel");
+    occ_bwd_params_kernel<<<nparams, 256, 0, st>>>(dw_ws, (int)nblocks, nparams, dparams);
+    RGBD_CHECK_LAUNCH("occ_bwd_params_kernel");
     return 0;
 }
 
