@@ -84,8 +84,16 @@ def pmc_traffic(kernel):
     ks = prof["kernels"]
     base = kernel.split("<")[0]
     width = kernel.split("<")[1].rstrip(">") if "<" in kernel else ""
+    # the launch-profile labels fold the upsampling variant into one name and tag the epilogue variants of the pipelined 3x3
+    # kernel (template <BN, UPS, KO, EPI>: "<128>" = EPI 0, "<128,actgrad>" = 1, "<128,stats>" = 2)
+    epi = None
+    if base == "conv3x3_sp_kernel":
+        width, _, tag = width.partition(",")
+        epi = {"": "0", "actgrad": "1", "stats": "2"}.get(tag)
     tot = cnt = 0
     for name, v in ks.items():
+        if epi is not None and not name.endswith(f", {epi}>"):
+            continue
         if name.startswith(base + "<" + width) or name == kernel:
             tot += v["hbm_bytes_per_launch"] * v["launches"]
             cnt += v["launches"]

@@ -2017,7 +2017,7 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
                 else if (vi == 1) conv3x3_sp_kernel<64, true, 0, 2><<<(unsigned)grid, 512, lds_sp, st>>>(a);
                 else              conv3x3_sp_kernel<64, false, 0, 2><<<(unsigned)grid, 512, lds_sp, st>>>(a);
                 RGBD_CHECK_LAUNCH("conv3x3_sp_kernel<stats>");
-                g_last_conv_kernel = wide ? "conv3x3_sp_kernel<128>" : "conv3x3_sp_kernel<64>";
+                g_last_conv_kernel = wide ? "conv3x3_sp_kernel<128,stats>" : "conv3x3_sp_kernel<64,stats>";
                 return 0;
             }
             if (mask_y) {
@@ -2032,7 +2032,7 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
                 if (wide) conv3x3_sp_kernel<128, false, 0, 1><<<(unsigned)grid, 512, lds_sp, st>>>(a);
                 else      conv3x3_sp_kernel<64, false, 0, 1><<<(unsigned)grid, 512, lds_sp, st>>>(a);
                 RGBD_CHECK_LAUNCH("conv3x3_sp_kernel<masked>");
-                g_last_conv_kernel = wide ? "conv3x3_sp_kernel<128>" : "conv3x3_sp_kernel<64>";
+                g_last_conv_kernel = wide ? "conv3x3_sp_kernel<128,actgrad>" : "conv3x3_sp_kernel<64,actgrad>";
                 return 0;
             }
             if (vi == 3)      conv3x3_sp_kernel<128, true><<<(unsigned)grid, 512, lds_sp, st>>>(a);

@@ -41,7 +41,7 @@ def main(fetch_dir, write_dir, out, command):
                "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE counts 128-B requests "
                              "as 64 B; unit KB)",
                "kernels": kernels}, open(out, "w"), indent=1)
-    for k in ("conv3x3_sp_kernel<128, false, 0>", "conv_wgrad_multi_kernel<9, true>"):
+    for k in ("conv3x3_sp_kernel<128, false, 0, 0>", "conv_wgrad_multi_kernel<9, true>"):
         if k in kernels:
             print(k, kernels[k])
 
