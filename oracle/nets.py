@@ -193,7 +193,7 @@ def synthesis_chans(ch, nb):
 def max_stage_of(p, outs_prefix):
     """Stage ceiling of a parameter set: 2 * blocks + 5 (17 for the reference's six, net.py:166,433)."""
     n = 0
-    while f"{outs_prefix}/{n}/c/W" in p:
+    while f"{outs_prefix}/{n}/c/W" in p or f"{outs_prefix}/{n}/W" in p:      # (spectral-norm links: <layer>/W)
         n += 1
     return 2 * n + 5
 
