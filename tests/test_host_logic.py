@@ -140,6 +140,30 @@ def test_alpha_override_replaces_the_blend_factor_only():
     assert net._split_stage(16.9999999999, 17)[0] == 16
 
 
+def test_block_plan_of_the_progressive_networks():
+    """Six blocks / stage ceiling 17 for the reference's 128 px networks (net.py:166,175-180,433); max_resolution=256 adds
+    the block it keeps commented out (net.py:181,192: ch//8 channels), ceiling 19.  Engine and oracle agree on the plan."""
+    from rgbd_gan_amd import net
+    from oracle import nets as onets
+    assert net._block_count(128) == 6 and net._block_count(256) == 7 and net._block_count(512) == 8
+    assert net._synthesis_chans(256, 6) == [(256, 256)] * 4 + [(128, 256), (64, 128)]
+    assert net._synthesis_chans(512, 7)[4:] == [(256, 512), (128, 256), (64, 128)]
+    for res, ch in ((128, 256), (256, 512)):
+        nb = net._block_count(res)
+        assert onets.block_count(res) == nb and onets.synthesis_chans(ch, nb) == net._synthesis_chans(ch, nb)
+    gp = onets.init_stylegan(256, max_resolution=256)
+    dp = onets.init_discriminator(256, max_resolution=256)
+    assert onets.max_stage_of(gp, "gen/outs") == 19 and onets.max_stage_of(dp, "ins") == 19
+    assert onets.max_stage_of(onets.init_discriminator_sn(256), "ins") == 17
+    assert tuple(gp["gen/blocks/6/c0/c/W"].shape) == (32, 64, 3, 3) and tuple(dp["blocks/6/c1/c/W"].shape) == (64, 64, 3, 3)
+    for bad in (64, 192, 100):
+        try:
+            net._block_count(bad)
+        except ValueError:
+            continue
+        raise AssertionError(f"max_resolution={bad} accepted")
+
+
 def test_param_store_fused_views_share_storage_and_gradient():
     """ParamStore.fused: back-to-back parameters as one leaf (the style scale / shift affines served by one launch)."""
     import torch
