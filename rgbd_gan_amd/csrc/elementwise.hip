@@ -606,7 +606,10 @@ __global__ __launch_bounds__(256) void from_planes_kernel(const float* __restric
                                                           unsigned short* __restrict__ y, int B, int HW, int C,
                                                           float wscale, int act, float slope) {
     // A thread keeps ONE octet of output channels for its whole walk (the grid stride is a multiple of C/8), so its
-    // 8 x KP weights and 8 biases sit in registers; four pixels' plane values are requested before any is used.
+    // 8 x KP weights and 8 biases sit in registers; NU pixels' plane values are requested before any is used (four, or
+    // two with four planes: 64 registers, so that a block still fits on a SIMD next to the weight-gradient kernel's two
+    // 224-register waves -- at 78 the launch waited for that kernel to finish, 375 us instead of 27).
+    constexpr int NU = KP == 4 ? 2 : 4;
     const int cvec = C >> 3;
     const long nvec = (long)B * HW * cvec;
     const long e0 = (long)blockIdx.x * 256 + threadIdx.x;
@@ -619,10 +622,10 @@ __global__ __launch_bounds__(256) void from_planes_kernel(const float* __restric
 #pragma unroll
         for (int k = 0; k < KP; ++k) wr[j][k] = w[(cv * 8 + j) * KP + k] * wscale;
     }
-    for (long e = e0; e < nvec; e += 4 * stride) {
-        float xin[4][KP];
+    for (long e = e0; e < nvec; e += NU * stride) {
+        float xin[NU][KP];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NU; ++u) {
             const long eu = e + u * stride;
             const long pix = (eu < nvec ? eu : e) / cvec;
             const int b = (int)(pix / HW);
@@ -631,7 +634,7 @@ __global__ __launch_bounds__(256) void from_planes_kernel(const float* __restric
             for (int k = 0; k < KP; ++k) xin[u][k] = x[((long)b * KP + k) * HW + p];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NU; ++u) {
             const long eu = e + u * stride;
             if (eu < nvec) {
                 float r[8];
@@ -856,10 +859,13 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
     const float* wr = w + (long)(nok ? n0 + r : 0) * K;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc = zero;
-    for (int k0 = kbeg; k0 < kend; k0 += 128) {    // 8 K-steps of 16 per chunk: 16 independent loads in flight
-        f32x4 a[8], b[8];
+    // NS K-steps of 16 per chunk: 16 independent loads in flight; the ragged-K variant takes half chunks (8 loads) to
+    // stay under 64 registers: at 92 its blocks could not start beside the other stream's weight-gradient kernel
+    constexpr int NS = VEC ? 8 : 4;
+    for (int k0 = kbeg; k0 < kend; k0 += 16 * NS) {
+        f32x4 a[NS], b[NS];
 #pragma unroll
-        for (int s2 = 0; s2 < 8; ++s2) {
+        for (int s2 = 0; s2 < NS; ++s2) {
             const int kb = k0 + 16 * s2 + 4 * q;
             if (VEC) {
                 const int kc = kb < kend ? kb : 0;
@@ -889,7 +895,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
             }
         }
 #pragma unroll
-        for (int s2 = 0; s2 < 8; ++s2)
+        for (int s2 = 0; s2 < NS; ++s2)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s2][j], b[s2][j], acc, 0, 0, 0);
     }
@@ -1376,7 +1382,7 @@ extern "C" int rgbd_from_planes(const float* x, const float* w, const float* bia
     RGBD_REQUIRE(x && w && y, "rgbd_from_planes: null pointer");
     RGBD_REQUIRE((KP == 3 || KP == 4) && C % 8 == 0 && B > 0 && HW > 0, "rgbd_from_planes: bad shape KP=%d C=%d", KP, C);
     const long nvec = (long)B * HW * C / 8;
-    const int blocks = (int)min((long)8192, (nvec + 1023) / 1024);       // four items per thread: the kernel's unroll
+    const int blocks = (int)min((long)8192, (nvec + 1023) / 1024);       // four items per thread (two rounds with four planes)
     hipStream_t st = (hipStream_t)stream;
     if (KP == 3) from_planes_kernel<3><<<blocks, 256, 0, st>>>(x, w, bias, (unsigned short*)y, B, HW, C, wscale, act, slope);
     else         from_planes_kernel<4><<<blocks, 256, 0, st>>>(x, w, bias, (unsigned short*)y, B, HW, C, wscale, act, slope);

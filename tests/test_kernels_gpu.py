@@ -755,7 +755,8 @@ def test_pool_and_unpool_lrelu_kernels():
     dz = kernels.unpool2_lrelu_bwd(dpd, yd, (B, H, H, C), bias_grad=bg, bias_grad2=bg2)
     torch.testing.assert_close(dz.float().cpu(), bf16_round(0.25 * up * mask), atol=1e-6, rtol=1e-6)
     torch.testing.assert_close(bg.cpu(), dz.float().cpu().reshape(-1, C).sum(0), atol=1e-3, rtol=1e-4)
-    assert torch.equal(bg2.cpu() - 1.0, (bg.cpu() + 1.0) - 1.0)
+    # (four blocks add to every address in arrival order, on top of different start values: equal to fp32 rounding only)
+    torch.testing.assert_close(bg2.cpu() - 1.0, bg.cpu(), atol=1e-4, rtol=1e-5)
     dz0 = kernels.unpool2_lrelu_bwd(dpd, None, (B, H, H, C))
     torch.testing.assert_close(dz0.float().cpu(), bf16_round(0.25 * up), atol=1e-6, rtol=1e-6)
     # pool, masked and plain; adjointness <pool(x), dp> == <x, unpool(dp)>
