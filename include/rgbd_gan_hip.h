@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RGBD_ABI_VERSION 11
+#define RGBD_ABI_VERSION 12
 
 int rgbd_abi_version(void);
 const char* rgbd_last_error(void);
@@ -389,7 +389,10 @@ int rgbd_occlusion_accum_bwd(const float* vol, const float* W1, const float* b1,
  *   3-tensor elementwise pass.  colsum (NULL or Cout floats, ACCUMULATED with fp32 atomics): the weighted column sums
  *   sum_b row_scale[b] sum_pixels y -- the bias gradient of that layer (row_scale NULL = 1; per-sample seeds of
  *   updater.py:405-422 otherwise).  Runs on the pipelined 3x3 kernel: H, W multiples of 16, Cin, Cout multiples of 64
- *   (rgbd_conv3x3_actgrad_supported tells, as a pure function of the shape).
+ *   (rgbd_conv3x3_actgrad_supported tells, as a pure function of the shape).  y2 / row_scale2 (both or neither): a
+ *   second output y2 = y + row_scale2[b] * act_y, i.e. rgbd_axpy_rows_bf16(y, act_y, row_scale2) -- in the R1 double
+ *   backward the weight-gradient operand dd h0 + s_b h0 of the convolution behind (updater.py:405-422 folded in) -- from
+ *   the tile the epilogue holds, instead of a 3-tensor pass.
  * rgbd_conv2d_fprop_stats_bf16: the generator's conv -> bias -> leaky ReLU (net.py:148-153,157-160; upsample != 0: nearest
  *   2x in front, rescale.py:4-5) as rgbd_conv2d_fprop_bf16 computes it, 3x3 pad 1 on output images that are multiples of
  *   16x16, PLUS the instance-norm statistics of the AdaIN that follows (adain.py:62-63): stats (B,Cout,2) int64, ZEROED
@@ -406,8 +409,8 @@ int rgbd_conv2d_dgrad_bf16(const void* dy, const void* wp_dgrad, const void* res
                            int Cin, int Cout, int K, int pad, int sum_pool2, void* workspace, void* stream);
 int rgbd_conv3x3_actgrad_supported(int B, int H, int W, int Cin, int Cout);
 int rgbd_conv3x3_actgrad_bf16(const void* x, const void* wp, const void* residual, const void* act_y, float slope,
-                              float* colsum, const float* row_scale, void* y, int B, int H, int W, int Cin, int Cout,
-                              void* stream);
+                              float* colsum, const float* row_scale, void* y, void* y2, const float* row_scale2, int B,
+                              int H, int W, int Cin, int Cout, void* stream);
 int rgbd_conv2d_fprop_stats_bf16(const void* x, const void* wp, const float* bias, void* y, int64_t* stats, int B, int Hin,
                                  int Win, int Cin, int Cout, int upsample, int lrelu_channels, float slope, void* stream);
 int rgbd_adain_apply_fixed(const void* x, const float* scale, const float* shift, void* y, const int64_t* stats, float* mean,

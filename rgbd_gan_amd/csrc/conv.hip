@@ -49,6 +49,8 @@ struct ConvArgs {
     const unsigned short* mask_y;
     float* colsum;
     const float* row_scale;
+    unsigned short* y2;             // MASKED, optional second output: y + row_scale2[b] * mask_y (what was stored, plus the
+    const float* row_scale2;        //   per-sample multiple of the activation tile the epilogue holds anyway)
     // pipelined 3x3 kernel, STATS variant: stats[b][co][0..1] += (sum y, sum y^2) over the image's pixels, as 64-bit
     // integers in units of 2^-32 (integer adds commute: the result does not depend on which workgroup adds first)
     long long* stats;
@@ -949,6 +951,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
         const int co = n0 + wave_co + 16 * q;            // this lane's 16 consecutive output channels
         const bool act = co < a.lrelu_ch;
         const float cw = MASKED && a.colsum && a.row_scale ? a.row_scale[b] : 1.f;
+        const float cw2 = MASKED && a.y2 ? a.row_scale2[b] : 0.f;
         if (STATS && b != st_b) {
             if (st_b >= 0) stats_flush();
             st_b = b;
@@ -1011,10 +1014,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
 #pragma unroll
                 for (int k2 = 0; k2 < 16; ++k2) v[k2] = v[k2] > 0.f ? v[k2] : v[k2] * a.slope;
             }
+            u32x4 mk[MASKED ? 2 : 1];
             if (MASKED) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const u32x4 mm = *reinterpret_cast<const u32x4*>(a.mask_y + o + 8 * h);
+                    mk[h] = mm;
 #pragma unroll
                     for (int w2 = 0; w2 < 4; ++w2) {
                         v[8 * h + 2 * w2] = bf16_lo(mm[w2]) > 0.f ? v[8 * h + 2 * w2] : v[8 * h + 2 * w2] * a.slope;
@@ -1032,6 +1037,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
                     for (int w2 = 0; w2 < 4; ++w2) {
                         cs[8 * h + 2 * w2] += cw * bf16_lo(out[w2]);
                         cs[8 * h + 2 * w2 + 1] += cw * bf16_hi(out[w2]);
+                    }
+                    if (a.y2) {         // rgbd_axpy_rows_bf16 of (what was stored, the activation tile): the injection operand
+                        u32x4 o2;
+#pragma unroll
+                        for (int w2 = 0; w2 < 4; ++w2)
+                            o2[w2] = pack_bf16x2(bf16_lo(out[w2]) + cw2 * bf16_lo(mk[h][w2]),
+                                                 bf16_hi(out[w2]) + cw2 * bf16_hi(mk[h][w2]));
+                        *reinterpret_cast<u32x4*>(a.y2 + o + 8 * h) = o2;
                     }
                 }
                 if (STATS) {
@@ -1871,7 +1884,8 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
                            void* y, int B, int Hin, int Win, int Cin, int Cout, int KH, int KW, int pad,
                            int upsample, int lrelu_channels, float slope, void* workspace, void* stream, int pool_sum,
                            void* y_pooled = nullptr, const void* mask_y = nullptr, float* colsum = nullptr,
-                           const float* row_scale = nullptr, long long* stats = nullptr) {
+                           const float* row_scale = nullptr, long long* stats = nullptr, void* y2 = nullptr,
+                           const float* row_scale2 = nullptr) {
     RGBD_REQUIRE(x && wp && y, "rgbd_conv2d_fprop_bf16: null pointer");
     RGBD_REQUIRE(B > 0 && Hin > 0 && Win > 0 && KH > 0 && KW > 0 && pad >= 0, "rgbd_conv2d_fprop_bf16: bad shape");
     RGBD_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0,
@@ -1905,6 +1919,7 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
     a.ypool = (unsigned short*)y_pooled;
     a.mask_y = (const unsigned short*)mask_y; a.colsum = colsum; a.row_scale = row_scale;
     a.stats = stats;
+    a.y2 = (unsigned short*)y2; a.row_scale2 = row_scale2;
     if (stats) {
         RGBD_REQUIRE(KH == 3 && KW == 3 && pad == 1 && a.Hout % 16 == 0 && a.Wout % 16 == 0 && !pool_sum && !y_pooled &&
                      !mask_y && !g_force_gather && g_conv_variant != 1,
@@ -2138,12 +2153,13 @@ extern "C" int rgbd_conv3x3_actgrad_supported(int B, int H, int W, int Cin, int 
 }
 
 extern "C" int rgbd_conv3x3_actgrad_bf16(const void* x, const void* wp, const void* residual, const void* act_y, float slope,
-                                         float* colsum, const float* row_scale, void* y, int B, int H, int W, int Cin,
-                                         int Cout, void* stream) {
+                                         float* colsum, const float* row_scale, void* y, void* y2, const float* row_scale2,
+                                         int B, int H, int W, int Cin, int Cout, void* stream) {
     RGBD_REQUIRE(act_y, "rgbd_conv3x3_actgrad_bf16: null pointer");
     RGBD_REQUIRE(colsum || !row_scale, "rgbd_conv3x3_actgrad_bf16: row_scale without colsum");
+    RGBD_REQUIRE(!y2 == !row_scale2, "rgbd_conv3x3_actgrad_bf16: y2 and row_scale2 come together");
     return conv_fprop_impl(x, wp, nullptr, residual, y, B, H, W, Cin, Cout, 3, 3, 1, 0, 0, slope, nullptr, stream, 0, nullptr,
-                           act_y, colsum, row_scale);
+                           act_y, colsum, row_scale, nullptr, y2, row_scale2);
 }
 
 extern "C" int rgbd_conv2d_fprop_stats_bf16(const void* x, const void* wp, const float* bias, void* y, int64_t* stats, int B,

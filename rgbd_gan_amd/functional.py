@@ -237,17 +237,22 @@ class _ConvFprop(torch.autograd.Function):
     times lrelu'(.) of that activation output, in the same epilogue."""
 
     @staticmethod
-    def forward(ctx, x, w, layer, ups, residual=None, mask_y=None):
+    def forward(ctx, x, w, layer, ups, residual=None, mask_y=None, operand_scale=None):
+        """operand_scale (with mask_y): -> (y, y + operand_scale[b] * mask_y), the second tensor (not differentiable) being
+        the injection operand of the convolution that reads mask_y in the forward pass (ResidualTie.c1_operand)."""
         ctx.layer, ctx.ups, ctx.masked = layer, ups, mask_y is not None
         ctx.save_for_backward(x, w)
         wf, _ = layer.packed()
         residual = residual.contiguous() if residual is not None else None
         if mask_y is not None:
-            return kernels.conv3x3_actgrad(x.contiguous(), wf, mask_y, residual=residual)
+            out = kernels.conv3x3_actgrad(x.contiguous(), wf, mask_y, residual=residual, operand_scale=operand_scale)
+            if operand_scale is not None:
+                ctx.mark_non_differentiable(out[1])
+            return out
         return kernels.conv2d_fprop(x.contiguous(), wf, layer.K, layer.K, layer.pad, upsample=ups, residual=residual)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *unused):
         if ctx.masked:
             raise NotImplementedError("third-order derivatives through the conv engine are not supported")
         x, w = ctx.saved_tensors
@@ -261,7 +266,7 @@ class _ConvFprop(torch.autograd.Function):
                 _wgrad_derived_deferred(x, dy, w, ctx.layer, ctx.ups)
             else:
                 dw = _ConvWgrad.apply(x, dy, ctx.layer, ctx.ups)
-        return dx, dw, None, None, (dy if ctx.needs_input_grad[4:5] == (True,) else None), None
+        return dx, dw, None, None, (dy if ctx.needs_input_grad[4:5] == (True,) else None), None, None
 
 
 class _ConvDgrad(torch.autograd.Function):
@@ -311,7 +316,12 @@ class _ConvDgrad(torch.autograd.Function):
                     tie.fused_mask.shape[3] == w.shape[0] and kernels.conv3x3_actgrad_supported(*ddx.shape, w.shape[0]):
                 # this node's dy is the OUTPUT of the main conv's fused (dgrad, activation-gradient) node, whose backward
                 # masks what arrives with lrelu'(h0): applied here, in the epilogue of the conv that produces it
-                g_dy = _ConvFprop.apply(ddx, w, ctx.layer, ctx.ups, None, tie.fused_mask)
+                if _INJECT is not None:
+                    # ... and the same epilogue forms the main conv's injection operand dd h0 + s_b h0 (its axpy_rows pass)
+                    g_dy, op2 = _ConvFprop.apply(ddx, w, ctx.layer, ctx.ups, None, tie.fused_mask, _INJECT)
+                    tie.c1_operand = ((g_dy.data_ptr(), tie.fused_mask.data_ptr()), op2)
+                else:
+                    g_dy = _ConvFprop.apply(ddx, w, ctx.layer, ctx.ups, None, tie.fused_mask)
                 tie.dd_premasked = True
             else:
                 g_dy = _ConvFprop.apply(ddx, w, ctx.layer, ctx.ups)
@@ -328,6 +338,8 @@ class _ConvDgrad(torch.autograd.Function):
                 if tie is not None and role in (ROLE_SHORTCUT, ROLE_ENTRY) and tie.operand is not None \
                         and tie.operand[0] == key:
                     operand, tie.operand = tie.operand[1], None      # the block's other entry conv already formed it
+                elif tie is not None and role == ROLE_MAIN and tie.c1_operand is not None and tie.c1_operand[0] == key:
+                    operand, tie.c1_operand = tie.c1_operand[1], None      # ... or the entry conv's double-backward epilogue
                 else:
                     operand = kernels.axpy_rows(ddx, x_fwd, _INJECT)
                     if tie is not None and role in (ROLE_SHORTCUT, ROLE_ENTRY):
@@ -795,7 +807,7 @@ class ResidualTie:
       taken in the epilogue of c1's input gradient (rgbd_conv3x3_actgrad_bf16; entry_bias / entry_ptr are left by c0's
       forward) and c0's backward skips its activation-gradient pass; fused_mask / dd_premasked: the same one order up --
       in the R1 double backward c0's fprop of dd x applies lrelu'(h0) in its epilogue and the fused node's backward
-      skips its own mask.
+      skips its own mask; c1_operand: that epilogue's second output dd h0 + s_b h0, c1's injection operand.
 
     Every hand-over has a fallback: if the consumer ran first it flags that, and the producer then returns its term to
     autograd the ordinary way (the engine adds)."""
@@ -804,7 +816,7 @@ class ResidualTie:
         self.bias, self.done = bias, False
         self.dx_sc = self.g_sc = self.operand = None
         self.entry_seen = self.main_seen = False
-        self.entry_bias = self.entry_ptr = self.fused_mask = None
+        self.entry_bias = self.entry_ptr = self.fused_mask = self.c1_operand = None
         self.premasked = self.dd_premasked = False
 
     def usable(self, inject):

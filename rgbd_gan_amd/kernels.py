@@ -278,10 +278,11 @@ def conv3x3_actgrad_supported(B, H, W, Cin, Cout):
     return bool(_lib.load().rgbd_conv3x3_actgrad_supported(int(B), int(H), int(W), int(Cin), int(Cout)))
 
 
-def conv3x3_actgrad(x, wp, act_y, residual=None, bias_grad=None, row_scale=None, slope=0.2):
+def conv3x3_actgrad(x, wp, act_y, residual=None, bias_grad=None, row_scale=None, slope=0.2, operand_scale=None):
     """(conv3x3_pad1(x, wp) + residual) * lrelu'(act_y) in one launch; x (B,H,W,Cin) bf16, wp [9][Cout][Cin] bf16 (the fprop
     image, or the dgrad image of a Cout->Cin convolution), act_y / residual (B,H,W,Cout) bf16.  bias_grad (Cout fp32,
-    accumulated): += sum_b row_scale[b] * column sums of the result (row_scale None = 1)."""
+    accumulated): += sum_b row_scale[b] * column sums of the result (row_scale None = 1).  operand_scale (B,) fp32:
+    -> (y, y + operand_scale[b] * act_y), the second tensor being axpy_rows(y, act_y, operand_scale)."""
     _chk(x, BF16, "x"); _chk(wp, BF16, "wp"); _chk(act_y, BF16, "act_y"); _chk(residual, BF16, "residual")
     _chk(bias_grad, F32, "bias_grad"); _chk(row_scale, F32, "row_scale")
     B, H, W, Cin = x.shape
@@ -292,17 +293,22 @@ def conv3x3_actgrad(x, wp, act_y, residual=None, bias_grad=None, row_scale=None,
         raise RuntimeError("conv3x3_actgrad: residual shape mismatch")
     if bias_grad is not None and bias_grad.numel() != Cout or (row_scale is not None and row_scale.numel() != B):
         raise RuntimeError("conv3x3_actgrad: bias_grad needs Cout entries, row_scale B")
+    _chk(operand_scale, F32, "operand_scale")
+    if operand_scale is not None and operand_scale.numel() != B:
+        raise RuntimeError("conv3x3_actgrad: operand_scale needs B entries")
     y = torch.empty(B, H, W, Cout, dtype=BF16, device=x.device)
+    y2 = torch.empty_like(y) if operand_scale is not None else None
     lib = _lib.load()
     flops = 2.0 * B * H * W * Cout * Cin * 9
-    nbytes = 2.0 * (x.numel() + 2 * y.numel() + wp.numel() + (residual.numel() if residual is not None else 0))
+    nbytes = 2.0 * (x.numel() + (3 if y2 is not None else 2) * y.numel() + wp.numel() +
+                    (residual.numel() if residual is not None else 0))
     rc = _timed(lambda: _conv_kernel_name(f"actgrad {H}x{W} {Cin}->{Cout}{' res' if residual is not None else ''}"),
                 flops, nbytes,
                 lambda: lib.rgbd_conv3x3_actgrad_bf16(_ptr(x), _ptr(wp), _ptr(residual), _ptr(act_y), float(slope),
-                                                      _ptr(bias_grad), _ptr(row_scale), _ptr(y), B, H, W, Cin, Cout,
-                                                      _stream()))
+                                                      _ptr(bias_grad), _ptr(row_scale), _ptr(y), _ptr(y2),
+                                                      _ptr(operand_scale), B, H, W, Cin, Cout, _stream()))
     _lib.check(rc, "rgbd_conv3x3_actgrad_bf16")
-    return y
+    return y if y2 is None else (y, y2)
 
 
 def conv2d_fprop_stats(x, wp, bias, upsample=False, lrelu_channels=0, slope=0.2):

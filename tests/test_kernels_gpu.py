@@ -584,6 +584,12 @@ def test_conv3x3_actgrad_matches_conv_then_activation_gradient(B, S, Cin, Cout, 
     ref_b = (one.float() * wts[:, None, None, None]).sum(dim=(0, 1, 2))
     torch.testing.assert_close(bias_one - 3.0, ref_b, atol=1e-3 * float(ref_b.abs().max()) + 1e-3, rtol=1e-3)
     assert torch.equal(kernels.conv3x3_actgrad(x, wf, act_y, residual=r), one)       # no column sums: same image
+    # second output: the stored tensor plus a per-sample multiple of the activation tile == the axpy_rows pass on both
+    sc = (torch.rand(B, generator=g) - 0.5).to(dev())
+    one_b, op = kernels.conv3x3_actgrad(x, wf, act_y, residual=r, operand_scale=sc)
+    assert torch.equal(one_b, one)
+    torch.testing.assert_close(op.float(), kernels.axpy_rows(one, act_y, sc).float(), atol=1e-2, rtol=8e-3)
+    assert float((op.float() - kernels.axpy_rows(one, act_y, sc).float()).abs().max()) <= float(op.float().abs().max()) * 2 ** -7
     # as an input gradient: dy (B,S,S,Cout) through the dgrad image, masked by an activation output of x's shape
     dy = torch.randn(B, S, S, Cout, generator=g).to(dev()).to(torch.bfloat16)
     h0 = torch.randn(B, S, S, Cin, generator=g).to(dev()).to(torch.bfloat16)
