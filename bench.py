@@ -31,6 +31,7 @@ if ROOT not in sys.path:
 # so it EXECUTES 3 F_G + 7 F_D; the whole-step roofline fraction is reported on executed work.
 STEP_GFLOP_PER_IMAGE = 296.6 - 4 * 24.11
 MFMA_BF16_PEAK_TFLOPS = 2500.0
+MFMA_FP8_PEAK_TFLOPS = 5000.0   # dense, block-scaled K = 128 form (MI355X_MICROARCH.md, Matrix cores)
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
@@ -45,8 +46,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--res256", action="store_true",
-                    help="BASELINE configuration 5's networks (ch=512, the 256x256 block, stage 12, per-GPU batch 16) with "
-                         "bf16 convs -- the fp8 conv kernels of that configuration are not built; never the default line")
+                    help="BASELINE configuration 5's networks (ch=512, the 256x256 block, stage 12, per-GPU batch 16); with "
+                         "--fp8 on its MXFP8 conv kernels, else on the bf16 ones; never the default line")
+    ap.add_argument("--fp8", action="store_true",
+                    help="conv_dtype: mxfp8 -- fprop / dgrad of the 3x3 convolutions on block-scaled fp8 operands "
+                         "(v_mfma_scale_f32_16x16x128_f8f6f4), weight gradients on the bf16 kernels")
     ap.add_argument("--arrangements", action="store_true",
                     help="also time the single-stream arrangement on the same box (extra key, never `value`)")
     return ap.parse_args()
@@ -224,6 +228,8 @@ def main():
         config.ch, config.max_resolution, config.max_stage = 512, 256, 13
         B = args.batch or 16
         side, extra = 256, {"fixed_stage": 12.0}
+    if args.fp8:
+        config.conv_dtype = "mxfp8"
     np.random.seed(2 + comm.rank)
     torch.manual_seed(comm.rank)
     images = np.random.RandomState(comm.rank).randint(0, 256, (256 if side == 128 else 64, 3, side, side)).astype("uint8")
@@ -263,14 +269,17 @@ def main():
     line = {
         "metric": "img/s (G+D+3D-loss step) at 128x128", "value": round(value, 2), "unit": "img/s",
         "n_gpus": comm.size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp8" if args.fp8 else "bf16",
+        "data": "synthetic",
         "config": {"workload": (f"{os.path.basename(args.config)} stage {upd.stage:.2f} (64x64), DeepVoxelsUpdater.update_core, "
                                 f"voxel generator 32^3 x 32 features -> frustum 56x64x64 -> occlusion compositing -> 2-D "
                                 f"renderer, rotation loss on, R1 on") if deepvoxels else
                                (f"{os.path.basename(args.config)} stage {upd.stage:.2f} ({side}x{side}), RGBDUpdater.update_core, "
                                 f"StyleGAN ch={config.ch}, rotation+occlusion loss on, R1 on"
-                                + (", max_resolution=256 (BASELINE configuration 5's networks; bf16 convs, its fp8 kernels are "
-                                   "not built)" if args.res256 else "")),
+                                + (", max_resolution=256 (BASELINE configuration 5's networks)" if args.res256 else "")
+                                + (", conv_dtype mxfp8: 3x3 fprop / dgrad on e4m3 operands with E8M0 scales per 32 channels "
+                                   "(fp32 accumulate, bf16 activations in HBM), weight gradients and the layers the fp8 kernel "
+                                   "does not cover on bf16" if args.fp8 else "")),
                    "per_gpu_batch": B, "global_batch": B * comm.size, "parallelism": f"dp{comm.size}",
                    "arrangement": "two streams, one graph per phase" if getattr(upd, "concurrent_phases", False) else "one stream",
                    # True only if the timed steps were replays of captured HIP graphs (a refused capture is fatal in the
@@ -321,9 +330,10 @@ def main():
             dom = max(summ, key=lambda k: summ[k][1])
             n, t, f, b = summ[dom]
             traffic, provenance = pmc_traffic(dom)
+            peak = MFMA_FP8_PEAK_TFLOPS if "mxfp8" in dom else MFMA_BF16_PEAK_TFLOPS
             line["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(f / t / 1e12, 2),
-                                "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": round(f / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                                "peak": peak, "unit": "TFLOP/s",
+                                "frac": round(f / t / 1e12 / peak, 4),
                                 "traffic": traffic, "traffic_provenance": provenance, "launches": n,
                                 "avg_launch_us": round(t / n * 1e6, 2), "flops_per_launch_avg": f / n, "timing": timing}
         line["kernels"] = table

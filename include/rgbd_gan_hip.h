@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RGBD_ABI_VERSION 12
+#define RGBD_ABI_VERSION 13
 
 int rgbd_abi_version(void);
 const char* rgbd_last_error(void);
@@ -415,6 +415,55 @@ int rgbd_conv2d_fprop_stats_bf16(const void* x, const void* wp, const float* bia
                                  int Win, int Cin, int Cout, int upsample, int lrelu_channels, float slope, void* stream);
 int rgbd_adain_apply_fixed(const void* x, const float* scale, const float* shift, void* y, const int64_t* stats, float* mean,
                            float* rstd, int B, int HW, int C, int ld, float eps, void* stream);
+
+/* ------------------------------------------------------------------ MXFP8 convolutions (BASELINE configuration 5)
+ * The 3x3 convolutions of the 256x256 networks -- the blocks the reference keeps commented out at net.py:181-183,192-194,
+ * again pggan.py:13-24 / cuDNN in the reference -- on the block-scaled fp8 matrix instruction of gfx950
+ * (v_mfma_scale_f32_16x16x128_f8f6f4, fp32 accumulate): fprop and dgrad; weight gradients stay on the bf16 kernels.
+ *
+ * Operand format (OCP microscaling MXFP8, element type E4M3): along the REDUCTION index -- the channels of an NHWC
+ * activation tensor, Cin of the fprop weight image, Cout of the dgrad image -- every 32 consecutive elements share one E8M0
+ * scale byte s: value = e4m3(q) * 2^(s - 127), s = max(E - 8 + (m > 1.75), 0) with E / m the biased fp32 exponent / significand
+ * of the block's largest magnitude (which therefore lands in (224, 448] and never saturates), q = e4m3_rne(clamp(x * 2^(127 - s),
+ * -448, 448)).  Stateless (no amax history), bit-reproducible, restated in
+ * oracle/mxfp8.py.
+ *
+ * rgbd_quantize_mxfp8: x (rows, C) bf16 -> q (rows, C) bytes + scales (rows, C/32) bytes; C % 128 == 0.
+ * rgbd_pack_weights_mxfp8_multi: for every descriptor, master W (cout,cin,3,3) fp32 times `scale` (inv_c) ->
+ *   wf_q [9][cout][cin] + wf_s [9][cout][cin/32]                (fprop image, blocks along cin), and
+ *   wd_q [9][cin][cout] + wd_s [9][cin][cout/32], taps flipped  (dgrad image, blocks along cout);
+ *   either pair may be NULL; cout, cin multiples of 32.  Descriptors live in DEVICE memory, descriptor i owns blocks
+ *   [block_begin[i], block_begin[i+1]) of the grid (as rgbd_pack_weights_multi).
+ * rgbd_conv2d_fprop_mxfp8 / _dgrad_mxfp8 / rgbd_conv3x3_actgrad_mxfp8 / rgbd_conv2d_fprop_stats_mxfp8: the launches of
+ *   rgbd_conv2d_fprop_bf16 (3x3, pad 1) / rgbd_conv2d_dgrad_bf16 / rgbd_conv3x3_actgrad_bf16 / rgbd_conv2d_fprop_stats_bf16
+ *   with (xq, xs) and (wq, ws) in place of the bf16 operands; every other argument, the epilogues and the bf16 NHWC outputs
+ *   are theirs.  Shapes: rgbd_conv3x3_mxfp8_supported(B, Hout, Wout, K-dim, N-dim) -- output images multiples of 16x16, the
+ *   reduction channels a multiple of 128, the output channels of 64.
+ */
+typedef struct rgbd_pack_mx8_desc {
+    const float* w;       /* (cout,cin,3,3) fp32 master */
+    void* wf_q;           /* [9][cout][cin] e4m3 or NULL */
+    void* wf_s;           /* [9][cout][cin/32] e8m0 */
+    void* wd_q;           /* [9][cin][cout] e4m3, taps flipped, or NULL */
+    void* wd_s;           /* [9][cin][cout/32] e8m0 */
+    int cout, cin;
+    float scale;
+    int block_begin;
+} rgbd_pack_mx8_desc;
+int rgbd_quantize_mxfp8(const void* x, void* q, void* scales, int64_t rows, int C, void* stream);
+int rgbd_pack_weights_mxfp8_multi(const rgbd_pack_mx8_desc* descs_device, int n, int total_blocks, void* stream);
+int rgbd_conv3x3_mxfp8_supported(int B, int Hout, int Wout, int Cin, int Cout);
+int rgbd_conv2d_fprop_mxfp8(const void* xq, const void* xs, const void* wq, const void* ws, const float* bias,
+                            const void* residual, void* y, void* y_pooled, int B, int Hin, int Win, int Cin, int Cout,
+                            int upsample, int lrelu_channels, float slope, void* stream);
+int rgbd_conv2d_dgrad_mxfp8(const void* dyq, const void* dys, const void* wdq, const void* wds, const void* residual,
+                            void* dx, int B, int H, int W, int Cin, int Cout, int sum_pool2, void* stream);
+int rgbd_conv3x3_actgrad_mxfp8(const void* xq, const void* xs, const void* wq, const void* ws, const void* residual,
+                               const void* act_y, float slope, float* colsum, const float* row_scale, void* y, void* y2,
+                               const float* row_scale2, int B, int H, int W, int Cin, int Cout, void* stream);
+int rgbd_conv2d_fprop_stats_mxfp8(const void* xq, const void* xs, const void* wq, const void* ws, const float* bias, void* y,
+                                  int64_t* stats, int B, int Hin, int Win, int Cin, int Cout, int upsample,
+                                  int lrelu_channels, float slope, void* stream);
 int rgbd_pixelnorm_fwd(const float* x, float* y, int M, int C, float eps, void* stream);
 int rgbd_pixelnorm_bwd(const float* x, const float* dy, float* dx, int M, int C, float eps, void* stream);
 int rgbd_depth_head_fwd(const float* x, float* y, int B, int HW, void* stream);

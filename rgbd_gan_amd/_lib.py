@@ -10,7 +10,7 @@ from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p, POINTER
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RGBD_LIB_PATH: A/B timing of another build of the same ABI; the default is the in-tree library
 LIB_PATH = os.environ.get("RGBD_LIB_PATH") or os.path.join(_HERE, "librgbdgan_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _P = c_void_p
 
@@ -89,6 +89,16 @@ PROTOTYPES = {
     "rgbd_conv3x3_actgrad_bf16": ([_P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P], c_int),
     "rgbd_conv2d_fprop_stats_bf16": ([_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P], c_int),
     "rgbd_adain_apply_fixed": ([_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P], c_int),
+    "rgbd_quantize_mxfp8": ([_P, _P, _P, c_int64, c_int, _P], c_int),
+    "rgbd_pack_weights_mxfp8_multi": ([_P, c_int, c_int, _P], c_int),
+    "rgbd_conv3x3_mxfp8_supported": ([c_int, c_int, c_int, c_int, c_int], c_int),
+    "rgbd_conv2d_fprop_mxfp8": ([_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                                 _P], c_int),
+    "rgbd_conv2d_dgrad_mxfp8": ([_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P], c_int),
+    "rgbd_conv3x3_actgrad_mxfp8": ([_P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
+                                    _P], c_int),
+    "rgbd_conv2d_fprop_stats_mxfp8": ([_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                                       _P], c_int),
     "rgbd_pixelnorm_fwd": ([_P, _P, c_int, c_int, c_float, _P], c_int),
     "rgbd_pixelnorm_bwd": ([_P, _P, _P, c_int, c_int, c_float, _P], c_int),
     "rgbd_depth_head_fwd": ([_P, _P, c_int, c_int, _P], c_int),

@@ -16,6 +16,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 void rgbd_set_error(const char* fmt, ...);
 

@@ -54,6 +54,11 @@ struct ConvArgs {
     // pipelined 3x3 kernel, STATS variant: stats[b][co][0..1] += (sum y, sum y^2) over the image's pixels, as 64-bit
     // integers in units of 2^-32 (integer adds commute: the result does not depend on which workgroup adds first)
     long long* stats;
+    // pipelined 3x3 kernel, MX variant (block-scaled fp8 MFMA): x and wp are e4m3 bytes, xs / ws their E8M0 block scales
+    // ((B,Hin,Win,Cin/32) and [9][Cout][Cin/32]: one byte per 32 consecutive input channels, csrc/mxfp8.hip)
+    const unsigned char* xs;
+    const unsigned char* ws;
+    int xs_bytes, ws_bytes;
 };
 
 __device__ __forceinline__ u32x4 ldg16(const unsigned short* p) { return *reinterpret_cast<const u32x4*>(p); }
@@ -728,6 +733,11 @@ __device__ __forceinline__ void lds_dma16(u32x4 rsrc, unsigned voff, unsigned so
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :: "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
 }
+// 4 bytes per lane (the E8M0 scale dwords of the MX variant): lane l lands at lds_dst + 4 l
+__device__ __forceinline__ void lds_dma4(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+                 :: "s"(lds_dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
+}
 #define RGBD_PP_BARRIER()                         \
     do {                                          \
         __builtin_amdgcn_sched_barrier(0);        \
@@ -749,9 +759,21 @@ __device__ __forceinline__ void lds_dma16(u32x4 rsrc, unsigned voff, unsigned so
 // EPI: 0 plain epilogue, 1 MASKED (activation gradient of the layer in front + its bias gradient, ConvArgs::mask_y),
 //      2 STATS (per-(sample, channel) sum y, sum y^2 of what is stored: the instance-norm statistics of the AdaIN behind
 //        this conv, ConvArgs::stats)
-template <int BN, bool UPS, int KO = 0, int EPI = 0>   // KO: timing knock-outs (wrong results): 1 no weight DMA, 2 no halo DMA, 3 no LDS reads, 4 no MFMAs, 6 MFMAs and barriers only
+// MX: the MXFP8 form (BASELINE configuration 5).  Operands are e4m3 bytes with one E8M0 scale byte per 32 input channels
+//   (csrc/mxfp8.hip), multiplied by v_mfma_scale_f32_16x16x128_f8f6f4 -- twice the K per matrix-pipe cycle of the bf16 form.
+//   A 128-byte LDS row is now 128 channels, so a K step is one tap x 128 channels and the LDS images, the DMA pieces, the
+//   bytes read per step and a step's matrix-pipe cycles (16 MFMAs x 32) are those of the bf16 kernel: same tiling, same
+//   barriers, same epilogue.  What differs: a lane's 32-byte operand is LDS chunks q and 4 + q of its row (= the
+//   instruction's K order, scripts/hw/mfma_f8_probe.hip), each operand carries a scale byte read from two more LDS images
+//   (one dword per halo pixel / weight row, filled by 4-byte LDS-DMA pieces), and fragments are pipelined a whole step
+//   ahead at QUARTER granularity: the A fragment of 16-channel tile i of step t+1 lands in the registers quarter i of
+//   step t has finished with; B rows sit in a ring of row slots, a row's slot being free again before its next tenant's
+//   read is issued (NSLOT below).
+template <int BN, bool UPS, int KO = 0, int EPI = 0, bool MX = false>   // KO: timing knock-outs (wrong results): 1 no weight DMA, 2 no halo DMA, 3 no LDS reads, 4 no MFMAs, 6 MFMAs and barriers only
 __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
     constexpr bool MASKED = EPI == 1, STATS = EPI == 2;
+    constexpr int EB = MX ? 1 : 2;                // bytes per operand element: a 128-byte slice is 64 bf16 or 128 e4m3 channels
+    static_assert(!MX || KO == 0, "the knock-outs exist for the bf16 form only");
     constexpr int HPW = UPS ? 10 : 18;            // halo patch width (and height)
     constexpr int NROWS = HPW * HPW;
     constexpr int P_PIECES = (NROWS * 128 + 1023) / 1024;   // 1-KiB DMA pieces per halo patch (41 or 13)
@@ -767,6 +789,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
     unsigned char* const patch_lds = dsm;                       // [2][P_BYTES]
     unsigned char* const w_lds = dsm + 2 * P_BYTES;             // [3][W_BYTES]
     const unsigned lds0 = (unsigned)(size_t)dsm;                // LDS byte address of dsm (low half of the flat address)
+    // MX: scale images behind the bias: one dword (the slice's four block scales) per halo pixel / per weight row
+    constexpr int S_PIECES = (NROWS + 63) / 64;                 // 256-byte DMA pieces of a halo patch's scale dwords (6 or 2)
+    constexpr int XS_BYTES = S_PIECES * 256, WS_BYTES = BN * 4;
+    constexpr int XS_OFF = 2 * P_BYTES + 3 * W_BYTES + BN * 4, WS_OFF = XS_OFF + 2 * XS_BYTES;
+    unsigned char* const xs_lds = dsm + XS_OFF;                 // [2][XS_BYTES]
+    unsigned char* const ws_lds = dsm + WS_OFF;                 // [3][WS_BYTES]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -784,7 +812,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
     const int wave_co = (wid / WAVES_PX) * 64;
     const int wave_py = (wid % WAVES_PX) * TPX;                  // first patch row of this wave
 
-    const int nc = a.Cin >> 6;
+    const int nc = a.Cin / (128 / EB);
     const int g_total = (pt_end - pt_begin) * nc;               // (tile, channel slice) pairs of this workgroup
     if (g_total <= 0) return;
 
@@ -815,24 +843,55 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
             const int r = (ridx * WPW4 + i) * 8 + (lane >> 3);
             const int wm = r & 15, wt = (r >> 4) & 3;
             const int wperm = (r & ~63) + 16 * (wm >> 2) + 4 * wt + (wm & 3);
-            wv = (unsigned)(((n0 + wperm) * a.Cin + ((lane & 7) ^ (r & 7)) * 8) * 2);
+            wv = (unsigned)((n0 + wperm) * a.Cin * EB + (((lane & 7) ^ (r & 7)) << 4));
         }
         if (i < PPW4) {
             const int pi = ridx + 4 * i < P_PIECES ? ridx + 4 * i : P_PIECES - 1;
             const int row = pi * 8 + (lane >> 3);
             const int hy = row / HPW, hx = row - hy * HPW;
-            pv = (unsigned)((hy * a.Win + hx) * a.Cin * 2 + (((lane & 7) ^ (hx & 7)) << 4));
+            pv = (unsigned)((hy * a.Win + hx) * a.Cin * EB + (((lane & 7) ^ (hx & 7)) << 4));
             const unsigned m = (hy == 0 ? 1u : 0u) | (hy == HPW - 1 ? 2u : 0u) | (hx == 0 ? 4u : 0u) |
                                (hx == HPW - 1 ? 8u : 0u) | (row >= NROWS ? 16u : 0u);
             pm[i / 6] |= m << (5 * (i % 6));
         }
         doff[i] = w_role ? wv : pv;
     }
-    const int tap_stride = a.Cout * a.Cin * 2;
-    const unsigned x_lead = (unsigned)((a.Win + 1) * a.Cin * 2);
+    const int tap_stride = a.Cout * a.Cin * EB;
+    const unsigned x_lead = (unsigned)((a.Win + 1) * a.Cin * EB);
     const unsigned long xp = (unsigned long)a.x - x_lead, wpp = (unsigned long)a.wp;
     const u32x4 xrsrc = {(unsigned)xp, (unsigned)(xp >> 32) & 0xffffu, (unsigned)a.x_bytes + x_lead, 0x00020000u};
     const u32x4 wrsrc = {(unsigned)wpp, (unsigned)(wpp >> 32) & 0xffffu, (unsigned)a.w_bytes, 0x00020000u};
+    // MX: per-lane source offsets of the scale pieces (4 bytes per lane, lane l -> dword 64 piece + l of the image).
+    //   halo wave: scale piece i covers halo pixels 64 spi .. + 63 (spi = ridx + 4 i, clamped: duplicates carry the same
+    //     bytes), border classes as for the data pieces;  weight wave: piece ridx % (BN / 64) = LDS rows 64 p .. + 63
+    //     (every piece is fetched by two -- BN = 64: all four -- weight waves, identical bytes, so that the waves of a role
+    //     issue the same number of operations per tile and one counted wait serves them all)
+    constexpr int SPW4 = (S_PIECES + 3) / 4;                     // scale pieces per halo wave per slice (2 or 1)
+    const int sgrp = a.Cin >> 5;                                 // scale bytes per pixel / per weight row
+    unsigned sdoff[SPW4], spm = 0u, wsv = 0u;
+    u32x4 xsrsrc = {0u, 0u, 0u, 0u}, wsrsrc = {0u, 0u, 0u, 0u};
+    if (MX) {
+#pragma unroll
+        for (int i = 0; i < SPW4; ++i) {
+            const int spi = ridx + 4 * i < S_PIECES ? ridx + 4 * i : S_PIECES - 1;
+            const int idx = spi * 64 + lane;
+            const int hy = idx / HPW, hx = idx - hy * HPW;
+            sdoff[i] = (unsigned)((hy * a.Win + hx) * sgrp);
+            const unsigned m = (hy == 0 ? 1u : 0u) | (hy == HPW - 1 ? 2u : 0u) | (hx == 0 ? 4u : 0u) |
+                               (hx == HPW - 1 ? 8u : 0u) | (idx >= NROWS ? 16u : 0u);
+            spm |= m << (5 * i);
+        }
+        {
+            const int r = (ridx % (BN / 64)) * 64 + lane;
+            const int wm = r & 15, wt = (r >> 4) & 3;
+            const int wperm = (r & ~63) + 16 * (wm >> 2) + 4 * wt + (wm & 3);
+            wsv = (unsigned)((n0 + wperm) * sgrp);
+        }
+        const unsigned xs_lead = (unsigned)((a.Win + 1) * sgrp);
+        const unsigned long xsp = (unsigned long)a.xs - xs_lead, wsp = (unsigned long)a.ws;
+        xsrsrc = u32x4{(unsigned)xsp, (unsigned)(xsp >> 32) & 0xffffu, (unsigned)a.xs_bytes + xs_lead, 0x00020000u};
+        wsrsrc = u32x4{(unsigned)wsp, (unsigned)(wsp >> 32) & 0xffffu, (unsigned)a.ws_bytes, 0x00020000u};
+    }
 
     auto tile_origin = [&](int pt, int& b, int& y0, int& x0) {
         b = pt / tiles_per_img;
@@ -846,7 +905,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
         int b, y0, x0;
         tile_origin(pt, b, y0, x0);
         const int sy = UPS ? y0 >> 1 : y0, sx = UPS ? x0 >> 1 : x0;
-        soff = (unsigned)((((b * a.Hin + sy) * a.Win + sx) * a.Cin) * 2 + c * 128);
+        soff = (unsigned)((((b * a.Hin + sy) * a.Win + sx) * a.Cin) * EB + c * 128);
         border = (y0 == 0 ? 1u : 0u) | (y0 + 16 == a.Hout ? 2u : 0u) | (x0 == 0 ? 4u : 0u) | (x0 + 16 == a.Wout ? 8u : 0u) | 16u;
     };
     auto dma_patch = [&](int i, int buf, unsigned soff, unsigned border) {     // halo waves only
@@ -861,6 +920,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
     auto dma_w = [&](int c, int tap, int buf) {
 #pragma unroll
         for (int i = 0; i < WPW4; ++i) dma_w_piece(c, tap, buf, i);
+    };
+    // MX: the scale pieces.  A patch's scale source differs from its data source by the element size only:
+    // soff = pixel * Cin + 128 c  ->  pixel * (Cin / 32) + 4 c = soff / 32
+    auto dma_patch_scale = [&](int i, int buf, unsigned soff, unsigned border) {     // halo waves only
+        const int spi = ridx + 4 * i < S_PIECES ? ridx + 4 * i : S_PIECES - 1;
+        const bool ok = (spm & (border << (5 * i))) == 0u;
+        lds_dma4(xsrsrc, ok ? sdoff[i] : 0x80000000u, soff >> 5, lds0 + (unsigned)(XS_OFF + buf * XS_BYTES + spi * 256));
+    };
+    auto dma_w_scale = [&](int c, int tap, int buf) {                                  // weight waves only
+        lds_dma4(wsrsrc, wsv, (unsigned)(tap * a.Cout * sgrp + 4 * c),
+                 lds0 + (unsigned)(WS_OFF + buf * WS_BYTES + (ridx % (BN / 64)) * 256));
     };
 
     f32x4 acc[4][TPX];
@@ -912,6 +982,68 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
     auto mfma_block = [&](int kh, int h) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) mfma_quarter(kh, h, i);
+    };
+    // ---- MX fragments.  A: one 32-byte operand + scale byte per 16-channel tile, slot i refilled (for the next step)
+    //      right after quarter i.  B: halo row r of filter column kw lives in slot (kw NR + r) % NSLOT.  A row is read one
+    //      step before its first use (the rows a column starts with: during the last step of the column before); NSLOT
+    //      is the smallest divisor-compatible ring in which the previous tenant of a slot has had its last use by then:
+    //        TPX 4: rows 0-3 enter during (kw-1, kh 2), row 4 during (kw, 0), row 5 during (kw, 1); row r is last used at
+    //               kh = min(r, 2); tenant ord + 9 = (kw+1, r+3) or (kw+2, r-3) enters at least one step later;
+    //        TPX 4 behind the folded upsample: 4 rows per column, rows 0-2 at kh 0, row 3 at kh 2: ring of 6;
+    //        TPX 2: every row of a slice has its own slot (12 or 9 rows).
+    constexpr int NSLOT = !MX ? 1 : TPX == 4 ? (UPS ? 6 : 9) : 3 * NR;
+    static_assert(!MX || (3 * NR) % NSLOT == 0, "a slice's rows must map to the same slots in every slice");
+    i32x8 afm[MX ? 4 : 1], bm[NSLOT];
+    int sam[MX ? 4 : 1], sbm[NSLOT];
+    const int sa_off = (wave_co + r16) * 4 + q;                         // scale byte of this lane's K block, weight row r16
+    int sb_off[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        const int colx = UPS ? ((r16 + kw - 1) >> 1) + 1 : r16 + kw;
+        sb_off[kw] = ((UPS ? (wave_py >> 1) : wave_py) * HPW + colx) * 4 + q;
+    }
+    auto load_a_mx = [&](int wb, int i) {                                // tile i's fragment of weight buffer wb
+        const unsigned char* wbuf = w_lds + wb * W_BYTES;
+        const u32x4 lo = *reinterpret_cast<const u32x4*>(wbuf + aoff[0] + i * 16 * 128);
+        const u32x4 hi = *reinterpret_cast<const u32x4*>(wbuf + aoff[1] + i * 16 * 128);
+        afm[i] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+        sam[i] = (int)ws_lds[wb * WS_BYTES + sa_off + i * 64];
+    };
+    auto load_b_mx = [&](int pb, int kh, int kw, int part) {             // the rows tap (kh, kw) uses and (kh - 1, kw) did not,
+        const unsigned char* pbuf = patch_lds + pb * P_BYTES;            // every third of them (part 0..2, or all: part < 0)
+        int cnt = 0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            bool used = false, prev = false;
+#pragma unroll
+            for (int j = 0; j < TPX; ++j) {
+                used = used || rowidx(j, kh) == r;
+                prev = prev || (kh > 0 && rowidx(j, kh - 1) == r);
+            }
+            if (used && !prev && (part < 0 || cnt++ % 3 == part)) {
+                const int sl = (kw * NR + r) % NSLOT;
+                const u32x4 lo = *reinterpret_cast<const u32x4*>(pbuf + boff[kw][0] + r * HPW * 128);
+                const u32x4 hi = *reinterpret_cast<const u32x4*>(pbuf + boff[kw][1] + r * HPW * 128);
+                bm[sl] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+                sbm[sl] = (int)xs_lds[pb * XS_BYTES + sb_off[kw] + r * HPW * 4];
+            }
+        }
+    };
+    // The scaled-MFMA builtin is not treated as convergent by the compiler, which then sinks every MFMA of the unrolled
+    // slice past the role branches to the accumulators' first real use, the epilogue (72 MFMAs in one block behind the last
+    // barrier, all fragments spilled on the way).  An empty volatile asm that "rewrites" a quarter's accumulators one
+    // quarter later keeps each MFMA within a quarter of where it is written; by then its result has long retired, so the
+    // asm costs no wait states.
+    auto pin_quarter = [&](int i) {
+#pragma unroll
+        for (int j = 0; j < TPX; ++j) asm volatile("" : "+v"(acc[i][j]));
+    };
+    auto mfma_quarter_mx = [&](int kh, int kw, int i) {
+#pragma unroll
+        for (int j = 0; j < TPX; ++j) {
+            const int sl = (kw * NR + rowidx(j, kh)) % NSLOT;
+            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(afm[i], bm[sl], acc[i][j], 0, 0, 0, sam[i], 0, sbm[sl]);
+        }
     };
 
     float* const bias_lds = reinterpret_cast<float*>(dsm + 2 * P_BYTES + 3 * W_BYTES);   // [BN]
@@ -1093,19 +1225,36 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
         dma_w(0, 0, 0);
         dma_w(0, 3, 1);
         dma_w(0, 6, 2);
+        if (MX) {
+            dma_w_scale(0, 0, 0);
+            dma_w_scale(0, 3, 1);
+            dma_w_scale(0, 6, 2);
+        }
     } else {
         unsigned soff, border;
         patch_scalar(pt_begin, 0, soff, border);
 #pragma unroll
         for (int i = 0; i < PPW4; ++i) dma_patch(i, 0, soff, border);
+        if (MX) {
+#pragma unroll
+            for (int i = 0; i < SPW4; ++i) dma_patch_scale(i, 0, soff, border);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    load_a(w_lds, 0);
-    load_b(patch_lds, 0, 0, 0);
+    if (MX) {
+        load_a_mx(0, 0);
+        load_a_mx(0, 1);
+        load_a_mx(0, 2);
+        load_b_mx(0, 0, 0, -1);
+    } else {
+        load_a(w_lds, 0);
+        load_b(patch_lds, 0, 0, 0);
+    }
 
     int c = 0, pt = pt_begin;
     bool w_waited = false;             // weight waves: tile 1 of this slice was already waited for (in front of an epilogue)
+    constexpr int NWT = MX ? WPW4 + 1 : WPW4;          // a weight wave's DMA operations per tile (MX: + the scale piece)
     for (int g = 0; g < g_total; ++g) {
         const unsigned char* pbuf = patch_lds + (g & 1) * P_BYTES;
         const unsigned char* pnext = patch_lds + ((g + 1) & 1) * P_BYTES;
@@ -1114,6 +1263,60 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
         const int pt_next = (c_next == 0 && !last) ? pt + 1 : pt;
         unsigned nsoff, nborder;
         patch_scalar(pt_next, c_next, nsoff, nborder);
+        if constexpr (MX) {
+            // One K step = tap (kh, kw) x 128 channels = four quarters of TPX MFMAs (one 16-channel tile each).
+            //   quarter 0 runs in front of B_t: it needs nothing B_t publishes; A_3 of THIS step is read under it
+            //   B_t: weight tile t + 1 (+ its scales) has landed in every weight wave; at t = 8 the next halo patch too
+            //   quarters 1-3: A_0..2 and the new B rows of step t + 1 arrive; the DMAs of weight tile t + 3 (into tile t's
+            //   buffer: its last reads, A_3 of step t, are retired by the lgkmcnt(0) in front of B_t) and of the next halo
+            //   patch go out one or two per quarter.  Hazards otherwise as in the bf16 form (the kernel's header).
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int kh = t % 3, kw = t / 3;
+                const int tn = (t + 1) % 9, khn = tn % 3, kwn = tn / 3;
+                load_a_mx(t % 3, 3);
+                mfma_quarter_mx(kh, kw, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, TPX, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t > 0) pin_quarter(3);
+                if (w_role) {
+                    if (!(t == 0 && w_waited)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWT) : "memory");
+                } else if (t == 8) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                RGBD_PP_BARRIER();
+#pragma unroll
+                for (int i = 1; i < 4; ++i) {
+                    load_a_mx(tn % 3, i - 1);
+                    load_b_mx(t == 8 ? (g + 1) & 1 : g & 1, khn, kwn, i - 1);
+                    mfma_quarter_mx(kh, kw, i);
+#pragma unroll
+                    for (int k_ = 0; k_ < TPX; ++k_) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    pin_quarter(i - 1);
+                    const int cw = t + 3 >= 9 ? c_next : c, tapw = 3 * (((t + 3) % 9) % 3) + ((t + 3) % 9) / 3;
+                    if (w_role) {
+                        if (i < 3) {
+#pragma unroll
+                            for (int k_ = (i - 1) * (WPW4 / 2); k_ < i * (WPW4 / 2); ++k_) dma_w_piece(cw, tapw, t % 3, k_);
+                        } else {
+                            dma_w_scale(cw, tapw, t % 3);
+                        }
+                    } else if (t < PSTEPS) {
+                        if (i - 1 < PPS && t * PPS + i - 1 < PPW4) dma_patch(t * PPS + i - 1, (g + 1) & 1, nsoff, nborder);
+                    } else if (t == PSTEPS) {
+                        if (i - 1 < SPW4) dma_patch_scale(i - 1, (g + 1) & 1, nsoff, nborder);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            pin_quarter(3);
+        } else {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             constexpr int dummy = 0;
@@ -1162,12 +1365,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        }
         w_waited = false;
         if (c_next == 0) {             // last slice of this pixel tile: write it out.  The weight waves first retire tile 1
                                        // of the next slice: behind the epilogue's stores a counted wait would also wait
                                        // for those
             if (w_role) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KO == 1 || KO == 6 ? 0 : WPW4) : "memory");
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KO == 1 || KO == 6 ? 0 : NWT) : "memory");
                 w_waited = true;
             }
             epilogue(pt);
@@ -1880,12 +2084,39 @@ extern "C" int64_t rgbd_conv2d_fprop_workspace(int B, int Hin, int Win, int Cin,
     return p.ksplit > 1 || p.small ? (int64_t)p.ksplit * B * Hout * Wout * Cout * (int64_t)sizeof(float) : 0;
 }
 
+namespace {
+// One launch of the pipelined 3x3 kernel's MXFP8 form; the LDS reservation is made once per instantiation.
+template <int BN, bool UPS, int EPI>
+int launch_sp_mx(const ConvArgs& a, unsigned grid, hipStream_t st) {
+    constexpr int pieces = UPS ? 13 : 41, spieces = UPS ? 2 : 6;
+    constexpr int lds = 2 * pieces * 1024 + 3 * BN * 128 + BN * 4 + 2 * spieces * 256 + 3 * BN * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        RGBD_REQUIRE(hipFuncSetAttribute((const void*)&conv3x3_sp_kernel<BN, UPS, 0, EPI, true>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess,
+                     "rgbd_conv3x3_mxfp8: cannot reserve %d B of LDS", lds);
+        attr_done = true;
+    }
+    conv3x3_sp_kernel<BN, UPS, 0, EPI, true><<<grid, 512, lds, st>>>(a);
+    RGBD_CHECK_LAUNCH("conv3x3_sp_kernel<mxfp8>");
+    return 0;
+}
+template <int EPI>
+int launch_sp_mx_any(const ConvArgs& a, bool wide, unsigned grid, hipStream_t st) {
+    if (EPI == 1) return wide ? launch_sp_mx<128, false, 1>(a, grid, st) : launch_sp_mx<64, false, 1>(a, grid, st);
+    if (a.ups) return wide ? launch_sp_mx<128, true, EPI == 1 ? 0 : EPI>(a, grid, st)
+                           : launch_sp_mx<64, true, EPI == 1 ? 0 : EPI>(a, grid, st);
+    return wide ? launch_sp_mx<128, false, EPI>(a, grid, st) : launch_sp_mx<64, false, EPI>(a, grid, st);
+}
+}  // namespace
+
 static int conv_fprop_impl(const void* x, const void* wp, const float* bias, const void* residual,
                            void* y, int B, int Hin, int Win, int Cin, int Cout, int KH, int KW, int pad,
                            int upsample, int lrelu_channels, float slope, void* workspace, void* stream, int pool_sum,
                            void* y_pooled = nullptr, const void* mask_y = nullptr, float* colsum = nullptr,
                            const float* row_scale = nullptr, long long* stats = nullptr, void* y2 = nullptr,
-                           const float* row_scale2 = nullptr) {
+                           const float* row_scale2 = nullptr, const void* x_scales = nullptr,
+                           const void* w_scales = nullptr) {
     RGBD_REQUIRE(x && wp && y, "rgbd_conv2d_fprop_bf16: null pointer");
     RGBD_REQUIRE(B > 0 && Hin > 0 && Win > 0 && KH > 0 && KW > 0 && pad >= 0, "rgbd_conv2d_fprop_bf16: bad shape");
     RGBD_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0,
@@ -1903,8 +2134,12 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
     RGBD_REQUIRE(a.Hout > 0 && a.Wout > 0, "rgbd_conv2d_fprop_bf16: empty output");
     RGBD_REQUIRE((long)B * Hin * Win * Cin < 0x3fffffffL && (long)KH * KW * Cout * Cin < 0x3fffffffL,
                  "rgbd_conv2d_fprop_bf16: tensors must be smaller than 2 GiB (32-bit buffer offsets)");
-    a.x_bytes = (int)((long)B * Hin * Win * Cin * 2);
-    a.w_bytes = (int)((long)KH * KW * Cout * Cin * 2);
+    const bool mx = x_scales != nullptr;
+    a.x_bytes = (int)((long)B * Hin * Win * Cin * (mx ? 1 : 2));
+    a.w_bytes = (int)((long)KH * KW * Cout * Cin * (mx ? 1 : 2));
+    a.xs = (const unsigned char*)x_scales; a.ws = (const unsigned char*)w_scales;
+    a.xs_bytes = (int)((long)B * Hin * Win * (Cin / 32));
+    a.ws_bytes = (int)((long)KH * KW * Cout * (Cin / 32));
     a.lrelu_ch = lrelu_channels; a.slope = slope;
     a.M = (long)B * a.Hout * a.Wout;
     const long mtiles = (a.M + 127) / 128;
@@ -1949,6 +2184,15 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
         plan.patch = true;
         plan.ksplit = 1;
     }
+    if (mx) {
+        RGBD_REQUIRE(w_scales, "rgbd_conv3x3_mxfp8: null pointer");
+        RGBD_REQUIRE(KH == 3 && KW == 3 && pad == 1 && a.Hout % 16 == 0 && a.Wout % 16 == 0 && Cin % 128 == 0,
+                     "rgbd_conv3x3_mxfp8: needs a 3x3 pad-1 conv, output images that are multiples of 16x16 and Cin a "
+                     "multiple of 128 (Cin=%d, output %dx%d)", Cin, a.Hout, a.Wout);
+        plan.patch = true;
+        plan.ksplit = 1;
+        plan.small = false;
+    }
     a.ksplit = plan.ksplit;
     a.partial = plan.ksplit > 1 || plan.small ? (float*)workspace : nullptr;
     if (plan.small) {
@@ -1988,6 +2232,16 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
         a.ptiles = (int)ptiles;
         a.wgs_per_ntile = per_nt;
         const long grid = (long)per_nt * n_tiles;
+        if (mx) {
+            const int rc = stats ? launch_sp_mx_any<2>(a, wide, (unsigned)grid, st)
+                         : mask_y ? launch_sp_mx_any<1>(a, wide, (unsigned)grid, st)
+                                  : launch_sp_mx_any<0>(a, wide, (unsigned)grid, st);
+            if (rc) return rc;
+            g_last_conv_kernel = stats ? (wide ? "conv3x3_sp_kernel<128,stats,mxfp8>" : "conv3x3_sp_kernel<64,stats,mxfp8>")
+                               : mask_y ? (wide ? "conv3x3_sp_kernel<128,actgrad,mxfp8>" : "conv3x3_sp_kernel<64,actgrad,mxfp8>")
+                                        : (wide ? "conv3x3_sp_kernel<128,mxfp8>" : "conv3x3_sp_kernel<64,mxfp8>");
+            return 0;
+        }
         if (g_conv_variant != 1) {
             const int pieces = a.ups ? 13 : 41, bn = wide ? 128 : 64;
             const int lds_sp = 2 * pieces * 1024 + 3 * bn * 128 + bn * 4;
@@ -2168,6 +2422,48 @@ extern "C" int rgbd_conv2d_fprop_stats_bf16(const void* x, const void* wp, const
     RGBD_REQUIRE(stats, "rgbd_conv2d_fprop_stats_bf16: null pointer");
     return conv_fprop_impl(x, wp, bias, nullptr, y, B, Hin, Win, Cin, Cout, 3, 3, 1, upsample, lrelu_channels, slope, nullptr,
                            stream, 0, nullptr, nullptr, nullptr, nullptr, (long long*)stats);
+}
+
+// ---- MXFP8 forms (BASELINE configuration 5): the same launches on e4m3 operands with E8M0 block scales (csrc/mxfp8.hip)
+extern "C" int rgbd_conv3x3_mxfp8_supported(int B, int Hout, int Wout, int Cin, int Cout) {
+    return B > 0 && Hout > 0 && Wout > 0 && Hout % 16 == 0 && Wout % 16 == 0 && Cin > 0 && Cout > 0 && Cin % 128 == 0 &&
+           Cout % 64 == 0 && (long)B * Hout * Wout * (Cin > Cout ? Cin : Cout) < 0x3fffffffL && !g_force_gather;
+}
+
+extern "C" int rgbd_conv2d_fprop_mxfp8(const void* xq, const void* xs, const void* wq, const void* ws, const float* bias,
+                                       const void* residual, void* y, void* y_pooled, int B, int Hin, int Win, int Cin,
+                                       int Cout, int upsample, int lrelu_channels, float slope, void* stream) {
+    RGBD_REQUIRE(xs && ws, "rgbd_conv2d_fprop_mxfp8: null pointer");
+    return conv_fprop_impl(xq, wq, bias, residual, y, B, Hin, Win, Cin, Cout, 3, 3, 1, upsample, lrelu_channels, slope, nullptr,
+                           stream, 0, y_pooled, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, xs, ws);
+}
+
+extern "C" int rgbd_conv2d_dgrad_mxfp8(const void* dyq, const void* dys, const void* wdq, const void* wds,
+                                       const void* residual, void* dx, int B, int H, int W, int Cin, int Cout, int sum_pool2,
+                                       void* stream) {
+    RGBD_REQUIRE(dys && wds, "rgbd_conv2d_dgrad_mxfp8: null pointer");
+    RGBD_REQUIRE(!(residual && sum_pool2), "rgbd_conv2d_dgrad_mxfp8: residual and sum_pool2 are exclusive");
+    return conv_fprop_impl(dyq, wdq, nullptr, residual, dx, B, H, W, Cout, Cin, 3, 3, 1, 0, 0, 0.2f, nullptr, stream, sum_pool2,
+                           nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, dys, wds);
+}
+
+extern "C" int rgbd_conv3x3_actgrad_mxfp8(const void* xq, const void* xs, const void* wq, const void* ws, const void* residual,
+                                          const void* act_y, float slope, float* colsum, const float* row_scale, void* y,
+                                          void* y2, const float* row_scale2, int B, int H, int W, int Cin, int Cout,
+                                          void* stream) {
+    RGBD_REQUIRE(act_y && xs && ws, "rgbd_conv3x3_actgrad_mxfp8: null pointer");
+    RGBD_REQUIRE(colsum || !row_scale, "rgbd_conv3x3_actgrad_mxfp8: row_scale without colsum");
+    RGBD_REQUIRE(!y2 == !row_scale2, "rgbd_conv3x3_actgrad_mxfp8: y2 and row_scale2 come together");
+    return conv_fprop_impl(xq, wq, nullptr, residual, y, B, H, W, Cin, Cout, 3, 3, 1, 0, 0, slope, nullptr, stream, 0, nullptr,
+                           act_y, colsum, row_scale, nullptr, y2, row_scale2, xs, ws);
+}
+
+extern "C" int rgbd_conv2d_fprop_stats_mxfp8(const void* xq, const void* xs, const void* wq, const void* ws, const float* bias,
+                                             void* y, int64_t* stats, int B, int Hin, int Win, int Cin, int Cout, int upsample,
+                                             int lrelu_channels, float slope, void* stream) {
+    RGBD_REQUIRE(stats && xs && ws, "rgbd_conv2d_fprop_stats_mxfp8: null pointer");
+    return conv_fprop_impl(xq, wq, bias, nullptr, y, B, Hin, Win, Cin, Cout, 3, 3, 1, upsample, lrelu_channels, slope, nullptr,
+                           stream, 0, nullptr, nullptr, nullptr, nullptr, (long long*)stats, nullptr, nullptr, xs, ws);
 }
 
 extern "C" int64_t rgbd_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int K) {

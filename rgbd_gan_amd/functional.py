@@ -25,6 +25,25 @@ _WEIGHT_EPOCH = 0          # bumped whenever master weights change (optimizer st
 _SKIP_WGRAD = False        # set while only input gradients are wanted (R1's inner grad)
 _FROZEN_PTRS = frozenset()  # parameters (by storage address) whose gradients the current backward must not produce
 _INJECT = None             # per-sample seeds (B,) fp32 of the adversarial loss while the R1 double backward runs
+_MXFP8 = False             # 3x3 convolutions whose reduction channels are a multiple of 128 run their fprop / dgrad on MXFP8
+                           # operands (BASELINE configuration 5; kernels.Mx8Image); weight gradients stay bf16
+
+
+def set_conv_dtype(name):
+    """"bf16" (default) or "mxfp8": the arithmetic of the 3x3 convolutions' fprop / dgrad launches from now on (YAML key
+    `conv_dtype`).  Layers and launches the MXFP8 kernel does not cover (reduction channels not a multiple of 128, images
+    below 16x16, 1x1 convs, weight gradients) stay on the bf16 kernels either way."""
+    global _MXFP8
+    if name not in ("bf16", "mxfp8", None):
+        raise ValueError(f"conv_dtype must be 'bf16' or 'mxfp8', got {name!r}")
+    new = name == "mxfp8"
+    if new != _MXFP8:
+        _MXFP8 = new
+        bump_weight_epoch()         # the next packed() builds (or drops) the fp8 images
+
+
+def conv_dtype():
+    return "mxfp8" if _MXFP8 else "bf16"
 
 
 def bump_weight_epoch():
@@ -98,6 +117,7 @@ class ConvLayer:
         self._wf = self._wd = None
 
     group = None              # PackGroup: all convolutions of a network repacked by one launch
+    _mxf = _mxd = None        # kernels.Mx8Image twins of _wf / _wd while conv_dtype is "mxfp8" (None: not eligible)
 
     def packed(self):
         if self._epoch != _WEIGHT_EPOCH:
@@ -105,8 +125,16 @@ class ConvLayer:
                 self.group.repack()
             else:
                 with torch.no_grad():
-                    self._wf, self._wd = kernels.pack_weights(self.weight.detach(), self.inv_c)
+                    w = self.weight.detach()
+                    self._wf, self._wd = kernels.pack_weights(w, self.inv_c)
+                    self._mxf = self._mxd = None
+                    if _MXFP8 and self.K == 3 and self.pad == 1 and w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0:
+                        f, d = kernels.pack_weights_mx8(w, self.inv_c)
+                        self._mxf = kernels.Mx8Image(self._wf, *f) if f is not None else None
+                        self._mxd = kernels.Mx8Image(self._wd, *d) if d is not None else None
                 self._epoch = _WEIGHT_EPOCH
+        if _MXFP8:
+            return self._mxf or self._wf, self._mxd or self._wd
         return self._wf, self._wd
 
 
@@ -126,10 +154,34 @@ class PackGroup:
             l.group = self
             entries.append((w, l.inv_c, l._wf, l._wd))
         self.table = kernels.build_pack_table(entries)
+        self.mx_table = None
+
+    def _build_mx(self):
+        """Persistent MXFP8 images of the eligible layers (3x3 pad 1; fprop image when Cin % 128 == 0, dgrad image when
+        Cout % 128 == 0) and their descriptor table: one more launch per repack."""
+        entries = []
+        for l in self.layers:
+            w = l.weight.detach()
+            co, ci, kh, kw = w.shape
+            l._mxf = l._mxd = None
+            if not (kh == 3 and l.pad == 1 and co % 32 == 0 and ci % 32 == 0 and (ci % 128 == 0 or co % 128 == 0)):
+                continue
+            u8 = lambda *shape: torch.empty(*shape, dtype=torch.uint8, device=w.device)
+            f = (u8(9, co, ci), u8(9, co, ci // 32)) if ci % 128 == 0 else (None, None)
+            d = (u8(9, ci, co), u8(9, ci, co // 32)) if co % 128 == 0 else (None, None)
+            l._mxf = kernels.Mx8Image(l._wf, *f) if f[0] is not None else None
+            l._mxd = kernels.Mx8Image(l._wd, *d) if d[0] is not None else None
+            entries.append((w, l.inv_c) + f + d)
+        self.mx_table = kernels.build_pack_table_mx8(entries) if entries else ()
 
     def repack(self):
         with torch.no_grad():
             kernels.pack_weights_multi(self.table)
+            if _MXFP8:
+                if self.mx_table is None:
+                    self._build_mx()
+                if self.mx_table:
+                    kernels.pack_weights_mx8_multi(self.mx_table)
         for l in self.layers:
             l._epoch = _WEIGHT_EPOCH
 

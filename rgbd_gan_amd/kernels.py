@@ -202,6 +202,96 @@ def pack_weights_multi(table):
     _lib.check(_lib.load().rgbd_pack_weights_multi(_ptr(dev), n, blocks, _stream()), "rgbd_pack_weights_multi")
 
 
+# ---- MXFP8 operands (BASELINE configuration 5; format: csrc/mxfp8.hip, include/rgbd_gan_hip.h)
+U8 = torch.uint8
+MX8_MIN_TILES = 64          # (tests set 0 to reach the fp8 kernel with oracle-sized problems)
+
+
+class Mx8Image:
+    """A packed 3x3 weight image in both forms: `.bf16` ([9][N][K] bf16, what every conv wrapper takes) and its MXFP8 twin
+    `.q` ([9][N][K] e4m3 bytes) + `.s` ([9][N][K/32] E8M0 bytes).  A conv wrapper handed one of these runs the block-scaled
+    fp8 kernel when the launch's shape allows (rgbd_conv3x3_mxfp8_supported) and the bf16 kernel on `.bf16` otherwise."""
+    __slots__ = ("bf16", "q", "s")
+
+    def __init__(self, bf16, q, s):
+        self.bf16, self.q, self.s = bf16, q, s
+
+    @property
+    def shape(self):
+        return self.bf16.shape
+
+
+def _mx8_split(wp, B, Hout, Wout, K=3, pad=1):
+    """-> (bf16 image, Mx8Image or None): the MXFP8 twin when this launch can use it."""
+    if not isinstance(wp, Mx8Image):
+        return wp, None
+    _, N, Kd = wp.bf16.shape
+    # launches with fewer 16x16 x 128 (or x 64) tiles than this stay on the bf16 planner, which has a split-K kernel for them
+    tiles = B * (Hout // 16) * (Wout // 16) * (N // (128 if N % 128 == 0 else 64))
+    ok = wp.q is not None and K == 3 and pad == 1 and tiles >= MX8_MIN_TILES and \
+        bool(_lib.load().rgbd_conv3x3_mxfp8_supported(int(B), int(Hout), int(Wout), int(Kd), int(N)))
+    return wp.bf16, (wp if ok else None)
+
+
+def quantize_mx8(x):
+    """x (..., C) bf16, C % 128 == 0 -> (q (..., C) uint8 e4m3, s (..., C/32) uint8 E8M0): blocks of 32 channels."""
+    _chk(x, BF16, "x")
+    C = x.shape[-1]
+    if C % 128:
+        raise RuntimeError(f"quantize_mx8: the channel count must be a multiple of 128, got {C}")
+    q = torch.empty(x.shape, dtype=U8, device=x.device)
+    sc = torch.empty(tuple(x.shape[:-1]) + (C // 32,), dtype=U8, device=x.device)
+    rows = x.numel() // C
+    rc = _timed("quantize_mx8_kernel", 0.0, 3.03125 * x.numel(),
+                lambda: _lib.load().rgbd_quantize_mxfp8(_ptr(x), _ptr(q), _ptr(sc), rows, C, _stream()))
+    _lib.check(rc, "rgbd_quantize_mxfp8")
+    return q, sc
+
+
+PACK_MX8_DESC = [("w", "<u8"), ("wf_q", "<u8"), ("wf_s", "<u8"), ("wd_q", "<u8"), ("wd_s", "<u8"), ("cout", "<i4"),
+                 ("cin", "<i4"), ("scale", "<f4"), ("block_begin", "<i4")]             # struct rgbd_pack_mx8_desc, 56 bytes
+
+
+def build_pack_table_mx8(entries):
+    """entries: list of (w fp32 (co,ci,3,3), scale, wf_q, wf_s, wd_q, wd_s) (either image pair may be None) -> table."""
+    import numpy as np
+    tab = np.zeros(len(entries), dtype=PACK_MX8_DESC)
+    assert tab.dtype.itemsize == 56
+    blocks = 0
+    for i, (w, scale, fq, fs, dq, ds) in enumerate(entries):
+        _chk(w, F32, "w")
+        for t in (fq, fs, dq, ds):
+            _chk(t, U8, "mxfp8 image")
+        co, ci, kh, kw = w.shape
+        if (kh, kw) != (3, 3) or co % 32 or ci % 32 or (fq is not None and ci % 128) or (dq is not None and co % 128):
+            raise RuntimeError(f"build_pack_table_mx8: unsupported weight {tuple(w.shape)}")
+        ptr = lambda t: t.data_ptr() if t is not None else 0
+        tab[i] = (w.data_ptr(), ptr(fq), ptr(fs), ptr(dq), ptr(ds), co, ci, scale, blocks)
+        blocks += min(512, (co // 32) * (ci // 32))
+    dev = torch.from_numpy(tab.view(np.uint8).copy()).to(entries[0][0].device)
+    return dev, len(entries), blocks
+
+
+def pack_weights_mx8_multi(table):
+    dev, n, blocks = table
+    _lib.check(_lib.load().rgbd_pack_weights_mxfp8_multi(_ptr(dev), n, blocks, _stream()), "rgbd_pack_weights_mxfp8_multi")
+
+
+def pack_weights_mx8(w, scale, want_fprop=True, want_dgrad=True):
+    """w (Cout,Cin,3,3) fp32 -> ((wf_q, wf_s) or None, (wd_q, wd_s) or None): the MXFP8 images with `scale` folded in; an image
+    whose reduction dimension is not a multiple of 128 is None."""
+    co, ci = w.shape[:2]
+    dev = w.device
+    f = (torch.empty(9, co, ci, dtype=U8, device=dev), torch.empty(9, co, ci // 32, dtype=U8, device=dev)) \
+        if want_fprop and ci % 128 == 0 else None
+    d = (torch.empty(9, ci, co, dtype=U8, device=dev), torch.empty(9, ci, co // 32, dtype=U8, device=dev)) \
+        if want_dgrad and co % 128 == 0 else None
+    if f is None and d is None:
+        return None, None
+    pack_weights_mx8_multi(build_pack_table_mx8([(w, scale) + (f or (None, None)) + (d or (None, None))]))
+    return f, d
+
+
 def _fprop_workspace(lib, B, H, W, Cin, Cout, KH, KW, pad, ups, device):
     """Scratch for the split-K path of the small layers (None when the shape is not split)."""
     nbytes = lib.rgbd_conv2d_fprop_workspace(B, H, W, Cin, Cout, KH, KW, pad, ups)
@@ -215,13 +305,14 @@ def conv2d_fprop(x, wp, KH, KW, pad, bias=None, residual=None, upsample=False, l
     """x (B,H,W,Cin) bf16, wp [KH*KW][Cout][Cin] bf16 -> y (B,Hout,Wout,Cout) bf16.
     avg_pool2: -> (y, 2x2 average of y at half resolution); the average comes out of the conv epilogue for 3x3 convs on
     images that are multiples of 16x16, out of a second pass (rgbd_pool2_masked) otherwise."""
-    _chk(x, BF16, "x"); _chk(wp, BF16, "wp"); _chk(bias, F32, "bias"); _chk(residual, BF16, "residual")
     B, H, W, Cin = x.shape
+    Hup, Wup = (2 * H, 2 * W) if upsample else (H, W)
+    Hout, Wout = Hup + 2 * pad - KH + 1, Wup + 2 * pad - KW + 1
+    wp, mx = _mx8_split(wp, B, Hout, Wout, KH if KH == KW else 0, pad)
+    _chk(x, BF16, "x"); _chk(wp, BF16, "wp"); _chk(bias, F32, "bias"); _chk(residual, BF16, "residual")
     T, Cout, Cin2 = wp.shape
     if T != KH * KW or Cin2 != Cin:
         raise RuntimeError(f"conv2d_fprop: weights {tuple(wp.shape)} do not match x {tuple(x.shape)} K={KH}x{KW}")
-    Hup, Wup = (2 * H, 2 * W) if upsample else (H, W)
-    Hout, Wout = Hup + 2 * pad - KH + 1, Wup + 2 * pad - KW + 1
     y = torch.empty(B, Hout, Wout, Cout, dtype=BF16, device=x.device)
     if residual is not None and residual.shape != y.shape:
         raise RuntimeError("conv2d_fprop: residual shape mismatch")
@@ -230,6 +321,19 @@ def conv2d_fprop(x, wp, KH, KW, pad, bias=None, residual=None, upsample=False, l
     nbytes = 2.0 * (x.numel() + y.numel() + wp.numel() + (residual.numel() if residual is not None else 0))
     fuse_pool = bool(avg_pool2) and KH == 3 and KW == 3 and pad == 1 and Hout % 16 == 0 and Wout % 16 == 0
     yp = torch.empty(B, Hout // 2, Wout // 2, Cout, dtype=BF16, device=x.device) if fuse_pool else None
+    if mx is not None:
+        xq, xs = quantize_mx8(x)
+        nbytes = 1.03 * (x.numel() + mx.q.numel()) + 2.0 * (y.numel() + (residual.numel() if residual is not None else 0))
+        rc = _timed(lambda: _conv_kernel_name(f"fprop {Hout}x{Wout} {Cin}->{Cout}{' ups' if upsample else ''}"
+                                              f"{' pool' if fuse_pool else ''}{' res' if residual is not None else ''}"),
+                    flops, nbytes,
+                    lambda: lib.rgbd_conv2d_fprop_mxfp8(_ptr(xq), _ptr(xs), _ptr(mx.q), _ptr(mx.s), _ptr(bias), _ptr(residual),
+                                                        _ptr(y), _ptr(yp), B, H, W, Cin, Cout, int(bool(upsample)),
+                                                        int(lrelu_channels), float(slope), _stream()))
+        _lib.check(rc, "rgbd_conv2d_fprop_mxfp8")
+        if avg_pool2:
+            return y, (yp if fuse_pool else pool2_masked(y))
+        return y
     ws = None if fuse_pool else _fprop_workspace(lib, B, H, W, Cin, Cout, KH, KW, pad, int(bool(upsample)), x.device)
     rc = _timed(lambda: _conv_kernel_name(f"fprop {Hout}x{Wout} {Cin}->{Cout}{' ups' if upsample else ''}"
                                           f"{' pool' if fuse_pool else ''}{' res' if residual is not None else ''}"),
@@ -247,8 +351,9 @@ def conv2d_dgrad(dy, wd, K, pad, sum_pool2=False, residual=None):
     """dy (B,H,W,Cout) bf16, wd [K*K][Cin][Cout] bf16 (dgrad image of pack_weights) -> dx (B,H',W',Cin) bf16.
     sum_pool2: return the 2x2 sums of dx at half resolution (adjoint of a nearest-2x upsample in front of the conv);
     taken in the conv epilogue for 3x3 convs on images that are multiples of 16x16, in a second pass otherwise."""
-    _chk(dy, BF16, "dy"); _chk(wd, BF16, "wd"); _chk(residual, BF16, "residual")
     B, H, W, Cout = dy.shape
+    wd, mx = _mx8_split(wd, B, H + 2 * (K - 1 - pad) - K + 1, W + 2 * (K - 1 - pad) - K + 1, K, K - 1 - pad)
+    _chk(dy, BF16, "dy"); _chk(wd, BF16, "wd"); _chk(residual, BF16, "residual")
     T, Cin, Cout2 = wd.shape
     if T != K * K or Cout2 != Cout:
         raise RuntimeError(f"conv2d_dgrad: weights {tuple(wd.shape)} do not match dy {tuple(dy.shape)} K={K}")
@@ -261,6 +366,15 @@ def conv2d_dgrad(dy, wd, K, pad, sum_pool2=False, residual=None):
     lib = _lib.load()
     flops = 2.0 * B * Ho * Wo * Cout * Cin * K * K
     nbytes = 2.0 * (dy.numel() + dx.numel() + wd.numel() + (residual.numel() if residual is not None else 0))
+    if mx is not None and (fuse or not sum_pool2):
+        dq, dsc = quantize_mx8(dy)
+        nbytes = 1.03 * (dy.numel() + mx.q.numel()) + 2.0 * (dx.numel() + (residual.numel() if residual is not None else 0))
+        rc = _timed(lambda: _conv_kernel_name(f"dgrad {Ho}x{Wo} {Cout}->{Cin}{' sumpool' if fuse else ''}"
+                                              f"{' res' if residual is not None else ''}"), flops, nbytes,
+                    lambda: lib.rgbd_conv2d_dgrad_mxfp8(_ptr(dq), _ptr(dsc), _ptr(mx.q), _ptr(mx.s), _ptr(residual), _ptr(dx), B,
+                                                        H, W, Cin, Cout, int(fuse), _stream()))
+        _lib.check(rc, "rgbd_conv2d_dgrad_mxfp8")
+        return dx
     ws = None if fuse else _fprop_workspace(lib, B, H, W, Cout, Cin, K, K, pd, 0, dy.device)
     rc = _timed(lambda: _conv_kernel_name(f"dgrad {Ho}x{Wo} {Cout}->{Cin}{' sumpool' if fuse else ''}"
                                           f"{' res' if residual is not None else ''}"), flops, nbytes,
@@ -283,9 +397,10 @@ def conv3x3_actgrad(x, wp, act_y, residual=None, bias_grad=None, row_scale=None,
     image, or the dgrad image of a Cout->Cin convolution), act_y / residual (B,H,W,Cout) bf16.  bias_grad (Cout fp32,
     accumulated): += sum_b row_scale[b] * column sums of the result (row_scale None = 1).  operand_scale (B,) fp32:
     -> (y, y + operand_scale[b] * act_y), the second tensor being axpy_rows(y, act_y, operand_scale)."""
+    B, H, W, Cin = x.shape
+    wp, mx = _mx8_split(wp, B, H, W)
     _chk(x, BF16, "x"); _chk(wp, BF16, "wp"); _chk(act_y, BF16, "act_y"); _chk(residual, BF16, "residual")
     _chk(bias_grad, F32, "bias_grad"); _chk(row_scale, F32, "row_scale")
-    B, H, W, Cin = x.shape
     T, Cout, Cin2 = wp.shape
     if T != 9 or Cin2 != Cin or tuple(act_y.shape) != (B, H, W, Cout):
         raise RuntimeError(f"conv3x3_actgrad: x {tuple(x.shape)}, weights {tuple(wp.shape)}, act_y {tuple(act_y.shape)}")
@@ -302,6 +417,16 @@ def conv3x3_actgrad(x, wp, act_y, residual=None, bias_grad=None, row_scale=None,
     flops = 2.0 * B * H * W * Cout * Cin * 9
     nbytes = 2.0 * (x.numel() + (3 if y2 is not None else 2) * y.numel() + wp.numel() +
                     (residual.numel() if residual is not None else 0))
+    if mx is not None:
+        xq, xs = quantize_mx8(x)
+        nbytes = nbytes - 0.97 * (x.numel() + wp.numel())
+        rc = _timed(lambda: _conv_kernel_name(f"actgrad {H}x{W} {Cin}->{Cout}{' res' if residual is not None else ''}"),
+                    flops, nbytes,
+                    lambda: lib.rgbd_conv3x3_actgrad_mxfp8(_ptr(xq), _ptr(xs), _ptr(mx.q), _ptr(mx.s), _ptr(residual),
+                                                           _ptr(act_y), float(slope), _ptr(bias_grad), _ptr(row_scale), _ptr(y),
+                                                           _ptr(y2), _ptr(operand_scale), B, H, W, Cin, Cout, _stream()))
+        _lib.check(rc, "rgbd_conv3x3_actgrad_mxfp8")
+        return y if y2 is None else (y, y2)
     rc = _timed(lambda: _conv_kernel_name(f"actgrad {H}x{W} {Cin}->{Cout}{' res' if residual is not None else ''}"),
                 flops, nbytes,
                 lambda: lib.rgbd_conv3x3_actgrad_bf16(_ptr(x), _ptr(wp), _ptr(residual), _ptr(act_y), float(slope),
@@ -315,17 +440,28 @@ def conv2d_fprop_stats(x, wp, bias, upsample=False, lrelu_channels=0, slope=0.2)
     """3x3 pad-1 conv (+ nearest-2x upsample in front) + bias + leaky ReLU like conv2d_fprop, and the per-(sample, channel)
     (sum y, sum y^2) of the stored values as (B,Cout,2) int64 in units of 2^-32 (for adain_apply_fixed).  Output images must
     be multiples of 16x16 (conv3x3_actgrad_supported(B, Hout, Wout, Cin, Cout))."""
-    _chk(x, BF16, "x"); _chk(wp, BF16, "wp"); _chk(bias, F32, "bias")
     B, H, W, Cin = x.shape
+    Hout, Wout = (2 * H, 2 * W) if upsample else (H, W)
+    wp, mx = _mx8_split(wp, B, Hout, Wout)
+    _chk(x, BF16, "x"); _chk(wp, BF16, "wp"); _chk(bias, F32, "bias")
     T, Cout, Cin2 = wp.shape
     if T != 9 or Cin2 != Cin:
         raise RuntimeError(f"conv2d_fprop_stats: weights {tuple(wp.shape)} do not match x {tuple(x.shape)}")
-    Hout, Wout = (2 * H, 2 * W) if upsample else (H, W)
     y = torch.empty(B, Hout, Wout, Cout, dtype=BF16, device=x.device)
     stats = torch.zeros(B, Cout, 2, dtype=torch.int64, device=x.device)
     lib = _lib.load()
     flops = 2.0 * B * Hout * Wout * Cout * Cin * 9
     nbytes = 2.0 * (x.numel() + y.numel() + wp.numel())
+    if mx is not None:
+        xq, xs = quantize_mx8(x)
+        nbytes = 1.03 * (x.numel() + mx.q.numel()) + 2.0 * y.numel()
+        rc = _timed(lambda: _conv_kernel_name(f"fprop {Hout}x{Wout} {Cin}->{Cout}{' ups' if upsample else ''} stats"),
+                    flops, nbytes,
+                    lambda: lib.rgbd_conv2d_fprop_stats_mxfp8(_ptr(xq), _ptr(xs), _ptr(mx.q), _ptr(mx.s), _ptr(bias), _ptr(y),
+                                                              _ptr(stats), B, H, W, Cin, Cout, int(bool(upsample)),
+                                                              int(lrelu_channels), float(slope), _stream()))
+        _lib.check(rc, "rgbd_conv2d_fprop_stats_mxfp8")
+        return y, stats
     rc = _timed(lambda: _conv_kernel_name(f"fprop {Hout}x{Wout} {Cin}->{Cout}{' ups' if upsample else ''} stats"),
                 flops, nbytes,
                 lambda: lib.rgbd_conv2d_fprop_stats_bf16(_ptr(x), _ptr(wp), _ptr(bias), _ptr(y), _ptr(stats), B, H, W, Cin,

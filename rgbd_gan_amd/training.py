@@ -141,6 +141,10 @@ class DeviceImageIterator:
 
 
 def build_training(config, device, comm=None, iterator=None, updater_class=None, **updater_kwargs):
+    # `conv_dtype: mxfp8` (BASELINE configuration 5; no such key in the reference's YAMLs, which compute in fp32): the 3x3
+    # convolutions' fprop / dgrad on block-scaled fp8 operands.  Process-wide, like chainer.global_config.dtype.
+    from . import functional as Fn
+    Fn.set_conv_dtype(config.conv_dtype or "bf16")
     generator = setup_generator(config, device)
     discriminator = setup_discriminator(config, device)
     optimizer = make_optimizers(config, generator, discriminator, comm)

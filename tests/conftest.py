@@ -34,3 +34,13 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _conv_dtype_is_bf16_unless_a_test_says_otherwise():
+    """functional.set_conv_dtype is process-wide (like chainer.global_config.dtype): a test that switches the 3x3 convolutions
+    to MXFP8 must not leak that into the tests behind it."""
+    yield
+    fn = sys.modules.get("rgbd_gan_amd.functional")
+    if fn is not None and fn.conv_dtype() != "bf16":
+        fn.set_conv_dtype("bf16")

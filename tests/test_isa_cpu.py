@@ -1,7 +1,7 @@
 """Static checks of the generated gfx950 code (hipcc cross-compiles without a GPU).
 
 The LDS-DMA staging of the conv kernels (csrc/conv.hip:lds_dma16) is inline asm that writes M0 (the LDS base of the
-`buffer_load_dwordx4 ... lds` that follows it).  LLVM treats M0 as a reserved register on AMDGPU: an asm clobber of it is
+`buffer_load_dwordx4 ... lds` / `buffer_load_dword ... lds` that follows it).  LLVM treats M0 as a reserved register on AMDGPU: an asm clobber of it is
 accepted but not tracked, so the guarantee that no compiler-generated instruction depends on M0 has to come from the
 code itself -- on gfx9 and later nothing hipcc emits for these kernels reads M0 (LDS instructions do not need it).
 This test pins that: every mention of M0 in the device code is one of the staging moves, and each is consumed by the
@@ -50,4 +50,5 @@ def test_m0_is_touched_only_by_the_lds_dma_staging(tmp_path):
     for i in hits:
         assert lines[i].startswith("s_mov_b32 m0,"), lines[i]
         nxt = [ln for ln in lines[i + 1:i + 4] if not ln.startswith("s_nop")]
-        assert nxt and nxt[0].startswith("buffer_load_dwordx4") and nxt[0].endswith("lds"), (lines[i], nxt[:1])
+        # 16-byte pieces (operand tiles) or 4-byte pieces (the scale dwords of the MXFP8 form: lds_dma4)
+        assert nxt and re.match(r"buffer_load_dword(x4)? ", nxt[0]) and nxt[0].endswith("lds"), (lines[i], nxt[:1])
