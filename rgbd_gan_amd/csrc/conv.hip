@@ -1073,8 +1073,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
         }
         unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.stats) +
                                   ((long)st_b * a.Cout + n0 + wave_co + 16 * q + r16) * 2;
-        atomicAdd(dst, (unsigned long long)__double2ll_rn((double)v1 * 4294967296.0));
-        atomicAdd(dst + 1, (unsigned long long)__double2ll_rn((double)v2 * 4294967296.0));
+        // a NaN / Inf activation or a sum beyond the fixed-point range (2^31) must not come out as a finite, wrong statistic:
+        // such a wave raises the second moment to INT64_MAX instead (any later add wraps it negative) and the consumer
+        // (adain_strip_sum) turns a negative or absurd second moment into NaN -- the layer's output shows the fault
+        if (!(fabsf(v1) < 1e9f) || !(v2 < 1e9f)) {
+            atomicMax(reinterpret_cast<long long*>(dst) + 1, 0x7fffffffffffffffLL);
+        } else {
+            atomicAdd(dst, (unsigned long long)__double2ll_rn((double)v1 * 4294967296.0));
+            atomicAdd(dst + 1, (unsigned long long)__double2ll_rn((double)v2 * 4294967296.0));
+        }
     };
 
     auto epilogue = [&](int pt) {       // bias -> residual -> leaky ReLU (or a given mask) -> bf16 NHWC, then clear the accumulators

@@ -77,8 +77,10 @@ __device__ __forceinline__ void adain_strip_sum(const float* __restrict__ sums, 
         const long long* q8 = reinterpret_cast<const long long*>(sums) + 2 * sidx;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            s1[k] = (float)((double)q8[2 * k] * unit);
-            s2[k] = (float)((double)q8[2 * k + 1] * unit);
+            const long long m2 = q8[2 * k + 1];
+            const bool poisoned = m2 < 0 || m2 >= (1LL << 62);     // see stats_flush (conv.hip): a non-finite or overflowing sum
+            s1[k] = poisoned ? __builtin_nanf("") : (float)((double)q8[2 * k] * unit);
+            s2[k] = poisoned ? __builtin_nanf("") : (float)((double)m2 * unit);
         }
         return;
     }

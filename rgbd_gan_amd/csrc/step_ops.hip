@@ -132,8 +132,8 @@ __global__ __launch_bounds__(256) void scale_by_scalar_kernel(const float* __res
 // the join, and the operand  dout + s_b * x_real  of the adversarial injection at the image planes (functional._ToPlanes).
 // (torch's add / mul kernels did this in rounds 1-2; the library's own kernels are built without packed-fp32
 // instructions)
-__global__ __launch_bounds__(256) void axpy_rows_f32_kernel(const float* __restrict__ a, const float* __restrict__ x,
-                                                            const float* __restrict__ s, float* __restrict__ out,
+__global__ __launch_bounds__(256) void axpy_rows_f32_kernel(const float* a, const float* __restrict__ x,      // `out` may BE `a`
+                                                            const float* __restrict__ s, float* out,             // (no restrict)
                                                             long rows, long row_len) {
     const long n4 = rows * row_len >> 2, r4 = row_len >> 2;
     const f32x4* a4 = reinterpret_cast<const f32x4*>(a);

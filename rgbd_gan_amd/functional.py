@@ -354,7 +354,13 @@ class _ConvDgrad(torch.autograd.Function):
             # the node's output was mask * dgrad(dy, W): its adjoint starts with the same mask -- unless the node that
             # produced ddx (the entry conv's double-backward fprop) has applied it in its epilogue already
             if tie is not None and tie.dd_premasked:
-                tie.dd_premasked = False
+                # the flag is the ADDRESS of the pre-masked tensor: a gradient that the engine has meanwhile summed with
+                # another term (a first-order pass run without input_grads_only: c0's weight-gradient node then feeds this
+                # one too) is a different tensor, partly masked, and cannot be repaired here
+                expected, tie.dd_premasked = tie.dd_premasked, 0
+                if expected != ddx.data_ptr():
+                    raise RuntimeError("ResidualTie: the pre-masked double-backward term was combined with another gradient "
+                                       "before it reached the fused node (run the first-order pass under input_grads_only())")
             else:
                 ddx = _LreluGrad.apply(ddx, ctx.mask_y, ddx.shape[-1])
         g_dy = None
@@ -374,7 +380,7 @@ class _ConvDgrad(torch.autograd.Function):
                     tie.c1_operand = ((g_dy.data_ptr(), tie.fused_mask.data_ptr()), op2)
                 else:
                     g_dy = _ConvFprop.apply(ddx, w, ctx.layer, ctx.ups, None, tie.fused_mask)
-                tie.dd_premasked = True
+                tie.dd_premasked = g_dy.data_ptr()
             else:
                 g_dy = _ConvFprop.apply(ddx, w, ctx.layer, ctx.ups)
                 if tie is not None and role == ROLE_SHORTCUT and tie.give("g_sc", "main_seen", g_dy):
@@ -776,8 +782,11 @@ class _ConvBiasAct(torch.autograd.Function):
                     tie.done = True
         elif ctx.act and tie is not None and role == ROLE_ENTRY and tie.premasked:
             # the main conv's backward produced dy in a fused (input gradient, activation gradient) launch: dy IS dz, and
-            # this bias has its column sums (it decided with the same rules as above: fast_b or inj_b or no gradient)
-            tie.premasked = False
+            # this bias has its column sums (it decided with the same rules as above: fast_b or inj_b or no gradient).
+            # Checked by address, like dd_premasked: h0 has one reader, so nothing can have been added on the way
+            expected, tie.premasked = tie.premasked, 0
+            if expected != dy.data_ptr():
+                raise RuntimeError("ResidualTie: the fused activation gradient did not reach the entry conv unchanged")
             dz = dy
         elif ctx.act:
             dz = kernels.lrelu_bwd(dy, y, w.shape[0], bias_grad=bias.grad) if fast_b else \
@@ -803,8 +812,10 @@ class _ConvBiasAct(torch.autograd.Function):
                 b0, scale0 = _entry_bias_mode(tie.entry_bias)
                 h0 = x.detach()
                 dx = _ConvDgrad.apply(dz, w, layer, ups, h0, inj_bias, tie, role, None, h0, b0, scale0)
-                tie.premasked, tie.fused_mask = True, h0
+                tie.premasked, tie.fused_mask = dx.data_ptr(), h0
             else:
+                if tie is not None and role == ROLE_MAIN:      # unfused this time: nothing stale from an earlier pass
+                    tie.premasked, tie.dd_premasked, tie.fused_mask = 0, 0, None
                 dx = _ConvDgrad.apply(dz, w, layer, ups, x.detach(), inj_bias, tie, role)
                 if tie is not None and role == ROLE_SHORTCUT and tie.give("dx_sc", "entry_seen", dx):
                     dx = None
@@ -869,7 +880,7 @@ class ResidualTie:
         self.dx_sc = self.g_sc = self.operand = None
         self.entry_seen = self.main_seen = False
         self.entry_bias = self.entry_ptr = self.fused_mask = self.c1_operand = None
-        self.premasked = self.dd_premasked = False
+        self.premasked = self.dd_premasked = 0          # addresses of the pre-masked tensors (0: none outstanding)
 
     def usable(self, inject):
         """Mirrors the conditions under which _ConvBiasAct.backward takes its own bias sums in the fused pass."""

@@ -140,6 +140,34 @@ class DeviceImageIterator:
         self.seed = int(sd["seed"])
 
 
+def iterator_state_path(directory, iteration, rank):
+    return os.path.join(directory, f"iterator_rank{rank}_iter_{iteration}.npz")
+
+
+def save_iterator_state(directory, iteration, rank, iterator):
+    """EVERY rank keeps its own iterator state next to the master's snapshot: ranks shuffle the whole data set with their own
+    seeds (train_rgbd.py of the reference: no scatter_dataset, one NumPy RNG per process), so rank 0's position / order /
+    generator state is not theirs."""
+    np.savez(iterator_state_path(directory, iteration, rank), **iterator.state_dict())
+
+
+def load_iterator_state(directory, iteration, rank, iterator, master_snapshot=None):
+    """Resume `iterator` as rank `rank` of a run snapshotted at `iteration`.  Its own file if there is one; else, on rank 0
+    only, the copy inside the master snapshot (snapshots written before per-rank files existed); any other rank keeps the
+    fresh, rank-seeded state it was built with -- loading rank 0's would make every rank draw the same reals for the rest of
+    the run.  -> "own" | "master" | "fresh"."""
+    path = iterator_state_path(directory, iteration, rank)
+    if os.path.exists(path):
+        with np.load(path) as f:
+            iterator.load_state_dict({k: f[k] for k in f.files})
+        return "own"
+    if rank == 0 and master_snapshot is not None and "iterator/pos" in master_snapshot:
+        iterator.load_state_dict({k[len("iterator/"):]: master_snapshot[k] for k in master_snapshot
+                                  if k.startswith("iterator/")})
+        return "master"
+    return "fresh"
+
+
 def build_training(config, device, comm=None, iterator=None, updater_class=None, **updater_kwargs):
     # `conv_dtype: mxfp8` (BASELINE configuration 5; no such key in the reference's YAMLs, which compute in fp32): the 3x3
     # convolutions' fprop / dgrad on block-scaled fp8 operands.  Process-wide, like chainer.global_config.dtype.
@@ -153,7 +181,7 @@ def build_training(config, device, comm=None, iterator=None, updater_class=None,
         models.append(setup_generator(config, device, seed=1000))    # its own random init, like the reference
     if config.generator_architecture == "deepvoxels":             # train_rgbd.py:355-356
         from .updater_deepvoxels import DeepVoxelsUpdater as Updater
-        for k in ("fixed_stage", "concurrent_phases", "dp_split_body", "graph_fallback"):
+        for k in ("fixed_stage", "concurrent_phases", "dp_split_body"):
             updater_kwargs.pop(k, None)
     elif config.rgb:                                               # train_rgbd.py:357-358
         Updater = RGBUpdater

@@ -9,7 +9,11 @@ how the library is built now.  To reproduce the fault:
 Every process repeats rgbd_warp_loss_bwd on fixed inputs into a freshly initialised buffer and counts the repetitions
 whose result differs from its own first one -- by a single bit for the warp-loss backward (its scatter accumulates in
 64-bit fixed point with integer atomics since round 3), by more than the rounding of re-ordered fp32 atomics for the
-fp32-atomic victims (--victim scatter / bias)."""
+fp32-atomic victims (--victim scatter / bias).
+Round 4: victims that are NOT this library's code -- `add_` (torch's in-place fp32 vector add, what gradient accumulation
+launches) and `sum2` (two 34 MB fp32 buffers summed into a third: the reduction step of an all-reduce, which under data
+parallelism runs beside the other stream's MFMA waves by design) -- built by torch with the compiler's defaults, i.e.
+possibly with packed-fp32 instructions; log: profiles/r04/hazard_foreign_fp32_kernels.log."""
 import argparse, os, subprocess, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
@@ -126,6 +130,15 @@ def worker(args):
             once = lambda: src / den
         elif args.victim == "trans":        # transcendental unit
             once = lambda: torch.exp(src) * torch.rsqrt(src.abs() + 1.0) + torch.log(src.abs() + 1.0)
+        elif args.victim == "add_":         # what autograd's AccumulateGrad launches: an in-place fp32 vector add (torch's
+            n_big = 34 * (1 << 20) // 4     #   vectorised elementwise kernel; 34 MB = the discriminator's flat gradient buffer)
+            ga, gb = torch.randn(n_big, device=dev), torch.randn(n_big, device=dev)
+            once = lambda: ga.clone().add_(gb)
+        elif args.victim == "sum2":         # an all-reduce's reduction step as RCCL runs it beside the other stream's MFMA waves:
+            n_big = 34 * (1 << 20) // 4     #   two 34 MB fp32 buffers -> one (out-of-place sum)
+            ga, gb = torch.randn(n_big, device=dev), torch.randn(n_big, device=dev)
+            gc = torch.empty_like(ga)
+            once = lambda: torch.add(ga, gb, out=gc).clone()
         elif args.victim == "fma":          # plain VALU arithmetic, many operations per element
             def once():
                 y = src
@@ -167,7 +180,7 @@ if __name__ == "__main__":
     ap.add_argument("--half", type=int, default=2)
     ap.add_argument("--partner", default="warp", help="warp | conv | idle | step | step_eager | k_sp | k_patch | k_gather | k_wgrad | k_lrelu | k_adain")
     ap.add_argument("--role", default=None)
-    ap.add_argument("--victim", default="warp", choices=["warp", "warpfwd", "bias", "scatter", "gather", "copy", "div", "trans", "fma"])
+    ap.add_argument("--victim", default="warp", choices=["warp", "warpfwd", "bias", "scatter", "gather", "copy", "div", "trans", "fma", "add_", "sum2"])
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--variant", type=int, default=0, help="partner k_sp: rgbd_debug_conv_variant (11-16: knock-outs)")
     ap.add_argument("--same-seed", action="store_true", help="every process works on identical data")

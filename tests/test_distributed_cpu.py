@@ -149,3 +149,38 @@ def test_bench_parent_fails_when_a_rank_fails():
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode != 0 and '"metric"' not in r.stdout
     assert "exited with code" in r.stderr
+
+
+def test_every_rank_resumes_its_own_sample_sequence(tmp_path):
+    """Resume under data parallelism (round-3 advisor finding): ranks shuffle the whole data set with their own seeds, so a
+    resumed rank must continue ITS sequence -- rank 0's state loaded everywhere makes all ranks draw the same reals for the
+    rest of the run.  Each rank writes / reads its own iterator file; with only the master's snapshot present (files written
+    before per-rank states existed) rank 0 takes that copy and the other ranks keep a fresh rank-seeded shuffle."""
+    from rgbd_gan_amd.training import DeviceImageIterator, load_iterator_state, save_iterator_state
+    images = np.random.RandomState(0).randint(0, 256, (40, 3, 8, 8)).astype("uint8")
+    make = lambda rank: DeviceImageIterator(images, 8, "cpu", seed=11 + rank)
+    its = [make(0), make(1)]
+    for it in its:
+        for _ in range(7):                                  # past an epoch boundary: a second permutation has been drawn
+            it.next_indices()
+    for r, it in enumerate(its):
+        save_iterator_state(str(tmp_path), 1000, r, it)
+    want = [[it.next_indices().tolist() for _ in range(6)] for it in its]
+    assert want[0] != want[1]
+    resumed = [make(0), make(1)]
+    assert [load_iterator_state(str(tmp_path), 1000, r, it) for r, it in enumerate(resumed)] == ["own", "own"]
+    got = [[it.next_indices().tolist() for _ in range(6)] for it in resumed]
+    assert got == want                                      # every rank continues its own sequence ...
+    assert got[0] != got[1]                                 # ... and they are different sequences
+    # only the master's copy: rank 0 resumes from it, rank 1 must NOT adopt it
+    its = [make(0), make(1)]
+    for it in its:
+        for _ in range(3):
+            it.next_indices()
+    master = {f"iterator/{k}": v for k, v in its[0].state_dict().items()}
+    want0 = [its[0].next_indices().tolist() for _ in range(4)]
+    fresh = [make(0), make(1)]
+    assert load_iterator_state(str(tmp_path), 2000, 0, fresh[0], master) == "master"
+    assert load_iterator_state(str(tmp_path), 2000, 1, fresh[1], master) == "fresh"
+    assert [fresh[0].next_indices().tolist() for _ in range(4)] == want0
+    assert [fresh[1].next_indices().tolist() for _ in range(4)] != want0

@@ -635,6 +635,34 @@ def test_conv_epilogue_statistics_feed_adain(B, S, Cin, Cout, ups):
     assert torch.equal(kernels.adain_apply_fixed(y, stats, ss, col_off=4)[0], out)
 
 
+def test_conv_epilogue_statistics_propagate_non_finite_values():
+    """A NaN (or an overflow of the 2^-32 fixed-point sums) in a conv output must not leave finite, wrong instance-norm
+    statistics behind (round-3 advisor finding): the sample / channel pairs a NaN reaches come out of the AdaIN as NaN, the
+    others are untouched."""
+    from rgbd_gan_amd import kernels
+    g = torch.Generator().manual_seed(77)
+    B, S, C = 2, 32, 128
+    x = torch.randn(B, S, S, C, generator=g).to(torch.bfloat16)
+    x[1, 7, 9, 3] = float("nan")
+    x = x.to(dev())
+    w = torch.randn(C, C, 3, 3, generator=g).to(dev())
+    bias = torch.zeros(C, device=dev())
+    ss = torch.randn(B, 2 * C, generator=g).to(dev())
+    wf, _ = kernels.pack_weights(w, float(np.sqrt(2.0 / (C * 9))), True, False)
+    y, stats = kernels.conv2d_fprop_stats(x, wf, bias, lrelu_channels=C)
+    out, mean, rstd = kernels.adain_apply_fixed(y, stats, ss)
+    assert torch.isfinite(out[0].float()).all() and torch.isfinite(mean[0]).all()
+    assert torch.isnan(mean[1]).all() and torch.isnan(out[1].float()).all()       # every output channel sees input channel 3
+    # overflow of the second moment: activations of ~3e3 over 1024 pixels sum to ~1e10 > 2^31
+    big = (torch.randn(B, S, S, C, generator=g) * 2e3).to(torch.bfloat16).to(dev())
+    y2, stats2 = kernels.conv2d_fprop_stats(big, wf, bias, lrelu_channels=C)
+    out2, mean2, _ = kernels.adain_apply_fixed(y2, stats2, ss)
+    ref, mean_ref, _ = kernels.adain_fwd(y2, ss)
+    ok = torch.isfinite(mean2)
+    torch.testing.assert_close(mean2[ok], mean_ref[ok], atol=1e-2, rtol=1e-4)     # where it is finite it is right ...
+    assert (~ok).any()                                                           # ... and the overflowing pairs say so
+
+
 CONV_VARIANT_CASES = [  # (B, Hout, Cin, Cout, upsample, residual, pooled output)
     (32, 64, 128, 128, False, False, False),     # two pixel tiles per persistent workgroup, two channel slices each
     (32, 64, 256, 256, False, True, True),       # four tiles per workgroup, residual + fused 2x2 average

@@ -22,7 +22,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from rgbd_gan_amd.dist import Communicator
-from rgbd_gan_amd.training import DeviceImageIterator, build_training, make_dataset
+from rgbd_gan_amd.training import (DeviceImageIterator, build_training, load_iterator_state, make_dataset,
+                                   save_iterator_state)
 from rgbd_gan_amd.utils import yaml_utils
 
 
@@ -92,8 +93,11 @@ def main():
             o.load_state_dict({"t": snap[f"{k}/t"], "m": snap[f"{k}/m"], "v": snap[f"{k}/v"]})
         # the trainer snapshot of the reference also carries the iterator (position, epoch, order) and LogReport's entries
         # (chainer serializes trainer -> updater -> iterators, extensions); older snapshots of this engine lack them
-        if "iterator/pos" in snap.files:
-            iterator.load_state_dict({k[len("iterator/"):]: snap[k] for k in snap.files if k.startswith("iterator/")})
+        # -- per rank: every rank shuffles with its own seed, so each resumes ITS position / order / generator state
+        how = load_iterator_state(d, resume, comm.rank if comm is not None else 0, iterator,
+                                  {k: snap[k] for k in snap.files if k.startswith("iterator/")})
+        if how == "fresh" and comm is not None and comm.rank > 0:
+            print(f"rank {comm.rank}: no iterator state of its own in {d}; continuing with a fresh rank-seeded shuffle")
         if "log" in snap.files:
             log_resumed = json.loads(str(snap["log"]))
             elapsed_resumed = float(snap["elapsed_time"])
@@ -119,6 +123,8 @@ def main():
         if previews and it % config.evaluation_sample_interval == 0:
             for pv in previews:
                 pv(updater.stage, it)
+        if it % (config.snapshot_interval or 10000) == 0 and comm is not None and comm.size > 1:
+            save_iterator_state(out, it, comm.rank, iterator)
         if is_master and it % (config.snapshot_interval or 10000) == 0:
             for name, m in models:
                 save_npz(f"{out}/{name}_{it}.npz", m)
