@@ -68,7 +68,56 @@ def deepvoxels_case(seed):
     return out
 
 
+STEP_TINY = dict(ch=16, B=4, cfg=dict(lambda_gp=1.0, lambda_depth=10, depth_min=1.0, lambda_geometric=None, lambda_rotate=None,
+                                      start_rotation=2000, start_occlusion_aware=2000))
+
+
+def step_tiny_case(stage):
+    """One full update_core of the ORACLE (oracle/step.py:rgbd_step: generator step, discriminator step, R1, 3-D loss, clipped
+    Chainer-flavoured Adam) on 16-channel networks: losses, pre-clip gradient norms, the norm and four probe entries of every
+    parameter gradient, and the norm of every parameter after the update.  Runs in well under a second on the CPU box, so an
+    edit of the oracle that changes a gradient or the optimizer is caught there (tests/test_golden.py), not only on the GPU
+    box where the engine is compared with it."""
+    from oracle import nets, step
+    ch, B = STEP_TINY["ch"], STEP_TINY["B"]
+    gp = {k: v.requires_grad_(True) for k, v in nets.init_stylegan(ch, seed=0).items()}
+    dp = {k: v.requires_grad_(True) for k, v in nets.init_discriminator(ch, seed=1).items()}
+    torch.manual_seed(0)
+    for i in range(6):                                   # a depth head that sees geometry
+        with torch.no_grad():
+            gp[f"gen/outs/{i}/c/W"][-1] = torch.randn(gp[f"gen/outs/{i}/c/W"][-1].shape) * 0.1
+    omap = {k: v for k, v in gp.items() if k.startswith("mapping/")}
+    ogen = {k: v for k, v in gp.items() if k.startswith("gen/")}
+    low = {k: 1e-5 for k in ("gen/l1/c/W", "gen/l1/c/b", "gen/l2/c/W", "gen/l2/c/b")}
+    opt = {"map": step.ChainerAdam(omap, 1e-5), "gen": step.ChainerAdam(ogen, 1e-3, alpha_override=low),
+           "dis": step.ChainerAdam(dp, 3e-3)}
+    rng = np.random.RandomState(0)
+    zh = nets.make_hidden(B // 2, ch, rng)
+    z = np.concatenate([zh, zh])
+    np.random.seed(2)
+    thetas = camera.PosePrior(0.3054, 1.0472, 0).sample(B)
+    x_real = rng.randint(0, 256, (B, 3, 128, 128)).astype("float32") / 127.5 - 1
+    ref = step.rgbd_step(gp, dp, opt, x_real, z, thetas, stage, STEP_TINY["cfg"], 200000)
+    out = {"stage": np.array(stage), "x_fake": ref["x_fake"].detach().numpy()}
+    for k in ("gen/loss_adv", "gen/loss_rotate", "dis/loss_adv", "dis/loss_gp", "norm_map", "norm_gen", "norm_dis"):
+        out["obs/" + k] = np.array(float(ref[k]), dtype=np.float64)
+    names, gnorm, probe, pnorm = [], [], [], []
+    for src in (gp, dp):
+        for k in sorted(src):
+            g = src[k].grad
+            names.append(k)
+            gnorm.append(0.0 if g is None else float(g.double().norm()))
+            flat = torch.zeros(4) if g is None else g.flatten()[:: max(1, g.numel() // 4)][:4]
+            probe.append(np.pad(flat.numpy(), (0, 4 - len(flat))))
+            pnorm.append(float(src[k].detach().double().norm()))
+    out.update(names=np.array(names), grad_norm=np.array(gnorm), grad_probe=np.stack(probe).astype("float32"),
+               param_norm_after=np.array(pnorm))
+    return out
+
+
 def main():
+    for stage in (4.0, 5.5):
+        np.savez_compressed(os.path.join(HERE, f"step_tiny_stage{stage}.npz"), **step_tiny_case(stage))
     np.savez_compressed(os.path.join(HERE, "deepvoxels_small.npz"), **deepvoxels_case(103))
     np.savez_compressed(os.path.join(HERE, "warp_loss_b2_s16_occ.npz"), **warp_case(101, 2, 16, True, 3.0))
     np.savez_compressed(os.path.join(HERE, "warp_loss_b3_s8.npz"), **warp_case(102, 3, 8, False, 2.0))

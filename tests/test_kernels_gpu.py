@@ -68,7 +68,7 @@ def test_warp_loss_forward_bit_exact_indices(b, S, occ):
     assert abs(float(loss.item()) - ref["loss"]) < 1e-4 * max(1.0, abs(ref["loss"]))
 
 
-@pytest.mark.parametrize("b,S,occ", [(3, 16, False), (2, 32, True)])
+@pytest.mark.parametrize("b,S,occ", [(3, 16, False), (2, 32, True), (16, 128, True)])     # the last: the benchmark's own size
 def test_warp_loss_backward_matches_autograd(b, S, occ):
     from rgbd_gan_amd import kernels
     img, img_rot, cam, cam_rot = _warp_case(b, S, seed=20 + S)
