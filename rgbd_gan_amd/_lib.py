@@ -113,12 +113,29 @@ PROTOTYPES = {
 _lib = None
 
 
-# test / tuning hooks (rgbd_gan_amd/csrc/rgbd_debug.h): exported by the library, NOT part of the drop-in ABI
+# rgbd_gan_amd/csrc/rgbd_debug.h: NOT part of the drop-in ABI.  The label query is exported by every build; the two planner
+# switches (and the A/B reference kernels they select) exist in the debug library only (python -m rgbd_gan_amd.build --debug)
 DEBUG_PROTOTYPES = {
-    "rgbd_debug_force_gather_kernel": ([c_int], c_int),
     "rgbd_last_conv_kernel": ([], c_char_p),
+}
+DEBUG_ONLY_PROTOTYPES = {
+    "rgbd_debug_force_gather_kernel": ([c_int], c_int),
     "rgbd_debug_conv_variant": ([c_int], c_int),
 }
+DEBUG_LIB_PATH = os.path.join(_HERE, "librgbdgan_hip_debug.so")
+
+
+def _bind(path, extra=()):
+    lib = ctypes.CDLL(path)
+    for name, (argtypes, restype) in list(PROTOTYPES.items()) + list(DEBUG_PROTOTYPES.items()) + list(extra):
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = restype
+    got = lib.rgbd_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"{os.path.basename(path)} ABI {got} != expected {ABI_VERSION}; rebuild")
+    return lib
+
 
 def load():
     """Load the library once; raise (never fall back) when it is absent or has the wrong ABI."""
@@ -129,18 +146,43 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} not found: build it with `python -m rgbd_gan_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU or PyTorch fallback for the hot path.")
-    lib = ctypes.CDLL(LIB_PATH)
-    for name, (argtypes, restype) in list(PROTOTYPES.items()) + list(DEBUG_PROTOTYPES.items()):
-        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
-        fn.argtypes = argtypes
-        fn.restype = restype
-    got = lib.rgbd_abi_version()
-    if got != ABI_VERSION:
-        raise RuntimeError(f"librgbdgan_hip.so ABI {got} != expected {ABI_VERSION}; rebuild")
-    if os.environ.get("RGBD_CONV_VARIANT"):            # tuning aid (scripts/ab_conv.py): see rgbd_debug_conv_variant
-        lib.rgbd_debug_conv_variant(int(os.environ["RGBD_CONV_VARIANT"]))
-    _lib = lib
-    return lib
+    _lib = _bind(LIB_PATH)
+    if os.environ.get("RGBD_CONV_VARIANT") and hasattr(_lib, "rgbd_debug_conv_variant"):
+        # tuning aid (scripts/soak.py): RGBD_LIB_PATH pointing at the debug library + a variant of rgbd_debug_conv_variant
+        _lib.rgbd_debug_conv_variant.argtypes, _lib.rgbd_debug_conv_variant.restype = [c_int], c_int
+        _lib.rgbd_debug_conv_variant(int(os.environ["RGBD_CONV_VARIANT"]))
+    return _lib
+
+
+_debug_lib = None
+
+
+def load_debug():
+    """The debug library (A/B reference kernels + planner switches): tests and tuning scripts only."""
+    global _debug_lib
+    if _debug_lib is None:
+        if not os.path.exists(DEBUG_LIB_PATH):
+            raise RuntimeError(f"{DEBUG_LIB_PATH} not found: build it with `python -m rgbd_gan_amd.build --debug`")
+        _debug_lib = _bind(DEBUG_LIB_PATH, DEBUG_ONLY_PROTOTYPES.items())
+    return _debug_lib
+
+
+class debug_library:
+    """with _lib.debug_library() as lib: ...  -- inside, every wrapper of rgbd_gan_amd.kernels calls the DEBUG library, whose
+    switches `lib.rgbd_debug_conv_variant` / `lib.rgbd_debug_force_gather_kernel` select the reference kernels; both are put
+    back to 0 on the way out.  Cross-checks and A/B timing only: the training path never enters this."""
+
+    def __enter__(self):
+        global _lib
+        self.saved = _lib
+        _lib = load_debug()
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib.rgbd_debug_conv_variant(0)
+        _lib.rgbd_debug_force_gather_kernel(0)
+        _lib = self.saved
 
 
 def check(rc, what):

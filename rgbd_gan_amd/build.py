@@ -1,6 +1,7 @@
 """Build librgbdgan_hip.so (gfx950) in-tree with hipcc.  No torch involved: the library is a plain C ABI.
 
     python -m rgbd_gan_amd.build [--force]
+    python -m rgbd_gan_amd.build --debug            # librgbdgan_hip_debug.so: + the A/B reference kernels and planner switches
     python -m rgbd_gan_amd.build --packed-fp32 --out /tmp/librgbdgan_pk.so     # A/B library for scripts/hw/ (never shipped)
 """
 import os
@@ -10,6 +11,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "librgbdgan_hip.so")
+# The debug library = the same sources with -DRGBD_DEBUG_BUILD: it additionally carries round 1's register-staged 3x3 kernel,
+# the tap-split weight-gradient body, the timing knock-outs of the pipelined kernel and the two process-wide planner switches
+# that select them (csrc/rgbd_debug.h).  Tests and scripts/ load it for cross-checks and A/B timing; the training path never.
+DEBUG_OUT = os.path.join(HERE, "librgbdgan_hip_debug.so")
 ARCH = "gfx950"
 
 # (source, extra flags).  warp_loss.hip must not contract a*b+c into FMAs: its index math is specified
@@ -56,11 +61,14 @@ def _run(cmd):
         raise subprocess.CalledProcessError(r.returncode, cmd)
 
 
-def build(force=False, verbose=True, out=OUT, packed_fp32=False):
+def build(force=False, verbose=True, out=OUT, packed_fp32=False, debug=False):
     """packed_fp32=True (with another `out`): the compiler's default code generation, for the A/B of DESIGN.md section 3
-    (scripts/hw/atomic_share_stress.py with RGBD_LIB_PATH); objects go to a directory next to `out`."""
+    (scripts/hw/atomic_share_stress.py with RGBD_LIB_PATH); objects go to a directory next to `out`.
+    debug=True: the debug library (DEBUG_OUT unless `out` says otherwise)."""
     hipcc = _hipcc()
-    common = [f for f in COMMON if packed_fp32 is False or f not in NO_PACKED_FP32]
+    if debug and out == OUT:
+        out = DEBUG_OUT
+    common = [f for f in COMMON if packed_fp32 is False or f not in NO_PACKED_FP32] + (["-DRGBD_DEBUG_BUILD"] if debug else [])
     objdir = CSRC if out == OUT else os.path.splitext(out)[0] + "_obj"
     if packed_fp32 and out == OUT:
         raise ValueError("the shipped library is built without packed-fp32 instructions; give another --out")
@@ -87,4 +95,4 @@ def build(force=False, verbose=True, out=OUT, packed_fp32=False):
 
 if __name__ == "__main__":
     target = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else OUT
-    print(build(force="--force" in sys.argv, out=target, packed_fp32="--packed-fp32" in sys.argv))
+    print(build(force="--force" in sys.argv, out=target, packed_fp32="--packed-fp32" in sys.argv, debug="--debug" in sys.argv))

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void conv_fprop_kernel(ConvArgs a) {
 template <int S>   // image side: 4 or 8
 __global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvArgs a) {
     constexpr int HP = S + 2, IM = 128 / (S * S), NH = IM * HP * HP;     // halo side, images per tile, halo pixels per tile
-    constexpr int X_BYTES = NH * 128, W_BYTES = 9 * 64 * 128;
+    constexpr int X_BYTES = NH * 128;
     constexpr int XL = (NH * 8 + 255) / 256, WL = 9 * 64 * 8 / 256;      // 16-byte pieces per thread: 7 or 9, and 18
     extern __shared__ __attribute__((aligned(16))) unsigned char ssm[];  // [X_BYTES] halo images, [W_BYTES] nine weight tiles
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -387,6 +387,7 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const float* __
     }
 }
 
+#ifdef RGBD_DEBUG_BUILD     // A/B reference of round 1: `python -m rgbd_gan_amd.build --debug` only (rgbd_debug.h)
 // ------------------------------------------------------------------------------------------------ 3x3 patch kernel
 // The hot fprop/dgrad kernel for 3x3 pad-1 convolutions on images of 16x16 and larger.
 //
@@ -694,6 +695,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(ConvArgs a) {
     }
 }
 
+#endif  // RGBD_DEBUG_BUILD
+
 // ------------------------------------------------------------------------------------------------ 3x3 pipelined kernel
 // The same tiling and LDS images as conv3x3_patch_kernel (16x16 output pixels x BN output channels per 512-thread
 // workgroup, 18x18 halo patch per 64-channel slice, one BN x 64 weight tile per filter tap), restructured so that the
@@ -778,9 +781,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
     constexpr int NROWS = HPW * HPW;
     constexpr int P_PIECES = (NROWS * 128 + 1023) / 1024;   // 1-KiB DMA pieces per halo patch (41 or 13)
     constexpr int P_BYTES = P_PIECES * 1024;
-    constexpr int PPW = (P_PIECES + 7) / 8;       // patch pieces per wave per slice (6 or 2)
     constexpr int W_BYTES = BN * 128;
-    constexpr int WPW = BN / 64;                  // weight pieces per wave per K step
     constexpr int WAVES_CO = BN / 64;
     constexpr int WAVES_PX = 8 / WAVES_CO;
     constexpr int PX_PER_WAVE = 256 / WAVES_PX;   // 64 or 32 pixels = 4 or 2 patch rows
@@ -1858,9 +1859,11 @@ __device__ __forceinline__ void conv_wgrad9_body(const WgradArgs& a, const int s
 }
 constexpr int WGRAD9_LDS = 9 * 16 * 4 * 64 * 4;            // the final exchange (147456 B) exceeds the three buffers
 
+#ifdef RGBD_DEBUG_BUILD
 __global__ __launch_bounds__(512, 2) void conv_wgrad_tapsplit_kernel(WgradArgs a) {    // A/B reference (variant 3)
     conv_wgrad_body<9, true>(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
+#endif
 template <int NT, bool FAST>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_kernel(WgradArgs a) {
     if constexpr (NT == 9 && FAST) conv_wgrad9_body(a, blockIdx.x, blockIdx.y, blockIdx.z);
@@ -2012,8 +2015,13 @@ int device_cus() {
     }
     return cus[dev];
 }
+#ifdef RGBD_DEBUG_BUILD
 bool g_force_gather = false;   // test hook: route every shape through the generic gather kernel
 int g_conv_variant = 0;        // test / tuning hook: 1 = the register-staged conv3x3_patch_kernel instead of the ping-pong one
+#else                          // the shipped library has neither switch nor the kernels they select: no process-wide state
+constexpr bool g_force_gather = false;
+constexpr int g_conv_variant = 0;
+#endif
 
 int ilog2(int v) {
     int l = 0;
@@ -2023,18 +2031,20 @@ int ilog2(int v) {
 
 }  // namespace
 
+#ifdef RGBD_DEBUG_BUILD
 extern "C" int rgbd_debug_force_gather_kernel(int on) {
     g_force_gather = on != 0;
     return 0;
 }
-namespace {
-thread_local const char* g_last_conv_kernel = "";     // per calling thread: profiling label of its last conv launch
-}
-extern "C" const char* rgbd_last_conv_kernel(void) { return g_last_conv_kernel; }
 extern "C" int rgbd_debug_conv_variant(int v) {
     g_conv_variant = v;
     return 0;
 }
+#endif
+namespace {
+thread_local const char* g_last_conv_kernel = "";     // per calling thread: profiling label of its last conv launch
+}
+extern "C" const char* rgbd_last_conv_kernel(void) { return g_last_conv_kernel; }
 namespace {
 // Split-K plan of the gather kernel: 1 (no split) when the unsplit launch already fills the chip.
 struct FpropPlan {
@@ -2069,6 +2079,7 @@ FpropPlan plan_fprop(int B, int Hout, int Wout, int Cin, int Cout, int KH, int K
         if (s > nk / 2) s = nk / 2;
         if (s > 1) p.ksplit = (int)s;
     }
+#ifdef RGBD_DEBUG_BUILD
     static const int ksplit_env = [] {                          // tuning aid, read ONCE: 0 = patch kernel where eligible, n = force n
         const char* e = getenv("RGBD_DEBUG_KSPLIT");
         return e ? atoi(e) : -1;
@@ -2078,6 +2089,7 @@ FpropPlan plan_fprop(int B, int Hout, int Wout, int Cin, int Cout, int KH, int K
         if (v == 0) { p.patch = eligible; p.ksplit = 1; }
         else if (v > 0) { p.patch = false; p.ksplit = v > nk / 2 ? (nk / 2 > 0 ? nk / 2 : 1) : v; }
     }
+#endif
     return p;
 }
 }  // namespace
@@ -2261,6 +2273,7 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
                              "rgbd_conv2d_fprop_bf16: cannot reserve %d B of LDS", lds_sp);
                 sp_attr_done[vi] = true;
             }
+#ifdef RGBD_DEBUG_BUILD
             if (g_conv_variant >= 11 && g_conv_variant <= 16 && vi == 2) {     // timing knock-outs (scripts/ab_conv.py)
                 const int ko = g_conv_variant - 10;
                 const void* fk = ko == 1 ? (const void*)&conv3x3_sp_kernel<128, false, 1>
@@ -2277,6 +2290,7 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
                 RGBD_CHECK_LAUNCH("conv3x3_sp_kernel<KO>");
                 return 0;
             }
+#endif
             if (stats) {
                 const void* fs = vi == 3 ? (const void*)&conv3x3_sp_kernel<128, true, 0, 2>
                                : vi == 2 ? (const void*)&conv3x3_sp_kernel<128, false, 0, 2>
@@ -2319,6 +2333,7 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
             g_last_conv_kernel = wide ? "conv3x3_sp_kernel<128>" : "conv3x3_sp_kernel<64>";
             return 0;
         }
+#ifdef RGBD_DEBUG_BUILD
         const int lds = 2 * 324 * 128 + 3 * (wide ? 128 : 64) * 128 + (wide ? 128 : 64) * 4;
         const void* fn = wide ? (a.ups ? (const void*)&conv3x3_patch_kernel<128, true>
                                        : (const void*)&conv3x3_patch_kernel<128, false>)
@@ -2341,6 +2356,10 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
         RGBD_CHECK_LAUNCH("conv3x3_patch_kernel");
         g_last_conv_kernel = wide ? "conv3x3_patch_kernel<128>" : "conv3x3_patch_kernel<64>";
         return 0;
+#else
+        rgbd_set_error("rgbd_conv2d_fprop_bf16: unreachable");
+        return -1;
+#endif
     }
     if (Cout % 128 == 0) {
         const long grid = mtiles * (Cout / 128) * a.ksplit;
@@ -2512,12 +2531,15 @@ static int wgrad_partial_impl(const void* x, const void* dy, void* workspace, in
                          "rgbd_conv2d_wgrad_bf16: cannot reserve %d B of LDS", lds);
             attr_done[v] = true;
         }
+#ifdef RGBD_DEBUG_BUILD
         if (K == 3 && fast && g_conv_variant == 3) {
             const int lds_old = 2 * (180 * 128 + 128 * 128);
             RGBD_REQUIRE(hipFuncSetAttribute((const void*)&conv_wgrad_tapsplit_kernel,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_old) == hipSuccess, "lds");
             conv_wgrad_tapsplit_kernel<<<grid, 512, lds_old, st>>>(a);
-        } else if (K == 3) {
+        } else
+#endif
+        if (K == 3) {
             if (fast) conv_wgrad_kernel<9, true><<<grid, 512, lds, st>>>(a);
             else      conv_wgrad_kernel<9, false><<<grid, 512, lds, st>>>(a);
         } else {

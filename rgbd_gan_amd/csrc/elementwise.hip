@@ -1275,8 +1275,10 @@ extern "C" int rgbd_adain_bwd(const void* x, const void* dy, const float* scale,
 // blocks on 2048-row strips; small ones: 256 threads on strips short enough to give every CU a block.
 struct ColsumPlan { int threads, rows; };
 static ColsumPlan plan_colsum(long M) {
+#ifdef RGBD_DEBUG_BUILD
     static const int dbg_rows = [] { const char* e = getenv("RGBD_DEBUG_COLSUM_ROWS"); return e ? atoi(e) : 0; }();
     if (dbg_rows > 0) return ColsumPlan{dbg_rows >= 1024 ? 1024 : 256, dbg_rows};
+#endif
     if (M >= 131072) return ColsumPlan{1024, 2048};
     if (M >= 32768) return ColsumPlan{256, 256};
     return ColsumPlan{256, 128};

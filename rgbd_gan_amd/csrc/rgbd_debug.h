@@ -1,7 +1,13 @@
 /*
  * rgbd_debug.h -- test / tuning hooks of librgbdgan_hip.so.  NOT part of the drop-in C ABI (include/rgbd_gan_hip.h): nothing
  * on the training path calls these; tests/ and scripts/ do (A/B timing of kernel variants, cross-checks of the conv planner's
- * choices, profiling labels).  They set process-wide switches, which the ABI proper never does.
+ * choices, profiling labels).
+ *
+ * rgbd_last_conv_kernel is exported by every build (a thread-local label, no switch).  The two SWITCHES below are process-wide
+ * state, which the ABI proper never has: they -- and the kernels they select (round 1's register-staged 3x3 kernel, the
+ * tap-split weight-gradient body, the timing knock-outs of the pipelined kernel) -- exist only in librgbdgan_hip_debug.so
+ * (`python -m rgbd_gan_amd.build --debug`, -DRGBD_DEBUG_BUILD; rgbd_gan_amd/_lib.py:debug_library).  The shipped
+ * librgbdgan_hip.so contains neither.
  */
 #pragma once
 #ifdef __cplusplus

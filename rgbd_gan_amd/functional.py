@@ -19,8 +19,6 @@ import torch.nn.functional as F
 
 from . import kernels
 
-# A/B switch, read once: RGBD_NO_FUSE=stats,actgrad turns the named epilogue fusions off (separate passes instead)
-_NO_FUSE = frozenset(t for t in os.environ.get("RGBD_NO_FUSE", "").split(",") if t)
 _WEIGHT_EPOCH = 0          # bumped whenever master weights change (optimizer step, checkpoint load)
 _SKIP_WGRAD = False        # set while only input gradients are wanted (R1's inner grad)
 _FROZEN_PTRS = frozenset()  # parameters (by storage address) whose gradients the current backward must not produce
@@ -521,7 +519,7 @@ class _ConvLreluAdaIN(torch.autograd.Function):
         wf, _ = layer.packed()
         x = x.contiguous()
         Ho, Wo = (2 * x.shape[1], 2 * x.shape[2]) if ups else (x.shape[1], x.shape[2])
-        if "stats" not in _NO_FUSE and layer.K == 3 and layer.pad == 1 and \
+        if layer.K == 3 and layer.pad == 1 and \
                 kernels.conv3x3_actgrad_supported(x.shape[0], Ho, Wo, x.shape[3], w.shape[0]):
             # images >= 16x16: the instance-norm statistics come out of the conv's epilogue (order-independent integer
             # sums), the AdaIN is its apply pass alone
@@ -850,7 +848,7 @@ def _entry_bias_mode(b0):
 
 
 def _entry_fusable(tie, x, dz, layer, ups):
-    return ("actgrad" not in _NO_FUSE and tie.entry_bias is not None and tie.entry_ptr == x.data_ptr() and not ups
+    return (tie.entry_bias is not None and tie.entry_ptr == x.data_ptr() and not ups
             and layer.K == 3 and layer.pad == 1
             and _entry_bias_mode(tie.entry_bias) is not False
             and kernels.conv3x3_actgrad_supported(dz.shape[0], dz.shape[1], dz.shape[2], dz.shape[3], x.shape[3]))

@@ -12,7 +12,7 @@ from rgbd_gan_amd import kernels, _lib
 B = int(os.environ.get("B", "32"))
 REPS = int(os.environ.get("REPS", "30"))
 dev = "cuda:0"
-lib = _lib.load()
+lib = _lib.debug_library().__enter__()     # the A/B reference kernels live in the debug library (build --debug)
 shapes = [(128, 64, 64, 0), (128, 128, 64, 1), (128, 64, 128, 0), (64, 128, 128, 0), (64, 128, 256, 0), (64, 256, 256, 0),
           (32, 256, 256, 0), (16, 256, 256, 0), (32, 256, 256, 1), (64, 256, 128, 1)]          # (Hout, Cin, Cout, upsample)
 variants = [int(v) for v in os.environ.get("VARIANTS", "1,0").split(",")]

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from rgbd_gan_amd import kernels, _lib
 N = int(os.environ.get("N", "300"))
-lib = _lib.load()
+lib = _lib.debug_library().__enter__()     # the A/B reference kernels live in the debug library (build --debug)
 dev = "cuda"
 g = torch.Generator(device=dev).manual_seed(1)
 bad = 0

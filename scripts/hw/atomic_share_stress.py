@@ -60,7 +60,7 @@ def worker(args):
         if name in ("sp", "patch"):
             if name == "patch" or args.variant:
                 from rgbd_gan_amd import _lib
-                _lib.load().rgbd_debug_conv_variant(args.variant or 1)
+                _lib.debug_library().__enter__().rgbd_debug_conv_variant(args.variant or 1)
             xx = t(B, 64, 64, 256); w = torch.randn(256, 256, 3, 3, device=dev)
             wf, wd = kernels.pack_weights(w, 0.02)
             fn = lambda: kernels.conv2d_fprop(xx, wf, 3, 3, 1)

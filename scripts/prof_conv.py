@@ -3,7 +3,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from rgbd_gan_amd import kernels, _lib
-lib = _lib.load()
+lib = _lib.debug_library().__enter__()     # the A/B reference kernels live in the debug library (build --debug)
 B = int(os.environ.get("B", "32"))
 reps = int(os.environ.get("REPS", "5"))
 dev = "cuda:0"

@@ -30,6 +30,9 @@ if os.environ.get("SOAK_CHILD"):
 out = {}
 for variant in ("0", "1"):
     env = dict(os.environ, SOAK_CHILD="1", RGBD_CONV_VARIANT=variant)
+    if variant != "0":       # the reference kernels live in the debug library (python -m rgbd_gan_amd.build --debug)
+        env["RGBD_LIB_PATH"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rgbd_gan_amd",
+                                            "librgbdgan_hip_debug.so")
     r = subprocess.run([sys.executable, __file__, str(N if variant == "0" else 12)], env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     out[variant] = json.loads([l for l in r.stdout.splitlines() if l.startswith("TRAJ ")][0][5:])

@@ -23,9 +23,16 @@ def test_library_exports_every_declared_symbol():
     assert lib.rgbd_abi_version() == _lib.ABI_VERSION
     assert not [n for n in names if "debug" in n], "test hooks belong in csrc/rgbd_debug.h, not in the public header"
     hooks = declared_symbols(os.path.join("rgbd_gan_amd", "csrc", "rgbd_debug.h"))
-    assert sorted(_lib.DEBUG_PROTOTYPES) == hooks
-    for n in hooks:
+    assert sorted(list(_lib.DEBUG_PROTOTYPES) + list(_lib.DEBUG_ONLY_PROTOTYPES)) == hooks
+    for n in _lib.DEBUG_PROTOTYPES:
         assert hasattr(lib, n), n
+    # the process-wide planner switches -- and the reference kernels behind them -- are NOT in the shipped library ...
+    for n in _lib.DEBUG_ONLY_PROTOTYPES:
+        assert not hasattr(lib, n), f"{n} is exported by the product library"
+    # ... only in the debug build, which exports everything the product does
+    dlib = _lib.load_debug()
+    for n in names + hooks:
+        assert hasattr(dlib, n), n
 
 
 def test_integration_document_names_only_real_entry_points():

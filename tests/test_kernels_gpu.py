@@ -498,12 +498,9 @@ def test_patch_kernel_agrees_with_gather_kernel(B, H, Cin, Cout, ups):
     bias = torch.randn(Cout, generator=g).to(dev())
     wf, _ = kernels.pack_weights(w, float(np.sqrt(2.0 / (Cin * 9))), True, False)
     y_patch = kernels.conv2d_fprop(x, wf, 3, 3, 1, bias=bias, upsample=ups, lrelu_channels=Cout)
-    lib = _lib.load()
-    lib.rgbd_debug_force_gather_kernel(1)
-    try:
+    with _lib.debug_library() as lib:                  # the planner switch lives in the debug library only
+        lib.rgbd_debug_force_gather_kernel(1)
         y_gather = kernels.conv2d_fprop(x, wf, 3, 3, 1, bias=bias, upsample=ups, lrelu_channels=Cout)
-    finally:
-        lib.rgbd_debug_force_gather_kernel(0)
     # same bf16 inputs, fp32 accumulation in a different order, one bf16 rounding at the end
     torch.testing.assert_close(y_patch.float(), y_gather.float(), atol=2e-2, rtol=8e-3)
 
@@ -527,12 +524,10 @@ def test_small_image_kernel_matches_gather_kernel_and_fp32_conv(B, H, Cin, Cout,
     assert lib.rgbd_last_conv_kernel().decode() == f"conv3x3_small_kernel<{H}>"
     for _ in range(5):
         assert torch.equal(kernels.conv2d_fprop(x, wf, 3, 3, 1, bias=bias, residual=r, lrelu_channels=Cout), y)
-    lib.rgbd_debug_force_gather_kernel(1)
-    try:
+    with _lib.debug_library() as dlib:
+        dlib.rgbd_debug_force_gather_kernel(1)
         y_gather = kernels.conv2d_fprop(x, wf, 3, 3, 1, bias=bias, residual=r, lrelu_channels=Cout)
-        assert lib.rgbd_last_conv_kernel().decode().startswith("conv_fprop_kernel")
-    finally:
-        lib.rgbd_debug_force_gather_kernel(0)
+        assert dlib.rgbd_last_conv_kernel().decode().startswith("conv_fprop_kernel")
     torch.testing.assert_close(y.float(), y_gather.float(), atol=2e-2, rtol=8e-3)
     wb = (w * scale).to(torch.bfloat16).float()
     ref = F.conv2d(x.float().permute(0, 3, 1, 2), wb, bias, padding=1)
@@ -692,12 +687,10 @@ def test_pipelined_conv_matches_register_staged_kernel_bit_for_bit(B, H, Cin, Co
         out = kernels.conv2d_fprop(x, wf, 3, 3, 1, bias=bias, residual=r, upsample=ups, lrelu_channels=Cout, avg_pool2=pool)
         return out if pool else (out,)
     lib = _lib.load()
-    lib.rgbd_debug_conv_variant(1)
-    try:
+    with _lib.debug_library() as dlib:                 # round 1's register-staged kernel: debug library only
+        dlib.rgbd_debug_conv_variant(1)
         ref = run()
-        assert lib.rgbd_last_conv_kernel().decode().startswith("conv3x3_patch_kernel")
-    finally:
-        lib.rgbd_debug_conv_variant(0)
+        assert dlib.rgbd_last_conv_kernel().decode().startswith("conv3x3_patch_kernel")
     for rep in range(12):
         got = run()
         assert lib.rgbd_last_conv_kernel().decode().startswith("conv3x3_sp_kernel")
@@ -715,12 +708,9 @@ def test_wgrad_bodies_agree_and_repeat(B, H, Cin, Cout, ups):
     Hx = H // 2 if ups else H
     x = torch.randn(B, Hx, Hx, Cin, generator=g).to(dev()).to(torch.bfloat16)
     dy = torch.randn(B, H, H, Cout, generator=g).to(dev()).to(torch.bfloat16)
-    lib = _lib.load()
-    lib.rgbd_debug_conv_variant(3)
-    try:
+    with _lib.debug_library() as dlib:
+        dlib.rgbd_debug_conv_variant(3)
         ref = kernels.conv2d_wgrad(x, dy, 3, 1.0, upsample=ups)
-    finally:
-        lib.rgbd_debug_conv_variant(0)
     first = kernels.conv2d_wgrad(x, dy, 3, 1.0, upsample=ups)
     torch.testing.assert_close(first, ref, rtol=2e-5, atol=2e-5 * float(ref.abs().max()))
     for rep in range(8):
