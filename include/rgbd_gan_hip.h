@@ -77,14 +77,17 @@ int rgbd_warp_loss_bwd(const float* img, const float* img_rot, const float* coef
 /* The same loss for ANY channel count C >= 2 (the last channel is the depth) and either criterion: norm_l2 == 0
  * F.mean_absolute_error, != 0 F.mean_squared_error (loss_functions.py:137-145; `LossFuncRotate(norm="l2")` on the
  * 257-channel feature maps of updater.py:345-354).  img, img_rot, grad_*: (b,C,S,S) fp32; partials as above; no depth hinge,
- * no debug outputs.  The backward scatters with fp32 atomics (not bit-reproducible); accumulate as above. */
+ * no debug outputs.  The backward's scatter is order-independent too: per tap it accumulates sign(diff) * w (L1) or
+ * diff * w (L2) as 64-bit integers in units of 2^-40 / 2^-32 in `workspace` (rgbd_warp_loss_nc_bwd_workspace(b, C, S)
+ * bytes, 8-byte aligned, no initialisation needed) and multiplies by the channel's constant once; accumulate as above. */
 int rgbd_warp_loss_nc_fwd(const float* img, const float* img_rot, const float* coef, int b, int C, int S, int flags,
                           int norm_l2, float lambda_geometric, float max_depth, float min_depth,
                           float* partials, float* loss, void* stream);
 int rgbd_warp_loss_nc_bwd(const float* img, const float* img_rot, const float* coef, int b, int C, int S, int flags,
                           int norm_l2, float lambda_geometric, float max_depth, float min_depth,
                           const float* grad_loss, float grad_scale, float* grad_img, float* grad_img_rot, int accumulate,
-                          void* stream);
+                          void* workspace, void* stream);
+int64_t rgbd_warp_loss_nc_bwd_workspace(int b, int C, int S);
 
 /* ------------------------------------------------------------------ equalized-LR convolution engine
  * Replaces pggan.py:13-24 (EqualizedConv2d -> L.Convolution2D = cuDNN fprop/dgrad/wgrad) for the

@@ -25,7 +25,8 @@ PROTOTYPES = {
                             _P, c_int, _P, _P], c_int),
     "rgbd_warp_loss_nc_fwd": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, _P, _P, _P], c_int),
     "rgbd_warp_loss_nc_bwd": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, _P, c_float, _P, _P,
-                               c_int, _P], c_int),
+                               c_int, _P, _P], c_int),
+    "rgbd_warp_loss_nc_bwd_workspace": ([c_int, c_int, c_int], c_int64),
     "rgbd_pack_weights": ([_P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P], c_int),
     "rgbd_pack_weights_multi": ([_P, c_int, c_int, _P], c_int),
     "rgbd_conv2d_fprop_workspace": ([c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int], c_int64),

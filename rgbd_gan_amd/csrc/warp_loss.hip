@@ -291,9 +291,11 @@ __global__ __launch_bounds__(256) void warp_loss_bwd_finish_kernel(
 
 // ---- any number of channels (the last one is the depth), L1 or L2 criterion: loss_functions.py:137-145 with norm="l2" and
 //      the 257-channel feature maps of updater.py:345-354.  Same projection / taps / masks as above; a thread loops over the
-//      channels of its pixel.  The backward scatters with fp32 atomics (the L2 seed 2 (warped - target) k is not a constant
-//      per channel, so the fixed-point accumulation of the RGB-D kernels does not apply): not bit-reproducible, and off the
-//      training step of every shipped config.
+//      channels of its pixel.  The backward's scatter is ORDER-INDEPENDENT like the RGB-D kernels': what is accumulated per
+//      tap is q * w with q = sign(warped - target) (L1) or warped - target itself (L2: the seed 2 k (warped - target) is
+//      not a per-channel constant, but k is), as a 64-bit integer in units of 2^-40 (L1) / 2^-32 (L2: differences up to 2^31,
+//      resolution 2.3e-10) by integer atomics into a workspace, and multiplied by the channel's constant once, in the finish
+//      kernel.  Off the training step of every shipped config (`rotate_feature`).
 __global__ __launch_bounds__(256) void warp_loss_nc_fwd_kernel(
     const float* __restrict__ img, const float* __restrict__ img_rot, const float* __restrict__ coef,
     int b, int C, int S, int flags, int l2, float max_depth, float min_depth, float* __restrict__ partials) {
@@ -349,7 +351,8 @@ __global__ __launch_bounds__(256) void warp_loss_nc_fwd_kernel(
 __global__ __launch_bounds__(256) void warp_loss_nc_bwd_kernel(
     const float* __restrict__ img, const float* __restrict__ img_rot, const float* __restrict__ coef,
     int b, int C, int S, int flags, int l2, float lambda_geo, float max_depth, float min_depth,
-    const float* __restrict__ grad_loss, float grad_scale, float* __restrict__ gimg, float* __restrict__ gimg_rot) {
+    const float* __restrict__ grad_loss, float grad_scale, float* __restrict__ gimg, float* __restrict__ gimg_rot,
+    long long* __restrict__ acc) {
     const int dir = blockIdx.y;
     const int hw = S * S;
     const long n = (long)blockIdx.x * 256 + threadIdx.x;
@@ -358,7 +361,6 @@ __global__ __launch_bounds__(256) void warp_loss_nc_bwd_kernel(
     const float* own = dir == 0 ? img : img_rot;
     const float* src = dir == 0 ? img_rot : img;
     float* gown = dir == 0 ? gimg : gimg_rot;
-    float* gsrc = dir == 0 ? gimg_rot : gimg;
     const int bi = (int)(n / hw);
     const int pix = (int)(n - (long)bi * hw);
     const int i = pix / S, j = pix - i * S;
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(256) void warp_loss_nc_bwd_kernel(
     const float* ob = own + (long)bi * C * hw;
     const float* sb = src + (long)bi * C * hw;
     float* gob = gown + (long)bi * C * hw;
-    float* gsb = gsrc + (long)bi * C * hw;
+    long long* asb = acc + ((long)(dir == 0 ? b : 0) + bi) * C * hw;      // acc: (2b,C,hw), images first, then rotated images
     const float z = ob[(long)(C - 1) * hw + pix];
     const PixelWarp w = project_pixel(cf, dir == 0 ? -1.f : 1.f, z, i, j, S);
     if (!w.mask) return;
@@ -382,23 +384,32 @@ __global__ __launch_bounds__(256) void warp_loss_nc_bwd_kernel(
     const float go = (grad_loss ? grad_loss[0] : 1.f) * grad_scale;
     const float k_rgb = go / ((float)N * (float)(C - 1));
     const float k_d = go * lambda_geo / (float)N;
-    auto seed = [&](float diff, float k) { return l2 ? 2.f * diff * k : (diff > 0.f ? k : (diff < 0.f ? -k : 0.f)); };
+    // q: the per-pixel factor of the seed (sign or difference); seed = (l2 ? 2 : 1) * k * q
+    auto factor = [&](float diff) { return l2 ? diff : (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)); };
+    const double unit = l2 ? 4294967296.0 : 1099511627776.0;            // 2^32 / 2^40
+    const float kk = l2 ? 2.f : 1.f;
+    auto scatter = [&](long long* p, float v) {
+        const long long q = __double2ll_rn((double)v * unit);
+        if (q != 0) atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)q);
+    };
     float gw_a = 0.f, gw_d = 0.f;
     for (int c = 0; c < C - 1; ++c) {
         const float a = sb[(long)c * hw + o00], d = sb[(long)c * hw + o01];
         const float wv = ((w.w1 * a + w.w2 * a) + w.w3 * d) + w.w4 * d;
-        const float g = seed(wv - ob[(long)c * hw + pix], k_rgb);
-        if (g != 0.f) {
-            atomicAdd(gsb + (long)c * hw + o00, g * wl);
-            atomicAdd(gsb + (long)c * hw + o01, g * wr);
-            atomicAdd(gob + (long)c * hw + pix, -g);
+        const float q = factor(wv - ob[(long)c * hw + pix]);
+        const float g = kk * k_rgb * q;
+        if (q != 0.f) {
+            scatter(asb + (long)c * hw + o00, q * wl);
+            scatter(asb + (long)c * hw + o01, q * wr);
+            gob[(long)c * hw + pix] -= g;                                // own pixel: this thread alone
         }
         gw_a += g * a;
         gw_d += g * d;
     }
-    const float g3 = seed(wd - w.zp2, k_d);
-    atomicAdd(gsb + (long)(C - 1) * hw + o00, g3 * wl);
-    atomicAdd(gsb + (long)(C - 1) * hw + o01, g3 * wr);
+    const float q3 = factor(wd - w.zp2);
+    const float g3 = kk * k_d * q3;
+    scatter(asb + (long)(C - 1) * hw + o00, q3 * wl);
+    scatter(asb + (long)(C - 1) * hw + o01, q3 * wr);
     gw_a += g3 * a3;
     gw_d += g3 * d3;
     float gzp2 = -g3;
@@ -411,7 +422,26 @@ __global__ __launch_bounds__(256) void warp_loss_nc_bwd_kernel(
     const float p0 = (float)j, p1 = (float)i;
     const float gz = gzp0 * (cf[0] * p0 + cf[1] * p1 + cf[2]) + gzp1 * (cf[3] * p0 + cf[4] * p1 + cf[5]) +
                      gzp2 * (cf[6] * p0 + cf[7] * p1 + cf[8]);
-    atomicAdd(gob + (long)(C - 1) * hw + pix, gz);
+    gob[(long)(C - 1) * hw + pix] += gz;
+}
+
+// grad[(image, c, pixel)] += (l2 ? 2 : 1) * k_c * acc * unit: the scattered sums, converted once
+__global__ __launch_bounds__(256) void warp_loss_nc_bwd_finish_kernel(
+    const long long* __restrict__ acc, int b, int C, int hw, int l2, float lambda_geo, const float* __restrict__ grad_loss,
+    float grad_scale, float* __restrict__ gimg, float* __restrict__ gimg_rot) {
+    const long N = (long)b * hw;
+    const long total = 2 * N * C;
+    const float go = (grad_loss ? grad_loss[0] : 1.f) * grad_scale;
+    const float kk = l2 ? 2.f : 1.f;
+    const double unit = l2 ? 2.3283064365386963e-10 : 9.094947017729282e-13;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const long long q = acc[e];
+        if (q == 0) continue;
+        const int c = (int)((e / hw) % C);
+        const float k = c < C - 1 ? go / ((float)N * (float)(C - 1)) : go * lambda_geo / (float)N;
+        float* g = e < N * C ? gimg + e : gimg_rot + (e - N * C);
+        *g += kk * k * (float)((double)q * unit);
+    }
 }
 
 }  // namespace
@@ -486,22 +516,35 @@ extern "C" int rgbd_warp_loss_nc_fwd(const float* img, const float* img_rot, con
     return 0;
 }
 
+extern "C" int64_t rgbd_warp_loss_nc_bwd_workspace(int b, int C, int S) {
+    return b > 0 && C > 0 && S > 0 ? (int64_t)2 * b * C * S * S * (int64_t)sizeof(long long) : 0;
+}
+
 extern "C" int rgbd_warp_loss_nc_bwd(const float* img, const float* img_rot, const float* coef, int b, int C, int S, int flags,
                                      int norm_l2, float lambda_geometric, float max_depth, float min_depth,
                                      const float* grad_loss, float grad_scale, float* grad_img, float* grad_img_rot,
-                                     int accumulate, void* stream) {
-    RGBD_REQUIRE(img && img_rot && coef && grad_img && grad_img_rot, "rgbd_warp_loss_nc_bwd: null pointer");
+                                     int accumulate, void* workspace, void* stream) {
+    RGBD_REQUIRE(img && img_rot && coef && grad_img && grad_img_rot && workspace, "rgbd_warp_loss_nc_bwd: null pointer");
     RGBD_REQUIRE(b > 0 && S >= 2 && C >= 2, "rgbd_warp_loss_nc_bwd: bad shape b=%d C=%d S=%d", b, C, S);
+    RGBD_REQUIRE(((uintptr_t)workspace & 7) == 0, "rgbd_warp_loss_nc_bwd: the workspace must be 8-byte aligned");
     const long N = (long)b * S * S;
     hipStream_t st = (hipStream_t)stream;
-    if (!accumulate && (rgbd_zero_async(grad_img, (size_t)N * C * sizeof(float), st) != hipSuccess ||
-                        rgbd_zero_async(grad_img_rot, (size_t)N * C * sizeof(float), st) != hipSuccess)) {
-        rgbd_set_error("rgbd_warp_loss_nc_bwd: clearing the gradients failed");
+    long long* acc = static_cast<long long*>(workspace);
+    bool ok = rgbd_zero_async(acc, (size_t)rgbd_warp_loss_nc_bwd_workspace(b, C, S), st) == hipSuccess;
+    if (!accumulate)
+        ok = ok && rgbd_zero_async(grad_img, (size_t)N * C * sizeof(float), st) == hipSuccess &&
+             rgbd_zero_async(grad_img_rot, (size_t)N * C * sizeof(float), st) == hipSuccess;
+    if (!ok) {
+        rgbd_set_error("rgbd_warp_loss_nc_bwd: clearing the accumulators failed");
         return -2;
     }
     warp_loss_nc_bwd_kernel<<<dim3(ceil_div(N, 256), 2), 256, 0, st>>>(img, img_rot, coef, b, C, S, flags, norm_l2 ? 1 : 0,
                                                                        lambda_geometric, max_depth, min_depth, grad_loss,
-                                                                       grad_scale, grad_img, grad_img_rot);
+                                                                       grad_scale, grad_img, grad_img_rot, acc);
     RGBD_CHECK_LAUNCH("warp_loss_nc_bwd_kernel");
+    const long total = 2 * N * C;
+    warp_loss_nc_bwd_finish_kernel<<<(unsigned)(ceil_div(total, 256) < 4096 ? ceil_div(total, 256) : 4096), 256, 0, st>>>(
+        acc, b, C, S * S, norm_l2 ? 1 : 0, lambda_geometric, grad_loss, grad_scale, grad_img, grad_img_rot);
+    RGBD_CHECK_LAUNCH("warp_loss_nc_bwd_finish_kernel");
     return 0;
 }

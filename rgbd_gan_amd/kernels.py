@@ -159,9 +159,11 @@ def warp_loss_nc_bwd(img, img_rot, coef, flags, norm_l2, lambda_geometric, max_d
     _chk(grad_loss, F32, "grad_loss")
     b, C, S, _ = img.shape
     gimg, gimg_rot = torch.empty_like(img), torch.empty_like(img_rot)
-    rc = _lib.load().rgbd_warp_loss_nc_bwd(_ptr(img), _ptr(img_rot), _ptr(coef), b, C, S, int(flags), int(bool(norm_l2)),
-                                           float(lambda_geometric), float(max_depth), float(min_depth), _ptr(grad_loss),
-                                           float(grad_scale), _ptr(gimg), _ptr(gimg_rot), 0, _stream())
+    lib = _lib.load()
+    ws = torch.empty(lib.rgbd_warp_loss_nc_bwd_workspace(b, C, S) // 8, dtype=torch.int64, device=img.device)
+    rc = lib.rgbd_warp_loss_nc_bwd(_ptr(img), _ptr(img_rot), _ptr(coef), b, C, S, int(flags), int(bool(norm_l2)),
+                                   float(lambda_geometric), float(max_depth), float(min_depth), _ptr(grad_loss),
+                                   float(grad_scale), _ptr(gimg), _ptr(gimg_rot), 0, _ptr(ws), _stream())
     _lib.check(rc, "rgbd_warp_loss_nc_bwd")
     return gimg, gimg_rot
 

@@ -975,6 +975,15 @@ def test_loss_func_rotate_any_channel_count_and_l2(C, norm, occ):
     torch.testing.assert_close(dr.grad.cpu(), tr.grad, atol=2e-5 * scale, rtol=1e-4)
     assert tuple(zp.shape) == (2 * b, S * S, 3)
     torch.testing.assert_close(zp.cpu(), zp_ref.detach(), atol=1e-4, rtol=1e-5)
+    # the scatter-add of the taps is accumulated as integers (round 4): launch after launch the same bits, for both criteria
+    from rgbd_gan_amd import kernels
+    coef = torch.from_numpy(_coef(cam, cam_rot, S)).to(dev())
+    go = torch.tensor([1.3], dtype=torch.float32, device=dev())
+    first = kernels.warp_loss_nc_bwd(di.detach(), dr.detach(), coef, 1 if occ else 0, norm == "l2", 3.0, 0.0, 0.0, go)
+    for _ in range(6):
+        again = kernels.warp_loss_nc_bwd(di.detach(), dr.detach(), coef, 1 if occ else 0, norm == "l2", 3.0, 0.0, 0.0, go)
+        assert torch.equal(again[0], first[0]) and torch.equal(again[1], first[1])
+    torch.testing.assert_close(first[0].cpu(), 1.3 * ti.grad, atol=3e-5 * scale, rtol=1e-4)
 
 
 def test_loss_func_rotate_debug_tuple():
