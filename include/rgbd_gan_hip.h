@@ -479,6 +479,9 @@ int rgbd_gan_logit_heads(const float* y, int n, float* losses, float* seed_neg, 
                          void* stream);
 /* Clear n floats with a kernel launch (a plain kernel node inside captured HIP graphs, unlike hipMemsetAsync). */
 int rgbd_zero_f32(float* p, int64_t n, void* stream);
+/* updater.py:336,360,439 (`assert not xp.isnan(loss.data)`) without a host synchronisation: scalars_host is a HOST array of n <= 8
+ * DEVICE pointers to fp32 scalars; bit i of *mask (device int32, OR-ed: sticky) is set when scalar i is NaN or +-Inf. */
+int rgbd_nonfinite_mask_f32(const float* const* scalars_host, int n, int32_t* mask, void* stream);
 
 /* ------------------------------------------------------------------ optimizer
  * Replaces chainer.optimizers.Adam + GradientClipping(5) (train_rgbd.py:151-161), one launch group per

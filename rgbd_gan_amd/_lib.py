@@ -107,6 +107,7 @@ PROTOTYPES = {
     "rgbd_gan_logit_heads": ([_P, c_int, _P, _P, _P, _P, _P], c_int),
     "rgbd_ema_update": ([_P, _P, c_int64, c_float, _P], c_int),
     "rgbd_zero_f32": ([_P, c_int64, _P], c_int),
+    "rgbd_nonfinite_mask_f32": ([POINTER(c_void_p), c_int, _P, _P], c_int),
     "rgbd_adam_clip_multi": ([_P, _P, _P, _P, c_int64, c_int, POINTER(c_int64), POINTER(c_float), c_float, c_float,
                               c_float, c_float, c_float, _P, _P, _P, _P], c_int),
 }

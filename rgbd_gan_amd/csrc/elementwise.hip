@@ -36,6 +36,30 @@ extern "C" int rgbd_zero_f32(float* p, int64_t n, void* stream) {
 }
 
 namespace {
+struct FinitePtrs { const float* p[8]; };
+// bit i of *mask is set when *p[i] is NaN or +-Inf (mask is OR-ed: sticky until the host clears it)
+__global__ void nonfinite_mask_kernel(FinitePtrs a, int n, int* __restrict__ mask) {
+    const int i = threadIdx.x;
+    if (i < n && a.p[i]) {
+        const unsigned bits = __float_as_uint(*a.p[i]);
+        if ((bits & 0x7f800000u) == 0x7f800000u) atomicOr(mask, 1 << i);
+    }
+}
+}  // namespace
+
+// The reference asserts `not xp.isnan(loss.data)` three times per step (updater.py:336,360,439), each a host synchronisation.
+// Here the losses stay on the device: this launch folds their finiteness into one sticky int32 that the host reads a step
+// later through a pinned copy (RGBDUpdater._nan_watch), so a diverging run stops within two steps and no step waits.
+extern "C" int rgbd_nonfinite_mask_f32(const float* const* scalars_host, int n, int32_t* mask, void* stream) {
+    RGBD_REQUIRE(scalars_host && mask && n > 0 && n <= 8, "rgbd_nonfinite_mask_f32: up to 8 device scalars");
+    FinitePtrs a;
+    for (int i = 0; i < 8; ++i) a.p[i] = i < n ? scalars_host[i] : nullptr;
+    nonfinite_mask_kernel<<<1, 64, 0, (hipStream_t)stream>>>(a, n, mask);
+    RGBD_CHECK_LAUNCH("nonfinite_mask_kernel");
+    return 0;
+}
+
+namespace {
 
 // ------------------------------------------------------------------------------------------------ weights
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, int cout, int cin, int kh,

@@ -168,6 +168,17 @@ def warp_loss_nc_bwd(img, img_rot, coef, flags, norm_l2, lambda_geometric, max_d
     return gimg, gimg_rot
 
 
+def nonfinite_mask(scalars, mask):
+    """scalars: up to 8 device fp32 scalars (0-dim or 1-element tensors); mask: (1,) int32 device, bit i OR-ed in when scalar i
+    is NaN / Inf."""
+    for t in scalars:
+        _chk(t, F32, "scalar")
+    if mask.dtype != torch.int32 or not mask.is_cuda:
+        raise RuntimeError("nonfinite_mask: the mask must be an int32 GPU tensor")
+    arr = (ctypes.c_void_p * len(scalars))(*[t.data_ptr() for t in scalars])
+    _lib.check(_lib.load().rgbd_nonfinite_mask_f32(arr, len(scalars), _ptr(mask), _stream()), "rgbd_nonfinite_mask_f32")
+
+
 # ------------------------------------------------------------------ conv engine
 def pack_weights(w, scale, want_fprop=True, want_dgrad=True):
     """w (Cout,Cin,KH,KW) fp32 -> (w_fprop [T][Cout][Cin], w_dgrad [T][Cin][Cout]) bf16 with `scale` folded in."""

@@ -136,8 +136,9 @@ class DeviceImageIterator:
                              f"{self.data.shape[0]}")
         self._pos, self.epoch = int(sd["pos"]), int(sd["epoch"])
         self._order = order.to(self.data.device)
-        self.gen.set_state(torch.as_tensor(np.asarray(sd["rng_state"]), dtype=torch.uint8))
-        self.seed = int(sd["seed"])
+        if sd.get("rng_state") is not None:        # (a trainer snapshot written by the reference has no generator state: the
+            self.gen.set_state(torch.as_tensor(np.asarray(sd["rng_state"]), dtype=torch.uint8))   # next epochs' permutations
+            self.seed = int(sd["seed"])                                                            # come from this run's seed)
 
 
 def iterator_state_path(directory, iteration, rank):

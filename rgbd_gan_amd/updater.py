@@ -177,6 +177,10 @@ class RGBDUpdater:
         # the reference asserts not-NaN (a host sync) three times per step (updater.py:336,360,439); here the losses
         # stay on the device and are checked every `nan_check_interval` iterations (1 = the reference's behaviour)
         self.nan_check_interval = int(kwargs.pop("nan_check_interval", 100))
+        # ... and EVERY step their finiteness is folded into a sticky device flag that the host reads one step later through a
+        # pinned copy (no synchronisation): a diverging run stops within two steps, not within nan_check_interval
+        self.nan_watch = bool(kwargs.pop("nan_watch", self.nan_check_interval > 0))
+        self._nan_state = None
         self.fixed_stage = kwargs.pop("fixed_stage", None)   # bench / tests: pin the stage
         # HIP graphs: the step body and the optimizer phase are captured once per (batch, stage, loss flags) and
         # replayed; collectives stay outside the graphs.  A refused capture is an error unless graph_fallback is set.
@@ -240,6 +244,33 @@ class RGBDUpdater:
     def update(self):
         self.update_core()
         self.iteration += 1
+
+    NAN_KEYS = ("gen/loss_adv", "gen/loss_rotate", "dis/loss_adv")       # updater.py:336,360,439
+
+    def _nan_watch_poll(self, block=False):
+        """Raise if a step whose flag has reached the host reported a non-finite loss (block=True: wait for the newest)."""
+        w = self._nan_state
+        if w is None:
+            return
+        if block:
+            w["event"].synchronize()
+        if w["event"].query() and int(w["host"][0]) != 0:
+            bad = [k for i, k in enumerate(w["keys"]) if int(w["host"][0]) >> i & 1]
+            raise AssertionError(f"{', '.join(bad)} not finite at or before iteration {w['iteration']}")
+
+    def _nan_watch_push(self):
+        keys = [k for k in self.NAN_KEYS if torch.is_tensor(self.observation.get(k)) and self.observation[k].is_cuda
+                and self.observation[k].dtype == torch.float32]
+        if not keys:
+            return
+        if self._nan_state is None:
+            self._nan_state = {"mask": torch.zeros(1, dtype=torch.int32, device=self.device),
+                               "host": torch.zeros(1, dtype=torch.int32).pin_memory(), "event": torch.cuda.Event()}
+        w = self._nan_state
+        kernels.nonfinite_mask([self.observation[k].detach().reshape(1) for k in keys], w["mask"])
+        w["host"].copy_(w["mask"], non_blocking=True)
+        w["event"].record()
+        w["keys"], w["iteration"] = keys, self.iteration
 
     def _check_finite(self):
         for key in ("gen/loss_adv", "gen/loss_rotate", "dis/loss_adv"):
@@ -787,6 +818,9 @@ class RGBDUpdater:
 
         obs = self.observation
         obs["stage"], obs["batch_size"], obs["image_size"] = stage, batch_size, int(st["x_real"].shape[2])
+        if self.nan_watch:
+            self._nan_watch_poll()          # what the previous steps reported, if it has arrived (never waits)
+            self._nan_watch_push()
         if self.nan_check_interval > 0 and (self.iteration + 1) % self.nan_check_interval == 0:
             self._check_finite()
 

@@ -130,6 +130,34 @@ def test_dcgan_config_training_steps_run():
     assert int(opt["gen"].t) == 4 and int(opt["dis"].t) == 4
 
 
+def test_a_diverging_run_stops_within_two_steps_without_a_per_step_sync():
+    """updater.py:336,360,439 of the reference assert not-NaN on the host three times per step.  Here the losses' finiteness is
+    folded into a sticky device flag every step (rgbd_nonfinite_mask_f32) and read a step later through a pinned copy: with
+    the synchronous check pushed out to every 1000th iteration, a NaN in the discriminator still stops the run by the second
+    update behind it, graphs replaying."""
+    from rgbd_gan_amd import functional as Fn
+    from rgbd_gan_amd.training import DeviceImageIterator, build_training
+    from rgbd_gan_amd.utils import yaml_utils
+    cfg = yaml_utils.load(os.path.join(ROOT, "configs", "stylegan_shapenet_car.yml"))
+    images = np.random.RandomState(0).randint(0, 256, (16, 3, 128, 128)).astype("uint8")
+    it = DeviceImageIterator(images, 4, "cuda:0", seed=0)
+    gen, dis, opt, upd = build_training(cfg, "cuda:0", iterator=it, fixed_stage=6.0, nan_check_interval=1000)
+    assert upd.nan_watch
+    upd.iteration = 3000
+    for _ in range(5):
+        upd.update()
+    torch.cuda.synchronize()
+    assert upd.graphs_in_use and int(upd._nan_state["host"][0]) == 0
+    with torch.no_grad():
+        dis.store.flat[dis.store.offsets["blocks/1/c0/c/W"]] = float("nan")
+    Fn.bump_weight_epoch()
+    with pytest.raises(AssertionError, match="not finite"):
+        for _ in range(3):
+            upd.update()
+            torch.cuda.synchronize()           # (only so that "within two steps" is deterministic in this test)
+    upd._nan_state = None
+
+
 def test_train_rgbd_cli_end_to_end(tmp_path):
     """python train_rgbd.py --config_path <ffhq config with paths / iteration count patched> on a synthetic images.npy:
     progressive stage 6 (32x32) from iteration 0, snapshots + log written, then resume."""

@@ -200,3 +200,69 @@ def test_residual_tie_hand_overs_work_in_either_order():
     # the two junctions are independent
     assert tie.give("g_sc", "main_seen", term) is True and tie.dx_sc is None
     assert tie.take("g_sc", "main_seen") is term
+
+
+def test_trainer_snapshot_uses_the_reference_key_layout_and_round_trips():
+    """snapshot_iter_*.npz (train_rgbd.py:378-381 of the reference: chainer's trainer snapshot): the keys a Chainer trainer
+    would write and read -- updater/iteration, updater/optimizer:<name>/<param>/{t,m,v}, updater/model:<name>/<param>,
+    updater/iterator:main/..., extensions/LogReport/_log -- and a round trip through fresh optimizers; the flat layout this
+    engine wrote in rounds 1-3 still loads; absent keys are skipped like load_npz(strict=False)."""
+    from rgbd_gan_amd.common.utils import trainer_snapshot as ts
+    from rgbd_gan_amd.optimizer import FlatAdam
+    from rgbd_gan_amd.params import ParamStore
+    from rgbd_gan_amd.training import DeviceImageIterator
+
+    def make():
+        stores = {"map": ParamStore([("l/0/c/W", (8, 8), "normal"), ("l/0/c/b", (8,), "zeros")], "cpu", seed=1),
+                  "dis": ParamStore([("blocks/0/c0/c/W", (4, 3, 3, 3), "normal"), ("ins/5/b", (5,), "ones")], "cpu", seed=2)}
+        return {k: FlatAdam(v, 1e-3) for k, v in stores.items()}
+    opts = make()
+    g = torch.Generator().manual_seed(0)
+    for o in opts.values():
+        o.m.copy_(torch.randn(o.m.shape, generator=g))
+        o.v.copy_(torch.rand(o.v.shape, generator=g))
+        o.step.fill_(7)
+    images = np.zeros((20, 3, 4, 4), "uint8")
+    it = DeviceImageIterator(images, 8, "cpu", seed=3)
+    for _ in range(4):
+        it.next_indices()
+    log = [{"iteration": 100, "gen/loss_adv": 0.5}]
+    snap = ts.pack(1200, opts, it.state_dict(), log, 12.5, 100)
+    for k in ("updater/iteration", "updater/optimizer:map/t", "updater/optimizer:map/l/0/c/W/m", "updater/optimizer:dis/ins/5/b/v",
+              "updater/model:dis/blocks/0/c0/c/W", "updater/iterator:main/current_position", "updater/iterator:main/order",
+              "extensions/LogReport/_log", "_snapshot_elapsed_time"):
+        assert k in snap, k
+    assert snap["updater/optimizer:map/l/0/c/W/m"].shape == (8, 8) and int(snap["updater/optimizer:dis/ins/5/b/t"]) == 7
+    np.testing.assert_array_equal(snap["updater/model:map/l/0/c/W"], opts["map"].store["l/0/c/W"].detach().numpy())
+    fresh = make()
+    got = ts.unpack(snap, fresh)
+    assert got["iteration"] == 1200 and got["log"] == log and got["elapsed_time"] == 12.5
+    def same_moments(a, b):           # per parameter: the flat buffers also hold alignment padding, which no file carries
+        for n in a.store.names:
+            sl = slice(a.store.offsets[n], a.store.offsets[n] + int(np.prod(a.store.shapes[n])))
+            if not (torch.equal(a.m[sl], b.m[sl]) and torch.equal(a.v[sl], b.v[sl])):
+                return False
+        return True
+    for k in opts:
+        assert same_moments(fresh[k], opts[k]) and fresh[k].t == 7
+    it2 = DeviceImageIterator(images, 8, "cpu", seed=99)
+    it2.load_state_dict(got["iterator"])
+    assert [it2.next_indices().tolist() for _ in range(5)] == [it.next_indices().tolist() for _ in range(5)]
+    # a file as the REFERENCE's trainer writes it: no generator state, '//'-joined parameter paths, only some keys
+    chainer_like = {"updater/iteration": np.int64(500), "updater/optimizer:map/t": np.int64(3),
+                    "updater/optimizer:map//l/0/c/W/m": np.full((8, 8), 2.0, "float32"),
+                    "updater/iterator:main/current_position": np.int64(8), "updater/iterator:main/epoch": np.int64(1),
+                    "updater/iterator:main/order": np.arange(20)[::-1].copy()}
+    fresh = make()
+    got = ts.unpack(chainer_like, fresh)
+    assert got["iteration"] == 500 and got["log"] is None and fresh["map"].t == 3 and fresh["dis"].t == 0
+    assert float(fresh["map"].m[:64].min()) == 2.0 and float(fresh["map"].v.abs().max()) == 0.0
+    it3 = DeviceImageIterator(images, 8, "cpu", seed=5)
+    it3.load_state_dict(got["iterator"])
+    assert it3.next_indices().tolist() == [11, 10, 9, 8, 7, 6, 5, 4]
+    # the flat layout of rounds 1-3
+    old = {"iteration": np.int64(40), "map/t": 2, "map/m": opts["map"].m.numpy(), "map/v": opts["map"].v.numpy(),
+           "log": np.asarray('[{"iteration": 40}]'), "elapsed_time": np.float64(1.0)}
+    fresh = make()
+    got = ts.unpack(old, fresh)
+    assert got["iteration"] == 40 and got["log"] == [{"iteration": 40}] and same_moments(fresh["map"], opts["map"])

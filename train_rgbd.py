@@ -24,6 +24,7 @@ if ROOT not in sys.path:
 from rgbd_gan_amd.dist import Communicator
 from rgbd_gan_amd.training import (DeviceImageIterator, build_training, load_iterator_state, make_dataset,
                                    save_iterator_state)
+from rgbd_gan_amd.common.utils import trainer_snapshot
 from rgbd_gan_amd.utils import yaml_utils
 
 
@@ -87,20 +88,19 @@ def main():
         print(f"Resume from {resume}")
         for name, m in models:
             m.load_state_dict(dict(np.load(f"{d}/{name}_{resume}.npz")), strict=False)
-        snap = np.load(f"{d}/snapshot_iter_{resume}.npz", allow_pickle=True)
-        updater.iteration = int(snap["iteration"])
-        for k, o in optimizer.items():
-            o.load_state_dict({"t": snap[f"{k}/t"], "m": snap[f"{k}/m"], "v": snap[f"{k}/v"]})
-        # the trainer snapshot of the reference also carries the iterator (position, epoch, order) and LogReport's entries
-        # (chainer serializes trainer -> updater -> iterators, extensions); older snapshots of this engine lack them
+        # the trainer snapshot, in the reference's key layout (rgbd_gan_amd/common/utils/trainer_snapshot.py): iteration,
+        # per-parameter Adam moments, the iterator (position, epoch, order) and LogReport's entries; also reads the flat
+        # layout this engine wrote before round 4.  Missing keys are skipped (the reference loads with strict=False)
+        with np.load(f"{d}/snapshot_iter_{resume}.npz", allow_pickle=True) as snap_file:
+            snap = trainer_snapshot.unpack(snap_file, optimizer)
+        updater.iteration = snap["iteration"]
+        if snap["log"] is not None:
+            log_resumed, elapsed_resumed = snap["log"], snap["elapsed_time"]
         # -- per rank: every rank shuffles with its own seed, so each resumes ITS position / order / generator state
         how = load_iterator_state(d, resume, comm.rank if comm is not None else 0, iterator,
-                                  {k: snap[k] for k in snap.files if k.startswith("iterator/")})
+                                  {f"iterator/{k}": v for k, v in (snap["iterator"] or {}).items()})
         if how == "fresh" and comm is not None and comm.rank > 0:
             print(f"rank {comm.rank}: no iterator state of its own in {d}; continuing with a fresh rank-seeded shuffle")
-        if "log" in snap.files:
-            log_resumed = json.loads(str(snap["log"]))
-            elapsed_resumed = float(snap["elapsed_time"])
 
     previews = []
     if is_master and config.evaluation_sample_interval:                # train_rgbd.py:386-396
@@ -128,11 +128,8 @@ def main():
         if is_master and it % (config.snapshot_interval or 10000) == 0:
             for name, m in models:
                 save_npz(f"{out}/{name}_{it}.npz", m)
-            snap = {"iteration": it, "log": json.dumps(log), "elapsed_time": time.time() - t0}
-            snap.update({f"iterator/{k}": v for k, v in iterator.state_dict().items()})
-            for k, o in optimizer.items():
-                sd = o.state_dict()
-                snap.update({f"{k}/t": sd["t"], f"{k}/m": sd["m"], f"{k}/v": sd["v"]})
+            snap = trainer_snapshot.pack(it, optimizer, iterator.state_dict(), log, time.time() - t0,
+                                         config.display_interval or 100)
             np.savez(f"{out}/snapshot_iter_{it}.npz", **snap)
     if is_master:
         for name, m in models:
