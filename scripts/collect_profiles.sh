@@ -4,7 +4,7 @@
 # conv kernels on the step's layer shapes; summaries into profiles/$1 (stamped with the kernel sources' hash).
 #   scripts/collect_profiles.sh r02 [commit]
 set -u
-R=${1:-r03}
+R=${1:-r04}
 export RGBD_COMMIT=${2:-unknown}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/$R profiles/$R
@@ -28,5 +28,24 @@ for CS in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_WAIT_ANY 
 done
 python3 scripts/pmc_kernels.py profiles/$R gpurun_out/$R/kpmc_*
 rm -rf gpurun_out/$R/kpmc_*/
+# ---- BASELINE configuration 5 (256x256, ch = 512, per-GPU batch 16): the MXFP8 line and its bf16 twin on the same box, the
+#      per-kernel time of the fp8 command, and the counters of the MXFP8 kernel beside its bf16 twin (scripts/prof_conv_mx8.py)
+python3 bench.py --res256 --fp8 --no-cpu-baseline > profiles/$R/bench_res256_fp8.json 2> gpurun_out/$R/res256_fp8.err
+python3 bench.py --res256 --no-cpu-baseline > profiles/$R/bench_res256_bf16.json 2> gpurun_out/$R/res256_bf16.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/stats256 -o b -- python3 bench.py --res256 --fp8 --steps 40 --no-cpu-baseline --no-roofline > gpurun_out/$R/stats256.log 2>&1
+cp gpurun_out/$R/stats256/b_kernel_stats.csv profiles/$R/bench_res256_fp8_kernel_stats.csv
+rm -f gpurun_out/$R/stats256/b_kernel_trace.csv
+P=0
+for CS in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" \
+          "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_MFMA" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
+  P=$((P+1))
+  REPS=3 rocprofv3 --kernel-trace --pmc $CS --output-format csv -d gpurun_out/$R/mpmc_$P -o k -- python3 scripts/prof_conv_mx8.py > gpurun_out/$R/mpmc_$P.log 2>&1
+done
+python3 scripts/pmc_kernels.py profiles/$R/mx8 gpurun_out/$R/mpmc_*
+rm -rf gpurun_out/$R/mpmc_*/
+# ---- the other configurations' lines: configuration 3's per-GPU shape (batch 64 over 8 GPUs) and configuration 4
+python3 bench.py --config configs/ffhq_stylegan_occlusion.yml --batch 8 --no-cpu-baseline > profiles/$R/bench_c3_b8.json 2> gpurun_out/$R/c3.err
+python3 bench.py --config configs/deepvoxels_shapenet_car.yml --no-cpu-baseline > profiles/$R/bench_c4.json 2> gpurun_out/$R/c4.err
+python3 bench.py > profiles/$R/bench_default.json 2> gpurun_out/$R/default.err
 cp profiles/$R/*.csv profiles/$R/*.json gpurun_out/$R/ 2>/dev/null
 ls -la profiles/$R

@@ -20,3 +20,8 @@ t(lambda: kernels.from_planes(x3, w3, b, 0.5, True), act + x3.numel() * 4, "from
 t(lambda: kernels.to_planes(h, w4, b4, 0.5), act + x4.numel() * 4, "to_planes<4>")
 t(lambda: kernels.planes_outer(h, x3, True), act + x3.numel() * 4, "planes_outer<3> (+tsum)")
 t(lambda: kernels.planes_outer(h, x4, False), act + x4.numel() * 4, "planes_outer<4>")
+ps = torch.zeros(4, device="cuda")
+t(lambda: kernels.planes_outer(h, x4, False, ps), act + x4.numel() * 4, "planes_outer<4> (+psum)")
+w4t = torch.randn(C, 4, device="cuda")
+t(lambda: kernels.from_planes(x4, w4t, None, 0.5, False), act + x4.numel() * 4, "from_planes<4>")
+t(lambda: kernels.to_planes(h, torch.randn(3, C, device="cuda"), None, 0.5), act + x3.numel() * 4, "to_planes<3>")
