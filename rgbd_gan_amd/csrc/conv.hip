@@ -1050,27 +1050,59 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
     float* const bias_lds = reinterpret_cast<float*>(dsm + 2 * P_BYTES + 3 * W_BYTES);   // [BN]
     if (tid < BN) bias_lds[tid] = a.bias ? a.bias[n0 + tid] : 0.f;
 
-    float cs[MASKED ? 16 : 1];          // MASKED: this lane's share of the weighted column sums, over all of its tiles
+    // TR (the MX form, which has no registers to spare): the epilogue's per-lane sums (16 channels x this lane's pixel column)
+    // do not live across the main loop -- each tile's 16 values are reduced over the 16 pixel lanes at the end of its
+    // epilogue by a transposing butterfly (round with distance d: a lane keeps the half of its values whose channel bit
+    // equals its lane bit and adds the partner's copy of them; after four rounds lane r16 holds channel r16's total) and
+    // added to ONE register per statistic.  The bf16 form keeps its 16 (32) registers and reduces once at the end.
+    constexpr bool TR = MX;
+    auto transpose_reduce16 = [&](const float (&v)[16]) {
+        float w8[8], w4[4], w2[2];
 #pragma unroll
-    for (int k2 = 0; k2 < (MASKED ? 16 : 1); ++k2) cs[k2] = 0.f;
+        for (int k = 0; k < 8; ++k) {
+            const bool hi = (r16 & 8) != 0;
+            w8[k] = (hi ? v[k + 8] : v[k]) + __shfl_xor(hi ? v[k] : v[k + 8], 8);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool hi = (r16 & 4) != 0;
+            w4[k] = (hi ? w8[k + 4] : w8[k]) + __shfl_xor(hi ? w8[k] : w8[k + 4], 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const bool hi = (r16 & 2) != 0;
+            w2[k] = (hi ? w4[k + 2] : w4[k]) + __shfl_xor(hi ? w4[k] : w4[k + 2], 2);
+        }
+        const bool hi = (r16 & 1) != 0;
+        return (hi ? w2[1] : w2[0]) + __shfl_xor(hi ? w2[0] : w2[1], 1);
+    };
+    float cs[(MASKED && !TR) ? 16 : 1]; // MASKED: this lane's share of the weighted column sums, over all of its tiles
+    float cs_acc = 0.f, st1_acc = 0.f, st2_acc = 0.f;      // TR: channel (co + r16)'s totals
+#pragma unroll
+    for (int k2 = 0; k2 < ((MASKED && !TR) ? 16 : 1); ++k2) cs[k2] = 0.f;
     // STATS: this lane's share of (sum y, sum y^2) of its 16 channels over the tiles of image st_b walked so far; a
     // workgroup's tiles are consecutive, so it flushes once per image it touches (and at the end)
-    float st1[STATS ? 16 : 1], st2[STATS ? 16 : 1];
+    float st1[(STATS && !TR) ? 16 : 1], st2[(STATS && !TR) ? 16 : 1];
     int st_b = -1;
 #pragma unroll
-    for (int k2 = 0; k2 < (STATS ? 16 : 1); ++k2) { st1[k2] = 0.f; st2[k2] = 0.f; }
+    for (int k2 = 0; k2 < ((STATS && !TR) ? 16 : 1); ++k2) { st1[k2] = 0.f; st2[k2] = 0.f; }
     auto stats_flush = [&]() {          // 16 pixel columns -> per-wave totals; lane r16 then owns channel co + r16
         float v1 = 0.f, v2 = 0.f;
+        if constexpr (TR) {
+            v1 = st1_acc; v2 = st2_acc;
+            st1_acc = 0.f; st2_acc = 0.f;
+        } else {
 #pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) {
-            float t1 = st1[k2], t2 = st2[k2];
-            t1 += __shfl_xor(t1, 1); t2 += __shfl_xor(t2, 1);
-            t1 += __shfl_xor(t1, 2); t2 += __shfl_xor(t2, 2);
-            t1 += __shfl_xor(t1, 4); t2 += __shfl_xor(t2, 4);
-            t1 += __shfl_xor(t1, 8); t2 += __shfl_xor(t2, 8);
-            v1 = r16 == k2 ? t1 : v1;
-            v2 = r16 == k2 ? t2 : v2;
-            st1[k2] = 0.f; st2[k2] = 0.f;
+            for (int k2 = 0; k2 < 16; ++k2) {
+                float t1 = st1[k2], t2 = st2[k2];
+                t1 += __shfl_xor(t1, 1); t2 += __shfl_xor(t2, 1);
+                t1 += __shfl_xor(t1, 2); t2 += __shfl_xor(t2, 2);
+                t1 += __shfl_xor(t1, 4); t2 += __shfl_xor(t2, 4);
+                t1 += __shfl_xor(t1, 8); t2 += __shfl_xor(t2, 8);
+                v1 = r16 == k2 ? t1 : v1;
+                v2 = r16 == k2 ? t2 : v2;
+                st1[k2] = 0.f; st2[k2] = 0.f;
+            }
         }
         unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.stats) +
                                   ((long)st_b * a.Cout + n0 + wave_co + 16 * q + r16) * 2;
@@ -1128,6 +1160,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
             return;
         }
         float ps[16];                   // ypool: running 2x2 sums of the bf16-rounded outputs of a row pair
+        float tl0[TR && (MASKED || STATS) ? 16 : 1], tl1[TR && STATS ? 16 : 1];     // TR: this tile's sums
+#pragma unroll
+        for (int k2 = 0; k2 < (TR && (MASKED || STATS) ? 16 : 1); ++k2) tl0[k2] = 0.f;
+#pragma unroll
+        for (int k2 = 0; k2 < (TR && STATS ? 16 : 1); ++k2) tl1[k2] = 0.f;
 #pragma unroll
         for (int j = 0; j < TPX; ++j) {
             const int yy = y0 + wave_py + j, xx = x0 + r16;
@@ -1175,8 +1212,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
                 if (MASKED) {           // column sums of what was stored (the rounded values, as the separate pass took them)
 #pragma unroll
                     for (int w2 = 0; w2 < 4; ++w2) {
-                        cs[8 * h + 2 * w2] += cw * bf16_lo(out[w2]);
-                        cs[8 * h + 2 * w2 + 1] += cw * bf16_hi(out[w2]);
+                        float* const cacc = TR ? tl0 : cs;
+                        cacc[TR || MASKED ? 8 * h + 2 * w2 : 0] += cw * bf16_lo(out[w2]);
+                        cacc[TR || MASKED ? 8 * h + 2 * w2 + 1 : 0] += cw * bf16_hi(out[w2]);
                     }
                     if (a.y2) {         // rgbd_axpy_rows_bf16 of (what was stored, the activation tile): the injection operand
                         u32x4 o2;
@@ -1191,10 +1229,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
 #pragma unroll
                     for (int w2 = 0; w2 < 4; ++w2) {
                         const float lo = bf16_lo(out[w2]), hi = bf16_hi(out[w2]);
-                        st1[8 * h + 2 * w2] += lo;
-                        st2[8 * h + 2 * w2] += lo * lo;
-                        st1[8 * h + 2 * w2 + 1] += hi;
-                        st2[8 * h + 2 * w2 + 1] += hi * hi;
+                        float* const s1p = TR ? tl0 : st1;
+                        float* const s2p = TR ? tl1 : st2;
+                        s1p[8 * h + 2 * w2] += lo;
+                        s2p[8 * h + 2 * w2] += lo * lo;
+                        s1p[8 * h + 2 * w2 + 1] += hi;
+                        s2p[8 * h + 2 * w2 + 1] += hi * hi;
                     }
                 }
                 if (a.ypool) {          // the block's downscale2x (rescale.py:12-13) of what was just stored
@@ -1224,6 +1264,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if constexpr (TR && MASKED) cs_acc += transpose_reduce16(tl0);
+        if constexpr (TR && STATS) {
+            st1_acc += transpose_reduce16(tl0);
+            st2_acc += transpose_reduce16(tl1);
         }
     };
 
@@ -1394,18 +1439,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
         // through LDS (idle by now: every wave has retired its DMAs, the barrier says so for all of them); then ONE fp32
         // atomic per channel per workgroup, BN consecutive addresses per instruction (4 lanes x 16 instructions per wave
         // on the same 64 addresses, all workgroups at once, serialised for 0.8 ms)
+        if constexpr (!TR) {
 #pragma unroll
-        for (int k2 = 0; k2 < 16; ++k2) {
-            float t = cs[k2];
-            t += __shfl_xor(t, 1);
-            t += __shfl_xor(t, 2);
-            t += __shfl_xor(t, 4);
-            t += __shfl_xor(t, 8);
-            cs[k2] = t;
+            for (int k2 = 0; k2 < 16; ++k2) {
+                float t = cs[k2];
+                t += __shfl_xor(t, 1);
+                t += __shfl_xor(t, 2);
+                t += __shfl_xor(t, 4);
+                t += __shfl_xor(t, 8);
+                cs[k2] = t;
+            }
         }
         __syncthreads();
         float* const red = reinterpret_cast<float*>(dsm);              // [WAVES_PX][BN]
-        if (r16 == 0) {
+        if constexpr (TR) {
+            red[(wid % WAVES_PX) * BN + wave_co + 16 * q + r16] = cs_acc;
+        } else if (r16 == 0) {
 #pragma unroll
             for (int k2 = 0; k2 < 16; ++k2) red[(wid % WAVES_PX) * BN + wave_co + 16 * q + k2] = cs[k2];
         }
