@@ -87,20 +87,27 @@ def pmc_traffic(kernel):
         return None, prov
     ks = prof["kernels"]
     base = kernel.split("<")[0]
-    width = kernel.split("<")[1].rstrip(">") if "<" in kernel else ""
-    # the launch-profile labels fold the upsampling variant into one name and tag the epilogue variants of the pipelined 3x3
-    # kernel (template <BN, UPS, KO, EPI>: "<128>" = EPI 0, "<128,actgrad>" = 1, "<128,stats>" = 2)
-    epi = None
-    if base == "conv3x3_sp_kernel":
-        width, _, tag = width.partition(",")
-        epi = {"": "0", "actgrad": "1", "stats": "2"}.get(tag)
+    tags = kernel.split("<")[1].rstrip(">").split(",") if "<" in kernel else [""]
+    width = tags[0]
+    # the launch-profile labels fold the upsampling variant into one name and tag the forms of the pipelined 3x3 kernel
+    # (template <BN, UPS, KO, EPI, MX>: "<128>" = EPI 0, "<128,actgrad>" = 1, "<128,stats>" = 2, ",mxfp8" = MX)
+    want_epi = "1" if "actgrad" in tags else "2" if "stats" in tags else "0"
+    want_mx = "true" if "mxfp8" in tags else "false"
     tot = cnt = 0
+    if base == "conv_wgrad_kernel":            # "conv_wgrad_kernel<9>+reduce": the batched body's launches (the reduction's
+        base, width = "conv_wgrad_multi_kernel", width.split(">")[0]     # slab traffic is a separate, small kernel)
     for name, v in ks.items():
-        if epi is not None and not name.endswith(f", {epi}>"):
+        if not name.startswith(base):
             continue
-        if name.startswith(base + "<" + width) or name == kernel:
-            tot += v["hbm_bytes_per_launch"] * v["launches"]
-            cnt += v["launches"]
+        if base == "conv3x3_sp_kernel":
+            args = [a.strip() for a in name.split("<", 1)[1].rstrip(">").split(",")]
+            mx = args[4] if len(args) > 4 else "false"
+            if args[0] != width or args[2] != "0" or args[3] != want_epi or mx != want_mx:
+                continue
+        elif not (name.startswith(base + "<" + width) or name == kernel):
+            continue
+        tot += v["hbm_bytes_per_launch"] * v["launches"]
+        cnt += v["launches"]
     return (round(tot / cnt) if cnt else None), prov
 
 

@@ -453,6 +453,24 @@ typedef struct rgbd_pack_mx8_desc {
     float scale;
     int block_begin;
 } rgbd_pack_mx8_desc;
+/* rgbd_conv3x3_ex: the pipelined 3x3 pad-1 launch with every option behind one descriptor -- what the entry points above
+ *   are special cases of, plus MXFP8 copies of its outputs: y_q / y_s (and yp_q / yp_s for y_pooled) receive exactly
+ *   rgbd_quantize_mxfp8 of the stored bf16 tensor (blocks of 32 along Cout), so that the NEXT convolution of the chain
+ *   (net.py:408-418: c0 -> c1 -> pooled -> next block) needs no quantiser pass.  x / w are bf16 when x_scales / w_scales are
+ *   NULL, else e4m3 + E8M0.  NULL / 0 for what is not wanted; output images must be multiples of 16x16. */
+typedef struct rgbd_conv3x3_desc {
+    const void* x; const void* x_scales;          /* (B,Hin,Win,Cin) bf16, or e4m3 bytes + (B,Hin,Win,Cin/32) scales */
+    const void* w; const void* w_scales;          /* [9][Cout][Cin] image (fprop, or the dgrad image with Cin / Cout exchanged) */
+    const float* bias; const void* residual;      /* (Cout) fp32; (B,Hout,Wout,Cout) bf16 */
+    const void* act_y;                            /* masked form (rgbd_conv3x3_actgrad_bf16) */
+    float* colsum; const float* row_scale;
+    void* y; void* y_pooled; void* y2; const float* row_scale2;
+    int64_t* stats;                               /* statistics form (rgbd_conv2d_fprop_stats_bf16), zeroed by the caller */
+    void* y_q; void* y_s; void* yp_q; void* yp_s; /* MXFP8 copies of y / y_pooled */
+    int B, Hin, Win, Cin, Cout, upsample, pool_sum, lrelu_channels;
+    float slope;
+} rgbd_conv3x3_desc;
+int rgbd_conv3x3_ex(const rgbd_conv3x3_desc* desc, void* stream);
 int rgbd_quantize_mxfp8(const void* x, void* q, void* scales, int64_t rows, int C, void* stream);
 int rgbd_pack_weights_mxfp8_multi(const rgbd_pack_mx8_desc* descs_device, int n, int total_blocks, void* stream);
 int rgbd_conv3x3_mxfp8_supported(int B, int Hout, int Wout, int Cin, int Cout);

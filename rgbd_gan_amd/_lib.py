@@ -90,6 +90,7 @@ PROTOTYPES = {
     "rgbd_conv3x3_actgrad_bf16": ([_P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P], c_int),
     "rgbd_conv2d_fprop_stats_bf16": ([_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P], c_int),
     "rgbd_adain_apply_fixed": ([_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P], c_int),
+    "rgbd_conv3x3_ex": ([_P, _P], c_int),
     "rgbd_quantize_mxfp8": ([_P, _P, _P, c_int64, c_int, _P], c_int),
     "rgbd_pack_weights_mxfp8_multi": ([_P, c_int, c_int, _P], c_int),
     "rgbd_conv3x3_mxfp8_supported": ([c_int, c_int, c_int, c_int, c_int], c_int),

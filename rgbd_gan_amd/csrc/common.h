@@ -55,6 +55,25 @@ __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
 __device__ __forceinline__ float bf16_lo(unsigned int w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }
 
+// ---- MXFP8 element / scale arithmetic (csrc/mxfp8.hip states the format; shared with the conv epilogues that emit it)
+__device__ __forceinline__ unsigned mx8_scale_of(float amax) {          // E8M0 byte of a block with this largest magnitude
+    const unsigned bits = __float_as_uint(amax);
+    const int E = (int)((bits >> 23) & 0xffu) + ((bits & 0x7fffffu) > 0x600000u ? 1 : 0);
+    return (unsigned)(E > 8 ? E - 8 : 0);
+}
+__device__ __forceinline__ float mx8_inv_scale(unsigned s) {            // 2^(127 - s), always a normal number (s <= 247)
+    return __uint_as_float((254u - s) << 23);
+}
+__device__ __forceinline__ float mx8_clamp(float v) {                   // NaN stays NaN (both comparisons are false)
+    v = v > 448.f ? 448.f : v;
+    return v < -448.f ? -448.f : v;
+}
+__device__ __forceinline__ unsigned mx8_pack4(float a, float b, float c, float d) {
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(mx8_clamp(a), mx8_clamp(b), 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(mx8_clamp(c), mx8_clamp(d), w, true);
+    return (unsigned)w;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -59,6 +59,12 @@ struct ConvArgs {
     const unsigned char* xs;
     const unsigned char* ws;
     int xs_bytes, ws_bytes;
+    // pipelined 3x3 kernel, any form: MXFP8 copies of what the epilogue stores (blocks of 32 along Cout: the next convolution's
+    // reduction channels), so that the consumer needs no quantiser pass -- of y (yq / ys) and of the pooled output (ypq / yps)
+    unsigned char* yq;
+    unsigned char* ys;
+    unsigned char* ypq;
+    unsigned char* yps;
 };
 
 __device__ __forceinline__ u32x4 ldg16(const unsigned short* p) { return *reinterpret_cast<const u32x4*>(p); }
@@ -772,7 +778,9 @@ __device__ __forceinline__ void lds_dma4(u32x4 rsrc, unsigned voff, unsigned sof
 //   ahead at QUARTER granularity: the A fragment of 16-channel tile i of step t+1 lands in the registers quarter i of
 //   step t has finished with; B rows sit in a ring of row slots, a row's slot being free again before its next tenant's
 //   read is issued (NSLOT below).
-template <int BN, bool UPS, int KO = 0, int EPI = 0, bool MX = false>   // KO: timing knock-outs (wrong results): 1 no weight DMA, 2 no halo DMA, 3 no LDS reads, 4 no MFMAs, 6 MFMAs and barriers only
+// EMIT: the epilogue also writes MXFP8 copies of what it stores (ConvArgs::yq ...) -- its own instantiation, because the
+//   wide MX form has not a register to spare and the pointers alone tip it into spilling.
+template <int BN, bool UPS, int KO = 0, int EPI = 0, bool MX = false, bool EMIT = false>   // KO: timing knock-outs (wrong results): 1 no weight DMA, 2 no halo DMA, 3 no LDS reads, 4 no MFMAs, 6 MFMAs and barriers only
 __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
     constexpr bool MASKED = EPI == 1, STATS = EPI == 2;
     constexpr int EB = MX ? 1 : 2;                // bytes per operand element: a 128-byte slice is 64 bf16 or 128 e4m3 channels
@@ -1005,8 +1013,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
     }
     auto load_a_mx = [&](int wb, int i) {                                // tile i's fragment of weight buffer wb
         const unsigned char* wbuf = w_lds + wb * W_BYTES;
+        // (the two chunks of a lane differ in chunk bit 2 = address bit 6, which the XOR swizzle never touches with a carry:
+        // aoff[1] == aoff[0] ^ 64 -- one short-lived VALU result instead of a register held across the kernel)
         const u32x4 lo = *reinterpret_cast<const u32x4*>(wbuf + aoff[0] + i * 16 * 128);
-        const u32x4 hi = *reinterpret_cast<const u32x4*>(wbuf + aoff[1] + i * 16 * 128);
+        const u32x4 hi = *reinterpret_cast<const u32x4*>(wbuf + (aoff[0] ^ 64) + i * 16 * 128);
         afm[i] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
         sam[i] = (int)ws_lds[wb * WS_BYTES + sa_off + i * 64];
     };
@@ -1024,9 +1034,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
             if (used && !prev && (part < 0 || cnt++ % 3 == part)) {
                 const int sl = (kw * NR + r) % NSLOT;
                 const u32x4 lo = *reinterpret_cast<const u32x4*>(pbuf + boff[kw][0] + r * HPW * 128);
-                const u32x4 hi = *reinterpret_cast<const u32x4*>(pbuf + boff[kw][1] + r * HPW * 128);
+                const u32x4 hi = *reinterpret_cast<const u32x4*>(pbuf + (boff[kw][0] ^ 64) + r * HPW * 128);
                 bm[sl] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
-                sbm[sl] = (int)xs_lds[pb * XS_BYTES + sb_off[kw] + r * HPW * 4];
+                sbm[sl] = (int)xs_lds[pb * XS_BYTES + (UPS ? sb_off[kw] : sb_off[0] + 4 * kw) + r * HPW * 4];
             }
         }
     };
@@ -1117,6 +1127,29 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
         }
     };
 
+    // MXFP8 copy of 16 stored channels of one pixel (two u32x4 of bf16 pairs): this lane and lane ^ 16 (q ^ 1: the same pixel,
+    // the neighbouring 16 channels) form one 32-channel block; exactly rgbd_quantize_mxfp8 of the stored tensor
+    auto emit_mx8 = [&](unsigned char* qbase, unsigned char* sbase, long o, const u32x4& lo4, const u32x4& hi4) {
+        float f[16];
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) {
+            f[2 * w2] = bf16_lo(lo4[w2]); f[2 * w2 + 1] = bf16_hi(lo4[w2]);
+            f[8 + 2 * w2] = bf16_lo(hi4[w2]); f[8 + 2 * w2 + 1] = bf16_hi(hi4[w2]);
+        }
+        float amax = 0.f;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) amax = fmaxf(amax, fabsf(f[k2]));
+        amax = fmaxf(amax, __shfl_xor(amax, 16));
+        const unsigned sc = mx8_scale_of(amax);
+        const float inv = mx8_inv_scale(sc);
+        const u32x4 qv = {mx8_pack4(f[0] * inv, f[1] * inv, f[2] * inv, f[3] * inv),
+                          mx8_pack4(f[4] * inv, f[5] * inv, f[6] * inv, f[7] * inv),
+                          mx8_pack4(f[8] * inv, f[9] * inv, f[10] * inv, f[11] * inv),
+                          mx8_pack4(f[12] * inv, f[13] * inv, f[14] * inv, f[15] * inv)};
+        *reinterpret_cast<u32x4*>(qbase + o) = qv;
+        if ((q & 1) == 0) sbase[o >> 5] = (unsigned char)sc;
+    };
+
     auto epilogue = [&](int pt) {       // bias -> residual -> leaky ReLU (or a given mask) -> bf16 NHWC, then clear the accumulators
         int b, y0, x0;
         tile_origin(pt, b, y0, x0);
@@ -1204,11 +1237,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
                     }
                 }
             }
+            u32x4 stored[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 u32x4 out = {pack_bf16x2(v[8 * h + 0], v[8 * h + 1]), pack_bf16x2(v[8 * h + 2], v[8 * h + 3]),
                              pack_bf16x2(v[8 * h + 4], v[8 * h + 5]), pack_bf16x2(v[8 * h + 6], v[8 * h + 7])};
                 *reinterpret_cast<u32x4*>(a.y + o + 8 * h) = out;
+                stored[h] = out;
                 if (MASKED) {           // column sums of what was stored (the rounded values, as the separate pass took them)
 #pragma unroll
                     for (int w2 = 0; w2 < 4; ++w2) {
@@ -1246,6 +1281,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
                     }
                 }
             }
+            if constexpr (EMIT) {
+                if (a.yq) emit_mx8(a.yq, a.ys, o, stored[0], stored[1]);
+            }
             if (a.ypool && (j & 1)) {
 #pragma unroll
                 for (int k2 = 0; k2 < 16; ++k2) {
@@ -1254,11 +1292,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
                 }
                 if ((r16 & 1) == 0) {
                     const long op = (((long)b * (a.Hout >> 1) + (yy >> 1)) * (a.Wout >> 1) + (xx >> 1)) * a.Cout + co;
+                    u32x4 pst[2];
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         u32x4 out = {pack_bf16x2(ps[8 * h + 0], ps[8 * h + 1]), pack_bf16x2(ps[8 * h + 2], ps[8 * h + 3]),
                                      pack_bf16x2(ps[8 * h + 4], ps[8 * h + 5]), pack_bf16x2(ps[8 * h + 6], ps[8 * h + 7])};
                         *reinterpret_cast<u32x4*>(a.ypool + op + 8 * h) = out;
+                        pst[h] = out;
+                    }
+                    if constexpr (EMIT) {
+                        if (a.ypq) emit_mx8(a.ypq, a.yps, op, pst[0], pst[1]);
                     }
                 }
             }
@@ -2154,19 +2197,19 @@ extern "C" int64_t rgbd_conv2d_fprop_workspace(int B, int Hin, int Win, int Cin,
 
 namespace {
 // One launch of the pipelined 3x3 kernel's MXFP8 form; the LDS reservation is made once per instantiation.
-template <int BN, bool UPS, int EPI>
+template <int BN, bool UPS, int EPI, bool MX = true, bool EMIT = false>
 int launch_sp_mx(const ConvArgs& a, unsigned grid, hipStream_t st) {
     constexpr int pieces = UPS ? 13 : 41, spieces = UPS ? 2 : 6;
-    constexpr int lds = 2 * pieces * 1024 + 3 * BN * 128 + BN * 4 + 2 * spieces * 256 + 3 * BN * 4;
+    constexpr int lds = 2 * pieces * 1024 + 3 * BN * 128 + BN * 4 + (MX ? 2 * spieces * 256 + 3 * BN * 4 : 0);
     static bool attr_done = false;
     if (!attr_done) {
-        RGBD_REQUIRE(hipFuncSetAttribute((const void*)&conv3x3_sp_kernel<BN, UPS, 0, EPI, true>,
+        RGBD_REQUIRE(hipFuncSetAttribute((const void*)&conv3x3_sp_kernel<BN, UPS, 0, EPI, MX, EMIT>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess,
-                     "rgbd_conv3x3_mxfp8: cannot reserve %d B of LDS", lds);
+                     "rgbd_conv3x3: cannot reserve %d B of LDS", lds);
         attr_done = true;
     }
-    conv3x3_sp_kernel<BN, UPS, 0, EPI, true><<<grid, 512, lds, st>>>(a);
-    RGBD_CHECK_LAUNCH("conv3x3_sp_kernel<mxfp8>");
+    conv3x3_sp_kernel<BN, UPS, 0, EPI, MX, EMIT><<<grid, 512, lds, st>>>(a);
+    RGBD_CHECK_LAUNCH("conv3x3_sp_kernel");
     return 0;
 }
 template <int EPI>
@@ -2176,6 +2219,12 @@ int launch_sp_mx_any(const ConvArgs& a, bool wide, unsigned grid, hipStream_t st
                            : launch_sp_mx<64, true, EPI == 1 ? 0 : EPI>(a, grid, st);
     return wide ? launch_sp_mx<128, false, EPI>(a, grid, st) : launch_sp_mx<64, false, EPI>(a, grid, st);
 }
+// the EMITting instantiations: plain and masked epilogues, no folded upsample, either operand type
+template <bool MX>
+int launch_sp_emit(const ConvArgs& a, bool wide, bool masked, unsigned grid, hipStream_t st) {
+    if (masked) return wide ? launch_sp_mx<128, false, 1, MX, true>(a, grid, st) : launch_sp_mx<64, false, 1, MX, true>(a, grid, st);
+    return wide ? launch_sp_mx<128, false, 0, MX, true>(a, grid, st) : launch_sp_mx<64, false, 0, MX, true>(a, grid, st);
+}
 }  // namespace
 
 static int conv_fprop_impl(const void* x, const void* wp, const float* bias, const void* residual,
@@ -2184,7 +2233,8 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
                            void* y_pooled = nullptr, const void* mask_y = nullptr, float* colsum = nullptr,
                            const float* row_scale = nullptr, long long* stats = nullptr, void* y2 = nullptr,
                            const float* row_scale2 = nullptr, const void* x_scales = nullptr,
-                           const void* w_scales = nullptr) {
+                           const void* w_scales = nullptr, void* y_q = nullptr, void* y_s = nullptr, void* yp_q = nullptr,
+                           void* yp_s = nullptr) {
     RGBD_REQUIRE(x && wp && y, "rgbd_conv2d_fprop_bf16: null pointer");
     RGBD_REQUIRE(B > 0 && Hin > 0 && Win > 0 && KH > 0 && KW > 0 && pad >= 0, "rgbd_conv2d_fprop_bf16: bad shape");
     RGBD_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0,
@@ -2223,6 +2273,16 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
     a.mask_y = (const unsigned short*)mask_y; a.colsum = colsum; a.row_scale = row_scale;
     a.stats = stats;
     a.y2 = (unsigned short*)y2; a.row_scale2 = row_scale2;
+    a.yq = (unsigned char*)y_q; a.ys = (unsigned char*)y_s; a.ypq = (unsigned char*)yp_q; a.yps = (unsigned char*)yp_s;
+    if (y_q || yp_q) {
+        RGBD_REQUIRE(KH == 3 && KW == 3 && pad == 1 && a.Hout % 16 == 0 && a.Wout % 16 == 0 && !pool_sum && !g_force_gather &&
+                     g_conv_variant == 0 && !upsample && !stats && Cout % 32 == 0 && (!y_q || y_s) && (!yp_q || (yp_s && y_pooled)),
+                     "rgbd_conv3x3_ex: MXFP8 copies of the outputs need a 3x3 pad-1 conv on output images that are multiples of "
+                     "16x16 (the pipelined kernel's epilogue), scale buffers, and y_pooled for the pooled copy");
+        plan.patch = true;
+        plan.ksplit = 1;
+        plan.small = false;
+    }
     if (stats) {
         RGBD_REQUIRE(KH == 3 && KW == 3 && pad == 1 && a.Hout % 16 == 0 && a.Wout % 16 == 0 && !pool_sum && !y_pooled &&
                      !mask_y && !g_force_gather && g_conv_variant != 1,
@@ -2300,6 +2360,16 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
         a.ptiles = (int)ptiles;
         a.wgs_per_ntile = per_nt;
         const long grid = (long)per_nt * n_tiles;
+        if (a.yq || a.ypq) {
+            const int rc = mx ? launch_sp_emit<true>(a, wide, mask_y != nullptr, (unsigned)grid, st)
+                              : launch_sp_emit<false>(a, wide, mask_y != nullptr, (unsigned)grid, st);
+            if (rc) return rc;
+            g_last_conv_kernel = mx ? (mask_y ? (wide ? "conv3x3_sp_kernel<128,actgrad,mxfp8>" : "conv3x3_sp_kernel<64,actgrad,mxfp8>")
+                                              : (wide ? "conv3x3_sp_kernel<128,mxfp8>" : "conv3x3_sp_kernel<64,mxfp8>"))
+                                    : (mask_y ? (wide ? "conv3x3_sp_kernel<128,actgrad>" : "conv3x3_sp_kernel<64,actgrad>")
+                                              : (wide ? "conv3x3_sp_kernel<128>" : "conv3x3_sp_kernel<64>"));
+            return 0;
+        }
         if (mx) {
             const int rc = stats ? launch_sp_mx_any<2>(a, wide, (unsigned)grid, st)
                          : mask_y ? launch_sp_mx_any<1>(a, wide, (unsigned)grid, st)
@@ -2539,6 +2609,19 @@ extern "C" int rgbd_conv2d_fprop_stats_mxfp8(const void* xq, const void* xs, con
     RGBD_REQUIRE(stats && xs && ws, "rgbd_conv2d_fprop_stats_mxfp8: null pointer");
     return conv_fprop_impl(xq, wq, bias, nullptr, y, B, Hin, Win, Cin, Cout, 3, 3, 1, upsample, lrelu_channels, slope, nullptr,
                            stream, 0, nullptr, nullptr, nullptr, nullptr, (long long*)stats, nullptr, nullptr, xs, ws);
+}
+
+// Every option of the pipelined 3x3 launch behind one descriptor (the entry points above are its common special cases)
+extern "C" int rgbd_conv3x3_ex(const rgbd_conv3x3_desc* d, void* stream) {
+    RGBD_REQUIRE(d, "rgbd_conv3x3_ex: null descriptor");
+    RGBD_REQUIRE(!d->x_scales == !d->w_scales, "rgbd_conv3x3_ex: x_scales and w_scales come together");
+    RGBD_REQUIRE(!(d->act_y && d->stats), "rgbd_conv3x3_ex: act_y and stats are exclusive");
+    RGBD_REQUIRE(d->colsum || !d->row_scale, "rgbd_conv3x3_ex: row_scale without colsum");
+    RGBD_REQUIRE(!d->y2 == !d->row_scale2, "rgbd_conv3x3_ex: y2 and row_scale2 come together");
+    return conv_fprop_impl(d->x, d->w, d->bias, d->residual, d->y, d->B, d->Hin, d->Win, d->Cin, d->Cout, 3, 3, 1, d->upsample,
+                           d->lrelu_channels, d->slope, nullptr, stream, d->pool_sum, d->y_pooled, d->act_y, d->colsum,
+                           d->row_scale, (long long*)d->stats, d->y2, d->row_scale2, d->x_scales, d->w_scales, d->y_q, d->y_s,
+                           d->yp_q, d->yp_s);
 }
 
 extern "C" int64_t rgbd_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int Cout, int K) {

@@ -19,24 +19,6 @@
 
 namespace {
 
-__device__ __forceinline__ unsigned mx8_scale_of(float amax) {          // E8M0 byte of a block with this largest magnitude
-    const unsigned bits = __float_as_uint(amax);
-    const int E = (int)((bits >> 23) & 0xffu) + ((bits & 0x7fffffu) > 0x600000u ? 1 : 0);
-    return (unsigned)(E > 8 ? E - 8 : 0);
-}
-__device__ __forceinline__ float mx8_inv_scale(unsigned s) {            // 2^(127 - s), always a normal number (s <= 247)
-    return __uint_as_float((254u - s) << 23);
-}
-__device__ __forceinline__ float mx8_clamp(float v) {                   // NaN stays NaN (both comparisons are false)
-    v = v > 448.f ? 448.f : v;
-    return v < -448.f ? -448.f : v;
-}
-__device__ __forceinline__ unsigned mx8_pack4(float a, float b, float c, float d) {
-    int w = __builtin_amdgcn_cvt_pk_fp8_f32(mx8_clamp(a), mx8_clamp(b), 0, false);
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(mx8_clamp(c), mx8_clamp(d), w, true);
-    return (unsigned)w;
-}
-
 // x (rows, C) bf16 -> q (rows, C) e4m3, scales (rows, C / 32) e8m0.  C % 128 == 0.  A thread owns 8 consecutive
 // elements (one 16-byte load, one 8-byte store), four neighbouring lanes one block, sixteen one scale dword.
 __global__ __launch_bounds__(256) void quantize_mx8_kernel(const unsigned short* __restrict__ x, unsigned char* __restrict__ q,

@@ -295,7 +295,9 @@ class _ConvFprop(torch.autograd.Function):
         wf, _ = layer.packed()
         residual = residual.contiguous() if residual is not None else None
         if mask_y is not None:
-            out = kernels.conv3x3_actgrad(x.contiguous(), wf, mask_y, residual=residual, operand_scale=operand_scale)
+            # (conv_dtype mxfp8: the masked result is the next convolution's input -- its fp8 copy leaves this epilogue)
+            out = kernels.conv3x3_actgrad(x.contiguous(), wf, mask_y, residual=residual, operand_scale=operand_scale,
+                                          emit_mx8=_MXFP8)
             if operand_scale is not None:
                 ctx.mark_non_differentiable(out[1])
             return out
@@ -340,7 +342,8 @@ class _ConvDgrad(torch.autograd.Function):
         resid = resid.contiguous() if resid is not None else None
         if mask_y is not None:
             return kernels.conv3x3_actgrad(dy.contiguous(), wd, mask_y, residual=resid,
-                                           bias_grad=mask_bias.grad if mask_bias is not None else None, row_scale=mask_scale)
+                                           bias_grad=mask_bias.grad if mask_bias is not None else None, row_scale=mask_scale,
+                                           emit_mx8=_MXFP8)          # dz0 feeds the entry conv's input gradient
         return kernels.conv2d_dgrad(dy.contiguous(), wd, layer.K, layer.pad, sum_pool2=ups, residual=resid)
 
     @staticmethod
@@ -732,9 +735,11 @@ class _ConvBiasAct(torch.autograd.Function):
     def forward(ctx, x, w, bias, residual, layer, ups, act, pool, tie=None, role=0):
         wf, _ = layer.packed()
         x = x.contiguous()
+        # conv_dtype mxfp8: an activation output feeds the next convolution (h0 -> c1; the pooled block output -> the next
+        # block's c0 / c_sc), so its fp8 copy is written by this epilogue instead of by a quantiser pass
         y = kernels.conv2d_fprop(x, wf, layer.K, layer.K, layer.pad, bias=bias.contiguous(),
                                  residual=residual.contiguous() if residual is not None else None, upsample=ups,
-                                 lrelu_channels=w.shape[0] if act else 0, avg_pool2=pool)
+                                 lrelu_channels=w.shape[0] if act else 0, avg_pool2=pool, emit_mx8=_MXFP8 and act)
         if pool:
             y, pooled = y
         ctx.layer, ctx.ups, ctx.act, ctx.pool = layer, ups, act, pool

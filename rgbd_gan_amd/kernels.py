@@ -268,6 +268,46 @@ def quantize_mx8(x):
     return q, sc
 
 
+class Conv3x3Desc(ctypes.Structure):
+    """struct rgbd_conv3x3_desc (include/rgbd_gan_hip.h)"""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("x", "x_scales", "w", "w_scales", "bias", "residual", "act_y", "colsum",
+                                                "row_scale", "y", "y_pooled", "y2", "row_scale2", "stats", "y_q", "y_s",
+                                                "yp_q", "yp_s")] + \
+               [(n, ctypes.c_int) for n in ("B", "Hin", "Win", "Cin", "Cout", "upsample", "pool_sum", "lrelu_channels")] + \
+               [("slope", ctypes.c_float)]
+
+
+def mx8_emittable(B, Hout, Wout, Cout):
+    """Can a 3x3 launch with this output write an MXFP8 copy of it that a following convolution will use?  (the pipelined
+    kernel's epilogue: output images multiples of 16x16; the consumer's reduction channels = Cout a multiple of 128)"""
+    return Hout % 16 == 0 and Wout % 16 == 0 and Cout % 128 == 0 and Hout >= 16 and \
+        B * (Hout // 16) * (Wout // 16) * (Cout // 128) >= MX8_MIN_TILES
+
+
+def _conv3x3_ex(x, mx_x, wp, mx_w, y, B, H, W, Cin, Cout, bias=None, residual=None, act_y=None, colsum=None, row_scale=None,
+                y_pooled=None, y2=None, row_scale2=None, lrelu_channels=0, slope=0.2, emit=False, emit_pooled=False):
+    """One rgbd_conv3x3_ex launch (no upsample, no statistics); emit / emit_pooled: also write the MXFP8 copies and hang them
+    on y / y_pooled (`_mx8`, what quantize_mx8 looks for)."""
+    dev = x.device
+    yq = ys = ypq = yps = None
+    if emit:
+        yq = torch.empty(y.shape, dtype=U8, device=dev)
+        ys = torch.empty(tuple(y.shape[:-1]) + (Cout // 32,), dtype=U8, device=dev)
+    if emit_pooled:
+        ypq = torch.empty(y_pooled.shape, dtype=U8, device=dev)
+        yps = torch.empty(tuple(y_pooled.shape[:-1]) + (Cout // 32,), dtype=U8, device=dev)
+    p = lambda t: t.data_ptr() if t is not None else None
+    d = Conv3x3Desc(p(mx_x[0]) if mx_x else p(x), p(mx_x[1]) if mx_x else None, p(mx_w.q) if mx_w else p(wp),
+                    p(mx_w.s) if mx_w else None, p(bias), p(residual), p(act_y), p(colsum), p(row_scale), p(y), p(y_pooled), p(y2),
+                    p(row_scale2), None, p(yq), p(ys), p(ypq), p(yps), B, H, W, Cin, Cout, 0, 0, int(lrelu_channels), float(slope))
+    rc = _lib.load().rgbd_conv3x3_ex(ctypes.byref(d), _stream())
+    if emit:
+        y._mx8 = (yq, ys, y._version)
+    if emit_pooled:
+        y_pooled._mx8 = (ypq, yps, y_pooled._version)
+    return rc
+
+
 PACK_MX8_DESC = [("w", "<u8"), ("wf_q", "<u8"), ("wf_s", "<u8"), ("wd_q", "<u8"), ("wd_s", "<u8"), ("cout", "<i4"),
                  ("cin", "<i4"), ("scale", "<f4"), ("block_begin", "<i4")]             # struct rgbd_pack_mx8_desc, 56 bytes
 
@@ -321,7 +361,7 @@ def _fprop_workspace(lib, B, H, W, Cin, Cout, KH, KW, pad, ups, device):
 
 
 def conv2d_fprop(x, wp, KH, KW, pad, bias=None, residual=None, upsample=False, lrelu_channels=0, slope=0.2,
-                 avg_pool2=False):
+                 avg_pool2=False, emit_mx8=False):
     """x (B,H,W,Cin) bf16, wp [KH*KW][Cout][Cin] bf16 -> y (B,Hout,Wout,Cout) bf16.
     avg_pool2: -> (y, 2x2 average of y at half resolution); the average comes out of the conv epilogue for 3x3 convs on
     images that are multiples of 16x16, out of a second pass (rgbd_pool2_masked) otherwise."""
@@ -341,6 +381,21 @@ def conv2d_fprop(x, wp, KH, KW, pad, bias=None, residual=None, upsample=False, l
     nbytes = 2.0 * (x.numel() + y.numel() + wp.numel() + (residual.numel() if residual is not None else 0))
     fuse_pool = bool(avg_pool2) and KH == 3 and KW == 3 and pad == 1 and Hout % 16 == 0 and Wout % 16 == 0
     yp = torch.empty(B, Hout // 2, Wout // 2, Cout, dtype=BF16, device=x.device) if fuse_pool else None
+    # emit_mx8: the launch also leaves the MXFP8 copy of what the NEXT convolution will read -- of the pooled output when
+    # there is one (the next residual block's input), else of y (c0 -> c1) -- where that convolution can use it
+    emit_y = bool(emit_mx8) and not avg_pool2 and not upsample and KH == 3 and pad == 1 and mx8_emittable(B, Hout, Wout, Cout)
+    emit_p = bool(emit_mx8) and fuse_pool and not upsample and mx8_emittable(B, Hout // 2, Wout // 2, Cout)
+    if emit_y or emit_p:
+        mx_x = quantize_mx8(x) if mx is not None else None
+        rc = _timed(lambda: _conv_kernel_name(f"fprop {Hout}x{Wout} {Cin}->{Cout}{' pool' if fuse_pool else ''}"
+                                              f"{' res' if residual is not None else ''} emit"), flops,
+                    nbytes if mx is None else nbytes - 0.97 * (x.numel() + wp.numel()),
+                    lambda: _conv3x3_ex(x, mx_x, wp, mx, y, B, H, W, Cin, Cout, bias=bias, residual=residual, y_pooled=yp,
+                                        lrelu_channels=lrelu_channels, slope=slope, emit=emit_y, emit_pooled=emit_p))
+        _lib.check(rc, "rgbd_conv3x3_ex")
+        if avg_pool2:
+            return y, yp
+        return y
     if mx is not None:
         xq, xs = quantize_mx8(x)
         nbytes = 1.03 * (x.numel() + mx.q.numel()) + 2.0 * (y.numel() + (residual.numel() if residual is not None else 0))
@@ -412,7 +467,8 @@ def conv3x3_actgrad_supported(B, H, W, Cin, Cout):
     return bool(_lib.load().rgbd_conv3x3_actgrad_supported(int(B), int(H), int(W), int(Cin), int(Cout)))
 
 
-def conv3x3_actgrad(x, wp, act_y, residual=None, bias_grad=None, row_scale=None, slope=0.2, operand_scale=None):
+def conv3x3_actgrad(x, wp, act_y, residual=None, bias_grad=None, row_scale=None, slope=0.2, operand_scale=None,
+                    emit_mx8=False):
     """(conv3x3_pad1(x, wp) + residual) * lrelu'(act_y) in one launch; x (B,H,W,Cin) bf16, wp [9][Cout][Cin] bf16 (the fprop
     image, or the dgrad image of a Cout->Cin convolution), act_y / residual (B,H,W,Cout) bf16.  bias_grad (Cout fp32,
     accumulated): += sum_b row_scale[b] * column sums of the result (row_scale None = 1).  operand_scale (B,) fp32:
@@ -437,6 +493,14 @@ def conv3x3_actgrad(x, wp, act_y, residual=None, bias_grad=None, row_scale=None,
     flops = 2.0 * B * H * W * Cout * Cin * 9
     nbytes = 2.0 * (x.numel() + (3 if y2 is not None else 2) * y.numel() + wp.numel() +
                     (residual.numel() if residual is not None else 0))
+    if emit_mx8 and mx8_emittable(B, H, W, Cout):
+        mx_x = quantize_mx8(x) if mx is not None else None
+        rc = _timed(lambda: _conv_kernel_name(f"actgrad {H}x{W} {Cin}->{Cout}{' res' if residual is not None else ''} emit"),
+                    flops, nbytes if mx is None else nbytes - 0.97 * (x.numel() + wp.numel()),
+                    lambda: _conv3x3_ex(x, mx_x, wp, mx, y, B, H, W, Cin, Cout, residual=residual, act_y=act_y, colsum=bias_grad,
+                                        row_scale=row_scale, y2=y2, row_scale2=operand_scale, slope=slope, emit=True))
+        _lib.check(rc, "rgbd_conv3x3_ex")
+        return y if y2 is None else (y, y2)
     if mx is not None:
         xq, xs = quantize_mx8(x)
         nbytes = nbytes - 0.97 * (x.numel() + wp.numel())

@@ -255,3 +255,47 @@ def test_mxfp8_adjoint_identity_at_benchmark_size():
     # exactly representable operands: the fp8 product sum equals the bf16 engine's up to the output rounding
     yb = kernels.conv2d_fprop(x, wf, 3, 3, 1)
     torch.testing.assert_close(y.float(), yb.float(), atol=2.0 ** -7 * float(yb.float().abs().max()), rtol=0)
+
+
+@pytest.mark.parametrize("operands", ["bf16", "mxfp8"])
+def test_epilogue_emits_the_quantisers_bytes(operands):
+    """rgbd_conv3x3_ex: the MXFP8 copies a launch writes of its outputs (y; the pooled second output; the masked form's y) are
+    bit for bit rgbd_quantize_mxfp8 of the bf16 tensors it stores, whatever the operand type of the launch itself -- and the
+    bf16 outputs are the non-emitting launch's."""
+    from rgbd_gan_amd import kernels
+    g = torch.Generator().manual_seed(17)
+    B, H, Cin, Cout = 2, 32, 128, 256
+    x = _bf16(torch.randn(B, H, H, Cin, generator=g) * torch.exp2(torch.randint(-3, 3, (B, H, H, 1), generator=g).float())).to(dev())
+    res = _bf16(torch.randn(B, H, H, Cout, generator=g)).to(dev())
+    act = _bf16(torch.randn(B, H, H, Cout, generator=g)).to(dev())
+    bias = torch.randn(Cout, generator=g).to(dev())
+    img = _image(torch.randn(Cout, Cin, 3, 3, generator=g), float(np.sqrt(2.0 / (Cin * 9))))
+    wp = img if operands == "mxfp8" else img.bf16
+
+    def check(t):
+        q, s, _ = t._mx8
+        t2 = t.clone()
+        rq, rs = kernels.quantize_mx8(t2)
+        assert torch.equal(q, rq) and torch.equal(s, rs)
+    def same(a, b):      # (a small bf16 problem without a copy to emit goes to the split-K gather kernel: another summation
+        if operands == "mxfp8":      # order, one bf16 rounding apart; the MXFP8 launches are the same kernel either way)
+            assert torch.equal(a, b)
+        else:
+            torch.testing.assert_close(a.float(), b.float(), atol=2.0 ** -7 * float(b.float().abs().max()), rtol=0)
+    y = kernels.conv2d_fprop(x, wp, 3, 3, 1, bias=bias, lrelu_channels=Cout, emit_mx8=True)
+    same(y, kernels.conv2d_fprop(x, wp, 3, 3, 1, bias=bias, lrelu_channels=Cout))
+    check(y)
+    y, yp = kernels.conv2d_fprop(x, wp, 3, 3, 1, bias=bias, residual=res, lrelu_channels=Cout, avg_pool2=True, emit_mx8=True)
+    y0, yp0 = kernels.conv2d_fprop(x, wp, 3, 3, 1, bias=bias, residual=res, lrelu_channels=Cout, avg_pool2=True)
+    same(y, y0), same(yp, yp0)
+    assert getattr(y, "_mx8", None) is None
+    check(yp)
+    bg, bg0 = torch.zeros(Cout, device=dev()), torch.zeros(Cout, device=dev())
+    dz = kernels.conv3x3_actgrad(x, wp, act, bias_grad=bg, emit_mx8=True)
+    same(dz, kernels.conv3x3_actgrad(x, wp, act, bias_grad=bg0))
+    torch.testing.assert_close(bg, bg0, rtol=1e-5, atol=1e-5 * float(bg0.abs().max()))
+    check(dz)
+    # the consumer takes the copy that rides on the tensor: no quantiser launch
+    with kernels.launch_profile() as prof:
+        kernels.conv2d_fprop(dz, _image(torch.randn(128, Cout, 3, 3, generator=g), 0.02), 3, 3, 1)
+    assert "quantize_mx8_kernel" not in prof.summary()
