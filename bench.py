@@ -53,6 +53,8 @@ def parse():
                          "(v_mfma_scale_f32_16x16x128_f8f6f4), weight gradients on the bf16 kernels")
     ap.add_argument("--arrangements", action="store_true",
                     help="also time the single-stream arrangement on the same box (extra key, never `value`)")
+    ap.add_argument("--mx8-standalone-quantiser", action="store_true",
+                    help="A/B aid for --fp8: every conv input through rgbd_quantize_mxfp8 instead of the producers' epilogues")
     return ap.parse_args()
 
 
@@ -237,6 +239,7 @@ def main():
         side, extra = 256, {"fixed_stage": 12.0}
     if args.fp8:
         config.conv_dtype = "mxfp8"
+        kernels.MX8_EMIT = not args.mx8_standalone_quantiser
     np.random.seed(2 + comm.rank)
     torch.manual_seed(comm.rank)
     images = np.random.RandomState(comm.rank).randint(0, 256, (256 if side == 128 else 64, 3, side, side)).astype("uint8")

@@ -193,8 +193,11 @@ int rgbd_conv2d_wgrad_partial_multi_bf16(const rgbd_wgrad_problem* probs, int n,
  *   backward).  Two launches: strip reduction, normalise + affine.
  */
 int64_t rgbd_adain_workspace(int B, int HW, int C);   /* floats */
+/* y_q / y_s (here and below; NULL = none): an MXFP8 copy of the bf16 tensor the call stores -- exactly rgbd_quantize_mxfp8 of
+ * it, (.., C) bytes + (.., C/32) scale bytes -- for the convolution that reads it next (conv_dtype mxfp8). */
 int rgbd_adain_fwd(const void* x, const float* scale, const float* shift, void* y,
-                   float* sums, float* mean, float* rstd, int B, int HW, int C, int ld, float eps, void* stream);
+                   float* sums, float* mean, float* rstd, int B, int HW, int C, int ld, float eps, void* y_q, void* y_s,
+                   void* stream);
 /* dy (B,HW,C) bf16 -> dx bf16, dscale/dshift fp32 rows `ld` apart like scale (overwritten).
  * sums: workspace of rgbd_adain_workspace(B,HW,C) floats, as above.
  * lrelu_slope > 0: x is the output of the leaky ReLU feeding this AdaIN (net.py:150-153: conv -> bias -> lrelu -> style)
@@ -202,7 +205,7 @@ int rgbd_adain_fwd(const void* x, const float* scale, const float* shift, void* 
  *   then accumulates sum_{b,p} dx (the gradient of the L.Bias in front of the activation). */
 int rgbd_adain_bwd(const void* x, const void* dy, const float* scale, const float* mean, const float* rstd,
                    void* dx, float* dscale, float* dshift, float* sums, int B, int HW, int C, int ld,
-                   float lrelu_slope, float* bias_grad, void* stream);
+                   float lrelu_slope, float* bias_grad, void* dx_q, void* dx_s, void* stream);
 
 /* ------------------------------------------------------------------ small fused elementwise / 1x1 kernels (HBM-bound)
  * rgbd_lrelu_bwd: dz = dy * (y > 0 ? 1 : slope) on channels [0, act_channels) of (M,C) bf16 tensors, pass-through on
@@ -227,7 +230,7 @@ int rgbd_axpy_rows_bf16(const void* a, const void* x, const float* s, void* out,
  * The two are adjoint (same mask), which closes the pair under differentiation (R1 double backward).
  */
 int rgbd_unpool2_lrelu_bwd(const void* dp, const void* y, void* dz, int B, int H, int W, int C, float slope,
-                           float* bias_grad, float* bias_grad2, const float* row_scale, void* stream);
+                           float* bias_grad, float* bias_grad2, const float* row_scale, void* dz_q, void* dz_s, void* stream);
 int rgbd_pool2_masked(const void* x, const void* y, void* out, int B, int H, int W, int C, float slope, void* stream);
 
 /* 1x1 convolutions between NCHW fp32 image planes (KP = 3 or 4 channels) and NHWC bf16 features (C channels):
@@ -417,7 +420,7 @@ int rgbd_conv3x3_actgrad_bf16(const void* x, const void* wp, const void* residua
 int rgbd_conv2d_fprop_stats_bf16(const void* x, const void* wp, const float* bias, void* y, int64_t* stats, int B, int Hin,
                                  int Win, int Cin, int Cout, int upsample, int lrelu_channels, float slope, void* stream);
 int rgbd_adain_apply_fixed(const void* x, const float* scale, const float* shift, void* y, const int64_t* stats, float* mean,
-                           float* rstd, int B, int HW, int C, int ld, float eps, void* stream);
+                           float* rstd, int B, int HW, int C, int ld, float eps, void* y_q, void* y_s, void* stream);
 
 /* ------------------------------------------------------------------ MXFP8 convolutions (BASELINE configuration 5)
  * The 3x3 convolutions of the 256x256 networks -- the blocks the reference keeps commented out at net.py:181-183,192-194,

@@ -43,12 +43,12 @@ PROTOTYPES = {
     "rgbd_conv2d_wgrad_multi_plan": ([_P, c_int, c_int], c_int),
     "rgbd_conv2d_wgrad_partial_multi_bf16": ([_P, c_int, _P], c_int),
     "rgbd_adain_workspace": ([c_int, c_int, c_int], c_int64),
-    "rgbd_adain_fwd": ([_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P], c_int),
-    "rgbd_adain_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P], c_int),
+    "rgbd_adain_fwd": ([_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P], c_int),
+    "rgbd_adain_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P], c_int),
     "rgbd_lrelu_bwd": ([_P, _P, _P, c_int64, c_int, c_int, c_float, _P, _P, c_int64, _P], c_int),
     "rgbd_colsum_bf16": ([_P, _P, c_int64, c_int, c_int, _P, c_int64, _P], c_int),
     "rgbd_axpy_rows_bf16": ([_P, _P, _P, _P, c_int64, c_int64, _P], c_int),
-    "rgbd_unpool2_lrelu_bwd": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P], c_int),
+    "rgbd_unpool2_lrelu_bwd": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, _P], c_int),
     "rgbd_pool2_masked": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P], c_int),
     "rgbd_from_planes": ([_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, c_float, _P], c_int),
     "rgbd_to_planes": ([_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P], c_int),
@@ -89,7 +89,7 @@ PROTOTYPES = {
     "rgbd_conv3x3_actgrad_supported": ([c_int, c_int, c_int, c_int, c_int], c_int),
     "rgbd_conv3x3_actgrad_bf16": ([_P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P], c_int),
     "rgbd_conv2d_fprop_stats_bf16": ([_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P], c_int),
-    "rgbd_adain_apply_fixed": ([_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P], c_int),
+    "rgbd_adain_apply_fixed": ([_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P], c_int),
     "rgbd_conv3x3_ex": ([_P, _P], c_int),
     "rgbd_quantize_mxfp8": ([_P, _P, _P, c_int64, c_int, _P], c_int),
     "rgbd_pack_weights_mxfp8_multi": ([_P, c_int, c_int, _P], c_int),

@@ -74,6 +74,26 @@ __device__ __forceinline__ unsigned mx8_pack4(float a, float b, float c, float d
     return (unsigned)w;
 }
 
+// MXFP8 copy of 8 consecutive channels held as bf16 pairs (what a lane of the 8-lanes-per-pixel elementwise kernels stores):
+// lanes l ^ 1, l ^ 2 hold the rest of the 32-channel block; q points at this lane's 8 bytes, s at the block's scale byte
+// (written by the block's first lane).  Bit for bit rgbd_quantize_mxfp8 of the stored tensor.
+__device__ __forceinline__ void mx8_emit8(const u32x4& v, unsigned char* q, unsigned char* s, bool block_leader) {
+    float f[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { f[2 * k] = bf16_lo(v[k]); f[2 * k + 1] = bf16_hi(v[k]); }
+    float amax = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) amax = fmaxf(amax, fabsf(f[k]));
+    amax = fmaxf(amax, __shfl_xor(amax, 1));
+    amax = fmaxf(amax, __shfl_xor(amax, 2));
+    const unsigned sc = mx8_scale_of(amax);
+    const float inv = mx8_inv_scale(sc);
+    const u32x2 out = {mx8_pack4(f[0] * inv, f[1] * inv, f[2] * inv, f[3] * inv),
+                       mx8_pack4(f[4] * inv, f[5] * inv, f[6] * inv, f[7] * inv)};
+    *reinterpret_cast<u32x2*>(q) = out;
+    if (block_leader) *s = (unsigned char)sc;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

@@ -206,7 +206,8 @@ __global__ __launch_bounds__(256) void adain_apply_kernel(const unsigned short* 
                                                           float* __restrict__ mean, float* __restrict__ rstd,
                                                           unsigned short* __restrict__ y, int HW, int C,
                                                           int ld, float inv_hw, float eps, int rows_per_block,
-                                                          int nstrips) {
+                                                          int nstrips, unsigned char* __restrict__ yq,
+                                                          unsigned char* __restrict__ ys) {
     const int cg = blockIdx.y, b = blockIdx.z;
     const int chunk = threadIdx.x & 7, lane_p = threadIdx.x >> 3;
     const int c0 = cg * 64 + chunk * 8;
@@ -265,6 +266,10 @@ __global__ __launch_bounds__(256) void adain_apply_kernel(const unsigned short* 
                     out[k] = pack_bf16x2(v0, v1);
                 }
                 *reinterpret_cast<u32x4*>(y + (base + r) * C + c0) = out;
+                if (yq) {               // conv_dtype mxfp8: the next convolution's operand leaves with the bf16 tensor
+                    const long e = (base + r) * C + c0;
+                    mx8_emit8(out, yq + e, ys + (e >> 5), (chunk & 3) == 0);
+                }
             }
         }
     }
@@ -288,7 +293,9 @@ __global__ __launch_bounds__(NT) void adain_bwd_apply_kernel(const unsigned shor
                                                               unsigned short* __restrict__ dx,
                                                               float* __restrict__ dscale, float* __restrict__ dshift,
                                                               int HW, int C, float inv_hw, int ld, int rows_per_block,
-                                                              float slope, float* __restrict__ bias_grad, int nstrips) {
+                                                              float slope, float* __restrict__ bias_grad, int nstrips,
+                                                              unsigned char* __restrict__ dxq,
+                                                              unsigned char* __restrict__ dxs) {
     const int cg = blockIdx.y, b = blockIdx.z;
     const int chunk = threadIdx.x & 7, lane_p = threadIdx.x >> 3;
     const int c0 = cg * 64 + chunk * 8;
@@ -353,6 +360,10 @@ __global__ __launch_bounds__(NT) void adain_bwd_apply_kernel(const unsigned shor
                     }
                 }
                 *reinterpret_cast<u32x4*>(dx + (base + r) * C + c0) = out;
+                if (dxq) {
+                    const long e = (base + r) * C + c0;
+                    mx8_emit8(out, dxq + e, dxs + (e >> 5), (chunk & 3) == 0);
+                }
             }
         }
     }
@@ -465,7 +476,9 @@ __global__ __launch_bounds__(NT) void unpool_lrelu_bwd_kernel(const unsigned sho
                                                                int C, float slope, int rows_per_block,
                                                                float* __restrict__ bias_grad,
                                                                float* __restrict__ bias_grad2,
-                                                               const float* __restrict__ row_scale) {
+                                                               const float* __restrict__ row_scale,
+                                                               unsigned char* __restrict__ dzq,
+                                                               unsigned char* __restrict__ dzs) {
     // same lane layout and 4-pass load batching as lrelu_bwd_colsum_kernel; dp is read at the pooled position
     const int cg = blockIdx.y;
     const int chunk = threadIdx.x & 7, lane_p = threadIdx.x >> 3;
@@ -505,6 +518,10 @@ __global__ __launch_bounds__(NT) void unpool_lrelu_bwd_kernel(const unsigned sho
                     s[2 * k + 1] += wr * bf16_hi(out[k]);
                 }
                 *reinterpret_cast<u32x4*>(dz + r * C + c0) = out;
+                if (dzq) {
+                    const long e = r * C + c0;
+                    mx8_emit8(out, dzq + e, dzs + (e >> 5), (chunk & 3) == 0);
+                }
             }
         }
     }
@@ -1231,7 +1248,9 @@ extern "C" int64_t rgbd_adain_workspace(int B, int HW, int C) {
 }
 
 extern "C" int rgbd_adain_fwd(const void* x, const float* scale, const float* shift, void* y, float* sums,
-                              float* mean, float* rstd, int B, int HW, int C, int ld, float eps, void* stream) {
+                              float* mean, float* rstd, int B, int HW, int C, int ld, float eps, void* y_q, void* y_s,
+                              void* stream) {
+    RGBD_REQUIRE(!y_q || (y_s && C % 32 == 0), "rgbd_adain_fwd: the MXFP8 copy needs its scale buffer");
     RGBD_REQUIRE(x && scale && shift && y && sums && mean && rstd, "rgbd_adain_fwd: null pointer");
     RGBD_REQUIRE(ld >= C, "rgbd_adain_fwd: ld must be >= C");
     RGBD_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 64 == 0, "rgbd_adain_fwd: C must be a multiple of 64 (C=%d)", C);
@@ -1242,13 +1261,16 @@ extern "C" int rgbd_adain_fwd(const void* x, const float* scale, const float* sh
     const int rows = HW <= 4096 ? 256 : 512;
     dim3 agrid(ceil_div(HW, rows), C / 64, B);
     adain_apply_kernel<<<agrid, 256, 0, st>>>((const unsigned short*)x, scale, shift, sums, mean, rstd,
-                                              (unsigned short*)y, HW, C, ld, 1.f / (float)HW, eps, rows, (int)grid.x);
+                                              (unsigned short*)y, HW, C, ld, 1.f / (float)HW, eps, rows, (int)grid.x,
+                                              (unsigned char*)y_q, (unsigned char*)y_s);
     RGBD_CHECK_LAUNCH("adain_apply_kernel");
     return 0;
 }
 
 extern "C" int rgbd_adain_apply_fixed(const void* x, const float* scale, const float* shift, void* y, const int64_t* stats,
-                                      float* mean, float* rstd, int B, int HW, int C, int ld, float eps, void* stream) {
+                                      float* mean, float* rstd, int B, int HW, int C, int ld, float eps, void* y_q, void* y_s,
+                                      void* stream) {
+    RGBD_REQUIRE(!y_q || y_s, "rgbd_adain_apply_fixed: the MXFP8 copy needs its scale buffer");
     RGBD_REQUIRE(x && scale && shift && y && stats && mean && rstd, "rgbd_adain_apply_fixed: null pointer");
     RGBD_REQUIRE(ld >= C, "rgbd_adain_apply_fixed: ld must be >= C");
     RGBD_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 64 == 0, "rgbd_adain_apply_fixed: C must be a multiple of 64 (C=%d)", C);
@@ -1256,14 +1278,18 @@ extern "C" int rgbd_adain_apply_fixed(const void* x, const float* scale, const f
     dim3 agrid(ceil_div(HW, rows), C / 64, B);
     adain_apply_kernel<<<agrid, 256, 0, (hipStream_t)stream>>>((const unsigned short*)x, scale, shift, (const float*)stats,
                                                                 mean, rstd, (unsigned short*)y, HW, C, ld, 1.f / (float)HW,
-                                                                eps, rows, -32);
+                                                                eps, rows, -32, (unsigned char*)y_q, (unsigned char*)y_s);
     RGBD_CHECK_LAUNCH("adain_apply_kernel");
     return 0;
 }
 
 extern "C" int rgbd_adain_bwd(const void* x, const void* dy, const float* scale, const float* mean,
                               const float* rstd, void* dx, float* dscale, float* dshift, float* sums, int B,
-                              int HW, int C, int ld, float lrelu_slope, float* bias_grad, void* stream) {
+                              int HW, int C, int ld, float lrelu_slope, float* bias_grad, void* dx_q, void* dx_s,
+                              void* stream) {
+    RGBD_REQUIRE(!dx_q || dx_s, "rgbd_adain_bwd: the MXFP8 copy needs its scale buffer");
+    unsigned char* const qq = (unsigned char*)dx_q;
+    unsigned char* const qs = (unsigned char*)dx_s;
     RGBD_REQUIRE(x && dy && scale && mean && rstd && dx && dscale && dshift && sums, "rgbd_adain_bwd: null pointer");
     RGBD_REQUIRE(ld >= C, "rgbd_adain_bwd: ld must be >= C");
     RGBD_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 64 == 0, "rgbd_adain_bwd: C must be a multiple of 64 (C=%d)", C);
@@ -1281,15 +1307,15 @@ extern "C" int rgbd_adain_bwd(const void* x, const void* dy, const float* scale,
         adain_bwd_apply_kernel<true, 1024><<<bgrid, 1024, 0, st>>>((const unsigned short*)x, (const unsigned short*)dy, scale,
                                                                    mean, rstd, sums, (unsigned short*)dx, dscale, dshift, HW,
                                                                    C, 1.f / (float)HW, ld, big_rows, lrelu_slope, bias_grad,
-                                                                   (int)grid.x);
+                                                                   (int)grid.x, qq, qs);
     } else if (lrelu_slope > 0.f)
         adain_bwd_apply_kernel<true><<<agrid, 256, 0, st>>>((const unsigned short*)x, (const unsigned short*)dy, scale,
                                                             mean, rstd, sums, (unsigned short*)dx, dscale, dshift, HW, C,
-                                                            1.f / (float)HW, ld, rows, lrelu_slope, bias_grad, (int)grid.x);
+                                                            1.f / (float)HW, ld, rows, lrelu_slope, bias_grad, (int)grid.x, qq, qs);
     else
         adain_bwd_apply_kernel<false><<<agrid, 256, 0, st>>>((const unsigned short*)x, (const unsigned short*)dy, scale,
                                                              mean, rstd, sums, (unsigned short*)dx, dscale, dshift, HW,
-                                                             C, 1.f / (float)HW, ld, rows, 0.f, nullptr, (int)grid.x);
+                                                             C, 1.f / (float)HW, ld, rows, 0.f, nullptr, (int)grid.x, qq, qs);
     RGBD_CHECK_LAUNCH("adain_bwd_apply_kernel");
     return 0;
 }
@@ -1373,7 +1399,9 @@ extern "C" int rgbd_axpy_rows_bf16(const void* a, const void* x, const float* s,
 }
 
 extern "C" int rgbd_unpool2_lrelu_bwd(const void* dp, const void* y, void* dz, int B, int H, int W, int C, float slope,
-                                      float* bias_grad, float* bias_grad2, const float* row_scale, void* stream) {
+                                      float* bias_grad, float* bias_grad2, const float* row_scale, void* dz_q, void* dz_s,
+                                      void* stream) {
+    RGBD_REQUIRE(!dz_q || dz_s, "rgbd_unpool2_lrelu_bwd: the MXFP8 copy needs its scale buffer");
     RGBD_REQUIRE(dp && dz, "rgbd_unpool2_lrelu_bwd: null pointer");
     RGBD_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C % 64 == 0,
                  "rgbd_unpool2_lrelu_bwd: H, W must be even and C a multiple of 64 (H=%d W=%d C=%d)", H, W, C);
@@ -1383,11 +1411,11 @@ extern "C" int rgbd_unpool2_lrelu_bwd(const void* dp, const void* y, void* dz, i
     if (cp.threads == 1024)
         unpool_lrelu_bwd_kernel<1024><<<grid, 1024, 0, (hipStream_t)stream>>>(
             (const unsigned short*)dp, (const unsigned short*)y, (unsigned short*)dz, M, H, W, C, slope, cp.rows, bias_grad,
-            bias_grad ? bias_grad2 : nullptr, row_scale);
+            bias_grad ? bias_grad2 : nullptr, row_scale, (unsigned char*)dz_q, (unsigned char*)dz_s);
     else
         unpool_lrelu_bwd_kernel<256><<<grid, 256, 0, (hipStream_t)stream>>>(
             (const unsigned short*)dp, (const unsigned short*)y, (unsigned short*)dz, M, H, W, C, slope, cp.rows, bias_grad,
-            bias_grad ? bias_grad2 : nullptr, row_scale);
+            bias_grad ? bias_grad2 : nullptr, row_scale, (unsigned char*)dz_q, (unsigned char*)dz_s);
     RGBD_CHECK_LAUNCH("unpool_lrelu_bwd_kernel");
     return 0;
 }

@@ -527,11 +527,12 @@ class _ConvLreluAdaIN(torch.autograd.Function):
             # images >= 16x16: the instance-norm statistics come out of the conv's epilogue (order-independent integer
             # sums), the AdaIN is its apply pass alone
             y, stats = kernels.conv2d_fprop_stats(x, wf, bias.contiguous(), upsample=ups, lrelu_channels=w.shape[0])
-            out, mean, rstd = kernels.adain_apply_fixed(y, stats, ss, col_off=group.offsets[j])
+            out, mean, rstd = kernels.adain_apply_fixed(y, stats, ss, col_off=group.offsets[j], emit_mx8=_MXFP8)
         else:
             y = kernels.conv2d_fprop(x, wf, layer.K, layer.K, layer.pad, bias=bias.contiguous(), upsample=ups,
                                      lrelu_channels=w.shape[0])
-            out, mean, rstd = kernels.adain_fwd(y, ss, col_off=group.offsets[j])
+            # (conv_dtype mxfp8: the AdaIN output is the next synthesis conv's input; its fp8 copy leaves the apply pass)
+            out, mean, rstd = kernels.adain_fwd(y, ss, col_off=group.offsets[j], emit_mx8=_MXFP8 and y.shape[1] >= 8)
         ctx.layer, ctx.ups, ctx.group, ctx.j = layer, ups, group, j
         ctx.save_for_backward(x, w, y, bias, ss, mean, rstd)
         return out
@@ -546,7 +547,8 @@ class _ConvLreluAdaIN(torch.autograd.Function):
         want_b = ctx.needs_input_grad[2] and not _skip_grad_of(bias)
         fast_b = want_b and _direct_grad(bias)
         dz, _, _ = kernels.adain_bwd(y, dout.contiguous(), ss, mean, rstd, fused=True, col_off=g.offsets[ctx.j],
-                                     out=g.dss, lrelu_slope=0.2, bias_grad=bias.grad if fast_b else None)
+                                     out=g.dss, lrelu_slope=0.2, bias_grad=bias.grad if fast_b else None,
+                                     emit_mx8=_MXFP8 and ctx.needs_input_grad[0] and y.shape[1] >= 16)   # dz feeds the dgrad
         dx = dw = db = dss = None
         if want_b and not fast_b:
             db = kernels.colsum(dz)
@@ -701,8 +703,9 @@ class _UnpoolLreluGrad(torch.autograd.Function):
         if inject_bias is not None:
             return kernels.unpool2_lrelu_bwd(dp.contiguous(), y if use_mask else None, shape,
                                              bias_grad=inject_bias.grad, row_scale=_INJECT,
-                                             bias_grad2=inject_bias2.grad if inject_bias2 is not None else None)
-        return kernels.unpool2_lrelu_bwd(dp.contiguous(), y if use_mask else None, shape)
+                                             bias_grad2=inject_bias2.grad if inject_bias2 is not None else None,
+                                             emit_mx8=_MXFP8 and shape[1] >= 16)
+        return kernels.unpool2_lrelu_bwd(dp.contiguous(), y if use_mask else None, shape, emit_mx8=_MXFP8 and shape[1] >= 16)
 
     @staticmethod
     def backward(ctx, ddz):
@@ -775,7 +778,8 @@ class _ConvBiasAct(torch.autograd.Function):
                 tb = tie.bias
             if fast_b:
                 dz = kernels.unpool2_lrelu_bwd(dy, y if ctx.act else None, tuple(y.shape), bias_grad=bias.grad,
-                                               bias_grad2=tb.grad if tb is not None else None)
+                                               bias_grad2=tb.grad if tb is not None else None,
+                                               emit_mx8=_MXFP8 and y.shape[1] >= 16)     # dz1 feeds both input gradients
                 if tb is not None:
                     tie.done = True
             else:

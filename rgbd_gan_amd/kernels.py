@@ -218,6 +218,8 @@ def pack_weights_multi(table):
 # ---- MXFP8 operands (BASELINE configuration 5; format: csrc/mxfp8.hip, include/rgbd_gan_hip.h)
 U8 = torch.uint8
 MX8_MIN_TILES = 64          # (tests set 0 to reach the fp8 kernel with oracle-sized problems)
+MX8_EMIT = True             # producers write the MXFP8 copy of their output (False: every conv input goes through the stand-alone
+                            # quantiser -- the A/B of bench.py --mx8-standalone-quantiser)
 
 
 class Mx8Image:
@@ -280,8 +282,23 @@ class Conv3x3Desc(ctypes.Structure):
 def mx8_emittable(B, Hout, Wout, Cout):
     """Can a 3x3 launch with this output write an MXFP8 copy of it that a following convolution will use?  (the pipelined
     kernel's epilogue: output images multiples of 16x16; the consumer's reduction channels = Cout a multiple of 128)"""
-    return Hout % 16 == 0 and Wout % 16 == 0 and Cout % 128 == 0 and Hout >= 16 and \
+    return MX8_EMIT and Hout % 16 == 0 and Wout % 16 == 0 and Cout % 128 == 0 and Hout >= 16 and \
         B * (Hout // 16) * (Wout // 16) * (Cout // 128) >= MX8_MIN_TILES
+
+
+def _mx8_side(t, want):
+    """(q, s) buffers for the MXFP8 copy of the bf16 tensor `t` a kernel is about to write, or (None, None); the caller hangs
+    them on the tensor with _mx8_attach once the launch has been issued."""
+    C = t.shape[-1]
+    if not want or not MX8_EMIT or C % 128:
+        return None, None
+    return (torch.empty(t.shape, dtype=U8, device=t.device),
+            torch.empty(tuple(t.shape[:-1]) + (C // 32,), dtype=U8, device=t.device))
+
+
+def _mx8_attach(t, q, s):
+    if q is not None:
+        t._mx8 = (q, s, t._version)
 
 
 def _conv3x3_ex(x, mx_x, wp, mx_w, y, B, H, W, Cin, Cout, bias=None, residual=None, act_y=None, colsum=None, row_scale=None,
@@ -555,7 +572,7 @@ def conv2d_fprop_stats(x, wp, bias, upsample=False, lrelu_channels=0, slope=0.2)
     return y, stats
 
 
-def adain_apply_fixed(x, stats, scale, shift=None, eps=1e-5, col_off=0):
+def adain_apply_fixed(x, stats, scale, shift=None, eps=1e-5, col_off=0, emit_mx8=False):
     """adain_fwd with the statistics given (conv2d_fprop_stats) instead of reduced from x -> y, mean, rstd."""
     _chk(x, BF16, "x"); _chk(scale, F32, "scale"); _chk(shift, F32, "shift")
     B, H, W, C = x.shape
@@ -571,10 +588,13 @@ def adain_apply_fixed(x, stats, scale, shift=None, eps=1e-5, col_off=0):
     y = torch.empty_like(x)
     mean = torch.empty(B, C, dtype=F32, device=x.device)
     rstd = torch.empty(B, C, dtype=F32, device=x.device)
+    yq, ysc = _mx8_side(y, emit_mx8)
     rc = _lib.load().rgbd_adain_apply_fixed(_ptr(x), _off(scale, col_off) if fused else _ptr(scale),
                                             _off(scale, col_off + C) if fused else _ptr(shift), _ptr(y), _ptr(stats),
-                                            _ptr(mean), _ptr(rstd), B, H * W, C, ld if fused else C, float(eps), _stream())
+                                            _ptr(mean), _ptr(rstd), B, H * W, C, ld if fused else C, float(eps), _ptr(yq),
+                                            _ptr(ysc), _stream())
     _lib.check(rc, "rgbd_adain_apply_fixed")
+    _mx8_attach(y, yq, ysc)
     return y, mean, rstd
 
 
@@ -737,16 +757,18 @@ def axpy_rows(a, x, s):
     return out
 
 
-def unpool2_lrelu_bwd(dp, y, shape, slope=0.2, bias_grad=None, row_scale=None, bias_grad2=None):
+def unpool2_lrelu_bwd(dp, y, shape, slope=0.2, bias_grad=None, row_scale=None, bias_grad2=None, emit_mx8=False):
     """dz (B,H,W,C) = 0.25 * upsample2(dp) * lrelu'(y); y may be None (plain average-pool backward).  bias_grad /
     row_scale as in lrelu_bwd; bias_grad2 receives the same sums as bias_grad (shortcut bias of a residual block)."""
     _chk(dp, BF16, "dp"); _chk(y, BF16, "y"); _chk(bias_grad, F32, "bias_grad"); _chk(row_scale, F32, "row_scale")
     _chk(bias_grad2, F32, "bias_grad2")
     B, H, W, C = shape
     dz = torch.empty(B, H, W, C, dtype=BF16, device=dp.device)
+    dzq, dzs = _mx8_side(dz, emit_mx8)
     rc = _lib.load().rgbd_unpool2_lrelu_bwd(_ptr(dp), _ptr(y), _ptr(dz), B, H, W, C, float(slope), _ptr(bias_grad),
-                                            _ptr(bias_grad2), _ptr(row_scale), _stream())
+                                            _ptr(bias_grad2), _ptr(row_scale), _ptr(dzq), _ptr(dzs), _stream())
     _lib.check(rc, "rgbd_unpool2_lrelu_bwd")
+    _mx8_attach(dz, dzq, dzs)
     return dz
 
 
@@ -851,7 +873,7 @@ def _off(t, nfloats):
     return ctypes.c_void_p(t.data_ptr() + 4 * nfloats)
 
 
-def adain_fwd(x, scale, shift=None, eps=1e-5, col_off=0):
+def adain_fwd(x, scale, shift=None, eps=1e-5, col_off=0, emit_mx8=False):
     """x (B,H,W,C) bf16; scale, shift (B,C) fp32 -- or shift None and scale = (B,Wtot) fp32 whose columns
     [col_off, col_off + 2C) hold [scale | shift] (the fused style-affine output, possibly of several style blocks)
     -> y, mean, rstd."""
@@ -868,14 +890,17 @@ def adain_fwd(x, scale, shift=None, eps=1e-5, col_off=0):
     sums = _adain_workspace(B, H * W, C, x.device)
     mean = torch.empty(B, C, dtype=F32, device=x.device)
     rstd = torch.empty(B, C, dtype=F32, device=x.device)
+    yq, ysc = _mx8_side(y, emit_mx8)
     rc = _lib.load().rgbd_adain_fwd(_ptr(x), _off(scale, col_off) if fused else _ptr(scale),
                                     _off(scale, col_off + C) if fused else _ptr(shift), _ptr(y), _ptr(sums),
-                                    _ptr(mean), _ptr(rstd), B, H * W, C, ld if fused else C, float(eps), _stream())
+                                    _ptr(mean), _ptr(rstd), B, H * W, C, ld if fused else C, float(eps), _ptr(yq), _ptr(ysc),
+                                    _stream())
     _lib.check(rc, "rgbd_adain_fwd")
+    _mx8_attach(y, yq, ysc)
     return y, mean, rstd
 
 
-def adain_bwd(x, dy, scale, mean, rstd, fused=False, col_off=0, out=None, lrelu_slope=0.0, bias_grad=None):
+def adain_bwd(x, dy, scale, mean, rstd, fused=False, col_off=0, out=None, lrelu_slope=0.0, bias_grad=None, emit_mx8=False):
     """-> dx, dscale, dshift; with fused (scale = (B,Wtot), window [col_off, col_off + 2C) = [scale | shift]):
     dx, d[scale | shift] written into the same window of `out` (B,Wtot) (allocated when None), None.
     lrelu_slope > 0: x is a leaky-ReLU output and dx also carries that activation's gradient; bias_grad (C) fp32 then
@@ -895,10 +920,12 @@ def adain_bwd(x, dy, scale, mean, rstd, fused=False, col_off=0, out=None, lrelu_
         ds = torch.empty(B, C, dtype=F32, device=x.device)
         dsh = torch.empty(B, C, dtype=F32, device=x.device)
         sc, dscale, dshift, ld = _ptr(scale), _ptr(ds), _ptr(dsh), C
+    dxq, dxs = _mx8_side(dx, emit_mx8)
     rc = _lib.load().rgbd_adain_bwd(_ptr(x), _ptr(dy), sc, _ptr(mean), _ptr(rstd), _ptr(dx), dscale,
                                     dshift, _ptr(sums), B, H * W, C, ld, float(lrelu_slope), _ptr(bias_grad),
-                                    _stream())
+                                    _ptr(dxq), _ptr(dxs), _stream())
     _lib.check(rc, "rgbd_adain_bwd")
+    _mx8_attach(dx, dxq, dxs)
     return (dx, dss, None) if fused else (dx, ds, dsh)
 
 

@@ -299,3 +299,39 @@ def test_epilogue_emits_the_quantisers_bytes(operands):
     with kernels.launch_profile() as prof:
         kernels.conv2d_fprop(dz, _image(torch.randn(128, Cout, 3, 3, generator=g), 0.02), 3, 3, 1)
     assert "quantize_mx8_kernel" not in prof.summary()
+
+
+def test_elementwise_producers_emit_the_quantisers_bytes():
+    """The AdaIN apply pass (both forms), the AdaIN backward and the fused unpool + activation-gradient pass write the MXFP8
+    copy of their bf16 output for the convolution behind them: bit for bit rgbd_quantize_mxfp8 of what they stored, and the
+    bf16 tensors are those of the plain calls."""
+    from rgbd_gan_amd import kernels
+    g = torch.Generator().manual_seed(23)
+    B, H, C = 2, 32, 256
+
+    def check(t):
+        q, s, _ = t._mx8
+        rq, rs = kernels.quantize_mx8(t.clone())
+        assert torch.equal(q, rq) and torch.equal(s, rs)
+    x = _bf16(torch.randn(B, H, H, C, generator=g) * 3).to(dev())
+    ss = torch.randn(B, 2 * C, generator=g).to(dev())
+    y, mean, rstd = kernels.adain_fwd(x, ss, emit_mx8=True)
+    y0, _, _ = kernels.adain_fwd(x, ss)
+    assert torch.equal(y, y0)
+    check(y)
+    dy = _bf16(torch.randn(B, H, H, C, generator=g) * 1e-3).to(dev())
+    for slope in (0.0, 0.2):
+        dx, _, _ = kernels.adain_bwd(x, dy, ss, mean, rstd, fused=True, lrelu_slope=slope, emit_mx8=True)
+        dx0, _, _ = kernels.adain_bwd(x, dy, ss, mean, rstd, fused=True, lrelu_slope=slope)
+        assert torch.equal(dx, dx0)
+        check(dx)
+    dp = _bf16(torch.randn(B, H // 2, H // 2, C, generator=g) * 1e-2).to(dev())
+    bg = torch.zeros(C, device=dev())
+    dz = kernels.unpool2_lrelu_bwd(dp, x, (B, H, H, C), bias_grad=bg, emit_mx8=True)
+    assert torch.equal(dz, kernels.unpool2_lrelu_bwd(dp, x, (B, H, H, C)))
+    check(dz)
+    wf, _ = kernels.pack_weights(torch.randn(C, C, 3, 3, generator=g).to(dev()), 0.02)
+    yc, stats = kernels.conv2d_fprop_stats(x, wf, torch.zeros(C, device=dev()), lrelu_channels=C)
+    out, _, _ = kernels.adain_apply_fixed(yc, stats, ss, emit_mx8=True)
+    assert torch.equal(out, kernels.adain_apply_fixed(yc, stats, ss)[0])
+    check(out)
