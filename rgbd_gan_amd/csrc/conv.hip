@@ -824,6 +824,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
     const int nc = a.Cin / (128 / EB);
     const int g_total = (pt_end - pt_begin) * nc;               // (tile, channel slice) pairs of this workgroup
     if (g_total <= 0) return;
+    if (KO == 8) {                      // KO 8: workgroups start 0 / 1 / 2 / 3 x ~0.5 us apart (are the epilogues' store bursts
+        for (unsigned k_ = 0; k_ < (blockIdx.x & 3u); ++k_) __builtin_amdgcn_s_sleep(16);   // the stall? timing experiment)
+    }
 
     // ---- DMA roles: weight waves 0,1,6,7, halo waves 2,3,4,5 (wave w and w+4 share a SIMD: one of each per SIMD)
     const bool w_role = ((wid >> 1) & 1) == (wid >> 2);
@@ -1151,6 +1154,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
     };
 
     auto epilogue = [&](int pt) {       // bias -> residual -> leaky ReLU (or a given mask) -> bf16 NHWC, then clear the accumulators
+        if (KO == 9 && a.B >= 0) {      // KO 9: no epilogue (the main loop alone; the opaque condition keeps the MFMAs live)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < TPX; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            return;
+        }
         int b, y0, x0;
         tile_origin(pt, b, y0, x0);
         const int co = n0 + wave_co + 16 * q;            // this lane's 16 consecutive output channels
@@ -1242,7 +1252,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
             for (int h = 0; h < 2; ++h) {
                 u32x4 out = {pack_bf16x2(v[8 * h + 0], v[8 * h + 1]), pack_bf16x2(v[8 * h + 2], v[8 * h + 3]),
                              pack_bf16x2(v[8 * h + 4], v[8 * h + 5]), pack_bf16x2(v[8 * h + 6], v[8 * h + 7])};
-                *reinterpret_cast<u32x4*>(a.y + o + 8 * h) = out;
+                if (KO != 7 || a.B < 0) *reinterpret_cast<u32x4*>(a.y + o + 8 * h) = out;   // KO 7: the epilogue without its stores
                 stored[h] = out;
                 if (MASKED) {           // column sums of what was stored (the rounded values, as the separate pass took them)
 #pragma unroll
@@ -2393,6 +2403,18 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
                 sp_attr_done[vi] = true;
             }
 #ifdef RGBD_DEBUG_BUILD
+            if (g_conv_variant >= 17 && g_conv_variant <= 19 && vi == 2) {     // epilogue / start-skew experiments
+                const int ko = g_conv_variant - 10;
+                const void* fk = ko == 7 ? (const void*)&conv3x3_sp_kernel<128, false, 7>
+                               : ko == 8 ? (const void*)&conv3x3_sp_kernel<128, false, 8>
+                                         : (const void*)&conv3x3_sp_kernel<128, false, 9>;
+                RGBD_REQUIRE(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, lds_sp) == hipSuccess, "lds");
+                if (ko == 7) conv3x3_sp_kernel<128, false, 7><<<(unsigned)grid, 512, lds_sp, st>>>(a);
+                else if (ko == 8) conv3x3_sp_kernel<128, false, 8><<<(unsigned)grid, 512, lds_sp, st>>>(a);
+                else conv3x3_sp_kernel<128, false, 9><<<(unsigned)grid, 512, lds_sp, st>>>(a);
+                RGBD_CHECK_LAUNCH("conv3x3_sp_kernel<KO>");
+                return 0;
+            }
             if (g_conv_variant >= 11 && g_conv_variant <= 16 && vi == 2) {     // timing knock-outs (scripts/ab_conv.py)
                 const int ko = g_conv_variant - 10;
                 const void* fk = ko == 1 ? (const void*)&conv3x3_sp_kernel<128, false, 1>
