@@ -121,7 +121,8 @@ int rgbd_pack_weights_multi(const rgbd_pack_desc* descs_device, int n, int total
  *         upsampled image (rescale.py:4-5 fused into the gather), so Hout = 2*Hin + 2*pad - KH + 1.
  *   wp  : packed weights [KH*KW][Cout][Cin] bf16 (rgbd_pack_weights).
  *   bias: (Cout) fp32 or NULL.  residual: (B,Hout,Wout,Cout) bf16 added after the bias, or NULL.
- *         lrelu_channels (multiple of 16): output channels [0, lrelu_channels) then get leaky-ReLU(slope) (0 = none), i.e.
+ *         lrelu_channels (multiple of 16): output channels [0, lrelu_channels) then get leaky-ReLU(slope) (0 = none;
+ *         0 <= slope <= 1 required, the reference uses 0.2 everywhere), i.e.
  *         y = lrelu(conv + bias + residual) as in net.py:413-416.
  *   y   : (B, Hout, Wout, Cout) bf16 NHWC.
  *   y_pooled: NULL, or (B, Hout/2, Wout/2, Cout) bf16 that receives the 2x2 average of y (of the bf16 values stored to

@@ -49,8 +49,13 @@ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
     bf16_t h = (bf16_t)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
     return __builtin_bit_cast(unsigned short, h);
 }
+typedef bf16_t bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
-    return (unsigned int)f32_to_bf16_bits(lo) | ((unsigned int)f32_to_bf16_bits(hi) << 16);
+    // ONE v_cvt_pk_bf16_f32 for the pair (two scalar conversions + shift + or took four VALU slots: a conv epilogue
+    // packs 32 pairs per lane while the matrix pipes wait)
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ float bf16_lo(unsigned int w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }

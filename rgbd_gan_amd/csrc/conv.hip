@@ -609,11 +609,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_patch_kernel(ConvArgs a) {
             const int yy = y0 + wave_py + j, xx = x0 + r16;
             const long o = (((long)b * a.Hout + yy) * a.Wout + xx) * a.Cout + co;
             float v[16];
+            if (a.bias) {               // (uniform: input-gradient launches have no bias and skip 16 VALU slots per row)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_lds + wave_co + 16 * q + 4 * i);
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_lds + wave_co + 16 * q + 4 * i);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[4 * i + r] = acc[i][j][r] + bq[r];
+                    for (int r = 0; r < 4; ++r) v[4 * i + r] = acc[i][j][r] + bq[r];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[4 * i + r] = acc[i][j][r];
             }
             if (a.resid) {
 #pragma unroll
@@ -1213,11 +1220,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
             const int yy = y0 + wave_py + j, xx = x0 + r16;
             const long o = (((long)b * a.Hout + yy) * a.Wout + xx) * a.Cout + co;
             float v[16];
+            if (a.bias) {               // (uniform: input-gradient launches have no bias and skip 16 VALU slots per row)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_lds + wave_co + 16 * q + 4 * i);
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_lds + wave_co + 16 * q + 4 * i);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[4 * i + r] = acc[i][j][r] + bq[r];
+                    for (int r = 0; r < 4; ++r) v[4 * i + r] = acc[i][j][r] + bq[r];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[4 * i + r] = acc[i][j][r];
             }
             if (a.resid) {
 #pragma unroll
@@ -1230,9 +1244,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
                     }
                 }
             }
-            if (act) {
-#pragma unroll
-                for (int k2 = 0; k2 < 16; ++k2) v[k2] = v[k2] > 0.f ? v[k2] : v[k2] * a.slope;
+            if (act) {                  // 0 <= slope <= 1 (checked by the launcher): max(v, slope v) IS the leaky ReLU, bit for
+#pragma unroll                  // bit incl. -0 and NaN, in two VALU slots per value instead of three
+                for (int k2 = 0; k2 < 16; ++k2) {       // (asm: fmaxf() puts a canonicalising v_max in front of every max)
+                    const float sv = v[k2] * a.slope;
+                    asm("v_max_f32 %0, %1, %2" : "=v"(v[k2]) : "v"(v[k2]), "v"(sv));
+                }
             }
             u32x4 mk[MASKED ? 2 : 1];
             if (MASKED) {
@@ -2251,6 +2268,8 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
                  "rgbd_conv2d_fprop_bf16: Cin and Cout must be multiples of 64 (Cin=%d Cout=%d)", Cin, Cout);
     RGBD_REQUIRE(lrelu_channels % 16 == 0 && lrelu_channels >= 0 && lrelu_channels <= Cout,
                  "rgbd_conv2d_fprop_bf16: lrelu_channels must be a multiple of 16 in [0, Cout]");
+    RGBD_REQUIRE(lrelu_channels == 0 || (slope >= 0.f && slope <= 1.f),
+                 "rgbd_conv2d_fprop_bf16: the leaky-ReLU slope must lie in [0, 1] (the epilogue computes max(v, slope v))");
     ConvArgs a;
     a.x = (const unsigned short*)x; a.wp = (const unsigned short*)wp; a.bias = bias;
     a.resid = (const unsigned short*)residual; a.y = (unsigned short*)y;
