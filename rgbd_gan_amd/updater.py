@@ -762,9 +762,9 @@ class RGBDUpdater:
             #     main:  prep -> gen_a ----------> gen_b -> [all-reduce map, gen] -> join -> optimizers
             #     side:       \-> dis ------\-> dfw ------------------------------/
             # Same step time as ONE graph with the fork inside it (rounds 1-2); per-phase graphs let the data-parallel job
-            # start the generator's all-reduces at the end of gen_b instead of after the join.  (Measure overlap with
-            # events, scripts/phase_timeline.py: rocprofv3's kernel trace serialises the queues of a process, its
-            # timelines show the second stream idle until the first one's last kernels.)
+            # start the generator's all-reduces at the end of gen_b instead of after the join.  (Overlap: events,
+            # scripts/phase_timeline.py, or a kernel trace through scripts/trace_overlap.py -- a small kernel's duration
+            # in a trace is its stretched length under the other queue's chip-filling kernel, not its cost.)
             if self._side_stream is None:
                 self._side_stream = torch.cuda.Stream(device=self.device)
             main, side = torch.cuda.current_stream(), self._side_stream

@@ -10,16 +10,24 @@ Differences from RGBDUpdater that the reference has and this keeps (SURVEY.md se
     lookup at :202 tests a misspelt key, so the YAML value can never be used), focal gamma from the YAML (:170).
 
 The class reuses RGBDUpdater's plumbing (optimizer / iterator accessors, batch conversion, finite checks, pinned
-upload rings, HIP-graph capture / replay of device-only phases) and replaces the step: two phases, the generator step
-and the discriminator step, each captured once per configuration.  Everything data dependent in them (the number of
-frustum samples inside the grid) stays on the device.
+upload rings, HIP-graph capture / replay of device-only phases) and replaces the step.  The reference's discriminator step
+is a sum of two terms that share nothing but D's weights: softplus(-D(x_real)) + R1 on the reals, and softplus(D(G'(z)))
+on fakes of the UPDATED generator.  Only the second has to wait for the generator step, so the step is four captured phases:
+
+    main:  prep -> gen (G fwd, frozen D, 3-D loss, G bwd, G update) ---------> join -> dis_fake (G' fwd, D fwd/bwd, D update)
+    side:       +-> dis_real (D(x_real), R1 double backward, weight gradients) -/
+
+(`concurrent_phases=False` / RGBD_CONCURRENT_PHASES=0: the same four phases back to back on one stream -- identical
+arithmetic, same accumulation order.)  ~960 mostly small launches per step: the second stream fills the gaps between the
+first one's kernels.  Everything data dependent (the number of frustum samples inside the grid) stays on the device.
 """
+import os
 import numpy as np
 import torch
 import torch.nn.functional as F
 
 from . import functional as Fn
-from .common.loss_functions import LossFuncRotate, loss_func_dcgan_dis, loss_func_dcgan_gen, loss_l2
+from .common.loss_functions import LossFuncRotate, loss_func_dcgan_gen, loss_l2
 from .updater import RGBDUpdater, get_camera_matries
 
 IMG_SIZE = 64
@@ -61,6 +69,9 @@ class DeepVoxelsUpdater(RGBDUpdater):
         self.use_graphs = bool(kwargs.pop("use_graphs", True)) and not (comm is not None and comm.active)
         self.graph_warmup = int(kwargs.pop("graph_warmup", 2))
         self.graph_fallback = bool(kwargs.pop("graph_fallback", False))
+        env = os.environ.get("RGBD_CONCURRENT_PHASES")
+        self.concurrent_phases = bool(kwargs.pop("concurrent_phases", env is None or env not in ("", "0")))
+        self._side_stream = None
         self._graphs, self._eager_calls, self._stagers = {}, {}, {}
 
     def get_stage(self):
@@ -69,19 +80,46 @@ class DeepVoxelsUpdater(RGBDUpdater):
     def get_z_fake_data(self, batch_size):
         return self.gen.mapping.make_hidden(batch_size)
 
-    # ---- the two halves of a step (device work only: capturable)
+    # ---- the phases of a step (device work only: capturable)
+    def _dv_prep_phase(self, st):
+        """What both streams depend on: cleared gradient buffers, the down-sized real batch, D's bf16 weight images (packed
+        here so that neither stream does it behind the other's back; G's are rebuilt inside its own phases -- it is
+        updated in the middle of the step)."""
+        for link in (self.gen, self.gen.mapping, self.dis):
+            link.cleargrads()
+        with torch.no_grad():
+            st["x_real"] = downsize_real(st["x_real_full"], IMG_SIZE).contiguous()
+        group = getattr(self.dis, "pack_group", None)
+        if group is not None:
+            group.layers[0].packed()
+
+    def _dv_dis_real_phase(self, st):
+        """The half of the discriminator step that does not involve G (:229-246): adversarial term on the reals + R1."""
+        obs = self.observation
+        x_real = st["x_real"].detach().requires_grad_(True)
+        y_real = self.dis(x_real, stage=FIXED_STAGE)
+        adv = torch.sum(F.softplus(-y_real)) / y_real.numel()          # loss_func_dcgan_dis' second term
+        st["adv_real"] = adv.detach()
+        total = adv
+        if not self.dis.sn and self.lambda_gp > 0:
+            with Fn.input_grads_only():
+                g, = torch.autograd.grad([y_real.sum()], [x_real], create_graph=True)
+            gp = self.lambda_gp * loss_l2(torch.sqrt(torch.sum(g ** 2, dim=(1, 2, 3))), 0.0)
+            obs["dis/loss_gp"] = gp.detach()
+            total = adv + gp
+        wgrads = []
+        with Fn.deferred_wgrads(wgrads):
+            total.backward()
+        Fn.run_deferred_wgrads(wgrads)
+
     def _dv_gen_phase(self, st):
         cfg, obs = self.config, self.observation
         half = st["B"] // 2
-        for link in (self.gen, self.gen.mapping, self.dis):
-            link.cleargrads()
         if st["z"] is not None:
             z, z2 = st["z"][0], st["z"][1]
         else:                                                      # one latent per view PAIR (:146-148)
             z = self.get_z_fake_data(half).repeat(2, 1, 1, 1, 1)
             z2 = self.get_z_fake_data(half).repeat(2, 1, 1, 1, 1)
-        with torch.no_grad():
-            st["x_real"] = downsize_real(st["x_real_full"], IMG_SIZE).contiguous()
         x_fake = self.gen(z, FIXED_STAGE, st["cams"], z2=z2, theta=st["theta9"])
         with self.dis.frozen():                                    # no D weight gradients in the generator step
             y_fake = self.dis(x_fake[:, :3].contiguous(), stage=FIXED_STAGE)
@@ -104,30 +142,22 @@ class DeepVoxelsUpdater(RGBDUpdater):
         for name in ("map", "gen"):
             self.get_optimizer(name).update()
 
-    def _dv_dis_phase(self, st):
+    def _dv_dis_fake_phase(self, st):
+        """... and the half that does: fresh fakes from the UPDATED generator (:221-228), their term of the loss, D's update
+        (its gradient buffer already holds the reals' half)."""
         obs, B = self.observation, st["B"]
-        self.dis.cleargrads()
         if st["z"] is not None:
             z, z2 = st["z"][2], st["z"][3]
         else:
             z, z2 = self.get_z_fake_data(B), self.get_z_fake_data(B)
-        with torch.no_grad():                                      # fresh fakes from the UPDATED generator (:221-228)
+        with torch.no_grad():
             x_fake = self.gen(z, FIXED_STAGE, st["cams"], z2=z2, theta=st["theta9"])
         y_fake = self.dis(x_fake[:, :3].contiguous(), stage=FIXED_STAGE)
-        x_real = st["x_real"].detach().requires_grad_(True)
-        y_real = self.dis(x_real, stage=FIXED_STAGE)
-        adv = loss_func_dcgan_dis(y_fake, y_real)
-        obs["dis/loss_adv"] = adv.detach()
-        total = adv
-        if not self.dis.sn and self.lambda_gp > 0:
-            with Fn.input_grads_only():
-                g, = torch.autograd.grad([y_real.sum()], [x_real], create_graph=True)
-            gp = self.lambda_gp * loss_l2(torch.sqrt(torch.sum(g ** 2, dim=(1, 2, 3))), 0.0)
-            obs["dis/loss_gp"] = gp.detach()
-            total = adv + gp
+        adv = torch.sum(F.softplus(y_fake)) / y_fake.numel()           # loss_func_dcgan_dis' first term
+        obs["dis/loss_adv"] = adv.detach() + st["adv_real"]
         wgrads = []
         with Fn.deferred_wgrads(wgrads):
-            total.backward()
+            adv.backward()
         Fn.run_deferred_wgrads(wgrads)
         self.get_optimizer("dis").update()
 
@@ -168,8 +198,19 @@ class DeepVoxelsUpdater(RGBDUpdater):
             key = (B, use_rotate, tuple(x_real_full.shape), z_fake is not None)
         st["x_real_full"] = x_real_full
 
-        self._run_phase("dv_gen", self._dv_gen_phase, st, key)
-        self._run_phase("dv_dis", self._dv_dis_phase, st, key)
+        self._run_phase("dv_prep", self._dv_prep_phase, st, key)
+        if self.concurrent_phases:
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=self.device)
+            main, side = torch.cuda.current_stream(), self._side_stream
+            side.wait_stream(main)
+            self._run_phase("dv_dis_real", self._dv_dis_real_phase, st, key, stream=side)
+            self._run_phase("dv_gen", self._dv_gen_phase, st, key)
+            main.wait_stream(side)
+        else:
+            self._run_phase("dv_dis_real", self._dv_dis_real_phase, st, key)
+            self._run_phase("dv_gen", self._dv_gen_phase, st, key)
+        self._run_phase("dv_dis_fake", self._dv_dis_fake_phase, st, key)
         if key is not None:
             Fn.bump_weight_epoch()      # replays change the weights behind Python's back: invalidate packed caches
 

@@ -172,3 +172,48 @@ def test_deepvoxels_training_step_matches_oracle():
     agree = float(((w1 - w0).sign() == (wr - w0).sign()).float().mean())
     assert agree > 0.85, agree
     assert opt["map"].t == opt["gen"].t == opt["dis"].t == 1
+
+
+def test_deepvoxels_two_stream_step_equals_one_stream_step():
+    """The four phases of a step (prep, D on the reals || generator step, D on the fresh fakes) on two streams, eager and
+    replayed from graphs, against the same phases back to back on one stream: same losses and gradient norms.  (Not bit
+    for bit: the frustum-resampling backward accumulates with fp32 atomics, so one arrangement does not repeat ITSELF to
+    the last bit either.  Learning rates are 0: every call starts from the same weights, all four are comparable.)"""
+    from rgbd_gan_amd.net import Discriminator
+    from rgbd_gan_amd.optimizer import FlatAdam
+    from rgbd_gan_amd.updater import CameraParamPrior
+    from rgbd_gan_amd.updater_deepvoxels import DeepVoxelsUpdater
+    from rgbd_gan_amd.utils.yaml_utils import Config
+    B = 4
+    z, z2, thetas = _inputs(B, seed=5)
+    g = torch.Generator().manual_seed(6)
+    zd, zd2 = torch.randn(B, CH, generator=g), torch.randn(B, CH, generator=g)
+    x_real = torch.from_numpy(np.random.RandomState(7).randint(0, 256, (B, 3, 128, 128)).astype("float32") / 127.5 - 1)
+    cfg = Config(dict(generator_architecture="deepvoxels", stage_interval="0,0,0,0,0,0,0,0", max_stage=11,
+                      start_rotation=0, start_occlusion_aware=0, lambda_depth=10, depth_min=0.6, focal_loss_gamma=2.0,
+                      x_rotate=0.3054, y_rotate=3.1415, z_rotate=0, x_translate=0, y_translate=0, z_translate=0,
+                      uniform_distribution=True, bigan=False))
+    runs = {}
+    for concurrent in (False, True):
+        _, _, gen = _generator(seed=3)
+        dis = Discriminator(CH, res=True)
+        dis.load_state_dict(nets.init_discriminator(CH, seed=8))
+        opt = {"map": FlatAdam(gen.mapping.store, 0.0), "gen": FlatAdam(gen.store, 0.0), "dis": FlatAdam(dis.store, 0.0)}
+        upd = DeepVoxelsUpdater(models=[gen, dis], config=cfg, optimizer=opt, iterator=None, lambda_gp=1.0,
+                                smoothing=0.999, total_gpu=1, prior=CameraParamPrior(cfg), concurrent_phases=concurrent)
+        upd.iteration = 10
+        rows = []
+        for it in range(4):                      # two eager steps, the capture, one replay
+            upd.update_core(batch=x_real, z_fake=(z, z2, zd, zd2), thetas=thetas)
+            torch.cuda.synchronize()
+            row = {k: float(v) for k, v in upd.observation.items() if k.startswith(("gen/", "dis/"))}
+            row.update({f"norm_{k}": float(o.grad_norm) for k, o in opt.items()})
+            rows.append(row)
+        assert len(upd._graphs) == 4 and opt["dis"].t == 4, (list(upd._graphs), opt["dis"].t)
+        runs[concurrent] = rows
+    for it, (a, b) in enumerate(zip(runs[False], runs[True])):
+        assert set(a) == set(b) and {"dis/loss_adv", "dis/loss_gp", "gen/loss_adv", "gen/loss_rotate"} <= set(a)
+        tol = 2e-3
+        for k in a:
+            assert np.isfinite(a[k]) and abs(a[k] - b[k]) <= tol * max(1.0, abs(a[k])), (it, k, a[k], b[k])
+            assert abs(a[k] - runs[False][0][k]) <= tol * max(1.0, abs(a[k])), (it, k)      # replay == capture == eager
