@@ -120,6 +120,8 @@ MX_CASES = [
     (2, 32, 32, 256, 128, False, True, 128, True, True),        # D block main conv: residual, lrelu, pooled second output
     (2, 16, 16, 256, 128, True, True, 128, False, False),       # folded upsample 16 -> 32
     (1, 32, 32, 128, 64, True, False, 0, False, False),         # folded upsample 32 -> 64, narrow
+    (1, 64, 64, 512, 512, False, True, 512, False, False),      # configuration 5's widest layer at its own size (four slices)
+    (1, 128, 128, 256, 256, False, True, 256, True, False),     # ... and its 128^2 block conv with the residual (one image)
 ]
 
 
