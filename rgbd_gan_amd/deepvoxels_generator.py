@@ -368,6 +368,12 @@ class Generator(_Link):
         self.style_generator = StyleGenerator(ch, GRID_FEATS, 256, device, store=self.store, prefix="style_generator/")
         self.mapping = MappingNetwork3D(ch, device, seed)        # not a registered child in the reference (:271)
         self.train = True
+        if torch.device(device).type == "cuda":
+            # all conv weights of the generator (folded 3-D / stride-2 / padded layers and the plain ones): persistent
+            # folded + packed images, rebuilt together and only after THIS network's optimizer step
+            vg = self.voxel_gen
+            self.pack_group = Fn.DerivedPackGroup([l for l in vg.c0 + vg.c1 if l is not None]
+                                                  + list(self.style_generator.layers.values()))
 
     def make_hidden(self, batch_size):
         """:273-283."""

@@ -19,7 +19,10 @@ import torch.nn.functional as F
 
 from . import kernels
 
-_WEIGHT_EPOCH = 0          # bumped whenever master weights change (optimizer step, checkpoint load)
+_WEIGHT_EPOCH = 0          # bumped whenever master weights change (optimizer step, checkpoint load) ...
+_STORE_EPOCH = {}          # ... of which the optimizer steps name the flat buffer they changed (by storage address): a layer whose
+                           # master lives in another buffer keeps its packed images (the DeepVoxels step updates G in the middle
+                           # and D at the end: without this G's 18 folded + 16 packed weights were rebuilt twice per step)
 _SKIP_WGRAD = False        # set while only input gradients are wanted (R1's inner grad)
 _FROZEN_PTRS = frozenset()  # parameters (by storage address) whose gradients the current backward must not produce
 _INJECT = None             # per-sample seeds (B,) fp32 of the adversarial loss while the R1 double backward runs
@@ -44,9 +47,19 @@ def conv_dtype():
     return "mxfp8" if _MXFP8 else "bf16"
 
 
-def bump_weight_epoch():
+def bump_weight_epoch(flat=None):
+    """Master weights changed: everywhere (flat=None), or in the one flat parameter buffer `flat`."""
     global _WEIGHT_EPOCH
-    _WEIGHT_EPOCH += 1
+    if flat is None:
+        _WEIGHT_EPOCH += 1
+    else:
+        key = flat.untyped_storage().data_ptr()
+        _STORE_EPOCH[key] = _STORE_EPOCH.get(key, 0) + 1
+
+
+def _epoch_of(w):
+    """The (global, own buffer) epoch pair of a master weight tensor."""
+    return _WEIGHT_EPOCH, _STORE_EPOCH.get(w.untyped_storage().data_ptr(), 0)
 
 
 @contextlib.contextmanager
@@ -117,8 +130,15 @@ class ConvLayer:
     group = None              # PackGroup: all convolutions of a network repacked by one launch
     _mxf = _mxd = None        # kernels.Mx8Image twins of _wf / _wd while conv_dtype is "mxfp8" (None: not eligible)
 
+    def _now(self):
+        m = getattr(self, "master", None)
+        w = m if m is not None else getattr(self, "_epoch_src", None)
+        if w is None:
+            w = self.__dict__.get("weight")          # (a derived layer without a master: any store's step invalidates it)
+        return _epoch_of(w) if w is not None else (_WEIGHT_EPOCH, sum(_STORE_EPOCH.values()))
+
     def packed(self):
-        if self._epoch != _WEIGHT_EPOCH:
+        if self._epoch != self._now():
             if self.group is not None:
                 self.group.repack()
             else:
@@ -130,7 +150,7 @@ class ConvLayer:
                         f, d = kernels.pack_weights_mx8(w, self.inv_c)
                         self._mxf = kernels.Mx8Image(self._wf, *f) if f is not None else None
                         self._mxd = kernels.Mx8Image(self._wd, *d) if d is not None else None
-                self._epoch = _WEIGHT_EPOCH
+                self._epoch = self._now()
         if _MXFP8:
             return self._mxf or self._wf, self._mxd or self._wd
         return self._wf, self._wd
@@ -181,7 +201,48 @@ class PackGroup:
                 if self.mx_table:
                     kernels.pack_weights_mx8_multi(self.mx_table)
         for l in self.layers:
-            l._epoch = _WEIGHT_EPOCH
+            l._epoch = l._now()
+
+
+class DerivedPackGroup(PackGroup):
+    """PackGroup for a network whose conv weights are (partly) DerivedConvLayers: every derived layer with a master gets a
+    PERSISTENT folded fp32 buffer (rgbd_fold_weight_f32 writes into it), the packed bf16 images are persistent too, and one
+    rgbd_pack_weights_multi launch packs all layers from (folded buffer | master).  Persistent because a captured phase that
+    finds the images valid must be able to read, on every replay, what ANOTHER captured phase rebuilt (the DeepVoxels step:
+    the discriminator's half rebuilds G's images after G's update, the next generator step reads them)."""
+
+    def __init__(self, layers):
+        self.layers = [l for l in layers if l is not None]
+        entries = []
+        for l in self.layers:
+            if isinstance(l, DerivedConvLayer):
+                if l.master is None or l.fold is None:
+                    raise ValueError("DerivedPackGroup: derived layers need (master, fold)")
+                mode, cop, cip = l.fold
+                m = l.master
+                shape = (cop, 3 * cip, 3, 3) if mode == 0 else (cop, 16 * cip, 1, 1) if mode == 1 else (cop, cip, l.K, l.K)
+                l._fold_buf = torch.empty(shape, dtype=torch.float32, device=m.device)
+                w = l._fold_buf
+            else:
+                w = l.weight.detach()
+            co, ci, kh, kw = w.shape
+            l._wf = torch.empty(kh * kw, co, ci, dtype=torch.bfloat16, device=w.device)
+            l._wd = torch.empty(kh * kw, ci, co, dtype=torch.bfloat16, device=w.device)
+            l.group = self
+            entries.append((w, l.inv_c, l._wf, l._wd))
+        self.table = kernels.build_pack_table(entries)
+        self.mx_table = ()          # (the networks of this kind run bf16 convs)
+
+    def repack(self):
+        with torch.no_grad():
+            for l in self.layers:
+                if isinstance(l, DerivedConvLayer):
+                    mode, cop, cip = l.fold
+                    m = l.master.detach()
+                    kernels.fold_weight(m, mode, m.shape[0], m.shape[1], m.shape[-1], cop, cip, out=l._fold_buf)
+            kernels.pack_weights_multi(self.table)
+        for l in self.layers:
+            l._epoch = l._now()
 
 
 class DerivedConvLayer(ConvLayer):
@@ -207,10 +268,17 @@ class DerivedConvLayer(ConvLayer):
         # one derivation per weight epoch and autograd context: the conv node and packed() ask for it in the same forward
         # pass (a tensor derived with autograd history also serves a later no-grad caller of the same epoch)
         c = getattr(self, "_derived", None)
-        if c is not None and c[0] == _WEIGHT_EPOCH and (c[1].requires_grad or not torch.is_grad_enabled()):
+        now = self._now()
+        if c is not None and c[0] == now and (c[1].requires_grad or not torch.is_grad_enabled()):
             return c[1]
-        w = self.derive()
-        self._derived = (_WEIGHT_EPOCH, w)
+        if self.group is not None:
+            # grouped: the folded weight is the group's persistent buffer (refreshed by packed()); autograd sees it as a
+            # function of the master through the fold's adjoint, without a launch of its own
+            self.packed()
+            w = _FoldView.apply(self.master, self) if torch.is_grad_enabled() else self._fold_buf
+        else:
+            w = self.derive()
+        self._derived = (now, w)
         return w
 
 
@@ -1431,6 +1499,25 @@ class _FoldWeight(torch.autograd.Function):
         if g is None:
             return None, None, None, None
         return kernels.fold_weight(g.contiguous(), *ctx.args, adjoint=True), None, None, None
+
+
+class _FoldView(torch.autograd.Function):
+    """The persistent folded buffer of a grouped DerivedConvLayer as a differentiable function of its master (no launch:
+    DerivedPackGroup.repack has already written it)."""
+
+    @staticmethod
+    def forward(ctx, W, layer):
+        mode, cop, cip = layer.fold
+        ctx.args = (mode, W.shape[0], W.shape[1], W.shape[-1], cop, cip)
+        ctx.set_materialize_grads(False)
+        return layer._fold_buf.view(layer._fold_buf.shape)     # (a fresh alias: the buffer itself is not an input)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        if g is None:
+            return None, None
+        return kernels.fold_weight(g.contiguous(), *ctx.args, adjoint=True), None
 
 
 def fold_weight(W, mode, Cop, Cip):

@@ -1269,16 +1269,17 @@ def pad_last(x, C1):
 def fold_weight(src, mode, Co, Ci, K, Cop, Cip, adjoint=False, out=None):
     """mode 0: (Co,Ci,3,3,3) -> (Cop,3*Cip,3,3); 1: (Co,Ci,4,4) -> (Cop,16*Cip,1,1); 2: (Co,Ci,K,K) -> (Cop,Cip,K,K); fp32.
     adjoint: src is the folded weight's gradient, the result the master's; with `out` (master-shaped, contiguous) the adjoint is
-    ADDED to it."""
+    ADDED to it.  Forward with `out` (folded-shaped): written there."""
     _chk(src, F32, "src"); _chk(out, F32, "out")
     folded = (Cop, 3 * Cip, 3, 3) if mode == 0 else (Cop, 16 * Cip, 1, 1) if mode == 1 else (Cop, Cip, K, K)
     master = (Co, Ci, 3, 3, 3) if mode == 0 else (Co, Ci, K, K)
     if tuple(src.shape) != (folded if adjoint else master):
         raise RuntimeError(f"fold_weight: mode {mode} expects {folded if adjoint else master}, got {tuple(src.shape)}")
-    if out is not None and (not adjoint or tuple(out.shape) != master or not out.is_contiguous()):
-        raise RuntimeError("fold_weight: `out` is the master-shaped, contiguous accumulation target of the adjoint")
+    if out is not None and (tuple(out.shape) != (master if adjoint else folded) or not out.is_contiguous()):
+        raise RuntimeError("fold_weight: `out` is the contiguous destination: master-shaped accumulation target of the "
+                           "adjoint, or the folded weight's (persistent) buffer of the forward fold")
     dst = out if out is not None else torch.empty(master if adjoint else folded, dtype=F32, device=src.device)
-    flag = 2 if out is not None else int(bool(adjoint))
+    flag = (2 if out is not None else 1) if adjoint else 0
     _lib.check(_lib.load().rgbd_fold_weight_f32(_ptr(src), _ptr(dst), mode, Co, Ci, K, Cop, Cip, flag, _stream()),
                "rgbd_fold_weight_f32")
     return dst

@@ -71,7 +71,7 @@ class FlatAdam:
         if self._needs_broadcast:                      # ChainerMN: first update() = broadcast, no step
             self.comm.broadcast(self.store.flat)
             self._needs_broadcast = False
-            functional.bump_weight_epoch()
+            functional.bump_weight_epoch(self.store.flat)
             return
         grad_scale = 1.0
         if self.comm is not None and self.comm.active:
@@ -83,7 +83,7 @@ class FlatAdam:
         kernels.adam_clip_multi(self.store.flat, self.store.grad, self.m, self.v, begins, alphas, self.beta1,
                                 self.beta2, self.eps, self.clip, grad_scale, self.step, self.workspace, self.grad_norm)
         if bump:
-            functional.bump_weight_epoch()
+            functional.bump_weight_epoch(self.store.flat)
 
     @property
     def t(self):

@@ -521,6 +521,7 @@ class RGBDUpdater:
 
     graph_fallback = False      # class defaults shared with DeepVoxelsUpdater (its own __init__)
     _capture_stream = None
+    _replayed = False           # a captured phase ran since update_core started (it changed weights behind Python's back)
     profile_ranges = False      # train_rgbd.py sets it for `nvprof` / `enable_cuda_profiling` (train_rgbd.py:100,363-364,462)
 
     @property
@@ -583,6 +584,7 @@ class RGBDUpdater:
             st.update({k: v for k, v in entry["st"].items() if k in ("x_real", "x_fake_data", "loss_dfake", "dfw")})
             self.observation.update(entry["obs"])
         entry["graph"].replay()
+        self._replayed = True
 
     def _feature_rotation_loss(self, feat, x_real, cams, occlusion):
         """updater.py:345-353 / 423-431 (`rotate_feature`): the 3-D consistency loss, L2 criterion, on the discriminator's

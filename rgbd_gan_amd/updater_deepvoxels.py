@@ -198,6 +198,7 @@ class DeepVoxelsUpdater(RGBDUpdater):
             key = (B, use_rotate, tuple(x_real_full.shape), z_fake is not None)
         st["x_real_full"] = x_real_full
 
+        self._replayed = False
         self._run_phase("dv_prep", self._dv_prep_phase, st, key)
         if self.concurrent_phases:
             if self._side_stream is None:
@@ -211,7 +212,7 @@ class DeepVoxelsUpdater(RGBDUpdater):
             self._run_phase("dv_dis_real", self._dv_dis_real_phase, st, key)
             self._run_phase("dv_gen", self._dv_gen_phase, st, key)
         self._run_phase("dv_dis_fake", self._dv_dis_fake_phase, st, key)
-        if key is not None:
+        if self._replayed:
             Fn.bump_weight_epoch()      # replays change the weights behind Python's back: invalidate packed caches
 
         obs = self.observation
