@@ -46,6 +46,19 @@ rm -rf gpurun_out/$R/mpmc_*/
 # ---- the other configurations' lines: configuration 3's per-GPU shape (batch 64 over 8 GPUs) and configuration 4
 python3 bench.py --config configs/ffhq_stylegan_occlusion.yml --batch 8 --no-cpu-baseline > profiles/$R/bench_c3_b8.json 2> gpurun_out/$R/c3.err
 python3 bench.py --config configs/deepvoxels_shapenet_car.yml --no-cpu-baseline > profiles/$R/bench_c4.json 2> gpurun_out/$R/c4.err
+RGBD_CONCURRENT_PHASES=0 python3 bench.py --config configs/deepvoxels_shapenet_car.yml --no-cpu-baseline --no-roofline > profiles/$R/bench_c4_one_stream.json 2> gpurun_out/$R/c4_1s.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/stats_c4 -o b -- python3 bench.py --config configs/deepvoxels_shapenet_car.yml --steps 40 --no-cpu-baseline --no-roofline > gpurun_out/$R/stats_c4.log 2>&1
+cp gpurun_out/$R/stats_c4/b_kernel_stats.csv profiles/$R/bench_c4_kernel_stats.csv
+rm -f gpurun_out/$R/stats_c4/b_kernel_trace.csv
+# ---- what lies under what: a kernel trace of the default command through scripts/trace_overlap.py (small kernels that the
+#      per-kernel averages show at 5-10x their stand-alone time are stretched under the other queue's chip-filling kernels)
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/$R/trace -o t -- python3 bench.py --steps 6 --warmup 10 --no-cpu-baseline --no-roofline > gpurun_out/$R/trace.log 2>&1
+T=$(find gpurun_out/$R/trace -name 't_kernel_trace.csv' | head -1)
+python3 scripts/trace_overlap.py $T 'planes_outer_kernel<4>' 'from_planes_kernel<4>' 'linear_fwd' 'adain_reduce' 'warp_loss_bwd_kernel' > profiles/$R/trace_overlap.txt 2>&1
+python3 scripts/timeline.py $T > profiles/$R/trace_timeline.txt 2>&1
+rm -f $T
+python3 scripts/time_planes.py > profiles/$R/time_planes_alone.txt 2>/dev/null
+python3 scripts/time_small_ops.py > profiles/$R/time_small_ops_alone.txt 2>/dev/null
 python3 bench.py > profiles/$R/bench_default.json 2> gpurun_out/$R/default.err
-cp profiles/$R/*.csv profiles/$R/*.json gpurun_out/$R/ 2>/dev/null
+cp profiles/$R/*.csv profiles/$R/*.json profiles/$R/*.txt gpurun_out/$R/ 2>/dev/null
 ls -la profiles/$R
