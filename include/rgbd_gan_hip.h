@@ -499,6 +499,10 @@ int rgbd_ema_update(float* dst, const float* src, int64_t n, float tau, void* st
  *   (-sigmoid(-y)/n, sigmoid(y)/n, taken at max(y, -60)); ratio (n) = seed_neg / seed_pos = -exp(-max(y, -60)). */
 int rgbd_gan_logit_heads(const float* y, int n, float* losses, float* seed_neg, float* seed_pos, float* ratio,
                          void* stream);
+/* One term of the DCGAN-style losses (loss_functions.py:15-31; updater_deepvoxels.py:170,229-232) on n logits, one launch:
+ *   loss[0] = mean_i softplus(sign y_i) * sigmoid(sign y_i)^gamma   (sign = +-1; gamma = 0: the plain term, > 0: focal),
+ *   dy[i]   = d loss / d y_i. */
+int rgbd_softplus_mean(const float* y, int n, float sign, float gamma, float* loss, float* dy, void* stream);
 /* Clear n floats with a kernel launch (a plain kernel node inside captured HIP graphs, unlike hipMemsetAsync). */
 int rgbd_zero_f32(float* p, int64_t n, void* stream);
 /* updater.py:336,360,439 (`assert not xp.isnan(loss.data)`) without a host synchronisation: scalars_host is a HOST array of n <= 8

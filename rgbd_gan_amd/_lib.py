@@ -106,6 +106,7 @@ PROTOTYPES = {
     "rgbd_depth_head_fwd": ([_P, _P, c_int, c_int, _P], c_int),
     "rgbd_depth_head_bwd": ([_P, _P, _P, _P, c_int, c_int, _P], c_int),
     "rgbd_gan_logit_heads": ([_P, c_int, _P, _P, _P, _P, _P], c_int),
+    "rgbd_softplus_mean": ([_P, c_int, c_float, c_float, _P, _P, _P], c_int),
     "rgbd_ema_update": ([_P, _P, c_int64, c_float, _P], c_int),
     "rgbd_zero_f32": ([_P, c_int64, _P], c_int),
     "rgbd_nonfinite_mask_f32": ([POINTER(c_void_p), c_int, _P, _P], c_int),

@@ -1631,6 +1631,36 @@ __global__ __launch_bounds__(256) void gan_logit_heads_kernel(const float* __res
     }
 }
 
+// loss = mean_i softplus(t_i) * sigmoid(t_i)^gamma with t = sign * y (loss_functions.py:15-31: gamma = 0 the plain
+// non-saturating terms, gamma > 0 the focal generator loss), dy_i = d loss / d y_i -- one block, tree-ordered sum
+__global__ __launch_bounds__(256) void softplus_mean_kernel(const float* __restrict__ y, int n, float sign, float gamma,
+                                                            float* __restrict__ loss, float* __restrict__ dy) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    const float inv_n = 1.0f / (float)n;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float t = sign * y[i];
+        const float sp = fmaxf(t, 0.f) + log1pf(expf(-fabsf(t)));                   // softplus(t)
+        const float e = expf(-fabsf(t));
+        const float sg = t >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);             // sigmoid(t)
+        float f = sp, df = sg;
+        if (gamma != 0.f) {
+            const float pw = powf(sg, gamma);
+            f = sp * pw;
+            df = sg * pw + gamma * sp * pw * (1.0f - sg);                           // d/dt [softplus(t) sigmoid(t)^gamma]
+        }
+        acc += f;
+        dy[i] = sign * df * inv_n;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = red[0] * inv_n;
+}
+
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ dst, const float* __restrict__ src, long n,
                                                   float tau) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -1679,6 +1709,14 @@ extern "C" int rgbd_gan_logit_heads(const float* y, int n, float* losses, float*
     RGBD_REQUIRE(y && losses && seed_neg && seed_pos && ratio && n > 0, "rgbd_gan_logit_heads: bad arguments");
     gan_logit_heads_kernel<<<1, 256, 0, (hipStream_t)stream>>>(y, n, losses, seed_neg, seed_pos, ratio);
     RGBD_CHECK_LAUNCH("gan_logit_heads_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_softplus_mean(const float* y, int n, float sign, float gamma, float* loss, float* dy, void* stream) {
+    RGBD_REQUIRE(y && loss && dy && n > 0, "rgbd_softplus_mean: bad arguments");
+    RGBD_REQUIRE((sign == 1.f || sign == -1.f) && gamma >= 0.f, "rgbd_softplus_mean: sign must be +-1, gamma >= 0");
+    softplus_mean_kernel<<<1, 256, 0, (hipStream_t)stream>>>(y, n, sign, gamma, loss, dy);
+    RGBD_CHECK_LAUNCH("softplus_mean_kernel");
     return 0;
 }
 

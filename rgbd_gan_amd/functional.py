@@ -1282,6 +1282,27 @@ class _R1Penalty(torch.autograd.Function):
         return kernels.scale_by_scalar(g, gl.reshape(1).float().contiguous(), 2.0 * ctx.coef / g.shape[0]), None
 
 
+class _SoftplusMean(torch.autograd.Function):
+    """mean softplus(sign y) * sigmoid(sign y)^gamma (loss_func_dcgan_gen / one term of loss_func_dcgan_dis,
+    loss_functions.py:15-31) with its derivative from the same launch; first order (the logits' own backward goes on from dy)."""
+
+    @staticmethod
+    def forward(ctx, y, sign, gamma):
+        loss, dy = kernels.softplus_mean(y, sign, gamma)
+        ctx.save_for_backward(dy)
+        return loss.reshape(())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gl):
+        dy, = ctx.saved_tensors
+        return kernels.scale_by_scalar(dy, gl.reshape(1).float().contiguous(), 1.0), None, None
+
+
+def softplus_mean(y, sign, gamma=0.0):
+    return _SoftplusMean.apply(y, float(sign), float(gamma or 0.0))
+
+
 def r1_penalty(grad_x, lambda_gp):
     return _R1Penalty.apply(grad_x, float(lambda_gp))
 

@@ -956,6 +956,17 @@ def gan_logit_heads(y):
     return losses, sn, sp, ratio
 
 
+def softplus_mean(y, sign, gamma=0.0):
+    """y: logits (any shape, fp32) -> (loss (1,) = mean softplus(sign y) sigmoid(sign y)^gamma, d loss / d y shaped like y)."""
+    _chk(y, F32, "y")
+    y = y.contiguous()
+    loss = torch.empty(1, dtype=F32, device=y.device)
+    dy = torch.empty_like(y)
+    rc = _lib.load().rgbd_softplus_mean(_ptr(y), y.numel(), float(sign), float(gamma), _ptr(loss), _ptr(dy), _stream())
+    _lib.check(rc, "rgbd_softplus_mean")
+    return loss, dy
+
+
 def depth_head_fwd(x):
     """x (B,4,H,W) fp32 -> [x0, x1, x2, 1 / (softplus(x3) + 1e-4)]."""
     _chk(x, F32, "x")

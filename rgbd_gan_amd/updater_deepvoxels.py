@@ -27,7 +27,8 @@ import torch
 import torch.nn.functional as F
 
 from . import functional as Fn
-from .common.loss_functions import LossFuncRotate, loss_func_dcgan_gen, loss_l2
+from . import kernels
+from .common.loss_functions import LossFuncRotate
 from .updater import RGBDUpdater, get_camera_matries
 
 IMG_SIZE = 64
@@ -98,13 +99,13 @@ class DeepVoxelsUpdater(RGBDUpdater):
         obs = self.observation
         x_real = st["x_real"].detach().requires_grad_(True)
         y_real = self.dis(x_real, stage=FIXED_STAGE)
-        adv = torch.sum(F.softplus(-y_real)) / y_real.numel()          # loss_func_dcgan_dis' second term
+        adv = Fn.softplus_mean(y_real, -1.0)                   # loss_func_dcgan_dis' second term (value + derivative: 1 launch)
         st["adv_real"] = adv.detach()
         total = adv
         if not self.dis.sn and self.lambda_gp > 0:
             with Fn.input_grads_only():
                 g, = torch.autograd.grad([y_real.sum()], [x_real], create_graph=True)
-            gp = self.lambda_gp * loss_l2(torch.sqrt(torch.sum(g ** 2, dim=(1, 2, 3))), 0.0)
+            gp = Fn.r1_penalty(g, self.lambda_gp)              # lambda_gp * loss_l2(sqrt(sum g^2), 0) (:239-241), fused
             obs["dis/loss_gp"] = gp.detach()
             total = adv + gp
         wgrads = []
@@ -121,23 +122,36 @@ class DeepVoxelsUpdater(RGBDUpdater):
             z = self.get_z_fake_data(half).repeat(2, 1, 1, 1, 1)
             z2 = self.get_z_fake_data(half).repeat(2, 1, 1, 1, 1)
         x_fake = self.gen(z, FIXED_STAGE, st["cams"], z2=z2, theta=st["theta9"])
+        # The gradient w.r.t. G's output is assembled by hand, as in RGBDUpdater._gen_backward (slicing, hinge, scaling and
+        # the loss arithmetic were ~60 torch launches of a few microseconds each): the focal adversarial term and its
+        # derivative from one launch (loss_func_dcgan_gen, :170), back through the frozen D to the RGB planes,
+        # rgbd_image_grad_init puts that on planes 0-2 and zeros on the depth plane, the warp-loss backward ADDS
+        # weight * d(loss_rotate + lambda_depth * hinge)/dx_fake (:193-203) with the hinge evaluated in the same kernels.
+        x3 = x_fake.detach()[:, :3].contiguous().requires_grad_(True)
         with self.dis.frozen():                                    # no D weight gradients in the generator step
-            y_fake = self.dis(x_fake[:, :3].contiguous(), stage=FIXED_STAGE)
-        loss = loss_func_dcgan_gen(y_fake, cfg.focal_loss_gamma)
-        obs["gen/loss_adv"] = loss.detach()
+            y_fake = self.dis(x3, stage=FIXED_STAGE)
+            adv, gy = kernels.softplus_mean(y_fake.detach(), -1.0, cfg.focal_loss_gamma or 0.0)
+            gx, = torch.autograd.grad([y_fake], [x3], [gy.reshape(y_fake.shape)])
+        obs["gen/loss_adv"] = adv.reshape(())
+        gout = kernels.image_grad_init(gx.contiguous(), None, x_fake.shape[1])
         if st["use_rotate"]:
             if cfg.background_generator:
                 raise AssertionError("background_generator is not supported")
-            rot = self.loss_func_rotate.loss_from_coefficients(x_fake[:half], x_fake[half:], st["coef"], False)
-            rot = rot + cfg.lambda_depth * torch.mean(F.relu(cfg.depth_min - x_fake[:, -1]) ** 2)
-            obs["gen/loss_rotate"] = rot.detach()
+            lf = self.loss_func_rotate
+            hinge, hmin = float(cfg.lambda_depth or 0.0), float(cfg.depth_min or 0.0)
             weight = cfg.lambda_loss_rotate if cfg.lambda_loss_rotatec else 0.3          # sic (:202)
-            loss = loss + weight * rot
+            xf = x_fake.detach()
+            rot = kernels.warp_loss_fwd(xf[:half], xf[half:], st["coef"], 0, lf.lambda_geometric, hinge_lambda=hinge,
+                                        hinge_min=hmin)
+            obs["gen/loss_rotate"] = rot.reshape(())
+            kernels.warp_loss_bwd(xf[:half], xf[half:], st["coef"], 0, lf.lambda_geometric, 0.0, 0.0, None,
+                                  hinge_lambda=hinge, hinge_min=hmin, grad_scale=float(weight),
+                                  out=(gout[:half], gout[half:]))
         # weight gradients are leaves of the backward pass: collected while it runs, issued as one batch afterwards (the
         # folded 3-D / stride-2 layers go through temporaries and the folds' adjoints into their masters' gradients)
         wgrads = []
         with Fn.deferred_wgrads(wgrads):
-            loss.backward()
+            torch.autograd.backward([x_fake], [gout])
         Fn.run_deferred_wgrads(wgrads)
         for name in ("map", "gen"):
             self.get_optimizer(name).update()
@@ -153,7 +167,7 @@ class DeepVoxelsUpdater(RGBDUpdater):
         with torch.no_grad():
             x_fake = self.gen(z, FIXED_STAGE, st["cams"], z2=z2, theta=st["theta9"])
         y_fake = self.dis(x_fake[:, :3].contiguous(), stage=FIXED_STAGE)
-        adv = torch.sum(F.softplus(y_fake)) / y_fake.numel()           # loss_func_dcgan_dis' first term
+        adv = Fn.softplus_mean(y_fake, 1.0)                            # loss_func_dcgan_dis' first term
         obs["dis/loss_adv"] = adv.detach() + st["adv_real"]
         wgrads = []
         with Fn.deferred_wgrads(wgrads):

@@ -213,7 +213,10 @@ def test_deepvoxels_two_stream_step_equals_one_stream_step():
         runs[concurrent] = rows
     for it, (a, b) in enumerate(zip(runs[False], runs[True])):
         assert set(a) == set(b) and {"dis/loss_adv", "dis/loss_gp", "gen/loss_adv", "gen/loss_rotate"} <= set(a)
-        tol = 2e-3
         for k in a:
+            # (losses: forward values; gradient norms sit behind the resampling backward's fp32 atomics, whose summation order
+            # changes from launch to launch: the mapping network's norm spreads over 0.3 % between runs of ONE arrangement,
+            # the losses repeat to the last digit printed)
+            tol = 1e-2 if k.startswith("norm_") else 1e-5
             assert np.isfinite(a[k]) and abs(a[k] - b[k]) <= tol * max(1.0, abs(a[k])), (it, k, a[k], b[k])
             assert abs(a[k] - runs[False][0][k]) <= tol * max(1.0, abs(a[k])), (it, k)      # replay == capture == eager

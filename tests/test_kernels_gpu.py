@@ -281,6 +281,29 @@ def test_gan_logit_heads_match_the_loss_functions():
     assert torch.isfinite(ratio).all()
 
 
+@pytest.mark.parametrize("sign,gamma", [(-1.0, 0.0), (1.0, 0.0), (-1.0, 2.0), (-1.0, 0.5)])
+def test_softplus_mean_matches_the_loss_functions(sign, gamma):
+    """rgbd_softplus_mean against loss_func_dcgan_gen (focal and plain) / the two terms of loss_func_dcgan_dis
+    (loss_functions.py:15-31) in torch fp32 on the CPU: value 1e-6, derivative 1e-5 relative, logits far in both tails;
+    through the autograd wrapper the derivative is scaled by the incoming gradient."""
+    from rgbd_gan_amd import functional as Fn, kernels
+    from rgbd_gan_amd.common.loss_functions import loss_func_dcgan_dis, loss_func_dcgan_gen
+    g = torch.Generator().manual_seed(37)
+    y = torch.cat([torch.randn(17, 1, generator=g) * 3, torch.tensor([[-80.0], [60.0], [0.0]])])
+    yl = y.clone().requires_grad_(True)
+    if sign < 0:
+        ref = loss_func_dcgan_gen(yl, gamma)
+    else:
+        ref = loss_func_dcgan_dis(yl, torch.zeros(1, 1)) - float(np.log(2.0))          # softplus(-0) = log 2
+    gref, = torch.autograd.grad(ref, yl)
+    loss, dy = kernels.softplus_mean(y.to(dev()), sign, gamma)
+    torch.testing.assert_close(loss.cpu().reshape(()), ref.detach(), atol=1e-6, rtol=1e-5)
+    torch.testing.assert_close(dy.cpu(), gref, atol=1e-9, rtol=2e-5)
+    yd = y.to(dev()).requires_grad_(True)
+    (3.0 * Fn.softplus_mean(yd, sign, gamma)).backward()
+    torch.testing.assert_close(yd.grad.cpu(), 3.0 * gref, atol=1e-9, rtol=2e-5)
+
+
 def test_conv_wgrad_batch_matches_single_calls():
     """Collected weight gradients (functional.deferred_wgrads): the 3x3 layers on images >= 8x16 share one partial-sum
     launch (workgroups dealt out over the layers by work), the 3x3 layers on 4x4 / 8x8 images share another, 1x1 convs get
