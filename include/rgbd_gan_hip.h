@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RGBD_ABI_VERSION 13
+#define RGBD_ABI_VERSION 14
 
 int rgbd_abi_version(void);
 const char* rgbd_last_error(void);
