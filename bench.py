@@ -346,6 +346,18 @@ def main():
                                 "frac": round(f / t / 1e12 / peak, 4),
                                 "traffic": traffic, "traffic_provenance": provenance, "launches": n,
                                 "avg_launch_us": round(t / n * 1e6, 2), "flops_per_launch_avg": f / n, "timing": timing}
+            mx = {k: v for k, v in summ.items() if "mxfp8" in k}
+            if mx and "mxfp8" not in dom:
+                # --fp8: with fprop / dgrad on the fp8 kernels the step's dominant kernel can be the bf16 weight-gradient
+                # kernel; the dominant MXFP8 kernel is priced as well, against the fp8 peak
+                d8 = max(mx, key=lambda k: mx[k][1])
+                n8, t8, f8, b8 = mx[d8]
+                tr8, pv8 = pmc_traffic(d8)
+                line["roofline_fp8"] = {"kernel": d8, "bound": "mfma", "achieved": round(f8 / t8 / 1e12, 2),
+                                        "peak": MFMA_FP8_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                        "frac": round(f8 / t8 / 1e12 / MFMA_FP8_PEAK_TFLOPS, 4), "traffic": tr8,
+                                        "traffic_provenance": pv8, "launches": n8, "avg_launch_us": round(t8 / n8 * 1e6, 2),
+                                        "flops_per_launch_avg": f8 / n8, "timing": timing}
         line["kernels"] = table
         line["kernels_note"] = "per-kernel totals over the 2 extra eager steps of the roofline leg, not per step"
     elif comm.size > 1 and not args.no_roofline:
