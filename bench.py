@@ -314,6 +314,8 @@ def main():
         # per-launch HIP-event timing of the conv kernels over extra (untimed) steps, on the launch stream
         # (eager launches: graph replays bypass the Python wrappers that record the events; one stream: with the
         # two-stream phase overlap an event pair would also time the other stream's kernels sharing the CUs)
+        # (data parallel: EVERY rank runs these two steps in this arrangement, see the elif below -- the arrangements issue
+        # their all-reduces in different orders, and a communicator matches collectives by order)
         was_graphs, was_concurrent = upd.use_graphs, getattr(upd, "concurrent_phases", False)
         upd.use_graphs, upd.concurrent_phases = False, False
         with kernels.launch_profile() as prof:
@@ -361,8 +363,13 @@ def main():
         line["kernels"] = table
         line["kernels_note"] = "per-kernel totals over the 2 extra eager steps of the roofline leg, not per step"
     elif comm.size > 1 and not args.no_roofline:
-        for _ in range(2):                      # keep ranks in lock-step with rank 0's extra steps
+        # keep the ranks in lock-step with rank 0's extra steps, in rank 0's arrangement: on one stream the all-reduces go
+        # map, gen, dis; on two streams dis, map, gen -- ranks in different arrangements would pair different buffers
+        was_graphs, was_concurrent = upd.use_graphs, getattr(upd, "concurrent_phases", False)
+        upd.use_graphs, upd.concurrent_phases = False, False
+        for _ in range(2):
             upd.update()
+        upd.use_graphs, upd.concurrent_phases = was_graphs, was_concurrent
     if comm.rank == 0 and comm.size == 1 and args.arrangements and not deepvoxels:
         # the single-stream arrangement (RGBD_CONCURRENT_PHASES=0), timed beside the default two-stream one on the same
         # box (never `value`)
