@@ -191,12 +191,13 @@ class RGBDUpdater:
         #   two streams (default): the generator phase and the discriminator-on-reals phase are independent until the
         #     optimizer phase; on two streams the bubbles of one fill with the other's kernels.  One graph, fork and
         #     join inside it.
-        #   one stream (concurrent_phases=False / RGBD_CONCURRENT_PHASES=0; always in the shared-device test arrangement):
+        #   one stream (concurrent_phases=False / RGBD_CONCURRENT_PHASES=0; the default of the shared-device test arrangement,
+        #     unless RGBD_CONCURRENT_PHASES=1 asks for two streams there too):
         #     the phases back to back; under data parallelism the body is split where G's gradients are final so that
         #     the map + gen all-reduces travel under D's half (dp_split_body).
         env = os.environ.get("RGBD_CONCURRENT_PHASES")
-        self.concurrent_phases = bool(kwargs.pop("concurrent_phases", (env is None or env not in ("", "0"))
-                                                 and not os.environ.get("RGBD_SHARE_DEVICE")))
+        default = (env not in ("", "0")) if env is not None else not os.environ.get("RGBD_SHARE_DEVICE")
+        self.concurrent_phases = bool(kwargs.pop("concurrent_phases", default))
         self.dp_split_body = bool(kwargs.pop("dp_split_body", True))
         if kwargs:
             raise TypeError(f"RGBDUpdater: unknown arguments {sorted(kwargs)}")

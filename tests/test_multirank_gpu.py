@@ -245,3 +245,20 @@ def test_bench_starts_its_own_ranks():
     line = json.loads(rows[0])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 8 and line["config"]["parallelism"] == "dp2"
     assert line["value"] > 0
+
+
+def test_bench_roofline_leg_keeps_the_ranks_collectives_paired():
+    """Two ranks on TWO streams each (the arrangement of a real multi-GPU job), with bench.py's roofline leg: rank 0 measures
+    its conv kernels in two extra eager one-stream steps.  The arrangements order their all-reduces differently (two streams:
+    dis, map, gen; one stream: map, gen, dis), and a communicator pairs collectives by order: if only rank 0 switched, its
+    2 MB all-reduce would meet rank 1's 34 MB one (gloo refuses that; RCCL would hang or corrupt) -- every rank must switch."""
+    env = dict(os.environ, RGBD_DIST_BACKEND="gloo", RGBD_SHARE_DEVICE="1", RGBD_CONCURRENT_PHASES="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "4",
+                        "--batch", "4", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rows = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(rows) == 1, r.stdout[-2000:]
+    line = json.loads(rows[0])
+    assert line["n_gpus"] == 2 and line["roofline"]["achieved"] > 0 and line["config"]["parallelism"] == "dp2"
