@@ -216,6 +216,27 @@ def test_generator_allreduce_under_the_discriminator_half_changes_nothing(tmp_pa
         _compare(got, ref, f"split body vs whole body, 2 ranks, run {rep}", SAME_STEP, exact_upd=2e-2)
 
 
+def test_two_real_ranks_on_two_streams_each(tmp_path):
+    """The arrangement of a real multi-GPU job -- every rank on two streams, D's all-reduce started on the side stream behind
+    dfw, the generator's on the main stream behind gen_b, graphs replayed, collectives outside them -- with a REAL transport
+    (two processes, gloo), against the same two ranks in the one-stream split-body arrangement: same kernels, same sums,
+    same Adam steps on both ranks."""
+    one = _two_ranks(tmp_path, "one", 10.0)
+    assert int(one["n_graphs"]) == 4
+    for rep in range(2):
+        port = _free_port()
+        _wait([_run(tmp_path / f"two{rep}_{r}.npz", "--calls", "4", "--stage", "10.0", "--concurrent",
+                    env=_rank_env(tmp_path, r, port)) for r in range(2)])
+        r0, r1 = np.load(tmp_path / f"two{rep}_0.npz"), np.load(tmp_path / f"two{rep}_1.npz")
+        assert int(r0["n_graphs"]) == 8 and int(r0["world"]) == 2
+        for k in ("map", "gen", "dis"):
+            np.testing.assert_array_equal(r0[f"{k}/grad"], r1[f"{k}/grad"])
+            np.testing.assert_array_equal(r0[f"{k}/delta"], r1[f"{k}/delta"])
+            assert int(r0[f"{k}/t"]) == 4
+        _compare(r0, one, f"2 ranks on two streams vs 2 ranks on one stream, run {rep}", TRANSPORT, exact_upd=2e-2)
+        _same_losses(r0, one)
+
+
 def test_seed_ratio_chain_at_the_logit_clamp(tmp_path):
     """D(x_fake) ~ -40: the discriminator's seed sigmoid(y)/B is ~4e-18/B and the generator's gradient is recovered
     from that backward pass through the per-sample ratio (updater.py: gan_logit_heads).  The bf16 chain must not flush:
