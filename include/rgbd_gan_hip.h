@@ -233,6 +233,9 @@ int rgbd_axpy_rows_bf16(const void* a, const void* x, const float* s, void* out,
 int rgbd_unpool2_lrelu_bwd(const void* dp, const void* y, void* dz, int B, int H, int W, int C, float slope,
                            float* bias_grad, float* bias_grad2, const float* row_scale, void* dz_q, void* dz_s, void* stream);
 int rgbd_pool2_masked(const void* x, const void* y, void* out, int B, int H, int W, int C, float slope, void* stream);
+/* 2x2 SUMS of a (B,H,W,C) bf16 tensor -> (B,H/2,W/2,C): the adjoint of the nearest-2x upsample (rescale.py:4-5) where the
+ * input-gradient kernel does not produce them in its epilogue (8x8 -> 4x4 layers). */
+int rgbd_pool2_sum_bf16(const void* x, void* out, int B, int H, int W, int C, void* stream);
 
 /* 1x1 convolutions between NCHW fp32 image planes (KP = 3 or 4 channels) and NHWC bf16 features (C channels):
  *   rgbd_from_planes: y[b,p,co] = act(wscale * sum_k w[co][k] x[b,k,p] + bias[co])   -- Discriminator.ins, net.py:449-455

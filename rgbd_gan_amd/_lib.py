@@ -50,6 +50,7 @@ PROTOTYPES = {
     "rgbd_axpy_rows_bf16": ([_P, _P, _P, _P, c_int64, c_int64, _P], c_int),
     "rgbd_unpool2_lrelu_bwd": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, _P], c_int),
     "rgbd_pool2_masked": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P], c_int),
+    "rgbd_pool2_sum_bf16": ([_P, _P, c_int, c_int, c_int, c_int, _P], c_int),
     "rgbd_from_planes": ([_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, c_float, _P], c_int),
     "rgbd_to_planes": ([_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P], c_int),
     "rgbd_planes_outer": ([_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P], c_int),

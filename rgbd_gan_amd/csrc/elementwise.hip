@@ -540,11 +540,11 @@ __global__ __launch_bounds__(NT) void unpool_lrelu_bwd_kernel(const unsigned sho
     }
 }
 
-// pool: out[b,hp,wp,c] = 0.25 * sum_{2x2} x[b,h,w,c] * (y ? lrelu'(y[b,h,w,c]) : 1)
+// pool: out[b,hp,wp,c] = scale * sum_{2x2} x[b,h,w,c] * (y ? lrelu'(y[b,h,w,c]) : 1)     (scale 0.25: average, 1: sum)
 __global__ __launch_bounds__(256) void pool2_masked_kernel(const unsigned short* __restrict__ x,
                                                            const unsigned short* __restrict__ y,
                                                            unsigned short* __restrict__ out, long nvec_out, int H, int W,
-                                                           int C, float slope) {
+                                                           int C, float slope, float scale) {
     const int cvec = C >> 3;
     const int Wp = W >> 1, Hp = H >> 1;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nvec_out; e += (long)gridDim.x * 256) {
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(256) void pool2_masked_kernel(const unsigned short*
             }
         u32x4 o;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = pack_bf16x2(acc[2 * k] * 0.25f, acc[2 * k + 1] * 0.25f);
+        for (int k = 0; k < 4; ++k) o[k] = pack_bf16x2(acc[2 * k] * scale, acc[2 * k + 1] * scale);
         *reinterpret_cast<u32x4*>(out + e * 8) = o;
     }
 }
@@ -1428,7 +1428,18 @@ extern "C" int rgbd_pool2_masked(const void* x, const void* y, void* out, int B,
     const long nvec = (long)B * (H / 2) * (W / 2) * C / 8;
     const int blocks = (int)min((long)4096, (nvec + 255) / 256);
     pool2_masked_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((const unsigned short*)x, (const unsigned short*)y,
-                                                                 (unsigned short*)out, nvec, H, W, C, slope);
+                                                                 (unsigned short*)out, nvec, H, W, C, slope, 0.25f);
+    RGBD_CHECK_LAUNCH("pool2_masked_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_pool2_sum_bf16(const void* x, void* out, int B, int H, int W, int C, void* stream) {
+    RGBD_REQUIRE(x && out, "rgbd_pool2_sum_bf16: null pointer");
+    RGBD_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C % 8 == 0, "rgbd_pool2_sum_bf16: bad shape");
+    const long nvec = (long)B * (H / 2) * (W / 2) * C / 8;
+    const int blocks = (int)min((long)4096, (nvec + 255) / 256);
+    pool2_masked_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>((const unsigned short*)x, nullptr, (unsigned short*)out, nvec,
+                                                                 H, W, C, 0.f, 1.0f);
     RGBD_CHECK_LAUNCH("pool2_masked_kernel");
     return 0;
 }

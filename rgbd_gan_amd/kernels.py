@@ -475,7 +475,9 @@ def conv2d_dgrad(dy, wd, K, pad, sum_pool2=False, residual=None):
                                                    _ptr(ws), _stream()))
     _lib.check(rc, "rgbd_conv2d_dgrad_bf16")
     if sum_pool2 and not fuse:
-        dx = dx.view(B, Ho // 2, 2, Wo // 2, 2, Cin).sum(dim=(2, 4))
+        out = torch.empty(B, Ho // 2, Wo // 2, Cin, dtype=BF16, device=dx.device)     # (a torch reduction here was the last one
+        _lib.check(lib.rgbd_pool2_sum_bf16(_ptr(dx), _ptr(out), B, Ho, Wo, Cin, _stream()), "rgbd_pool2_sum_bf16")    # on the step)
+        dx = out
     return dx
 
 
