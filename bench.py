@@ -53,6 +53,10 @@ def parse():
                          "(v_mfma_scale_f32_16x16x128_f8f6f4), weight gradients on the bf16 kernels")
     ap.add_argument("--arrangements", action="store_true",
                     help="also time the single-stream arrangement on the same box (extra key, never `value`)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="the default command also runs short lines of configurations 3 (per-GPU shape), 4 and 5 (bf16 / fp8) "
+                         "into `other_configs`; this switches them off")
+    ap.add_argument("--other-steps", type=int, default=10)
     ap.add_argument("--mx8-standalone-quantiser", action="store_true",
                     help="A/B aid for --fp8: every conv input through rgbd_quantize_mxfp8 instead of the producers' epilogues")
     return ap.parse_args()
@@ -70,20 +74,42 @@ def kernel_source_sha16():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest committed PMC passes of this same command
-    (profiles/rNN/bench_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, corrected as
-    MI355X_MICROARCH.md prescribes: 2 * FETCH_SIZE + WRITE_SIZE, KB).  Returns (bytes, provenance): bytes is None when
-    no profile holds the kernel OR the profile was taken with different kernel sources than the ones running now."""
+def workload_key(args):
+    """Name of the workload a command line runs: profiles are keyed by it (a PMC pass of one workload says nothing about
+    the layer shapes and batch of another)."""
+    cfg = os.path.basename(args.config)
+    if args.res256:
+        return "res256_fp8" if args.fp8 else "res256"
+    if cfg == "deepvoxels_shapenet_car.yml":
+        return "c4"
+    if cfg == "ffhq_stylegan_occlusion.yml" and args.batch == 8:
+        return "c3_b8"
+    if cfg == "stylegan_shapenet_car.yml" and args.batch in (None, 32) and not args.fp8:
+        return "default"
+    return None
+
+
+def pmc_traffic(kernel, workload):
+    """HBM bytes per launch of `kernel` from the newest committed PMC passes of THIS workload
+    (profiles/rNN/bench_pmc_traffic_<workload>.json, written by scripts/collect_profiles.sh: rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate passes of the same bench.py command, corrected as MI355X_MICROARCH.md prescribes:
+    2 * FETCH_SIZE + WRITE_SIZE, KB).  Returns (bytes, provenance): bytes is None when no profile of this workload holds the
+    kernel OR the profile was taken with different kernel sources than the ones running now."""
     import glob
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_pmc_traffic.json")))
+    if workload is None:
+        return None, {"profile": None, "note": "no PMC profile is kept for this command line"}
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"bench_pmc_traffic_{workload}.json")))
     if not paths:
-        return None, {"profile": None}
+        return None, {"profile": None, "workload": workload}
     path = paths[-1]
     with open(path) as fjson:
         prof = json.load(fjson)
-    prov = {"profile": os.path.relpath(path, ROOT), "profile_source_sha16": prof.get("source_sha16"),
+    prov = {"profile": os.path.relpath(path, ROOT), "workload": workload, "profile_workload": prof.get("workload"),
+            "profile_source_sha16": prof.get("source_sha16"),
             "profile_commit": prof.get("commit"), "running_source_sha16": kernel_source_sha16()}
+    if prov["profile_workload"] != workload:
+        prov["note"] = "the profile was recorded on another workload: traffic withheld"
+        return None, prov
     if prov["profile_source_sha16"] != prov["running_source_sha16"]:
         prov["note"] = "kernel sources changed since the PMC passes: traffic withheld"
         return None, prov
@@ -91,8 +117,9 @@ def pmc_traffic(kernel):
     base = kernel.split("<")[0]
     tags = kernel.split("<")[1].rstrip(">").split(",") if "<" in kernel else [""]
     width = tags[0]
-    # the launch-profile labels fold the upsampling variant into one name and tag the forms of the pipelined 3x3 kernel
-    # (template <BN, UPS, KO, EPI, MX>: "<128>" = EPI 0, "<128,actgrad>" = 1, "<128,stats>" = 2, ",mxfp8" = MX)
+    # the launch-profile labels fold the upsampling variant into one name and tag the forms of the 3x3 kernels
+    # (conv3x3_sp_kernel<BN, UPS, KO, EPI, MX, EMIT>, conv3x3_dw_kernel<BN, UPS, EPI, KO>: "<128>" = EPI 0,
+    # "<128,actgrad>" = 1, "<128,stats>" = 2, ",mxfp8" = MX)
     want_epi = "1" if "actgrad" in tags else "2" if "stats" in tags else "0"
     want_mx = "true" if "mxfp8" in tags else "false"
     tot = cnt = 0
@@ -102,9 +129,13 @@ def pmc_traffic(kernel):
         if not name.startswith(base):
             continue
         if base == "conv3x3_sp_kernel":
-            args = [a.strip() for a in name.split("<", 1)[1].rstrip(">").split(",")]
-            mx = args[4] if len(args) > 4 else "false"
-            if args[0] != width or args[2] != "0" or args[3] != want_epi or mx != want_mx:
+            targs = [a.strip() for a in name.split("<", 1)[1].rstrip(">").split(",")]
+            mx = targs[4] if len(targs) > 4 else "false"
+            if targs[0] != width or targs[2] != "0" or targs[3] != want_epi or mx != want_mx:
+                continue
+        elif base == "conv3x3_dw_kernel":
+            targs = [a.strip() for a in name.split("<", 1)[1].rstrip(">").split(",")]
+            if targs[0] != width or targs[2] != want_epi or (len(targs) > 3 and targs[3] != "0"):
                 continue
         elif not (name.startswith(base + "<" + width) or name == kernel):
             continue
@@ -195,39 +226,14 @@ def launch_ranks(n):
     print(rows[0], flush=True)
 
 
-def main():
-    args = parse()
-    world_env = os.environ.get("WORLD_SIZE")
-    if world_env is None and (args.gpus or 1) > 1:
-        return launch_ranks(args.gpus)
-    if world_env is not None and args.gpus is not None and int(world_env) != args.gpus:
-        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env}: refusing to report a mislabelled run",
-              file=sys.stderr, flush=True)
-        sys.exit(2)
-    # stdout carries exactly ONE line (the JSON): everything else that writes to file descriptor 1 -- RCCL prints its
-    # version banner there when a process group is created -- is sent to stderr
-    sys.stdout.flush()
-    json_out = os.fdopen(os.dup(1), "w")
-    os.dup2(2, 1)
+def run_workload(args, comm, device):
+    """One bench line: build the trainer of `args`' workload, W untimed + K timed steps between barriers, the roofline leg.
+    Returns the dict that becomes the JSON line (rank 0 fills the roofline keys)."""
     import numpy as np
     import torch
     from rgbd_gan_amd import kernels
-    from rgbd_gan_amd.dist import Communicator
     from rgbd_gan_amd.training import DeviceImageIterator, build_training
     from rgbd_gan_amd.utils import yaml_utils
-
-    world = int(world_env or "1")
-    args.gpus = world
-    local = 0 if (world == 1 or os.environ.get("RGBD_SHARE_DEVICE")) else int(os.environ.get("LOCAL_RANK", "0"))
-    if local >= torch.cuda.device_count():
-        print(f"bench.py: rank needs cuda:{local} but only {torch.cuda.device_count()} device(s) are visible",
-              file=sys.stderr, flush=True)
-        sys.exit(3)
-    torch.cuda.set_device(local)
-    comm = Communicator()
-    device = torch.device("cuda", local)
-    if comm.size != world:
-        raise RuntimeError(f"process group reports {comm.size} ranks, WORLD_SIZE={world}")
 
     config = yaml_utils.load(args.config)
     deepvoxels = config.generator_architecture == "deepvoxels"      # BASELINE config 4: DeepVoxelsUpdater, 64x64, B=10
@@ -333,7 +339,7 @@ def main():
             hbm = {k: v for k, v in summ.items() if k.startswith(("trilinear", "occlusion"))}
             dom = max(hbm, key=lambda k: hbm[k][1])
             n, t, f, b = hbm[dom]
-            traffic, provenance = pmc_traffic(dom)
+            traffic, provenance = pmc_traffic(dom, workload_key(args))
             line["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(b / t / 1e9, 1), "peak": HBM_PEAK_GBPS,
                                 "unit": "GB/s", "frac": round(b / t / 1e9 / HBM_PEAK_GBPS, 4), "traffic": traffic,
                                 "traffic_provenance": provenance, "launches": n, "avg_launch_us": round(t / n * 1e6, 2),
@@ -341,7 +347,7 @@ def main():
         else:
             dom = max(summ, key=lambda k: summ[k][1])
             n, t, f, b = summ[dom]
-            traffic, provenance = pmc_traffic(dom)
+            traffic, provenance = pmc_traffic(dom, workload_key(args))
             peak = MFMA_FP8_PEAK_TFLOPS if "mxfp8" in dom else MFMA_BF16_PEAK_TFLOPS
             line["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(f / t / 1e12, 2),
                                 "peak": peak, "unit": "TFLOP/s",
@@ -354,7 +360,7 @@ def main():
                 # kernel; the dominant MXFP8 kernel is priced as well, against the fp8 peak
                 d8 = max(mx, key=lambda k: mx[k][1])
                 n8, t8, f8, b8 = mx[d8]
-                tr8, pv8 = pmc_traffic(d8)
+                tr8, pv8 = pmc_traffic(d8, workload_key(args))
                 line["roofline_fp8"] = {"kernel": d8, "bound": "mfma", "achieved": round(f8 / t8 / 1e12, 2),
                                         "peak": MFMA_FP8_PEAK_TFLOPS, "unit": "TFLOP/s",
                                         "frac": round(f8 / t8 / 1e12 / MFMA_FP8_PEAK_TFLOPS, 4), "traffic": tr8,
@@ -391,8 +397,85 @@ def main():
             "img_per_s": round(B / ms2 * 1e3, 1), "steps": n2,
             "note": "same step, same kernels, generator and discriminator phases back to back instead of on two streams"}
         del upd2
+    line["_deepvoxels"] = deepvoxels
+    del gen, dis, opt, upd, it
+    torch.cuda.empty_cache()
+    return line
+
+
+# The other BASELINE configurations, run by the DEFAULT command behind its timed region (never `value`): short runs so that
+# every performance claim of DESIGN.md has a driver-visible line.  (name, command-line overrides)
+OTHER_CONFIGS = [
+    ("c3_b8", {"config": os.path.join(ROOT, "configs", "ffhq_stylegan_occlusion.yml"), "batch": 8}),
+    ("c4", {"config": os.path.join(ROOT, "configs", "deepvoxels_shapenet_car.yml")}),
+    ("c5_bf16", {"res256": True}),
+    ("c5_fp8", {"res256": True, "fp8": True}),
+]
+
+
+def main():
+    args = parse()
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and (args.gpus or 1) > 1:
+        return launch_ranks(args.gpus)
+    if world_env is not None and args.gpus is not None and int(world_env) != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env}: refusing to report a mislabelled run",
+              file=sys.stderr, flush=True)
+        sys.exit(2)
+    # stdout carries exactly ONE line (the JSON): everything else that writes to file descriptor 1 -- RCCL prints its
+    # version banner there when a process group is created -- is sent to stderr
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    import torch
+    from rgbd_gan_amd import kernels
+    from rgbd_gan_amd.dist import Communicator
+
+    world = int(world_env or "1")
+    args.gpus = world
+    local = 0 if (world == 1 or os.environ.get("RGBD_SHARE_DEVICE")) else int(os.environ.get("LOCAL_RANK", "0"))
+    if local >= torch.cuda.device_count():
+        print(f"bench.py: rank needs cuda:{local} but only {torch.cuda.device_count()} device(s) are visible",
+              file=sys.stderr, flush=True)
+        sys.exit(3)
+    torch.cuda.set_device(local)
+    comm = Communicator()
+    device = torch.device("cuda", local)
+    if comm.size != world:
+        raise RuntimeError(f"process group reports {comm.size} ranks, WORLD_SIZE={world}")
+
+    line = run_workload(args, comm, device)
+    deepvoxels = line.pop("_deepvoxels")
     if comm.rank == 0 and comm.size == 1 and not args.no_cpu_baseline and not deepvoxels:
         line["cpu_baseline"] = cpu_baseline()
+    if (comm.size == 1 and workload_key(args) == "default" and not args.no_other_configs and not args.arrangements
+            and not args.mx8_standalone_quantiser):
+        import copy
+        line["other_configs"] = {}
+        for name, over in OTHER_CONFIGS:
+            a2 = copy.copy(args)
+            for k, v in over.items():
+                setattr(a2, k, v)
+            a2.steps, a2.warmup, a2.no_cpu_baseline, a2.no_other_configs = args.other_steps, 8, True, True
+            try:
+                l2 = run_workload(a2, comm, device)
+            except Exception as e:      # a broken side line must not take the headline number with it; it says so instead
+                line["other_configs"][name] = {"error": f"{type(e).__name__}: {e}"}
+                continue
+            finally:
+                kernels.MX8_EMIT = True
+                from rgbd_gan_amd import functional as Fn
+                Fn.set_conv_dtype("bf16")
+            l2.pop("_deepvoxels")
+            keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline", "roofline_fp8",
+                    "host_enqueue_ms_per_step")
+            line["other_configs"][name] = {k: l2[k] for k in keep if k in l2}
+            line["other_configs"][name]["command"] = "python bench.py " + " ".join(
+                (f"--{k.replace('_', '-')}" if v is True else f"--{k.replace('_', '-')} {os.path.relpath(v, ROOT) if k == 'config' else v}")
+                for k, v in over.items()) + f" --steps {a2.steps} --warmup {a2.warmup}"
+        line["other_configs_note"] = ("short runs of the other BASELINE configurations by the same process, after the timed "
+                                      "region of the headline workload; each with its own ms_per_step / dtype / roofline; "
+                                      "never `value`")
     if comm.rank == 0:
         print(json.dumps(line), file=json_out, flush=True)
     comm.barrier()

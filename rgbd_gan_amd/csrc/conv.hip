@@ -1538,6 +1538,560 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
     }
 }
 
+#ifdef RGBD_DEBUG_BUILD
+// ------------------------------------------------------------------------------------------------ 3x3 dual-workgroup kernel
+// (DEBUG library only: the measured A/B of round 5, not a shipped dataflow -- see "Outcome" below.)
+// conv3x3_dw_kernel: the pipelined kernel's dataflow (halo patch per channel slice, LDS-DMA staging with source-side
+// swizzles and counted waits, fragments pipelined through registers, one barrier per K step) re-tiled so that TWO
+// independent workgroups live on every CU:
+//   * 256 threads = 4 waves, one per SIMD; a workgroup still owns 16x16 output pixels x BN output channels, every wave
+//     4 patch rows (64 pixels) x ALL BN channels: BN / 16 x 4 accumulator tiles = 128 registers for BN = 128.  With at
+//     most 256 registers per wave two workgroups share a CU's SIMDs, i.e. half of the register file holds accumulators
+//     -- the "second accumulator set" the 8-wave kernel has no room for, owned by another workgroup.
+//   * channel slices of 32 (64-byte LDS rows): 2 x 21 KiB of halo patch + 3 x BN x 64 B of weight tiles + bias =
+//     66.5 KiB per workgroup, 133 of the CU's 160 KiB for the pair.
+//   * the two workgroups of a CU share nothing and synchronise with nobody but themselves: one's epilogue, barrier waits,
+//     DMA issue and LDS latency can run under the other's MFMAs.
+//   A K step = one filter tap x 32 channels = BN / 16 x 4 v_mfma_f32_16x16x32_bf16 per wave (the same 32 MFMAs between
+//   two barriers as a wave of the 8-wave kernel at BN = 128); a fragment is ONE ds_read_b128 (lane (r16, q): row r16,
+//   16-byte chunk q = k 8q .. 8q+7).
+//   LDS images: rows of 64 bytes, four 16-byte chunks; chunk position p of row R holds source chunk p ^ f(R) with
+//     f = 2 ((r16 >> 2) & 1) for weight rows and 2 ((hx >> 2) & 1) for the halo pixel in patch column hx: the sixteen
+//     lanes that ds_read_b128 serves together (rows R0 .. R0+15 of one chunk column pair, ANY R0: a filter column shifts
+//     it) then touch sixteen different 16-byte bank groups -- four rows apart f flips, which separates the two rows of a
+//     bank class that read the same chunk (MI355X_MICROARCH.md, LDS: lane groups {0-3,12-15,20-27}, ...).
+//   DMA roles: waves 0,1 weight pieces (BN / 32 per step each), waves 2,3 halo pieces (11 per slice each, steps 0-3): a
+//     wave's memory operations retire in issue order, so an L2-hit weight piece must not queue behind an HBM halo piece.
+//   Pipeline per step t (tap (t % 3, t / 3), A tiles in four quarters, double-buffered at quarter granularity: NI / 2
+//     register slots): see the comment at the main loop.  Halo row r of filter column kw lives in register slot
+//     (kw NR + r) % NSLOT (conv3x3_sp_kernel's MX form, same proof).
+//   Sum order differs from conv3x3_sp_kernel (32-channel slices), so outputs agree with it to fp32 accumulation noise
+//   (1-2 in 10^4 bf16 outputs one ulp apart), not byte for byte; run to run the kernel is bit-reproducible.
+// Outcome (profiles/r05/ab_conv_dw*.txt, dw_census.txt): level with the 8-wave kernel on every shape of
+//   the step (within +-3 % once the measurement order is rotated; +5-7 % only on the upsampling 128 -> 64 layer), so it is
+//   not shipped.  The census shows why the premise fails: the CU's two workgroups DO run side by side (512 of 512
+//   co-resident pairs), but issue arbitration favours the older one, which finishes 20-25 % earlier and leaves the younger
+//   a tail alone on the CU; with priorities alternated per tile both end together and the launch gains 1-3 %.  In-kernel
+//   stamps: a wave spends 12-31 % of its time in the step's wait + barrier and 17-20 % (Cin = 64) in the epilogue whether or
+//   not another workgroup is there to fill the matrix pipe -- per step the pair needs ~1300 cycles where the MFMAs need 1024.
+//   BN = 128 needs 128 accumulator + 16 A + 36 B registers before addresses: the fused epilogues spill inside the main loop.
+template <int BN, bool UPS, int EPI = 0, int KO = 0>      // KO (debug library; timing only, wrong results): 1 no weight DMA, 2 no halo DMA, 3 no LDS reads, 6 all three, 9 no epilogue
+__global__ __launch_bounds__(256, 2) void conv3x3_dw_kernel(ConvArgs a) {
+    constexpr bool MASKED = EPI == 1, STATS = EPI == 2;
+    constexpr int HPW = UPS ? 10 : 18;            // halo patch width (and height)
+    constexpr int NROWS = HPW * HPW;
+    constexpr int P_PIECES = (NROWS * 64 + 1023) / 1024;     // 1-KiB DMA pieces (16 rows) per halo patch: 21 or 7
+    constexpr int P_BYTES = P_PIECES * 1024;
+    constexpr int W_BYTES = BN * 64;
+    constexpr int NI = BN / 16;                   // 16-channel A tiles per wave: 8 or 4
+    constexpr int QT = NI / 4;                    // ... per quarter of a step
+    constexpr int NH = BN / 64;                   // 64-channel halves: the epilogue's unit (a lane owns 16 consecutive channels of each)
+    constexpr int TPX = 4;                        // patch rows per wave
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+    unsigned char* const patch_lds = dsm;                       // [2][P_BYTES]
+    unsigned char* const w_lds = dsm + 2 * P_BYTES;             // [3][W_BYTES]
+    const unsigned lds0 = (unsigned)(size_t)dsm;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned bid = blockIdx.x;
+    {
+        const unsigned nwg = gridDim.x, xcd = bid & 7u, q8 = nwg >> 3, r8 = nwg & 7u;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    }
+    const int nt = bid / a.wgs_per_ntile;
+    const int slot = bid - nt * a.wgs_per_ntile;
+    const int pt_begin = (int)((long)slot * a.ptiles / a.wgs_per_ntile);
+    const int pt_end = (int)((long)(slot + 1) * a.ptiles / a.wgs_per_ntile);
+    const int tiles_x = a.Wout >> 4, tiles_per_img = tiles_x * (a.Hout >> 4);
+    const int n0 = nt * BN;
+    const int wave_py = wid * TPX;                               // first patch row of this wave
+
+    const int nc = a.Cin >> 5;
+    const int g_total = (pt_end - pt_begin) * nc;               // (tile, channel slice) pairs of this workgroup
+    if (g_total <= 0) return;
+#ifdef RGBD_DEBUG_BUILD
+    unsigned long long census_t0 = 0;
+    if (a.partial) census_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+
+    const bool w_role = wid < 2;
+    const int ridx = wid & 1;                                    // 0..1 within the role
+    constexpr int WPW = NI / 2;                                  // weight pieces per weight wave per K step (4 or 2)
+    constexpr int PPW = (P_PIECES + 1) / 2;                      // halo pieces per halo wave per slice (11 or 4)
+    constexpr int PPS = (PPW + 3) / 4;                           // ... issued per step (3 or 1), in steps 0 .. PSTEPS-1
+    constexpr int PSTEPS = (PPW + PPS - 1) / PPS;                // 4
+    constexpr int NOFF = PPW > WPW ? PPW : WPW;
+    static_assert(PPW <= 12 && PPS <= 3, "halo border masks: 5 bits x 6 pieces x 2 registers; one piece per quarter 1-3");
+    // Per-lane source offsets (see conv3x3_sp_kernel).  halo piece pi = LDS rows 16 pi .. + 15, lane l -> row 16 pi + (l >> 2),
+    // chunk position l & 3; weight piece pw = LDS rows 16 pw .. + 15 of the tile, LDS row (64 w + 16 t + m) = output channel
+    // 64 w + 16 (m >> 2) + 4 t + (m & 3): a lane's accumulators of a 64-channel half are then 16 consecutive channels
+    unsigned doff[NOFF], pm[2] = {0u, 0u};
+#pragma unroll
+    for (int i = 0; i < NOFF; ++i) {
+        unsigned wv = 0, pv = 0;
+        if (i < WPW) {
+            const int r = (ridx * WPW + i) * 16 + (lane >> 2);
+            const int wm = r & 15, wt = (r >> 4) & 3;
+            const int wperm = (r & ~63) + 16 * (wm >> 2) + 4 * wt + (wm & 3);
+            wv = (unsigned)((n0 + wperm) * a.Cin * 2 + (((lane & 3) ^ (2 * ((wm >> 2) & 1))) << 4));
+        }
+        if (i < PPW) {
+            const int pi = ridx + 2 * i < P_PIECES ? ridx + 2 * i : P_PIECES - 1;
+            const int row = pi * 16 + (lane >> 2);
+            const int hy = row / HPW, hx = row - hy * HPW;
+            pv = (unsigned)((hy * a.Win + hx) * a.Cin * 2 + (((lane & 3) ^ (2 * ((hx >> 2) & 1))) << 4));
+            const unsigned m = (hy == 0 ? 1u : 0u) | (hy == HPW - 1 ? 2u : 0u) | (hx == 0 ? 4u : 0u) |
+                               (hx == HPW - 1 ? 8u : 0u) | (row >= NROWS ? 16u : 0u);
+            pm[i / 6] |= m << (5 * (i % 6));
+        }
+        doff[i] = w_role ? wv : pv;
+    }
+    const int tap_stride = a.Cout * a.Cin * 2;
+    const unsigned x_lead = (unsigned)((a.Win + 1) * a.Cin * 2);
+    const unsigned long xp = (unsigned long)a.x - x_lead, wpp = (unsigned long)a.wp;
+    const u32x4 xrsrc = {(unsigned)xp, (unsigned)(xp >> 32) & 0xffffu, (unsigned)a.x_bytes + x_lead, 0x00020000u};
+    const u32x4 wrsrc = {(unsigned)wpp, (unsigned)(wpp >> 32) & 0xffffu, (unsigned)a.w_bytes, 0x00020000u};
+
+    auto tile_origin = [&](int pt, int& b, int& y0, int& x0) {
+        b = pt / tiles_per_img;
+        const int rem = pt - b * tiles_per_img;
+        const int ty = rem / tiles_x;
+        y0 = ty << 4;
+        x0 = (rem - ty * tiles_x) << 4;
+    };
+    auto patch_scalar = [&](int pt, int c, unsigned& soff, unsigned& border) {
+        int b, y0, x0;
+        tile_origin(pt, b, y0, x0);
+        const int sy = UPS ? y0 >> 1 : y0, sx = UPS ? x0 >> 1 : x0;
+        soff = (unsigned)((((b * a.Hin + sy) * a.Win + sx) * a.Cin) * 2 + c * 64);
+        border = (y0 == 0 ? 1u : 0u) | (y0 + 16 == a.Hout ? 2u : 0u) | (x0 == 0 ? 4u : 0u) | (x0 + 16 == a.Wout ? 8u : 0u) | 16u;
+    };
+    auto dma_patch = [&](int i, int buf, unsigned soff, unsigned border) {     // halo waves only
+        const int pi = ridx + 2 * i < P_PIECES ? ridx + 2 * i : P_PIECES - 1;
+        const bool ok = (pm[i / 6] & (border << (5 * (i % 6)))) == 0u;
+        lds_dma16(xrsrc, ok ? doff[i] : 0x80000000u, soff, lds0 + (unsigned)(buf * P_BYTES + pi * 1024));
+    };
+    auto dma_w_piece = [&](int c, int tap, int buf, int i) {                     // weight waves only
+        lds_dma16(wrsrc, doff[i], (unsigned)(tap * tap_stride + c * 64),
+                  lds0 + (unsigned)(2 * P_BYTES + buf * W_BYTES + (ridx * WPW + i) * 1024));
+    };
+
+    f32x4 acc[NI][TPX];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < TPX; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int r16 = lane & 15, q = lane >> 4;
+    const int aoff = r16 * 64 + ((q ^ (2 * ((r16 >> 2) & 1))) << 4);
+    int boff[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+        const int colx = UPS ? ((r16 + kw - 1) >> 1) + 1 : r16 + kw;
+        const int row0 = UPS ? (wave_py >> 1) : wave_py;
+        boff[kw] = (row0 * HPW + colx) * 64 + ((q ^ (2 * ((colx >> 2) & 1))) << 4);
+    }
+    constexpr int NR = UPS ? TPX / 2 + 2 : TPX + 2;     // halo rows a wave needs per filter column
+    auto rowidx = [](int j, int kh) { return UPS ? ((j + kh - 1) >> 1) + 1 : j + kh; };
+    constexpr int NSLOT = UPS ? 6 : 9;
+    static_assert((3 * NR) % NSLOT == 0, "a slice's rows must map to the same slots in every slice");
+    // A tiles are double-buffered at QUARTER granularity: quarter qi's tiles sit in slot set qi & 1 and are read from LDS
+    // while quarter qi - 1 multiplies (NI / 2 slots, not NI: the registers BN = 128 does not have)
+    constexpr int NAS = 2 * QT;
+    bf16x8 af[NAS], bm[NSLOT];
+    auto load_a = [&](int wb, int i) {                                   // tile i's fragment of weight buffer wb
+        af[i % NAS] = *reinterpret_cast<const bf16x8*>(w_lds + wb * W_BYTES + aoff + i * 16 * 64);
+    };
+    auto load_a_quarter = [&](int wb, int qi) {
+#pragma unroll
+        for (int i = qi * QT; i < (qi + 1) * QT; ++i) load_a(wb, i);
+    };
+    auto load_b = [&](int pb, int kh, int kw, int part) {               // the rows tap (kh, kw) uses and (kh - 1, kw) did not,
+        const unsigned char* pbuf = patch_lds + pb * P_BYTES;           // every third of them (part 0..2, or all: part < 0)
+        int cnt = 0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            bool used = false, prev = false;
+#pragma unroll
+            for (int j = 0; j < TPX; ++j) {
+                used = used || rowidx(j, kh) == r;
+                prev = prev || (kh > 0 && rowidx(j, kh - 1) == r);
+            }
+            if (used && !prev && (part < 0 || cnt++ % 3 == part))
+                bm[(kw * NR + r) % NSLOT] = *reinterpret_cast<const bf16x8*>(pbuf + boff[kw] + r * HPW * 64);
+        }
+    };
+    auto mfma_quarter = [&](int kh, int kw, int qi) {
+#pragma unroll
+        for (int i = qi * QT; i < (qi + 1) * QT; ++i)
+#pragma unroll
+            for (int j = 0; j < TPX; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i % NAS], bm[(kw * NR + rowidx(j, kh)) % NSLOT], acc[i][j], 0, 0, 0);
+    };
+
+    float* const bias_lds = reinterpret_cast<float*>(dsm + 2 * P_BYTES + 3 * W_BYTES);   // [BN]
+    if (tid < BN) bias_lds[tid] = a.bias ? a.bias[n0 + tid] : 0.f;
+
+    // the fused epilogues' per-lane sums do not live across the main loop: a tile's 16 values per half are reduced over the
+    // 16 pixel lanes by a transposing butterfly (lane r16 ends up with channel r16's total) and added to ONE register
+    auto transpose_reduce16 = [&](const float (&v)[16]) {
+        float w8[8], w4[4], w2[2];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const bool hi = (r16 & 8) != 0;
+            w8[k] = (hi ? v[k + 8] : v[k]) + __shfl_xor(hi ? v[k] : v[k + 8], 8);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool hi = (r16 & 4) != 0;
+            w4[k] = (hi ? w8[k + 4] : w8[k]) + __shfl_xor(hi ? w8[k] : w8[k + 4], 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const bool hi = (r16 & 2) != 0;
+            w2[k] = (hi ? w4[k + 2] : w4[k]) + __shfl_xor(hi ? w4[k] : w4[k + 2], 2);
+        }
+        const bool hi = (r16 & 1) != 0;
+        return (hi ? w2[1] : w2[0]) + __shfl_xor(hi ? w2[0] : w2[1], 1);
+    };
+    float cs_acc[NH], st1_acc[NH], st2_acc[NH];            // channel (64 hw + 16 q + r16)'s running totals
+#pragma unroll
+    for (int hw = 0; hw < NH; ++hw) { cs_acc[hw] = 0.f; st1_acc[hw] = 0.f; st2_acc[hw] = 0.f; }
+    int st_b = -1;
+    auto stats_flush = [&]() {
+#pragma unroll
+        for (int hw = 0; hw < NH; ++hw) {
+            const float v1 = st1_acc[hw], v2 = st2_acc[hw];
+            st1_acc[hw] = 0.f; st2_acc[hw] = 0.f;
+            unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.stats) +
+                                      ((long)st_b * a.Cout + n0 + 64 * hw + 16 * q + r16) * 2;
+            if (!(fabsf(v1) < 1e9f) || !(v2 < 1e9f)) {          // (conv3x3_sp_kernel: a non-finite sum must not come out finite)
+                atomicMax(reinterpret_cast<long long*>(dst) + 1, 0x7fffffffffffffffLL);
+            } else {
+                atomicAdd(dst, (unsigned long long)__double2ll_rn((double)v1 * 4294967296.0));
+                atomicAdd(dst + 1, (unsigned long long)__double2ll_rn((double)v2 * 4294967296.0));
+            }
+        }
+    };
+
+    auto epilogue = [&](int pt) {       // bias -> residual -> leaky ReLU (or a given mask) -> bf16 NHWC, then clear the accumulators
+        if (KO == 9 && a.B >= 0) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < TPX; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            return;
+        }
+        int b, y0, x0;
+        tile_origin(pt, b, y0, x0);
+        const float cw = MASKED && a.colsum && a.row_scale ? a.row_scale[b] : 1.f;
+        const float cw2 = MASKED && a.y2 ? a.row_scale2[b] : 0.f;
+        if (STATS && b != st_b) {
+            if (st_b >= 0) stats_flush();
+            st_b = b;
+        }
+#pragma unroll
+        for (int hw = 0; hw < NH; ++hw) {
+            const int co = n0 + 64 * hw + 16 * q;            // this lane's 16 consecutive output channels of the half
+            const bool act = co < a.lrelu_ch;
+            if (a.pool_sum) {
+                const int Hp = a.Hout >> 1, Wp = a.Wout >> 1;
+#pragma unroll
+                for (int j = 0; j < TPX; j += 2) {
+                    float v[16];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float t = acc[4 * hw + i][j][r] + acc[4 * hw + i][j + 1][r];
+                            const int o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, false);
+                            v[4 * i + r] = t + __builtin_bit_cast(float, o);
+                        }
+                    if ((r16 & 1) == 0) {
+                        const int yy = (y0 + wave_py + j) >> 1, xx = (x0 + r16) >> 1;
+                        const long o = (((long)b * Hp + yy) * Wp + xx) * a.Cout + co;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            u32x4 out = {pack_bf16x2(v[8 * h + 0], v[8 * h + 1]), pack_bf16x2(v[8 * h + 2], v[8 * h + 3]),
+                                         pack_bf16x2(v[8 * h + 4], v[8 * h + 5]), pack_bf16x2(v[8 * h + 6], v[8 * h + 7])};
+                            *reinterpret_cast<u32x4*>(a.y + o + 8 * h) = out;
+                        }
+                    }
+                }
+            } else {
+            float ps[16];                   // ypool: running 2x2 sums of the bf16-rounded outputs of a row pair
+            float tl0[(MASKED || STATS) ? 16 : 1], tl1[STATS ? 16 : 1];     // this tile's sums
+#pragma unroll
+            for (int k2 = 0; k2 < ((MASKED || STATS) ? 16 : 1); ++k2) tl0[k2] = 0.f;
+#pragma unroll
+            for (int k2 = 0; k2 < (STATS ? 16 : 1); ++k2) tl1[k2] = 0.f;
+#pragma unroll
+            for (int j = 0; j < TPX; ++j) {
+                const int yy = y0 + wave_py + j, xx = x0 + r16;
+                const long o = (((long)b * a.Hout + yy) * a.Wout + xx) * a.Cout + co;
+                float v[16];
+                if (a.bias) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x4 bq = *reinterpret_cast<const f32x4*>(bias_lds + 64 * hw + 16 * q + 4 * i);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[4 * i + r] = acc[4 * hw + i][j][r] + bq[r];
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[4 * i + r] = acc[4 * hw + i][j][r];
+                }
+                if (a.resid) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const u32x4 rr = *reinterpret_cast<const u32x4*>(a.resid + o + 8 * h);
+#pragma unroll
+                        for (int w2 = 0; w2 < 4; ++w2) {
+                            v[8 * h + 2 * w2] += bf16_lo(rr[w2]);
+                            v[8 * h + 2 * w2 + 1] += bf16_hi(rr[w2]);
+                        }
+                    }
+                }
+                if (act) {                  // 0 <= slope <= 1 (checked by the launcher): max(v, slope v) IS the leaky ReLU
+#pragma unroll
+                    for (int k2 = 0; k2 < 16; ++k2) {
+                        const float sv = v[k2] * a.slope;
+                        asm("v_max_f32 %0, %1, %2" : "=v"(v[k2]) : "v"(v[k2]), "v"(sv));
+                    }
+                }
+                u32x4 mk[MASKED ? 2 : 1];
+                if (MASKED) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const u32x4 mm = *reinterpret_cast<const u32x4*>(a.mask_y + o + 8 * h);
+                        mk[h] = mm;
+#pragma unroll
+                        for (int w2 = 0; w2 < 4; ++w2) {
+                            v[8 * h + 2 * w2] = bf16_lo(mm[w2]) > 0.f ? v[8 * h + 2 * w2] : v[8 * h + 2 * w2] * a.slope;
+                            v[8 * h + 2 * w2 + 1] = bf16_hi(mm[w2]) > 0.f ? v[8 * h + 2 * w2 + 1] : v[8 * h + 2 * w2 + 1] * a.slope;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    u32x4 out = {pack_bf16x2(v[8 * h + 0], v[8 * h + 1]), pack_bf16x2(v[8 * h + 2], v[8 * h + 3]),
+                                 pack_bf16x2(v[8 * h + 4], v[8 * h + 5]), pack_bf16x2(v[8 * h + 6], v[8 * h + 7])};
+                    *reinterpret_cast<u32x4*>(a.y + o + 8 * h) = out;
+                    if (MASKED) {           // column sums of what was stored (the rounded values, as the separate pass took them)
+#pragma unroll
+                        for (int w2 = 0; w2 < 4; ++w2) {
+                            tl0[MASKED ? 8 * h + 2 * w2 : 0] += cw * bf16_lo(out[w2]);
+                            tl0[MASKED ? 8 * h + 2 * w2 + 1 : 0] += cw * bf16_hi(out[w2]);
+                        }
+                        if (a.y2) {         // rgbd_axpy_rows_bf16 of (what was stored, the activation tile): the injection operand
+                            u32x4 o2;
+#pragma unroll
+                            for (int w2 = 0; w2 < 4; ++w2)
+                                o2[w2] = pack_bf16x2(bf16_lo(out[w2]) + cw2 * bf16_lo(mk[h][w2]),
+                                                     bf16_hi(out[w2]) + cw2 * bf16_hi(mk[h][w2]));
+                            *reinterpret_cast<u32x4*>(a.y2 + o + 8 * h) = o2;
+                        }
+                    }
+                    if (STATS) {
+#pragma unroll
+                        for (int w2 = 0; w2 < 4; ++w2) {
+                            const float lo = bf16_lo(out[w2]), hi = bf16_hi(out[w2]);
+                            tl0[STATS ? 8 * h + 2 * w2 : 0] += lo;
+                            tl1[STATS ? 8 * h + 2 * w2 : 0] += lo * lo;
+                            tl0[STATS ? 8 * h + 2 * w2 + 1 : 0] += hi;
+                            tl1[STATS ? 8 * h + 2 * w2 + 1 : 0] += hi * hi;
+                        }
+                    }
+                    if (a.ypool) {          // the block's downscale2x (rescale.py:12-13) of what was just stored
+#pragma unroll
+                        for (int w2 = 0; w2 < 4; ++w2) {
+                            const float lo = bf16_lo(out[w2]), hi = bf16_hi(out[w2]);
+                            ps[8 * h + 2 * w2] = (j & 1) ? ps[8 * h + 2 * w2] + lo : lo;
+                            ps[8 * h + 2 * w2 + 1] = (j & 1) ? ps[8 * h + 2 * w2 + 1] + hi : hi;
+                        }
+                    }
+                }
+                if (a.ypool && (j & 1)) {
+#pragma unroll
+                    for (int k2 = 0; k2 < 16; ++k2) {
+                        const int o2 = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ps[k2]), 0xB1, 0xF, 0xF, false);
+                        ps[k2] = 0.25f * (ps[k2] + __builtin_bit_cast(float, o2));
+                    }
+                    if ((r16 & 1) == 0) {
+                        const long op = (((long)b * (a.Hout >> 1) + (yy >> 1)) * (a.Wout >> 1) + (xx >> 1)) * a.Cout + co;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            u32x4 out = {pack_bf16x2(ps[8 * h + 0], ps[8 * h + 1]), pack_bf16x2(ps[8 * h + 2], ps[8 * h + 3]),
+                                         pack_bf16x2(ps[8 * h + 4], ps[8 * h + 5]), pack_bf16x2(ps[8 * h + 6], ps[8 * h + 7])};
+                            *reinterpret_cast<u32x4*>(a.ypool + op + 8 * h) = out;
+                        }
+                    }
+                }
+            }
+            if constexpr (MASKED) cs_acc[hw] += transpose_reduce16(tl0);
+            if constexpr (STATS) {
+                st1_acc[hw] += transpose_reduce16(tl0);
+                st2_acc[hw] += transpose_reduce16(tl1);
+            }
+            }
+            // (cleared in ONE place behind both forms: with a clear in each branch the compiler merges the branch tails
+            // through a phi of accumulator ADDRESSES, which keeps those accumulators in scratch memory for the whole kernel)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < TPX; ++j) acc[4 * hw + i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+
+    // ---- prologue: halo patch of slice 0, weight tiles of steps 0-1 and the first pieces of step 2's (step t multiplies
+    //      filter tap (kh, kw) = (t % 3, t / 3), i.e. weight image 3 (t % 3) + t / 3), then quarter 0's A tiles and the halo
+    //      rows of step 0
+    constexpr int WFIRST = WPW == 4 ? 2 : 1;          // a tile's pieces go out in three gaps: WFIRST, then one and one (or one, none)
+    if (w_role) {
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) dma_w_piece(0, 0, 0, i);
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) dma_w_piece(0, 3, 1, i);
+#pragma unroll
+        for (int i = 0; i < WFIRST; ++i) dma_w_piece(0, 6, 2, i);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WFIRST) : "memory");
+    } else {
+        unsigned soff, border;
+        patch_scalar(pt_begin, 0, soff, border);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) dma_patch(i, 0, soff, border);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    load_a_quarter(0, 0);
+    load_b(0, 0, 0, -1);
+
+    // One K step t: quarters 0-2 multiply while the NEXT quarter's A tiles of weight tile t are read; the barrier B_t sits
+    // between quarters 2 and 3: by then every read of tile t has been issued and retired (lgkmcnt(0)), so its buffer may take
+    // tile t + 3, and tile t + 1 (needed from quarter 3 on: quarter 0's tiles of step t + 1) has landed in every weight wave
+    // (vmcnt(WPW): all but the youngest tile, t + 2); at t = 8 the halo waves have retired the next patch.  Quarter 3 runs
+    // behind B_t with the reads of step t + 1: its first A tiles and its new halo rows.  DMA issue points (a piece holds its
+    // wave for ~60 cycles; the other workgroup's MFMAs cover it): behind quarter 3 the first pieces of tile t + 3, behind
+    // quarters 0 and 1 of the next step the rest; the next patch's pieces in the same gaps of steps 0-3.
+    int c = 0, pt = pt_begin;
+    bool w_waited = false;             // weight waves: tile 1 of this slice was already waited for (in front of an epilogue)
+    unsigned long long stamp_sum[4] = {0, 0, 0, 0};     // KO 10: cycles in quarters 0-2 / waits + barrier / quarter 3 + DMA issue / epilogue
+    for (int g = 0; g < g_total; ++g) {
+        const int c_next = c + 1 == nc ? 0 : c + 1;
+        const bool last = g + 1 >= g_total;
+        const int pt_next = (c_next == 0 && !last) ? pt + 1 : pt;
+        unsigned nsoff, nborder;
+        patch_scalar(pt_next, c_next, nsoff, nborder);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int kh = t % 3, kw = t / 3;
+            const int tn = (t + 1) % 9, khn = tn % 3, kwn = tn / 3;
+            unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+            if (KO == 10) ts0 = __builtin_amdgcn_s_memtime();
+#pragma unroll
+            for (int qi = 0; qi < 4; ++qi) {
+                if (qi == 3) {
+                    if (KO == 10) ts1 = __builtin_amdgcn_s_memtime();
+                    if (w_role) {
+                        if (!(t == 0 && w_waited)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WPW) : "memory");
+                    } else if (t == 8) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    RGBD_PP_BARRIER();
+                    if (KO == 10) ts2 = __builtin_amdgcn_s_memtime();
+                    if (KO != 3 && KO != 6) {
+                        load_a_quarter(tn % 3, 0);
+                        load_b(t == 8 ? (g + 1) & 1 : g & 1, khn, kwn, -1);
+                    }
+                } else if (KO != 3 && KO != 6) {
+                    load_a_quarter(t % 3, qi + 1);
+                }
+                mfma_quarter(kh, kw, qi);
+#pragma unroll
+                for (int k_ = 0; k_ < QT * TPX; ++k_) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (qi != 2) {
+                    const int gap = qi == 3 ? 0 : qi + 1;                 // 0: behind B_t, 1 / 2: the next two gaps of the same tile
+                    if (w_role && KO != 1 && KO != 6) {
+                        // gap 0 opens tile t + 3 (into tile t's buffer); gaps 1, 2 of THIS step finish tile t + 2
+                        const int tt = gap == 0 ? t + 3 : t + 2;
+                        const int cw_ = tt >= 9 ? c_next : c, tapw = 3 * ((tt % 9) % 3) + (tt % 9) / 3;
+                        if (gap == 0) {
+#pragma unroll
+                            for (int k_ = 0; k_ < WFIRST; ++k_) dma_w_piece(cw_, tapw, tt % 3, k_);
+                        } else if (WFIRST + gap - 1 < WPW) {
+                            dma_w_piece(cw_, tapw, tt % 3, WFIRST + gap - 1);
+                        }
+                    } else if (!w_role && t < PSTEPS && KO != 2 && KO != 6) {
+                        const int pi_ = qi == 3 ? 2 : qi;                 // gaps behind quarters 0, 1, 3 of steps 0 .. PSTEPS-1
+                        if (pi_ < PPS && t * PPS + pi_ < PPW) dma_patch(t * PPS + pi_, (g + 1) & 1, nsoff, nborder);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (KO == 10) {
+                const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
+                stamp_sum[0] += ts1 - ts0; stamp_sum[1] += ts2 - ts1; stamp_sum[2] += ts3 - ts2;
+            }
+        }
+        w_waited = false;
+        if (c_next == 0) {             // last slice of this pixel tile: write it out.  The weight waves first retire tile 1 of
+                                       // the next slice (all but the pieces of tile 2 issued so far): behind the epilogue's
+                                       // stores a counted wait would also wait for those
+            if (w_role) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WFIRST) : "memory");
+                w_waited = true;
+            }
+            unsigned long long te0 = 0;
+            if (KO == 10) te0 = __builtin_amdgcn_s_memtime();
+            epilogue(pt);
+            if (KO == 10) stamp_sum[3] += __builtin_amdgcn_s_memtime() - te0;
+        }
+        c = c_next;
+        pt = pt_next;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // no DMA may land in LDS after the workgroup has gone
+#ifdef RGBD_DEBUG_BUILD
+    if (KO == 10 && a.partial && lane == 0) {
+        unsigned* o = reinterpret_cast<unsigned*>(a.partial) + 8 * 1024 + (blockIdx.x * 4 + wid) * 4;
+#pragma unroll
+        for (int k_ = 0; k_ < 4; ++k_) o[k_] = (unsigned)stamp_sum[k_];
+    }
+#endif
+#ifdef RGBD_DEBUG_BUILD
+    if (a.partial && tid == 0) {        // census (scripts/dw_census.py): where and when this workgroup ran
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+        unsigned* o = reinterpret_cast<unsigned*>(a.partial) + 8 * blockIdx.x;
+        o[0] = hw; o[1] = xcc; o[2] = (unsigned)census_t0; o[3] = (unsigned)(census_t0 >> 32);
+        o[4] = (unsigned)t1; o[5] = (unsigned)(t1 >> 32); o[6] = (unsigned)g_total; o[7] = blockIdx.x;
+    }
+#endif
+    if (STATS && st_b >= 0) stats_flush();
+    if (MASKED && a.colsum) {
+        __syncthreads();
+        float* const red = reinterpret_cast<float*>(dsm);              // [4 waves][BN]
+#pragma unroll
+        for (int hw = 0; hw < NH; ++hw) red[wid * BN + 64 * hw + 16 * q + r16] = cs_acc[hw];
+        __syncthreads();
+        if (tid < BN) {
+            const float t = (red[tid] + red[BN + tid]) + (red[2 * BN + tid] + red[3 * BN + tid]);
+            atomicAdd(a.colsum + n0 + tid, t);
+        }
+    }
+}
+
+#endif  // RGBD_DEBUG_BUILD (conv3x3_dw_kernel)
+
 // ------------------------------------------------------------------------------------------------ wgrad
 struct WgradArgs {
     const unsigned short* x;
@@ -2151,6 +2705,16 @@ int ilog2(int v) {
 }  // namespace
 
 #ifdef RGBD_DEBUG_BUILD
+namespace { unsigned* g_dw_census = nullptr; }
+// census of the dual-workgroup kernel's last launch: 8 words per workgroup (HW_ID, XCC_ID, start and end of s_memrealtime,
+// slices, block index); on = 1 allocates the buffer and switches the census on, host_out != null copies n workgroups out
+extern "C" int rgbd_debug_dw_census(int on, unsigned* host_out, int n) {
+    if (on && !g_dw_census) RGBD_REQUIRE(hipMalloc(&g_dw_census, 8 * 4096 * sizeof(unsigned)) == hipSuccess, "census: hipMalloc");
+    if (!on && g_dw_census) { (void)hipFree(g_dw_census); g_dw_census = nullptr; }
+    if (host_out && g_dw_census)
+        RGBD_REQUIRE(hipMemcpy(host_out, g_dw_census, (size_t)8 * n * sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess, "census: copy");
+    return 0;
+}
 extern "C" int rgbd_debug_force_gather_kernel(int on) {
     g_force_gather = on != 0;
     return 0;
@@ -2409,6 +2973,75 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
                                         : (wide ? "conv3x3_sp_kernel<128,mxfp8>" : "conv3x3_sp_kernel<64,mxfp8>");
             return 0;
         }
+        // ---- the dual-workgroup kernel (two 4-wave workgroups per CU): round 5's A/B against the 8-wave kernel, debug library
+        //      only (variants 8 / 7: 64- / 128-channel tiles, 6 and 21-30: its knock-outs and stamps; scripts/ab_conv_dw.py)
+#ifdef RGBD_DEBUG_BUILD
+        const bool dw_debug = g_conv_variant == 6 || g_conv_variant == 7 || g_conv_variant == 8 || (g_conv_variant >= 21 && g_conv_variant <= 30);
+        if (dw_debug) {
+            bool wide2 = false;
+            if (g_conv_variant == 7 || g_conv_variant == 6 || g_conv_variant >= 21) wide2 = Cout % 128 == 0;
+            const int n_tiles2 = wide2 ? Cout / 128 : Cout / 64;
+            int per_nt2 = 2 * num_cus / n_tiles2;
+            if (per_nt2 < 1) per_nt2 = 1;
+            if (per_nt2 > ptiles) per_nt2 = (int)ptiles;
+            a.wgs_per_ntile = per_nt2;
+            a.partial = nullptr;
+#ifdef RGBD_DEBUG_BUILD
+            a.partial = (float*)g_dw_census;
+#endif
+            const unsigned grid2 = (unsigned)(per_nt2 * n_tiles2);
+            const int bn2 = wide2 ? 128 : 64;
+            const int lds_dw = 2 * (a.ups ? 7 : 21) * 1024 + 3 * bn2 * 64 + bn2 * 4;
+            const int epi = stats ? 2 : mask_y ? 1 : 0;
+            const int vi2 = ((wide2 ? 1 : 0) * 2 + a.ups) * 3 + epi;
+            static bool dw_attr_done[12] = {};
+#define RGBD_DW_CASE(BNv, UPSv, EPIv)                                                                                      \
+    do {                                                                                                                   \
+        if (!dw_attr_done[vi2]) {                                                                                          \
+            RGBD_REQUIRE(hipFuncSetAttribute((const void*)&conv3x3_dw_kernel<BNv, UPSv, EPIv>,                             \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_dw) == hipSuccess,            \
+                         "rgbd_conv3x3: cannot reserve %d B of LDS", lds_dw);                                              \
+            dw_attr_done[vi2] = true;                                                                                      \
+        }                                                                                                                  \
+        conv3x3_dw_kernel<BNv, UPSv, EPIv><<<grid2, 256, lds_dw, st>>>(a);                                                 \
+    } while (0)
+#ifdef RGBD_DEBUG_BUILD
+            if ((g_conv_variant == 6 || (g_conv_variant >= 21 && g_conv_variant <= 30)) && wide2 && !a.ups && epi == 0) {   // timing knock-outs, stamps
+                const int ko = g_conv_variant == 6 ? 9 : g_conv_variant - 20;
+                const void* fk = ko == 9 ? (const void*)&conv3x3_dw_kernel<128, false, 0, 9>
+                               : ko == 1 ? (const void*)&conv3x3_dw_kernel<128, false, 0, 1>
+                               : ko == 2 ? (const void*)&conv3x3_dw_kernel<128, false, 0, 2>
+                               : ko == 3 ? (const void*)&conv3x3_dw_kernel<128, false, 0, 3>
+                               : ko == 10 ? (const void*)&conv3x3_dw_kernel<128, false, 0, 10>
+                                          : (const void*)&conv3x3_dw_kernel<128, false, 0, 6>;
+                RGBD_REQUIRE(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, lds_dw) == hipSuccess, "lds");
+                if (ko == 9) conv3x3_dw_kernel<128, false, 0, 9><<<grid2, 256, lds_dw, st>>>(a);
+                else if (ko == 1) conv3x3_dw_kernel<128, false, 0, 1><<<grid2, 256, lds_dw, st>>>(a);
+                else if (ko == 2) conv3x3_dw_kernel<128, false, 0, 2><<<grid2, 256, lds_dw, st>>>(a);
+                else if (ko == 3) conv3x3_dw_kernel<128, false, 0, 3><<<grid2, 256, lds_dw, st>>>(a);
+                else if (ko == 10) conv3x3_dw_kernel<128, false, 0, 10><<<grid2, 256, lds_dw, st>>>(a);
+                else conv3x3_dw_kernel<128, false, 0, 6><<<grid2, 256, lds_dw, st>>>(a);
+                RGBD_CHECK_LAUNCH("conv3x3_dw_kernel<KO>");
+                return 0;
+            }
+            if (wide2) {           // 128-channel tiles: the A/B of scripts/ab_conv_dw.py only (plain epilogue)
+                RGBD_REQUIRE(epi == 0, "rgbd_debug_conv_variant(7): the 128-channel dual-workgroup form exists with the plain epilogue only");
+                if (a.ups) RGBD_DW_CASE(128, true, 0); else RGBD_DW_CASE(128, false, 0);
+                RGBD_CHECK_LAUNCH("conv3x3_dw_kernel");
+                g_last_conv_kernel = "conv3x3_dw_kernel<128>";
+                return 0;
+            }
+#endif
+            if (a.ups) { if (epi == 2) RGBD_DW_CASE(64, true, 2); else RGBD_DW_CASE(64, true, 0); }
+            else if (epi == 2) RGBD_DW_CASE(64, false, 2);
+            else if (epi == 1) RGBD_DW_CASE(64, false, 1);
+            else RGBD_DW_CASE(64, false, 0);
+#undef RGBD_DW_CASE
+            RGBD_CHECK_LAUNCH("conv3x3_dw_kernel");
+            g_last_conv_kernel = stats ? "conv3x3_dw_kernel<64,stats>" : mask_y ? "conv3x3_dw_kernel<64,actgrad>" : "conv3x3_dw_kernel<64>";
+            return 0;
+        }
+#endif
         if (g_conv_variant != 1) {
             const int pieces = a.ups ? 13 : 41, bn = wide ? 128 : 64;
             const int lds_sp = 2 * pieces * 1024 + 3 * bn * 128 + bn * 4;

@@ -138,7 +138,8 @@ class DeviceImageIterator:
         self._order = order.to(self.data.device)
         if sd.get("rng_state") is not None:        # (a trainer snapshot written by the reference has no generator state: the
             self.gen.set_state(torch.as_tensor(np.asarray(sd["rng_state"]), dtype=torch.uint8))   # next epochs' permutations
-            self.seed = int(sd["seed"])                                                            # come from this run's seed)
+            if sd.get("seed") is not None:                                                         # come from this run's seed)
+                self.seed = int(sd["seed"])
 
 
 def iterator_state_path(directory, iteration, rank):
@@ -149,7 +150,24 @@ def save_iterator_state(directory, iteration, rank, iterator):
     """EVERY rank keeps its own iterator state next to the master's snapshot: ranks shuffle the whole data set with their own
     seeds (train_rgbd.py of the reference: no scatter_dataset, one NumPy RNG per process), so rank 0's position / order /
     generator state is not theirs."""
-    np.savez(iterator_state_path(directory, iteration, rank), **iterator.state_dict())
+    path = iterator_state_path(directory, iteration, rank)
+    tmp = path + ".tmp.npz"
+    try:
+        # every rank makes the directory for itself (a node-local `out` exists on the master's node only) and replaces the
+        # file in one step: a crash in the middle of the write must not leave a truncated file that a resume would prefer
+        os.makedirs(directory, exist_ok=True)
+        np.savez(tmp, **iterator.state_dict())
+        os.replace(tmp, path)
+    except OSError as e:
+        # a rank that cannot write its file must not die here and leave the other ranks in their next collective: a missing
+        # file already degrades to "fresh" on resume (load_iterator_state)
+        if rank == 0:
+            raise
+        print(f"[rank {rank}] could not write {path}: {e}; a resume will start this rank's iterator fresh", flush=True)
+        try:
+            os.remove(tmp)
+        except OSError:
+            pass
 
 
 def load_iterator_state(directory, iteration, rank, iterator, master_snapshot=None):
@@ -159,9 +177,15 @@ def load_iterator_state(directory, iteration, rank, iterator, master_snapshot=No
     the run.  -> "own" | "master" | "fresh"."""
     path = iterator_state_path(directory, iteration, rank)
     if os.path.exists(path):
-        with np.load(path) as f:
-            iterator.load_state_dict({k: f[k] for k in f.files})
-        return "own"
+        try:
+            with np.load(path) as f:
+                sd = {k: f[k] for k in f.files}
+            iterator.load_state_dict(sd)
+            return "own"
+        except (OSError, ValueError, KeyError, EOFError) as e:      # zipfile.BadZipFile is an OSError-free Exception: see below
+            print(f"[rank {rank}] unreadable iterator state {path}: {e}", flush=True)
+        except Exception as e:                                      # a truncated archive (BadZipFile) and the like
+            print(f"[rank {rank}] unreadable iterator state {path}: {type(e).__name__}: {e}", flush=True)
     if rank == 0 and master_snapshot is not None and "iterator/pos" in master_snapshot:
         iterator.load_state_dict({k[len("iterator/"):]: master_snapshot[k] for k in master_snapshot
                                   if k.startswith("iterator/")})

@@ -259,6 +259,21 @@ class RGBDUpdater:
             bad = [k for i, k in enumerate(w["keys"]) if int(w["host"][0]) >> i & 1]
             raise AssertionError(f"{', '.join(bad)} not finite at or before iteration {w['iteration']}")
 
+    def _end_of_step_checks(self):
+        """The non-finite checks every updater runs behind a step (DeepVoxelsUpdater too): the per-step device-side watch
+        (no host synchronisation) and the reference's host check every nan_check_interval steps."""
+        if self.nan_watch:
+            self._nan_watch_poll()          # what the previous steps reported, if it has arrived (never waits)
+            self._nan_watch_push()
+        if self.nan_check_interval > 0 and (self.iteration + 1) % self.nan_check_interval == 0:
+            self._check_finite()
+
+    def assert_finite_so_far(self):
+        """Wait for the newest step's flag (train_rgbd.py calls this before it writes a snapshot and after the last step: a
+        NaN produced by the step in front of a snapshot must not be saved)."""
+        if getattr(self, "nan_watch", False):
+            self._nan_watch_poll(block=True)
+
     def _nan_watch_push(self):
         keys = [k for k in self.NAN_KEYS if torch.is_tensor(self.observation.get(k)) and self.observation[k].is_cuda
                 and self.observation[k].dtype == torch.float32]
@@ -821,11 +836,7 @@ class RGBDUpdater:
 
         obs = self.observation
         obs["stage"], obs["batch_size"], obs["image_size"] = stage, batch_size, int(st["x_real"].shape[2])
-        if self.nan_watch:
-            self._nan_watch_poll()          # what the previous steps reported, if it has arrived (never waits)
-            self._nan_watch_push()
-        if self.nan_check_interval > 0 and (self.iteration + 1) % self.nan_check_interval == 0:
-            self._check_finite()
+        self._end_of_step_checks()
 
 
 class RGBUpdater(RGBDUpdater):

@@ -58,6 +58,8 @@ class DeepVoxelsUpdater(RGBDUpdater):
         self._optimizers = kwargs.pop("optimizer")
         self._iterators = {"main": kwargs.pop("iterator")}
         self.nan_check_interval = int(kwargs.pop("nan_check_interval", 100))
+        self.nan_watch = bool(kwargs.pop("nan_watch", self.nan_check_interval > 0))     # the per-step watch of RGBDUpdater
+        self._nan_state = None
         self.loss_func_rotate = LossFuncRotate(torch, K=self.gen.projection.projection_intrinsic,
                                                lambda_geometric=config.lambda_geometric or 3)
         self.stage_interval = [int(v) for v in str(config.stage_interval).split(",")]
@@ -231,5 +233,4 @@ class DeepVoxelsUpdater(RGBDUpdater):
 
         obs = self.observation
         obs["stage"], obs["batch_size"], obs["image_size"] = FIXED_STAGE, B, IMG_SIZE
-        if self.nan_check_interval > 0 and (self.iteration + 1) % self.nan_check_interval == 0:
-            self._check_finite()
+        self._end_of_step_checks()

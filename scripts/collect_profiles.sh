@@ -4,20 +4,30 @@
 # conv kernels on the step's layer shapes; summaries into profiles/$1 (stamped with the kernel sources' hash).
 #   scripts/collect_profiles.sh r02 [commit]
 set -u
-R=${1:-r04}
+R=${1:-r05}
 export RGBD_COMMIT=${2:-unknown}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/$R profiles/$R
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/stats -o b -- python3 bench.py --no-cpu-baseline > gpurun_out/$R/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/stats -o b -- python3 bench.py --no-cpu-baseline --no-other-configs > gpurun_out/$R/stats.log 2>&1
 cp gpurun_out/$R/stats/b_kernel_stats.csv profiles/$R/bench_kernel_stats.csv
 grep '"metric"' gpurun_out/$R/stats.log > profiles/$R/bench_line_under_rocprof.json
 rm -f gpurun_out/$R/stats/b_kernel_trace.csv
-for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d gpurun_out/$R/pmc_$C -o p -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-roofline > gpurun_out/$R/pmc_$C.log 2>&1
-done
-python3 scripts/pmc_summary.py gpurun_out/$R/pmc_FETCH_SIZE gpurun_out/$R/pmc_WRITE_SIZE profiles/$R/bench_pmc_traffic.json \
-  "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-roofline"
-rm -rf gpurun_out/$R/pmc_FETCH_SIZE gpurun_out/$R/pmc_WRITE_SIZE
+# HBM traffic per kernel, ONE profile per workload (bench.py:workload_key): bench.py quotes a profile only on the workload it was
+# recorded on
+pmc_traffic() {   # name, bench.py arguments
+  local W=$1; shift
+  for C in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --kernel-trace --pmc $C --output-format csv -d gpurun_out/$R/pmc_${W}_$C -o p -- python3 bench.py "$@" --steps 3 --warmup 3 --no-cpu-baseline --no-roofline --no-other-configs > gpurun_out/$R/pmc_${W}_$C.log 2>&1
+  done
+  python3 scripts/pmc_summary.py gpurun_out/$R/pmc_${W}_FETCH_SIZE gpurun_out/$R/pmc_${W}_WRITE_SIZE profiles/$R/bench_pmc_traffic_$W.json \
+    "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py $* --steps 3 --warmup 3 --no-cpu-baseline --no-roofline --no-other-configs" $W
+  rm -rf gpurun_out/$R/pmc_${W}_FETCH_SIZE gpurun_out/$R/pmc_${W}_WRITE_SIZE
+}
+pmc_traffic default
+pmc_traffic res256 --res256
+pmc_traffic res256_fp8 --res256 --fp8
+pmc_traffic c3_b8 --config configs/ffhq_stylegan_occlusion.yml --batch 8
+pmc_traffic c4 --config configs/deepvoxels_shapenet_car.yml
 # SQ / LDS / L2 counters of the conv kernels alone (scripts/prof_conv.py: the step's layer shapes at B=32), a few counters per pass
 P=0
 for CS in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS" \
@@ -52,7 +62,7 @@ cp gpurun_out/$R/stats_c4/b_kernel_stats.csv profiles/$R/bench_c4_kernel_stats.c
 rm -f gpurun_out/$R/stats_c4/b_kernel_trace.csv
 # ---- what lies under what: a kernel trace of the default command through scripts/trace_overlap.py (small kernels that the
 #      per-kernel averages show at 5-10x their stand-alone time are stretched under the other queue's chip-filling kernels)
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/$R/trace -o t -- python3 bench.py --steps 6 --warmup 10 --no-cpu-baseline --no-roofline > gpurun_out/$R/trace.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/$R/trace -o t -- python3 bench.py --steps 6 --warmup 10 --no-cpu-baseline --no-roofline --no-other-configs > gpurun_out/$R/trace.log 2>&1
 T=$(find gpurun_out/$R/trace -name 't_kernel_trace.csv' | head -1)
 python3 scripts/trace_overlap.py $T 'planes_outer_kernel<4>' 'from_planes_kernel<4>' 'linear_fwd' 'adain_reduce' 'warp_loss_bwd_kernel' > profiles/$R/trace_overlap.txt 2>&1
 python3 scripts/timeline.py $T > profiles/$R/trace_timeline.txt 2>&1

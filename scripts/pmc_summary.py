@@ -1,5 +1,6 @@
 """Aggregate rocprofv3 --pmc counter_collection.csv files (FETCH_SIZE and WRITE_SIZE passes) into
-profiles/<round>/bench_pmc_traffic.json: HBM bytes per launch for every kernel.
+profiles/<round>/bench_pmc_traffic_<workload>.json: HBM bytes per launch for every kernel of ONE bench.py workload
+(bench.py:workload_key; bench.py only quotes a profile whose recorded workload is the one it is running).
 
 gfx950 correction (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE counts 128-byte requests as 64 B, so
 hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (both counters are in KB)."""
@@ -25,7 +26,7 @@ def load(pattern, counter):
     return acc
 
 
-def main(fetch_dir, write_dir, out, command):
+def main(fetch_dir, write_dir, out, command, workload=None):
     f = load(fetch_dir + "/**/*counter_collection.csv", "FETCH_SIZE")
     w = load(write_dir + "/**/*counter_collection.csv", "WRITE_SIZE")
     kernels = {}
@@ -37,7 +38,7 @@ def main(fetch_dir, write_dir, out, command):
     import os
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import kernel_source_sha16
-    json.dump({"command": command, "source_sha16": kernel_source_sha16(), "commit": os.environ.get("RGBD_COMMIT"),
+    json.dump({"command": command, "workload": workload, "source_sha16": kernel_source_sha16(), "commit": os.environ.get("RGBD_COMMIT"),
                "correction": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024  (gfx950: FETCH_SIZE counts 128-B requests "
                              "as 64 B; unit KB)",
                "kernels": kernels}, open(out, "w"), indent=1)
@@ -47,4 +48,4 @@ def main(fetch_dir, write_dir, out, command):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:6])

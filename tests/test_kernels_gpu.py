@@ -721,6 +721,88 @@ def test_pipelined_conv_matches_register_staged_kernel_bit_for_bit(B, H, Cin, Co
             assert torch.equal(a, b), f"launch {rep}: {int((a != b).sum())} of {a.numel()} values differ"
 
 
+def assert_bf16_near(a, b, max_frac=2e-3):
+    """bf16 tensors that hold the same fp32 sums taken in a different order: at most `max_frac` of the values differ, each by
+    at most one bf16 unit in the last place (of the larger magnitude; 2^-7 relative) or, next to zero, an absolute 1e-3 of
+    the tensor's scale (cancellation: a sum of O(1) products that lands near zero keeps the products' absolute noise)."""
+    af, bf = a.float(), b.float()
+    d = (af - bf).abs()
+    frac = float((d > 0).float().mean())
+    assert frac <= max_frac, f"{frac:.5f} of the values differ"
+    tol = torch.maximum(af.abs(), bf.abs()) * 2.0 ** -7 + 1e-3 * float(bf.abs().max())
+    assert bool((d <= tol).all()), f"worst excess {float((d - tol).max()):.3e}"
+
+
+DW_CASES = [  # (B, Hout, Cin, Cout, upsample, form): 64-channel tiles, two workgroups per CU
+    (8, 128, 64, 64, False, "plain"), (8, 128, 128, 64, False, "res"), (9, 128, 128, 64, True, "plain"),
+    (8, 128, 64, 64, False, "pool"), (8, 128, 64, 64, False, "sumpool"), (8, 128, 128, 64, False, "actgrad"),
+    (8, 128, 64, 64, False, "actgrad_y2"), (8, 128, 64, 64, False, "stats"), (10, 128, 128, 64, True, "stats"),
+    (32, 64, 64, 64, False, "plain"), (3, 256, 64, 64, False, "res"),
+]
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,ups,form", DW_CASES)
+def test_dual_workgroup_conv_matches_the_8_wave_kernel(B, H, Cin, Cout, ups, form):
+    """Round 5's A/B kernel, kept correct so that its timing evidence (profiles/r05/ab_conv_dw*.txt) means something:
+    conv3x3_dw_kernel (two 4-wave workgroups per CU, 32-channel slices; debug library, variant 8) against the shipped
+    conv3x3_sp_kernel on every epilogue form: plain, residual, pooled second output, 2x2 sums, masked (activation gradient +
+    column sums + second output), statistics.  bf16 outputs: assert_bf16_near; fp32 column sums / integer statistics: relative
+    1e-4 of their scale (sums over 1e4..1e5 stored bf16 values, of which ~1e-4 differ by one ulp); repeated launches
+    bit-exact (the statistics are integer sums, the column sums end in one fp32 atomic per channel per workgroup)."""
+    from rgbd_gan_amd import _lib, kernels
+    g = torch.Generator().manual_seed(B + H + Cin + len(form))
+    Hin = H // 2 if ups else H
+    x = torch.randn(B, Hin, Hin, Cin, generator=g).to(dev()).to(torch.bfloat16)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g).to(dev())
+    bias = torch.randn(Cout, generator=g).to(dev())
+    r = torch.randn(B, H, H, Cout, generator=g).to(dev()).to(torch.bfloat16)
+    act = torch.randn(B, H, H, Cout, generator=g).to(dev()).to(torch.bfloat16)
+    rs = (torch.rand(B, generator=g) + 0.5).to(dev())
+    wf, wd = kernels.pack_weights(w, float(np.sqrt(2.0 / (Cin * 9))))
+
+    def run():
+        if form == "plain":
+            return (kernels.conv2d_fprop(x, wf, 3, 3, 1, bias=bias, upsample=ups, lrelu_channels=Cout),)
+        if form == "res":
+            return (kernels.conv2d_fprop(x, wf, 3, 3, 1, bias=bias, residual=r, lrelu_channels=Cout),)
+        if form == "pool":
+            return kernels.conv2d_fprop(x, wf, 3, 3, 1, bias=bias, residual=r, lrelu_channels=Cout, avg_pool2=True)
+        if form == "sumpool":       # the input gradient of an upsampling conv: r plays dy (B,H,H,Cout), dx has Cin channels
+            return (kernels.conv2d_dgrad(r, wd, 3, 1, sum_pool2=True),)
+        if form in ("actgrad", "actgrad_y2"):
+            colsum = torch.zeros(Cout, device=dev())
+            out = kernels.conv3x3_actgrad(x, wf, act, residual=r, bias_grad=colsum, row_scale=rs, slope=0.2,
+                                          operand_scale=rs if form == "actgrad_y2" else None)
+            return tuple(out if isinstance(out, tuple) else (out,)) + (colsum,)
+        y, st = kernels.conv2d_fprop_stats(x, wf, bias, lrelu_channels=Cout, upsample=ups)
+        return (y, st)
+    ref = run()
+    assert _lib.load().rgbd_last_conv_kernel().decode().startswith("conv3x3_sp_kernel")
+    with _lib.debug_library() as dlib:
+        try:
+            dlib.rgbd_debug_conv_variant(8)
+            first = run()
+            assert dlib.rgbd_last_conv_kernel().decode().startswith("conv3x3_dw_kernel<64"), dlib.rgbd_last_conv_kernel().decode()
+            again = [run() for _ in range(6)]
+        finally:
+            dlib.rgbd_debug_conv_variant(0)
+    for a, b in zip(first, ref):
+        assert a.shape == b.shape and a.dtype == b.dtype
+        if a.dtype == torch.bfloat16:
+            assert_bf16_near(a, b)
+        elif a.dtype == torch.int64:            # instance-norm statistics in units of 2^-32
+            af, bf = a.double() / 2.0 ** 32, b.double() / 2.0 ** 32
+            assert float((af - bf).abs().max()) <= 1e-4 * float(bf.abs().max())
+        else:
+            assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-6
+    for rep, ag in enumerate(again):
+        for a, f in zip(ag, first):
+            if a.dtype == torch.float32:        # one fp32 atomic per channel per workgroup: order-dependent in the last bits
+                assert float((a - f).abs().max()) <= 5e-6 * float(f.abs().max()) + 1e-7
+            else:
+                assert torch.equal(a, f), f"launch {rep}: {int((a != f).sum())} of {a.numel()} values differ"
+
+
 @pytest.mark.parametrize("B,H,Cin,Cout,ups", [(32, 64, 128, 256, False), (4, 128, 64, 64, False), (16, 64, 256, 128, True),
                                               (2, 16, 192, 64, False), (32, 8, 256, 256, False)])
 def test_wgrad_bodies_agree_and_repeat(B, H, Cin, Cout, ups):

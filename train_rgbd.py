@@ -123,6 +123,8 @@ def main():
         if previews and it % config.evaluation_sample_interval == 0:
             for pv in previews:
                 pv(updater.stage, it)
+        if it % (config.snapshot_interval or 10000) == 0:
+            updater.assert_finite_so_far()      # the newest step's non-finite flag, before anything of it is written out
         if it % (config.snapshot_interval or 10000) == 0 and comm is not None and comm.size > 1:
             save_iterator_state(out, it, comm.rank, iterator)
         if is_master and it % (config.snapshot_interval or 10000) == 0:
@@ -131,6 +133,7 @@ def main():
             snap = trainer_snapshot.pack(it, optimizer, iterator.state_dict(), log, time.time() - t0,
                                          config.display_interval or 100)
             np.savez(f"{out}/snapshot_iter_{it}.npz", **snap)
+    updater.assert_finite_so_far()
     if is_master:
         for name, m in models:
             save_npz(f"{out}/{name}_latest.npz", m)
