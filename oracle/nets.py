@@ -83,6 +83,107 @@ def rg(x):
     return _RoundGrad.apply(x) if _EMULATE_BF16 else x
 
 
+# ---------------------------------------------------------------- MXFP8 conv emulation (optional, on top of the bf16 one)
+# `conv_dtype: mxfp8` (BASELINE configuration 5): the engine runs the fprop-type and dgrad-type launches of its 3x3 pad-1
+# convolutions on block-scaled fp8 operands whenever the launch is eligible (rgbd_gan_amd/kernels.py:_mx8_split,
+# csrc/conv.hip:rgbd_conv3x3_mxfp8_supported): reduction channels a multiple of 128, output channels of 64, output image a
+# multiple of 16x16, at least `min_tiles` 16x16 x 128 (or x 64) output tiles; weight gradients stay on the bf16 kernel.
+# Inside `mx8_emulation()` the restatement quantises (oracle/mxfp8.py, bit for bit the engine's format) exactly those
+# operands -- activations / activation gradients in blocks of 32 along the reduction channels, inv_c * W (fp32) in the fprop
+# image's blocks (along Cin) or the dgrad image's (along Cout) -- and is bf16-emulating everywhere else.  A conv is three
+# bilinear maps (fprop, dgrad, wgrad); the derivative of each is made of the other two, so two autograd Functions that call
+# each other carry the rule through the R1 double backward as well.
+_EMULATE_MX8 = None          # None, or the engine's MX8_MIN_TILES
+
+
+@contextlib.contextmanager
+def mx8_emulation(min_tiles=64):
+    global _EMULATE_MX8
+    old = _EMULATE_MX8
+    _EMULATE_MX8 = int(min_tiles)
+    try:
+        with bf16_emulation(True):
+            yield
+    finally:
+        _EMULATE_MX8 = old
+
+
+def _mx8_eligible(B, H, W, red, N):
+    """kernels._mx8_split + rgbd_conv3x3_mxfp8_supported for a launch with `red` reduction and N output channels."""
+    if H % 16 or W % 16 or H < 16 or W < 16 or red % 128 or N % 64:
+        return False
+    return B * (H // 16) * (W // 16) * (N // (128 if N % 128 == 0 else 64)) >= _EMULATE_MX8
+
+
+def _fq_act(x):
+    """NCHW float tensor -> its MXFP8 fake quantisation along the channels (the engine's NHWC blocks of 32 channels)."""
+    from . import mxfp8
+    a = np.ascontiguousarray(x.detach().permute(0, 2, 3, 1).numpy(), dtype=np.float32)
+    return torch.from_numpy(mxfp8.fake_quantize(a)).permute(0, 3, 1, 2).contiguous()
+
+
+def _fq_weights(Ws):
+    """inv_c * W (Cout, Cin, 3, 3) fp32 -> (fprop image dequantised as (Cout, Cin, 3, 3), dgrad image dequantised as the
+    correlation kernel (Cin, Cout, 3, 3) with flipped taps that turns dy into dx); None where the image does not exist."""
+    from . import mxfp8
+    w = Ws.detach().numpy().astype(np.float32)
+    co, ci = w.shape[:2]
+    taps = w.reshape(co, ci, 9)
+    f = d = None
+    if ci % 128 == 0:
+        q, sc = mxfp8.quantize(np.ascontiguousarray(taps.transpose(2, 0, 1)))
+        f = torch.from_numpy(np.ascontiguousarray(mxfp8.dequantize(q, sc).reshape(3, 3, co, ci).transpose(2, 3, 0, 1)))
+    if co % 128 == 0:
+        q, sc = mxfp8.quantize(np.ascontiguousarray(taps[:, :, ::-1].transpose(2, 1, 0)))
+        d = torch.from_numpy(np.ascontiguousarray(mxfp8.dequantize(q, sc).reshape(3, 3, ci, co).transpose(2, 3, 0, 1)))
+    return f, d
+
+
+def _conv_wgrad(x, g, wshape):
+    """weight gradient of a 3x3 pad-1 correlation: the engine's bf16 kernel on the stored (bf16) operands, fp32 sums."""
+    return torch.nn.grad.conv2d_weight(x, wshape, g, padding=1)
+
+
+class _MxFprop(torch.autograd.Function):
+    """y = conv3x3_pad1(x, Ws) as the engine launches it: fp8 operands if eligible, else bf16 weights."""
+
+    @staticmethod
+    def forward(ctx, x, Ws):
+        ctx.save_for_backward(x, Ws)
+        B, ci, H, W = x.shape
+        f, _ = _fq_weights(Ws) if _mx8_eligible(B, H, W, ci, Ws.shape[0]) else (None, None)
+        if f is not None:
+            return F.conv2d(_fq_act(x), f, None, padding=1)
+        return F.conv2d(x, _round(Ws), None, padding=1)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, Ws = ctx.saved_tensors
+        gx = _MxDgrad.apply(g, Ws) if ctx.needs_input_grad[0] else None
+        gw = _conv_wgrad(x, g, Ws.shape) if ctx.needs_input_grad[1] else None
+        return gx, gw
+
+
+class _MxDgrad(torch.autograd.Function):
+    """dx = the input gradient of conv3x3_pad1(., Ws) for the output gradient g, as the engine launches it."""
+
+    @staticmethod
+    def forward(ctx, g, Ws):
+        ctx.save_for_backward(g, Ws)
+        B, co, H, W = g.shape
+        _, d = _fq_weights(Ws) if _mx8_eligible(B, H, W, co, Ws.shape[1]) else (None, None)
+        if d is not None:
+            return F.conv2d(_fq_act(g), d, None, padding=1)
+        return F.conv_transpose2d(g, _round(Ws), None, padding=1)
+
+    @staticmethod
+    def backward(ctx, h):
+        g, Ws = ctx.saved_tensors
+        gg = _MxFprop.apply(h, Ws) if ctx.needs_input_grad[0] else None
+        gw = _conv_wgrad(h, g, Ws.shape) if ctx.needs_input_grad[1] else None
+        return gg, gw
+
+
 def lrelu(x):
     """chainer F.leaky_relu default slope 0.2."""
     return F.leaky_relu(x, 0.2)
@@ -124,6 +225,9 @@ def eq_conv(x, p, name, pad, gain=SQRT2):
         return F.conv2d(x, rf(Wn) if _EMULATE_BF16 and Wn.shape[2] == 3 else Wn, p[name + "/b"], padding=pad)
     W = p[name + "/c/W"]
     b = p.get(name + "/c/b")
+    if _EMULATE_MX8 is not None and W.shape[2] == 3 and pad == 1:      # launch by launch: fp8 operands where the engine's are
+        y = _MxFprop.apply(x, inv_c(W.shape[1] * W.shape[2] ** 2, gain) * W)
+        return y if b is None else y + b.reshape(1, -1, 1, 1)
     if _EMULATE_BF16 and W.shape[2] == 3:          # the engine's 3x3 convs read bf16(inv_c * W); its 1x1 planes convs fp32
         return F.conv2d(x, rf(inv_c(W.shape[1] * W.shape[2] ** 2, gain) * W), b, padding=pad)
     return F.conv2d(inv_c(W.shape[1] * W.shape[2] ** 2, gain) * x, W, b, padding=pad)

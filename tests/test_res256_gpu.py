@@ -133,7 +133,7 @@ def test_256px_networks_on_mxfp8_convs_stay_close_to_the_bf16_engine_and_the_ora
 
 
 def test_256px_training_step_on_mxfp8_convs():
-    """`conv_dtype: mxfp8` through build_training: the step is replayed from graphs, the fp8 kernels are the ones that ran
+    """(B = 16: the benched per-GPU batch of configuration 5.)  `conv_dtype: mxfp8` through build_training: the step is replayed from graphs, the fp8 kernels are the ones that ran
     (launch profile of an eager step), losses are finite, parameters move, and the step's parameter gradients keep the
     direction of the bf16 step's from the same weights and inputs (flat-buffer cosine; measured 0.97-0.99)."""
     import os
@@ -144,9 +144,9 @@ def test_256px_training_step_on_mxfp8_convs():
     grads = {}
     for dt in ("bf16", "mxfp8"):
         cfg = yaml_utils.load(os.path.join(root, "configs", "stylegan_shapenet_car.yml"))
-        cfg.ch, cfg.max_resolution, cfg.max_stage, cfg.batchsize, cfg.conv_dtype = 512, 256, 13, 4, dt
-        images = np.random.RandomState(0).randint(0, 256, (16, 3, 256, 256)).astype("uint8")
-        it = DeviceImageIterator(images, 4, "cuda:0", seed=0)
+        cfg.ch, cfg.max_resolution, cfg.max_stage, cfg.batchsize, cfg.conv_dtype = 512, 256, 13, 16, dt
+        images = np.random.RandomState(0).randint(0, 256, (32, 3, 256, 256)).astype("uint8")
+        it = DeviceImageIterator(images, 16, "cuda:0", seed=0)
         np.random.seed(5)
         torch.manual_seed(5)
         gen, dis, opt, upd = build_training(cfg, "cuda:0", iterator=it, fixed_stage=12.0, nan_check_interval=0)
