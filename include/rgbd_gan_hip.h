@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RGBD_ABI_VERSION 14
+#define RGBD_ABI_VERSION 15
 
 int rgbd_abi_version(void);
 const char* rgbd_last_error(void);
@@ -196,16 +196,19 @@ int rgbd_conv2d_wgrad_partial_multi_bf16(const rgbd_wgrad_problem* probs, int n,
 int64_t rgbd_adain_workspace(int B, int HW, int C);   /* floats */
 /* y_q / y_s (here and below; NULL = none): an MXFP8 copy of the bf16 tensor the call stores -- exactly rgbd_quantize_mxfp8 of
  * it, (.., C) bytes + (.., C/32) scale bytes -- for the convolution that reads it next (conv_dtype mxfp8). */
+/* c_live (a multiple of 8 in (0, C]; C for an ordinary tensor): channels [c_live, C) of x are zero padding (a 32-channel
+ * block of the DeepVoxels generator on the engine's 64-channel granularity, deepvoxels_generator.py:112-168): they have no
+ * scale / shift entries -- a fused [scale | shift] window is 2 c_live floats wide, shift = scale + c_live -- and stay zero. */
 int rgbd_adain_fwd(const void* x, const float* scale, const float* shift, void* y,
-                   float* sums, float* mean, float* rstd, int B, int HW, int C, int ld, float eps, void* y_q, void* y_s,
-                   void* stream);
+                   float* sums, float* mean, float* rstd, int B, int HW, int C, int c_live, int ld, float eps, void* y_q,
+                   void* y_s, void* stream);
 /* dy (B,HW,C) bf16 -> dx bf16, dscale/dshift fp32 rows `ld` apart like scale (overwritten).
  * sums: workspace of rgbd_adain_workspace(B,HW,C) floats, as above.
  * lrelu_slope > 0: x is the output of the leaky ReLU feeding this AdaIN (net.py:150-153: conv -> bias -> lrelu -> style)
  *   and dx additionally carries that activation's gradient, dx *= (x > 0 ? 1 : lrelu_slope); bias_grad (C) fp32 or NULL
  *   then accumulates sum_{b,p} dx (the gradient of the L.Bias in front of the activation). */
 int rgbd_adain_bwd(const void* x, const void* dy, const float* scale, const float* mean, const float* rstd,
-                   void* dx, float* dscale, float* dshift, float* sums, int B, int HW, int C, int ld,
+                   void* dx, float* dscale, float* dshift, float* sums, int B, int HW, int C, int c_live, int ld,
                    float lrelu_slope, float* bias_grad, void* dx_q, void* dx_s, void* stream);
 
 /* ------------------------------------------------------------------ small fused elementwise / 1x1 kernels (HBM-bound)

@@ -10,7 +10,7 @@ from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p, POINTER
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RGBD_LIB_PATH: A/B timing of another build of the same ABI; the default is the in-tree library
 LIB_PATH = os.environ.get("RGBD_LIB_PATH") or os.path.join(_HERE, "librgbdgan_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _P = c_void_p
 
@@ -43,8 +43,8 @@ PROTOTYPES = {
     "rgbd_conv2d_wgrad_multi_plan": ([_P, c_int, c_int], c_int),
     "rgbd_conv2d_wgrad_partial_multi_bf16": ([_P, c_int, _P], c_int),
     "rgbd_adain_workspace": ([c_int, c_int, c_int], c_int64),
-    "rgbd_adain_fwd": ([_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P], c_int),
-    "rgbd_adain_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P], c_int),
+    "rgbd_adain_fwd": ([_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, _P], c_int),
+    "rgbd_adain_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P], c_int),
     "rgbd_lrelu_bwd": ([_P, _P, _P, c_int64, c_int, c_int, c_float, _P, _P, c_int64, _P], c_int),
     "rgbd_colsum_bf16": ([_P, _P, c_int64, c_int, c_int, _P, c_int64, _P], c_int),
     "rgbd_axpy_rows_bf16": ([_P, _P, _P, _P, c_int64, c_int64, _P], c_int),

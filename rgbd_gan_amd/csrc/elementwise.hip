@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void adain_apply_kernel(const unsigned short* 
                                                           unsigned short* __restrict__ y, int HW, int C,
                                                           int ld, float inv_hw, float eps, int rows_per_block,
                                                           int nstrips, unsigned char* __restrict__ yq,
-                                                          unsigned char* __restrict__ ys) {
+                                                          unsigned char* __restrict__ ys, int c_live) {
     const int cg = blockIdx.y, b = blockIdx.z;
     const int chunk = threadIdx.x & 7, lane_p = threadIdx.x >> 3;
     const int c0 = cg * 64 + chunk * 8;
@@ -229,8 +229,12 @@ __global__ __launch_bounds__(256) void adain_apply_kernel(const unsigned short* 
     if (r_begin + lane_p < r_end) request(r_begin + lane_p);
     float s1[8], s2[8];
     adain_strip_sum(sums, sidx, (long)gridDim.z * C * 2, nstrips, s1, s2);
-    const f32x4 g0 = *reinterpret_cast<const f32x4*>(scale + aidx), g1 = *reinterpret_cast<const f32x4*>(scale + aidx + 4);
-    const f32x4 h0 = *reinterpret_cast<const f32x4*>(shift + aidx), h1 = *reinterpret_cast<const f32x4*>(shift + aidx + 4);
+    // channels >= c_live are zero padding (a 32-channel block of the DeepVoxels generator on the engine's 64-channel
+    // granularity): no scale / shift exists for them -- the [scale | shift] window is 2 c_live wide -- and they stay zero
+    const bool live = c0 < c_live;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 g0 = live ? *reinterpret_cast<const f32x4*>(scale + aidx) : z4, g1 = live ? *reinterpret_cast<const f32x4*>(scale + aidx + 4) : z4;
+    const f32x4 h0 = live ? *reinterpret_cast<const f32x4*>(shift + aidx) : z4, h1 = live ? *reinterpret_cast<const f32x4*>(shift + aidx + 4) : z4;
     const float gg[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
     const float hh[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
     float m[8], a[8];
@@ -295,7 +299,7 @@ __global__ __launch_bounds__(NT) void adain_bwd_apply_kernel(const unsigned shor
                                                               int HW, int C, float inv_hw, int ld, int rows_per_block,
                                                               float slope, float* __restrict__ bias_grad, int nstrips,
                                                               unsigned char* __restrict__ dxq,
-                                                              unsigned char* __restrict__ dxs) {
+                                                              unsigned char* __restrict__ dxs, int c_live) {
     const int cg = blockIdx.y, b = blockIdx.z;
     const int chunk = threadIdx.x & 7, lane_p = threadIdx.x >> 3;
     const int c0 = cg * 64 + chunk * 8;
@@ -318,13 +322,15 @@ __global__ __launch_bounds__(NT) void adain_bwd_apply_kernel(const unsigned shor
     if (r_begin + lane_p < r_end) request(r_begin + lane_p);
     float s1[8], s2[8];                                 // sum dy, sum dy * xhat
     adain_strip_sum(sums, sidx, (long)gridDim.z * C * 2, nstrips, s1, s2);
-    const f32x4 g0 = *reinterpret_cast<const f32x4*>(scale + aidx), g1 = *reinterpret_cast<const f32x4*>(scale + aidx + 4);
+    const bool live = c0 < c_live;              // (padding channels: scale 0, so dx = 0, and no d scale / d shift entries)
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 g0 = live ? *reinterpret_cast<const f32x4*>(scale + aidx) : z4, g1 = live ? *reinterpret_cast<const f32x4*>(scale + aidx + 4) : z4;
     const f32x4 m0 = *reinterpret_cast<const f32x4*>(mean + sidx), m1 = *reinterpret_cast<const f32x4*>(mean + sidx + 4);
     const f32x4 r0v = *reinterpret_cast<const f32x4*>(rstd + sidx), r1v = *reinterpret_cast<const f32x4*>(rstd + sidx + 4);
     const float gg[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
     const float mm[8] = {m0[0], m0[1], m0[2], m0[3], m1[0], m1[1], m1[2], m1[3]};
     const float rr[8] = {r0v[0], r0v[1], r0v[2], r0v[3], r1v[0], r1v[1], r1v[2], r1v[3]};
-    if (blockIdx.x == 0 && lane_p == 0) {      // d shift = sum dy, d scale = sum dy * xhat (adain.py:76-77)
+    if (blockIdx.x == 0 && lane_p == 0 && live) {      // d shift = sum dy, d scale = sum dy * xhat (adain.py:76-77)
         *reinterpret_cast<f32x4*>(dshift + aidx) = f32x4{s1[0], s1[1], s1[2], s1[3]};
         *reinterpret_cast<f32x4*>(dshift + aidx + 4) = f32x4{s1[4], s1[5], s1[6], s1[7]};
         *reinterpret_cast<f32x4*>(dscale + aidx) = f32x4{s2[0], s2[1], s2[2], s2[3]};
@@ -1248,12 +1254,13 @@ extern "C" int64_t rgbd_adain_workspace(int B, int HW, int C) {
 }
 
 extern "C" int rgbd_adain_fwd(const void* x, const float* scale, const float* shift, void* y, float* sums,
-                              float* mean, float* rstd, int B, int HW, int C, int ld, float eps, void* y_q, void* y_s,
+                              float* mean, float* rstd, int B, int HW, int C, int c_live, int ld, float eps, void* y_q, void* y_s,
                               void* stream) {
     RGBD_REQUIRE(!y_q || (y_s && C % 32 == 0), "rgbd_adain_fwd: the MXFP8 copy needs its scale buffer");
     RGBD_REQUIRE(x && scale && shift && y && sums && mean && rstd, "rgbd_adain_fwd: null pointer");
     RGBD_REQUIRE(ld >= C, "rgbd_adain_fwd: ld must be >= C");
     RGBD_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 64 == 0, "rgbd_adain_fwd: C must be a multiple of 64 (C=%d)", C);
+    RGBD_REQUIRE(c_live > 0 && c_live <= C && c_live % 8 == 0, "rgbd_adain_fwd: c_live must be a multiple of 8 in (0, C] (c_live=%d)", c_live);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(ceil_div(HW, ADAIN_STRIP), C / 64, B);
     adain_reduce_kernel<false><<<grid, 256, 0, st>>>((const unsigned short*)x, nullptr, nullptr, nullptr, sums, HW, C);
@@ -1262,7 +1269,7 @@ extern "C" int rgbd_adain_fwd(const void* x, const float* scale, const float* sh
     dim3 agrid(ceil_div(HW, rows), C / 64, B);
     adain_apply_kernel<<<agrid, 256, 0, st>>>((const unsigned short*)x, scale, shift, sums, mean, rstd,
                                               (unsigned short*)y, HW, C, ld, 1.f / (float)HW, eps, rows, (int)grid.x,
-                                              (unsigned char*)y_q, (unsigned char*)y_s);
+                                              (unsigned char*)y_q, (unsigned char*)y_s, c_live);
     RGBD_CHECK_LAUNCH("adain_apply_kernel");
     return 0;
 }
@@ -1278,15 +1285,16 @@ extern "C" int rgbd_adain_apply_fixed(const void* x, const float* scale, const f
     dim3 agrid(ceil_div(HW, rows), C / 64, B);
     adain_apply_kernel<<<agrid, 256, 0, (hipStream_t)stream>>>((const unsigned short*)x, scale, shift, (const float*)stats,
                                                                 mean, rstd, (unsigned short*)y, HW, C, ld, 1.f / (float)HW,
-                                                                eps, rows, -32, (unsigned char*)y_q, (unsigned char*)y_s);
+                                                                eps, rows, -32, (unsigned char*)y_q, (unsigned char*)y_s, C);
     RGBD_CHECK_LAUNCH("adain_apply_kernel");
     return 0;
 }
 
 extern "C" int rgbd_adain_bwd(const void* x, const void* dy, const float* scale, const float* mean,
                               const float* rstd, void* dx, float* dscale, float* dshift, float* sums, int B,
-                              int HW, int C, int ld, float lrelu_slope, float* bias_grad, void* dx_q, void* dx_s,
+                              int HW, int C, int c_live, int ld, float lrelu_slope, float* bias_grad, void* dx_q, void* dx_s,
                               void* stream) {
+    RGBD_REQUIRE(c_live > 0 && c_live <= C && c_live % 8 == 0, "rgbd_adain_bwd: c_live must be a multiple of 8 in (0, C] (c_live=%d)", c_live);
     RGBD_REQUIRE(!dx_q || dx_s, "rgbd_adain_bwd: the MXFP8 copy needs its scale buffer");
     unsigned char* const qq = (unsigned char*)dx_q;
     unsigned char* const qs = (unsigned char*)dx_s;
@@ -1307,15 +1315,15 @@ extern "C" int rgbd_adain_bwd(const void* x, const void* dy, const float* scale,
         adain_bwd_apply_kernel<true, 1024><<<bgrid, 1024, 0, st>>>((const unsigned short*)x, (const unsigned short*)dy, scale,
                                                                    mean, rstd, sums, (unsigned short*)dx, dscale, dshift, HW,
                                                                    C, 1.f / (float)HW, ld, big_rows, lrelu_slope, bias_grad,
-                                                                   (int)grid.x, qq, qs);
+                                                                   (int)grid.x, qq, qs, c_live);
     } else if (lrelu_slope > 0.f)
         adain_bwd_apply_kernel<true><<<agrid, 256, 0, st>>>((const unsigned short*)x, (const unsigned short*)dy, scale,
                                                             mean, rstd, sums, (unsigned short*)dx, dscale, dshift, HW, C,
-                                                            1.f / (float)HW, ld, rows, lrelu_slope, bias_grad, (int)grid.x, qq, qs);
+                                                            1.f / (float)HW, ld, rows, lrelu_slope, bias_grad, (int)grid.x, qq, qs, c_live);
     else
         adain_bwd_apply_kernel<false><<<agrid, 256, 0, st>>>((const unsigned short*)x, (const unsigned short*)dy, scale,
                                                              mean, rstd, sums, (unsigned short*)dx, dscale, dshift, HW,
-                                                             C, 1.f / (float)HW, ld, rows, 0.f, nullptr, (int)grid.x, qq, qs);
+                                                             C, 1.f / (float)HW, ld, rows, 0.f, nullptr, (int)grid.x, qq, qs, c_live);
     RGBD_CHECK_LAUNCH("adain_bwd_apply_kernel");
     return 0;
 }

@@ -125,12 +125,38 @@ class MappingNetwork3D(_Link):
 
 
 class _StyleMixin:
+    _styles = None          # {style block name: (Fn.StyleGroup, index)} of the pass in flight (device tensors only)
+
+    def _style_group(self, w, names):
+        """The [scale | shift] affines (:96-101) of ALL style blocks `names` of this network -- they share the latent `w` -- as
+        ONE linear over their parameters, which sit back to back in the flat buffer (voxel_specs / renderer_specs), and one
+        shared gradient buffer backward.  A block whose tensor is zero padded to the engine's 64-channel granularity (the
+        32-channel voxel blocks) keeps its unpadded window of 2 co columns: the AdaIN kernels take the live channel count."""
+        p = self.p
+        names_w, names_b, offsets, lives, tot = [], [], [], [], 0
+        for nm in names:
+            full = p.prefix + nm
+            co = self.store.shapes[full + "/s/c/W"][0]
+            names_w += [full + "/s/c/W", full + "/b/c/W"]
+            names_b += [full + "/s/c/b", full + "/b/c/b"]
+            offsets.append(tot)
+            lives.append(co)
+            tot += 2 * co
+        W = self.store.fused(tuple(names_w), (tot, self.w_ch))
+        b = self.store.fused(tuple(names_b), (tot,))
+        ss = Fn.linear_act(w, W, b, _inv_c(self.w_ch, 1.0), act=False)
+        group = Fn.StyleGroup(ss, offsets, lives)
+        return {nm: (group, j) for j, nm in enumerate(names)}
+
     def _style(self, name, w, h):
         """StyleBlock (:96-109): AdaIN(h, s(w), b(w)) over all spatial axes; h is (B, ..., Cpad) bf16."""
         p = self.p
         c = _inv_c(self.w_ch, 1.0)
         C = h.shape[-1]
         full = p.prefix + name
+        if self._styles is not None and name in self._styles:
+            shp = h.shape
+            return Fn.adain_window(h.reshape(shp[0], -1, 1, C), *self._styles[name]).reshape(shp)
         if h.is_cuda and self.store.shapes[full + "/s/c/W"][0] == C:
             # scale and shift affines sit back to back in the flat buffer: one linear, [scale | shift] read in place
             W = self.store.fused((full + "/s/c/W", full + "/b/c/W"), (2 * C, self.w_ch))
@@ -156,10 +182,15 @@ def voxel_specs(prefix, ch, ch_out):
             specs.append((pre + "/W", (ci, 4, 4, 4), "ones"))
         specs += [(pre + "/b0/b", (co,), "zeros"), (pre + "/b1/b", (co,), "zeros"),
                   (pre + "/n0/b/W", (co,), "zeros"), (pre + "/n1/b/W", (co,), "zeros")]
-        for s in ("s0", "s1"):          # [scale W | shift W], then [scale b | shift b]: adjacent pairs (ParamStore.fused)
-            specs += [(f"{pre}/{s}/s/c/W", (co, ch), "normal"), (f"{pre}/{s}/b/c/W", (co, ch), "normal"),
-                      (f"{pre}/{s}/s/c/b", (co,), "ones"), (f"{pre}/{s}/b/c/b", (co,), "zeros")]
         specs += [(pre + "/c0/c/W", (co, ci, 3, 3, 3), "normal"), (pre + "/c1/c/W", (co, co, 3, 3, 3), "normal")]
+    # the style affines of ALL blocks back to back, [scale W | shift W] block by block in the order the forward pass runs
+    # them, and their biases likewise: one matrix, one linear per pass (_StyleMixin._style_group)
+    for i, (co, ci) in enumerate(voxel_channels(ch)):
+        for s in ("s0", "s1"):
+            specs += [(f"{prefix}net/{i}/{s}/s/c/W", (co, ch), "normal"), (f"{prefix}net/{i}/{s}/b/c/W", (co, ch), "normal")]
+    for i, (co, ci) in enumerate(voxel_channels(ch)):
+        for s in ("s0", "s1"):
+            specs += [(f"{prefix}net/{i}/{s}/s/c/b", (co,), "ones"), (f"{prefix}net/{i}/{s}/b/c/b", (co,), "zeros")]
     specs += [(prefix + "out/c/W", (ch_out, ch // 8, 1, 1, 1), "normal"), (prefix + "out/c/b", (ch_out,), "zeros")]
     return specs
 
@@ -224,8 +255,12 @@ class VoxelGenerator(_Link, _StyleMixin):
         """feature_minor: return (B,32,32,32,ch_out) fp32 -- the conv stack's own layout, which the frustum resampling reads
         directly (rgbd_trilinear_fwd_fm) -- instead of the reference's (B,ch_out,32,32,32)."""
         h = None
-        for i in range(4):
-            h = self._block(i, w, h)
+        self._styles = self._style_group(w, [f"net/{i}/{s}" for i in range(4) for s in ("s0", "s1")]) if w.is_cuda else None
+        try:
+            for i in range(4):
+                h = self._block(i, w, h)
+        finally:
+            self._styles = None
         B, D, H, W, C = h.shape
         y = Fn.conv_bias(h.reshape(B * D, H, W, C), self.out, _pad_to(self.p["out/c/b"], _ceil64(self.ch_out)))
         y = y.reshape(B, D, H, W, -1)[..., :self.ch_out]
@@ -253,10 +288,11 @@ def renderer_specs(prefix, w_ch, in_ch, hidden):
              "c6": (h, 4 * h, 3), "c7": (3, h + in_ch, 3)}
     for name, (co, ci, k) in convs.items():
         specs += [(f"{prefix}{name}/c/W", (co, ci, k, k), "normal"), (f"{prefix}{name}/c/b", (co,), "zeros")]
-    for name, co in {"s0": 2 * h, "s1": 4 * h, "s4": 4 * h, "s5": 2 * h, "s6": h}.items():
-        pre = f"{prefix}{name}"
-        specs += [(pre + "/s/c/W", (co, w_ch), "normal"), (pre + "/b/c/W", (co, w_ch), "normal"),
-                  (pre + "/s/c/b", (co,), "ones"), (pre + "/b/c/b", (co,), "zeros")]
+    styles = {"s0": 2 * h, "s1": 4 * h, "s4": 4 * h, "s5": 2 * h, "s6": h}      # forward order; all W's, then all b's (one linear)
+    for name, co in styles.items():
+        specs += [(f"{prefix}{name}/s/c/W", (co, w_ch), "normal"), (f"{prefix}{name}/b/c/W", (co, w_ch), "normal")]
+    for name, co in styles.items():
+        specs += [(f"{prefix}{name}/s/c/b", (co,), "ones"), (f"{prefix}{name}/b/c/b", (co,), "zeros")]
     return specs
 
 
@@ -287,13 +323,17 @@ class StyleGenerator(_Link, _StyleMixin):
         L = self.layers
         x = h.permute(0, 2, 3, 1).to(BF16).contiguous()                                     # (B,64,64,32)
         fold = Fn.fold_4x4s2 if x.is_cuda else fold_4x4s2
-        h1 = self._style("s0", w, Fn.conv_bias_lrelu(fold(x), L["c0"], p["c0/c/b"]))
-        h2 = self._style("s1", w, Fn.conv_bias_lrelu(fold(h1), L["c1"], p["c1/c/b"]))
-        h3 = self._style("s4", w, Fn.conv_bias_lrelu(h2, L["c4"], p["c4/c/b"]))
-        h3 = Fn.conv_bias_lrelu(h3, L["c5"], p["c5/c/b"], upsample=True)
-        h3 = torch.cat([self._style("s5", w, h3), h1], dim=-1)
-        h3 = Fn.conv_bias_lrelu(h3, L["c6"], p["c6/c/b"], upsample=True)
-        h3 = torch.cat([self._style("s6", w, h3), x], dim=-1)
+        self._styles = self._style_group(w, ["s0", "s1", "s4", "s5", "s6"]) if w.is_cuda else None
+        try:
+            h1 = self._style("s0", w, Fn.conv_bias_lrelu(fold(x), L["c0"], p["c0/c/b"]))
+            h2 = self._style("s1", w, Fn.conv_bias_lrelu(fold(h1), L["c1"], p["c1/c/b"]))
+            h3 = self._style("s4", w, Fn.conv_bias_lrelu(h2, L["c4"], p["c4/c/b"]))
+            h3 = Fn.conv_bias_lrelu(h3, L["c5"], p["c5/c/b"], upsample=True)
+            h3 = torch.cat([self._style("s5", w, h3), h1], dim=-1)
+            h3 = Fn.conv_bias_lrelu(h3, L["c6"], p["c6/c/b"], upsample=True)
+            h3 = torch.cat([self._style("s6", w, h3), x], dim=-1)
+        finally:
+            self._styles = None
         h3 = _pad_to(h3, _ceil64(h3.shape[-1]))
         out = Fn.conv_bias(h3, L["c7"], _pad_to(p["c7/c/b"], 64))
         return out[..., :3].permute(0, 3, 1, 2).float().contiguous()

@@ -548,14 +548,17 @@ class StyleGroup:
     writes its window of one shared gradient buffer; the block that ran FIRST in the forward (its backward runs last:
     every later block depends on its output) hands that buffer to autograd as the gradient of `ss`."""
 
-    def __init__(self, ss, offsets):
-        self.ss, self.offsets, self.dss = ss, offsets, None
+    def __init__(self, ss, offsets, lives=None):
+        # lives[j] (or None): the live channel count of block j when its tensor is zero padded beyond it (a 32-channel block
+        # of the DeepVoxels generator on 64-channel tensors): its window is 2 lives[j] columns wide (kernels.adain_fwd c_live)
+        self.ss, self.offsets, self.dss, self.lives = ss, offsets, None, lives
 
 
 class _AdaINWindow(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, ss, group, j):
-        y, mean, rstd = kernels.adain_fwd(x.contiguous(), ss, col_off=group.offsets[j])
+        y, mean, rstd = kernels.adain_fwd(x.contiguous(), ss, col_off=group.offsets[j],
+                                          c_live=group.lives[j] if group.lives else None)
         ctx.group, ctx.j = group, j
         ctx.save_for_backward(x, ss, mean, rstd)
         return y
@@ -568,7 +571,7 @@ class _AdaINWindow(torch.autograd.Function):
         if g.dss is None:
             g.dss = torch.empty_like(ss)
         dx, _, _ = kernels.adain_bwd(x.contiguous(), dy.contiguous(), ss, mean, rstd, fused=True,
-                                     col_off=g.offsets[ctx.j], out=g.dss)
+                                     col_off=g.offsets[ctx.j], out=g.dss, c_live=g.lives[ctx.j] if g.lives else None)
         if ctx.j == 0:
             dss, g.dss = g.dss, None
             return dx, dss, None, None

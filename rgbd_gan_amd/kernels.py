@@ -539,6 +539,40 @@ def conv3x3_actgrad(x, wp, act_y, residual=None, bias_grad=None, row_scale=None,
     return y if y2 is None else (y, y2)
 
 
+class _StatsPool:
+    """Zeroed int64 scratch for the instance-norm statistics of the `stats` conv epilogues (integer atomics ADD into them).
+    A training step clears the whole pool with the launch that clears its gradient buffers (begin_step: one more pointer in
+    kernels.zero_multi) and the convolutions of the step take consecutive slices -- instead of one torch fill launch per
+    layer (eight per step, the last torch `zeros` on it).  The take sequence of a step is fixed, so a captured step finds the
+    same slices on every replay; a caller outside a step, or a pool that is still too small (the first step), falls back to
+    a fresh torch.zeros and the pool grows at the next begin_step."""
+
+    def __init__(self):
+        self.buf, self.off, self.used, self._retired = None, 0, 0, []
+
+    def take(self, n, device):
+        self.used += n
+        if self.buf is None or self.buf.device != device or self.off + n > self.buf.numel():
+            return None
+        v = self.buf[self.off:self.off + n]
+        self.off += n
+        return v
+
+    def begin_step(self, device, defer):
+        """Start of a step (a prep phase, before any conv of the step): grow to what the last step asked for, hand the pool
+        to the caller's zero launch, rewind."""
+        device = torch.device(device)
+        if self.buf is None or self.buf.device != device or self.used > self.buf.numel():
+            if self.buf is not None:
+                self._retired.append(self.buf)      # steps captured as HIP graphs keep clearing and using the pool they saw
+            self.buf = torch.empty(max(2 * self.used, 1 << 17), dtype=torch.int64, device=device)
+        self.off, self.used = 0, 0
+        defer.append(self.buf.view(F32))
+
+
+STATS_POOL = _StatsPool()
+
+
 def conv2d_fprop_stats(x, wp, bias, upsample=False, lrelu_channels=0, slope=0.2):
     """3x3 pad-1 conv (+ nearest-2x upsample in front) + bias + leaky ReLU like conv2d_fprop, and the per-(sample, channel)
     (sum y, sum y^2) of the stored values as (B,Cout,2) int64 in units of 2^-32 (for adain_apply_fixed).  Output images must
@@ -551,7 +585,8 @@ def conv2d_fprop_stats(x, wp, bias, upsample=False, lrelu_channels=0, slope=0.2)
     if T != 9 or Cin2 != Cin:
         raise RuntimeError(f"conv2d_fprop_stats: weights {tuple(wp.shape)} do not match x {tuple(x.shape)}")
     y = torch.empty(B, Hout, Wout, Cout, dtype=BF16, device=x.device)
-    stats = torch.zeros(B, Cout, 2, dtype=torch.int64, device=x.device)
+    stats = STATS_POOL.take(B * Cout * 2, x.device)
+    stats = stats.view(B, Cout, 2) if stats is not None else torch.zeros(B, Cout, 2, dtype=torch.int64, device=x.device)
     lib = _lib.load()
     flops = 2.0 * B * Hout * Wout * Cout * Cin * 9
     nbytes = 2.0 * (x.numel() + y.numel() + wp.numel())
@@ -875,16 +910,20 @@ def _off(t, nfloats):
     return ctypes.c_void_p(t.data_ptr() + 4 * nfloats)
 
 
-def adain_fwd(x, scale, shift=None, eps=1e-5, col_off=0, emit_mx8=False):
+def adain_fwd(x, scale, shift=None, eps=1e-5, col_off=0, emit_mx8=False, c_live=None):
     """x (B,H,W,C) bf16; scale, shift (B,C) fp32 -- or shift None and scale = (B,Wtot) fp32 whose columns
     [col_off, col_off + 2C) hold [scale | shift] (the fused style-affine output, possibly of several style blocks)
-    -> y, mean, rstd."""
+    -> y, mean, rstd.  c_live < C (fused form only): channels [c_live, C) of x are zero padding, the window is
+    [col_off, col_off + 2 c_live) and the padding channels of y stay zero."""
     _chk(x, BF16, "x"); _chk(scale, F32, "scale"); _chk(shift, F32, "shift")
     B, H, W, C = x.shape
     fused = shift is None
+    live = C if c_live is None else int(c_live)
+    if live != C and (not fused or live % 8 or not 0 < live < C):
+        raise RuntimeError(f"adain_fwd: c_live={c_live} needs the fused form and a multiple of 8 below C={C}")
     if fused:
-        if scale.dim() != 2 or scale.shape[0] != B or col_off % 4 or col_off + 2 * C > scale.shape[1]:
-            raise RuntimeError(f"adain_fwd: window [{col_off},{col_off + 2 * C}) outside {tuple(scale.shape)}")
+        if scale.dim() != 2 or scale.shape[0] != B or col_off % 4 or col_off + 2 * live > scale.shape[1]:
+            raise RuntimeError(f"adain_fwd: window [{col_off},{col_off + 2 * live}) outside {tuple(scale.shape)}")
         ld = scale.shape[1]
     elif scale.shape != (B, C):
         raise RuntimeError(f"adain_fwd: scale {tuple(scale.shape)} does not match x {tuple(x.shape)}")
@@ -894,15 +933,16 @@ def adain_fwd(x, scale, shift=None, eps=1e-5, col_off=0, emit_mx8=False):
     rstd = torch.empty(B, C, dtype=F32, device=x.device)
     yq, ysc = _mx8_side(y, emit_mx8)
     rc = _lib.load().rgbd_adain_fwd(_ptr(x), _off(scale, col_off) if fused else _ptr(scale),
-                                    _off(scale, col_off + C) if fused else _ptr(shift), _ptr(y), _ptr(sums),
-                                    _ptr(mean), _ptr(rstd), B, H * W, C, ld if fused else C, float(eps), _ptr(yq), _ptr(ysc),
-                                    _stream())
+                                    _off(scale, col_off + live) if fused else _ptr(shift), _ptr(y), _ptr(sums),
+                                    _ptr(mean), _ptr(rstd), B, H * W, C, live, ld if fused else C, float(eps), _ptr(yq),
+                                    _ptr(ysc), _stream())
     _lib.check(rc, "rgbd_adain_fwd")
     _mx8_attach(y, yq, ysc)
     return y, mean, rstd
 
 
-def adain_bwd(x, dy, scale, mean, rstd, fused=False, col_off=0, out=None, lrelu_slope=0.0, bias_grad=None, emit_mx8=False):
+def adain_bwd(x, dy, scale, mean, rstd, fused=False, col_off=0, out=None, lrelu_slope=0.0, bias_grad=None, emit_mx8=False,
+              c_live=None):
     """-> dx, dscale, dshift; with fused (scale = (B,Wtot), window [col_off, col_off + 2C) = [scale | shift]):
     dx, d[scale | shift] written into the same window of `out` (B,Wtot) (allocated when None), None.
     lrelu_slope > 0: x is a leaky-ReLU output and dx also carries that activation's gradient; bias_grad (C) fp32 then
@@ -910,6 +950,9 @@ def adain_bwd(x, dy, scale, mean, rstd, fused=False, col_off=0, out=None, lrelu_
     _chk(x, BF16, "x"); _chk(dy, BF16, "dy"); _chk(scale, F32, "scale"); _chk(out, F32, "out")
     _chk(bias_grad, F32, "bias_grad")
     B, H, W, C = x.shape
+    live = C if c_live is None else int(c_live)       # (see adain_fwd: a window of 2 c_live columns, padding channels stay 0)
+    if live != C and (not fused or live % 8 or not 0 < live < C):
+        raise RuntimeError(f"adain_bwd: c_live={c_live} needs the fused form and a multiple of 8 below C={C}")
     dx = torch.empty_like(x)
     sums = _adain_workspace(B, H * W, C, x.device)
     if fused:
@@ -917,14 +960,14 @@ def adain_bwd(x, dy, scale, mean, rstd, fused=False, col_off=0, out=None, lrelu_
         dss = out if out is not None else torch.empty(B, ld, dtype=F32, device=x.device)
         if dss.shape != scale.shape:
             raise RuntimeError("adain_bwd: gradient buffer shape mismatch")
-        sc, dscale, dshift = _off(scale, col_off), _off(dss, col_off), _off(dss, col_off + C)
+        sc, dscale, dshift = _off(scale, col_off), _off(dss, col_off), _off(dss, col_off + live)
     else:
         ds = torch.empty(B, C, dtype=F32, device=x.device)
         dsh = torch.empty(B, C, dtype=F32, device=x.device)
         sc, dscale, dshift, ld = _ptr(scale), _ptr(ds), _ptr(dsh), C
     dxq, dxs = _mx8_side(dx, emit_mx8)
     rc = _lib.load().rgbd_adain_bwd(_ptr(x), _ptr(dy), sc, _ptr(mean), _ptr(rstd), _ptr(dx), dscale,
-                                    dshift, _ptr(sums), B, H * W, C, ld, float(lrelu_slope), _ptr(bias_grad),
+                                    dshift, _ptr(sums), B, H * W, C, live, ld, float(lrelu_slope), _ptr(bias_grad),
                                     _ptr(dxq), _ptr(dxs), _stream())
     _lib.check(rc, "rgbd_adain_bwd")
     _mx8_attach(dx, dxq, dxs)

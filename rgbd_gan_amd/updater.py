@@ -309,6 +309,7 @@ class RGBDUpdater:
         for link in (self.gen, self.dis):
             for _, store in link.stores:
                 store.zero_grad(defer=bufs)
+        kernels.STATS_POOL.begin_step(self.device, bufs)           # + the step's instance-norm statistics scratch
         kernels.zero_multi(bufs)                                   # one launch for all flat gradient buffers
         if st.get("real_idx") is not None:
             # the uint8 data set lives in HBM: gather + x/127.5 - 1 + downsize_real (block means, fade-in blend) in ONE
