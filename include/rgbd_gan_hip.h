@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RGBD_ABI_VERSION 15
+#define RGBD_ABI_VERSION 16
 
 int rgbd_abi_version(void);
 const char* rgbd_last_error(void);
@@ -367,6 +367,14 @@ int rgbd_pad_last(const void* x, void* y, int64_t rows, int C0, int C1, int elem
  * pggan.py:27-38]; mode 1: (Co,Ci,4,4) -> (Cop,16*Cip,1,1) [:191-205]; mode 2: (Co,Ci,K,K) -> (Cop,Cip,K,K) (zero padding). */
 int rgbd_fold_weight_f32(const float* src, float* dst, int mode, int Co, int Ci, int K, int Cop, int Cip, int adjoint,
                          void* stream);
+/* The same for n layers in ONE launch (a network's folds on a rebuild of its weight images; the adjoints behind a backward
+ * pass): descs is a HOST array, copied by value into the kernel arguments. */
+typedef struct rgbd_fold_desc {
+    const float* src;
+    float* dst;
+    int32_t mode, Co, Ci, K, Cop, Cip, adjoint, reserved;
+} rgbd_fold_desc;
+int rgbd_fold_weight_multi_f32(const rgbd_fold_desc* descs, int n, void* stream);
 int rgbd_trilinear_fwd(const float* grid, const int32_t* idx, const float* coords, const int32_t* counts, float* out,
                        int B, int F, int G, int N, void* stream);
 int rgbd_trilinear_bwd(const float* dout, const int32_t* idx, const float* coords, const int32_t* counts, float* dgrid,

@@ -10,7 +10,7 @@ from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p, POINTER
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RGBD_LIB_PATH: A/B timing of another build of the same ABI; the default is the in-tree library
 LIB_PATH = os.environ.get("RGBD_LIB_PATH") or os.path.join(_HERE, "librgbdgan_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _P = c_void_p
 
@@ -36,6 +36,7 @@ PROTOTYPES = {
     "rgbd_fold_4x4s2_bf16": ([_P, _P, c_int, c_int, c_int, c_int, c_int, _P], c_int),
     "rgbd_pad_last": ([_P, _P, c_int64, c_int, c_int, c_int, _P], c_int),
     "rgbd_fold_weight_f32": ([_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P], c_int),
+    "rgbd_fold_weight_multi_f32": ([_P, c_int, _P], c_int),
     "rgbd_conv2d_wgrad_workspace": ([c_int, c_int, c_int, c_int, c_int, c_int], c_int64),
     "rgbd_conv2d_wgrad_bf16": ([_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int, _P], c_int),
     "rgbd_conv2d_wgrad_partial_bf16": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P], c_int),

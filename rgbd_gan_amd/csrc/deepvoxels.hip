@@ -850,6 +850,70 @@ __global__ __launch_bounds__(256) void fold_weight_kernel(const float* __restric
 }
 }  // namespace
 
+// Up to FOLD_MULTI_MAX folds (or adjoints) in ONE launch: the DeepVoxels generator has 18 derived layers, whose folds are a few
+// microseconds each and were a launch each, on every rebuild of the weight images and again (adjoint) behind every backward
+// pass.  Descriptors by value in the kernel arguments; blocks are dealt out by element count.
+namespace {
+constexpr int FOLD_MULTI_MAX = 32;
+struct FoldMultiArgs {
+    const float* src[FOLD_MULTI_MAX];
+    float* dst[FOLD_MULTI_MAX];
+    FoldW f[FOLD_MULTI_MAX];
+    long n_folded[FOLD_MULTI_MAX], n_master[FOLD_MULTI_MAX];
+    int adjoint[FOLD_MULTI_MAX];
+    int block_begin[FOLD_MULTI_MAX + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void fold_weight_multi_kernel(FoldMultiArgs m) {
+    int i = 0;
+    while (i + 1 < m.n && (int)blockIdx.x >= m.block_begin[i + 1]) ++i;          // block-uniform scan
+    const FoldW f = m.f[i];
+    const int adjoint = m.adjoint[i];
+    const long total = adjoint ? m.n_master[i] : m.n_folded[i];
+    const float* __restrict__ src = m.src[i];
+    float* __restrict__ dst = m.dst[i];
+    const int nb = m.block_begin[i + 1] - m.block_begin[i];
+    for (long e = (long)((int)blockIdx.x - m.block_begin[i]) * 256 + threadIdx.x; e < total; e += (long)nb * 256) {
+        if (adjoint) {
+            const float v = src[fold_w_folded_index(f, e)];
+            dst[e] = adjoint == 2 ? dst[e] + v : v;
+        } else {
+            const long mi = fold_w_master_index(f, e);
+            dst[e] = mi >= 0 ? src[mi] : 0.f;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int rgbd_fold_weight_multi_f32(const rgbd_fold_desc* descs, int n, void* stream) {
+    RGBD_REQUIRE(descs && n > 0, "rgbd_fold_weight_multi_f32: no descriptors");
+    for (int g0 = 0; g0 < n; g0 += FOLD_MULTI_MAX) {
+        FoldMultiArgs m;
+        m.n = n - g0 < FOLD_MULTI_MAX ? n - g0 : FOLD_MULTI_MAX;
+        int blocks = 0;
+        for (int i = 0; i < m.n; ++i) {
+            const rgbd_fold_desc& d = descs[g0 + i];
+            RGBD_REQUIRE(d.src && d.dst && d.mode >= 0 && d.mode <= 2 && d.Co > 0 && d.Ci > 0 && d.Cop >= d.Co && d.Cip >= d.Ci &&
+                         d.K > 0 && (d.mode != 0 || d.K == 3) && (d.mode != 1 || d.K == 4) && d.adjoint >= 0 && d.adjoint <= 2,
+                         "rgbd_fold_weight_multi_f32: bad descriptor %d", g0 + i);
+            m.src[i] = d.src; m.dst[i] = d.dst; m.adjoint[i] = d.adjoint;
+            m.f[i] = FoldW{d.mode, d.Co, d.Ci, d.K, d.Cop, d.Cip};
+            m.n_master[i] = (long)d.Co * d.Ci * (d.mode == 0 ? 27 : d.K * d.K);
+            m.n_folded[i] = d.mode == 0 ? (long)d.Cop * 3 * d.Cip * 9 : d.mode == 1 ? (long)d.Cop * 16 * d.Cip
+                                                                                     : (long)d.Cop * d.Cip * d.K * d.K;
+            const long total = d.adjoint ? m.n_master[i] : m.n_folded[i];
+            long nb = (total + 1023) / 1024;              // four elements per thread
+            if (nb > 256) nb = 256;
+            m.block_begin[i] = blocks;
+            blocks += (int)nb;
+        }
+        m.block_begin[m.n] = blocks;
+        fold_weight_multi_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(m);
+        RGBD_CHECK_LAUNCH("fold_weight_multi_kernel");
+    }
+    return 0;
+}
+
 extern "C" int rgbd_fold_weight_f32(const float* src, float* dst, int mode, int Co, int Ci, int K, int Cop, int Cip, int adjoint,
                                     void* stream) {
     RGBD_REQUIRE(src && dst && mode >= 0 && mode <= 2 && Co > 0 && Ci > 0 && Cop >= Co && Cip >= Ci && K > 0,

@@ -235,11 +235,13 @@ class DerivedPackGroup(PackGroup):
 
     def repack(self):
         with torch.no_grad():
+            folds = []
             for l in self.layers:
                 if isinstance(l, DerivedConvLayer):
                     mode, cop, cip = l.fold
-                    m = l.master.detach()
-                    kernels.fold_weight(m, mode, m.shape[0], m.shape[1], m.shape[-1], cop, cip, out=l._fold_buf)
+                    m = l.master.detach().contiguous()
+                    folds.append((m, l._fold_buf, mode, m.shape[0], m.shape[1], m.shape[-1], cop, cip, False))
+            kernels.fold_weight_multi(folds)                       # all folds of the network: one launch
             kernels.pack_weights_multi(self.table)
         for l in self.layers:
             l._epoch = l._now()
@@ -309,11 +311,12 @@ def deferred_wgrads(items):
 
 def run_deferred_wgrads(items):
     kernels.conv2d_wgrad_batch([it[:7] for it in items])
+    folds = []
     for it in items:
         if len(it) > 7:                       # derived layer: folded gradient -> master gradient (accumulating adjoint)
             master, (mode, cop, cip) = it[7]
-            kernels.fold_weight(it[2], mode, master.shape[0], master.shape[1], master.shape[-1], cop, cip, adjoint=True,
-                                out=master.grad)
+            folds.append((it[2], master.grad, mode, master.shape[0], master.shape[1], master.shape[-1], cop, cip, True))
+    kernels.fold_weight_multi(folds)          # ... of all derived layers of the pass: one launch
 
 
 def _derived_deferrable(layer):

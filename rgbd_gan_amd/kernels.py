@@ -1322,6 +1322,29 @@ def pad_last(x, C1):
     return y
 
 
+class _FoldDesc(ctypes.Structure):          # struct rgbd_fold_desc (include/rgbd_gan_hip.h)
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p)] + \
+               [(n, ctypes.c_int32) for n in ("mode", "Co", "Ci", "K", "Cop", "Cip", "adjoint", "reserved")]
+
+
+def fold_weight_multi(items):
+    """fold_weight for several layers in ONE launch.  items: (src, dst, mode, Co, Ci, K, Cop, Cip, adjoint) with dst the
+    contiguous destination (folded buffer of a forward fold; master-shaped gradient, ACCUMULATED into, of an adjoint)."""
+    if not items:
+        return
+    descs = (_FoldDesc * len(items))()
+    for d, (src, dst, mode, Co, Ci, K, Cop, Cip, adjoint) in zip(descs, items):
+        _chk(src, F32, "src"); _chk(dst, F32, "dst")
+        folded = (Cop, 3 * Cip, 3, 3) if mode == 0 else (Cop, 16 * Cip, 1, 1) if mode == 1 else (Cop, Cip, K, K)
+        master = (Co, Ci, 3, 3, 3) if mode == 0 else (Co, Ci, K, K)
+        if tuple(src.shape) != (folded if adjoint else master) or tuple(dst.shape) != (master if adjoint else folded) \
+                or not dst.is_contiguous():
+            raise RuntimeError(f"fold_weight_multi: mode {mode}: src {tuple(src.shape)} dst {tuple(dst.shape)}")
+        d.src, d.dst = src.data_ptr(), dst.data_ptr()
+        d.mode, d.Co, d.Ci, d.K, d.Cop, d.Cip, d.adjoint = mode, Co, Ci, K, Cop, Cip, (2 if adjoint else 0)
+    _lib.check(_lib.load().rgbd_fold_weight_multi_f32(descs, len(items), _stream()), "rgbd_fold_weight_multi_f32")
+
+
 def fold_weight(src, mode, Co, Ci, K, Cop, Cip, adjoint=False, out=None):
     """mode 0: (Co,Ci,3,3,3) -> (Cop,3*Cip,3,3); 1: (Co,Ci,4,4) -> (Cop,16*Cip,1,1); 2: (Co,Ci,K,K) -> (Cop,Cip,K,K); fp32.
     adjoint: src is the folded weight's gradient, the result the master's; with `out` (master-shaped, contiguous) the adjoint is

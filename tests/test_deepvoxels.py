@@ -199,3 +199,33 @@ def test_fold_weight_matches_torch_and_its_backward_is_the_adjoint(mode, shape):
     assert torch.equal(got.cpu(), ref.detach())
     got.backward(dy.cuda())
     assert torch.equal(Wd.grad.cpu(), Wr.grad)
+
+
+@pytest.mark.gpu
+def test_fold_weight_multi_matches_the_single_launches():
+    """rgbd_fold_weight_multi_f32 (all folds of a network / all adjoints of a backward pass in one launch) against
+    rgbd_fold_weight_f32 layer by layer: identical bytes forward, identical accumulated gradients backward."""
+    from rgbd_gan_amd import kernels
+    g = torch.Generator().manual_seed(11)
+    layers = [(0, (32, 64, 3, 3, 3), 64, 64), (0, (64, 64, 3, 3, 3), 64, 64), (1, (512, 32, 4, 4), 512, 64),
+              (2, (3, 288, 3, 3), 64, 320), (2, (32, 32, 1, 1), 64, 64), (0, (64, 32, 3, 3, 3), 64, 64)]
+    fwd, adj, refs_f, refs_a = [], [], [], []
+    for mode, shape, cop, cip in layers:
+        W = torch.randn(*shape, generator=g).cuda()
+        Co, Ci, K = shape[0], shape[1], shape[-1]
+        ref = kernels.fold_weight(W, mode, Co, Ci, K, cop, cip)
+        out = torch.full_like(ref, float("nan"))
+        fwd.append((W, out, mode, Co, Ci, K, cop, cip, False))
+        refs_f.append(ref)
+        dy = torch.randn(ref.shape, generator=g).cuda()
+        base = torch.randn(*shape, generator=g).cuda()
+        acc_ref = kernels.fold_weight(dy, mode, Co, Ci, K, cop, cip, adjoint=True, out=base.clone())
+        acc = base.clone()
+        adj.append((dy, acc, mode, Co, Ci, K, cop, cip, True))
+        refs_a.append(acc_ref)
+    kernels.fold_weight_multi(fwd)
+    kernels.fold_weight_multi(adj)
+    for it, ref in zip(fwd, refs_f):
+        assert torch.equal(it[1], ref), it[2:8]
+    for it, ref in zip(adj, refs_a):
+        assert torch.equal(it[1], ref), it[2:8]
