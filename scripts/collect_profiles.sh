@@ -69,6 +69,15 @@ python3 scripts/timeline.py $T > profiles/$R/trace_timeline.txt 2>&1
 rm -f $T
 python3 scripts/time_planes.py > profiles/$R/time_planes_alone.txt 2>/dev/null
 python3 scripts/time_small_ops.py > profiles/$R/time_small_ops_alone.txt 2>/dev/null
+# (the figures of time_small_ops.py are host-paced launch pairs; the kernels' own durations of the same script under the tracer:)
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/smallops -o s -- python3 scripts/time_small_ops.py > gpurun_out/$R/smallops.log 2>&1
+cp $(find gpurun_out/$R/smallops -name 's_kernel_stats.csv' | head -1) profiles/$R/time_small_ops_kernel_stats.csv
+rm -rf gpurun_out/$R/smallops
+# ---- the phases' timeline from events (no tracer), and which torch ops still launch kernels in a step (default config, config 4)
+python3 scripts/phase_timeline.py > profiles/$R/phase_timeline.txt 2>/dev/null
+python3 scripts/phases_alone.py > profiles/$R/phases_alone.txt 2>/dev/null
+python3 scripts/torch_op_sources.py 2>/dev/null | grep -v amdgpu.ids > profiles/$R/torch_op_sources.txt
+python3 scripts/torch_op_sources.py 200000 configs/deepvoxels_shapenet_car.yml 2>/dev/null | grep -v amdgpu.ids > profiles/$R/torch_op_sources_c4.txt
 python3 bench.py > profiles/$R/bench_default.json 2> gpurun_out/$R/default.err
 cp profiles/$R/*.csv profiles/$R/*.json profiles/$R/*.txt gpurun_out/$R/ 2>/dev/null
 ls -la profiles/$R

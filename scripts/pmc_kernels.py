@@ -8,7 +8,8 @@ import collections, csv, glob, os, re, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import kernel_source_sha16
 
-FAMILIES = {"conv3x3_sp_kernel": "conv3x3_sp_kernel", "conv3x3_patch_kernel": "conv3x3_patch_kernel", "conv_wgrad": "conv_wgrad",
+FAMILIES = {"conv3x3_sp_kernel": "conv3x3_sp_kernel", "conv3x3_patch_kernel": "conv3x3_patch_kernel",
+            "conv3x3_dw_kernel": "conv3x3_dw_kernel", "conv_wgrad": "conv_wgrad",
             "conv_fprop_kernel": "conv_fprop_kernel", "quantize_mx8_kernel": "quantize_mx8_kernel"}
 
 

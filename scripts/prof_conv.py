@@ -17,12 +17,12 @@ for H, Cin, Cout in shapes:
     wf, wd = kernels.pack_weights(w, float(np.sqrt(2.0 / (Cin * 9))))
     # both generations of each kernel in the same pass (same box, same counters): the register-staged references
     # (variants 1 / 3) first, then the shipped LDS-DMA kernels (variant 0)
-    for variant in (1, 3, 0):
+    for variant in (1, 3, 7, 0):          # 7: round 5's dual-workgroup A/B kernel (128-channel tiles), same pass as the shipped one
         lib.rgbd_debug_conv_variant(variant)
         for _ in range(reps):
             if "fprop" in which and variant != 3:
                 kernels.conv2d_fprop(x, wf, 3, 3, 1, bias=bias, lrelu_channels=Cout)
-            if "wgrad" in which and variant != 1:
+            if "wgrad" in which and variant not in (1, 7):
                 kernels.conv2d_wgrad(x, dy, 3, 1.0)
         torch.cuda.synchronize()
     lib.rgbd_debug_conv_variant(0)
