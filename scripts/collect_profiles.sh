@@ -80,4 +80,5 @@ python3 scripts/torch_op_sources.py 2>/dev/null | grep -v amdgpu.ids > profiles/
 python3 scripts/torch_op_sources.py 200000 configs/deepvoxels_shapenet_car.yml 2>/dev/null | grep -v amdgpu.ids > profiles/$R/torch_op_sources_c4.txt
 python3 bench.py > profiles/$R/bench_default.json 2> gpurun_out/$R/default.err
 cp profiles/$R/*.csv profiles/$R/*.json profiles/$R/*.txt gpurun_out/$R/ 2>/dev/null
+mkdir -p gpurun_out/$R/mx8 && cp profiles/$R/mx8/* gpurun_out/$R/mx8/ 2>/dev/null
 ls -la profiles/$R
