@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RGBD_ABI_VERSION 16
+#define RGBD_ABI_VERSION 17
 
 int rgbd_abi_version(void);
 const char* rgbd_last_error(void);
@@ -299,6 +299,11 @@ int rgbd_real_batch_u8(const uint8_t* data, const int64_t* idx, float* out, int 
                        const float* alpha_device, float alpha, void* stream);
 int rgbd_zero_multi_f32(float* const* ptrs /* host array */, const int64_t* counts /* host array */, int n, void* stream);
 int rgbd_hidden_normalize(const float* z, float* out, int M, int C, float ch, int copies, void* stream);
+/* The same with the draw inside (net.py:333-343 `xp.random.normal` + the normalisation): out (copies*M, C) fp32 from
+ * Philox4x32-10 + Box-Muller, keyed by state[0..1] (seed), counter (state[2] = launch number, row, column quad).  state: four
+ * uint32 in DEVICE memory, {seed lo, seed hi, launch number, 0}; the kernel's last block bumps the launch number, so a launch
+ * replayed from a captured graph draws new values every time.  C a multiple of 4, at most 1024. */
+int rgbd_hidden_draw(uint32_t* state, float* out, int M, int C, float ch, int copies, void* stream);
 int rgbd_r1_penalty_fwd(const float* g, int B, int64_t n, float coef, float* workspace, float* loss, void* stream);
 int rgbd_scale_by_scalar_f32(const float* x, const float* scalar_device, float k, float* out, int64_t n, void* stream);
 /* out[r, :] = a[r, :] + s[r] * x[r, :] over (rows, row_len) fp32, row_len % 4 == 0, 16-byte aligned; s NULL = 1; out may

@@ -10,7 +10,7 @@ from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p, POINTER
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RGBD_LIB_PATH: A/B timing of another build of the same ABI; the default is the in-tree library
 LIB_PATH = os.environ.get("RGBD_LIB_PATH") or os.path.join(_HERE, "librgbdgan_hip.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 _P = c_void_p
 
@@ -61,6 +61,7 @@ PROTOTYPES = {
     "rgbd_real_batch_u8": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_float, _P], c_int),
     "rgbd_zero_multi_f32": ([POINTER(c_void_p), POINTER(c_int64), c_int, _P], c_int),
     "rgbd_hidden_normalize": ([_P, _P, c_int, c_int, c_float, c_int, _P], c_int),
+    "rgbd_hidden_draw": ([_P, _P, c_int, c_int, c_float, c_int, _P], c_int),
     "rgbd_r1_penalty_fwd": ([_P, c_int, c_int64, c_float, _P, _P, _P], c_int),
     "rgbd_scale_by_scalar_f32": ([_P, _P, c_float, _P, c_int64, _P], c_int),
     "rgbd_axpy_rows_f32": ([_P, _P, _P, _P, c_int64, c_int64, _P], c_int),

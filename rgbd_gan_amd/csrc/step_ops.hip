@@ -83,6 +83,69 @@ __global__ __launch_bounds__(256) void hidden_normalize_kernel(const float* __re
     }
 }
 
+// make_hidden with the draw inside (net.py:333-343: xp.random.normal, then the normalisation above): Philox4x32-10 keyed by a
+// seed, counter = (launch number, row, column quad), Box-Muller on the four words.  The launch number lives in device memory
+// (state[2]) and is bumped by the LAST block of every launch (ticket in state[3]), so a step replayed from a captured graph
+// draws fresh latents on every replay -- what torch.randn's graph-safe generator did for the kernel this replaces (the last
+// torch arithmetic kernel on the generator's input side; this library is built without packed-fp32 instructions, DESIGN.md
+// section 3).  One wave per row; the row (C <= 1024 values) is held in registers between the two passes.
+__device__ __forceinline__ void philox4x32_10(unsigned k0, unsigned k1, unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__global__ __launch_bounds__(256) void hidden_draw_kernel(unsigned* __restrict__ state, float* __restrict__ out, int M, int C,
+                                                          float ch, int copies) {
+    const unsigned launch = *reinterpret_cast<volatile unsigned*>(state + 2);
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row < M) {
+        float v[16];                                   // quads lane, lane + 64, ... of this row: up to 4 quads = 16 values
+        float acc = 0.f;
+        const int quads = C >> 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int qd = lane + 64 * i;
+            unsigned w[4];
+            philox4x32_10(state[0], state[1], launch, (unsigned)row, (unsigned)qd, 0x52474244u, w);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {              // Box-Muller: (0,1] x [0,1) -> two N(0,1) values
+                const float u1 = ((float)(w[2 * h] >> 8) + 1.0f) * (1.0f / 16777216.0f);
+                const float u2 = (float)(w[2 * h + 1] >> 8) * (1.0f / 16777216.0f);
+                const float rad = sqrtf(-2.0f * logf(u1));
+                float sn, cs;
+                sincosf(6.283185307179586f * u2, &sn, &cs);
+                v[4 * i + 2 * h] = qd < quads ? rad * cs : 0.f;
+                v[4 * i + 2 * h + 1] = qd < quads ? rad * sn : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc += v[4 * i + k] * v[4 * i + k];
+        }
+        acc = wave_sum(acc);
+        const float inv = 1.f / sqrtf(acc / ch + 1e-8f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int qd = lane + 64 * i;
+            if (qd < quads) {
+                const f32x4 o = {v[4 * i] * inv, v[4 * i + 1] * inv, v[4 * i + 2] * inv, v[4 * i + 3] * inv};
+                for (int k = 0; k < copies; ++k) *reinterpret_cast<f32x4*>(out + ((long)k * M + row) * C + 4 * qd) = o;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = atomicAdd(state + 3, 1u);
+        if (t == gridDim.x - 1) {                      // every other block has read `launch` and is done: the next launch number
+            state[3] = 0u;
+            state[2] = launch + 1u;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ R1 penalty
 // updater.py:416-418 + loss_functions.py:7-8: loss = coef * (1/B) * sum_b (sqrt(sum g_b^2))^2 over g (B, n) fp32.
 constexpr int R1_CHUNKS = 16;
@@ -436,6 +499,14 @@ extern "C" int rgbd_hidden_normalize(const float* z, float* out, int M, int C, f
     RGBD_REQUIRE(z && out && M > 0 && C > 0 && ch > 0.f && copies >= 1, "rgbd_hidden_normalize: bad arguments");
     hidden_normalize_kernel<<<(M + 3) / 4, 256, 0, (hipStream_t)stream>>>(z, out, M, C, ch, copies);
     RGBD_CHECK_LAUNCH("hidden_normalize_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_hidden_draw(uint32_t* state, float* out, int M, int C, float ch, int copies, void* stream) {
+    RGBD_REQUIRE(state && out && M > 0 && C > 0 && C % 4 == 0 && C <= 1024 && ch > 0.f && copies >= 1 && ((uintptr_t)out & 15) == 0,
+                 "rgbd_hidden_draw: bad arguments (C must be a multiple of 4, at most 1024; C=%d)", C);
+    hidden_draw_kernel<<<(M + 3) / 4, 256, 0, (hipStream_t)stream>>>(state, out, M, C, ch, copies);
+    RGBD_CHECK_LAUNCH("hidden_draw_kernel");
     return 0;
 }
 

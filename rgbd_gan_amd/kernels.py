@@ -1086,6 +1086,26 @@ def hidden_normalize(z, ch, copies=1):
     return out
 
 
+def new_hidden_rng_state(device, seed=None):
+    """A latent generator's state on `device`: uint32[4] {seed lo, seed hi, launch number, ticket} for rgbd_hidden_draw,
+    seeded from `seed` or from torch's seed of this moment.  One per generator OBJECT, created at its first draw: a model built
+    after torch.manual_seed(s) draws the same latent sequence every time, and the launch number advances on the device (also
+    under graph replay)."""
+    seed = (torch.initial_seed() if seed is None else int(seed)) & 0xFFFFFFFFFFFFFFFF
+    return torch.tensor([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, 0, 0], dtype=torch.int64).to(torch.int32).to(device)
+
+
+def hidden_draw(state, M, C, ch, copies=1):
+    """make_hidden in one launch: (copies*M, C) fp32 = normalised N(0,1) rows (Philox + Box-Muller on the device), each row
+    written `copies` times (rows m and m + M are the same latent); `state` from new_hidden_rng_state."""
+    if state.dtype != torch.int32 or state.numel() != 4 or not state.is_cuda:
+        raise RuntimeError("hidden_draw: state must be the int32[4] device tensor of new_hidden_rng_state")
+    out = torch.empty(copies * M, C, dtype=F32, device=state.device)
+    _lib.check(_lib.load().rgbd_hidden_draw(_ptr(state), _ptr(out), M, C, float(ch), int(copies), _stream()),
+               "rgbd_hidden_draw")
+    return out
+
+
 def r1_penalty_fwd(g, coef):
     """g (B, ...) fp32 -> (1,) = coef * mean_b (sqrt(sum g_b^2))^2."""
     _chk(g, F32, "g")

@@ -328,6 +328,8 @@ class StyleGANGenerator(_Link):
     def make_hidden(self, batch_size):
         """net.py:333-343; drawn on the device (the reference draws with cupy when on GPU)."""
         from . import kernels
+        if torch.device(self.device).type == "cuda":
+            return kernels.hidden_draw(self._latent_rng(), batch_size, self.ch * 2, self.ch).reshape(batch_size, self.ch * 2, 1, 1)
         z = torch.randn(batch_size, self.ch * 2, device=self.device)
         return kernels.hidden_normalize(z, self.ch).reshape(batch_size, self.ch * 2, 1, 1)
 
@@ -335,8 +337,14 @@ class StyleGANGenerator(_Link):
         """The step's latent batch (updater.py:300: the same `half` latents for both views of every pair) in one launch
         after the draw: rows [0, half) and [half, 2 half) are identical."""
         from . import kernels
-        z = torch.randn(half, self.ch * 2, device=self.device)
-        return kernels.hidden_normalize(z, self.ch, copies=2).reshape(2 * half, self.ch * 2, 1, 1)
+        return kernels.hidden_draw(self._latent_rng(), half, self.ch * 2, self.ch, copies=2).reshape(2 * half, self.ch * 2, 1, 1)
+
+    def _latent_rng(self):
+        """This generator's latent stream (kernels.new_hidden_rng_state), seeded from torch's seed at the first draw."""
+        from . import kernels
+        if getattr(self, "_rng_state", None) is None:
+            self._rng_state = kernels.new_hidden_rng_state(self.device)
+        return self._rng_state
 
     def __call__(self, z, stage, theta=None, return_feature=False):
         z = _as_device_tensor(z, self.device).reshape(-1, 2 * self.ch)

@@ -53,6 +53,55 @@ def test_zero_multi_and_hidden_normalize():
     assert torch.equal(out[:5], out[5:])
 
 
+def test_hidden_draw_is_make_hidden_with_the_draw_inside():
+    """rgbd_hidden_draw (Philox4x32-10 + Box-Muller + net.py:333-343's normalisation in one launch): every row has
+    sum z^2 / ch == 1, the raw draws are N(0,1) (moments and tail fractions over 2 M values, no correlation between the two
+    Box-Muller outputs or neighbouring rows), the same torch seed reproduces the sequence, successive launches differ, and a
+    launch replayed from a captured HIP graph draws fresh values on every replay (the launch number lives on the device)."""
+    from rgbd_gan_amd import kernels
+    torch.manual_seed(1234)
+    st = kernels.new_hidden_rng_state(DEV)
+    a1 = kernels.hidden_draw(st, 4096, 512, 256.0)
+    a2 = kernels.hidden_draw(st, 4096, 512, 256.0)
+    assert st.cpu().tolist()[2:] == [2, 0]                         # the launch number advanced on the device, the ticket is back at 0
+    torch.manual_seed(1234)
+    b1 = kernels.hidden_draw(kernels.new_hidden_rng_state(DEV), 4096, 512, 256.0)
+    torch.manual_seed(1235)
+    c1 = kernels.hidden_draw(kernels.new_hidden_rng_state(DEV), 4096, 512, 256.0)
+    assert torch.equal(a1, b1) and not torch.equal(a1, a2) and not torch.equal(a1, c1)
+    ms = (a1.double() ** 2).sum(dim=1) / 256.0
+    assert float((ms - 1.0).abs().max()) < 1e-5
+    # un-normalise: a row's scale is sqrt(sum z^2 / ch); over 512 draws it is sqrt(2) (1 +- 0.03), so the pooled moments of
+    # z * sqrt(2) / ... are checked on the normalised values with their known scale: E[x^2] = ch / C = 1/2
+    x = a1.double().flatten()
+    n = x.numel()
+    assert abs(float(x.mean())) < 4.0 * (0.5 / n) ** 0.5 * 1.5
+    assert abs(float((x ** 2).mean()) - 0.5) < 1e-9 + 1e-12          # exact by the normalisation
+    z = x / (0.5 ** 0.5)                                             # ~N(0,1) up to the 3 % row scale
+    assert abs(float((z ** 3).mean())) < 0.02 and abs(float((z ** 4).mean()) - 3.0) < 0.06
+    for t, p in ((1.0, 0.31731), (2.0, 0.04550), (3.0, 0.00270)):
+        assert abs(float((z.abs() > t).double().mean()) - p) < 0.08 * p + 2e-4
+    zz = z.reshape(4096, 128, 4)
+    assert abs(float((zz[..., 0] * zz[..., 1]).mean())) < 0.01 and abs(float((zz[..., 0] * zz[..., 2]).mean())) < 0.01
+    assert abs(float((zz[1:, :, 0] * zz[:-1, :, 0]).mean())) < 0.01
+    # copies: rows m and m + M are the same latent
+    c = kernels.hidden_draw(st, 5, 512, 256.0, copies=2)
+    assert torch.equal(c[:5], c[5:]) and float((c[0] - c[1]).abs().max()) > 0.1
+    # graph replay: new draws every time
+    s = torch.cuda.Stream()
+    out = torch.empty(8, 512, device=DEV)
+    with torch.cuda.stream(s):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            out.copy_(kernels.hidden_draw(st, 8, 512, 256.0))
+        seen = []
+        for _ in range(3):
+            g.replay()
+            s.synchronize()
+            seen.append(out.clone())
+    assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
+
+
 def test_r1_penalty_kernel_and_gradient():
     from rgbd_gan_amd import functional as Fn
     g = torch.randn(6, 3, 64, 64, device=DEV) * 0.3
