@@ -59,14 +59,25 @@ def pack(iteration, optimizers, iterator_state=None, log=None, elapsed_time=0.0,
     return out
 
 
-def _get(f, key):
-    """Chainer's DictionarySerializer strips slashes around every path component; accept '//' variants as well."""
-    if key in f:
-        return f[key]
+def _normalised(f):
+    """Chainer's DictionarySerializer strips slashes around every path component: index a file's keys by their '//'-free
+    form once (a linear scan per miss was O(parameters x keys) on a reference-written file)."""
+    out = {}
     for k in f:
-        if k.replace("//", "/") == key:
-            return f[k]
-    return None
+        nk = k
+        while "//" in nk:
+            nk = nk.replace("//", "/")
+        out.setdefault(nk.strip("/"), f[k])
+    return out
+
+
+def _get(f, key):
+    return f.get(key)
+
+
+def _as_flat_tensor(a, like):
+    import torch
+    return torch.as_tensor(np.asarray(a, dtype=np.float32).reshape(-1)).to(like.device)
 
 
 def unpack(f, optimizers):
@@ -75,7 +86,7 @@ def unpack(f, optimizers):
     {"iteration", "iterator" (state dict for DeviceImageIterator.load_state_dict, or None), "log" (list or None),
      "elapsed_time"}."""
     keys = set(f.keys()) if hasattr(f, "keys") else set(f.files)
-    f = {k: f[k] for k in keys}
+    f = _normalised({k: f[k] for k in keys})
     if "iteration" in f and "updater/iteration" not in f:          # this engine's layout of rounds 1-3
         for k, o in optimizers.items():
             if f"{k}/t" in f:
@@ -99,6 +110,15 @@ def unpack(f, optimizers):
                 t = _get(f, f"{base}{pname}/t")
         sd["t"] = int(t) if t is not None else sd["t"]
         opt.load_state_dict(sd)
+        # the optimizer's target link travels in the trainer snapshot too (updater/model:{name}/...): a reference-style resume
+        # from the snapshot alone finds the weights there; train_rgbd.py loads the separate Generator_*.npz files first and these
+        # agree with them
+        flat = store.flat
+        for pname in store.names:
+            a = _get(f, f"updater/model:{name}/{pname}")
+            if a is not None and tuple(np.shape(a)) == tuple(store.shapes[pname]):
+                off, n = store.offsets[pname], int(np.prod(store.shapes[pname]))
+                flat[off:off + n].copy_(_as_flat_tensor(a, flat))
     it = None
     base = "updater/iterator:main/"
     if _get(f, base + "current_position") is not None and _get(f, base + "order") is not None:
@@ -107,7 +127,9 @@ def unpack(f, optimizers):
         rng = _get(f, "rgbd_gan_amd/iterator:main/rng_state")
         if rng is not None:                                            # (a Chainer-written file has no generator state)
             it["rng_state"] = rng
-            it["seed"] = _get(f, "rgbd_gan_amd/iterator:main/seed")
+            seed = _get(f, "rgbd_gan_amd/iterator:main/seed")
+            if seed is not None:                                       # (never None in a file pack() wrote; a hand-merged one)
+                it["seed"] = seed
     log = _get(f, "extensions/LogReport/_log")
     el = _get(f, "_snapshot_elapsed_time")
     return {"iteration": int(_get(f, "updater/iteration")), "iterator": it,

@@ -25,6 +25,10 @@ void rgbd_set_error(const char* fmt, ...);
 // replay with ROCm 7.2).  Returns hipSuccess or the launch error.
 hipError_t rgbd_zero_async(void* ptr, size_t bytes, hipStream_t stream);
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: reserved once per (kernel, device) -- a
+// process that drives a second GPU must set it there too (a per-process flag left that device at the 64 KB default).
+bool rgbd_reserve_lds(const void* fn, int bytes);
+
 #define RGBD_REQUIRE(cond, ...)            \
     do {                                   \
         if (!(cond)) {                     \

@@ -2688,6 +2688,7 @@ int device_cus() {
     }
     return cus[dev];
 }
+bool reserve_lds(const void* fn, int bytes) { return rgbd_reserve_lds(fn, bytes); }      // (common.h: once per kernel AND device)
 #ifdef RGBD_DEBUG_BUILD
 bool g_force_gather = false;   // test hook: route every shape through the generic gather kernel
 int g_conv_variant = 0;        // test / tuning hook: 1 = the register-staged conv3x3_patch_kernel instead of the ping-pong one
@@ -2792,13 +2793,8 @@ template <int BN, bool UPS, int EPI, bool MX = true, bool EMIT = false>
 int launch_sp_mx(const ConvArgs& a, unsigned grid, hipStream_t st) {
     constexpr int pieces = UPS ? 13 : 41, spieces = UPS ? 2 : 6;
     constexpr int lds = 2 * pieces * 1024 + 3 * BN * 128 + BN * 4 + (MX ? 2 * spieces * 256 + 3 * BN * 4 : 0);
-    static bool attr_done = false;
-    if (!attr_done) {
-        RGBD_REQUIRE(hipFuncSetAttribute((const void*)&conv3x3_sp_kernel<BN, UPS, 0, EPI, MX, EMIT>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess,
-                     "rgbd_conv3x3: cannot reserve %d B of LDS", lds);
-        attr_done = true;
-    }
+    RGBD_REQUIRE(reserve_lds((const void*)&conv3x3_sp_kernel<BN, UPS, 0, EPI, MX, EMIT>, lds),
+                 "rgbd_conv3x3: cannot reserve %d B of LDS", lds);
     conv3x3_sp_kernel<BN, UPS, 0, EPI, MX, EMIT><<<grid, 512, lds, st>>>(a);
     RGBD_CHECK_LAUNCH("conv3x3_sp_kernel");
     return 0;
@@ -2919,13 +2915,8 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
     if (plan.small) {
         const int S = a.Hout;
         const int lds = (128 / (S * S)) * (S + 2) * (S + 2) * 128 + 9 * 64 * 128;
-        static bool small_attr_done[2] = {false, false};
-        if (!small_attr_done[S == 8]) {
-            const void* fn = S == 8 ? (const void*)&conv3x3_small_kernel<8> : (const void*)&conv3x3_small_kernel<4>;
-            RGBD_REQUIRE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess,
-                         "rgbd_conv2d_fprop_bf16: cannot reserve %d B of LDS", lds);
-            small_attr_done[S == 8] = true;
-        }
+        RGBD_REQUIRE(reserve_lds(S == 8 ? (const void*)&conv3x3_small_kernel<8> : (const void*)&conv3x3_small_kernel<4>, lds),
+                     "rgbd_conv2d_fprop_bf16: cannot reserve %d B of LDS", lds);
         const unsigned grid = (unsigned)((a.M / 128) * (Cout / 64) * (Cin / 64));
         if (S == 8) conv3x3_small_kernel<8><<<grid, 256, lds, st>>>(a);
         else        conv3x3_small_kernel<4><<<grid, 256, lds, st>>>(a);
@@ -2993,16 +2984,10 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
             const int bn2 = wide2 ? 128 : 64;
             const int lds_dw = 2 * (a.ups ? 7 : 21) * 1024 + 3 * bn2 * 64 + bn2 * 4;
             const int epi = stats ? 2 : mask_y ? 1 : 0;
-            const int vi2 = ((wide2 ? 1 : 0) * 2 + a.ups) * 3 + epi;
-            static bool dw_attr_done[12] = {};
 #define RGBD_DW_CASE(BNv, UPSv, EPIv)                                                                                      \
     do {                                                                                                                   \
-        if (!dw_attr_done[vi2]) {                                                                                          \
-            RGBD_REQUIRE(hipFuncSetAttribute((const void*)&conv3x3_dw_kernel<BNv, UPSv, EPIv>,                             \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_dw) == hipSuccess,            \
-                         "rgbd_conv3x3: cannot reserve %d B of LDS", lds_dw);                                              \
-            dw_attr_done[vi2] = true;                                                                                      \
-        }                                                                                                                  \
+        RGBD_REQUIRE(reserve_lds((const void*)&conv3x3_dw_kernel<BNv, UPSv, EPIv>, lds_dw),                                \
+                     "rgbd_conv3x3: cannot reserve %d B of LDS", lds_dw);                                                  \
         conv3x3_dw_kernel<BNv, UPSv, EPIv><<<grid2, 256, lds_dw, st>>>(a);                                                 \
     } while (0)
 #ifdef RGBD_DEBUG_BUILD
@@ -3048,12 +3033,8 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
             const int vi = (wide ? 2 : 0) + a.ups;
             const void* fsp = vi == 3 ? (const void*)&conv3x3_sp_kernel<128, true> : vi == 2 ? (const void*)&conv3x3_sp_kernel<128, false>
                             : vi == 1 ? (const void*)&conv3x3_sp_kernel<64, true> : (const void*)&conv3x3_sp_kernel<64, false>;
-            static bool sp_attr_done[4] = {false, false, false, false};   // once per variant (not a stream operation)
-            if (!sp_attr_done[vi]) {
-                RGBD_REQUIRE(hipFuncSetAttribute(fsp, hipFuncAttributeMaxDynamicSharedMemorySize, lds_sp) == hipSuccess,
+            RGBD_REQUIRE(reserve_lds(fsp, lds_sp),
                              "rgbd_conv2d_fprop_bf16: cannot reserve %d B of LDS", lds_sp);
-                sp_attr_done[vi] = true;
-            }
 #ifdef RGBD_DEBUG_BUILD
             if (g_conv_variant >= 17 && g_conv_variant <= 19 && vi == 2) {     // epilogue / start-skew experiments
                 const int ko = g_conv_variant - 10;
@@ -3089,12 +3070,8 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
                                : vi == 2 ? (const void*)&conv3x3_sp_kernel<128, false, 0, 2>
                                : vi == 1 ? (const void*)&conv3x3_sp_kernel<64, true, 0, 2>
                                          : (const void*)&conv3x3_sp_kernel<64, false, 0, 2>;
-                static bool sps_attr_done[4] = {false, false, false, false};
-                if (!sps_attr_done[vi]) {
-                    RGBD_REQUIRE(hipFuncSetAttribute(fs, hipFuncAttributeMaxDynamicSharedMemorySize, lds_sp) == hipSuccess,
+                RGBD_REQUIRE(reserve_lds(fs, lds_sp),
                                  "rgbd_conv2d_fprop_stats_bf16: cannot reserve %d B of LDS", lds_sp);
-                    sps_attr_done[vi] = true;
-                }
                 if (vi == 3)      conv3x3_sp_kernel<128, true, 0, 2><<<(unsigned)grid, 512, lds_sp, st>>>(a);
                 else if (vi == 2) conv3x3_sp_kernel<128, false, 0, 2><<<(unsigned)grid, 512, lds_sp, st>>>(a);
                 else if (vi == 1) conv3x3_sp_kernel<64, true, 0, 2><<<(unsigned)grid, 512, lds_sp, st>>>(a);
@@ -3106,12 +3083,8 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
             if (mask_y) {
                 const void* fm = wide ? (const void*)&conv3x3_sp_kernel<128, false, 0, 1>
                                       : (const void*)&conv3x3_sp_kernel<64, false, 0, 1>;
-                static bool spm_attr_done[2] = {false, false};
-                if (!spm_attr_done[wide]) {
-                    RGBD_REQUIRE(hipFuncSetAttribute(fm, hipFuncAttributeMaxDynamicSharedMemorySize, lds_sp) == hipSuccess,
+                RGBD_REQUIRE(reserve_lds(fm, lds_sp),
                                  "rgbd_conv3x3_actgrad_bf16: cannot reserve %d B of LDS", lds_sp);
-                    spm_attr_done[wide] = true;
-                }
                 if (wide) conv3x3_sp_kernel<128, false, 0, 1><<<(unsigned)grid, 512, lds_sp, st>>>(a);
                 else      conv3x3_sp_kernel<64, false, 0, 1><<<(unsigned)grid, 512, lds_sp, st>>>(a);
                 RGBD_CHECK_LAUNCH("conv3x3_sp_kernel<masked>");
@@ -3132,13 +3105,7 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
                                        : (const void*)&conv3x3_patch_kernel<128, false>)
                               : (a.ups ? (const void*)&conv3x3_patch_kernel<64, true>
                                        : (const void*)&conv3x3_patch_kernel<64, false>);
-        static bool attr_done[4] = {false, false, false, false};   // once per variant (not a stream operation)
-        const int variant = (wide ? 2 : 0) + (a.ups ? 1 : 0);
-        if (!attr_done[variant]) {
-            RGBD_REQUIRE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess,
-                         "rgbd_conv2d_fprop_bf16: cannot reserve %d B of LDS", lds);
-            attr_done[variant] = true;
-        }
+        RGBD_REQUIRE(reserve_lds(fn, lds), "rgbd_conv2d_fprop_bf16: cannot reserve %d B of LDS", lds);
         if (wide) {
             if (a.ups) conv3x3_patch_kernel<128, true><<<(unsigned)grid, 512, lds, st>>>(a);
             else       conv3x3_patch_kernel<128, false><<<(unsigned)grid, 512, lds, st>>>(a);
@@ -3326,17 +3293,11 @@ static int wgrad_partial_impl(const void* x, const void* dy, void* workspace, in
     dim3 grid(p.nsplit, Cin / 64, Cout / 64);
     hipStream_t st = (hipStream_t)stream;
     {
-        static bool attr_done[4] = {false, false, false, false};
         const bool fast = p.PW == 16 && p.PH == 8;
-        const int v = (K == 3 ? 0 : 2) + (fast ? 1 : 0);
         const int lds = K == 3 ? (fast ? WGRAD9_LDS : 2 * (180 * 128 + 128 * 128)) : 2 * (128 * 128 + 128 * 128);
         const void* fn = K == 3 ? (fast ? (const void*)&conv_wgrad_kernel<9, true> : (const void*)&conv_wgrad_kernel<9, false>)
                                 : (fast ? (const void*)&conv_wgrad_kernel<1, true> : (const void*)&conv_wgrad_kernel<1, false>);
-        if (!attr_done[v]) {
-            RGBD_REQUIRE(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess,
-                         "rgbd_conv2d_wgrad_bf16: cannot reserve %d B of LDS", lds);
-            attr_done[v] = true;
-        }
+        RGBD_REQUIRE(reserve_lds(fn, lds), "rgbd_conv2d_wgrad_bf16: cannot reserve %d B of LDS", lds);
 #ifdef RGBD_DEBUG_BUILD
         if (K == 3 && fast && g_conv_variant == 3) {
             const int lds_old = 2 * (180 * 128 + 128 * 128);
@@ -3479,13 +3440,8 @@ extern "C" int rgbd_conv2d_wgrad_partial_multi_bf16(const rgbd_wgrad_problem* pr
         }
         m.wg_begin[n] = (int)wgs;
         const int lds_small = 2 * (180 * 128 + 128 * 128);
-        static bool small_attr_done = false;
-        if (!small_attr_done) {
-            RGBD_REQUIRE(hipFuncSetAttribute((const void*)&conv_wgrad_multi_kernel<9, false>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_small) == hipSuccess,
-                         "rgbd_conv2d_wgrad_partial_multi_bf16: cannot reserve %d B of LDS", lds_small);
-            small_attr_done = true;
-        }
+        RGBD_REQUIRE(reserve_lds((const void*)&conv_wgrad_multi_kernel<9, false>, lds_small),
+                     "rgbd_conv2d_wgrad_partial_multi_bf16: cannot reserve %d B of LDS", lds_small);
         conv_wgrad_multi_kernel<9, false><<<(unsigned)wgs, 512, lds_small, (hipStream_t)stream>>>(m);
         RGBD_CHECK_LAUNCH("conv_wgrad_multi_kernel<small>");
         return 0;
@@ -3523,13 +3479,8 @@ extern "C" int rgbd_conv2d_wgrad_partial_multi_bf16(const rgbd_wgrad_problem* pr
     m.wg_begin[n] = (int)wgs;
     RGBD_REQUIRE(wgs < 0x7fffffffL, "rgbd_conv2d_wgrad_partial_multi_bf16: grid too large");
     const int lds = WGRAD9_LDS;
-    static bool attr_done = false;
-    if (!attr_done) {
-        RGBD_REQUIRE(hipFuncSetAttribute((const void*)&conv_wgrad_multi_kernel<9, true>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess,
-                     "rgbd_conv2d_wgrad_partial_multi_bf16: cannot reserve %d B of LDS", lds);
-        attr_done = true;
-    }
+    RGBD_REQUIRE(reserve_lds((const void*)&conv_wgrad_multi_kernel<9, true>, lds),
+                 "rgbd_conv2d_wgrad_partial_multi_bf16: cannot reserve %d B of LDS", lds);
     conv_wgrad_multi_kernel<9, true><<<(unsigned)wgs, 512, lds, (hipStream_t)stream>>>(m);
     RGBD_CHECK_LAUNCH("conv_wgrad_multi_kernel");
     return 0;

@@ -26,6 +26,19 @@ hipError_t rgbd_zero_async(void* ptr, size_t bytes, hipStream_t stream) {
 extern "C" const char* rgbd_last_error(void) { return g_err; }
 extern "C" int rgbd_abi_version(void) { return RGBD_ABI_VERSION; }
 
+bool rgbd_reserve_lds(const void* fn, int bytes) {
+    struct Key { const void* fn; int dev; };
+    static Key done[512];
+    static int ndone = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    for (int i = 0; i < ndone; ++i)
+        if (done[i].fn == fn && done[i].dev == dev) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+    if (ndone < 512) done[ndone++] = Key{fn, dev};
+    return true;
+}
+
 extern "C" int rgbd_zero_f32(float* p, int64_t n, void* stream) {
     RGBD_REQUIRE(p && n > 0, "rgbd_zero_f32: bad arguments");
     if (rgbd_zero_async(p, (size_t)n * sizeof(float), (hipStream_t)stream) != hipSuccess) {
@@ -1237,12 +1250,8 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const rgbd_pack
 extern "C" int rgbd_pack_weights_multi(const rgbd_pack_desc* descs_device, int n, int total_blocks, void* stream) {
     RGBD_REQUIRE(descs_device && n > 0 && total_blocks > 0, "rgbd_pack_weights_multi: bad arguments");
     constexpr int lds = PACK_TCO * (PACK_TCI * 9 + 1) * (int)sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        RGBD_REQUIRE(hipFuncSetAttribute((const void*)&pack_weights_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         lds) == hipSuccess, "rgbd_pack_weights_multi: cannot reserve %d B of LDS", lds);
-        attr_done = true;
-    }
+    RGBD_REQUIRE(rgbd_reserve_lds((const void*)&pack_weights_multi_kernel, lds),
+                 "rgbd_pack_weights_multi: cannot reserve %d B of LDS", lds);
     pack_weights_multi_kernel<<<total_blocks, 256, lds, (hipStream_t)stream>>>(descs_device, n);
     RGBD_CHECK_LAUNCH("pack_weights_multi_kernel");
     return 0;

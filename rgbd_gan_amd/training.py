@@ -201,6 +201,13 @@ def build_training(config, device, comm=None, iterator=None, updater_class=None,
     generator = setup_generator(config, device)
     discriminator = setup_discriminator(config, device)
     optimizer = make_optimizers(config, generator, discriminator, comm)
+    # the persistent weight images (and, with conv_dtype mxfp8, their fp8 twins and descriptor tables: allocations and a
+    # host-to-device copy) exist before the first step -- a first build inside a HIP-graph capture (graph_warmup = 0, or the
+    # conv dtype switched late) would be an illegal synchronous copy there
+    for net in (getattr(generator, "gen", generator), discriminator):
+        group = getattr(net, "pack_group", None)
+        if group is not None and torch.device(device).type == "cuda":
+            group.repack()
     models = [generator, discriminator]
     if config.keep_smoothed_gen and (comm is None or comm.rank == 0):       # train_rgbd.py:124-125,288-295
         models.append(setup_generator(config, device, seed=1000))    # its own random init, like the reference

@@ -227,6 +227,8 @@ def test_trainer_snapshot_uses_the_reference_key_layout_and_round_trips():
     for _ in range(4):
         it.next_indices()
     log = [{"iteration": 100, "gen/loss_adv": 0.5}]
+    with torch.no_grad():
+        opts["dis"].store.flat.add_(0.25)                 # trained weights: the snapshot's updater/model:* keys carry them
     snap = ts.pack(1200, opts, it.state_dict(), log, 12.5, 100)
     for k in ("updater/iteration", "updater/optimizer:map/t", "updater/optimizer:map/l/0/c/W/m", "updater/optimizer:dis/ins/5/b/v",
               "updater/model:dis/blocks/0/c0/c/W", "updater/iterator:main/current_position", "updater/iterator:main/order",
@@ -245,6 +247,12 @@ def test_trainer_snapshot_uses_the_reference_key_layout_and_round_trips():
         return True
     for k in opts:
         assert same_moments(fresh[k], opts[k]) and fresh[k].t == 7
+        for n in opts[k].store.names:                      # the optimizer's target link is restored from the snapshot as well
+            assert torch.equal(fresh[k].store[n], opts[k].store[n]), (k, n)
+    partial = {k: v for k, v in snap.items() if k != "rgbd_gan_amd/iterator:main/seed"}     # rng_state without its seed
+    it4 = DeviceImageIterator(images, 8, "cpu", seed=77)
+    it4.load_state_dict(ts.unpack(partial, make())["iterator"])
+    assert it4.seed == 77
     it2 = DeviceImageIterator(images, 8, "cpu", seed=99)
     it2.load_state_dict(got["iterator"])
     assert [it2.next_indices().tolist() for _ in range(5)] == [it.next_indices().tolist() for _ in range(5)]

@@ -93,6 +93,8 @@ def main():
         # layout this engine wrote before round 4.  Missing keys are skipped (the reference loads with strict=False)
         with np.load(f"{d}/snapshot_iter_{resume}.npz", allow_pickle=True) as snap_file:
             snap = trainer_snapshot.unpack(snap_file, optimizer)
+        from rgbd_gan_amd import functional as Fn
+        Fn.bump_weight_epoch()          # (unpack also restores the optimizers' target weights: packed images are stale)
         updater.iteration = snap["iteration"]
         if snap["log"] is not None:
             log_resumed, elapsed_resumed = snap["log"], snap["elapsed_time"]
