@@ -836,8 +836,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
     }
 
     // ---- DMA roles: weight waves 0,1,6,7, halo waves 2,3,4,5 (wave w and w+4 share a SIMD: one of each per SIMD)
-    const bool w_role = ((wid >> 1) & 1) == (wid >> 2);
-    const int ridx = (wid & 1) + 2 * (wid >> 2);                 // 0..3 within the role
+    // (KO 41 / 42, debug A/B: the weight role on the OLDER half, waves 0-3, / on the younger half.  In-kernel stamps,
+    // profiles/r05/sp_stamps.txt: the older waves win the issue arbitration, finish a step early and wait ~650 cycles at its
+    // barrier while the younger ones are still at work -- DMA issue is cheapest where that wait is)
+    const bool w_role = KO == 41 || KO == 31 ? wid < 4 : KO == 42 ? wid >= 4 : ((wid >> 1) & 1) == (wid >> 2);
+    const int ridx = (KO == 41 || KO == 42 || KO == 31) ? (wid & 3) : (wid & 1) + 2 * (wid >> 2);     // 0..3 within the role
     constexpr int WPW4 = BN / 32;                                // weight pieces per weight wave per K step (BN / 8 / 4)
     constexpr int PPW4 = (P_PIECES + 3) / 4;                     // halo pieces per halo wave per slice (11 or 4)
     constexpr int PPS = (PPW4 + 3) / 4;                          // ... issued per step (3 or 1), in steps 0 .. PSTEPS-1
@@ -1377,6 +1380,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
 
     int c = 0, pt = pt_begin;
     bool w_waited = false;             // weight waves: tile 1 of this slice was already waited for (in front of an epilogue)
+    unsigned long long stamp_sum[5] = {0, 0, 0, 0, 0};   // KO 30 (debug): cycles in block 1 / wait + barrier / block 2 + DMA of the steps with / without halo DMA / epilogue
     constexpr int NWT = MX ? WPW4 + 1 : WPW4;          // a weight wave's DMA operations per tile (MX: + the scale piece)
     for (int g = 0; g < g_total; ++g) {
         const unsigned char* pbuf = patch_lds + (g & 1) * P_BYTES;
@@ -1446,6 +1450,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
             (void)dummy;
             const int kh = t % 3, kw = t / 3;
             const int tn = (t + 1) % 9, khn = tn % 3, kwn = tn / 3;
+            unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+            if (KO == 30 || KO == 31) ts0 = __builtin_amdgcn_s_memtime();
             // ---- block (t, k 0-31); meanwhile the k 32-63 fragments of this step arrive
             if (KO != 3 && KO != 6) {
                 load_a(w_lds + (t % 3) * W_BYTES, 1);
@@ -1454,6 +1460,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
             if (KO != 4) mfma_block(kh, 0);
             RGBD_SP_INTERLEAVE();
             __builtin_amdgcn_sched_barrier(0);
+            if (KO == 30 || KO == 31) ts1 = __builtin_amdgcn_s_memtime();
             // ---- B_t.  Weight waves: all but the youngest tile (t + 2) have landed, i.e. tile t + 1; halo waves: the
             //      whole next patch (issued in steps 0-3: HBM latency under load is a few steps), in front of B_8
             if (w_role) {
@@ -1463,6 +1470,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             RGBD_PP_BARRIER();
+            if (KO == 30 || KO == 31) ts2 = __builtin_amdgcn_s_memtime();
             // ---- block (t, k 32-63): the k 0-31 fragments of step t + 1 arrive, and the DMAs go out one per quarter of
             //      the block (an LDS-DMA holds its wave for ~60 cycles: spread out, the SIMD partner's MFMAs cover it):
             //      weight tile t + 3 into tile t's buffer / the next halo pieces
@@ -1487,6 +1495,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (KO == 30 || KO == 31) {
+                const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
+                stamp_sum[0] += ts1 - ts0; stamp_sum[1] += ts2 - ts1; stamp_sum[t < PSTEPS ? 2 : 3] += ts3 - ts2;
+            }
         }
         }
         w_waited = false;
@@ -1497,12 +1509,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KO == 1 || KO == 6 ? 0 : NWT) : "memory");
                 w_waited = true;
             }
+            unsigned long long te0 = 0;
+            if (KO == 30 || KO == 31) te0 = __builtin_amdgcn_s_memtime();
             epilogue(pt);
+            if (KO == 30 || KO == 31) stamp_sum[4] += __builtin_amdgcn_s_memtime() - te0;
         }
         c = c_next;
         pt = pt_next;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // no DMA may land in LDS after the workgroup has gone
+#ifdef RGBD_DEBUG_BUILD
+    if ((KO == 30 || KO == 31) && a.partial && lane == 0) {
+        unsigned* o = reinterpret_cast<unsigned*>(a.partial) + 8 * 1024 + (blockIdx.x * 8 + wid) * 5;
+#pragma unroll
+        for (int k_ = 0; k_ < 5; ++k_) o[k_] = (unsigned)stamp_sum[k_];
+    }
+#endif
     if (STATS && st_b >= 0) stats_flush();
     if (MASKED && a.colsum) {
         // 16 pixel columns (lanes r16) -> one value per channel per wave; the WAVES_PX waves that share channels meet
@@ -3036,6 +3058,28 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
             RGBD_REQUIRE(reserve_lds(fsp, lds_sp),
                              "rgbd_conv2d_fprop_bf16: cannot reserve %d B of LDS", lds_sp);
 #ifdef RGBD_DEBUG_BUILD
+            if ((g_conv_variant == 41 || g_conv_variant == 42 || g_conv_variant == 32) && vi == 2 && !stats && !mask_y) {   // DMA roles by wave age
+                a.partial = (float*)g_dw_census;
+                if (g_conv_variant == 41) {
+                    RGBD_REQUIRE(reserve_lds((const void*)&conv3x3_sp_kernel<128, false, 41>, lds_sp), "lds");
+                    conv3x3_sp_kernel<128, false, 41><<<(unsigned)grid, 512, lds_sp, st>>>(a);
+                } else if (g_conv_variant == 42) {
+                    RGBD_REQUIRE(reserve_lds((const void*)&conv3x3_sp_kernel<128, false, 42>, lds_sp), "lds");
+                    conv3x3_sp_kernel<128, false, 42><<<(unsigned)grid, 512, lds_sp, st>>>(a);
+                } else {
+                    RGBD_REQUIRE(reserve_lds((const void*)&conv3x3_sp_kernel<128, false, 31>, lds_sp), "lds");
+                    conv3x3_sp_kernel<128, false, 31><<<(unsigned)grid, 512, lds_sp, st>>>(a);
+                }
+                RGBD_CHECK_LAUNCH("conv3x3_sp_kernel<roles>");
+                return 0;
+            }
+            if (g_conv_variant == 31 && vi == 2 && !stats && !mask_y) {       // in-kernel stamps of the 8-wave kernel (scripts/dw_census.py)
+                a.partial = (float*)g_dw_census;
+                RGBD_REQUIRE(reserve_lds((const void*)&conv3x3_sp_kernel<128, false, 30>, lds_sp), "lds");
+                conv3x3_sp_kernel<128, false, 30><<<(unsigned)grid, 512, lds_sp, st>>>(a);
+                RGBD_CHECK_LAUNCH("conv3x3_sp_kernel<stamps>");
+                return 0;
+            }
             if (g_conv_variant >= 17 && g_conv_variant <= 19 && vi == 2) {     // epilogue / start-skew experiments
                 const int ko = g_conv_variant - 10;
                 const void* fk = ko == 7 ? (const void*)&conv3x3_sp_kernel<128, false, 7>

@@ -25,10 +25,17 @@ hw, xcc = out[:, 0], out[:, 1] & 0xf
 cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7      # HW_ID: wave 3:0 simd 5:4 pipe 7:6 cu 11:8 sh 12 se 15:13
 key = xcc.astype(np.int64) * 4096 + se * 256 + sh * 16 + cu
 live = t1 > 0
+if os.environ.get("VARIANT") in ("31", "32"):
+    live[:] = False
 print("workgroups that reported:", int(live.sum()), " distinct CUs:", len(set(key[live])))
-base = t0[live].min()
+if not live.any():
+    per = {}
+else:
+    pass
+base = t0[live].min() if live.any() else 0
 s0 = (t0 - base) / 100.0; s1 = (t1 - base) / 100.0      # s_memrealtime ticks at 100 MHz -> us
-print("start us: min %.1f max %.1f   end us: min %.1f max %.1f" % (s0[live].min(), s0[live].max(), s1[live].min(), s1[live].max()))
+if live.any():
+    print("start us: min %.1f max %.1f   end us: min %.1f max %.1f" % (s0[live].min(), s0[live].max(), s1[live].min(), s1[live].max()))
 from collections import defaultdict
 per = defaultdict(list)
 for i in range(n):
@@ -50,3 +57,11 @@ if os.environ.get("VARIANT") == "30":          # in-kernel stamps: cycles per ph
         m = st[sel].mean(axis=0)
         for w in range(4):
             print(f"{nm} wave {w} ({'W' if w < 2 else 'H'}): quarters 0-2 {m[w,0]:9.0f}  wait+barrier {m[w,1]:9.0f}  quarter 3 + DMA {m[w,2]:9.0f}  epilogue {m[w,3]:9.0f}  cycles; sum {m[w].sum():9.0f}")
+if os.environ.get("VARIANT") in ("31", "32"):          # the 8-wave kernel's stamps: cycles per phase, per wave (roles: 0,1,6,7 weights; 2-5 halo)
+    big = np.zeros((4096, 8), dtype=np.uint32)
+    lib.rgbd_debug_dw_census(1, big.ctypes.data, 4096)
+    st = big.reshape(-1)[8 * 1024:8 * 1024 + 256 * 8 * 5].reshape(256, 8, 5).astype(np.float64)
+    m = st.mean(axis=0)
+    for w in range(8):
+        role = "W" if w in (0, 1, 6, 7) else "H"
+        print(f"wave {w} ({role}): block 1 {m[w,0]:9.0f}  wait+barrier {m[w,1]:9.0f}  block 2 + DMA, steps with halo DMA {m[w,2]:9.0f} / without {m[w,3]:9.0f}  epilogue {m[w,4]:9.0f}  cycles; sum {m[w].sum():9.0f}")
