@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="the default command also runs short lines of configurations 3 (per-GPU shape), 4 and 5 (bf16 / fp8) "
                          "into `other_configs`; this switches them off")
-    ap.add_argument("--other-steps", type=int, default=10)
+    ap.add_argument("--other-steps", type=int, default=30)
     ap.add_argument("--mx8-standalone-quantiser", action="store_true",
                     help="A/B aid for --fp8: every conv input through rgbd_quantize_mxfp8 instead of the producers' epilogues")
     return ap.parse_args()
@@ -463,7 +463,7 @@ def main():
             a2 = copy.copy(args)
             for k, v in over.items():
                 setattr(a2, k, v)
-            a2.steps, a2.warmup, a2.no_cpu_baseline, a2.no_other_configs = args.other_steps, 8, True, True
+            a2.steps, a2.warmup, a2.no_cpu_baseline, a2.no_other_configs = args.other_steps, 12, True, True
             try:
                 l2 = run_workload(a2, comm, device)
             except Exception as e:      # a broken side line must not take the headline number with it; it says so instead

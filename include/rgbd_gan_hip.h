@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RGBD_ABI_VERSION 17
+#define RGBD_ABI_VERSION 18
 
 int rgbd_abi_version(void);
 const char* rgbd_last_error(void);
@@ -181,6 +181,15 @@ typedef struct rgbd_wgrad_problem {
     int32_t B, H, W, Cin, Cout, K, upsample, nsplit;
 } rgbd_wgrad_problem;
 int rgbd_conv2d_wgrad_multi_plan(rgbd_wgrad_problem* probs, int n, int total_workgroups);
+/* Compute units the next launches of the chip-filling persistent kernels (the pipelined 3x3 kernel, the batched
+ * weight-gradient plan with total_workgroups <= 0) size their grids for: 0 = all of the device (the default), otherwise
+ * min(n, the device's).  These kernels hold a compute unit completely (130 KB of LDS, 512 registers per SIMD): while one of
+ * them covers the chip nothing of another stream starts.  A host that runs two streams side by side gives the launches of
+ * the stream that is NOT its critical path a smaller budget, and the other stream's kernels find free compute units at once
+ * (RGBDUpdater: 160 of 256 for the discriminator phases beside the generator's; 7.70 -> 7.14 ms per step).  One value per
+ * process (launches issued from autograd's worker threads must see it); returns the previous value.  A grid size is fixed
+ * when its launch is captured into a HIP graph. */
+int rgbd_set_cu_budget(int n);
 int rgbd_conv2d_wgrad_partial_multi_bf16(const rgbd_wgrad_problem* probs, int n, void* stream);
 
 /* ------------------------------------------------------------------ AdaIN (instance norm + style affine)

@@ -10,7 +10,7 @@ from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p, POINTER
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RGBD_LIB_PATH: A/B timing of another build of the same ABI; the default is the in-tree library
 LIB_PATH = os.environ.get("RGBD_LIB_PATH") or os.path.join(_HERE, "librgbdgan_hip.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _P = c_void_p
 
@@ -42,6 +42,7 @@ PROTOTYPES = {
     "rgbd_conv2d_wgrad_partial_bf16": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P], c_int),
     "rgbd_wgrad_reduce_multi": ([_P, c_int, _P], c_int),
     "rgbd_conv2d_wgrad_multi_plan": ([_P, c_int, c_int], c_int),
+    "rgbd_set_cu_budget": ([c_int], c_int),
     "rgbd_conv2d_wgrad_partial_multi_bf16": ([_P, c_int, _P], c_int),
     "rgbd_adain_workspace": ([c_int, c_int, c_int], c_int64),
     "rgbd_adain_fwd": ([_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, _P], c_int),

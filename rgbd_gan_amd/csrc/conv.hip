@@ -24,6 +24,7 @@
 #include "common.h"
 
 #include <stdlib.h>
+#include <atomic>
 #include <type_traits>
 
 namespace {
@@ -2700,15 +2701,26 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(WgradMultiArgs 
 }
 
 // compute units of the CURRENT device (a process may drive several): looked up once per device, immutable afterwards
-int device_cus() {
+std::atomic<int> g_cu_budget{0};        // rgbd_set_cu_budget: 0 = all compute units
+int device_cus(bool for_wgrad = false) {
+#ifdef RGBD_DEBUG_BUILD
+    // experiment hook (debug library only): persistent grids sized for FEWER compute units than the chip has
+    static const int forced = getenv("RGBD_DEBUG_CUS") ? atoi(getenv("RGBD_DEBUG_CUS")) : 0;
+    static const int forced_w = getenv("RGBD_DEBUG_CUS_WGRAD") ? atoi(getenv("RGBD_DEBUG_CUS_WGRAD")) : 0;
+    if (for_wgrad && forced_w > 0) return forced_w;
+    if (forced > 0) return forced;
+#endif
     static int cus[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    if (cus[dev] == 0) {
-        hipDeviceProp_t prop;
-        cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+        if (cus[dev] == 0) {
+            hipDeviceProp_t prop;
+            cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        }
+        n = cus[dev];
     }
-    return cus[dev];
+    const int budget = g_cu_budget.load(std::memory_order_relaxed);
+    return budget > 0 && budget < n ? budget : n;
 }
 bool reserve_lds(const void* fn, int bytes) { return rgbd_reserve_lds(fn, bytes); }      // (common.h: once per kernel AND device)
 #ifdef RGBD_DEBUG_BUILD
@@ -3419,6 +3431,10 @@ bool multi_eligible_small(const rgbd_wgrad_problem& q) {
 }
 }  // namespace
 
+extern "C" int rgbd_set_cu_budget(int n) {
+    return g_cu_budget.exchange(n > 0 ? n : 0);
+}
+
 extern "C" int rgbd_conv2d_wgrad_multi_plan(rgbd_wgrad_problem* probs, int n, int total_workgroups) {
     RGBD_REQUIRE(probs && n > 0 && n <= WGRAD_MULTI_PROBLEMS, "rgbd_conv2d_wgrad_multi_plan: 1..%d problems", WGRAD_MULTI_PROBLEMS);
     if (multi_eligible_small(probs[0])) {
@@ -3429,7 +3445,7 @@ extern "C" int rgbd_conv2d_wgrad_multi_plan(rgbd_wgrad_problem* probs, int n, in
         }
         return 0;
     }
-    if (total_workgroups <= 0) total_workgroups = device_cus();
+    if (total_workgroups <= 0) total_workgroups = device_cus(true);
     double units = 0.0;
     for (int i = 0; i < n; ++i) {
         RGBD_REQUIRE(multi_eligible(probs[i]), "rgbd_conv2d_wgrad_multi_plan: problem %d is not a 3x3 conv on a power-of-two "

@@ -1,4 +1,5 @@
 """Thin, typed wrappers: torch device tensors in, C-ABI calls out.  No arithmetic happens here."""
+import contextlib
 import ctypes
 import os
 
@@ -703,6 +704,32 @@ class _WgradProblem(ctypes.Structure):          # struct rgbd_wgrad_problem (inc
 
 
 WGRAD_MULTI_MAX = 24
+# Persistent workgroups the batched weight-gradient launch deals out over its problems: 0 = one per compute unit.  A host
+# that runs a second stream beside the launch leaves compute units for it (wgrad_workgroups; RGBDUpdater does, for the
+# launches of its side stream: the launch fills the chip for ~0.5 ms, during which nothing of the other stream would start).
+WGRAD_WORKGROUPS = 0
+
+
+@contextlib.contextmanager
+def cu_budget(n):
+    """Launches inside size the persistent 3x3 kernels' grids (and weight-gradient plans without an explicit count) for `n`
+    compute units instead of all (rgbd_set_cu_budget; 0 / None = all)."""
+    lib = _lib.load()
+    prev = lib.rgbd_set_cu_budget(int(n or 0))
+    try:
+        yield
+    finally:
+        lib.rgbd_set_cu_budget(prev)
+
+
+@contextlib.contextmanager
+def wgrad_workgroups(n):
+    global WGRAD_WORKGROUPS
+    saved, WGRAD_WORKGROUPS = WGRAD_WORKGROUPS, int(n or 0)
+    try:
+        yield
+    finally:
+        WGRAD_WORKGROUPS = saved
 
 
 def _multi_ok(H, W, K):
@@ -764,7 +791,7 @@ def conv2d_wgrad_batch(items):
         for q, (i, x, dy, B, H, W, Cin, Cout, ups) in zip(probs, group):
             q.x, q.dy, q.workspace = x.data_ptr(), dy.data_ptr(), 0
             q.B, q.H, q.W, q.Cin, q.Cout, q.K, q.upsample, q.nsplit = B, H, W, Cin, Cout, 3, int(ups), 0
-        _lib.check(lib.rgbd_conv2d_wgrad_multi_plan(probs, len(group), 0), "rgbd_conv2d_wgrad_multi_plan")
+        _lib.check(lib.rgbd_conv2d_wgrad_multi_plan(probs, len(group), WGRAD_WORKGROUPS), "rgbd_conv2d_wgrad_multi_plan")
         sizes = [q.nsplit * 9 * q.Cout * q.Cin for q in probs]
         ws = torch.empty(sum(sizes), dtype=F32, device=group[0][1].device)
         keep.append(ws)

@@ -199,6 +199,18 @@ class RGBDUpdater:
         default = (env not in ("", "0")) if env is not None else not os.environ.get("RGBD_SHARE_DEVICE")
         self.concurrent_phases = bool(kwargs.pop("concurrent_phases", default))
         self.dp_split_body = bool(kwargs.pop("dp_split_body", True))
+        # Two streams: the side stream (D on the reals, D's weight gradients) is NOT the step's critical path (dis + dfw
+        # 6.8 ms beside gen_a + gen_b 7.9 ms), but its chip-filling launches -- the persistent 3x3 kernel, the 0.5 ms batched
+        # weight-gradient launch -- hold every compute unit while they run, and the generator's dependent chain of small
+        # kernels on the main stream waits.  Sized for FEWER compute units they leave the rest to the main stream
+        # (profiles/r05/cu_budget_sweep.txt).  0 = all.
+        # The weight-gradient launch is the one that pays: 160 of 256 workgroups at the benched shape (4040 -> 4290-4340
+        # img/s), fewer where the step is short kernels (B = 8: 64-128, +4-5 %), nearly all where it is long ones (256x256,
+        # B = 16: 224, +1 %); None = that dependence as a rule of thumb in the step's pixel count (_side_wgrad_auto).  The 3x3
+        # kernels' budget helps only the small-batch shapes (B = 8: 192, +3 % more) and costs 2-3 % at the benched one: off.
+        self.side_cu_budget = int(kwargs.pop("side_cu_budget", os.environ.get("RGBD_SIDE_CUS", "0")))
+        env = os.environ.get("RGBD_SIDE_WGRAD_WGS")
+        self.side_wgrad_workgroups = kwargs.pop("side_wgrad_workgroups", int(env) if env else None)
         if kwargs:
             raise TypeError(f"RGBDUpdater: unknown arguments {sorted(kwargs)}")
         self._side_stream = self._capture_stream = None
@@ -343,7 +355,8 @@ class RGBDUpdater:
     def _dfw_phase(self, st):
         """D's weight gradients for the fakes; on two streams this is the last writer of D's gradients (it follows `dis` on
         the side stream), so the two gradient buffers are merged here and D's all-reduce can start behind it."""
-        Fn.run_deferred_wgrads(st["dfw"])
+        with kernels.wgrad_workgroups(st.get("side_wgrad_wgs", 0)):
+            Fn.run_deferred_wgrads(st["dfw"])
         if st.get("concurrent"):
             for _, store in self.dis.stores:
                 store.merge_alt()
@@ -460,7 +473,8 @@ class RGBDUpdater:
             torch.autograd.backward([grad_x], [ggx])
         # D's weight gradients are leaves of the double backward: one partial-sum launch for all of them
         # (rgbd_conv2d_wgrad_partial_multi_bf16: one slab per CU for the whole pass instead of per layer)
-        Fn.run_deferred_wgrads(wgrads)
+        with kernels.wgrad_workgroups(st.get("side_wgrad_wgs", 0)):
+            Fn.run_deferred_wgrads(wgrads)
 
     def _join_phase(self, st):
         """After both phases: the reported discriminator loss gets its fake half."""
@@ -546,11 +560,22 @@ class RGBDUpdater:
         """True once the step is being replayed from captured HIP graphs (bench.py reports it)."""
         return bool(self.use_graphs and self._graphs)
 
-    def _run_phase(self, name, fn, st, key, stream=None):
+    def _side_wgrad_auto(self, st):
+        """Workgroups of the side stream's batched weight-gradient launches: 5/8 of the compute units at B x H x W = 32 x 128^2,
+        towards all of them for larger steps and a quarter for smaller ones (measured optima: 144-160 / 224 / 64-128 of 256 at
+        32 x 128^2 / 16 x 256^2 / 8 x 128^2; profiles/r05/cu_budget_sweep.txt), in multiples of 8 (one per XCD)."""
+        cus = torch.cuda.get_device_properties(self.device).multi_processor_count if torch.cuda.is_available() else 256
+        px = float(st["B"]) * float(st["x_real"].shape[2]) * float(st["x_real"].shape[3])
+        frac = min(1.0, max(0.25, 1.0 - 0.375 * (32.0 * 128.0 * 128.0) / px))
+        return max(8, int(round(cus * frac / 8.0)) * 8)
+
+    def _run_phase(self, name, fn, st, key, stream=None, cu_budget=0):
         """Eager for the first calls of a configuration, then capture once and replay -- on `stream` (default: the current
         one).  With profile_ranges every phase is bracketed by a roctx range (torch.cuda.nvtx maps to roctx on ROCm),
-        visible to rocprofv3 --marker-trace."""
-        with self._range(name), (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+        visible to rocprofv3 --marker-trace.  cu_budget: compute units the phase's chip-filling launches size their grids
+        for (kernels.cu_budget; fixed at capture)."""
+        with self._range(name), (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()), \
+                (kernels.cu_budget(cu_budget) if cu_budget else contextlib.nullcontext()):
             self._run_phase_inner(name, fn, st, key)
 
     def _run_phase_inner(self, name, fn, st, key):
@@ -789,10 +814,13 @@ class RGBDUpdater:
             main, side = torch.cuda.current_stream(), self._side_stream
             self._run_phase("prep", self._prep_only_phase, st, key)
             side.wait_stream(main)
-            self._run_phase("dis", self._dis_phase, st, key, stream=side)        # D on the reals, R1, its weight gradients
+            st["side_wgrad_wgs"] = self._side_wgrad_auto(st) if self.side_wgrad_workgroups is None else int(self.side_wgrad_workgroups)
+            self._run_phase("dis", self._dis_phase, st, key, stream=side,         # D on the reals, R1, its weight gradients
+                            cu_budget=self.side_cu_budget)
             self._run_phase("gen_a", self._gen_a_phase, st, key)                 # G forward, the one pass through D(x_fake)
             side.wait_stream(main)
-            self._run_phase("dfw", self._dfw_phase, st, key, stream=side)        # D's weight gradients for the fakes, merge
+            self._run_phase("dfw", self._dfw_phase, st, key, stream=side,         # D's weight gradients for the fakes, merge
+                            cu_budget=self.side_cu_budget)
             self._mark("side_end", side)
             if dp:
                 with torch.cuda.stream(side):   # D's gradients are final: 34 MB travel under the generator's backward

@@ -5,9 +5,10 @@ import numpy as np, torch
 from rgbd_gan_amd.training import DeviceImageIterator, build_training
 from rgbd_gan_amd.utils import yaml_utils
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-cfg = yaml_utils.load(os.path.join(root, "configs", "stylegan_shapenet_car.yml"))
+cfg = yaml_utils.load(os.path.join(root, "configs", os.environ.get("CONFIG", "stylegan_shapenet_car.yml")))   # CONFIG / B: another workload
 images = np.random.RandomState(0).randint(0, 256, (256, 3, 128, 128)).astype("uint8")
-it = DeviceImageIterator(images, 32, "cuda:0", seed=0)
+it = DeviceImageIterator(images, int(os.environ.get("B", "32")), "cuda:0", seed=0)
+cfg.batchsize = int(os.environ.get("B", "32"))
 gen, dis, opt, upd = build_training(cfg, "cuda:0", iterator=it, nan_check_interval=0)
 upd.iteration = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
 for i in range(8):

@@ -10,7 +10,9 @@ from rgbd_gan_amd.training import DeviceImageIterator, build_training
 from rgbd_gan_amd.utils import yaml_utils
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-config = yaml_utils.load(os.path.join(ROOT, "configs", "stylegan_shapenet_car.yml"))
+config = yaml_utils.load(os.path.join(ROOT, "configs", os.environ.get("CONFIG", "stylegan_shapenet_car.yml")))    # CONFIG / B: another workload
+if os.environ.get("B"):
+    config.batchsize = int(os.environ["B"])
 device = torch.device("cuda", 0)
 images = np.random.RandomState(0).randint(0, 256, (256, 3, 128, 128)).astype("uint8")
 it = DeviceImageIterator(images, config.batchsize, device, seed=0)
