@@ -2975,6 +2975,10 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
         int per_nt = num_cus / n_tiles;
         if (per_nt < 1) per_nt = 1;
         if (per_nt > ptiles) per_nt = (int)ptiles;
+        // ... and no more of them than the number of ROUNDS needs: the launch lasts as long as its busiest workgroup, so
+        // 320 tiles are two rounds on 256 workgroups and on 160, and the 96 compute units left over serve the other stream
+        // (profiles/r05/cu_budget_sweep.txt)
+        per_nt = (int)((ptiles + (ptiles + per_nt - 1) / per_nt - 1) / ((ptiles + per_nt - 1) / per_nt));
         a.ptiles = (int)ptiles;
         a.wgs_per_ntile = per_nt;
         const long grid = (long)per_nt * n_tiles;

@@ -207,8 +207,9 @@ class RGBDUpdater:
         # The weight-gradient launch is the one that pays: 160 of 256 workgroups at the benched shape (4040 -> 4290-4340
         # img/s), fewer where the step is short kernels (B = 8: 64-128, +4-5 %), nearly all where it is long ones (256x256,
         # B = 16: 224, +1 %); None = that dependence as a rule of thumb in the step's pixel count (_side_wgrad_auto).  The 3x3
-        # kernels' budget helps only the small-batch shapes (B = 8: 192, +3 % more) and costs 2-3 % at the benched one: off.
-        self.side_cu_budget = int(kwargs.pop("side_cu_budget", os.environ.get("RGBD_SIDE_CUS", "0")))
+        # kernels' budget (with grids already cut down to what their number of rounds needs, conv.hip): 224 of 256 is +3 % at
+        # B = 8 and at 256x256 and neutral at the benched shape; 192 and below cost there.
+        self.side_cu_budget = int(kwargs.pop("side_cu_budget", os.environ.get("RGBD_SIDE_CUS", "224")))
         env = os.environ.get("RGBD_SIDE_WGRAD_WGS")
         self.side_wgrad_workgroups = kwargs.pop("side_wgrad_workgroups", int(env) if env else None)
         if kwargs:

@@ -74,6 +74,8 @@ class DeepVoxelsUpdater(RGBDUpdater):
         self.graph_fallback = bool(kwargs.pop("graph_fallback", False))
         env = os.environ.get("RGBD_CONCURRENT_PHASES")
         self.concurrent_phases = bool(kwargs.pop("concurrent_phases", env is None or env not in ("", "0")))
+        self.side_cu_budget = int(kwargs.pop("side_cu_budget", os.environ.get("RGBD_SIDE_CUS", "192")))
+        self.side_wgrad_workgroups = int(kwargs.pop("side_wgrad_workgroups", os.environ.get("RGBD_SIDE_WGRAD_WGS", "128")))
         self._side_stream = None
         self._graphs, self._eager_calls, self._stagers = {}, {}, {}
 
@@ -113,7 +115,8 @@ class DeepVoxelsUpdater(RGBDUpdater):
         wgrads = []
         with Fn.deferred_wgrads(wgrads):
             total.backward()
-        Fn.run_deferred_wgrads(wgrads)
+        with kernels.wgrad_workgroups(st.get("side_wgrad_wgs", 0)):
+            Fn.run_deferred_wgrads(wgrads)
 
     def _dv_gen_phase(self, st):
         cfg, obs = self.config, self.observation
@@ -221,7 +224,10 @@ class DeepVoxelsUpdater(RGBDUpdater):
                 self._side_stream = torch.cuda.Stream(device=self.device)
             main, side = torch.cuda.current_stream(), self._side_stream
             side.wait_stream(main)
-            self._run_phase("dv_dis_real", self._dv_dis_real_phase, st, key, stream=side)
+            # the side stream's chip-filling launches leave compute units to the generator phase (RGBDUpdater.side_cu_budget;
+            # here 192 / 128 of 256: 977 -> 984-992 img/s, profiles/r05/cu_budget_sweep.txt)
+            st["side_wgrad_wgs"] = self.side_wgrad_workgroups
+            self._run_phase("dv_dis_real", self._dv_dis_real_phase, st, key, stream=side, cu_budget=self.side_cu_budget)
             self._run_phase("dv_gen", self._dv_gen_phase, st, key)
             main.wait_stream(side)
         else:

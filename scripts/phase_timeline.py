@@ -15,10 +15,10 @@ for i in range(8):
     upd.update()
 torch.cuda.synchronize()
 marks, orig = [], upd._run_phase
-def rp(name, fn, st, key, stream=None):
+def rp(name, fn, st, key, stream=None, **kw):
     s = stream if stream is not None else torch.cuda.current_stream()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(s); orig(name, fn, st, key, stream); e1.record(s)
+    e0.record(s); orig(name, fn, st, key, stream, **kw); e1.record(s)
     marks.append((name, e0, e1))
 upd._run_phase = rp
 steps = 4
