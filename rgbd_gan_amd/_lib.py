@@ -129,6 +129,7 @@ DEBUG_PROTOTYPES = {
 DEBUG_ONLY_PROTOTYPES = {
     "rgbd_debug_force_gather_kernel": ([c_int], c_int),
     "rgbd_debug_conv_variant": ([c_int], c_int),
+    "rgbd_debug_occ_unfused": ([c_int], None),
 }
 DEBUG_LIB_PATH = os.path.join(_HERE, "librgbdgan_hip_debug.so")
 
@@ -190,6 +191,7 @@ class debug_library:
         global _lib
         _lib.rgbd_debug_conv_variant(0)
         _lib.rgbd_debug_force_gather_kernel(0)
+        _lib.rgbd_debug_occ_unfused(0)
         _lib = self.saved
 
 

@@ -355,6 +355,92 @@ __global__ __launch_bounds__(256) void occ_compose_kernel(OccArgs a, const float
     feat[i] = acc;
 }
 
+// The three forward kernels above as ONE pass over the volume for F = 32 (the shipped grid width): a thread owns a ray,
+// holds its 32 feature sums in registers and walks the depth axis with the next depth's 32 loads in flight while it scores
+// and composes the current one -- the volume (335 MB at B = 20, D = 32, 64x64 rays) is read once instead of twice, and the
+// score / weight planes are written once instead of written and read back.  Same expressions in the same order as
+// occ_score / occ_scan / occ_compose: bit-identical outputs (tests/test_deepvoxels.py).
+template <int F>
+__global__ __launch_bounds__(256, 3) void occ_fwd_fused_kernel(OccArgs a, const float* __restrict__ vol,
+                                                            const float* __restrict__ W1, const float* __restrict__ b1,
+                                                            const float* __restrict__ W2, const float* __restrict__ b2,
+                                                            float* __restrict__ s, float* __restrict__ w,
+                                                            float* __restrict__ feat, float* __restrict__ depth,
+                                                            float depth_scale, float near_plane) {
+    // the first layer's weights, transposed to [input][4 hidden units], in LDS: one broadcast ds_read_b128 per input feature
+    // and depth step (as 132 + 9 scalars they did not fit the scalar file and were spilled to vector lanes)
+    constexpr int F1 = F + 1;
+    __shared__ f32x4 w1t[F1];
+    static_assert(OCC_NF == 4, "w1t packs the four hidden units of an input into one float4");
+    if (threadIdx.x < F1) {
+        const f32x4 t = {W1[threadIdx.x], W1[F1 + threadIdx.x], W1[2 * F1 + threadIdx.x], W1[3 * F1 + threadIdx.x]};
+        w1t[threadIdx.x] = t;
+    }
+    __syncthreads();
+    long ray = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = ray < (long)a.B * a.HW;
+    if (!live) return;
+    const int b = (int)(ray / a.HW);
+    const int p = (int)(ray - (long)b * a.HW);
+    const long vox = (long)a.D * a.HW;
+    // volume reads: (per-thread byte offset of the ray) + (scalar offset of the feature / depth plane) against one buffer
+    // descriptor -- one address register instead of 32 pointer pairs (the launcher checks that the volume is below 4 GB)
+    const auto vrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vol), 0, (int)((long)a.B * F * vox * 4), 0x00020000);
+    const unsigned voff = (unsigned)(((long)b * F * vox + p) * 4);
+    const long base = (long)b * vox + p;
+    float acc[F], xa[F], xb[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) acc[f] = 0.f;
+    float run = 0.f, prev = 0.f, dacc = 0.f;
+    auto load = [&](float (&x)[F], int d) {
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+            x[f] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(vrsrc, voff, (unsigned)(((long)f * vox + (long)d * a.HW) * 4), 0));
+    };
+    auto step = [&](const float (&x)[F], int d) {
+        float h[OCC_NF];
+        const float xc = depth_coord(d, a.D) * a.c1;
+        unsigned opaque = 0;            // the weights are re-read from LDS every step (hoisted out of the depth loop they
+        asm volatile("" : "+v"(opaque));                                   // occupied 132 registers: one wave per SIMD)
+        const f32x4* wl = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(w1t) + opaque);
+#pragma unroll
+        for (int j = 0; j < OCC_NF; ++j) h[j] = b1[j] + wl[0][j] * xc;
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const float xs = x[f] * a.c1;
+            const f32x4 wf = wl[1 + f];
+#pragma unroll
+            for (int j = 0; j < OCC_NF; ++j) h[j] += wf[j] * xs;
+        }
+        float pre = b2[0];
+#pragma unroll
+        for (int j = 0; j < OCC_NF; ++j) {
+            const float hj = h[j] > 0.f ? h[j] : 0.2f * h[j];
+            pre += W2[j] * (hj * a.c2);
+        }
+        const float sv = 1.f / (1.f + __expf(-(pre - a.threshold)));
+        run += sv;
+        const float c = fminf(fmaxf(run, 0.f), 1.f);
+        const float wd = c - prev;
+        prev = c;
+        s[base + (long)d * a.HW] = sv;
+        w[base + (long)d * a.HW] = wd;
+        dacc += depth_coord(d, a.D) * wd;
+#pragma unroll
+        for (int f = 0; f < F; ++f) acc[f] += wd * x[f];
+    };
+    load(xa, 0);
+    for (int d = 0; d < a.D; d += 2) {          // D is even (checked by the launcher)
+        load(xb, d + 1);
+        step(xa, d);
+        if (d + 2 < a.D) load(xa, d + 2);
+        step(xb, d + 1);
+    }
+#pragma unroll
+    for (int f = 0; f < F; ++f) feat[((long)b * F + f) * a.HW + p] = acc[f];
+    depth[ray] = ((dacc + 0.5f) * depth_scale) + near_plane;
+}
+
 // backward 1: dw[b,d,p] = sum_f dfeat[b,f,p] * vol[b,f,d,p] + ddepth'[b,p] * coord(d)
 __global__ __launch_bounds__(256) void occ_bwd_dw_kernel(OccArgs a, const float* __restrict__ vol,
                                                          const float* __restrict__ dfeat,
@@ -516,7 +602,16 @@ __global__ __launch_bounds__(256) void occ_bwd_params_kernel(const float* __rest
     if (threadIdx.x == 0) dparams[t] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+#ifdef RGBD_DEBUG_BUILD
+bool g_occ_unfused = false;    // test hook (debug library): the three-kernel forward for F = 32 too (bit-identity A/B)
+#else
+constexpr bool g_occ_unfused = false;
+#endif
 }  // namespace
+
+#ifdef RGBD_DEBUG_BUILD
+extern "C" void rgbd_debug_occ_unfused(int on) { g_occ_unfused = on != 0; }
+#endif
 
 extern "C" int rgbd_proj_idcs(const float* cam2world, int B, int W, int H, int D, int G, float voxel_size,
                               float near_plane, float fx, float fy, float cx, float cy, int32_t* idx, float* coords,
@@ -604,6 +699,12 @@ extern "C" int rgbd_occlusion_accum_fwd(const float* vol, const float* W1, const
     RGBD_REQUIRE(F > 0 && F <= OCC_MAXF && B > 0 && D > 0 && HW > 0, "rgbd_occlusion_accum_fwd: bad shape");
     OccArgs a{B, F, D, HW, sqrtf(2.f / (float)(F + 1)), sqrtf(2.f / (float)OCC_NF), threshold};
     hipStream_t st = (hipStream_t)stream;
+    if (F == 32 && (D & 1) == 0 && (long)B * F * D * HW * 4 < 0x7fffffffL && !g_occ_unfused) {
+        occ_fwd_fused_kernel<32><<<(unsigned)(((long)B * HW + 255) / 256), 256, 0, st>>>(a, vol, W1, b1, W2, b2, s, w, feat, depth,
+                                                                                       (float)D * voxel_size, near_plane);
+        RGBD_CHECK_LAUNCH("occ_fwd_fused_kernel");
+        return 0;
+    }
     const long nv = (long)B * D * HW;
     occ_score_kernel<<<(unsigned)((nv + 255) / 256), 256, 0, st>>>(a, vol, W1, b1, W2, b2, s);
     RGBD_CHECK_LAUNCH("occ_score_kernel");

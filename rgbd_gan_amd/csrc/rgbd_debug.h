@@ -23,6 +23,9 @@ const char* rgbd_last_conv_kernel(void);
 /* Test / tuning hook: 0 = default kernels, 1 = the register-staged 3x3 halo-patch kernel instead of the pipelined LDS-DMA
  * one, 2 = the pipelined kernel with 64-channel output tiles everywhere, 11-16 = timing knock-outs (wrong results). */
 int rgbd_debug_conv_variant(int v);
+/* Test hook: when on != 0, rgbd_occlusion_accum_fwd runs its three-kernel form (score, scan, compose) for the 32-feature
+ * grids too, which by default take the single-pass kernel: the bit-identity A/B of tests/test_deepvoxels.py. */
+void rgbd_debug_occ_unfused(int on);
 
 #ifdef __cplusplus
 }

@@ -130,6 +130,37 @@ def test_hip_accumulative_occlusion_forward_backward():
         torch.testing.assert_close(got.grad.cpu(), ref.grad, atol=2e-3 * scale, rtol=2e-3)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,D,S", [(2, 32, 64), (3, 8, 24)])
+def test_single_pass_occlusion_forward_is_the_three_kernel_forward_bit_for_bit(B, D, S):
+    """F = 32 grids take occ_fwd_fused_kernel (one pass over the volume); the debug library's switch sends them through the
+    score / scan / compose kernels the other widths use.  Same expressions in the same order: every output equal as bits
+    (ragged ray counts included: 3 x 24 x 24 is not a multiple of the block)."""
+    from rgbd_gan_amd import _lib
+    from rgbd_gan_amd.deepvoxel import deepvoxel as dv
+    g = torch.Generator().manual_seed(B * 100 + D)
+    F = 32
+    vol = (torch.randn(B, F, D, S, S, generator=g) * 0.5).cuda()
+    W1 = torch.randn(4, F + 1, generator=g).cuda()
+    b1 = (torch.randn(4, generator=g) * 0.1).cuda()
+    W2 = (torch.randn(1, 4, generator=g) * 2).cuda()
+    b2 = torch.full((1,), 3.0).cuda()
+    outs = []
+    with _lib.debug_library() as lib:
+        for unfused in (0, 1):
+            lib.rgbd_debug_occ_unfused(unfused)
+            try:
+                with torch.no_grad():
+                    f, d, w = dv.accumulative_occlusion(vol, W1, b1, W2, b2, threshold=4.0, voxel_size=0.05, near_plane=0.5)
+                torch.cuda.synchronize()
+            finally:
+                lib.rgbd_debug_occ_unfused(0)
+            outs.append((f.clone(), d.clone(), w.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    assert float(outs[0][2].abs().sum()) > 0
+
+
 # ---- layout folds of the DeepVoxels networks (deepvoxels_generator.py): HIP ops against the torch formulations
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,D0,H,C,up", [(2, 4, 4, 64, True), (3, 8, 8, 64, False), (1, 16, 16, 128, True), (2, 32, 32, 64, False)])
