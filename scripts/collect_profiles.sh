@@ -76,6 +76,13 @@ rm -rf gpurun_out/$R/smallops
 # ---- the phases' timeline from events (no tracer), and which torch ops still launch kernels in a step (default config, config 4)
 python3 scripts/phase_timeline.py > profiles/$R/phase_timeline.txt 2>/dev/null
 python3 scripts/phases_alone.py > profiles/$R/phases_alone.txt 2>/dev/null
+CONFIG=ffhq_stylegan_occlusion.yml B=8 python3 scripts/phase_timeline.py > profiles/$R/phase_timeline_c3_b8.txt 2>/dev/null
+CONFIG=ffhq_stylegan_occlusion.yml B=8 python3 scripts/phases_alone.py > profiles/$R/phases_alone_c3_b8.txt 2>/dev/null
+python3 scripts/step_conv_shapes.py 2>/dev/null | grep -v amdgpu.ids > profiles/$R/step_conv_shapes.txt
+CONFIG=deepvoxels_shapenet_car.yml ITERATION=100 python3 scripts/step_conv_shapes.py 2>/dev/null | grep -v amdgpu.ids > profiles/$R/step_conv_shapes_c4.txt
+# the two-stream step without the side stream's compute-unit budgets, same box (profiles/r05/cu_budget_sweep.txt)
+RGBD_SIDE_CUS=0 RGBD_SIDE_WGRAD_WGS=0 python3 bench.py --no-cpu-baseline --no-roofline --no-other-configs > profiles/$R/bench_default_no_cu_budget.json 2>/dev/null
+python3 -m pytest tests -q -m gpu 2>&1 | tail -3 > profiles/$R/gpu_tests_same_box.txt
 python3 scripts/torch_op_sources.py 2>/dev/null | grep -v amdgpu.ids > profiles/$R/torch_op_sources.txt
 python3 scripts/torch_op_sources.py 200000 configs/deepvoxels_shapenet_car.yml 2>/dev/null | grep -v amdgpu.ids > profiles/$R/torch_op_sources_c4.txt
 python3 bench.py > profiles/$R/bench_default.json 2> gpurun_out/$R/default.err
