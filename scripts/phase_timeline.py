@@ -9,7 +9,17 @@ cfg = yaml_utils.load(os.path.join(root, "configs", os.environ.get("CONFIG", "st
 images = np.random.RandomState(0).randint(0, 256, (256, 3, 128, 128)).astype("uint8")
 it = DeviceImageIterator(images, int(os.environ.get("B", "32")), "cuda:0", seed=0)
 cfg.batchsize = int(os.environ.get("B", "32"))
-gen, dis, opt, upd = build_training(cfg, "cuda:0", iterator=it, nan_check_interval=0)
+extra = {}
+if os.environ.get("RES256"):            # BASELINE configuration 5 as bench.py --res256 [--fp8] builds it (B = 16)
+    from rgbd_gan_amd import kernels
+    cfg.ch, cfg.max_resolution, cfg.max_stage = 512, 256, 13
+    extra = {"fixed_stage": 12.0}
+    images = np.random.RandomState(0).randint(0, 256, (64, 3, 256, 256)).astype("uint8")
+    it = DeviceImageIterator(images, int(os.environ.get("B", "16")), "cuda:0", seed=0)
+    if os.environ.get("RES256") == "fp8":
+        cfg.conv_dtype = "mxfp8"
+        kernels.MX8_EMIT = True
+gen, dis, opt, upd = build_training(cfg, "cuda:0", iterator=it, nan_check_interval=0, **extra)
 upd.iteration = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
 for i in range(8):
     upd.update()
