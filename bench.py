@@ -57,6 +57,7 @@ def parse():
                     help="the default command also runs short lines of configurations 3 (per-GPU shape), 4 and 5 (bf16 / fp8) "
                          "into `other_configs`; this switches them off")
     ap.add_argument("--other-steps", type=int, default=30)
+    ap.add_argument("--other-only", type=str, default="", help="comma list: run only these of the other configurations")
     ap.add_argument("--mx8-standalone-quantiser", action="store_true",
                     help="A/B aid for --fp8: every conv input through rgbd_quantize_mxfp8 instead of the producers' epilogues")
     return ap.parse_args()
@@ -460,6 +461,8 @@ def main():
         import copy
         line["other_configs"] = {}
         for name, over in OTHER_CONFIGS:
+            if args.other_only and name not in args.other_only.split(","):
+                continue
             a2 = copy.copy(args)
             for k, v in over.items():
                 setattr(a2, k, v)

@@ -127,6 +127,21 @@ def _alpha_ctx(st):
     return net.alpha_override(st["alpha"]) if st.get("alpha") is not None else contextlib.nullcontext()
 
 
+_SHARED_STREAMS = {}
+
+
+def shared_stream(device, role):
+    """The process's ONE side stream / capture stream per device, shared by every updater built in it.  HIP deals a
+    process's streams out over a handful of hardware queues in creation order: an updater that made its own pair -- the
+    fourth one built in a process, as bench.py's other_configs did -- could get a side stream on the main stream's queue,
+    and the two-stream step ran at the one-stream time (configuration 5 on bf16: 21.0 instead of 18.5 ms, exactly
+    reproducible)."""
+    key = (torch.device(device).index or 0, role)
+    if key not in _SHARED_STREAMS:
+        _SHARED_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SHARED_STREAMS[key]
+
+
 class _HostStager:
     """Small host -> device uploads without blocking the host on the stream: a ring of pinned staging buffers,
     each guarded by an event (the reference does a blocking cupy.asarray per step, updater.py:267,315-318)."""
@@ -604,7 +619,7 @@ class RGBDUpdater:
                 # parameters (D in gen_a and in dis) could come out with a fork / join around an accumulation; captured
                 # on one stream every phase is a plain chain of kernel nodes (checked: hipGraphGetEdges = nodes - 1)
                 if self._capture_stream is None:
-                    self._capture_stream = torch.cuda.Stream(device=self.device)
+                    self._capture_stream = shared_stream(self.device, "capture")
                 with torch.cuda.graph(graph, stream=self._capture_stream, capture_error_mode="thread_local"):
                     fn(st)
             except Exception as exc:
@@ -811,7 +826,7 @@ class RGBDUpdater:
             # scripts/phase_timeline.py, or a kernel trace through scripts/trace_overlap.py -- a small kernel's duration
             # in a trace is its stretched length under the other queue's chip-filling kernel, not its cost.)
             if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream(device=self.device)
+                self._side_stream = shared_stream(self.device, "side")
             main, side = torch.cuda.current_stream(), self._side_stream
             self._run_phase("prep", self._prep_only_phase, st, key)
             side.wait_stream(main)

@@ -29,7 +29,7 @@ import torch.nn.functional as F
 from . import functional as Fn
 from . import kernels
 from .common.loss_functions import LossFuncRotate
-from .updater import RGBDUpdater, get_camera_matries
+from .updater import RGBDUpdater, get_camera_matries, shared_stream
 
 IMG_SIZE = 64
 FIXED_STAGE = 8.5
@@ -221,7 +221,7 @@ class DeepVoxelsUpdater(RGBDUpdater):
         self._run_phase("dv_prep", self._dv_prep_phase, st, key)
         if self.concurrent_phases:
             if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream(device=self.device)
+                self._side_stream = shared_stream(self.device, "side")
             main, side = torch.cuda.current_stream(), self._side_stream
             side.wait_stream(main)
             # the side stream's chip-filling launches leave compute units to the generator phase (RGBDUpdater.side_cu_budget;
