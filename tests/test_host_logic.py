@@ -274,3 +274,20 @@ def test_trainer_snapshot_uses_the_reference_key_layout_and_round_trips():
     fresh = make()
     got = ts.unpack(old, fresh)
     assert got["iteration"] == 40 and got["log"] == [{"iteration": 40}] and same_moments(fresh["map"], opts["map"])
+
+
+def test_side_stream_weight_gradient_budget_rule():
+    """RGBDUpdater._side_wgrad_auto: workgroups of the side stream's batched weight-gradient launches, a rule of thumb through
+    the three measured optima (profiles/r05/cu_budget_sweep.txt): 5/8 of the compute units at 32 x 128^2, towards all of them for
+    larger steps, a quarter for smaller ones; multiples of 8."""
+    from rgbd_gan_amd.updater import RGBDUpdater
+
+    class Shape:
+        def __init__(self, *s):
+            self.shape = s
+    fake = type("U", (), {"device": "cpu"})()
+    rule = lambda B, S: RGBDUpdater._side_wgrad_auto(fake, {"B": B, "x_real": Shape(B, 3, S, S)})
+    if not torch.cuda.is_available():
+        assert rule(32, 128) == 160 and rule(8, 128) == 64 and rule(16, 256) == 208 and rule(32, 64) == 64
+        assert rule(64, 256) == 240 and rule(2, 16) == 64
+    assert all(rule(B, S) % 8 == 0 for B in (2, 8, 32) for S in (16, 64, 256))

@@ -330,6 +330,52 @@ def test_conv_wgrad_batch_matches_single_calls():
         torch.testing.assert_close(got, ref, rtol=1e-5, atol=2e-5 * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("budget", [8, 40, 100, 224])
+def test_compute_unit_budget_changes_grids_not_results(budget):
+    """rgbd_set_cu_budget / the weight-gradient plan's workgroup count (RGBDUpdater gives its side stream's chip-filling
+    launches fewer compute units): the 3x3 kernel walks the same tiles with the same arithmetic on fewer persistent
+    workgroups -- every form bit-identical; the weight gradients are the same sums split over a different number of slabs
+    (fp32 summation order)."""
+    from rgbd_gan_amd import kernels
+    g = torch.Generator().manual_seed(budget)
+    B, H, Cin, Cout = 5, 64, 128, 256                        # 80 pixel tiles x 2 channel tiles: 2 rounds on 40 workgroups
+    x = torch.randn(B, H, H, Cin, generator=g).to(dev()).to(torch.bfloat16)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g).to(dev())
+    bias = torch.randn(Cout, generator=g).to(dev())
+    act = torch.randn(B, H, H, Cout, generator=g).to(dev()).to(torch.bfloat16)
+    wf, wd = kernels.pack_weights(w, 0.03)
+    dy = torch.randn(B, H, H, Cout, generator=g).to(dev()).to(torch.bfloat16)
+
+    def run():
+        y = kernels.conv2d_fprop(x, wf, 3, 3, 1, bias=bias, lrelu_channels=Cout)
+        ya = kernels.conv3x3_actgrad(x, wf, act)
+        ys = kernels.conv2d_fprop_stats(x, wf, bias=bias, lrelu_channels=Cout)
+        items = [(x, dy, torch.zeros(Cout, Cin, 3, 3, device=dev()), 3, 1.0, False),
+                 (x[:, ::2, ::2].contiguous(), dy, torch.zeros(Cout, Cin, 3, 3, device=dev()), 3, 0.5, True)]
+        kernels.conv2d_wgrad_batch(items)
+        return [y, ya] + [t for t in ys if torch.is_tensor(t)], [it[2] for it in items]
+
+    ref_y, ref_w = run()
+    with kernels.cu_budget(budget), kernels.wgrad_workgroups(budget):
+        got_y, got_w = run()
+    assert _lib_budget() == 0                                   # the context put the default back
+    for a, b in zip(ref_y, got_y):
+        if a.dtype == torch.bfloat16:
+            assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+        else:               # the instance-norm statistics: a workgroup adds up its tiles of a sample in fp32 before the fixed-point add
+            torch.testing.assert_close(a.double(), b.double(), rtol=1e-6, atol=1e-6 * float(a.double().abs().max()))
+    for a, b in zip(ref_w, got_w):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=2e-5 * float(a.abs().max()))
+
+
+def _lib_budget():
+    from rgbd_gan_amd import _lib
+    lib = _lib.load()
+    prev = lib.rgbd_set_cu_budget(0)
+    lib.rgbd_set_cu_budget(prev)
+    return prev
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 4, 4, 64, 64), (3, 8, 8, 128, 64), (2, 32, 32, 64, 128), (1, 64, 64, 64, 64)])
 def test_conv_wgrad_through_the_upsampling(B, H, W, Cin, Cout):
     """c0(upscale2x(h)) of a synthesis block (net.py:148-150, rescale.py:4-5): the weight gradient reads the
