@@ -379,9 +379,9 @@ def test_full_training_step_matches_oracle(stage):
         src = gpl if prefix else dpl
         for n in names:
             a, b = store[n].grad.cpu(), src[prefix + n].grad
-            # noise floor of bf16 activations vs the fp32 oracle (leaky-ReLU mask flips): measured 0.85..0.999 run to run,
-            # median 0.985 over all 130 parameter tensors (scripts/diag_grads.py)
-            assert cosine(a, b) > 0.8, (prefix + n, cosine(a, b))
+            # noise floor of bf16 activations vs the fp32 oracle (leaky-ReLU mask flips); round 5, four seeds x two stages: the
+            # worst of ALL ~130 tensors 0.914-0.975 (a 256-entry bias), these large ones > 0.97
+            assert cosine(a, b) > 0.9, (prefix + n, cosine(a, b))
     # ... and ALL of them as a population: against the fp32 oracle the floor is set by leaky-ReLU mask flips of bf16
     # pre-activations, so single tensors scatter (the 0.8 above) while the bulk must sit near 1 -- a systematic error of the
     # single-pass dataflow (a dropped 1/B, a seed ratio applied twice) would move the whole distribution or the norms
@@ -399,9 +399,11 @@ def test_full_training_step_matches_oracle(stage):
     if os.environ.get("RGBD_TEST_VERBOSE"):
         print("cosine: min %.3f, 5 %% %.3f, median %.4f; norm ratio median %.3f" %
               (cos[0], cos[len(cos) // 20], np.median(cos), np.median(ratio)), sorted(rows, key=lambda r: r[1])[:5])
-    assert np.median(cos) > 0.97, np.median(cos)
-    assert cos[len(cos) // 20] > 0.85, cos[:8]
-    assert cos[0] > 0.5, min(rows, key=lambda r: r[1])
+    # measured (RGBD_TEST_SEED 0-3, stages 10 and 9.5): median 0.9925-0.9960, 5th percentile 0.976-0.986, worst single tensor
+    # 0.914-0.975, median norm ratio 0.998-1.014
+    assert np.median(cos) > 0.985, np.median(cos)
+    assert cos[len(cos) // 20] > 0.95, cos[:8]
+    assert cos[0] > 0.8, min(rows, key=lambda r: r[1])
     assert abs(np.median(ratio) - 1.0) < 0.03, np.median(ratio)
     # pre-clip gradient norms seen by the optimizers
     for k, o in (("norm_map", opt["map"]), ("norm_gen", opt["gen"]), ("norm_dis", opt["dis"])):
