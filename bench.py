@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="the default command also runs short lines of configurations 3 (per-GPU shape), 4 and 5 (bf16 / fp8) "
                          "into `other_configs`; this switches them off")
+    ap.add_argument("--no-autotune", action="store_true", help="take the rule of thumb for the side stream's budget, measure nothing")
     ap.add_argument("--other-steps", type=int, default=30)
     ap.add_argument("--other-only", type=str, default="", help="comma list: run only these of the other configurations")
     ap.add_argument("--mx8-standalone-quantiser", action="store_true",
@@ -261,6 +262,14 @@ def run_workload(args, comm, device):
     gen, dis, opt, upd = build_training(config, device, comm if comm.active else None, iterator=it,
                                         nan_check_interval=0, **extra)
     upd.iteration = args.iteration
+    tuning = None
+    if not args.no_autotune and hasattr(upd, "autotune_side_budget"):
+        # set-up, before the W warm-up and K timed steps: the side stream's weight-gradient workgroup count measured on this
+        # device at this shape (RGBDUpdater.autotune_side_budget: a fixed number of ordinary steps on every rank)
+        if upd.autotune_side_budget(log=(lambda m: print(m, file=sys.stderr, flush=True)) if comm.rank == 0 else None) is not None:
+            tuning = upd.side_budget_tuning      # (the landscape is flat near its optimum -- 144-192 within 1 % at the benched
+                                                 # shape -- and devices of the pool differ in where it lies)
+        upd.iteration = args.iteration
 
     def sync():
         torch.cuda.synchronize()
@@ -308,7 +317,11 @@ def run_workload(args, comm, device):
                    "arrangement": "two streams, one graph per phase" if getattr(upd, "concurrent_phases", False) else "one stream",
                    # True only if the timed steps were replays of captured HIP graphs (a refused capture is fatal in the
                    # updater: graph_fallback is off)
-                   "graphs": bool(getattr(upd, "graphs_in_use", upd.use_graphs))},
+                   "graphs": bool(getattr(upd, "graphs_in_use", upd.use_graphs)),
+                   # compute units the side stream's chip-filling launches are sized for: the
+                   # weight-gradient workgroup count measured at set-up on this device (rule of thumb -> chosen), or None
+                   "side_stream_budget": ({"cus_3x3": getattr(upd, "side_cu_budget", None), "wgrad_workgroups": tuning}
+                                          if getattr(upd, "concurrent_phases", False) else None)},
         "host_enqueue_ms_per_step": round(t_burst / burst * 1e3, 3),
         "host_enqueue_note": f"wall time of the launch thread per step over a {burst}-step burst after a sync (no queue "
                              f"back-pressure); over the timed loop it was {t_enqueue / args.steps * 1e3:.3f} ms",

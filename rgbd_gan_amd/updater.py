@@ -579,11 +579,69 @@ class RGBDUpdater:
     def _side_wgrad_auto(self, st):
         """Workgroups of the side stream's batched weight-gradient launches: 5/8 of the compute units at B x H x W = 32 x 128^2,
         towards all of them for larger steps and a quarter for smaller ones (measured optima: 144-160 / 224 / 64-128 of 256 at
-        32 x 128^2 / 16 x 256^2 / 8 x 128^2; profiles/r05/cu_budget_sweep.txt), in multiples of 8 (one per XCD)."""
+        32 x 128^2 / 16 x 256^2 / 8 x 128^2; profiles/r05/cu_budget_sweep.txt), in multiples of 8 (one per XCD) -- unless
+        autotune_side_budget has MEASURED this shape on this device (devices of the pool differ by several percent in how
+        the two streams' work compares)."""
+        shape = (int(st["B"]), int(st["x_real"].shape[2]), int(st["x_real"].shape[3]))
+        tuned = getattr(self, "_side_wgrad_tuned", {}).get(shape)
+        if tuned is not None:
+            return tuned
         cus = torch.cuda.get_device_properties(self.device).multi_processor_count if torch.cuda.is_available() else 256
-        px = float(st["B"]) * float(st["x_real"].shape[2]) * float(st["x_real"].shape[3])
+        px = float(shape[0]) * float(shape[1]) * float(shape[2])
         frac = min(1.0, max(0.25, 1.0 - 0.375 * (32.0 * 128.0 * 128.0) / px))
         return max(8, int(round(cus * frac / 8.0)) * 8)
+
+    def autotune_side_budget(self, measure_steps=12, log=None):
+        """Measure, on THIS device and at the CURRENT stage / batch, the workgroup count of the side stream's weight-gradient
+        launches instead of taking the rule of thumb: the rule's value and five neighbours (-32, +32, +64, then best -16 / +16),
+        each timed over `measure_steps` replayed steps behind a re-capture; the fastest is kept for this (batch, image size)
+        (_side_wgrad_auto).  ~60 ordinary training steps -- they update the networks like any others -- and six captures, about
+        a second.  The number of steps is fixed, whatever is measured, so the ranks of a data-parallel job stay in step (each
+        keeps its own optimum).  No-op (returns None) without two streams + graphs, or with an explicit side_wgrad_workgroups."""
+        import time
+        if not (self.concurrent_phases and self.use_graphs and self.side_wgrad_workgroups is None and torch.cuda.is_available()):
+            return None
+        for _ in range(self.graph_warmup + 1):                 # the shape's graphs exist, _last_shape is known
+            self.update()
+        shape = self._last_shape
+        cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        self._side_wgrad_tuned = getattr(self, "_side_wgrad_tuned", {})
+        self._side_wgrad_tuned.pop(shape, None)
+        w0 = self._side_wgrad_auto({"B": shape[0], "x_real": torch.empty(0, 0, shape[1], shape[2])})
+        clamp = lambda w: int(min(cus, max(32, w)))
+        results = {}
+
+        def timed(w):
+            self._side_wgrad_tuned[shape] = w
+            self._graphs.clear()                                # every phase is re-captured (the side phases bake the count in)
+            for _ in range(2):
+                self.update()
+            torch.cuda.synchronize(self.device)
+            t0 = time.perf_counter()
+            for _ in range(measure_steps):
+                self.update()
+            torch.cuda.synchronize(self.device)
+            t = (time.perf_counter() - t0) / measure_steps
+            results[w] = min(t, results.get(w, t))
+            if log is not None:
+                log(f"autotune_side_budget {shape}: {w} workgroups {1e3 * t:.3f} ms per step")
+
+        try:
+            for d in (0, -32, 32, 64):
+                timed(clamp(w0 + d))
+            best = min(results, key=results.get)
+            for d in (-16, 16):
+                timed(clamp(best + d))
+            best = min(results, key=results.get)
+        except Exception:
+            self._side_wgrad_tuned.pop(shape, None)             # back to the rule of thumb, nothing half-measured kept
+            self._graphs.clear()
+            raise
+        self._side_wgrad_tuned[shape] = best
+        self._graphs.clear()
+        self.side_budget_tuning = {"shape": shape, "rule": w0, "chosen": best,
+                                   "ms_per_step": {int(k): round(1e3 * v, 4) for k, v in sorted(results.items())}}
+        return best
 
     def _run_phase(self, name, fn, st, key, stream=None, cu_budget=0):
         """Eager for the first calls of a configuration, then capture once and replay -- on `stream` (default: the current
@@ -831,6 +889,7 @@ class RGBDUpdater:
             self._run_phase("prep", self._prep_only_phase, st, key)
             side.wait_stream(main)
             st["side_wgrad_wgs"] = self._side_wgrad_auto(st) if self.side_wgrad_workgroups is None else int(self.side_wgrad_workgroups)
+            self._last_shape = (int(st["B"]), int(st["x_real"].shape[2]), int(st["x_real"].shape[3]))
             self._run_phase("dis", self._dis_phase, st, key, stream=side,         # D on the reals, R1, its weight gradients
                             cu_budget=self.side_cu_budget)
             self._run_phase("gen_a", self._gen_a_phase, st, key)                 # G forward, the one pass through D(x_fake)

@@ -130,6 +130,37 @@ def test_dcgan_config_training_steps_run():
     assert int(opt["gen"].t) == 4 and int(opt["dis"].t) == 4
 
 
+def test_side_budget_autotune_measures_a_fixed_number_of_steps_and_keeps_the_step_working():
+    """RGBDUpdater.autotune_side_budget: the side stream's weight-gradient workgroup count measured on this device (six candidates
+    around the rule of thumb, every phase re-captured for each) -- the number of steps it takes is FIXED (the ranks of a
+    data-parallel job must stay in step), the chosen count is one of the measured ones and is what the next captures use."""
+    from rgbd_gan_amd.training import DeviceImageIterator, build_training
+    from rgbd_gan_amd.utils import yaml_utils
+    cfg = yaml_utils.load(os.path.join(ROOT, "configs", "stylegan_shapenet_car.yml"))
+    images = np.random.RandomState(0).randint(0, 256, (32, 3, 128, 128)).astype("uint8")
+    np.random.seed(0)
+    torch.manual_seed(0)
+    it = DeviceImageIterator(images, 8, "cuda:0", seed=0)
+    gen, dis, opt, upd = build_training(cfg, "cuda:0", iterator=it, fixed_stage=8.0, nan_check_interval=1)
+    upd.iteration = 150000
+    if not upd.concurrent_phases:
+        pytest.skip("one-stream arrangement selected by the environment")
+    it0 = upd.iteration
+    best = upd.autotune_side_budget(measure_steps=2)
+    steps = upd.iteration - it0
+    assert steps == (upd.graph_warmup + 1) + 6 * (2 + 2), steps
+    tune = upd.side_budget_tuning
+    assert tune["shape"] == (8, 64, 64) and tune["rule"] == 64 and best == tune["chosen"] and best in tune["ms_per_step"]
+    assert upd._side_wgrad_auto({"B": 8, "x_real": torch.empty(8, 3, 64, 64)}) == best
+    assert upd._side_wgrad_auto({"B": 8, "x_real": torch.empty(8, 3, 128, 128)}) == 64        # another shape: the rule
+    for _ in range(4):
+        upd.update()                                            # re-captured with the chosen count, replayed
+    assert any(k[-1] == "dis" for k in upd._graphs)
+    assert all(np.isfinite(float(v)) for v in upd.observation.values())
+    upd.side_wgrad_workgroups = 96                              # an explicit count: nothing to measure
+    assert upd.autotune_side_budget() is None
+
+
 def test_a_diverging_run_stops_within_two_steps_without_a_per_step_sync():
     """updater.py:336,360,439 of the reference assert not-NaN on the host three times per step.  Here the losses' finiteness is
     folded into a sticky device flag every step (rgbd_nonfinite_mask_f32) and read a step later through a pinned copy: with

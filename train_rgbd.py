@@ -111,6 +111,12 @@ def main():
         if updater.smoothed_gen is not None:
             previews.append(PreviewSampler(updater.smoothed_gen, out, config, rows=8, cols=8, subdir="preview_smoothed"))
 
+    if hasattr(updater, "autotune_side_budget") and updater.iteration + 200 < config.iteration:
+        # ~90 ordinary training steps that also measure, on this device and at the current stage, how many compute units the
+        # side stream's weight-gradient launches should leave to the generator's stream
+        tuned = updater.autotune_side_budget()
+        if tuned is not None and is_master:
+            print(f"side stream budget: {updater.side_budget_tuning}")
     log, t0 = log_resumed, time.time() - elapsed_resumed       # a resumed run appends to the log it left (LogReport)
     while updater.iteration < config.iteration:
         updater.update()
