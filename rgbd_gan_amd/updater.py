@@ -595,9 +595,9 @@ class RGBDUpdater:
         """Measure, on THIS device and at the CURRENT stage / batch, the workgroup count of the side stream's weight-gradient
         launches instead of taking the rule of thumb: the rule's value and five neighbours (-32, +32, +64, then best -16 / +16),
         each timed over `measure_steps` replayed steps behind a re-capture; the fastest is kept for this (batch, image size)
-        (_side_wgrad_auto).  ~60 ordinary training steps -- they update the networks like any others -- and six captures, about
-        a second.  The number of steps is fixed, whatever is measured, so the ranks of a data-parallel job stay in step (each
-        keeps its own optimum).  No-op (returns None) without two streams + graphs, or with an explicit side_wgrad_workgroups."""
+        (_side_wgrad_auto).  graph_warmup + 1 + 6 x (2 + measure_steps) ordinary training steps (87 by default) -- they update
+        the networks like any others -- and seven re-captures of the step's graphs: one to three seconds.  The number of steps is
+        fixed, whatever is measured, so the ranks of a data-parallel job stay in step (each keeps its own optimum).  No-op (returns None) without two streams + graphs, or with an explicit side_wgrad_workgroups."""
         import time
         if not (self.concurrent_phases and self.use_graphs and self.side_wgrad_workgroups is None and torch.cuda.is_available()):
             return None
