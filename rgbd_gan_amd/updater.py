@@ -869,7 +869,9 @@ class RGBDUpdater:
                     self._stagers[skey] = torch.empty_like(x_real_data)
                 self._stagers[skey].copy_(x_real_data)
                 st["x_real_full"] = self._stagers[skey]
-            key = (batch_size, fl, use_rotate, occlusion, full_shape, z_fake_data is not None, real_idx is not None)
+            # (the conv dtype is baked into a capture: a set_conv_dtype after the graphs exist gets graphs of its own)
+            key = (batch_size, fl, use_rotate, occlusion, full_shape, z_fake_data is not None, real_idx is not None,
+                   Fn.conv_dtype())
 
         st["concurrent"] = self.concurrent_phases
         dp = getattr(opt_d, "comm", None) is not None and opt_d.comm.active

@@ -214,7 +214,7 @@ class DeepVoxelsUpdater(RGBDUpdater):
                 self._stagers[skey] = torch.empty_like(x_real_full)
             self._stagers[skey].copy_(x_real_full)
             x_real_full = self._stagers[skey]
-            key = (B, use_rotate, tuple(x_real_full.shape), z_fake is not None)
+            key = (B, use_rotate, tuple(x_real_full.shape), z_fake is not None, Fn.conv_dtype())
         st["x_real_full"] = x_real_full
 
         self._replayed = False
