@@ -263,7 +263,8 @@ def run_workload(args, comm, device):
                                         nan_check_interval=0, **extra)
     upd.iteration = args.iteration
     tuning = None
-    if not args.no_autotune and hasattr(upd, "autotune_side_budget"):
+    if not args.no_autotune and comm.size == 1 and hasattr(upd, "autotune_side_budget"):    # (N > 1: the rule of thumb -- the
+        # measurement's re-captures beside RCCL have never run on more than one device; its step count is rank-independent)
         # set-up, before the W warm-up and K timed steps: the side stream's weight-gradient workgroup count measured on this
         # device at this shape (RGBDUpdater.autotune_side_budget: a fixed number of ordinary steps on every rank)
         if upd.autotune_side_budget(log=(lambda m: print(m, file=sys.stderr, flush=True)) if comm.rank == 0 else None) is not None:
