@@ -56,7 +56,8 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="the default command also runs short lines of configurations 3 (per-GPU shape), 4 and 5 (bf16 / fp8) "
                          "into `other_configs`; this switches them off")
-    ap.add_argument("--no-autotune", action="store_true", help="take the rule of thumb for the side stream's budget, measure nothing")
+    ap.add_argument("--autotune", action="store_true", help="measure the side stream's workgroup counts at set-up (RGBDUpdater.autotune_side_budget) "
+                                                         "instead of taking the rule of thumb")
     ap.add_argument("--other-steps", type=int, default=30)
     ap.add_argument("--other-only", type=str, default="", help="comma list: run only these of the other configurations")
     ap.add_argument("--mx8-standalone-quantiser", action="store_true",
@@ -263,7 +264,7 @@ def run_workload(args, comm, device):
                                         nan_check_interval=0, **extra)
     upd.iteration = args.iteration
     tuning = None
-    if not args.no_autotune and comm.size == 1 and hasattr(upd, "autotune_side_budget"):    # (N > 1: the rule of thumb -- the
+    if args.autotune and comm.size == 1 and hasattr(upd, "autotune_side_budget"):    # (N > 1: the rule of thumb -- the
         # measurement's re-captures beside RCCL have never run on more than one device; its step count is rank-independent)
         # set-up, before the W warm-up and K timed steps: the side stream's weight-gradient workgroup count measured on this
         # device at this shape (RGBDUpdater.autotune_side_budget: a fixed number of ordinary steps on every rank)
@@ -321,7 +322,10 @@ def run_workload(args, comm, device):
                    "graphs": bool(getattr(upd, "graphs_in_use", upd.use_graphs)),
                    # compute units the side stream's chip-filling launches are sized for: the
                    # weight-gradient workgroup count measured at set-up on this device (rule of thumb -> chosen), or None
-                   "side_stream_budget": ({"cus_3x3": getattr(upd, "side_cu_budget", None), "wgrad_workgroups": tuning}
+                   "side_stream_budget": ({"cus_3x3": getattr(upd, "side_cu_budget", None),
+                                           "wgrad_workgroups_dis_dfw": list(upd._side_wgrad_pair({"B": B, "x_real": torch.empty(0, 0, side, side)}))
+                                           if hasattr(upd, "_side_wgrad_pair") and getattr(upd, "side_wgrad_workgroups", 0) is None else
+                                           getattr(upd, "side_wgrad_workgroups", None), "measured": tuning}
                                           if getattr(upd, "concurrent_phases", False) else None)},
         "host_enqueue_ms_per_step": round(t_burst / burst * 1e3, 3),
         "host_enqueue_note": f"wall time of the launch thread per step over a {burst}-step burst after a sync (no queue "

@@ -227,6 +227,11 @@ class RGBDUpdater:
         self.side_cu_budget = int(kwargs.pop("side_cu_budget", os.environ.get("RGBD_SIDE_CUS", "224")))
         env = os.environ.get("RGBD_SIDE_WGRAD_WGS")
         self.side_wgrad_workgroups = kwargs.pop("side_wgrad_workgroups", int(env) if env else None)
+        # ... of which the SECOND launch (D's weight gradients for the fakes, `dfw`) mostly runs behind the end of the
+        # generator's backward on most devices of the pool and is better off with (nearly) the whole chip, while on a fast one it
+        # still overlaps it: its own count, by default half way between the first launch's and all (measured: autotune_side_budget)
+        env = os.environ.get("RGBD_DFW_WGRAD_WGS")
+        self.dfw_wgrad_workgroups = kwargs.pop("dfw_wgrad_workgroups", int(env) if env else None)
         if kwargs:
             raise TypeError(f"RGBDUpdater: unknown arguments {sorted(kwargs)}")
         self._side_stream = self._capture_stream = None
@@ -371,7 +376,7 @@ class RGBDUpdater:
     def _dfw_phase(self, st):
         """D's weight gradients for the fakes; on two streams this is the last writer of D's gradients (it follows `dis` on
         the side stream), so the two gradient buffers are merged here and D's all-reduce can start behind it."""
-        with kernels.wgrad_workgroups(st.get("side_wgrad_wgs", 0)):
+        with kernels.wgrad_workgroups(st.get("dfw_wgrad_wgs", st.get("side_wgrad_wgs", 0))):
             Fn.run_deferred_wgrads(st["dfw"])
         if st.get("concurrent"):
             for _, store in self.dis.stores:
@@ -582,6 +587,10 @@ class RGBDUpdater:
         32 x 128^2 / 16 x 256^2 / 8 x 128^2; profiles/r05/cu_budget_sweep.txt), in multiples of 8 (one per XCD) -- unless
         autotune_side_budget has MEASURED this shape on this device (devices of the pool differ by several percent in how
         the two streams' work compares)."""
+        return self._side_wgrad_pair(st)[0]
+
+    def _side_wgrad_pair(self, st):
+        """-> (workgroups of the `dis` launch, of the `dfw` launch): measured (autotune_side_budget) or by rule."""
         shape = (int(st["B"]), int(st["x_real"].shape[2]), int(st["x_real"].shape[3]))
         tuned = getattr(self, "_side_wgrad_tuned", {}).get(shape)
         if tuned is not None:
@@ -589,14 +598,20 @@ class RGBDUpdater:
         cus = torch.cuda.get_device_properties(self.device).multi_processor_count if torch.cuda.is_available() else 256
         px = float(shape[0]) * float(shape[1]) * float(shape[2])
         frac = min(1.0, max(0.25, 1.0 - 0.375 * (32.0 * 128.0 * 128.0) / px))
-        return max(8, int(round(cus * frac / 8.0)) * 8)
+        w = max(8, int(round(cus * frac / 8.0)) * 8)
+        return w, self._dfw_rule(w, cus)
+
+    @staticmethod
+    def _dfw_rule(w, cus):
+        return int(round((w + cus) / 16.0)) * 8                 # half way to the whole chip, a multiple of 8
 
     def autotune_side_budget(self, measure_steps=12, log=None):
         """Measure, on THIS device and at the CURRENT stage / batch, the workgroup count of the side stream's weight-gradient
-        launches instead of taking the rule of thumb: the rule's value and five neighbours (-32, +32, +64, then best -16 / +16),
-        each timed over `measure_steps` replayed steps behind a re-capture; the fastest is kept for this (batch, image size)
-        (_side_wgrad_auto).  graph_warmup + 1 + 6 x (2 + measure_steps) ordinary training steps (87 by default) -- they update
-        the networks like any others -- and seven re-captures of the step's graphs: one to three seconds.  The number of steps is
+        launches instead of taking the rule of thumb: the rule's value and five neighbours for the first launch (-32, +32, +64,
+        then best -16 / +16; the second launch at half way to the whole chip), then two more for the second launch (the same as the
+        first; the whole chip), each timed over `measure_steps` replayed steps behind a re-capture; the fastest pair is kept for
+        this (batch, image size) (_side_wgrad_pair).  graph_warmup + 1 + 8 x (2 + measure_steps) ordinary training steps (115 by default) -- they update
+        the networks like any others -- and nine re-captures of the step's graphs: one to four seconds.  The number of steps is
         fixed, whatever is measured, so the ranks of a data-parallel job stay in step (each keeps its own optimum).  No-op (returns None) without two streams + graphs, or with an explicit side_wgrad_workgroups."""
         import time
         if not (self.concurrent_phases and self.use_graphs and self.side_wgrad_workgroups is None and torch.cuda.is_available()):
@@ -607,13 +622,13 @@ class RGBDUpdater:
         cus = torch.cuda.get_device_properties(self.device).multi_processor_count
         self._side_wgrad_tuned = getattr(self, "_side_wgrad_tuned", {})
         self._side_wgrad_tuned.pop(shape, None)
-        w0 = self._side_wgrad_auto({"B": shape[0], "x_real": torch.empty(0, 0, shape[1], shape[2])})
+        w0 = self._side_wgrad_pair({"B": shape[0], "x_real": torch.empty(0, 0, shape[1], shape[2])})[0]
         clamp = lambda w: int(min(cus, max(32, w)))
         results = {}
 
-        def timed(w):
-            self._side_wgrad_tuned[shape] = w
-            self._graphs.clear()                                # every phase is re-captured (the side phases bake the count in)
+        def timed(pair):
+            self._side_wgrad_tuned[shape] = pair
+            self._graphs.clear()                                # every phase is re-captured (the side phases bake the counts in)
             for _ in range(2):
                 self.update()
             torch.cuda.synchronize(self.device)
@@ -622,16 +637,21 @@ class RGBDUpdater:
                 self.update()
             torch.cuda.synchronize(self.device)
             t = (time.perf_counter() - t0) / measure_steps
-            results[w] = min(t, results.get(w, t))
+            results[pair] = min(t, results.get(pair, t))
             if log is not None:
-                log(f"autotune_side_budget {shape}: {w} workgroups {1e3 * t:.3f} ms per step")
+                log(f"autotune_side_budget {shape}: dis {pair[0]} / dfw {pair[1]} workgroups {1e3 * t:.3f} ms per step")
 
         try:
-            for d in (0, -32, 32, 64):
-                timed(clamp(w0 + d))
+            for d in (0, -32, 32, 64):                          # the first launch's count, the second at its rule
+                w = clamp(w0 + d)
+                timed((w, self._dfw_rule(w, cus)))
             best = min(results, key=results.get)
             for d in (-16, 16):
-                timed(clamp(best + d))
+                w = clamp(best[0] + d)
+                timed((w, self._dfw_rule(w, cus)))
+            best = min(results, key=results.get)
+            for dfw in (best[0], cus):                          # ... then the second launch's: the same as the first, the whole chip
+                timed((best[0], dfw))
             best = min(results, key=results.get)
         except Exception:
             self._side_wgrad_tuned.pop(shape, None)             # back to the rule of thumb, nothing half-measured kept
@@ -639,8 +659,8 @@ class RGBDUpdater:
             raise
         self._side_wgrad_tuned[shape] = best
         self._graphs.clear()
-        self.side_budget_tuning = {"shape": shape, "rule": w0, "chosen": best,
-                                   "ms_per_step": {int(k): round(1e3 * v, 4) for k, v in sorted(results.items())}}
+        self.side_budget_tuning = {"shape": shape, "rule": (w0, self._dfw_rule(w0, cus)), "chosen": best,
+                                   "ms_per_step": {f"{k[0]}/{k[1]}": round(1e3 * v, 4) for k, v in sorted(results.items())}}
         return best
 
     def _run_phase(self, name, fn, st, key, stream=None, cu_budget=0):
@@ -890,7 +910,12 @@ class RGBDUpdater:
             main, side = torch.cuda.current_stream(), self._side_stream
             self._run_phase("prep", self._prep_only_phase, st, key)
             side.wait_stream(main)
-            st["side_wgrad_wgs"] = self._side_wgrad_auto(st) if self.side_wgrad_workgroups is None else int(self.side_wgrad_workgroups)
+            if self.side_wgrad_workgroups is None:
+                st["side_wgrad_wgs"], st["dfw_wgrad_wgs"] = self._side_wgrad_pair(st)
+            else:
+                st["side_wgrad_wgs"] = st["dfw_wgrad_wgs"] = int(self.side_wgrad_workgroups)
+            if self.dfw_wgrad_workgroups is not None:
+                st["dfw_wgrad_wgs"] = int(self.dfw_wgrad_workgroups)
             self._last_shape = (int(st["B"]), int(st["x_real"].shape[2]), int(st["x_real"].shape[3]))
             self._run_phase("dis", self._dis_phase, st, key, stream=side,         # D on the reals, R1, its weight gradients
                             cu_budget=self.side_cu_budget)

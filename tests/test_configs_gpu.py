@@ -131,7 +131,7 @@ def test_dcgan_config_training_steps_run():
 
 
 def test_side_budget_autotune_measures_a_fixed_number_of_steps_and_keeps_the_step_working():
-    """RGBDUpdater.autotune_side_budget: the side stream's weight-gradient workgroup count measured on this device (six candidates
+    """RGBDUpdater.autotune_side_budget: the side stream's weight-gradient workgroup count measured on this device (eight candidates
     around the rule of thumb, every phase re-captured for each) -- the number of steps it takes is FIXED (the ranks of a
     data-parallel job must stay in step), the chosen count is one of the measured ones and is what the next captures use."""
     from rgbd_gan_amd.training import DeviceImageIterator, build_training
@@ -148,11 +148,12 @@ def test_side_budget_autotune_measures_a_fixed_number_of_steps_and_keeps_the_ste
     it0 = upd.iteration
     best = upd.autotune_side_budget(measure_steps=2)
     steps = upd.iteration - it0
-    assert steps == (upd.graph_warmup + 1) + 6 * (2 + 2), steps
+    assert steps == (upd.graph_warmup + 1) + 8 * (2 + 2), steps
     tune = upd.side_budget_tuning
-    assert tune["shape"] == (8, 64, 64) and tune["rule"] == 64 and best == tune["chosen"] and best in tune["ms_per_step"]
-    assert upd._side_wgrad_auto({"B": 8, "x_real": torch.empty(8, 3, 64, 64)}) == best
-    assert upd._side_wgrad_auto({"B": 8, "x_real": torch.empty(8, 3, 128, 128)}) == 64        # another shape: the rule
+    assert tune["shape"] == (8, 64, 64) and tune["rule"] == (64, 160) and best == tune["chosen"]
+    assert f"{best[0]}/{best[1]}" in tune["ms_per_step"] and len(tune["ms_per_step"]) >= 6
+    assert upd._side_wgrad_pair({"B": 8, "x_real": torch.empty(8, 3, 64, 64)}) == best
+    assert upd._side_wgrad_pair({"B": 8, "x_real": torch.empty(8, 3, 128, 128)}) == (64, 160)   # another shape: the rule
     for _ in range(4):
         upd.update()                                            # re-captured with the chosen count, replayed
     assert any(k[-1] == "dis" for k in upd._graphs)

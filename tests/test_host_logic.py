@@ -285,9 +285,13 @@ def test_side_stream_weight_gradient_budget_rule():
     class Shape:
         def __init__(self, *s):
             self.shape = s
-    fake = type("U", (), {"device": "cpu"})()
+    fake = type("U", (), {"device": "cpu", "_dfw_rule": staticmethod(RGBDUpdater._dfw_rule),
+                          "_side_wgrad_pair": RGBDUpdater._side_wgrad_pair})()
     rule = lambda B, S: RGBDUpdater._side_wgrad_auto(fake, {"B": B, "x_real": Shape(B, 3, S, S)})
+    pair = lambda B, S: RGBDUpdater._side_wgrad_pair(fake, {"B": B, "x_real": Shape(B, 3, S, S)})
     if not torch.cuda.is_available():
         assert rule(32, 128) == 160 and rule(8, 128) == 64 and rule(16, 256) == 208 and rule(32, 64) == 64
         assert rule(64, 256) == 240 and rule(2, 16) == 64
-    assert all(rule(B, S) % 8 == 0 for B in (2, 8, 32) for S in (16, 64, 256))
+        # the second launch (`dfw`, mostly behind the end of the generator's backward): half way to the whole chip
+        assert pair(32, 128) == (160, 208) and pair(8, 128) == (64, 160) and pair(16, 256) == (208, 232)
+    assert all(rule(B, S) % 8 == 0 and pair(B, S)[1] % 8 == 0 for B in (2, 8, 32) for S in (16, 64, 256))

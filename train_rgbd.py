@@ -111,8 +111,9 @@ def main():
         if updater.smoothed_gen is not None:
             previews.append(PreviewSampler(updater.smoothed_gen, out, config, rows=8, cols=8, subdir="preview_smoothed"))
 
-    if hasattr(updater, "autotune_side_budget") and updater.iteration + 200 < config.iteration and (comm is None or comm.size == 1):
-        # ~90 ordinary training steps that also measure, on this device and at the current stage, how many compute units the
+    if os.environ.get("RGBD_AUTOTUNE_SIDE_BUDGET") and hasattr(updater, "autotune_side_budget") and \
+            updater.iteration + 200 < config.iteration and (comm is None or comm.size == 1):
+        # opt-in: ~115 ordinary training steps that also measure, on this device and at the current stage, how many compute units the
         # side stream's weight-gradient launches should leave to the generator's stream
         tuned = updater.autotune_side_budget()
         if tuned is not None and is_master:
