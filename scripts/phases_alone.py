@@ -1,5 +1,6 @@
 """Each captured phase of the step replayed ALONE (nothing on the other stream), timed with events: the phases' own cost,
-against which the overlapped step (scripts/phase_timeline.py) is read.  RGBD_FORK_GEN_WGRADS=0/1 etc. apply."""
+against which the overlapped step (scripts/phase_timeline.py) is read.  CONFIG=... B=... RES256=[fp8] select another workload; the
+updater's switches (RGBD_SIDE_CUS, RGBD_SIDE_WGRAD_WGS, RGBD_DFW_WGRAD_WGS, RGBD_CONCURRENT_PHASES) apply."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
