@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RGBD_ABI_VERSION 18
+#define RGBD_ABI_VERSION 19
 
 int rgbd_abi_version(void);
 const char* rgbd_last_error(void);
@@ -131,12 +131,21 @@ int rgbd_pack_weights_multi(const rgbd_pack_desc* descs_device, int n, int total
  *   workspace: rgbd_conv2d_fprop_workspace(...) bytes of device scratch, or NULL.  Layers with few output tiles and
  *         a long reduction (the 4x4 .. 16x16 images) are split along K over several workgroups per tile; the fp32
  *         partial sums go through this scratch and a second kernel applies the epilogue.  NULL = never split.
+ *   cus : compute-unit budget of THIS launch, 0 = all of the device.  The pipelined 3x3 kernel is persistent and holds a
+ *         compute unit completely (130 KB of LDS, 512 registers per SIMD): while one launch covers the chip nothing of
+ *         another stream starts.  A host that runs two streams side by side sizes the launches of the stream that is
+ *         NOT its critical path for fewer compute units (grid = min(cus, the device's) workgroups, cut down further to
+ *         what the number of rounds needs), and the other stream's kernels find free ones at once (RGBDUpdater: 224 of
+ *         256 for the discriminator phases beside the generator's).  A per-launch argument: the library keeps no budget
+ *         of its own (ABI <= 18 had a process-wide rgbd_set_cu_budget); a grid size is fixed when a launch is
+ *         captured into a HIP graph.  Every conv entry point below takes the same argument in front of `stream`;
+ *         launches that do not use the persistent kernel ignore it.
  * Requires Cin % 64 == 0 and Cout % 64 == 0.  dgrad = this function on dY with w_dgrad, pad' = KH-1-pad.
  */
 int64_t rgbd_conv2d_fprop_workspace(int B, int Hin, int Win, int Cin, int Cout, int KH, int KW, int pad, int upsample);
 int rgbd_conv2d_fprop_bf16(const void* x, const void* wp, const float* bias, const void* residual, void* y,
                            void* y_pooled, int B, int Hin, int Win, int Cin, int Cout, int KH, int KW, int pad,
-                           int upsample, int lrelu_channels, float slope, void* workspace, void* stream);
+                           int upsample, int lrelu_channels, float slope, void* workspace, int cus, void* stream);
 
 /* Weight gradient: dw[co][ci][kh][kw] (+)= scale * sum_{b,h,w} dy[b,h,w,co] * x[b,h+kh-pad,w+kw-pad,ci]  (fp32).
  *   x  : (B,H,W,Cin) bf16, dy : (B,H,W,Cout) bf16 (same H,W: stride 1, pad = (K-1)/2), K in {1,3}.
@@ -172,7 +181,7 @@ int rgbd_wgrad_reduce_multi(const rgbd_wgrad_reduce_desc* descs, int n, void* st
  * deals the CUs out over the layers in proportion to their work and costs 38 MB in total.  3x3 pad-1 convs on
  * power-of-two images; one call takes either problems of at least 8x16 pixels or smaller ones (4x4 .. 8x8: each planned
  * on its own, one launch instead of a dozen latency-bound ones), not a mix.  rgbd_conv2d_wgrad_multi_plan fills `nsplit` of every problem (HOST
- * arrays; total_workgroups <= 0: one per CU); the caller then provides workspace = nsplit * 9 * Cout * Cin floats per
+ * arrays; total_workgroups <= 0: one per CU; a host running a second stream beside the launch passes fewer); the caller then provides workspace = nsplit * 9 * Cout * Cin floats per
  * problem and finishes with rgbd_wgrad_reduce_multi. */
 typedef struct rgbd_wgrad_problem {
     const void* x;        /* (B,H,W,Cin) bf16, or (B,H/2,W/2,Cin) when upsample != 0 */
@@ -181,15 +190,6 @@ typedef struct rgbd_wgrad_problem {
     int32_t B, H, W, Cin, Cout, K, upsample, nsplit;
 } rgbd_wgrad_problem;
 int rgbd_conv2d_wgrad_multi_plan(rgbd_wgrad_problem* probs, int n, int total_workgroups);
-/* Compute units the next launches of the chip-filling persistent kernels (the pipelined 3x3 kernel, the batched
- * weight-gradient plan with total_workgroups <= 0) size their grids for: 0 = all of the device (the default), otherwise
- * min(n, the device's).  These kernels hold a compute unit completely (130 KB of LDS, 512 registers per SIMD): while one of
- * them covers the chip nothing of another stream starts.  A host that runs two streams side by side gives the launches of
- * the stream that is NOT its critical path a smaller budget, and the other stream's kernels find free compute units at once
- * (RGBDUpdater: 160 of 256 for the discriminator phases beside the generator's; 7.70 -> 7.14 ms per step).  One value per
- * process (launches issued from autograd's worker threads must see it); returns the previous value.  A grid size is fixed
- * when its launch is captured into a HIP graph. */
-int rgbd_set_cu_budget(int n);
 int rgbd_conv2d_wgrad_partial_multi_bf16(const rgbd_wgrad_problem* probs, int n, void* stream);
 
 /* ------------------------------------------------------------------ AdaIN (instance norm + style affine)
@@ -441,13 +441,13 @@ int rgbd_occlusion_accum_bwd(const float* vol, const float* W1, const float* b1,
  * rgbd_ema_update: copy_param.py:17-40 (soft_copy_param) over a flat parameter buffer: dst = (1-tau) dst + tau src.
  */
 int rgbd_conv2d_dgrad_bf16(const void* dy, const void* wp_dgrad, const void* residual, void* dx, int B, int H, int W,
-                           int Cin, int Cout, int K, int pad, int sum_pool2, void* workspace, void* stream);
+                           int Cin, int Cout, int K, int pad, int sum_pool2, void* workspace, int cus, void* stream);
 int rgbd_conv3x3_actgrad_supported(int B, int H, int W, int Cin, int Cout);
 int rgbd_conv3x3_actgrad_bf16(const void* x, const void* wp, const void* residual, const void* act_y, float slope,
                               float* colsum, const float* row_scale, void* y, void* y2, const float* row_scale2, int B,
-                              int H, int W, int Cin, int Cout, void* stream);
+                              int H, int W, int Cin, int Cout, int cus, void* stream);
 int rgbd_conv2d_fprop_stats_bf16(const void* x, const void* wp, const float* bias, void* y, int64_t* stats, int B, int Hin,
-                                 int Win, int Cin, int Cout, int upsample, int lrelu_channels, float slope, void* stream);
+                                 int Win, int Cin, int Cout, int upsample, int lrelu_channels, float slope, int cus, void* stream);
 int rgbd_adain_apply_fixed(const void* x, const float* scale, const float* shift, void* y, const int64_t* stats, float* mean,
                            float* rstd, int B, int HW, int C, int ld, float eps, void* y_q, void* y_s, void* stream);
 
@@ -501,6 +501,7 @@ typedef struct rgbd_conv3x3_desc {
     void* y_q; void* y_s; void* yp_q; void* yp_s; /* MXFP8 copies of y / y_pooled */
     int B, Hin, Win, Cin, Cout, upsample, pool_sum, lrelu_channels;
     float slope;
+    int cus;                                      /* compute-unit budget of this launch (see `cus` above); 0 = all */
 } rgbd_conv3x3_desc;
 int rgbd_conv3x3_ex(const rgbd_conv3x3_desc* desc, void* stream);
 int rgbd_quantize_mxfp8(const void* x, void* q, void* scales, int64_t rows, int C, void* stream);
@@ -508,15 +509,15 @@ int rgbd_pack_weights_mxfp8_multi(const rgbd_pack_mx8_desc* descs_device, int n,
 int rgbd_conv3x3_mxfp8_supported(int B, int Hout, int Wout, int Cin, int Cout);
 int rgbd_conv2d_fprop_mxfp8(const void* xq, const void* xs, const void* wq, const void* ws, const float* bias,
                             const void* residual, void* y, void* y_pooled, int B, int Hin, int Win, int Cin, int Cout,
-                            int upsample, int lrelu_channels, float slope, void* stream);
+                            int upsample, int lrelu_channels, float slope, int cus, void* stream);
 int rgbd_conv2d_dgrad_mxfp8(const void* dyq, const void* dys, const void* wdq, const void* wds, const void* residual,
-                            void* dx, int B, int H, int W, int Cin, int Cout, int sum_pool2, void* stream);
+                            void* dx, int B, int H, int W, int Cin, int Cout, int sum_pool2, int cus, void* stream);
 int rgbd_conv3x3_actgrad_mxfp8(const void* xq, const void* xs, const void* wq, const void* ws, const void* residual,
                                const void* act_y, float slope, float* colsum, const float* row_scale, void* y, void* y2,
-                               const float* row_scale2, int B, int H, int W, int Cin, int Cout, void* stream);
+                               const float* row_scale2, int B, int H, int W, int Cin, int Cout, int cus, void* stream);
 int rgbd_conv2d_fprop_stats_mxfp8(const void* xq, const void* xs, const void* wq, const void* ws, const float* bias, void* y,
                                   int64_t* stats, int B, int Hin, int Win, int Cin, int Cout, int upsample,
-                                  int lrelu_channels, float slope, void* stream);
+                                  int lrelu_channels, float slope, int cus, void* stream);
 int rgbd_pixelnorm_fwd(const float* x, float* y, int M, int C, float eps, void* stream);
 int rgbd_pixelnorm_bwd(const float* x, const float* dy, float* dx, int M, int C, float eps, void* stream);
 int rgbd_depth_head_fwd(const float* x, float* y, int B, int HW, void* stream);

@@ -10,7 +10,7 @@ from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p, POINTER
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RGBD_LIB_PATH: A/B timing of another build of the same ABI; the default is the in-tree library
 LIB_PATH = os.environ.get("RGBD_LIB_PATH") or os.path.join(_HERE, "librgbdgan_hip.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _P = c_void_p
 
@@ -31,7 +31,7 @@ PROTOTYPES = {
     "rgbd_pack_weights_multi": ([_P, c_int, c_int, _P], c_int),
     "rgbd_conv2d_fprop_workspace": ([c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int], c_int64),
     "rgbd_conv2d_fprop_bf16": ([_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
-                                c_int, c_int, c_float, _P, _P], c_int),
+                                c_int, c_int, c_float, _P, c_int, _P], c_int),
     "rgbd_fold_depth_taps_bf16": ([_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P], c_int),
     "rgbd_fold_4x4s2_bf16": ([_P, _P, c_int, c_int, c_int, c_int, c_int, _P], c_int),
     "rgbd_pad_last": ([_P, _P, c_int64, c_int, c_int, c_int, _P], c_int),
@@ -42,7 +42,6 @@ PROTOTYPES = {
     "rgbd_conv2d_wgrad_partial_bf16": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P], c_int),
     "rgbd_wgrad_reduce_multi": ([_P, c_int, _P], c_int),
     "rgbd_conv2d_wgrad_multi_plan": ([_P, c_int, c_int], c_int),
-    "rgbd_set_cu_budget": ([c_int], c_int),
     "rgbd_conv2d_wgrad_partial_multi_bf16": ([_P, c_int, _P], c_int),
     "rgbd_adain_workspace": ([c_int, c_int, c_int], c_int64),
     "rgbd_adain_fwd": ([_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P, _P, _P], c_int),
@@ -89,22 +88,22 @@ PROTOTYPES = {
                                   c_int, _P], c_int),
     "rgbd_occlusion_accum_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, c_int, c_int, c_int, c_int,
                                   _P], c_int),
-    "rgbd_conv2d_dgrad_bf16": ([_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P], c_int),
+    "rgbd_conv2d_dgrad_bf16": ([_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P], c_int),
     "rgbd_conv3x3_actgrad_supported": ([c_int, c_int, c_int, c_int, c_int], c_int),
-    "rgbd_conv3x3_actgrad_bf16": ([_P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P], c_int),
-    "rgbd_conv2d_fprop_stats_bf16": ([_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P], c_int),
+    "rgbd_conv3x3_actgrad_bf16": ([_P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P], c_int),
+    "rgbd_conv2d_fprop_stats_bf16": ([_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int, _P], c_int),
     "rgbd_adain_apply_fixed": ([_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, _P, _P], c_int),
     "rgbd_conv3x3_ex": ([_P, _P], c_int),
     "rgbd_quantize_mxfp8": ([_P, _P, _P, c_int64, c_int, _P], c_int),
     "rgbd_pack_weights_mxfp8_multi": ([_P, c_int, c_int, _P], c_int),
     "rgbd_conv3x3_mxfp8_supported": ([c_int, c_int, c_int, c_int, c_int], c_int),
     "rgbd_conv2d_fprop_mxfp8": ([_P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
-                                 _P], c_int),
-    "rgbd_conv2d_dgrad_mxfp8": ([_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P], c_int),
+                                 c_int, _P], c_int),
+    "rgbd_conv2d_dgrad_mxfp8": ([_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P], c_int),
     "rgbd_conv3x3_actgrad_mxfp8": ([_P, _P, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
-                                    _P], c_int),
+                                    c_int, _P], c_int),
     "rgbd_conv2d_fprop_stats_mxfp8": ([_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
-                                       _P], c_int),
+                                       c_int, _P], c_int),
     "rgbd_pixelnorm_fwd": ([_P, _P, c_int, c_int, c_float, _P], c_int),
     "rgbd_pixelnorm_bwd": ([_P, _P, _P, c_int, c_int, c_float, _P], c_int),
     "rgbd_depth_head_fwd": ([_P, _P, c_int, c_int, _P], c_int),

@@ -46,12 +46,21 @@ class PreviewSampler:
         from ...updater import get_camera_matries
         cfg, gen, rows, cols = self.config, self.gen, self.rows, self.cols
         if self.z is None:
-            state = torch.cuda.get_rng_state(gen.device)          # seeded draw that leaves the training stream alone
-            torch.cuda.manual_seed(self.seed)
-            try:
-                self.z = gen.make_hidden(rows * cols) if cfg.rgb else self._tile(gen.make_hidden(cols))
-            finally:
-                torch.cuda.set_rng_state(state, gen.device)
+            n = rows * cols if cfg.rgb else cols
+            if hasattr(gen, "_latent_rng") and torch.device(gen.device).type == "cuda":
+                # StyleGAN latents come from the library's Philox stream: a PRIVATE stream seeded with the sampler's seed --
+                # the same latents in every run and after a resume, and the training stream's launch counter is not touched
+                from ... import kernels
+                z = gen.make_hidden(n, rng_state=kernels.new_hidden_rng_state(gen.device, seed=self.seed))
+            else:
+                dev = torch.device(gen.device)
+                state = torch.cuda.get_rng_state(dev) if dev.type == "cuda" else torch.get_rng_state()
+                (torch.cuda.manual_seed if dev.type == "cuda" else torch.manual_seed)(self.seed)    # torch.randn generators
+                try:
+                    z = gen.make_hidden(n)
+                finally:
+                    torch.cuda.set_rng_state(state, dev) if dev.type == "cuda" else torch.set_rng_state(state)
+            self.z = z if cfg.rgb else self._tile(z)
         z = self.z[:rows * cols]
         theta = cams = None
         if not cfg.rgb:

@@ -2714,8 +2714,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(WgradMultiArgs 
 }
 
 // compute units of the CURRENT device (a process may drive several): looked up once per device, immutable afterwards
-std::atomic<int> g_cu_budget{0};        // rgbd_set_cu_budget: 0 = all compute units
-int device_cus(bool for_wgrad = false) {
+// `budget` > 0: the caller's compute-unit budget for THIS launch (the `cus` argument of the conv entry points, the `cus`
+// field of rgbd_conv3x3_desc): min(budget, the device's).  The library keeps no budget of its own.
+int device_cus(bool for_wgrad = false, int budget = 0) {
 #ifdef RGBD_DEBUG_BUILD
     // experiment hook (debug library only): persistent grids sized for FEWER compute units than the chip has
     static const int forced = getenv("RGBD_DEBUG_CUS") ? atoi(getenv("RGBD_DEBUG_CUS")) : 0;
@@ -2732,7 +2733,6 @@ int device_cus(bool for_wgrad = false) {
         }
         n = cus[dev];
     }
-    const int budget = g_cu_budget.load(std::memory_order_relaxed);
     return budget > 0 && budget < n ? budget : n;
 }
 bool reserve_lds(const void* fn, int bytes) { return rgbd_reserve_lds(fn, bytes); }      // (common.h: once per kernel AND device)
@@ -2863,8 +2863,8 @@ int launch_sp_emit(const ConvArgs& a, bool wide, bool masked, unsigned grid, hip
 
 static int conv_fprop_impl(const void* x, const void* wp, const float* bias, const void* residual,
                            void* y, int B, int Hin, int Win, int Cin, int Cout, int KH, int KW, int pad,
-                           int upsample, int lrelu_channels, float slope, void* workspace, void* stream, int pool_sum,
-                           void* y_pooled = nullptr, const void* mask_y = nullptr, float* colsum = nullptr,
+                           int upsample, int lrelu_channels, float slope, void* workspace, void* stream, int cus,
+                           int pool_sum, void* y_pooled = nullptr, const void* mask_y = nullptr, float* colsum = nullptr,
                            const float* row_scale = nullptr, long long* stats = nullptr, void* y2 = nullptr,
                            const float* row_scale2 = nullptr, const void* x_scales = nullptr,
                            const void* w_scales = nullptr, void* y_q = nullptr, void* y_s = nullptr, void* yp_q = nullptr,
@@ -2984,7 +2984,7 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
         const int n_tiles = wide ? Cout / 128 : Cout / 64;
         // persistent workgroups: one per CU (the kernel's LDS footprint allows exactly one), split evenly over the
         // output-channel tiles; each walks a contiguous range of pixel tiles
-        const int num_cus = device_cus();
+        const int num_cus = device_cus(false, cus);
         int per_nt = num_cus / n_tiles;
         if (per_nt < 1) per_nt = 1;
         if (per_nt > ptiles) per_nt = (int)ptiles;
@@ -3218,9 +3218,9 @@ static int conv_fprop_impl(const void* x, const void* wp, const float* bias, con
 extern "C" int rgbd_conv2d_fprop_bf16(const void* x, const void* wp, const float* bias, const void* residual,
                                       void* y, void* y_pooled, int B, int Hin, int Win, int Cin, int Cout, int KH, int KW,
                                       int pad, int upsample, int lrelu_channels, float slope, void* workspace,
-                                      void* stream) {
+                                      int cus, void* stream) {
     return conv_fprop_impl(x, wp, bias, residual, y, B, Hin, Win, Cin, Cout, KH, KW, pad, upsample, lrelu_channels, slope,
-                           workspace, stream, 0, y_pooled);
+                           workspace, stream, cus, 0, y_pooled);
 }
 
 namespace {
@@ -3252,12 +3252,12 @@ WgradPlan plan_wgrad(int B, int H, int W, int Cin, int Cout) {
 
 extern "C" int rgbd_conv2d_dgrad_bf16(const void* dy, const void* wp_dgrad, const void* residual, void* dx, int B, int H,
                                       int W, int Cin, int Cout, int K, int pad, int sum_pool2, void* workspace,
-                                      void* stream) {
+                                      int cus, void* stream) {
     RGBD_REQUIRE(K >= 1 && pad >= 0 && pad <= K - 1, "rgbd_conv2d_dgrad_bf16: need 0 <= pad <= K-1 (K=%d pad=%d)", K, pad);
     RGBD_REQUIRE(!(residual && sum_pool2), "rgbd_conv2d_dgrad_bf16: residual and sum_pool2 are exclusive");
     // dx = correlation of dy with the flipped, transposed kernel at padding K-1-pad
     return conv_fprop_impl(dy, wp_dgrad, nullptr, residual, dx, B, H, W, Cout, Cin, K, K, K - 1 - pad, 0, 0, 0.2f,
-                           workspace, stream, sum_pool2);
+                           workspace, stream, cus, sum_pool2);
 }
 
 extern "C" int rgbd_conv3x3_actgrad_supported(int B, int H, int W, int Cin, int Cout) {
@@ -3267,20 +3267,20 @@ extern "C" int rgbd_conv3x3_actgrad_supported(int B, int H, int W, int Cin, int 
 
 extern "C" int rgbd_conv3x3_actgrad_bf16(const void* x, const void* wp, const void* residual, const void* act_y, float slope,
                                          float* colsum, const float* row_scale, void* y, void* y2, const float* row_scale2,
-                                         int B, int H, int W, int Cin, int Cout, void* stream) {
+                                         int B, int H, int W, int Cin, int Cout, int cus, void* stream) {
     RGBD_REQUIRE(act_y, "rgbd_conv3x3_actgrad_bf16: null pointer");
     RGBD_REQUIRE(colsum || !row_scale, "rgbd_conv3x3_actgrad_bf16: row_scale without colsum");
     RGBD_REQUIRE(!y2 == !row_scale2, "rgbd_conv3x3_actgrad_bf16: y2 and row_scale2 come together");
-    return conv_fprop_impl(x, wp, nullptr, residual, y, B, H, W, Cin, Cout, 3, 3, 1, 0, 0, slope, nullptr, stream, 0, nullptr,
+    return conv_fprop_impl(x, wp, nullptr, residual, y, B, H, W, Cin, Cout, 3, 3, 1, 0, 0, slope, nullptr, stream, cus, 0, nullptr,
                            act_y, colsum, row_scale, nullptr, y2, row_scale2);
 }
 
 extern "C" int rgbd_conv2d_fprop_stats_bf16(const void* x, const void* wp, const float* bias, void* y, int64_t* stats, int B,
                                             int Hin, int Win, int Cin, int Cout, int upsample, int lrelu_channels, float slope,
-                                            void* stream) {
+                                            int cus, void* stream) {
     RGBD_REQUIRE(stats, "rgbd_conv2d_fprop_stats_bf16: null pointer");
     return conv_fprop_impl(x, wp, bias, nullptr, y, B, Hin, Win, Cin, Cout, 3, 3, 1, upsample, lrelu_channels, slope, nullptr,
-                           stream, 0, nullptr, nullptr, nullptr, nullptr, (long long*)stats);
+                           stream, cus, 0, nullptr, nullptr, nullptr, nullptr, (long long*)stats);
 }
 
 // ---- MXFP8 forms (BASELINE configuration 5): the same launches on e4m3 operands with E8M0 block scales (csrc/mxfp8.hip)
@@ -3291,38 +3291,38 @@ extern "C" int rgbd_conv3x3_mxfp8_supported(int B, int Hout, int Wout, int Cin, 
 
 extern "C" int rgbd_conv2d_fprop_mxfp8(const void* xq, const void* xs, const void* wq, const void* ws, const float* bias,
                                        const void* residual, void* y, void* y_pooled, int B, int Hin, int Win, int Cin,
-                                       int Cout, int upsample, int lrelu_channels, float slope, void* stream) {
+                                       int Cout, int upsample, int lrelu_channels, float slope, int cus, void* stream) {
     RGBD_REQUIRE(xs && ws, "rgbd_conv2d_fprop_mxfp8: null pointer");
     return conv_fprop_impl(xq, wq, bias, residual, y, B, Hin, Win, Cin, Cout, 3, 3, 1, upsample, lrelu_channels, slope, nullptr,
-                           stream, 0, y_pooled, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, xs, ws);
+                           stream, cus, 0, y_pooled, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, xs, ws);
 }
 
 extern "C" int rgbd_conv2d_dgrad_mxfp8(const void* dyq, const void* dys, const void* wdq, const void* wds,
                                        const void* residual, void* dx, int B, int H, int W, int Cin, int Cout, int sum_pool2,
-                                       void* stream) {
+                                       int cus, void* stream) {
     RGBD_REQUIRE(dys && wds, "rgbd_conv2d_dgrad_mxfp8: null pointer");
     RGBD_REQUIRE(!(residual && sum_pool2), "rgbd_conv2d_dgrad_mxfp8: residual and sum_pool2 are exclusive");
-    return conv_fprop_impl(dyq, wdq, nullptr, residual, dx, B, H, W, Cout, Cin, 3, 3, 1, 0, 0, 0.2f, nullptr, stream, sum_pool2,
+    return conv_fprop_impl(dyq, wdq, nullptr, residual, dx, B, H, W, Cout, Cin, 3, 3, 1, 0, 0, 0.2f, nullptr, stream, cus, sum_pool2,
                            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, dys, wds);
 }
 
 extern "C" int rgbd_conv3x3_actgrad_mxfp8(const void* xq, const void* xs, const void* wq, const void* ws, const void* residual,
                                           const void* act_y, float slope, float* colsum, const float* row_scale, void* y,
                                           void* y2, const float* row_scale2, int B, int H, int W, int Cin, int Cout,
-                                          void* stream) {
+                                          int cus, void* stream) {
     RGBD_REQUIRE(act_y && xs && ws, "rgbd_conv3x3_actgrad_mxfp8: null pointer");
     RGBD_REQUIRE(colsum || !row_scale, "rgbd_conv3x3_actgrad_mxfp8: row_scale without colsum");
     RGBD_REQUIRE(!y2 == !row_scale2, "rgbd_conv3x3_actgrad_mxfp8: y2 and row_scale2 come together");
-    return conv_fprop_impl(xq, wq, nullptr, residual, y, B, H, W, Cin, Cout, 3, 3, 1, 0, 0, slope, nullptr, stream, 0, nullptr,
+    return conv_fprop_impl(xq, wq, nullptr, residual, y, B, H, W, Cin, Cout, 3, 3, 1, 0, 0, slope, nullptr, stream, cus, 0, nullptr,
                            act_y, colsum, row_scale, nullptr, y2, row_scale2, xs, ws);
 }
 
 extern "C" int rgbd_conv2d_fprop_stats_mxfp8(const void* xq, const void* xs, const void* wq, const void* ws, const float* bias,
                                              void* y, int64_t* stats, int B, int Hin, int Win, int Cin, int Cout, int upsample,
-                                             int lrelu_channels, float slope, void* stream) {
+                                             int lrelu_channels, float slope, int cus, void* stream) {
     RGBD_REQUIRE(stats && xs && ws, "rgbd_conv2d_fprop_stats_mxfp8: null pointer");
     return conv_fprop_impl(xq, wq, bias, nullptr, y, B, Hin, Win, Cin, Cout, 3, 3, 1, upsample, lrelu_channels, slope, nullptr,
-                           stream, 0, nullptr, nullptr, nullptr, nullptr, (long long*)stats, nullptr, nullptr, xs, ws);
+                           stream, cus, 0, nullptr, nullptr, nullptr, nullptr, (long long*)stats, nullptr, nullptr, xs, ws);
 }
 
 // Every option of the pipelined 3x3 launch behind one descriptor (the entry points above are its common special cases)
@@ -3333,7 +3333,7 @@ extern "C" int rgbd_conv3x3_ex(const rgbd_conv3x3_desc* d, void* stream) {
     RGBD_REQUIRE(d->colsum || !d->row_scale, "rgbd_conv3x3_ex: row_scale without colsum");
     RGBD_REQUIRE(!d->y2 == !d->row_scale2, "rgbd_conv3x3_ex: y2 and row_scale2 come together");
     return conv_fprop_impl(d->x, d->w, d->bias, d->residual, d->y, d->B, d->Hin, d->Win, d->Cin, d->Cout, 3, 3, 1, d->upsample,
-                           d->lrelu_channels, d->slope, nullptr, stream, d->pool_sum, d->y_pooled, d->act_y, d->colsum,
+                           d->lrelu_channels, d->slope, nullptr, stream, d->cus, d->pool_sum, d->y_pooled, d->act_y, d->colsum,
                            d->row_scale, (long long*)d->stats, d->y2, d->row_scale2, d->x_scales, d->w_scales, d->y_q, d->y_s,
                            d->yp_q, d->yp_s);
 }
@@ -3449,9 +3449,6 @@ bool multi_eligible_small(const rgbd_wgrad_problem& q) {
 }
 }  // namespace
 
-extern "C" int rgbd_set_cu_budget(int n) {
-    return g_cu_budget.exchange(n > 0 ? n : 0);
-}
 
 extern "C" int rgbd_conv2d_wgrad_multi_plan(rgbd_wgrad_problem* probs, int n, int total_workgroups) {
     RGBD_REQUIRE(probs && n > 0 && n <= WGRAD_MULTI_PROBLEMS, "rgbd_conv2d_wgrad_multi_plan: 1..%d problems", WGRAD_MULTI_PROBLEMS);

@@ -2,6 +2,8 @@
 // layout allows; bounded by the ~6.3 TB/s achievable HBM rate (MI355X_MICROARCH.md), not by MFMA.
 #include "common.h"
 
+#include <mutex>
+
 static thread_local char g_err[512] = "";
 
 void rgbd_set_error(const char* fmt, ...) {
@@ -26,16 +28,24 @@ hipError_t rgbd_zero_async(void* ptr, size_t bytes, hipStream_t stream) {
 extern "C" const char* rgbd_last_error(void) { return g_err; }
 extern "C" int rgbd_abi_version(void) { return RGBD_ABI_VERSION; }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device) and again only when a LARGER size is asked for.
+// Called from whichever thread launches (the host's, autograd's workers): the table is guarded by a mutex -- the one-time
+// module state section 8(b) allows; it never influences what a launch computes.
 bool rgbd_reserve_lds(const void* fn, int bytes) {
-    struct Key { const void* fn; int dev; };
+    struct Key { const void* fn; int dev; int bytes; };
     static Key done[512];
     static int ndone = 0;
+    static std::mutex mu;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lock(mu);
+    Key* slot = nullptr;
     for (int i = 0; i < ndone; ++i)
-        if (done[i].fn == fn && done[i].dev == dev) return true;
+        if (done[i].fn == fn && done[i].dev == dev) { slot = &done[i]; break; }
+    if (slot && slot->bytes >= bytes) return true;
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
-    if (ndone < 512) done[ndone++] = Key{fn, dev};
+    if (slot) slot->bytes = bytes;
+    else if (ndone < 512) done[ndone++] = Key{fn, dev, bytes};
     return true;
 }
 

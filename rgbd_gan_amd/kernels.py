@@ -71,6 +71,22 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Compute-unit budgets of the persistent 3x3 launches, per STREAM (cu_budget): host policy, handed to the library as the `cus`
+# argument of every conv launch -- the library itself keeps none (ABI 19).  Keyed by (device, stream handle): launches issued
+# by autograd's worker threads run on the stream their forward ran on and find the same entry; two updaters on two devices
+# (or two streams) never see each other's.
+_STREAM_CUS = {}
+
+
+def _stream_key():
+    s = torch.cuda.current_stream()
+    return (s.device_index, s.cuda_stream)
+
+
+def _cus():
+    return _STREAM_CUS.get(_stream_key(), 0) if _STREAM_CUS else 0
+
+
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
@@ -277,7 +293,7 @@ class Conv3x3Desc(ctypes.Structure):
                                                 "row_scale", "y", "y_pooled", "y2", "row_scale2", "stats", "y_q", "y_s",
                                                 "yp_q", "yp_s")] + \
                [(n, ctypes.c_int) for n in ("B", "Hin", "Win", "Cin", "Cout", "upsample", "pool_sum", "lrelu_channels")] + \
-               [("slope", ctypes.c_float)]
+               [("slope", ctypes.c_float), ("cus", ctypes.c_int)]
 
 
 def mx8_emittable(B, Hout, Wout, Cout):
@@ -317,7 +333,7 @@ def _conv3x3_ex(x, mx_x, wp, mx_w, y, B, H, W, Cin, Cout, bias=None, residual=No
     p = lambda t: t.data_ptr() if t is not None else None
     d = Conv3x3Desc(p(mx_x[0]) if mx_x else p(x), p(mx_x[1]) if mx_x else None, p(mx_w.q) if mx_w else p(wp),
                     p(mx_w.s) if mx_w else None, p(bias), p(residual), p(act_y), p(colsum), p(row_scale), p(y), p(y_pooled), p(y2),
-                    p(row_scale2), None, p(yq), p(ys), p(ypq), p(yps), B, H, W, Cin, Cout, 0, 0, int(lrelu_channels), float(slope))
+                    p(row_scale2), None, p(yq), p(ys), p(ypq), p(yps), B, H, W, Cin, Cout, 0, 0, int(lrelu_channels), float(slope), _cus())
     rc = _lib.load().rgbd_conv3x3_ex(ctypes.byref(d), _stream())
     if emit:
         y._mx8 = (yq, ys, y._version)
@@ -422,7 +438,7 @@ def conv2d_fprop(x, wp, KH, KW, pad, bias=None, residual=None, upsample=False, l
                     flops, nbytes,
                     lambda: lib.rgbd_conv2d_fprop_mxfp8(_ptr(xq), _ptr(xs), _ptr(mx.q), _ptr(mx.s), _ptr(bias), _ptr(residual),
                                                         _ptr(y), _ptr(yp), B, H, W, Cin, Cout, int(bool(upsample)),
-                                                        int(lrelu_channels), float(slope), _stream()))
+                                                        int(lrelu_channels), float(slope), _cus(), _stream()))
         _lib.check(rc, "rgbd_conv2d_fprop_mxfp8")
         if avg_pool2:
             return y, (yp if fuse_pool else pool2_masked(y))
@@ -433,7 +449,7 @@ def conv2d_fprop(x, wp, KH, KW, pad, bias=None, residual=None, upsample=False, l
                 flops, nbytes,
                 lambda: lib.rgbd_conv2d_fprop_bf16(_ptr(x), _ptr(wp), _ptr(bias), _ptr(residual), _ptr(y), _ptr(yp), B, H,
                                                    W, Cin, Cout, KH, KW, pad, int(bool(upsample)), int(lrelu_channels),
-                                                   float(slope), _ptr(ws), _stream()))
+                                                   float(slope), _ptr(ws), _cus(), _stream()))
     _lib.check(rc, "rgbd_conv2d_fprop_bf16")
     if avg_pool2:
         return y, (yp if fuse_pool else pool2_masked(y))
@@ -465,7 +481,7 @@ def conv2d_dgrad(dy, wd, K, pad, sum_pool2=False, residual=None):
         rc = _timed(lambda: _conv_kernel_name(f"dgrad {Ho}x{Wo} {Cout}->{Cin}{' sumpool' if fuse else ''}"
                                               f"{' res' if residual is not None else ''}"), flops, nbytes,
                     lambda: lib.rgbd_conv2d_dgrad_mxfp8(_ptr(dq), _ptr(dsc), _ptr(mx.q), _ptr(mx.s), _ptr(residual), _ptr(dx), B,
-                                                        H, W, Cin, Cout, int(fuse), _stream()))
+                                                        H, W, Cin, Cout, int(fuse), _cus(), _stream()))
         _lib.check(rc, "rgbd_conv2d_dgrad_mxfp8")
         return dx
     ws = None if fuse else _fprop_workspace(lib, B, H, W, Cout, Cin, K, K, pd, 0, dy.device)
@@ -473,7 +489,7 @@ def conv2d_dgrad(dy, wd, K, pad, sum_pool2=False, residual=None):
                                           f"{' res' if residual is not None else ''}"), flops, nbytes,
                 lambda: lib.rgbd_conv2d_dgrad_bf16(_ptr(dy), _ptr(wd), _ptr(residual), _ptr(dx), B, H, W, Cin, Cout, K, pad,
                                                    int(fuse),
-                                                   _ptr(ws), _stream()))
+                                                   _ptr(ws), _cus(), _stream()))
     _lib.check(rc, "rgbd_conv2d_dgrad_bf16")
     if sum_pool2 and not fuse:
         out = torch.empty(B, Ho // 2, Wo // 2, Cin, dtype=BF16, device=dx.device)     # (a torch reduction here was the last one
@@ -528,30 +544,35 @@ def conv3x3_actgrad(x, wp, act_y, residual=None, bias_grad=None, row_scale=None,
                     flops, nbytes,
                     lambda: lib.rgbd_conv3x3_actgrad_mxfp8(_ptr(xq), _ptr(xs), _ptr(mx.q), _ptr(mx.s), _ptr(residual),
                                                            _ptr(act_y), float(slope), _ptr(bias_grad), _ptr(row_scale), _ptr(y),
-                                                           _ptr(y2), _ptr(operand_scale), B, H, W, Cin, Cout, _stream()))
+                                                           _ptr(y2), _ptr(operand_scale), B, H, W, Cin, Cout, _cus(), _stream()))
         _lib.check(rc, "rgbd_conv3x3_actgrad_mxfp8")
         return y if y2 is None else (y, y2)
     rc = _timed(lambda: _conv_kernel_name(f"actgrad {H}x{W} {Cin}->{Cout}{' res' if residual is not None else ''}"),
                 flops, nbytes,
                 lambda: lib.rgbd_conv3x3_actgrad_bf16(_ptr(x), _ptr(wp), _ptr(residual), _ptr(act_y), float(slope),
                                                       _ptr(bias_grad), _ptr(row_scale), _ptr(y), _ptr(y2),
-                                                      _ptr(operand_scale), B, H, W, Cin, Cout, _stream()))
+                                                      _ptr(operand_scale), B, H, W, Cin, Cout, _cus(), _stream()))
     _lib.check(rc, "rgbd_conv3x3_actgrad_bf16")
     return y if y2 is None else (y, y2)
 
 
 class _StatsPool:
     """Zeroed int64 scratch for the instance-norm statistics of the `stats` conv epilogues (integer atomics ADD into them).
-    A training step clears the whole pool with the launch that clears its gradient buffers (begin_step: one more pointer in
+    A training step clears the pool with the launch that clears its gradient buffers (begin_step: one more pointer in
     kernels.zero_multi) and the convolutions of the step take consecutive slices -- instead of one torch fill launch per
     layer (eight per step, the last torch `zeros` on it).  The take sequence of a step is fixed, so a captured step finds the
-    same slices on every replay; a caller outside a step, or a pool that is still too small (the first step), falls back to
-    a fresh torch.zeros and the pool grows at the next begin_step."""
+    same slices on every replay.  ONLY a step's own takes count: a caller outside begin_step .. end_step (the preview
+    sampler, tests, a generator called by hand) gets a fresh torch.zeros and leaves no trace -- a run that replays its steps
+    from graphs for 100 000 iterations and renders previews in between must not grow the pool.  A pool that is still too
+    small (a configuration's first step) also falls back to torch.zeros and the pool grows to exactly that step's demand at
+    the next begin_step."""
 
     def __init__(self):
-        self.buf, self.off, self.used, self._retired = None, 0, 0, []
+        self.buf, self.off, self.used, self.in_step, self._retired = None, 0, 0, False, []
 
     def take(self, n, device):
+        if not self.in_step:
+            return None
         self.used += n
         if self.buf is None or self.buf.device != device or self.off + n > self.buf.numel():
             return None
@@ -566,9 +587,12 @@ class _StatsPool:
         if self.buf is None or self.buf.device != device or self.used > self.buf.numel():
             if self.buf is not None:
                 self._retired.append(self.buf)      # steps captured as HIP graphs keep clearing and using the pool they saw
-            self.buf = torch.empty(max(2 * self.used, 1 << 17), dtype=torch.int64, device=device)
-        self.off, self.used = 0, 0
+            self.buf = torch.empty(max(-(-self.used // 4096) * 4096, 1 << 14), dtype=torch.int64, device=device)
+        self.off, self.used, self.in_step = 0, 0, True
         defer.append(self.buf.view(F32))
+
+    def end_step(self):
+        self.in_step = False
 
 
 STATS_POOL = _StatsPool()
@@ -598,14 +622,14 @@ def conv2d_fprop_stats(x, wp, bias, upsample=False, lrelu_channels=0, slope=0.2)
                     flops, nbytes,
                     lambda: lib.rgbd_conv2d_fprop_stats_mxfp8(_ptr(xq), _ptr(xs), _ptr(mx.q), _ptr(mx.s), _ptr(bias), _ptr(y),
                                                               _ptr(stats), B, H, W, Cin, Cout, int(bool(upsample)),
-                                                              int(lrelu_channels), float(slope), _stream()))
+                                                              int(lrelu_channels), float(slope), _cus(), _stream()))
         _lib.check(rc, "rgbd_conv2d_fprop_stats_mxfp8")
         return y, stats
     rc = _timed(lambda: _conv_kernel_name(f"fprop {Hout}x{Wout} {Cin}->{Cout}{' ups' if upsample else ''} stats"),
                 flops, nbytes,
                 lambda: lib.rgbd_conv2d_fprop_stats_bf16(_ptr(x), _ptr(wp), _ptr(bias), _ptr(y), _ptr(stats), B, H, W, Cin,
                                                          Cout, int(bool(upsample)), int(lrelu_channels), float(slope),
-                                                         _stream()))
+                                                         _cus(), _stream()))
     _lib.check(rc, "rgbd_conv2d_fprop_stats_bf16")
     return y, stats
 
@@ -712,14 +736,22 @@ WGRAD_WORKGROUPS = 0
 
 @contextlib.contextmanager
 def cu_budget(n):
-    """Launches inside size the persistent 3x3 kernels' grids (and weight-gradient plans without an explicit count) for `n`
-    compute units instead of all (rgbd_set_cu_budget; 0 / None = all)."""
-    lib = _lib.load()
-    prev = lib.rgbd_set_cu_budget(int(n or 0))
+    """Conv launches issued inside ON THE STREAM THAT IS CURRENT AT ENTRY size the persistent 3x3 kernels' grids for `n`
+    compute units instead of all (the `cus` argument of the conv entry points; 0 / None = all).  Enter it where the stream
+    the launches go to is already current (inside a graph capture: the capture stream)."""
+    key = _stream_key()
+    prev = _STREAM_CUS.get(key)
+    if n:
+        _STREAM_CUS[key] = int(n)
+    else:
+        _STREAM_CUS.pop(key, None)
     try:
         yield
     finally:
-        lib.rgbd_set_cu_budget(prev)
+        if prev is None:
+            _STREAM_CUS.pop(key, None)
+        else:
+            _STREAM_CUS[key] = prev
 
 
 @contextlib.contextmanager

@@ -325,11 +325,14 @@ class StyleGANGenerator(_Link):
         self.stores = (("mapping/", self.mapping.store), ("gen/", self.gen.store))
         self.train = True
 
-    def make_hidden(self, batch_size):
-        """net.py:333-343; drawn on the device (the reference draws with cupy when on GPU)."""
+    def make_hidden(self, batch_size, rng_state=None):
+        """net.py:333-343; drawn on the device (the reference draws with cupy when on GPU).  rng_state: a latent stream of the
+        caller's own (kernels.new_hidden_rng_state(device, seed)) instead of this generator's training stream -- the preview
+        sampler's seeded latents (train_rgbd.py:39-92) neither depend on nor advance the training draws."""
         from . import kernels
         if torch.device(self.device).type == "cuda":
-            return kernels.hidden_draw(self._latent_rng(), batch_size, self.ch * 2, self.ch).reshape(batch_size, self.ch * 2, 1, 1)
+            state = rng_state if rng_state is not None else self._latent_rng()
+            return kernels.hidden_draw(state, batch_size, self.ch * 2, self.ch).reshape(batch_size, self.ch * 2, 1, 1)
         z = torch.randn(batch_size, self.ch * 2, device=self.device)
         return kernels.hidden_normalize(z, self.ch).reshape(batch_size, self.ch * 2, 1, 1)
 
@@ -339,11 +342,17 @@ class StyleGANGenerator(_Link):
         from . import kernels
         return kernels.hidden_draw(self._latent_rng(), half, self.ch * 2, self.ch, copies=2).reshape(2 * half, self.ch * 2, 1, 1)
 
+    _latent_streams = 0         # latent streams created in this process so far (class-wide)
+
     def _latent_rng(self):
-        """This generator's latent stream (kernels.new_hidden_rng_state), seeded from torch's seed at the first draw."""
+        """This generator's latent stream (kernels.new_hidden_rng_state), seeded at the first draw from torch's seed and the
+        stream's ordinal in the process: a model built after torch.manual_seed(s) draws the same sequence every run, and two
+        generator objects (gen / smoothed_gen) never share one."""
         from . import kernels
         if getattr(self, "_rng_state", None) is None:
-            self._rng_state = kernels.new_hidden_rng_state(self.device)
+            k = StyleGANGenerator._latent_streams
+            StyleGANGenerator._latent_streams = k + 1
+            self._rng_state = kernels.new_hidden_rng_state(self.device, seed=torch.initial_seed() + 0x9E3779B97F4A7C15 * k)
         return self._rng_state
 
     def __call__(self, z, stage, theta=None, return_feature=False):

@@ -232,6 +232,17 @@ class RGBDUpdater:
         # still overlaps it: its own count, by default half way between the first launch's and all (measured: autotune_side_budget)
         env = os.environ.get("RGBD_DFW_WGRAD_WGS")
         self.dfw_wgrad_workgroups = kwargs.pop("dfw_wgrad_workgroups", int(env) if env else None)
+        # Data parallel (N > 1), two streams -- the same budgets priced for a step with collectives in it:
+        #   dp_reserve_cus: RCCL's kernels need compute units of their own while the all-reduces travel beside the step; a
+        #     persistent launch that claims every CU while some are held by a collective runs its last workgroups as a SECOND
+        #     round.  While a collective can be pending (gen_b beside D's all-reduce; the side stream's phases beside nothing of
+        #     RCCL's, but they share the chip with gen_b) no persistent grid is sized for more than cus - dp_reserve_cus.
+        #   dp_side_lead_workgroups: D's 34 MB should be on the wire BEFORE the generator's backward ends (then only the
+        #     generator's 29 MB are exposed); the side stream's weight-gradient launches get this many workgroups more than the
+        #     one-GPU rule gives them, so that the side stream ends earlier than the main one instead of together with it.
+        # Neither could be measured (one GPU per lease: a one-rank RCCL group moves nothing); both are arguments.
+        self.dp_reserve_cus = int(kwargs.pop("dp_reserve_cus", os.environ.get("RGBD_DP_RESERVE_CUS", "16")))
+        self.dp_side_lead_workgroups = int(kwargs.pop("dp_side_lead_workgroups", os.environ.get("RGBD_DP_SIDE_LEAD_WGS", "32")))
         if kwargs:
             raise TypeError(f"RGBDUpdater: unknown arguments {sorted(kwargs)}")
         self._side_stream = self._capture_stream = None
@@ -295,6 +306,7 @@ class RGBDUpdater:
     def _end_of_step_checks(self):
         """The non-finite checks every updater runs behind a step (DeepVoxelsUpdater too): the per-step device-side watch
         (no host synchronisation) and the reference's host check every nan_check_interval steps."""
+        kernels.STATS_POOL.end_step()       # takes behind this point (previews, tests) are not the step's
         if self.nan_watch:
             self._nan_watch_poll()          # what the previous steps reported, if it has arrived (never waits)
             self._nan_watch_push()
@@ -450,7 +462,8 @@ class RGBDUpdater:
         wgrads = []
         with Fn.deferred_wgrads(wgrads):
             torch.autograd.backward([x_fake], [gout])
-        Fn.run_deferred_wgrads(wgrads)
+        with kernels.wgrad_workgroups(st.get("main_cus", 0)):      # data parallel: not every CU (dp_reserve_cus)
+            Fn.run_deferred_wgrads(wgrads)
         st["x_fake_data"] = x_fake.detach()
         st["x_fake"] = st["gx"] = None                 # drop the autograd graph
 
@@ -559,6 +572,24 @@ class RGBDUpdater:
         self._optimizers["dis"].update(bump=not st.get("d_step_on_side"))
 
     timeline = None             # set to a dict: update_core leaves timing events of its last step there (tests, scripts)
+    call_log = None             # set to a list: update_core appends (what, name, current stream handle) in HOST ORDER as it
+                                # launches phases and starts all-reduces (tests pin the order; no timing involved)
+
+    def _note(self, what, name):
+        if self.call_log is not None:
+            self.call_log.append((what, name, torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0))
+
+    def _dp_budgets(self, st):
+        """Data parallel on two streams -> (side stream's 3x3 budget, main stream's budget); also moves the side stream's
+        weight-gradient workgroup counts in st (dp_reserve_cus / dp_side_lead_workgroups, __init__)."""
+        cus = torch.cuda.get_device_properties(self.device).multi_processor_count if torch.cuda.is_available() else 256
+        cap = max(8, cus - max(0, self.dp_reserve_cus))
+        for k in ("side_wgrad_wgs", "dfw_wgrad_wgs"):
+            if self.side_wgrad_workgroups is None and st.get(k):
+                st[k] = int(st[k]) + self.dp_side_lead_workgroups
+            st[k] = min(cap, int(st.get(k) or cap))
+        side = min(cap, self.side_cu_budget) if self.side_cu_budget else cap
+        return side, cap
 
     def _mark(self, name, stream):
         if self.timeline is not None:
@@ -667,10 +698,23 @@ class RGBDUpdater:
         """Eager for the first calls of a configuration, then capture once and replay -- on `stream` (default: the current
         one).  With profile_ranges every phase is bracketed by a roctx range (torch.cuda.nvtx maps to roctx on ROCm),
         visible to rocprofv3 --marker-trace.  cu_budget: compute units the phase's chip-filling launches size their grids
-        for (kernels.cu_budget; fixed at capture)."""
-        with self._range(name), (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()), \
-                (kernels.cu_budget(cu_budget) if cu_budget else contextlib.nullcontext()):
-            self._run_phase_inner(name, fn, st, key)
+        for (kernels.cu_budget: the `cus` argument of every conv launch of the phase; fixed at capture)."""
+        with self._range(name), (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+            self._note("phase", name)
+            self._run_phase_inner(name, self._budgeted(fn, cu_budget), st, key)
+
+    @staticmethod
+    def _budgeted(fn, cu_budget):
+        """fn with its conv launches sized for `cu_budget` compute units.  The budget is entered where fn RUNS -- on the
+        replay stream when eager, on the capture stream inside a capture -- because kernels.cu_budget belongs to the stream
+        that is current at entry."""
+        if not cu_budget:
+            return fn
+
+        def run(st):
+            with kernels.cu_budget(cu_budget):
+                fn(st)
+        return run
 
     def _run_phase_inner(self, name, fn, st, key):
         if key is None:
@@ -869,6 +913,7 @@ class RGBDUpdater:
 
         if getattr(self.dis, "sn", False) or (self.camera_conditioned and cfg.rotate_feature):
             self._literal_step(st, opt_g_m, opt_g_g, opt_d, random_camera_matrices if self.camera_conditioned else None)
+            kernels.STATS_POOL.end_step()
             obs = self.observation
             obs["stage"], obs["batch_size"], obs["image_size"] = stage, batch_size, int(st["x_real"].shape[2])
             return
@@ -916,57 +961,70 @@ class RGBDUpdater:
                 st["side_wgrad_wgs"] = st["dfw_wgrad_wgs"] = int(self.side_wgrad_workgroups)
             if self.dfw_wgrad_workgroups is not None:
                 st["dfw_wgrad_wgs"] = int(self.dfw_wgrad_workgroups)
+            side_cus, main_cus = self.side_cu_budget, 0
+            if dp:
+                side_cus, main_cus = self._dp_budgets(st)
+            st["main_cus"] = main_cus
             self._last_shape = (int(st["B"]), int(st["x_real"].shape[2]), int(st["x_real"].shape[3]))
             self._run_phase("dis", self._dis_phase, st, key, stream=side,         # D on the reals, R1, its weight gradients
-                            cu_budget=self.side_cu_budget)
-            self._run_phase("gen_a", self._gen_a_phase, st, key)                 # G forward, the one pass through D(x_fake)
+                            cu_budget=side_cus)
+            self._run_phase("gen_a", self._gen_a_phase, st, key, cu_budget=main_cus)   # G forward, the one pass through D(x_fake)
             side.wait_stream(main)
             self._run_phase("dfw", self._dfw_phase, st, key, stream=side,         # D's weight gradients for the fakes, merge
-                            cu_budget=self.side_cu_budget)
+                            cu_budget=side_cus)
             self._mark("side_end", side)
-            if dp:
-                with torch.cuda.stream(side):   # D's gradients are final: 34 MB travel under the generator's backward
+            # D's gradients are final and nothing on the main stream reads D's weights any more (D(x_fake)'s backward finished
+            # in gen_a): D's clip + Adam step runs HERE, on the side stream, under the generator's backward.  Data parallel:
+            # its 34 MB all-reduce goes in front of it, started the moment the gradients are final, and the side stream -- not
+            # the host, not the main stream -- waits for it.
+            st["d_step_on_side"] = True
+            with torch.cuda.stream(side):
+                if dp:
+                    self._note("allreduce", "dis")
                     opt_d.start_allreduce()
-            else:
-                # ... or, on one GPU, D's clip + Adam step itself runs here, under the generator's backward (nothing on the
-                # main stream reads D's weights any more: D(x_fake)'s backward finished in gen_a)
-                st["d_step_on_side"] = True
-                self._run_phase("opt_d", self._opt_d_phase, st, key, stream=side)
-            self._run_phase("gen_b", self._gen_b_phase, st, key)                 # 3-D loss, G backward, G's weight gradients
+                    opt_d.finish_allreduce()
+                self._mark("opt_d_start", side)
+            self._run_phase("opt_d", self._opt_d_phase, st, key, stream=side)
+            self._run_phase("gen_b", self._gen_b_phase, st, key, cu_budget=main_cus)   # 3-D loss, G backward, G's weight gradients
             self._mark("gen_b_end", main)
+            # the generator's clip + Adam step (+ EMA) needs nothing of the side stream: it runs before the join, under
+            # whatever D's weight gradients and D's own step still have to do.  Data parallel: behind the generator's two
+            # all-reduces (2 + 27 MB), which are the step's exposed communication -- they cannot start before the last of
+            # the generator's weight gradients, and the optimizer cannot start before they end.
             if dp:
-                for opt in g_opts:          # ... and the generator's 29 MB under whatever the side stream still has to do
+                for opt in g_opts:
+                    self._note("allreduce", "gen")
                     opt.start_allreduce()
-            else:
-                # the generator's clip + Adam step (+ EMA) needs nothing of the side stream: it runs before the join, under
-                # whatever D's weight gradients and D's own step still have to do (the streams end within 0.1 ms of each
-                # other; B = 8: 3.20 -> 3.14 ms per step, the benched shape +0.5 %)
-                self._run_phase("opt_g", self._opt_g_phase, st, key)
-                st["opt_g_done"] = True
+                for opt in g_opts:
+                    opt.finish_allreduce()
+            self._mark("opt_g_start", main)
+            self._run_phase("opt_g", self._opt_g_phase, st, key)
+            st["opt_g_done"] = True
             main.wait_stream(side)
             self._run_phase("join", self._join_phase, st, key)
         elif dp and self.dp_split_body:
             self._run_phase("body_g", self._body_g_phase, st, key)
             for opt in g_opts:              # ~29 MB of generator gradients travel while D's half of the step runs
+                self._note("allreduce", "gen")
                 opt.start_allreduce()
             self._run_phase("body_d", self._body_d_phase, st, key)
         else:
             self._run_phase("body", self._body_phase, st, key)
-        if dp:
-            # data parallel (train_rgbd.py:154-156: the multi-node optimizers all-reduce before they update): one
-            # all-reduce per flat gradient buffer on the communicator's stream, the collectives outside the graphs;
+        if st.get("d_step_on_side"):
+            pass                        # two streams: both optimizer phases ran inside the arrangement above
+        elif dp:
+            # data parallel on ONE stream (train_rgbd.py:154-156: the multi-node optimizers all-reduce before they update):
+            # one all-reduce per flat gradient buffer on the communicator's stream, the collectives outside the graphs;
             # the generator's Adam step runs while D's 34 MB all-reduce is still in flight
             for opt in g_opts + [opt_d]:
                 if getattr(opt, "_pending", None) is None:
+                    self._note("allreduce", "gen" if opt is not opt_d else "dis")
                     opt.start_allreduce()
             for opt in g_opts:
                 opt.finish_allreduce()
             self._run_phase("opt_g", self._opt_g_phase, st, key)
             opt_d.finish_allreduce()
             self._run_phase("opt_d", self._opt_d_phase, st, key)
-        elif st.get("d_step_on_side"):
-            if not st.get("opt_g_done"):
-                self._run_phase("opt_g", self._opt_g_phase, st, key)
         else:
             self._run_phase("opt", self._opt_phase, st, key)
         if key is not None or st.get("d_step_on_side"):

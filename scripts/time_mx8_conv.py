@@ -48,7 +48,7 @@ for H, Cin, Cout, ups in shapes:
     tb = timeit(lambda: kernels.conv2d_fprop(x, wf, 3, 3, 1, bias=bias, lrelu_channels=Cout, upsample=ups))
     tm = timeit(lambda: _lib.check(lib.rgbd_conv2d_fprop_mxfp8(kernels._ptr(xq), kernels._ptr(xs), kernels._ptr(f[0]),
                                                                kernels._ptr(f[1]), kernels._ptr(bias), None, kernels._ptr(y),
-                                                               None, B, Hi, Hi, Cin, Cout, int(ups), Cout, 0.2, st()), "mx"))
+                                                               None, B, Hi, Hi, Cin, Cout, int(ups), Cout, 0.2, 0, st()), "mx"))
     tq = timeit(lambda: (setattr(x, "_mx8", None), kernels.quantize_mx8(x)))
     print(f"H={H:4d} {Cin:4d}->{Cout:4d}{' ups' if ups else '    '}  bf16 {tb:7.1f} us {fl / tb / 1e6:6.0f} TF | mxfp8 {tm:7.1f} us "
           f"{fl / tm / 1e6:6.0f} TF ({tb / tm:4.2f}x) | quantise {tq:6.1f} us {3.03 * x.numel() / tq / 1e3:5.0f} GB/s | "

@@ -55,6 +55,6 @@ def test_integration_document_names_only_real_entry_points():
 
 def test_bad_arguments_are_reported_not_crashed():
     lib = _lib.load()
-    rc = lib.rgbd_conv2d_fprop_bf16(None, None, None, None, None, None, 1, 4, 4, 64, 64, 3, 3, 1, 0, 0, 0.2, None, None)
+    rc = lib.rgbd_conv2d_fprop_bf16(None, None, None, None, None, None, 1, 4, 4, 64, 64, 3, 3, 1, 0, 0, 0.2, None, 0, None)
     assert rc == -1
     assert b"null pointer" in lib.rgbd_last_error()

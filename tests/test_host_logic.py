@@ -295,3 +295,47 @@ def test_side_stream_weight_gradient_budget_rule():
         # the second launch (`dfw`, mostly behind the end of the generator's backward): half way to the whole chip
         assert pair(32, 128) == (160, 208) and pair(8, 128) == (64, 160) and pair(16, 256) == (208, 232)
     assert all(rule(B, S) % 8 == 0 and pair(B, S)[1] % 8 == 0 for B in (2, 8, 32) for S in (16, 64, 256))
+
+
+def test_statistics_pool_counts_only_a_steps_own_takes():
+    """kernels._StatsPool: while a stage is replayed from HIP graphs no begin_step runs in Python, but the
+    preview sampler still calls the generator -- those takes must neither grow the pool nor move the step's slices."""
+    from rgbd_gan_amd.kernels import _StatsPool
+    cpu = torch.device("cpu")
+    pool = _StatsPool()
+    assert pool.take(1000, cpu) is None and pool.used == 0           # outside a step: caller falls back to torch.zeros
+    bufs = []
+    pool.begin_step(cpu, bufs)                                        # first step of a configuration: pool too small
+    first = pool.buf.numel()
+    assert len(bufs) == 1 and bufs[0].dtype == torch.float32 and bufs[0].numel() == 2 * first
+    assert pool.take(3 * first, cpu) is None and pool.used == 3 * first
+    pool.end_step()
+    for _ in range(500):                                              # 500 previews between steps
+        assert pool.take(3 * first, cpu) is None
+    assert pool.used == 3 * first
+    pool.begin_step(cpu, [])                                          # second step: exactly the first one's demand
+    assert pool.buf.numel() == 3 * first and len(pool._retired) == 1
+    a = pool.take(2 * first, cpu)
+    b = pool.take(first, cpu)
+    assert a.numel() == 2 * first and b.data_ptr() == a.data_ptr() + 8 * 2 * first
+    pool.end_step()
+    pool.begin_step(cpu, [])                                          # steady state: same buffer, same slices
+    assert pool.buf.numel() == 3 * first and pool.take(2 * first, cpu).data_ptr() == a.data_ptr()
+
+
+def test_data_parallel_budgets_leave_compute_units_to_the_collectives():
+    """RGBDUpdater._dp_budgets: beside a pending all-reduce no persistent grid is sized for the whole chip,
+    and the side stream's weight-gradient launches get more workgroups than the one-GPU rule gives them (so that D's gradients
+    are on the wire before the generator's backward ends)."""
+    from rgbd_gan_amd.updater import RGBDUpdater
+    fake = type("U", (), {"device": "cpu", "dp_reserve_cus": 16, "dp_side_lead_workgroups": 32, "side_cu_budget": 224,
+                          "side_wgrad_workgroups": None})()
+    if torch.cuda.is_available():
+        return
+    st = {"side_wgrad_wgs": 64, "dfw_wgrad_wgs": 160}
+    assert RGBDUpdater._dp_budgets(fake, st) == (224, 240) and st == {"side_wgrad_wgs": 96, "dfw_wgrad_wgs": 192}
+    st = {"side_wgrad_wgs": 208, "dfw_wgrad_wgs": 232}
+    assert RGBDUpdater._dp_budgets(fake, st) == (224, 240) and st == {"side_wgrad_wgs": 240, "dfw_wgrad_wgs": 240}
+    fake.side_wgrad_workgroups, fake.side_cu_budget = 96, 0                # explicit counts are capped, not moved
+    st = {"side_wgrad_wgs": 96, "dfw_wgrad_wgs": 0}
+    assert RGBDUpdater._dp_budgets(fake, st) == (240, 240) and st == {"side_wgrad_wgs": 96, "dfw_wgrad_wgs": 240}

@@ -332,8 +332,8 @@ def test_conv_wgrad_batch_matches_single_calls():
 
 @pytest.mark.parametrize("budget", [8, 40, 100, 224])
 def test_compute_unit_budget_changes_grids_not_results(budget):
-    """rgbd_set_cu_budget / the weight-gradient plan's workgroup count (RGBDUpdater gives its side stream's chip-filling
-    launches fewer compute units): the 3x3 kernel walks the same tiles with the same arithmetic on fewer persistent
+    """The conv entry points' `cus` argument (kernels.cu_budget: per stream, host side) / the weight-gradient plan's workgroup
+    count (RGBDUpdater gives its side stream's chip-filling launches fewer compute units): the 3x3 kernel walks the same tiles with the same arithmetic on fewer persistent
     workgroups -- every form bit-identical; the weight gradients are the same sums split over a different number of slabs
     (fp32 summation order)."""
     from rgbd_gan_amd import kernels
@@ -358,7 +358,12 @@ def test_compute_unit_budget_changes_grids_not_results(budget):
     ref_y, ref_w = run()
     with kernels.cu_budget(budget), kernels.wgrad_workgroups(budget):
         got_y, got_w = run()
-    assert _lib_budget() == 0                                   # the context put the default back
+    assert kernels._cus() == 0 and not kernels._STREAM_CUS      # the context put the default back
+    other = torch.cuda.Stream()
+    with kernels.cu_budget(budget):                             # a budget belongs to the stream it was set on ...
+        assert kernels._cus() == budget
+        with torch.cuda.stream(other):
+            assert kernels._cus() == 0                          # ... another stream's launches do not see it
     for a, b in zip(ref_y, got_y):
         if a.dtype == torch.bfloat16:
             assert torch.equal(a.view(torch.int16), b.view(torch.int16))
@@ -366,14 +371,6 @@ def test_compute_unit_budget_changes_grids_not_results(budget):
             torch.testing.assert_close(a.double(), b.double(), rtol=1e-6, atol=1e-6 * float(a.double().abs().max()))
     for a, b in zip(ref_w, got_w):
         torch.testing.assert_close(a, b, rtol=1e-5, atol=2e-5 * float(a.abs().max()))
-
-
-def _lib_budget():
-    from rgbd_gan_amd import _lib
-    lib = _lib.load()
-    prev = lib.rgbd_set_cu_budget(0)
-    lib.rgbd_set_cu_budget(prev)
-    return prev
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 4, 4, 64, 64), (3, 8, 8, 128, 64), (2, 32, 32, 64, 128), (1, 64, 64, 64, 64)])
@@ -1062,7 +1059,7 @@ def test_split_k_path_matches_unsplit(B, H, Cin, Cout, K, pad, ups):
     y_ref = torch.empty_like(y_split)
     rc = lib.rgbd_conv2d_fprop_bf16(kernels._ptr(x), kernels._ptr(wf), kernels._ptr(bias), kernels._ptr(res),
                                     kernels._ptr(y_ref), None, B, H, H, Cin, Cout, K, K, pad, int(ups), Cout, 0.2, None,
-                                    kernels._stream())
+                                    0, kernels._stream())
     assert rc == 0
     d = (y_split.float() - y_ref.float()).abs().max().item()
     scale = y_ref.float().abs().max().item()

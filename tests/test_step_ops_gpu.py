@@ -102,6 +102,41 @@ def test_hidden_draw_is_make_hidden_with_the_draw_inside():
     assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
 
 
+def test_preview_latents_are_seeded_and_leave_the_training_stream_alone():
+    """sample_generate_light draws its latents once from a FIXED seed (train_rgbd.py:39-92).  StyleGAN's latents come from the
+    library's Philox stream, so the preview sampler draws from a private stream seeded with its own seed: the same latents
+    whatever torch's seed is (every run, after a resume), and the generator's training stream neither moves nor is shared
+    by a second generator object (gen / smoothed_gen)."""
+    from rgbd_gan_amd.common.utils.save_images import PreviewSampler
+    from rgbd_gan_amd.net import StyleGANGenerator
+    from rgbd_gan_amd.utils.yaml_utils import Config
+    cfg = Config(generator_architecture="stylegan", rgb=False, test_y_rotate=0.5)
+
+    def preview_latents(torch_seed, draws_before):
+        torch.manual_seed(torch_seed)
+        gen, smoothed = StyleGANGenerator(256, rgbd=True, device=DEV), StyleGANGenerator(256, rgbd=True, device=DEV)
+        for _ in range(draws_before):
+            gen.make_hidden(4)
+        before = gen._latent_rng().cpu().tolist()
+        ps = PreviewSampler(gen, "/tmp/unused", cfg, rows=2, cols=3, seed=0)
+        ps.render(4.0)
+        assert gen._latent_rng().cpu().tolist() == before               # the training stream did not move
+        assert before[2] == draws_before
+        train_next = gen.make_hidden(4)
+        assert not torch.equal(train_next, smoothed.make_hidden(4))     # two generator objects, two streams
+        return ps.z.clone(), train_next
+
+    z_a, t_a = preview_latents(11, 0)
+    z_b, t_b = preview_latents(12, 3)
+    z_c, t_c = preview_latents(11, 0)
+    assert z_a.shape == (6, 512, 1, 1) and torch.equal(z_a[0], z_a[1]) and not torch.equal(z_a[0], z_a[2])   # tiled over the rows
+    assert torch.equal(z_a, z_b) and torch.equal(z_a, z_c)             # seed 0 -> the same preview latents, always
+    assert torch.equal(t_a, t_c) and not torch.equal(t_a, t_b)         # the training stream follows torch's seed
+    other = PreviewSampler(StyleGANGenerator(256, rgbd=True, device=DEV), "/tmp/unused", cfg, rows=2, cols=3, seed=1)
+    other.render(4.0)
+    assert not torch.equal(other.z, z_a)
+
+
 def test_r1_penalty_kernel_and_gradient():
     from rgbd_gan_amd import functional as Fn
     g = torch.randn(6, 3, 64, 64, device=DEV) * 0.3
