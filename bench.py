@@ -189,6 +189,90 @@ def cpu_baseline(batch=8, threads=None, budget_s=12.0, max_steps=12):
                       f"path (Chainer unavailable), {dt:.1f} s"}
 
 
+class VerifyingComm:
+    """Proxy of a Communicator for the `dp.allreduce_verified` screen: every all-reduce it starts is repeated afterwards on a
+    QUIET device from a copy of the same inputs, and the two results are compared bit for bit.  The first one runs where the
+    step runs it -- on RCCL's stream beside the step's MFMA kernels on both compute streams -- which is the situation in which
+    packed-fp32 arithmetic was found to return wrong lanes on this chip (the library is built without
+    those instructions, RCCL's reduction kernels are not ours to build)."""
+
+    def __init__(self, comm):
+        self._comm, self.records = comm, []
+
+    def __getattr__(self, name):
+        return getattr(self._comm, name)
+
+    def allreduce_async(self, flat):
+        pre = flat.clone()                             # on the stream the gradients just became final on
+        self.records.append([flat, pre, None])
+        return (self._comm.allreduce_async(flat), len(self.records) - 1)
+
+    def wait(self, handle):
+        if handle is None:
+            return
+        work, i = handle
+        self._comm.wait(work)
+        self.records[i][2] = self.records[i][0].clone()        # what the optimizer is about to read
+
+    def check(self):
+        """Call on every rank at the same point, after a device-wide synchronisation.  -> (all equal, buffers compared)"""
+        import torch
+        import torch.distributed as dist
+        ok, n = True, 0
+        for flat, pre, post in self.records:
+            if post is None:
+                continue
+            dist.all_reduce(pre, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize()
+            ok = ok and bool(torch.equal(pre.view(torch.int32), post.view(torch.int32)))
+            n += 1
+        self.records = []
+        return ok, n
+
+
+def dp_verify(upd, opt, steps=3):
+    """`steps` ordinary training steps with every optimizer's communicator wrapped in VerifyingComm."""
+    import torch
+    proxies = {}
+    for o in opt.values():
+        proxies.setdefault(id(o.comm), VerifyingComm(o.comm))
+        o.comm = proxies[id(o.comm)]
+    ok, n = True, 0
+    try:
+        for _ in range(steps):
+            upd.update()
+            torch.cuda.synchronize()
+            for p in proxies.values():
+                a, b = p.check()
+                ok, n = ok and a, n + b
+    finally:
+        for o in opt.values():
+            o.comm = o.comm._comm
+    return ok, n
+
+
+def dp_exposed(upd, steps=5):
+    """Event-timed gaps the collectives leave in the two compute streams, mean over `steps` steps (ms): on the main stream from
+    the end of gen_b (the generator's gradients final, its all-reduces enqueued) to the start of its optimizer phase; on the side
+    stream from the end of dfw + merge to the start of D's optimizer phase.  The main stream's gap is on the step's critical path;
+    the side stream's is exposed only as far as it outlasts the generator's backward."""
+    import torch
+    gaps = {"gen": [], "dis": [], "side_end_before_gen_b_end": []}
+    for _ in range(steps):
+        upd.timeline = {}
+        upd.update()
+        torch.cuda.synchronize()
+        t = upd.timeline
+        if not all(k in t for k in ("gen_b_end", "opt_g_start", "side_end", "opt_d_start")):
+            upd.timeline = None
+            return None
+        gaps["gen"].append(t["gen_b_end"].elapsed_time(t["opt_g_start"]))
+        gaps["dis"].append(t["side_end"].elapsed_time(t["opt_d_start"]))
+        gaps["side_end_before_gen_b_end"].append(t["side_end"].elapsed_time(t["gen_b_end"]))
+    upd.timeline = None
+    return {k: sum(v) / len(v) for k, v in gaps.items()}
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` outside any launcher: start N ranks of this script (one per GPU) and relay rank 0's
     JSON line.  This parent never imports torch and never touches a GPU (a process that has initialised HIP must not
@@ -280,13 +364,20 @@ def run_workload(args, comm, device):
 
     for _ in range(args.warmup):
         upd.update()
+    dp_checked = None
+    if comm.active and not deepvoxels:
+        # data parallel: screen the collectives before anything is timed (three more untimed steps on every rank)
+        sync()
+        dp_checked = dp_verify(upd, opt)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         upd.update()
     t_enqueue = time.perf_counter() - t0          # host time to enqueue the steps (GPU still running)
     sync()
-    elapsed = comm.max_over_ranks(time.perf_counter() - t0)
+    own = time.perf_counter() - t0
+    elapsed = comm.max_over_ranks(own)
+    fastest = -comm.max_over_ranks(-own)
     upd._check_finite()
 
     # host cost of enqueueing a step, measured on a short burst right after a sync: over the long timed loop the launch
@@ -338,9 +429,29 @@ def run_workload(args, comm, device):
     else:
         line["step_tflops_algorithmic"] = round(value * STEP_GFLOP_PER_IMAGE / 1e3, 2)
         line["mfma_roofline_frac_whole_step"] = round(value * STEP_GFLOP_PER_IMAGE / 1e3 / (MFMA_BF16_PEAK_TFLOPS * comm.size), 4)
-        if comm.size > 1:
-            line["config"]["collectives"] = {"backend": torch.distributed.get_backend(),
-                                             "world_size_reported_by_group": torch.distributed.get_world_size()}
+    if comm.active and not deepvoxels:
+        # the data-parallel job describes itself (train_rgbd.py:103-121,154-156): what moved, what of it the step waited for,
+        # and whether the sums that arrived are the sums a quiet device computes
+        exposed = dp_exposed(upd) if getattr(upd, "concurrent_phases", False) else None
+        sync()
+        if exposed is not None:
+            exposed = {k: round(comm.max_over_ranks(v), 4) for k, v in exposed.items()}
+        line["dp"] = {
+            "backend": torch.distributed.get_backend(), "world_size": torch.distributed.get_world_size(),
+            "allreduce_bytes": {k: int(o.store.grad.numel() * o.store.grad.element_size()) for k, o in opt.items()},
+            "allreduce_exposed_ms": exposed["gen"] if exposed else None,
+            "allreduce_wait_ms": ({"main_stream_gen": exposed["gen"], "side_stream_dis": exposed["dis"],
+                                   "side_end_before_gen_b_end": exposed["side_end_before_gen_b_end"]} if exposed else None),
+            "allreduce_exposed_note": "HIP events, mean over 5 steps behind the timed region, max over ranks: the gap between the "
+                                      "end of a stream's last compute phase (its all-reduces are enqueued there) and the start of "
+                                      "its optimizer phase; the main stream's gap is the step's exposed communication",
+            "ms_per_step_rank_spread": [round(fastest / args.steps * 1e3, 3), round(elapsed / args.steps * 1e3, 3)],
+            "allreduce_verified": bool(dp_checked[0]) if dp_checked and dp_checked[1] else None,
+            "allreduce_verified_buffers": dp_checked[1] if dp_checked else 0,
+            "allreduce_verified_note": "3 untimed steps before the timed region: every all-reduce that ran beside the step's MFMA "
+                                       "kernels repeated on a quiet device from a copy of its inputs, results compared bit for bit",
+            "budgets": {"reserve_cus": getattr(upd, "dp_reserve_cus", None),
+                        "side_lead_workgroups": getattr(upd, "dp_side_lead_workgroups", None)}}
 
     if comm.rank == 0 and not args.no_roofline:
         # per-launch HIP-event timing of the conv kernels over extra (untimed) steps, on the launch stream

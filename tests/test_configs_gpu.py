@@ -301,6 +301,9 @@ def test_data_parallel_path_on_a_one_rank_rccl_group():
     assert len(rows) == 1, r.stdout[-2000:]
     line = json.loads(rows[0])
     assert line["n_gpus"] == 1 and line["value"] > 0 and np.isfinite(line["ms_per_step"])
+    dp = line["dp"]                                        # RCCL's own kernels beside the step's: their sums are checked
+    assert dp["backend"] == "nccl" and dp["world_size"] == 1 and dp["allreduce_verified"] is True
+    assert dp["allreduce_verified_buffers"] == 9 and dp["allreduce_exposed_ms"] is not None
 
 
 ORDER_SCRIPT = r"""

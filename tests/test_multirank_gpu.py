@@ -283,3 +283,13 @@ def test_bench_roofline_leg_keeps_the_ranks_collectives_paired():
     assert len(rows) == 1, r.stdout[-2000:]
     line = json.loads(rows[0])
     assert line["n_gpus"] == 2 and line["roofline"]["achieved"] > 0 and line["config"]["parallelism"] == "dp2"
+    # the data-parallel job describes itself: what moved, what the step waited for, and whether the sums that arrived beside
+    # the step's kernels are the sums a quiet device computes (bit for bit; 3 steps x 3 buffers)
+    dp = line["dp"]
+    assert dp["backend"] == "gloo" and dp["world_size"] == 2
+    assert set(dp["allreduce_bytes"]) == {"map", "gen", "dis"} and dp["allreduce_bytes"]["dis"] > dp["allreduce_bytes"]["gen"] > 2e7
+    assert dp["allreduce_verified"] is True and dp["allreduce_verified_buffers"] == 9
+    assert dp["allreduce_exposed_ms"] is not None and dp["allreduce_exposed_ms"] >= 0.0          # a measurement: no bound asserted
+    assert set(dp["allreduce_wait_ms"]) == {"main_stream_gen", "side_stream_dis", "side_end_before_gen_b_end"}
+    lo, hi = dp["ms_per_step_rank_spread"]
+    assert 0 < lo <= hi
