@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="the default command also runs short lines of configurations 3 (per-GPU shape), 4 and 5 (bf16 / fp8) "
                          "into `other_configs`; this switches them off")
+    ap.add_argument("--stage", type=float, default=None,
+                    help="pin the progressive-growing stage (default: the schedule's stage at --iteration, 10 = 128x128 without "
+                         "fade-in); 9.5 = the fade-in arrangement between 64x64 and 128x128 (two output heads, blended reals)")
     ap.add_argument("--autotune", action="store_true", help="measure the side stream's workgroup counts at set-up (RGBDUpdater.autotune_side_budget) "
                                                          "instead of taking the rule of thumb")
     ap.add_argument("--other-steps", type=int, default=30)
@@ -87,7 +90,9 @@ def workload_key(args):
         return "c4"
     if cfg == "ffhq_stylegan_occlusion.yml" and args.batch == 8:
         return "c3_b8"
-    if cfg == "stylegan_shapenet_car.yml" and args.batch in (None, 32) and not args.fp8:
+    if cfg == "stylegan_shapenet_car.yml" and args.batch in (None, 32) and not args.fp8 and args.stage == 9.5:
+        return "c2_fade"
+    if cfg == "stylegan_shapenet_car.yml" and args.batch in (None, 32) and not args.fp8 and args.stage in (None, 10.0):
         return "default"
     return None
 
@@ -337,6 +342,8 @@ def run_workload(args, comm, device):
         config.ch, config.max_resolution, config.max_stage = 512, 256, 13
         B = args.batch or 16
         side, extra = 256, {"fixed_stage": 12.0}
+    if args.stage is not None and not deepvoxels:
+        extra["fixed_stage"] = float(args.stage)
     if args.fp8:
         config.conv_dtype = "mxfp8"
         kernels.MX8_EMIT = not args.mx8_standalone_quantiser
@@ -426,6 +433,8 @@ def run_workload(args, comm, device):
         line["metric"] = "img/s (G+D+3D-loss step) at 64x64, DeepVoxels generator"
     elif args.res256:
         line["metric"] = "img/s (G+D+3D-loss step) at 256x256"
+    elif args.stage not in (None, 10.0):
+        pass                            # (the whole-step FLOP count below is stage 10's)
     else:
         line["step_tflops_algorithmic"] = round(value * STEP_GFLOP_PER_IMAGE / 1e3, 2)
         line["mfma_roofline_frac_whole_step"] = round(value * STEP_GFLOP_PER_IMAGE / 1e3 / (MFMA_BF16_PEAK_TFLOPS * comm.size), 4)
@@ -543,6 +552,9 @@ def run_workload(args, comm, device):
 # The other BASELINE configurations, run by the DEFAULT command behind its timed region (never `value`): short runs so that
 # every performance claim of DESIGN.md has a driver-visible line.  (name, command-line overrides)
 OTHER_CONFIGS = [
+    # configuration 2 in a FADE-IN stage (the reference spends 20 000 of its first 180 000 iterations in stage 9.x,
+    # updater.py:252-256): two output / input heads, blended reals, 64x64 trunk + the 128x128 block
+    ("c2_fade", {"stage": 9.5}),
     ("c3_b8", {"config": os.path.join(ROOT, "configs", "ffhq_stylegan_occlusion.yml"), "batch": 8}),
     ("c4", {"config": os.path.join(ROOT, "configs", "deepvoxels_shapenet_car.yml")}),
     ("c5_bf16", {"res256": True}),

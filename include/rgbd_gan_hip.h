@@ -278,6 +278,17 @@ int rgbd_linear_fwd(const float* x, const float* w, const float* bias, float* y,
                     float slope, float* workspace, void* stream);
 int rgbd_linear_bwd(const float* dy, const float* y, const float* x, const float* w, float* dx, float* dw, float* db,
                     int M, int K, int N, float c, int act, float slope, int accumulate_dx, void* stream);
+/* A CHAIN of L <= 8 such layers with K = N = C (256 or 512), leaky ReLU behind every one -- the mapping network, net.py:22-62
+ * (`for l in self.l: h = l(h)`) -- as ONE launch per pass: a workgroup per 16 rows keeps the activations in LDS and streams the
+ * weights of all layers.  w_host / b_host / dw_host / db_host: HOST arrays of L device pointers (copied into the launch).
+ *   fwd: acts (L,M,C) receives every layer's output; acts[L-1] is the chain's result.
+ *   bwd: dy (M,C) = gradient of acts[L-1]; writes dz (L,M,C) (scratch: the gradients of the pre-activations) and dx (M,C);
+ *        when dw_host != NULL a second launch ADDS c * dz[l]^T in_l to dw_host[l] (C,C) and sum_m dz[l] to db_host[l] (C)
+ *        for all layers (in_0 = x, in_l = acts[l-1]); a NULL entry skips that layer. */
+int rgbd_mlp_fwd(const float* x, const float* const* w_host, const float* const* b_host, int L, int M, int C, float c,
+                 float slope, float* acts, void* stream);
+int rgbd_mlp_bwd(const float* dy, const float* x, const float* acts, const float* const* w_host, float* const* dw_host,
+                 float* const* db_host, int L, int M, int C, float c, float slope, float* dz, float* dx, void* stream);
 /* y = (c * x W^T) * lrelu'(mask_y): the derivative of rgbd_linear_bwd's dx w.r.t. its dy -- what the R1 double backward
  * (updater.py:414-422, chainer.grad(..., enable_double_backprop=True)) sends back through the discriminator's dense tail
  * (net.py:372-377).  mask_y (M,N): the activation OUTPUT whose slope mask applies. */

@@ -57,6 +57,9 @@ PROTOTYPES = {
     "rgbd_planes_outer": ([_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P], c_int),
     "rgbd_linear_fwd_workspace": ([c_int, c_int, c_int], c_int64),
     "rgbd_linear_fwd": ([_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_int, c_float, _P, _P], c_int),
+    "rgbd_mlp_fwd": ([_P, POINTER(c_void_p), POINTER(c_void_p), c_int, c_int, c_int, c_float, c_float, _P, _P], c_int),
+    "rgbd_mlp_bwd": ([_P, _P, _P, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_int, c_int, c_int, c_float,
+                      c_float, _P, _P, _P], c_int),
     "rgbd_linear_fwd_masked": ([_P, _P, _P, _P, c_int, c_int, c_int, c_float, c_float, _P, _P], c_int),
     "rgbd_real_batch_u8": ([_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_float, _P], c_int),
     "rgbd_zero_multi_f32": ([POINTER(c_void_p), POINTER(c_int64), c_int, _P], c_int),

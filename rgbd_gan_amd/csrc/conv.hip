@@ -1178,10 +1178,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
         const bool act = co < a.lrelu_ch;
         const float cw = MASKED && a.colsum && a.row_scale ? a.row_scale[b] : 1.f;
         const float cw2 = MASKED && a.y2 ? a.row_scale2[b] : 0.f;
-        if (STATS && b != st_b) {
-            if (st_b >= 0) stats_flush();
-            st_b = b;
-        }
+        if (STATS) st_b = b;
         if (a.pool_sum) {
             const int Hp = a.Hout >> 1, Wp = a.Wout >> 1;
 #pragma unroll
@@ -1344,6 +1341,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
             st1_acc += transpose_reduce16(tl0);
             st2_acc += transpose_reduce16(tl1);
         }
+        // one flush per TILE, not per (workgroup, image): a tile's fp32 partial sums do not depend on which workgroup walks it,
+        // and the fixed-point integer adds behind them are associative -- the statistics (and with them the generator's
+        // forward) are bit-identical whatever grid the launch was sized for (`cus`).  Per-image flushes made them depend on the
+        // tile-to-workgroup assignment at fp32 rounding level (1e-7), which bf16 roundings downstream amplified to 1e-4 in the
+        // mapping network's gradient between a 240- and a 256-workgroup launch.
+        if constexpr (STATS) stats_flush();
     };
 
     // ---- prologue: halo patch of slice 0, weight tiles of steps 0-2 (step t multiplies filter tap
@@ -1526,7 +1529,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_sp_kernel(ConvArgs a) {
         for (int k_ = 0; k_ < 5; ++k_) o[k_] = (unsigned)stamp_sum[k_];
     }
 #endif
-    if (STATS && st_b >= 0) stats_flush();
     if (MASKED && a.colsum) {
         // 16 pixel columns (lanes r16) -> one value per channel per wave; the WAVES_PX waves that share channels meet
         // through LDS (idle by now: every wave has retired its DMAs, the barrier says so for all of them); then ONE fp32
@@ -1810,10 +1812,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dw_kernel(ConvArgs a) {
         tile_origin(pt, b, y0, x0);
         const float cw = MASKED && a.colsum && a.row_scale ? a.row_scale[b] : 1.f;
         const float cw2 = MASKED && a.y2 ? a.row_scale2[b] : 0.f;
-        if (STATS && b != st_b) {
-            if (st_b >= 0) stats_flush();
-            st_b = b;
-        }
+        if (STATS) st_b = b;
 #pragma unroll
         for (int hw = 0; hw < NH; ++hw) {
             const int co = n0 + 64 * hw + 16 * q;            // this lane's 16 consecutive output channels of the half
@@ -1967,6 +1966,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dw_kernel(ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < TPX; ++j) acc[4 * hw + i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        if constexpr (STATS) stats_flush();          // per tile: grid-independent statistics (see conv3x3_sp_kernel)
     };
 
     // ---- prologue: halo patch of slice 0, weight tiles of steps 0-1 and the first pieces of step 2's (step t multiplies
@@ -2099,7 +2099,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dw_kernel(ConvArgs a) {
         o[4] = (unsigned)t1; o[5] = (unsigned)(t1 >> 32); o[6] = (unsigned)g_total; o[7] = blockIdx.x;
     }
 #endif
-    if (STATS && st_b >= 0) stats_flush();
     if (MASKED && a.colsum) {
         __syncthreads();
         float* const red = reinterpret_cast<float*>(dsm);              // [4 waves][BN]

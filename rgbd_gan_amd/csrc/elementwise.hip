@@ -1582,6 +1582,212 @@ extern "C" int rgbd_linear_bwd(const float* dy, const float* y, const float* x, 
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------- fused MLP chain
+namespace {
+// The mapping network (net.py:22-62: 8 x [equalized linear C -> C, leaky ReLU] on 2B <= 64 latent rows) as ONE launch per pass
+// instead of one per layer (forward) / two per layer (backward).  The chain is a dependent sequence of tiny GEMMs: per layer a
+// launch costs a kernel boundary plus a dependent global-load round trip (~10 us), eight of them sit at the head of the
+// generator's forward and sixteen at the tail of its backward, on the step's critical stream.
+// One 8-wave workgroup per 16 rows walks ALL layers: the 16 x C activations live in LDS (double-buffered), every wave owns
+// C/128 column tiles of 16 and streams its 16 x 256 slices of W straight from global memory (L2-resident: the whole network is
+// 2 MB at C = 256) into registers in the fp32 MFMA's B-operand layout -- the slice of the NEXT unit is requested before the
+// current one is multiplied, across layer boundaries too (weights do not depend on activations), so after the first slice
+// the kernel runs at the CU's fp32 matrix rate: 16 x C x C MACs per layer = 3.4 us at C = 256.  No cross-workgroup hand-off:
+// rows are independent.  fp32 throughout (v_mfma_f32_16x16x4_f32), the summation order over k differs from the per-layer
+// kernels' (quads of k interleaved the same way, halves of K accumulated in sequence).
+constexpr int MLP_MAX_LAYERS = 8;
+struct MlpArgs {
+    const float* w[MLP_MAX_LAYERS];     // (C,C) row-major [n][k] master weights
+    const float* b[MLP_MAX_LAYERS];     // (C) or null (forward only)
+    const float* x;                     // forward: (M,C) input;  backward: (M,C) gradient of the last layer's output
+    const float* acts_in;               // backward: (L,M,C) the layers' outputs
+    float* acts;                        // forward: (L,M,C) out
+    float* dz;                          // backward: (L,M,C) out: dz[l] = d loss / d (pre-activation of layer l)
+    float* dx;                          // backward: (M,C) out
+    int L, M;
+    float c, slope;
+};
+
+template <int C, bool BWD>
+__global__ __launch_bounds__(512) void mlp_chain_kernel(MlpArgs a) {
+    constexpr int LD = C + 4;
+    constexpr int KH = C / 256;                     // K halves of 256 per column tile
+    constexpr int CTW = C / 16 / 8;                 // column tiles per wave
+    constexpr int UPL = CTW * KH;                   // units (16 columns x 256 k) per wave per layer: 2 (C = 256), 8 (C = 512)
+    static_assert(C % 256 == 0 && UPL % 2 == 0, "mlp_chain_kernel: C must be a multiple of 256");
+    __shared__ float xs[2][16][LD];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.x * 16;
+    const int L = a.L, M = a.M;
+    // ---- the chain's input into LDS (rows beyond M: zeros)
+    for (int i = threadIdx.x; i < 16 * (C / 4); i += 512) {
+        const int row = i / (C / 4), c4 = (i % (C / 4)) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m0 + row < M) {
+            v = *reinterpret_cast<const f32x4*>(a.x + (long)(m0 + row) * C + c4);
+            if (BWD) {                              // dz[L-1] = dy * lrelu'(y[L-1])
+                const f32x4 y = *reinterpret_cast<const f32x4*>(a.acts_in + ((long)(L - 1) * M + m0 + row) * C + c4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = y[j] > 0.f ? v[j] : v[j] * a.slope;
+                *reinterpret_cast<f32x4*>(a.dz + ((long)(L - 1) * M + m0 + row) * C + c4) = v;
+            }
+        }
+        *reinterpret_cast<f32x4*>(&xs[0][row][c4]) = v;
+    }
+    __syncthreads();
+
+    auto load_unit = [&](int u, f32x4 (&b)[16]) {
+        const int lay = BWD ? L - 1 - u / UPL : u / UPL, within = u % UPL;
+        const int ct = wave + 8 * (within / KH), kh = within % KH;
+        const float* w = a.w[lay];
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+            const int kk = 256 * kh + 16 * s2 + 4 * q;          // reduction index of this lane's quad
+            if (!BWD) {
+                b[s2] = *reinterpret_cast<const f32x4*>(w + (long)(16 * ct + r) * C + kk);        // W[n][k..k+3]
+            } else {
+                // W[n..n+3][k]: a wave-uniform row base (scalar registers) + ONE per-lane offset for all 64 loads of a unit
+                const int lane_off = 4 * q * C + r;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[s2][j] = (w + (long)(256 * kh + 16 * s2 + j) * C + 16 * ct)[lane_off];
+            }
+        }
+    };
+    int cur = 0;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    auto compute_unit = [&](int u, const f32x4 (&b)[16]) {
+        const int lay = BWD ? L - 1 - u / UPL : u / UPL, within = u % UPL;
+        const int ct = wave + 8 * (within / KH), kh = within % KH;
+        if (kh == 0) acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(&xs[cur][r][256 * kh + 16 * s2 + 4 * q]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], b[s2][j], acc, 0, 0, 0);
+        }
+        if (kh != KH - 1) return;
+        const int col = 16 * ct + r;
+        const float bv = (!BWD && a.b[lay]) ? a.b[lay][col] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int row = 4 * q + t, m = m0 + row;
+            float v = acc[t] * a.c + bv;
+            if (!BWD) {
+                v = v > 0.f ? v : v * a.slope;
+                if (m < M) a.acts[((long)lay * M + m) * C + col] = v;
+            } else if (lay > 0) {                   // gradient w.r.t. layer lay-1's output -> w.r.t. its pre-activation
+                const float y = m < M ? a.acts_in[((long)(lay - 1) * M + m) * C + col] : 0.f;
+                v = y > 0.f ? v : v * a.slope;
+                if (m < M) a.dz[((long)(lay - 1) * M + m) * C + col] = v;
+            } else if (m < M) {
+                a.dx[(long)m * C + col] = v;
+            }
+            xs[cur ^ 1][row][col] = v;
+        }
+    };
+
+    const int total = L * UPL;
+    f32x4 bA[16], bB[16];
+    load_unit(0, bA);
+    for (int u = 0; u < total; u += 2) {
+        load_unit(u + 1, bB);
+        compute_unit(u, bA);
+        if (u + 2 < total) load_unit(u + 2, bA);    // the next layer's first slice is on its way before the barrier below
+        compute_unit(u + 1, bB);
+        if ((u + 2) % UPL == 0) {                   // layer done (uniform: every wave has UPL units per layer)
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+}
+
+// dW[l][n][k] += c * sum_m dz[l][m][n] * in_l[m][k],  db[l][n] += sum_m dz[l][m][n]  for ALL layers in one launch
+// (in_0 = the chain's input, in_l = acts[l-1]).  M <= a few dozen rows: a thread owns four k of one n.
+struct MlpWgradArgs {
+    float* dw[MLP_MAX_LAYERS];
+    float* db[MLP_MAX_LAYERS];
+    const float* x;
+    const float* acts;
+    const float* dz;
+    int L, M;
+    float c;
+};
+template <int C>
+__global__ __launch_bounds__(256) void mlp_wgrad_kernel(MlpWgradArgs a) {
+    const int lay = blockIdx.y, M = a.M;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), kq = threadIdx.x & 63;
+    const float* in = lay == 0 ? a.x : a.acts + (long)(lay - 1) * M * C;
+    const float* dz = a.dz + (long)lay * M * C + n;
+    float* dw = a.dw[lay];
+    if (!dw) return;
+    float bsum = 0.f;
+    for (int kk = kq * 4; kk < C; kk += 256) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        bsum = 0.f;
+        for (int m = 0; m < M; ++m) {
+            const float g = dz[(long)m * C];
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(in + (long)m * C + kk);
+            s += g * xv;
+            bsum += g;
+        }
+        f32x4* o = reinterpret_cast<f32x4*>(dw + (long)n * C + kk);
+        *o = *o + a.c * s;
+    }
+    if (kq == 0 && a.db[lay]) a.db[lay][n] += bsum;
+}
+}  // namespace
+
+extern "C" int rgbd_mlp_fwd(const float* x, const float* const* w_host, const float* const* b_host, int L, int M, int C,
+                            float c, float slope, float* acts, void* stream) {
+    RGBD_REQUIRE(x && w_host && acts, "rgbd_mlp_fwd: null pointer");
+    RGBD_REQUIRE(L > 0 && L <= MLP_MAX_LAYERS && M > 0 && (C == 256 || C == 512),
+                 "rgbd_mlp_fwd: needs 1 <= L <= %d layers of C = 256 or 512 (L=%d C=%d)", MLP_MAX_LAYERS, L, C);
+    MlpArgs a{};
+    for (int l = 0; l < L; ++l) {
+        RGBD_REQUIRE(w_host[l], "rgbd_mlp_fwd: null weight pointer");
+        a.w[l] = w_host[l];
+        a.b[l] = b_host ? b_host[l] : nullptr;
+    }
+    a.x = x; a.acts = acts; a.L = L; a.M = M; a.c = c; a.slope = slope;
+    const unsigned grid = (unsigned)((M + 15) / 16);
+    if (C == 256) mlp_chain_kernel<256, false><<<grid, 512, 0, (hipStream_t)stream>>>(a);
+    else          mlp_chain_kernel<512, false><<<grid, 512, 0, (hipStream_t)stream>>>(a);
+    RGBD_CHECK_LAUNCH("mlp_chain_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_mlp_bwd(const float* dy, const float* x, const float* acts, const float* const* w_host,
+                            float* const* dw_host, float* const* db_host, int L, int M, int C, float c, float slope,
+                            float* dz, float* dx, void* stream) {
+    RGBD_REQUIRE(dy && x && acts && w_host && dz && dx, "rgbd_mlp_bwd: null pointer");
+    RGBD_REQUIRE(L > 0 && L <= MLP_MAX_LAYERS && M > 0 && (C == 256 || C == 512),
+                 "rgbd_mlp_bwd: needs 1 <= L <= %d layers of C = 256 or 512 (L=%d C=%d)", MLP_MAX_LAYERS, L, C);
+    hipStream_t st = (hipStream_t)stream;
+    MlpArgs a{};
+    for (int l = 0; l < L; ++l) {
+        RGBD_REQUIRE(w_host[l], "rgbd_mlp_bwd: null weight pointer");
+        a.w[l] = w_host[l];
+    }
+    a.x = dy; a.acts_in = acts; a.dz = dz; a.dx = dx; a.L = L; a.M = M; a.c = c; a.slope = slope;
+    const unsigned grid = (unsigned)((M + 15) / 16);
+    if (C == 256) mlp_chain_kernel<256, true><<<grid, 512, 0, st>>>(a);
+    else          mlp_chain_kernel<512, true><<<grid, 512, 0, st>>>(a);
+    RGBD_CHECK_LAUNCH("mlp_chain_kernel");
+    if (dw_host) {
+        MlpWgradArgs g{};
+        for (int l = 0; l < L; ++l) {
+            g.dw[l] = dw_host[l];
+            g.db[l] = db_host ? db_host[l] : nullptr;
+        }
+        g.x = x; g.acts = acts; g.dz = dz; g.L = L; g.M = M; g.c = c;
+        if (C == 256) mlp_wgrad_kernel<256><<<dim3(C / 4, L), 256, 0, st>>>(g);
+        else          mlp_wgrad_kernel<512><<<dim3(C / 4, L), 256, 0, st>>>(g);
+        RGBD_CHECK_LAUNCH("mlp_wgrad_kernel");
+    }
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------- small pointwise ops
 namespace {
 __global__ __launch_bounds__(256) void pixelnorm_kernel(const float* __restrict__ x, const float* __restrict__ dy,

@@ -47,6 +47,48 @@ def conv_dtype():
     return "mxfp8" if _MXFP8 else "bf16"
 
 
+MX8_COVERAGES = ("all", "fprop_only", "dis_only", "gen_only", "gen_fprop_only", "gen_skip_last2", "gen_fprop_only+skip_last2")
+
+
+def apply_mx8_coverage(generator, discriminator, spec):
+    """Which 3x3 launches `conv_dtype: mxfp8` covers (YAML key `mxfp8_coverage`; profiles/r06/soak_fp8_ablation.txt is why
+    there is a choice):
+        all               every eligible fprop and dgrad launch of both networks
+        fprop_only        forward launches only; every input-gradient launch on bf16 operands (no E4M3 dy anywhere)
+        dis_only / gen_only     one network on fp8, the other on bf16
+        gen_fprop_only    D as `all`; the generator's forward on fp8, its backward (dy chain towards the styles and the
+                          mapping network, the path the 3-D consistency loss trains) on bf16
+        gen_skip_last2    D as `all`; the generator's last two synthesis blocks (in front of the RGB / depth heads) on bf16
+        gen_fprop_only+skip_last2   both restrictions on the generator
+    Sets per-layer flags; the fp8 weight images are still built for every eligible layer (one launch)."""
+    if spec in (None, "", "all"):
+        spec = "all"
+    if spec not in MX8_COVERAGES:
+        raise ValueError(f"mxfp8_coverage must be one of {MX8_COVERAGES}, got {spec!r}")
+    gnet = getattr(generator, "gen", generator)
+    g_layers = [l for l in getattr(getattr(gnet, "pack_group", None), "layers", [])]
+    d_layers = [l for l in getattr(getattr(discriminator, "pack_group", None), "layers", [])]
+    for l in g_layers + d_layers:
+        l.mx_fprop = l.mx_dgrad = True
+    if spec == "fprop_only":
+        for l in g_layers + d_layers:
+            l.mx_dgrad = False
+    if spec == "dis_only":
+        for l in g_layers:
+            l.mx_fprop = l.mx_dgrad = False
+    if spec == "gen_only":
+        for l in d_layers:
+            l.mx_fprop = l.mx_dgrad = False
+    if spec in ("gen_fprop_only", "gen_fprop_only+skip_last2"):
+        for l in g_layers:
+            l.mx_dgrad = False
+    if spec in ("gen_skip_last2", "gen_fprop_only+skip_last2"):
+        c0, c1 = getattr(gnet, "c0", []), getattr(gnet, "c1", [])
+        for l in [x for x in list(c0[-2:]) + list(c1[-2:]) if x is not None]:
+            l.mx_fprop = l.mx_dgrad = False
+    return spec
+
+
 def bump_weight_epoch(flat=None):
     """Master weights changed: everywhere (flat=None), or in the one flat parameter buffer `flat`."""
     global _WEIGHT_EPOCH
@@ -152,8 +194,10 @@ class ConvLayer:
                         self._mxd = kernels.Mx8Image(self._wd, *d) if d is not None else None
                 self._epoch = self._now()
         if _MXFP8:
-            return self._mxf or self._wf, self._mxd or self._wd
+            return (self._mxf if self.mx_fprop else None) or self._wf, (self._mxd if self.mx_dgrad else None) or self._wd
         return self._wf, self._wd
+
+    mx_fprop = mx_dgrad = True    # conv_dtype mxfp8: may THIS layer's fprop / dgrad launches take fp8 operands (apply_mx8_coverage)
 
 
 class PackGroup:
@@ -1136,6 +1180,54 @@ class _LinearAct(torch.autograd.Function):
 def linear_act(x, w, bias, c, act=True):
     """Equalized-LR linear (pggan.py:39-50) + optional leaky ReLU on a small batch of rows, one HIP launch."""
     return _LinearAct.apply(x, w, bias, float(c), bool(act))
+
+
+class _MlpChain(torch.autograd.Function):
+    """h <- lrelu(c * h W_l^T + b_l) for l = 0..L-1 as ONE launch forward and two backward (kernels.mlp_fwd / mlp_bwd): the
+    mapping network (net.py:58-62).  First-order only (generator side); weight and bias gradients are accumulated straight
+    into the flat gradient buffer when one is bound, like _LinearAct's."""
+
+    @staticmethod
+    def forward(ctx, x, c, *params):
+        L = len(params) // 2
+        ws, bs = [p.detach() for p in params[:L]], [p.detach() for p in params[L:]]
+        x = x.contiguous()
+        acts = kernels.mlp_fwd(x, ws, bs, c)
+        ctx.c, ctx.L = c, L
+        ctx.save_for_backward(x, acts, *params)
+        return acts[L - 1]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, acts = ctx.saved_tensors[:2]
+        params = ctx.saved_tensors[2:]
+        L = ctx.L
+        ws, bs = list(params[:L]), list(params[L:])
+        need = [ctx.needs_input_grad[2 + i] and not _skip_grad_of(params[i]) for i in range(2 * L)]
+        direct = all(_direct_grad(p) for p, n in zip(params, need) if n)
+        if direct:
+            dws = [w.grad if n else None for w, n in zip(ws, need[:L])]
+            dbs = [b.grad if n else None for b, n in zip(bs, need[L:])]
+        else:
+            dws = [torch.zeros_like(w) if n else None for w, n in zip(ws, need[:L])]
+            dbs = [torch.zeros_like(b) if n else None for b, n in zip(bs, need[L:])]
+        any_w = any(t is not None for t in dws + dbs)
+        dx = kernels.mlp_bwd(dy.contiguous(), x, acts, [w.detach() for w in ws], ctx.c, dws if any_w else None,
+                             dbs if any_w else None)
+        grads = (None,) * (2 * L) if direct else tuple(dws + dbs)
+        return (dx if ctx.needs_input_grad[0] else None, None) + grads
+
+
+def mlp_chain(x, weights, biases, c):
+    """The mapping network's eight layers (net.py:58-62) as one fused chain; falls back to one launch per layer for shapes the
+    fused kernel does not cover (C other than 256 / 512)."""
+    if kernels.mlp_supported(x.shape[0], x.shape[1], len(weights)) and all(w.shape == (x.shape[1], x.shape[1]) for w in weights):
+        return _MlpChain.apply(x, float(c), *weights, *biases)
+    h = x
+    for w, b in zip(weights, biases):
+        h = linear_act(h, w, b, c, act=True)
+    return h
 
 
 class _Dense(torch.autograd.Function):

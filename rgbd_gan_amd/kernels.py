@@ -930,6 +930,49 @@ def linear_fwd(x, w, bias, c, act, slope=0.2):
     return y
 
 
+def _ptr_array(tensors):
+    """HOST array of device pointers (NULL for None) for the entry points that take `const float* const*`."""
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr() if t is not None else None
+    return arr
+
+
+def mlp_supported(M, C, L):
+    return C in (256, 512) and 1 <= L <= 8 and M >= 1
+
+
+def mlp_fwd(x, ws, bs, c, slope=0.2):
+    """The chain  h <- lrelu(c * h W_l^T + b_l), l = 0..L-1  (mapping network, net.py:58-62) in ONE launch.
+    x (M,C) fp32, ws L x (C,C), bs L x (C) -> acts (L,M,C): every layer's output (acts[-1] is the result)."""
+    _chk(x, F32, "x")
+    for t in list(ws) + list(bs):
+        _chk(t, F32, "mlp parameter")
+    M, C = x.shape
+    L = len(ws)
+    acts = torch.empty(L, M, C, dtype=F32, device=x.device)
+    rc = _lib.load().rgbd_mlp_fwd(_ptr(x), _ptr_array(ws), _ptr_array(bs), L, M, C, float(c), float(slope), _ptr(acts),
+                                  _stream())
+    _lib.check(rc, "rgbd_mlp_fwd")
+    return acts
+
+
+def mlp_bwd(dy, x, acts, ws, c, dws=None, dbs=None, slope=0.2):
+    """Backward of mlp_fwd in two launches: the dgrad chain (-> dx) and ONE weight / bias gradient launch for all layers, which
+    ACCUMULATES into dws[l] (C,C) / dbs[l] (C) (None entries are skipped; dws None: no second launch)."""
+    _chk(dy, F32, "dy"); _chk(x, F32, "x"); _chk(acts, F32, "acts")
+    L, M, C = acts.shape
+    dz = torch.empty_like(acts)
+    dx = torch.empty(M, C, dtype=F32, device=dy.device)
+    for t in (dws or []) + (dbs or []):
+        _chk(t, F32, "mlp gradient")
+    rc = _lib.load().rgbd_mlp_bwd(_ptr(dy), _ptr(x), _ptr(acts), _ptr_array(ws), _ptr_array(dws) if dws else None,
+                                  _ptr_array(dbs) if dbs else None, L, M, C, float(c), float(slope), _ptr(dz), _ptr(dx),
+                                  _stream())
+    _lib.check(rc, "rgbd_mlp_bwd")
+    return dx
+
+
 def linear_fwd_masked(x, w, mask_y, c, slope=0.2):
     """(c * x w^T) * lrelu'(mask_y): x (M,K), w (N,K), mask_y (M,N) an activation OUTPUT -> (M,N)."""
     _chk(x, F32, "x"); _chk(w, F32, "w"); _chk(mask_y, F32, "mask_y")

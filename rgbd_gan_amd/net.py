@@ -131,8 +131,8 @@ class _Link:
 
 # ---------------------------------------------------------------------------------------------- StyleGAN
 class MappingNetwork(_Link):
-    """net.py:22-62: pixel-norm then 8 x (equalized linear, leaky ReLU).  Tiny GEMMs (M=B, N=K=ch): fp32 library
-    kernel per layer (rgbd_linear_fwd); launch-latency bound, not a roofline kernel."""
+    """net.py:22-62: pixel-norm then 8 x (equalized linear, leaky ReLU).  Tiny fp32 GEMMs (M = 2B rows, N = K = ch) in a
+    dependent chain: one fused launch per pass (rgbd_mlp_fwd / rgbd_mlp_bwd; per-layer rgbd_linear_* for other widths)."""
 
     def __init__(self, ch, device, seed=0):
         self.ch = ch
@@ -146,9 +146,9 @@ class MappingNetwork(_Link):
     def __call__(self, z):
         h = Fn.pixel_norm(z.reshape(z.shape[0], -1))
         p = self.store.params
-        for i in range(0, 16, 2):
-            h = Fn.linear_act(h, p[f"l/{i}/c/W"], p[f"l/{i}/c/b"], self.inv_c, act=True)
-        return h
+        # the eight layers as one launch per pass (rgbd_mlp_fwd / rgbd_mlp_bwd) instead of 8 forward + 16 backward ones
+        return Fn.mlp_chain(h, [p[f"l/{i}/c/W"] for i in range(0, 16, 2)], [p[f"l/{i}/c/b"] for i in range(0, 16, 2)],
+                            self.inv_c)
 
     forward = __call__
 
@@ -318,6 +318,7 @@ class StyleGANGenerator(_Link):
         assert not rotate_conv_input and not use_encoder and not use_occupancy_net, "unsupported generator option"
         assert ch % 256 == 0, "the MFMA conv engine needs ch/4 to be a multiple of 64"
         self.ch = ch
+        self.seed = int(seed)
         self.device = torch.device(device)
         self.mapping = MappingNetwork(ch, device, seed)
         self.gen = StyleGenerator(ch, device, rgbd, 1.0 if initial_depth is None else initial_depth, seed + 1,
@@ -342,17 +343,15 @@ class StyleGANGenerator(_Link):
         from . import kernels
         return kernels.hidden_draw(self._latent_rng(), half, self.ch * 2, self.ch, copies=2).reshape(2 * half, self.ch * 2, 1, 1)
 
-    _latent_streams = 0         # latent streams created in this process so far (class-wide)
-
     def _latent_rng(self):
         """This generator's latent stream (kernels.new_hidden_rng_state), seeded at the first draw from torch's seed and the
-        stream's ordinal in the process: a model built after torch.manual_seed(s) draws the same sequence every run, and two
-        generator objects (gen / smoothed_gen) never share one."""
+        generator's own construction seed (its role: 0 for the trained generator, 1000 for the smoothed one, training.py): a
+        model built after torch.manual_seed(s) draws the same sequence every time, in every process, and gen / smoothed_gen
+        never share a stream."""
         from . import kernels
         if getattr(self, "_rng_state", None) is None:
-            k = StyleGANGenerator._latent_streams
-            StyleGANGenerator._latent_streams = k + 1
-            self._rng_state = kernels.new_hidden_rng_state(self.device, seed=torch.initial_seed() + 0x9E3779B97F4A7C15 * k)
+            self._rng_state = kernels.new_hidden_rng_state(
+                self.device, seed=torch.initial_seed() + 0x9E3779B97F4A7C15 * int(getattr(self, "seed", 0)))
         return self._rng_state
 
     def __call__(self, z, stage, theta=None, return_feature=False):

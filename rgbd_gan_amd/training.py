@@ -200,6 +200,7 @@ def build_training(config, device, comm=None, iterator=None, updater_class=None,
     Fn.set_conv_dtype(config.conv_dtype or "bf16")
     generator = setup_generator(config, device)
     discriminator = setup_discriminator(config, device)
+    Fn.apply_mx8_coverage(generator, discriminator, config.mxfp8_coverage)
     optimizer = make_optimizers(config, generator, discriminator, comm)
     # the persistent weight images (and, with conv_dtype mxfp8, their fp8 twins and descriptor tables: allocations and a
     # host-to-device copy) exist before the first step -- a first build inside a HIP-graph capture (graph_warmup = 0, or the

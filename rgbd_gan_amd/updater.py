@@ -1002,12 +1002,17 @@ class RGBDUpdater:
             st["opt_g_done"] = True
             main.wait_stream(side)
             self._run_phase("join", self._join_phase, st, key)
-        elif dp and self.dp_split_body:
-            self._run_phase("body_g", self._body_g_phase, st, key)
-            for opt in g_opts:              # ~29 MB of generator gradients travel while D's half of the step runs
-                self._note("allreduce", "gen")
-                opt.start_allreduce()
-            self._run_phase("body_d", self._body_d_phase, st, key)
+        elif dp:
+            cap = self._dp_budgets(st)[1]   # one stream: every persistent grid leaves dp_reserve_cus to the collectives
+            st["main_cus"] = st["side_wgrad_wgs"] = st["dfw_wgrad_wgs"] = cap
+            if self.dp_split_body:
+                self._run_phase("body_g", self._body_g_phase, st, key, cu_budget=cap)
+                for opt in g_opts:          # ~29 MB of generator gradients travel while D's half of the step runs
+                    self._note("allreduce", "gen")
+                    opt.start_allreduce()
+                self._run_phase("body_d", self._body_d_phase, st, key, cu_budget=cap)
+            else:
+                self._run_phase("body", self._body_phase, st, key, cu_budget=cap)
         else:
             self._run_phase("body", self._body_phase, st, key)
         if st.get("d_step_on_side"):
