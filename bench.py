@@ -59,8 +59,10 @@ def parse():
     ap.add_argument("--stage", type=float, default=None,
                     help="pin the progressive-growing stage (default: the schedule's stage at --iteration, 10 = 128x128 without "
                          "fade-in); 9.5 = the fade-in arrangement between 64x64 and 128x128 (two output heads, blended reals)")
-    ap.add_argument("--autotune", action="store_true", help="measure the side stream's workgroup counts at set-up (RGBDUpdater.autotune_side_budget) "
-                                                         "instead of taking the rule of thumb")
+    ap.add_argument("--autotune", action="store_true", help="(kept for old command lines: the measurement is the default now)")
+    ap.add_argument("--no-tune", action="store_true",
+                    help="take the rule of thumb for the side stream's workgroup counts instead of measuring them on this device "
+                         "before the warm-up (RGBDUpdater(tune_side_budget=True) + finish_tuning: ~120 ordinary steps)")
     ap.add_argument("--other-steps", type=int, default=30)
     ap.add_argument("--other-only", type=str, default="", help="comma list: run only these of the other configurations")
     ap.add_argument("--mx8-standalone-quantiser", action="store_true",
@@ -355,13 +357,16 @@ def run_workload(args, comm, device):
                                         nan_check_interval=0, **extra)
     upd.iteration = args.iteration
     tuning = None
-    if args.autotune and comm.size == 1 and hasattr(upd, "autotune_side_budget"):    # (N > 1: the rule of thumb -- the
-        # measurement's re-captures beside RCCL have never run on more than one device; its step count is rank-independent)
-        # set-up, before the W warm-up and K timed steps: the side stream's weight-gradient workgroup count measured on this
-        # device at this shape (RGBDUpdater.autotune_side_budget: a fixed number of ordinary steps on every rank)
-        if upd.autotune_side_budget(log=(lambda m: print(m, file=sys.stderr, flush=True)) if comm.rank == 0 else None) is not None:
-            tuning = upd.side_budget_tuning      # (the landscape is flat near its optimum -- 144-192 within 1 % at the benched
-                                                 # shape -- and devices of the pool differ in where it lies)
+    if not args.no_tune and not comm.active and getattr(upd, "concurrent_phases", False) and hasattr(upd, "finish_tuning") \
+            and not deepvoxels:
+        # set-up, before the W warm-up and K timed steps: the side stream's weight-gradient workgroup counts measured on this
+        # device at this shape, as the training CLI does in its first ~120 iterations at every new image size (SideBudgetTuner:
+        # ordinary training steps).  (N > 1: the rule of thumb + the data-parallel lead -- the re-captures beside RCCL have never
+        # run on more than one device.)
+        upd.tune_side_budget = True
+        upd.finish_tuning()
+        tuning = getattr(upd, "side_budget_tuning", None)
+        upd.tune_side_budget = False
         upd.iteration = args.iteration
 
     def sync():
@@ -390,10 +395,12 @@ def run_workload(args, comm, device):
     # host cost of enqueueing a step, measured on a short burst right after a sync: over the long timed loop the launch
     # thread runs into the back-pressure of the bounded HIP queues, so its wall time per step converges to the GPU's
     # step time whatever the host really costs
-    burst = 3
+    burst, burst_each = 3, []
     t1 = time.perf_counter()
     for _ in range(burst):
+        t2 = time.perf_counter()
         upd.update()
+        burst_each.append(time.perf_counter() - t2)
     t_burst = time.perf_counter() - t1
     sync()
 
@@ -425,9 +432,12 @@ def run_workload(args, comm, device):
                                            if hasattr(upd, "_side_wgrad_pair") and getattr(upd, "side_wgrad_workgroups", 0) is None else
                                            getattr(upd, "side_wgrad_workgroups", None), "measured": tuning}
                                           if getattr(upd, "concurrent_phases", False) else None)},
-        "host_enqueue_ms_per_step": round(t_burst / burst * 1e3, 3),
-        "host_enqueue_note": f"wall time of the launch thread per step over a {burst}-step burst after a sync (no queue "
-                             f"back-pressure); over the timed loop it was {t_enqueue / args.steps * 1e3:.3f} ms",
+        "host_enqueue_ms_per_step": round(min(burst_each) * 1e3, 3),
+        "host_enqueue_burst_ms": [round(t * 1e3, 3) for t in burst_each],
+        "host_enqueue_note": f"wall time of the launch thread for one step: the fastest of a {burst}-step burst after a sync (the "
+                             f"first step of a burst meets empty queues; a later one can already wait for a free slot in a "
+                             f"bounded hardware queue when a step is long -- its time then is the GPU's, not the host's); burst mean "
+                             f"{t_burst / burst * 1e3:.3f} ms; over the timed loop {t_enqueue / args.steps * 1e3:.3f} ms",
     }
     if deepvoxels:
         line["metric"] = "img/s (G+D+3D-loss step) at 64x64, DeepVoxels generator"
@@ -619,7 +629,7 @@ def main():
                 Fn.set_conv_dtype("bf16")
             l2.pop("_deepvoxels")
             keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline", "roofline_fp8",
-                    "host_enqueue_ms_per_step")
+                    "host_enqueue_ms_per_step", "host_enqueue_burst_ms")
             line["other_configs"][name] = {k: l2[k] for k in keep if k in l2}
             line["other_configs"][name]["command"] = "python bench.py " + " ".join(
                 (f"--{k.replace('_', '-')}" if v is True else f"--{k.replace('_', '-')} {os.path.relpath(v, ROOT) if k == 'config' else v}")

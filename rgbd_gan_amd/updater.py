@@ -241,6 +241,16 @@ class RGBDUpdater:
         #     generator's 29 MB are exposed); the side stream's weight-gradient launches get this many workgroups more than the
         #     one-GPU rule gives them, so that the side stream ends earlier than the main one instead of together with it.
         # Neither could be measured (one GPU per lease: a one-rank RCCL group moves nothing); both are arguments.
+        # tune_side_budget: measure the side stream's two weight-gradient workgroup counts on THIS device for every (batch, image
+        # size) the run meets, inside the ordinary training steps (SideBudgetTuner below), instead of trusting the rule of thumb --
+        # the rule was fitted on three shapes and misses a shape it was not fitted on by up to 20 % (stage 8, B = 32:
+        # profiles/r06/cu_budget_sweep.txt).  Default: on for a one-GPU run that replays graphs on two streams; off under data
+        # parallelism (the re-captures beside RCCL have never run on more than one device) and with explicit counts.
+        # train_rgbd.py and bench.py switch it on for one-GPU runs (RGBD_TUNE_SIDE_BUDGET=0 keeps the rule); a bare
+        # RGBDUpdater(...) takes the rule.
+        env = os.environ.get("RGBD_TUNE_SIDE_BUDGET")
+        self.tune_side_budget = bool(kwargs.pop("tune_side_budget", False)) and env not in ("", "0")
+        self._tuner = None
         self.dp_reserve_cus = int(kwargs.pop("dp_reserve_cus", os.environ.get("RGBD_DP_RESERVE_CUS", "16")))
         self.dp_side_lead_workgroups = int(kwargs.pop("dp_side_lead_workgroups", os.environ.get("RGBD_DP_SIDE_LEAD_WGS", "32")))
         if kwargs:
@@ -287,8 +297,30 @@ class RGBDUpdater:
         return self.gen.make_hidden(batch_size)
 
     def update(self):
+        tuner = self._tuner
+        if tuner is not None:
+            tuner.before_step()
         self.update_core()
         self.iteration += 1
+        if self._tuner is not None:
+            if self._tuner.after_step():
+                self._tuner = None
+
+    @property
+    def tuning_in_progress(self):
+        return self._tuner is not None
+
+    def finish_tuning(self, max_steps=400):
+        """Run ordinary training steps until the side-budget measurement of the current shape has finished (bench.py: before
+        anything is timed).  -> number of steps taken."""
+        n = 0
+        if self.tune_side_budget and self._tuner is None and n < max_steps:
+            self.update()                       # a first step makes the shape known (and starts the tuner if one is due)
+            n += 1
+        while self._tuner is not None and n < max_steps:
+            self.update()
+            n += 1
+        return n
 
     NAN_KEYS = ("gen/loss_adv", "gen/loss_rotate", "dis/loss_adv")       # updater.py:336,360,439
 
@@ -571,6 +603,8 @@ class RGBDUpdater:
     def _opt_d_phase(self, st):
         self._optimizers["dis"].update(bump=not st.get("d_step_on_side"))
 
+    tune_side_budget = False    # class defaults shared with DeepVoxelsUpdater (its own __init__)
+    _tuner = None
     timeline = None             # set to a dict: update_core leaves timing events of its last step there (tests, scripts)
     call_log = None             # set to a list: update_core appends (what, name, current stream handle) in HOST ORDER as it
                                 # launches phases and starts all-reduces (tests pin the order; no timing involved)
@@ -613,11 +647,11 @@ class RGBDUpdater:
         return bool(self.use_graphs and self._graphs)
 
     def _side_wgrad_auto(self, st):
-        """Workgroups of the side stream's batched weight-gradient launches: 5/8 of the compute units at B x H x W = 32 x 128^2,
-        towards all of them for larger steps and a quarter for smaller ones (measured optima: 144-160 / 224 / 64-128 of 256 at
-        32 x 128^2 / 16 x 256^2 / 8 x 128^2; profiles/r05/cu_budget_sweep.txt), in multiples of 8 (one per XCD) -- unless
-        autotune_side_budget has MEASURED this shape on this device (devices of the pool differ by several percent in how
-        the two streams' work compares)."""
+        """Workgroups of the side stream's batched weight-gradient launches when nothing has been MEASURED for this shape on this
+        device (SideBudgetTuner / autotune_side_budget): a line through the measured optima of five shapes, 112 + pixels / 10240 of
+        256 compute units in multiples of 8 (one per XCD) -- 128 / 136 / 160 / 216 at 32 x 64^2 / 16 x 128^2 / 32 x 128^2 / 16 x 256^2,
+        where 128-144 / 144 / 144-176 / 208-224 were fastest (profiles/r06/cu_budget_sweep.txt; round 5's three-point curve gave
+        64 at the first two and lost 20 % / 5 % there).  A prior, not a model: the measurement is the default (tune_side_budget)."""
         return self._side_wgrad_pair(st)[0]
 
     def _side_wgrad_pair(self, st):
@@ -628,8 +662,7 @@ class RGBDUpdater:
             return tuned
         cus = torch.cuda.get_device_properties(self.device).multi_processor_count if torch.cuda.is_available() else 256
         px = float(shape[0]) * float(shape[1]) * float(shape[2])
-        frac = min(1.0, max(0.25, 1.0 - 0.375 * (32.0 * 128.0 * 128.0) / px))
-        w = max(8, int(round(cus * frac / 8.0)) * 8)
+        w = min(cus, max(64, int(round((0.4375 * cus + px / 10240.0 * cus / 256.0) / 8.0)) * 8))
         return w, self._dfw_rule(w, cus)
 
     @staticmethod
@@ -647,6 +680,7 @@ class RGBDUpdater:
         import time
         if not (self.concurrent_phases and self.use_graphs and self.side_wgrad_workgroups is None and torch.cuda.is_available()):
             return None
+        self.tune_side_budget, self._tuner = False, None         # this IS the measurement: the in-loop one stays out of its way
         for _ in range(self.graph_warmup + 1):                 # the shape's graphs exist, _last_shape is known
             self.update()
         shape = self._last_shape
@@ -966,6 +1000,9 @@ class RGBDUpdater:
                 side_cus, main_cus = self._dp_budgets(st)
             st["main_cus"] = main_cus
             self._last_shape = (int(st["B"]), int(st["x_real"].shape[2]), int(st["x_real"].shape[3]))
+            if (self.tune_side_budget and self._tuner is None and key is not None and not dp and self.side_wgrad_workgroups is None
+                    and self.dfw_wgrad_workgroups is None and self._last_shape not in getattr(self, "_side_wgrad_tuned", {})):
+                self._tuner = SideBudgetTuner(self, self._last_shape)        # measures from the NEXT step on
             self._run_phase("dis", self._dis_phase, st, key, stream=side,         # D on the reals, R1, its weight gradients
                             cu_budget=side_cus)
             self._run_phase("gen_a", self._gen_a_phase, st, key, cu_budget=main_cus)   # G forward, the one pass through D(x_fake)
@@ -1038,6 +1075,90 @@ class RGBDUpdater:
         obs = self.observation
         obs["stage"], obs["batch_size"], obs["image_size"] = stage, batch_size, int(st["x_real"].shape[2])
         self._end_of_step_checks()
+
+
+class SideBudgetTuner:
+    """The set-up measurement of RGBDUpdater.autotune_side_budget spread over ORDINARY training steps: the caller's loop keeps
+    calling update() (its log / preview / snapshot triggers fire as always, `iteration` advances as always) and the tuner, from
+    inside update(), walks a fixed plan of candidate (dis, dfw) workgroup pairs for ONE (batch, image size): per candidate the
+    step's graphs are re-captured with the pair baked in (graph_warmup eager steps + the capturing one), then `measure` replayed
+    steps are timed between two device synchronisations.  Plan: the rule's pair and -32 / +32 / +64 for the first launch (the second
+    at its rule), best -16 / +16, then two more for the second launch (same as the first; the whole chip): 8 candidates x
+    (graph_warmup + 1 + measure) steps = 120 by default, 1-4 s.  The fastest pair is kept for the shape
+    (RGBDUpdater._side_wgrad_tuned) and the run goes on with it.  A stage change in the middle (another image size) drops the
+    half-finished measurement -- the new shape gets a tuner of its own, the old one its rule until it comes up again."""
+
+    def __init__(self, upd, shape, measure=12):
+        self.upd, self.shape, self.measure = upd, shape, int(measure)
+        self.cus = torch.cuda.get_device_properties(upd.device).multi_processor_count
+        upd._side_wgrad_tuned = getattr(upd, "_side_wgrad_tuned", {})
+        self.rule = upd._side_wgrad_pair({"B": shape[0], "x_real": torch.empty(0, 0, shape[1], shape[2])})
+        self.results, self.queue, self.round = {}, [], 0
+        self.cand, self.c, self.t0 = None, 0, None
+        self._next_round()
+
+    def _clamp(self, w):
+        return int(min(self.cus, max(32, w)))
+
+    def _next_round(self):
+        """-> False when the plan is exhausted."""
+        up, cus = self.upd, self.cus
+        best = min(self.results, key=self.results.get) if self.results else None
+        if self.round == 0:
+            ws = [self._clamp(self.rule[0] + d) for d in (0, -32, 32, 64)]
+            self.queue = [(w, up._dfw_rule(w, cus)) for w in ws]
+        elif self.round == 1:
+            self.queue = [(w, up._dfw_rule(w, cus)) for w in (self._clamp(best[0] - 16), self._clamp(best[0] + 16))]
+        elif self.round == 2:
+            self.queue = [(best[0], best[0]), (best[0], cus)]
+        else:
+            return False
+        self.round += 1
+        self.queue = [p for i, p in enumerate(self.queue) if p not in self.results and p not in self.queue[:i]]
+        return True if self.queue else self._next_round()
+
+    def _install(self, pair):
+        up = self.upd
+        up._side_wgrad_tuned[self.shape] = pair
+        up._graphs.clear()                  # every phase is re-captured (the side phases bake the counts in)
+        up._eager_calls.clear()
+
+    def before_step(self):
+        up = self.upd
+        if getattr(up, "_last_shape", self.shape) != self.shape:
+            return
+        if self.cand is None:
+            self.cand, self.c = self.queue.pop(0), 0
+            self._install(self.cand)
+        if self.c == up.graph_warmup + 1:   # every phase has been captured: the timed replays start here
+            torch.cuda.synchronize(up.device)
+            import time
+            self.t0 = time.perf_counter()
+
+    def after_step(self):
+        """-> True when this tuner is finished (measured, or abandoned because the shape changed)."""
+        up = self.upd
+        if self.cand is None:               # created during this very step: the plan starts with the next one
+            return False
+        if getattr(up, "_last_shape", self.shape) != self.shape or not up.graphs_in_use and self.c > up.graph_warmup:
+            up._side_wgrad_tuned.pop(self.shape, None)      # back to the rule; nothing half-measured is kept
+            up._graphs.clear()
+            up._eager_calls.clear()
+            return True
+        self.c += 1
+        if self.c < up.graph_warmup + 1 + self.measure:
+            return False
+        import time
+        torch.cuda.synchronize(up.device)
+        self.results[self.cand] = (time.perf_counter() - self.t0) / self.measure
+        self.cand = None
+        if self.queue or self._next_round():
+            return False
+        best = min(self.results, key=self.results.get)
+        self._install(best)
+        up.side_budget_tuning = {"shape": self.shape, "rule": tuple(self.rule), "chosen": best,
+                                 "ms_per_step": {f"{k[0]}/{k[1]}": round(1e3 * v, 4) for k, v in sorted(self.results.items())}}
+        return True
 
 
 class RGBUpdater(RGBDUpdater):

@@ -27,28 +27,7 @@ sys.path.insert(0, ROOT)
 KEYS = ("gen/loss_rotate", "gen/loss_adv", "dis/loss_adv", "dis/loss_gp", "|g| gen", "|g| dis", "|g| map")
 
 
-def procedural_images(n, side, seed=0):
-    """(n,3,side,side) uint8: one shaded ellipsoid per image on a vertical two-colour gradient."""
-    import numpy as np
-    rng = np.random.RandomState(seed)
-    yy, xx = np.mgrid[0:side, 0:side].astype("float32") / (side - 1) * 2 - 1
-    out = np.empty((n, 3, side, side), dtype="uint8")
-    for i in range(n):
-        top, bot = rng.uniform(0.2, 1.0, 3), rng.uniform(0.0, 0.6, 3)
-        t = ((yy + 1) / 2)[None]
-        img = top[:, None, None] * (1 - t) + bot[:, None, None] * t
-        cx, cy = rng.uniform(-0.3, 0.3, 2)
-        a, b = rng.uniform(0.35, 0.7), rng.uniform(0.2, 0.45)
-        th = rng.uniform(-0.5, 0.5)
-        xr = (xx - cx) * np.cos(th) + (yy - cy) * np.sin(th)
-        yr = -(xx - cx) * np.sin(th) + (yy - cy) * np.cos(th)
-        r2 = (xr / a) ** 2 + (yr / b) ** 2
-        inside = r2 < 1
-        shade = np.sqrt(np.clip(1 - r2, 0, 1)) * 0.8 + 0.2             # a lit ellipsoid: brightness ~ surface height
-        col = rng.uniform(0.1, 1.0, 3)
-        img = np.where(inside[None], col[:, None, None] * shade[None], img)
-        out[i] = np.clip(img * 255 + rng.normal(0, 2.0, img.shape), 0, 255).astype("uint8")
-    return out
+from rgbd_gan_amd.utils.synthetic import procedural_images   # noqa: E402
 
 
 def child(args):

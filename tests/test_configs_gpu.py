@@ -150,16 +150,65 @@ def test_side_budget_autotune_measures_a_fixed_number_of_steps_and_keeps_the_ste
     steps = upd.iteration - it0
     assert steps == (upd.graph_warmup + 1) + 8 * (2 + 2), steps
     tune = upd.side_budget_tuning
-    assert tune["shape"] == (8, 64, 64) and tune["rule"] == (64, 160) and best == tune["chosen"]
+    assert tune["shape"] == (8, 64, 64) and tune["rule"] == (112, 184) and best == tune["chosen"]
     assert f"{best[0]}/{best[1]}" in tune["ms_per_step"] and len(tune["ms_per_step"]) >= 6
     assert upd._side_wgrad_pair({"B": 8, "x_real": torch.empty(8, 3, 64, 64)}) == best
-    assert upd._side_wgrad_pair({"B": 8, "x_real": torch.empty(8, 3, 128, 128)}) == (64, 160)   # another shape: the rule
+    assert upd._side_wgrad_pair({"B": 8, "x_real": torch.empty(8, 3, 128, 128)}) == (128, 192)  # another shape: the rule
     for _ in range(4):
         upd.update()                                            # re-captured with the chosen count, replayed
     assert any(k[-1] == "dis" for k in upd._graphs)
     assert all(np.isfinite(float(v)) for v in upd.observation.values())
     upd.side_wgrad_workgroups = 96                              # an explicit count: nothing to measure
     assert upd.autotune_side_budget() is None
+
+
+def test_side_budget_is_measured_inside_ordinary_training_steps():
+    """SideBudgetTuner (what train_rgbd.py and bench.py switch on for a one-GPU run): the same measurement spread over the
+    caller's own update() calls -- `iteration` advances by exactly one per call (the loop's log / preview / snapshot triggers see
+    every iteration), the plan is 8 candidates x (graph_warmup + 1 + measure) steps at most, the chosen pair is one of the
+    measured ones and is what the step is re-captured with; a stage change in the middle of a measurement drops it and the new
+    image size gets a measurement of its own."""
+    from rgbd_gan_amd.training import DeviceImageIterator, build_training
+    from rgbd_gan_amd.updater import SideBudgetTuner
+    from rgbd_gan_amd.utils import yaml_utils
+    cfg = yaml_utils.load(os.path.join(ROOT, "configs", "stylegan_shapenet_car.yml"))
+    images = np.random.RandomState(0).randint(0, 256, (32, 3, 128, 128)).astype("uint8")
+    np.random.seed(0)
+    torch.manual_seed(0)
+    it = DeviceImageIterator(images, 8, "cuda:0", seed=0)
+    gen, dis, opt, upd = build_training(cfg, "cuda:0", iterator=it, fixed_stage=8.0, nan_check_interval=1, tune_side_budget=True)
+    upd.iteration = 150000
+    if not (upd.concurrent_phases and upd.tune_side_budget):
+        pytest.skip("one-stream arrangement / rule of thumb selected by the environment")
+    it0 = upd.iteration
+    for _ in range(3):                                          # graph_warmup eager steps + the capture: the shape becomes known
+        upd.update()
+    assert upd.tuning_in_progress and isinstance(upd._tuner, SideBudgetTuner)
+    upd._tuner.measure = 2
+    upd.fixed_stage = 10.0                                      # ... and the stage changes under the measurement (64 -> 128 px)
+    upd.update()
+    assert not upd.tuning_in_progress and (8, 64, 64) not in upd._side_wgrad_tuned
+    upd.update()                                                # eager steps of the new configuration
+    upd.update()
+    upd.update()                                                # its capture: a tuner for 8 x 128 x 128
+    assert upd.tuning_in_progress and upd._tuner.shape == (8, 128, 128)
+    upd._tuner.measure = 2
+    n = 0
+    while upd.tuning_in_progress:
+        upd.update()
+        n += 1
+        assert n <= 8 * (upd.graph_warmup + 1 + 2)
+    assert upd.iteration - it0 == 7 + n                         # one iteration per update(), nothing hidden
+    tune = upd.side_budget_tuning
+    best = tune["chosen"]
+    assert tune["shape"] == (8, 128, 128) and tune["rule"] == (128, 192) and len(tune["ms_per_step"]) >= 6
+    assert f"{best[0]}/{best[1]}" in tune["ms_per_step"]
+    assert upd._side_wgrad_pair({"B": 8, "x_real": torch.empty(8, 3, 128, 128)}) == best
+    for _ in range(4):
+        upd.update()                                            # re-captured with the chosen pair, replayed; no new tuner
+    assert not upd.tuning_in_progress and upd.graphs_in_use
+    assert all(np.isfinite(float(v)) for v in upd.observation.values())
+    assert int(opt["gen"].t) == upd.iteration - it0
 
 
 def test_a_diverging_run_stops_within_two_steps_without_a_per_step_sync():

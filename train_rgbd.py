@@ -111,17 +111,21 @@ def main():
         if updater.smoothed_gen is not None:
             previews.append(PreviewSampler(updater.smoothed_gen, out, config, rows=8, cols=8, subdir="preview_smoothed"))
 
-    if os.environ.get("RGBD_AUTOTUNE_SIDE_BUDGET") and hasattr(updater, "autotune_side_budget") and \
-            updater.iteration + 200 < config.iteration and (comm is None or comm.size == 1):
-        # opt-in: ~115 ordinary training steps that also measure, on this device and at the current stage, how many compute units the
-        # side stream's weight-gradient launches should leave to the generator's stream
-        tuned = updater.autotune_side_budget()
-        if tuned is not None and is_master:
-            print(f"side stream budget: {updater.side_budget_tuning}")
+    # The side stream's compute-unit budget is MEASURED on this device at every image size the run meets, inside the ordinary
+    # iterations of the loop below (rgbd_gan_amd.updater.SideBudgetTuner: ~120 steps per size, triggers fire as always; one GPU,
+    # two streams, graphs; RGBD_TUNE_SIDE_BUDGET=0 keeps the rule of thumb).  DESIGN.md section 3.
+    if comm is None or comm.size == 1:
+        updater.tune_side_budget = os.environ.get("RGBD_TUNE_SIDE_BUDGET") not in ("", "0") and hasattr(updater, "finish_tuning") \
+            and config.generator_architecture != "deepvoxels"
+    reported_tuning = None
     log, t0 = log_resumed, time.time() - elapsed_resumed       # a resumed run appends to the log it left (LogReport)
     while updater.iteration < config.iteration:
         updater.update()
         it = updater.iteration
+        tuned = getattr(updater, "side_budget_tuning", None)
+        if is_master and tuned is not None and tuned is not reported_tuning:
+            reported_tuning = tuned
+            print(f"side stream budget at iteration {it}: {tuned}")
         if is_master and it % (config.display_interval or 100) == 0:
             obs = {k: (float(v) if torch.is_tensor(v) else v) for k, v in updater.observation.items()}
             entry = {"iteration": it, "elapsed_time": time.time() - t0, **obs}
