@@ -405,6 +405,15 @@ int rgbd_trilinear_fwd(const float* grid, const int32_t* idx, const float* coord
 int rgbd_trilinear_bwd(const float* dout, const int32_t* idx, const float* coords, const int32_t* counts, float* dgrid,
                        float* workspace /* B*G^3*F floats: feature-major scatter target */, int B, int F, int G, int N,
                        void* stream);
+/* The feature-minor backward without the compacted list: the voxel coordinates of every frustum element are recomputed from
+ * the camera (the arithmetic of rgbd_proj_idcs, bit for bit), a workgroup takes a 16 x 8 x 2 brick of the frustum, sorts the
+ * brick's (voxel, sample, corner) contributions by voxel and issues ONE line atomic per distinct voxel of the brick.
+ * dout (B,F,W*H*D) fp32, cam2world (B,4,4) device fp32, dgrid_fm (B,G,G,G,F) zero-filled inside.
+ * rgbd_trilinear_bwd_frustum_supported: W % 16 == 0, H % 8 == 0, F <= 32, G^3 <= 2^20. */
+int rgbd_trilinear_bwd_frustum_supported(int W, int H, int D, int G, int F);
+int rgbd_trilinear_bwd_frustum(const float* dout, const float* cam2world, int B, int F, int W, int H, int D, int G,
+                               float voxel_size, float near_plane, float fx, float fy, float cx, float cy, float* dgrid_fm,
+                               void* stream);
 /* The same resampling on a FEATURE-MINOR grid (B,G,G,G,F) -- what the voxel generator's NHWC conv stack produces, no
  * transposition on either side: 8 line reads per sample forward, and the backward's scatter target IS the gradient. */
 int rgbd_trilinear_fwd_fm(const float* grid_fm, const int32_t* idx, const float* coords, const int32_t* counts, float* out,

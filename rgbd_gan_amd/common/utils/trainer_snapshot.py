@@ -90,6 +90,17 @@ def unpack(f, optimizers):
     if "iteration" in f and "updater/iteration" not in f:          # this engine's layout of rounds 1-3
         for k, o in optimizers.items():
             if f"{k}/t" in f:
+                # flat moments are positional: they only mean something under the flat parameter layout they were written
+                # with.  The DeepVoxels generator's layout changed in round 5 (style W's / b's regrouped, same total size), so a
+                # rounds-1-3 snapshot of it would load silently misaligned Adam moments: refused, as is any size mismatch.
+                names = getattr(o.store, "names", ())
+                if any(n.startswith(("voxel_gen/", "style_generator/")) for n in names):
+                    raise ValueError(f"snapshot in the flat layout of rounds 1-3: the Adam moments of optimizer '{k}' are positional "
+                                     "and the DeepVoxels generator's flat parameter layout has changed since; resume from the "
+                                     "per-parameter snapshot format (rounds 4+) or restart the optimizer state")
+                if int(np.asarray(f[f"{k}/m"]).size) != int(o.store.numel):
+                    raise ValueError(f"snapshot in the flat layout of rounds 1-3: optimizer '{k}' holds {int(np.asarray(f[f'{k}/m']).size)} "
+                                     f"moments, the model has {int(o.store.numel)} parameters")
                 o.load_state_dict({"t": f[f"{k}/t"], "m": f[f"{k}/m"], "v": f[f"{k}/v"]})
         it = {k[len("iterator/"):]: f[k] for k in f if k.startswith("iterator/")} or None
         return {"iteration": int(f["iteration"]), "iterator": it,

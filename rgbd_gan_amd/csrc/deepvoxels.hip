@@ -107,10 +107,13 @@ struct Corners {
     float w[8];
 };
 
+__device__ __forceinline__ Corners trilinear_corners_at(float xi, float yi, float zi, int G);
 __device__ __forceinline__ Corners trilinear_corners(const float* __restrict__ coords, long base, int N, int pos,
                                                      int G) {
     // deepvoxel.py:394-410: x = v[2], y = v[1], z = v[0]; grid indexed [x][y][z]
-    const float xi = coords[base + 2l * N + pos], yi = coords[base + 1l * N + pos], zi = coords[base + pos];
+    return trilinear_corners_at(coords[base + 2l * N + pos], coords[base + 1l * N + pos], coords[base + pos], G);
+}
+__device__ __forceinline__ Corners trilinear_corners_at(float xi, float yi, float zi, int G) {
     const int x0 = (int)xi, y0 = (int)yi, z0 = (int)zi;
     const int x1 = min(max(x0 + 1, 0), G - 1), y1 = min(max(y0 + 1, 0), G - 1), z1 = min(max(z0 + 1, 0), G - 1);
     const float x = xi - (float)x0, y = yi - (float)y0, z = zi - (float)z0;
@@ -214,6 +217,88 @@ __global__ __launch_bounds__(256) void trilinear_bwd_scatter_kernel(const float*
         }
         atomicAdd(base + (long)cur * F, acc);
     }
+}
+
+// The same backward over BRICKS of the frustum (16 x 8 pixels x 2 depth slices = 256 samples per workgroup) with the brick's
+// 2048 (sample, corner) contributions SORTED by voxel before anything is added: one line atomic per DISTINCT voxel of the
+// brick (~100) instead of one per run of equal voxels along a pixel row (~800) -- neighbouring rows and depth slices hit the same
+// voxels, which the row-wise list kernel above cannot see (its counter traffic was 3.0x the algorithmic bytes, the memory-side
+// atomic rate its bound).  The voxel coordinates are recomputed from the camera (frustum_point: the projection kernels' own
+// arithmetic, bit for bit), so the brick needs no compacted list.  LDS: the brick's dout tile [256][F] (stride 33), the corner
+// weights [256][8], 2048 sort words = (voxel offset << 11 | sample << 3 | corner); a bitonic sort in LDS (66 passes); then 8
+// groups of 32 feature lanes walk 256 sorted words each and flush a register sum whenever the voxel changes.  Round 5's LDS
+// HASH-TABLE form of the same idea lost to the LDS float atomics' serialisation (profiles/r05/trilinear_brick_experiment.txt);
+// here nothing is added in LDS.
+constexpr int TB_X = 16, TB_Y = 8, TB_D = 2;
+constexpr int TB_S = TB_X * TB_Y * TB_D;            // 256 samples
+constexpr unsigned TB_INVALID = 0xffffffffu;
+__global__ __launch_bounds__(256) void trilinear_bwd_brick_kernel(FrustumArgs fa, const float* __restrict__ cams,
+                                                                  const float* __restrict__ dout, float* __restrict__ ws,
+                                                                  int F, int N) {
+    __shared__ float tile[TB_S][33];
+    __shared__ float cw[TB_S][8];
+    __shared__ unsigned sk[TB_S * 8];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.z;
+    const int bricks_x = fa.W / TB_X;
+    const int x0 = (blockIdx.x % bricks_x) * TB_X, y0 = (blockIdx.x / bricks_x) * TB_Y, d0 = blockIdx.y * TB_D;
+    {
+        const int sx = tid & (TB_X - 1), sy = (tid >> 4) & (TB_Y - 1), sd = tid >> 7;
+        const int d = d0 + sd;
+        const int n = (d * fa.H + (y0 + sy)) * fa.W + x0 + sx;
+        float v[3];
+        const bool live = d < fa.D && frustum_point(fa, cams + b * 16, n, v);
+        if (!__syncthreads_or(live)) return;            // the whole brick lies outside the grid (frustum corners)
+        if (live) {
+            const Corners c = trilinear_corners_at(v[2], v[1], v[0], fa.G);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                cw[tid][k] = c.w[k];
+                sk[tid * 8 + k] = ((unsigned)c.o[k] << 11) | ((unsigned)tid << 3) | (unsigned)k;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sk[tid * 8 + k] = TB_INVALID;
+        }
+        for (int f = 0; f < F; ++f) tile[tid][f] = live ? dout[((long)b * F + f) * N + n] : 0.f;
+    }
+    __syncthreads();
+    // bitonic sort of the 2048 words, 4 compare-exchanges per thread per pass
+    for (int k = 2; k <= TB_S * 8; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = tid + 256 * r;                       // pair index 0..1023
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // lower element of the pair
+                const int p = i | j;
+                const unsigned a0 = sk[i], a1 = sk[p];
+                const bool up = (i & k) == 0;
+                if ((a0 > a1) == up) { sk[i] = a1; sk[p] = a0; }
+            }
+            __syncthreads();
+        }
+    }
+    const int f = tid & 31, g = tid >> 5;
+    if (f >= F) return;
+    const long g3 = (long)fa.G * fa.G * fa.G;
+    float* base = ws + (long)b * g3 * F + f;
+    const int i0 = g * 256;
+    unsigned e = sk[i0];
+    if (e == TB_INVALID) return;
+    unsigned cur = e >> 11;
+    float acc = 0.f;
+    for (int i = i0; i < i0 + 256; ++i) {
+        e = sk[i];
+        if (e == TB_INVALID) break;
+        const unsigned key = e >> 11;
+        if (key != cur) {
+            atomicAdd(base + (long)cur * F, acc);
+            cur = key;
+            acc = 0.f;
+        }
+        acc += tile[(e >> 3) & 255][f] * cw[(e >> 3) & 255][e & 7];
+    }
+    atomicAdd(base + (long)cur * F, acc);
 }
 
 // Forward from a FEATURE-MINOR grid (B, G^3, F) -- the layout the voxel generator's NHWC conv stack produces: the 32
@@ -670,6 +755,30 @@ extern "C" int rgbd_trilinear_bwd_fm(const float* dout, const int32_t* idx, cons
     }
     trilinear_bwd_scatter_kernel<<<dim3((N + TRI_S - 1) / TRI_S, B), 256, 0, st>>>(dout, idx, coords, counts, dgrid_fm, F, G, N);
     RGBD_CHECK_LAUNCH("trilinear_bwd_scatter_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_trilinear_bwd_frustum_supported(int W, int H, int D, int G, int F) {
+    return W > 0 && H > 0 && D > 0 && W % TB_X == 0 && H % TB_Y == 0 && F > 0 && F <= 32 && G > 0 &&
+           (long)G * G * G <= (1l << 20) && (long)W * H * D < (1l << 24);
+}
+
+extern "C" int rgbd_trilinear_bwd_frustum(const float* dout, const float* cam2world, int B, int F, int W, int H, int D,
+                                          int G, float voxel_size, float near_plane, float fx, float fy, float cx, float cy,
+                                          float* dgrid_fm, void* stream) {
+    RGBD_REQUIRE(dout && cam2world && dgrid_fm, "rgbd_trilinear_bwd_frustum: null pointer");
+    RGBD_REQUIRE(B > 0 && rgbd_trilinear_bwd_frustum_supported(W, H, D, G, F),
+                 "rgbd_trilinear_bwd_frustum: needs W %% 16 == 0, H %% 8 == 0, F <= 32, G^3 <= 2^20 (W=%d H=%d D=%d G=%d F=%d)",
+                 W, H, D, G, F);
+    hipStream_t st = (hipStream_t)stream;
+    if (rgbd_zero_async(dgrid_fm, (size_t)B * G * G * G * F * sizeof(float), st) != hipSuccess) {
+        rgbd_set_error("rgbd_trilinear_bwd_frustum: zero fill failed");
+        return -2;
+    }
+    FrustumArgs f{W, H, D, G, voxel_size, near_plane, fx, fy, cx, cy};
+    trilinear_bwd_brick_kernel<<<dim3((W / TB_X) * (H / TB_Y), (D + TB_D - 1) / TB_D, B), 256, 0, st>>>(
+        f, cam2world, dout, dgrid_fm, F, W * H * D);
+    RGBD_CHECK_LAUNCH("trilinear_bwd_brick_kernel");
     return 0;
 }
 

@@ -7,6 +7,7 @@ from .. import _lib
 from ..kernels import _ptr, _stream, _timed
 
 OCC_NF = 4
+TRILINEAR_BWD_BRICKS = True     # the feature-minor backward over sorted bricks of the frustum (False: the row-wise list kernel)
 
 
 class _Trilinear(torch.autograd.Function):
@@ -54,6 +55,7 @@ class _TrilinearFM(torch.autograd.Function):
         _lib.check(rc, "rgbd_trilinear_fwd_fm")
         ctx.save_for_backward(idx, coords, counts)
         ctx.dims = (B, F, G, N)
+        ctx.frustum = getattr(idx, "_frustum", None) if TRILINEAR_BWD_BRICKS else None
         return out
 
     @staticmethod
@@ -63,6 +65,17 @@ class _TrilinearFM(torch.autograd.Function):
         B, F, G, N = ctx.dims
         dgrid = torch.empty(B, G, G, G, F, dtype=torch.float32, device=dout.device)
         dout = dout.contiguous()
+        fr = ctx.frustum
+        lib = _lib.load()
+        if fr is not None and fr[0].shape[0] == B and fr[1] * fr[2] * fr[3] == N and fr[4] == G and \
+                lib.rgbd_trilinear_bwd_frustum_supported(fr[1], fr[2], fr[3], G, F):
+            # bricks of the frustum, contributions sorted by voxel: one line atomic per distinct voxel of a brick
+            cams = fr[0]
+            rc = _timed("trilinear_bwd_kernel", 0.0, 4.0 * B * F * (G ** 3 + N),
+                        lambda: lib.rgbd_trilinear_bwd_frustum(_ptr(dout), _ptr(cams), B, F, fr[1], fr[2], fr[3], G, fr[5], fr[6],
+                                                               fr[7], fr[8], fr[9], fr[10], _ptr(dgrid), _stream()))
+            _lib.check(rc, "rgbd_trilinear_bwd_frustum")
+            return dgrid, None, None, None, None
         rc = _timed("trilinear_bwd_kernel", 0.0, 4.0 * B * F * (G ** 3 + N),
                     lambda: _lib.load().rgbd_trilinear_bwd_fm(_ptr(dout), _ptr(idx), _ptr(coords), _ptr(counts), _ptr(dgrid),
                                                               B, F, G, N, _stream()))

@@ -49,6 +49,10 @@ class ProjectionHelper:
                                         float(K[0][2]), float(K[1][2]), _ptr(idx), _ptr(coords), _ptr(counts), _ptr(ws),
                                         _stream())
         _lib.check(rc, "rgbd_proj_idcs")
+        # what the index list was computed FROM travels with it: the backward of the resampling recomputes the voxel coordinates
+        # brick by brick from the cameras instead of walking the compacted list (deepvoxel._TrilinearFM.backward)
+        idx._frustum = (cams, int(W), int(H), int(self.frustrum_depth), int(self.grid_dims[2]), float(self.voxel_size),
+                        float(self.near_plane), float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2]))
         return idx, coords, counts
 
     def compute_proj_idcs(self, cam2world, grid2world=None):

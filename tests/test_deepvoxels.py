@@ -93,6 +93,26 @@ def test_hip_trilinear_forward_backward():
     lin, v = odv.proj_idcs_np(cams[0], fr)
     o1 = dv.interpolate_trilinear(grid[:1].cuda(), torch.from_numpy(lin).cuda(), torch.from_numpy(v).cuda(), [64, 64], fr.depth)
     torch.testing.assert_close(o1.cpu(), outs[0], atol=1e-5, rtol=1e-5)
+    # the two forms of the feature-minor backward at the step's size (32 features): the row-wise list kernel (one line atomic
+    # per run of equal voxels along a pixel row) and the sorted bricks (rgbd_trilinear_bwd_frustum: voxel coordinates recomputed
+    # from the cameras, one line atomic per distinct voxel of a 16 x 8 x 2 brick) add up the same contributions
+    assert getattr(idx, "_frustum", None) is not None and dv.TRILINEAR_BWD_BRICKS
+    g32 = torch.randn(2, 32, 32, 32, 32, generator=g).cuda()
+    d32 = torch.randn(2, 32, fr.depth, 64, 64, generator=g).cuda()
+    got = {}
+    for bricks in (True, False):
+        dv.TRILINEAR_BWD_BRICKS = bricks
+        try:
+            gg = g32.clone().requires_grad_(True)
+            dv.interpolate_trilinear_batch(gg, idx, coords, counts, [64, 64], fr.depth, feature_minor=True).backward(d32)
+            got[bricks] = gg.grad
+        finally:
+            dv.TRILINEAR_BWD_BRICKS = True
+    scale = float(got[False].abs().max())
+    assert scale > 1.0
+    torch.testing.assert_close(got[True], got[False], atol=2e-5 * scale, rtol=1e-4)
+    untouched = got[False] == 0                     # voxels outside every camera's frustum stay exactly zero in both
+    assert bool((got[True][untouched] == 0).all()) and int(untouched.sum()) > 0
 
 
 @pytest.mark.gpu
