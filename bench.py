@@ -480,6 +480,9 @@ def run_workload(args, comm, device):
         # their all-reduces in different orders, and a communicator matches collectives by order)
         was_graphs, was_concurrent = upd.use_graphs, getattr(upd, "concurrent_phases", False)
         upd.use_graphs, upd.concurrent_phases = False, False
+        upd.update()        # one unprofiled step in this arrangement first: whatever switching to it costs once (allocations of
+        #                     the eager one-stream step, lazily loaded code) must not land in a kernel's event pair -- it did:
+        #                     one 50 ms "launch" of the first conv kernel of the leg, profiles/r06/roofline_leg_outlier.txt
         with kernels.launch_profile() as prof:
             for _ in range(2):
                 upd.update()
@@ -488,7 +491,7 @@ def run_workload(args, comm, device):
         table = {k: {"launches": n, "ms": round(t * 1e3, 3), "tflops": round(f / t / 1e12, 1),
                      "avg_us": round(t / n * 1e6, 1), "gbps": round(b / t / 1e9, 1)} for k, (n, t, f, b) in summ.items()}
         timing = ("HIP events on the launch stream around every launch of this kernel in 2 extra eager single-stream "
-                  "steps after the timed region")
+                  "steps after the timed region (behind one unprofiled step in that arrangement)")
         if deepvoxels:
             # the path's own kernels are the HBM-bound frustum resampling / occlusion compositing (SURVEY.md section 8(d):
             # 4.2 MB read + 29.4 MB written per sample, ~2 x 29.4 MB per sample); the conv stack is shared with config 2
@@ -529,7 +532,7 @@ def run_workload(args, comm, device):
         # map, gen, dis; on two streams dis, map, gen -- ranks in different arrangements would pair different buffers
         was_graphs, was_concurrent = upd.use_graphs, getattr(upd, "concurrent_phases", False)
         upd.use_graphs, upd.concurrent_phases = False, False
-        for _ in range(2):
+        for _ in range(3):
             upd.update()
         upd.use_graphs, upd.concurrent_phases = was_graphs, was_concurrent
     if comm.rank == 0 and comm.size == 1 and args.arrangements and not deepvoxels:

@@ -225,80 +225,173 @@ __global__ __launch_bounds__(256) void trilinear_bwd_scatter_kernel(const float*
 // voxels, which the row-wise list kernel above cannot see (its counter traffic was 3.0x the algorithmic bytes, the memory-side
 // atomic rate its bound).  The voxel coordinates are recomputed from the camera (frustum_point: the projection kernels' own
 // arithmetic, bit for bit), so the brick needs no compacted list.  LDS: the brick's dout tile [256][F] (stride 33), the corner
-// weights [256][8], 2048 sort words = (voxel offset << 11 | sample << 3 | corner); a bitonic sort in LDS (66 passes); then 8
-// groups of 32 feature lanes walk 256 sorted words each and flush a register sum whenever the voxel changes.  Round 5's LDS
+// weights [256][8], 2048 sort words = (relative voxel position << 11 | sample << 3 | corner), sorted by a counting sort; then 8
+// groups of 32 feature lanes walk an equal share of the sorted words each and flush a register sum whenever the voxel changes.  Round 5's LDS
 // HASH-TABLE form of the same idea lost to the LDS float atomics' serialisation (profiles/r05/trilinear_brick_experiment.txt);
 // here nothing is added in LDS.
 constexpr int TB_X = 16, TB_Y = 8, TB_D = 2;
 constexpr int TB_S = TB_X * TB_Y * TB_D;            // 256 samples
-constexpr unsigned TB_INVALID = 0xffffffffu;
+constexpr int TB_BINS = 4096;                       // 16^3 voxel positions relative to the brick's lowest corner voxel
 __global__ __launch_bounds__(256) void trilinear_bwd_brick_kernel(FrustumArgs fa, const float* __restrict__ cams,
                                                                   const float* __restrict__ dout, float* __restrict__ ws,
-                                                                  int F, int N) {
+                                                                  int F, int N, int nbricks, int ko) {
+    // (ko: timing knock-outs of the debug library, 0 in the shipped one: 1 = no dout loads, 2 = stop behind the loads,
+    //  3 = stop behind the sort, 4 = fold without the atomics)
+    // A brick is at most 16 x 8 pixels x 2 slices of ONE camera's frustum: its physical diagonal is < 12 voxels at the far plane,
+    // so the corner voxels of all its samples lie within 16 voxels of the lowest one along every axis -- 4 bits per axis.  The
+    // sort by voxel is therefore a COUNTING sort in LDS (a histogram over 4096 relative positions, an exclusive scan that also
+    // lists the occupied positions, a scatter) instead of a comparison sort (the 66-pass bitonic network of this kernel's first
+    // form took as long as the row-wise kernel's atomics: 554 vs 648 us, scripts/time_trilinear_bwd.py).
     __shared__ float tile[TB_S][33];
     __shared__ float cw[TB_S][8];
-    __shared__ unsigned sk[TB_S * 8];
+    __shared__ unsigned bins[TB_BINS];
+    __shared__ unsigned short sorted_[TB_S * 8];      // (sample << 3 | corner), grouped by voxel
+    __shared__ unsigned short bstart[TB_S * 8 + 1];   // occupied voxel j: its words are sorted_[bstart[j] .. bstart[j + 1])
+    __shared__ unsigned short bkey[TB_S * 8];         //                   its relative position (x << 8 | y << 4 | z)
+    __shared__ int box[4][3];
+    __shared__ unsigned wsum[4];
     const int tid = threadIdx.x;
-    const int b = blockIdx.z;
-    const int bricks_x = fa.W / TB_X;
-    const int x0 = (blockIdx.x % bricks_x) * TB_X, y0 = (blockIdx.x / bricks_x) * TB_Y, d0 = blockIdx.y * TB_D;
-    {
-        const int sx = tid & (TB_X - 1), sy = (tid >> 4) & (TB_Y - 1), sd = tid >> 7;
-        const int d = d0 + sd;
-        const int n = (d * fa.H + (y0 + sy)) * fa.W + x0 + sx;
-        float v[3];
-        const bool live = d < fa.D && frustum_point(fa, cams + b * 16, n, v);
-        if (!__syncthreads_or(live)) return;            // the whole brick lies outside the grid (frustum corners)
-        if (live) {
-            const Corners c = trilinear_corners_at(v[2], v[1], v[0], fa.G);
+    // workgroup ids go round the 8 XCDs: give each XCD a contiguous range of bricks, so that the two bricks that share every
+    // 128-byte line of dout (x neighbours: a brick row is 16 floats) meet in ONE L2
+    const int per_xcd = (nbricks + 7) >> 3;
+    const int brick = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (brick >= nbricks) return;
+    const int bricks_x = fa.W / TB_X, bricks_y = fa.H / TB_Y, bricks_d = (fa.D + TB_D - 1) / TB_D;
+    const int bxi = brick % bricks_x, byi = (brick / bricks_x) % bricks_y, bdi = (brick / (bricks_x * bricks_y)) % bricks_d;
+    const int b = brick / (bricks_x * bricks_y * bricks_d);
+    const int sx = tid & (TB_X - 1), sy = (tid >> 4) & (TB_Y - 1), sd = tid >> 7;
+    const int d = bdi * TB_D + sd;
+    const int n = (d * fa.H + (byi * TB_Y + sy)) * fa.W + bxi * TB_X + sx;
+    float v[3];
+    const bool live = d < fa.D && frustum_point(fa, cams + b * 16, n, v);
+    if (!__syncthreads_or(live)) return;            // the whole brick lies outside the grid (frustum corners)
+    // the sample's dout values: requested now, parked in LDS behind the sort (their latency covers it)
+    float dv[32];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                cw[tid][k] = c.w[k];
-                sk[tid * 8 + k] = ((unsigned)c.o[k] << 11) | ((unsigned)tid << 3) | (unsigned)k;
-            }
-        } else {
+    for (int f = 0; f < 32; ++f) dv[f] = (live && f < F && ko != 1) ? dout[((long)b * F + f) * N + n] : 0.f;
+    for (int i = tid; i < TB_BINS; i += 256) bins[i] = 0u;
+    // corners (deepvoxel.py:394-410: x = v[2], y = v[1], z = v[0]; same arithmetic as trilinear_corners_at)
+    int cx0 = 0x7fffffff, cy0 = 0x7fffffff, cz0 = 0x7fffffff, cx1 = 0, cy1 = 0, cz1 = 0;
+    if (live) {
+        const float xi = v[2], yi = v[1], zi = v[0];
+        cx0 = (int)xi; cy0 = (int)yi; cz0 = (int)zi;
+        cx1 = min(max(cx0 + 1, 0), fa.G - 1); cy1 = min(max(cy0 + 1, 0), fa.G - 1); cz1 = min(max(cz0 + 1, 0), fa.G - 1);
+        const float x = xi - (float)cx0, y = yi - (float)cy0, z = zi - (float)cz0;
+        cw[tid][0] = ((1.f - x) * (1.f - y)) * (1.f - z);
+        cw[tid][1] = (x * (1.f - y)) * (1.f - z);
+        cw[tid][2] = ((1.f - x) * y) * (1.f - z);
+        cw[tid][3] = ((1.f - x) * (1.f - y)) * z;
+        cw[tid][4] = (x * (1.f - y)) * z;
+        cw[tid][5] = ((1.f - x) * y) * z;
+        cw[tid][6] = (x * y) * (1.f - z);
+        cw[tid][7] = (x * y) * z;
+    }
+    const int lane = tid & 63, wv = tid >> 6;
+    {   // the brick's lowest corner voxel: wave minima by shuffles, the four waves' through LDS (no LDS atomics)
+        int mx = cx0, my = cy0, mz = cz0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) sk[tid * 8 + k] = TB_INVALID;
+        for (int off = 32; off > 0; off >>= 1) {
+            mx = min(mx, __shfl_xor(mx, off)); my = min(my, __shfl_xor(my, off)); mz = min(mz, __shfl_xor(mz, off));
         }
-        for (int f = 0; f < F; ++f) tile[tid][f] = live ? dout[((long)b * F + f) * N + n] : 0.f;
+        if (lane == 0) { box[wv][0] = mx; box[wv][1] = my; box[wv][2] = mz; }
     }
     __syncthreads();
-    // bitonic sort of the 2048 words, 4 compare-exchanges per thread per pass
-    for (int k = 2; k <= TB_S * 8; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
+    const int bx = min(min(box[0][0], box[1][0]), min(box[2][0], box[3][0]));
+    const int by = min(min(box[0][1], box[1][1]), min(box[2][1], box[3][1]));
+    const int bz = min(min(box[0][2], box[1][2]), min(box[2][2], box[3][2]));
+    unsigned key[8];
+    bool fits = true;
+    if (live) {
+        const int lx0 = cx0 - bx, lx1 = cx1 - bx, ly0 = cy0 - by, ly1 = cy1 - by, lz0 = cz0 - bz, lz1 = cz1 - bz;
+        fits = (lx1 | ly1 | lz1 | lx0 | ly0 | lz0) < 16;                // (x1 >= x0 >= box: all non-negative)
+        // corner order of trilinear_corners_at: (x0y0z0, x1y0z0, x0y1z0, x0y0z1, x1y0z1, x0y1z1, x1y1z0, x1y1z1)
+        key[0] = (lx0 << 8) | (ly0 << 4) | lz0; key[1] = (lx1 << 8) | (ly0 << 4) | lz0;
+        key[2] = (lx0 << 8) | (ly1 << 4) | lz0; key[3] = (lx0 << 8) | (ly0 << 4) | lz1;
+        key[4] = (lx1 << 8) | (ly0 << 4) | lz1; key[5] = (lx0 << 8) | (ly1 << 4) | lz1;
+        key[6] = (lx1 << 8) | (ly1 << 4) | lz0; key[7] = (lx1 << 8) | (ly1 << 4) | lz1;
+    }
+    if (__syncthreads_or(!fits)) {
+        // never at the shipped geometry (see above); a brick that does not fit falls back to one atomic per contribution
+        if (live) {
+            const int G = fa.G;
+            const int o[8] = {(cx0 * G + cy0) * G + cz0, (cx1 * G + cy0) * G + cz0, (cx0 * G + cy1) * G + cz0, (cx0 * G + cy0) * G + cz1,
+                              (cx1 * G + cy0) * G + cz1, (cx0 * G + cy1) * G + cz1, (cx1 * G + cy1) * G + cz0, (cx1 * G + cy1) * G + cz1};
+            float* base = ws + (long)b * G * G * G * F;
+            for (int f = 0; f < F; ++f)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int t = tid + 256 * r;                       // pair index 0..1023
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // lower element of the pair
-                const int p = i | j;
-                const unsigned a0 = sk[i], a1 = sk[p];
-                const bool up = (i & k) == 0;
-                if ((a0 > a1) == up) { sk[i] = a1; sk[p] = a0; }
-            }
-            __syncthreads();
+                for (int k = 0; k < 8; ++k) atomicAdd(base + (long)o[k] * F + f, dv[f] * cw[tid][k]);
+        }
+        return;
+    }
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) atomicAdd(&bins[key[k]], 1u);
+    }
+#pragma unroll
+    for (int f = 0; f < 32; ++f) tile[tid][f] = dv[f];
+    __syncthreads();
+    if (ko == 2) { if (tile[tid][tid & 31] == 1.2345f) ws[0] = 1.f; return; }
+    // exclusive scan of the 4096 counts (and of the number of occupied positions, in the upper half of the same word): 16 positions
+    // per thread, a wave scan of the thread totals, the four wave totals through LDS
+    unsigned c16[16], mine = 0u;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { c16[i] = bins[tid * 16 + i]; mine += c16[i] + (c16[i] ? 0x10000u : 0u); }
+    unsigned inc = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    unsigned run = inc - mine;
+    for (int w2 = 0; w2 < wv; ++w2) run += wsum[w2];
+    const unsigned total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    const int nwords = (int)(total & 0xffffu), nocc = (int)(total >> 16);
+    {
+        unsigned words = run & 0xffffu, occ = run >> 16;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            bins[tid * 16 + i] = words;
+            if (c16[i]) { bstart[occ] = (unsigned short)words; bkey[occ] = (unsigned short)(tid * 16 + i); ++occ; }
+            words += c16[i];
+        }
+        if (tid == 255) bstart[nocc] = (unsigned short)nwords;
+    }
+    __syncthreads();
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned pos = atomicAdd(&bins[key[k]], 1u);
+            sorted_[pos] = (unsigned short)((tid << 3) | k);
         }
     }
+    __syncthreads();
+    if (ko == 3) { if (sorted_[tid] == 0xbeefu) ws[0] = 1.f; return; }
+    // fold: 8 groups of 32 feature lanes; a group takes every eighth occupied voxel and adds up that voxel's words (no comparisons:
+    // the voxel's range is known), eight words in flight at a time; ONE line atomic per occupied voxel
     const int f = tid & 31, g = tid >> 5;
     if (f >= F) return;
-    const long g3 = (long)fa.G * fa.G * fa.G;
-    float* base = ws + (long)b * g3 * F + f;
-    const int i0 = g * 256;
-    unsigned e = sk[i0];
-    if (e == TB_INVALID) return;
-    unsigned cur = e >> 11;
-    float acc = 0.f;
-    for (int i = i0; i < i0 + 256; ++i) {
-        e = sk[i];
-        if (e == TB_INVALID) break;
-        const unsigned key = e >> 11;
-        if (key != cur) {
-            atomicAdd(base + (long)cur * F, acc);
-            cur = key;
-            acc = 0.f;
+    const int G = fa.G;
+    float* base = ws + (long)b * G * G * G * F + f;
+    for (int j = g; j < nocc; j += 8) {
+        const int s0 = bstart[j], s1 = bstart[j + 1];
+        const unsigned k2 = bkey[j];
+        float acc = 0.f;
+        for (int i = s0; i < s1; i += 8) {
+            unsigned e[8];
+            float t[8], c[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) e[q] = sorted_[min(i + q, s1 - 1)];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { t[q] = tile[e[q] >> 3][f]; c[q] = cw[0][e[q]]; }      // cw[s][k] = cw[0][s * 8 + k]
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += i + q < s1 ? t[q] * c[q] : 0.f;
         }
-        acc += tile[(e >> 3) & 255][f] * cw[(e >> 3) & 255][e & 7];
+        const int gx = bx + (int)(k2 >> 8), gy = by + (int)((k2 >> 4) & 15u), gz = bz + (int)(k2 & 15u);
+        if (ko != 4) atomicAdd(base + (long)((gx * G + gy) * G + gz) * F, acc);
+        else if (acc == 1.2345f) base[0] = acc;
     }
-    atomicAdd(base + (long)cur * F, acc);
 }
 
 // Forward from a FEATURE-MINOR grid (B, G^3, F) -- the layout the voxel generator's NHWC conv stack produces: the 32
@@ -776,8 +869,14 @@ extern "C" int rgbd_trilinear_bwd_frustum(const float* dout, const float* cam2wo
         return -2;
     }
     FrustumArgs f{W, H, D, G, voxel_size, near_plane, fx, fy, cx, cy};
-    trilinear_bwd_brick_kernel<<<dim3((W / TB_X) * (H / TB_Y), (D + TB_D - 1) / TB_D, B), 256, 0, st>>>(
-        f, cam2world, dout, dgrid_fm, F, W * H * D);
+#ifdef RGBD_DEBUG_BUILD
+    static const int ko = getenv("RGBD_DEBUG_TRIBRICK_KO") ? atoi(getenv("RGBD_DEBUG_TRIBRICK_KO")) : 0;
+#else
+    constexpr int ko = 0;
+#endif
+    const int nbricks = (W / TB_X) * (H / TB_Y) * ((D + TB_D - 1) / TB_D) * B;
+    trilinear_bwd_brick_kernel<<<(unsigned)(((nbricks + 7) / 8) * 8), 256, 0, st>>>(f, cam2world, dout, dgrid_fm, F, W * H * D,
+                                                                                nbricks, ko);
     RGBD_CHECK_LAUNCH("trilinear_bwd_brick_kernel");
     return 0;
 }
