@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--fp8", action="store_true",
                     help="conv_dtype: mxfp8 -- fprop / dgrad of the 3x3 convolutions on block-scaled fp8 operands "
                          "(v_mfma_scale_f32_16x16x128_f8f6f4), weight gradients on the bf16 kernels")
+    ap.add_argument("--fp8-coverage", default=None,
+                    help="with --fp8: which launches take fp8 operands (YAML key mxfp8_coverage, functional.MX8_COVERAGES); default: "
+                         "the engine's default coverage")
     ap.add_argument("--arrangements", action="store_true",
                     help="also time the single-stream arrangement on the same box (extra key, never `value`)")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -125,7 +128,7 @@ def pmc_traffic(kernel, workload):
         return None, prov
     ks = prof["kernels"]
     # launch-profile labels of the DeepVoxels path that stand for one or several kernels of the library
-    alias = {"trilinear_bwd_kernel": ("trilinear_bwd_scatter_kernel",), "trilinear_fwd_kernel": ("trilinear_fwd_fm_kernel",),
+    alias = {"trilinear_bwd_kernel": ("trilinear_bwd_brick_kernel", "trilinear_bwd_scatter_kernel"), "trilinear_fwd_kernel": ("trilinear_fwd_fm_kernel",),
              "occlusion_accum_fwd_kernel": ("occ_fwd_fused_kernel<32>", "occ_score_kernel", "occ_scan_kernel", "occ_compose_kernel"),
              "occlusion_accum_bwd_kernel": ("occ_bwd_scan_kernel", "occ_bwd_mlp_kernel", "occ_bwd_dw_kernel", "occ_bwd_params_kernel")}
     if kernel in alias:
@@ -348,6 +351,8 @@ def run_workload(args, comm, device):
         extra["fixed_stage"] = float(args.stage)
     if args.fp8:
         config.conv_dtype = "mxfp8"
+        if args.fp8_coverage:
+            config.mxfp8_coverage = args.fp8_coverage
         kernels.MX8_EMIT = not args.mx8_standalone_quantiser
     np.random.seed(2 + comm.rank)
     torch.manual_seed(comm.rank)

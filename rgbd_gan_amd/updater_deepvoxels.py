@@ -90,8 +90,11 @@ class DeepVoxelsUpdater(RGBDUpdater):
         """What both streams depend on: cleared gradient buffers, the down-sized real batch, D's bf16 weight images (packed
         here so that neither stream does it behind the other's back; G's are rebuilt inside its own phases -- it is
         updated in the middle of the step)."""
+        bufs = []
         for link in (self.gen, self.gen.mapping, self.dis):
-            link.cleargrads()
+            for _, store in link.stores:
+                store.zero_grad(defer=bufs)
+        kernels.zero_multi(bufs)                                   # one launch for all flat gradient buffers
         with torch.no_grad():
             st["x_real"] = downsize_real(st["x_real_full"], IMG_SIZE).contiguous()
         group = getattr(self.dis, "pack_group", None)

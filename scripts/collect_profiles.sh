@@ -4,11 +4,13 @@
 # conv kernels on the step's layer shapes; summaries into profiles/$1 (stamped with the kernel sources' hash).
 #   scripts/collect_profiles.sh r02 [commit]
 set -u
-R=${1:-r05}
+R=${1:-r06}
 export RGBD_COMMIT=${2:-unknown}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/$R profiles/$R
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/stats -o b -- python3 bench.py --no-cpu-baseline --no-other-configs > gpurun_out/$R/stats.log 2>&1
+# (--no-tune under the profiler: the 120 measuring steps of the side-budget tuner -- eager steps, re-captures, other workgroup counts --
+#  would be averaged into the per-kernel table; the profiled step uses the rule of thumb's counts)
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/stats -o b -- python3 bench.py --no-tune --no-cpu-baseline --no-other-configs > gpurun_out/$R/stats.log 2>&1
 cp gpurun_out/$R/stats/b_kernel_stats.csv profiles/$R/bench_kernel_stats.csv
 grep '"metric"' gpurun_out/$R/stats.log > profiles/$R/bench_line_under_rocprof.json
 rm -f gpurun_out/$R/stats/b_kernel_trace.csv
@@ -17,13 +19,14 @@ rm -f gpurun_out/$R/stats/b_kernel_trace.csv
 pmc_traffic() {   # name, bench.py arguments
   local W=$1; shift
   for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $C --output-format csv -d gpurun_out/$R/pmc_${W}_$C -o p -- python3 bench.py "$@" --steps 3 --warmup 3 --no-cpu-baseline --no-roofline --no-other-configs > gpurun_out/$R/pmc_${W}_$C.log 2>&1
+    rocprofv3 --kernel-trace --pmc $C --output-format csv -d gpurun_out/$R/pmc_${W}_$C -o p -- python3 bench.py "$@" --no-tune --steps 3 --warmup 3 --no-cpu-baseline --no-roofline --no-other-configs > gpurun_out/$R/pmc_${W}_$C.log 2>&1
   done
   python3 scripts/pmc_summary.py gpurun_out/$R/pmc_${W}_FETCH_SIZE gpurun_out/$R/pmc_${W}_WRITE_SIZE profiles/$R/bench_pmc_traffic_$W.json \
-    "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py $* --steps 3 --warmup 3 --no-cpu-baseline --no-roofline --no-other-configs" $W
+    "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py $* --no-tune --steps 3 --warmup 3 --no-cpu-baseline --no-roofline --no-other-configs" $W
   rm -rf gpurun_out/$R/pmc_${W}_FETCH_SIZE gpurun_out/$R/pmc_${W}_WRITE_SIZE
 }
 pmc_traffic default
+pmc_traffic c2_fade --stage 9.5
 pmc_traffic res256 --res256
 pmc_traffic res256_fp8 --res256 --fp8
 pmc_traffic c3_b8 --config configs/ffhq_stylegan_occlusion.yml --batch 8
@@ -42,7 +45,7 @@ rm -rf gpurun_out/$R/kpmc_*/
 #      per-kernel time of the fp8 command, and the counters of the MXFP8 kernel beside its bf16 twin (scripts/prof_conv_mx8.py)
 python3 bench.py --res256 --fp8 --no-cpu-baseline > profiles/$R/bench_res256_fp8.json 2> gpurun_out/$R/res256_fp8.err
 python3 bench.py --res256 --no-cpu-baseline > profiles/$R/bench_res256_bf16.json 2> gpurun_out/$R/res256_bf16.err
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/stats256 -o b -- python3 bench.py --res256 --fp8 --steps 40 --no-cpu-baseline --no-roofline > gpurun_out/$R/stats256.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$R/stats256 -o b -- python3 bench.py --res256 --fp8 --no-tune --steps 40 --no-cpu-baseline --no-roofline > gpurun_out/$R/stats256.log 2>&1
 cp gpurun_out/$R/stats256/b_kernel_stats.csv profiles/$R/bench_res256_fp8_kernel_stats.csv
 rm -f gpurun_out/$R/stats256/b_kernel_trace.csv
 P=0
@@ -62,7 +65,7 @@ cp gpurun_out/$R/stats_c4/b_kernel_stats.csv profiles/$R/bench_c4_kernel_stats.c
 rm -f gpurun_out/$R/stats_c4/b_kernel_trace.csv
 # ---- what lies under what: a kernel trace of the default command through scripts/trace_overlap.py (small kernels that the
 #      per-kernel averages show at 5-10x their stand-alone time are stretched under the other queue's chip-filling kernels)
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/$R/trace -o t -- python3 bench.py --steps 6 --warmup 10 --no-cpu-baseline --no-roofline --no-other-configs > gpurun_out/$R/trace.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/$R/trace -o t -- python3 bench.py --no-tune --steps 6 --warmup 10 --no-cpu-baseline --no-roofline --no-other-configs > gpurun_out/$R/trace.log 2>&1
 T=$(find gpurun_out/$R/trace -name 't_kernel_trace.csv' | head -1)
 python3 scripts/trace_overlap.py $T 'planes_outer_kernel<4>' 'from_planes_kernel<4>' 'linear_fwd' 'adain_reduce' 'warp_loss_bwd_kernel' > profiles/$R/trace_overlap.txt 2>&1
 python3 scripts/timeline.py $T > profiles/$R/trace_timeline.txt 2>&1
@@ -81,7 +84,10 @@ CONFIG=ffhq_stylegan_occlusion.yml B=8 python3 scripts/phases_alone.py > profile
 python3 scripts/step_conv_shapes.py 2>/dev/null | grep -v amdgpu.ids > profiles/$R/step_conv_shapes.txt
 CONFIG=deepvoxels_shapenet_car.yml ITERATION=100 python3 scripts/step_conv_shapes.py 2>/dev/null | grep -v amdgpu.ids > profiles/$R/step_conv_shapes_c4.txt
 # the two-stream step without the side stream's compute-unit budgets, same box (profiles/r05/cu_budget_sweep.txt)
-RGBD_SIDE_CUS=0 RGBD_SIDE_WGRAD_WGS=0 python3 bench.py --no-cpu-baseline --no-roofline --no-other-configs > profiles/$R/bench_default_no_cu_budget.json 2>/dev/null
+RGBD_SIDE_CUS=0 RGBD_SIDE_WGRAD_WGS=0 python3 bench.py --no-tune --no-cpu-baseline --no-roofline --no-other-configs > profiles/$R/bench_default_no_cu_budget.json 2>/dev/null
+# ... and with the rule of thumb instead of the measured workgroup counts
+python3 bench.py --no-tune --no-cpu-baseline --no-roofline --no-other-configs > profiles/$R/bench_default_rule_of_thumb.json 2>/dev/null
+python3 scripts/time_trilinear_bwd.py 2>/dev/null | grep -v amdgpu.ids > profiles/$R/time_trilinear_bwd.txt
 python3 -m pytest tests -q -m gpu 2>&1 | tail -3 > profiles/$R/gpu_tests_same_box.txt
 python3 scripts/torch_op_sources.py 2>/dev/null | grep -v amdgpu.ids > profiles/$R/torch_op_sources.txt
 python3 scripts/torch_op_sources.py 200000 configs/deepvoxels_shapenet_car.yml 2>/dev/null | grep -v amdgpu.ids > profiles/$R/torch_op_sources_c4.txt

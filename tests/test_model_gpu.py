@@ -389,9 +389,12 @@ def test_256px_training_step_matches_mx8_emulating_oracle():
         assert abs(obs[key] - ref[key]) < 2e-2 * max(1.0, abs(ref[key])), (key, obs[key], ref[key])
     assert abs(obs["gen/loss_adv"] - ref["gen/loss_adv"]) < 0.2 * abs(ref["gen/loss_adv"]) + 1e-5     # softplus(-8): 2e-4
     assert len(rows) > 140
-    assert summ["dis/"][0] > 0.9 and summ["dis/"][1] > 0.7, summ
-    assert summ["gen/"][0] > 0.75 and summ["gen/"][1] > 0.3, summ
-    assert abs(float(opt["dis"].grad_norm) - ref["norm_dis"]) < 0.1 * ref["norm_dis"]
+    # measured: dis 0.991 / 0.987 (median / worst cosine of its 20 large tensors), mapping 0.899 / 0.888, gen 0.680 / 0.475; the bf16
+    # engine against the bf16-emulating oracle on the same step: 0.997 / 0.995, 0.965 / 0.947, 0.875 / 0.815
+    assert summ["dis/"][0] > 0.98 and summ["dis/"][1] > 0.97, summ
+    assert summ["mapping/"][0] > 0.8, summ
+    assert summ["gen/"][0] > 0.55 and summ["gen/"][1] > 0.35, summ
+    assert abs(float(opt["dis"].grad_norm) - ref["norm_dis"]) < 0.05 * ref["norm_dis"]
     assert abs(float(opt["gen"].grad_norm) - ref["norm_gen"]) < 0.3 * ref["norm_gen"]
 
 
