@@ -232,25 +232,18 @@ class RGBDUpdater:
         # still overlaps it: its own count, by default half way between the first launch's and all (measured: autotune_side_budget)
         env = os.environ.get("RGBD_DFW_WGRAD_WGS")
         self.dfw_wgrad_workgroups = kwargs.pop("dfw_wgrad_workgroups", int(env) if env else None)
-        # Data parallel (N > 1), two streams -- the same budgets priced for a step with collectives in it:
-        #   dp_reserve_cus: RCCL's kernels need compute units of their own while the all-reduces travel beside the step; a
+        # Data parallel (N > 1) -- the same budgets priced for a step with collectives in it:
+        #   dp_reserve_cus: RCCL's kernels need compute units of their own while the all-reduces travel beside the step, and a
         #     persistent launch that claims every CU while some are held by a collective runs its last workgroups as a SECOND
-        #     round.  While a collective can be pending (gen_b beside D's all-reduce; the side stream's phases beside nothing of
-        #     RCCL's, but they share the chip with gen_b) no persistent grid is sized for more than cus - dp_reserve_cus.
+        #     round.  The batched WEIGHT-GRADIENT launches split their work over any number of workgroups, so leaving 16 of 256
+        #     costs them 6 %: while comm.active they are never planned for more than cus - dp_reserve_cus.  The 3x3 kernel's grids
+        #     are NOT reduced: every layer's tile count is a power of two, so a grid of 240 instead of 256 always adds a whole round
+        #     (+12 % at 8 rounds, +50 % at 2, +100 % at 1: the 8-GPU job's B = 8 layers have 1-2) -- as much as the collision it
+        #     would avoid, paid on every launch instead of the few that meet a collective.
         #   dp_side_lead_workgroups: D's 34 MB should be on the wire BEFORE the generator's backward ends (then only the
         #     generator's 29 MB are exposed); the side stream's weight-gradient launches get this many workgroups more than the
         #     one-GPU rule gives them, so that the side stream ends earlier than the main one instead of together with it.
         # Neither could be measured (one GPU per lease: a one-rank RCCL group moves nothing); both are arguments.
-        # tune_side_budget: measure the side stream's two weight-gradient workgroup counts on THIS device for every (batch, image
-        # size) the run meets, inside the ordinary training steps (SideBudgetTuner below), instead of trusting the rule of thumb --
-        # the rule was fitted on three shapes and misses a shape it was not fitted on by up to 20 % (stage 8, B = 32:
-        # profiles/r06/cu_budget_sweep.txt).  Default: on for a one-GPU run that replays graphs on two streams; off under data
-        # parallelism (the re-captures beside RCCL have never run on more than one device) and with explicit counts.
-        # train_rgbd.py and bench.py switch it on for one-GPU runs (RGBD_TUNE_SIDE_BUDGET=0 keeps the rule); a bare
-        # RGBDUpdater(...) takes the rule.
-        env = os.environ.get("RGBD_TUNE_SIDE_BUDGET")
-        self.tune_side_budget = bool(kwargs.pop("tune_side_budget", False)) and env not in ("", "0")
-        self._tuner = None
         self.dp_reserve_cus = int(kwargs.pop("dp_reserve_cus", os.environ.get("RGBD_DP_RESERVE_CUS", "16")))
         self.dp_side_lead_workgroups = int(kwargs.pop("dp_side_lead_workgroups", os.environ.get("RGBD_DP_SIDE_LEAD_WGS", "32")))
         if kwargs:
@@ -494,7 +487,7 @@ class RGBDUpdater:
         wgrads = []
         with Fn.deferred_wgrads(wgrads):
             torch.autograd.backward([x_fake], [gout])
-        with kernels.wgrad_workgroups(st.get("main_cus", 0)):      # data parallel: not every CU (dp_reserve_cus)
+        with kernels.wgrad_workgroups(st.get("main_wgrad_wgs", 0)):      # data parallel: not every CU (dp_reserve_cus)
             Fn.run_deferred_wgrads(wgrads)
         st["x_fake_data"] = x_fake.detach()
         st["x_fake"] = st["gx"] = None                 # drop the autograd graph
@@ -614,16 +607,15 @@ class RGBDUpdater:
             self.call_log.append((what, name, torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0))
 
     def _dp_budgets(self, st):
-        """Data parallel on two streams -> (side stream's 3x3 budget, main stream's budget); also moves the side stream's
-        weight-gradient workgroup counts in st (dp_reserve_cus / dp_side_lead_workgroups, __init__)."""
+        """Data parallel -> the cap on every weight-gradient plan's workgroup count (cus - dp_reserve_cus); also moves the side
+        stream's two counts in st by dp_side_lead_workgroups (rule-given counts only) and caps them (__init__)."""
         cus = torch.cuda.get_device_properties(self.device).multi_processor_count if torch.cuda.is_available() else 256
         cap = max(8, cus - max(0, self.dp_reserve_cus))
         for k in ("side_wgrad_wgs", "dfw_wgrad_wgs"):
             if self.side_wgrad_workgroups is None and st.get(k):
                 st[k] = int(st[k]) + self.dp_side_lead_workgroups
             st[k] = min(cap, int(st.get(k) or cap))
-        side = min(cap, self.side_cu_budget) if self.side_cu_budget else cap
-        return side, cap
+        return cap
 
     def _mark(self, name, stream):
         if self.timeline is not None:
@@ -997,8 +989,7 @@ class RGBDUpdater:
                 st["dfw_wgrad_wgs"] = int(self.dfw_wgrad_workgroups)
             side_cus, main_cus = self.side_cu_budget, 0
             if dp:
-                side_cus, main_cus = self._dp_budgets(st)
-            st["main_cus"] = main_cus
+                st["main_wgrad_wgs"] = self._dp_budgets(st)
             self._last_shape = (int(st["B"]), int(st["x_real"].shape[2]), int(st["x_real"].shape[3]))
             if (self.tune_side_budget and self._tuner is None and key is not None and not dp and self.side_wgrad_workgroups is None
                     and self.dfw_wgrad_workgroups is None and self._last_shape not in getattr(self, "_side_wgrad_tuned", {})):
@@ -1040,16 +1031,15 @@ class RGBDUpdater:
             main.wait_stream(side)
             self._run_phase("join", self._join_phase, st, key)
         elif dp:
-            cap = self._dp_budgets(st)[1]   # one stream: every persistent grid leaves dp_reserve_cus to the collectives
-            st["main_cus"] = st["side_wgrad_wgs"] = st["dfw_wgrad_wgs"] = cap
+            st["main_wgrad_wgs"] = self._dp_budgets(st)     # one stream: every weight-gradient plan leaves dp_reserve_cus
             if self.dp_split_body:
-                self._run_phase("body_g", self._body_g_phase, st, key, cu_budget=cap)
+                self._run_phase("body_g", self._body_g_phase, st, key)
                 for opt in g_opts:          # ~29 MB of generator gradients travel while D's half of the step runs
                     self._note("allreduce", "gen")
                     opt.start_allreduce()
-                self._run_phase("body_d", self._body_d_phase, st, key, cu_budget=cap)
+                self._run_phase("body_d", self._body_d_phase, st, key)
             else:
-                self._run_phase("body", self._body_phase, st, key, cu_budget=cap)
+                self._run_phase("body", self._body_phase, st, key)
         else:
             self._run_phase("body", self._body_phase, st, key)
         if st.get("d_step_on_side"):

@@ -324,18 +324,21 @@ def test_statistics_pool_counts_only_a_steps_own_takes():
 
 
 def test_data_parallel_budgets_leave_compute_units_to_the_collectives():
-    """RGBDUpdater._dp_budgets: beside a pending all-reduce no persistent grid is sized for the whole chip,
-    and the side stream's weight-gradient launches get more workgroups than the one-GPU rule gives them (so that D's gradients
-    are on the wire before the generator's backward ends)."""
+    """RGBDUpdater._dp_budgets: beside a pending all-reduce no weight-gradient plan is sized for the whole
+    chip (the 3x3 grids are left alone: a power-of-two tile count makes any smaller grid a whole extra round), and the side
+    stream's weight-gradient launches get more workgroups than the one-GPU rule gives them (so that D's gradients are on the
+    wire before the generator's backward ends)."""
     from rgbd_gan_amd.updater import RGBDUpdater
     fake = type("U", (), {"device": "cpu", "dp_reserve_cus": 16, "dp_side_lead_workgroups": 32, "side_cu_budget": 224,
                           "side_wgrad_workgroups": None})()
     if torch.cuda.is_available():
         return
     st = {"side_wgrad_wgs": 64, "dfw_wgrad_wgs": 160}
-    assert RGBDUpdater._dp_budgets(fake, st) == (224, 240) and st == {"side_wgrad_wgs": 96, "dfw_wgrad_wgs": 192}
+    assert RGBDUpdater._dp_budgets(fake, st) == 240 and st == {"side_wgrad_wgs": 96, "dfw_wgrad_wgs": 192}
     st = {"side_wgrad_wgs": 208, "dfw_wgrad_wgs": 232}
-    assert RGBDUpdater._dp_budgets(fake, st) == (224, 240) and st == {"side_wgrad_wgs": 240, "dfw_wgrad_wgs": 240}
-    fake.side_wgrad_workgroups, fake.side_cu_budget = 96, 0                # explicit counts are capped, not moved
+    assert RGBDUpdater._dp_budgets(fake, st) == 240 and st == {"side_wgrad_wgs": 240, "dfw_wgrad_wgs": 240}
+    fake.side_wgrad_workgroups = 96                                        # explicit counts are capped, not moved
     st = {"side_wgrad_wgs": 96, "dfw_wgrad_wgs": 0}
-    assert RGBDUpdater._dp_budgets(fake, st) == (240, 240) and st == {"side_wgrad_wgs": 96, "dfw_wgrad_wgs": 240}
+    assert RGBDUpdater._dp_budgets(fake, st) == 240 and st == {"side_wgrad_wgs": 96, "dfw_wgrad_wgs": 240}
+    st = {}                                                                # one stream: no side counts, everything capped
+    assert RGBDUpdater._dp_budgets(fake, st) == 240 and st == {"side_wgrad_wgs": 240, "dfw_wgrad_wgs": 240}
