@@ -232,6 +232,15 @@ class RGBDUpdater:
         # still overlaps it: its own count, by default half way between the first launch's and all (measured: autotune_side_budget)
         env = os.environ.get("RGBD_DFW_WGRAD_WGS")
         self.dfw_wgrad_workgroups = kwargs.pop("dfw_wgrad_workgroups", int(env) if env else None)
+        # tune_side_budget: measure the side stream's two weight-gradient workgroup counts on THIS device for every (batch, image
+        # size) the run meets, inside the ordinary training steps (SideBudgetTuner below), instead of trusting the rule of thumb --
+        # round 5's rule was fitted on three shapes and missed a shape it was not fitted on by up to 20 % (stage 8, B = 32:
+        # profiles/r06/cu_budget_sweep_rule_r05.txt).  train_rgbd.py and bench.py switch it on for one-GPU runs that replay graphs on
+        # two streams (RGBD_TUNE_SIDE_BUDGET=0 keeps the rule); a bare RGBDUpdater(...) takes the rule; off under data parallelism
+        # (the re-captures beside RCCL have never run on more than one device) and with explicit counts.
+        env = os.environ.get("RGBD_TUNE_SIDE_BUDGET")
+        self.tune_side_budget = bool(kwargs.pop("tune_side_budget", False)) and env not in ("", "0")
+        self._tuner = None
         # Data parallel (N > 1) -- the same budgets priced for a step with collectives in it:
         #   dp_reserve_cus: RCCL's kernels need compute units of their own while the all-reduces travel beside the step, and a
         #     persistent launch that claims every CU while some are held by a collective runs its last workgroups as a SECOND
