@@ -1084,7 +1084,8 @@ class SideBudgetTuner:
     steps are timed between two device synchronisations.  Plan: the rule's pair and -32 / +32 / +64 for the first launch (the second
     at its rule), best -16 / +16, then two more for the second launch (same as the first; the whole chip): 8 candidates x
     (graph_warmup + 1 + measure) steps = 120 by default, 1-4 s.  The fastest pair is kept for the shape
-    (RGBDUpdater._side_wgrad_tuned) and the run goes on with it.  A stage change in the middle (another image size) drops the
+    (RGBDUpdater._side_wgrad_tuned) -- the rule's own pair if it is within 1 % of the fastest (what a 12-step window resolves) --
+    and the run goes on with it.  A stage change in the middle (another image size) drops the
     half-finished measurement -- the new shape gets a tuner of its own, the old one its rule until it comes up again."""
 
     def __init__(self, upd, shape, measure=12):
@@ -1154,6 +1155,9 @@ class SideBudgetTuner:
         if self.queue or self._next_round():
             return False
         best = min(self.results, key=self.results.get)
+        rule = tuple(self.rule)
+        if rule in self.results and self.results[rule] <= 1.01 * self.results[best]:
+            best = rule                     # a 12-step window resolves ~1 %: within that the rule's pair stays (flat landscapes)
         self._install(best)
         up.side_budget_tuning = {"shape": self.shape, "rule": tuple(self.rule), "chosen": best,
                                  "ms_per_step": {f"{k[0]}/{k[1]}": round(1e3 * v, 4) for k, v in sorted(self.results.items())}}
