@@ -342,3 +342,23 @@ def test_data_parallel_budgets_leave_compute_units_to_the_collectives():
     assert RGBDUpdater._dp_budgets(fake, st) == 240 and st == {"side_wgrad_wgs": 96, "dfw_wgrad_wgs": 240}
     st = {}                                                                # one stream: no side counts, everything capped
     assert RGBDUpdater._dp_budgets(fake, st) == 240 and st == {"side_wgrad_wgs": 240, "dfw_wgrad_wgs": 240}
+
+
+def test_updater_constructor_takes_every_documented_argument_and_rejects_unknown_ones():
+    """RGBDUpdater.__init__ pops its keyword arguments one by one and raises on leftovers: an edit that drops one of the pops turns
+    a documented argument into a TypeError (it happened to `tune_side_budget` in round 6, and only a GPU test noticed)."""
+    import types
+    from rgbd_gan_amd.updater import CameraParamPrior, RGBDUpdater
+    from rgbd_gan_amd.utils.yaml_utils import Config
+    cfg = Config(dict(stage_interval="0,0,0,0,0,0,0,100,200", max_stage=11, x_rotate=0.3, y_rotate=1.0, z_rotate=0, x_translate=0,
+                      y_translate=0, z_translate=0, bigan=False, generator_architecture="stylegan"))
+    gen, dis = types.SimpleNamespace(device=torch.device("cpu")), types.SimpleNamespace()
+    base = dict(optimizer={}, iterator=None, lambda_gp=1.0, smoothing=0.999, total_gpu=1, prior=CameraParamPrior(cfg))
+    extra = dict(nan_check_interval=10, nan_watch=False, fixed_stage=8.0, use_graphs=True, graph_warmup=2, graph_fallback=False,
+                 concurrent_phases=True, dp_split_body=True, side_cu_budget=224, side_wgrad_workgroups=None, dfw_wgrad_workgroups=None,
+                 tune_side_budget=True, dp_reserve_cus=16, dp_side_lead_workgroups=32)
+    upd = RGBDUpdater(models=[gen, dis], config=cfg, **base, **extra)
+    assert upd.tune_side_budget and upd.fixed_stage == 8.0 and upd.dp_reserve_cus == 16 and upd.stage == 8.0
+    assert not upd.tuning_in_progress
+    with pytest.raises(TypeError, match="unknown arguments"):
+        RGBDUpdater(models=[gen, dis], config=cfg, **base, no_such_argument=1)
