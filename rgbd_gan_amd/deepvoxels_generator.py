@@ -241,7 +241,11 @@ class VoxelGenerator(_Link, _StyleMixin):
         pre = f"net/{i}"
         co, ci = self.chans[i]
         C = _ceil64(co)
-        if i == 0:
+        if i == 0 and ci == C and p[pre + "/W"].is_cuda:
+            # lrelu(W + b0) for every sample as (B,4,4,4,C) bf16 in ONE launch, gradients straight into the bound buffers
+            # (rgbd_const_input_{fwd,bwd}, as SynthesisBlock 0 of the 2-D networks) instead of ~10 torch launches per call
+            h = Fn.const_input(p[pre + "/W"], p[pre + "/b0/b"], w.shape[0])
+        elif i == 0:
             const = p[pre + "/W"].permute(1, 2, 3, 0).unsqueeze(0)                       # (1,4,4,4,ci)
             h = _pad_to(Fn.lrelu(const + p[pre + "/b0/b"]), C).to(BF16)
             h = h.expand(w.shape[0], 4, 4, 4, C).contiguous()

@@ -3,6 +3,8 @@ import contextlib
 import ctypes
 import os
 
+import numpy as np
+
 import torch
 
 from . import _lib
@@ -1255,11 +1257,11 @@ def image_grad_init(gx, ratio, planes_out):
 
 
 def const_input_fwd(w, bias, B, slope=0.2):
-    """w (C,H,W), bias (C) fp32 -> (B,H,W,C) bf16 = lrelu(w + bias) for every sample."""
+    """w (C,H,W) [or (C,D,H,W): any trailing positions], bias (C) fp32 -> (B,H,W,C) bf16 = lrelu(w + bias) for every sample."""
     _chk(w, F32, "w"); _chk(bias, F32, "bias")
-    C, H, W = w.shape
-    out = torch.empty(B, H, W, C, dtype=BF16, device=w.device)
-    _lib.check(_lib.load().rgbd_const_input_fwd(_ptr(w), _ptr(bias), _ptr(out), B, H * W, C, float(slope), _stream()),
+    C, pos = w.shape[0], tuple(w.shape[1:])
+    out = torch.empty((B,) + pos + (C,), dtype=BF16, device=w.device)
+    _lib.check(_lib.load().rgbd_const_input_fwd(_ptr(w), _ptr(bias), _ptr(out), B, int(np.prod(pos)), C, float(slope), _stream()),
                "rgbd_const_input_fwd")
     return out
 
@@ -1267,8 +1269,8 @@ def const_input_fwd(w, bias, B, slope=0.2):
 def const_input_bwd(dh, w, bias, dw, db, slope=0.2):
     """Accumulates into dw (C,H,W) / db (C) (either may be None)."""
     _chk(dh, BF16, "dh"); _chk(w, F32, "w"); _chk(bias, F32, "bias"); _chk(dw, F32, "dw"); _chk(db, F32, "db")
-    B, H, W, C = dh.shape
-    _lib.check(_lib.load().rgbd_const_input_bwd(_ptr(dh), _ptr(w), _ptr(bias), _ptr(dw), _ptr(db), B, H * W, C,
+    B, C = dh.shape[0], dh.shape[-1]
+    _lib.check(_lib.load().rgbd_const_input_bwd(_ptr(dh), _ptr(w), _ptr(bias), _ptr(dw), _ptr(db), B, int(np.prod(dh.shape[1:-1])), C,
                                                 float(slope), _stream()), "rgbd_const_input_bwd")
 
 

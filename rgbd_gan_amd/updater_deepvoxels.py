@@ -77,7 +77,7 @@ class DeepVoxelsUpdater(RGBDUpdater):
         self.side_cu_budget = int(kwargs.pop("side_cu_budget", os.environ.get("RGBD_SIDE_CUS", "192")))
         self.side_wgrad_workgroups = int(kwargs.pop("side_wgrad_workgroups", os.environ.get("RGBD_SIDE_WGRAD_WGS", "128")))
         self._side_stream = None
-        self._graphs, self._eager_calls, self._stagers = {}, {}, {}
+        self._graphs, self._eager_calls, self._stagers, self._ones = {}, {}, {}, {}
 
     def get_stage(self):
         return FIXED_STAGE
@@ -95,8 +95,11 @@ class DeepVoxelsUpdater(RGBDUpdater):
             for _, store in link.stores:
                 store.zero_grad(defer=bufs)
         kernels.zero_multi(bufs)                                   # one launch for all flat gradient buffers
-        with torch.no_grad():
-            st["x_real"] = downsize_real(st["x_real_full"], IMG_SIZE).contiguous()
+        if st.get("real_idx") is not None:
+            st["x_real"] = kernels.real_batch(st["real_data"], st["real_idx"], IMG_SIZE)
+        else:
+            with torch.no_grad():
+                st["x_real"] = downsize_real(st["x_real_full"], IMG_SIZE).contiguous()
         group = getattr(self.dis, "pack_group", None)
         if group is not None:
             group.layers[0].packed()
@@ -110,8 +113,11 @@ class DeepVoxelsUpdater(RGBDUpdater):
         st["adv_real"] = adv.detach()
         total = adv
         if not self.dis.sn and self.lambda_gp > 0:
+            ones = self._ones.get(tuple(y_real.shape))                 # chainer.grad seeds ones (a cached buffer: no sum / expand)
+            if ones is None:
+                ones = self._ones[tuple(y_real.shape)] = torch.ones_like(y_real)
             with Fn.input_grads_only():
-                g, = torch.autograd.grad([y_real.sum()], [x_real], create_graph=True)
+                g, = torch.autograd.grad([y_real], [x_real], [ones], create_graph=True)
             gp = Fn.r1_penalty(g, self.lambda_gp)              # lambda_gp * loss_l2(sqrt(sum g^2), 0) (:239-241), fused
             obs["dis/loss_gp"] = gp.detach()
             total = adv + gp
@@ -185,16 +191,31 @@ class DeepVoxelsUpdater(RGBDUpdater):
 
     def update_core(self, batch=None, z_fake=None, thetas=None):
         """z_fake: optional (z, z2, z_dis, z2_dis) injected by tests; otherwise drawn as the reference draws them."""
-        if batch is None:
-            batch = self.get_iterator("main").next()
-        B = len(batch)
+        real_idx = real_data = None
+        it = self.get_iterator("main") if batch is None else None
+        if it is not None and hasattr(it, "next_indices") and it.data.shape[1] == 3 and it.data.shape[2] == it.data.shape[3] \
+                and it.data.shape[2] % IMG_SIZE == 0:
+            # data set resident in HBM (as in RGBDUpdater.update_core): only the batch's indices move; gather + x / 127.5 - 1 +
+            # the block means of downsize_real are ONE kernel of the prep phase (rgbd_real_batch_u8) instead of six torch launches
+            idx = it.next_indices()
+            B = int(idx.numel())
+            key_i = ("real_idx", B)
+            if key_i not in self._stagers:
+                self._stagers[key_i] = torch.empty(B, dtype=torch.int64, device=self.device)
+            self._stagers[key_i].copy_(idx)
+            real_idx, real_data = self._stagers[key_i], it.data
+            x_real_full = None
+        else:
+            if batch is None:
+                batch = it.next()
+            B = len(batch)
+            x_real_full = self.get_x_real_data(batch, B)
         half = B // 2
-        x_real_full = self.get_x_real_data(batch, B)
         # host side, NumPy, as the reference: pose prior, camera matrices, pose code, warp constants
         thetas = np.asarray(self.prior.sample(B) if thetas is None else thetas, dtype="float32")
         cams = get_camera_matries(thetas)
         use_rotate = self.iteration > self.config.start_rotation
-        st = {"B": B, "use_rotate": use_rotate, "z": None}
+        st = {"B": B, "use_rotate": use_rotate, "z": None, "real_idx": real_idx, "real_data": real_data}
         st["cams"] = self._stager("cams", (B, 4, 4)).upload(cams)
         st["theta9"] = self._stager("theta9", (B, 9)).upload(pose_code(thetas))
         if use_rotate:
@@ -212,12 +233,14 @@ class DeepVoxelsUpdater(RGBDUpdater):
             st["z"] = zs
         key = None
         if self.use_graphs:
-            skey = ("x_real_full",) + tuple(x_real_full.shape)
-            if skey not in self._stagers:
-                self._stagers[skey] = torch.empty_like(x_real_full)
-            self._stagers[skey].copy_(x_real_full)
-            x_real_full = self._stagers[skey]
-            key = (B, use_rotate, tuple(x_real_full.shape), z_fake is not None, Fn.conv_dtype())
+            if x_real_full is not None:
+                skey = ("x_real_full",) + tuple(x_real_full.shape)
+                if skey not in self._stagers:
+                    self._stagers[skey] = torch.empty_like(x_real_full)
+                self._stagers[skey].copy_(x_real_full)
+                x_real_full = self._stagers[skey]
+            shape = tuple(x_real_full.shape) if x_real_full is not None else (B,) + tuple(real_data.shape[1:])
+            key = (B, use_rotate, shape, z_fake is not None, Fn.conv_dtype(), real_idx is not None)
         st["x_real_full"] = x_real_full
 
         self._replayed = False
