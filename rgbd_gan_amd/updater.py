@@ -15,12 +15,14 @@ gradients, same Adam updates), arranged for the GPU:
     dis  : D(x_real), R1 first-order pass, double backward with the adversarial seeds on the reals folded in
            (runs on a second stream, concurrently with gen)
     join : merge D's two gradient buffers;  opt : clip + Adam for map / gen / dis (+ EMA generator)
-prep .. join ("body") are captured once per configuration as ONE HIP graph with the two-stream fork / join inside it, the
-optimizer phase as a second one; a replayed step is two graph launches.
-Data-parallel: each optimizer's flat gradient buffer is all-reduced once (RCCL), outside the graphs: after the body, the
-generator's first, so that its Adam step runs under D's all-reduce (train_rgbd.py:154-156).  On ONE stream
-(RGBD_CONCURRENT_PHASES=0, fade-in stages, the shared-device tests) the body is captured as two graphs, split where the
-generator's gradients are final (after gen_b), and the map + gen all-reduces run under the discriminator half.
+Two streams (default): every phase is captured once per configuration as its own HIP graph and replayed on the stream it belongs
+to (generator phases on the main stream, discriminator phases and D's optimizer on a second one), stream events between the launches;
+one stream: the body as one graph (two under data parallelism) + the optimizer phase.
+Data-parallel: each optimizer's flat gradient buffer is all-reduced once (RCCL), outside the graphs (train_rgbd.py:154-156).  Two
+streams: D's all-reduce is enqueued from the side stream directly behind dfw and D's Adam step follows it there, under the generator's
+backward; the generator's all-reduces and Adam step follow gen_b on the main stream.  On ONE stream
+(RGBD_CONCURRENT_PHASES=0, the shared-device tests) the body is captured as two graphs, split where the generator's gradients are
+final (after gen_b), and the map + gen all-reduces run under the discriminator half.
 """
 import contextlib
 import math
@@ -979,10 +981,10 @@ class RGBDUpdater:
         if st["concurrent"]:
             # TWO STREAMS.  Every phase is its own captured graph, launched on the stream it belongs to, and the fork / join
             # dependencies are stream events between the launches:
-            #     main:  prep -> gen_a ----------> gen_b -> [all-reduce map, gen] -> join -> optimizers
-            #     side:       \-> dis ------\-> dfw ------------------------------/
-            # Same step time as ONE graph with the fork inside it (rounds 1-2); per-phase graphs let the data-parallel job
-            # start the generator's all-reduces at the end of gen_b instead of after the join.  (Overlap: events,
+            #     main:  prep -> gen_a ---------------------> gen_b -> [all-reduce map, gen] -> opt_g -> (wait side) -> join
+            #     side:       \-> dis --------\-> dfw + merge -> [all-reduce dis] -> opt_d ---------/
+            # ([..]: data parallel only.)  Same step time as ONE graph with the fork inside it (rounds 1-2); per-phase graphs let
+            # every optimizer's all-reduce start the moment ITS gradients are final, on the stream that produced them.  (Overlap: events,
             # scripts/phase_timeline.py, or a kernel trace through scripts/trace_overlap.py -- a small kernel's duration
             # in a trace is its stretched length under the other queue's chip-filling kernel, not its cost.)
             if self._side_stream is None:
