@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void trilinear_bwd_brick_kernel(FrustumArgs fa
     // sort by voxel is therefore a COUNTING sort in LDS (a histogram over 4096 relative positions, an exclusive scan that also
     // lists the occupied positions, a scatter) instead of a comparison sort (the 66-pass bitonic network of this kernel's first
     // form took as long as the row-wise kernel's atomics: 554 vs 648 us, scripts/time_trilinear_bwd.py).
-    __shared__ float tile[TB_S][33];
+    __shared__ __attribute__((aligned(16))) float tile[TB_S][36];     // row stride 144 B: 16-byte reads of four features
     __shared__ float cw[TB_S][8];
     __shared__ unsigned bins[TB_BINS];
     __shared__ unsigned short sorted_[TB_S * 8];      // (sample << 3 | corner), grouped by voxel
@@ -251,12 +251,14 @@ __global__ __launch_bounds__(256) void trilinear_bwd_brick_kernel(FrustumArgs fa
     __shared__ int box[4][3];
     __shared__ unsigned wsum[4];
     const int tid = threadIdx.x;
-    // workgroup ids go round the 8 XCDs: give each XCD a contiguous range of bricks, so that the two bricks that share every
-    // 128-byte line of dout (x neighbours: a brick row is 16 floats) meet in ONE L2
-    const int per_xcd = (nbricks + 7) >> 3;
-    const int brick = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
-    if (brick >= nbricks) return;
+    // PERSISTENT workgroups (two per CU): a workgroup walks brick PAIRS p = blockIdx, blockIdx + grid, ...; bricks 2p and 2p + 1 are
+    // x neighbours, which share every 128-byte line of dout (a brick row is 16 floats), so the second one finds its half in this CU's
+    // cache.  One launch per brick cost ~80 us per launch before a brick did anything (8960 workgroups of 74 KB LDS each, 40 % of them
+    // bricks that lie outside the grid and exit at once: profiles/r06/trilinear_bwd_bricks.txt).
     const int bricks_x = fa.W / TB_X, bricks_y = fa.H / TB_Y, bricks_d = (fa.D + TB_D - 1) / TB_D;
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int brick = 2 * (int)blockIdx.x; brick < nbricks; brick += (brick & 1) ? 2 * (int)gridDim.x - 1 : 1) {
+    __syncthreads();                                // the previous brick's fold has finished with the LDS images
     const int bxi = brick % bricks_x, byi = (brick / bricks_x) % bricks_y, bdi = (brick / (bricks_x * bricks_y)) % bricks_d;
     const int b = brick / (bricks_x * bricks_y * bricks_d);
     const int sx = tid & (TB_X - 1), sy = (tid >> 4) & (TB_Y - 1), sd = tid >> 7;
@@ -264,7 +266,8 @@ __global__ __launch_bounds__(256) void trilinear_bwd_brick_kernel(FrustumArgs fa
     const int n = (d * fa.H + (byi * TB_Y + sy)) * fa.W + bxi * TB_X + sx;
     float v[3];
     const bool live = d < fa.D && frustum_point(fa, cams + b * 16, n, v);
-    if (!__syncthreads_or(live)) return;            // the whole brick lies outside the grid (frustum corners)
+    if (!__syncthreads_or(live)) continue;          // the whole brick lies outside the grid (frustum corners)
+    if (ko == 8) { if (v[0] == 1.2345f) ws[0] = 1.f; return; }
     // the sample's dout values: requested now, parked in LDS behind the sort (their latency covers it)
     float dv[32];
 #pragma unroll
@@ -286,7 +289,6 @@ __global__ __launch_bounds__(256) void trilinear_bwd_brick_kernel(FrustumArgs fa
         cw[tid][6] = (x * y) * (1.f - z);
         cw[tid][7] = (x * y) * z;
     }
-    const int lane = tid & 63, wv = tid >> 6;
     {   // the brick's lowest corner voxel: wave minima by shuffles, the four waves' through LDS (no LDS atomics)
         int mx = cx0, my = cy0, mz = cz0;
 #pragma unroll
@@ -296,6 +298,7 @@ __global__ __launch_bounds__(256) void trilinear_bwd_brick_kernel(FrustumArgs fa
         if (lane == 0) { box[wv][0] = mx; box[wv][1] = my; box[wv][2] = mz; }
     }
     __syncthreads();
+    if (ko == 9) { if (box[0][0] == 12345 || dv[tid & 31] == 1.2345f) ws[0] = 1.f; return; }
     const int bx = min(min(box[0][0], box[1][0]), min(box[2][0], box[3][0]));
     const int by = min(min(box[0][1], box[1][1]), min(box[2][1], box[3][1]));
     const int bz = min(min(box[0][2], box[1][2]), min(box[2][2], box[3][2]));
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(256) void trilinear_bwd_brick_kernel(FrustumArgs fa
 #pragma unroll
                 for (int k = 0; k < 8; ++k) atomicAdd(base + (long)o[k] * F + f, dv[f] * cw[tid][k]);
         }
-        return;
+        continue;
     }
     if (live) {
 #pragma unroll
@@ -368,30 +371,52 @@ __global__ __launch_bounds__(256) void trilinear_bwd_brick_kernel(FrustumArgs fa
     }
     __syncthreads();
     if (ko == 3) { if (sorted_[tid] == 0xbeefu) ws[0] = 1.f; return; }
-    // fold: 8 groups of 32 feature lanes; a group takes every eighth occupied voxel and adds up that voxel's words (no comparisons:
-    // the voxel's range is known), eight words in flight at a time; ONE line atomic per occupied voxel
-    const int f = tid & 31, g = tid >> 5;
-    if (f >= F) return;
+    // fold: 32 groups of 8 lanes, a lane owns FOUR features (one 16-byte LDS read per word); a group takes every 32nd occupied
+    // voxel and adds up that voxel's words (no comparisons: the voxel's range is known), four words in flight at a time; then
+    // four atomics per lane = the voxel's 128-byte line.  (With 32 feature lanes per group -- one feature per lane -- the groups'
+    // serial chains of dependent LDS reads were four times as long and the fold took 260 of the kernel's 450 us.)
+    const int fq = (tid & 7) * 4, g = tid >> 3;
     const int G = fa.G;
-    float* base = ws + (long)b * G * G * G * F + f;
-    for (int j = g; j < nocc; j += 8) {
-        const int s0 = bstart[j], s1 = bstart[j + 1];
-        const unsigned k2 = bkey[j];
-        float acc = 0.f;
-        for (int i = s0; i < s1; i += 8) {
-            unsigned e[8];
-            float t[8], c[8];
+    float* wsb = ws + (long)b * G * G * G * F;
+    const int iters = (nocc + 31) >> 5;              // uniform: the hand-over below is a wave-wide exchange
+    for (int it = 0; it < iters; ++it) {
+        const int j = g + 32 * it;
+        const bool valid = j < nocc;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        int vo = -1;
+        if (valid) {
+            const int s0 = bstart[j], s1 = bstart[j + 1];
+            const unsigned k2 = bkey[j];
+            for (int i = s0; i < s1; i += 4) {
+                unsigned e[4];
+                f32x4 t[4];
+                float c[4];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) e[q] = sorted_[min(i + q, s1 - 1)];
+                for (int q2 = 0; q2 < 4; ++q2) e[q2] = sorted_[min(i + q2, s1 - 1)];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { t[q] = tile[e[q] >> 3][f]; c[q] = cw[0][e[q]]; }      // cw[s][k] = cw[0][s * 8 + k]
+                for (int q2 = 0; q2 < 4; ++q2) { t[q2] = *reinterpret_cast<const f32x4*>(&tile[e[q2] >> 3][fq]); c[q2] = cw[0][e[q2]]; }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc += i + q < s1 ? t[q] * c[q] : 0.f;
+                for (int q2 = 0; q2 < 4; ++q2) acc += (i + q2 < s1 ? c[q2] : 0.f) * t[q2];
+            }
+            vo = ((bx + (int)(k2 >> 8)) * G + by + (int)((k2 >> 4) & 15u)) * G + bz + (int)(k2 & 15u);
         }
-        const int gx = bx + (int)(k2 >> 8), gy = by + (int)((k2 >> 4) & 15u), gz = bz + (int)(k2 & 15u);
-        if (ko != 4) atomicAdd(base + (long)((gx * G + gy) * G + gz) * F, acc);
-        else if (acc == 1.2345f) base[0] = acc;
+        // hand-over inside the wave: its 8 groups hold 8 voxels x 32 features as (group, feature quad) x 4; the atomics want whole
+        // lines -- lane L of instruction c adds feature L & 31 of the voxel of group 2c + (L >> 5): 2 full 128-byte lines per
+        // instruction instead of 8 quarter lines (four scalar atomics per lane touched every line four times: 80 us per launch)
+#pragma unroll
+        for (int c2 = 0; c2 < 4; ++c2) {
+            const int f = lane & 31;
+            const int src = 8 * (2 * c2 + (lane >> 5)) + (f >> 2);
+            const float x0 = __shfl(acc[0], src), x1 = __shfl(acc[1], src), x2 = __shfl(acc[2], src), x3 = __shfl(acc[3], src);
+            const int vsrc = __shfl(vo, src);
+            const float val = (f & 2) ? ((f & 1) ? x3 : x2) : ((f & 1) ? x1 : x0);
+            if (vsrc >= 0 && f < F) {
+                if (ko != 4) atomicAdd(wsb + (long)vsrc * F + f, val);
+                else if (val == 1.2345f) wsb[0] = val;
+            }
+        }
     }
+    }   // bricks of this workgroup
 }
 
 // Forward from a FEATURE-MINOR grid (B, G^3, F) -- the layout the voxel generator's NHWC conv stack produces: the 32
@@ -874,9 +899,14 @@ extern "C" int rgbd_trilinear_bwd_frustum(const float* dout, const float* cam2wo
 #else
     constexpr int ko = 0;
 #endif
-    const int nbricks = (W / TB_X) * (H / TB_Y) * ((D + TB_D - 1) / TB_D) * B;
-    trilinear_bwd_brick_kernel<<<(unsigned)(((nbricks + 7) / 8) * 8), 256, 0, st>>>(f, cam2world, dout, dgrid_fm, F, W * H * D,
-                                                                                nbricks, ko);
+    const int nbricks = (W / TB_X) * (H / TB_Y) * ((D + TB_D - 1) / TB_D) * B;        // (W / 16 is even or the pairs straddle rows: harmless)
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        cus = prop.multiProcessorCount;
+    const int npairs = (nbricks + 1) / 2;
+    const int grid = npairs < 2 * cus ? npairs : 2 * cus;
+    trilinear_bwd_brick_kernel<<<(unsigned)grid, 256, 0, st>>>(f, cam2world, dout, dgrid_fm, F, W * H * D, nbricks, ko);
     RGBD_CHECK_LAUNCH("trilinear_bwd_brick_kernel");
     return 0;
 }
