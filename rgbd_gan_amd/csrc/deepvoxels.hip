@@ -792,6 +792,117 @@ __global__ __launch_bounds__(256) void occ_bwd_mlp_kernel(OccArgs a, const float
     for (int t = threadIdx.x; t < nparams; t += 256) partial[(long)blockIdx.x * nparams + t] = red[t];
 }
 
+// The same pass with FOUR consecutive voxels per thread (HW % 4 == 0): a wave reads and writes 1-KB runs of a feature plane with
+// 16-byte accesses instead of 256-byte runs with 4-byte ones, and a workgroup meets at its barrier once per 256 voxels instead of once
+// per 64 -- the one-voxel form moved its 620 MB at 1.9 TB/s (section 3 of DESIGN.md, round 6).  Same expressions per voxel; the
+// parameter-gradient sums are formed in another (still fixed) order.
+constexpr int OCC_VPT = 4;
+__global__ __launch_bounds__(256) void occ_bwd_mlp4_kernel(OccArgs a, const float* __restrict__ vol,
+                                                           const float* __restrict__ W1, const float* __restrict__ b1,
+                                                           const float* __restrict__ W2, const float* __restrict__ s,
+                                                           const float* __restrict__ ds, const float* __restrict__ w,
+                                                           const float* __restrict__ dfeat, float* __restrict__ dvol,
+                                                           float* __restrict__ partial) {
+    __shared__ f32x4 hp[2][4][OCC_NF][64];
+    __shared__ float red[OCC_NPARAM_MAX];
+    const int v = threadIdx.x & 63;
+    const int fg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), f0 = fg * OCC_FG;
+    const long vox = (long)a.D * a.HW;
+    const long total = (long)a.B * vox;
+    const int F1 = a.F + 1, nW1 = OCC_NF * F1;
+    float w1[OCC_NF][OCC_FG], w10[OCC_NF], bb[OCC_NF], w2[OCC_NF];
+    float g[OCC_NF][OCC_FG], g0[OCC_NF], gb1[OCC_NF], gW2[OCC_NF], gb2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < OCC_NF; ++j) {
+        w10[j] = W1[j * F1]; bb[j] = b1[j]; w2[j] = W2[j] * a.c2;
+        g0[j] = 0.f; gb1[j] = 0.f; gW2[j] = 0.f;
+#pragma unroll
+        for (int k = 0; k < OCC_FG; ++k) {
+            w1[j][k] = f0 + k < a.F ? W1[j * F1 + 1 + f0 + k] : 0.f;
+            g[j][k] = 0.f;
+        }
+    }
+    const long nchunks = (total + 255) / 256;
+    int buf = 0;
+    for (long c = blockIdx.x; c < nchunks; c += gridDim.x, buf ^= 1) {      // block-uniform trip count
+        const long i = c * 256 + 4 * v;                                     // first of this thread's four voxels
+        const bool live = i < total;                                        // (total % 4 == 0: all four or none)
+        const long ii = live ? i : total - 4;
+        const int b = (int)(ii / vox);
+        const long r = ii - (long)b * vox;
+        const int d = (int)(r / a.HW);
+        const int p = (int)(r - (long)d * a.HW);
+        f32x4 x[OCC_FG], df[OCC_FG];
+#pragma unroll
+        for (int k = 0; k < OCC_FG; ++k) {
+            const bool ok = f0 + k < a.F;
+            const long plane = (long)b * a.F + (ok ? f0 + k : 0);
+            x[k] = *reinterpret_cast<const f32x4*>(vol + plane * vox + r) * (ok ? a.c1 : 0.f);
+            df[k] = *reinterpret_cast<const f32x4*>(dfeat + plane * a.HW + p) * (ok ? 1.f : 0.f);
+        }
+        const f32x4 sv = *reinterpret_cast<const f32x4*>(s + ii), dsv = *reinterpret_cast<const f32x4*>(ds + ii),
+                    wd = *reinterpret_cast<const f32x4*>(w + ii);
+#pragma unroll
+        for (int j = 0; j < OCC_NF; ++j) {
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < OCC_FG; ++k) t += w1[j][k] * x[k];
+            hp[buf][fg][j][v] = t;
+        }
+        __syncthreads();
+        const float xc = depth_coord(d, a.D) * a.c1;
+        f32x4 dpre1[OCC_NF];
+        f32x4 dpre2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dpre2[e] = live ? dsv[e] * sv[e] * (1.f - sv[e]) : 0.f;
+#pragma unroll
+        for (int j = 0; j < OCC_NF; ++j) {
+            const f32x4 hsum = (hp[buf][0][j][v] + hp[buf][1][j][v]) + (hp[buf][2][j][v] + hp[buf][3][j][v]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float h = (bb[j] + w10[j] * xc) + hsum[e];
+                const float ha = h > 0.f ? h : 0.2f * h;
+                const float d1 = w2[j] * dpre2[e] * (h > 0.f ? 1.f : 0.2f);
+                dpre1[j][e] = d1;
+                g0[j] += d1 * xc;                  // (these four are read from wave 0 only)
+                gb1[j] += d1;
+                gW2[j] += dpre2[e] * a.c2 * ha;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gb2 += dpre2[e];
+#pragma unroll
+        for (int k = 0; k < OCC_FG; ++k) {
+            f32x4 dx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < OCC_NF; ++j) {
+                dx += w1[j][k] * dpre1[j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[j][k] += dpre1[j][e] * x[k][e];
+            }
+            if (live && f0 + k < a.F)
+                *reinterpret_cast<f32x4*>(dvol + ((long)b * a.F + f0 + k) * vox + r) = wd * df[k] + dx * a.c1;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < OCC_NF; ++j) {
+#pragma unroll
+        for (int k = 0; k < OCC_FG; ++k) {
+            const float t = wave_sum(g[j][k]);
+            if (v == 0 && f0 + k < a.F) red[j * F1 + 1 + f0 + k] = t;
+        }
+        const float t0 = wave_sum(g0[j]), t1 = wave_sum(gb1[j]), t2 = wave_sum(gW2[j]);
+        if (v == 0 && fg == 0) { red[j * F1] = t0; red[nW1 + j] = t1; red[nW1 + OCC_NF + j] = t2; }
+    }
+    {
+        const float t3 = wave_sum(gb2);
+        if (v == 0 && fg == 0) red[nW1 + 2 * OCC_NF] = t3;
+    }
+    __syncthreads();
+    const int nparams = nW1 + 2 * OCC_NF + 1;
+    for (int t = threadIdx.x; t < nparams; t += 256) partial[(long)blockIdx.x * nparams + t] = red[t];
+}
+
 // dparams[t] = sum over the rows of `partial` (one per block of occ_bwd_mlp_kernel), in row order
 __global__ __launch_bounds__(256) void occ_bwd_params_kernel(const float* __restrict__ partial, int nrows, int nparams,
                                                              float* __restrict__ dparams) {
@@ -978,8 +1089,16 @@ extern "C" int rgbd_occlusion_accum_bwd(const float* vol, const float* W1, const
     long nblocks = nchunks < 1024 ? nchunks : 1024;
     if (nblocks * nparams > nv) nblocks = nv / nparams;          // (tiny volumes: as many rows as dw_ws holds)
     RGBD_REQUIRE(nblocks >= 1, "rgbd_occlusion_accum_bwd: volume smaller than the parameter-gradient row (%ld < %d)", nv, nparams);
-    occ_bwd_mlp_kernel<<<(unsigned)nblocks, 256, 0, st>>>(a, vol, W1, b1, W2, s, ds_ws, w, dfeat, dvol, dw_ws);
-    RGBD_CHECK_LAUNCH("occ_bwd_mlp_kernel");
+    if (HW % 4 == 0 && nv >= 1024 * 256 && ((uintptr_t)vol & 15) == 0 && ((uintptr_t)dvol & 15) == 0 && ((uintptr_t)s & 15) == 0 &&
+        ((uintptr_t)ds_ws & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)dfeat & 15) == 0) {
+        // four voxels per thread: 1-KB runs per feature plane, a quarter of the barriers (the step's volumes; small ones keep the
+        // one-voxel form below, whose row count `nblocks` was sized for 64-voxel chunks)
+        occ_bwd_mlp4_kernel<<<(unsigned)nblocks, 256, 0, st>>>(a, vol, W1, b1, W2, s, ds_ws, w, dfeat, dvol, dw_ws);
+        RGBD_CHECK_LAUNCH("occ_bwd_mlp4_kernel");
+    } else {
+        occ_bwd_mlp_kernel<<<(unsigned)nblocks, 256, 0, st>>>(a, vol, W1, b1, W2, s, ds_ws, w, dfeat, dvol, dw_ws);
+        RGBD_CHECK_LAUNCH("occ_bwd_mlp_kernel");
+    }
     occ_bwd_params_kernel<<<nparams, 256, 0, st>>>(dw_ws, (int)nblocks, nparams, dparams);
     RGBD_CHECK_LAUNCH("occ_bwd_params_kernel");
     return 0;
