@@ -130,7 +130,7 @@ def pmc_traffic(kernel, workload):
     # launch-profile labels of the DeepVoxels path that stand for one or several kernels of the library
     alias = {"trilinear_bwd_kernel": ("trilinear_bwd_brick_kernel", "trilinear_bwd_scatter_kernel"), "trilinear_fwd_kernel": ("trilinear_fwd_fm_kernel",),
              "occlusion_accum_fwd_kernel": ("occ_fwd_fused_kernel<32>", "occ_score_kernel", "occ_scan_kernel", "occ_compose_kernel"),
-             "occlusion_accum_bwd_kernel": ("occ_bwd_scan_kernel", "occ_bwd_mlp_kernel", "occ_bwd_dw_kernel", "occ_bwd_params_kernel")}
+             "occlusion_accum_bwd_kernel": ("occ_bwd_scan_kernel", "occ_bwd_mlp_kernel", "occ_bwd_mlp4_kernel", "occ_bwd_dw_kernel", "occ_bwd_params_kernel")}
     if kernel in alias:
         per_launch = [ks[n]["hbm_bytes_per_launch"] for n in alias[kernel] if n in ks]
         return (int(sum(per_launch)) if per_launch else None), prov
@@ -532,6 +532,10 @@ def run_workload(args, comm, device):
                                         "flops_per_launch_avg": f8 / n8, "timing": timing}
         line["kernels"] = table
         line["kernels_note"] = "per-kernel totals over the 2 extra eager steps of the roofline leg, not per step"
+        if getattr(prof, "outliers", None):
+            line["kernels_timing_outliers"] = {"replaced_by_their_shape_median": prof.outliers,
+                                               "note": "event pairs > 8x the median of the same kernel on the same shape: a host stall "
+                                                       "between the two event records, not a kernel duration (kernels.launch_profile)"}
     elif comm.size > 1 and not args.no_roofline:
         # keep the ranks in lock-step with rank 0's extra steps, in rank 0's arrangement: on one stream the all-reduces go
         # map, gen, dis; on two streams dis, map, gen -- ranks in different arrangements would pair different buffers
