@@ -128,7 +128,7 @@ def pmc_traffic(kernel, workload):
         return None, prov
     ks = prof["kernels"]
     # launch-profile labels of the DeepVoxels path that stand for one or several kernels of the library
-    alias = {"trilinear_bwd_kernel": ("trilinear_bwd_brick_kernel", "trilinear_bwd_scatter_kernel"), "trilinear_fwd_kernel": ("trilinear_fwd_fm_kernel",),
+    alias = {"trilinear_bwd_kernel": ("trilinear_bwd_brick_kernel", "trilinear_bwd_scatter_kernel"), "trilinear_fwd_kernel": ("trilinear_fwd_frustum_kernel", "trilinear_fwd_fm_kernel"),
              "occlusion_accum_fwd_kernel": ("occ_fwd_fused_kernel<32>", "occ_score_kernel", "occ_scan_kernel", "occ_compose_kernel"),
              "occlusion_accum_bwd_kernel": ("occ_bwd_scan_kernel", "occ_bwd_mlp_kernel", "occ_bwd_mlp4_kernel", "occ_bwd_dw_kernel", "occ_bwd_params_kernel")}
     if kernel in alias:

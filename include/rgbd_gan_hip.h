@@ -411,6 +411,10 @@ int rgbd_trilinear_bwd(const float* dout, const int32_t* idx, const float* coord
  * dout (B,F,W*H*D) fp32, cam2world (B,4,4) device fp32, dgrid_fm (B,G,G,G,F) zero-filled inside.
  * rgbd_trilinear_bwd_frustum_supported: W % 16 == 0, H % 8 == 0, F <= 32, G^3 <= 2^20. */
 int rgbd_trilinear_bwd_frustum_supported(int W, int H, int D, int G, int F);
+/* ... and the forward the same way: out (B,F,W*H*D) written completely (zeros outside the grid: no fill in front of it), values bit-identical
+ * to rgbd_trilinear_fwd_fm's on the elements the list holds.  F <= 32. */
+int rgbd_trilinear_fwd_frustum(const float* grid_fm, const float* cam2world, int B, int F, int W, int H, int D, int G,
+                               float voxel_size, float near_plane, float fx, float fy, float cx, float cy, float* out, void* stream);
 int rgbd_trilinear_bwd_frustum(const float* dout, const float* cam2world, int B, int F, int W, int H, int D, int G,
                                float voxel_size, float near_plane, float fx, float fy, float cx, float cy, float* dgrid_fm,
                                void* stream);

@@ -86,6 +86,8 @@ PROTOTYPES = {
     "rgbd_trilinear_fwd": ([_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P], c_int),
     "rgbd_trilinear_fwd_fm": ([_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P], c_int),
     "rgbd_trilinear_bwd_fm": ([_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P], c_int),
+    "rgbd_trilinear_fwd_frustum": ([_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float,
+                                    c_float, c_float, _P, _P], c_int),
     "rgbd_trilinear_bwd_frustum_supported": ([c_int, c_int, c_int, c_int, c_int], c_int),
     "rgbd_trilinear_bwd_frustum": ([_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float,
                                     c_float, c_float, _P, _P], c_int),

@@ -257,6 +257,8 @@ __global__ __launch_bounds__(256) void trilinear_bwd_brick_kernel(FrustumArgs fa
     // bricks that lie outside the grid and exit at once: profiles/r06/trilinear_bwd_bricks.txt).
     const int bricks_x = fa.W / TB_X, bricks_y = fa.H / TB_Y, bricks_d = (fa.D + TB_D - 1) / TB_D;
     const int lane = tid & 63, wv = tid >> 6;
+    // (the pair's two bricks on two workgroups of ONE XCD at the same time instead of back to back on one workgroup: 336 against
+    //  322 us, profiles/r06/trilinear_bwd_bricks.txt)
     for (int brick = 2 * (int)blockIdx.x; brick < nbricks; brick += (brick & 1) ? 2 * (int)gridDim.x - 1 : 1) {
     __syncthreads();                                // the previous brick's fold has finished with the LDS images
     const int bxi = brick % bricks_x, byi = (brick / bricks_x) % bricks_y, bdi = (brick / (bricks_x * bricks_y)) % bricks_d;
@@ -466,6 +468,58 @@ __global__ __launch_bounds__(256) void trilinear_fwd_fm_kernel(const float* __re
     const int p = tid & (TRI_S - 1), fq = tid >> 6;
     const int n = nn[p];
     if (n >= 0)
+        for (int f = fq; f < F; f += 4) out[((long)b * F + f) * N + n] = tile[p][f];
+}
+
+// The feature-minor forward WITHOUT the compacted list and WITHOUT a zero fill of its 293 MB output: a workgroup takes 64
+// consecutive frustum elements (a pixel row of a depth slice), recomputes their voxel coordinates from the camera
+// (frustum_point: bit for bit what the projection kernels compute), gathers as trilinear_fwd_fm_kernel does (same term order: the
+// same bits) and writes EVERY element of its runs -- zeros where the element lies outside the grid.  The list form cleared the
+// whole output first (a 293 MB fill per call) and then wrote the 55 % of it that lies inside.
+constexpr int TF_S = 64;     // elements per workgroup (with 256 the gather was a long chain per workgroup at three workgroups per CU: 165 us against 121)
+__global__ __launch_bounds__(256) void trilinear_fwd_frustum_kernel(FrustumArgs fa, const float* __restrict__ cams,
+                                                                    const float* __restrict__ grid, float* __restrict__ out,
+                                                                    int F, int N) {
+    __shared__ float tile[TF_S][33];
+    __shared__ int co[TF_S][8];
+    __shared__ float cw[TF_S][8];
+    __shared__ int lv[TF_S];
+    const int b = blockIdx.y;
+    const int n0 = blockIdx.x * TF_S;
+    const int tid = threadIdx.x;
+    if (tid < TF_S) {
+        const int n = n0 + tid;
+        float v[3];
+        const bool live = n < N && frustum_point(fa, cams + b * 16, n, v);
+        if (live) {
+            const Corners c = trilinear_corners_at(v[2], v[1], v[0], fa.G);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { co[tid][k] = c.o[k]; cw[tid][k] = c.w[k]; }
+        }
+        lv[tid] = live ? 1 : 0;
+    }
+    __syncthreads();
+    const int G = fa.G;
+    const long g3 = (long)G * G * G;
+    {
+        const int f = tid & 31, e0 = tid >> 5;
+        if (f < F) {
+            const float* g = grid + (long)b * g3 * F + f;
+            for (int e = e0; e < TF_S; e += 8) {
+                float acc = 0.f;
+                if (lv[e]) {
+                    acc = g[(long)co[e][0] * F] * cw[e][0];
+#pragma unroll
+                    for (int k = 1; k < 8; ++k) acc = acc + g[(long)co[e][k] * F] * cw[e][k];
+                }
+                tile[e][f] = acc;
+            }
+        }
+    }
+    __syncthreads();
+    const int p = tid & (TF_S - 1), fq = tid >> 6;
+    const int n = n0 + p;
+    if (n < N)
         for (int f = fq; f < F; f += 4) out[((long)b * F + f) * N + n] = tile[p][f];
 }
 
@@ -796,7 +850,6 @@ __global__ __launch_bounds__(256) void occ_bwd_mlp_kernel(OccArgs a, const float
 // 16-byte accesses instead of 256-byte runs with 4-byte ones, and a workgroup meets at its barrier once per 256 voxels instead of once
 // per 64 -- the one-voxel form moved its 620 MB at 1.9 TB/s (section 3 of DESIGN.md, round 6).  Same expressions per voxel; the
 // parameter-gradient sums are formed in another (still fixed) order.
-constexpr int OCC_VPT = 4;
 __global__ __launch_bounds__(256) void occ_bwd_mlp4_kernel(OccArgs a, const float* __restrict__ vol,
                                                            const float* __restrict__ W1, const float* __restrict__ b1,
                                                            const float* __restrict__ W2, const float* __restrict__ s,
@@ -984,6 +1037,19 @@ extern "C" int rgbd_trilinear_bwd_fm(const float* dout, const int32_t* idx, cons
     }
     trilinear_bwd_scatter_kernel<<<dim3((N + TRI_S - 1) / TRI_S, B), 256, 0, st>>>(dout, idx, coords, counts, dgrid_fm, F, G, N);
     RGBD_CHECK_LAUNCH("trilinear_bwd_scatter_kernel");
+    return 0;
+}
+
+extern "C" int rgbd_trilinear_fwd_frustum(const float* grid_fm, const float* cam2world, int B, int F, int W, int H, int D, int G,
+                                          float voxel_size, float near_plane, float fx, float fy, float cx, float cy, float* out,
+                                          void* stream) {
+    RGBD_REQUIRE(grid_fm && cam2world && out, "rgbd_trilinear_fwd_frustum: null pointer");
+    RGBD_REQUIRE(B > 0 && F > 0 && F <= 32 && G > 0 && W > 0 && H > 0 && D > 0 && (long)W * H * D < (1l << 24),
+                 "rgbd_trilinear_fwd_frustum: needs 0 < F <= 32 and fewer than 2^24 frustum elements (F=%d)", F);
+    const int N = W * H * D;
+    FrustumArgs f{W, H, D, G, voxel_size, near_plane, fx, fy, cx, cy};
+    trilinear_fwd_frustum_kernel<<<dim3((N + TF_S - 1) / TF_S, B), 256, 0, (hipStream_t)stream>>>(f, cam2world, grid_fm, out, F, N);
+    RGBD_CHECK_LAUNCH("trilinear_fwd_frustum_kernel");
     return 0;
 }
 

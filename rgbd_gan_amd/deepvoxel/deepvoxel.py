@@ -83,6 +83,52 @@ class _TrilinearFM(torch.autograd.Function):
         return dgrid, None, None, None, None
 
 
+class _TrilinearFrustum(torch.autograd.Function):
+    """The feature-minor resampling straight from the cameras (ProjectionHelper.frustum): no compacted list, no fill of the output
+    in front of the forward (every element is written, zeros outside the grid), the backward over sorted bricks."""
+
+    @staticmethod
+    def forward(ctx, grid, cams, fr):
+        grid = grid.contiguous()
+        B, G, F = grid.shape[0], grid.shape[1], grid.shape[4]
+        W, H, D = fr[1], fr[2], fr[3]
+        N = W * H * D
+        out = torch.empty(B, F, N, dtype=torch.float32, device=grid.device)
+        rc = _timed("trilinear_fwd_kernel", 0.0, 4.0 * B * F * (G ** 3 + N),
+                    lambda: _lib.load().rgbd_trilinear_fwd_frustum(_ptr(grid), _ptr(cams), B, F, W, H, D, G, fr[5], fr[6], fr[7], fr[8],
+                                                                   fr[9], fr[10], _ptr(out), _stream()))
+        _lib.check(rc, "rgbd_trilinear_fwd_frustum")
+        ctx.save_for_backward(cams)
+        ctx.fr, ctx.dims = fr, (B, F, G, N)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout):
+        cams, = ctx.saved_tensors
+        fr = ctx.fr
+        B, F, G, N = ctx.dims
+        dgrid = torch.empty(B, G, G, G, F, dtype=torch.float32, device=dout.device)
+        dout = dout.contiguous()
+        rc = _timed("trilinear_bwd_kernel", 0.0, 4.0 * B * F * (G ** 3 + N),
+                    lambda: _lib.load().rgbd_trilinear_bwd_frustum(_ptr(dout), _ptr(cams), B, F, fr[1], fr[2], fr[3], G, fr[5], fr[6],
+                                                                   fr[7], fr[8], fr[9], fr[10], _ptr(dgrid), _stream()))
+        _lib.check(rc, "rgbd_trilinear_bwd_frustum")
+        return dgrid, None, None
+
+
+def frustum_kernels_apply(fr, F, B):
+    """Can the list-free kernels take this frustum?  (16 x 8 bricks, <= 32 features, one camera per sample)"""
+    return (TRILINEAR_BWD_BRICKS and fr is not None and fr[0].is_cuda and fr[0].shape[0] == B and
+            bool(_lib.load().rgbd_trilinear_bwd_frustum_supported(fr[1], fr[2], fr[3], fr[4], F)))
+
+
+def interpolate_trilinear_frustum(grid_fm, fr):
+    """grid_fm (B,G,G,G,F) fp32, fr = ProjectionHelper.frustum(cameras) -> (B,F,depth,H,W)."""
+    out = _TrilinearFrustum.apply(grid_fm, fr[0], tuple(fr))
+    return out.reshape(grid_fm.shape[0], grid_fm.shape[4], fr[3], fr[2], fr[1])
+
+
 def interpolate_trilinear_batch(grid, idx, coords, counts, img_shape, frustrum_depth, feature_minor=False):
     """grid (B,F,G,G,G) [feature_minor: (B,G,G,G,F)]; idx/coords/counts from ProjectionHelper.compute_proj_idcs_batch ->
     (B,F,depth,H,W)."""

@@ -33,6 +33,16 @@ class ProjectionHelper:
     def num_frust_elements(self):
         return self.projection_image_dims[0] * self.projection_image_dims[1] * self.frustrum_depth
 
+    def frustum(self, cam2world):
+        """What the frustum kernels that work straight from the cameras need (rgbd_trilinear_{fwd,bwd}_frustum): the (B,16) camera
+        matrices on the device + the frustum's constants -- no index list, no compaction."""
+        cams = torch.as_tensor(np.asarray(cam2world, dtype="float32") if not torch.is_tensor(cam2world) else cam2world)
+        cams = cams.to(self.device, torch.float32).reshape(-1, 16).contiguous()
+        K = self.projection_intrinsic
+        W, H = self.projection_image_dims[0], self.projection_image_dims[1]
+        return (cams, int(W), int(H), int(self.frustrum_depth), int(self.grid_dims[2]), float(self.voxel_size),
+                float(self.near_plane), float(K[0][0]), float(K[1][1]), float(K[0][2]), float(K[1][2]))
+
     def compute_proj_idcs_batch(self, cam2world):
         """cam2world (B,4,4) -> idx (B,N) int32, coords (B,3,N) fp32 (compacted in order), counts (B,) int32."""
         cams = torch.as_tensor(np.asarray(cam2world, dtype="float32") if not torch.is_tensor(cam2world) else cam2world)

@@ -28,7 +28,8 @@ import torch
 import torch.nn.functional as F
 
 from . import functional as Fn
-from .deepvoxel.deepvoxel import accumulative_occlusion, interpolate_trilinear_batch
+from .deepvoxel.deepvoxel import (accumulative_occlusion, frustum_kernels_apply, interpolate_trilinear_batch,
+                                  interpolate_trilinear_frustum)
 from .deepvoxel.projection import ProjectionHelper
 from .net import BF16, SQRT2, _Link, _as_device_tensor, _inv_c
 from .params import ParamStore
@@ -356,9 +357,12 @@ class DeepVoxels:
         self.voxel_size, self.near_plane = voxel_size, near_plane
         self.threshold = threshold if threshold else 4           # deepvoxel.py:555
 
-    def __call__(self, idx, coords, counts, deepvoxels, feature_minor=False):
-        vol = interpolate_trilinear_batch(deepvoxels, idx, coords, counts, self.frustrum_img_dims, self.frustrum_depth,
-                                          feature_minor=feature_minor)
+    def __call__(self, idx, coords, counts, deepvoxels, feature_minor=False, frustum=None):
+        if frustum is not None:             # straight from the cameras: no index list (Generator.__call__ decides)
+            vol = interpolate_trilinear_frustum(deepvoxels, frustum)
+        else:
+            vol = interpolate_trilinear_batch(deepvoxels, idx, coords, counts, self.frustrum_img_dims, self.frustrum_depth,
+                                              feature_minor=feature_minor)
         p = self.p
         W1, W2 = p["0/net/1/c/W"], p["2/net/1/c/W"]
         feats, depth, _ = accumulative_occlusion(vol, W1.reshape(W1.shape[0], W1.shape[1]), p["0/net/1/c/b"],
@@ -425,7 +429,6 @@ class Generator(_Link):
         return z / torch.sqrt(torch.sum(z * z, dim=1, keepdim=True) / self.ch + 1e-8)
 
     def __call__(self, z, stage, camera_matrices, z2=None, z3=None, z4=None, theta=None):
-        idx, coords, counts = self.projection.compute_proj_idcs_batch(camera_matrices)
         z = _as_device_tensor(z, self.device)
         if z2 is None:
             z2 = self.make_hidden(z.shape[0])
@@ -440,7 +443,14 @@ class Generator(_Link):
             w, w2 = self.mapping(z), self.mapping(z2)
         fm = w.is_cuda
         voxel = self.voxel_gen(w, feature_minor=fm)
-        novel_feats, depth = self.deepvoxel(idx, coords, counts, voxel, feature_minor=fm)
+        # the frustum's index list (deepvoxel/projection.py:48-105: three launches + 2 x 9 MB of lists per call) is only built when
+        # the resampling needs it: the feature-minor kernels work straight from the cameras
+        fr = self.projection.frustum(camera_matrices) if fm else None
+        if fm and frustum_kernels_apply(fr, voxel.shape[-1], voxel.shape[0]):
+            novel_feats, depth = self.deepvoxel(None, None, None, voxel, feature_minor=True, frustum=fr)
+        else:
+            idx, coords, counts = self.projection.compute_proj_idcs_batch(camera_matrices)
+            novel_feats, depth = self.deepvoxel(idx, coords, counts, voxel, feature_minor=fm)
         novel_img = self.style_generator(novel_feats, w2, stage)
         return torch.cat([novel_img, depth], dim=1)
 

@@ -93,6 +93,15 @@ def test_hip_trilinear_forward_backward():
     lin, v = odv.proj_idcs_np(cams[0], fr)
     o1 = dv.interpolate_trilinear(grid[:1].cuda(), torch.from_numpy(lin).cuda(), torch.from_numpy(v).cuda(), [64, 64], fr.depth)
     torch.testing.assert_close(o1.cpu(), outs[0], atol=1e-5, rtol=1e-5)
+    # straight from the cameras (ProjectionHelper.frustum -> rgbd_trilinear_fwd_frustum / rgbd_trilinear_bwd_frustum): no index list, no
+    # zero fill in front of the forward -- every element written, bit-identical to the list forward, zeros outside the grid
+    fru = ph.frustum(cams)
+    assert dv.frustum_kernels_apply(fru, 8, 2)
+    gfr = grid.permute(0, 2, 3, 4, 1).contiguous().cuda().requires_grad_(True)
+    ofr = dv.interpolate_trilinear_frustum(gfr, fru)
+    assert torch.equal(ofr.detach(), ofm.detach())
+    ofr.backward(dout.cuda())
+    torch.testing.assert_close(gfr.grad.permute(0, 4, 1, 2, 3).cpu(), torch.cat(grads), atol=1e-3, rtol=1e-4)
     # the two forms of the feature-minor backward at the step's size (32 features): the row-wise list kernel (one line atomic
     # per run of equal voxels along a pixel row) and the sorted bricks (rgbd_trilinear_bwd_frustum: voxel coordinates recomputed
     # from the cameras, one line atomic per distinct voxel of a 16 x 8 x 2 brick) add up the same contributions
