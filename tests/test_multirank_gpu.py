@@ -119,11 +119,11 @@ def test_graph_replay_equals_eager_step(tmp_path):
 def test_two_stream_replay_at_the_sizes_that_used_to_fail(tmp_path, batch):
     """While the library was built with packed-fp32 instructions the two-stream replay gave wrong generator gradients in 9-11
     of 12 runs at these batch sizes (the warp-loss backward's v_pk_* arithmetic next to the other stream's MFMA waves,
-    DESIGN.md section 3).  Three runs each against the eager single-stream step."""
+    DESIGN.md section 3).  Two runs each against the eager single-stream step (three until round 6: the suite's wall time)."""
     flags = ["--calls", "4", "--stage", "10.0", "--batch", str(batch)]
     _wait([_run(tmp_path / "eager.npz", *flags, "--eager", "--sequential")])
     e = np.load(tmp_path / "eager.npz")
-    for rep in range(3):
+    for rep in range(2):
         _wait([_run(tmp_path / f"two{rep}.npz", *flags, "--concurrent")])
         two = np.load(tmp_path / f"two{rep}.npz")
         _compare(two, e, f"two-stream replay vs eager, batch {batch}, run {rep}", SAME_STEP, exact_upd=2e-2)
@@ -210,7 +210,7 @@ def test_generator_allreduce_under_the_discriminator_half_changes_nothing(tmp_pa
     same-arrangement noise floor, every time."""
     ref = _two_ranks(tmp_path, "whole", 10.0, "--no-dp-split")
     assert int(ref["n_graphs"]) == 3
-    for rep in range(3):
+    for rep in range(2):
         got = _two_ranks(tmp_path, f"split{rep}", 10.0)
         assert int(got["n_graphs"]) == 4
         _compare(got, ref, f"split body vs whole body, 2 ranks, run {rep}", SAME_STEP, exact_upd=2e-2)
@@ -223,7 +223,7 @@ def test_two_real_ranks_on_two_streams_each(tmp_path):
     same Adam steps on both ranks."""
     one = _two_ranks(tmp_path, "one", 10.0)
     assert int(one["n_graphs"]) == 4
-    for rep in range(2):
+    for rep in range(1):
         port = _free_port()
         _wait([_run(tmp_path / f"two{rep}_{r}.npz", "--calls", "4", "--stage", "10.0", "--concurrent",
                     env=_rank_env(tmp_path, r, port)) for r in range(2)])
