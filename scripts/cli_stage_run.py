@@ -22,6 +22,8 @@ from rgbd_gan_amd.utils.synthetic import procedural_images      # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--iterations", type=int, default=900)
 ap.add_argument("--batch", type=int, default=8)
+ap.add_argument("--full", action="store_true", help="the whole schedule compressed: 32x32 -> fade -> 64x64 -> fade -> 128x128, a sixth of the "
+                "iterations each stage (and a third for the last)")
 a = ap.parse_args()
 tmp = tempfile.mkdtemp(prefix="rgbd_cli_")
 os.makedirs(os.path.join(tmp, "data"))
@@ -32,6 +34,8 @@ n = a.iterations
 # 120-step measurement, which is dropped -- then the fade-in 7.x to 64x64 (its own measurement) until n/2, then stage 8.x (64x64: the same
 # batch and image size, so the measured pair carries over)
 si = [0] * 7 + [60, n // 2, 10 * n, 11 * n, 12 * n]
+if a.full:
+    si = [0] * 7 + [n // 6, n // 3, n // 2, 2 * n // 3, n]
 cfg.update(dataset_path=os.path.join(tmp, "data"), out=os.path.join(tmp, "out"), iteration=n, batchsize=a.batch,
            stage_interval=",".join(str(x) for x in si), snapshot_interval=n // 3, display_interval=max(10, n // 18),
            evaluation_sample_interval=n // 3, start_rotation=20, start_occlusion_aware=20)
