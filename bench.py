@@ -426,7 +426,10 @@ def run_workload(args, comm, device):
                                    "(fp32 accumulate, bf16 activations in HBM), weight gradients and the layers the fp8 kernel "
                                    "does not cover on bf16" if args.fp8 else "")),
                    "per_gpu_batch": B, "global_batch": B * comm.size, "parallelism": f"dp{comm.size}",
-                   "arrangement": "two streams, one graph per phase" if getattr(upd, "concurrent_phases", False) else "one stream",
+                   "arrangement": ("two streams, one graph per phase"
+                                   + (", the next step's generator forward on the side stream under this step's dis_fake phase "
+                                      f"(sized for {upd.forward_cu_budget} CUs)" if getattr(upd, "prefetch_forward", False) else ""))
+                   if getattr(upd, "concurrent_phases", False) else "one stream",
                    # True only if the timed steps were replays of captured HIP graphs (a refused capture is fatal in the
                    # updater: graph_fallback is off)
                    "graphs": bool(getattr(upd, "graphs_in_use", upd.use_graphs)),

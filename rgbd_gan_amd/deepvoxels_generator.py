@@ -118,9 +118,10 @@ class MappingNetwork3D(_Link):
     def __call__(self, x):
         h = Fn.pixel_norm(_as_device_tensor(x, self.device).reshape(x.shape[0], -1))
         p = self.store.params
-        for i in range(0, 16, 2):
-            h = Fn.linear_act(h, p[f"l/{i}/c/W"], p[f"l/{i}/c/b"], self.inv_c, act=True)
-        return h
+        # one launch per pass (rgbd_mlp_fwd / rgbd_mlp_bwd, as net.MappingNetwork) where the width is covered; the mapping sits
+        # at the head of both generator passes of a step, on the critical path
+        return Fn.mlp_chain(h, [p[f"l/{i}/c/W"] for i in range(0, 16, 2)], [p[f"l/{i}/c/b"] for i in range(0, 16, 2)],
+                            self.inv_c)
 
     forward = __call__
 
@@ -215,8 +216,9 @@ class VoxelGenerator(_Link, _StyleMixin):
                 self.c0.append(self._conv3d_layer(f"net/{i}/c0/c/W", ci))
             self.c1.append(self._conv3d_layer(f"net/{i}/c1/c/W", co))
         W = self.p["out/c/W"]
-        self.out = Fn.DerivedConvLayer(
-            lambda: _fold_w(W.reshape(W.shape[0], W.shape[1], 1, 1), 2), _inv_c(W.shape[1]), 1, 0)      # (5-D master: autograd path)
+        # (a 1x1x1 convolution: the 5-D master is the (Cout,Cin,1,1) matrix in memory -- padding-only fold, in the pack group)
+        self.out = Fn.DerivedConvLayer(lambda: _fold_w(W.reshape(W.shape[0], W.shape[1], 1, 1), 2), _inv_c(W.shape[1]), 1, 0,
+                                       master=W, fold=_fold_args(W, 2))
 
     def _conv3d_layer(self, name, cin):
         """(Cout,Cin,3,3,3) -> (Cout64, 3*Cin64, 3, 3) with input channel index kd*Cin64 + ci.
@@ -420,8 +422,16 @@ class Generator(_Link):
             # all conv weights of the generator (folded 3-D / stride-2 / padded layers and the plain ones): persistent
             # folded + packed images, rebuilt together and only after THIS network's optimizer step
             vg = self.voxel_gen
-            self.pack_group = Fn.DerivedPackGroup([l for l in vg.c0 + vg.c1 if l is not None]
+            self.pack_group = Fn.DerivedPackGroup([l for l in vg.c0 + vg.c1 if l is not None] + [vg.out]
                                                   + list(self.style_generator.layers.values()))
+
+    def mark_weight_images_current(self):
+        """The packed / folded weight images on the device are those of the current master weights (DeepVoxelsUpdater rebuilds them
+        right behind the generator's update, inside a captured phase: Python's epochs cannot know after a replay)."""
+        self.pack_group.mark_current()
+
+    def rebuild_weight_images(self):
+        self.pack_group.layers[0].packed()
 
     def make_hidden(self, batch_size):
         """:273-283."""

@@ -20,6 +20,8 @@ import torch.nn.functional as F
 from . import kernels
 
 _WEIGHT_EPOCH = 0          # bumped whenever master weights change (optimizer step, checkpoint load) ...
+_EXTERNAL_EPOCH = 0        # ... and this one only when they change OUTSIDE a training step (checkpoint load, parameter copy, dtype
+                           # switch): work a step has started for the next one (DeepVoxelsUpdater's generator forward) is stale then
 _STORE_EPOCH = {}          # ... of which the optimizer steps name the flat buffer they changed (by storage address): a layer whose
                            # master lives in another buffer keeps its packed images (the DeepVoxels step updates G in the middle
                            # and D at the end: without this G's 18 folded + 16 packed weights were rebuilt twice per step)
@@ -89,14 +91,21 @@ def apply_mx8_coverage(generator, discriminator, spec):
     return spec
 
 
-def bump_weight_epoch(flat=None):
-    """Master weights changed: everywhere (flat=None), or in the one flat parameter buffer `flat`."""
-    global _WEIGHT_EPOCH
+def bump_weight_epoch(flat=None, own_step=False):
+    """Master weights changed: everywhere (flat=None), or in the one flat parameter buffer `flat`.  own_step: the caller is an
+    updater invalidating Python's view behind its own replayed step (not an outside change)."""
+    global _WEIGHT_EPOCH, _EXTERNAL_EPOCH
     if flat is None:
         _WEIGHT_EPOCH += 1
+        if not own_step:
+            _EXTERNAL_EPOCH += 1
     else:
         key = flat.untyped_storage().data_ptr()
         _STORE_EPOCH[key] = _STORE_EPOCH.get(key, 0) + 1
+
+
+def external_epoch():
+    return _EXTERNAL_EPOCH
 
 
 def _epoch_of(w):
@@ -236,6 +245,13 @@ class PackGroup:
             entries.append((w, l.inv_c) + f + d)
         self.mx_table = kernels.build_pack_table_mx8(entries) if entries else ()
 
+    def mark_current(self):
+        """The persistent images ARE those of the current master weights (a captured phase rebuilt them on the device behind the
+        last change, whatever Python's epochs say after a replay): the next packed() does not rebuild them."""
+        for l in self.layers:
+            if l._wf is not None:
+                l._epoch = l._now()
+
     def repack(self):
         with torch.no_grad():
             kernels.pack_weights_multi(self.table)
@@ -283,7 +299,7 @@ class DerivedPackGroup(PackGroup):
             for l in self.layers:
                 if isinstance(l, DerivedConvLayer):
                     mode, cop, cip = l.fold
-                    m = l.master.detach().contiguous()
+                    m = _master4(l.master.detach().contiguous(), mode)
                     folds.append((m, l._fold_buf, mode, m.shape[0], m.shape[1], m.shape[-1], cop, cip, False))
             kernels.fold_weight_multi(folds)                       # all folds of the network: one launch
             kernels.pack_weights_multi(self.table)
@@ -353,13 +369,20 @@ def deferred_wgrads(items):
         _DEFERRED = old
 
 
+def _master4(t, mode):
+    """A 1x1x1 / KxK master of the padding-only fold seen as (Co,Ci,K,K) (the 3-D generator keeps its 1x1x1 convolutions'
+    parameters 5-D, deepvoxels_generator.py:186: same memory)."""
+    return t if mode == 0 or t.dim() == 4 else t.view(t.shape[0], t.shape[1], t.shape[-1], t.shape[-1])
+
+
 def run_deferred_wgrads(items):
     kernels.conv2d_wgrad_batch([it[:7] for it in items])
     folds = []
     for it in items:
         if len(it) > 7:                       # derived layer: folded gradient -> master gradient (accumulating adjoint)
             master, (mode, cop, cip) = it[7]
-            folds.append((it[2], master.grad, mode, master.shape[0], master.shape[1], master.shape[-1], cop, cip, True))
+            folds.append((it[2], _master4(master.grad, mode), mode, master.shape[0], master.shape[1], master.shape[-1], cop, cip,
+                          True))
     kernels.fold_weight_multi(folds)          # ... of all derived layers of the pass: one launch
 
 
@@ -1628,6 +1651,7 @@ class _FoldView(torch.autograd.Function):
     def forward(ctx, W, layer):
         mode, cop, cip = layer.fold
         ctx.args = (mode, W.shape[0], W.shape[1], W.shape[-1], cop, cip)
+        ctx.master_shape = tuple(W.shape)
         ctx.set_materialize_grads(False)
         return layer._fold_buf.view(layer._fold_buf.shape)     # (a fresh alias: the buffer itself is not an input)
 
@@ -1636,7 +1660,7 @@ class _FoldView(torch.autograd.Function):
     def backward(ctx, g):
         if g is None:
             return None, None
-        return kernels.fold_weight(g.contiguous(), *ctx.args, adjoint=True), None
+        return kernels.fold_weight(g.contiguous(), *ctx.args, adjoint=True).view(ctx.master_shape), None
 
 
 def fold_weight(W, mode, Cop, Cip):

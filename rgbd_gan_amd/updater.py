@@ -798,7 +798,7 @@ class RGBDUpdater:
                                                              if saved.get(k) is not v}}
             self._graphs[gkey] = entry
         else:
-            st.update({k: v for k, v in entry["st"].items() if k in ("x_real", "x_fake_data", "loss_dfake", "dfw")})
+            st.update({k: v for k, v in entry["st"].items() if k in ("x_real", "x_fake_data", "loss_dfake", "dfw", "fwd_x_fake")})
             self.observation.update(entry["obs"])
         entry["graph"].replay()
         self._replayed = True
@@ -1071,7 +1071,7 @@ class RGBDUpdater:
         else:
             self._run_phase("opt", self._opt_phase, st, key)
         if key is not None or st.get("d_step_on_side"):
-            Fn.bump_weight_epoch()      # replays change the weights behind Python's back: invalidate packed caches
+            Fn.bump_weight_epoch(own_step=True)      # replays change the weights behind Python's back: invalidate packed caches
 
         obs = self.observation
         obs["stage"], obs["batch_size"], obs["image_size"] = stage, batch_size, int(st["x_real"].shape[2])

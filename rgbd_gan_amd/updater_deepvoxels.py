@@ -17,6 +17,14 @@ on fakes of the UPDATED generator.  Only the second has to wait for the generato
     main:  prep -> gen (G fwd, frozen D, 3-D loss, G bwd, G update) ---------> join -> dis_fake (G' fwd, D fwd/bwd, D update)
     side:       +-> dis_real (D(x_real), R1 double backward, weight gradients) -/
 
+G' = G after its update is also the generator the NEXT step's generator phase starts from, and its forward pass needs nothing of
+the discriminator: with `prefetch_forward` (default where the step draws its own poses and latents; RGBD_DV_PREFETCH=0 turns it
+off) the generator phase is cut behind its forward pass, and the next step's forward runs on the side stream UNDER this step's
+dis_fake -- same arithmetic per step, 1.2 ms off the critical path (profiles/r06/c4_prefetch.txt):
+
+    main:  prep -> (wait fwd(n)) gen_rest(n): frozen D, 3-D loss, G bwd, G update, G's weight images -> (wait dis_real) dis_fake(n)
+    side:       +-> dis_real(n) ---------------------------------------------------> (wait G update) fwd(n+1): G'(z) of step n+1
+
 (`concurrent_phases=False` / RGBD_CONCURRENT_PHASES=0: the same four phases back to back on one stream -- identical
 arithmetic, same accumulation order.)  ~960 mostly small launches per step: the second stream fills the gaps between the
 first one's kernels.  Everything data dependent (the number of frustum samples inside the grid) stays on the device.
@@ -76,8 +84,16 @@ class DeepVoxelsUpdater(RGBDUpdater):
         self.concurrent_phases = bool(kwargs.pop("concurrent_phases", env is None or env not in ("", "0")))
         self.side_cu_budget = int(kwargs.pop("side_cu_budget", os.environ.get("RGBD_SIDE_CUS", "192")))
         self.side_wgrad_workgroups = int(kwargs.pop("side_wgrad_workgroups", os.environ.get("RGBD_SIDE_WGRAD_WGS", "128")))
+        env = os.environ.get("RGBD_DV_PREFETCH")
+        self.prefetch_forward = bool(kwargs.pop("prefetch_forward", env is None or env not in ("", "0"))) \
+            and not (comm is not None and comm.active)
+        # ... and the early forward pass, which has 3 ms of dis_fake to hide 2 ms under, fewer still (16 / 32 / 48 / 64 / 96 / 128 /
+        # 192 / all: 873 / 1130 / 1209 / 1239 / 1253 / 1233 / 1226 / 1224 img/s, profiles/r06/c4_prefetch.txt)
+        self.forward_cu_budget = int(kwargs.pop("forward_cu_budget", os.environ.get("RGBD_DV_FWD_CUS", "96")))
         self._side_stream = None
         self._graphs, self._eager_calls, self._stagers, self._ones = {}, {}, {}, {}
+        self._pf = None                 # the next step's generator forward in flight (see _start_forward)
+        self._events = {}
 
     def get_stage(self):
         return FIXED_STAGE
@@ -127,15 +143,34 @@ class DeepVoxelsUpdater(RGBDUpdater):
         with kernels.wgrad_workgroups(st.get("side_wgrad_wgs", 0)):
             Fn.run_deferred_wgrads(wgrads)
 
-    def _dv_gen_phase(self, st):
-        cfg, obs = self.config, self.observation
+    def _dv_gen_forward(self, st):
         half = st["B"] // 2
         if st["z"] is not None:
             z, z2 = st["z"][0], st["z"][1]
         else:                                                      # one latent per view PAIR (:146-148)
             z = self.get_z_fake_data(half).repeat(2, 1, 1, 1, 1)
             z2 = self.get_z_fake_data(half).repeat(2, 1, 1, 1, 1)
-        x_fake = self.gen(z, FIXED_STAGE, st["cams"], z2=z2, theta=st["theta9"])
+        return self.gen(z, FIXED_STAGE, st["cams"], z2=z2, theta=st["theta9"])
+
+    def _dv_gen_phase(self, st):
+        self._dv_gen_rest(st, self._dv_gen_forward(st))
+
+    # ---- ... and the generator phase cut behind its forward pass (prefetch_forward)
+    def _dv_gen_fwd_phase(self, sf):
+        sf["fwd_x_fake"] = self._dv_gen_forward(sf)
+
+    def _dv_gen_rest_phase(self, st):
+        # G's weight images on the device are current: the previous generator phase rebuilt them behind G's update (below), and
+        # a forward pass of these weights has run since.  Python's epochs do not know it after a replayed step.
+        self.gen.mark_weight_images_current()
+        self._dv_gen_rest(st, st["fwd"]["fwd_x_fake"], fwd_stream=st["fwd"].get("stream"))
+        # both readers of the updated generator -- this step's dis_fake and the next step's forward, on two streams -- find the
+        # images built (persistent buffers: functional.DerivedPackGroup)
+        self.gen.rebuild_weight_images()
+
+    def _dv_gen_rest(self, st, x_fake, fwd_stream=None):
+        cfg, obs = self.config, self.observation
+        half = st["B"] // 2
         # The gradient w.r.t. G's output is assembled by hand, as in RGBDUpdater._gen_backward (slicing, hinge, scaling and
         # the loss arithmetic were ~60 torch launches of a few microseconds each): the focal adversarial term and its
         # derivative from one launch (loss_func_dcgan_gen, :170), back through the frozen D to the RGB planes,
@@ -164,8 +199,13 @@ class DeepVoxelsUpdater(RGBDUpdater):
         # weight gradients are leaves of the backward pass: collected while it runs, issued as one batch afterwards (the
         # folded 3-D / stride-2 layers go through temporaries and the folds' adjoints into their masters' gradients)
         wgrads = []
+        cross = fwd_stream is not None and not torch.cuda.is_current_stream_capturing()
+        if cross:       # eager steps only (a capture is one stream): autograd runs G's backward nodes on the forward pass's stream
+            fwd_stream.wait_stream(torch.cuda.current_stream())
         with Fn.deferred_wgrads(wgrads):
             torch.autograd.backward([x_fake], [gout])
+        if cross:
+            torch.cuda.current_stream().wait_stream(fwd_stream)
         Fn.run_deferred_wgrads(wgrads)
         for name in ("map", "gen"):
             self.get_optimizer(name).update()
@@ -189,6 +229,49 @@ class DeepVoxelsUpdater(RGBDUpdater):
         Fn.run_deferred_wgrads(wgrads)
         self.get_optimizer("dis").update()
 
+    # ---- the next step's generator forward (prefetch_forward)
+    def _event(self, name):
+        if name not in self._events:
+            self._events[name] = torch.cuda.Event()
+        return self._events[name]
+
+    def _forward_record(self, B, key, thetas, cams):
+        """What a forward pass of the generator phase needs and leaves: its own copies of the pose uploads (the step's other
+        phases read theirs while the next step's are already on their way), later x_fake."""
+        sf = {"B": B, "z": None, "cams": self._stager("fwd_cams", (B, 4, 4)).upload(cams),
+              "theta9": self._stager("fwd_theta9", (B, 9)).upload(pose_code(thetas))}
+        return {"B": B, "key": key, "thetas": thetas, "st": sf, "external_epoch": Fn.external_epoch(), "done": None}
+
+    def _start_forward(self, B, key, main, side):
+        """Draw the NEXT step's poses (the prior's stream is consumed in step order, one step early), and run that step's
+        generator forward on the side stream behind this step's generator update.  The pair (forward of step n+1, rest of
+        step n+1) is eager / captured / replayed TOGETHER: both phases are called once per step under the same graph key, the
+        forward one step ahead, so their call counts -- which decide (RGBDUpdater._run_phase_inner) -- stay equal."""
+        if key is not None:
+            use_rotate = self.iteration + 1 > self.config.start_rotation
+            key = (key[0], use_rotate) + tuple(key[2:])
+        thetas = np.asarray(self.prior.sample(B), dtype="float32")
+        rec = self._forward_record(B, key, thetas, get_camera_matries(thetas))      # (uploads: on the main stream, before the event)
+        updated = self._event("gen_updated")
+        updated.record(main)
+        side.wait_event(updated)
+        rec["st"]["stream"] = side
+        # (sized like the side stream's other work: the discriminator phase it runs under is the critical path)
+        self._run_phase("dv_gen_fwd", self._dv_gen_fwd_phase, rec["st"], key, stream=side, cu_budget=self.forward_cu_budget)
+        rec["done"] = torch.cuda.Event()
+        rec["done"].record(side)
+        return rec
+
+    def _drop_forward(self, pf):
+        """A forward pass in flight that is not the coming step's (another batch size or graph key, injected inputs, weights
+        loaded from outside): forget it, and let its graph key start over -- the dropped call has put the forward phase's call
+        count one ahead of the rest phase's."""
+        if pf["key"] is not None:
+            for name in ("dv_gen_fwd", "dv_gen_rest"):
+                self._graphs.pop(pf["key"] + (name,), None)
+                self._eager_calls.pop(pf["key"] + (name,), None)
+        return None
+
     def update_core(self, batch=None, z_fake=None, thetas=None):
         """z_fake: optional (z, z2, z_dis, z2_dis) injected by tests; otherwise drawn as the reference draws them."""
         real_idx = real_data = None
@@ -211,7 +294,15 @@ class DeepVoxelsUpdater(RGBDUpdater):
             B = len(batch)
             x_real_full = self.get_x_real_data(batch, B)
         half = B // 2
+        # the generator forward a previous step started for this one (if any, and if it is still this step's: same batch size,
+        # nothing injected, weights untouched from outside since)
+        prefetch = self.prefetch_forward and self.concurrent_phases and z_fake is None and thetas is None
+        pf, self._pf = self._pf, None
+        if pf is not None and not (prefetch and pf["B"] == B and pf["external_epoch"] == Fn.external_epoch()):
+            pf = self._drop_forward(pf)
         # host side, NumPy, as the reference: pose prior, camera matrices, pose code, warp constants
+        if pf is not None:
+            thetas = pf["thetas"]
         thetas = np.asarray(self.prior.sample(B) if thetas is None else thetas, dtype="float32")
         cams = get_camera_matries(thetas)
         use_rotate = self.iteration > self.config.start_rotation
@@ -243,6 +334,8 @@ class DeepVoxelsUpdater(RGBDUpdater):
             key = (B, use_rotate, shape, z_fake is not None, Fn.conv_dtype(), real_idx is not None)
         st["x_real_full"] = x_real_full
 
+        if pf is not None and pf["key"] != key:
+            pf = self._drop_forward(pf)
         self._replayed = False
         self._run_phase("dv_prep", self._dv_prep_phase, st, key)
         if self.concurrent_phases:
@@ -254,14 +347,33 @@ class DeepVoxelsUpdater(RGBDUpdater):
             # here 192 / 128 of 256: 977 -> 984-992 img/s, profiles/r05/cu_budget_sweep.txt)
             st["side_wgrad_wgs"] = self.side_wgrad_workgroups
             self._run_phase("dv_dis_real", self._dv_dis_real_phase, st, key, stream=side, cu_budget=self.side_cu_budget)
-            self._run_phase("dv_gen", self._dv_gen_phase, st, key)
-            main.wait_stream(side)
+            if prefetch:
+                dis_real_done = self._event("dis_real")
+                dis_real_done.record(side)
+                if pf is None:                  # nothing in flight (first step, or dropped): this step's forward, here
+                    pf = self._forward_record(B, key, thetas, cams)
+                    self._run_phase("dv_gen_fwd", self._dv_gen_fwd_phase, pf["st"], key)
+                else:
+                    main.wait_event(pf["done"])
+                st["fwd"] = pf["st"]
+                self._run_phase("dv_gen_rest", self._dv_gen_rest_phase, st, key)
+                if key is None or key + ("dv_gen_rest",) not in self._graphs:
+                    # an eager pair: let its autograd graph die before the next forward is built.  A live graph keeps its
+                    # leaves' gradient accumulators, each tied to the stream it was made on (the side stream here); a forward
+                    # CAPTURED while they live inherits them, and the capture of its backward forks onto that stream
+                    # (hipStreamEndCapture then fails -- RGBDUpdater._run_phase_inner has the same rule for its phases)
+                    pf["st"]["fwd_x_fake"] = st["fwd"] = None
+                self._pf = self._start_forward(B, key, main, side)           # fwd(n+1) under dis_fake(n)
+                main.wait_event(dis_real_done)
+            else:
+                self._run_phase("dv_gen", self._dv_gen_phase, st, key)
+                main.wait_stream(side)
         else:
             self._run_phase("dv_dis_real", self._dv_dis_real_phase, st, key)
             self._run_phase("dv_gen", self._dv_gen_phase, st, key)
         self._run_phase("dv_dis_fake", self._dv_dis_fake_phase, st, key)
         if self._replayed:
-            Fn.bump_weight_epoch()      # replays change the weights behind Python's back: invalidate packed caches
+            Fn.bump_weight_epoch(own_step=True)      # replays change the weights behind Python's back: invalidate packed caches
 
         obs = self.observation
         obs["stage"], obs["batch_size"], obs["image_size"] = FIXED_STAGE, B, IMG_SIZE

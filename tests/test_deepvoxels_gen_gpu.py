@@ -220,3 +220,120 @@ def test_deepvoxels_two_stream_step_equals_one_stream_step():
             tol = 1e-2 if k.startswith("norm_") else 1e-5
             assert np.isfinite(a[k]) and abs(a[k] - b[k]) <= tol * max(1.0, abs(a[k])), (it, k, a[k], b[k])
             assert abs(a[k] - runs[False][0][k]) <= tol * max(1.0, abs(a[k])), (it, k)      # replay == capture == eager
+
+
+def _dv_updater(lrs, **kwargs):
+    from rgbd_gan_amd.net import Discriminator
+    from rgbd_gan_amd.optimizer import FlatAdam
+    from rgbd_gan_amd.updater import CameraParamPrior
+    from rgbd_gan_amd.updater_deepvoxels import DeepVoxelsUpdater
+    from rgbd_gan_amd.utils.yaml_utils import Config
+    cfg = Config(dict(generator_architecture="deepvoxels", stage_interval="0,0,0,0,0,0,0,0", max_stage=11,
+                      start_rotation=0, start_occlusion_aware=0, lambda_depth=10, depth_min=0.6, focal_loss_gamma=2.0,
+                      x_rotate=0.3054, y_rotate=3.1415, z_rotate=0, x_translate=0, y_translate=0, z_translate=0,
+                      uniform_distribution=True, bigan=False))
+    _, _, gen = _generator(seed=3)
+    dis = Discriminator(CH, res=True)
+    dis.load_state_dict(nets.init_discriminator(CH, seed=8))
+    opt = {"map": FlatAdam(gen.mapping.store, lrs[0]), "gen": FlatAdam(gen.store, lrs[1]), "dis": FlatAdam(dis.store, lrs[2])}
+    upd = DeepVoxelsUpdater(models=[gen, dis], config=cfg, optimizer=opt, iterator=None, lambda_gp=1.0, smoothing=0.999,
+                            total_gpu=1, prior=CameraParamPrior(cfg), **kwargs)
+    upd.iteration = 10
+    return gen, dis, opt, upd
+
+
+def test_deepvoxels_step_with_the_next_forward_started_early_equals_the_plain_step():
+    """prefetch_forward (updater_deepvoxels.py: the generator forward of step n+1 on the side stream under dis_fake of step n)
+    against the plain four-phase step: the prior's poses drawn in the same order (one step early), the latents pinned, learning
+    rates 0 -- so step k of one arrangement is step k of the other: same losses and gradient norms through the eager steps,
+    the captures and the replays (tolerances of the two-stream test above: the resampling backward's fp32 atomics)."""
+    B = 4
+    x_real = torch.from_numpy(np.random.RandomState(7).randint(0, 256, (B, 3, 128, 128)).astype("float32") / 127.5 - 1)
+    fixed = torch.randn(B, CH, 1, 1, 1, generator=torch.Generator().manual_seed(12)).cuda()
+    runs = {}
+    for prefetch in (False, True):
+        gen, dis, opt, upd = _dv_updater((0.0, 0.0, 0.0), prefetch_forward=prefetch)
+        upd.get_z_fake_data = lambda n: fixed[:n]
+        upd.call_log = []
+        np.random.seed(21)
+        rows = []
+        for it in range(6):                      # two eager steps, the captures, replays
+            upd.update_core(batch=x_real)
+            upd.iteration += 1
+            torch.cuda.synchronize()
+            row = {k: float(v) for k, v in upd.observation.items() if k.startswith(("gen/", "dis/"))}
+            row.update({f"norm_{k}": float(o.grad_norm) for k, o in opt.items()})
+            rows.append(row)
+        runs[prefetch] = rows
+        names = [n for what, n, _ in upd.call_log if what == "phase"]
+        if prefetch:
+            # the first step runs its own forward; every step starts the next one's between G's update and dis_fake
+            assert names[:6] == ["dv_prep", "dv_dis_real", "dv_gen_fwd", "dv_gen_rest", "dv_gen_fwd", "dv_dis_fake"], names[:6]
+            assert names[6:11] == ["dv_prep", "dv_dis_real", "dv_gen_rest", "dv_gen_fwd", "dv_dis_fake"], names[6:11]
+            assert len(upd._graphs) == 5 and upd._pf is not None, list(upd._graphs)
+            streams = {n: s for what, n, s in upd.call_log[-5:]}
+            assert streams["dv_gen_fwd"] == streams["dv_dis_real"] != streams["dv_dis_fake"] == streams["dv_gen_rest"]
+        else:
+            assert len(upd._graphs) == 4 and upd._pf is None and "dv_gen_fwd" not in names
+    assert len({round(r["gen/loss_rotate"], 6) for r in runs[False]}) > 1          # the poses do change from step to step
+    for it, (a, b) in enumerate(zip(runs[False], runs[True])):
+        assert set(a) == set(b) and {"dis/loss_adv", "dis/loss_gp", "gen/loss_adv", "gen/loss_rotate"} <= set(a)
+        for k in a:
+            tol = 1e-2 if k.startswith("norm_") else 1e-5
+            assert np.isfinite(a[k]) and abs(a[k] - b[k]) <= tol * max(1.0, abs(a[k])), (it, k, a[k], b[k])
+
+
+def test_deepvoxels_early_forward_reads_the_updated_generator():
+    """... and with the optimizers running: the forward pass in flight after step n IS G_{n}'s (the weights behind step n's
+    generator update, weight images rebuilt) on step n+1's poses -- recomputed here from the master weights after a
+    synchronise -- in the eager steps, at the captures and in the replays; injected inputs drop the pass in flight and the pair
+    of phases starts over."""
+    B = 4
+    x_real = torch.from_numpy(np.random.RandomState(7).randint(0, 256, (B, 3, 128, 128)).astype("float32") / 127.5 - 1)
+    fixed = torch.randn(B, CH, 1, 1, 1, generator=torch.Generator().manual_seed(12)).cuda()
+    gen, dis, opt, upd = _dv_updater((1e-5, 1e-3, 3e-3))
+    assert upd.prefetch_forward
+    upd.get_z_fake_data = lambda n: fixed[:n]
+    np.random.seed(22)
+    zz = fixed[:B // 2].repeat(2, 1, 1, 1, 1)
+
+    def check(tag):
+        torch.cuda.synchronize()
+        pf = upd._pf
+        assert pf is not None and pf["st"]["fwd_x_fake"] is not None, tag
+        with torch.no_grad():
+            fresh = gen(zz, 8.5, pf["st"]["cams"], z2=zz, theta=pf["st"]["theta9"])
+        got = pf["st"]["fwd_x_fake"].detach()
+        assert bool(torch.isfinite(got).all()) and rel_err(got, fresh) < 2e-3, (tag, rel_err(got, fresh))
+        return got.clone()
+
+    w0 = gen.store.flat.detach().clone()
+    outs = []
+    for it in range(5):
+        upd.update_core(batch=x_real)
+        upd.iteration += 1
+        outs.append(check(it))
+    assert float((gen.store.flat.detach() - w0).abs().max()) > 4e-3            # five Adam steps of 1e-3
+    assert rel_err(outs[-1], outs[0]) > 2e-2                                  # (a stale generator would not pass `check`)
+    assert opt["gen"].t == opt["dis"].t == 5
+    # injected poses and latents: not the step the pass in flight was started for
+    z, z2, thetas = _inputs(B, seed=5)
+    upd.update_core(batch=x_real, z_fake=(z, z2, z, z2), thetas=thetas)
+    upd.iteration += 1
+    assert upd._pf is None and not any(k[-1] in ("dv_gen_fwd", "dv_gen_rest") for k in upd._graphs)
+    # a change of the weights from outside: likewise
+    for it in range(2):
+        upd.update_core(batch=x_real)
+        upd.iteration += 1
+        check(("again", it))
+    from rgbd_gan_amd import functional as Fn
+    with torch.no_grad():
+        gen.store.flat.mul_(1.0)
+    Fn.bump_weight_epoch()
+    stale = upd._pf
+    for it in range(4):
+        upd.update_core(batch=x_real)
+        upd.iteration += 1
+        check(("after a load", it))
+    assert upd._pf is not stale and opt["gen"].t == 12
+    assert all(np.isfinite(float(v)) for k, v in upd.observation.items() if k.startswith(("gen/", "dis/")))
