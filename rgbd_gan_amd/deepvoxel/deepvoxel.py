@@ -172,6 +172,8 @@ class _OcclusionAccum(torch.autograd.Function):
         _lib.check(rc, "rgbd_occlusion_accum_fwd")
         ctx.save_for_backward(vol, W1c, b1c, W2c, s, w)
         ctx.voxel_size = float(voxel_size)
+        ctx.shapes = (feat.shape, depth.shape)
+        ctx.set_materialize_grads(False)      # the weights output is a by-product nobody differentiates: no 9 MB of zeros for it
         return feat, depth, w.reshape(B, 1, D, H, W)
 
     @staticmethod
@@ -185,7 +187,12 @@ class _OcclusionAccum(torch.autograd.Function):
         dvol = torch.empty_like(vol)
         nparams = OCC_NF * (F + 1) + 2 * OCC_NF + 1
         dparams = torch.empty((nparams + 3) // 4 * 4, dtype=torch.float32, device=dev)
-        dfeat, ddepth = dfeat.contiguous(), ddepth.contiguous()
+        if dw_unused is not None:
+            raise RuntimeError("accumulative_occlusion: the weights output is not differentiable here")
+        if dfeat is None and ddepth is None:
+            return (None,) * 8
+        dfeat = dfeat.contiguous() if dfeat is not None else torch.zeros(ctx.shapes[0], dtype=torch.float32, device=dev)
+        ddepth = ddepth.contiguous() if ddepth is not None else torch.zeros(ctx.shapes[1], dtype=torch.float32, device=dev)
         # algorithmic bytes: the volume read, its gradient written, s / w read, the plane gradients read
         rc = _timed("occlusion_accum_bwd_kernel", 0.0, 4.0 * B * H * W * (2 * F * D + 2 * D + F + 1),
                     lambda: _lib.load().rgbd_occlusion_accum_bwd(_ptr(vol), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(s), _ptr(w),

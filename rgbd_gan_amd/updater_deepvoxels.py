@@ -120,6 +120,13 @@ class DeepVoxelsUpdater(RGBDUpdater):
         if group is not None:
             group.layers[0].packed()
 
+    def _one(self, like):
+        """The seed of a scalar loss's backward pass (a cached buffer instead of one ones_like launch per pass)."""
+        key = ("one", tuple(like.shape))
+        if key not in self._ones:
+            self._ones[key] = torch.ones_like(like.detach())
+        return self._ones[key]
+
     def _dv_dis_real_phase(self, st):
         """The half of the discriminator step that does not involve G (:229-246): adversarial term on the reals + R1."""
         obs = self.observation
@@ -139,7 +146,7 @@ class DeepVoxelsUpdater(RGBDUpdater):
             total = adv + gp
         wgrads = []
         with Fn.deferred_wgrads(wgrads):
-            total.backward()
+            torch.autograd.backward([total], [self._one(total)])
         with kernels.wgrad_workgroups(st.get("side_wgrad_wgs", 0)):
             Fn.run_deferred_wgrads(wgrads)
 
@@ -147,9 +154,9 @@ class DeepVoxelsUpdater(RGBDUpdater):
         half = st["B"] // 2
         if st["z"] is not None:
             z, z2 = st["z"][0], st["z"][1]
-        else:                                                      # one latent per view PAIR (:146-148)
-            z = self.get_z_fake_data(half).repeat(2, 1, 1, 1, 1)
-            z2 = self.get_z_fake_data(half).repeat(2, 1, 1, 1, 1)
+        else:                                                      # one latent per view PAIR (:146-148); both from one draw
+            zz = self.get_z_fake_data(2 * half)
+            z, z2 = zz[:half].repeat(2, 1, 1, 1, 1), zz[half:].repeat(2, 1, 1, 1, 1)
         return self.gen(z, FIXED_STAGE, st["cams"], z2=z2, theta=st["theta9"])
 
     def _dv_gen_phase(self, st):
@@ -217,7 +224,8 @@ class DeepVoxelsUpdater(RGBDUpdater):
         if st["z"] is not None:
             z, z2 = st["z"][2], st["z"][3]
         else:
-            z, z2 = self.get_z_fake_data(B), self.get_z_fake_data(B)
+            zz = self.get_z_fake_data(2 * B)
+            z, z2 = zz[:B], zz[B:]
         with torch.no_grad():
             x_fake = self.gen(z, FIXED_STAGE, st["cams"], z2=z2, theta=st["theta9"])
         y_fake = self.dis(x_fake[:, :3].contiguous(), stage=FIXED_STAGE)
@@ -225,7 +233,7 @@ class DeepVoxelsUpdater(RGBDUpdater):
         obs["dis/loss_adv"] = adv.detach() + st["adv_real"]
         wgrads = []
         with Fn.deferred_wgrads(wgrads):
-            adv.backward()
+            torch.autograd.backward([adv], [self._one(adv)])
         Fn.run_deferred_wgrads(wgrads)
         self.get_optimizer("dis").update()
 

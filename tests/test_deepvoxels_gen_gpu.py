@@ -249,7 +249,7 @@ def test_deepvoxels_step_with_the_next_forward_started_early_equals_the_plain_st
     the captures and the replays (tolerances of the two-stream test above: the resampling backward's fp32 atomics)."""
     B = 4
     x_real = torch.from_numpy(np.random.RandomState(7).randint(0, 256, (B, 3, 128, 128)).astype("float32") / 127.5 - 1)
-    fixed = torch.randn(B, CH, 1, 1, 1, generator=torch.Generator().manual_seed(12)).cuda()
+    fixed = torch.randn(2 * B, CH, 1, 1, 1, generator=torch.Generator().manual_seed(12)).cuda()
     runs = {}
     for prefetch in (False, True):
         gen, dis, opt, upd = _dv_updater((0.0, 0.0, 0.0), prefetch_forward=prefetch)
@@ -290,19 +290,19 @@ def test_deepvoxels_early_forward_reads_the_updated_generator():
     of phases starts over."""
     B = 4
     x_real = torch.from_numpy(np.random.RandomState(7).randint(0, 256, (B, 3, 128, 128)).astype("float32") / 127.5 - 1)
-    fixed = torch.randn(B, CH, 1, 1, 1, generator=torch.Generator().manual_seed(12)).cuda()
+    fixed = torch.randn(2 * B, CH, 1, 1, 1, generator=torch.Generator().manual_seed(12)).cuda()
     gen, dis, opt, upd = _dv_updater((1e-5, 1e-3, 3e-3))
     assert upd.prefetch_forward
     upd.get_z_fake_data = lambda n: fixed[:n]
     np.random.seed(22)
-    zz = fixed[:B // 2].repeat(2, 1, 1, 1, 1)
+    zz, zz2 = fixed[:B // 2].repeat(2, 1, 1, 1, 1), fixed[B // 2:B].repeat(2, 1, 1, 1, 1)     # (one draw per pass, split)
 
     def check(tag):
         torch.cuda.synchronize()
         pf = upd._pf
         assert pf is not None and pf["st"]["fwd_x_fake"] is not None, tag
         with torch.no_grad():
-            fresh = gen(zz, 8.5, pf["st"]["cams"], z2=zz, theta=pf["st"]["theta9"])
+            fresh = gen(zz, 8.5, pf["st"]["cams"], z2=zz2, theta=pf["st"]["theta9"])
         got = pf["st"]["fwd_x_fake"].detach()
         assert bool(torch.isfinite(got).all()) and rel_err(got, fresh) < 2e-3, (tag, rel_err(got, fresh))
         return got.clone()
