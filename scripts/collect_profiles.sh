@@ -92,6 +92,8 @@ python3 -m pytest tests -q -m gpu 2>&1 | tail -3 > profiles/$R/gpu_tests_same_bo
 python3 scripts/torch_op_sources.py 2>/dev/null | grep -v amdgpu.ids > profiles/$R/torch_op_sources.txt
 python3 scripts/torch_op_sources.py 200000 configs/deepvoxels_shapenet_car.yml 2>/dev/null | grep -v amdgpu.ids > profiles/$R/torch_op_sources_c4.txt
 python3 bench.py > profiles/$R/bench_default.json 2> gpurun_out/$R/default.err
+RGBD_DV_PREFETCH=0 python3 bench.py --config configs/deepvoxels_shapenet_car.yml --no-cpu-baseline --no-roofline > profiles/$R/bench_c4_no_early_forward.json 2>/dev/null
+CONFIG=deepvoxels_shapenet_car.yml B=10 python3 scripts/phase_timeline.py > profiles/$R/phase_timeline_c4.txt 2>/dev/null
 cp profiles/$R/*.csv profiles/$R/*.json profiles/$R/*.txt gpurun_out/$R/ 2>/dev/null
 mkdir -p gpurun_out/$R/mx8 && cp profiles/$R/mx8/* gpurun_out/$R/mx8/ 2>/dev/null
 ls -la profiles/$R
