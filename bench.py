@@ -428,7 +428,9 @@ def run_workload(args, comm, device):
                    "per_gpu_batch": B, "global_batch": B * comm.size, "parallelism": f"dp{comm.size}",
                    "arrangement": ("two streams, one graph per phase"
                                    + (", the next step's generator forward on the side stream under this step's dis_fake phase "
-                                      f"(sized for {upd.forward_cu_budget} CUs)" if getattr(upd, "prefetch_forward", False) else ""))
+                                      f"(sized for {upd.forward_cu_budget} CUs)" if getattr(upd, "prefetch_forward", False) else "")
+                                   + (", the renderer's weight gradients on the side stream under the backward pass below the renderer"
+                                      if getattr(upd, "split_backward", False) else ""))
                    if getattr(upd, "concurrent_phases", False) else "one stream",
                    # True only if the timed steps were replays of captured HIP graphs (a refused capture is fatal in the
                    # updater: graph_fallback is off)

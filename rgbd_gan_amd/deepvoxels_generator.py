@@ -438,7 +438,11 @@ class Generator(_Link):
         z = torch.randn(batch_size, self.ch, 1, 1, device=self.device)
         return z / torch.sqrt(torch.sum(z * z, dim=1, keepdim=True) / self.ch + 1e-8)
 
-    def __call__(self, z, stage, camera_matrices, z2=None, z3=None, z4=None, theta=None):
+    def __call__(self, z, stage, camera_matrices, z2=None, z3=None, z4=None, theta=None, cut=None):
+        """cut (a dict, filled here): run the 2-D renderer behind a CUT in the autograd graph -- cut["leaves"] = detached
+        (features, depth, w2) the renderer and the output are built on, cut["below"] = the tensors they were detached from.  A
+        backward pass from the output then stops at the leaves (their .grad), a second one from cut["below"] with those gradients
+        does the rest: DeepVoxelsUpdater runs the renderer's weight gradients on another stream between the two."""
         z = _as_device_tensor(z, self.device)
         if z2 is None:
             z2 = self.make_hidden(z.shape[0])
@@ -461,6 +465,10 @@ class Generator(_Link):
         else:
             idx, coords, counts = self.projection.compute_proj_idcs_batch(camera_matrices)
             novel_feats, depth = self.deepvoxel(idx, coords, counts, voxel, feature_minor=fm)
+        if cut is not None and torch.is_grad_enabled():
+            cut["below"] = (novel_feats, depth, w2)
+            novel_feats, depth, w2 = (t.detach().requires_grad_(True) for t in cut["below"])
+            cut["leaves"] = (novel_feats, depth, w2)
         novel_img = self.style_generator(novel_feats, w2, stage)
         return torch.cat([novel_img, depth], dim=1)
 

@@ -25,6 +25,13 @@ dis_fake -- same arithmetic per step, 1.2 ms off the critical path (profiles/r06
     main:  prep -> (wait fwd(n)) gen_rest(n): frozen D, 3-D loss, G bwd, G update, G's weight images -> (wait dis_real) dis_fake(n)
     side:       +-> dis_real(n) ---------------------------------------------------> (wait G update) fwd(n+1): G'(z) of step n+1
 
+and with `split_backward` (default with prefetch_forward; RGBD_DV_SPLIT_BACKWARD=0) gen_rest is cut once more, at the 2-D renderer's input
+(Generator.__call__'s `cut`): the renderer's weight gradients -- 45 % of G's -- leave the critical path for the side stream while the
+backward pass goes on through the occlusion network, the resampling and the voxel generator (1260 -> 1300 img/s):
+
+    main:  ... rest_a: frozen D, loss, backward down to the renderer's input -> rest_b: backward below it + voxel weight gradients -> (wait) rest_c: updates, images
+    side:  ... dis_real ------------------------------------------------------> (wait rest_a) wgrad_a: the renderer's weight gradients
+
 (`concurrent_phases=False` / RGBD_CONCURRENT_PHASES=0: the same four phases back to back on one stream -- identical
 arithmetic, same accumulation order.)  ~960 mostly small launches per step: the second stream fills the gaps between the
 first one's kernels.  Everything data dependent (the number of frustum samples inside the grid) stays on the device.
@@ -90,6 +97,13 @@ class DeepVoxelsUpdater(RGBDUpdater):
         # ... and the early forward pass, which has 3 ms of dis_fake to hide 2 ms under, fewer still (16 / 32 / 48 / 64 / 96 / 128 /
         # 192 / all: 873 / 1130 / 1209 / 1239 / 1253 / 1233 / 1226 / 1224 img/s, profiles/r06/c4_prefetch.txt)
         self.forward_cu_budget = int(kwargs.pop("forward_cu_budget", os.environ.get("RGBD_DV_FWD_CUS", "96")))
+        # split_backward (with prefetch_forward): the renderer's weight gradients on the side stream while the backward pass goes on
+        # below the renderer (Generator.__call__'s cut)
+        env = os.environ.get("RGBD_DV_SPLIT_BACKWARD")
+        self.split_backward = bool(kwargs.pop("split_backward", env is None or env not in ("", "0"))) and self.prefetch_forward
+        # (workgroups of that launch: 64 / 128 / 192 / all: 1307 / 1300 / 1296 / 1297 img/s -- it has until the end of the backward
+        # pass below the cut, and every CU it takes is one the critical path does not get)
+        self.renderer_wgrad_workgroups = int(kwargs.pop("renderer_wgrad_workgroups", os.environ.get("RGBD_DV_WGRAD_A_WGS", "64")))
         self._side_stream = None
         self._graphs, self._eager_calls, self._stagers, self._ones = {}, {}, {}, {}
         self._pf = None                 # the next step's generator forward in flight (see _start_forward)
@@ -157,7 +171,7 @@ class DeepVoxelsUpdater(RGBDUpdater):
         else:                                                      # one latent per view PAIR (:146-148); both from one draw
             zz = self.get_z_fake_data(2 * half)
             z, z2 = zz[:half].repeat(2, 1, 1, 1, 1), zz[half:].repeat(2, 1, 1, 1, 1)
-        return self.gen(z, FIXED_STAGE, st["cams"], z2=z2, theta=st["theta9"])
+        return self.gen(z, FIXED_STAGE, st["cams"], z2=z2, theta=st["theta9"], cut=st.get("cut"))
 
     def _dv_gen_phase(self, st):
         self._dv_gen_rest(st, self._dv_gen_forward(st))
@@ -175,7 +189,42 @@ class DeepVoxelsUpdater(RGBDUpdater):
         # images built (persistent buffers: functional.DerivedPackGroup)
         self.gen.rebuild_weight_images()
 
-    def _dv_gen_rest(self, st, x_fake, fwd_stream=None):
+    # ---- ... and, with split_backward, the rest in three: down to the renderer's input (its weight gradients then run on the
+    #      side stream, _dv_gen_wgrad_a_phase), below it (+ the voxel generator's weight gradients), the update
+    def _dv_gen_rest_a_phase(self, st):
+        self.gen.mark_weight_images_current()
+        st["wgrads_a"] = []
+        self._dv_gen_rest(st, st["fwd"]["fwd_x_fake"], fwd_stream=st["fwd"].get("stream"), collect=st["wgrads_a"])
+
+    def _dv_gen_wgrad_a_phase(self, st):
+        with kernels.wgrad_workgroups(self.renderer_wgrad_workgroups):
+            Fn.run_deferred_wgrads(st["wgrads_a"])      # (the operands stay referenced until the main stream has joined: rest_c)
+
+    def _dv_gen_rest_b_phase(self, st):
+        cut, fwd_stream = st["fwd"]["cut"], st["fwd"].get("stream")
+        grads = [t.grad for t in cut["leaves"]]
+        pairs = [(b, g) for b, g in zip(cut["below"], grads) if g is not None]
+        for t in cut["leaves"]:
+            t.grad = None
+        wgrads = []
+        cross = fwd_stream is not None and not torch.cuda.is_current_stream_capturing()
+        if cross:
+            fwd_stream.wait_stream(torch.cuda.current_stream())
+        with Fn.deferred_wgrads(wgrads):
+            torch.autograd.backward([b for b, _ in pairs], [g for _, g in pairs])
+        if cross:
+            torch.cuda.current_stream().wait_stream(fwd_stream)
+        Fn.run_deferred_wgrads(wgrads)
+
+    def _dv_gen_rest_c_phase(self, st):
+        st["wgrads_a"] = None
+        for name in ("map", "gen"):
+            self.get_optimizer(name).update()
+        self.gen.rebuild_weight_images()
+
+    def _dv_gen_rest(self, st, x_fake, fwd_stream=None, collect=None):
+        """collect (a list): the backward pass stops at the generator's cut; its weight-gradient launches are handed over in
+        `collect` instead of being issued, and the optimizers are left to the caller."""
         cfg, obs = self.config, self.observation
         half = st["B"] // 2
         # The gradient w.r.t. G's output is assembled by hand, as in RGBDUpdater._gen_backward (slicing, hinge, scaling and
@@ -213,6 +262,9 @@ class DeepVoxelsUpdater(RGBDUpdater):
             torch.autograd.backward([x_fake], [gout])
         if cross:
             torch.cuda.current_stream().wait_stream(fwd_stream)
+        if collect is not None:
+            collect.extend(wgrads)
+            return
         Fn.run_deferred_wgrads(wgrads)
         for name in ("map", "gen"):
             self.get_optimizer(name).update()
@@ -247,7 +299,8 @@ class DeepVoxelsUpdater(RGBDUpdater):
         """What a forward pass of the generator phase needs and leaves: its own copies of the pose uploads (the step's other
         phases read theirs while the next step's are already on their way), later x_fake."""
         sf = {"B": B, "z": None, "cams": self._stager("fwd_cams", (B, 4, 4)).upload(cams),
-              "theta9": self._stager("fwd_theta9", (B, 9)).upload(pose_code(thetas))}
+              "theta9": self._stager("fwd_theta9", (B, 9)).upload(pose_code(thetas)),
+              "cut": {} if self.split_backward else None}
         return {"B": B, "key": key, "thetas": thetas, "st": sf, "external_epoch": Fn.external_epoch(), "done": None}
 
     def _start_forward(self, B, key, main, side):
@@ -275,7 +328,7 @@ class DeepVoxelsUpdater(RGBDUpdater):
         loaded from outside): forget it, and let its graph key start over -- the dropped call has put the forward phase's call
         count one ahead of the rest phase's."""
         if pf["key"] is not None:
-            for name in ("dv_gen_fwd", "dv_gen_rest"):
+            for name in ("dv_gen_fwd", "dv_gen_rest", "dv_gen_rest_a", "dv_gen_wgrad_a", "dv_gen_rest_b"):
                 self._graphs.pop(pf["key"] + (name,), None)
                 self._eager_calls.pop(pf["key"] + (name,), None)
         return None
@@ -364,13 +417,24 @@ class DeepVoxelsUpdater(RGBDUpdater):
                 else:
                     main.wait_event(pf["done"])
                 st["fwd"] = pf["st"]
-                self._run_phase("dv_gen_rest", self._dv_gen_rest_phase, st, key)
+                if self.split_backward:
+                    self._run_phase("dv_gen_rest_a", self._dv_gen_rest_a_phase, st, key)
+                    rest_a_done, wgrad_a_done = self._event("rest_a"), self._event("wgrad_a")
+                    rest_a_done.record(main)
+                    side.wait_event(rest_a_done)
+                    self._run_phase("dv_gen_wgrad_a", self._dv_gen_wgrad_a_phase, st, key, stream=side)
+                    wgrad_a_done.record(side)
+                    self._run_phase("dv_gen_rest_b", self._dv_gen_rest_b_phase, st, key)
+                    main.wait_event(wgrad_a_done)
+                    self._run_phase("dv_gen_rest", self._dv_gen_rest_c_phase, st, key)
+                else:
+                    self._run_phase("dv_gen_rest", self._dv_gen_rest_phase, st, key)
                 if key is None or key + ("dv_gen_rest",) not in self._graphs:
                     # an eager pair: let its autograd graph die before the next forward is built.  A live graph keeps its
                     # leaves' gradient accumulators, each tied to the stream it was made on (the side stream here); a forward
                     # CAPTURED while they live inherits them, and the capture of its backward forks onto that stream
                     # (hipStreamEndCapture then fails -- RGBDUpdater._run_phase_inner has the same rule for its phases)
-                    pf["st"]["fwd_x_fake"] = st["fwd"] = None
+                    pf["st"]["fwd_x_fake"] = pf["st"]["cut"] = st["fwd"] = None
                 self._pf = self._start_forward(B, key, main, side)           # fwd(n+1) under dis_fake(n)
                 main.wait_event(dis_real_done)
             else:

@@ -251,8 +251,9 @@ def test_deepvoxels_step_with_the_next_forward_started_early_equals_the_plain_st
     x_real = torch.from_numpy(np.random.RandomState(7).randint(0, 256, (B, 3, 128, 128)).astype("float32") / 127.5 - 1)
     fixed = torch.randn(2 * B, CH, 1, 1, 1, generator=torch.Generator().manual_seed(12)).cuda()
     runs = {}
-    for prefetch in (False, True):
-        gen, dis, opt, upd = _dv_updater((0.0, 0.0, 0.0), prefetch_forward=prefetch)
+    for prefetch, split in ((False, False), (True, False), (True, True)):
+        gen, dis, opt, upd = _dv_updater((0.0, 0.0, 0.0), prefetch_forward=prefetch, split_backward=split)
+        assert upd.split_backward == split
         upd.get_z_fake_data = lambda n: fixed[:n]
         upd.call_log = []
         np.random.seed(21)
@@ -264,23 +265,28 @@ def test_deepvoxels_step_with_the_next_forward_started_early_equals_the_plain_st
             row = {k: float(v) for k, v in upd.observation.items() if k.startswith(("gen/", "dis/"))}
             row.update({f"norm_{k}": float(o.grad_norm) for k, o in opt.items()})
             rows.append(row)
-        runs[prefetch] = rows
+        runs[prefetch, split] = rows
         names = [n for what, n, _ in upd.call_log if what == "phase"]
+        rest = ["dv_gen_rest_a", "dv_gen_wgrad_a", "dv_gen_rest_b", "dv_gen_rest"] if split else ["dv_gen_rest"]
         if prefetch:
             # the first step runs its own forward; every step starts the next one's between G's update and dis_fake
-            assert names[:6] == ["dv_prep", "dv_dis_real", "dv_gen_fwd", "dv_gen_rest", "dv_gen_fwd", "dv_dis_fake"], names[:6]
-            assert names[6:11] == ["dv_prep", "dv_dis_real", "dv_gen_rest", "dv_gen_fwd", "dv_dis_fake"], names[6:11]
-            assert len(upd._graphs) == 5 and upd._pf is not None, list(upd._graphs)
-            streams = {n: s for what, n, s in upd.call_log[-5:]}
+            n = 5 + len(rest)
+            assert names[:n] == ["dv_prep", "dv_dis_real", "dv_gen_fwd"] + rest + ["dv_gen_fwd", "dv_dis_fake"], names[:n]
+            assert names[n:2 * n - 1] == ["dv_prep", "dv_dis_real"] + rest + ["dv_gen_fwd", "dv_dis_fake"], names[n:2 * n - 1]
+            assert len(upd._graphs) == n - 1 and upd._pf is not None, list(upd._graphs)
+            streams = {n: s for what, n, s in upd.call_log[-(n - 1):]}
             assert streams["dv_gen_fwd"] == streams["dv_dis_real"] != streams["dv_dis_fake"] == streams["dv_gen_rest"]
+            assert not split or streams["dv_gen_wgrad_a"] == streams["dv_dis_real"] != streams["dv_gen_rest_b"]
         else:
             assert len(upd._graphs) == 4 and upd._pf is None and "dv_gen_fwd" not in names
-    assert len({round(r["gen/loss_rotate"], 6) for r in runs[False]}) > 1          # the poses do change from step to step
-    for it, (a, b) in enumerate(zip(runs[False], runs[True])):
-        assert set(a) == set(b) and {"dis/loss_adv", "dis/loss_gp", "gen/loss_adv", "gen/loss_rotate"} <= set(a)
-        for k in a:
-            tol = 1e-2 if k.startswith("norm_") else 1e-5
-            assert np.isfinite(a[k]) and abs(a[k] - b[k]) <= tol * max(1.0, abs(a[k])), (it, k, a[k], b[k])
+    plain = runs[False, False]
+    assert len({round(r["gen/loss_rotate"], 6) for r in plain}) > 1          # the poses do change from step to step
+    for mode in ((True, False), (True, True)):
+        for it, (a, b) in enumerate(zip(plain, runs[mode])):
+            assert set(a) == set(b) and {"dis/loss_adv", "dis/loss_gp", "gen/loss_adv", "gen/loss_rotate"} <= set(a)
+            for k in a:
+                tol = 1e-2 if k.startswith("norm_") else 1e-5
+                assert np.isfinite(a[k]) and abs(a[k] - b[k]) <= tol * max(1.0, abs(a[k])), (mode, it, k, a[k], b[k])
 
 
 def test_deepvoxels_early_forward_reads_the_updated_generator():
@@ -320,7 +326,7 @@ def test_deepvoxels_early_forward_reads_the_updated_generator():
     z, z2, thetas = _inputs(B, seed=5)
     upd.update_core(batch=x_real, z_fake=(z, z2, z, z2), thetas=thetas)
     upd.iteration += 1
-    assert upd._pf is None and not any(k[-1] in ("dv_gen_fwd", "dv_gen_rest") for k in upd._graphs)
+    assert upd._pf is None and not any(k[-1].startswith("dv_gen_") for k in upd._graphs)
     # a change of the weights from outside: likewise
     for it in range(2):
         upd.update_core(batch=x_real)
