@@ -317,7 +317,7 @@ class DeepVoxelsUpdater(RGBDUpdater):
         updated.record(main)
         side.wait_event(updated)
         rec["st"]["stream"] = side
-        # (sized like the side stream's other work: the discriminator phase it runs under is the critical path)
+        # (sized for forward_cu_budget compute units: the discriminator phase it runs under is the critical path)
         self._run_phase("dv_gen_fwd", self._dv_gen_fwd_phase, rec["st"], key, stream=side, cu_budget=self.forward_cu_budget)
         rec["done"] = torch.cuda.Event()
         rec["done"].record(side)

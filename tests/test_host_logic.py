@@ -362,3 +362,30 @@ def test_updater_constructor_takes_every_documented_argument_and_rejects_unknown
     assert not upd.tuning_in_progress
     with pytest.raises(TypeError, match="unknown arguments"):
         RGBDUpdater(models=[gen, dis], config=cfg, **base, no_such_argument=1)
+
+
+def test_deepvoxels_updater_arrangement_switches():
+    """DeepVoxelsUpdater's arrangement arguments: the early forward needs the two-stream step and a step that is not data parallel
+    (there the generator phase holds the collectives); the split backward needs the early forward."""
+    import types
+    from rgbd_gan_amd.updater import CameraParamPrior
+    from rgbd_gan_amd.updater_deepvoxels import DeepVoxelsUpdater
+    from rgbd_gan_amd.utils.yaml_utils import Config
+    cfg = Config(dict(stage_interval="0,0,0,0,0,0,0,0", max_stage=11, x_rotate=0.3, y_rotate=1.0, z_rotate=0, x_translate=0,
+                      y_translate=0, z_translate=0, bigan=False, generator_architecture="deepvoxels", lambda_geometric=None))
+    K = np.array([[64.0, 0, 32], [0, 64.0, 32], [0, 0, 1]], dtype="float32")
+    gen = types.SimpleNamespace(device=torch.device("cpu"), projection=types.SimpleNamespace(projection_intrinsic=K))
+
+    def build(comm_active=False, **kw):
+        opt = {"gen": types.SimpleNamespace(comm=types.SimpleNamespace(active=comm_active))}
+        return DeepVoxelsUpdater(models=[gen, types.SimpleNamespace()], config=cfg, optimizer=opt, iterator=None, lambda_gp=1.0,
+                                 smoothing=0.999, total_gpu=1, prior=CameraParamPrior(cfg), **kw)
+    upd = build()
+    assert upd.prefetch_forward and upd.split_backward and upd.forward_cu_budget == 96 and upd.renderer_wgrad_workgroups == 64
+    assert upd._pf is None and upd.get_stage() == 8.5
+    upd = build(prefetch_forward=False)
+    assert not upd.prefetch_forward and not upd.split_backward
+    upd = build(split_backward=False, forward_cu_budget=128, renderer_wgrad_workgroups=0)
+    assert upd.prefetch_forward and not upd.split_backward and upd.forward_cu_budget == 128 and upd.renderer_wgrad_workgroups == 0
+    upd = build(comm_active=True)
+    assert not upd.use_graphs and not upd.prefetch_forward and not upd.split_backward
