@@ -37,14 +37,14 @@ s = s[:i] + f"""*Numbers* (`profiles/r06/`: one `scripts/collect_profiles.sh` ru
 **{d['value']:.0f} img/s, {d['ms_per_step']:.2f} ms per step**; dominant kernel `conv3x3_sp_kernel<128>` {d['roofline']['achieved']:.0f} TFLOP/s = **{d['roofline']['frac']:.3f} of the bf16 MFMA peak** (HBM traffic
 per launch {d['roofline']['traffic'] / 1e6:.1f} MB vs 123.8 algorithmic); whole step {d['mfma_roofline_frac_whole_step']:.3f} of the peak on executed work (200.1 GFLOP/img; {d['value'] * 296.6 / 1e3 / 2500:.3f} on SURVEY's
 296.6).  Same process, `other_configs`: fade-in stage 9.5 {oc['c2_fade']['value']:.0f} img/s; configuration 3's per-GPU shape (B = 8) {oc['c3_b8']['value']:.0f} img/s ({oc['c3_b8']['ms_per_step']:.2f} ms);
-configuration 4 (DeepVoxels) **{c4['value']:.0f} img/s** (its stand-alone command with the early forward of section 3, measured after the collection;
-{oc['c4']['value']:.0f} in the collection's process before it, 1033 in round 5); configuration 5 (256x256, ch 512, B = 16) {oc['c5_bf16']['value']:.0f} on bf16, **{oc['c5_fp8']['value']:.0f} on fp8 convs**.
+configuration 4 (DeepVoxels) **{oc['c4']['value']:.0f} img/s** ({c4['value']:.0f} as its stand-alone command; 1033 in round 5, 1124 without the early forward of section 3);
+configuration 5 (256x256, ch 512, B = 16) {oc['c5_bf16']['value']:.0f} on bf16, **{oc['c5_fp8']['value']:.0f} on fp8 convs**.
 CPU restatement of the same step: {d['cpu_baseline']['value']:.1f} img/s on 16 host cores.  Driver history of the default line: r03 4020, r04 3860, r05 4386.
 """ + s[j:]
 i = s.index("Round 6, final kernel sources (hash `")
 j = s.index("`bench_kernel_stats.csv` (rocprofv3 `--kernel-trace --stats`, `--no-tune`,")
 s = s[:i] + f"""Round 6, final kernel sources (hash `{sha}`, commit {commit}), ONE box, one `collect_profiles.sh` run (`profiles/r06/`; the
-stand-alone commands, 100 timed steps each, side budgets measured at set-up unless noted; 288 GPU tests green on the same box,
+stand-alone commands, 100 timed steps each, side budgets measured at set-up unless noted; 290 GPU tests green on the same box,
 `gpu_tests_same_box.txt`).  The pool's boxes differ by +-4 %: earlier collections and runs of the round gave 4130 / 4224 / 4320 / 4336 / 4376 /
 4450 img/s on the default command (`other_boxes/`, `ab_mlp_chain.txt`, `bench_dp_one_rank_rccl.json`).
 
@@ -87,8 +87,7 @@ r = r[:i] + f"""Round 6 on MI355X (`profiles/r06/`: one `scripts/collect_profile
 img/s on the default command).  Default line (stage 10, 128x128, per-GPU batch 32, bf16, graphs, two streams, side-stream budgets measured
 at set-up) **{d['value']:.0f} img/s, {d['ms_per_step']:.2f} ms per step**; dominant kernel `conv3x3_sp_kernel<128>` {d['roofline']['frac']:.3f} of the bf16 MFMA peak, whole step {d['mfma_roofline_frac_whole_step']:.3f} on
 executed work; `other_configs` of the same process: fade-in stage 9.5 {oc['c2_fade']['value']:.0f} img/s, configuration 3's per-GPU shape {oc['c3_b8']['value']:.0f} img/s
-({oc['c3_b8']['ms_per_step']:.2f} ms), configuration 4 (DeepVoxels) **{c4['value']:.0f} img/s** (stand-alone command, with the next step's generator forward started early; {oc['c4']['value']:.0f} before that, 1033 in
-round 5), configuration 5 {oc['c5_bf16']['value']:.0f} img/s on bf16 and **{oc['c5_fp8']['value']:.0f} on fp8 convs**;
+({oc['c3_b8']['ms_per_step']:.2f} ms), configuration 4 (DeepVoxels) **{oc['c4']['value']:.0f} img/s** ({c4['value']:.0f} as its stand-alone command; 1033 in round 5), configuration 5 {oc['c5_bf16']['value']:.0f} img/s on bf16 and **{oc['c5_fp8']['value']:.0f} on fp8 convs**;
 """ + r[j:]
 open(p, "w").write(r)
 print("default", d["value"], "c4", oc["c4"]["value"], c4["value"], "hash", sha, commit)
