@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RGBD_ABI_VERSION 19
+#define RGBD_ABI_VERSION 20
 
 int rgbd_abi_version(void);
 const char* rgbd_last_error(void);
@@ -106,13 +106,16 @@ int rgbd_pack_weights(const float* w, int cout, int cin, int kh, int kw, float s
  * fixed addresses); descriptor i owns blocks [block_begin[i], block_begin[i+1]) of the total_blocks-block grid.
  */
 typedef struct rgbd_pack_desc {
-    const float* w;       /* (cout,cin,kh,kw) fp32 master */
+    const float* w;       /* (cout,cin,kh,kw) fp32 master; with `fold`: the reference-shaped master it is folded from */
     void* w_fprop;        /* [taps][cout][cin] bf16 or NULL */
     void* w_dgrad;        /* [taps][cin][cout] bf16, taps flipped, or NULL */
     int cout, cin, taps;
     float scale;
     int block_begin;
-    int reserved;
+    int fold;             /* 0: none.  Else (ABI 20) w is a master parameter and (cout,cin,taps) its rgbd_fold_weight_f32
+                           * rearrangement, made in the packing read: bits 0-1 = mode + 1 (mode 0: (Co,Ci,3,3,3) -> cin = 3 Cip,
+                           * taps 9; 1: (Co,Ci,4,4) -> cin = 16 Cip, taps 1; 2: channel padding), bits 2-16 = Co, 17-31 = Ci
+                           * (cout = Cop, Cip = cin / 3 | cin / 16 | cin); padding elements are zeros */
 } rgbd_pack_desc;
 int rgbd_pack_weights_multi(const rgbd_pack_desc* descs_device, int n, int total_blocks, void* stream);
 

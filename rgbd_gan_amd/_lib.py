@@ -10,7 +10,7 @@ from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_void_p, POINTER
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RGBD_LIB_PATH: A/B timing of another build of the same ABI; the default is the in-tree library
 LIB_PATH = os.environ.get("RGBD_LIB_PATH") or os.path.join(_HERE, "librgbdgan_hip.so")
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 _P = c_void_p
 

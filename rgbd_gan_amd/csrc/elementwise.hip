@@ -1208,6 +1208,23 @@ extern "C" int rgbd_pack_weights(const float* w, int cout, int cin, int kh, int 
 
 namespace {
 constexpr int PACK_TCO = 8, PACK_TCI = 64;          // tile of the tiled path: 8 x 64 (co, ci) x up to 9 taps = 18 KB of LDS
+// Element (co, ci, tap) of the (cout, cin, taps) weight a descriptor describes -> its index in D.w, or -1 for a padding zero.
+// fold == 0: D.w IS that tensor.  Otherwise D.w is a reference-shaped MASTER parameter and (cout, cin, taps) its rearrangement
+// for the 2-D conv engine (rgbd_fold_weight_f32's modes; the DeepVoxels generator): the fold happens in this read, the folded fp32
+// copy (a launch and 8 bytes per element of traffic on every rebuild of the images) is never made.
+__device__ __forceinline__ long pack_src_index(const rgbd_pack_desc& D, int co, int ci, int tap) {
+    if (D.fold == 0) return ((long)co * D.cin + ci) * D.taps + tap;
+    const int mode = (D.fold & 3) - 1, Co = (D.fold >> 2) & 0x7fff, Ci = (D.fold >> 17) & 0x7fff;
+    if (mode == 0) {                                 // (Co,Ci,3,3,3) -> (cout, 3 * Cip, 3 x 3): channel kd * Cip + c carries depth tap kd
+        const int Cip = D.cin / 3, kd = ci / Cip, c = ci - kd * Cip;
+        return (co < Co && c < Ci) ? (((long)co * Ci + c) * 3 + kd) * 9 + tap : -1;
+    }
+    if (mode == 1) {                                 // (Co,Ci,4,4) -> (cout, 16 * Cip, 1 x 1): channel (ky * 4 + kx) * Cip + c
+        const int Cip = D.cin / 16, t = ci / Cip, c = ci - t * Cip;
+        return (co < Co && c < Ci) ? ((long)co * Ci + c) * 16 + t : -1;
+    }
+    return (co < Co && ci < Ci) ? ((long)co * Ci + ci) * D.taps + tap : -1;       // zero padding of both channel counts only
+}
 __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const rgbd_pack_desc* __restrict__ descs, int n) {
     extern __shared__ float ptile[];                // [PACK_TCO][PACK_TCI * taps], as the master stores it
     int d = 0;
@@ -1218,7 +1235,43 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const rgbd_pack
     const long total = (long)D.cout * D.cin * D.taps;
     unsigned short* wf = (unsigned short*)D.w_fprop;
     unsigned short* wd = (unsigned short*)D.w_dgrad;
-    if (D.taps <= 9 && D.cin % PACK_TCI == 0 && D.cout % PACK_TCO == 0) {
+    if (D.fold != 0) {
+        const int mode = (D.fold & 3) - 1, Co = (D.fold >> 2) & 0x7fff, Ci = (D.fold >> 17) & 0x7fff;
+        const int G = mode == 0 ? 3 : mode == 1 ? 16 : 1;               // the folded cin is G groups of Cip channels
+        const int Cip = D.cin / G, T = D.taps;
+        const int Tm = mode == 0 ? 27 : mode == 1 ? 16 : T;            // master elements per (co, ci): contiguous in the master
+        if (Cip % PACK_TCI == 0 && D.cout % PACK_TCO == 0 && Tm <= 27) {
+            // Tiled over the MASTER: 8 co x 64 ci x all Tm taps -- per co one contiguous run of up to 64 * Tm floats, read
+            // coalesced ONCE (the element-wise gather below touches every 64- / 108-byte group of the master from G tiles, four
+            // bytes at a time) -- then every group g writes its (tap, co, g Cip + ci) / (tap, g Cip + ci, co) slice of the images
+            // as the unfolded path does.  Pitch per ci odd (16 -> 17): the ci-fastest reads stay conflict-free.
+            const int Tp = Tm | 1, rowm = PACK_TCI * Tp + 1;
+            const int tiles_ci = Cip / PACK_TCI, tiles = tiles_ci * (D.cout / PACK_TCO);
+            for (int tile = (int)blockIdx.x - D.block_begin; tile < tiles; tile += nblk) {
+                const int co0 = (tile / tiles_ci) * PACK_TCO, c0 = (tile % tiles_ci) * PACK_TCI;
+                for (int e = threadIdx.x; e < PACK_TCO * PACK_TCI * Tm; e += 256) {
+                    const int r = e / (PACK_TCI * Tm), cc = e - r * (PACK_TCI * Tm), c = cc / Tm, j = cc - c * Tm;
+                    const bool ok = co0 + r < Co && c0 + c < Ci;
+                    ptile[r * rowm + c * Tp + j] = ok ? D.w[((long)(co0 + r) * Ci + c0) * Tm + cc] * D.scale : 0.f;
+                }
+                __syncthreads();
+                for (int e = threadIdx.x; e < G * T * PACK_TCO * PACK_TCI; e += 256) {
+                    const int gt = e / (PACK_TCO * PACK_TCI), g = gt / T, tap = gt - g * T, j = mode == 0 ? g * 9 + tap : mode == 1 ? g : tap;
+                    const int l = e - gt * (PACK_TCO * PACK_TCI);
+                    if (wf) {                                                               // (tap, co, ci), ci fastest
+                        const int ci = l % PACK_TCI, r = l / PACK_TCI;
+                        wf[((long)tap * D.cout + co0 + r) * D.cin + g * Cip + c0 + ci] = f32_to_bf16_bits(ptile[r * rowm + ci * Tp + j]);
+                    }
+                    if (wd) {                                                               // (tap, ci, co), co fastest
+                        const int r = l % PACK_TCO, ci = l / PACK_TCO;
+                        wd[((long)(T - 1 - tap) * D.cin + g * Cip + c0 + ci) * D.cout + co0 + r] = f32_to_bf16_bits(ptile[r * rowm + ci * Tp + j]);
+                    }
+                }
+                __syncthreads();
+            }
+            return;
+        }
+    } else if (D.taps <= 9 && D.cin % PACK_TCI == 0 && D.cout % PACK_TCO == 0) {
         // Tiled: the master's rows (one co: cin x taps contiguous) are read coalesced into LDS, the fprop image leaves in
         // 128-byte runs along ci and the dgrad image in 16-byte runs along co -- the element-wise form below gathers the
         // master with a stride of `taps` floats and scatters the dgrad image 2 bytes at a time.
@@ -1250,7 +1303,8 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const rgbd_pack
         const long r = e / D.cin;
         const int co = (int)(r % D.cout);
         const int tap = (int)(r / D.cout);
-        const unsigned short h = f32_to_bf16_bits(D.w[((long)co * D.cin + ci) * D.taps + tap] * D.scale);
+        const long m = pack_src_index(D, co, ci, tap);
+        const unsigned short h = f32_to_bf16_bits(m >= 0 ? D.w[m] * D.scale : 0.f);
         if (wf) wf[e] = h;
         if (wd) wd[((long)(D.taps - 1 - tap) * D.cin + ci) * D.cout + co] = h;
     }
@@ -1259,7 +1313,7 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const rgbd_pack
 
 extern "C" int rgbd_pack_weights_multi(const rgbd_pack_desc* descs_device, int n, int total_blocks, void* stream) {
     RGBD_REQUIRE(descs_device && n > 0 && total_blocks > 0, "rgbd_pack_weights_multi: bad arguments");
-    constexpr int lds = PACK_TCO * (PACK_TCI * 9 + 1) * (int)sizeof(float);
+    constexpr int lds = PACK_TCO * (PACK_TCI * 27 + 1) * (int)sizeof(float);      // the folded path's master tile: 27 taps
     RGBD_REQUIRE(rgbd_reserve_lds((const void*)&pack_weights_multi_kernel, lds),
                  "rgbd_pack_weights_multi: cannot reserve %d B of LDS", lds);
     pack_weights_multi_kernel<<<total_blocks, 256, lds, (hipStream_t)stream>>>(descs_device, n);

@@ -275,34 +275,35 @@ class DerivedPackGroup(PackGroup):
         self.layers = [l for l in layers if l is not None]
         entries = []
         for l in self.layers:
+            fold = ()
             if isinstance(l, DerivedConvLayer):
                 if l.master is None or l.fold is None:
                     raise ValueError("DerivedPackGroup: derived layers need (master, fold)")
                 mode, cop, cip = l.fold
                 m = l.master
                 shape = (cop, 3 * cip, 3, 3) if mode == 0 else (cop, 16 * cip, 1, 1) if mode == 1 else (cop, cip, l.K, l.K)
-                l._fold_buf = torch.empty(shape, dtype=torch.float32, device=m.device)
-                w = l._fold_buf
+                # the folded fp32 weight exists as a SHAPE only (the conv nodes' `w`: autograd routes its gradient through the
+                # fold's adjoint); its values are never needed -- the packing kernel reads the master through the fold
+                # (rgbd_pack_desc.fold, ABI 20: one launch and 8 bytes per folded element less on every rebuild)
+                l._fold_buf = torch.zeros(shape, dtype=torch.float32, device=m.device)
+                w = m.detach()
+                if not w.is_contiguous():
+                    raise ValueError("DerivedPackGroup: master parameters must be contiguous")
+                fold = (shape, (mode, m.shape[0], m.shape[1]))
+                co, ci, kh, kw = shape
             else:
                 w = l.weight.detach()
-            co, ci, kh, kw = w.shape
+                co, ci, kh, kw = w.shape
             l._wf = torch.empty(kh * kw, co, ci, dtype=torch.bfloat16, device=w.device)
             l._wd = torch.empty(kh * kw, ci, co, dtype=torch.bfloat16, device=w.device)
             l.group = self
-            entries.append((w, l.inv_c, l._wf, l._wd))
+            entries.append((w, l.inv_c, l._wf, l._wd) + fold)
         self.table = kernels.build_pack_table(entries)
         self.mx_table = ()          # (the networks of this kind run bf16 convs)
 
     def repack(self):
         with torch.no_grad():
-            folds = []
-            for l in self.layers:
-                if isinstance(l, DerivedConvLayer):
-                    mode, cop, cip = l.fold
-                    m = _master4(l.master.detach().contiguous(), mode)
-                    folds.append((m, l._fold_buf, mode, m.shape[0], m.shape[1], m.shape[-1], cop, cip, False))
-            kernels.fold_weight_multi(folds)                       # all folds of the network: one launch
-            kernels.pack_weights_multi(self.table)
+            kernels.pack_weights_multi(self.table)                 # folds included: one launch for the whole network
         for l in self.layers:
             l._epoch = l._now()
 

@@ -223,20 +223,42 @@ def pack_weights(w, scale, want_fprop=True, want_dgrad=True):
 
 
 PACK_DESC = [("w", "<u8"), ("wf", "<u8"), ("wd", "<u8"), ("cout", "<i4"), ("cin", "<i4"), ("taps", "<i4"),
-             ("scale", "<f4"), ("block_begin", "<i4"), ("reserved", "<i4")]          # struct rgbd_pack_desc, 48 bytes
+             ("scale", "<f4"), ("block_begin", "<i4"), ("fold", "<i4")]          # struct rgbd_pack_desc, 48 bytes
+
+
+def pack_fold_code(mode, Co, Ci):
+    """The `fold` field of rgbd_pack_desc: the packing kernel reads a reference-shaped master through fold_weight's mode."""
+    if not (0 <= mode <= 2 and 0 < Co < 32768 and 0 < Ci < 32768):
+        raise ValueError(f"pack_fold_code: mode {mode}, master channels ({Co}, {Ci})")
+    return (mode + 1) | (Co << 2) | (Ci << 17)
 
 
 def build_pack_table(entries):
-    """entries: list of (w fp32 (co,ci,k,k), scale, wf, wd) -> (device descriptor table, n, total_blocks)."""
+    """entries: list of (w fp32 (co,ci,k,k), scale, wf, wd) -> (device descriptor table, n, total_blocks).
+    A folded entry is (master fp32, scale, wf, wd, (cop, cin_folded, k, k), (mode, Co, Ci)): the images are those of the master's
+    fold_weight rearrangement, which is never materialised."""
     import numpy as np
     tab = np.zeros(len(entries), dtype=PACK_DESC)
     assert tab.dtype.itemsize == 48
     blocks = 0
-    for i, (w, scale, wf, wd) in enumerate(entries):
+    for i, ent in enumerate(entries):
+        w, scale, wf, wd = ent[:4]
         _chk(w, F32, "w"); _chk(wf, BF16, "wf"); _chk(wd, BF16, "wd")
-        co, ci, kh, kw = w.shape
-        tab[i] = (w.data_ptr(), wf.data_ptr(), wd.data_ptr(), co, ci, kh * kw, scale, blocks, 0)
-        blocks += min(256, (w.numel() + 255) // 256)
+        fold = 0
+        if len(ent) > 4:
+            (co, ci, kh, kw), (mode, Co, Ci) = ent[4], ent[5]
+            want = (Co, Ci, 3, 3, 3) if mode == 0 else (Co, Ci, 4, 4) if mode == 1 else (Co, Ci, kh, kw)
+            if tuple(w.shape)[:2] != want[:2] or w.numel() != int(np.prod(want)) or not w.is_contiguous():
+                raise RuntimeError(f"build_pack_table: master {tuple(w.shape)} is not the contiguous {want} of fold mode {mode}")
+            if (mode == 0 and (kh, kw, ci % 3) != (3, 3, 0)) or (mode == 1 and (kh, kw, ci % 16) != (1, 1, 0)) or co < Co:
+                raise RuntimeError(f"build_pack_table: folded shape {(co, ci, kh, kw)} does not fit mode {mode}")
+            fold = pack_fold_code(mode, Co, Ci)
+        else:
+            co, ci, kh, kw = w.shape
+        if tuple(wf.shape) != (kh * kw, co, ci) or tuple(wd.shape) != (kh * kw, ci, co):
+            raise RuntimeError(f"build_pack_table: images {tuple(wf.shape)} / {tuple(wd.shape)} for a ({co},{ci},{kh},{kw}) weight")
+        tab[i] = (w.data_ptr(), wf.data_ptr(), wd.data_ptr(), co, ci, kh * kw, scale, blocks, fold)
+        blocks += min(256, (co * ci * kh * kw + 255) // 256)
     dev = torch.from_numpy(tab.view(np.uint8).copy()).to(entries[0][0].device)
     return dev, len(entries), blocks
 

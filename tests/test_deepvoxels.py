@@ -289,3 +289,36 @@ def test_fold_weight_multi_matches_the_single_launches():
         assert torch.equal(it[1], ref), it[2:8]
     for it, ref in zip(adj, refs_a):
         assert torch.equal(it[1], ref), it[2:8]
+
+
+@pytest.mark.gpu
+def test_packing_through_the_fold_equals_fold_then_pack():
+    """rgbd_pack_desc.fold (ABI 20): the bf16 weight images packed straight from reference-shaped master parameters -- the fold done
+    in the packing read -- against fold (rgbd_fold_weight_f32) then pack (rgbd_pack_weights), bytes equal; every mode, padded channel
+    counts, the tiled and the element-wise path of the packing kernel, a 5-D 1x1x1 master, all in ONE table (= one launch), next
+    to an ordinary entry."""
+    from rgbd_gan_amd import kernels
+    g = torch.Generator().manual_seed(13)
+    layers = [(0, (32, 64, 3, 3, 3), 64, 64), (0, (256, 128, 3, 3, 3), 256, 128), (1, (512, 32, 4, 4), 512, 32),
+              (1, (20, 3, 4, 4), 20, 3), (2, (3, 288, 3, 3), 64, 320), (2, (32, 32, 1, 1, 1), 64, 64), (2, (24, 40, 3, 3), 64, 64)]
+    entries, refs = [], []
+    for mode, shape, cop, cip in layers:
+        W = torch.randn(*shape, generator=g).cuda()
+        Co, Ci, K = shape[0], shape[1], shape[-1]
+        W4 = W if mode == 0 or W.dim() == 4 else W.view(Co, Ci, K, K)
+        folded = kernels.fold_weight(W4, mode, Co, Ci, K, cop, cip)
+        refs.append(kernels.pack_weights(folded, 0.37))
+        co, ci, kh, kw = folded.shape
+        wf = torch.full((kh * kw, co, ci), float("nan"), dtype=torch.bfloat16, device="cuda")
+        wd = torch.full((kh * kw, ci, co), float("nan"), dtype=torch.bfloat16, device="cuda")
+        entries.append((W, 0.37, wf, wd, tuple(folded.shape), (mode, Co, Ci)))
+    plain = torch.randn(128, 64, 3, 3, generator=g).cuda()
+    refs.append(kernels.pack_weights(plain, 0.5))
+    entries.append((plain, 0.5, torch.empty_like(refs[-1][0]), torch.empty_like(refs[-1][1])))
+    kernels.pack_weights_multi(kernels.build_pack_table(entries))
+    for ent, (wf0, wd0), lay in zip(entries, refs, layers + [("plain",)]):
+        assert torch.equal(ent[2].view(torch.int16), wf0.view(torch.int16)), lay
+        assert torch.equal(ent[3].view(torch.int16), wd0.view(torch.int16)), lay
+    with pytest.raises(RuntimeError, match="master"):
+        kernels.build_pack_table([(torch.zeros(32, 64, 3, 3, device="cuda"), 1.0, entries[0][2], entries[0][3], (64, 192, 3, 3),
+                                  (0, 32, 64))])
