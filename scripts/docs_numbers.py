@@ -44,7 +44,7 @@ CPU restatement of the same step: {d['cpu_baseline']['value']:.1f} img/s on 16 h
 i = s.index("Round 6, final kernel sources (hash `")
 j = s.index("`bench_kernel_stats.csv` (rocprofv3 `--kernel-trace --stats`, `--no-tune`,")
 s = s[:i] + f"""Round 6, final kernel sources (hash `{sha}`, commit {commit}), ONE box, one `collect_profiles.sh` run (`profiles/r06/`; the
-stand-alone commands, 100 timed steps each, side budgets measured at set-up unless noted; 290 GPU tests green on the same box,
+stand-alone commands, 100 timed steps each, side budgets measured at set-up unless noted; 291 GPU tests green on the same box,
 `gpu_tests_same_box.txt`).  The pool's boxes differ by +-4 %: earlier collections and runs of the round gave 4130 / 4224 / 4320 / 4336 / 4376 /
 4450 img/s on the default command (`other_boxes/`, `ab_mlp_chain.txt`, `bench_dp_one_rank_rccl.json`).
 
