@@ -332,6 +332,14 @@ def test_deepvoxels_early_forward_reads_the_updated_generator():
         upd.update_core(batch=x_real)
         upd.iteration += 1
         check(("again", it))
+    # another batch size (a data set's last, short batch): the pass in flight was drawn for four samples
+    upd.update_core(batch=x_real[:2])
+    upd.iteration += 1
+    assert upd._pf is not None and upd._pf["B"] == 2 and upd.observation["batch_size"] == 2
+    for it in range(2):
+        upd.update_core(batch=x_real)
+        upd.iteration += 1
+        check(("after a short batch", it))
     from rgbd_gan_amd import functional as Fn
     with torch.no_grad():
         gen.store.flat.mul_(1.0)
@@ -341,5 +349,5 @@ def test_deepvoxels_early_forward_reads_the_updated_generator():
         upd.update_core(batch=x_real)
         upd.iteration += 1
         check(("after a load", it))
-    assert upd._pf is not stale and opt["gen"].t == 12
+    assert upd._pf is not stale and opt["gen"].t == 15
     assert all(np.isfinite(float(v)) for k, v in upd.observation.items() if k.startswith(("gen/", "dis/")))
