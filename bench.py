@@ -374,6 +374,11 @@ def run_workload(args, comm, device):
         upd.tune_side_budget = False
         upd.iteration = args.iteration
 
+    px = side                     # the step's image side: the progressive stage's (--stage), not the data set's
+    if not deepvoxels and hasattr(upd, "_net_max_stage"):
+        from rgbd_gan_amd.updater import downsized_size
+        px = downsized_size(upd.stage, upd._net_max_stage)
+
     def sync():
         torch.cuda.synchronize()
         comm.barrier()
@@ -419,7 +424,7 @@ def run_workload(args, comm, device):
         "config": {"workload": (f"{os.path.basename(args.config)} stage {upd.stage:.2f} (64x64), DeepVoxelsUpdater.update_core, "
                                 f"voxel generator 32^3 x 32 features -> frustum 56x64x64 -> occlusion compositing -> 2-D "
                                 f"renderer, rotation loss on, R1 on") if deepvoxels else
-                               (f"{os.path.basename(args.config)} stage {upd.stage:.2f} ({side}x{side}), RGBDUpdater.update_core, "
+                               (f"{os.path.basename(args.config)} stage {upd.stage:.2f} ({px}x{px}), RGBDUpdater.update_core, "
                                 f"StyleGAN ch={config.ch}, rotation+occlusion loss on, R1 on"
                                 + (", max_resolution=256 (BASELINE configuration 5's networks)" if args.res256 else "")
                                 + (", conv_dtype mxfp8: 3x3 fprop / dgrad on e4m3 operands with E8M0 scales per 32 channels "
@@ -438,7 +443,7 @@ def run_workload(args, comm, device):
                    # compute units the side stream's chip-filling launches are sized for: the
                    # weight-gradient workgroup count measured at set-up on this device (rule of thumb -> chosen), or None
                    "side_stream_budget": ({"cus_3x3": getattr(upd, "side_cu_budget", None),
-                                           "wgrad_workgroups_dis_dfw": list(upd._side_wgrad_pair({"B": B, "x_real": torch.empty(0, 0, side, side)}))
+                                           "wgrad_workgroups_dis_dfw": list(upd._side_wgrad_pair({"B": B, "x_real": torch.empty(0, 0, px, px)}))
                                            if hasattr(upd, "_side_wgrad_pair") and getattr(upd, "side_wgrad_workgroups", 0) is None else
                                            getattr(upd, "side_wgrad_workgroups", None), "measured": tuning}
                                           if getattr(upd, "concurrent_phases", False) else None)},
@@ -454,7 +459,8 @@ def run_workload(args, comm, device):
     elif args.res256:
         line["metric"] = "img/s (G+D+3D-loss step) at 256x256"
     elif args.stage not in (None, 10.0):
-        pass                            # (the whole-step FLOP count below is stage 10's)
+        if px != 128:                   # (the whole-step FLOP count below is stage 10's)
+            line["metric"] = f"img/s (G+D+3D-loss step) at {px}x{px} (progressive stage {upd.stage:g})"
     else:
         line["step_tflops_algorithmic"] = round(value * STEP_GFLOP_PER_IMAGE / 1e3, 2)
         line["mfma_roofline_frac_whole_step"] = round(value * STEP_GFLOP_PER_IMAGE / 1e3 / (MFMA_BF16_PEAK_TFLOPS * comm.size), 4)
