@@ -77,6 +77,12 @@ kernel, the difference is the other queue.  The new small kernels in that table:
 workgroups that wait for a free CU beside the other stream's chip-filling launches; 8 layers x 3.4 us of matrix work each),
 `mlp_wgrad_kernel` {mlp['mlp_wgrad_kernel']:.0f} us.
 
+The other progressive-growing stages of configuration 2 (`python bench.py --stage S --no-other-configs`; B = 32, side counts measured at set-up
+per shape; another box than the table's, default command 4205 img/s there; `profiles/r06/bench_stage_*.json`) -- the reference spends its
+first 180 000 iterations below stage 10: stage 6 (32x32) **13 261 img/s** (2.41 ms; `conv3x3_sp_kernel<128>` 0.462, pair 128/192), stage 7.5
+(64x64 fading in) 6507 (4.92 ms; 0.477, 176/216), stage 8 (64x64) **6818** (4.69 ms; 0.470, 176/216), stage 9 (128x128 fading in, alpha 0)
+4123 (7.76 ms; 0.450, 144/144), stage 9.5 in the table above.
+
 """ + s[j:]
 open(p, "w").write(s)
 
