@@ -230,7 +230,8 @@ def pack_fold_code(mode, Co, Ci):
     """The `fold` field of rgbd_pack_desc: the packing kernel reads a reference-shaped master through fold_weight's mode."""
     if not (0 <= mode <= 2 and 0 < Co < 32768 and 0 < Ci < 32768):
         raise ValueError(f"pack_fold_code: mode {mode}, master channels ({Co}, {Ci})")
-    return (mode + 1) | (Co << 2) | (Ci << 17)
+    code = (mode + 1) | (Co << 2) | (Ci << 17)
+    return code - (1 << 32) if code >= 1 << 31 else code            # the struct's field is a signed 32-bit integer
 
 
 def build_pack_table(entries):

@@ -389,3 +389,21 @@ def test_deepvoxels_updater_arrangement_switches():
     assert upd.prefetch_forward and not upd.split_backward and upd.forward_cu_budget == 128 and upd.renderer_wgrad_workgroups == 0
     upd = build(comm_active=True)
     assert not upd.use_graphs and not upd.prefetch_forward and not upd.split_backward
+
+
+def test_pack_fold_code_is_the_headers_bit_layout():
+    """rgbd_pack_desc.fold (include/rgbd_gan_hip.h): bits 0-1 = mode + 1, bits 2-16 = master Cout, bits 17-31 = master Cin, and it must fit
+    the struct's int32 (kernels.PACK_DESC)."""
+    from rgbd_gan_amd import kernels
+    for mode, co, ci in ((0, 32, 64), (1, 1024, 512), (2, 3, 288), (2, 32767, 32767)):
+        code = kernels.pack_fold_code(mode, co, ci)
+        assert -2 ** 31 <= code < 2 ** 31 and np.zeros(1, dtype=kernels.PACK_DESC)["fold"].dtype == np.dtype("<i4")
+        bits = code & 0xffffffff                       # what the kernel sees: (fold & 3) - 1, (fold >> 2) & 0x7fff, (fold >> 17) & 0x7fff
+        assert (bits & 3) - 1 == mode and (bits >> 2) & 0x7fff == co and (bits >> 17) & 0x7fff == ci
+        tab = np.zeros(1, dtype=kernels.PACK_DESC)
+        tab["fold"] = code
+        assert int(tab["fold"][0]) == code
+    assert dict(kernels.PACK_DESC)["fold"] == "<i4" and np.dtype(kernels.PACK_DESC).itemsize == 48
+    for bad in ((3, 8, 8), (0, 0, 8), (0, 8, 32768)):
+        with pytest.raises(ValueError):
+            kernels.pack_fold_code(*bad)
