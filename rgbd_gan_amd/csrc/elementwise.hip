@@ -1240,26 +1240,30 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const rgbd_pack
         const int G = mode == 0 ? 3 : mode == 1 ? 16 : 1;               // the folded cin is G groups of Cip channels
         const int Cip = D.cin / G, T = D.taps;
         const int Tm = mode == 0 ? 27 : mode == 1 ? 16 : T;            // master elements per (co, ci): contiguous in the master
-        if (Cip % PACK_TCI == 0 && D.cout % PACK_TCO == 0 && Tm <= 27) {
-            // Tiled over the MASTER: 8 co x 64 ci x all Tm taps -- per co one contiguous run of up to 64 * Tm floats, read
+        // master channels per tile: chosen so that the tile fits the LDS of the unfolded path (8 x (64 x 9 + 1) floats = 18 KB) -- a launch
+        // reserves ONE size for all its workgroups, and at the 55 KB of an 8 x 64 x 27 tile two workgroups per CU instead of eight
+        // slowed every launch down, the unfolded layers' included (default step: 29 -> 50 us per call, profiles/r06/time_pack.txt)
+        const int CT = mode == 0 ? 16 : mode == 1 ? 32 : PACK_TCI;
+        if (Cip % CT == 0 && D.cout % PACK_TCO == 0 && Tm <= (mode == 2 ? 9 : 27)) {
+            // Tiled over the MASTER: 8 co x CT ci x all Tm taps -- per co one contiguous run of up to CT * Tm floats, read
             // coalesced ONCE (the element-wise gather below touches every 64- / 108-byte group of the master from G tiles, four
             // bytes at a time) -- then every group g writes its (tap, co, g Cip + ci) / (tap, g Cip + ci, co) slice of the images
             // as the unfolded path does.  Pitch per ci odd (16 -> 17): the ci-fastest reads stay conflict-free.
-            const int Tp = Tm | 1, rowm = PACK_TCI * Tp + 1;
-            const int tiles_ci = Cip / PACK_TCI, tiles = tiles_ci * (D.cout / PACK_TCO);
+            const int Tp = Tm | 1, rowm = CT * Tp + 1;
+            const int tiles_ci = Cip / CT, tiles = tiles_ci * (D.cout / PACK_TCO);
             for (int tile = (int)blockIdx.x - D.block_begin; tile < tiles; tile += nblk) {
-                const int co0 = (tile / tiles_ci) * PACK_TCO, c0 = (tile % tiles_ci) * PACK_TCI;
-                for (int e = threadIdx.x; e < PACK_TCO * PACK_TCI * Tm; e += 256) {
-                    const int r = e / (PACK_TCI * Tm), cc = e - r * (PACK_TCI * Tm), c = cc / Tm, j = cc - c * Tm;
+                const int co0 = (tile / tiles_ci) * PACK_TCO, c0 = (tile % tiles_ci) * CT;
+                for (int e = threadIdx.x; e < PACK_TCO * CT * Tm; e += 256) {
+                    const int r = e / (CT * Tm), cc = e - r * (CT * Tm), c = cc / Tm, j = cc - c * Tm;
                     const bool ok = co0 + r < Co && c0 + c < Ci;
                     ptile[r * rowm + c * Tp + j] = ok ? D.w[((long)(co0 + r) * Ci + c0) * Tm + cc] * D.scale : 0.f;
                 }
                 __syncthreads();
-                for (int e = threadIdx.x; e < G * T * PACK_TCO * PACK_TCI; e += 256) {
-                    const int gt = e / (PACK_TCO * PACK_TCI), g = gt / T, tap = gt - g * T, j = mode == 0 ? g * 9 + tap : mode == 1 ? g : tap;
-                    const int l = e - gt * (PACK_TCO * PACK_TCI);
+                for (int e = threadIdx.x; e < G * T * PACK_TCO * CT; e += 256) {
+                    const int gt = e / (PACK_TCO * CT), g = gt / T, tap = gt - g * T, j = mode == 0 ? g * 9 + tap : mode == 1 ? g : tap;
+                    const int l = e - gt * (PACK_TCO * CT);
                     if (wf) {                                                               // (tap, co, ci), ci fastest
-                        const int ci = l % PACK_TCI, r = l / PACK_TCI;
+                        const int ci = l % CT, r = l / CT;
                         wf[((long)tap * D.cout + co0 + r) * D.cin + g * Cip + c0 + ci] = f32_to_bf16_bits(ptile[r * rowm + ci * Tp + j]);
                     }
                     if (wd) {                                                               // (tap, ci, co), co fastest
@@ -1313,7 +1317,7 @@ __global__ __launch_bounds__(256) void pack_weights_multi_kernel(const rgbd_pack
 
 extern "C" int rgbd_pack_weights_multi(const rgbd_pack_desc* descs_device, int n, int total_blocks, void* stream) {
     RGBD_REQUIRE(descs_device && n > 0 && total_blocks > 0, "rgbd_pack_weights_multi: bad arguments");
-    constexpr int lds = PACK_TCO * (PACK_TCI * 27 + 1) * (int)sizeof(float);      // the folded path's master tile: 27 taps
+    constexpr int lds = PACK_TCO * (PACK_TCI * 9 + 1) * (int)sizeof(float);       // every tile shape of the kernel fits this
     RGBD_REQUIRE(rgbd_reserve_lds((const void*)&pack_weights_multi_kernel, lds),
                  "rgbd_pack_weights_multi: cannot reserve %d B of LDS", lds);
     pack_weights_multi_kernel<<<total_blocks, 256, lds, (hipStream_t)stream>>>(descs_device, n);

@@ -226,6 +226,20 @@ PACK_DESC = [("w", "<u8"), ("wf", "<u8"), ("wd", "<u8"), ("cout", "<i4"), ("cin"
              ("scale", "<f4"), ("block_begin", "<i4"), ("fold", "<i4")]          # struct rgbd_pack_desc, 48 bytes
 
 
+PACK_MAX_BLOCKS = int(os.environ.get("RGBD_PACK_MAX_BLOCKS", "1024"))     # workgroups per layer of a pack launch (256 / 512 / 1024:
+#                                                                             the DeepVoxels generator's 26 M weights in 114 / 97 / 77 us)
+
+
+def _pack_work_items(co, ci, taps, fold_mode):
+    """What pack_weights_multi_kernel deals out over a layer's workgroups: tiles of 8 output channels x 64 (unfolded) / 16 / 32 / 64 (fold
+    mode 0 / 1 / 2) master input channels where the tiled path applies (csrc/elementwise.hip), else runs of 256 elements."""
+    groups, ct, tm = ((1, 64, taps) if fold_mode in (None, 2) else (3, 16, 27) if fold_mode == 0 else (16, 32, 16))
+    cip = ci // groups
+    if co % 8 == 0 and cip % ct == 0 and tm <= (9 if fold_mode in (None, 2) else 27):
+        return max(1, (co // 8) * (cip // ct))
+    return (co * ci * taps + 255) // 256
+
+
 def pack_fold_code(mode, Co, Ci):
     """The `fold` field of rgbd_pack_desc: the packing kernel reads a reference-shaped master through fold_weight's mode."""
     if not (0 <= mode <= 2 and 0 < Co < 32768 and 0 < Ci < 32768):
@@ -259,7 +273,7 @@ def build_pack_table(entries):
         if tuple(wf.shape) != (kh * kw, co, ci) or tuple(wd.shape) != (kh * kw, ci, co):
             raise RuntimeError(f"build_pack_table: images {tuple(wf.shape)} / {tuple(wd.shape)} for a ({co},{ci},{kh},{kw}) weight")
         tab[i] = (w.data_ptr(), wf.data_ptr(), wd.data_ptr(), co, ci, kh * kw, scale, blocks, fold)
-        blocks += min(256, (co * ci * kh * kw + 255) // 256)
+        blocks += min(PACK_MAX_BLOCKS, _pack_work_items(co, ci, kh * kw, ent[5][0] if len(ent) > 4 else None))
     dev = torch.from_numpy(tab.view(np.uint8).copy()).to(entries[0][0].device)
     return dev, len(entries), blocks
 
