@@ -45,8 +45,8 @@ i = s.index("Round 6, final kernel sources (hash `")
 j = s.index("`bench_kernel_stats.csv` (rocprofv3 `--kernel-trace --stats`, `--no-tune`,")
 s = s[:i] + f"""Round 6, final kernel sources (hash `{sha}`, commit {commit}), ONE box, one `collect_profiles.sh` run (`profiles/r06/`; the
 stand-alone commands, 100 timed steps each, side budgets measured at set-up unless noted; 291 GPU tests green on the same box,
-`gpu_tests_same_box.txt`).  The pool's boxes differ by +-4 %: earlier collections and runs of the round gave 4130 / 4224 / 4320 / 4336 / 4340 /
-4376 / 4444 / 4450 img/s on the default command (`other_boxes/` -- the two collections before this one among them --, `ab_mlp_chain.txt`,
+`gpu_tests_same_box.txt`).  The pool's boxes differ by +-4 %: earlier collections and runs of the round gave 4130 / 4224 / 4235 / 4320 / 4336 / 4340 /
+4376 / 4444 / 4450 img/s on the default command (`other_boxes/` -- the three collections before this one among them --, `ab_mlp_chain.txt`,
 `bench_dp_one_rank_rccl.json`).
 
 | line | command | img/s (ms / step) | roofline kernel (traffic: PMC of the SAME workload) |
