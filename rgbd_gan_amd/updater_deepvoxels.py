@@ -33,7 +33,7 @@ backward pass goes on through the occlusion network, the resampling and the voxe
     side:  ... dis_real ------------------------------------------------------> (wait rest_a) wgrad_a: the renderer's weight gradients
 
 (`concurrent_phases=False` / RGBD_CONCURRENT_PHASES=0: the same four phases back to back on one stream -- identical
-arithmetic, same accumulation order.)  ~960 mostly small launches per step: the second stream fills the gaps between the
+arithmetic, same accumulation order.)  ~600 mostly small launches per step (960 in round 3): the second stream fills the gaps between the
 first one's kernels.  Everything data dependent (the number of frustum samples inside the grid) stays on the device.
 """
 import os
