@@ -37,7 +37,7 @@ s = s[:i] + f"""*Numbers* (`profiles/r06/`: one `scripts/collect_profiles.sh` ru
 **{d['value']:.0f} img/s, {d['ms_per_step']:.2f} ms per step**; dominant kernel `conv3x3_sp_kernel<128>` {d['roofline']['achieved']:.0f} TFLOP/s = **{d['roofline']['frac']:.3f} of the bf16 MFMA peak** (HBM traffic
 per launch {d['roofline']['traffic'] / 1e6:.1f} MB vs 123.8 algorithmic); whole step {d['mfma_roofline_frac_whole_step']:.3f} of the peak on executed work (200.1 GFLOP/img; {d['value'] * 296.6 / 1e3 / 2500:.3f} on SURVEY's
 296.6).  Same process, `other_configs`: fade-in stage 9.5 {oc['c2_fade']['value']:.0f} img/s; configuration 3's per-GPU shape (B = 8) {oc['c3_b8']['value']:.0f} img/s ({oc['c3_b8']['ms_per_step']:.2f} ms);
-configuration 4 (DeepVoxels) **{oc['c4']['value']:.0f} img/s** ({c4['value']:.0f} as its stand-alone command; 1033 in round 5, 1124 without the early forward of section 3);
+configuration 4 (DeepVoxels) **{oc['c4']['value']:.0f} img/s** ({c4['value']:.0f} as its stand-alone command; 1033 in round 5, {L('bench_c4_no_early_forward.json')['value']:.0f} without the early forward of section 3 on this box);
 configuration 5 (256x256, ch 512, B = 16) {oc['c5_bf16']['value']:.0f} on bf16, **{oc['c5_fp8']['value']:.0f} on fp8 convs**.
 CPU restatement of the same step: {d['cpu_baseline']['value']:.1f} img/s on 16 host cores.  Driver history of the default line: r03 4020, r04 3860, r05 4386.
 """ + s[j:]
